@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the reference (itailang/SampleNet, /root/reference).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    python tests/golden/make_golden.py
+
+What is executed is the reference's own Python -- registration/src/{soft_projection,samplenet,
+sputils}.py imported unmodified, in place, with bytecode writing disabled so nothing is written
+under /root/reference -- on CPU.  Three names the reference imports do not exist here and are
+supplied by this script:
+  * knn_cuda.KNN (third-party wheel, source absent)  -> the (squared distance, index)-ordered
+    contract of oracle.knn (see oracle/samplenet_oracle.c: orc_knn);
+  * pointnet2.utils.pointnet2_utils.grouping_operation (third-party) -> torch.gather;
+  * src.chamfer_distance (JIT-compiles a .cu at import: impossible without CUDA) -> an
+    autograd.Function around the reference's OWN compiled CPU functions, oracle/_ref/cd_ref
+    (built from chamfer_distance.cpp by oracle/Makefile), mirroring chamfer_distance.py:14-66.
+The known-answer tables of the reference's __main__ tests are read out of the reference files
+with ast (the numbers are parsed, not retyped):
+  registration/src/soft_projection.py:161-222 and classification/soft_projection.py:90-129.
+"""
+import ast
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SAMPLENET_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from oracle import oracle as O  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shims
+def install_shims():
+    knn_cuda = types.ModuleType("knn_cuda")
+
+    class KNN:
+        """knn_cuda.KNN(k, transpose_mode=False)(ref (B,C,N), query (B,C,M)) -> dist (B,k,M), idx (B,k,M)."""
+
+        def __init__(self, k, transpose_mode=False):
+            self.k, self.t = k, transpose_mode
+
+        def __call__(self, ref, query):
+            if not self.t:
+                ref, query = ref.permute(0, 2, 1), query.permute(0, 2, 1)
+            d, i = O.knn(self.k, ref.detach().contiguous().numpy(), query.detach().contiguous().numpy())
+            d = torch.from_numpy(np.sqrt(d))
+            i = torch.from_numpy(i.astype(np.int64))
+            if not self.t:
+                d, i = d.permute(0, 2, 1).contiguous(), i.permute(0, 2, 1).contiguous()
+            return d, i
+
+    knn_cuda.KNN = KNN
+    sys.modules["knn_cuda"] = knn_cuda
+
+    def grouping_operation(features, idx):
+        B, C, N = features.shape
+        _, M, K = idx.shape
+        g = torch.gather(features.unsqueeze(2).expand(B, C, M, N), 3, idx.long().unsqueeze(1).expand(B, C, M, K))
+        return g
+
+    p2 = types.ModuleType("pointnet2")
+    p2u = types.ModuleType("pointnet2.utils")
+    p2uu = types.ModuleType("pointnet2.utils.pointnet2_utils")
+    p2uu.grouping_operation = grouping_operation
+    p2.utils, p2u.pointnet2_utils = p2u, p2uu
+    sys.modules.update({"pointnet2": p2, "pointnet2.utils": p2u, "pointnet2.utils.pointnet2_utils": p2uu})
+
+    cd = O.ref_cd()
+
+    class ChamferDistanceFunction(torch.autograd.Function):
+        # mirrors registration/src/chamfer_distance/chamfer_distance.py:14-61 (CPU branch)
+        @staticmethod
+        def forward(ctx, xyz1, xyz2):
+            b, n, _ = xyz1.size()
+            m = xyz2.size(1)
+            xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+            d1, d2 = torch.zeros(b, n), torch.zeros(b, m)
+            i1, i2 = torch.zeros(b, n, dtype=torch.int), torch.zeros(b, m, dtype=torch.int)
+            cd.forward(xyz1, xyz2, d1, d2, i1, i2)
+            ctx.save_for_backward(xyz1, xyz2, i1, i2)
+            ctx.mark_non_differentiable(i1, i2)
+            return d1, d2, i1, i2
+
+        @staticmethod
+        def backward(ctx, g1, g2, _a, _b):
+            xyz1, xyz2, i1, i2 = ctx.saved_tensors
+            gx1, gx2 = torch.zeros(xyz1.size()), torch.zeros(xyz2.size())
+            cd.backward(xyz1, xyz2, gx1, gx2, g1.contiguous(), g2.contiguous(), i1, i2)
+            return gx1, gx2
+
+    class ChamferDistance(torch.nn.Module):
+        def forward(self, xyz1, xyz2):
+            d1, d2, self.last_idx1, self.last_idx2 = ChamferDistanceFunction.apply(xyz1, xyz2)
+            return d1, d2
+
+    src = types.ModuleType("src")
+    src.__path__ = [os.path.join(REF, "registration", "src")]
+    sys.modules["src"] = src
+    cdm = types.ModuleType("src.chamfer_distance")
+    cdm.ChamferDistance = ChamferDistance
+    sys.modules["src.chamfer_distance"] = cdm
+    return ChamferDistance
+
+
+def main_block_arrays(path, names):
+    """Evaluate `name = np.array(...)` assignments found in the `if __name__ == '__main__':` block."""
+    tree = ast.parse(open(path).read())
+    out = {}
+    for node in tree.body:
+        if isinstance(node, ast.If) and "__main__" in ast.dump(node.test):
+            for st in ast.walk(node):
+                if isinstance(st, ast.Assign) and len(st.targets) == 1 and isinstance(st.targets[0], ast.Name):
+                    nm = st.targets[0].id
+                    if nm in names and nm not in out:
+                        out[nm] = np.asarray(eval(compile(ast.Expression(st.value), path, "eval"), {"np": np}), dtype=np.float64)
+    missing = set(names) - set(out)
+    assert not missing, missing
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez(path, **arrs)
+    print("wrote", os.path.relpath(path, ROOT), "(%d arrays)" % len(arrs))
+
+
+# ----------------------------------------------------------------------------- goldens
+def golden_known_answers():
+    a = main_block_arrays(os.path.join(REF, "registration/src/soft_projection.py"),
+                          ["query_cloud", "point_cloud", "point_features", "expected_nn_cloud",
+                           "expected_features_nn_1", "expected_features_nn_3"])
+    save("known_answer_registration.npz", **a)
+    b = main_block_arrays(os.path.join(REF, "classification/soft_projection.py"),
+                          ["query_cloud", "point_cloud", "expected_cloud_soft", "expected_cloud_hard"])
+    save("known_answer_classification.npz", **b)
+
+
+def golden_softproj(SoftProjection):
+    torch.manual_seed(1234)
+    out = {}
+    for tag, (B, N, M, K, CF, T) in {"a": (3, 200, 24, 8, 5, 0.7), "b": (2, 64, 9, 3, 4, 0.05), "c": (1, 33, 7, 16, 2, 1.0)}.items():
+        P = (torch.rand(B, 3, N) - 0.5).requires_grad_(True)
+        Q = (torch.rand(B, 3, M) - 0.5).requires_grad_(True)
+        F = torch.randn(B, CF, N, requires_grad=True)
+        sp = SoftProjection(K, initial_temperature=T, is_temperature_trainable=True, min_sigma=1e-2)
+        proj = sp(P, Q, action="project")
+        gp = torch.randn_like(proj)
+        gP, gQ, gT = torch.autograd.grad(proj, [P, Q, sp._temperature], gp)
+        prop = sp(P, Q, F, action="propagate")
+        gprop = torch.randn_like(prop)
+        hP, hQ, hF, hT = torch.autograd.grad(prop, [P, Q, F, sp._temperature], gprop)
+        proj2, prop2 = sp(P, Q, F, action="project_and_propagate")
+        _, idx = sys.modules["knn_cuda"].KNN(K, False)(P.detach(), Q.detach())
+        d = dict(P=P, Q=Q, F=F, T=torch.tensor(T), K=torch.tensor(K), idx=idx.permute(0, 2, 1).int(),
+                 sigma=sp.sigma(), proj=proj, gproj=gp, gP=gP, gQ=gQ, gT=gT,
+                 prop=prop, gprop=gprop, hP=hP, hQ=hQ, hF=hF, hT=hT, proj2=proj2, prop2=prop2)
+        out.update({f"{tag}_{k}": v.detach().numpy() for k, v in d.items()})
+    save("softproj_reference.npz", **out)
+
+
+def golden_chamfer(ChamferDistance):
+    rng = np.random.default_rng(7)
+    out = {}
+    for tag, (B, n, m) in {"a": (3, 64, 1024), "b": (2, 100, 37), "c": (1, 1, 5)}.items():
+        x1 = torch.from_numpy((rng.random((B, n, 3), dtype=np.float32) - 0.5)).requires_grad_(True)
+        x2 = torch.from_numpy((rng.random((B, m, 3), dtype=np.float32) - 0.5))
+        if tag == "b":  # exact duplicates: tie-break stress (lowest index must win)
+            x2[:, 5] = x2[:, 20]
+            x2[:, 6] = x2[:, 20]
+            x1 = x1.detach()
+            x1[:, 3] = x1[:, 50]
+            x1.requires_grad_(True)
+        x2.requires_grad_(True)
+        cdm = ChamferDistance()
+        d1, d2 = cdm(x1, x2)
+        g1 = torch.from_numpy(rng.standard_normal(d1.shape).astype(np.float32))
+        g2 = torch.from_numpy(rng.standard_normal(d2.shape).astype(np.float32))
+        gx1, gx2 = torch.autograd.grad([d1, d2], [x1, x2], [g1, g2])
+        d = dict(xyz1=x1, xyz2=x2, dist1=d1, dist2=d2, idx1=cdm.last_idx1, idx2=cdm.last_idx2,
+                 gdist1=g1, gdist2=g2, gxyz1=gx1, gxyz2=gx2)
+        out.update({f"{tag}_{k}": v.detach().numpy() for k, v in d.items()})
+    save("chamfer_reference.npz", **out)
+
+
+def golden_samplenet(SampleNet):
+    """Config C1 (B=4, 1024 -> 64, K=8) train step as registration/main.py:500-531 issues it, plus eval."""
+    out = {}
+    for tag, (B, N, M, K, bneck, shape) in {"c1": (4, 1024, 64, 8, 128, "bnc"), "s": (3, 96, 12, 5, 32, "bcn")}.items():
+        torch.manual_seed(0)
+        net = SampleNet(M, bneck, group_size=K, initial_temperature=1.0, is_temperature_trainable=True,
+                        min_sigma=1e-2, input_shape=shape, output_shape=shape)
+        # move the BN affine params and temperature off their trivial init so their grads are exercised
+        with torch.no_grad():
+            for nme, p in net.named_parameters():
+                if "bn" in nme:
+                    p.add_(0.1 * torch.randn_like(p))
+            net.project._temperature.fill_(0.3)
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        x = torch.rand(B, N, 3) - 0.5
+        if shape == "bcn":
+            x = x.permute(0, 2, 1).contiguous()
+        net.train()
+        simp, proj = net(x)
+        x_bnc = x if shape == "bnc" else x.permute(0, 2, 1).contiguous()
+        simp_bnc = simp if shape == "bnc" else simp.permute(0, 2, 1).contiguous()
+        lsimp = net.get_simplification_loss(x_bnc, simp_bnc, M, 1.0, 0.5 / M)
+        lproj = net.get_projection_loss()
+        gw = torch.randn_like(proj)
+        loss = 0.01 * lsimp + 0.01 * lproj + (proj * gw).sum() / proj.numel()
+        loss.backward()
+        for k, v in sd0.items():
+            out[f"{tag}_sd_{k}"] = v.numpy()
+        for k, v in net.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out[f"{tag}_sd1_{k}"] = v.numpy()
+        for k, p in net.named_parameters():
+            out[f"{tag}_grad_{k}"] = p.grad.numpy()
+        out.update({f"{tag}_x": x.numpy(), f"{tag}_simp": simp.detach().numpy(), f"{tag}_proj": proj.detach().numpy(),
+                    f"{tag}_gw": gw.numpy(), f"{tag}_lsimp": lsimp.detach().numpy(), f"{tag}_lproj": lproj.detach().numpy(),
+                    f"{tag}_loss": loss.detach().numpy(),
+                    f"{tag}_cfg": np.array([B, N, M, K, bneck, 0 if shape == "bnc" else 1])})
+        # eval branch (samplenet.py:119-141) -- its hard-coded .cuda() is neutralised for the CPU run
+        net.eval()
+        orig = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            with torch.no_grad():
+                simp_e, match = net(x)
+        finally:
+            torch.Tensor.cuda = orig
+        out[f"{tag}_eval_simp"] = simp_e.numpy()
+        out[f"{tag}_eval_match"] = match.numpy()
+    save("samplenet_reference.npz", **out)
+
+
+def golden_nn_matching(sputils):
+    rng = np.random.default_rng(3)
+    B, N, k = 3, 200, 32
+    pc = rng.random((B, N, 3), dtype=np.float32)
+    idx = rng.integers(0, 40, (B, k))  # many repeats -> exercises unique + FPS completion
+    save("nn_matching_reference.npz", pc=pc, idx=idx,
+         out_fps=sputils.nn_matching(pc, idx, k, complete_fps=True),
+         out_nofps=sputils.nn_matching(pc, idx, k, complete_fps=False))
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference checkout not found: " + REF
+    O.build(ref=True)
+    ChamferDistance = install_shims()
+    sp_mod = importlib.import_module("src.soft_projection")
+    sn_mod = importlib.import_module("src.samplenet")
+    sputils = importlib.import_module("src.sputils")
+    golden_known_answers()
+    golden_softproj(sp_mod.SoftProjection)
+    golden_chamfer(ChamferDistance)
+    golden_samplenet(sn_mod.SampleNet)
+    golden_nn_matching(sputils)
+    left = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc") or f == "__pycache__"]
+    assert not left, "bytecode leaked into the reference tree: %s" % left[:3]

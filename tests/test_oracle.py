@@ -1,0 +1,231 @@
+"""CPU tests that PIN the oracle (oracle/samplenet_oracle.c):
+  * against the reference's own compiled CPU code (oracle/_ref, built from /root/reference
+    by oracle/Makefile) -- skipped where oracle/_ref is not present;
+  * against the golden vectors produced by running the reference Python modules
+    (tests/golden/*.npz, generator tests/golden/make_golden.py);
+  * against the known-answer tables of the reference's own __main__ tests.
+"""
+import numpy as np
+import pytest
+
+
+def _need_ref(O):
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+
+
+# ------------------------------------------------------------------ Chamfer
+@pytest.mark.parametrize("shape", [(2, 64, 1024), (3, 100, 37), (1, 1, 1), (2, 513, 515)])
+def test_chamfer_matches_compiled_reference(oracle, shape):
+    _need_ref(oracle)
+    b, n, m = shape
+    rng = np.random.default_rng(n * 7 + m)
+    x1 = rng.random((b, n, 3), dtype=np.float32) - 0.5
+    x2 = rng.random((b, m, 3), dtype=np.float32) - 0.5
+    if n > 10 and m > 10:  # exact duplicates: lowest index must win on both sides
+        x2[:, 3] = x2[:, 9]
+        x1[:, 2] = x1[:, 7]
+    got = oracle.chamfer_forward(x1, x2)
+    ref = oracle.ref_chamfer_forward(x1, x2)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+    gd1 = rng.standard_normal((b, n)).astype(np.float32)
+    gd2 = rng.standard_normal((b, m)).astype(np.float32)
+    g = oracle.chamfer_backward(x1, x2, gd1, got[1], gd2, got[3])
+    r = oracle.ref_chamfer_backward(x1, x2, gd1, got[1], gd2, got[3])
+    assert np.array_equal(g[0], r[0]) and np.array_equal(g[1], r[1])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_chamfer_matches_golden(oracle, golden, tag):
+    g = golden("chamfer_reference.npz")
+    d1, i1, d2, i2 = oracle.chamfer_forward(g[f"{tag}_xyz1"], g[f"{tag}_xyz2"])
+    assert np.array_equal(d1, g[f"{tag}_dist1"]) and np.array_equal(i1, g[f"{tag}_idx1"])
+    assert np.array_equal(d2, g[f"{tag}_dist2"]) and np.array_equal(i2, g[f"{tag}_idx2"])
+    gx1, gx2 = oracle.chamfer_backward(g[f"{tag}_xyz1"], g[f"{tag}_xyz2"], g[f"{tag}_gdist1"], i1, g[f"{tag}_gdist2"], i2)
+    assert np.array_equal(gx1, g[f"{tag}_gxyz1"]) and np.array_equal(gx2, g[f"{tag}_gxyz2"])
+
+
+def test_chamfer_bruteforce_numpy(oracle):
+    """The commented-out parity recipe of tf_nndistance.py:87-94: argmin / min of the full matrix."""
+    rng = np.random.default_rng(5)
+    x1 = rng.standard_normal((2, 300, 3)).astype(np.float32)
+    x2 = rng.standard_normal((2, 77, 3)).astype(np.float32)
+    d1, i1, d2, i2 = oracle.chamfer_forward(x1, x2)
+    D = oracle.sqdist_matrix(x2, x1)  # (b, n1, n2): query = x1 rows
+    assert np.array_equal(i1, D.argmin(2)) and np.array_equal(d1, D.min(2))
+    assert np.array_equal(i2, D.argmin(1)) and np.array_equal(d2, D.min(1))
+
+
+# ------------------------------------------------------------------ kNN
+def test_selection_sort_toy_vector(oracle):
+    """grouping/test/selection_sort.cpp:65-93: b=2,n=4,m=2,k=3, dist[i] = 10 - i."""
+    b, n, m, k = 2, 4, 2, 3
+    dist = (10 - np.arange(b * n * m)).astype(np.float32).reshape(b, m, n)
+    oi, ov = oracle.selection_sort(dist, k)
+    assert np.array_equal(oi[..., :k], np.broadcast_to(np.array([3, 2, 1]), (b, m, k)))
+    assert np.array_equal(ov[..., :k], np.sort(dist, axis=2)[..., :k])
+    if oracle.have_ref():
+        ri, rv = oracle.ref_selection_sort(dist, k)
+        assert np.array_equal(oi, ri) and np.array_equal(ov, rv)
+
+
+def test_selection_sort_matches_compiled_reference(oracle):
+    _need_ref(oracle)
+    rng = np.random.default_rng(11)
+    dist = rng.random((2, 5, 40), dtype=np.float32)
+    dist[:, :, 7] = dist[:, :, 3]  # ties
+    oi, ov = oracle.selection_sort(dist, 9)
+    ri, rv = oracle.ref_selection_sort(dist, 9)
+    assert np.array_equal(oi, ri) and np.array_equal(ov, rv)
+
+
+@pytest.mark.parametrize("k", [1, 7, 8, 16])
+def test_knn_contract_equals_in_tree_definition_when_distinct(oracle, k):
+    rng = np.random.default_rng(k)
+    P = rng.random((3, 500, 3), dtype=np.float32) - 0.5
+    Q = rng.random((3, 40, 3), dtype=np.float32) - 0.5
+    d, i = oracle.knn(k, P, Q)
+    d2, i2 = oracle.knn_point_tf(k, P, Q)
+    assert np.array_equal(i, i2) and np.array_equal(d, d2)
+    assert np.all(np.diff(d, axis=2) >= 0)
+
+
+def test_knn_contract_on_ties(oracle):
+    """Exact duplicates: (d, idx) order, lowest indices kept at the k-th boundary."""
+    P = np.zeros((1, 10, 3), np.float32)
+    P[0, :, 0] = [5, 1, 5, 1, 2, 2, 9, 1, 5, 0]
+    Q = np.zeros((1, 1, 3), np.float32)
+    d, i = oracle.knn(6, P, Q)
+    assert i[0, 0].tolist() == [9, 1, 3, 7, 4, 5]
+    d, i = oracle.knn(8, P, Q)
+    assert i[0, 0].tolist() == [9, 1, 3, 7, 4, 5, 0, 2]
+
+
+# ------------------------------------------------------------------ group_point
+def test_group_point_matches_compiled_reference(oracle):
+    _need_ref(oracle)
+    rng = np.random.default_rng(2)
+    pts = rng.random((3, 50, 6), dtype=np.float32)
+    idx = rng.integers(0, 50, (3, 11, 4)).astype(np.int32)
+    assert np.array_equal(oracle.group_point(pts, idx), oracle.ref_group_point(pts, idx))
+    go = rng.random((3, 11, 4, 6), dtype=np.float32)
+    assert np.array_equal(oracle.group_point_grad(pts.shape, idx, go), oracle.ref_group_point_grad(pts.shape, idx, go))
+
+
+def test_group_point_numeric_gradient(oracle):
+    """Recipe of grouping/tf_grouping_op_test.py:8-30: numeric vs analytic gradient, err < 1e-4."""
+    rng = np.random.default_rng(4)
+    pts = rng.random((1, 16, 3)).astype(np.float32)
+    idx = rng.integers(0, 16, (1, 8, 5)).astype(np.int32)
+    w = rng.random((1, 8, 5, 3)).astype(np.float32)
+    ana = oracle.group_point_grad(pts.shape, idx, w)
+    num = np.zeros_like(pts)
+    eps = 1e-2
+    for j in range(pts.size):
+        p1 = pts.copy().ravel(); p1[j] += eps
+        p0 = pts.copy().ravel(); p0[j] -= eps
+        f1 = (oracle.group_point(p1.reshape(pts.shape), idx) * w).sum(dtype=np.float64)
+        f0 = (oracle.group_point(p0.reshape(pts.shape), idx) * w).sum(dtype=np.float64)
+        num.ravel()[j] = (f1 - f0) / (2 * eps)
+    assert np.abs(num - ana).max() < 1e-4
+
+
+def test_grouping_operation_layout(oracle):
+    rng = np.random.default_rng(6)
+    feat = rng.random((2, 4, 30), dtype=np.float32)
+    idx = rng.integers(0, 30, (2, 7, 3)).astype(np.int32)
+    a = oracle.grouping_operation(feat, idx)
+    b = oracle.group_point(feat.transpose(0, 2, 1).copy(), idx).transpose(0, 3, 1, 2)
+    assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ SoftProjection
+def test_softproj_known_answer_registration(oracle, golden):
+    """registration/src/soft_projection.py:158-284 (K=3; propagate at T=1, project at T=0.1 with roles swapped)."""
+    g = golden("known_answer_registration.npz")
+    P = g["point_cloud"].T[None].astype(np.float32)
+    Q = g["query_cloud"].T[None].astype(np.float32)
+    F = g["point_features"].T[None].astype(np.float32)
+    _, idx = oracle.knn(3, P.transpose(0, 2, 1), Q.transpose(0, 2, 1))
+    _, prop, _ = oracle.softproj_forward(P, Q, idx, max(1.0 ** 2, 1e-4), F)
+    assert np.mean(np.sum((prop[0].T - g["expected_features_nn_3"]) ** 2, axis=1)) < 1e-6
+    _, idx = oracle.knn(3, Q.transpose(0, 2, 1), P.transpose(0, 2, 1))
+    proj, _, _ = oracle.softproj_forward(Q, P, idx, max(0.1 ** 2, 1e-4))
+    assert np.mean(np.sum((proj[0].T - g["expected_nn_cloud"]) ** 2, axis=1)) < 1e-6
+
+
+def test_softproj_known_answer_classification(oracle, golden):
+    """classification/soft_projection.py:86-161 (K=3, T=0.01, batch of 2 with x3 scaling; soft + hard)."""
+    g = golden("known_answer_classification.npz")
+    pc = np.stack([g["point_cloud"], g["point_cloud"] * 3]).astype(np.float32)
+    qc = np.stack([g["query_cloud"], g["query_cloud"] * 3]).astype(np.float32)
+    exp_soft = np.stack([g["expected_cloud_soft"], g["expected_cloud_soft"] * 3])
+    exp_hard = np.stack([g["expected_cloud_hard"], g["expected_cloud_hard"] * 3])
+    _, idx = oracle.knn(3, pc, qc)
+    sigma = max(0.01 ** 2, 1e-4)  # classification/soft_projection.py min_sigma default 1e-4
+    proj, _, w = oracle.softproj_forward(pc.transpose(0, 2, 1), qc.transpose(0, 2, 1), idx, sigma)
+    assert np.abs(proj.transpose(0, 2, 1) - exp_soft).max() < 2e-3
+    hard = np.take_along_axis(pc, idx[:, :, :1].astype(np.int64).repeat(3, 2), 1)  # one-hot of the nearest
+    assert np.array_equal(hard, exp_hard)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_softproj_matches_reference_module(oracle, golden, tag):
+    g = golden("softproj_reference.npz")
+    P, Q, F = g[f"{tag}_P"], g[f"{tag}_Q"], g[f"{tag}_F"]
+    K, sigma, T = int(g[f"{tag}_K"]), float(g[f"{tag}_sigma"]), float(g[f"{tag}_T"])
+    _, idx = oracle.knn(K, P.transpose(0, 2, 1), Q.transpose(0, 2, 1))
+    assert np.array_equal(idx, g[f"{tag}_idx"])
+    proj, prop, _ = oracle.softproj_forward(P, Q, idx, sigma, F)
+    np.testing.assert_allclose(proj, g[f"{tag}_proj"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(prop, g[f"{tag}_prop"], rtol=1e-6, atol=2e-6)
+    np.testing.assert_allclose(proj, g[f"{tag}_proj2"], rtol=0, atol=1e-6)
+    gq, gp, gs = oracle.softproj_backward(P, Q, idx, sigma, g[f"{tag}_gproj"], want_grad_P=True)
+    np.testing.assert_allclose(gq, g[f"{tag}_gQ"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gp, g[f"{tag}_gP"], rtol=1e-4, atol=1e-5)
+    gT = gs * 2 * T if T * T > 1e-2 else 0.0
+    np.testing.assert_allclose(gT, g[f"{tag}_gT"], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ EMD
+def test_approxmatch_vs_compiled_reference_cpu(oracle):
+    """Reference bar: |match_gpu - match_cpu| <= 1e-2 per entry (approxmatch.cpp:216-226); data recipe
+    approxmatch.cpp:131-144 (uniform(0,1), n = 4 m), shrunk so it runs in seconds."""
+    _need_ref(oracle)
+    rng = np.random.default_rng(101)
+    x1 = rng.random((2, 256, 3), dtype=np.float32)
+    x2 = rng.random((2, 64, 3), dtype=np.float32)
+    m = oracle.approxmatch(x1, x2)
+    r = oracle.ref_approxmatch_cpu(x1, x2)
+    assert np.abs(m - r.transpose(0, 2, 1)).max() < 1e-2
+    np.testing.assert_allclose(m.sum(1), 1.0, atol=1e-3)   # each xyz1 point ships mass 1
+    np.testing.assert_allclose(m.sum(2), 4.0, atol=1e-3)   # each xyz2 point receives n/m
+    np.testing.assert_allclose(oracle.matchcost(x1, x2, m), oracle.ref_matchcost_cpu(x1, x2, r), rtol=1e-4)
+    g1, g2 = oracle.matchcost_grad(x1, x2, m)
+    np.testing.assert_allclose(g2, oracle.ref_matchcostgrad_cpu(x1, x2, r), atol=1e-3)
+
+
+def test_matchcost_grad_is_gradient_of_matchcost(oracle):
+    rng = np.random.default_rng(9)
+    x1 = rng.random((1, 24, 3)).astype(np.float32)
+    x2 = rng.random((1, 24, 3)).astype(np.float32)
+    m = oracle.approxmatch(x1, x2)
+    g1, g2 = oracle.matchcost_grad(x1, x2, m)
+    eps = 1e-3
+    for (arr, grad, which) in ((x1, g1, 0), (x2, g2, 1)):
+        for j in (0, 17, 40, 71):
+            a1 = arr.copy().ravel(); a1[j] += eps
+            a0 = arr.copy().ravel(); a0[j] -= eps
+            args1 = (a1.reshape(arr.shape), x2) if which == 0 else (x1, a1.reshape(arr.shape))
+            args0 = (a0.reshape(arr.shape), x2) if which == 0 else (x1, a0.reshape(arr.shape))
+            num = (float(oracle.matchcost(*args1, m)[0]) - float(oracle.matchcost(*args0, m)[0])) / (2 * eps)
+            assert abs(num - grad.ravel()[j]) < 5e-3
+
+
+# ------------------------------------------------------------------ inference matching
+def test_nn_matching_matches_reference(oracle, golden):
+    g = golden("nn_matching_reference.npz")
+    k = g["idx"].shape[1]
+    assert np.array_equal(oracle.nn_matching(g["pc"], g["idx"], k, True), g["out_fps"])
+    assert np.array_equal(oracle.nn_matching(g["pc"], g["idx"], k, False), g["out_nofps"])
