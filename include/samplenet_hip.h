@@ -1,0 +1,168 @@
+/*
+ * samplenet_hip.h -- C ABI of libsamplenet_hip.so: the MI355X (gfx950) implementation of the
+ * SampleNet differentiable-sampling hot path.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to caller-owned memory; the library allocates nothing
+ *     and keeps no state between calls (re-entrant; any number of streams / host threads);
+ *   - tensors are dense fp32 / int32 in the layout stated per argument -- the same layouts the
+ *     reference launchers take; no strides except the explicit `layout` selectors below;
+ *   - `stream` is a hipStream_t (passed as void*); work is enqueued on it and the call returns
+ *     without synchronising (safe under hipGraph stream capture);
+ *   - return value: 0 on success, otherwise a hipError_t value or SN_ERR_*; the text of the
+ *     most recent error of the calling thread is returned by sn_last_error_string().
+ *
+ * Each function names the reference interface it replaces (file:line under the
+ * itailang/SampleNet checkout).
+ */
+#ifndef SAMPLENET_HIP_H
+#define SAMPLENET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_ABI_VERSION 1
+
+/* error codes beyond hipError_t (which are < 10000) */
+#define SN_ERR_BAD_ARGUMENT 10001 /* null pointer, negative size, K > N, unsupported K ... */
+#define SN_ERR_UNSUPPORTED 10002  /* shape outside what the kernels implement            */
+
+/* point-cloud layout selectors */
+#define SN_LAYOUT_BNC 0 /* (B, N, 3)  point-major  -- Chamfer / TF ops           */
+#define SN_LAYOUT_BCN 1 /* (B, 3, N)  channel-major -- torch SoftProjection/KNN  */
+
+typedef void *sn_stream_t;
+
+int sn_abi_version(void);
+const char *sn_last_error_string(void);
+/* bytes of scratch sn_* functions with a `workspace` argument need for the given sizes */
+long long sn_workspace_bytes(const char *op, int B, int N, int M, int K);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused pair scan: ONE pass over the M x N squared-distance matrix of every cloud producing
+ *   - kNN indices of every query among the dataset points, ascending by (distance, index)
+ *   - nearest dataset point of every query   (dist_q, idx_q)   [Chamfer direction 1]
+ *   - nearest query of every dataset point   (dist_p, idx_p)   [Chamfer direction 2]
+ *   - the soft projection of every query onto its K neighbours
+ * Any output pointer may be NULL to skip that product.
+ *
+ *   P (dataset, N points) / Q (queries, M points): layout selectors above.
+ *   knn_idx (B,M,K) int32, knn_dist (B,M,K) squared distances.
+ *   dist_q/idx_q (B,M); dist_p/idx_p (B,N).
+ *   proj: soft projection, written in `proj_layout`; weights (B,M,K) optional softmax weights.
+ *   temperature: device pointer to the scalar T; sigma = max(T*T, min_sigma)
+ *                (registration/src/soft_projection.py:97-99).
+ * Replaces, in one launch: knn_cuda.KNN (call sites soft_projection.py:11-14, samplenet.py:121;
+ * in-tree definition classification/grouping/tf_grouping.py:64-91 + tf_grouping_g.cu:83-123),
+ * pointnet2 grouping_operation + the softmax/weighted-sum torch ops of soft_projection.py:138-152,
+ * and ChamferDistanceKernelLauncher (chamfer_distance.cu:139-155).
+ * Squared distance = ((dx*dx + dy*dy) + dz*dz) in fp32, one rounding per operation, never
+ * contracted to FMA -- the expression of chamfer_distance.cpp:74-77.
+ * ------------------------------------------------------------------------------------------- */
+int sn_pairscan_forward(int B, int N, int M, int K,
+                        const float *P, int p_layout, const float *Q, int q_layout,
+                        int *knn_idx, float *knn_dist,
+                        float *dist_q, int *idx_q, float *dist_p, int *idx_p,
+                        float *proj, int proj_layout, float *weights,
+                        const float *temperature, float min_sigma,
+                        sn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Chamfer / nn_distance with the reference launcher signatures.
+ * Replaces ChamferDistanceKernelLauncher / ChamferDistanceGradKernelLauncher
+ * (registration/src/chamfer_distance/chamfer_distance.cpp:4-24, .cu:139-209) and
+ * NmDistanceKernelLauncher / NmDistanceGradKernelLauncher
+ * (classification/structural_losses/tf_nndistance_g.cu:129-157).
+ * xyz (b,n,3), xyz2 (b,m,3); result/result_i (b,n); result2/result2_i (b,m).
+ * Backward: grad_xyz1 (b,n,3), grad_xyz2 (b,m,3) are fully overwritten (no memset needed);
+ * either may be NULL to skip it.  Deterministic (no atomics).
+ * ------------------------------------------------------------------------------------------- */
+int sn_chamfer_forward(int b, int n, const float *xyz, int m, const float *xyz2,
+                       float *result, int *result_i, float *result2, int *result2_i,
+                       sn_stream_t stream);
+int sn_chamfer_backward(int b, int n, const float *xyz1, int m, const float *xyz2,
+                        const float *grad_dist1, const int *idx1,
+                        const float *grad_dist2, const int *idx2,
+                        float *grad_xyz1, float *grad_xyz2, sn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.
+ * Replaces knn_cuda.KNN(k)(ref, query) (soft_projection.py:11-14) and knn_point
+ * (tf_grouping.py:64-91).  idx (b,m,k) int32; dist (b,m,k) SQUARED distances (may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+int sn_knn(int b, int n, int m, int k, const float *xyz1, int layout1, const float *xyz2, int layout2,
+           int *idx, float *dist, sn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * group_point gather / scatter-add.
+ * (a) TF layout: points (b,n,c), idx (b,m,nsample) -> out (b,m,nsample,c).
+ *     Replaces groupPointLauncher / groupPointGradLauncher (tf_grouping_g.cu:133-141;
+ *     op shells tf_grouping.cpp:142-208).  grad_points is overwritten (zero-filled inside).
+ * (b) channel-major: features (b,c,n), idx (b,m,nsample) -> out (b,c,m,nsample).
+ *     Replaces pointnet2_utils.grouping_operation fwd/bwd (call site soft_projection.py:83-89).
+ * ------------------------------------------------------------------------------------------- */
+int sn_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
+                   float *out, sn_stream_t stream);
+int sn_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out,
+                        const int *idx, float *grad_points, sn_stream_t stream);
+int sn_grouping_operation(int b, int c, int n, int m, int nsample, const float *features,
+                          const int *idx, float *out, sn_stream_t stream);
+int sn_grouping_operation_grad(int b, int c, int n, int m, int nsample, const float *grad_out,
+                               const int *idx, float *grad_features, sn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SoftProjection pieces (channel-major tensors, as the torch module uses them).
+ *   sn_soft_weights_forward : w = softmax_k(-|P[idx]-Q|^2 / sigma)          soft_projection.py:92-95,143
+ *   sn_soft_weights_backward: grad_w -> grad_Q (b,3,m) [overwritten], grad_P (b,3,n)
+ *                             [ACCUMULATED with atomics; may be NULL], grad_sigma_partial (b)
+ *                             [overwritten; sum it and apply d sigma/dT on the caller side]
+ *   sn_weighted_gather_forward : out[c,j] = sum_k w[j,k] X[c, idx[j,k]]      soft_projection.py:113-118,131-134,148-151
+ *   sn_weighted_gather_backward: grad_out -> grad_w (b,m,k) [overwritten, may be NULL],
+ *                                grad_X (b,c,n) [ACCUMULATED with atomics, may be NULL]
+ *   sn_soft_project_backward   : fused backward of `project` for the hot path:
+ *                                grad_proj (layout selectable) -> grad_Q (b,3,m) overwritten,
+ *                                grad_sigma_partial (b) overwritten, grad_P optional (atomics).
+ * ------------------------------------------------------------------------------------------- */
+int sn_soft_weights_forward(int b, int n, int m, int k, const float *P, const float *Q, const int *idx,
+                            const float *temperature, float min_sigma, float *weights,
+                            sn_stream_t stream);
+int sn_soft_weights_backward(int b, int n, int m, int k, const float *P, const float *Q, const int *idx,
+                             const float *temperature, float min_sigma, const float *weights,
+                             const float *grad_weights, float *grad_Q, float *grad_P,
+                             float *grad_sigma_partial, sn_stream_t stream);
+int sn_weighted_gather_forward(int b, int c, int n, int m, int k, const float *X, const int *idx,
+                               const float *weights, float *out, sn_stream_t stream);
+int sn_weighted_gather_backward(int b, int c, int n, int m, int k, const float *X, const int *idx,
+                                const float *weights, const float *grad_out, float *grad_weights,
+                                float *grad_X, sn_stream_t stream);
+int sn_soft_project_backward(int b, int n, int m, int k, const float *P, int p_layout,
+                             const float *Q, int q_layout, const int *idx,
+                             const float *temperature, float min_sigma,
+                             const float *grad_proj, int gproj_layout,
+                             float *grad_Q, int gq_layout, float *grad_P, float *grad_sigma_partial,
+                             sn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * EMD: approx_match / match_cost / match_cost_grad.
+ * Replaces approxmatchLauncher / matchcostLauncher / matchcostgradLauncher
+ * (classification/structural_losses/tf_approxmatch_g.cu:180-182,226-228,292-295; op shells
+ * tf_approxmatch.cpp:145-329).  xyz1 (b,n,3), xyz2 (b,m,3), match (b,m,n) (may be NULL: only the
+ * per-level ratio vectors are then produced), cost (b), grad1 (b,n,3), grad2 (b,m,3).
+ * temp: caller-owned scratch of sn_workspace_bytes("approxmatch", b, n, m, 0) bytes -- a superset
+ * of the (b,(n+m)*2) floats the reference op allocates (tf_approxmatch.cpp:167-168): the ratio
+ * vectors of all 10 levels are kept so that `match` is written once instead of being
+ * read-modify-written per level.  sn_matchcost needs sn_workspace_bytes("matchcost", ...) bytes
+ * of scratch for its per-workgroup partial sums (deterministic two-stage reduction).
+ * ------------------------------------------------------------------------------------------- */
+int sn_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                   float *temp, sn_stream_t stream);
+int sn_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                 float *cost, float *workspace, sn_stream_t stream);
+int sn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                      float *grad1, float *grad2, sn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAMPLENET_HIP_H */

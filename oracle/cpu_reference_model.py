@@ -1,0 +1,138 @@
+"""CPU baseline of the hot-path unit of work: the reference SampleNet training step
+-- forward, simplification + projection losses, backward -- restated for the host cores.
+
+TEST / BENCH INFRASTRUCTURE ONLY (bench.py `cpu_baseline`, tests); never imported by samplenet_amd.
+
+It follows registration/src/samplenet.py:82-187 and soft_projection.py:75-152 op for op with torch CPU
+ops, exactly as the reference module executes them; the two third-party CUDA-only calls are stood in
+for as the survey's probe did (kNN = broadcast squared distance + topk, grouping = torch.gather), and
+Chamfer runs the reference's OWN compiled CPU loop (oracle/_ref/cd_ref, built from
+chamfer_distance.cpp) when that build is present -- otherwise the C restatement of the same loop
+(oracle/samplenet_oracle.c: orc_chamfer_forward/backward, pinned bit-exact against it).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import oracle as O
+
+
+class _ChamferCPU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+        if O.have_ref():
+            cd = O.ref_cd()
+            b, n, _ = xyz1.shape
+            m = xyz2.shape[1]
+            d1, d2 = torch.zeros(b, n), torch.zeros(b, m)
+            i1, i2 = torch.zeros(b, n, dtype=torch.int), torch.zeros(b, m, dtype=torch.int)
+            cd.forward(xyz1, xyz2, d1, d2, i1, i2)
+        else:
+            r = O.chamfer_forward(xyz1.numpy(), xyz2.numpy())
+            d1, i1, d2, i2 = [torch.from_numpy(a) for a in r]
+        ctx.save_for_backward(xyz1, xyz2, i1, i2)
+        return d1, d2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        xyz1, xyz2, i1, i2 = ctx.saved_tensors
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        if O.have_ref():
+            gx1, gx2 = torch.zeros(xyz1.size()), torch.zeros(xyz2.size())
+            O.ref_cd().backward(xyz1, xyz2, gx1, gx2, g1, g2, i1, i2)
+        else:
+            a, b = O.chamfer_backward(xyz1.numpy(), xyz2.numpy(), g1.numpy(), i1.numpy(), g2.numpy(), i2.numpy())
+            gx1, gx2 = torch.from_numpy(a), torch.from_numpy(b)
+        return gx1, gx2
+
+
+class SampleNetCPU(nn.Module):
+    """Same parameters / state_dict keys as the reference module."""
+
+    def __init__(self, num_out_points, bottleneck_size, group_size, initial_temperature=1.0, min_sigma=1e-2):
+        super().__init__()
+        self.num_out_points, self.group_size, self.min_sigma = num_out_points, group_size, min_sigma
+        self.conv1, self.conv2, self.conv3 = nn.Conv1d(3, 64, 1), nn.Conv1d(64, 64, 1), nn.Conv1d(64, 64, 1)
+        self.conv4, self.conv5 = nn.Conv1d(64, 128, 1), nn.Conv1d(128, bottleneck_size, 1)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(64), nn.BatchNorm1d(64), nn.BatchNorm1d(64)
+        self.bn4, self.bn5 = nn.BatchNorm1d(128), nn.BatchNorm1d(bottleneck_size)
+        self.fc1, self.fc2, self.fc3 = nn.Linear(bottleneck_size, 256), nn.Linear(256, 256), nn.Linear(256, 256)
+        self.fc4 = nn.Linear(256, 3 * num_out_points)
+        self.bn_fc1, self.bn_fc2, self.bn_fc3 = nn.BatchNorm1d(256), nn.BatchNorm1d(256), nn.BatchNorm1d(256)
+        self.temperature = nn.Parameter(torch.tensor(initial_temperature, dtype=torch.float32))
+
+    def sigma(self):
+        return torch.max(self.temperature ** 2, torch.tensor(self.min_sigma))
+
+    def forward(self, x_bnc):
+        x = x_bnc.permute(0, 2, 1)
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = F.relu(self.bn3(self.conv3(y)))
+        y = F.relu(self.bn4(self.conv4(y)))
+        y = F.relu(self.bn5(self.conv5(y)))
+        y = torch.max(y, 2)[0]
+        y = F.relu(self.bn_fc1(self.fc1(y)))
+        y = F.relu(self.bn_fc2(self.fc2(y)))
+        y = F.relu(self.bn_fc3(self.fc3(y)))
+        y = self.fc4(y).view(-1, 3, self.num_out_points)
+        xc = x.contiguous()
+        # kNN stand-in (knn_cuda has no CPU path): broadcast squared distances + topk
+        with torch.no_grad():
+            d = ((y.unsqueeze(3) - xc.unsqueeze(2)) ** 2).sum(1)  # (B, M, N)
+            idx = d.topk(self.group_size, dim=2, largest=False)[1]  # (B, M, K)
+        B, C, N = xc.shape
+        M, K = idx.shape[1], idx.shape[2]
+        grouped = torch.gather(xc.unsqueeze(2).expand(B, C, M, N), 3, idx.unsqueeze(1).expand(B, C, M, K))
+        deltas = grouped - y.unsqueeze(-1).expand_as(grouped)
+        dist = torch.sum(deltas ** 2, dim=1, keepdim=True) / self.sigma()
+        weights = torch.softmax(-dist, dim=3).repeat(1, 3, 1, 1)
+        proj = torch.sum(grouped * weights, dim=3)
+        return y.permute(0, 2, 1).contiguous(), proj.permute(0, 2, 1).contiguous()
+
+    def get_simplification_loss(self, ref_pc, samp_pc, pc_size, gamma=1, delta=0):
+        c12, c21 = _ChamferCPU.apply(samp_pc, ref_pc)
+        return torch.mean(c12) + torch.mean(torch.max(c12, dim=1)[0]) + (gamma + delta * pc_size) * torch.mean(c21)
+
+
+def time_cpu_baseline(batch=32, n_in=1024, n_out=64, k=8, budget_s=12.0, warmup=3, threads=None, seed=0):
+    """Runs the unit of work on the host cores for about budget_s seconds; returns a dict for bench.py."""
+    import os
+    import time
+
+    threads = threads or os.cpu_count()
+    torch.set_num_threads(threads)
+    torch.manual_seed(seed)
+    net = SampleNetCPU(n_out, 128, k).train()
+    x = torch.rand(batch, n_in, 3) - 0.5
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        simp, proj = net(x)
+        loss = 0.01 * net.get_simplification_loss(x, simp, n_out, 1, 0) + 0.01 * net.sigma() + proj.mean()
+        loss.backward()
+
+    for _ in range(warmup):
+        step()
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end or len(times) < 5:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {
+        "value": batch / med,
+        "unit": "point-clouds/s",
+        "cores": int(torch.get_num_threads()),
+        "kind": "port",
+        "ms_per_step": med * 1e3,
+        "sample": "%d steps of B=%d, %d->%d, K=%d fwd+loss+bwd on torch-CPU %s (MLP/softmax: torch CPU ops as the "
+                  "reference runs them; kNN: broadcast+topk stand-in for knn_cuda; Chamfer: %s, single-threaded)"
+                  % (len(times), batch, n_in, n_out, k, torch.__version__,
+                     "the reference's own chamfer_distance.cpp CPU loop (oracle/_ref/cd_ref)" if O.have_ref()
+                     else "C restatement of chamfer_distance.cpp:59-177 (oracle/liboracle.so)"),
+    }

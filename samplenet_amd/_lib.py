@@ -1,0 +1,78 @@
+"""ctypes binding of libsamplenet_hip.so (the C ABI declared in include/samplenet_hip.h).
+
+There is NO fallback: if the HIP library is missing or does not export a symbol, importing
+samplenet_amd fails loudly -- the product path never routes through a CPU or eager-PyTorch
+substitute.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- first: its bundled HIP runtime (libamdhip64.so.7) must be the one this process uses,
+# because the streams and device pointers handed to the library come from torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsamplenet_hip.so")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argument types (restype is int unless listed in _RESTYPES); mirrors include/samplenet_hip.h
+PROTOTYPES = {
+    "sn_abi_version": [],
+    "sn_last_error_string": [],
+    "sn_workspace_bytes": [ctypes.c_char_p, _i, _i, _i, _i],
+    "sn_pairscan_forward": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp],
+    "sn_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
+    "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_grouping_operation": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_grouping_operation_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_soft_weights_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp],
+    "sn_soft_weights_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_weighted_gather_forward": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sn_weighted_gather_backward": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_soft_project_backward": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp],
+    "sn_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "sn_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+_RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong}
+
+
+class SampleNetHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "samplenet_amd: %s not found. Build it with `python -m samplenet_amd.build` (hipcc, gfx950). "
+            "There is no CPU / eager fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError("samplenet_amd: %s does not export %s (stale build?)" % (LIB_PATH, name)) from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, _i)
+    return lib
+
+
+lib = _load()
+if lib.sn_abi_version() != 1:
+    raise ImportError("samplenet_amd: ABI version mismatch in %s" % LIB_PATH)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.sn_last_error_string()
+        raise SampleNetHipError("%s failed (code %d): %s" % (what or "samplenet_hip call", rc, (msg or b"").decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,74 @@
+"""Build libsamplenet_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m samplenet_amd.build            # incremental
+    python -m samplenet_amd.build --force
+
+hipcc cross-compiles without a GPU.  The shared object lands in samplenet_amd/lib/ so that it
+travels with the source snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT_DIR, "libsamplenet_hip.so")
+ARCH = "gfx950"
+
+# (source, extra flags).  The geometric kernels must round like the reference's CPU code
+# (product then sum, never FMA): -ffp-contract=off on top of the in-source pragma.
+SOURCES = [
+    ("capi_common.cpp", []),
+    ("pairscan.hip", ["-ffp-contract=off"]),
+    ("geometry_ops.hip", ["-ffp-contract=off"]),
+    ("emd.hip", ["-ffp-contract=off"]),
+    ("pointnet_mlp.hip", []),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+          "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "samplenet_hip.h"))
+    objs, rebuilt = [], False
+    for src, extra in SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(OUT_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers):
+            cmd = [hipcc, "-x", "hip", "-c", path, "-o", obj] + COMMON + extra
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,347 @@
+// emd.hip -- approx_match / match_cost / match_cost_grad for gfx950.
+//
+// Reference: classification/structural_losses/tf_approxmatch_g.cu:1-295 (one 512-thread block per
+// cloud, <<<32,512>>>; `match` is read-modify-written in global memory at each of the 10 levels).
+//
+// Re-design for MI355X.  The auction is kept arithmetically identical -- every per-point sum runs
+// sequentially over the other cloud in ascending index order, in fp32, exactly as each reference
+// thread accumulates it -- but it is spread over the whole chip and `match` is written ONCE:
+//   * one THREAD per point, many workgroups per cloud; the three block-synchronous passes of a
+//     level become two kernels (the level's pass 1 is fused with the previous level's pass 3,
+//     both being sums over l for a fixed k), i.e. 21 launches instead of a 30-phase single block;
+//   * the other cloud's coordinates + per-point weight are staged through LDS as float4 tiles and
+//     read back as wave-uniform broadcasts (ds_read_b128, conflict-free);
+//   * the per-level ratio vectors (10 x (n+m) floats per cloud) are kept in the workspace, and
+//     match[l,k] = sum_levels exp(level d) ratioL_lev[k] ratioR_lev[l] is materialised by one
+//     streaming kernel -- the same terms added in the same order as the reference's `+=`, so the
+//     result is identical, at 1/20 of the HBM traffic (write-once instead of 10 x read+write).
+#include <algorithm>
+
+#include "sn_common.h"
+
+#pragma clang fp contract(off)
+
+namespace sn {
+
+constexpr int kLevels = 10;  // j = 7 .. -2  (tf_approxmatch_g.cu:21)
+constexpr int kTile = 1024;  // points of the other cloud staged per LDS tile (16 KiB)
+
+__host__ __device__ inline float emd_level(int li)
+{
+    // li = 0..9  <->  j = 7..-2 ; level = -4^j, 0 at j == -2   (tf_approxmatch_g.cu:22-25)
+    const int j = 7 - li;
+    if (j == -2) return 0.0f;
+    float p = 1.0f;
+    if (j >= 0)
+        for (int t = 0; t < j; ++t) p *= 4.0f;
+    else
+        p = 0.25f;  // j == -1
+    return -p;
+}
+
+__device__ __forceinline__ float emd_sq(float ax, float ay, float az, float bx, float by, float bz)
+{
+    // (x2-x1)*(x2-x1)+(y2-y1)*(y2-y1)+(z2-z1)*(z2-z1)   (tf_approxmatch_g.cu:48)
+    const float dx = bx - ax, dy = by - ay, dz = bz - az;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// The reference op uses __expf (tf_approxmatch_g.cu:49).  The auction amplifies exp rounding through its
+// 10 levels, so the correctly-rounded expf is used: it keeps `match` within ~1e-6 of the fp32 restatement.
+__device__ __forceinline__ float emd_exp(float x) { return expf(x); }
+
+// Workspace layout per cloud (floats): remainL[n] remainR[m] ratioL[kLevels][n] ratioR[kLevels][m]
+__host__ __device__ inline size_t emd_ws_floats(int n, int m) { return (size_t)(n + m) * (1 + kLevels); }
+
+// Kernel A(li): thread per xyz1 point k.
+//   if li > 0 : pass 3 of level li-1 -> remainL[k] = max(0, remainL[k] - sum_l exp(lev' d) ratioL'[k] ratioR'[l])
+//   then      : pass 1 of level li   -> ratioL[li][k] = remainL[k] / (1e-9 + sum_l exp(lev d) remainR[l])
+// (pass 3 of the last level only updates remainL, which nothing reads afterwards: it is not run.)
+// li == 0 also initialises remainL (and, by its first block column, remainR).
+__global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2, float *__restrict__ ws,
+                                                         float multiL, float multiR)
+{
+    __shared__ float4 tile[kTile];
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *X1 = xyz1 + (size_t)b * n * 3;
+    const float *X2 = xyz2 + (size_t)b * m * 3;
+    float *base = ws + (size_t)b * emd_ws_floats(n, m);
+    float *remainL = base, *remainR = base + n;
+    float *ratioL = base + n + m, *ratioR = ratioL + (size_t)kLevels * n;
+    const bool do3 = li > 0;
+    const float lev3 = do3 ? emd_level(li - 1) : 0.f, lev1 = emd_level(li);
+    const float *rR3 = ratioR + (size_t)(do3 ? li - 1 : 0) * m;
+
+    float x1 = 0, y1 = 0, z1 = 0, rl = 0;
+    if (k < n) {
+        x1 = X1[k * 3 + 0], y1 = X1[k * 3 + 1], z1 = X1[k * 3 + 2];
+        if (do3) rl = ratioL[(size_t)(li - 1) * n + k];
+    }
+    float sum3 = 0.f;  // pass 3 accumulator (suml = 0)
+    for (int l0 = 0; do3 && l0 < m; l0 += kTile) {
+        const int lend = min(m, l0 + kTile) - l0;
+        __syncthreads();
+        for (int l = threadIdx.x; l < lend; l += blockDim.x)
+            tile[l] = make_float4(X2[(l0 + l) * 3 + 0], X2[(l0 + l) * 3 + 1], X2[(l0 + l) * 3 + 2], rR3[l0 + l]);
+        __syncthreads();
+        for (int l = 0; l < lend; ++l) {
+            const float4 t = tile[l];
+            const float w = emd_exp(lev3 * emd_sq(x1, y1, z1, t.x, t.y, t.z)) * rl * t.w;
+            sum3 += w;
+        }
+    }
+    float remL = multiL;
+    if (k < n) {
+        if (do3) remL = fmaxf(0.0f, remainL[k] - sum3);
+        if (do3 || li == 0) remainL[k] = remL;
+    }
+    if (li == 0 && blockIdx.x == 0)
+        for (int l = threadIdx.x; l < m; l += blockDim.x) remainR[l] = multiR;
+    float sum1 = 1e-9f;
+    for (int l0 = 0; l0 < m; l0 += kTile) {
+        const int lend = min(m, l0 + kTile) - l0;
+        __syncthreads();
+        for (int l = threadIdx.x; l < lend; l += blockDim.x)
+            tile[l] = make_float4(X2[(l0 + l) * 3 + 0], X2[(l0 + l) * 3 + 1], X2[(l0 + l) * 3 + 2],
+                                  li == 0 ? multiR : remainR[l0 + l]);
+        __syncthreads();
+        for (int l = 0; l < lend; ++l) {
+            const float4 t = tile[l];
+            const float d = lev1 * emd_sq(x1, y1, z1, t.x, t.y, t.z);
+            const float w = emd_exp(d) * t.w;
+            sum1 += w;
+        }
+    }
+    if (k < n) ratioL[(size_t)li * n + k] = remL / sum1;
+}
+
+// Kernel B(li): thread per xyz2 point l -- pass 2 of level li (tf_approxmatch_g.cu:75-110).
+__global__ void __launch_bounds__(256) emd_pass_l_kernel(int n, int m, int li, const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2, float *__restrict__ ws)
+{
+    __shared__ float4 tile[kTile];
+    const int b = blockIdx.y;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *X1 = xyz1 + (size_t)b * n * 3;
+    const float *X2 = xyz2 + (size_t)b * m * 3;
+    float *base = ws + (size_t)b * emd_ws_floats(n, m);
+    float *remainR = base + n;
+    const float *ratioL = base + n + m + (size_t)li * n;
+    float *ratioR = base + n + m + (size_t)kLevels * n + (size_t)li * m;
+    const float level = emd_level(li);
+    float x2 = 0, y2 = 0, z2 = 0;
+    if (l < m) x2 = X2[l * 3 + 0], y2 = X2[l * 3 + 1], z2 = X2[l * 3 + 2];
+    float sumr = 0.f;
+    for (int k0 = 0; k0 < n; k0 += kTile) {
+        const int kend = min(n, k0 + kTile) - k0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < kend; k += blockDim.x)
+            tile[k] = make_float4(X1[(k0 + k) * 3 + 0], X1[(k0 + k) * 3 + 1], X1[(k0 + k) * 3 + 2], ratioL[k0 + k]);
+        __syncthreads();
+        for (int k = 0; k < kend; ++k) {
+            const float4 t = tile[k];
+            const float w = emd_exp(level * emd_sq(t.x, t.y, t.z, x2, y2, z2)) * t.w;
+            sumr += w;
+        }
+    }
+    if (l < m) {
+        const float rr = remainR[l];
+        sumr *= rr;
+        const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+        ratioR[l] = consumption * rr;
+        remainR[l] = fmaxf(0.0f, rr - sumr);
+    }
+}
+
+// match[l,k] = sum over levels (in level order) of exp(level d_kl) * ratioL[lev][k] * ratioR[lev][l]
+__global__ void __launch_bounds__(256) emd_materialize_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                              const float *__restrict__ xyz2,
+                                                              const float *__restrict__ ws, float *__restrict__ match)
+{
+    const int b = blockIdx.z;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l0 = blockIdx.y * 16;
+    const float *X1 = xyz1 + (size_t)b * n * 3;
+    const float *X2 = xyz2 + (size_t)b * m * 3;
+    const float *base = ws + (size_t)b * emd_ws_floats(n, m);
+    const float *ratioL = base + n + m, *ratioR = ratioL + (size_t)kLevels * n;
+    if (k >= n) return;
+    const float x1 = X1[k * 3 + 0], y1 = X1[k * 3 + 1], z1 = X1[k * 3 + 2];
+    float rl[kLevels];
+#pragma unroll
+    for (int li = 0; li < kLevels; ++li) rl[li] = ratioL[(size_t)li * n + k];
+    float *Mb = match + (size_t)b * n * m;
+    for (int l = l0; l < min(m, l0 + 16); ++l) {  // l is block-uniform: scalar loads
+        const float d2 = emd_sq(x1, y1, z1, X2[l * 3 + 0], X2[l * 3 + 1], X2[l * 3 + 2]);
+        float acc = 0.f;
+#pragma unroll
+        for (int li = 0; li < kLevels; ++li) {
+            const float w = emd_exp(emd_level(li) * d2) * rl[li] * ratioR[(size_t)li * m + l];
+            acc += w;
+        }
+        Mb[(size_t)l * n + k] = acc;
+    }
+}
+
+// cost[b] = sum_{k,l} match[l,k] ||x1_k - x2_l||.  Thread per k accumulates over l (as each reference
+// thread does, tf_approxmatch_g.cu:183-213), fixed-order block tree, then one partial per block;
+// partials are combined in index order by the last kernel -> deterministic.
+__global__ void __launch_bounds__(256) emd_cost_partial_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                               const float *__restrict__ xyz2,
+                                                               const float *__restrict__ match,
+                                                               float *__restrict__ partial)
+{
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const float *X1 = xyz1 + (size_t)b * n * 3;
+    const float *X2 = xyz2 + (size_t)b * m * 3;
+    const float *Mb = match + (size_t)b * n * m;
+    float sub = 0.f;
+    if (k < n) {
+        const float x1 = X1[k * 3 + 0], y1 = X1[k * 3 + 1], z1 = X1[k * 3 + 2];
+        for (int l = 0; l < m; ++l) {
+            const float d = sqrtf(emd_sq(x1, y1, z1, X2[l * 3 + 0], X2[l * 3 + 1], X2[l * 3 + 2]));
+            sub += d * Mb[(size_t)l * n + k];
+        }
+    }
+    red[threadIdx.x] = sub;
+    for (int s = 128; s > 0; s >>= 1) {
+        __syncthreads();
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    }
+    if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ void emd_cost_final_kernel(int nb, int nparts, const float *__restrict__ partial, float *__restrict__ cost)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += partial[(size_t)b * nparts + p];
+    cost[b] = acc;
+}
+
+// grad1[k] = sum_l match[l,k] (x1_k - x2_l) rsqrt(max(d2, 1e-20))     (tf_approxmatch_g.cu:270-291)
+__global__ void __launch_bounds__(256) emd_grad1_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2,
+                                                        const float *__restrict__ match, float *__restrict__ grad1)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float *X1 = xyz1 + (size_t)b * n * 3;
+    const float *X2 = xyz2 + (size_t)b * m * 3;
+    const float *Mb = match + (size_t)b * n * m;
+    const float x1 = X1[k * 3 + 0], y1 = X1[k * 3 + 1], z1 = X1[k * 3 + 2];
+    float dx = 0, dy = 0, dz = 0;
+    for (int l = 0; l < m; ++l) {
+        const float ex = x1 - X2[l * 3 + 0], ey = y1 - X2[l * 3 + 1], ez = z1 - X2[l * 3 + 2];
+        const float d = Mb[(size_t)l * n + k] * rsqrtf(fmaxf((ex * ex + ey * ey) + ez * ez, 1e-20f));
+        dx += ex * d;
+        dy += ey * d;
+        dz += ez * d;
+    }
+    grad1[((size_t)b * n + k) * 3 + 0] = dx;
+    grad1[((size_t)b * n + k) * 3 + 1] = dy;
+    grad1[((size_t)b * n + k) * 3 + 2] = dz;
+}
+
+// grad2[l] = sum_k match[l,k] (x2_l - x1_k) rsqrt(max(d2, 1e-20)): a wave per l, lanes stride over k
+// (coalesced match row), fixed-order butterfly                         (tf_approxmatch_g.cu:229-269)
+__global__ void __launch_bounds__(256) emd_grad2_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2,
+                                                        const float *__restrict__ match, float *__restrict__ grad2)
+{
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (l >= m) return;
+    const float *X1 = xyz1 + (size_t)b * n * 3;
+    const float *X2 = xyz2 + (size_t)b * m * 3;
+    const float *Mrow = match + (size_t)b * n * m + (size_t)l * n;
+    const float x2 = X2[l * 3 + 0], y2 = X2[l * 3 + 1], z2 = X2[l * 3 + 2];
+    float sx = 0, sy = 0, sz = 0;
+    for (int k = lane; k < n; k += 64) {
+        const float ex = x2 - X1[k * 3 + 0], ey = y2 - X1[k * 3 + 1], ez = z2 - X1[k * 3 + 2];
+        const float d = Mrow[k] * rsqrtf(fmaxf((ex * ex + ey * ey) + ez * ez, 1e-20f));
+        sx += ex * d;
+        sy += ey * d;
+        sz += ez * d;
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        sx += __shfl_xor(sx, s);
+        sy += __shfl_xor(sy, s);
+        sz += __shfl_xor(sz, s);
+    }
+    if (lane == 0) {
+        grad2[((size_t)b * m + l) * 3 + 0] = sx;
+        grad2[((size_t)b * m + l) * 3 + 1] = sy;
+        grad2[((size_t)b * m + l) * 3 + 2] = sz;
+    }
+}
+
+}  // namespace sn
+
+using namespace sn;
+
+long long sn_emd_workspace_floats(int b, int n, int m) { return (long long)b * (long long)emd_ws_floats(n, m); }
+
+extern "C" int sn_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                              sn_stream_t stream)
+{
+    SN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+    if (b == 0 || n == 0 || m == 0) return 0;
+    SN_REQUIRE(xyz1 && xyz2 && temp, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    float multiL, multiR;  // tf_approxmatch_g.cu:3-10 (integer division)
+    if (n >= m)
+        multiL = 1, multiR = (float)(n / m);
+    else
+        multiL = (float)(m / n), multiR = 1;
+    const dim3 gk((n + 255) / 256, b), gl((m + 255) / 256, b);
+    for (int li = 0; li < kLevels; ++li) {
+        hipLaunchKernelGGL(emd_pass_k_kernel, gk, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp, multiL, multiR);
+        hipLaunchKernelGGL(emd_pass_l_kernel, gl, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp);
+    }
+    if (match)
+        hipLaunchKernelGGL(emd_materialize_kernel, dim3((n + 255) / 256, (m + 15) / 16, b), dim3(256), 0, st, n, m,
+                           xyz1, xyz2, temp, match);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                            float *cost, float *workspace, sn_stream_t stream)
+{
+    SN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+    if (b == 0) return 0;
+    SN_REQUIRE(cost, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0 || m == 0) {
+        hipError_t e = hipMemsetAsync(cost, 0, sizeof(float) * b, st);
+        return e == hipSuccess ? 0 : sn_set_error((int)e, "sn_matchcost: %s", hipGetErrorString(e));
+    }
+    SN_REQUIRE(xyz1 && xyz2 && match && workspace, "null pointer");
+    const int nparts = (n + 255) / 256;  // workspace: b * nparts floats (sn_workspace_bytes("matchcost", ...))
+    hipLaunchKernelGGL(emd_cost_partial_kernel, dim3(nparts, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, workspace);
+    hipLaunchKernelGGL(emd_cost_final_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, nparts, workspace, cost);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                                 float *grad1, float *grad2, sn_stream_t stream)
+{
+    SN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+    if (b == 0 || n == 0 || m == 0) return 0;
+    SN_REQUIRE(xyz1 && xyz2 && match, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (grad1) hipLaunchKernelGGL(emd_grad1_kernel, dim3((n + 255) / 256, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad1);
+    if (grad2) hipLaunchKernelGGL(emd_grad2_kernel, dim3((m + 3) / 4, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
+    SN_LAUNCH_CHECK();
+    return 0;
+}

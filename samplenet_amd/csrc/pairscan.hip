@@ -1,0 +1,397 @@
+// pairscan.hip -- the fused pair-scan kernel of the SampleNet hot path (gfx950 / CDNA4).
+//
+// One pass over the M x N squared-distance matrix of a cloud yields everything geometric the
+// reference computes in three separate packages:
+//   kNN top-K of every query          knn_cuda.KNN  (soft_projection.py:11-14; in-tree definition
+//                                     tf_grouping.py:64-91 + tf_grouping_g.cu:83-123)
+//   row min/argmin   (dist_q, idx_q)  ChamferDistanceKernel, 1st launch (chamfer_distance.cu:149)
+//   column min/argmin (dist_p, idx_p) ChamferDistanceKernel, 2nd launch (chamfer_distance.cu:150)
+//   soft projection of the query      soft_projection.py:138-152
+//
+// Mapping (wave64):  a wave owns one QUERY at a time (coordinates wave-uniform -> SGPR operands),
+// its 64 lanes own the dataset POINTS, PPL points per lane held in registers for the whole block
+// lifetime (N <= 64*PPL: "single chunk"), so the cloud is read from HBM/L2 exactly once per wave.
+//   column minima : per-lane running (min, argmin) over the wave's queries  -> free of cross-lane work
+//   top-K / row min: threshold filter.  tau = max over G lane-groups of the group's minimum
+//                   (G = pow2 >= K) is an upper bound of the K-th smallest distance that costs
+//                   6 cross-lane steps; the ~K..3K candidates with d <= tau are compacted to LDS
+//                   as 64-bit (distance, index) keys and ranked by counting.  Keys are unique, so
+//                   the order is exactly ascending (distance, index) and ties resolve to the lowest
+//                   index, as the reference's strict '<' ascending scans do.
+// Work per pair is ~8 VALU for the distance (never contracted: see sqdist) + ~3 for the column
+// minimum + ~6 amortised for filter/compaction; nothing is re-read from memory.
+//
+// Multi-chunk mode (N > 64*PPL_MAX): the wave walks the cloud in chunks keeping its running top-K
+// in LDS; column minima are then produced by a second launch with the roles swapped.
+#include <algorithm>
+
+#include "sn_common.h"
+
+// The distance expression must round exactly like the reference's CPU code
+// (chamfer_distance.cpp:74-77: float products and sums, no FMA).  hipcc contracts by default.
+#pragma clang fp contract(off)
+
+namespace sn {
+
+constexpr int kListCap = 192;  // per-wave candidate list entries (3 per lane)
+
+__device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, float py, float pz)
+{
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float s = xx + yy;
+    return s + zz;
+}
+
+// Keep the K smallest of list[0..cnt) in list[0..min(K,cnt)) sorted ascending (rank by counting;
+// keys are unique).  Wave-synchronous: every lane of the wave calls it with the same arguments.
+__device__ __forceinline__ int merge_topk(sn_u64 *list, int cnt, int K, int lane)
+{
+    constexpr int R = kListCap / kWave;
+    sn_u64 mine[R];
+    int rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = lane + r * kWave;
+        mine[r] = e < cnt ? list[e] : kKeyInf;
+        rank[r] = 0;
+    }
+    for (int t = 0; t < cnt; ++t) {
+        const sn_u64 k = list[t];  // same address for all lanes: LDS broadcast
+#pragma unroll
+        for (int r = 0; r < R; ++r) rank[r] += (k < mine[r]) ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = lane + r * kWave;
+        if (e < cnt && rank[r] < K) list[rank[r]] = mine[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return cnt < K ? cnt : K;
+}
+
+// Load this lane's PPL points of the chunk starting at c0 (point i*64+lane); lanes past the end of
+// the cloud get +inf coordinates, i.e. distance +inf: never selected.
+template <int PPL>
+__device__ __forceinline__ void load_chunk(float (&px)[PPL], float (&py)[PPL], float (&pz)[PPL],
+                                           const float *__restrict__ Pb, int layout, int N, int c0, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int n = c0 + i * kWave + lane;
+        const bool ok = n < N;
+        const int nn = ok ? n : 0;
+        const float x = Pb[pt_off(layout, N, nn, 0)];
+        const float y = Pb[pt_off(layout, N, nn, 1)];
+        const float z = Pb[pt_off(layout, N, nn, 2)];
+        px[i] = ok ? x : INFINITY;
+        py[i] = ok ? y : INFINITY;
+        pz[i] = ok ? z : INFINITY;
+    }
+}
+
+// Workgroup size cap per variant: registers hold 3*PPL coordinates + PPL distances (+ 2*PPL column
+// minima), so the wider variants trade waves per SIMD for VGPRs (no spills at any size).
+constexpr int max_threads(int ppl, bool colmin)
+{
+    return (ppl >= 32 && colmin) ? 256 : ((ppl >= 32 || (ppl == 16 && colmin)) ? 512 : 1024);
+}
+
+struct PairscanArgs {
+    const float *P;
+    const float *Q;
+    int p_layout, q_layout;
+    int B, N, M, K;  // K >= 1 internally (K == 1 when only the nearest neighbour is wanted)
+    int *knn_idx;
+    float *knn_dist;
+    float *dist_q;
+    int *idx_q;
+    float *dist_p;
+    int *idx_p;
+    float *proj;
+    int proj_layout;
+    float *weights;
+    const float *temperature;
+    float min_sigma;
+};
+
+template <int PPL, bool SINGLE, bool COLMIN>
+__global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(PairscanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    const int N = a.N, M = a.M, K = a.K;
+    const int qpb = (M + gridDim.y - 1) / gridDim.y;
+    const int q0 = blockIdx.y * qpb;
+    const int q1 = min(M, q0 + qpb);
+
+    sn_u64 *list = reinterpret_cast<sn_u64 *>(smem) + wave * kListCap;
+    sn_u64 *colmin = reinterpret_cast<sn_u64 *>(smem) + nwaves * kListCap;  // [64*PPL] when COLMIN
+
+    const float *__restrict__ Pb = a.P + (size_t)b * 3 * N;
+    const float *__restrict__ Qb = a.Q + (size_t)b * 3 * M;
+
+    // lane groups for the threshold: G = pow2 >= K (<= 64), contiguous groups of gs lanes
+    int G = 1;
+    while (G < K && G < kWave) G <<= 1;
+    const int gs = kWave / G;
+
+    const bool want_soft = (a.proj != nullptr) || (a.weights != nullptr);
+    float sigma = 1.0f;
+    if (want_soft) {
+        const float T = *a.temperature;
+        sigma = fmaxf(T * T, a.min_sigma);  // soft_projection.py:97-99
+    }
+
+    if (COLMIN) {
+        for (int i = threadIdx.x; i < kWave * PPL; i += blockDim.x) colmin[i] = kKeyInf;
+        __syncthreads();
+    }
+
+    float px[PPL], py[PPL], pz[PPL];
+    float cd[PPL];  // column minima (COLMIN)
+    int ci[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        cd[i] = INFINITY;
+        ci[i] = 0;
+    }
+    if (SINGLE) load_chunk<PPL>(px, py, pz, Pb, a.p_layout, N, 0, lane);
+
+    for (int j = q0 + wave; j < q1; j += nwaves) {  // wave-uniform
+        const float qx = Qb[pt_off(a.q_layout, M, j, 0)];
+        const float qy = Qb[pt_off(a.q_layout, M, j, 1)];
+        const float qz = Qb[pt_off(a.q_layout, M, j, 2)];
+        int cnt = 0;
+        float thr_run = INFINITY;
+
+        for (int c0 = 0; c0 < N; c0 += kWave * PPL) {
+            if (!SINGLE) load_chunk<PPL>(px, py, pz, Pb, a.p_layout, N, c0, lane);
+            float d[PPL];
+            float lmin = INFINITY;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                d[i] = sqdist(qx, qy, qz, px[i], py[i], pz[i]);
+                lmin = fminf(lmin, d[i]);
+                if (COLMIN) {
+                    if (d[i] < cd[i]) {  // strict '<', ascending j: lowest query index wins
+                        cd[i] = d[i];
+                        ci[i] = j;
+                    }
+                }
+            }
+            // tau = max over groups of (min over the group's lanes)
+            float x = lmin;
+#pragma unroll
+            for (int s = 1; s < kWave; s <<= 1) {
+                const float y = __shfl_xor(x, s);
+                x = (s < gs) ? fminf(x, y) : fmaxf(x, y);
+            }
+            float thr = fminf(x, thr_run);
+            // compact candidates (d <= thr) into the wave's LDS list
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                const int n = c0 + i * kWave + lane;
+                const bool pred = (n < N) && (d[i] <= thr);
+                const sn_u64 mask = __ballot(pred);
+                if (mask != 0) {
+                    if (cnt + kWave > kListCap) {
+                        cnt = merge_topk(list, cnt, K, lane);
+                        if (cnt == K) thr = fminf(thr, key_dist(list[K - 1]));
+                    }
+                    const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (pred) list[pos] = make_key(d[i], n);
+                    cnt += __builtin_popcountll(mask);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (!SINGLE) {
+                cnt = merge_topk(list, cnt, K, lane);
+                if (cnt == K) thr_run = key_dist(list[K - 1]);
+            }
+        }
+        if (SINGLE) cnt = merge_topk(list, cnt, K, lane);
+
+        // ---- per-query outputs: lanes t < K hold neighbour t (ascending (distance, index)) ----
+        const sn_u64 key = (lane < cnt) ? list[lane] : kKeyInf;
+        const int nidx = (lane < cnt) ? key_index(key) : 0;
+        const float nd = (lane < cnt) ? key_dist(key) : INFINITY;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const size_t qrow = (size_t)b * M + j;
+        if (lane < K) {
+            if (a.knn_idx) a.knn_idx[qrow * K + lane] = nidx;
+            if (a.knn_dist) a.knn_dist[qrow * K + lane] = nd;
+        }
+        if (lane == 0) {
+            if (a.dist_q) a.dist_q[qrow] = nd;
+            if (a.idx_q) a.idx_q[qrow] = nidx;
+        }
+        if (want_soft) {
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+            if (lane < cnt) {
+                gx = Pb[pt_off(a.p_layout, N, nidx, 0)];
+                gy = Pb[pt_off(a.p_layout, N, nidx, 1)];
+                gz = Pb[pt_off(a.p_layout, N, nidx, 2)];
+            }
+            const float s = (lane < cnt) ? -(nd / sigma) : -INFINITY;  // soft_projection.py:92-95
+            float mx = s;
+#pragma unroll
+            for (int t = 1; t < kWave; t <<= 1) mx = fmaxf(mx, __shfl_xor(mx, t));
+            const float e = (lane < cnt) ? expf(s - mx) : 0.f;
+            float den = 0.f;
+            for (int t = 0; t < K; ++t) den += readlane_f(e, t);
+            const float w = e / den;  // softmax over the K neighbours (:143)
+            if (a.weights && lane < K) a.weights[qrow * K + lane] = w;
+            if (a.proj) {
+                float ox = 0.f, oy = 0.f, oz = 0.f;
+                for (int t = 0; t < K; ++t) {  // ascending k, product then sum (:148-151)
+                    const float wt = readlane_f(w, t);
+                    ox += readlane_f(gx, t) * wt;
+                    oy += readlane_f(gy, t) * wt;
+                    oz += readlane_f(gz, t) * wt;
+                }
+                if (lane < 3) {
+                    const float o = lane == 0 ? ox : (lane == 1 ? oy : oz);
+                    a.proj[(size_t)b * 3 * M + pt_off(a.proj_layout, M, j, lane)] = o;
+                }
+            }
+        }
+    }
+
+    if (COLMIN) {
+        // combine the waves' column minima: unsigned min of (distance, query index) keys
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) atomicMin(&colmin[i * kWave + lane], make_key(cd[i], ci[i]));
+        __syncthreads();
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+            const sn_u64 k = colmin[n];
+            if (a.dist_p) a.dist_p[(size_t)b * N + n] = key_dist(k);
+            if (a.idx_p) a.idx_p[(size_t)b * N + n] = key_index(k);
+        }
+    }
+}
+
+template <int PPL, bool SINGLE, bool COLMIN>
+static int launch_pairscan(const PairscanArgs &a, int waves, int ysplit, hipStream_t st)
+{
+    const size_t lds = (size_t)waves * kListCap * 8 + (COLMIN ? (size_t)kWave * PPL * 8 : 0);
+    hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN>), dim3(a.B, ysplit), dim3(waves * kWave), lds, st, a);
+    return 0;
+}
+
+static int next_pow2(int x)
+{
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// Host-side dispatch.  colmin => dist_p / idx_p requested.
+int pairscan_dispatch(PairscanArgs a, hipStream_t st)
+{
+    const bool colmin = a.dist_p || a.idx_p;
+    const int N = a.N, M = a.M;
+    if (N <= kWave * 32) {
+        // single chunk: the whole cloud lives in the wave's registers
+        const int ppl = N <= 64 ? 1 : (N <= 256 ? 4 : (N <= 1024 ? 16 : 32));
+        const int maxw = max_threads(ppl, colmin) / kWave;
+        // without column minima the queries of a cloud can be spread over several workgroups
+        int ysplit = 1;
+        if (!colmin) {
+            const int want = (512 + a.B - 1) / a.B;  // aim at >= 2 workgroups per CU
+            ysplit = std::max(1, std::min(want, (M + maxw - 1) / maxw));
+        }
+        const int qpb = (M + ysplit - 1) / ysplit;
+        const int waves = std::max(1, std::min(maxw, qpb));
+#define SN_PS(PPL_)                                                                      \
+    (colmin ? launch_pairscan<PPL_, true, true>(a, waves, ysplit, st)                    \
+            : launch_pairscan<PPL_, true, false>(a, waves, ysplit, st))
+        switch (ppl) {
+            case 1: return SN_PS(1);
+            case 4: return SN_PS(4);
+            case 16: return SN_PS(16);
+            default: return SN_PS(32);
+        }
+#undef SN_PS
+    }
+    // multi chunk: row products only; the caller obtains column minima by a swapped second call
+    if (colmin) return sn_set_error(SN_ERR_UNSUPPORTED, "pairscan: column minima need N <= 2048 (internal)");
+    const int want = (1024 + a.B - 1) / a.B;
+    const int ysplit = std::max(1, std::min(want, (M + 15) / 16));
+    const int qpb = (M + ysplit - 1) / ysplit;
+    const int waves = std::max(1, std::min(16, qpb));
+    return launch_pairscan<16, false, false>(a, waves, ysplit, st);
+}
+
+}  // namespace sn
+
+using sn::PairscanArgs;
+
+extern "C" int sn_pairscan_forward(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
+                                   int q_layout, int *knn_idx, float *knn_dist, float *dist_q, int *idx_q,
+                                   float *dist_p, int *idx_p, float *proj, int proj_layout, float *weights,
+                                   const float *temperature, float min_sigma, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 0 && N >= 0 && M >= 0 && K >= 0, "negative size");
+    if (B == 0 || (M == 0 && N == 0)) return 0;
+    SN_REQUIRE(P && Q, "null point cloud");
+    SN_REQUIRE(N >= 1 && M >= 1, "empty cloud on one side only");
+    SN_REQUIRE(K <= N, "K exceeds the number of dataset points");
+    SN_REQUIRE(K <= 64, "K > 64 unsupported");
+    SN_REQUIRE(p_layout == SN_LAYOUT_BNC || p_layout == SN_LAYOUT_BCN, "bad p_layout");
+    SN_REQUIRE(q_layout == SN_LAYOUT_BNC || q_layout == SN_LAYOUT_BCN, "bad q_layout");
+    const bool knn = knn_idx || knn_dist, soft = proj || weights;
+    SN_REQUIRE(!(knn || soft) || K >= 1, "K must be >= 1 for kNN / projection outputs");
+    SN_REQUIRE(!soft || temperature, "projection needs the temperature pointer");
+    hipStream_t st = (hipStream_t)stream;
+    PairscanArgs a{};
+    a.P = P, a.Q = Q, a.p_layout = p_layout, a.q_layout = q_layout;
+    a.B = B, a.N = N, a.M = M, a.K = K < 1 ? 1 : K;
+    a.knn_idx = knn_idx, a.knn_dist = knn_dist, a.dist_q = dist_q, a.idx_q = idx_q;
+    a.proj = proj, a.proj_layout = proj_layout, a.weights = weights;
+    a.temperature = temperature, a.min_sigma = min_sigma;
+    const bool colmin = dist_p || idx_p;
+    if (N <= sn::kWave * 32 || !colmin) {
+        a.dist_p = dist_p, a.idx_p = idx_p;
+        int rc = sn::pairscan_dispatch(a, st);
+        if (rc) return rc;
+    } else {
+        int rc = sn::pairscan_dispatch(a, st);  // row products
+        if (rc) return rc;
+        PairscanArgs s{};  // column minima = row minima of the swapped problem
+        s.P = Q, s.Q = P, s.p_layout = q_layout, s.q_layout = p_layout;
+        s.B = B, s.N = M, s.M = N, s.K = 1;
+        s.dist_q = dist_p, s.idx_q = idx_p;
+        rc = sn::pairscan_dispatch(s, st);
+        if (rc) return rc;
+    }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_chamfer_forward(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
+                                  int *result_i, float *result2, int *result2_i, sn_stream_t stream)
+{
+    SN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+    if (b == 0 || (n == 0 && m == 0)) return 0;
+    SN_REQUIRE(n >= 1 && m >= 1, "empty cloud on one side only");
+    // lanes own the larger set (it amortises the per-query filter cost); outputs map accordingly
+    if (m >= n)
+        return sn_pairscan_forward(b, m, n, 0, xyz2, SN_LAYOUT_BNC, xyz, SN_LAYOUT_BNC, nullptr, nullptr, result,
+                                   result_i, result2, result2_i, nullptr, 0, nullptr, nullptr, 0.f, stream);
+    return sn_pairscan_forward(b, n, m, 0, xyz, SN_LAYOUT_BNC, xyz2, SN_LAYOUT_BNC, nullptr, nullptr, result2,
+                               result2_i, result, result_i, nullptr, 0, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int sn_knn(int b, int n, int m, int k, const float *xyz1, int layout1, const float *xyz2, int layout2,
+                      int *idx, float *dist, sn_stream_t stream)
+{
+    SN_REQUIRE(k >= 1, "k must be >= 1");
+    return sn_pairscan_forward(b, n, m, k, xyz1, layout1, xyz2, layout2, idx, dist, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, 0, nullptr, nullptr, 0.f, stream);
+}

@@ -1,0 +1,368 @@
+"""Functional layer: torch.autograd.Functions over the C ABI of libsamplenet_hip.so.
+
+Host-side plumbing only -- allocation of outputs with torch, stream / device selection, autograd
+bookkeeping.  All arithmetic happens in the HIP kernels (samplenet_amd/csrc).  Every function
+requires CUDA(HIP) tensors and raises otherwise: there is no CPU path in the product.
+"""
+import torch
+
+from ._lib import check, lib, ptr
+
+BNC, BCN = 0, 1  # SN_LAYOUT_*
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("samplenet_amd ops run on the GPU only (got a %s tensor); no CPU fallback exists" % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------- Chamfer
+def chamfer_forward_impl(xyz1, xyz2):
+    """xyz1 (B,n,3), xyz2 (B,m,3) -> contiguous inputs, dist1 (B,n), idx1, dist2 (B,m), idx2 (one launch)."""
+    _need_gpu(xyz1, xyz2)
+    xyz1, xyz2 = _f32c(xyz1), _f32c(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist1 = torch.empty(b, n, device=xyz1.device, dtype=torch.float32)
+    dist2 = torch.empty(b, m, device=xyz1.device, dtype=torch.float32)
+    idx1 = torch.empty(b, n, device=xyz1.device, dtype=torch.int32)
+    idx2 = torch.empty(b, m, device=xyz1.device, dtype=torch.int32)
+    with torch.cuda.device(xyz1.device):
+        check(lib.sn_chamfer_forward(b, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2),
+                                     _stream(xyz1)), "sn_chamfer_forward")
+    return xyz1, xyz2, dist1, idx1, dist2, idx2
+
+
+def chamfer_backward_impl(xyz1, xyz2, idx1, idx2, graddist1, graddist2, need1=True, need2=True):
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    graddist1, graddist2 = graddist1.contiguous(), graddist2.contiguous()
+    g1 = torch.empty_like(xyz1) if need1 else None
+    g2 = torch.empty_like(xyz2) if need2 else None
+    with torch.cuda.device(xyz1.device):
+        check(lib.sn_chamfer_backward(b, n, ptr(xyz1), m, ptr(xyz2), ptr(graddist1), ptr(idx1), ptr(graddist2),
+                                      ptr(idx2), ptr(g1), ptr(g2), _stream(xyz1)), "sn_chamfer_backward")
+    return g1, g2
+
+
+class ChamferDistanceFunction(torch.autograd.Function):
+    """Four-output form: dist1 (B,n), dist2 (B,m), idx1, idx2 (indices non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1, xyz2, dist1, idx1, dist2, idx2 = chamfer_forward_impl(xyz1, xyz2)
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        ctx.mark_non_differentiable(idx1, idx2)
+        return dist1, dist2, idx1, idx2
+
+    @staticmethod
+    def backward(ctx, graddist1, graddist2, _gi1, _gi2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        return chamfer_backward_impl(xyz1, xyz2, idx1, idx2, graddist1, graddist2, ctx.needs_input_grad[0],
+                                     ctx.needs_input_grad[1])
+
+
+def chamfer_distance(xyz1, xyz2, return_idx=False):
+    d1, d2, i1, i2 = ChamferDistanceFunction.apply(xyz1, xyz2)
+    return (d1, d2, i1, i2) if return_idx else (d1, d2)
+
+
+# --------------------------------------------------------------------------------------------- kNN
+def knn(k, ref, query, ref_layout=BCN, query_layout=BCN, return_dist=True):
+    """K nearest `ref` points of every `query` point (no gradient).
+
+    ref (B,3,N) / query (B,3,M) for BCN, (B,N,3) / (B,M,3) for BNC.
+    Returns idx (B,M,K) int32 and squared distances (B,M,K), ascending by (distance, index).
+    """
+    _need_gpu(ref, query)
+    ref, query = _f32c(ref.detach()), _f32c(query.detach())
+    B = ref.shape[0]
+    N = ref.shape[2] if ref_layout == BCN else ref.shape[1]
+    M = query.shape[2] if query_layout == BCN else query.shape[1]
+    idx = torch.empty(B, M, k, device=ref.device, dtype=torch.int32)
+    dist = torch.empty(B, M, k, device=ref.device, dtype=torch.float32) if return_dist else None
+    with torch.cuda.device(ref.device):
+        check(lib.sn_knn(B, N, M, k, ptr(ref), ref_layout, ptr(query), query_layout, ptr(idx), ptr(dist), _stream(ref)),
+              "sn_knn")
+    return idx, dist
+
+
+# --------------------------------------------------------------------------------------------- gather ops
+class GroupPointFunction(torch.autograd.Function):
+    """points (B,n,c), idx (B,m,ns) int32 -> (B,m,ns,c)   [tf_grouping.py:46-61]"""
+
+    @staticmethod
+    def forward(ctx, points, idx):
+        _need_gpu(points, idx)
+        points, idx = _f32c(points), idx.contiguous().int()
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        out = torch.empty(b, m, ns, c, device=points.device, dtype=torch.float32)
+        with torch.cuda.device(points.device):
+            check(lib.sn_group_point(b, n, c, m, ns, ptr(points), ptr(idx), ptr(out), _stream(points)), "sn_group_point")
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, n, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, n, c = ctx.shape
+        _, m, ns = idx.shape
+        grad_out = grad_out.contiguous()
+        g = torch.empty(b, n, c, device=grad_out.device, dtype=torch.float32)
+        with torch.cuda.device(grad_out.device):
+            check(lib.sn_group_point_grad(b, n, c, m, ns, ptr(grad_out), ptr(idx), ptr(g), _stream(grad_out)),
+                  "sn_group_point_grad")
+        return g, None
+
+
+class GroupingOperationFunction(torch.autograd.Function):
+    """features (B,C,N), idx (B,npoint,nsample) int32 -> (B,C,npoint,nsample)   [pointnet2 grouping_operation]"""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        _need_gpu(features, idx)
+        features, idx = _f32c(features), idx.contiguous().int()
+        b, c, n = features.shape
+        _, m, ns = idx.shape
+        out = torch.empty(b, c, m, ns, device=features.device, dtype=torch.float32)
+        with torch.cuda.device(features.device):
+            check(lib.sn_grouping_operation(b, c, n, m, ns, ptr(features), ptr(idx), ptr(out), _stream(features)),
+                  "sn_grouping_operation")
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, c, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, c, n = ctx.shape
+        _, m, ns = idx.shape
+        grad_out = grad_out.contiguous()
+        g = torch.empty(b, c, n, device=grad_out.device, dtype=torch.float32)
+        with torch.cuda.device(grad_out.device):
+            check(lib.sn_grouping_operation_grad(b, c, n, m, ns, ptr(grad_out), ptr(idx), ptr(g), _stream(grad_out)),
+                  "sn_grouping_operation_grad")
+        return g, None
+
+
+group_point = GroupPointFunction.apply
+grouping_operation = GroupingOperationFunction.apply
+
+
+# --------------------------------------------------------------------------------------------- SoftProjection
+def _dsigma_dT(temperature, min_sigma):
+    """d max(T^2, min_sigma) / dT, with torch.max's even split on an exact tie."""
+    t2 = temperature.detach() ** 2
+    ms = torch.as_tensor(min_sigma, device=temperature.device, dtype=torch.float32)
+    w = (t2 > ms).float() + 0.5 * (t2 == ms).float()
+    return w * 2.0 * temperature.detach()
+
+
+class SoftProjectFunction(torch.autograd.Function):
+    """Fused SoftProjection.project (soft_projection.py:138-152): kNN + softmax weights + weighted sum
+    in ONE kernel (sn_pairscan_forward), optionally together with both Chamfer directions between the
+    query cloud and the point cloud (the sampler's simplification loss reuses them).
+
+    forward(point_cloud (B,3,N), query_cloud (B,3,M), temperature (scalar tensor), min_sigma, K, want_chamfer)
+      -> proj (B,3,M), idx (B,M,K) [, dist_q (B,M), idx_q, dist_p (B,N), idx_p]
+    """
+
+    @staticmethod
+    def forward(ctx, point_cloud, query_cloud, temperature, min_sigma, K, want_chamfer):
+        _need_gpu(point_cloud, query_cloud, temperature)
+        P, Q = _f32c(point_cloud), _f32c(query_cloud)
+        B, _, N = P.shape
+        M = Q.shape[2]
+        dev = P.device
+        proj = torch.empty(B, 3, M, device=dev, dtype=torch.float32)
+        idx = torch.empty(B, M, K, device=dev, dtype=torch.int32)
+        dq = iq = dp = ip = None
+        if want_chamfer:
+            dq = torch.empty(B, M, device=dev, dtype=torch.float32)
+            iq = torch.empty(B, M, device=dev, dtype=torch.int32)
+            dp = torch.empty(B, N, device=dev, dtype=torch.float32)
+            ip = torch.empty(B, N, device=dev, dtype=torch.int32)
+        T = temperature.detach().float().reshape(1)
+        with torch.cuda.device(dev):
+            check(lib.sn_pairscan_forward(B, N, M, K, ptr(P), BCN, ptr(Q), BCN, ptr(idx), None, ptr(dq), ptr(iq),
+                                          ptr(dp), ptr(ip), ptr(proj), BCN, None, ptr(T), float(min_sigma), _stream(P)),
+                  "sn_pairscan_forward")
+        ctx.save_for_backward(P, Q, idx, temperature)
+        ctx.min_sigma = float(min_sigma)
+        ctx.K = K
+        ctx.mark_non_differentiable(idx)
+        if want_chamfer:
+            ctx.mark_non_differentiable(dq, iq, dp, ip)  # their gradient is taken by ChamferFromScan
+            return proj, idx, dq, iq, dp, ip
+        return proj, idx
+
+    @staticmethod
+    def backward(ctx, grad_proj, *_unused):
+        P, Q, idx, temperature = ctx.saved_tensors
+        B, _, N = P.shape
+        M = Q.shape[2]
+        dev = P.device
+        grad_proj = grad_proj.contiguous()
+        gQ = torch.empty_like(Q)
+        gP = torch.zeros_like(P) if ctx.needs_input_grad[0] else None
+        gsig = torch.empty(B, device=dev, dtype=torch.float32)
+        T = temperature.detach().float().reshape(1)
+        with torch.cuda.device(dev):
+            check(lib.sn_soft_project_backward(B, N, M, ctx.K, ptr(P), BCN, ptr(Q), BCN, ptr(idx), ptr(T), ctx.min_sigma,
+                                               ptr(grad_proj), BCN, ptr(gQ), BCN, ptr(gP), ptr(gsig), _stream(P)),
+                  "sn_soft_project_backward")
+        gT = None
+        if ctx.needs_input_grad[2]:
+            gT = (gsig.sum() * _dsigma_dT(temperature, ctx.min_sigma)).reshape(temperature.shape)
+        return gP, (gQ if ctx.needs_input_grad[1] else None), gT, None, None, None
+
+
+class SoftWeightsFunction(torch.autograd.Function):
+    """w (B,M,K) = softmax_k(-|P[idx]-Q|^2 / sigma)   (soft_projection.py:92-95,110,128,143)"""
+
+    @staticmethod
+    def forward(ctx, P, Q, idx, temperature, min_sigma):
+        _need_gpu(P, Q, idx, temperature)
+        P, Q, idx = _f32c(P), _f32c(Q), idx.contiguous().int()
+        B, _, N = P.shape
+        M = Q.shape[2]
+        K = idx.shape[2]
+        w = torch.empty(B, M, K, device=P.device, dtype=torch.float32)
+        T = temperature.detach().float().reshape(1)
+        with torch.cuda.device(P.device):
+            check(lib.sn_soft_weights_forward(B, N, M, K, ptr(P), ptr(Q), ptr(idx), ptr(T), float(min_sigma), ptr(w),
+                                              _stream(P)), "sn_soft_weights_forward")
+        ctx.save_for_backward(P, Q, idx, temperature, w)
+        ctx.min_sigma = float(min_sigma)
+        return w
+
+    @staticmethod
+    def backward(ctx, grad_w):
+        P, Q, idx, temperature, w = ctx.saved_tensors
+        B, _, N = P.shape
+        M = Q.shape[2]
+        K = idx.shape[2]
+        grad_w = grad_w.contiguous()
+        gQ = torch.empty_like(Q)
+        gP = torch.zeros_like(P) if ctx.needs_input_grad[0] else None
+        gsig = torch.empty(B, device=P.device, dtype=torch.float32)
+        T = temperature.detach().float().reshape(1)
+        with torch.cuda.device(P.device):
+            check(lib.sn_soft_weights_backward(B, N, M, K, ptr(P), ptr(Q), ptr(idx), ptr(T), ctx.min_sigma, ptr(w),
+                                               ptr(grad_w), ptr(gQ), ptr(gP), ptr(gsig), _stream(P)),
+                  "sn_soft_weights_backward")
+        gT = None
+        if ctx.needs_input_grad[3]:
+            gT = (gsig.sum() * _dsigma_dT(temperature, ctx.min_sigma)).reshape(temperature.shape)
+        return gP, (gQ if ctx.needs_input_grad[1] else None), None, gT, None
+
+
+class WeightedGatherFunction(torch.autograd.Function):
+    """out (B,C,M) = sum_k w[:, :, k] * X[:, :, idx[:, :, k]]   (soft_projection.py:113-118,131-134,148-151)"""
+
+    @staticmethod
+    def forward(ctx, X, idx, w):
+        _need_gpu(X, idx, w)
+        X, idx, w = _f32c(X), idx.contiguous().int(), _f32c(w)
+        B, C, N = X.shape
+        _, M, K = idx.shape
+        out = torch.empty(B, C, M, device=X.device, dtype=torch.float32)
+        with torch.cuda.device(X.device):
+            check(lib.sn_weighted_gather_forward(B, C, N, M, K, ptr(X), ptr(idx), ptr(w), ptr(out), _stream(X)),
+                  "sn_weighted_gather_forward")
+        ctx.save_for_backward(X, idx, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        X, idx, w = ctx.saved_tensors
+        B, C, N = X.shape
+        _, M, K = idx.shape
+        grad_out = grad_out.contiguous()
+        gw = torch.empty_like(w) if ctx.needs_input_grad[2] else None
+        gX = torch.zeros_like(X) if ctx.needs_input_grad[0] else None
+        with torch.cuda.device(X.device):
+            check(lib.sn_weighted_gather_backward(B, C, N, M, K, ptr(X), ptr(idx), ptr(w), ptr(grad_out), ptr(gw), ptr(gX),
+                                                  _stream(X)), "sn_weighted_gather_backward")
+        return gX, None, gw
+
+
+class ChamferFromScanFunction(torch.autograd.Function):
+    """Autograd node for Chamfer distances that were produced by a previous pair scan.
+
+    forward(xyz1 (B,n,3), xyz2 (B,m,3), dist1, idx1, dist2, idx2) -> dist1, dist2 (no kernel launch);
+    backward = sn_chamfer_backward.  Used by SampleNet.get_simplification_loss when the sampler's own
+    forward pass already scanned the same pair of clouds (one distance matrix instead of three).
+    """
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, dist1, idx1, dist2, idx2):
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        return dist1.clone(), dist2.clone()
+
+    @staticmethod
+    def backward(ctx, graddist1, graddist2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        g1, g2 = chamfer_backward_impl(xyz1.contiguous(), xyz2.contiguous(), idx1, idx2, graddist1, graddist2,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return g1, g2, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------- EMD
+def approx_match(xyz1, xyz2):
+    """xyz1 (B,n,3), xyz2 (B,m,3) -> match (B,m,n); no gradient (tf_approxmatch.py:13-24)."""
+    _need_gpu(xyz1, xyz2)
+    xyz1, xyz2 = _f32c(xyz1.detach()), _f32c(xyz2.detach())
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    match = torch.empty(b, m, n, device=xyz1.device, dtype=torch.float32)
+    ws = torch.empty(max(1, lib.sn_workspace_bytes(b"approxmatch", b, n, m, 0) // 4), device=xyz1.device, dtype=torch.float32)
+    with torch.cuda.device(xyz1.device):
+        check(lib.sn_approxmatch(b, n, m, ptr(xyz1), ptr(xyz2), ptr(match), ptr(ws), _stream(xyz1)), "sn_approxmatch")
+    return match
+
+
+class MatchCostFunction(torch.autograd.Function):
+    """cost (B,) = sum match * distance; gradient to xyz1 / xyz2 with match constant (tf_approxmatch.py:34-64)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, match):
+        _need_gpu(xyz1, xyz2, match)
+        xyz1, xyz2, match = _f32c(xyz1), _f32c(xyz2), _f32c(match)
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        cost = torch.empty(b, device=xyz1.device, dtype=torch.float32)
+        ws = torch.empty(max(1, lib.sn_workspace_bytes(b"matchcost", b, n, m, 0) // 4), device=xyz1.device, dtype=torch.float32)
+        with torch.cuda.device(xyz1.device):
+            check(lib.sn_matchcost(b, n, m, ptr(xyz1), ptr(xyz2), ptr(match), ptr(cost), ptr(ws), _stream(xyz1)), "sn_matchcost")
+        ctx.save_for_backward(xyz1, xyz2, match)
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        xyz1, xyz2, match = ctx.saved_tensors
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        g1 = torch.empty_like(xyz1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(xyz2) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(xyz1.device):
+            check(lib.sn_matchcost_grad(b, n, m, ptr(xyz1), ptr(xyz2), ptr(match), ptr(g1), ptr(g2), _stream(xyz1)),
+                  "sn_matchcost_grad")
+        gc = grad_cost.reshape(b, 1, 1)
+        return (g1 * gc if g1 is not None else None), (g2 * gc if g2 is not None else None), None
+
+
+match_cost = MatchCostFunction.apply

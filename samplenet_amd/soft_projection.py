@@ -1,0 +1,76 @@
+"""SoftProjection -- drop-in for registration/src/soft_projection.py (same constructor, same
+`forward(point_cloud, query_cloud, point_features=None, action=...)`, same `_temperature` parameter
+name, same `sigma()`), running on the HIP kernels of libsamplenet_hip.so.
+
+  project               : one fused kernel (kNN + softmax + weighted sum), fused backward
+  propagate / project_and_propagate : kNN kernel + softmax-weights kernel + weighted-gather kernel(s)
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def knn_point(group_size, point_cloud, query_cloud):
+    """(dist, idx) like knn_cuda.KNN(k, transpose_mode=False): dist (B,k,M) Euclidean, idx (B,k,M) int64.
+    Mirrors registration/src/soft_projection.py:11-14."""
+    idx, d2 = ops.knn(group_size, point_cloud, query_cloud, ops.BCN, ops.BCN, return_dist=True)
+    return d2.sqrt().permute(0, 2, 1).contiguous(), idx.permute(0, 2, 1).contiguous().long()
+
+
+class SoftProjection(nn.Module):
+    def __init__(self, group_size, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-4):
+        """Computes a soft nearest neighbor point cloud (arguments as soft_projection.py:23-44)."""
+        super().__init__()
+        self._group_size = group_size
+        self._temperature = torch.nn.Parameter(
+            torch.tensor(initial_temperature, requires_grad=is_temperature_trainable, dtype=torch.float32))
+        self._min_sigma = torch.tensor(min_sigma, dtype=torch.float32)
+        self._min_sigma_f = float(min_sigma)
+
+    def forward(self, point_cloud, query_cloud, point_features=None, action="project"):
+        point_cloud = point_cloud.contiguous()
+        query_cloud = query_cloud.contiguous()
+        if action == "project":
+            return self.project(point_cloud, query_cloud)
+        elif action == "propagate":
+            return self.propagate(point_cloud, point_features, query_cloud)
+        elif action == "project_and_propagate":
+            return self.project_and_propagate(point_cloud, point_features, query_cloud)
+        else:
+            raise ValueError(
+                "action should be one of the following: 'project', 'propagate', 'project_and_propagate'")
+
+    def sigma(self):
+        device = self._temperature.device
+        return torch.max(self._temperature ** 2, self._min_sigma.to(device))
+
+    # -- fused hot path -------------------------------------------------------------------------
+    def project(self, point_cloud, query_cloud, hard=False):
+        if hard:
+            raise NotImplementedError
+        proj, _idx = ops.SoftProjectFunction.apply(point_cloud, query_cloud, self._temperature, self._min_sigma_f,
+                                                   self._group_size, False)
+        return proj
+
+    def project_with_chamfer(self, point_cloud, query_cloud):
+        """project() plus both nearest-neighbour directions between query_cloud and point_cloud from the same
+        distance scan: returns proj (B,3,M), idx (B,M,K), dist_q (B,M), idx_q, dist_p (B,N), idx_p."""
+        return ops.SoftProjectFunction.apply(point_cloud, query_cloud, self._temperature, self._min_sigma_f,
+                                             self._group_size, True)
+
+    # -- split path (features) ------------------------------------------------------------------
+    def _weights(self, point_cloud, query_cloud):
+        idx, _ = ops.knn(self._group_size, point_cloud, query_cloud, ops.BCN, ops.BCN, return_dist=False)
+        w = ops.SoftWeightsFunction.apply(point_cloud, query_cloud, idx, self._temperature, self._min_sigma_f)
+        return idx, w
+
+    def propagate(self, point_cloud, point_features, query_cloud):
+        idx, w = self._weights(point_cloud, query_cloud)
+        return ops.WeightedGatherFunction.apply(point_features.contiguous(), idx, w)
+
+    def project_and_propagate(self, point_cloud, point_features, query_cloud):
+        idx, w = self._weights(point_cloud, query_cloud)
+        projected_points = ops.WeightedGatherFunction.apply(point_cloud, idx, w)
+        propagated_features = ops.WeightedGatherFunction.apply(point_features.contiguous(), idx, w)
+        return (projected_points, propagated_features)

@@ -1,0 +1,302 @@
+"""GPU parity tests of the geometric kernels (pair scan, Chamfer, kNN, gathers, SoftProjection).
+
+Every test calls the HIP path through the C ABI (samplenet_amd -> libsamplenet_hip.so) and compares with
+the CPU oracle (oracle/) on the same seeded inputs and/or with the committed golden vectors that were
+produced by running the reference modules (tests/golden/).  Bars: indices and Chamfer distances /
+gradients bit-exact; soft-projection values within 1e-6 abs (1e-5 is the north-star bar).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def clouds(seed, b, n, m, dup=True):
+    rng = np.random.default_rng(seed)
+    x1 = rng.random((b, n, 3), dtype=np.float32) - 0.5
+    x2 = rng.random((b, m, 3), dtype=np.float32) - 0.5
+    if dup and n > 12 and m > 12:
+        x2[:, 3] = x2[:, 9]      # exact duplicates: lowest index must win
+        x2[:, 11] = x2[:, 9]
+        x1[:, 2] = x1[:, 7]
+        x1[0, 5] = x2[0, 4]      # zero distance
+    return x1, x2
+
+
+# ------------------------------------------------------------------------------------------ Chamfer
+CH_SHAPES = [(2, 64, 1024), (3, 100, 37), (1, 1, 1), (2, 1, 70), (2, 513, 515), (4, 1024, 64), (2, 1024, 1024),
+             (1, 2048, 64), (2, 64, 2048), (1, 2049, 70), (1, 70, 2049), (1, 3000, 2500), (32, 64, 1024)]
+
+
+@pytest.mark.parametrize("shape", CH_SHAPES)
+def test_chamfer_forward_backward_bit_exact(oracle, shape):
+    from samplenet_amd import ops
+
+    b, n, m = shape
+    x1, x2 = clouds(n * 31 + m, b, n, m)
+    o = oracle.chamfer_forward(x1, x2)
+    t1, t2 = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
+    d1, d2, i1, i2 = ops.chamfer_distance(t1, t2, return_idx=True)
+    assert np.array_equal(i1.cpu().numpy(), o[1]) and np.array_equal(i2.cpu().numpy(), o[3])
+    assert np.array_equal(d1.detach().cpu().numpy(), o[0]) and np.array_equal(d2.detach().cpu().numpy(), o[2])
+    rng = np.random.default_rng(1)
+    g1 = rng.standard_normal((b, n)).astype(np.float32)
+    g2 = rng.standard_normal((b, m)).astype(np.float32)
+    og1, og2 = oracle.chamfer_backward(x1, x2, g1, o[1], g2, o[3])
+    gx1, gx2 = torch.autograd.grad([d1, d2], [t1, t2], [dev(g1), dev(g2)])
+    assert np.array_equal(gx1.cpu().numpy(), og1)
+    assert np.array_equal(gx2.cpu().numpy(), og2)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_chamfer_module_matches_reference_golden(golden, tag):
+    from samplenet_amd import ChamferDistance
+
+    g = golden("chamfer_reference.npz")
+    t1 = dev(g[f"{tag}_xyz1"]).requires_grad_(True)
+    t2 = dev(g[f"{tag}_xyz2"]).requires_grad_(True)
+    d1, d2 = ChamferDistance()(t1, t2)
+    assert np.array_equal(d1.detach().cpu().numpy(), g[f"{tag}_dist1"])
+    assert np.array_equal(d2.detach().cpu().numpy(), g[f"{tag}_dist2"])
+    gx1, gx2 = torch.autograd.grad([d1, d2], [t1, t2], [dev(g[f"{tag}_gdist1"]), dev(g[f"{tag}_gdist2"])])
+    assert np.array_equal(gx1.cpu().numpy(), g[f"{tag}_gxyz1"])
+    assert np.array_equal(gx2.cpu().numpy(), g[f"{tag}_gxyz2"])
+
+
+def test_chamfer_empty_and_errors():
+    from samplenet_amd import ops
+    from samplenet_amd._lib import SampleNetHipError
+
+    d1, d2 = ops.chamfer_distance(torch.zeros(0, 5, 3).cuda(), torch.zeros(0, 7, 3).cuda())
+    assert d1.shape == (0, 5) and d2.shape == (0, 7)
+    with pytest.raises(SampleNetHipError):
+        ops.chamfer_distance(torch.zeros(2, 0, 3).cuda(), torch.zeros(2, 7, 3).cuda())
+    with pytest.raises(RuntimeError):
+        ops.chamfer_distance(torch.zeros(2, 4, 3), torch.zeros(2, 7, 3))  # CPU tensors: no fallback
+
+
+def test_chamfer_full_size_properties():
+    """BASELINE config 2 size (B=32, 1024 <-> 64) and a saturating batch: size-independent properties."""
+    from samplenet_amd import ops
+
+    for B in (32, 1024):
+        g = torch.Generator(device="cuda").manual_seed(B)
+        ref = torch.rand(B, 1024, 3, device="cuda", generator=g) - 0.5
+        smp = torch.rand(B, 64, 3, device="cuda", generator=g) - 0.5
+        d1, d2, i1, i2 = ops.chamfer_distance(smp, ref, return_idx=True)
+        # (1) the reported distance is exactly the distance to the reported index
+        nn1 = torch.gather(ref, 1, i1.long().unsqueeze(2).expand(-1, -1, 3))
+        diff = nn1 - smp
+        re = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+        assert torch.equal(re, d1)
+        # (2) swapping the arguments swaps the outputs bit-for-bit
+        e2, e1, j2, j1 = ops.chamfer_distance(ref, smp, return_idx=True)
+        assert torch.equal(e1, d1) and torch.equal(e2, d2) and torch.equal(j1, i1) and torch.equal(j2, i2)
+        # (3) minimality against the dense matrix of a few clouds
+        D = ((smp[:4, :, None, :] - ref[:4, None, :, :]) ** 2)
+        D = (D[..., 0] + D[..., 1]) + D[..., 2]
+        assert torch.equal(D.min(2)[0], d1[:4]) and torch.equal(D.min(1)[0], d2[:4])
+
+
+# ------------------------------------------------------------------------------------------ kNN
+@pytest.mark.parametrize("cfg", [(3, 1024, 64, 8), (2, 1024, 64, 7), (2, 2048, 64, 16), (2, 500, 40, 1), (1, 6, 9, 3),
+                                 (2, 64, 64, 64), (1, 100, 5, 33), (2, 3000, 50, 8), (1, 5000, 20, 16), (2, 1024, 1024, 8),
+                                 (1, 200, 3, 10)])
+@pytest.mark.parametrize("layout", ["bcn", "bnc"])
+def test_knn_matches_oracle(oracle, cfg, layout):
+    from samplenet_amd import ops
+
+    b, n, m, k = cfg
+    P, Q = clouds(n + m + k, b, n, m)
+    if n > 300:
+        P[:, 100:140] = P[:, 100:101]  # 40 identical points: deep ties at the k-th boundary
+        Q[:, 0] = P[:, 100]
+    od, oi = oracle.knn(k, P, Q)
+    if layout == "bcn":
+        idx, d2 = ops.knn(k, dev(P.transpose(0, 2, 1)), dev(Q.transpose(0, 2, 1)), ops.BCN, ops.BCN)
+    else:
+        idx, d2 = ops.knn(k, dev(P), dev(Q), ops.BNC, ops.BNC)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(d2.cpu().numpy(), od)
+
+
+def test_knn_all_points_identical(oracle):
+    from samplenet_amd import ops
+
+    P = np.full((2, 700, 3), 0.25, np.float32)
+    Q = np.random.default_rng(0).random((2, 9, 3), dtype=np.float32)
+    od, oi = oracle.knn(16, P, Q)
+    idx, d2 = ops.knn(16, dev(P), dev(Q), ops.BNC, ops.BNC)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d2.cpu().numpy(), od)
+    assert np.array_equal(oi[0, 0], np.arange(16))
+
+
+def test_knn_in_tree_definition_when_distinct(oracle):
+    """Membership and order equal the in-tree TF definition (matrix + selection sort) on distinct distances."""
+    from samplenet_amd import ops
+
+    P, Q = clouds(77, 2, 1024, 64, dup=False)
+    _, ti = oracle.knn_point_tf(8, P, Q)
+    idx, _ = ops.knn(8, dev(P), dev(Q), ops.BNC, ops.BNC)
+    assert np.array_equal(idx.cpu().numpy(), ti)
+
+
+def test_knn_compat_shim_interface(oracle):
+    from samplenet_amd.compat.knn_cuda import KNN
+
+    P, Q = clouds(5, 2, 300, 20)
+    d, i = KNN(4, transpose_mode=False)(dev(P.transpose(0, 2, 1)), dev(Q.transpose(0, 2, 1)))
+    od, oi = oracle.knn(4, P, Q)
+    assert d.shape == (2, 4, 20) and i.dtype == torch.int64
+    assert np.array_equal(i.permute(0, 2, 1).cpu().numpy(), oi)
+    np.testing.assert_allclose(d.permute(0, 2, 1).cpu().numpy(), np.sqrt(od), rtol=1e-6)
+    d, i = KNN(4, transpose_mode=True)(dev(P), dev(Q))
+    assert np.array_equal(i.cpu().numpy(), oi)
+
+
+# ------------------------------------------------------------------------------------------ gathers
+def test_group_point_and_grad(oracle):
+    from samplenet_amd import ops
+
+    rng = np.random.default_rng(2)
+    pts = rng.random((3, 50, 6), dtype=np.float32)
+    idx = rng.integers(0, 50, (3, 11, 4)).astype(np.int32)
+    t = dev(pts).requires_grad_(True)
+    out = ops.group_point(t, dev(idx))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.group_point(pts, idx))
+    go = rng.random((3, 11, 4, 6), dtype=np.float32)
+    (g,) = torch.autograd.grad(out, t, dev(go))
+    np.testing.assert_allclose(g.cpu().numpy(), oracle.group_point_grad(pts.shape, idx, go), rtol=1e-6, atol=1e-6)
+
+
+def test_grouping_operation_and_grad(oracle):
+    from samplenet_amd.compat.pointnet2.utils.pointnet2_utils import grouping_operation
+
+    rng = np.random.default_rng(3)
+    feat = rng.random((2, 5, 64), dtype=np.float32)
+    idx = rng.integers(0, 64, (2, 9, 8)).astype(np.int32)
+    t = dev(feat).requires_grad_(True)
+    out = grouping_operation(t, dev(idx))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.grouping_operation(feat, idx))
+    go = rng.random(out.shape, dtype=np.float32)
+    (g,) = torch.autograd.grad(out, t, dev(go))
+    np.testing.assert_allclose(g.cpu().numpy(), oracle.grouping_operation_grad(feat.shape, idx, go), rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ SoftProjection
+@pytest.mark.parametrize("cfg", [(4, 1024, 64, 8, 1.0), (2, 1024, 64, 7, 0.3), (2, 2048, 64, 16, 0.05), (1, 33, 7, 16, 1.0),
+                                 (3, 200, 24, 1, 0.5)])
+def test_soft_project_fused_vs_oracle(oracle, cfg):
+    from samplenet_amd import ops
+
+    b, n, m, k, T = cfg
+    Pn, Qn = clouds(n * 3 + k, b, n, m)
+    # queries near the surface make near-ties likely (SURVEY 8d set ii)
+    Qn = (Pn[:, :m] + 0.02 * np.random.default_rng(k).standard_normal((b, m, 3))).astype(np.float32)
+    P = np.ascontiguousarray(Pn.transpose(0, 2, 1))
+    Q = np.ascontiguousarray(Qn.transpose(0, 2, 1))
+    min_sigma = 1e-2
+    sigma = max(T * T, min_sigma)
+    _, oi = oracle.knn(k, Pn, Qn)
+    oproj, _, _ = oracle.softproj_forward(P, Q, oi, sigma)
+    tP, tQ = dev(P).requires_grad_(True), dev(Q).requires_grad_(True)
+    tT = torch.tensor(T, device="cuda", requires_grad=True)
+    proj, idx, dq, iq, dp, ip = ops.SoftProjectFunction.apply(tP, tQ, tT, min_sigma, k, True)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    np.testing.assert_allclose(proj.detach().cpu().numpy(), oproj, rtol=0, atol=1e-6)
+    od = oracle.chamfer_forward(Qn, Pn)
+    assert np.array_equal(dq.cpu().numpy(), od[0]) and np.array_equal(iq.cpu().numpy(), od[1])
+    assert np.array_equal(dp.cpu().numpy(), od[2]) and np.array_equal(ip.cpu().numpy(), od[3])
+    gp = np.random.default_rng(9).standard_normal(oproj.shape).astype(np.float32)
+    ogq, ogp, ogs = oracle.softproj_backward(P, Q, oi, sigma, gp, want_grad_P=True)
+    gP, gQ, gT = torch.autograd.grad(proj, [tP, tQ, tT], dev(gp))
+    np.testing.assert_allclose(gQ.cpu().numpy(), ogq, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gP.cpu().numpy(), ogp, rtol=1e-4, atol=1e-5)
+    ogT = ogs * 2 * T if T * T > min_sigma else 0.0
+    np.testing.assert_allclose(float(gT), ogT, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_soft_projection_module_matches_reference_golden(golden, tag):
+    """All three actions + gradients against outputs of the reference module (tests/golden/make_golden.py)."""
+    from samplenet_amd import SoftProjection
+
+    g = golden("softproj_reference.npz")
+    K, T = int(g[f"{tag}_K"]), float(g[f"{tag}_T"])
+    sp = SoftProjection(K, initial_temperature=T, is_temperature_trainable=True, min_sigma=1e-2).cuda()
+    P = dev(g[f"{tag}_P"]).requires_grad_(True)
+    Q = dev(g[f"{tag}_Q"]).requires_grad_(True)
+    Fe = dev(g[f"{tag}_F"]).requires_grad_(True)
+    proj = sp(P, Q, action="project")
+    np.testing.assert_allclose(proj.detach().cpu().numpy(), g[f"{tag}_proj"], rtol=0, atol=1e-6)
+    gP, gQ, gT = torch.autograd.grad(proj, [P, Q, sp._temperature], dev(g[f"{tag}_gproj"]))
+    np.testing.assert_allclose(gQ.cpu().numpy(), g[f"{tag}_gQ"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gP.cpu().numpy(), g[f"{tag}_gP"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gT.cpu().numpy(), g[f"{tag}_gT"], rtol=1e-4, atol=1e-5)
+    prop = sp(P, Q, Fe, action="propagate")
+    np.testing.assert_allclose(prop.detach().cpu().numpy(), g[f"{tag}_prop"], rtol=1e-6, atol=2e-6)
+    hP, hQ, hF, hT = torch.autograd.grad(prop, [P, Q, Fe, sp._temperature], dev(g[f"{tag}_gprop"]))
+    np.testing.assert_allclose(hQ.cpu().numpy(), g[f"{tag}_hQ"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(hP.cpu().numpy(), g[f"{tag}_hP"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(hF.cpu().numpy(), g[f"{tag}_hF"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(hT.cpu().numpy(), g[f"{tag}_hT"], rtol=1e-4, atol=2e-5)
+    proj2, prop2 = sp(P, Q, Fe, action="project_and_propagate")
+    np.testing.assert_allclose(proj2.detach().cpu().numpy(), g[f"{tag}_proj2"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(prop2.detach().cpu().numpy(), g[f"{tag}_prop2"], rtol=1e-6, atol=2e-6)
+    with pytest.raises(ValueError):
+        sp(P, Q, action="nope")
+
+
+def test_soft_projection_known_answers(golden):
+    """registration/src/soft_projection.py:158-284 and classification/soft_projection.py:86-161 through the module."""
+    from samplenet_amd import SoftProjection
+
+    g = golden("known_answer_registration.npz")
+    P = dev(g["point_cloud"].T[None], torch.float32)
+    Q = dev(g["query_cloud"].T[None], torch.float32)
+    Fe = dev(g["point_features"].T[None], torch.float32)
+    sp = SoftProjection(3, initial_temperature=1.0).cuda()
+    prop = sp.propagate(P, Fe, Q).cpu().detach().numpy().squeeze()
+    assert np.mean(np.sum((prop.T - g["expected_features_nn_3"]) ** 2, axis=1)) < 1e-6
+    sd = sp.state_dict()
+    sd["_temperature"] = torch.tensor(0.1, dtype=torch.float32)
+    sp.load_state_dict(sd)
+    proj = sp.project(Q, P).cpu().detach().numpy().squeeze()
+    assert np.mean(np.sum((proj.T - g["expected_nn_cloud"]) ** 2, axis=1)) < 1e-6
+
+    c = golden("known_answer_classification.npz")
+    pc = np.stack([c["point_cloud"], c["point_cloud"] * 3]).astype(np.float32)
+    qc = np.stack([c["query_cloud"], c["query_cloud"] * 3]).astype(np.float32)
+    exp_soft = np.stack([c["expected_cloud_soft"], c["expected_cloud_soft"] * 3])
+    sp = SoftProjection(3, initial_temperature=0.01, min_sigma=1e-4).cuda()
+    out = sp(dev(pc.transpose(0, 2, 1)), dev(qc.transpose(0, 2, 1)))
+    assert np.abs(out.detach().cpu().numpy().transpose(0, 2, 1) - exp_soft).max() < 2e-3
+
+
+def test_soft_project_full_size_properties():
+    """B=32 (config 2) and B=512: projected points lie in the convex hull of their neighbours; T -> 0 gives the
+    nearest neighbour (hard projection, classification/soft_projection.py:73-76); idempotence on dataset points."""
+    from samplenet_amd import ops
+
+    for B in (32, 512):
+        g = torch.Generator(device="cuda").manual_seed(B)
+        P = (torch.rand(B, 3, 1024, device="cuda", generator=g) - 0.5)
+        Q = (torch.rand(B, 3, 64, device="cuda", generator=g) - 0.5)
+        T = torch.tensor(1.0, device="cuda")
+        proj, idx = ops.SoftProjectFunction.apply(P, Q, T, 1e-2, 8, False)
+        nb = torch.gather(P.unsqueeze(2).expand(-1, -1, 64, -1), 3, idx.long().unsqueeze(1).expand(-1, 3, -1, -1))
+        assert torch.all(proj <= nb.max(3)[0] + 1e-6) and torch.all(proj >= nb.min(3)[0] - 1e-6)
+        tiny = torch.tensor(1e-10, device="cuda")  # sigma = 1e-20: only exact distance ties could share weight
+        hard, idx1 = ops.SoftProjectFunction.apply(P, Q, tiny, 1e-30, 8, False)
+        assert torch.allclose(hard, nb[..., 0], atol=1e-6)
+        # queries that ARE dataset points project onto themselves as T -> 0
+        Q2 = P[:, :, 5:69].contiguous()
+        self_proj, idx2 = ops.SoftProjectFunction.apply(P, Q2, tiny, 1e-30, 8, False)
+        assert torch.equal(idx2[:, :, 0], torch.arange(5, 69, device="cuda", dtype=torch.int32).expand(B, -1))
+        assert torch.allclose(self_proj, Q2, atol=1e-6)

@@ -1,0 +1,116 @@
+"""GPU parity of the SampleNet drop-in against outputs of the reference module (tests/golden/samplenet_reference.npz,
+produced by tests/golden/make_golden.py running registration/src/samplenet.py on CPU)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(g, tag, after_step=False, **kw):
+    from samplenet_amd import SampleNet
+
+    B, N, M, K, bneck, lay = [int(v) for v in g[f"{tag}_cfg"]]
+    shape = "bnc" if lay == 0 else "bcn"
+    net = SampleNet(M, bneck, group_size=K, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-2,
+                    input_shape=shape, output_shape=shape, **kw)
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_sd_")}
+    if after_step:  # BatchNorm running statistics as they were after the golden training step
+        sd.update({k[len(tag) + 5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_sd1_")})
+    missing, unexpected = net.load_state_dict(sd, strict=True)  # state_dict keys are part of the drop-in contract
+    assert not missing and not unexpected
+    return net.cuda(), (B, N, M, K, shape)
+
+
+@pytest.mark.parametrize("tag", ["c1", "s"])
+def test_train_step_matches_reference(golden, oracle, tag):
+    g = golden("samplenet_reference.npz")
+    net, (B, N, M, K, shape) = _build(g, tag)
+    net.train()
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    simp, proj = net(x)
+    # the MLP output feeds BatchNorm over a batch of only B samples in the FC head, which amplifies the
+    # GPU-vs-CPU summation-order noise of the fp32 GEMMs: ~1e-4 on O(1) coordinates
+    np.testing.assert_allclose(simp.detach().cpu().numpy(), g[f"{tag}_simp"], rtol=3e-4, atol=3e-4)
+    # projection: tight against the oracle on the simplified cloud actually produced ...
+    xn = (x if shape == "bnc" else x.permute(0, 2, 1)).contiguous().cpu().numpy()
+    sn = (simp if shape == "bnc" else simp.permute(0, 2, 1)).detach().contiguous().cpu().numpy()
+    _, oidx = oracle.knn(K, xn, sn)
+    sigma = float(net.project.sigma())
+    oproj, _, _ = oracle.softproj_forward(xn.transpose(0, 2, 1), sn.transpose(0, 2, 1), oidx, sigma)
+    pn = (proj if shape == "bnc" else proj.permute(0, 2, 1)).detach().cpu().numpy()
+    np.testing.assert_allclose(pn, oproj.transpose(0, 2, 1), rtol=0, atol=1e-6)
+    # ... and against the reference run: a 1e-4 shift of a query can swap its K-th/(K+1)-th neighbour (the
+    # projection is discontinuous there), so a few entries may legitimately differ
+    close = np.isclose(proj.detach().cpu().numpy(), g[f"{tag}_proj"], rtol=3e-4, atol=3e-4)
+    assert close.mean() >= 0.97
+    x_bnc = x if shape == "bnc" else x.permute(0, 2, 1).contiguous()
+    simp_bnc = simp if shape == "bnc" else simp.permute(0, 2, 1).contiguous()
+    lsimp = net.get_simplification_loss(x_bnc, simp_bnc, M, 1.0, 0.5 / M)
+    lproj = net.get_projection_loss()
+    assert (net._scan is not None) and (shape != "bnc" or net._scan_hit(x_bnc, simp_bnc) is not None)
+    gw = torch.from_numpy(g[f"{tag}_gw"]).cuda()
+    loss = 0.01 * lsimp + 0.01 * lproj + (proj * gw).sum() / proj.numel()
+    loss.backward()
+    assert abs(float(lsimp.detach()) - float(g[f"{tag}_lsimp"])) <= 1e-5 * max(1.0, abs(float(g[f"{tag}_lsimp"])))
+    assert abs(float(lproj.detach()) - float(g[f"{tag}_lproj"])) <= 1e-6
+    assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) <= 2e-4
+    bad = []
+    for name, p in net.named_parameters():
+        ref = g[f"{tag}_grad_{name}"].astype(np.float64)
+        got = p.grad.detach().cpu().numpy().astype(np.float64)
+        nref = np.linalg.norm(ref)
+        err = np.linalg.norm(got - ref)
+        if nref < 1e-5:      # conv biases in front of BatchNorm: the true gradient is 0, both sides hold rounding noise
+            ok = err < 1e-4
+        else:
+            ok = err <= 3e-2 * nref
+        if not ok:
+            bad.append((name, err, nref))
+    assert not bad, bad
+    for k in g.files:
+        if k.startswith(f"{tag}_sd1_"):
+            name = k[len(tag) + 5:]
+            np.testing.assert_allclose(net.state_dict()[name].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["c1", "s"])
+def test_loss_without_scan_reuse_is_identical(golden, tag):
+    """get_simplification_loss on tensors that did NOT come from forward() takes the standalone Chamfer kernels."""
+    g = golden("samplenet_reference.npz")
+    net, (B, N, M, K, shape) = _build(g, tag)
+    net.train()
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    simp, proj = net(x)
+    x_bnc = x if shape == "bnc" else x.permute(0, 2, 1).contiguous()
+    simp_bnc = simp if shape == "bnc" else simp.permute(0, 2, 1).contiguous()
+    l_reuse = net.get_simplification_loss(x_bnc, simp_bnc, M, 1.0, 0.25)
+    l_fresh = net.get_simplification_loss(x_bnc.clone(), simp_bnc.clone(), M, 1.0, 0.25)
+    assert float(l_reuse.detach()) == float(l_fresh.detach())
+
+
+@pytest.mark.parametrize("tag", ["c1", "s"])
+def test_eval_branch_matches_reference(golden, tag):
+    g = golden("samplenet_reference.npz")
+    net, _ = _build(g, tag, after_step=True)
+    net.eval()
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    with torch.no_grad():
+        simp, match = net(x)
+    np.testing.assert_allclose(simp.cpu().numpy(), g[f"{tag}_eval_simp"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(match.cpu().numpy(), g[f"{tag}_eval_match"])
+    assert float(net.get_simplification_loss(x, simp, 64)) == 0.0 and float(net.get_projection_loss()) == 0.0
+
+
+def test_surface_and_errors():
+    from samplenet_amd import SampleNet
+
+    with pytest.raises(ValueError):
+        SampleNet(8, 16, 4, input_shape="nbc")
+    net = SampleNet(8, 16, 4, input_shape="bcn", output_shape="bcn").cuda()
+    assert net.name == "samplenet"
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(2, 4, 32, device="cuda"))
+    skip = SampleNet(8, 16, 4, input_shape="bnc", output_shape="bnc", skip_projection=True).cuda().train()
+    simp, proj = skip(torch.rand(2, 32, 3, device="cuda"))
+    assert torch.equal(simp, proj) and float(skip.get_simplification_loss(simp, simp, 8)) == 0.0
