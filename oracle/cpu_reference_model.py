@@ -97,12 +97,34 @@ class SampleNetCPU(nn.Module):
         return torch.mean(c12) + torch.mean(torch.max(c12, dim=1)[0]) + (gamma + delta * pc_size) * torch.mean(c21)
 
 
-def time_cpu_baseline(batch=32, n_in=1024, n_out=64, k=8, budget_s=12.0, warmup=3, threads=None, seed=0):
-    """Runs the unit of work on the host cores for about budget_s seconds; returns a dict for bench.py."""
+def host_cpu_budget():
+    """CPUs this process may actually use: min(affinity mask, cgroup quota)."""
     import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def time_cpu_baseline(batch=32, n_in=1024, n_out=64, k=8, budget_s=12.0, warmup=3, threads=None, seed=0):
+    """Runs the unit of work on the host cores for about budget_s seconds; returns a dict for bench.py.
+    threads=None: calibrates the torch thread count (half / all of the CPUs the cgroup grants) for ~2 s."""
     import time
 
-    threads = threads or os.cpu_count()
+    if threads is None:
+        cap = host_cpu_budget()
+        best = None
+        for th in sorted({max(1, cap // 2), cap}):
+            r = time_cpu_baseline(batch, n_in, n_out, k, budget_s=1.0, warmup=1, threads=th, seed=seed)
+            if best is None or r["value"] > best[1]:
+                best = (th, r["value"])
+        threads = best[0]
+        budget_s = max(1.0, budget_s - 3.0)
     torch.set_num_threads(threads)
     torch.manual_seed(seed)
     net = SampleNetCPU(n_out, 128, k).train()
@@ -119,7 +141,7 @@ def time_cpu_baseline(batch=32, n_in=1024, n_out=64, k=8, budget_s=12.0, warmup=
         step()
     times = []
     t_end = time.perf_counter() + budget_s
-    while time.perf_counter() < t_end or len(times) < 5:
+    while time.perf_counter() < t_end or len(times) < 2:
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
@@ -129,6 +151,7 @@ def time_cpu_baseline(batch=32, n_in=1024, n_out=64, k=8, budget_s=12.0, warmup=
         "unit": "point-clouds/s",
         "cores": int(torch.get_num_threads()),
         "kind": "port",
+        "host_cpus_granted": host_cpu_budget(),
         "ms_per_step": med * 1e3,
         "sample": "%d steps of B=%d, %d->%d, K=%d fwd+loss+bwd on torch-CPU %s (MLP/softmax: torch CPU ops as the "
                   "reference runs them; kNN: broadcast+topk stand-in for knn_cuda; Chamfer: %s, single-threaded)"
