@@ -34,6 +34,29 @@ def geometry_bytes_fwd(N, M, K):
     return 12 * N + 12 * M + 4 * M * K + 12 * M + 8 * M + 8 * N
 
 
+def time_pairscan_kernel(net, pool, K, reps=50):
+    """Average duration of the geometric kernel (sn_pairscan_forward: kNN + soft projection + both Chamfer
+    directions) measured with HIP events on the stream it is launched on, on the bench's own inputs, launches
+    back to back (so the bracket holds kernel time, not Python launch overhead)."""
+    from samplenet_amd import ops
+
+    with torch.no_grad():
+        x = pool[0]
+        simp, _ = net(x)
+        P = x.permute(0, 2, 1).contiguous()
+        Q = simp.permute(0, 2, 1).contiguous()
+        T = net.project._temperature.detach()
+        for _ in range(5):
+            ops.SoftProjectFunction.apply(P, Q, T, 1e-2, K, True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.SoftProjectFunction.apply(P, Q, T, 1e-2, K, True)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -41,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
+    ap.add_argument("--torch-mlp", action="store_true", help="A/B: feature extractor through torch.nn instead of the HIP MLP")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -60,45 +85,25 @@ def main():
 
     import samplenet_amd
     from samplenet_amd import SampleNet, ops
+    from samplenet_amd.engine import SamplerTrainStep
     from samplenet_amd.parallel import FlatGradAllReducer
 
     B, N, M, K = args.batch, 1024, 64, 8
     torch.manual_seed(0)  # identical replicas on every rank (registration/main.py:18 seeds 0 as well)
     net = SampleNet(M, 128, group_size=K, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-2,
-                    input_shape="bnc", output_shape="bnc").to(dev).train()
+                    input_shape="bnc", output_shape="bnc", use_hip_mlp=not args.torch_mlp).to(dev).train()
     reducer = FlatGradAllReducer(net)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank data shard
     pool = [torch.rand(B, N, 3, device=dev, generator=g) - 0.5 for _ in range(8)]
-
-    # live timing of the geometric kernel (sn_pairscan_forward) with events on the stream it is launched on
-    ev = []
-    orig_apply = ops.SoftProjectFunction.apply
-    timing = {"on": False}
-
-    def timed_apply(*a):
-        if not timing["on"]:
-            return orig_apply(*a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig_apply(*a)
-        e1.record()
-        ev.append((e0, e1))
-        return out
-
-    ops.SoftProjectFunction.apply = timed_apply
+    # sampler loss weights of registration/src/sputils.py:53-59: alpha=0.01, lmbda=0.01, gamma=1, delta=0
+    train_step = SamplerTrainStep(net, pool[0], alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=reducer,
+                                  use_graph=not args.no_graph)
 
     def step(i):
-        x = pool[i % len(pool)]
-        reducer.zero_grad()
-        simp, proj = net(x)
-        loss = 0.01 * net.get_simplification_loss(x, simp, M, 1, 0) + 0.01 * net.get_projection_loss() + proj.mean()
-        loss.backward()
-        reducer.reduce()
-        return loss
+        return train_step(pool[i % len(pool)])
 
     for i in range(args.warmup):
         step(i)
-    timing["on"] = True
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -110,7 +115,6 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    timing["on"] = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -120,7 +124,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+        kern_ms = time_pairscan_kernel(net, pool, K)
         alg = geometry_bytes_fwd(N, M, K) * B
         achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
@@ -131,12 +135,14 @@ def main():
             "config": {"workload": "BASELINE configs[1]: SampleNet sampler train step (fwd + simplification/projection "
                                    "losses + bwd), B=%d per GPU, 1024->64 points, K=8, bottleneck 128; no optimizer step" % B,
                        "batch_per_gpu": B, "global_batch": B * world, "n_in": N, "n_out": M, "group_size": K,
-                       "parallelism": "dp%d" % world, "grad_allreduce": "1 flat bucket, RCCL" if world > 1 else "none"},
+                       "parallelism": "dp%d" % world, "grad_allreduce": "1 flat bucket, RCCL" if world > 1 else "none",
+                       "execution": "eager launches" if args.no_graph else "whole step replayed as one hipGraph",
+                       "mlp": "torch.nn (A/B)" if args.torch_mlp else "hand-written fp32 MFMA kernels"},
             "roofline": {"kernel": "sn::pairscan_kernel<16,true,true> (kNN + soft projection + both Chamfer directions)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms,
-                         "note": "event bracket includes the host-side launch path of one kernel"},
+                         "note": "geometric kernel of the path; the MLP GEMM kernels are listed in profiles/"},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_reference_model import time_cpu_baseline

@@ -162,6 +162,50 @@ int sn_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, cons
 int sn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
                       float *grad1, float *grad2, sn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * PointNet feature extractor + FC head (registration/src/samplenet.py:40-59, :90-104): every layer is a
+ * GEMM over rows (R = B*N points for the 1x1 convolutions, R = B for the Linear layers) on fp32 MFMA
+ * with BatchNorm / ReLU / bias / reductions fused (samplenet_amd/csrc/pointnet_mlp.hip).
+ * All matrices are row-major with channels contiguous: activations [R][C], weights [Co][Ci] (the
+ * memory layout of torch Conv1d(k=1).weight and Linear.weight).
+ *
+ *  sn_linear_forward   Z[R][Co] = act(Ain)[R][Ci] . W^T + bias;  act = relu(scale*x + shift) with
+ *                      coef_prev = {scale[Ci], shift[Ci], ...} or identity when coef_prev == NULL.
+ *                      stats (optional): [sn_linear_stats_blocks(R)][2][Co] partial sum / sum of squares.
+ *  sn_bn_finalize      batch statistics -> coef[4][C] = scale, shift, mean, invstd; updates the running
+ *                      statistics and num_batches_tracked like torch.nn.BatchNorm1d in training mode.
+ *  sn_bn_eval_coef     coef from the running statistics (eval mode).
+ *  sn_pool_forward     pooled[b][c] = max_n relu(bn(z[b][n][c])) (+ index and pre-BN value of the selected point).
+ *  sn_pool_backward    gsel = g * [pooled > 0] and the BN-backward sums of the last conv layer.
+ *  sn_bn_backward_coef (sum dY, sum dY*Z) partials -> dgamma, dbeta, dbias, kcoef[3][C] with dZ = k1 dY + k2 Z + k3.
+ *  sn_linear_dgrad     dYprev[R][Ci] = relu-mask . (dZ[R][Co] . W), + BN-backward partial sums of the previous
+ *                      layer [sn_linear_stats_blocks(R)][2][Ci];  dz_mode 0: dZ = dy; 1: k1 dy + k2 z + k3;
+ *                      2: as 1 with dy given sparsely by (gsel, argsel) per cloud of npts rows.
+ *  sn_linear_wgrad     dW[Co][Ci] (and db[Co] if non-NULL) = dZ^T . act(Aprev); `part` is scratch of
+ *                      sn_linear_wgrad_splits(R,Ci,Co,db!=NULL) * Co * (Ci + (db!=NULL)) floats.
+ * ------------------------------------------------------------------------------------------- */
+int sn_linear_stats_blocks(int R);
+int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
+                      const float *bias, float *z, float *stats, sn_stream_t stream);
+int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,
+                   float eps, float momentum, float *running_mean, float *running_var,
+                   long long *num_batches_tracked, float *coef, sn_stream_t stream);
+int sn_bn_eval_coef(int C, const float *gamma, const float *beta, float eps, const float *running_mean,
+                    const float *running_var, float *coef, sn_stream_t stream);
+int sn_pool_forward(int B, int N, int C, const float *z, const float *coef, float *pooled, int *argsel,
+                    float *zsel, sn_stream_t stream);
+int sn_pool_backward(int B, int C, const float *g, const float *pooled, const float *zsel, float *gsel,
+                     float *stats, sn_stream_t stream);
+int sn_bn_backward_coef(int nblk, int C, long long R, const float *stats, const float *coef, float *dgamma,
+                        float *dbeta, float *dbias, float *kcoef, sn_stream_t stream);
+int sn_linear_dgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                    const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                    const float *coef_prev, float *dyprev, float *stats, sn_stream_t stream);
+int sn_linear_wgrad_splits(int R, int Ci, int Co, int with_bias);
+int sn_linear_wgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                    const float *gsel, const int *argsel, int npts, const float *aprev, const float *coef_prev,
+                    float *part, float *dW, float *db, sn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

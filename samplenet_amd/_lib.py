@@ -35,6 +35,16 @@ PROTOTYPES = {
     "sn_weighted_gather_forward": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sn_weighted_gather_backward": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_soft_project_backward": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp],
+    "sn_linear_stats_blocks": [_i],
+    "sn_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_bn_finalize": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sn_bn_eval_coef": [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "sn_pool_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_pool_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_bn_backward_coef": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_linear_dgrad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_linear_wgrad_splits": [_i, _i, _i, _i],
+    "sn_linear_wgrad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sn_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1,0 +1,821 @@
+// pointnet_mlp.hip -- the PointNet feature extractor + FC head of SampleNet on gfx950 matrix cores.
+//
+// Reference: registration/src/samplenet.py:40-59 (parameters) and :90-104 (forward):
+//   5 x [Conv1d(k=1) -> BatchNorm1d -> ReLU]  3->64->64->64->128->bottleneck over B*N points,
+//   max over N, 3 x [Linear -> BatchNorm1d -> ReLU] 256, Linear -> 3*M.
+// A 1x1 convolution over points is a GEMM with R = B*N rows; a Linear layer is the same GEMM
+// with R = B rows.  Every layer (forward, data-gradient, weight-gradient) runs on ONE tiled
+// GEMM core built on v_mfma_f32_32x32x2_f32 (exact fp32: each product rounded once, fp32
+// accumulate -- bitwise a k-ordered fmaf chain), with the surrounding elementwise work fused in:
+//
+//   forward  Z = relu(bn_prev(Zprev)) . W^T + b     BN-apply + ReLU of the PREVIOUS layer fused into
+//                                                   the A-operand load; bias + per-channel
+//                                                   sum / sum-of-squares (BatchNorm batch statistics)
+//                                                   fused into the epilogue (deterministic two-stage
+//                                                   reduction, no atomics)
+//   dgrad    dY_prev = mask(relu) . (dZ . W)        BN-backward of THIS layer fused into the A load
+//                                                   (dZ = k1*dY + k2*Z + k3 per channel), ReLU mask
+//                                                   + BN-backward statistics of the previous layer
+//                                                   fused into the epilogue
+//   wgrad    dW|db = dZ^T . [relu(bn(Zprev)) | 1]   both operands rebuilt on the fly from the stored
+//                                                   pre-BN activations; bias gradient = extra column
+//                                                   of ones; split over R, partials reduced in order
+// Only the pre-BN activations Z_i are ever written to HBM (once) and read back (forward: once,
+// backward: by dgrad and wgrad).
+//
+// GEMM core: block tile BM x BN, K chunks of 32 staged through LDS k-major ([k][m], so an MFMA
+// fragment is one conflict-free ds_read_b32: lanes 0-31 read 32 consecutive floats of row k,
+// lanes 32-63 of row k+1), next chunk prefetched into registers while the current one is in
+// the matrix pipe.
+#include <algorithm>
+
+#include "sn_common.h"
+
+namespace sn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;   // K chunk
+constexpr int LPAD = 4;  // LDS row padding (floats): keeps rows 16-B aligned for the float4 staging stores
+
+// ------------------------------------------------------------------------------------------------
+// Operand loaders.  Each returns 4 consecutive elements along the operand's contiguous dimension,
+// already transformed, zero-filled out of bounds.
+//   KC (k contiguous):  value(x, k..k+3)     source [X][K]
+//   XC (x contiguous):  value(x..x+3, k)     source [K][X]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4_guard(const float *__restrict__ p, size_t off, int valid, bool aligned)
+{
+    // valid in [0,4]: number of in-bounds elements starting at p[off]
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid >= 4 && aligned) return *reinterpret_cast<const float4 *>(p + off);
+    if (valid > 0) v.x = p[off];
+    if (valid > 1) v.y = p[off + 1];
+    if (valid > 2) v.z = p[off + 2];
+    if (valid > 3) v.w = p[off + 3];
+    return v;
+}
+
+enum { ACT_NONE = 0, ACT_BN_RELU = 1 };
+enum { DZ_PLAIN = 0, DZ_BN = 1, DZ_POOL = 2 };
+
+// activation of the previous layer, rows x channels, channel-contiguous: a = relu(scale[c]*z + shift[c]) or raw
+struct ActSrc {
+    const float *z;      // [rows][ch]
+    const float *scale;  // [ch] (ACT_BN_RELU)
+    const float *shift;
+    int rows, ch, mode;
+    int ones_col;  // if >= 0: channel index that reads as 1.0 (bias column of wgrad)
+
+    __device__ __forceinline__ float4 load_c4(int r, int c) const  // 4 consecutive channels of row r
+    {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= rows) return v;
+        const int valid = min(4, ch - c);
+        const bool al = (ch & 3) == 0;
+        if (valid > 0) {
+            v = ld4_guard(z, (size_t)r * ch + c, valid, al);
+            if (mode == ACT_BN_RELU) {
+                const float4 s = ld4_guard(scale, c, valid, al), t = ld4_guard(shift, c, valid, al);
+                v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f);
+                v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f);
+                v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+            }
+            if (valid < 2) v.y = 0.f;
+            if (valid < 3) v.z = 0.f;
+            if (valid < 4) v.w = 0.f;
+        }
+        if (ones_col >= 0) {
+            if (c == ones_col) v.x = 1.f;
+            if (c + 1 == ones_col) v.y = 1.f;
+            if (c + 2 == ones_col) v.z = 1.f;
+            if (c + 3 == ones_col) v.w = 1.f;
+        }
+        return v;
+    }
+};
+
+// gradient w.r.t. the pre-BN output of a layer, rows x channels, channel-contiguous
+struct DzSrc {
+    const float *dy;  // [rows][ch]   (DZ_PLAIN / DZ_BN)
+    const float *z;   // [rows][ch]   (DZ_BN / DZ_POOL not needed for the sparse part)
+    const float *k1, *k2, *k3;  // [ch]  dz = k1*dy + k2*z + k3
+    const float *gsel;          // [B][ch]  (DZ_POOL) gradient at the pooled element
+    const int *argsel;          // [B][ch]  (DZ_POOL) row-within-cloud of the pooled element
+    int rows, ch, mode, npts;
+
+    __device__ __forceinline__ float4 load_c4(int r, int c) const
+    {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= rows) return v;
+        const int valid = min(4, ch - c);
+        if (valid <= 0) return v;
+        const bool al = (ch & 3) == 0;
+        if (mode == DZ_PLAIN) return ld4_guard(dy, (size_t)r * ch + c, valid, al);
+        float4 d;
+        if (mode == DZ_POOL) {
+            const int b = r / npts, n = r - b * npts;
+            const size_t o = (size_t)b * ch + c;
+            d.x = (valid > 0 && argsel[o] == n) ? gsel[o] : 0.f;
+            d.y = (valid > 1 && argsel[o + 1] == n) ? gsel[o + 1] : 0.f;
+            d.z = (valid > 2 && argsel[o + 2] == n) ? gsel[o + 2] : 0.f;
+            d.w = (valid > 3 && argsel[o + 3] == n) ? gsel[o + 3] : 0.f;
+        } else {
+            d = ld4_guard(dy, (size_t)r * ch + c, valid, al);
+        }
+        const float4 zz = ld4_guard(z, (size_t)r * ch + c, valid, al);
+        const float4 a = ld4_guard(k1, c, valid, al), bb = ld4_guard(k2, c, valid, al), cc = ld4_guard(k3, c, valid, al);
+        v.x = fmaf(a.x, d.x, fmaf(bb.x, zz.x, cc.x));
+        v.y = valid > 1 ? fmaf(a.y, d.y, fmaf(bb.y, zz.y, cc.y)) : 0.f;
+        v.z = valid > 2 ? fmaf(a.z, d.z, fmaf(bb.z, zz.z, cc.z)) : 0.f;
+        v.w = valid > 3 ? fmaf(a.w, d.w, fmaf(bb.w, zz.w, cc.w)) : 0.f;
+        return v;
+    }
+};
+
+// weights W [co][ci] row-major
+struct WSrc {
+    const float *w;
+    int co, ci;
+    __device__ __forceinline__ float4 load_ci4(int o, int i) const  // 4 consecutive ci of row co=o
+    {
+        if (o >= co) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return ld4_guard(w, (size_t)o * ci + i, min(4, ci - i), (ci & 3) == 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// GEMM core
+// ------------------------------------------------------------------------------------------------
+template <int BM_, int BN_, int WR_, int WC_>
+struct Tile {
+    static constexpr int BM = BM_, BN = BN_, WR = WR_, WC = WC_;
+    static constexpr int THREADS = WR * WC * 64;
+    static constexpr int TM = BM / (WR * 32), TN = BN / (WC * 32);
+    static constexpr int LDA = BM + LPAD, LDB = BN + LPAD;
+    static constexpr int LDS_FLOATS = BK * (LDA + LDB);
+    static constexpr int A4 = (BM * BK / 4 + THREADS - 1) / THREADS;  // float4 per thread per chunk
+    static constexpr int B4 = (BN * BK / 4 + THREADS - 1) / THREADS;
+};
+
+// Stage one operand chunk from registers to LDS (k-major).  KC: v holds 4 consecutive k of one x.
+template <int BX, int LD, int N4, int THREADS, bool KC>
+__device__ __forceinline__ void stage_store(float *__restrict__ S, const float4 (&v)[N4], int tid)
+{
+#pragma unroll
+    for (int q = 0; q < N4; ++q) {
+        const int f = tid + q * THREADS;
+        if (f < BX * BK / 4) {
+            if (KC) {
+                const int x = f / (BK / 4), k4 = (f % (BK / 4)) * 4;
+                S[(k4 + 0) * LD + x] = v[q].x;
+                S[(k4 + 1) * LD + x] = v[q].y;
+                S[(k4 + 2) * LD + x] = v[q].z;
+                S[(k4 + 3) * LD + x] = v[q].w;
+            } else {
+                const int k = f / (BX / 4), x4 = (f % (BX / 4)) * 4;
+                *reinterpret_cast<float4 *>(&S[k * LD + x4]) = v[q];
+            }
+        }
+    }
+}
+
+// Fetch one K chunk of both operands into registers (float4 per thread, transformed by the loaders).
+template <class T, bool A_KC, bool B_KC, class FA, class FB>
+__device__ __forceinline__ void fetch_chunk(float4 (&ra)[T::A4], float4 (&rb)[T::B4], const FA &fa, const FB &fb, int k0,
+                                            int tid)
+{
+#pragma unroll
+    for (int q = 0; q < T::A4; ++q) {
+        const int f = tid + q * T::THREADS;
+        ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < T::BM * BK / 4) {
+            if (A_KC)
+                ra[q] = fa(f / (BK / 4), k0 + (f % (BK / 4)) * 4);
+            else
+                ra[q] = fa((f % (T::BM / 4)) * 4, k0 + f / (T::BM / 4));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < T::B4; ++q) {
+        const int f = tid + q * T::THREADS;
+        rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < T::BN * BK / 4) {
+            if (B_KC)
+                rb[q] = fb(f / (BK / 4), k0 + (f % (BK / 4)) * 4);
+            else
+                rb[q] = fb((f % (T::BN / 4)) * 4, k0 + f / (T::BN / 4));
+        }
+    }
+}
+
+// acc[tm][tn] += A(BM x K) . B(K x BN) for this block's tile.  fa(x, k) / fb(x, k) return float4 along the
+// operand's contiguous dimension (k for KC, x for XC); x is relative to the tile origin already applied by the caller.
+template <class T, bool A_KC, bool B_KC, class FA, class FB>
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[T::TM][T::TN], int K, const FA &fa, const FB &fb, float *lds)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    float *As = lds, *Bs = lds + BK * T::LDA;
+    float4 ra[T::A4], rb[T::B4];
+
+    fetch_chunk<T, A_KC, B_KC>(ra, rb, fa, fb, 0, tid);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        stage_store<T::BM, T::LDA, T::A4, T::THREADS, A_KC>(As, ra, tid);
+        stage_store<T::BN, T::LDB, T::B4, T::THREADS, B_KC>(Bs, rb, tid);
+        __syncthreads();
+        if (k0 + BK < K) fetch_chunk<T, A_KC, B_KC>(ra, rb, fa, fb, k0 + BK, tid);  // loads in flight under the MFMAs
+        const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[T::TM], b[T::TN];
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i) a[i] = As[(2 * s + h) * T::LDA + (wr * T::TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) b[j] = Bs[(2 * s + h) * T::LDB + (wc * T::TN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+}
+
+// C/D fragment coordinates of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// Deterministic per-column reduction of two per-lane partials over the block's rows:
+// halves of a wave (same column) -> wave rows in index order -> out0/out1[col] (valid for tid < BN).
+template <class T>
+__device__ __forceinline__ void column_reduce2(float (&p0)[T::TN], float (&p1)[T::TN], float *lds, float *out0,
+                                               float *out1, int col0, int ncols)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    float *red = lds;  // [WR][2][BN]
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const float s0 = p0[j] + __shfl_xor(p0[j], 32);
+        const float s1 = p1[j] + __shfl_xor(p1[j], 32);
+        if (lane < 32) {
+            const int c = (wc * T::TN + j) * 32 + lane;
+            red[(wr * 2 + 0) * T::BN + c] = s0;
+            red[(wr * 2 + 1) * T::BN + c] = s1;
+        }
+    }
+    __syncthreads();
+    if (tid < T::BN && col0 + tid < ncols) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < T::WR; ++r) {
+            a0 += red[(r * 2 + 0) * T::BN + tid];
+            a1 += red[(r * 2 + 1) * T::BN + tid];
+        }
+        out0[col0 + tid] = a0;
+        out1[col0 + tid] = a1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward:  Z[R][Co] = act(Ain)[R][Ci] . W^T + bias ; stats partial [gridDim.x][2][Co]
+// ------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    ActSrc a;
+    WSrc w;
+    const float *bias;
+    float *z;
+    float *stats;  // may be null
+};
+
+template <class T>
+__global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int row0 = blockIdx.x * T::BM, col0 = blockIdx.y * T::BN;
+    const int R = g.a.rows, Co = g.w.co, Ci = g.w.ci;
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const ActSrc a = g.a;
+    const WSrc w = g.w;
+    gemm_tile<T, true, true>(
+        acc, Ci, [&](int x, int k) { return a.load_c4(row0 + x, k); }, [&](int x, int k) { return w.load_ci4(col0 + x, k); },
+        lds);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    float s0[T::TN], s1[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
+        const float bias = (col < Co && g.bias) ? g.bias[col] : 0.f;
+        s0[j] = 0.f, s1[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
+                const float v = acc[i][j][e] + bias;
+                if (row < R && col < Co) {
+                    g.z[(size_t)row * Co + col] = v;
+                    s0[j] += v;
+                    s1[j] += v * v;
+                }
+            }
+    }
+    if (g.stats) {
+        float *st = g.stats + (size_t)blockIdx.x * 2 * Co;
+        column_reduce2<T>(s0, s1, lds, st, st + Co, col0, Co);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dgrad:  dYprev[R][Ci] = relu_mask_prev . ( dZ[R][Co] . W[Co][Ci] ) ; stats partial [gridDim.x][2][Ci]
+//         (sum dYprev, sum dYprev * Zprev).  prev.mode == ACT_NONE: plain store, no mask / stats.
+// ------------------------------------------------------------------------------------------------
+struct DgradArgs {
+    DzSrc dz;
+    WSrc w;
+    ActSrc prev;  // pre-BN activations + BN coefficients of the previous layer (for the ReLU mask)
+    float *dyprev;
+    float *stats;
+};
+
+template <class T>
+__global__ void __launch_bounds__(T::THREADS) linear_dgrad_kernel(DgradArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int row0 = blockIdx.x * T::BM, col0 = blockIdx.y * T::BN;
+    const int R = g.dz.rows, Co = g.w.co, Ci = g.w.ci;
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const DzSrc dz = g.dz;
+    const WSrc w = g.w;
+    // A: dZ rows, k = co contiguous.  B[k = co][x = ci]: W row-major is exactly [K][X], x contiguous.
+    gemm_tile<T, true, false>(
+        acc, Co, [&](int x, int k) { return dz.load_c4(row0 + x, k); }, [&](int x, int k) { return w.load_ci4(k, col0 + x); },
+        lds);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    const bool masked = g.prev.mode == ACT_BN_RELU;
+    float s0[T::TN], s1[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
+        float sc = 0.f, sh = 0.f;
+        if (masked && col < Ci) sc = g.prev.scale[col], sh = g.prev.shift[col];
+        s0[j] = 0.f, s1[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = row0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
+                if (row < R && col < Ci) {
+                    float v = acc[i][j][e];
+                    if (masked) {
+                        const float zp = g.prev.z[(size_t)row * Ci + col];
+                        v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
+                        s0[j] += v;
+                        s1[j] += v * zp;
+                    }
+                    g.dyprev[(size_t)row * Ci + col] = v;
+                }
+            }
+    }
+    if (masked && g.stats) {
+        float *st = g.stats + (size_t)blockIdx.x * 2 * Ci;
+        column_reduce2<T>(s0, s1, lds, st, st + Ci, col0, Ci);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad:  part[split][Co][Ci+1] = sum over the split's rows of dZ[r][co] * [act(prev)[r][ci] | 1]
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    DzSrc dz;
+    ActSrc prev;  // ch = Ci (storage stride); ones_col = Ci when the bias-gradient column is requested, else -1
+    float *part;
+    int rows_per_split;
+    int ncols;  // Ci + 1 with the bias column, Ci without
+};
+
+template <class T>
+__global__ void __launch_bounds__(T::THREADS) linear_wgrad_kernel(WgradArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int m0 = blockIdx.x * T::BM, n0 = blockIdx.y * T::BN;
+    const int Co = g.dz.ch, Ce = g.ncols;
+    const int r0 = blockIdx.z * g.rows_per_split;
+    const int r1 = min(g.dz.rows, r0 + g.rows_per_split);
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    DzSrc dz = g.dz;
+    ActSrc pv = g.prev;
+    dz.rows = r1;  // rows beyond the split read as zero
+    pv.rows = r1;
+    // both operands: source [K = r][X], x contiguous
+    gemm_tile<T, false, false>(
+        acc, max(0, r1 - r0), [&](int x, int k) { return dz.load_c4(r0 + k, m0 + x); },
+        [&](int x, int k) { return pv.load_c4(r0 + k, n0 + x); }, lds);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    float *P = g.part + (size_t)blockIdx.z * Co * Ce;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int col = n0 + (wc * T::TN + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
+                if (row < Co && col < Ce) P[(size_t)row * Ce + col] = acc[i][j][e];
+            }
+    }
+}
+
+// partials [nsplit][Co][Ce] -> dW [Co][Ci], db [Co] (Ce = Ci + 1).  64 elements x 4 split-slices per workgroup;
+// slices and the final 4-way sum run in a fixed order: deterministic.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(int nsplit, int Co, int Ci, int Ce, const float *__restrict__ part,
+                                                           float *__restrict__ dW, float *__restrict__ db)
+{
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const size_t stride = (size_t)Co * Ce;
+    float acc = 0.f;
+    if (e < Co * Ce) {
+        int s = sl;
+        for (; s + 12 < nsplit; s += 16)
+            acc += (part[(size_t)s * stride + e] + part[(size_t)(s + 4) * stride + e]) +
+                   (part[(size_t)(s + 8) * stride + e] + part[(size_t)(s + 12) * stride + e]);
+        for (; s < nsplit; s += 4) acc += part[(size_t)s * stride + e];
+    }
+    red[sl][el] = acc;
+    __syncthreads();
+    if (sl == 0 && e < Co * Ce) {
+        const float tot = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        const int o = e / Ce, i = e - o * Ce;
+        if (i < Ci)
+            dW[(size_t)o * Ci + i] = tot;
+        else if (db)
+            db[o] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping (tiny kernels, one thread per channel)
+// ------------------------------------------------------------------------------------------------
+// Sum the [nblk][2][C] partials of channel c over the workgroup's 8 slices (32 channels x 8 slices per workgroup),
+// in double, fixed order.  Returns true on the threads (slice 0) that hold the totals.
+__device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__restrict__ stats, double &s0, double &s1)
+{
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int b = sl; b < nblk; b += 8) {
+            a0 += (double)stats[((size_t)b * 2 + 0) * C + c];
+            a1 += (double)stats[((size_t)b * 2 + 1) * C + c];
+        }
+    red[0][sl][cl] = a0, red[1][sl][cl] = a1;
+    __syncthreads();
+    if (sl != 0 || c >= C) return false;
+    s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s0 += red[0][q][cl], s1 += red[1][q][cl];
+    return true;
+}
+
+// training: batch statistics from the forward partials -> coef [4][C] = scale, shift, mean, invstd;
+// running statistics updated as torch.nn.BatchNorm1d does (unbiased variance, momentum).
+__global__ void __launch_bounds__(256) bn_finalize_kernel(int nblk, int C, long long R, const float *__restrict__ stats,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, float momentum, float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var,
+                                                          long long *__restrict__ num_batches_tracked, float *__restrict__ coef)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    double s, ss;
+    if (!partial_sums(nblk, C, stats, s, ss)) return;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double mean = s / (double)R;
+    double var = ss / (double)R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    coef[c] = sc;
+    coef[C + c] = beta[c] - (float)mean * sc;
+    coef[2 * C + c] = (float)mean;
+    coef[3 * C + c] = invstd;
+    if (running_mean) {
+        const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval: coefficients from the running statistics
+__global__ void bn_eval_coef_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                    const float *__restrict__ running_mean, const float *__restrict__ running_var,
+                                    float *__restrict__ coef)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float sc = gamma[c] * invstd;
+    coef[c] = sc;
+    coef[C + c] = beta[c] - running_mean[c] * sc;
+    coef[2 * C + c] = running_mean[c];
+    coef[3 * C + c] = invstd;
+}
+
+// backward: partial (sum dY, sum dY*Z) -> dgamma, dbeta and the per-channel dZ coefficients
+//   dZ = scale * (dY - dbeta/R - zhat * dgamma/R),  zhat = (Z - mean) invstd
+//      = k1 dY + k2 Z + k3
+// dbias (gradient of the conv/linear bias in front of the BN) = sum_r dZ = k1 sum dY + k2 R mean + R k3 (== 0 up to rounding).
+__global__ void __launch_bounds__(256) bn_bwd_coef_kernel(int nblk, int C, long long R, const float *__restrict__ stats,
+                                                          const float *__restrict__ coef, float *__restrict__ dgamma,
+                                                          float *__restrict__ dbeta, float *__restrict__ dbias,
+                                                          float *__restrict__ kcoef)
+{
+    double s, sz;
+    if (!partial_sums(nblk, C, stats, s, sz)) return;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const double scale = coef[c], mean = coef[2 * C + c], invstd = coef[3 * C + c];
+    const double dg = invstd * (sz - mean * s);
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)s;
+    const double rinv = 1.0 / (double)R;
+    const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
+    const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
+    kcoef[c] = k1, kcoef[C + c] = k2, kcoef[2 * C + c] = k3;
+    if (dbias) dbias[c] = (float)((double)k1 * s + (double)k2 * (double)R * mean + (double)R * (double)k3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// max pooling over the points of each cloud, fused with BN + ReLU of the last conv layer
+//   pooled[b][c] = max_n relu(scale z + shift) = relu(scale * (scale >= 0 ? max_n z : min_n z) + shift)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) pool_fwd_kernel(int N, int C, const float *__restrict__ z,
+                                                        const float *__restrict__ coef, float *__restrict__ pooled,
+                                                        int *__restrict__ argsel, float *__restrict__ zsel)
+{
+    constexpr int NW = 16;
+    __shared__ float smax[NW][64], smin[NW][64];
+    __shared__ int amax[NW][64], amin[NW][64];
+    const int b = blockIdx.x, cl = threadIdx.x & 63, c = blockIdx.y * 64 + cl;
+    const int w = threadIdx.x >> 6;
+    float vmax = -INFINITY, vmin = INFINITY;
+    int imax = 0, imin = 0;
+    if (c < C) {
+        const float *zb = z + (size_t)b * N * C + c;
+        // wave w scans rows w, w+16, ... in ascending order: the first occurrence wins within the wave
+        int n = w;
+        for (; n + 3 * NW < N; n += 4 * NW) {
+            const float v0 = zb[(size_t)n * C], v1 = zb[(size_t)(n + NW) * C], v2 = zb[(size_t)(n + 2 * NW) * C],
+                        v3 = zb[(size_t)(n + 3 * NW) * C];
+            if (v0 > vmax) vmax = v0, imax = n;
+            if (v0 < vmin) vmin = v0, imin = n;
+            if (v1 > vmax) vmax = v1, imax = n + NW;
+            if (v1 < vmin) vmin = v1, imin = n + NW;
+            if (v2 > vmax) vmax = v2, imax = n + 2 * NW;
+            if (v2 < vmin) vmin = v2, imin = n + 2 * NW;
+            if (v3 > vmax) vmax = v3, imax = n + 3 * NW;
+            if (v3 < vmin) vmin = v3, imin = n + 3 * NW;
+        }
+        for (; n < N; n += NW) {
+            const float v = zb[(size_t)n * C];
+            if (v > vmax) vmax = v, imax = n;
+            if (v < vmin) vmin = v, imin = n;
+        }
+    }
+    smax[w][cl] = vmax, smin[w][cl] = vmin;
+    amax[w][cl] = imax, amin[w][cl] = imin;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        for (int q = 1; q < NW; ++q) {  // ties across waves: lowest row index
+            const float a = smax[q][cl], bb = smin[q][cl];
+            const int ia = amax[q][cl], ib = amin[q][cl];
+            if (a > vmax || (a == vmax && ia < imax)) vmax = a, imax = ia;
+            if (bb < vmin || (bb == vmin && ib < imin)) vmin = bb, imin = ib;
+        }
+        const float sc = coef[c], sh = coef[C + c];
+        const bool up = sc >= 0.f;
+        const float zs = up ? vmax : vmin;
+        pooled[(size_t)b * C + c] = fmaxf(fmaf(zs, sc, sh), 0.f);
+        argsel[(size_t)b * C + c] = up ? imax : imin;
+        zsel[(size_t)b * C + c] = zs;
+    }
+}
+
+// backward of the pooling: gsel = g * [pooled > 0]; BN-backward partial sums of the last conv layer
+// (one partial block: sum_b gsel, sum_b gsel * zsel), summed over b in ascending order.
+__global__ void pool_bwd_kernel(int B, int C, const float *__restrict__ g, const float *__restrict__ pooled,
+                                const float *__restrict__ zsel, float *__restrict__ gsel, float *__restrict__ stats)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, sz = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const size_t o = (size_t)b * C + c;
+        const float v = pooled[o] > 0.f ? g[o] : 0.f;
+        gsel[o] = v;
+        s += v;
+        sz += v * zsel[o];
+    }
+    stats[c] = s;
+    stats[C + c] = sz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------------
+using TileBig = Tile<128, 64, 4, 1>;    // R large: 128 rows x 64 cols per 256-thread workgroup
+using TileSmall = Tile<32, 128, 1, 4>;  // R small (FC head at small batch): 32 rows x 128 cols
+using TileW = Tile<64, 64, 2, 2>;       // weight gradient: Co x (Ci+1) output tile
+
+template <class T>
+static size_t lds_bytes()
+{
+    return sizeof(float) * std::max(T::LDS_FLOATS, T::WR * 2 * T::BN);
+}
+
+}  // namespace sn
+
+using namespace sn;
+
+static ActSrc make_act(const float *z, const float *coef, int rows, int ch, int ones_col = -1)
+{
+    ActSrc a{};
+    a.z = z, a.rows = rows, a.ch = ch, a.ones_col = ones_col;
+    a.mode = coef ? ACT_BN_RELU : ACT_NONE;
+    a.scale = coef, a.shift = coef ? coef + ch : nullptr;
+    return a;
+}
+
+extern "C" int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
+                                 const float *bias, float *z, float *stats, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(ain && W && z, "null pointer");
+    FwdArgs g{};
+    g.a = make_act(ain, coef_prev, R, Ci);
+    g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+    g.bias = bias, g.z = z, g.stats = stats;
+    hipStream_t st = (hipStream_t)stream;
+    if (R > 64) {
+        dim3 grid((R + TileBig::BM - 1) / TileBig::BM, (Co + TileBig::BN - 1) / TileBig::BN);
+        hipLaunchKernelGGL(linear_fwd_kernel<TileBig>, grid, dim3(TileBig::THREADS), lds_bytes<TileBig>(), st, g);
+    } else {
+        dim3 grid((R + TileSmall::BM - 1) / TileSmall::BM, (Co + TileSmall::BN - 1) / TileSmall::BN);
+        hipLaunchKernelGGL(linear_fwd_kernel<TileSmall>, grid, dim3(TileSmall::THREADS), lds_bytes<TileSmall>(), st, g);
+    }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_linear_stats_blocks(int R) { return R > 64 ? (R + TileBig::BM - 1) / TileBig::BM : (R + TileSmall::BM - 1) / TileSmall::BM; }
+
+static DzSrc make_dz(int mode, const float *dy, const float *z, const float *kcoef, const float *gsel, const int *argsel,
+                     int rows, int ch, int npts)
+{
+    DzSrc d{};
+    d.mode = mode, d.dy = dy, d.z = z, d.rows = rows, d.ch = ch, d.npts = npts > 0 ? npts : 1;
+    d.k1 = kcoef, d.k2 = kcoef ? kcoef + ch : nullptr, d.k3 = kcoef ? kcoef + 2 * ch : nullptr;
+    d.gsel = gsel, d.argsel = argsel;
+    return d;
+}
+
+extern "C" int sn_linear_dgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                               const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                               const float *coef_prev, float *dyprev, float *stats, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(W && dyprev, "null pointer");
+    DgradArgs g{};
+    g.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
+    g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+    g.prev = make_act(zprev, coef_prev, R, Ci);
+    g.dyprev = dyprev, g.stats = stats;
+    hipStream_t st = (hipStream_t)stream;
+    if (R > 64) {
+        dim3 grid((R + TileBig::BM - 1) / TileBig::BM, (Ci + TileBig::BN - 1) / TileBig::BN);
+        hipLaunchKernelGGL(linear_dgrad_kernel<TileBig>, grid, dim3(TileBig::THREADS), lds_bytes<TileBig>(), st, g);
+    } else {
+        dim3 grid((R + TileSmall::BM - 1) / TileSmall::BM, (Ci + TileSmall::BN - 1) / TileSmall::BN);
+        hipLaunchKernelGGL(linear_dgrad_kernel<TileSmall>, grid, dim3(TileSmall::THREADS), lds_bytes<TileSmall>(), st, g);
+    }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_linear_wgrad_splits(int R, int Ci, int Co, int with_bias)
+{
+    const int ncols = Ci + (with_bias ? 1 : 0);
+    const int tiles = ((Co + TileW::BM - 1) / TileW::BM) * ((ncols + TileW::BN - 1) / TileW::BN);
+    const int want = std::max(1, 512 / tiles);                       // aim at ~2 workgroups per CU
+    const int maxsplit = std::max(1, (R + 4 * BK - 1) / (4 * BK));   // at least 128 rows per split
+    return std::max(1, std::min(want, maxsplit));
+}
+
+// part: scratch of sn_linear_wgrad_splits(...) * Co * (Ci + with_bias) floats.  db may be NULL (no bias column).
+extern "C" int sn_linear_wgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                               const float *gsel, const int *argsel, int npts, const float *aprev,
+                               const float *coef_prev, float *part, float *dW, float *db, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(aprev && part && dW, "null pointer");
+    const int with_bias = db != nullptr;
+    WgradArgs g{};
+    g.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
+    g.prev = make_act(aprev, coef_prev, R, Ci, with_bias ? Ci : -1);
+    g.ncols = Ci + with_bias;
+    const int nsplit = sn_linear_wgrad_splits(R, Ci, Co, with_bias);
+    int rps = (R + nsplit - 1) / nsplit;
+    rps = ((rps + BK - 1) / BK) * BK;
+    g.rows_per_split = rps;
+    g.part = part;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((Co + TileW::BM - 1) / TileW::BM, (g.ncols + TileW::BN - 1) / TileW::BN, nsplit);
+    hipLaunchKernelGGL(linear_wgrad_kernel<TileW>, grid, dim3(TileW::THREADS), lds_bytes<TileW>(), st, g);
+    const int tot = Co * g.ncols;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, st, nsplit, Co, Ci, g.ncols, part, dW, db);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,
+                              float eps, float momentum, float *running_mean, float *running_var,
+                              long long *num_batches_tracked, float *coef, sn_stream_t stream)
+{
+    SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && gamma && beta && coef, "bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, nblk, C, R, stats, gamma,
+                       beta, eps, momentum, running_mean, running_var, num_batches_tracked, coef);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_bn_eval_coef(int C, const float *gamma, const float *beta, float eps, const float *running_mean,
+                               const float *running_var, float *coef, sn_stream_t stream)
+{
+    SN_REQUIRE(C >= 1 && gamma && beta && running_mean && running_var && coef, "bad argument");
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, C, gamma, beta, eps,
+                       running_mean, running_var, coef);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_bn_backward_coef(int nblk, int C, long long R, const float *stats, const float *coef, float *dgamma,
+                                   float *dbeta, float *dbias, float *kcoef, sn_stream_t stream)
+{
+    SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && coef && dgamma && dbeta && kcoef, "bad argument");
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, nblk, C, R, stats, coef,
+                       dgamma, dbeta, dbias, kcoef);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_pool_forward(int B, int N, int C, const float *z, const float *coef, float *pooled, int *argsel,
+                               float *zsel, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && C >= 1 && z && coef && pooled && argsel && zsel, "bad argument");
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(B, (C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, N, C, z, coef, pooled,
+                       argsel, zsel);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_pool_backward(int B, int C, const float *g, const float *pooled, const float *zsel, float *gsel,
+                                float *stats, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && C >= 1 && g && pooled && zsel && gsel && stats, "bad argument");
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, C, g, pooled, zsel, gsel,
+                       stats);
+    SN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,66 @@
+"""Whole-step execution of the sampler's training step as ONE hipGraph.
+
+At the reference's batch size (B = 32) the step is a chain of ~70 short kernels; launched one by one from
+Python it is host-bound (a few microseconds of launch path per kernel, tens of microseconds of Python per op).
+`SamplerTrainStep` captures   forward -> losses -> backward   once (torch.cuda.CUDAGraph: the ctypes-launched HIP
+kernels are recorded like any other work on the capturing stream) and replays it per batch; inputs are copied
+into a static buffer, gradients land in static tensors (or in the flat all-reduce bucket).
+
+The loss is the one registration/main.py:507-531 builds for the sampler:
+    alpha * simplification_loss + lmbda * projection_loss + task_loss(proj)
+with `task_loss` a callable (default: mean of the projected points -- the stand-in SURVEY.md 8d prescribes
+for the benchmark so that the projection branch receives gradient).
+"""
+import torch
+
+
+class SamplerTrainStep:
+    def __init__(self, net, example_x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=None, reducer=None,
+                 use_graph=True, warmup=3):
+        self.net, self.reducer = net, reducer
+        self.alpha, self.lmbda, self.gamma, self.delta = alpha, lmbda, gamma, delta
+        self.task_loss = task_loss if task_loss is not None else (lambda proj: proj.mean())
+        self.x = example_x.clone()
+        self.graph = None
+        self.loss = None
+        if use_graph:
+            self._capture(warmup)
+
+    def _step(self):
+        net, x = self.net, self.x
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        simp, proj = net(x)
+        loss = (self.alpha * net.get_simplification_loss(x, simp, net.num_out_points, self.gamma, self.delta)
+                + self.lmbda * net.get_projection_loss() + self.task_loss(proj))
+        loss.backward()
+        return loss.detach()
+
+    def _capture(self, warmup):
+        if self.reducer is None:
+            for p in self.net.parameters():
+                p.grad = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step()
+                if self.reducer is None:
+                    for p in self.net.parameters():
+                        p.grad = None
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._step()
+
+    def __call__(self, x):
+        """Runs one step on batch x (same shape as example_x); returns the (static) loss tensor.
+        Gradients are in p.grad afterwards (cross-rank averaged when a reducer is attached)."""
+        self.x.copy_(x, non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.loss = self._step()
+        if self.reducer is not None:
+            self.reducer.reduce()
+        return self.loss

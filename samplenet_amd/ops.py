@@ -166,7 +166,7 @@ grouping_operation = GroupingOperationFunction.apply
 def _dsigma_dT(temperature, min_sigma):
     """d max(T^2, min_sigma) / dT, with torch.max's even split on an exact tie."""
     t2 = temperature.detach() ** 2
-    ms = torch.as_tensor(min_sigma, device=temperature.device, dtype=torch.float32)
+    ms = float(min_sigma)  # python scalar: no host->device copy (keeps the step capturable into a hipGraph)
     w = (t2 > ms).float() + 0.5 * (t2 == ms).float()
     return w * 2.0 * temperature.detach()
 

@@ -17,41 +17,54 @@ import torch.distributed as dist
 
 
 class FlatGradAllReducer:
-    """Keeps every parameter's .grad as a view into one flat fp32 buffer and averages it across ranks."""
+    """Keeps every parameter's .grad as a view into one flat fp32 buffer and averages it across ranks.
 
-    def __init__(self, module, process_group=None, overlap=True, early_prefixes=("fc", "bn_fc")):
+    The MLP gradients are WRITTEN into the views by the HIP backward kernels themselves (module._grad_sink), so
+    there is no per-parameter accumulate / copy kernel; only the temperature goes through autograd's accumulate
+    and is zeroed by zero_grad().  Layout: [FC head | temperature | conv stack] -- the first segment is complete
+    before the conv stack's backward starts.
+    """
+
+    def __init__(self, module, process_group=None, overlap=True):
+        self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
-        # early segment first: parameters whose gradients are produced first in backward (the FC head)
-        early = [(n, p) for n, p in named if n.startswith(tuple(early_prefixes)) or n.startswith("project")]
-        late = [(n, p) for n, p in named if (n, p) not in early]
-        self.params = [p for _, p in early + late]
-        self.n_early = sum(p.numel() for _, p in early)
-        total = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
+        early = [(n, p) for n, p in named if n.startswith(("fc", "bn_fc"))]
+        other = [(n, p) for n, p in named if n.startswith("project")]
+        late = [(n, p) for n, p in named if (n, p) not in early and (n, p) not in other]
+        order = early + other + late
+        self.n_early = sum(p.numel() for _, p in early + other)
+        total = sum(p.numel() for _, p in order)
+        dev = order[0][1].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+        sink, off = {}, 0
+        self._autograd_slices = []
+        for n, p in order:
+            view = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = view
+            if n.startswith("project"):
+                self._autograd_slices.append(view)
+            else:
+                sink[n] = view
             off += p.numel()
-        self.overlap = overlap and self.world > 1 and dev.type == "cuda" and 0 < self.n_early < total
+        if getattr(module, "use_hip_mlp", False):
+            module._grad_sink = sink
+        else:  # torch MLP: every gradient arrives through autograd's accumulate
+            self._autograd_slices = [self.flat]
+        self.overlap = bool(overlap and self.world > 1 and dev.type == "cuda" and getattr(module, "use_hip_mlp", False))
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self._early_work = None
-        self._hook_handles = []
         if self.overlap:
-            # fire the early all-reduce once the last early-segment gradient has been accumulated:
-            # in backward order that is fc1 (its hook runs before the conv stack's backward is queued)
-            first_layer = [p for n, p in early if n.startswith("fc1.weight")]
-            if first_layer:
-                self._hook_handles.append(first_layer[0].register_post_accumulate_grad_hook(self._early_ready))
-            else:
-                self.overlap = False
+            module._after_fc_grads = self._early_ready
 
     def zero_grad(self):
-        self.flat.zero_()
+        for v in self._autograd_slices:
+            v.zero_()
 
-    def _early_ready(self, _param):
+    def _early_ready(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
         cur = torch.cuda.current_stream()
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
@@ -61,7 +74,7 @@ class FlatGradAllReducer:
         """Call after backward(): on return (stream-ordered) every .grad holds the cross-rank mean."""
         if self.world == 1:
             return
-        if self.overlap and self._early_work is not None:
+        if self._early_work is not None:
             dist.all_reduce(self.flat[self.n_early:], group=self.group)
             self._early_work.wait()
             torch.cuda.current_stream().wait_stream(self._side)

@@ -1,0 +1,232 @@
+"""PointNet feature extractor + FC head of SampleNet on the hand-written MFMA kernels
+(samplenet_amd/csrc/pointnet_mlp.hip), as ONE autograd node.
+
+Replaces the torch.nn call chain of registration/src/samplenet.py:90-104
+    5 x relu(bn(conv1d_k1(.)))  ->  max over points  ->  3 x relu(bn(linear(.)))  ->  linear
+while the parameters stay ordinary nn.Conv1d / nn.BatchNorm1d / nn.Linear members of the module
+(state_dict compatibility).  Host side: buffer allocation and launch sequencing only.
+"""
+import torch
+
+from ._lib import check, lib, ptr
+
+DZ_PLAIN, DZ_BN, DZ_POOL = 0, 1, 2
+
+
+def _st(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+class _Layer:
+    """Plain record of one GEMM layer's tensors."""
+
+    __slots__ = ("W", "b", "bn", "Ci", "Co")
+
+    def __init__(self, lin, bn):
+        self.W, self.b, self.bn = lin.weight, lin.bias, bn
+        self.Co, self.Ci = lin.weight.shape[0], lin.weight.shape[1]
+
+
+def _layers(net):
+    convs = [_Layer(net.conv1, net.bn1), _Layer(net.conv2, net.bn2), _Layer(net.conv3, net.bn3),
+             _Layer(net.conv4, net.bn4), _Layer(net.conv5, net.bn5)]
+    fcs = [_Layer(net.fc1, net.bn_fc1), _Layer(net.fc2, net.bn_fc2), _Layer(net.fc3, net.bn_fc3), _Layer(net.fc4, None)]
+    return convs, fcs
+
+
+def _linear_fwd(R, L, a_in, coef_prev, want_stats):
+    z = _empty((R, L.Co), a_in)
+    nblk = lib.sn_linear_stats_blocks(R)
+    stats = _empty((nblk, 2, L.Co), a_in) if want_stats else None
+    check(lib.sn_linear_forward(R, L.Ci, L.Co, ptr(a_in), ptr(coef_prev), ptr(L.W), ptr(L.b), ptr(z), ptr(stats), _st(a_in)),
+          "sn_linear_forward")
+    return z, stats, nblk
+
+
+def _bn_coef(L, R, stats, nblk, training):
+    bn = L.bn
+    C = L.Co
+    coef = _empty((4, C), L.W)
+    if training or not bn.track_running_stats:
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        upd = training and bn.track_running_stats
+        check(lib.sn_bn_finalize(nblk, C, R, ptr(stats), ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(mom),
+                                 ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None,
+                                 ptr(bn.num_batches_tracked) if upd else None, ptr(coef), _st(L.W)), "sn_bn_finalize")
+    else:
+        check(lib.sn_bn_eval_coef(C, ptr(bn.weight), ptr(bn.bias), float(bn.eps), ptr(bn.running_mean), ptr(bn.running_var),
+                                  ptr(coef), _st(L.W)), "sn_bn_eval_coef")
+    return coef
+
+
+def forward_impl(net, x_bnc, training):
+    """x (B,N,3) contiguous -> y (B, 3*M) and the tensors backward needs."""
+    convs, fcs = _layers(net)
+    B, N, _ = x_bnc.shape
+    R = B * N
+    saved = {"x": x_bnc, "B": B, "N": N, "zc": [], "cc": [], "zf": [], "cf": []}
+    use_batch_stats = training
+    a_in, coef_prev = x_bnc.view(R, 3), None
+    for L in convs:
+        z, stats, nblk = _linear_fwd(R, L, a_in, coef_prev, use_batch_stats)
+        coef = _bn_coef(L, R, stats, nblk, training)
+        saved["zc"].append(z)
+        saved["cc"].append(coef)
+        a_in, coef_prev = z, coef
+    C5 = convs[-1].Co
+    pooled = _empty((B, C5), x_bnc)
+    argsel = _empty((B, C5), x_bnc, torch.int32)
+    zsel = _empty((B, C5), x_bnc)
+    check(lib.sn_pool_forward(B, N, C5, ptr(a_in), ptr(coef_prev), ptr(pooled), ptr(argsel), ptr(zsel), _st(x_bnc)),
+          "sn_pool_forward")
+    saved.update(pooled=pooled, argsel=argsel, zsel=zsel)
+    a_in, coef_prev = pooled, None
+    for L in fcs[:-1]:
+        z, stats, nblk = _linear_fwd(B, L, a_in, coef_prev, use_batch_stats)
+        coef = _bn_coef(L, B, stats, nblk, training)
+        saved["zf"].append(z)
+        saved["cf"].append(coef)
+        a_in, coef_prev = z, coef
+    y, _, _ = _linear_fwd(B, fcs[-1], a_in, coef_prev, False)
+    return y, saved
+
+
+def _out(sink, name, like):
+    """Gradient destination: the caller-provided sink tensor (e.g. a view of a flat all-reduce bucket) or a fresh one."""
+    if sink is not None and name in sink:
+        return sink[name]
+    return torch.empty_like(like)
+
+
+def _wgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, aprev, coef_prev, with_bias, sink=None, name=""):
+    dW = _out(sink, name + ".weight", L.W)
+    db = _out(sink, name + ".bias", L.b) if with_bias else None
+    nsplit = lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 1 if with_bias else 0)
+    part = _empty((nsplit * L.Co * (L.Ci + (1 if with_bias else 0)),), L.W)
+    check(lib.sn_linear_wgrad(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(aprev),
+                              ptr(coef_prev), ptr(part), ptr(dW), ptr(db), _st(L.W)), "sn_linear_wgrad")
+    return dW, db
+
+
+def _dgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev):
+    dyprev = _empty((R, L.Ci), L.W)
+    nblk = lib.sn_linear_stats_blocks(R)
+    stats = _empty((nblk, 2, L.Ci), L.W) if coef_prev is not None else None
+    check(lib.sn_linear_dgrad(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(L.W),
+                              ptr(zprev), ptr(coef_prev), ptr(dyprev), ptr(stats), _st(L.W)), "sn_linear_dgrad")
+    return dyprev, stats, nblk
+
+
+def _bn_bwd(L, R, stats, nblk, coef, sink=None, bn_name="", lin_name=""):
+    C = L.Co
+    dgamma, dbeta = _out(sink, bn_name + ".weight", L.bn.weight), _out(sink, bn_name + ".bias", L.bn.bias)
+    dbias = _out(sink, lin_name + ".bias", L.b)
+    kcoef = _empty((3, C), L.W)
+    check(lib.sn_bn_backward_coef(nblk, C, R, ptr(stats), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(kcoef),
+                                  _st(L.W)), "sn_bn_backward_coef")
+    return dgamma, dbeta, dbias, kcoef
+
+
+def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
+    """-> dict parameter-name -> gradient tensor (every parameter of the MLP).
+    sink: optional dict name -> preallocated tensor the gradient is written into (overwritten, not accumulated).
+    after_fc: optional callback invoked once all FC-head gradients have been enqueued (DP overlap point)."""
+    convs, fcs = _layers(net)
+    names_c = ["conv1", "conv2", "conv3", "conv4", "conv5"]
+    bn_c = ["bn1", "bn2", "bn3", "bn4", "bn5"]
+    names_f = ["fc1", "fc2", "fc3", "fc4"]
+    bn_f = ["bn_fc1", "bn_fc2", "bn_fc3"]
+    B, N = saved["B"], saved["N"]
+    R = B * N
+    grads = {}
+    grad_y = grad_y.contiguous()
+    zf, cf, zc, cc = saved["zf"], saved["cf"], saved["zc"], saved["cc"]
+
+    # ---- FC head (rows = B) ----
+    L = fcs[3]
+    dW, db = _wgrad(B, L, DZ_PLAIN, grad_y, None, None, None, None, 1, zf[2], cf[2], True, sink, "fc4")
+    grads["fc4.weight"], grads["fc4.bias"] = dW, db
+    dy, stats, nblk = _dgrad(B, L, DZ_PLAIN, grad_y, None, None, None, None, 1, zf[2], cf[2])
+    for j in (2, 1, 0):
+        L = fcs[j]
+        dgamma, dbeta, dbias, kcoef = _bn_bwd(L, B, stats, nblk, cf[j], sink, bn_f[j], names_f[j])
+        grads[bn_f[j] + ".weight"], grads[bn_f[j] + ".bias"], grads[names_f[j] + ".bias"] = dgamma, dbeta, dbias
+        aprev, cprev = (zf[j - 1], cf[j - 1]) if j > 0 else (saved["pooled"], None)
+        dW, _ = _wgrad(B, L, DZ_BN, dy, zf[j], kcoef, None, None, 1, aprev, cprev, False, sink, names_f[j])
+        grads[names_f[j] + ".weight"] = dW
+        dy, stats, nblk = _dgrad(B, L, DZ_BN, dy, zf[j], kcoef, None, None, 1, aprev, cprev)
+    g_pool = dy  # (B, C5): gradient w.r.t. the pooled features
+    if after_fc is not None:
+        after_fc()
+
+    # ---- max-pool + last conv layer's BatchNorm ----
+    C5 = convs[4].Co
+    gsel = _empty((B, C5), grad_y)
+    stats = _empty((1, 2, C5), grad_y)
+    check(lib.sn_pool_backward(B, C5, ptr(g_pool), ptr(saved["pooled"]), ptr(saved["zsel"]), ptr(gsel), ptr(stats),
+                               _st(grad_y)), "sn_pool_backward")
+    nblk = 1
+    # ---- conv stack (rows = B*N) ----
+    dy = None
+    for i in (4, 3, 2, 1, 0):
+        L = convs[i]
+        dgamma, dbeta, dbias, kcoef = _bn_bwd(L, R, stats, nblk, cc[i], sink, bn_c[i], names_c[i])
+        grads[bn_c[i] + ".weight"], grads[bn_c[i] + ".bias"], grads[names_c[i] + ".bias"] = dgamma, dbeta, dbias
+        mode = DZ_POOL if i == 4 else DZ_BN
+        gs, ag = (gsel, saved["argsel"]) if i == 4 else (None, None)
+        aprev, cprev = (zc[i - 1], cc[i - 1]) if i > 0 else (saved["x"].view(R, 3), None)
+        dW, _ = _wgrad(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev, False, sink, names_c[i])
+        grads[names_c[i] + ".weight"] = dW
+        if i > 0:
+            dy, stats, nblk = _dgrad(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev)
+    return grads
+
+
+PARAM_ORDER = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv3.weight", "conv3.bias",
+               "conv4.weight", "conv4.bias", "conv5.weight", "conv5.bias",
+               "bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias", "bn3.weight", "bn3.bias", "bn4.weight", "bn4.bias",
+               "bn5.weight", "bn5.bias",
+               "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias",
+               "bn_fc1.weight", "bn_fc1.bias", "bn_fc2.weight", "bn_fc2.bias", "bn_fc3.weight", "bn_fc3.bias"]
+
+
+class PointNetMLPFunction(torch.autograd.Function):
+    """y (B, 3M) = head(x (B,N,3)); differentiable w.r.t. all 34 parameter tensors (x is data: no gradient)."""
+
+    @staticmethod
+    def forward(ctx, net, x_bnc, training, *params):
+        with torch.cuda.device(x_bnc.device):
+            y, saved = forward_impl(net, x_bnc, training)
+        ctx.net, ctx.saved = net, saved
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        net = ctx.net
+        sink = getattr(net, "_grad_sink", None)
+        with torch.cuda.device(grad_y.device):
+            grads = backward_impl(net, ctx.saved, grad_y, sink, getattr(net, "_after_fc_grads", None))
+        ctx.saved = None
+        # gradients written straight into a sink are not handed to autograd (nothing left to accumulate)
+        return (None, None, None) + tuple(None if (sink is not None and n in sink) else grads[n] for n in PARAM_ORDER)
+
+
+def pointnet_head(net, x_bnc):
+    """x (B,N,3) float32 CUDA -> y (B, 3, M) exactly as samplenet.py:90-104 produces it."""
+    if not x_bnc.is_cuda:
+        raise RuntimeError("samplenet_amd.pointnet runs on the GPU only; no CPU fallback exists")
+    if x_bnc.dtype != torch.float32:
+        raise TypeError("expected float32")
+    x_bnc = x_bnc.contiguous()
+    sd = dict(net.named_parameters())
+    params = [sd[n] for n in PARAM_ORDER]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        y = PointNetMLPFunction.apply(net, x_bnc, net.training, *params)
+    else:
+        with torch.cuda.device(x_bnc.device):
+            y, _ = forward_impl(net, x_bnc, net.training)
+    return y.view(-1, 3, net.num_out_points)

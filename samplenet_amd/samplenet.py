@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops, sputils
+from . import ops, pointnet, sputils
 from .chamfer_distance import ChamferDistance
 from .soft_projection import SoftProjection
 
@@ -37,8 +37,12 @@ class SampleNet(nn.Module):
         output_shape="bcn",
         complete_fps=True,
         skip_projection=False,
+        use_hip_mlp=True,
     ):
         super().__init__()
+        # use_hip_mlp=False routes the feature extractor through torch.nn (MIOpen / rocBLAS); it exists for
+        # A/B parity tests of the hand-written MFMA kernels -- the geometric ops are on HIP either way.
+        self.use_hip_mlp = use_hip_mlp
         self.num_out_points = num_out_points
         self.name = "samplenet"
 
@@ -80,8 +84,12 @@ class SampleNet(nn.Module):
         self._scan = None  # Chamfer products of the last training forward (see get_simplification_loss)
 
     # ------------------------------------------------------------------------------------------ MLP
-    def _features(self, x):
+    def _features(self, x, x_bnc=None):
         """PointNet feature extractor + FC head: x (B,3,N) -> y (B,3,M)   (samplenet.py:90-104)."""
+        if self.use_hip_mlp:
+            if x_bnc is None:
+                x_bnc = x.permute(0, 2, 1)
+            return pointnet.pointnet_head(self, x_bnc)
         y = F.relu(self.bn1(self.conv1(x)))
         y = F.relu(self.bn2(self.conv2(y)))
         y = F.relu(self.bn3(self.conv3(y)))
@@ -102,7 +110,7 @@ class SampleNet(nn.Module):
         if x.shape[1] != 3:
             raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
 
-        y = self._features(x)
+        y = self._features(x, x_in if self.input_shape == "bnc" else None)
         simp = y
         match = None
         proj = None

@@ -25,8 +25,9 @@ class SoftProjection(nn.Module):
         self._group_size = group_size
         self._temperature = torch.nn.Parameter(
             torch.tensor(initial_temperature, requires_grad=is_temperature_trainable, dtype=torch.float32))
-        self._min_sigma = torch.tensor(min_sigma, dtype=torch.float32)
+        self._min_sigma = torch.tensor(min_sigma, dtype=torch.float32)  # plain attribute, as in the reference
         self._min_sigma_f = float(min_sigma)
+        self._min_sigma_dev = {}  # per-device copies (the reference re-uploads it on every call)
 
     def forward(self, point_cloud, query_cloud, point_features=None, action="project"):
         point_cloud = point_cloud.contiguous()
@@ -43,7 +44,11 @@ class SoftProjection(nn.Module):
 
     def sigma(self):
         device = self._temperature.device
-        return torch.max(self._temperature ** 2, self._min_sigma.to(device))
+        ms = self._min_sigma_dev.get(device)
+        if ms is None:
+            ms = self._min_sigma.to(device)
+            self._min_sigma_dev[device] = ms
+        return torch.max(self._temperature ** 2, ms)
 
     # -- fused hot path -------------------------------------------------------------------------
     def project(self, point_cloud, query_cloud, hard=False):

@@ -1,0 +1,114 @@
+"""GPU parity of the hand-written MFMA PointNet MLP (samplenet_amd/csrc/pointnet_mlp.hip) against the plain
+PyTorch fp32 modules of the same network (the reference's own op chain, samplenet.py:90-104) on the same
+weights and inputs: outputs, BatchNorm running statistics, and the gradient of every parameter."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(B, N, M, K, bneck, shape, seed=0):
+    from samplenet_amd import SampleNet
+
+    torch.manual_seed(seed)
+    hip = SampleNet(M, bneck, group_size=K, input_shape=shape, output_shape=shape, use_hip_mlp=True).cuda()
+    with torch.no_grad():
+        for n, p in hip.named_parameters():
+            if "bn" in n:
+                p.add_(0.2 * torch.randn_like(p))
+        hip.bn3.weight[:5] *= -1.0  # negative BatchNorm scale: the fused max-pool must then select the minimum
+        hip.bn5.weight[:7] *= -1.0
+    ref = copy.deepcopy(hip)
+    ref.use_hip_mlp = False
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    if shape == "bcn":
+        x = x.permute(0, 2, 1).contiguous()
+    return hip, ref, x
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+CFGS = [(4, 1024, 64, 8, 128, "bnc"), (3, 96, 12, 5, 32, "bcn"), (32, 1024, 64, 8, 128, "bnc"), (6, 130, 7, 4, 40, "bnc"),
+        (70, 64, 16, 4, 128, "bnc")]
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_mlp_forward_backward_vs_torch(cfg):
+    B, N, M, K, bneck, shape = cfg
+    hip, ref, x = _pair(*cfg)
+    hip.train(), ref.train()
+    y_h = hip._features(x if shape == "bcn" else x.permute(0, 2, 1), x if shape == "bnc" else None)
+    y_r = ref._features(x if shape == "bcn" else x.permute(0, 2, 1))
+    assert y_h.shape == y_r.shape == (B, 3, M)
+    # small-batch BatchNorm in the FC head amplifies fp32 summation-order noise (2e-4 relative at B=3..4, 6e-5 at B=32)
+    assert _rel(y_h.detach(), y_r.detach()) < 3e-4
+    g = torch.randn_like(y_r)
+    (y_h * g).sum().backward()
+    (y_r * g).sum().backward()
+    for (n, ph), (_, pr) in zip(hip.named_parameters(), ref.named_parameters()):
+        if n.startswith("project"):
+            continue
+        nr = float(pr.grad.double().norm())
+        err = float((ph.grad.double() - pr.grad.double()).norm())
+        if (n.endswith(".bias") and not n.startswith(("bn", "fc4"))) or n == "bn5.bias":
+            # a bias in front of a BatchNorm: the true gradient is exactly 0; both sides hold rounding noise.
+            # bn5.bias likewise: it is sum_b of the pooled-feature gradient, which the batch-BatchNorm of fc1
+            # makes sum to zero over the batch wherever the pooled feature is positive.
+            wn = float(dict(ref.named_parameters())[n.replace(".bias", ".weight")].grad.double().norm())
+            assert float(ph.grad.double().norm()) <= 1e-3 * wn + 1e-6 and nr <= 1e-3 * wn + 1e-6, (n, err, nr, wn)
+        else:
+            assert err <= 2e-3 * nr, (n, err / nr)
+    for (n, bh), (_, br) in zip(hip.named_buffers(), ref.named_buffers()):
+        if bh.dtype == torch.long:
+            assert int(bh) == int(br) == 1, n
+        else:
+            assert torch.allclose(bh, br, rtol=1e-4, atol=1e-5), n
+
+
+def test_mlp_eval_mode_vs_torch():
+    hip, ref, x = _pair(5, 256, 16, 4, 64, "bnc")
+    for net in (hip, ref):
+        net.train()
+        with torch.no_grad():
+            net._features(x.permute(0, 2, 1), x if net.use_hip_mlp else None)  # populate running statistics
+        net.eval()
+    with torch.no_grad():
+        y_h = hip._features(x.permute(0, 2, 1), x)
+        y_r = ref._features(x.permute(0, 2, 1))
+    assert _rel(y_h, y_r) < 1e-4
+
+
+def test_linear_kernels_exact_small_integers():
+    """MFMA fragment / tile indexing check that is transpose-detecting: small-integer operands make every
+    product and sum exact in fp32, so the three GEMM kernels must match an integer reference bit-for-bit."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    st = torch.cuda.current_stream().cuda_stream
+    for (R, Ci, Co) in [(300, 24, 40), (32, 128, 256), (1000, 3, 64), (129, 64, 128), (64, 256, 36)]:
+        A = torch.randint(-4, 5, (R, Ci), device="cuda", generator=g).float()
+        W = torch.randint(-4, 5, (Co, Ci), device="cuda", generator=g).float()
+        b = torch.randint(-4, 5, (Co,), device="cuda", generator=g).float()
+        Z = torch.empty(R, Co, device="cuda")
+        nblk = lib.sn_linear_stats_blocks(R)
+        stats = torch.empty(nblk, 2, Co, device="cuda")
+        check(lib.sn_linear_forward(R, Ci, Co, ptr(A), None, ptr(W), ptr(b), ptr(Z), ptr(stats), st))
+        Zr = A.double() @ W.double().t() + b.double()
+        assert torch.equal(Z.double(), Zr), (R, Ci, Co)
+        assert torch.equal(stats.double().sum(0)[0], Zr.sum(0)) and torch.equal(stats.double().sum(0)[1], (Zr * Zr).sum(0))
+        dZ = torch.randint(-3, 4, (R, Co), device="cuda", generator=g).float()
+        dA = torch.empty(R, Ci, device="cuda")
+        check(lib.sn_linear_dgrad(R, Ci, Co, 0, ptr(dZ), None, None, None, None, 1, ptr(W), None, None, ptr(dA), None, st))
+        assert torch.equal(dA.double(), dZ.double() @ W.double())
+        ns = lib.sn_linear_wgrad_splits(R, Ci, Co, 1)
+        part = torch.empty(ns * Co * (Ci + 1), device="cuda")
+        dW, db = torch.empty(Co, Ci, device="cuda"), torch.empty(Co, device="cuda")
+        check(lib.sn_linear_wgrad(R, Ci, Co, 0, ptr(dZ), None, None, None, None, 1, ptr(A), None, ptr(part), ptr(dW), ptr(db), st))
+        assert torch.equal(dW.double(), dZ.double().t() @ A.double())
+        assert torch.equal(db.double(), dZ.double().sum(0))
