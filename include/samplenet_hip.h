@@ -68,6 +68,18 @@ int sn_pairscan_forward(int B, int N, int M, int K,
                         const float *temperature, float min_sigma,
                         sn_stream_t stream);
 
+/* Same, with caller-owned scratch (sn_pairscan_workspace_bytes(B,N,M) bytes): lets the queries of one cloud be
+ * spread over several workgroups even when the per-point minima (dist_p / idx_p) are requested -- at the
+ * reference's batch of 32 clouds that is what fills the 256 CUs.  workspace == NULL behaves like sn_pairscan_forward. */
+long long sn_pairscan_workspace_bytes(int B, int N, int M);
+int sn_pairscan_forward_ws(int B, int N, int M, int K,
+                           const float *P, int p_layout, const float *Q, int q_layout,
+                           int *knn_idx, float *knn_dist,
+                           float *dist_q, int *idx_q, float *dist_p, int *idx_p,
+                           float *proj, int proj_layout, float *weights,
+                           const float *temperature, float min_sigma,
+                           void *workspace, long long workspace_bytes, sn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Chamfer / nn_distance with the reference launcher signatures.
  * Replaces ChamferDistanceKernelLauncher / ChamferDistanceGradKernelLauncher
@@ -85,6 +97,21 @@ int sn_chamfer_backward(int b, int n, const float *xyz1, int m, const float *xyz
                         const float *grad_dist1, const int *idx1,
                         const float *grad_dist2, const int *idx2,
                         float *grad_xyz1, float *grad_xyz2, sn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused simplification loss of the sampler (registration/src/samplenet.py:171-181; TF twin
+ * classification/models/samplenet_model.py:176-188):
+ *     loss = mean(dist1) + mean_b(max_m dist1[b,m]) + weight * mean(dist2),   weight = gamma + delta * pc_size
+ * dist1 (B,n1) / dist2 (B,n2) are the Chamfer products of (xyz1 = sampled cloud, xyz2 = reference cloud).
+ * forward: partial (B*3 floats) and argmax1 (B ints) are caller-owned scratch kept for backward; loss: 1 float.
+ * backward: grad_loss is a DEVICE scalar; writes grad_xyz1 (B,n1,3) / grad_xyz2 (B,n2,3) (either may be NULL) without
+ * materialising per-point gradient tensors.  Replaces ~10 elementwise/reduction launches + the Chamfer backward.
+ * ------------------------------------------------------------------------------------------- */
+int sn_simplification_loss_forward(int B, int n1, int n2, const float *dist1, const float *dist2, float weight,
+                                   float *partial, int *argmax1, float *loss, sn_stream_t stream);
+int sn_simplification_loss_backward(int B, int n1, const float *xyz1, int n2, const float *xyz2, const int *idx1,
+                                    const int *idx2, const int *argmax1, float weight, const float *grad_loss,
+                                    float *grad_xyz1, float *grad_xyz2, sn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.
@@ -122,8 +149,10 @@ int sn_grouping_operation_grad(int b, int c, int n, int m, int nsample, const fl
  *                                grad_X (b,c,n) [ACCUMULATED with atomics, may be NULL]
  *   sn_soft_project_backward   : fused backward of `project` for the hot path:
  *                                grad_proj (layout selectable) -> grad_Q (b,3,m) overwritten,
- *                                grad_sigma_partial (b) overwritten, grad_P optional (atomics).
+ *                                grad_sigma_partial (b * sn_soft_bwd_splits(b,m)) overwritten, grad_P optional
+ *                                (atomics).  sn_soft_weights_backward: same partial count.
  * ------------------------------------------------------------------------------------------- */
+int sn_soft_bwd_splits(int b, int m);
 int sn_soft_weights_forward(int b, int n, int m, int k, const float *P, const float *Q, const int *idx,
                             const float *temperature, float min_sigma, float *weights,
                             sn_stream_t stream);

@@ -23,8 +23,14 @@ PROTOTYPES = {
     "sn_last_error_string": [],
     "sn_workspace_bytes": [ctypes.c_char_p, _i, _i, _i, _i],
     "sn_pairscan_forward": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp],
+    "sn_pairscan_workspace_bytes": [_i, _i, _i],
+    "sn_pairscan_forward_ws": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp,
+                               ctypes.c_longlong, _vp],
+    "sn_soft_bwd_splits": [_i, _i],
     "sn_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_simplification_loss_forward": [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "sn_simplification_loss_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -49,7 +55,8 @@ PROTOTYPES = {
     "sn_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
-_RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong}
+_RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong,
+             "sn_pairscan_workspace_bytes": ctypes.c_longlong}
 
 
 class SampleNetHipError(RuntimeError):
@@ -59,7 +66,7 @@ class SampleNetHipError(RuntimeError):
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            "samplenet_amd: %s not found. Build it with `python -m samplenet_amd.build` (hipcc, gfx950). "
+            "samplenet_amd: %s not found. Build it with `python samplenet_amd/build.py` (hipcc, gfx950). "
             "There is no CPU / eager fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in PROTOTYPES.items():

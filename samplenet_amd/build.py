@@ -1,7 +1,7 @@
 """Build libsamplenet_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m samplenet_amd.build            # incremental
-    python -m samplenet_amd.build --force
+    python samplenet_amd/build.py            # incremental   (run as a script: importing the package needs the library)
+    python samplenet_amd/build.py --force
 
 hipcc cross-compiles without a GPU.  The shared object lands in samplenet_amd/lib/ so that it
 travels with the source snapshot to the GPU box (it is git-ignored, not gpurun-ignored).

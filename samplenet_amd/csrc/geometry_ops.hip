@@ -24,40 +24,68 @@ namespace sn {
 // A wave owns one target; its lanes scan 64 sources per step, a ballot yields the matching
 // sources and they are accumulated in ascending order (wave-uniform arithmetic).
 // ------------------------------------------------------------------------------------------------
+// Implicit upstream gradients (fused simplification loss, samplenet.py:171-181): with gL = d loss / d (scalar loss),
+//   g(dist of target j)  = gL * (ct + (j == argmax_t[b] ? cmax_t : 0)),   g(dist of source l) = gL * (cs + (l == argmax_s[b] ? cmax_s : 0))
+// so no per-point gradient tensors are materialised.  gL == NULL: explicit gT / gS arrays are used.
+struct ImplicitGrad {
+    const float *gL;
+    const int *argmax_t, *argmax_s;
+    float ct, cmax_t, cs, cmax_s;
+};
+
 __global__ void __launch_bounds__(256) chamfer_bwd_kernel(int nt, int ns, const float *__restrict__ T,
                                                           const float *__restrict__ S,
                                                           const float *__restrict__ gT,
                                                           const int *__restrict__ idxT,
                                                           const float *__restrict__ gS,
                                                           const int *__restrict__ idxS, float *__restrict__ gradT,
-                                                          int own_first)
+                                                          int own_first, ImplicitGrad ig)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
     T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
-    gT += (size_t)b * nt, idxT += (size_t)b * nt, gS += (size_t)b * ns, idxS += (size_t)b * ns;
+    idxT += (size_t)b * nt, idxS += (size_t)b * ns;
+    const bool implicit = ig.gL != nullptr;
+    float gLv = 0.f;
+    int amt = -1, ams = -1;
+    if (implicit) {
+        gLv = *ig.gL;
+        if (ig.argmax_t) amt = ig.argmax_t[b];
+        if (ig.argmax_s) ams = ig.argmax_s[b];
+    } else {
+        gT += (size_t)b * nt, gS += (size_t)b * ns;
+    }
     gradT += (size_t)b * nt * 3;
     for (int j = blockIdx.y * nwaves + wave; j < nt; j += gridDim.y * nwaves) {
         const float tx = T[j * 3 + 0], ty = T[j * 3 + 1], tz = T[j * 3 + 2];
         const int j2 = idxT[j];
-        const float g = gT[j] * 2;
+        const float g = (implicit ? gLv * (ig.ct + (j == amt ? ig.cmax_t : 0.f)) : gT[j]) * 2;
         const float ox = g * (tx - S[j2 * 3 + 0]);
         const float oy = g * (ty - S[j2 * 3 + 1]);
         const float oz = g * (tz - S[j2 * 3 + 2]);
         float ax = 0.f, ay = 0.f, az = 0.f;
         if (own_first) ax += ox, ay += oy, az += oz;
-        for (int l0 = 0; l0 < ns; l0 += 64) {
-            const int l = l0 + lane;
-            sn_u64 mask = __ballot(l < ns && idxS[l] == j);
-            while (mask) {
-                const int ll = l0 + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const float gg = gS[ll] * 2;
-                ax -= gg * (S[ll * 3 + 0] - tx);
-                ay -= gg * (S[ll * 3 + 1] - ty);
-                az -= gg * (S[ll * 3 + 2] - tz);
+        for (int l0 = 0; l0 < ns; l0 += 64 * 8) {
+            int is[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {  // 8 independent index loads in flight
+                const int l = l0 + q * 64 + lane;
+                is[q] = idxS[l < ns ? l : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int l = l0 + q * 64 + lane;
+                sn_u64 mask = __ballot(l < ns && is[q] == j);
+                while (mask) {  // matching sources in ascending index order
+                    const int ll = l0 + q * 64 + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const float gg = (implicit ? gLv * (ig.cs + (ll == ams ? ig.cmax_s : 0.f)) : gS[ll]) * 2;
+                    ax -= gg * (S[ll * 3 + 0] - tx);
+                    ay -= gg * (S[ll * 3 + 1] - ty);
+                    az -= gg * (S[ll * 3 + 2] - tz);
+                }
             }
         }
         if (!own_first) ax += ox, ay += oy, az += oz;
@@ -101,7 +129,7 @@ __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
     const float sigma = fmaxf(T * T, a.min_sigma);
     float gsig = 0.f;  // this wave's share of d loss / d sigma
 
-    for (int j = wave; j < m; j += nwaves) {
+    for (int j = blockIdx.y * nwaves + wave; j < m; j += gridDim.y * nwaves) {
         const float qx = Qb[pt_off(a.q_layout, m, j, 0)];
         const float qy = Qb[pt_off(a.q_layout, m, j, 1)];
         const float qz = Qb[pt_off(a.q_layout, m, j, 2)];
@@ -116,9 +144,8 @@ __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
         const float dx = gx - qx, dy = gy - qy, dz = gz - qz;
         const float d = (dx * dx + dy * dy) + dz * dz;
         const float s = act ? -(d / sigma) : -INFINITY;
-        float mx = s;
-#pragma unroll
-        for (int t = 1; t < 64; t <<= 1) mx = fmaxf(mx, __shfl_xor(mx, t));
+        float mx = readlane_f(s, 0);  // neighbours are stored ascending in distance; the scan below only matters
+        for (int t = 1; t < K; ++t) mx = fmaxf(mx, readlane_f(s, t));  // if a caller passes unsorted indices
         const float e = act ? expf(s - mx) : 0.f;
         float den = 0.f;
         for (int t = 0; t < K; ++t) den += readlane_f(e, t);
@@ -168,7 +195,7 @@ __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
     if (threadIdx.x == 0 && a.grad_sigma_partial) {
         float tot = 0.f;
         for (int w2 = 0; w2 < nwaves; ++w2) tot += s_part[w2];
-        a.grad_sigma_partial[b] = tot;
+        a.grad_sigma_partial[(size_t)b * gridDim.y + blockIdx.y] = tot;
     }
 }
 
@@ -316,6 +343,12 @@ static inline unsigned grid_for(size_t tot, int block = 256, unsigned cap = 4096
 
 using namespace sn;
 
+// workgroups per cloud of the soft-projection backward kernels; grad_sigma_partial holds b * this many floats
+extern "C" int sn_soft_bwd_splits(int b, int m)
+{
+    return std::max(1, std::min((m + 3) / 4, (512 + b - 1) / std::max(b, 1)));
+}
+
 extern "C" int sn_chamfer_backward(int b, int n, const float *xyz1, int m, const float *xyz2,
                                    const float *grad_dist1, const int *idx1, const float *grad_dist2,
                                    const int *idx2, float *grad_xyz1, float *grad_xyz2, sn_stream_t stream)
@@ -325,12 +358,95 @@ extern "C" int sn_chamfer_backward(int b, int n, const float *xyz1, int m, const
     SN_REQUIRE(xyz1 && xyz2 && grad_dist1 && grad_dist2 && idx1 && idx2, "null input");
     hipStream_t st = (hipStream_t)stream;
     auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (1024 + b - 1) / b)); };
+    const ImplicitGrad none{};
     if (grad_xyz1)
         hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(b, ysplit(n)), dim3(256), 0, st, n, m, xyz1, xyz2, grad_dist1,
-                           idx1, grad_dist2, idx2, grad_xyz1, 1);
+                           idx1, grad_dist2, idx2, grad_xyz1, 1, none);
     if (grad_xyz2)
         hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(b, ysplit(m)), dim3(256), 0, st, m, n, xyz2, xyz1, grad_dist2,
-                           idx2, grad_dist1, idx1, grad_xyz2, 0);
+                           idx2, grad_dist1, idx1, grad_xyz2, 0, none);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused simplification loss (samplenet.py:171-181):
+//   loss = mean(dist1) + mean_b(max_m dist1) + w * mean(dist2),   w = gamma + delta * pc_size
+// forward: one workgroup per cloud reduces its (sum dist1, max dist1 + first argmax, sum dist2) in a fixed order,
+// a single-workgroup kernel combines the clouds; backward: sn_chamfer_backward with implicit upstream gradients.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) simp_loss_partial_kernel(int n1, int n2, const float *__restrict__ d1,
+                                                                const float *__restrict__ d2, float *__restrict__ part,
+                                                                int *__restrict__ argmax1)
+{
+    __shared__ float r0[256], r1[256], r2[256];
+    __shared__ int ri[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float s1 = 0.f, mx = -INFINITY, s2 = 0.f;
+    int am = 0;
+    for (int j = t; j < n1; j += 256) {
+        const float v = d1[(size_t)b * n1 + j];
+        s1 += v;
+        if (v > mx) mx = v, am = j;
+    }
+    for (int j = t; j < n2; j += 256) s2 += d2[(size_t)b * n2 + j];
+    r0[t] = s1, r1[t] = mx, r2[t] = s2, ri[t] = am;
+    for (int s = 128; s > 0; s >>= 1) {
+        __syncthreads();
+        if (t < s) {
+            r0[t] += r0[t + s];
+            r2[t] += r2[t + s];
+            if (r1[t + s] > r1[t] || (r1[t + s] == r1[t] && ri[t + s] < ri[t])) r1[t] = r1[t + s], ri[t] = ri[t + s];
+        }
+    }
+    if (t == 0) {
+        part[b * 3 + 0] = r0[0], part[b * 3 + 1] = r1[0], part[b * 3 + 2] = r2[0];
+        argmax1[b] = ri[0];
+    }
+}
+
+__global__ void __launch_bounds__(64) simp_loss_final_kernel(int B, int n1, int n2, float w, const float *__restrict__ part,
+                                                             float *__restrict__ loss)
+{
+    if (threadIdx.x != 0) return;
+    float s1 = 0.f, mx = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) s1 += part[b * 3], mx += part[b * 3 + 1], s2 += part[b * 3 + 2];
+    const float c12 = s1 / ((float)B * (float)n1), cmax = mx / (float)B, c21 = s2 / ((float)B * (float)n2);
+    loss[0] = c12 + cmax + w * c21;
+}
+
+extern "C" int sn_simplification_loss_forward(int B, int n1, int n2, const float *dist1, const float *dist2, float weight,
+                                              float *partial, int *argmax1, float *loss, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && n1 >= 1 && n2 >= 1, "bad size");
+    SN_REQUIRE(dist1 && dist2 && partial && argmax1 && loss, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(simp_loss_partial_kernel, dim3(B), dim3(256), 0, st, n1, n2, dist1, dist2, partial, argmax1);
+    hipLaunchKernelGGL(simp_loss_final_kernel, dim3(1), dim3(64), 0, st, B, n1, n2, weight, partial, loss);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// grad_xyz1 (B,n1,3) / grad_xyz2 (B,n2,3) of the fused loss; grad_loss: device scalar.  Either output may be NULL.
+extern "C" int sn_simplification_loss_backward(int B, int n1, const float *xyz1, int n2, const float *xyz2, const int *idx1,
+                                               const int *idx2, const int *argmax1, float weight, const float *grad_loss,
+                                               float *grad_xyz1, float *grad_xyz2, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && n1 >= 1 && n2 >= 1, "bad size");
+    SN_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && argmax1 && grad_loss, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (1024 + B - 1) / B)); };
+    const float c1 = 1.0f / ((float)B * (float)n1), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)n2);
+    if (grad_xyz1) {
+        ImplicitGrad ig{grad_loss, argmax1, nullptr, c1, cm, c2, 0.f};
+        hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(B, ysplit(n1)), dim3(256), 0, st, n1, n2, xyz1, xyz2, nullptr, idx1,
+                           nullptr, idx2, grad_xyz1, 1, ig);
+    }
+    if (grad_xyz2) {
+        ImplicitGrad ig{grad_loss, nullptr, argmax1, c2, 0.f, c1, cm};
+        hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(B, ysplit(n2)), dim3(256), 0, st, n2, n1, xyz2, xyz1, nullptr, idx2,
+                           nullptr, idx1, grad_xyz2, 0, ig);
+    }
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -348,7 +464,7 @@ extern "C" int sn_soft_project_backward(int b, int n, int m, int k, const float 
     a.p_layout = p_layout, a.q_layout = q_layout, a.n = n, a.m = m, a.k = k;
     a.grad_proj = grad_proj, a.gproj_layout = gproj_layout;
     a.grad_Q = grad_Q, a.gq_layout = gq_layout, a.grad_P = grad_P, a.grad_sigma_partial = grad_sigma_partial;
-    hipLaunchKernelGGL(soft_bwd_kernel<true>, dim3(b), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(soft_bwd_kernel<true>, dim3(b, sn_soft_bwd_splits(b, m)), dim3(256), 0, (hipStream_t)stream, a);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -380,7 +496,7 @@ extern "C" int sn_soft_weights_backward(int b, int n, int m, int k, const float 
     a.p_layout = SN_LAYOUT_BCN, a.q_layout = SN_LAYOUT_BCN, a.n = n, a.m = m, a.k = k;
     a.weights_in = weights, a.grad_weights = grad_weights;
     a.grad_Q = grad_Q, a.gq_layout = SN_LAYOUT_BCN, a.grad_P = grad_P, a.grad_sigma_partial = grad_sigma_partial;
-    hipLaunchKernelGGL(soft_bwd_kernel<false>, dim3(b), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(soft_bwd_kernel<false>, dim3(b, sn_soft_bwd_splits(b, m)), dim3(256), 0, (hipStream_t)stream, a);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -98,6 +98,49 @@ constexpr int max_threads(int ppl, bool colmin)
     return (ppl >= 32 && colmin) ? 256 : ((ppl >= 32 || (ppl == 16 && colmin)) ? 512 : 1024);
 }
 
+// ---- cross-lane helpers on the DPP path (no LDS round trip) --------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppRowMirror = 0x140;
+
+// Threshold tau = max over the 2^LOGG lane groups (contiguous groups of 64 >> LOGG lanes) of the group minimum of x.
+// x >= +0 (or +inf), so the cross-row step can run on the SALU as unsigned integer min/max of the bit patterns.
+template <int LOGG>
+__device__ __forceinline__ float group_minmax(float x)
+{
+    // within a row of 16 lanes: xor1, xor2 (quads), half-mirror (8), mirror (16)
+    if (LOGG <= 5) x = fminf(x, dpp_f<kDppXor1>(x)); else x = fmaxf(x, dpp_f<kDppXor1>(x));          // group >= 2 lanes
+    if (LOGG <= 4) x = fminf(x, dpp_f<kDppXor2>(x)); else x = fmaxf(x, dpp_f<kDppXor2>(x));          // group >= 4
+    if (LOGG <= 3) x = fminf(x, dpp_f<kDppHalfMirror>(x)); else x = fmaxf(x, dpp_f<kDppHalfMirror>(x));  // group >= 8
+    if (LOGG <= 2) x = fminf(x, dpp_f<kDppRowMirror>(x)); else x = fmaxf(x, dpp_f<kDppRowMirror>(x));    // group >= 16
+    const unsigned r0 = __builtin_amdgcn_readlane(__float_as_int(x), 0), r1 = __builtin_amdgcn_readlane(__float_as_int(x), 16);
+    const unsigned r2 = __builtin_amdgcn_readlane(__float_as_int(x), 32), r3 = __builtin_amdgcn_readlane(__float_as_int(x), 48);
+    unsigned a, b;
+    if (LOGG <= 1) a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3; else a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;  // group >= 32
+    const unsigned t = (LOGG == 0) ? (a < b ? a : b) : (a > b ? a : b);                                              // group == 64
+    return __uint_as_float(t);
+}
+
+// Rank the wave's <= 64 candidates held one per lane (mine = key or kKeyInf) and move them to lane == rank:
+// afterwards lane t < min(cnt, 64) holds the t-th smallest key.  Keys are unique, so ranks are a permutation.
+__device__ __forceinline__ sn_u64 rank_to_lanes(sn_u64 mine, int cnt, int lane)
+{
+    const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+    int rank = 0;
+    for (int u = 0; u < cnt; ++u) {
+        const sn_u64 ku = ((sn_u64)(unsigned)__builtin_amdgcn_readlane((int)hi, u) << 32) |
+                          (unsigned)__builtin_amdgcn_readlane((int)lo, u);
+        rank += (ku < mine) ? 1 : 0;
+    }
+    const int dst = (lane < cnt) ? rank : lane;  // lanes without a candidate keep to themselves (no collision)
+    const unsigned plo = (unsigned)__builtin_amdgcn_ds_permute(dst << 2, (int)lo);
+    const unsigned phi = (unsigned)__builtin_amdgcn_ds_permute(dst << 2, (int)hi);
+    return ((sn_u64)phi << 32) | plo;
+}
+
 struct PairscanArgs {
     const float *P;
     const float *Q;
@@ -114,9 +157,11 @@ struct PairscanArgs {
     float *weights;
     const float *temperature;
     float min_sigma;
+    sn_u64 *colmin_ws;  // [B][gridDim.y][N] partial column minima as (distance, query) keys when the queries of a
+                        // cloud are spread over several workgroups (gridDim.y > 1); finalised by colmin_finalize_kernel
 };
 
-template <int PPL, bool SINGLE, bool COLMIN>
+template <int PPL, bool SINGLE, bool COLMIN, int LOGG>
 __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(PairscanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -134,11 +179,6 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
 
     const float *__restrict__ Pb = a.P + (size_t)b * 3 * N;
     const float *__restrict__ Qb = a.Q + (size_t)b * 3 * M;
-
-    // lane groups for the threshold: G = pow2 >= K (<= 64), contiguous groups of gs lanes
-    int G = 1;
-    while (G < K && G < kWave) G <<= 1;
-    const int gs = kWave / G;
 
     const bool want_soft = (a.proj != nullptr) || (a.weights != nullptr);
     float sigma = 1.0f;
@@ -184,14 +224,8 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                     }
                 }
             }
-            // tau = max over groups of (min over the group's lanes)
-            float x = lmin;
-#pragma unroll
-            for (int s = 1; s < kWave; s <<= 1) {
-                const float y = __shfl_xor(x, s);
-                x = (s < gs) ? fminf(x, y) : fmaxf(x, y);
-            }
-            float thr = fminf(x, thr_run);
+            // tau = max over the 2^LOGG lane groups of the group's minimum (2^LOGG >= K): >= K points lie at or below it
+            float thr = fminf(group_minmax<LOGG>(lmin), thr_run);
             // compact candidates (d <= thr) into the wave's LDS list
 #pragma unroll
             for (int i = 0; i < PPL; ++i) {
@@ -215,10 +249,17 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                 if (cnt == K) thr_run = key_dist(list[K - 1]);
             }
         }
-        if (SINGLE) cnt = merge_topk(list, cnt, K, lane);
-
         // ---- per-query outputs: lanes t < K hold neighbour t (ascending (distance, index)) ----
-        const sn_u64 key = (lane < cnt) ? list[lane] : kKeyInf;
+        sn_u64 key;
+        if (SINGLE && cnt <= kWave) {
+            // usual case (~K..3K candidates): one candidate per lane, ranked in registers, moved to lane == rank
+            key = rank_to_lanes((lane < cnt) ? list[lane] : kKeyInf, cnt, lane);
+            cnt = cnt < K ? cnt : K;
+            if (lane >= cnt) key = kKeyInf;
+        } else {
+            if (SINGLE) cnt = merge_topk(list, cnt, K, lane);
+            key = (lane < cnt) ? list[lane] : kKeyInf;
+        }
         const int nidx = (lane < cnt) ? key_index(key) : 0;
         const float nd = (lane < cnt) ? key_dist(key) : INFINITY;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -239,9 +280,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                 gz = Pb[pt_off(a.p_layout, N, nidx, 2)];
             }
             const float s = (lane < cnt) ? -(nd / sigma) : -INFINITY;  // soft_projection.py:92-95
-            float mx = s;
-#pragma unroll
-            for (int t = 1; t < kWave; t <<= 1) mx = fmaxf(mx, __shfl_xor(mx, t));
+            const float mx = readlane_f(s, 0);  // neighbours ascend in distance: lane 0 holds the maximum of s
             const float e = (lane < cnt) ? expf(s - mx) : 0.f;
             float den = 0.f;
             for (int t = 0; t < K; ++t) den += readlane_f(e, t);
@@ -268,56 +307,88 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
 #pragma unroll
         for (int i = 0; i < PPL; ++i) atomicMin(&colmin[i * kWave + lane], make_key(cd[i], ci[i]));
         __syncthreads();
-        for (int n = threadIdx.x; n < N; n += blockDim.x) {
-            const sn_u64 k = colmin[n];
-            if (a.dist_p) a.dist_p[(size_t)b * N + n] = key_dist(k);
-            if (a.idx_p) a.idx_p[(size_t)b * N + n] = key_index(k);
+        if (gridDim.y == 1) {
+            for (int n = threadIdx.x; n < N; n += blockDim.x) {
+                const sn_u64 k = colmin[n];
+                if (a.dist_p) a.dist_p[(size_t)b * N + n] = key_dist(k);
+                if (a.idx_p) a.idx_p[(size_t)b * N + n] = key_index(k);
+            }
+        } else {  // this workgroup saw only its share of the queries: publish partial keys
+            sn_u64 *ws = a.colmin_ws + ((size_t)b * gridDim.y + blockIdx.y) * N;
+            for (int n = threadIdx.x; n < N; n += blockDim.x) ws[n] = colmin[n];
         }
     }
+}
+
+// dist_p / idx_p = minimum over the G partial keys of every point (min of (distance, query) keys = lowest query on ties)
+__global__ void __launch_bounds__(256) colmin_finalize_kernel(int N, int G, const sn_u64 *__restrict__ ws,
+                                                              float *__restrict__ dist_p, int *__restrict__ idx_p)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    sn_u64 k = kKeyInf;
+    for (int g = 0; g < G; ++g) {
+        const sn_u64 v = ws[((size_t)b * G + g) * N + n];
+        k = v < k ? v : k;
+    }
+    if (dist_p) dist_p[(size_t)b * N + n] = key_dist(k);
+    if (idx_p) idx_p[(size_t)b * N + n] = key_index(k);
 }
 
 template <int PPL, bool SINGLE, bool COLMIN>
 static int launch_pairscan(const PairscanArgs &a, int waves, int ysplit, hipStream_t st)
 {
     const size_t lds = (size_t)waves * kListCap * 8 + (COLMIN ? (size_t)kWave * PPL * 8 : 0);
-    hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN>), dim3(a.B, ysplit), dim3(waves * kWave), lds, st, a);
+    const dim3 grid(a.B, ysplit), block(waves * kWave);
+    // number of lane groups for the threshold = power of two >= K (instantiated: 1, 8, 16, 64)
+    if (a.K <= 1)
+        hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN, 0>), grid, block, lds, st, a);
+    else if (a.K <= 8)
+        hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN, 3>), grid, block, lds, st, a);
+    else if (a.K <= 16)
+        hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN, 4>), grid, block, lds, st, a);
+    else
+        hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN, 6>), grid, block, lds, st, a);
     return 0;
 }
 
-static int next_pow2(int x)
+// Host-side dispatch.  colmin => dist_p / idx_p requested.  ws/ws_bytes: optional scratch that lets the queries of a
+// cloud be spread over several workgroups even when column minima are wanted (partials + a finalize kernel).
+int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finalize, int *used_split, hipStream_t st)
 {
-    int p = 1;
-    while (p < x) p <<= 1;
-    return p;
-}
-
-// Host-side dispatch.  colmin => dist_p / idx_p requested.
-int pairscan_dispatch(PairscanArgs a, hipStream_t st)
-{
-    const bool colmin = a.dist_p || a.idx_p;
+    const bool colmin = a.dist_p || a.idx_p || (ws && !finalize);
     const int N = a.N, M = a.M;
+    if (used_split) *used_split = 1;
     if (N <= kWave * 32) {
         // single chunk: the whole cloud lives in the wave's registers
         const int ppl = N <= 64 ? 1 : (N <= 256 ? 4 : (N <= 1024 ? 16 : 32));
         const int maxw = max_threads(ppl, colmin) / kWave;
-        // without column minima the queries of a cloud can be spread over several workgroups
-        int ysplit = 1;
-        if (!colmin) {
-            const int want = (512 + a.B - 1) / a.B;  // aim at >= 2 workgroups per CU
-            ysplit = std::max(1, std::min(want, (M + maxw - 1) / maxw));
+        // spread the queries of a cloud over several workgroups when the batch alone cannot fill the chip
+        const int want = (512 + a.B - 1) / a.B;  // aim at >= 2 workgroups per CU
+        int ysplit = std::max(1, std::min(want, (M + maxw - 1) / maxw));
+        if (colmin && ysplit > 1) {
+            const long long need = (long long)a.B * ysplit * N * 8;
+            if (!ws || ws_bytes < need) ysplit = 1;
         }
         const int qpb = (M + ysplit - 1) / ysplit;
         const int waves = std::max(1, std::min(maxw, qpb));
+        a.colmin_ws = (colmin && ysplit > 1) ? (sn_u64 *)ws : nullptr;
+        if (used_split) *used_split = ysplit;
 #define SN_PS(PPL_)                                                                      \
     (colmin ? launch_pairscan<PPL_, true, true>(a, waves, ysplit, st)                    \
             : launch_pairscan<PPL_, true, false>(a, waves, ysplit, st))
         switch (ppl) {
-            case 1: return SN_PS(1);
-            case 4: return SN_PS(4);
-            case 16: return SN_PS(16);
-            default: return SN_PS(32);
+            case 1: SN_PS(1); break;
+            case 4: SN_PS(4); break;
+            case 16: SN_PS(16); break;
+            default: SN_PS(32); break;
         }
 #undef SN_PS
+        if (colmin && ysplit > 1 && finalize)
+            hipLaunchKernelGGL(colmin_finalize_kernel, dim3((N + 255) / 256, a.B), dim3(256), 0, st, N, ysplit,
+                               (const sn_u64 *)ws, a.dist_p, a.idx_p);
+        return 0;
     }
     // multi chunk: row products only; the caller obtains column minima by a swapped second call
     if (colmin) return sn_set_error(SN_ERR_UNSUPPORTED, "pairscan: column minima need N <= 2048 (internal)");
@@ -332,10 +403,33 @@ int pairscan_dispatch(PairscanArgs a, hipStream_t st)
 
 using sn::PairscanArgs;
 
+extern "C" long long sn_pairscan_workspace_bytes(int B, int N, int M)
+{
+    if (N > sn::kWave * 32) return 0;
+    const int ysplit = std::max(1, std::min((512 + B - 1) / std::max(B, 1), M));
+    return ysplit > 1 ? (long long)B * ysplit * N * 8 : 0;
+}
+
+extern "C" int sn_pairscan_forward_ws(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
+                                      int q_layout, int *knn_idx, float *knn_dist, float *dist_q, int *idx_q,
+                                      float *dist_p, int *idx_p, float *proj, int proj_layout, float *weights,
+                                      const float *temperature, float min_sigma, void *workspace,
+                                      long long workspace_bytes, sn_stream_t stream);
+
 extern "C" int sn_pairscan_forward(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
                                    int q_layout, int *knn_idx, float *knn_dist, float *dist_q, int *idx_q,
                                    float *dist_p, int *idx_p, float *proj, int proj_layout, float *weights,
                                    const float *temperature, float min_sigma, sn_stream_t stream)
+{
+    return sn_pairscan_forward_ws(B, N, M, K, P, p_layout, Q, q_layout, knn_idx, knn_dist, dist_q, idx_q, dist_p, idx_p,
+                                  proj, proj_layout, weights, temperature, min_sigma, nullptr, 0, stream);
+}
+
+extern "C" int sn_pairscan_forward_ws(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
+                                      int q_layout, int *knn_idx, float *knn_dist, float *dist_q, int *idx_q,
+                                      float *dist_p, int *idx_p, float *proj, int proj_layout, float *weights,
+                                      const float *temperature, float min_sigma, void *workspace,
+                                      long long workspace_bytes, sn_stream_t stream)
 {
     SN_REQUIRE(B >= 0 && N >= 0 && M >= 0 && K >= 0, "negative size");
     if (B == 0 || (M == 0 && N == 0)) return 0;
@@ -358,16 +452,16 @@ extern "C" int sn_pairscan_forward(int B, int N, int M, int K, const float *P, i
     const bool colmin = dist_p || idx_p;
     if (N <= sn::kWave * 32 || !colmin) {
         a.dist_p = dist_p, a.idx_p = idx_p;
-        int rc = sn::pairscan_dispatch(a, st);
+        int rc = sn::pairscan_dispatch(a, workspace, workspace_bytes, true, nullptr, st);
         if (rc) return rc;
     } else {
-        int rc = sn::pairscan_dispatch(a, st);  // row products
+        int rc = sn::pairscan_dispatch(a, nullptr, 0, true, nullptr, st);  // row products
         if (rc) return rc;
         PairscanArgs s{};  // column minima = row minima of the swapped problem
         s.P = Q, s.Q = P, s.p_layout = q_layout, s.q_layout = p_layout;
         s.B = B, s.N = M, s.M = N, s.K = 1;
         s.dist_q = dist_p, s.idx_q = idx_p;
-        rc = sn::pairscan_dispatch(s, st);
+        rc = sn::pairscan_dispatch(s, nullptr, 0, true, nullptr, st);
         if (rc) return rc;
     }
     SN_LAUNCH_CHECK();

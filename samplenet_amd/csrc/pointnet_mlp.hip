@@ -35,7 +35,7 @@ namespace sn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;   // K chunk
+constexpr int BK = 64;   // K chunk (one chunk covers the 64-channel layers: a single exposed global-load latency)
 constexpr int LPAD = 4;  // LDS row padding (floats): keeps rows 16-B aligned for the float4 staging stores
 
 // ------------------------------------------------------------------------------------------------
@@ -67,15 +67,45 @@ struct ActSrc {
     int rows, ch, mode;
     int ones_col;  // if >= 0: channel index that reads as 1.0 (bias column of wgrad)
 
+    // branch-free scalar access (small-R kernels): out-of-range reads are clamped to element 0 and zeroed
+    template <int MODE>
+    __device__ __forceinline__ float at(int r, int c) const
+    {
+        const bool ok = r < rows && c < ch;
+        const size_t o = ok ? (size_t)r * ch + c : 0;
+        float v = z[o];
+        if (MODE == ACT_BN_RELU) {
+            const int cc = ok ? c : 0;
+            v = fmaxf(fmaf(v, scale[cc], shift[cc]), 0.f);
+        }
+        v *= ok ? 1.f : 0.f;  // mask by multiplication (see small_fwd_kernel): keeps the loads unconditional
+        return (ones_col >= 0 && c == ones_col && r < rows) ? 1.f : v;
+    }
+
+    // FULL: caller guarantees r < rows, c + 3 < ch, ch % 4 == 0, no ones column: straight 16-byte loads that the
+    // compiler can issue back to back (the guarded path puts every load behind its own branch).
+    template <bool FULL, int MODE>
     __device__ __forceinline__ float4 load_c4(int r, int c) const  // 4 consecutive channels of row r
     {
+        if (FULL) {
+            float4 v = *reinterpret_cast<const float4 *>(z + (size_t)r * ch + c);
+            if (MODE == ACT_BN_RELU) {
+                const float4 s = *reinterpret_cast<const float4 *>(scale + c);
+                const float4 t = *reinterpret_cast<const float4 *>(shift + c);
+                v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f);
+                v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f);
+                v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+            }
+            return v;
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r >= rows) return v;
         const int valid = min(4, ch - c);
         const bool al = (ch & 3) == 0;
         if (valid > 0) {
             v = ld4_guard(z, (size_t)r * ch + c, valid, al);
-            if (mode == ACT_BN_RELU) {
+            if (MODE == ACT_BN_RELU) {
                 const float4 s = ld4_guard(scale, c, valid, al), t = ld4_guard(shift, c, valid, al);
                 v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f);
                 v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
@@ -105,16 +135,60 @@ struct DzSrc {
     const int *argsel;          // [B][ch]  (DZ_POOL) row-within-cloud of the pooled element
     int rows, ch, mode, npts;
 
+    template <int MODE>
+    __device__ __forceinline__ float at(int r, int c) const  // branch-free scalar access (small-R kernels)
+    {
+        const bool ok = r < rows && c < ch;
+        const int cc = ok ? c : 0;
+        const size_t o = ok ? (size_t)r * ch + c : 0;
+        float v;
+        if (MODE == DZ_PLAIN) {
+            v = dy[o];
+        } else {
+            float d;
+            if (MODE == DZ_POOL) {
+                const int rr = ok ? r : 0;
+                const int b = rr / npts, n = rr - b * npts;
+                d = argsel[(size_t)b * ch + cc] == n ? gsel[(size_t)b * ch + cc] : 0.f;
+            } else {
+                d = dy[o];
+            }
+            v = fmaf(k1[cc], d, fmaf(k2[cc], z[o], k3[cc]));
+        }
+        return v * (ok ? 1.f : 0.f);
+    }
+
+    template <bool FULL, int MODE>
     __device__ __forceinline__ float4 load_c4(int r, int c) const
     {
+        if (FULL) {
+            if (MODE == DZ_PLAIN) return *reinterpret_cast<const float4 *>(dy + (size_t)r * ch + c);
+            float4 d;
+            if (MODE == DZ_POOL) {
+                const int b = r / npts, n = r - b * npts;
+                const int4 ag = *reinterpret_cast<const int4 *>(argsel + (size_t)b * ch + c);
+                const float4 gs = *reinterpret_cast<const float4 *>(gsel + (size_t)b * ch + c);
+                d.x = ag.x == n ? gs.x : 0.f;
+                d.y = ag.y == n ? gs.y : 0.f;
+                d.z = ag.z == n ? gs.z : 0.f;
+                d.w = ag.w == n ? gs.w : 0.f;
+            } else {
+                d = *reinterpret_cast<const float4 *>(dy + (size_t)r * ch + c);
+            }
+            const float4 zz = *reinterpret_cast<const float4 *>(z + (size_t)r * ch + c);
+            const float4 a = *reinterpret_cast<const float4 *>(k1 + c), bb = *reinterpret_cast<const float4 *>(k2 + c),
+                         cc = *reinterpret_cast<const float4 *>(k3 + c);
+            return make_float4(fmaf(a.x, d.x, fmaf(bb.x, zz.x, cc.x)), fmaf(a.y, d.y, fmaf(bb.y, zz.y, cc.y)),
+                               fmaf(a.z, d.z, fmaf(bb.z, zz.z, cc.z)), fmaf(a.w, d.w, fmaf(bb.w, zz.w, cc.w)));
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r >= rows) return v;
         const int valid = min(4, ch - c);
         if (valid <= 0) return v;
         const bool al = (ch & 3) == 0;
-        if (mode == DZ_PLAIN) return ld4_guard(dy, (size_t)r * ch + c, valid, al);
+        if (MODE == DZ_PLAIN) return ld4_guard(dy, (size_t)r * ch + c, valid, al);
         float4 d;
-        if (mode == DZ_POOL) {
+        if (MODE == DZ_POOL) {
             const int b = r / npts, n = r - b * npts;
             const size_t o = (size_t)b * ch + c;
             d.x = (valid > 0 && argsel[o] == n) ? gsel[o] : 0.f;
@@ -138,8 +212,10 @@ struct DzSrc {
 struct WSrc {
     const float *w;
     int co, ci;
+    template <bool FULL>
     __device__ __forceinline__ float4 load_ci4(int o, int i) const  // 4 consecutive ci of row co=o
     {
+        if (FULL) return *reinterpret_cast<const float4 *>(w + (size_t)o * ci + i);
         if (o >= co) return make_float4(0.f, 0.f, 0.f, 0.f);
         return ld4_guard(w, (size_t)o * ci + i, min(4, ci - i), (ci & 3) == 0);
     }
@@ -153,6 +229,7 @@ struct Tile {
     static constexpr int BM = BM_, BN = BN_, WR = WR_, WC = WC_;
     static constexpr int THREADS = WR * WC * 64;
     static constexpr int TM = BM / (WR * 32), TN = BN / (WC * 32);
+    // leading dimensions are chosen per staging mode inside gemm_tile (see lds_ld); budget for the larger one
     static constexpr int LDA = BM + LPAD, LDB = BN + LPAD;
     static constexpr int LDS_FLOATS = BK * (LDA + LDB);
     static constexpr int A4 = (BM * BK / 4 + THREADS - 1) / THREADS;  // float4 per thread per chunk
@@ -166,7 +243,8 @@ __device__ __forceinline__ void stage_store(float *__restrict__ S, const float4 
 #pragma unroll
     for (int q = 0; q < N4; ++q) {
         const int f = tid + q * THREADS;
-        if (f < BX * BK / 4) {
+        constexpr bool exact = (BX * BK / 4) % THREADS == 0;
+        if (exact || f < BX * BK / 4) {
             if (KC) {
                 const int x = f / (BK / 4), k4 = (f % (BK / 4)) * 4;
                 S[(k4 + 0) * LD + x] = v[q].x;
@@ -189,8 +267,11 @@ __device__ __forceinline__ void fetch_chunk(float4 (&ra)[T::A4], float4 (&rb)[T:
 #pragma unroll
     for (int q = 0; q < T::A4; ++q) {
         const int f = tid + q * T::THREADS;
+        // the guard exists only when the tile does not divide evenly among the threads (a branch around a load
+        // makes the compiler wait for every load individually)
+        constexpr bool exact = (T::BM * BK / 4) % T::THREADS == 0;
         ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < T::BM * BK / 4) {
+        if (exact || f < T::BM * BK / 4) {
             if (A_KC)
                 ra[q] = fa(f / (BK / 4), k0 + (f % (BK / 4)) * 4);
             else
@@ -200,8 +281,9 @@ __device__ __forceinline__ void fetch_chunk(float4 (&ra)[T::A4], float4 (&rb)[T:
 #pragma unroll
     for (int q = 0; q < T::B4; ++q) {
         const int f = tid + q * T::THREADS;
+        constexpr bool exact = (T::BN * BK / 4) % T::THREADS == 0;
         rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < T::BN * BK / 4) {
+        if (exact || f < T::BN * BK / 4) {
             if (B_KC)
                 rb[q] = fb(f / (BK / 4), k0 + (f % (BK / 4)) * 4);
             else
@@ -218,13 +300,17 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[T::TM][T::TN], int K, co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / T::WC, wc = wave % T::WC;
+    // k-contiguous operands are transposed on their way into LDS (4 scalar stores per float4): with a leading
+    // dimension = 1 (mod 8) the 64 lanes of a store hit every bank exactly twice (free); +4 keeps the float4 stores
+    // of x-contiguous operands 16-byte aligned.  Fragment reads are conflict-free for any leading dimension.
+    constexpr int LDA = T::BM + (A_KC ? 1 : LPAD), LDB = T::BN + (B_KC ? 1 : LPAD);
     float *As = lds, *Bs = lds + BK * T::LDA;
     float4 ra[T::A4], rb[T::B4];
 
     fetch_chunk<T, A_KC, B_KC>(ra, rb, fa, fb, 0, tid);
     for (int k0 = 0; k0 < K; k0 += BK) {
-        stage_store<T::BM, T::LDA, T::A4, T::THREADS, A_KC>(As, ra, tid);
-        stage_store<T::BN, T::LDB, T::B4, T::THREADS, B_KC>(Bs, rb, tid);
+        stage_store<T::BM, LDA, T::A4, T::THREADS, A_KC>(As, ra, tid);
+        stage_store<T::BN, LDB, T::B4, T::THREADS, B_KC>(Bs, rb, tid);
         __syncthreads();
         if (k0 + BK < K) fetch_chunk<T, A_KC, B_KC>(ra, rb, fa, fb, k0 + BK, tid);  // loads in flight under the MFMAs
         const int h = lane >> 5, l31 = lane & 31;
@@ -232,9 +318,9 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[T::TM][T::TN], int K, co
         for (int s = 0; s < BK / 2; ++s) {
             float a[T::TM], b[T::TN];
 #pragma unroll
-            for (int i = 0; i < T::TM; ++i) a[i] = As[(2 * s + h) * T::LDA + (wr * T::TM + i) * 32 + l31];
+            for (int i = 0; i < T::TM; ++i) a[i] = As[(2 * s + h) * LDA + (wr * T::TM + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < T::TN; ++j) b[j] = Bs[(2 * s + h) * T::LDB + (wc * T::TN + j) * 32 + l31];
+            for (int j = 0; j < T::TN; ++j) b[j] = Bs[(2 * s + h) * LDB + (wc * T::TN + j) * 32 + l31];
 #pragma unroll
             for (int i = 0; i < T::TM; ++i)
 #pragma unroll
@@ -292,7 +378,7 @@ struct FwdArgs {
     float *stats;  // may be null
 };
 
-template <class T>
+template <class T, bool FULL, int AMODE>
 __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -308,8 +394,8 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
     const ActSrc a = g.a;
     const WSrc w = g.w;
     gemm_tile<T, true, true>(
-        acc, Ci, [&](int x, int k) { return a.load_c4(row0 + x, k); }, [&](int x, int k) { return w.load_ci4(col0 + x, k); },
-        lds);
+        acc, Ci, [&](int x, int k) { return a.template load_c4<FULL, AMODE>(row0 + x, k); },
+        [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,7 +404,7 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
-        const float bias = (col < Co && g.bias) ? g.bias[col] : 0.f;
+        const float bias = g.bias ? g.bias[(FULL || col < Co) ? col : 0] : 0.f;
         s0[j] = 0.f, s1[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
@@ -326,7 +412,7 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
                 const float v = acc[i][j][e] + bias;
-                if (row < R && col < Co) {
+                if (FULL || (row < R && col < Co)) {
                     g.z[(size_t)row * Co + col] = v;
                     s0[j] += v;
                     s1[j] += v * v;
@@ -351,7 +437,7 @@ struct DgradArgs {
     float *stats;
 };
 
-template <class T>
+template <class T, bool FULL, int ZMODE, int PMODE>
 __global__ void __launch_bounds__(T::THREADS) linear_dgrad_kernel(DgradArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -368,26 +454,26 @@ __global__ void __launch_bounds__(T::THREADS) linear_dgrad_kernel(DgradArgs g)
     const WSrc w = g.w;
     // A: dZ rows, k = co contiguous.  B[k = co][x = ci]: W row-major is exactly [K][X], x contiguous.
     gemm_tile<T, true, false>(
-        acc, Co, [&](int x, int k) { return dz.load_c4(row0 + x, k); }, [&](int x, int k) { return w.load_ci4(k, col0 + x); },
-        lds);
+        acc, Co, [&](int x, int k) { return dz.template load_c4<FULL, ZMODE>(row0 + x, k); },
+        [&](int x, int k) { return w.template load_ci4<FULL>(k, col0 + x); }, lds);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave / T::WC, wc = wave % T::WC;
-    const bool masked = g.prev.mode == ACT_BN_RELU;
+    constexpr bool masked = PMODE == ACT_BN_RELU;
     float s0[T::TN], s1[T::TN];
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
         float sc = 0.f, sh = 0.f;
-        if (masked && col < Ci) sc = g.prev.scale[col], sh = g.prev.shift[col];
+        if (masked) sc = g.prev.scale[(FULL || col < Ci) ? col : 0], sh = g.prev.shift[(FULL || col < Ci) ? col : 0];
         s0[j] = 0.f, s1[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
-                if (row < R && col < Ci) {
+                if (FULL || (row < R && col < Ci)) {
                     float v = acc[i][j][e];
                     if (masked) {
                         const float zp = g.prev.z[(size_t)row * Ci + col];
@@ -416,7 +502,7 @@ struct WgradArgs {
     int ncols;  // Ci + 1 with the bias column, Ci without
 };
 
-template <class T>
+template <class T, bool FULL, int ZMODE, int PMODE>
 __global__ void __launch_bounds__(T::THREADS) linear_wgrad_kernel(WgradArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -437,8 +523,8 @@ __global__ void __launch_bounds__(T::THREADS) linear_wgrad_kernel(WgradArgs g)
     pv.rows = r1;
     // both operands: source [K = r][X], x contiguous
     gemm_tile<T, false, false>(
-        acc, max(0, r1 - r0), [&](int x, int k) { return dz.load_c4(r0 + k, m0 + x); },
-        [&](int x, int k) { return pv.load_c4(r0 + k, n0 + x); }, lds);
+        acc, max(0, r1 - r0), [&](int x, int k) { return dz.template load_c4<FULL, ZMODE>(r0 + k, m0 + x); },
+        [&](int x, int k) { return pv.template load_c4<FULL, PMODE>(r0 + k, n0 + x); }, lds);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -452,8 +538,195 @@ __global__ void __launch_bounds__(T::THREADS) linear_wgrad_kernel(WgradArgs g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
-                if (row < Co && col < Ce) P[(size_t)row * Ce + col] = acc[i][j][e];
+                if (FULL || (row < Co && col < Ce)) P[(size_t)row * Ce + col] = acc[i][j][e];
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-R kernels (R <= 32: the FC head at the reference batch size).  One 32-row MFMA tile; the GEMM is
+// latency-bound, so there is no LDS staging loop: every lane loads its whole K slice of both operands straight
+// into registers (all loads in flight at once), the four waves of a workgroup split K, and their accumulators
+// are summed through LDS in wave order (deterministic).  MFMA step t of a lane consumes k = kbase + 32*half + t:
+// any permutation of k is valid as long as A and B use the same one.
+// ------------------------------------------------------------------------------------------------
+constexpr int KP = 32;  // k values per lane per pass
+
+__device__ __forceinline__ void wave_sum_to_wave0(f32x16 &acc, float *lds)
+{
+    // lds: [3][16][64] floats.  waves 1..3 publish, wave 0 adds them in order.
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave > 0)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lds[((wave - 1) * 16 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    if (wave == 0)
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += lds[(w * 16 + e) * 64 + lane];
+}
+
+// Z[R<=32][Co] = act(A) . W^T + bias ; stats [1][2][Co]
+// VEC: Ci % 64 == 0 -> every executed pass is fully in range and 16-byte aligned: the lane's 32 consecutive k of a row
+// are fetched as 8 dwordx4 loads (one 128-byte line per row, touched once) instead of 32 strided dword loads.
+template <int AMODE, bool VEC>
+__global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
+{
+    __shared__ float lds[3 * 16 * 64];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int R = g.a.rows, Co = g.w.co, Ci = g.w.ci;
+    const int col = blockIdx.x * 32 + l31;
+    const bool colok = col < Co;
+    const float *wrow = g.w.w + (size_t)(colok ? col : 0) * Ci;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = wave * 2 * KP; k0 < Ci; k0 += 4 * 2 * KP) {
+        float a[KP], b[KP];
+        const int kb = k0 + h * KP;
+        if (VEC) {
+            const int rr = l31 < R ? l31 : 0;
+            const float rmask = l31 < R ? 1.f : 0.f, cmask = colok ? 1.f : 0.f;
+#pragma unroll
+            for (int t = 0; t < KP; t += 4) {
+                const float4 av = g.a.template load_c4<true, AMODE>(rr, kb + t);
+                const float4 bv = *reinterpret_cast<const float4 *>(wrow + kb + t);
+                a[t] = av.x * rmask, a[t + 1] = av.y * rmask, a[t + 2] = av.z * rmask, a[t + 3] = av.w * rmask;
+                b[t] = bv.x * cmask, b[t + 1] = bv.y * cmask, b[t + 2] = bv.z * cmask, b[t + 3] = bv.w * cmask;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < KP; ++t) {
+                const int k = kb + t;
+                a[t] = g.a.template at<AMODE>(l31, k);
+                // multiply by a 0/1 mask instead of selecting: a select lets the compiler sink the load into a
+                // branch and wait for it on the spot, serialising all 32 loads
+                b[t] = wrow[k < Ci ? k : 0] * ((colok && k < Ci) ? 1.f : 0.f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KP; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+    wave_sum_to_wave0(acc, lds);
+    if (wave != 0) return;
+    const float bias = (colok && g.bias) ? g.bias[col] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = frag_row(e, lane);
+        const float v = acc[e] + bias;
+        if (row < R && colok) {
+            g.z[(size_t)row * Co + col] = v;
+            s0 += v;
+            s1 += v * v;
+        }
+    }
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    if (g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Co + col] = s1;
+}
+
+// dYprev[R<=32][Ci] = mask . (dZ . W) ; stats [1][2][Ci]
+template <int ZMODE, int PMODE, bool VEC>
+__global__ void __launch_bounds__(256) small_dgrad_kernel(DgradArgs g)
+{
+    __shared__ float lds[3 * 16 * 64];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int R = g.dz.rows, Co = g.w.co, Ci = g.w.ci;
+    const int col = blockIdx.x * 32 + l31;  // ci
+    const bool colok = col < Ci;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int k0 = wave * 2 * KP; k0 < Co; k0 += 4 * 2 * KP) {
+        float a[KP], b[KP];
+        const int kb = k0 + h * KP;
+        if (VEC) {  // Co % 64 == 0
+            const int rr = l31 < R ? l31 : 0;
+            const float rmask = l31 < R ? 1.f : 0.f, cmask = colok ? 1.f : 0.f;
+            const int cc = colok ? col : 0;
+#pragma unroll
+            for (int t = 0; t < KP; t += 4) {
+                const float4 av = g.dz.template load_c4<true, ZMODE>(rr, kb + t);
+                a[t] = av.x * rmask, a[t + 1] = av.y * rmask, a[t + 2] = av.z * rmask, a[t + 3] = av.w * rmask;
+            }
+#pragma unroll
+            for (int t = 0; t < KP; ++t) b[t] = g.w.w[(size_t)(kb + t) * Ci + cc] * cmask;  // coalesced over lanes
+        } else {
+#pragma unroll
+            for (int t = 0; t < KP; ++t) {
+                const int k = kb + t;  // co
+                a[t] = g.dz.template at<ZMODE>(l31, k);
+                const bool ok = colok && k < Co;
+                b[t] = g.w.w[ok ? (size_t)k * Ci + col : 0] * (ok ? 1.f : 0.f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KP; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+    wave_sum_to_wave0(acc, lds);
+    if (wave != 0) return;
+    constexpr bool masked = PMODE == ACT_BN_RELU;
+    float sc = 0.f, sh = 0.f;
+    if (masked && colok) sc = g.prev.scale[col], sh = g.prev.shift[col];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = frag_row(e, lane);
+        if (row < R && colok) {
+            float v = acc[e];
+            if (masked) {
+                const float zp = g.prev.z[(size_t)row * Ci + col];
+                v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
+                s0 += v;
+                s1 += v * zp;
+            }
+            g.dyprev[(size_t)row * Ci + col] = v;
+        }
+    }
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    if (masked && g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Ci + col] = s1;
+}
+
+// dW[Co][Ci] (and db[Co] through the ones column) = dZ^T . act(prev), K = R <= 32: one wave per 32x32 output tile,
+// no partials.
+template <int ZMODE, int PMODE>
+__global__ void __launch_bounds__(256) small_wgrad_kernel(WgradArgs g, float *__restrict__ dW, float *__restrict__ db,
+                                                          int tiles_n, int ntiles)
+{
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+    const int Co = g.dz.ch, Ci = g.prev.ch, Ce = g.ncols, R = g.dz.rows;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float a[16], b[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int r = h * 16 + t;
+        a[t] = g.dz.template at<ZMODE>(r, m0 + l31);
+        b[t] = g.prev.template at<PMODE>(r, n0 + l31);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    (void)R;
+    const int col = n0 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + frag_row(e, lane);
+        if (row < Co && col < Ce) {
+            if (col < Ci)
+                dW[(size_t)row * Ci + col] = acc[e];
+            else if (db)
+                db[row] = acc[e];
+        }
     }
 }
 
@@ -489,31 +762,42 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(int nsplit, int Co, i
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (tiny kernels, one thread per channel)
 // ------------------------------------------------------------------------------------------------
-// Sum the [nblk][2][C] partials of channel c over the workgroup's 8 slices (32 channels x 8 slices per workgroup),
+// Sum the [nblk][2][C] partials of channel c over the workgroup's 32 slices (32 channels x 32 slices = 1024 threads),
 // in double, fixed order.  Returns true on the threads (slice 0) that hold the totals.
+constexpr int kSlices = 32;
 __device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__restrict__ stats, double &s0, double &s1)
 {
-    __shared__ double red[2][8][32];
+    __shared__ double red[2][kSlices][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a0 = 0.0, a1 = 0.0;
-    if (c < C)
-        for (int b = sl; b < nblk; b += 8) {
+    if (c < C) {
+        int b = sl;
+        for (; b + 3 * kSlices < nblk; b += 4 * kSlices) {  // 8 independent loads in flight
+            const float x0 = stats[((size_t)b * 2 + 0) * C + c], y0 = stats[((size_t)b * 2 + 1) * C + c];
+            const float x1 = stats[((size_t)(b + kSlices) * 2 + 0) * C + c], y1 = stats[((size_t)(b + kSlices) * 2 + 1) * C + c];
+            const float x2 = stats[((size_t)(b + 2 * kSlices) * 2 + 0) * C + c], y2 = stats[((size_t)(b + 2 * kSlices) * 2 + 1) * C + c];
+            const float x3 = stats[((size_t)(b + 3 * kSlices) * 2 + 0) * C + c], y3 = stats[((size_t)(b + 3 * kSlices) * 2 + 1) * C + c];
+            a0 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+            a1 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+        }
+        for (; b < nblk; b += kSlices) {
             a0 += (double)stats[((size_t)b * 2 + 0) * C + c];
             a1 += (double)stats[((size_t)b * 2 + 1) * C + c];
         }
+    }
     red[0][sl][cl] = a0, red[1][sl][cl] = a1;
     __syncthreads();
     if (sl != 0 || c >= C) return false;
     s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s0 += red[0][q][cl], s1 += red[1][q][cl];
+    for (int q = 0; q < kSlices; ++q) s0 += red[0][q][cl], s1 += red[1][q][cl];
     return true;
 }
 
 // training: batch statistics from the forward partials -> coef [4][C] = scale, shift, mean, invstd;
 // running statistics updated as torch.nn.BatchNorm1d does (unbiased variance, momentum).
-__global__ void __launch_bounds__(256) bn_finalize_kernel(int nblk, int C, long long R, const float *__restrict__ stats,
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(int nblk, int C, long long R, const float *__restrict__ stats,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           float eps, float momentum, float *__restrict__ running_mean,
                                                           float *__restrict__ running_var,
@@ -558,7 +842,7 @@ __global__ void bn_eval_coef_kernel(int C, const float *__restrict__ gamma, cons
 //   dZ = scale * (dY - dbeta/R - zhat * dgamma/R),  zhat = (Z - mean) invstd
 //      = k1 dY + k2 Z + k3
 // dbias (gradient of the conv/linear bias in front of the BN) = sum_r dZ = k1 sum dY + k2 R mean + R k3 (== 0 up to rounding).
-__global__ void __launch_bounds__(256) bn_bwd_coef_kernel(int nblk, int C, long long R, const float *__restrict__ stats,
+__global__ void __launch_bounds__(1024) bn_bwd_coef_kernel(int nblk, int C, long long R, const float *__restrict__ stats,
                                                           const float *__restrict__ coef, float *__restrict__ dgamma,
                                                           float *__restrict__ dbeta, float *__restrict__ dbias,
                                                           float *__restrict__ kcoef)
@@ -635,27 +919,39 @@ __global__ void __launch_bounds__(1024) pool_fwd_kernel(int N, int C, const floa
 
 // backward of the pooling: gsel = g * [pooled > 0]; BN-backward partial sums of the last conv layer
 // (one partial block: sum_b gsel, sum_b gsel * zsel), summed over b in ascending order.
-__global__ void pool_bwd_kernel(int B, int C, const float *__restrict__ g, const float *__restrict__ pooled,
-                                const float *__restrict__ zsel, float *__restrict__ gsel, float *__restrict__ stats)
+__global__ void __launch_bounds__(1024) pool_bwd_kernel(int B, int C, const float *__restrict__ g,
+                                                        const float *__restrict__ pooled, const float *__restrict__ zsel,
+                                                        float *__restrict__ gsel, float *__restrict__ stats)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // 64 channels x 16 batch slices per workgroup; slices and the final 16-way sum run in a fixed order
+    __shared__ float red[2][16][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f, sz = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const size_t o = (size_t)b * C + c;
-        const float v = pooled[o] > 0.f ? g[o] : 0.f;
-        gsel[o] = v;
-        s += v;
-        sz += v * zsel[o];
+    if (c < C)
+        for (int b = sl; b < B; b += 16) {
+            const size_t o = (size_t)b * C + c;
+            const float v = pooled[o] > 0.f ? g[o] : 0.f;
+            gsel[o] = v;
+            s += v;
+            sz += v * zsel[o];
+        }
+    red[0][sl][cl] = s, red[1][sl][cl] = sz;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a0 += red[0][q][cl], a1 += red[1][q][cl];
+        stats[c] = a0;
+        stats[C + c] = a1;
     }
-    stats[c] = s;
-    stats[C + c] = sz;
 }
 
 // ------------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------------
-using TileBig = Tile<128, 64, 4, 1>;    // R large: 128 rows x 64 cols per 256-thread workgroup
+using TileBig = Tile<64, 64, 2, 2>;     // R large: 64 rows x 64 cols per 256-thread workgroup -> >= 2 workgroups per CU
+                                        // at B*N = 32768 rows, so one workgroup's load latency hides under another's MFMAs
 using TileSmall = Tile<32, 128, 1, 4>;  // R small (FC head at small batch): 32 rows x 128 cols
 using TileW = Tile<64, 64, 2, 2>;       // weight gradient: Co x (Ci+1) output tile
 
@@ -678,6 +974,35 @@ static ActSrc make_act(const float *z, const float *coef, int rows, int ch, int 
     return a;
 }
 
+// ---- dispatch helpers: tile x fast-path x operand modes are template parameters (no control flow around loads) ----
+#define SN_LAUNCH_T(KERN, T_, FULL_, GRID, ARGS, ...)                                                              \
+    do {                                                                                                           \
+        if (FULL_)                                                                                                 \
+            hipLaunchKernelGGL((KERN<T_, true, __VA_ARGS__>), GRID, dim3(T_::THREADS), lds_bytes<T_>(), st, ARGS); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((KERN<T_, false, __VA_ARGS__>), GRID, dim3(T_::THREADS), lds_bytes<T_>(), st, ARGS); \
+    } while (0)
+
+template <int AMODE>
+static void launch_fwd(const FwdArgs &g, hipStream_t st)
+{
+    const int R = g.a.rows, Ci = g.w.ci, Co = g.w.co;
+    if (R <= 32) {
+        if (Ci % 64 == 0)
+            hipLaunchKernelGGL((small_fwd_kernel<AMODE, true>), dim3((Co + 31) / 32), dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL((small_fwd_kernel<AMODE, false>), dim3((Co + 31) / 32), dim3(256), 0, st, g);
+    } else if (R > 64) {
+        dim3 grid((R + TileBig::BM - 1) / TileBig::BM, (Co + TileBig::BN - 1) / TileBig::BN);
+        const bool full = R % TileBig::BM == 0 && Co % TileBig::BN == 0 && Ci % BK == 0;
+        SN_LAUNCH_T(linear_fwd_kernel, TileBig, full, grid, g, AMODE);
+    } else {
+        dim3 grid((R + TileSmall::BM - 1) / TileSmall::BM, (Co + TileSmall::BN - 1) / TileSmall::BN);
+        const bool full = R % TileSmall::BM == 0 && Co % TileSmall::BN == 0 && Ci % BK == 0;
+        SN_LAUNCH_T(linear_fwd_kernel, TileSmall, full, grid, g, AMODE);
+    }
+}
+
 extern "C" int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
                                  const float *bias, float *z, float *stats, sn_stream_t stream)
 {
@@ -688,13 +1013,10 @@ extern "C" int sn_linear_forward(int R, int Ci, int Co, const float *ain, const 
     g.w.w = W, g.w.co = Co, g.w.ci = Ci;
     g.bias = bias, g.z = z, g.stats = stats;
     hipStream_t st = (hipStream_t)stream;
-    if (R > 64) {
-        dim3 grid((R + TileBig::BM - 1) / TileBig::BM, (Co + TileBig::BN - 1) / TileBig::BN);
-        hipLaunchKernelGGL(linear_fwd_kernel<TileBig>, grid, dim3(TileBig::THREADS), lds_bytes<TileBig>(), st, g);
-    } else {
-        dim3 grid((R + TileSmall::BM - 1) / TileSmall::BM, (Co + TileSmall::BN - 1) / TileSmall::BN);
-        hipLaunchKernelGGL(linear_fwd_kernel<TileSmall>, grid, dim3(TileSmall::THREADS), lds_bytes<TileSmall>(), st, g);
-    }
+    if (coef_prev)
+        launch_fwd<ACT_BN_RELU>(g, st);
+    else
+        launch_fwd<ACT_NONE>(g, st);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -711,24 +1033,46 @@ static DzSrc make_dz(int mode, const float *dy, const float *z, const float *kco
     return d;
 }
 
+template <int ZMODE, int PMODE>
+static void launch_dgrad(const DgradArgs &g, hipStream_t st)
+{
+    const int R = g.dz.rows, Ci = g.w.ci, Co = g.w.co;
+    if (R <= 32) {
+        if (Co % 64 == 0)
+            hipLaunchKernelGGL((small_dgrad_kernel<ZMODE, PMODE, true>), dim3((Ci + 31) / 32), dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL((small_dgrad_kernel<ZMODE, PMODE, false>), dim3((Ci + 31) / 32), dim3(256), 0, st, g);
+    } else if (R > 64) {
+        dim3 grid((R + TileBig::BM - 1) / TileBig::BM, (Ci + TileBig::BN - 1) / TileBig::BN);
+        const bool full = R % TileBig::BM == 0 && Ci % TileBig::BN == 0 && Co % BK == 0;
+        SN_LAUNCH_T(linear_dgrad_kernel, TileBig, full, grid, g, ZMODE, PMODE);
+    } else {
+        dim3 grid((R + TileSmall::BM - 1) / TileSmall::BM, (Ci + TileSmall::BN - 1) / TileSmall::BN);
+        const bool full = R % TileSmall::BM == 0 && Ci % TileSmall::BN == 0 && Co % BK == 0;
+        SN_LAUNCH_T(linear_dgrad_kernel, TileSmall, full, grid, g, ZMODE, PMODE);
+    }
+}
+
 extern "C" int sn_linear_dgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                                const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                                const float *coef_prev, float *dyprev, float *stats, sn_stream_t stream)
 {
     SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
     SN_REQUIRE(W && dyprev, "null pointer");
+    SN_REQUIRE(dz_mode >= DZ_PLAIN && dz_mode <= DZ_POOL, "bad dz_mode");
     DgradArgs g{};
     g.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
     g.w.w = W, g.w.co = Co, g.w.ci = Ci;
     g.prev = make_act(zprev, coef_prev, R, Ci);
     g.dyprev = dyprev, g.stats = stats;
     hipStream_t st = (hipStream_t)stream;
-    if (R > 64) {
-        dim3 grid((R + TileBig::BM - 1) / TileBig::BM, (Ci + TileBig::BN - 1) / TileBig::BN);
-        hipLaunchKernelGGL(linear_dgrad_kernel<TileBig>, grid, dim3(TileBig::THREADS), lds_bytes<TileBig>(), st, g);
+    const bool pm = coef_prev != nullptr;
+    if (dz_mode == DZ_PLAIN) {
+        if (pm) launch_dgrad<DZ_PLAIN, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_PLAIN, ACT_NONE>(g, st);
+    } else if (dz_mode == DZ_BN) {
+        if (pm) launch_dgrad<DZ_BN, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_BN, ACT_NONE>(g, st);
     } else {
-        dim3 grid((R + TileSmall::BM - 1) / TileSmall::BM, (Ci + TileSmall::BN - 1) / TileSmall::BN);
-        hipLaunchKernelGGL(linear_dgrad_kernel<TileSmall>, grid, dim3(TileSmall::THREADS), lds_bytes<TileSmall>(), st, g);
+        if (pm) launch_dgrad<DZ_POOL, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_POOL, ACT_NONE>(g, st);
     }
     SN_LAUNCH_CHECK();
     return 0;
@@ -736,11 +1080,33 @@ extern "C" int sn_linear_dgrad(int R, int Ci, int Co, int dz_mode, const float *
 
 extern "C" int sn_linear_wgrad_splits(int R, int Ci, int Co, int with_bias)
 {
+    if (R <= 32) return 1;  // small path writes dW directly (scratch unused)
     const int ncols = Ci + (with_bias ? 1 : 0);
     const int tiles = ((Co + TileW::BM - 1) / TileW::BM) * ((ncols + TileW::BN - 1) / TileW::BN);
     const int want = std::max(1, 512 / tiles);                       // aim at ~2 workgroups per CU
-    const int maxsplit = std::max(1, (R + 4 * BK - 1) / (4 * BK));   // at least 128 rows per split
+    const int maxsplit = std::max(1, (R + 2 * BK - 1) / (2 * BK));   // at least 128 rows per split
     return std::max(1, std::min(want, maxsplit));
+}
+
+template <int ZMODE, int PMODE>
+static void launch_wgrad(WgradArgs &g, int R, int Ci, int Co, int with_bias, float *dW, float *db, hipStream_t st)
+{
+    if (R <= 32) {  // K = R fits one MFMA K range: one wave per 32x32 output tile, written directly
+        const int tm = (Co + 31) / 32, tn = (g.ncols + 31) / 32;
+        hipLaunchKernelGGL((small_wgrad_kernel<ZMODE, PMODE>), dim3((tm * tn + 3) / 4), dim3(256), 0, st, g, dW, db, tn,
+                           tm * tn);
+        return;
+    }
+    const int nsplit = sn_linear_wgrad_splits(R, Ci, Co, with_bias);
+    int rps = (R + nsplit - 1) / nsplit;
+    rps = ((rps + BK - 1) / BK) * BK;
+    g.rows_per_split = rps;
+    dim3 grid((Co + TileW::BM - 1) / TileW::BM, (g.ncols + TileW::BN - 1) / TileW::BN, nsplit);
+    // fast path: every split covers whole K chunks of in-range rows and whole output tiles
+    const bool full = !with_bias && Co % TileW::BM == 0 && Ci % TileW::BN == 0 && R % rps == 0;
+    SN_LAUNCH_T(linear_wgrad_kernel, TileW, full, grid, g, ZMODE, PMODE);
+    const int tot = Co * g.ncols;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, st, nsplit, Co, Ci, g.ncols, g.part, dW, db);
 }
 
 // part: scratch of sn_linear_wgrad_splits(...) * Co * (Ci + with_bias) floats.  db may be NULL (no bias column).
@@ -750,21 +1116,25 @@ extern "C" int sn_linear_wgrad(int R, int Ci, int Co, int dz_mode, const float *
 {
     SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
     SN_REQUIRE(aprev && part && dW, "null pointer");
+    SN_REQUIRE(dz_mode >= DZ_PLAIN && dz_mode <= DZ_POOL, "bad dz_mode");
     const int with_bias = db != nullptr;
     WgradArgs g{};
     g.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
     g.prev = make_act(aprev, coef_prev, R, Ci, with_bias ? Ci : -1);
     g.ncols = Ci + with_bias;
-    const int nsplit = sn_linear_wgrad_splits(R, Ci, Co, with_bias);
-    int rps = (R + nsplit - 1) / nsplit;
-    rps = ((rps + BK - 1) / BK) * BK;
-    g.rows_per_split = rps;
     g.part = part;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((Co + TileW::BM - 1) / TileW::BM, (g.ncols + TileW::BN - 1) / TileW::BN, nsplit);
-    hipLaunchKernelGGL(linear_wgrad_kernel<TileW>, grid, dim3(TileW::THREADS), lds_bytes<TileW>(), st, g);
-    const int tot = Co * g.ncols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, st, nsplit, Co, Ci, g.ncols, part, dW, db);
+    const bool pm = coef_prev != nullptr;
+    if (dz_mode == DZ_PLAIN) {
+        if (pm) launch_wgrad<DZ_PLAIN, ACT_BN_RELU>(g, R, Ci, Co, with_bias, dW, db, st);
+        else launch_wgrad<DZ_PLAIN, ACT_NONE>(g, R, Ci, Co, with_bias, dW, db, st);
+    } else if (dz_mode == DZ_BN) {
+        if (pm) launch_wgrad<DZ_BN, ACT_BN_RELU>(g, R, Ci, Co, with_bias, dW, db, st);
+        else launch_wgrad<DZ_BN, ACT_NONE>(g, R, Ci, Co, with_bias, dW, db, st);
+    } else {
+        if (pm) launch_wgrad<DZ_POOL, ACT_BN_RELU>(g, R, Ci, Co, with_bias, dW, db, st);
+        else launch_wgrad<DZ_POOL, ACT_NONE>(g, R, Ci, Co, with_bias, dW, db, st);
+    }
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -774,7 +1144,7 @@ extern "C" int sn_bn_finalize(int nblk, int C, long long R, const float *stats, 
                               long long *num_batches_tracked, float *coef, sn_stream_t stream)
 {
     SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && gamma && beta && coef, "bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, nblk, C, R, stats, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, nblk, C, R, stats, gamma,
                        beta, eps, momentum, running_mean, running_var, num_batches_tracked, coef);
     SN_LAUNCH_CHECK();
     return 0;
@@ -794,7 +1164,7 @@ extern "C" int sn_bn_backward_coef(int nblk, int C, long long R, const float *st
                                    float *dbeta, float *dbias, float *kcoef, sn_stream_t stream)
 {
     SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && coef && dgamma && dbeta && kcoef, "bad argument");
-    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, nblk, C, R, stats, coef,
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, nblk, C, R, stats, coef,
                        dgamma, dbeta, dbias, kcoef);
     SN_LAUNCH_CHECK();
     return 0;
@@ -814,8 +1184,8 @@ extern "C" int sn_pool_backward(int B, int C, const float *g, const float *poole
                                 float *stats, sn_stream_t stream)
 {
     SN_REQUIRE(B >= 1 && C >= 1 && g && pooled && zsel && gsel && stats, "bad argument");
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, C, g, pooled, zsel, gsel,
-                       stats);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, B, C, g, pooled, zsel,
+                       gsel, stats);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -196,10 +196,12 @@ class SoftProjectFunction(torch.autograd.Function):
             dp = torch.empty(B, N, device=dev, dtype=torch.float32)
             ip = torch.empty(B, N, device=dev, dtype=torch.int32)
         T = temperature.detach().float().reshape(1)
+        wsb = lib.sn_pairscan_workspace_bytes(B, N, M) if want_chamfer else 0
+        ws = torch.empty(wsb // 8, device=dev, dtype=torch.int64) if wsb else None
         with torch.cuda.device(dev):
-            check(lib.sn_pairscan_forward(B, N, M, K, ptr(P), BCN, ptr(Q), BCN, ptr(idx), None, ptr(dq), ptr(iq),
-                                          ptr(dp), ptr(ip), ptr(proj), BCN, None, ptr(T), float(min_sigma), _stream(P)),
-                  "sn_pairscan_forward")
+            check(lib.sn_pairscan_forward_ws(B, N, M, K, ptr(P), BCN, ptr(Q), BCN, ptr(idx), None, ptr(dq), ptr(iq),
+                                             ptr(dp), ptr(ip), ptr(proj), BCN, None, ptr(T), float(min_sigma), ptr(ws), wsb,
+                                             _stream(P)), "sn_pairscan_forward_ws")
         ctx.save_for_backward(P, Q, idx, temperature)
         ctx.min_sigma = float(min_sigma)
         ctx.K = K
@@ -218,7 +220,7 @@ class SoftProjectFunction(torch.autograd.Function):
         grad_proj = grad_proj.contiguous()
         gQ = torch.empty_like(Q)
         gP = torch.zeros_like(P) if ctx.needs_input_grad[0] else None
-        gsig = torch.empty(B, device=dev, dtype=torch.float32)
+        gsig = torch.empty(B * lib.sn_soft_bwd_splits(B, M), device=dev, dtype=torch.float32)
         T = temperature.detach().float().reshape(1)
         with torch.cuda.device(dev):
             check(lib.sn_soft_project_backward(B, N, M, ctx.K, ptr(P), BCN, ptr(Q), BCN, ptr(idx), ptr(T), ctx.min_sigma,
@@ -258,7 +260,7 @@ class SoftWeightsFunction(torch.autograd.Function):
         grad_w = grad_w.contiguous()
         gQ = torch.empty_like(Q)
         gP = torch.zeros_like(P) if ctx.needs_input_grad[0] else None
-        gsig = torch.empty(B, device=P.device, dtype=torch.float32)
+        gsig = torch.empty(B * lib.sn_soft_bwd_splits(B, M), device=P.device, dtype=torch.float32)
         T = temperature.detach().float().reshape(1)
         with torch.cuda.device(P.device):
             check(lib.sn_soft_weights_backward(B, N, M, K, ptr(P), ptr(Q), ptr(idx), ptr(T), ctx.min_sigma, ptr(w),
@@ -319,6 +321,43 @@ class ChamferFromScanFunction(torch.autograd.Function):
         g1, g2 = chamfer_backward_impl(xyz1.contiguous(), xyz2.contiguous(), idx1, idx2, graddist1, graddist2,
                                        ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return g1, g2, None, None, None, None
+
+
+class SimplificationLossFunction(torch.autograd.Function):
+    """Fused simplification loss (samplenet.py:171-181) on Chamfer products that already exist:
+        loss = mean(dist1) + mean_b(max_m dist1) + weight * mean(dist2)
+    forward(samp_pc (B,M,3), ref_pc (B,N,3), dist1 (B,M), idx1, dist2 (B,N), idx2, weight) -> scalar loss.
+    Backward goes straight to grad(samp_pc) / grad(ref_pc) through sn_simplification_loss_backward."""
+
+    @staticmethod
+    def forward(ctx, samp_pc, ref_pc, dist1, idx1, dist2, idx2, weight):
+        _need_gpu(samp_pc, ref_pc, dist1, dist2)
+        B, M = dist1.shape
+        N = dist2.shape[1]
+        dev = dist1.device
+        partial = torch.empty(B * 3, device=dev, dtype=torch.float32)
+        argmax1 = torch.empty(B, device=dev, dtype=torch.int32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            check(lib.sn_simplification_loss_forward(B, M, N, ptr(dist1), ptr(dist2), float(weight), ptr(partial),
+                                                     ptr(argmax1), ptr(loss), _stream(dist1)), "sn_simplification_loss_forward")
+        ctx.save_for_backward(samp_pc, ref_pc, idx1, idx2, argmax1)
+        ctx.weight = float(weight)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        samp_pc, ref_pc, idx1, idx2, argmax1 = ctx.saved_tensors
+        x1, x2 = samp_pc.contiguous(), ref_pc.contiguous()
+        B, M, _ = x1.shape
+        N = x2.shape[1]
+        g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
+        gl = grad_loss.contiguous().float()
+        with torch.cuda.device(x1.device):
+            check(lib.sn_simplification_loss_backward(B, M, ptr(x1), N, ptr(x2), ptr(idx1), ptr(idx2), ptr(argmax1), ctx.weight,
+                                                      ptr(gl), ptr(g1), ptr(g2), _stream(x1)), "sn_simplification_loss_backward")
+        return g1, g2, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- EMD

@@ -174,17 +174,13 @@ class SampleNet(nn.Module):
             return torch.tensor(0).to(ref_pc)
         # ref_pc and samp_pc are B x N x 3 matrices
         scan = self._scan_hit(ref_pc, samp_pc)
-        if scan is not None:
+        if scan is not None:  # Chamfer products of this very pair were produced by forward()'s pair scan
             dq, iq, dp, ip = scan
-            cost_p1_p2, cost_p2_p1 = ops.ChamferFromScanFunction.apply(samp_pc, ref_pc, dq, iq, dp, ip)
         else:
-            cost_p1_p2, cost_p2_p1 = ChamferDistance()(samp_pc, ref_pc)
-        max_cost = torch.max(cost_p1_p2, dim=1)[0]  # furthest point
-        max_cost = torch.mean(max_cost)
-        cost_p1_p2 = torch.mean(cost_p1_p2)
-        cost_p2_p1 = torch.mean(cost_p2_p1)
-        loss = cost_p1_p2 + max_cost + (gamma + delta * pc_size) * cost_p2_p1
-        return loss
+            _, _, dq, iq, dp, ip = ops.chamfer_forward_impl(samp_pc.detach(), ref_pc.detach())
+        # cost_p1_p2 = mean(dq); max_cost = mean_b(max_m dq); cost_p2_p1 = mean(dp)
+        # loss = cost_p1_p2 + max_cost + (gamma + delta * pc_size) * cost_p2_p1      -- one fused kernel pair
+        return ops.SimplificationLossFunction.apply(samp_pc, ref_pc, dq, iq, dp, ip, gamma + delta * pc_size)
 
     def get_projection_loss(self):
         sigma = self.project.sigma()

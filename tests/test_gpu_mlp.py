@@ -35,40 +35,54 @@ def _rel(a, b):
 
 
 CFGS = [(4, 1024, 64, 8, 128, "bnc"), (3, 96, 12, 5, 32, "bcn"), (32, 1024, 64, 8, 128, "bnc"), (6, 130, 7, 4, 40, "bnc"),
-        (70, 64, 16, 4, 128, "bnc")]
+        (70, 64, 16, 4, 128, "bnc"), (33, 1024, 64, 8, 128, "bnc"), (48, 512, 32, 8, 64, "bnc")]
 
 
 @pytest.mark.parametrize("cfg", CFGS)
 def test_mlp_forward_backward_vs_torch(cfg):
+    """Three implementations of the same network on the same weights / inputs: the HIP kernels (fp32 MFMA), the torch
+    fp32 modules (MIOpen / rocBLAS) and the torch fp64 modules.  Bar: the HIP result is as close to the fp64 result as
+    torch's own fp32 path is (factor 2), or within 2e-4 -- torch-fp32 itself drifts up to a few 1e-2 from fp64 on some
+    shapes (measured: conv1.weight at B=33), so it cannot serve as the only yardstick.  Where the fp64 run takes a
+    different max-pool / ReLU branch than both fp32 runs, the two fp32 runs are compared with each other instead."""
     B, N, M, K, bneck, shape = cfg
     hip, ref, x = _pair(*cfg)
-    hip.train(), ref.train()
-    y_h = hip._features(x if shape == "bcn" else x.permute(0, 2, 1), x if shape == "bnc" else None)
-    y_r = ref._features(x if shape == "bcn" else x.permute(0, 2, 1))
+    ref64 = copy.deepcopy(ref).double()
+    for net in (hip, ref, ref64):
+        net.train()
+    xb = x if shape == "bcn" else x.permute(0, 2, 1)
+    y_h = hip._features(xb, x if shape == "bnc" else None)
+    y_r = ref._features(xb)
+    y_d = ref64._features(xb.double())
     assert y_h.shape == y_r.shape == (B, 3, M)
-    # small-batch BatchNorm in the FC head amplifies fp32 summation-order noise (2e-4 relative at B=3..4, 6e-5 at B=32)
-    assert _rel(y_h.detach(), y_r.detach()) < 3e-4
+    e_h, e_r = _rel(y_h.detach(), y_d.detach()), _rel(y_r.detach(), y_d.detach())
+    # BatchNorm over a batch of only 3-6 samples in the FC head amplifies fp32 summation-order noise (~3e-4 there)
+    floor = 2e-4 if B >= 16 else 6e-4
+    assert e_h <= max(floor, 2 * e_r) or _rel(y_h.detach(), y_r.detach()) < floor, (e_h, e_r)
     g = torch.randn_like(y_r)
     (y_h * g).sum().backward()
     (y_r * g).sum().backward()
-    for (n, ph), (_, pr) in zip(hip.named_parameters(), ref.named_parameters()):
+    (y_d * g.double()).sum().backward()
+    wnorm = {n: float(p.grad.norm()) for n, p in ref64.named_parameters() if p.grad is not None}
+    for (n, ph), (_, pr), (_, pd) in zip(hip.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
         if n.startswith("project"):
             continue
-        nr = float(pr.grad.double().norm())
-        err = float((ph.grad.double() - pr.grad.double()).norm())
         if (n.endswith(".bias") and not n.startswith(("bn", "fc4"))) or n == "bn5.bias":
-            # a bias in front of a BatchNorm: the true gradient is exactly 0; both sides hold rounding noise.
-            # bn5.bias likewise: it is sum_b of the pooled-feature gradient, which the batch-BatchNorm of fc1
-            # makes sum to zero over the batch wherever the pooled feature is positive.
-            wn = float(dict(ref.named_parameters())[n.replace(".bias", ".weight")].grad.double().norm())
-            assert float(ph.grad.double().norm()) <= 1e-3 * wn + 1e-6 and nr <= 1e-3 * wn + 1e-6, (n, err, nr, wn)
-        else:
-            assert err <= 2e-3 * nr, (n, err / nr)
-    for (n, bh), (_, br) in zip(hip.named_buffers(), ref.named_buffers()):
+            # a bias in front of a BatchNorm: the true gradient is exactly 0 (fp64 gives ~1e-12); fp32 holds rounding
+            # noise.  bn5.bias likewise: sum_b of the pooled-feature gradient, which fc1's batch-BatchNorm makes
+            # vanish over the batch wherever the pooled feature is positive.
+            assert float(ph.grad.double().norm()) <= 1e-3 * wnorm[n.replace(".bias", ".weight")] + 1e-6, n
+            continue
+        nd = float(pd.grad.norm())
+        err_h = float((ph.grad.double() - pd.grad).norm()) / nd
+        err_r = float((pr.grad.double() - pd.grad).norm()) / nd
+        err_hr = float((ph.grad.double() - pr.grad.double()).norm()) / nd
+        assert err_h <= max(floor, 2 * err_r) or err_hr <= (2e-3 if B >= 16 else 5e-3), (n, err_h, err_r, err_hr)
+    for (n, bh), (_, bd) in zip(hip.named_buffers(), ref64.named_buffers()):
         if bh.dtype == torch.long:
-            assert int(bh) == int(br) == 1, n
+            assert int(bh) == int(bd) == 1, n
         else:
-            assert torch.allclose(bh, br, rtol=1e-4, atol=1e-5), n
+            assert torch.allclose(bh.double(), bd, rtol=1e-4, atol=1e-5), n
 
 
 def test_mlp_eval_mode_vs_torch():
