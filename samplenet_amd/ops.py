@@ -176,18 +176,21 @@ class SoftProjectFunction(torch.autograd.Function):
     in ONE kernel (sn_pairscan_forward), optionally together with both Chamfer directions between the
     query cloud and the point cloud (the sampler's simplification loss reuses them).
 
-    forward(point_cloud (B,3,N), query_cloud (B,3,M), temperature (scalar tensor), min_sigma, K, want_chamfer)
-      -> proj (B,3,M), idx (B,M,K) [, dist_q (B,M), idx_q, dist_p (B,N), idx_p]
+    forward(point_cloud, query_cloud (B,3,M), temperature (scalar tensor), min_sigma, K, want_chamfer,
+            p_layout=BCN, out_layout=BCN)
+      point_cloud: (B,3,N) for BCN or (B,N,3) for BNC (the kernels read either layout: no transposed copy)
+      -> proj (B,3,M) for BCN / (B,M,3) for BNC, idx (B,M,K) [, dist_q (B,M), idx_q, dist_p (B,N), idx_p]
     """
 
     @staticmethod
-    def forward(ctx, point_cloud, query_cloud, temperature, min_sigma, K, want_chamfer):
+    def forward(ctx, point_cloud, query_cloud, temperature, min_sigma, K, want_chamfer, p_layout=BCN, out_layout=BCN):
         _need_gpu(point_cloud, query_cloud, temperature)
         P, Q = _f32c(point_cloud), _f32c(query_cloud)
-        B, _, N = P.shape
+        B = P.shape[0]
+        N = P.shape[2] if p_layout == BCN else P.shape[1]
         M = Q.shape[2]
         dev = P.device
-        proj = torch.empty(B, 3, M, device=dev, dtype=torch.float32)
+        proj = torch.empty((B, 3, M) if out_layout == BCN else (B, M, 3), device=dev, dtype=torch.float32)
         idx = torch.empty(B, M, K, device=dev, dtype=torch.int32)
         dq = iq = dp = ip = None
         if want_chamfer:
@@ -199,23 +202,22 @@ class SoftProjectFunction(torch.autograd.Function):
         wsb = lib.sn_pairscan_workspace_bytes(B, N, M) if want_chamfer else 0
         ws = torch.empty(wsb // 8, device=dev, dtype=torch.int64) if wsb else None
         with torch.cuda.device(dev):
-            check(lib.sn_pairscan_forward_ws(B, N, M, K, ptr(P), BCN, ptr(Q), BCN, ptr(idx), None, ptr(dq), ptr(iq),
-                                             ptr(dp), ptr(ip), ptr(proj), BCN, None, ptr(T), float(min_sigma), ptr(ws), wsb,
-                                             _stream(P)), "sn_pairscan_forward_ws")
+            check(lib.sn_pairscan_forward_ws(B, N, M, K, ptr(P), p_layout, ptr(Q), BCN, ptr(idx), None, ptr(dq), ptr(iq),
+                                             ptr(dp), ptr(ip), ptr(proj), out_layout, None, ptr(T), float(min_sigma), ptr(ws),
+                                             wsb, _stream(P)), "sn_pairscan_forward_ws")
         ctx.save_for_backward(P, Q, idx, temperature)
         ctx.min_sigma = float(min_sigma)
-        ctx.K = K
+        ctx.K, ctx.N, ctx.p_layout, ctx.out_layout = K, N, p_layout, out_layout
         ctx.mark_non_differentiable(idx)
         if want_chamfer:
-            ctx.mark_non_differentiable(dq, iq, dp, ip)  # their gradient is taken by ChamferFromScan
+            ctx.mark_non_differentiable(dq, iq, dp, ip)  # their gradient is taken by the loss functions below
             return proj, idx, dq, iq, dp, ip
         return proj, idx
 
     @staticmethod
     def backward(ctx, grad_proj, *_unused):
         P, Q, idx, temperature = ctx.saved_tensors
-        B, _, N = P.shape
-        M = Q.shape[2]
+        B, N, M = P.shape[0], ctx.N, Q.shape[2]
         dev = P.device
         grad_proj = grad_proj.contiguous()
         gQ = torch.empty_like(Q)
@@ -223,13 +225,13 @@ class SoftProjectFunction(torch.autograd.Function):
         gsig = torch.empty(B * lib.sn_soft_bwd_splits(B, M), device=dev, dtype=torch.float32)
         T = temperature.detach().float().reshape(1)
         with torch.cuda.device(dev):
-            check(lib.sn_soft_project_backward(B, N, M, ctx.K, ptr(P), BCN, ptr(Q), BCN, ptr(idx), ptr(T), ctx.min_sigma,
-                                               ptr(grad_proj), BCN, ptr(gQ), BCN, ptr(gP), ptr(gsig), _stream(P)),
-                  "sn_soft_project_backward")
+            check(lib.sn_soft_project_backward(B, N, M, ctx.K, ptr(P), ctx.p_layout, ptr(Q), BCN, ptr(idx), ptr(T),
+                                               ctx.min_sigma, ptr(grad_proj), ctx.out_layout, ptr(gQ), BCN, ptr(gP), ptr(gsig),
+                                               _stream(P)), "sn_soft_project_backward")
         gT = None
         if ctx.needs_input_grad[2]:
             gT = (gsig.sum() * _dsigma_dT(temperature, ctx.min_sigma)).reshape(temperature.shape)
-        return gP, (gQ if ctx.needs_input_grad[1] else None), gT, None, None, None
+        return gP, (gQ if ctx.needs_input_grad[1] else None), gT, None, None, None, None, None
 
 
 class SoftWeightsFunction(torch.autograd.Function):

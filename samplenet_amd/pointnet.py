@@ -102,14 +102,38 @@ def _out(sink, name, like):
     return torch.empty_like(like)
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """Second stream per device: a layer's weight-gradient GEMM is independent of its data-gradient GEMM, so the two
+    run concurrently (fork / join around the wgrad launch; under hipGraph capture this becomes a parallel branch)."""
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def _wgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, aprev, coef_prev, with_bias, sink=None, name=""):
+    dev = L.W.device
+    main = torch.cuda.current_stream(dev)
     dW = _out(sink, name + ".weight", L.W)
     db = _out(sink, name + ".bias", L.b) if with_bias else None
     nsplit = lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 1 if with_bias else 0)
-    part = _empty((nsplit * L.Co * (L.Ci + (1 if with_bias else 0)),), L.W)
-    check(lib.sn_linear_wgrad(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(aprev),
-                              ptr(coef_prev), ptr(part), ptr(dW), ptr(db), _st(L.W)), "sn_linear_wgrad")
+    side = _side_stream(dev)
+    side.wait_stream(main)  # fork: everything enqueued so far (dy, kcoef, ...) is visible to the side stream
+    with torch.cuda.stream(side):
+        part = _empty((nsplit * L.Co * (L.Ci + (1 if with_bias else 0)),), L.W)
+        check(lib.sn_linear_wgrad(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(aprev),
+                                  ptr(coef_prev), ptr(part), ptr(dW), ptr(db), side.cuda_stream), "sn_linear_wgrad")
+    for t in (dy, z, kcoef, gsel, argsel, aprev, coef_prev, dW, db):
+        if t is not None:
+            t.record_stream(side)  # allocated on the main stream, read / written on the side stream
     return dW, db
+
+
+def _join_side(dev):
+    torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
 
 
 def _dgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev):
@@ -161,6 +185,7 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
         dy, stats, nblk = _dgrad(B, L, DZ_BN, dy, zf[j], kcoef, None, None, 1, aprev, cprev)
     g_pool = dy  # (B, C5): gradient w.r.t. the pooled features
     if after_fc is not None:
+        _join_side(grad_y.device)
         after_fc()
 
     # ---- max-pool + last conv layer's BatchNorm ----
@@ -183,6 +208,7 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
         grads[names_c[i] + ".weight"] = dW
         if i > 0:
             dy, stats, nblk = _dgrad(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev)
+    _join_side(grad_y.device)  # all weight gradients complete before backward returns on the main stream
     return grads
 
 

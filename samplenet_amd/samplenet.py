@@ -116,10 +116,15 @@ class SampleNet(nn.Module):
         proj = None
         scan = None
 
+        proj_is_out_layout = False
         if self.training:
             if not self.skip_projection:
-                x_bcn = x.contiguous()
-                proj, _idx, dq, iq, dp, ip = self.project.project_with_chamfer(x_bcn, y.contiguous())
+                # the pair-scan kernel reads the cloud and writes the projection in either layout: no transposed copies
+                bnc_in, bnc_out = self.input_shape == "bnc", self.output_shape == "bnc"
+                proj, _idx, dq, iq, dp, ip = self.project.project_with_chamfer(
+                    x_in.contiguous() if bnc_in else x.contiguous(), y.contiguous(),
+                    ops.BNC if bnc_in else ops.BCN, ops.BNC if bnc_out else ops.BCN)
+                proj_is_out_layout = True
                 scan = (dq, iq, dp, ip)
             else:
                 proj = simp
@@ -132,7 +137,7 @@ class SampleNet(nn.Module):
 
         if self.output_shape == "bnc":
             simp = simp.permute(0, 2, 1)
-            if proj is not None:
+            if proj is not None and not proj_is_out_layout:
                 proj = proj.permute(0, 2, 1)
         elif self.output_shape == "bcn" and match is not None:
             match = match.permute(0, 2, 1)

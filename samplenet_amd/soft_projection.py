@@ -58,11 +58,12 @@ class SoftProjection(nn.Module):
                                                    self._group_size, False)
         return proj
 
-    def project_with_chamfer(self, point_cloud, query_cloud):
+    def project_with_chamfer(self, point_cloud, query_cloud, p_layout=ops.BCN, out_layout=ops.BCN):
         """project() plus both nearest-neighbour directions between query_cloud and point_cloud from the same
-        distance scan: returns proj (B,3,M), idx (B,M,K), dist_q (B,M), idx_q, dist_p (B,N), idx_p."""
+        distance scan: returns proj, idx (B,M,K), dist_q (B,M), idx_q, dist_p (B,N), idx_p.
+        point_cloud may be given point-major ((B,N,3), p_layout=BNC) and proj requested point-major ((B,M,3))."""
         return ops.SoftProjectFunction.apply(point_cloud, query_cloud, self._temperature, self._min_sigma_f,
-                                             self._group_size, True)
+                                             self._group_size, True, p_layout, out_layout)
 
     # -- split path (features) ------------------------------------------------------------------
     def _weights(self, point_cloud, query_cloud):

@@ -194,7 +194,9 @@ def golden_chamfer(ChamferDistance):
 def golden_samplenet(SampleNet):
     """Config C1 (B=4, 1024 -> 64, K=8) train step as registration/main.py:500-531 issues it, plus eval."""
     out = {}
-    for tag, (B, N, M, K, bneck, shape) in {"c1": (4, 1024, 64, 8, 128, "bnc"), "s": (3, 96, 12, 5, 32, "bcn")}.items():
+    # "m" shares c1's constructor arguments, hence (same seed) its initial state_dict: only x / outputs / grads are stored
+    for tag, (B, N, M, K, bneck, shape) in {"c1": (4, 1024, 64, 8, 128, "bnc"), "s": (3, 96, 12, 5, 32, "bcn"),
+                                            "m": (16, 256, 64, 8, 128, "bnc")}.items():
         torch.manual_seed(0)
         net = SampleNet(M, bneck, group_size=K, initial_temperature=1.0, is_temperature_trainable=True,
                         min_sigma=1e-2, input_shape=shape, output_shape=shape)
@@ -217,8 +219,11 @@ def golden_samplenet(SampleNet):
         gw = torch.randn_like(proj)
         loss = 0.01 * lsimp + 0.01 * lproj + (proj * gw).sum() / proj.numel()
         loss.backward()
-        for k, v in sd0.items():
-            out[f"{tag}_sd_{k}"] = v.numpy()
+        if tag != "m":
+            for k, v in sd0.items():
+                out[f"{tag}_sd_{k}"] = v.numpy()
+        else:
+            assert all(np.array_equal(v.numpy(), out[f"c1_sd_{k}"]) for k, v in sd0.items())
         for k, v in net.state_dict().items():
             if "running" in k or "num_batches" in k:
                 out[f"{tag}_sd1_{k}"] = v.numpy()

@@ -14,7 +14,8 @@ def _build(g, tag, after_step=False, **kw):
     shape = "bnc" if lay == 0 else "bcn"
     net = SampleNet(M, bneck, group_size=K, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-2,
                     input_shape=shape, output_shape=shape, **kw)
-    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_sd_")}
+    sd_tag = "c1" if tag == "m" else tag  # "m" was generated from c1's initial weights (tests/golden/make_golden.py)
+    sd = {k[len(sd_tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{sd_tag}_sd_")}
     if after_step:  # BatchNorm running statistics as they were after the golden training step
         sd.update({k[len(tag) + 5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_sd1_")})
     missing, unexpected = net.load_state_dict(sd, strict=True)  # state_dict keys are part of the drop-in contract
@@ -22,7 +23,7 @@ def _build(g, tag, after_step=False, **kw):
     return net.cuda(), (B, N, M, K, shape)
 
 
-@pytest.mark.parametrize("tag", ["c1", "s"])
+@pytest.mark.parametrize("tag", ["c1", "s", "m"])
 def test_train_step_matches_reference(golden, oracle, tag):
     g = golden("samplenet_reference.npz")
     net, (B, N, M, K, shape) = _build(g, tag)
@@ -31,7 +32,8 @@ def test_train_step_matches_reference(golden, oracle, tag):
     simp, proj = net(x)
     # the MLP output feeds BatchNorm over a batch of only B = 3..4 samples in the FC head, which amplifies the
     # GPU-vs-CPU summation-order noise of the fp32 GEMMs to ~1e-3 on O(1) coordinates (6e-5 at B = 32, test_gpu_mlp.py)
-    np.testing.assert_allclose(simp.detach().cpu().numpy(), g[f"{tag}_simp"], rtol=2e-3, atol=2e-3)
+    tol = 2e-3 if B < 8 else 3e-4
+    np.testing.assert_allclose(simp.detach().cpu().numpy(), g[f"{tag}_simp"], rtol=tol, atol=tol)
     # projection: tight against the oracle on the simplified cloud actually produced ...
     xn = (x if shape == "bnc" else x.permute(0, 2, 1)).contiguous().cpu().numpy()
     sn = (simp if shape == "bnc" else simp.permute(0, 2, 1)).detach().contiguous().cpu().numpy()
@@ -42,7 +44,7 @@ def test_train_step_matches_reference(golden, oracle, tag):
     np.testing.assert_allclose(pn, oproj.transpose(0, 2, 1), rtol=0, atol=1e-6)
     # ... and against the reference run: a 1e-4 shift of a query can swap its K-th/(K+1)-th neighbour (the
     # projection is discontinuous there), so a few entries may legitimately differ
-    close = np.isclose(proj.detach().cpu().numpy(), g[f"{tag}_proj"], rtol=2e-3, atol=2e-3)
+    close = np.isclose(proj.detach().cpu().numpy(), g[f"{tag}_proj"], rtol=tol, atol=tol)
     assert close.mean() >= 0.95
     x_bnc = x if shape == "bnc" else x.permute(0, 2, 1).contiguous()
     simp_bnc = simp if shape == "bnc" else simp.permute(0, 2, 1).contiguous()
@@ -68,15 +70,15 @@ def test_train_step_matches_reference(golden, oracle, tag):
         err = np.linalg.norm(got - ref)
         if nref < 1e-5:      # conv biases in front of BatchNorm: the true gradient is 0, both sides hold rounding noise
             ok = err < 1e-4
-        else:
-            ok = err <= 3e-2 * nref
+        else:                # B = 3..4: BatchNorm over the batch + neighbour flips make this a sanity bound only
+            ok = err <= (1e-1 if B < 8 else 2e-2) * nref
         if not ok:
             bad.append((name, err, nref))
     assert not bad, bad
     for k in g.files:
         if k.startswith(f"{tag}_sd1_"):
             name = k[len(tag) + 5:]
-            np.testing.assert_allclose(net.state_dict()[name].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(net.state_dict()[name].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize("tag", ["c1", "s"])
