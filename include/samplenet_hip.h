@@ -153,6 +153,9 @@ int sn_grouping_operation_grad(int b, int c, int n, int m, int nsample, const fl
  *                                (atomics).  sn_soft_weights_backward: same partial count.
  * ------------------------------------------------------------------------------------------- */
 int sn_soft_bwd_splits(int b, int m);
+/* d loss/dT = (sum of the grad_sigma partials) * d max(T^2, min_sigma)/dT  (soft_projection.py:97-99), one launch */
+int sn_sigma_grad(int nparts, const float *partial, const float *temperature, float min_sigma, float *grad_T,
+                  sn_stream_t stream);
 int sn_soft_weights_forward(int b, int n, int m, int k, const float *P, const float *Q, const int *idx,
                             const float *temperature, float min_sigma, float *weights,
                             sn_stream_t stream);
@@ -230,6 +233,10 @@ int sn_bn_backward_coef(int nblk, int C, long long R, const float *stats, const 
 int sn_linear_dgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                     const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                     const float *coef_prev, float *dyprev, float *stats, sn_stream_t stream);
+/* dgrad + wgrad of one layer in ONE launch (both kinds of workgroups resident together); same arguments, no bias column */
+int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                       const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                       const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, sn_stream_t stream);
 int sn_linear_wgrad_splits(int R, int Ci, int Co, int with_bias);
 int sn_linear_wgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                     const float *gsel, const int *argsel, int npts, const float *aprev, const float *coef_prev,

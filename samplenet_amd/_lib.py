@@ -27,6 +27,7 @@ PROTOTYPES = {
     "sn_pairscan_forward_ws": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp,
                                ctypes.c_longlong, _vp],
     "sn_soft_bwd_splits": [_i, _i],
+    "sn_sigma_grad": [_i, _vp, _vp, _f, _vp, _vp],
     "sn_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_simplification_loss_forward": [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
@@ -49,6 +50,7 @@ PROTOTYPES = {
     "sn_pool_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_backward_coef": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_dgrad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_linear_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_wgrad_splits": [_i, _i, _i, _i],
     "sn_linear_wgrad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

@@ -93,6 +93,91 @@ __global__ void __launch_bounds__(256) chamfer_bwd_kernel(int nt, int ns, const 
     }
 }
 
+// Register-resident variant for ns <= 64*PPL (the sampler's 1024-point clouds): every lane loads its PPL sources
+// (coordinates, nearest-target index, upstream gradient) ONCE, all loads in flight together; per target the matching
+// lanes form their contribution in parallel and only the ordered accumulation (ascending source index, as the
+// reference CPU loop) is sequential -- on registers via v_readlane, no memory latency inside it.
+template <int PPL>
+__global__ void __launch_bounds__(256) chamfer_bwd_reg_kernel(int nt, int ns, const float *__restrict__ T,
+                                                              const float *__restrict__ S,
+                                                              const float *__restrict__ gT,
+                                                              const int *__restrict__ idxT,
+                                                              const float *__restrict__ gS,
+                                                              const int *__restrict__ idxS, float *__restrict__ gradT,
+                                                              int own_first, ImplicitGrad ig)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
+    idxT += (size_t)b * nt, idxS += (size_t)b * ns;
+    const bool implicit = ig.gL != nullptr;
+    float gLv = 0.f;
+    int amt = -1, ams = -1;
+    if (implicit) {
+        gLv = *ig.gL;
+        if (ig.argmax_t) amt = ig.argmax_t[b];
+        if (ig.argmax_s) ams = ig.argmax_s[b];
+    } else {
+        gT += (size_t)b * nt, gS += (size_t)b * ns;
+    }
+    gradT += (size_t)b * nt * 3;
+
+    float sx[PPL], sy[PPL], sz[PPL], gg[PPL];
+    int is[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int l = i * 64 + lane;
+        const int lc = l < ns ? l : 0;
+        sx[i] = S[lc * 3 + 0], sy[i] = S[lc * 3 + 1], sz[i] = S[lc * 3 + 2];
+        is[i] = l < ns ? idxS[lc] : -1;
+        gg[i] = (implicit ? gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) : gS[lc]) * 2;
+    }
+    for (int j = blockIdx.y * nwaves + wave; j < nt; j += gridDim.y * nwaves) {
+        const float tx = T[j * 3 + 0], ty = T[j * 3 + 1], tz = T[j * 3 + 2];
+        const int j2 = idxT[j];
+        const float g = (implicit ? gLv * (ig.ct + (j == amt ? ig.cmax_t : 0.f)) : gT[j]) * 2;
+        const float ox = g * (tx - S[j2 * 3 + 0]);
+        const float oy = g * (ty - S[j2 * 3 + 1]);
+        const float oz = g * (tz - S[j2 * 3 + 2]);
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (own_first) ax += ox, ay += oy, az += oz;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            sn_u64 mask = __ballot(is[i] == j);
+            if (mask) {
+                const float cx = gg[i] * (sx[i] - tx), cy = gg[i] * (sy[i] - ty), cz = gg[i] * (sz[i] - tz);
+                while (mask) {  // ascending source index: lanes of slot i in lane order, slots in order
+                    const int t = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    ax -= readlane_f(cx, t);
+                    ay -= readlane_f(cy, t);
+                    az -= readlane_f(cz, t);
+                }
+            }
+        }
+        if (!own_first) ax += ox, ay += oy, az += oz;
+        if (lane < 3) gradT[j * 3 + lane] = lane == 0 ? ax : (lane == 1 ? ay : az);
+    }
+}
+
+static void launch_chamfer_bwd(int b, int ysplit, int nt, int ns, const float *T, const float *S, const float *gT,
+                               const int *idxT, const float *gS, const int *idxS, float *gradT, int own_first,
+                               const ImplicitGrad &ig, hipStream_t st)
+{
+    const dim3 grid(b, ysplit), block(256);
+#define SN_CB(PPL_) \
+    hipLaunchKernelGGL(chamfer_bwd_reg_kernel<PPL_>, grid, block, 0, st, nt, ns, T, S, gT, idxT, gS, idxS, gradT, own_first, ig)
+    if (ns <= 64) SN_CB(1);
+    else if (ns <= 256) SN_CB(4);
+    else if (ns <= 1024) SN_CB(16);
+    else if (ns <= 2048) SN_CB(32);
+    else
+        hipLaunchKernelGGL(chamfer_bwd_kernel, grid, block, 0, st, nt, ns, T, S, gT, idxT, gS, idxS, gradT, own_first, ig);
+#undef SN_CB
+}
+
 // ------------------------------------------------------------------------------------------------
 // SoftProjection backward (fused 'project').  One wave per query, lane t < K = neighbour t.
 // ------------------------------------------------------------------------------------------------
@@ -359,12 +444,8 @@ extern "C" int sn_chamfer_backward(int b, int n, const float *xyz1, int m, const
     hipStream_t st = (hipStream_t)stream;
     auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (1024 + b - 1) / b)); };
     const ImplicitGrad none{};
-    if (grad_xyz1)
-        hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(b, ysplit(n)), dim3(256), 0, st, n, m, xyz1, xyz2, grad_dist1,
-                           idx1, grad_dist2, idx2, grad_xyz1, 1, none);
-    if (grad_xyz2)
-        hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(b, ysplit(m)), dim3(256), 0, st, m, n, xyz2, xyz1, grad_dist2,
-                           idx2, grad_dist1, idx1, grad_xyz2, 0, none);
+    if (grad_xyz1) launch_chamfer_bwd(b, ysplit(n), n, m, xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, 1, none, st);
+    if (grad_xyz2) launch_chamfer_bwd(b, ysplit(m), m, n, xyz2, xyz1, grad_dist2, idx2, grad_dist1, idx1, grad_xyz2, 0, none, st);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -439,14 +520,43 @@ extern "C" int sn_simplification_loss_backward(int B, int n1, const float *xyz1,
     const float c1 = 1.0f / ((float)B * (float)n1), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)n2);
     if (grad_xyz1) {
         ImplicitGrad ig{grad_loss, argmax1, nullptr, c1, cm, c2, 0.f};
-        hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(B, ysplit(n1)), dim3(256), 0, st, n1, n2, xyz1, xyz2, nullptr, idx1,
-                           nullptr, idx2, grad_xyz1, 1, ig);
+        launch_chamfer_bwd(B, ysplit(n1), n1, n2, xyz1, xyz2, nullptr, idx1, nullptr, idx2, grad_xyz1, 1, ig, st);
     }
     if (grad_xyz2) {
         ImplicitGrad ig{grad_loss, nullptr, argmax1, c2, 0.f, c1, cm};
-        hipLaunchKernelGGL(chamfer_bwd_kernel, dim3(B, ysplit(n2)), dim3(256), 0, st, n2, n1, xyz2, xyz1, nullptr, idx2,
-                           nullptr, idx1, grad_xyz2, 0, ig);
+        launch_chamfer_bwd(B, ysplit(n2), n2, n1, xyz2, xyz1, nullptr, idx2, nullptr, idx1, grad_xyz2, 0, ig, st);
     }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// d loss / dT from the per-workgroup partials of d loss / d sigma:  sigma = max(T^2, min_sigma)
+//   dT = (sum partial) * 2T * [T^2 > min_sigma]   (torch.max splits the gradient evenly on an exact tie)
+__global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float *__restrict__ partial,
+                                                         const float *__restrict__ temperature, float min_sigma,
+                                                         float *__restrict__ grad_T)
+{
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    for (int s = 128; s > 0; s >>= 1) {
+        __syncthreads();
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    }
+    if (threadIdx.x == 0) {
+        const float T = *temperature, t2 = T * T;
+        const float w = t2 > min_sigma ? 1.f : (t2 == min_sigma ? 0.5f : 0.f);
+        grad_T[0] = red[0] * w * 2.0f * T;
+    }
+}
+
+extern "C" int sn_sigma_grad(int nparts, const float *partial, const float *temperature, float min_sigma, float *grad_T,
+                             sn_stream_t stream)
+{
+    SN_REQUIRE(nparts >= 1 && partial && temperature && grad_T, "bad argument");
+    hipLaunchKernelGGL(sigma_grad_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nparts, partial, temperature,
+                       min_sigma, grad_T);
     SN_LAUNCH_CHECK();
     return 0;
 }

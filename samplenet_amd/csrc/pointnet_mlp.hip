@@ -438,10 +438,9 @@ struct DgradArgs {
 };
 
 template <class T, bool FULL, int ZMODE, int PMODE>
-__global__ void __launch_bounds__(T::THREADS) linear_dgrad_kernel(DgradArgs g)
+__device__ __forceinline__ void dgrad_body(const DgradArgs &g, int bx, int by, float *lds)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int row0 = blockIdx.x * T::BM, col0 = blockIdx.y * T::BN;
+    const int row0 = bx * T::BM, col0 = by * T::BN;
     const int R = g.dz.rows, Co = g.w.co, Ci = g.w.ci;
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -486,9 +485,16 @@ __global__ void __launch_bounds__(T::THREADS) linear_dgrad_kernel(DgradArgs g)
             }
     }
     if (masked && g.stats) {
-        float *st = g.stats + (size_t)blockIdx.x * 2 * Ci;
+        float *st = g.stats + (size_t)bx * 2 * Ci;
         column_reduce2<T>(s0, s1, lds, st, st + Ci, col0, Ci);
     }
+}
+
+template <class T, bool FULL, int ZMODE, int PMODE>
+__global__ void __launch_bounds__(T::THREADS) linear_dgrad_kernel(DgradArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    dgrad_body<T, FULL, ZMODE, PMODE>(g, blockIdx.x, blockIdx.y, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -503,12 +509,11 @@ struct WgradArgs {
 };
 
 template <class T, bool FULL, int ZMODE, int PMODE>
-__global__ void __launch_bounds__(T::THREADS) linear_wgrad_kernel(WgradArgs g)
+__device__ __forceinline__ void wgrad_body(const WgradArgs &g, int bx, int by, int bz, float *lds)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int m0 = blockIdx.x * T::BM, n0 = blockIdx.y * T::BN;
+    const int m0 = bx * T::BM, n0 = by * T::BN;
     const int Co = g.dz.ch, Ce = g.ncols;
-    const int r0 = blockIdx.z * g.rows_per_split;
+    const int r0 = bz * g.rows_per_split;
     const int r1 = min(g.dz.rows, r0 + g.rows_per_split);
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -529,7 +534,7 @@ __global__ void __launch_bounds__(T::THREADS) linear_wgrad_kernel(WgradArgs g)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave / T::WC, wc = wave % T::WC;
-    float *P = g.part + (size_t)blockIdx.z * Co * Ce;
+    float *P = g.part + (size_t)bz * Co * Ce;
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int col = n0 + (wc * T::TN + j) * 32 + (lane & 31);
@@ -540,6 +545,30 @@ __global__ void __launch_bounds__(T::THREADS) linear_wgrad_kernel(WgradArgs g)
                 const int row = m0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
                 if (FULL || (row < Co && col < Ce)) P[(size_t)row * Ce + col] = acc[i][j][e];
             }
+    }
+}
+
+template <class T, bool FULL, int ZMODE, int PMODE>
+__global__ void __launch_bounds__(T::THREADS) linear_wgrad_kernel(WgradArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    wgrad_body<T, FULL, ZMODE, PMODE>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+// Backward of one layer as ONE launch: the weight-gradient workgroups (MFMA-heavy: K = 128 rows per split) and the
+// data-gradient workgroups (memory-heavy: read dY, Z, Zprev, write dYprev) are resident side by side, so the two
+// kinds of phases overlap on every CU instead of running as two lock-stepped kernels.  Workgroup ids
+// [0, n_w) -> wgrad (dispatched first: the longer of the two), [n_w, n_w + n_d) -> dgrad.
+template <class T, int ZMODE, int PMODE>
+__global__ void __launch_bounds__(T::THREADS) linear_bwd_kernel(DgradArgs d, WgradArgs w, int n_w, int wgx, int wgy, int dgx)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int id = blockIdx.x;
+    if (id < n_w) {
+        wgrad_body<T, true, ZMODE, PMODE>(w, id % wgx, (id / wgx) % wgy, id / (wgx * wgy), lds);
+    } else {
+        const int e = id - n_w;
+        dgrad_body<T, true, ZMODE, PMODE>(d, e % dgx, e / dgx, lds);
     }
 }
 
@@ -974,13 +1003,26 @@ static ActSrc make_act(const float *z, const float *coef, int rows, int ch, int 
     return a;
 }
 
+// Occupancy shaping.  The dispatcher stacks workgroups on a CU up to its resource limit before moving on, so a grid of
+// 512 small workgroups can land 4-deep on half of the 256 CUs (measured: SQ_WAIT_INST_ANY 52 % of wave cycles -- four
+// waves per SIMD queueing on one matrix pipe) instead of 2-deep on all of them.  Requesting 160 KB / (workgroups per CU
+// the grid needs) of LDS makes exactly that many fit, which spreads the grid evenly.
+static size_t shaped_lds(size_t needed, dim3 grid)
+{
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    const size_t per_cu = std::max<size_t>(1, (nblk + 255) / 256);
+    const size_t want = std::min<size_t>(64 * 1024, (160 * 1024) / per_cu);
+    return std::max(needed, want > 1024 ? want - 1024 : needed);
+}
+
 // ---- dispatch helpers: tile x fast-path x operand modes are template parameters (no control flow around loads) ----
 #define SN_LAUNCH_T(KERN, T_, FULL_, GRID, ARGS, ...)                                                              \
     do {                                                                                                           \
+        const size_t lds_ = shaped_lds(lds_bytes<T_>(), GRID);                                                     \
         if (FULL_)                                                                                                 \
-            hipLaunchKernelGGL((KERN<T_, true, __VA_ARGS__>), GRID, dim3(T_::THREADS), lds_bytes<T_>(), st, ARGS); \
+            hipLaunchKernelGGL((KERN<T_, true, __VA_ARGS__>), GRID, dim3(T_::THREADS), lds_, st, ARGS);            \
         else                                                                                                       \
-            hipLaunchKernelGGL((KERN<T_, false, __VA_ARGS__>), GRID, dim3(T_::THREADS), lds_bytes<T_>(), st, ARGS); \
+            hipLaunchKernelGGL((KERN<T_, false, __VA_ARGS__>), GRID, dim3(T_::THREADS), lds_, st, ARGS);           \
     } while (0)
 
 template <int AMODE>
@@ -1135,6 +1177,50 @@ extern "C" int sn_linear_wgrad(int R, int Ci, int Co, int dz_mode, const float *
         if (pm) launch_wgrad<DZ_POOL, ACT_BN_RELU>(g, R, Ci, Co, with_bias, dW, db, st);
         else launch_wgrad<DZ_POOL, ACT_NONE>(g, R, Ci, Co, with_bias, dW, db, st);
     }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// dgrad + wgrad of one layer.  Arguments as sn_linear_dgrad / sn_linear_wgrad (aprev == zprev: the previous layer's
+// pre-BN activations, or the raw input when coef_prev == NULL).  One launch on the fast path, else the two kernels.
+extern "C" int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                                  const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                                  const float *coef_prev, float *dyprev, float *stats, float *part, float *dW,
+                                  sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(W && zprev && dyprev && part && dW, "null pointer");
+    SN_REQUIRE(dz_mode >= DZ_PLAIN && dz_mode <= DZ_POOL, "bad dz_mode");
+    const int nsplit = sn_linear_wgrad_splits(R, Ci, Co, 0);
+    int rps = (R + nsplit - 1) / nsplit;
+    rps = ((rps + BK - 1) / BK) * BK;
+    const bool fast = R > 64 && coef_prev && dz_mode != DZ_PLAIN && R % TileBig::BM == 0 && Ci % TileBig::BN == 0 &&
+                      Co % BK == 0 && Co % TileW::BM == 0 && Ci % TileW::BN == 0 && R % rps == 0;
+    if (!fast) {
+        int rc = sn_linear_wgrad(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, part, dW, nullptr, stream);
+        if (rc) return rc;
+        return sn_linear_dgrad(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev, stats, stream);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    DgradArgs d{};
+    d.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
+    d.w.w = W, d.w.co = Co, d.w.ci = Ci;
+    d.prev = make_act(zprev, coef_prev, R, Ci);
+    d.dyprev = dyprev, d.stats = stats;
+    WgradArgs w{};
+    w.dz = d.dz;
+    w.prev = make_act(zprev, coef_prev, R, Ci, -1);
+    w.ncols = Ci, w.part = part, w.rows_per_split = rps;
+    const int wgx = Co / TileW::BM, wgy = Ci / TileW::BN, n_w = wgx * wgy * nsplit;
+    const int dgx = R / TileBig::BM, n_d = dgx * (Ci / TileBig::BN);
+    const dim3 grid(n_w + n_d);
+    const size_t lds = shaped_lds(std::max(lds_bytes<TileBig>(), lds_bytes<TileW>()), grid);
+    static_assert(TileBig::THREADS == TileW::THREADS, "combined backward kernel needs one workgroup size");
+    if (dz_mode == DZ_BN)
+        hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_BN, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
+    else
+        hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_POOL, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(256), 0, st, nsplit, Co, Ci, Ci, part, dW, nullptr);
     SN_LAUNCH_CHECK();
     return 0;
 }

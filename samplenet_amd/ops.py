@@ -163,12 +163,14 @@ grouping_operation = GroupingOperationFunction.apply
 
 
 # --------------------------------------------------------------------------------------------- SoftProjection
-def _dsigma_dT(temperature, min_sigma):
-    """d max(T^2, min_sigma) / dT, with torch.max's even split on an exact tie."""
-    t2 = temperature.detach() ** 2
-    ms = float(min_sigma)  # python scalar: no host->device copy (keeps the step capturable into a hipGraph)
-    w = (t2 > ms).float() + 0.5 * (t2 == ms).float()
-    return w * 2.0 * temperature.detach()
+def _grad_temperature(gsig, temperature, min_sigma):
+    """d loss / dT from the d loss / d sigma partials (one tiny kernel): sigma = max(T^2, min_sigma), with torch.max's
+    even split of the gradient on an exact tie."""
+    T = temperature.detach().float().reshape(1)
+    gT = torch.empty(1, device=gsig.device, dtype=torch.float32)
+    with torch.cuda.device(gsig.device):
+        check(lib.sn_sigma_grad(gsig.numel(), ptr(gsig), ptr(T), float(min_sigma), ptr(gT), _stream(gsig)), "sn_sigma_grad")
+    return gT.reshape(temperature.shape)
 
 
 class SoftProjectFunction(torch.autograd.Function):
@@ -230,7 +232,7 @@ class SoftProjectFunction(torch.autograd.Function):
                                                _stream(P)), "sn_soft_project_backward")
         gT = None
         if ctx.needs_input_grad[2]:
-            gT = (gsig.sum() * _dsigma_dT(temperature, ctx.min_sigma)).reshape(temperature.shape)
+            gT = _grad_temperature(gsig, temperature, ctx.min_sigma)
         return gP, (gQ if ctx.needs_input_grad[1] else None), gT, None, None, None, None, None
 
 
@@ -270,7 +272,7 @@ class SoftWeightsFunction(torch.autograd.Function):
                   "sn_soft_weights_backward")
         gT = None
         if ctx.needs_input_grad[3]:
-            gT = (gsig.sum() * _dsigma_dT(temperature, ctx.min_sigma)).reshape(temperature.shape)
+            gT = _grad_temperature(gsig, temperature, ctx.min_sigma)
         return gP, (gQ if ctx.needs_input_grad[1] else None), None, gT, None
 
 

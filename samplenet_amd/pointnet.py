@@ -6,6 +6,8 @@ Replaces the torch.nn call chain of registration/src/samplenet.py:90-104
 while the parameters stay ordinary nn.Conv1d / nn.BatchNorm1d / nn.Linear members of the module
 (state_dict compatibility).  Host side: buffer allocation and launch sequencing only.
 """
+import os
+
 import torch
 
 from ._lib import check, lib, ptr
@@ -103,6 +105,9 @@ def _out(sink, name, like):
 
 
 _SIDE = {}
+# measured on MI355X / ROCm 7.2: inside a replayed hipGraph the fork/join edges cost more than the overlap buys
+# (0.73 vs 0.60 ms per step at B = 32), so the side stream is opt-in
+USE_SIDE_STREAM = os.environ.get("SAMPLENET_AMD_WGRAD_SIDE_STREAM", "0") != "0"
 
 
 def _side_stream(dev):
@@ -120,20 +125,23 @@ def _wgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, aprev, coef_prev, with_
     dW = _out(sink, name + ".weight", L.W)
     db = _out(sink, name + ".bias", L.b) if with_bias else None
     nsplit = lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 1 if with_bias else 0)
-    side = _side_stream(dev)
-    side.wait_stream(main)  # fork: everything enqueued so far (dy, kcoef, ...) is visible to the side stream
+    side = _side_stream(dev) if USE_SIDE_STREAM else main
+    if side is not main:
+        side.wait_stream(main)  # fork: everything enqueued so far (dy, kcoef, ...) is visible to the side stream
     with torch.cuda.stream(side):
         part = _empty((nsplit * L.Co * (L.Ci + (1 if with_bias else 0)),), L.W)
         check(lib.sn_linear_wgrad(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(aprev),
                                   ptr(coef_prev), ptr(part), ptr(dW), ptr(db), side.cuda_stream), "sn_linear_wgrad")
-    for t in (dy, z, kcoef, gsel, argsel, aprev, coef_prev, dW, db):
-        if t is not None:
-            t.record_stream(side)  # allocated on the main stream, read / written on the side stream
+    if side is not main:
+        for t in (dy, z, kcoef, gsel, argsel, aprev, coef_prev, dW, db):
+            if t is not None:
+                t.record_stream(side)  # allocated on the main stream, read / written on the side stream
     return dW, db
 
 
 def _join_side(dev):
-    torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+    if USE_SIDE_STREAM:
+        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
 
 
 def _dgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev):
@@ -143,6 +151,20 @@ def _dgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev):
     check(lib.sn_linear_dgrad(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(L.W),
                               ptr(zprev), ptr(coef_prev), ptr(dyprev), ptr(stats), _st(L.W)), "sn_linear_dgrad")
     return dyprev, stats, nblk
+
+
+def _bwd_layer(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, sink=None, name=""):
+    """dgrad + wgrad of one layer through sn_linear_backward (one launch on the fast path)."""
+    dW = _out(sink, name + ".weight", L.W)
+    dyprev = _empty((R, L.Ci), L.W)
+    nblk = lib.sn_linear_stats_blocks(R)
+    stats = _empty((nblk, 2, L.Ci), L.W)
+    nsplit = lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 0)
+    part = _empty((nsplit * L.Co * L.Ci,), L.W)
+    check(lib.sn_linear_backward(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(L.W),
+                                 ptr(zprev), ptr(coef_prev), ptr(dyprev), ptr(stats), ptr(part), ptr(dW), _st(L.W)),
+          "sn_linear_backward")
+    return dW, dyprev, stats, nblk
 
 
 def _bn_bwd(L, R, stats, nblk, coef, sink=None, bn_name="", lin_name=""):
@@ -204,10 +226,11 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
         mode = DZ_POOL if i == 4 else DZ_BN
         gs, ag = (gsel, saved["argsel"]) if i == 4 else (None, None)
         aprev, cprev = (zc[i - 1], cc[i - 1]) if i > 0 else (saved["x"].view(R, 3), None)
-        dW, _ = _wgrad(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev, False, sink, names_c[i])
-        grads[names_c[i] + ".weight"] = dW
         if i > 0:
-            dy, stats, nblk = _dgrad(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev)
+            dW, dy, stats, nblk = _bwd_layer(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev, sink, names_c[i])
+        else:
+            dW, _ = _wgrad(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev, False, sink, names_c[i])
+        grads[names_c[i] + ".weight"] = dW
     _join_side(grad_y.device)  # all weight gradients complete before backward returns on the main stream
     return grads
 
