@@ -217,6 +217,17 @@ int sn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
  *                      sn_linear_wgrad_splits(R,Ci,Co,db!=NULL) * Co * (Ci + (db!=NULL)) floats.
  * ------------------------------------------------------------------------------------------- */
 int sn_linear_stats_blocks(int R);
+/* layer-level entry points (what samplenet_amd/pointnet.py calls): a layer's forward INCLUDING its BatchNorm
+ * finalisation, and a layer's backward (dW, optional db, dYprev) INCLUDING the BatchNorm backward coefficients of the
+ * layer below; they pick the fused single-/dual-launch kernels by shape and fall back to the pieces above otherwise. */
+int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
+                        const float *bias, float *z, float *stats, const float *gamma, const float *beta,
+                        float eps, float momentum, float *running_mean, float *running_var,
+                        long long *num_batches_tracked, float *coef, sn_stream_t stream);
+int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                      const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                      const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,
+                      float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef, sn_stream_t stream);
 int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
                       const float *bias, float *z, float *stats, sn_stream_t stream);
 int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,

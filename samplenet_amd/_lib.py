@@ -43,6 +43,9 @@ PROTOTYPES = {
     "sn_weighted_gather_backward": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_soft_project_backward": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_linear_stats_blocks": [_i],
+    "sn_layer_forward_bn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sn_layer_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                          _vp, _vp],
     "sn_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_finalize": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_eval_coef": [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp],

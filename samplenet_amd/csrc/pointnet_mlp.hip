@@ -370,12 +370,63 @@ __device__ __forceinline__ void column_reduce2(float (&p0)[T::TN], float (&p1)[T
 // ------------------------------------------------------------------------------------------------
 // forward:  Z[R][Co] = act(Ain)[R][Ci] . W^T + bias ; stats partial [gridDim.x][2][Co]
 // ------------------------------------------------------------------------------------------------
+// BatchNorm (training) finalisation of one channel from its batch sums: coefficients for the next layer / backward and
+// the running-statistics update of torch.nn.BatchNorm1d.  Used by bn_finalize_kernel and, when a workgroup already
+// owns all rows of its columns (R <= 32), directly by the forward epilogue (no partials, no extra launch).
+struct BnFwd {
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    long long *num_batches_tracked;
+    float *coef;  // [4][C]: scale, shift, mean, invstd;  NULL: no BatchNorm behind this layer
+    float eps, momentum;
+    long long R;
+};
+
+__device__ __forceinline__ void bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss)
+{
+    const double mean = s / (double)bn.R;
+    double var = ss / (double)bn.R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)bn.eps));
+    const float sc = bn.gamma[c] * invstd;
+    bn.coef[c] = sc;
+    bn.coef[C + c] = bn.beta[c] - (float)mean * sc;
+    bn.coef[2 * C + c] = (float)mean;
+    bn.coef[3 * C + c] = invstd;
+    if (bn.running_mean) {
+        const double unbiased = bn.R > 1 ? var * (double)bn.R / (double)(bn.R - 1) : var;
+        bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
+        bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * (float)unbiased;
+    }
+}
+
+// BatchNorm backward coefficients of one channel from (sum dY, sum dY*Z):  dZ = k1 dY + k2 Z + k3
+struct BnBwd {
+    const float *coef;  // [4][C] of that layer;  NULL: nothing to do
+    float *dgamma, *dbeta, *dbias, *kcoef;
+    long long R;
+};
+
+__device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz)
+{
+    const double scale = bb.coef[c], mean = bb.coef[2 * C + c], invstd = bb.coef[3 * C + c];
+    const double dg = invstd * (sz - mean * s);
+    bb.dgamma[c] = (float)dg;
+    bb.dbeta[c] = (float)s;
+    const double rinv = 1.0 / (double)bb.R;
+    const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
+    const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
+    bb.kcoef[c] = k1, bb.kcoef[C + c] = k2, bb.kcoef[2 * C + c] = k3;
+    if (bb.dbias) bb.dbias[c] = (float)((double)k1 * s + (double)k2 * (double)bb.R * mean + (double)bb.R * (double)k3);
+}
+
 struct FwdArgs {
     ActSrc a;
     WSrc w;
     const float *bias;
     float *z;
     float *stats;  // may be null
+    BnFwd bn;      // small-R kernels only: finalise the BatchNorm in the epilogue (bn.coef != NULL)
 };
 
 template <class T, bool FULL, int AMODE>
@@ -435,6 +486,7 @@ struct DgradArgs {
     ActSrc prev;  // pre-BN activations + BN coefficients of the previous layer (for the ReLU mask)
     float *dyprev;
     float *stats;
+    BnBwd bb;  // small-R kernels only: BatchNorm backward coefficients of the previous layer in the epilogue
 };
 
 template <class T, bool FULL, int ZMODE, int PMODE>
@@ -656,6 +708,10 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
     s0 += __shfl_xor(s0, 32);
     s1 += __shfl_xor(s1, 32);
     if (g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Co + col] = s1;
+    if (g.bn.coef) {  // this workgroup holds every row of its 32 columns: their batch statistics are complete here
+        if (blockIdx.x == 0 && lane == 0 && g.bn.num_batches_tracked) *g.bn.num_batches_tracked += 1;
+        if (lane < 32 && colok) bn_finalize_channel(g.bn, Co, col, (double)s0, (double)s1);
+    }
 }
 
 // dYprev[R<=32][Ci] = mask . (dZ . W) ; stats [1][2][Ci]
@@ -720,6 +776,7 @@ __global__ void __launch_bounds__(256) small_dgrad_kernel(DgradArgs g)
     s0 += __shfl_xor(s0, 32);
     s1 += __shfl_xor(s1, 32);
     if (masked && g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Ci + col] = s1;
+    if (masked && g.bb.coef && lane < 32 && colok) bn_backward_channel(g.bb, Ci, col, (double)s0, (double)s1);
 }
 
 // dW[Co][Ci] (and db[Co] through the ones column) = dZ^T . act(prev), K = R <= 32: one wave per 32x32 output tile,
@@ -756,6 +813,73 @@ __global__ void __launch_bounds__(256) small_wgrad_kernel(WgradArgs g, float *__
             else if (db)
                 db[row] = acc[e];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First layer (Ci = 3: the xyz input).  K = 3 is no GEMM: z = w0 x + w1 y + w2 z + b is a streaming kernel bound by
+// the 256 B/row it writes; the matrix-core path would spend 95 % of its tile on zero padding.
+// Workgroup = 64 rows x 64 output channels (thread = channel, 4 row groups), stats partial per workgroup row block
+// exactly like linear_fwd_kernel ([gridDim.x][2][Co], 64 rows per block).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const float *__restrict__ x,
+                                                           const float *__restrict__ W, const float *__restrict__ bias,
+                                                           float *__restrict__ z, float *__restrict__ stats)
+{
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const int co = blockIdx.y * 64 + cl;
+    const int row0 = blockIdx.x * 64;
+    const bool ok = co < Co;
+    const float w0 = ok ? W[co * 3 + 0] : 0.f, w1 = ok ? W[co * 3 + 1] : 0.f, w2 = ok ? W[co * 3 + 2] : 0.f;
+    const float b = (ok && bias) ? bias[co] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int r = row0 + rq + 4 * i;
+        if (r < R) {
+            const float v = fmaf(w2, x[(size_t)r * 3 + 2], fmaf(w1, x[(size_t)r * 3 + 1], w0 * x[(size_t)r * 3])) + b;
+            if (ok) z[(size_t)r * Co + co] = v;
+            s0 += v;
+            s1 += v * v;
+        }
+    }
+    red[0][rq][cl] = s0, red[1][rq][cl] = s1;
+    __syncthreads();
+    if (rq == 0 && ok && stats) {
+        float *st = stats + (size_t)blockIdx.x * 2 * Co;
+        st[co] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        st[Co + co] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+// dW[co][0..2] partial over a split of the rows: sum_r dZ[r][co] * x[r][c], dZ = k1 dY + k2 Z + k3.
+// part layout [split][Co][3] (reduced by wgrad_reduce_kernel).
+__global__ void __launch_bounds__(256) conv_in3_wgrad_kernel(int R, int Co, int rows_per_split, const float *__restrict__ x,
+                                                             const float *__restrict__ dy, const float *__restrict__ z,
+                                                             const float *__restrict__ kcoef, float *__restrict__ part)
+{
+    __shared__ float red[3][4][64];
+    const int cl = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const int co = blockIdx.y * 64 + cl;
+    const bool ok = co < Co;
+    const int cc = ok ? co : 0;
+    const float k1 = kcoef[cc], k2 = kcoef[Co + cc], k3 = kcoef[2 * Co + cc];
+    const int r0 = blockIdx.x * rows_per_split, r1 = min(R, r0 + rows_per_split);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
+    for (int r = r0 + rq; r < r1; r += 4) {
+        const float d = fmaf(k1, dy[(size_t)r * Co + cc], fmaf(k2, z[(size_t)r * Co + cc], k3));
+        a0 = fmaf(d, x[(size_t)r * 3 + 0], a0);
+        a1 = fmaf(d, x[(size_t)r * 3 + 1], a1);
+        a2 = fmaf(d, x[(size_t)r * 3 + 2], a2);
+    }
+    red[0][rq][cl] = a0, red[1][rq][cl] = a1, red[2][rq][cl] = a2;
+    __syncthreads();
+    if (rq == 0 && ok) {
+        float *P = part + ((size_t)blockIdx.x * Co + co) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P[c] = (red[c][0][cl] + red[c][1][cl]) + (red[c][2][cl] + red[c][3][cl]);
     }
 }
 
@@ -826,30 +950,12 @@ __device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__res
 
 // training: batch statistics from the forward partials -> coef [4][C] = scale, shift, mean, invstd;
 // running statistics updated as torch.nn.BatchNorm1d does (unbiased variance, momentum).
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(int nblk, int C, long long R, const float *__restrict__ stats,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          float eps, float momentum, float *__restrict__ running_mean,
-                                                          float *__restrict__ running_var,
-                                                          long long *__restrict__ num_batches_tracked, float *__restrict__ coef)
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(int nblk, int C, const float *__restrict__ stats, BnFwd bn)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
     double s, ss;
     if (!partial_sums(nblk, C, stats, s, ss)) return;
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const double mean = s / (double)R;
-    double var = ss / (double)R - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * invstd;
-    coef[c] = sc;
-    coef[C + c] = beta[c] - (float)mean * sc;
-    coef[2 * C + c] = (float)mean;
-    coef[3 * C + c] = invstd;
-    if (running_mean) {
-        const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
+    bn_finalize_channel(bn, C, blockIdx.x * 32 + (threadIdx.x & 31), s, ss);
 }
 
 // eval: coefficients from the running statistics
@@ -871,23 +977,55 @@ __global__ void bn_eval_coef_kernel(int C, const float *__restrict__ gamma, cons
 //   dZ = scale * (dY - dbeta/R - zhat * dgamma/R),  zhat = (Z - mean) invstd
 //      = k1 dY + k2 Z + k3
 // dbias (gradient of the conv/linear bias in front of the BN) = sum_r dZ = k1 sum dY + k2 R mean + R k3 (== 0 up to rounding).
-__global__ void __launch_bounds__(1024) bn_bwd_coef_kernel(int nblk, int C, long long R, const float *__restrict__ stats,
-                                                          const float *__restrict__ coef, float *__restrict__ dgamma,
-                                                          float *__restrict__ dbeta, float *__restrict__ dbias,
-                                                          float *__restrict__ kcoef)
+__global__ void __launch_bounds__(1024) bn_bwd_coef_kernel(int nblk, int C, const float *__restrict__ stats, BnBwd bb)
 {
     double s, sz;
     if (!partial_sums(nblk, C, stats, s, sz)) return;
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const double scale = coef[c], mean = coef[2 * C + c], invstd = coef[3 * C + c];
-    const double dg = invstd * (sz - mean * s);
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)s;
-    const double rinv = 1.0 / (double)R;
-    const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
-    const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
-    kcoef[c] = k1, kcoef[C + c] = k2, kcoef[2 * C + c] = k3;
-    if (dbias) dbias[c] = (float)((double)k1 * s + (double)k2 * (double)R * mean + (double)R * (double)k3);
+    bn_backward_channel(bb, C, blockIdx.x * 32 + (threadIdx.x & 31), s, sz);
+}
+
+// wgrad_reduce of layer i and the BatchNorm backward coefficients of layer i-1 depend on the same launch (the combined
+// backward kernel of layer i) and on nothing else: one launch for both.  Workgroups [0, nred) reduce, the rest do BN.
+__global__ void __launch_bounds__(1024) post_bwd_kernel(int nred, int nsplit, int Co, int Ci, const float *__restrict__ part,
+                                                        float *__restrict__ dW, int nblk, int C,
+                                                        const float *__restrict__ stats, BnBwd bb)
+{
+    if ((int)blockIdx.x < nred) {
+        // 256 elements x 4 split-slices per workgroup (fixed-order sums)
+        __shared__ float red[4][256];
+        const int el = threadIdx.x & 255, sl = threadIdx.x >> 8;
+        const int e = blockIdx.x * 256 + el;
+        const size_t stride = (size_t)Co * Ci;
+        float acc = 0.f;
+        if (e < Co * Ci) {
+            int sp = sl;
+            for (; sp + 12 < nsplit; sp += 16)
+                acc += (part[(size_t)sp * stride + e] + part[(size_t)(sp + 4) * stride + e]) +
+                       (part[(size_t)(sp + 8) * stride + e] + part[(size_t)(sp + 12) * stride + e]);
+            for (; sp < nsplit; sp += 4) acc += part[(size_t)sp * stride + e];
+        }
+        red[sl][el] = acc;
+        __syncthreads();
+        if (sl == 0 && e < Co * Ci) dW[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        return;
+    }
+    // BatchNorm backward coefficients: 32 channels x 32 slices, as bn_bwd_coef_kernel
+    __shared__ double red2[2][kSlices][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = ((int)blockIdx.x - nred) * 32 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int b = sl; b < nblk; b += kSlices) {
+            a0 += (double)stats[((size_t)b * 2 + 0) * C + c];
+            a1 += (double)stats[((size_t)b * 2 + 1) * C + c];
+        }
+    red2[0][sl][cl] = a0, red2[1][sl][cl] = a1;
+    __syncthreads();
+    if (sl != 0 || c >= C) return;
+    double s = 0.0, sz = 0.0;
+#pragma unroll
+    for (int q = 0; q < kSlices; ++q) s += red2[0][q][cl], sz += red2[1][q][cl];
+    bn_backward_channel(bb, C, c, s, sz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1029,6 +1167,12 @@ template <int AMODE>
 static void launch_fwd(const FwdArgs &g, hipStream_t st)
 {
     const int R = g.a.rows, Ci = g.w.ci, Co = g.w.co;
+    if (AMODE == ACT_NONE && Ci == 3 && R > 64) {  // xyz input layer: streaming kernel, same stats layout (64 rows / block)
+        static_assert(TileBig::BM == 64, "conv_in3_fwd_kernel writes one stats partial per 64 rows");
+        hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3((R + 63) / 64, (Co + 63) / 64), dim3(256), 0, st, R, Co, g.a.z, g.w.w,
+                           g.bias, g.z, g.stats);
+        return;
+    }
     if (R <= 32) {
         if (Ci % 64 == 0)
             hipLaunchKernelGGL((small_fwd_kernel<AMODE, true>), dim3((Co + 31) / 32), dim3(256), 0, st, g);
@@ -1059,6 +1203,38 @@ extern "C" int sn_linear_forward(int R, int Ci, int Co, const float *ain, const 
         launch_fwd<ACT_BN_RELU>(g, st);
     else
         launch_fwd<ACT_NONE>(g, st);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_linear_stats_blocks(int R);
+
+// Layer forward INCLUDING its BatchNorm finalisation (training): Z, then coef[4][Co] + running statistics.
+// R <= 32: one launch (the epilogue finalises); otherwise the GEMM launch + bn_finalize.  stats: scratch of
+// sn_linear_stats_blocks(R) * 2 * Co floats.
+extern "C" int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
+                                   const float *bias, float *z, float *stats, const float *gamma, const float *beta,
+                                   float eps, float momentum, float *running_mean, float *running_var,
+                                   long long *num_batches_tracked, float *coef, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(ain && W && z && stats && gamma && beta && coef, "null pointer");
+    FwdArgs g{};
+    g.a = make_act(ain, coef_prev, R, Ci);
+    g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+    g.bias = bias, g.z = z, g.stats = stats;
+    const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
+    hipStream_t st = (hipStream_t)stream;
+    if (R <= 32) {
+        g.bn = bn;
+        g.stats = nullptr;
+    }
+    if (coef_prev)
+        launch_fwd<ACT_BN_RELU>(g, st);
+    else
+        launch_fwd<ACT_NONE>(g, st);
+    if (R > 32)
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((Co + 31) / 32), dim3(1024), 0, st, sn_linear_stats_blocks(R), Co, stats, bn);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -1143,6 +1319,12 @@ static void launch_wgrad(WgradArgs &g, int R, int Ci, int Co, int with_bias, flo
     int rps = (R + nsplit - 1) / nsplit;
     rps = ((rps + BK - 1) / BK) * BK;
     g.rows_per_split = rps;
+    if (ZMODE == DZ_BN && PMODE == ACT_NONE && Ci == 3 && !with_bias) {  // xyz input layer
+        hipLaunchKernelGGL(conv_in3_wgrad_kernel, dim3(nsplit, (Co + 63) / 64), dim3(256), 0, st, R, Co, rps, g.prev.z, g.dz.dy,
+                           g.dz.z, g.dz.k1, g.part);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * 3 + 63) / 64), dim3(256), 0, st, nsplit, Co, 3, 3, g.part, dW, db);
+        return;
+    }
     dim3 grid((Co + TileW::BM - 1) / TileW::BM, (g.ncols + TileW::BN - 1) / TileW::BN, nsplit);
     // fast path: every split covers whole K chunks of in-range rows and whole output tiles
     const bool full = !with_bias && Co % TileW::BM == 0 && Ci % TileW::BN == 0 && R % rps == 0;
@@ -1225,13 +1407,92 @@ extern "C" int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const floa
     return 0;
 }
 
+// Backward of one layer INCLUDING the BatchNorm backward coefficients of the layer below it:
+//   dW (and db when db != NULL: bias column, plain dz only), dYprev, and -- when the layer below has a BatchNorm
+//   (coef_prev != NULL) -- its dgamma / dbeta / dbias / kcoef[3][Ci].
+// R <= 32: two launches (register-resident wgrad; dgrad whose epilogue finishes the BatchNorm backward);
+// large R fast path: the combined dgrad+wgrad launch + one launch for (wgrad reduce | BatchNorm coefficients).
+extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                                 const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                                 const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,
+                                 float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef,
+                                 sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(W && zprev && dyprev && dW, "null pointer");
+    SN_REQUIRE(dz_mode >= DZ_PLAIN && dz_mode <= DZ_POOL, "bad dz_mode");
+    SN_REQUIRE(!coef_prev || (stats && prev_dgamma && prev_dbeta && prev_kcoef), "previous-layer BatchNorm outputs missing");
+    hipStream_t st = (hipStream_t)stream;
+    const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, (long long)R};
+    if (R <= 32) {
+        int rc = sn_linear_wgrad(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, part ? part : dW, dW, db,
+                                 stream);
+        if (rc) return rc;
+        DgradArgs g{};
+        g.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
+        g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+        g.prev = make_act(zprev, coef_prev, R, Ci);
+        g.dyprev = dyprev, g.stats = nullptr;
+        if (coef_prev) g.bb = bb;
+        const bool pm = coef_prev != nullptr;
+        if (dz_mode == DZ_PLAIN) {
+            if (pm) launch_dgrad<DZ_PLAIN, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_PLAIN, ACT_NONE>(g, st);
+        } else if (dz_mode == DZ_BN) {
+            if (pm) launch_dgrad<DZ_BN, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_BN, ACT_NONE>(g, st);
+        } else {
+            if (pm) launch_dgrad<DZ_POOL, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_POOL, ACT_NONE>(g, st);
+        }
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
+    SN_REQUIRE(part, "scratch missing");
+    const int nsplit = sn_linear_wgrad_splits(R, Ci, Co, db ? 1 : 0);
+    int rps = (R + nsplit - 1) / nsplit;
+    rps = ((rps + BK - 1) / BK) * BK;
+    const bool fast = !db && coef_prev && dz_mode != DZ_PLAIN && R % TileBig::BM == 0 && Ci % TileBig::BN == 0 &&
+                      Co % BK == 0 && Co % TileW::BM == 0 && Ci % TileW::BN == 0 && R % rps == 0;
+    const int nblk = sn_linear_stats_blocks(R);
+    if (!fast) {
+        int rc = sn_linear_wgrad(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, part, dW, db, stream);
+        if (rc) return rc;
+        rc = sn_linear_dgrad(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev, stats, stream);
+        if (rc) return rc;
+        if (coef_prev)
+            hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Ci + 31) / 32), dim3(1024), 0, st, nblk, Ci, stats, bb);
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
+    DgradArgs d{};
+    d.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
+    d.w.w = W, d.w.co = Co, d.w.ci = Ci;
+    d.prev = make_act(zprev, coef_prev, R, Ci);
+    d.dyprev = dyprev, d.stats = stats;
+    WgradArgs w{};
+    w.dz = d.dz;
+    w.prev = make_act(zprev, coef_prev, R, Ci, -1);
+    w.ncols = Ci, w.part = part, w.rows_per_split = rps;
+    const int wgx = Co / TileW::BM, wgy = Ci / TileW::BN, n_w = wgx * wgy * nsplit;
+    const int dgx = R / TileBig::BM, n_d = dgx * (Ci / TileBig::BN);
+    const dim3 grid(n_w + n_d);
+    const size_t lds = shaped_lds(std::max(lds_bytes<TileBig>(), lds_bytes<TileW>()), grid);
+    if (dz_mode == DZ_BN)
+        hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_BN, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
+    else
+        hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_POOL, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
+    const int nred = (Co * Ci + 255) / 256;
+    hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + 31) / 32), dim3(1024), 0, st, nred, nsplit, Co, Ci, part, dW, nblk, Ci,
+                       stats, bb);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,
                               float eps, float momentum, float *running_mean, float *running_var,
                               long long *num_batches_tracked, float *coef, sn_stream_t stream)
 {
     SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && gamma && beta && coef, "bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, nblk, C, R, stats, gamma,
-                       beta, eps, momentum, running_mean, running_var, num_batches_tracked, coef);
+    const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, R};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, nblk, C, stats, bn);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -1250,8 +1511,8 @@ extern "C" int sn_bn_backward_coef(int nblk, int C, long long R, const float *st
                                    float *dbeta, float *dbias, float *kcoef, sn_stream_t stream)
 {
     SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && coef && dgamma && dbeta && kcoef, "bad argument");
-    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, nblk, C, R, stats, coef,
-                       dgamma, dbeta, dbias, kcoef);
+    const BnBwd bb{coef, dgamma, dbeta, dbias, kcoef, R};
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, nblk, C, stats, bb);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -49,6 +49,22 @@ def _linear_fwd(R, L, a_in, coef_prev, want_stats):
     return z, stats, nblk
 
 
+def _layer_fwd_bn(R, L, a_in, coef_prev):
+    """Training forward of a layer with BatchNorm: pre-BN output z and coef (scale, shift, mean, invstd); running
+    statistics updated in place.  One launch when R <= 32 (finalisation fused), GEMM + bn_finalize otherwise."""
+    bn = L.bn
+    z = _empty((R, L.Co), a_in)
+    coef = _empty((4, L.Co), a_in)
+    stats = _empty((lib.sn_linear_stats_blocks(R), 2, L.Co), a_in)
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    upd = bn.track_running_stats
+    check(lib.sn_layer_forward_bn(R, L.Ci, L.Co, ptr(a_in), ptr(coef_prev), ptr(L.W), ptr(L.b), ptr(z), ptr(stats),
+                                  ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(mom),
+                                  ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None,
+                                  ptr(bn.num_batches_tracked) if upd else None, ptr(coef), _st(a_in)), "sn_layer_forward_bn")
+    return z, coef
+
+
 def _bn_coef(L, R, stats, nblk, training):
     bn = L.bn
     C = L.Co
@@ -74,8 +90,11 @@ def forward_impl(net, x_bnc, training):
     use_batch_stats = training
     a_in, coef_prev = x_bnc.view(R, 3), None
     for L in convs:
-        z, stats, nblk = _linear_fwd(R, L, a_in, coef_prev, use_batch_stats)
-        coef = _bn_coef(L, R, stats, nblk, training)
+        if training:
+            z, coef = _layer_fwd_bn(R, L, a_in, coef_prev)
+        else:
+            z, stats, nblk = _linear_fwd(R, L, a_in, coef_prev, use_batch_stats)
+            coef = _bn_coef(L, R, stats, nblk, training)
         saved["zc"].append(z)
         saved["cc"].append(coef)
         a_in, coef_prev = z, coef
@@ -88,8 +107,11 @@ def forward_impl(net, x_bnc, training):
     saved.update(pooled=pooled, argsel=argsel, zsel=zsel)
     a_in, coef_prev = pooled, None
     for L in fcs[:-1]:
-        z, stats, nblk = _linear_fwd(B, L, a_in, coef_prev, use_batch_stats)
-        coef = _bn_coef(L, B, stats, nblk, training)
+        if training:
+            z, coef = _layer_fwd_bn(B, L, a_in, coef_prev)
+        else:
+            z, stats, nblk = _linear_fwd(B, L, a_in, coef_prev, use_batch_stats)
+            coef = _bn_coef(L, B, stats, nblk, training)
         saved["zf"].append(z)
         saved["cf"].append(coef)
         a_in, coef_prev = z, coef
@@ -177,6 +199,28 @@ def _bn_bwd(L, R, stats, nblk, coef, sink=None, bn_name="", lin_name=""):
     return dgamma, dbeta, dbias, kcoef
 
 
+def _layer_bwd(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, Lprev, sink, name, bn_prev, lin_prev,
+               with_bias):
+    """Backward of layer `name`: dW (db when with_bias), dYprev and -- when the layer below (Lprev) has a BatchNorm --
+    that BatchNorm's dgamma / dbeta, the bias gradient of the layer below, and its dZ coefficients (kcoef)."""
+    dW = _out(sink, name + ".weight", L.W)
+    db = _out(sink, name + ".bias", L.b) if with_bias else None
+    dyprev = _empty((R, L.Ci), L.W)
+    has_bn = coef_prev is not None
+    stats = _empty((lib.sn_linear_stats_blocks(R), 2, L.Ci), L.W) if has_bn else None
+    nsplit = lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 1 if with_bias else 0)
+    part = _empty((nsplit * L.Co * (L.Ci + (1 if with_bias else 0)),), L.W)
+    dg = dbt = dbs = kc = None
+    if has_bn:
+        dg, dbt = _out(sink, bn_prev + ".weight", Lprev.bn.weight), _out(sink, bn_prev + ".bias", Lprev.bn.bias)
+        dbs = _out(sink, lin_prev + ".bias", Lprev.b)
+        kc = _empty((3, L.Ci), L.W)
+    check(lib.sn_layer_backward(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(L.W),
+                                ptr(zprev), ptr(coef_prev), ptr(dyprev), ptr(stats), ptr(part), ptr(dW), ptr(db), ptr(dg),
+                                ptr(dbt), ptr(dbs), ptr(kc), _st(L.W)), "sn_layer_backward")
+    return dW, db, dyprev, dg, dbt, dbs, kc
+
+
 def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
     """-> dict parameter-name -> gradient tensor (every parameter of the MLP).
     sink: optional dict name -> preallocated tensor the gradient is written into (overwritten, not accumulated).
@@ -192,19 +236,21 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
     grad_y = grad_y.contiguous()
     zf, cf, zc, cc = saved["zf"], saved["cf"], saved["zc"], saved["cc"]
 
-    # ---- FC head (rows = B) ----
-    L = fcs[3]
-    dW, db = _wgrad(B, L, DZ_PLAIN, grad_y, None, None, None, None, 1, zf[2], cf[2], True, sink, "fc4")
-    grads["fc4.weight"], grads["fc4.bias"] = dW, db
-    dy, stats, nblk = _dgrad(B, L, DZ_PLAIN, grad_y, None, None, None, None, 1, zf[2], cf[2])
-    for j in (2, 1, 0):
+    # ---- FC head (rows = B): fc4 -> fc3 -> fc2 -> fc1 -> pooled features ----
+    dy, kcoef = grad_y, None
+    for j in (3, 2, 1, 0):
         L = fcs[j]
-        dgamma, dbeta, dbias, kcoef = _bn_bwd(L, B, stats, nblk, cf[j], sink, bn_f[j], names_f[j])
-        grads[bn_f[j] + ".weight"], grads[bn_f[j] + ".bias"], grads[names_f[j] + ".bias"] = dgamma, dbeta, dbias
-        aprev, cprev = (zf[j - 1], cf[j - 1]) if j > 0 else (saved["pooled"], None)
-        dW, _ = _wgrad(B, L, DZ_BN, dy, zf[j], kcoef, None, None, 1, aprev, cprev, False, sink, names_f[j])
+        mode = DZ_PLAIN if j == 3 else DZ_BN
+        zprev, cprev, Lprev = (zf[j - 1], cf[j - 1], fcs[j - 1]) if j > 0 else (saved["pooled"], None, None)
+        dW, db, dy, dg, dbt, dbs, kc = _layer_bwd(B, L, mode, dy, zf[j] if j < 3 else None, kcoef, None, None, 1, zprev, cprev,
+                                                  Lprev, sink, names_f[j], bn_f[j - 1] if j > 0 else "", names_f[j - 1] if j > 0 else "",
+                                                  j == 3)
         grads[names_f[j] + ".weight"] = dW
-        dy, stats, nblk = _dgrad(B, L, DZ_BN, dy, zf[j], kcoef, None, None, 1, aprev, cprev)
+        if db is not None:
+            grads[names_f[j] + ".bias"] = db
+        if j > 0:
+            grads[bn_f[j - 1] + ".weight"], grads[bn_f[j - 1] + ".bias"], grads[names_f[j - 1] + ".bias"] = dg, dbt, dbs
+        kcoef = kc
     g_pool = dy  # (B, C5): gradient w.r.t. the pooled features
     if after_fc is not None:
         _join_side(grad_y.device)
@@ -216,21 +262,22 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
     stats = _empty((1, 2, C5), grad_y)
     check(lib.sn_pool_backward(B, C5, ptr(g_pool), ptr(saved["pooled"]), ptr(saved["zsel"]), ptr(gsel), ptr(stats),
                                _st(grad_y)), "sn_pool_backward")
-    nblk = 1
-    # ---- conv stack (rows = B*N) ----
+    dgamma, dbeta, dbias, kcoef = _bn_bwd(convs[4], R, stats, 1, cc[4], sink, bn_c[4], names_c[4])
+    grads[bn_c[4] + ".weight"], grads[bn_c[4] + ".bias"], grads[names_c[4] + ".bias"] = dgamma, dbeta, dbias
+
+    # ---- conv stack (rows = B*N): conv5 -> ... -> conv2 (each also finishes the BatchNorm of the layer below), conv1 ----
     dy = None
-    for i in (4, 3, 2, 1, 0):
+    for i in (4, 3, 2, 1):
         L = convs[i]
-        dgamma, dbeta, dbias, kcoef = _bn_bwd(L, R, stats, nblk, cc[i], sink, bn_c[i], names_c[i])
-        grads[bn_c[i] + ".weight"], grads[bn_c[i] + ".bias"], grads[names_c[i] + ".bias"] = dgamma, dbeta, dbias
         mode = DZ_POOL if i == 4 else DZ_BN
         gs, ag = (gsel, saved["argsel"]) if i == 4 else (None, None)
-        aprev, cprev = (zc[i - 1], cc[i - 1]) if i > 0 else (saved["x"].view(R, 3), None)
-        if i > 0:
-            dW, dy, stats, nblk = _bwd_layer(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev, sink, names_c[i])
-        else:
-            dW, _ = _wgrad(R, L, mode, dy, zc[i], kcoef, gs, ag, N, aprev, cprev, False, sink, names_c[i])
+        dW, _, dy, dg, dbt, dbs, kc = _layer_bwd(R, L, mode, dy, zc[i], kcoef, gs, ag, N, zc[i - 1], cc[i - 1], convs[i - 1],
+                                                 sink, names_c[i], bn_c[i - 1], names_c[i - 1], False)
         grads[names_c[i] + ".weight"] = dW
+        grads[bn_c[i - 1] + ".weight"], grads[bn_c[i - 1] + ".bias"], grads[names_c[i - 1] + ".bias"] = dg, dbt, dbs
+        kcoef = kc
+    dW, _ = _wgrad(R, convs[0], DZ_BN, dy, zc[0], kcoef, None, None, N, saved["x"].view(R, 3), None, False, sink, names_c[0])
+    grads[names_c[0] + ".weight"] = dW
     _join_side(grad_y.device)  # all weight gradients complete before backward returns on the main stream
     return grads
 
