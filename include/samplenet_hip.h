@@ -113,6 +113,14 @@ int sn_simplification_loss_backward(int B, int n1, const float *xyz1, int n2, co
                                     const int *idx2, const int *argmax1, float weight, const float *grad_loss,
                                     float *grad_xyz1, float *grad_xyz2, sn_stream_t stream);
 
+/* The sampler's total loss with the benchmark's stand-in task term (registration/main.py:507-531):
+ *     L = alpha * L_simp + lmbda * max(T^2, min_sigma) + mean(proj)        (all operands device scalars / tensors)
+ * forward: loss (1 float).  backward: grad_proj (nproj floats, = grad_loss / nproj), grad_lsimp (1), grad_T (1). */
+int sn_sampler_loss_forward(int nproj, const float *proj, const float *lsimp, const float *temperature,
+                            float alpha, float lmbda, float min_sigma, float *loss, sn_stream_t stream);
+int sn_sampler_loss_backward(int nproj, const float *grad_loss, const float *temperature, float alpha, float lmbda,
+                             float min_sigma, float *grad_proj, float *grad_lsimp, float *grad_T, sn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.
  * Replaces knn_cuda.KNN(k)(ref, query) (soft_projection.py:11-14) and knn_point

@@ -32,6 +32,8 @@ PROTOTYPES = {
     "sn_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_simplification_loss_forward": [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "sn_simplification_loss_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "sn_sampler_loss_forward": [_i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
+    "sn_sampler_loss_backward": [_i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -530,6 +530,68 @@ extern "C" int sn_simplification_loss_backward(int B, int n1, const float *xyz1,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The sampler's total loss as registration/main.py:507-531 composes it, with the benchmark's stand-in task term
+// (SURVEY.md 8d):   L = alpha * L_simp + lmbda * max(T^2, min_sigma) + mean(proj)
+// One single-workgroup kernel forward, one backward (replaces ~20 elementwise / reduction launches of the op-by-op
+// composition).  Reductions run in a fixed order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) sampler_loss_fwd_kernel(int nproj, const float *__restrict__ proj,
+                                                                const float *__restrict__ lsimp,
+                                                                const float *__restrict__ temperature, float alpha,
+                                                                float lmbda, float min_sigma, float *__restrict__ loss)
+{
+    __shared__ float red[1024];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nproj; i += 1024) acc += proj[i];
+    red[threadIdx.x] = acc;
+    for (int s = 512; s > 0; s >>= 1) {
+        __syncthreads();
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    }
+    if (threadIdx.x == 0) {
+        const float T = *temperature;
+        loss[0] = alpha * lsimp[0] + lmbda * fmaxf(T * T, min_sigma) + red[0] / (float)nproj;
+    }
+}
+
+__global__ void __launch_bounds__(256) sampler_loss_bwd_kernel(int nproj, const float *__restrict__ grad_loss,
+                                                               const float *__restrict__ temperature, float alpha,
+                                                               float lmbda, float min_sigma, float *__restrict__ grad_proj,
+                                                               float *__restrict__ grad_lsimp, float *__restrict__ grad_T)
+{
+    const float g = grad_loss[0];
+    const float gp = g / (float)nproj;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nproj; i += gridDim.x * blockDim.x) grad_proj[i] = gp;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        grad_lsimp[0] = alpha * g;
+        const float T = *temperature, t2 = T * T;
+        const float w = t2 > min_sigma ? 1.f : (t2 == min_sigma ? 0.5f : 0.f);
+        grad_T[0] = lmbda * g * w * 2.0f * T;
+    }
+}
+
+extern "C" int sn_sampler_loss_forward(int nproj, const float *proj, const float *lsimp, const float *temperature,
+                                       float alpha, float lmbda, float min_sigma, float *loss, sn_stream_t stream)
+{
+    SN_REQUIRE(nproj >= 1 && proj && lsimp && temperature && loss, "bad argument");
+    hipLaunchKernelGGL(sampler_loss_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nproj, proj, lsimp, temperature,
+                       alpha, lmbda, min_sigma, loss);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_sampler_loss_backward(int nproj, const float *grad_loss, const float *temperature, float alpha,
+                                        float lmbda, float min_sigma, float *grad_proj, float *grad_lsimp, float *grad_T,
+                                        sn_stream_t stream)
+{
+    SN_REQUIRE(nproj >= 1 && grad_loss && temperature && grad_proj && grad_lsimp && grad_T, "bad argument");
+    hipLaunchKernelGGL(sampler_loss_bwd_kernel, dim3((nproj + 255) / 256), dim3(256), 0, (hipStream_t)stream, nproj, grad_loss,
+                       temperature, alpha, lmbda, min_sigma, grad_proj, grad_lsimp, grad_T);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 // d loss / dT from the per-workgroup partials of d loss / d sigma:  sigma = max(T^2, min_sigma)
 //   dT = (sum partial) * 2T * [T^2 > min_sigma]   (torch.max splits the gradient evenly on an exact tie)
 __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float *__restrict__ partial,

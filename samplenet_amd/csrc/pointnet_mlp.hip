@@ -444,18 +444,25 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const ActSrc a = g.a;
     const WSrc w = g.w;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    // epilogue inputs are fetched BEFORE the GEMM: a load issued in the epilogue would expose a full memory latency
+    float biasv[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
+        biasv[j] = g.bias ? g.bias[(FULL || col < Co) ? col : 0] : 0.f;
+    }
     gemm_tile<T, true, true>(
         acc, Ci, [&](int x, int k) { return a.template load_c4<FULL, AMODE>(row0 + x, k); },
         [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave / T::WC, wc = wave % T::WC;
     float s0[T::TN], s1[T::TN];
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
-        const float bias = g.bias ? g.bias[(FULL || col < Co) ? col : 0] : 0.f;
+        const float bias = biasv[j];
         s0[j] = 0.f, s1[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
@@ -503,21 +510,38 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &g, int bx, int by, f
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const DzSrc dz = g.dz;
     const WSrc w = g.w;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    constexpr bool masked = PMODE == ACT_BN_RELU;
+    // epilogue inputs (previous layer's pre-BN activations at this lane's output elements, its BN scale / shift) are
+    // fetched BEFORE the GEMM so that their latency hides under it
+    float zpv[T::TM][T::TN][16], scv[T::TN], shv[T::TN];
+    if (masked) {
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
+            const int cc = (FULL || col < Ci) ? col : 0;
+            scv[j] = g.prev.scale[cc], shv[j] = g.prev.shift[cc];
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
+                    zpv[i][j][e] = g.prev.z[(FULL || (row < R && col < Ci)) ? (size_t)row * Ci + col : 0];
+                }
+        }
+    }
     // A: dZ rows, k = co contiguous.  B[k = co][x = ci]: W row-major is exactly [K][X], x contiguous.
     gemm_tile<T, true, false>(
         acc, Co, [&](int x, int k) { return dz.template load_c4<FULL, ZMODE>(row0 + x, k); },
         [&](int x, int k) { return w.template load_ci4<FULL>(k, col0 + x); }, lds);
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave / T::WC, wc = wave % T::WC;
-    constexpr bool masked = PMODE == ACT_BN_RELU;
     float s0[T::TN], s1[T::TN];
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
-        float sc = 0.f, sh = 0.f;
-        if (masked) sc = g.prev.scale[(FULL || col < Ci) ? col : 0], sh = g.prev.shift[(FULL || col < Ci) ? col : 0];
+        const float sc = masked ? scv[j] : 0.f, sh = masked ? shv[j] : 0.f;
         s0[j] = 0.f, s1[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
@@ -527,7 +551,7 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &g, int bx, int by, f
                 if (FULL || (row < R && col < Ci)) {
                     float v = acc[i][j][e];
                     if (masked) {
-                        const float zp = g.prev.z[(size_t)row * Ci + col];
+                        const float zp = zpv[i][j][e];
                         v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
                         s0[j] += v;
                         s1[j] += v * zp;
@@ -661,7 +685,15 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
     const int R = g.a.rows, Co = g.w.co, Ci = g.w.ci;
     const int col = blockIdx.x * 32 + l31;
     const bool colok = col < Co;
-    const float *wrow = g.w.w + (size_t)(colok ? col : 0) * Ci;
+    const int ccol = colok ? col : 0;
+    const float *wrow = g.w.w + (size_t)ccol * Ci;
+    // epilogue inputs first: loads issued after the MFMAs would each expose a full memory latency
+    const float bias = g.bias ? g.bias[ccol] : 0.f;
+    float bn_g = 0.f, bn_b = 0.f, bn_rm = 0.f, bn_rv = 0.f;
+    if (g.bn.coef) {
+        bn_g = g.bn.gamma[ccol], bn_b = g.bn.beta[ccol];
+        if (g.bn.running_mean) bn_rm = g.bn.running_mean[ccol], bn_rv = g.bn.running_var[ccol];
+    }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -693,7 +725,6 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
     }
     wave_sum_to_wave0(acc, lds);
     if (wave != 0) return;
-    const float bias = (colok && g.bias) ? g.bias[col] : 0.f;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -710,20 +741,47 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
     if (g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Co + col] = s1;
     if (g.bn.coef) {  // this workgroup holds every row of its 32 columns: their batch statistics are complete here
         if (blockIdx.x == 0 && lane == 0 && g.bn.num_batches_tracked) *g.bn.num_batches_tracked += 1;
-        if (lane < 32 && colok) bn_finalize_channel(g.bn, Co, col, (double)s0, (double)s1);
+        if (lane < 32 && colok) {  // same arithmetic as bn_finalize_channel, on the prefetched parameters
+            const double mean = (double)s0 / (double)g.bn.R;
+            double var = (double)s1 / (double)g.bn.R - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)g.bn.eps));
+            const float sc = bn_g * invstd;
+            g.bn.coef[col] = sc;
+            g.bn.coef[Co + col] = bn_b - (float)mean * sc;
+            g.bn.coef[2 * Co + col] = (float)mean;
+            g.bn.coef[3 * Co + col] = invstd;
+            if (g.bn.running_mean) {
+                const double unbiased = g.bn.R > 1 ? var * (double)g.bn.R / (double)(g.bn.R - 1) : var;
+                g.bn.running_mean[col] = (1.f - g.bn.momentum) * bn_rm + g.bn.momentum * (float)mean;
+                g.bn.running_var[col] = (1.f - g.bn.momentum) * bn_rv + g.bn.momentum * (float)unbiased;
+            }
+        }
     }
 }
 
 // dYprev[R<=32][Ci] = mask . (dZ . W) ; stats [1][2][Ci]
 template <int ZMODE, int PMODE, bool VEC>
-__global__ void __launch_bounds__(256) small_dgrad_kernel(DgradArgs g)
+__device__ __forceinline__ void small_dgrad_body(const DgradArgs &g, int bx, float *lds)
 {
-    __shared__ float lds[3 * 16 * 64];
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int R = g.dz.rows, Co = g.w.co, Ci = g.w.ci;
-    const int col = blockIdx.x * 32 + l31;  // ci
+    const int col = bx * 32 + l31;  // ci
     const bool colok = col < Ci;
+    constexpr bool masked = PMODE == ACT_BN_RELU;
+    // epilogue inputs first (previous layer's pre-BN activations at this lane's outputs, its BN coefficients)
+    float zpv[16], sc = 0.f, sh = 0.f, pmean = 0.f, pinv = 0.f;
+    if (masked) {
+        const int cc = colok ? col : 0;
+        sc = g.prev.scale[cc], sh = g.prev.shift[cc];
+        if (g.bb.coef) pmean = g.bb.coef[2 * Ci + cc], pinv = g.bb.coef[3 * Ci + cc];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = frag_row(e, lane);
+            zpv[e] = g.prev.z[(row < R && colok) ? (size_t)row * Ci + col : 0];
+        }
+    }
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -755,9 +813,6 @@ __global__ void __launch_bounds__(256) small_dgrad_kernel(DgradArgs g)
     }
     wave_sum_to_wave0(acc, lds);
     if (wave != 0) return;
-    constexpr bool masked = PMODE == ACT_BN_RELU;
-    float sc = 0.f, sh = 0.f;
-    if (masked && colok) sc = g.prev.scale[col], sh = g.prev.shift[col];
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -765,7 +820,7 @@ __global__ void __launch_bounds__(256) small_dgrad_kernel(DgradArgs g)
         if (row < R && colok) {
             float v = acc[e];
             if (masked) {
-                const float zp = g.prev.z[(size_t)row * Ci + col];
+                const float zp = zpv[e];
                 v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
                 s0 += v;
                 s1 += v * zp;
@@ -776,17 +831,35 @@ __global__ void __launch_bounds__(256) small_dgrad_kernel(DgradArgs g)
     s0 += __shfl_xor(s0, 32);
     s1 += __shfl_xor(s1, 32);
     if (masked && g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Ci + col] = s1;
-    if (masked && g.bb.coef && lane < 32 && colok) bn_backward_channel(g.bb, Ci, col, (double)s0, (double)s1);
+    if (masked && g.bb.coef && lane < 32 && colok) {  // bn_backward_channel on the prefetched mean / invstd
+        const double scale = sc, mean = pmean, invstd = pinv, s = s0, sz = s1;
+        const double dg = invstd * (sz - mean * s);
+        g.bb.dgamma[col] = (float)dg;
+        g.bb.dbeta[col] = (float)s;
+        const double rinv = 1.0 / (double)g.bb.R;
+        const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
+        const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
+        g.bb.kcoef[col] = k1, g.bb.kcoef[Ci + col] = k2, g.bb.kcoef[2 * Ci + col] = k3;
+        if (g.bb.dbias)
+            g.bb.dbias[col] = (float)((double)k1 * s + (double)k2 * (double)g.bb.R * mean + (double)g.bb.R * (double)k3);
+    }
+}
+
+template <int ZMODE, int PMODE, bool VEC>
+__global__ void __launch_bounds__(256) small_dgrad_kernel(DgradArgs g)
+{
+    __shared__ float lds[3 * 16 * 64];
+    small_dgrad_body<ZMODE, PMODE, VEC>(g, blockIdx.x, lds);
 }
 
 // dW[Co][Ci] (and db[Co] through the ones column) = dZ^T . act(prev), K = R <= 32: one wave per 32x32 output tile,
 // no partials.
 template <int ZMODE, int PMODE>
-__global__ void __launch_bounds__(256) small_wgrad_kernel(WgradArgs g, float *__restrict__ dW, float *__restrict__ db,
-                                                          int tiles_n, int ntiles)
+__device__ __forceinline__ void small_wgrad_body(const WgradArgs &g, float *__restrict__ dW, float *__restrict__ db,
+                                                 int tiles_n, int ntiles, int bx)
 {
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = bx * 4 + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
     const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
     const int Co = g.dz.ch, Ci = g.prev.ch, Ce = g.ncols, R = g.dz.rows;
@@ -814,6 +887,27 @@ __global__ void __launch_bounds__(256) small_wgrad_kernel(WgradArgs g, float *__
                 db[row] = acc[e];
         }
     }
+}
+
+template <int ZMODE, int PMODE>
+__global__ void __launch_bounds__(256) small_wgrad_kernel(WgradArgs g, float *__restrict__ dW, float *__restrict__ db,
+                                                          int tiles_n, int ntiles)
+{
+    small_wgrad_body<ZMODE, PMODE>(g, dW, db, tiles_n, ntiles, blockIdx.x);
+}
+
+// R <= 32 backward of one layer in ONE launch: workgroups [0, n_d) compute the data gradient (their epilogue also
+// finishes the BatchNorm backward of the layer below), the rest the weight gradient.  Every launch on this chain costs
+// a kernel boundary plus a cold first load (~4-5 us), whatever the amount of work.
+template <int ZMODE, int PMODE, bool VEC>
+__global__ void __launch_bounds__(256) small_bwd_kernel(DgradArgs d, WgradArgs w, float *__restrict__ dW,
+                                                        float *__restrict__ db, int tiles_n, int ntiles, int n_d)
+{
+    __shared__ float lds[3 * 16 * 64];
+    if ((int)blockIdx.x < n_d)
+        small_dgrad_body<ZMODE, PMODE, VEC>(d, blockIdx.x, lds);
+    else
+        small_wgrad_body<ZMODE, PMODE>(w, dW, db, tiles_n, ntiles, blockIdx.x - n_d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1425,23 +1519,35 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
     hipStream_t st = (hipStream_t)stream;
     const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, (long long)R};
     if (R <= 32) {
-        int rc = sn_linear_wgrad(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, part ? part : dW, dW, db,
-                                 stream);
-        if (rc) return rc;
         DgradArgs g{};
         g.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
         g.w.w = W, g.w.co = Co, g.w.ci = Ci;
         g.prev = make_act(zprev, coef_prev, R, Ci);
         g.dyprev = dyprev, g.stats = nullptr;
         if (coef_prev) g.bb = bb;
-        const bool pm = coef_prev != nullptr;
+        WgradArgs wg{};
+        wg.dz = g.dz;
+        wg.prev = make_act(zprev, coef_prev, R, Ci, db ? Ci : -1);
+        wg.ncols = Ci + (db ? 1 : 0);
+        const int tm = (Co + 31) / 32, tn = (wg.ncols + 31) / 32, ntiles = tm * tn;
+        const int n_d = (Ci + 31) / 32, n_w = (ntiles + 3) / 4;
+        const dim3 grid(n_d + n_w), block(256);
+        const bool pm = coef_prev != nullptr, vec = Co % 64 == 0;
+#define SN_SB(ZM, PM)                                                                                                   \
+    do {                                                                                                                \
+        if (vec)                                                                                                        \
+            hipLaunchKernelGGL((small_bwd_kernel<ZM, PM, true>), grid, block, 0, st, g, wg, dW, db, tn, ntiles, n_d);    \
+        else                                                                                                            \
+            hipLaunchKernelGGL((small_bwd_kernel<ZM, PM, false>), grid, block, 0, st, g, wg, dW, db, tn, ntiles, n_d);   \
+    } while (0)
         if (dz_mode == DZ_PLAIN) {
-            if (pm) launch_dgrad<DZ_PLAIN, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_PLAIN, ACT_NONE>(g, st);
+            if (pm) SN_SB(DZ_PLAIN, ACT_BN_RELU); else SN_SB(DZ_PLAIN, ACT_NONE);
         } else if (dz_mode == DZ_BN) {
-            if (pm) launch_dgrad<DZ_BN, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_BN, ACT_NONE>(g, st);
+            if (pm) SN_SB(DZ_BN, ACT_BN_RELU); else SN_SB(DZ_BN, ACT_NONE);
         } else {
-            if (pm) launch_dgrad<DZ_POOL, ACT_BN_RELU>(g, st); else launch_dgrad<DZ_POOL, ACT_NONE>(g, st);
+            if (pm) SN_SB(DZ_POOL, ACT_BN_RELU); else SN_SB(DZ_POOL, ACT_NONE);
         }
+#undef SN_SB
         SN_LAUNCH_CHECK();
         return 0;
     }

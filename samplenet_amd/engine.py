@@ -19,7 +19,7 @@ class SamplerTrainStep:
                  use_graph=True, warmup=3):
         self.net, self.reducer = net, reducer
         self.alpha, self.lmbda, self.gamma, self.delta = alpha, lmbda, gamma, delta
-        self.task_loss = task_loss if task_loss is not None else (lambda proj: proj.mean())
+        self.task_loss = task_loss  # None: the benchmark's stand-in mean(proj), fused with the loss weighting
         self.x = example_x.clone()
         self.graph = None
         self.loss = None
@@ -31,8 +31,16 @@ class SamplerTrainStep:
         if self.reducer is not None:
             self.reducer.zero_grad()
         simp, proj = net(x)
-        loss = (self.alpha * net.get_simplification_loss(x, simp, net.num_out_points, self.gamma, self.delta)
-                + self.lmbda * net.get_projection_loss() + self.task_loss(proj))
+        lsimp = net.get_simplification_loss(x, simp, net.num_out_points, self.gamma, self.delta)
+        if self.task_loss is None and net.training and not net.skip_projection:
+            # alpha * L_simp + lmbda * sigma + mean(proj) in one fused kernel pair (same value as the composition below)
+            from . import ops
+
+            loss = ops.SamplerLossFunction.apply(lsimp, net.project._temperature, proj, self.alpha, self.lmbda,
+                                                 net.project._min_sigma_f)
+        else:
+            task = self.task_loss(proj) if self.task_loss is not None else proj.mean()
+            loss = self.alpha * lsimp + self.lmbda * net.get_projection_loss() + task
         loss.backward()
         return loss.detach()
 

@@ -364,6 +364,40 @@ class SimplificationLossFunction(torch.autograd.Function):
         return g1, g2, None, None, None, None, None
 
 
+class SamplerLossFunction(torch.autograd.Function):
+    """L = alpha * L_simp + lmbda * max(T^2, min_sigma) + mean(proj): the sampler's loss as registration/main.py:507-531
+    composes it, with mean(proj) standing in for the task loss.  One kernel forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, lsimp, temperature, proj, alpha, lmbda, min_sigma):
+        _need_gpu(lsimp, temperature, proj)
+        proj = _f32c(proj)
+        T = temperature.detach().float().reshape(1)
+        ls = lsimp.detach().float().reshape(1)
+        loss = torch.empty((), device=proj.device, dtype=torch.float32)
+        with torch.cuda.device(proj.device):
+            check(lib.sn_sampler_loss_forward(proj.numel(), ptr(proj), ptr(ls), ptr(T), float(alpha), float(lmbda),
+                                              float(min_sigma), ptr(loss), _stream(proj)), "sn_sampler_loss_forward")
+        ctx.save_for_backward(temperature)
+        ctx.cfg = (float(alpha), float(lmbda), float(min_sigma), tuple(proj.shape), lsimp.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (temperature,) = ctx.saved_tensors
+        alpha, lmbda, min_sigma, pshape, lshape = ctx.cfg
+        dev = grad_loss.device
+        gproj = torch.empty(pshape, device=dev, dtype=torch.float32)
+        gls = torch.empty(1, device=dev, dtype=torch.float32)
+        gT = torch.empty(1, device=dev, dtype=torch.float32)
+        gl = grad_loss.contiguous().float().reshape(1)
+        T = temperature.detach().float().reshape(1)
+        with torch.cuda.device(dev):
+            check(lib.sn_sampler_loss_backward(gproj.numel(), ptr(gl), ptr(T), alpha, lmbda, min_sigma, ptr(gproj), ptr(gls),
+                                               ptr(gT), _stream(gl)), "sn_sampler_loss_backward")
+        return gls.reshape(lshape), gT.reshape(temperature.shape), gproj, None, None, None
+
+
 # --------------------------------------------------------------------------------------------- EMD
 def approx_match(xyz1, xyz2):
     """xyz1 (B,n,3), xyz2 (B,m,3) -> match (B,m,n); no gradient (tf_approxmatch.py:13-24)."""

@@ -146,3 +146,23 @@ def test_graphed_step_equals_eager_step():
         assert torch.equal(red_a.flat, red_b.flat)
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         assert torch.equal(ba, bb), n
+
+
+def test_fused_sampler_loss_equals_composition():
+    """engine.SamplerTrainStep with the default (fused) loss == the op-by-op composition alpha*L_simp + lmbda*sigma + mean(proj)."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(1)
+    net_a = SampleNet(64, 128, group_size=8, initial_temperature=0.5, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    x = torch.rand(6, 512, 3, device="cuda") - 0.5
+    red_a, red_b = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b)
+    la = SamplerTrainStep(net_a, x, alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, reducer=red_a, use_graph=False)(x)
+    lb = SamplerTrainStep(net_b, x, alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, reducer=red_b, use_graph=False,
+                          task_loss=lambda p: p.mean())(x)
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+    assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
