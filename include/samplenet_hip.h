@@ -111,7 +111,8 @@ int sn_simplification_loss_forward(int B, int n1, int n2, const float *dist1, co
                                    float *partial, int *argmax1, float *loss, sn_stream_t stream);
 int sn_simplification_loss_backward(int B, int n1, const float *xyz1, int n2, const float *xyz2, const int *idx1,
                                     const int *idx2, const int *argmax1, float weight, const float *grad_loss,
-                                    float *grad_xyz1, float *grad_xyz2, sn_stream_t stream);
+                                    float *grad_xyz1, float *grad_xyz2, int layout1, sn_stream_t stream);
+/* layout1: 0 = xyz1 / grad_xyz1 are (B,n1,3); 1 = (B,3,n1), the layout the sampler's FC head emits (grad_xyz2 must be NULL) */
 
 /* The sampler's total loss with the benchmark's stand-in task term (registration/main.py:507-531):
  *     L = alpha * L_simp + lmbda * max(T^2, min_sigma) + mean(proj)        (all operands device scalars / tensors)

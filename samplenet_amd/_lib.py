@@ -31,7 +31,7 @@ PROTOTYPES = {
     "sn_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_simplification_loss_forward": [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
-    "sn_simplification_loss_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "sn_simplification_loss_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp],
     "sn_sampler_loss_forward": [_i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
     "sn_sampler_loss_backward": [_i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) chamfer_bwd_kernel(int nt, int ns, const 
                                                           const int *__restrict__ idxT,
                                                           const float *__restrict__ gS,
                                                           const int *__restrict__ idxS, float *__restrict__ gradT,
-                                                          int own_first, ImplicitGrad ig)
+                                                          int own_first, ImplicitGrad ig, int t_layout)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -59,7 +59,9 @@ __global__ void __launch_bounds__(256) chamfer_bwd_kernel(int nt, int ns, const 
     }
     gradT += (size_t)b * nt * 3;
     for (int j = blockIdx.y * nwaves + wave; j < nt; j += gridDim.y * nwaves) {
-        const float tx = T[j * 3 + 0], ty = T[j * 3 + 1], tz = T[j * 3 + 2];
+        // target coordinates / gradient: point-major (nt,3) or channel-major (3,nt) -- the sampler's FC head emits (3,M)
+        const int o0 = t_layout ? j : j * 3, os = t_layout ? nt : 1;
+        const float tx = T[o0], ty = T[o0 + os], tz = T[o0 + 2 * os];
         const int j2 = idxT[j];
         const float g = (implicit ? gLv * (ig.ct + (j == amt ? ig.cmax_t : 0.f)) : gT[j]) * 2;
         const float ox = g * (tx - S[j2 * 3 + 0]);
@@ -89,7 +91,7 @@ __global__ void __launch_bounds__(256) chamfer_bwd_kernel(int nt, int ns, const 
             }
         }
         if (!own_first) ax += ox, ay += oy, az += oz;
-        if (lane < 3) gradT[j * 3 + lane] = lane == 0 ? ax : (lane == 1 ? ay : az);
+        if (lane < 3) gradT[o0 + lane * os] = lane == 0 ? ax : (lane == 1 ? ay : az);
     }
 }
 
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(256) chamfer_bwd_reg_kernel(int nt, int ns, co
                                                               const int *__restrict__ idxT,
                                                               const float *__restrict__ gS,
                                                               const int *__restrict__ idxS, float *__restrict__ gradT,
-                                                              int own_first, ImplicitGrad ig)
+                                                              int own_first, ImplicitGrad ig, int t_layout)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -135,7 +137,9 @@ __global__ void __launch_bounds__(256) chamfer_bwd_reg_kernel(int nt, int ns, co
         gg[i] = (implicit ? gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) : gS[lc]) * 2;
     }
     for (int j = blockIdx.y * nwaves + wave; j < nt; j += gridDim.y * nwaves) {
-        const float tx = T[j * 3 + 0], ty = T[j * 3 + 1], tz = T[j * 3 + 2];
+        // target coordinates / gradient: point-major (nt,3) or channel-major (3,nt) -- the sampler's FC head emits (3,M)
+        const int o0 = t_layout ? j : j * 3, os = t_layout ? nt : 1;
+        const float tx = T[o0], ty = T[o0 + os], tz = T[o0 + 2 * os];
         const int j2 = idxT[j];
         const float g = (implicit ? gLv * (ig.ct + (j == amt ? ig.cmax_t : 0.f)) : gT[j]) * 2;
         const float ox = g * (tx - S[j2 * 3 + 0]);
@@ -158,23 +162,23 @@ __global__ void __launch_bounds__(256) chamfer_bwd_reg_kernel(int nt, int ns, co
             }
         }
         if (!own_first) ax += ox, ay += oy, az += oz;
-        if (lane < 3) gradT[j * 3 + lane] = lane == 0 ? ax : (lane == 1 ? ay : az);
+        if (lane < 3) gradT[o0 + lane * os] = lane == 0 ? ax : (lane == 1 ? ay : az);
     }
 }
 
 static void launch_chamfer_bwd(int b, int ysplit, int nt, int ns, const float *T, const float *S, const float *gT,
                                const int *idxT, const float *gS, const int *idxS, float *gradT, int own_first,
-                               const ImplicitGrad &ig, hipStream_t st)
+                               const ImplicitGrad &ig, hipStream_t st, int t_layout = 0)
 {
     const dim3 grid(b, ysplit), block(256);
 #define SN_CB(PPL_) \
-    hipLaunchKernelGGL(chamfer_bwd_reg_kernel<PPL_>, grid, block, 0, st, nt, ns, T, S, gT, idxT, gS, idxS, gradT, own_first, ig)
+    hipLaunchKernelGGL(chamfer_bwd_reg_kernel<PPL_>, grid, block, 0, st, nt, ns, T, S, gT, idxT, gS, idxS, gradT, own_first, ig, t_layout)
     if (ns <= 64) SN_CB(1);
     else if (ns <= 256) SN_CB(4);
     else if (ns <= 1024) SN_CB(16);
     else if (ns <= 2048) SN_CB(32);
     else
-        hipLaunchKernelGGL(chamfer_bwd_kernel, grid, block, 0, st, nt, ns, T, S, gT, idxT, gS, idxS, gradT, own_first, ig);
+        hipLaunchKernelGGL(chamfer_bwd_kernel, grid, block, 0, st, nt, ns, T, S, gT, idxT, gS, idxS, gradT, own_first, ig, t_layout);
 #undef SN_CB
 }
 
@@ -511,8 +515,10 @@ extern "C" int sn_simplification_loss_forward(int B, int n1, int n2, const float
 // grad_xyz1 (B,n1,3) / grad_xyz2 (B,n2,3) of the fused loss; grad_loss: device scalar.  Either output may be NULL.
 extern "C" int sn_simplification_loss_backward(int B, int n1, const float *xyz1, int n2, const float *xyz2, const int *idx1,
                                                const int *idx2, const int *argmax1, float weight, const float *grad_loss,
-                                               float *grad_xyz1, float *grad_xyz2, sn_stream_t stream)
+                                               float *grad_xyz1, float *grad_xyz2, int layout1, sn_stream_t stream)
 {
+    SN_REQUIRE(layout1 == 0 || layout1 == 1, "layout1 must be 0 (B,n1,3) or 1 (B,3,n1)");
+    SN_REQUIRE(layout1 == 0 || !grad_xyz2, "grad_xyz2 needs xyz1 in (B,n1,3) layout");
     SN_REQUIRE(B >= 1 && n1 >= 1 && n2 >= 1, "bad size");
     SN_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && argmax1 && grad_loss, "null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -520,7 +526,7 @@ extern "C" int sn_simplification_loss_backward(int B, int n1, const float *xyz1,
     const float c1 = 1.0f / ((float)B * (float)n1), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)n2);
     if (grad_xyz1) {
         ImplicitGrad ig{grad_loss, argmax1, nullptr, c1, cm, c2, 0.f};
-        launch_chamfer_bwd(B, ysplit(n1), n1, n2, xyz1, xyz2, nullptr, idx1, nullptr, idx2, grad_xyz1, 1, ig, st);
+        launch_chamfer_bwd(B, ysplit(n1), n1, n2, xyz1, xyz2, nullptr, idx1, nullptr, idx2, grad_xyz1, 1, ig, st, layout1);
     }
     if (grad_xyz2) {
         ImplicitGrad ig{grad_loss, nullptr, argmax1, c2, 0.f, c1, cm};

@@ -21,6 +21,7 @@ class SamplerTrainStep:
         self.alpha, self.lmbda, self.gamma, self.delta = alpha, lmbda, gamma, delta
         self.task_loss = task_loss  # None: the benchmark's stand-in mean(proj), fused with the loss weighting
         self.x = example_x.clone()
+        self._one = torch.ones((), device=example_x.device, dtype=torch.float32)
         self.graph = None
         self.loss = None
         if use_graph:
@@ -41,7 +42,7 @@ class SamplerTrainStep:
         else:
             task = self.task_loss(proj) if self.task_loss is not None else proj.mean()
             loss = self.alpha * lsimp + self.lmbda * net.get_projection_loss() + task
-        loss.backward()
+        loss.backward(self._one)  # preallocated upstream gradient: no ones_like fill per step
         return loss.detach()
 
     def _capture(self, warmup):

@@ -210,6 +210,7 @@ class SoftProjectFunction(torch.autograd.Function):
         ctx.save_for_backward(P, Q, idx, temperature)
         ctx.min_sigma = float(min_sigma)
         ctx.K, ctx.N, ctx.p_layout, ctx.out_layout = K, N, p_layout, out_layout
+        ctx.set_materialize_grads(False)  # no zero tensors for the (non-differentiable) index / distance outputs
         ctx.mark_non_differentiable(idx)
         if want_chamfer:
             ctx.mark_non_differentiable(dq, iq, dp, ip)  # their gradient is taken by the loss functions below
@@ -218,6 +219,8 @@ class SoftProjectFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_proj, *_unused):
+        if grad_proj is None:
+            return (None,) * 8
         P, Q, idx, temperature = ctx.saved_tensors
         B, N, M = P.shape[0], ctx.N, Q.shape[2]
         dev = P.device
@@ -328,13 +331,12 @@ class ChamferFromScanFunction(torch.autograd.Function):
 
 
 class SimplificationLossFunction(torch.autograd.Function):
-    """Fused simplification loss (samplenet.py:171-181) on Chamfer products that already exist:
-        loss = mean(dist1) + mean_b(max_m dist1) + weight * mean(dist2)
-    forward(samp_pc (B,M,3), ref_pc (B,N,3), dist1 (B,M), idx1, dist2 (B,N), idx2, weight) -> scalar loss.
-    Backward goes straight to grad(samp_pc) / grad(ref_pc) through sn_simplification_loss_backward."""
+    """loss = mean(dist1) + mean_b(max_m dist1) + weight * mean(dist2)   (samplenet.py:171-181) from the Chamfer products
+    of (samp_pc, ref_pc); backward = Chamfer backward with the implicit upstream gradients, one launch per input.
+    samp_layout: BNC (B,M,3) or BCN (B,3,M) -- the latter lets the loss hang directly off the FC head's output."""
 
     @staticmethod
-    def forward(ctx, samp_pc, ref_pc, dist1, idx1, dist2, idx2, weight):
+    def forward(ctx, samp_pc, ref_pc, dist1, idx1, dist2, idx2, weight, samp_layout=BNC):
         _need_gpu(samp_pc, ref_pc, dist1, dist2)
         B, M = dist1.shape
         N = dist2.shape[1]
@@ -347,21 +349,25 @@ class SimplificationLossFunction(torch.autograd.Function):
                                                      ptr(argmax1), ptr(loss), _stream(dist1)), "sn_simplification_loss_forward")
         ctx.save_for_backward(samp_pc, ref_pc, idx1, idx2, argmax1)
         ctx.weight = float(weight)
+        ctx.samp_layout = samp_layout
+        if samp_layout != BNC and ref_pc.requires_grad:
+            raise ValueError("SimplificationLossFunction: a (B,3,M) sampled cloud needs a constant reference cloud")
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         samp_pc, ref_pc, idx1, idx2, argmax1 = ctx.saved_tensors
         x1, x2 = samp_pc.contiguous(), ref_pc.contiguous()
-        B, M, _ = x1.shape
-        N = x2.shape[1]
+        B, N = x2.shape[0], x2.shape[1]
+        M = idx1.shape[1]
         g1 = torch.empty_like(x1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(x2) if ctx.needs_input_grad[1] else None
         gl = grad_loss.contiguous().float()
         with torch.cuda.device(x1.device):
             check(lib.sn_simplification_loss_backward(B, M, ptr(x1), N, ptr(x2), ptr(idx1), ptr(idx2), ptr(argmax1), ctx.weight,
-                                                      ptr(gl), ptr(g1), ptr(g2), _stream(x1)), "sn_simplification_loss_backward")
-        return g1, g2, None, None, None, None, None
+                                                      ptr(gl), ptr(g1), ptr(g2), ctx.samp_layout, _stream(x1)),
+                  "sn_simplification_loss_backward")
+        return g1, g2, None, None, None, None, None, None
 
 
 class SamplerLossFunction(torch.autograd.Function):

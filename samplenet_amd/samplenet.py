@@ -152,7 +152,7 @@ class SampleNet(nn.Module):
         self._scan = None
         if scan is not None:
             # remember which tensors the scan belongs to: the input cloud and the simplified cloud we return
-            self._scan = (x_in, x_in._version, simp, scan)
+            self._scan = (x_in, x_in._version, simp, scan, y)
 
         out = proj if self.training else match
         return simp, out
@@ -165,14 +165,14 @@ class SampleNet(nn.Module):
     def _scan_hit(self, ref_pc, samp_pc):
         if self._scan is None:
             return None
-        x_in, ver, simp, scan = self._scan
+        x_in, ver, simp, scan, y_bcn = self._scan
         if samp_pc is not simp or samp_pc.dim() != 3 or samp_pc.shape[2] != 3:
             return None
         same_ref = ref_pc is x_in or (
             ref_pc.data_ptr() == x_in.data_ptr() and ref_pc.shape == x_in.shape and ref_pc.stride() == x_in.stride())
         if not same_ref or x_in._version != ver or ref_pc.dim() != 3 or ref_pc.shape[2] != 3:
             return None
-        return scan
+        return scan + (y_bcn,)
 
     def get_simplification_loss(self, ref_pc, samp_pc, pc_size, gamma=1, delta=0):
         if self.skip_projection or not self.training:
@@ -180,7 +180,11 @@ class SampleNet(nn.Module):
         # ref_pc and samp_pc are B x N x 3 matrices
         scan = self._scan_hit(ref_pc, samp_pc)
         if scan is not None:  # Chamfer products of this very pair were produced by forward()'s pair scan
-            dq, iq, dp, ip = scan
+            dq, iq, dp, ip, y_bcn = scan
+            if not ref_pc.requires_grad:
+                # samp_pc is the (B,M,3) copy of the FC head's (B,3,M) output: hang the loss off that tensor directly, so
+                # the gradient reaches the head without passing through the transposed copy (same values, no copy kernels)
+                return ops.SimplificationLossFunction.apply(y_bcn, ref_pc, dq, iq, dp, ip, gamma + delta * pc_size, ops.BCN)
         else:
             _, _, dq, iq, dp, ip = ops.chamfer_forward_impl(samp_pc.detach(), ref_pc.detach())
         # cost_p1_p2 = mean(dq); max_cost = mean_b(max_m dq); cost_p2_p1 = mean(dp)

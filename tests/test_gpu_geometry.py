@@ -325,3 +325,23 @@ def test_fused_simplification_loss_matches_composition(oracle, shape):
     hs, hr = torch.autograd.grad(ref_loss, [ts, tr], torch.tensor(0.7, device="cuda"))
     np.testing.assert_allclose(gs.cpu().numpy(), hs.cpu().numpy(), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(gr.cpu().numpy(), hr.cpu().numpy(), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("shape", [(32, 64, 1024), (3, 12, 96), (2, 1, 7), (5, 300, 200)])
+def test_fused_simplification_loss_channel_major_sample(shape):
+    """samp_layout = BCN (the FC head's (B,3,M) output, used by SampleNet.get_simplification_loss on a scan hit):
+    same loss, and the gradient is bit-for-bit the transposed gradient of the (B,M,3) call."""
+    from samplenet_amd import ops
+
+    b, m, n = shape
+    smp, ref = clouds(m * 7 + n, b, m, n)
+    ts, tr = dev(smp).requires_grad_(True), dev(ref)
+    tsT = dev(np.ascontiguousarray(smp.transpose(0, 2, 1))).requires_grad_(True)
+    _, _, d1, i1, d2, i2 = ops.chamfer_forward_impl(ts.detach(), tr)
+    la = ops.SimplificationLossFunction.apply(ts, tr, d1, i1, d2, i2, 1.5)
+    lb = ops.SimplificationLossFunction.apply(tsT, tr, d1, i1, d2, i2, 1.5, ops.BCN)
+    assert float(la) == float(lb)
+    (ga,) = torch.autograd.grad(la, [ts], torch.tensor(0.3, device="cuda"))
+    (gb,) = torch.autograd.grad(lb, [tsT], torch.tensor(0.3, device="cuda"))
+    assert gb.shape == tsT.shape
+    assert torch.equal(ga.permute(0, 2, 1), gb)
