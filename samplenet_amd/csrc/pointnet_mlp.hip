@@ -28,6 +28,7 @@
 // lanes 32-63 of row k+1), next chunk prefetched into registers while the current one is in
 // the matrix pipe.
 #include <algorithm>
+#include <cstdlib>
 
 #include "sn_common.h"
 
@@ -224,6 +225,24 @@ struct WSrc {
 // ------------------------------------------------------------------------------------------------
 // GEMM core
 // ------------------------------------------------------------------------------------------------
+#ifdef SN_TIMELINE
+// Debug build only (tools/timeline.sh): per-workgroup phase timestamps (100 MHz wall clock) of the GEMM kernels.
+__device__ unsigned long long sn_tl_buf[16384 * 8];
+__device__ __forceinline__ void sn_tl(int slot, unsigned long long v)
+{
+    const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && id < 16384u) sn_tl_buf[(size_t)id * 8 + slot] = v;
+}
+#define SN_TL(slot) sn_tl(slot, wall_clock64())
+#define SN_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SN_TL_ID(kind) sn_tl(7, ((unsigned long long)(kind) << 48) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | \
+                                    (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4))
+#else
+#define SN_TL(slot)
+#define SN_TL_DRAIN()
+#define SN_TL_ID(kind)
+#endif
+
 template <int BM_, int BN_, int WR_, int WC_>
 struct Tile {
     static constexpr int BM = BM_, BN = BN_, WR = WR_, WC = WC_;
@@ -312,6 +331,7 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[T::TM][T::TN], int K, co
         stage_store<T::BM, LDA, T::A4, T::THREADS, A_KC>(As, ra, tid);
         stage_store<T::BN, LDB, T::B4, T::THREADS, B_KC>(Bs, rb, tid);
         __syncthreads();
+        if (k0 == 0) SN_TL(1);
         if (k0 + BK < K) fetch_chunk<T, A_KC, B_KC>(ra, rb, fa, fb, k0 + BK, tid);  // loads in flight under the MFMAs
         const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -329,6 +349,7 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[T::TM][T::TN], int K, co
         }
         __syncthreads();
     }
+    SN_TL(2);
 }
 
 // C/D fragment coordinates of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -382,22 +403,36 @@ struct BnFwd {
     long long R;
 };
 
-__device__ __forceinline__ void bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss)
+// (gamma, beta, running mean / var are passed in: the callers fetch them BEFORE their reduction so that the loads overlap it)
+struct BnFwdIn {
+    float gamma, beta, rmean, rvar;
+};
+__device__ __forceinline__ BnFwdIn bn_fwd_inputs(const BnFwd &bn, int c)
+{
+    BnFwdIn in{bn.gamma[c], bn.beta[c], 0.f, 0.f};
+    if (bn.running_mean) in.rmean = bn.running_mean[c], in.rvar = bn.running_var[c];
+    return in;
+}
+__device__ __forceinline__ void bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss, const BnFwdIn &in)
 {
     const double mean = s / (double)bn.R;
     double var = ss / (double)bn.R - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)bn.eps));
-    const float sc = bn.gamma[c] * invstd;
+    const float sc = in.gamma * invstd;
     bn.coef[c] = sc;
-    bn.coef[C + c] = bn.beta[c] - (float)mean * sc;
+    bn.coef[C + c] = in.beta - (float)mean * sc;
     bn.coef[2 * C + c] = (float)mean;
     bn.coef[3 * C + c] = invstd;
     if (bn.running_mean) {
         const double unbiased = bn.R > 1 ? var * (double)bn.R / (double)(bn.R - 1) : var;
-        bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
-        bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * (float)unbiased;
+        bn.running_mean[c] = (1.f - bn.momentum) * in.rmean + bn.momentum * (float)mean;
+        bn.running_var[c] = (1.f - bn.momentum) * in.rvar + bn.momentum * (float)unbiased;
     }
+}
+__device__ __forceinline__ void bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss)
+{
+    bn_finalize_channel(bn, C, c, s, ss, bn_fwd_inputs(bn, c));
 }
 
 // BatchNorm backward coefficients of one channel from (sum dY, sum dY*Z):  dZ = k1 dY + k2 Z + k3
@@ -407,9 +442,16 @@ struct BnBwd {
     long long R;
 };
 
-__device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz)
+struct BnBwdIn {
+    float scale, mean, invstd;
+};
+__device__ __forceinline__ BnBwdIn bn_bwd_inputs(const BnBwd &bb, int C, int c)
 {
-    const double scale = bb.coef[c], mean = bb.coef[2 * C + c], invstd = bb.coef[3 * C + c];
+    return BnBwdIn{bb.coef[c], bb.coef[2 * C + c], bb.coef[3 * C + c]};
+}
+__device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz, const BnBwdIn &in)
+{
+    const double scale = in.scale, mean = in.mean, invstd = in.invstd;
     const double dg = invstd * (sz - mean * s);
     bb.dgamma[c] = (float)dg;
     bb.dbeta[c] = (float)s;
@@ -418,6 +460,10 @@ __device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int 
     const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
     bb.kcoef[c] = k1, bb.kcoef[C + c] = k2, bb.kcoef[2 * C + c] = k3;
     if (bb.dbias) bb.dbias[c] = (float)((double)k1 * s + (double)k2 * (double)bb.R * mean + (double)bb.R * (double)k3);
+}
+__device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz)
+{
+    bn_backward_channel(bb, C, c, s, sz, bn_bwd_inputs(bb, C, c));
 }
 
 struct FwdArgs {
@@ -433,6 +479,8 @@ template <class T, bool FULL, int AMODE>
 __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    SN_TL(0);
+    SN_TL_ID(0);
     const int row0 = blockIdx.x * T::BM, col0 = blockIdx.y * T::BN;
     const int R = g.a.rows, Co = g.w.co, Ci = g.w.ci;
     f32x16 acc[T::TM][T::TN];
@@ -477,10 +525,14 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
                 }
             }
     }
+    SN_TL(3);
+    SN_TL_DRAIN();
+    SN_TL(4);
     if (g.stats) {
         float *st = g.stats + (size_t)blockIdx.x * 2 * Co;
         column_reduce2<T>(s0, s1, lds, st, st + Co, col0, Co);
     }
+    SN_TL(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,6 +551,8 @@ struct DgradArgs {
 template <class T, bool FULL, int ZMODE, int PMODE>
 __device__ __forceinline__ void dgrad_body(const DgradArgs &g, int bx, int by, float *lds)
 {
+    SN_TL(0);
+    SN_TL_ID(2);
     const int row0 = bx * T::BM, col0 = by * T::BN;
     const int R = g.dz.rows, Co = g.w.co, Ci = g.w.ci;
     f32x16 acc[T::TM][T::TN];
@@ -560,10 +614,14 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs &g, int bx, int by, f
                 }
             }
     }
+    SN_TL(3);
+    SN_TL_DRAIN();
+    SN_TL(4);
     if (masked && g.stats) {
         float *st = g.stats + (size_t)bx * 2 * Ci;
         column_reduce2<T>(s0, s1, lds, st, st + Ci, col0, Ci);
     }
+    SN_TL(5);
 }
 
 template <class T, bool FULL, int ZMODE, int PMODE>
@@ -587,6 +645,8 @@ struct WgradArgs {
 template <class T, bool FULL, int ZMODE, int PMODE>
 __device__ __forceinline__ void wgrad_body(const WgradArgs &g, int bx, int by, int bz, float *lds)
 {
+    SN_TL(0);
+    SN_TL_ID(1);
     const int m0 = bx * T::BM, n0 = by * T::BN;
     const int Co = g.dz.ch, Ce = g.ncols;
     const int r0 = bz * g.rows_per_split;
@@ -622,6 +682,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs &g, int bx, int by, i
                 if (FULL || (row < Co && col < Ce)) P[(size_t)row * Ce + col] = acc[i][j][e];
             }
     }
+    SN_TL(3);
+    SN_TL_DRAIN();
+    SN_TL(5);
 }
 
 template <class T, bool FULL, int ZMODE, int PMODE>
@@ -645,6 +708,231 @@ __global__ void __launch_bounds__(T::THREADS) linear_bwd_kernel(DgradArgs d, Wgr
     } else {
         const int e = id - n_w;
         dgrad_body<T, true, ZMODE, PMODE>(d, e % dgx, e / dgx, lds);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward of a 1x1-convolution layer with 64 / 128 channels on either side (R = B*N rows >> channels).
+// The separate dgrad / wgrad kernels above each stream dZ (= k1 dY + k2 Z + k3) and the previous layer's
+// activations from HBM; here ONE persistent workgroup per CU walks over 64-row tiles and uses every tile for both
+// products while it sits in LDS:
+//     dYprev[64 x CI]  = relu'(.) . ( dZ[64 x CO] . W[CO x CI] )      W lives in registers (B fragments, loaded once)
+//     dWpart[CO x CI] += dZ^T[CO x 64] . relu(bn(Zprev))[64 x CI]     accumulated in registers over all tiles
+// so Z / dY / Zprev are read once and the ReLU mask / BatchNorm-backward sums of the layer below come from the same
+// LDS tile.  dZ is stored row-major with an even, non-multiple-of-4 leading dimension: the dgrad A fragment (transposed
+// read, lane = row) and the wgrad A fragment (lane = channel) are both bank-conflict-free.  Tiles are double-buffered
+// in LDS; the next tile's global loads are in flight under the current tile's MFMAs.
+// 8 waves: CI = CO = 128: every wave owns one dgrad tile (32 rows x 32 ci, K = 128) and two wgrad tiles;
+// otherwise waves 0-3 own the dgrad tiles and waves 4-7 the wgrad tiles (one matrix-pipe each way per SIMD).
+// Outputs: dYprev, stats partial [gridDim.x][2][CI] (sum dYprev, sum dYprev * Zprev), dW partial [gridDim.x][CO][CI].
+// ------------------------------------------------------------------------------------------------
+struct ConvBwdArgs {
+    DzSrc dz;  // rows, ch = CO
+    const float *W;
+    const float *zprev, *scale_prev, *shift_prev;
+    float *dyprev, *stats, *part;
+    int ntiles;
+};
+
+template <int CO, int CI, int ZMODE, bool FULLR, int NZ4, int NP4>
+__device__ __forceinline__ void cbf_issue_loads(const ConvBwdArgs &g, int tile, int tid, float4 (&rz)[NZ4], float4 (&rdy)[NZ4],
+                                                float4 (&rp)[NP4], int4 &rag, float4 &rgs)
+{
+    constexpr int ZSTEP = 512 / (CO / 4), PSTEP = 512 / (CI / 4);
+    const int R = g.dz.rows;
+    const int row0 = tile * 64;
+    const int zc4 = (tid % (CO / 4)) * 4, zr = tid / (CO / 4);
+    const int pc4 = (tid % (CI / 4)) * 4, pr = tid / (CI / 4);
+#pragma unroll
+    for (int q = 0; q < NZ4; ++q) {
+        int r = row0 + zr + q * ZSTEP;
+        if (!FULLR) r = min(r, R - 1);
+        rz[q] = *reinterpret_cast<const float4 *>(g.dz.z + (size_t)r * CO + zc4);
+        if (ZMODE == DZ_BN) rdy[q] = *reinterpret_cast<const float4 *>(g.dz.dy + (size_t)r * CO + zc4);
+    }
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+        int r = row0 + pr + q * PSTEP;
+        if (!FULLR) r = min(r, R - 1);
+        rp[q] = *reinterpret_cast<const float4 *>(g.zprev + (size_t)r * CI + pc4);
+    }
+    if (ZMODE == DZ_POOL) {  // the host guarantees npts % 64 == 0: one cloud per tile
+        const int b = row0 / g.dz.npts;
+        rag = *reinterpret_cast<const int4 *>(g.dz.argsel + (size_t)b * CO + zc4);
+        rgs = *reinterpret_cast<const float4 *>(g.dz.gsel + (size_t)b * CO + zc4);
+    }
+}
+
+template <int CO, int CI, int ZMODE, bool FULLR, int NZ4, int NP4>
+__device__ __forceinline__ void cbf_stage(const ConvBwdArgs &g, int tile, int tid, float *__restrict__ Zs, float *__restrict__ Ps,
+                                          const float4 (&rz)[NZ4], const float4 (&rdy)[NZ4], const float4 (&rp)[NP4],
+                                          const int4 &rag, const float4 &rgs, const float4 &k1, const float4 &k2,
+                                          const float4 &k3)
+{
+    constexpr int ZSTEP = 512 / (CO / 4), PSTEP = 512 / (CI / 4);
+    constexpr int LDZ = CO + 2, LDP = CI + 2;
+    const int R = g.dz.rows;
+    const int row0 = tile * 64;
+    const int zc4 = (tid % (CO / 4)) * 4, zr = tid / (CO / 4);
+    const int pc4 = (tid % (CI / 4)) * 4, pr = tid / (CI / 4);
+    const int n0 = ZMODE == DZ_POOL ? row0 - (row0 / g.dz.npts) * g.dz.npts : 0;
+#pragma unroll
+    for (int q = 0; q < NZ4; ++q) {
+        const int rt = zr + q * ZSTEP;
+        float4 d;
+        if (ZMODE == DZ_POOL) {
+            const int n = n0 + rt;
+            d.x = rag.x == n ? rgs.x : 0.f;
+            d.y = rag.y == n ? rgs.y : 0.f;
+            d.z = rag.z == n ? rgs.z : 0.f;
+            d.w = rag.w == n ? rgs.w : 0.f;
+        } else {
+            d = rdy[q];
+        }
+        float4 v = make_float4(fmaf(k1.x, d.x, fmaf(k2.x, rz[q].x, k3.x)), fmaf(k1.y, d.y, fmaf(k2.y, rz[q].y, k3.y)),
+                               fmaf(k1.z, d.z, fmaf(k2.z, rz[q].z, k3.z)), fmaf(k1.w, d.w, fmaf(k2.w, rz[q].w, k3.w)));
+        if (!FULLR) {
+            const float m = row0 + rt < R ? 1.f : 0.f;
+            v.x *= m, v.y *= m, v.z *= m, v.w *= m;
+        }
+        float *o = Zs + rt * LDZ + zc4;
+        *reinterpret_cast<float2 *>(o) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2 *>(o + 2) = make_float2(v.z, v.w);
+    }
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+        float *o = Ps + (pr + q * PSTEP) * LDP + pc4;
+        *reinterpret_cast<float2 *>(o) = make_float2(rp[q].x, rp[q].y);
+        *reinterpret_cast<float2 *>(o + 2) = make_float2(rp[q].z, rp[q].w);
+    }
+}
+
+template <int CI, int CO, int ZMODE, bool FULLR>
+__global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
+{
+    constexpr int LDZ = CO + 2, LDP = CI + 2;
+    constexpr int ZB = 64 * LDZ, PB = 64 * LDP, BUF = ZB + PB;
+    constexpr int NZ4 = CO / 32, NP4 = CI / 32;  // float4 per thread per tile (64 rows x C / 4 / 512 threads)
+    constexpr bool BOTH = CI == 128 && CO == 128;
+    constexpr int NCB = CI / 32, NOB = CO / 32;
+    constexpr int NWT = NOB * NCB / (BOTH ? 8 : 4);  // wgrad tiles per wgrad wave
+    static_assert((CI == 64 || CI == 128) && (CO == 64 || CO == 128), "instantiated for 64 / 128 channels");
+    static_assert(BOTH || NCB == 2, "wave roles below assume CI = 64 unless both sides are 128");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = g.dz.rows;
+    const bool do_d = BOTH || wave < 4, do_w = BOTH || wave >= 4;
+    const int dwv = BOTH ? wave : (wave & 3);
+    const int rb = dwv & 1, cb = dwv >> 1;  // dgrad tile: rows rb*32.., channels cb*32..
+    const int q0 = dwv * NWT;               // first wgrad tile of this wave
+    const int cob = q0 / NCB;               // wgrad tiles: dW rows cob*32.., columns ((q0 + n) % NCB)*32..
+
+    // per-thread constants
+    const int zc4 = (tid % (CO / 4)) * 4;
+    const float4 k1 = *reinterpret_cast<const float4 *>(g.dz.k1 + zc4);
+    const float4 k2 = *reinterpret_cast<const float4 *>(g.dz.k2 + zc4);
+    const float4 k3 = *reinterpret_cast<const float4 *>(g.dz.k3 + zc4);
+    const float scd = g.scale_prev[cb * 32 + l31], shd = g.shift_prev[cb * 32 + l31];
+    float scw[NWT], shw[NWT];
+#pragma unroll
+    for (int n = 0; n < NWT; ++n) {
+        const int col = ((q0 + n) % NCB) * 32 + l31;
+        scw[n] = g.scale_prev[col], shw[n] = g.shift_prev[col];
+    }
+    // dgrad B fragments: W[k = co][j = ci], k = 2 s + h
+    float wreg[CO / 2];
+#pragma unroll
+    for (int s = 0; s < CO / 2; ++s) wreg[s] = do_d ? g.W[(size_t)(2 * s + h) * CI + cb * 32 + l31] : 0.f;
+
+    float4 rz[NZ4], rdy[NZ4], rp[NP4];
+    int4 rag = make_int4(0, 0, 0, 0);
+    float4 rgs = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x16 accw[NWT];
+#pragma unroll
+    for (int n = 0; n < NWT; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[n][e] = 0.f;
+    float s0 = 0.f, s1 = 0.f;
+
+    int tile = blockIdx.x;
+    cbf_issue_loads<CO, CI, ZMODE, FULLR, NZ4, NP4>(g, tile, tid, rz, rdy, rp, rag, rgs);
+    for (int it = 0; tile < g.ntiles; ++it, tile += gridDim.x) {
+        float *Zs = lds + (it & 1) * BUF, *Ps = Zs + ZB;
+        cbf_stage<CO, CI, ZMODE, FULLR, NZ4, NP4>(g, tile, tid, Zs, Ps, rz, rdy, rp, rag, rgs, k1, k2, k3);
+        __syncthreads();
+        {
+            // next tile's loads (the last iteration re-reads its own tile: keeps the loads unconditional)
+            const int nxt = tile + (int)gridDim.x < g.ntiles ? tile + (int)gridDim.x : tile;
+            cbf_issue_loads<CO, CI, ZMODE, FULLR, NZ4, NP4>(g, nxt, tid, rz, rdy, rp, rag, rgs);
+        }
+        const int row0 = tile * 64;
+        if (do_d) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const float *ap = Zs + (rb * 32 + l31) * LDZ + h;
+#pragma unroll
+            for (int s = 0; s < CO / 2; ++s) {
+                // bound how far ahead the scheduler hoists the LDS fragment reads (each costs a live register)
+                if ((s & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], wreg[s], acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float *zp = Ps + cb * 32 + l31;
+            float *out = g.dyprev + (size_t)row0 * CI + cb * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rt = rb * 32 + frag_row(e, lane);
+                const float z = zp[rt * LDP];
+                const float v = fmaf(z, scd, shd) > 0.f ? acc[e] : 0.f;
+                s0 += v;
+                s1 += v * z;
+                if (FULLR || row0 + rt < R) out[(size_t)rt * CI] = v;
+            }
+        }
+        if (do_w) {
+            const float *ap = Zs + h * LDZ + cob * 32 + l31;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                if ((s & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                const float a = ap[2 * s * LDZ];
+#pragma unroll
+                for (int n = 0; n < NWT; ++n) {
+                    const float zpv = Ps[(2 * s + h) * LDP + ((q0 + n) % NCB) * 32 + l31];
+                    const float b = fmaxf(fmaf(zpv, scw[n], shw[n]), 0.f);
+                    accw[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accw[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // weight-gradient partial of this workgroup
+    if (do_w) {
+        float *P = g.part + (size_t)blockIdx.x * CO * CI;
+#pragma unroll
+        for (int n = 0; n < NWT; ++n) {
+            const int col = ((q0 + n) % NCB) * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) P[(size_t)(cob * 32 + frag_row(e, lane)) * CI + col] = accw[n][e];
+        }
+    }
+    // BatchNorm-backward sums of the layer below: halves of a wave, then the two row blocks, fixed order
+    __syncthreads();
+    float *red = lds;  // [2 (rb)][2][CI]
+    if (do_d) {
+        const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
+        if (lane < 32) {
+            red[(rb * 2 + 0) * CI + cb * 32 + lane] = t0;
+            red[(rb * 2 + 1) * CI + cb * 32 + lane] = t1;
+        }
+    }
+    __syncthreads();
+    if (tid < CI) {
+        float *st = g.stats + (size_t)blockIdx.x * 2 * CI;
+        st[tid] = red[0 * CI + tid] + red[2 * CI + tid];
+        st[CI + tid] = red[1 * CI + tid] + red[3 * CI + tid];
     }
 }
 
@@ -1009,14 +1297,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(int nsplit, int Co, i
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping (tiny kernels, one thread per channel)
 // ------------------------------------------------------------------------------------------------
-// Sum the [nblk][2][C] partials of channel c over the workgroup's 32 slices (32 channels x 32 slices = 1024 threads),
+// Sum the [nblk][2][C] partials of channel c over the workgroup's 128 slices (8 channels x 128 slices = 1024 threads:
+// with the usual 256..512 row blocks every thread has at most 8 loads, all in flight together -- one memory round trip),
 // in double, fixed order.  Returns true on the threads (slice 0) that hold the totals.
-constexpr int kSlices = 32;
-__device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__restrict__ stats, double &s0, double &s1)
+constexpr int kSlices = 128, kChan = 8;
+__device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__restrict__ stats, int cblock, double &s0, double &s1)
 {
-    __shared__ double red[2][kSlices][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double red[2][kSlices][kChan];
+    __shared__ double red2[2][16][kChan];
+    const int cl = threadIdx.x & (kChan - 1), sl = threadIdx.x >> 3;
+    const int c = cblock * kChan + cl;
     double a0 = 0.0, a1 = 0.0;
     if (c < C) {
         int b = sl;
@@ -1035,10 +1325,17 @@ __device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__res
     }
     red[0][sl][cl] = a0, red[1][sl][cl] = a1;
     __syncthreads();
+    if (sl < 16) {  // slices 8 sl .. 8 sl + 7
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t0 += red[0][sl * 8 + q][cl], t1 += red[1][sl * 8 + q][cl];
+        red2[0][sl][cl] = t0, red2[1][sl][cl] = t1;
+    }
+    __syncthreads();
     if (sl != 0 || c >= C) return false;
     s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < kSlices; ++q) s0 += red[0][q][cl], s1 += red[1][q][cl];
+    for (int q = 0; q < 16; ++q) s0 += red2[0][q][cl], s1 += red2[1][q][cl];
     return true;
 }
 
@@ -1048,8 +1345,11 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(int nblk, int C, cons
 {
     if (blockIdx.x == 0 && threadIdx.x == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
     double s, ss;
-    if (!partial_sums(nblk, C, stats, s, ss)) return;
-    bn_finalize_channel(bn, C, blockIdx.x * 32 + (threadIdx.x & 31), s, ss);
+    const int c = blockIdx.x * kChan + (threadIdx.x & (kChan - 1));
+    BnFwdIn in{};
+    if (threadIdx.x < kChan && c < C) in = bn_fwd_inputs(bn, c);  // in flight during the reduction
+    if (!partial_sums(nblk, C, stats, blockIdx.x, s, ss)) return;
+    bn_finalize_channel(bn, C, c, s, ss, in);
 }
 
 // eval: coefficients from the running statistics
@@ -1074,8 +1374,11 @@ __global__ void bn_eval_coef_kernel(int C, const float *__restrict__ gamma, cons
 __global__ void __launch_bounds__(1024) bn_bwd_coef_kernel(int nblk, int C, const float *__restrict__ stats, BnBwd bb)
 {
     double s, sz;
-    if (!partial_sums(nblk, C, stats, s, sz)) return;
-    bn_backward_channel(bb, C, blockIdx.x * 32 + (threadIdx.x & 31), s, sz);
+    const int c = blockIdx.x * kChan + (threadIdx.x & (kChan - 1));
+    BnBwdIn in{};
+    if (threadIdx.x < kChan && c < C) in = bn_bwd_inputs(bb, C, c);
+    if (!partial_sums(nblk, C, stats, blockIdx.x, s, sz)) return;
+    bn_backward_channel(bb, C, c, s, sz, in);
 }
 
 // wgrad_reduce of layer i and the BatchNorm backward coefficients of layer i-1 depend on the same launch (the combined
@@ -1085,41 +1388,42 @@ __global__ void __launch_bounds__(1024) post_bwd_kernel(int nred, int nsplit, in
                                                         const float *__restrict__ stats, BnBwd bb)
 {
     if ((int)blockIdx.x < nred) {
-        // 256 elements x 4 split-slices per workgroup (fixed-order sums)
-        __shared__ float red[4][256];
-        const int el = threadIdx.x & 255, sl = threadIdx.x >> 8;
-        const int e = blockIdx.x * 256 + el;
+        // 64 elements x 16 split-slices per workgroup, 8 independent loads in flight per thread (fixed-order sums)
+        __shared__ float red[16][64];
+        const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int e = blockIdx.x * 64 + el;
         const size_t stride = (size_t)Co * Ci;
         float acc = 0.f;
         if (e < Co * Ci) {
+            const float *p = part + e;
             int sp = sl;
-            for (; sp + 12 < nsplit; sp += 16)
-                acc += (part[(size_t)sp * stride + e] + part[(size_t)(sp + 4) * stride + e]) +
-                       (part[(size_t)(sp + 8) * stride + e] + part[(size_t)(sp + 12) * stride + e]);
-            for (; sp < nsplit; sp += 4) acc += part[(size_t)sp * stride + e];
+            for (; sp + 7 * 16 < nsplit; sp += 8 * 16) {
+                const float v0 = p[(size_t)sp * stride], v1 = p[(size_t)(sp + 16) * stride];
+                const float v2 = p[(size_t)(sp + 32) * stride], v3 = p[(size_t)(sp + 48) * stride];
+                const float v4 = p[(size_t)(sp + 64) * stride], v5 = p[(size_t)(sp + 80) * stride];
+                const float v6 = p[(size_t)(sp + 96) * stride], v7 = p[(size_t)(sp + 112) * stride];
+                acc += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+            }
+            for (; sp < nsplit; sp += 16) acc += p[(size_t)sp * stride];
         }
         red[sl][el] = acc;
         __syncthreads();
-        if (sl == 0 && e < Co * Ci) dW[e] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        if (sl == 0 && e < Co * Ci) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += red[q][el];
+            dW[e] = tot;
+        }
         return;
     }
-    // BatchNorm backward coefficients: 32 channels x 32 slices, as bn_bwd_coef_kernel
-    __shared__ double red2[2][kSlices][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = ((int)blockIdx.x - nred) * 32 + cl;
-    double a0 = 0.0, a1 = 0.0;
-    if (c < C)
-        for (int b = sl; b < nblk; b += kSlices) {
-            a0 += (double)stats[((size_t)b * 2 + 0) * C + c];
-            a1 += (double)stats[((size_t)b * 2 + 1) * C + c];
-        }
-    red2[0][sl][cl] = a0, red2[1][sl][cl] = a1;
-    __syncthreads();
-    if (sl != 0 || c >= C) return;
-    double s = 0.0, sz = 0.0;
-#pragma unroll
-    for (int q = 0; q < kSlices; ++q) s += red2[0][q][cl], sz += red2[1][q][cl];
-    bn_backward_channel(bb, C, c, s, sz);
+    // BatchNorm backward coefficients, as bn_bwd_coef_kernel
+    double s, sz;
+    const int cblock = (int)blockIdx.x - nred;
+    const int c = cblock * kChan + (threadIdx.x & (kChan - 1));
+    BnBwdIn in{};
+    if (threadIdx.x < kChan && c < C) in = bn_bwd_inputs(bb, C, c);
+    if (!partial_sums(nblk, C, stats, cblock, s, sz)) return;
+    bn_backward_channel(bb, C, c, s, sz, in);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1328,7 +1632,7 @@ extern "C" int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, cons
     else
         launch_fwd<ACT_NONE>(g, st);
     if (R > 32)
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((Co + 31) / 32), dim3(1024), 0, st, sn_linear_stats_blocks(R), Co, stats, bn);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((Co + kChan - 1) / kChan), dim3(1024), 0, st, sn_linear_stats_blocks(R), Co, stats, bn);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -1390,9 +1694,95 @@ extern "C" int sn_linear_dgrad(int R, int Ci, int Co, int dz_mode, const float *
     return 0;
 }
 
+// ---- fused convolution backward (conv_bwd_fused_kernel): shapes, grid, launch -------------------------------------
+static int device_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;  // MI355X
+        (void)hipGetLastError();
+    }
+    return n;
+}
+
+static bool conv_bwd_fused_enabled()
+{
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("SN_NO_FUSED_CONV_BWD");
+        on = (e && e[0] == '1') ? 0 : 1;
+    }
+    return on == 1;
+}
+
+static bool conv_bwd_fused_shape(int R, int Ci, int Co)
+{
+    return conv_bwd_fused_enabled() && R >= 256 && ((Ci == 64 && (Co == 64 || Co == 128)) || (Ci == 128 && Co == 128));
+}
+
+// persistent workgroups: one per CU (each walks over ceil(tiles / groups) 64-row tiles)
+static int conv_bwd_fused_groups(int R) { return std::min((R + 63) / 64, device_cus()); }
+
+template <int CI, int CO, int ZMODE>
+static void launch_conv_bwd_fused_t(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)2 * 64 * (CO + 2 + CI + 2) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {  // more than 64 KB of dynamic LDS must be requested explicitly
+        (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<CI, CO, ZMODE, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<CI, CO, ZMODE, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (fullr)
+        hipLaunchKernelGGL((conv_bwd_fused_kernel<CI, CO, ZMODE, true>), dim3(G), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL((conv_bwd_fused_kernel<CI, CO, ZMODE, false>), dim3(G), dim3(512), lds, st, a);
+}
+
+// returns the number of workgroups (= partials in `stats` and `part`)
+static int launch_conv_bwd_fused(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                                 const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                                 const float *coef_prev, float *dyprev, float *stats, float *part, hipStream_t st)
+{
+    ConvBwdArgs a{};
+    a.dz.mode = dz_mode, a.dz.dy = dy, a.dz.z = z, a.dz.rows = R, a.dz.ch = Co, a.dz.npts = npts > 0 ? npts : 1;
+    a.dz.k1 = kcoef, a.dz.k2 = kcoef + Co, a.dz.k3 = kcoef + 2 * Co;
+    a.dz.gsel = gsel, a.dz.argsel = argsel;
+    a.W = W, a.zprev = zprev, a.scale_prev = coef_prev, a.shift_prev = coef_prev + Ci;
+    a.dyprev = dyprev, a.stats = stats, a.part = part;
+    a.ntiles = (R + 63) / 64;
+    const int G = conv_bwd_fused_groups(R);
+    const bool fullr = R % 64 == 0;
+#define SN_CBF(CI_, CO_)                                                                       \
+    do {                                                                                       \
+        if (dz_mode == DZ_BN) launch_conv_bwd_fused_t<CI_, CO_, DZ_BN>(a, G, fullr, st);        \
+        else launch_conv_bwd_fused_t<CI_, CO_, DZ_POOL>(a, G, fullr, st);                       \
+    } while (0)
+    if (Ci == 64 && Co == 64) SN_CBF(64, 64);
+    else if (Ci == 64 && Co == 128) SN_CBF(64, 128);
+    else SN_CBF(128, 128);
+#undef SN_CBF
+    return G;
+}
+
+static bool conv_bwd_fused_ok(int R, int Ci, int Co, int dz_mode, int npts, const float *coef_prev, const float *kcoef,
+                              const float *db)
+{
+    return !db && coef_prev && kcoef && conv_bwd_fused_shape(R, Ci, Co) &&
+           (dz_mode == DZ_BN || (dz_mode == DZ_POOL && npts > 0 && npts % 64 == 0));
+}
+
 extern "C" int sn_linear_wgrad_splits(int R, int Ci, int Co, int with_bias)
 {
     if (R <= 32) return 1;  // small path writes dW directly (scratch unused)
+    if (!with_bias && conv_bwd_fused_shape(R, Ci, Co)) return conv_bwd_fused_groups(R);  // one partial per workgroup
     const int ncols = Ci + (with_bias ? 1 : 0);
     const int tiles = ((Co + TileW::BM - 1) / TileW::BM) * ((ncols + TileW::BN - 1) / TileW::BN);
     const int want = std::max(1, 512 / tiles);                       // aim at ~2 workgroups per CU
@@ -1467,6 +1857,15 @@ extern "C" int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const floa
     SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
     SN_REQUIRE(W && zprev && dyprev && part && dW, "null pointer");
     SN_REQUIRE(dz_mode >= DZ_PLAIN && dz_mode <= DZ_POOL, "bad dz_mode");
+    if (conv_bwd_fused_ok(R, Ci, Co, dz_mode, npts, coef_prev, kcoef, nullptr)) {
+        SN_REQUIRE(stats && z && (dz_mode != DZ_BN || dy) && (dz_mode != DZ_POOL || (gsel && argsel)), "null pointer");
+        const int G = launch_conv_bwd_fused(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev,
+                                            stats, part, (hipStream_t)stream);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, Co, Ci, Ci,
+                           part, dW, nullptr);
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
     const int nsplit = sn_linear_wgrad_splits(R, Ci, Co, 0);
     int rps = (R + nsplit - 1) / nsplit;
     rps = ((rps + BK - 1) / BK) * BK;
@@ -1552,6 +1951,16 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
         return 0;
     }
     SN_REQUIRE(part, "scratch missing");
+    if (conv_bwd_fused_ok(R, Ci, Co, dz_mode, npts, coef_prev, kcoef, db)) {
+        SN_REQUIRE(z && (dz_mode != DZ_BN || dy) && (dz_mode != DZ_POOL || (gsel && argsel)), "null pointer");
+        const int G = launch_conv_bwd_fused(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev,
+                                            stats, part, st);
+        const int nred = (Co * Ci + 63) / 64;
+        hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW,
+                           G, Ci, stats, bb);
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
     const int nsplit = sn_linear_wgrad_splits(R, Ci, Co, db ? 1 : 0);
     int rps = (R + nsplit - 1) / nsplit;
     rps = ((rps + BK - 1) / BK) * BK;
@@ -1564,7 +1973,7 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
         rc = sn_linear_dgrad(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev, stats, stream);
         if (rc) return rc;
         if (coef_prev)
-            hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Ci + 31) / 32), dim3(1024), 0, st, nblk, Ci, stats, bb);
+            hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Ci + kChan - 1) / kChan), dim3(1024), 0, st, nblk, Ci, stats, bb);
         SN_LAUNCH_CHECK();
         return 0;
     }
@@ -1585,8 +1994,8 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_BN, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
     else
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_POOL, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
-    const int nred = (Co * Ci + 255) / 256;
-    hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + 31) / 32), dim3(1024), 0, st, nred, nsplit, Co, Ci, part, dW, nblk, Ci,
+    const int nred = (Co * Ci + 63) / 64;
+    hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, nsplit, Co, Ci, part, dW, nblk, Ci,
                        stats, bb);
     SN_LAUNCH_CHECK();
     return 0;
@@ -1598,7 +2007,7 @@ extern "C" int sn_bn_finalize(int nblk, int C, long long R, const float *stats, 
 {
     SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && gamma && beta && coef, "bad argument");
     const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, R};
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, nblk, C, stats, bn);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + kChan - 1) / kChan), dim3(1024), 0, (hipStream_t)stream, nblk, C, stats, bn);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -1618,7 +2027,7 @@ extern "C" int sn_bn_backward_coef(int nblk, int C, long long R, const float *st
 {
     SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && coef && dgamma && dbeta && kcoef, "bad argument");
     const BnBwd bb{coef, dgamma, dbeta, dbias, kcoef, R};
-    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, nblk, C, stats, bb);
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + kChan - 1) / kChan), dim3(1024), 0, (hipStream_t)stream, nblk, C, stats, bb);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -1642,3 +2051,15 @@ extern "C" int sn_pool_backward(int B, int C, const float *g, const float *poole
     SN_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SN_TIMELINE
+extern "C" int sn_debug_timeline(unsigned long long *host, int nblocks, int clear)
+{
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(sn::sn_tl_buf)) != hipSuccess) return 1;
+        return hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 8) != hipSuccess;
+    }
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(sn::sn_tl_buf), sizeof(unsigned long long) * 8 * (size_t)nblocks) != hipSuccess;
+}
+#endif

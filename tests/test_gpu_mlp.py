@@ -128,3 +128,51 @@ def test_linear_kernels_exact_small_integers():
         check(lib.sn_linear_wgrad(R, Ci, Co, 0, ptr(dZ), None, None, None, None, 1, ptr(A), None, ptr(part), ptr(dW), ptr(db), st))
         assert torch.equal(dW.double(), dZ.double().t() @ A.double())
         assert torch.equal(db.double(), dZ.double().sum(0))
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("mode,B,npts", [(1, 5, 512), (1, 1, 1000), (1, 75, 512), (2, 5, 512), (2, 33, 1024), (2, 3, 320)])
+def test_fused_conv_backward_exact_small_integers(shape, mode, B, npts):
+    """sn_linear_backward on the shapes served by conv_bwd_fused_kernel (persistent workgroups, dgrad + wgrad from one
+    LDS tile, W in registers): integer operands make every product and sum exact, so dYprev, the BatchNorm-backward
+    sums and dW must equal the float64 reference bit-for-bit -- for one tile per workgroup, several, a ragged last
+    tile, and both dZ modes (dense dY; dY scattered from the max-pool selection)."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    Ci, Co = shape
+    R = B * npts
+    g = torch.Generator(device="cuda").manual_seed(R + Ci + 7 * Co + mode)
+
+    def ri(lo, hi, *size):
+        return torch.randint(lo, hi + 1, size, device="cuda", generator=g).float()
+
+    z, zprev, W = ri(-1, 1, R, Co), ri(-2, 2, R, Ci), ri(-1, 1, Co, Ci)
+    kcoef = torch.stack([ri(1, 2, Co), ri(-1, 1, Co), ri(0, 1, Co)]).contiguous()
+    coefp = torch.zeros(4, Ci, device="cuda")
+    coefp[0], coefp[1] = ri(-1, 2, Ci), ri(-1, 1, Ci)
+    dy = gsel = argsel = None
+    if mode == 1:
+        dy = ri(-1, 1, R, Co)
+        dyd = dy.double()
+    else:
+        gsel = ri(-3, 3, B, Co)
+        argsel = torch.randint(0, npts, (B, Co), device="cuda", generator=g, dtype=torch.int32)
+        dyd = torch.zeros(B, npts, Co, device="cuda", dtype=torch.float64)
+        dyd.scatter_(1, argsel.long().unsqueeze(1), gsel.double().unsqueeze(1))
+        dyd = dyd.reshape(R, Co)
+    dZ = kcoef[0].double() * dyd + kcoef[1].double() * z.double() + kcoef[2].double()
+    pre = coefp[0].double() * zprev.double() + coefp[1].double()
+    ref_dyp = (pre > 0) * (dZ @ W.double())
+    ref_dW = dZ.t() @ pre.clamp_min(0)
+    dyprev = torch.empty(R, Ci, device="cuda")
+    stats = torch.zeros(lib.sn_linear_stats_blocks(R), 2, Ci, device="cuda")
+    ns = lib.sn_linear_wgrad_splits(R, Ci, Co, 0)
+    part = torch.empty(ns * Co * Ci, device="cuda")
+    dW = torch.empty(Co, Ci, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.sn_linear_backward(R, Ci, Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(W), ptr(zprev),
+                                 ptr(coefp), ptr(dyprev), ptr(stats), ptr(part), ptr(dW), st), "sn_linear_backward")
+    assert torch.equal(dyprev.double(), ref_dyp)
+    assert torch.equal(dW.double(), ref_dW)
+    assert torch.equal(stats.double().sum(0)[0], ref_dyp.sum(0))
+    assert torch.equal(stats.double().sum(0)[1], (ref_dyp * zprev.double()).sum(0))

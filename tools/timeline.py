@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Phase timeline of the MLP GEMM kernels on the GPU (debug build: tools/build_timeline_lib.sh).
+Prints, per kernel shape, the distribution over workgroups of: start offset from the first workgroup,
+t(load landed in LDS), t(MFMA loop done), t(stores issued), t(stores drained), t(end) -- all in microseconds."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_dbg", "libsamplenet_hip_tl.so"))
+vp, i = ctypes.c_void_p, ctypes.c_int
+
+
+def P(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def dump(name, nblocks):
+    torch.cuda.synchronize()
+    host = np.zeros((nblocks, 8), dtype=np.uint64)
+    rc = lib.sn_debug_timeline(host.ctypes.data_as(vp), nblocks, 0)
+    assert rc == 0
+    t = host[:, :6].astype(np.float64) / 100.0  # 100 MHz -> us
+    kind = (host[:, 7] >> np.uint64(48)).astype(int)
+    xcc = ((host[:, 7] >> np.uint64(32)) & np.uint64(0xF)).astype(int)
+    hw = (host[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    cu = (hw >> 8) & 0xF
+    se = (hw >> 13) & 0x7
+    valid = host[:, 0] > 0
+    t0 = t[valid, 0].min()
+    print("== %s: %d workgroups, span %.2f us (first start -> last end)" % (name, valid.sum(), t[valid, 5].max() - t0))
+    for k in sorted(set(kind[valid])):
+        m = valid & (kind == k)
+        label = {0: "fwd", 1: "wgrad", 2: "dgrad"}[k]
+        st = t[m, 0] - t0
+        print("  [%s] n=%d start: min %.2f med %.2f p90 %.2f max %.2f" % (label, m.sum(), st.min(), np.median(st), np.percentile(st, 90), st.max()))
+        names = ["loaded", "mfma_done", "stores_issued", "drained", "end"]
+        prev = t[m, 0]
+        for s, nm in zip(range(1, 6), names):
+            if not (host[m, s] > 0).all():
+                continue
+            d = t[m, s] - prev
+            print("     +%-14s med %.2f  p10 %.2f p90 %.2f max %.2f   (abs med %.2f)" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90), d.max(), np.median(t[m, s] - t0)))
+            prev = t[m, s]
+    # distinct (xcc, se, cu) used
+    key = set(zip(xcc[valid], se[valid], cu[valid]))
+    print("  distinct (xcc,se,cu): %d" % len(key))
+
+
+def fwd(R, Ci, Co, reps=3):
+    dev = "cuda"
+    a = torch.randn(R, Ci, device=dev)
+    coef = torch.rand(4, Ci, device=dev) + 0.5
+    W = torch.randn(Co, Ci, device=dev) * 0.1
+    b = torch.randn(Co, device=dev)
+    z = torch.empty(R, Co, device=dev)
+    nblk = lib.sn_linear_stats_blocks(R)
+    stats = torch.empty(nblk, 2, Co, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for r in range(reps):
+        lib.sn_debug_timeline(None, 0, 1)
+        rc = lib.sn_linear_forward(R, Ci, Co, P(a), P(coef), P(W), P(b), P(z), P(stats), vp(st))
+        assert rc == 0, rc
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        lib.sn_linear_forward(R, Ci, Co, P(a), P(coef), P(W), P(b), P(z), P(stats), vp(st))
+    e1.record()
+    torch.cuda.synchronize()
+    print("fwd %dx%d->%d: %.2f us/launch back-to-back" % (R, Ci, Co, e0.elapsed_time(e1) * 1e3 / 20))
+    lib.sn_debug_timeline(None, 0, 1)
+    lib.sn_linear_forward(R, Ci, Co, P(a), P(coef), P(W), P(b), P(z), P(stats), vp(st))
+    dump("linear_fwd R=%d %d->%d" % (R, Ci, Co), ((R + 63) // 64) * ((Co + 63) // 64))
+
+
+def bwd(R, Ci, Co, mode, B=32):
+    dev = "cuda"
+    npts = R // B
+    dy = torch.randn(R, Co, device=dev) if mode != 2 else None
+    z = torch.randn(R, Co, device=dev)
+    kc = torch.randn(3, Co, device=dev)
+    gsel = torch.randn(B, Co, device=dev) if mode == 2 else None
+    argsel = torch.randint(0, npts, (B, Co), device=dev, dtype=torch.int32) if mode == 2 else None
+    W = torch.randn(Co, Ci, device=dev) * 0.1
+    zprev = torch.randn(R, Ci, device=dev)
+    coefp = torch.rand(4, Ci, device=dev) + 0.5
+    dyprev = torch.empty(R, Ci, device=dev)
+    nblk = lib.sn_linear_stats_blocks(R)
+    stats = torch.empty(nblk, 2, Ci, device=dev)
+    ns = lib.sn_linear_wgrad_splits(R, Ci, Co, 0)
+    part = torch.empty(ns * Co * Ci, device=dev)
+    dW = torch.empty(Co, Ci, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        rc = lib.sn_linear_backward(R, Ci, Co, mode, P(dy), P(z), P(kc), P(gsel), P(argsel), npts, P(W), P(zprev), P(coefp),
+                                    P(dyprev), P(stats), P(part), P(dW), vp(st))
+        assert rc == 0, rc
+
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    print("bwd %dx%d->%d mode %d: %.2f us/call (linear_bwd + wgrad_reduce) back-to-back, splits %d" % (R, Ci, Co, mode, e0.elapsed_time(e1) * 1e3 / 20, ns))
+    lib.sn_debug_timeline(None, 0, 1)
+    run()
+    nw = ((Co + 63) // 64) * ((Ci + 63) // 64) * ns
+    nd = ((R + 63) // 64) * ((Ci + 63) // 64)
+    dump("linear_bwd R=%d %d->%d mode %d" % (R, Ci, Co, mode), min(16384, nw + nd))
+
+
+if __name__ == "__main__":
+    lib.sn_debug_timeline.argtypes = [vp, i, i]
+    lib.sn_linear_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
+    lib.sn_linear_backward.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
+    R = 32 * 1024
+    fwd(R, 64, 64)
+    fwd(R, 64, 128)
+    fwd(R, 128, 128)
+    bwd(R, 64, 64, 1)
+    bwd(R, 64, 128, 1)
+    bwd(R, 128, 128, 2)
