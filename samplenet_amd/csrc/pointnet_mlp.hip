@@ -227,11 +227,20 @@ struct WSrc {
 // ------------------------------------------------------------------------------------------------
 #ifdef SN_TIMELINE
 // Debug build only (tools/timeline.sh): per-workgroup phase timestamps (100 MHz wall clock) of the GEMM kernels.
-__device__ unsigned long long sn_tl_buf[16384 * 8];
+__device__ unsigned long long sn_tl_buf[16384 * 16];
 __device__ __forceinline__ void sn_tl(int slot, unsigned long long v)
 {
     const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (threadIdx.x == 0 && id < 16384u) sn_tl_buf[(size_t)id * 8 + slot] = v;
+    if (id >= 16384u) return;
+    if (threadIdx.x == 0) sn_tl_buf[(size_t)id * 16 + slot] = v;
+    if (threadIdx.x == 256) sn_tl_buf[(size_t)id * 16 + 8 + slot] = v;  // a wave of the second kind (fused backward)
+}
+__device__ unsigned sn_hw_buf[16384 * 8];  // HW_ID of every wave of a workgroup (fused backward)
+__device__ __forceinline__ void sn_hw_record()
+{
+    const unsigned id = blockIdx.x;
+    if ((threadIdx.x & 63) == 0 && id < 16384u && (threadIdx.x >> 6) < 8)
+        sn_hw_buf[id * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
 }
 #define SN_TL(slot) sn_tl(slot, wall_clock64())
 #define SN_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -722,8 +731,8 @@ __global__ void __launch_bounds__(T::THREADS) linear_bwd_kernel(DgradArgs d, Wgr
 // LDS tile.  dZ is stored row-major with an even, non-multiple-of-4 leading dimension: the dgrad A fragment (transposed
 // read, lane = row) and the wgrad A fragment (lane = channel) are both bank-conflict-free.  Tiles are double-buffered
 // in LDS; the next tile's global loads are in flight under the current tile's MFMAs.
-// 8 waves: CI = CO = 128: every wave owns one dgrad tile (32 rows x 32 ci, K = 128) and two wgrad tiles;
-// otherwise waves 0-3 own the dgrad tiles and waves 4-7 the wgrad tiles (one matrix-pipe each way per SIMD).
+// 8 waves: waves 0-3 own the four dgrad tiles of a row tile, waves 4-7 the wgrad tiles -- every SIMD hosts one wave of
+// each kind with the same MFMA count, so one wave's fragment reads / epilogue overlap the other's matrix work.
 // Outputs: dYprev, stats partial [gridDim.x][2][CI] (sum dYprev, sum dYprev * Zprev), dW partial [gridDim.x][CO][CI].
 // ------------------------------------------------------------------------------------------------
 struct ConvBwdArgs {
@@ -734,48 +743,75 @@ struct ConvBwdArgs {
     int ntiles;
 };
 
-template <int CO, int CI, int ZMODE, bool FULLR, int NZ4, int NP4>
-__device__ __forceinline__ void cbf_issue_loads(const ConvBwdArgs &g, int tile, int tid, float4 (&rz)[NZ4], float4 (&rdy)[NZ4],
-                                                float4 (&rp)[NP4], int4 &rag, float4 &rgs)
+// Global-memory access of the dgrad waves goes through raw buffer instructions: resource (SGPRs) + per-lane byte offset
+// that never changes (VGPR) + the tile's byte offset (SGPR).  The other wave of the SIMD keeps the matrix pipe busy and
+// VALU instructions of this wave only find an issue slot now and then: with flat addressing the 64-bit per-lane address
+// arithmetic in front of ~30 memory instructions made the top of every iteration take 2 us.  Out-of-range rows need no
+// special casing either: loads beyond num_records return 0, stores are dropped.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t sn_rsrc;
+__device__ __forceinline__ sn_rsrc make_rsrc(const void *p, unsigned bytes)
 {
-    constexpr int ZSTEP = 512 / (CO / 4), PSTEP = 512 / (CI / 4);
-    const int R = g.dz.rows;
-    const int row0 = tile * 64;
-    const int zc4 = (tid % (CO / 4)) * 4, zr = tid / (CO / 4);
-    const int pc4 = (tid % (CI / 4)) * 4, pr = tid / (CI / 4);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(sn_rsrc r, unsigned voff, unsigned soff)
+{
+    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+__device__ __forceinline__ int4 buf_load4i(sn_rsrc r, unsigned voff, unsigned soff)
+{
+    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_int4((int)x.x, (int)x.y, (int)x.z, (int)x.w);
+}
+__device__ __forceinline__ float buf_load1(sn_rsrc r, unsigned voff, unsigned soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store4(const float4 &v, sn_rsrc r, unsigned voff, unsigned soff)
+{
+    u32x4 x;
+    x.x = __float_as_uint(v.x), x.y = __float_as_uint(v.y), x.z = __float_as_uint(v.z), x.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, voff, soff, 0);
+}
+
+struct CbfRsrc {
+    sn_rsrc z, dy, zprev, dyprev, argsel, gsel;
+};
+
+template <int CO, int CI, int TR, int ZMODE, int NZ4, int NP4>
+__device__ __forceinline__ void cbf_issue_loads(const CbfRsrc &rs, int tile, int b, unsigned zvo, unsigned pvo, unsigned avo,
+                                                float4 (&rz)[NZ4], float4 (&rdy)[NZ4], float4 (&rp)[NP4], int4 &rag,
+                                                float4 &rgs)
+{
+    constexpr int ZSTEP = 256 / (CO / 4), PSTEP = 256 / (CI / 4);  // staged by the 256 threads of the dgrad waves
+    const unsigned zso = (unsigned)tile * (TR * CO * 4), pso = (unsigned)tile * (TR * CI * 4);
 #pragma unroll
     for (int q = 0; q < NZ4; ++q) {
-        int r = row0 + zr + q * ZSTEP;
-        if (!FULLR) r = min(r, R - 1);
-        rz[q] = *reinterpret_cast<const float4 *>(g.dz.z + (size_t)r * CO + zc4);
-        if (ZMODE == DZ_BN) rdy[q] = *reinterpret_cast<const float4 *>(g.dz.dy + (size_t)r * CO + zc4);
+        rz[q] = buf_load4(rs.z, zvo + q * (ZSTEP * CO * 4), zso);
+        if (ZMODE == DZ_BN) rdy[q] = buf_load4(rs.dy, zvo + q * (ZSTEP * CO * 4), zso);
     }
 #pragma unroll
-    for (int q = 0; q < NP4; ++q) {
-        int r = row0 + pr + q * PSTEP;
-        if (!FULLR) r = min(r, R - 1);
-        rp[q] = *reinterpret_cast<const float4 *>(g.zprev + (size_t)r * CI + pc4);
-    }
-    if (ZMODE == DZ_POOL) {  // the host guarantees npts % 64 == 0: one cloud per tile
-        const int b = row0 / g.dz.npts;
-        rag = *reinterpret_cast<const int4 *>(g.dz.argsel + (size_t)b * CO + zc4);
-        rgs = *reinterpret_cast<const float4 *>(g.dz.gsel + (size_t)b * CO + zc4);
+    for (int q = 0; q < NP4; ++q) rp[q] = buf_load4(rs.zprev, pvo + q * (PSTEP * CI * 4), pso);
+    if (ZMODE == DZ_POOL) {  // the host guarantees npts % 64 == 0: one cloud (b) per tile
+        rag = buf_load4i(rs.argsel, avo, (unsigned)b * (CO * 4));
+        rgs = buf_load4(rs.gsel, avo, (unsigned)b * (CO * 4));
     }
 }
 
-template <int CO, int CI, int ZMODE, bool FULLR, int NZ4, int NP4>
-__device__ __forceinline__ void cbf_stage(const ConvBwdArgs &g, int tile, int tid, float *__restrict__ Zs, float *__restrict__ Ps,
+template <int CO, int CI, int TR, int ZMODE, bool FULLR, int NZ4, int NP4>
+__device__ __forceinline__ void cbf_stage(const ConvBwdArgs &g, int tile, int n0, int tid, float *__restrict__ Zs,
+                                          float *__restrict__ Ps,
                                           const float4 (&rz)[NZ4], const float4 (&rdy)[NZ4], const float4 (&rp)[NP4],
                                           const int4 &rag, const float4 &rgs, const float4 &k1, const float4 &k2,
-                                          const float4 &k3)
+                                          const float4 &k3, const float4 &sc4, const float4 &sh4)
 {
-    constexpr int ZSTEP = 512 / (CO / 4), PSTEP = 512 / (CI / 4);
+    constexpr int ZSTEP = 256 / (CO / 4), PSTEP = 256 / (CI / 4);  // staged by the 256 threads of the dgrad waves
     constexpr int LDZ = CO + 2, LDP = CI + 2;
     const int R = g.dz.rows;
-    const int row0 = tile * 64;
+    const int row0 = tile * TR;
     const int zc4 = (tid % (CO / 4)) * 4, zr = tid / (CO / 4);
     const int pc4 = (tid % (CI / 4)) * 4, pr = tid / (CI / 4);
-    const int n0 = ZMODE == DZ_POOL ? row0 - (row0 / g.dz.npts) * g.dz.npts : 0;
 #pragma unroll
     for (int q = 0; q < NZ4; ++q) {
         const int rt = zr + q * ZSTEP;
@@ -801,115 +837,276 @@ __device__ __forceinline__ void cbf_stage(const ConvBwdArgs &g, int tile, int ti
     }
 #pragma unroll
     for (int q = 0; q < NP4; ++q) {
+        // the wgrad B operand is the ACTIVATION relu(bn(Zprev)): transformed here, once, by all eight waves (in the MFMA
+        // loop the two VALU ops per fragment serialised with the wave's own MFMAs -- measured 3x slower)
         float *o = Ps + (pr + q * PSTEP) * LDP + pc4;
-        *reinterpret_cast<float2 *>(o) = make_float2(rp[q].x, rp[q].y);
-        *reinterpret_cast<float2 *>(o + 2) = make_float2(rp[q].z, rp[q].w);
+        *reinterpret_cast<float2 *>(o) = make_float2(fmaxf(fmaf(rp[q].x, sc4.x, sh4.x), 0.f), fmaxf(fmaf(rp[q].y, sc4.y, sh4.y), 0.f));
+        *reinterpret_cast<float2 *>(o + 2) =
+            make_float2(fmaxf(fmaf(rp[q].z, sc4.z, sh4.z), 0.f), fmaxf(fmaf(rp[q].w, sc4.w, sh4.w), 0.f));
     }
 }
+
+// Fragment fetch / MFMA groups of the fused kernel.  The MFMA loops are software-pipelined by hand: the LDS reads of
+// group g+1 are issued before the MFMAs of group g, and a scheduling barrier after every group keeps the compiler from
+// hoisting all reads to the top (which costs a live register per read) while still overlapping read latency with MFMAs.
+template <int GS, bool WLDS, int LDW>
+__device__ __forceinline__ void cbf_dg_load(float (&a)[GS], float (&b)[GS], const float *ap, const float *bp, int s0)
+{
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+        a[i] = ap[2 * (s0 + i)];
+        if (WLDS) b[i] = bp[2 * (s0 + i) * LDW];
+    }
+}
+
+template <int GS, int NWT, int NCB, int LDZ, int LDP>
+__device__ __forceinline__ void cbf_wg_load(float (&a)[GS], float (&b)[GS][NWT], const float *ap, const float *bp, int q0,
+                                            int s0)
+{
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+        a[i] = ap[2 * (s0 + i) * LDZ];
+#pragma unroll
+        for (int n = 0; n < NWT; ++n) b[i][n] = bp[2 * (s0 + i) * LDP + ((q0 + n) % NCB) * 32];
+    }
+}
+
+template <int GS, int NWT>
+__device__ __forceinline__ void cbf_wg_mfma(f32x16 (&acc)[NWT], const float (&a)[GS], const float (&b)[GS][NWT])
+{
+#pragma unroll
+    for (int i = 0; i < GS; ++i)
+#pragma unroll
+        for (int n = 0; n < NWT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i][n], acc[n], 0, 0, 0);
+}
+
+// Tile height and the home of W by shape: CO = 128 -> W in LDS (its 64 B-fragment registers per dgrad wave do not fit
+// next to the prefetch registers); 128 x 128 channels -> 32-row tiles so that W and two tile buffers fit in 160 KB.
+template <int CI, int CO>
+struct CbfShape {
+    static constexpr bool BOTH = CI == 128 && CO == 128;
+    static constexpr int TR = BOTH ? 32 : 64;
+    static constexpr bool WLDS = CO == 128;  // 64 B-fragment registers per dgrad wave otherwise
+    static constexpr int LDW = CI + 4;
+    static constexpr int LDZ = CO + 2, LDP = CI + 2;
+    static constexpr int BUF = TR * (LDZ + LDP);
+    static constexpr int WSZ = WLDS ? CO * LDW : 0;
+    static constexpr int TSZ = 4 * 32 * 36;  // per dgrad wave: 32 x 32 output fragment, transposed for 16-byte stores
+    static constexpr size_t LDS_BYTES = ((size_t)2 * BUF + WSZ + TSZ) * sizeof(float);
+};
 
 template <int CI, int CO, int ZMODE, bool FULLR>
 __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
 {
-    constexpr int LDZ = CO + 2, LDP = CI + 2;
-    constexpr int ZB = 64 * LDZ, PB = 64 * LDP, BUF = ZB + PB;
-    constexpr int NZ4 = CO / 32, NP4 = CI / 32;  // float4 per thread per tile (64 rows x C / 4 / 512 threads)
-    constexpr bool BOTH = CI == 128 && CO == 128;
-    constexpr int NCB = CI / 32, NOB = CO / 32;
-    constexpr int NWT = NOB * NCB / (BOTH ? 8 : 4);  // wgrad tiles per wgrad wave
+    using S = CbfShape<CI, CO>;
+    constexpr int TR = S::TR, LDZ = S::LDZ, LDP = S::LDP, LDW = S::LDW;
+    constexpr int ZB = TR * LDZ, BUF = S::BUF;
+    constexpr int NZ4 = TR * CO / 4 / 256, NP4 = TR * CI / 4 / 256;  // float4 per dgrad-wave thread per tile
+    constexpr bool WLDS = S::WLDS;
+    constexpr int NCB = CI / 32, NOB = CO / 32, RB = TR / 32;
+    constexpr int NDW = RB * NCB;          // dgrad tiles per row tile = dgrad waves (waves 0..3)
+    constexpr int NWT = NOB * NCB / 4;     // wgrad tiles per wgrad wave (waves 4..7): one dW row block, NWT column blocks
     static_assert((CI == 64 || CI == 128) && (CO == 64 || CO == 128), "instantiated for 64 / 128 channels");
-    static_assert(BOTH || NCB == 2, "wave roles below assume CI = 64 unless both sides are 128");
+    static_assert(NDW == 4 && NZ4 >= 1 && NP4 >= 1 && NWT >= 1, "wave roles below assume four dgrad tiles per row tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Ws = lds + 2 * BUF;  // [CO][LDW] when WLDS
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *Ts = lds + 2 * BUF + S::WSZ + (wave & 3) * (32 * 36);  // this dgrad wave's transpose scratch [32][36]
     const int R = g.dz.rows;
-    const bool do_d = BOTH || wave < 4, do_w = BOTH || wave >= 4;
-    const int dwv = BOTH ? wave : (wave & 3);
-    const int rb = dwv & 1, cb = dwv >> 1;  // dgrad tile: rows rb*32.., channels cb*32..
-    const int q0 = dwv * NWT;               // first wgrad tile of this wave
-    const int cob = q0 / NCB;               // wgrad tiles: dW rows cob*32.., columns ((q0 + n) % NCB)*32..
+    const bool do_d = wave < 4;
+    const int dwv = wave & 3;
+    const int rb = dwv % RB, cb = dwv / RB;  // dgrad tile: rows rb*32.., channels cb*32..
+    const int q0 = dwv * NWT;                // first wgrad tile of this wave
+    const int cob = q0 / NCB;                // wgrad tiles: dW rows cob*32.., columns ((q0 + n) % NCB)*32..
+    const int G = gridDim.x;
 
-    // per-thread constants
-    const int zc4 = (tid % (CO / 4)) * 4;
-    const float4 k1 = *reinterpret_cast<const float4 *>(g.dz.k1 + zc4);
-    const float4 k2 = *reinterpret_cast<const float4 *>(g.dz.k2 + zc4);
-    const float4 k3 = *reinterpret_cast<const float4 *>(g.dz.k3 + zc4);
-    const float scd = g.scale_prev[cb * 32 + l31], shd = g.shift_prev[cb * 32 + l31];
-    float scw[NWT], shw[NWT];
+    SN_TL(0);
+#ifdef SN_TIMELINE
+    sn_hw_record();
+#endif
+    if (WLDS) {  // W[k = co][j = ci] -> LDS, all eight waves
+        constexpr int W4 = CO * CI / 4 / 512;
+        float4 wv[W4];
 #pragma unroll
-    for (int n = 0; n < NWT; ++n) {
-        const int col = ((q0 + n) % NCB) * 32 + l31;
-        scw[n] = g.scale_prev[col], shw[n] = g.shift_prev[col];
-    }
-    // dgrad B fragments: W[k = co][j = ci], k = 2 s + h
-    float wreg[CO / 2];
+        for (int q = 0; q < W4; ++q) wv[q] = *reinterpret_cast<const float4 *>(g.W + (size_t)(tid + q * 512) * 4);
 #pragma unroll
-    for (int s = 0; s < CO / 2; ++s) wreg[s] = do_d ? g.W[(size_t)(2 * s + h) * CI + cb * 32 + l31] : 0.f;
-
-    float4 rz[NZ4], rdy[NZ4], rp[NP4];
-    int4 rag = make_int4(0, 0, 0, 0);
-    float4 rgs = make_float4(0.f, 0.f, 0.f, 0.f);
-    f32x16 accw[NWT];
-#pragma unroll
-    for (int n = 0; n < NWT; ++n)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accw[n][e] = 0.f;
-    float s0 = 0.f, s1 = 0.f;
-
-    int tile = blockIdx.x;
-    cbf_issue_loads<CO, CI, ZMODE, FULLR, NZ4, NP4>(g, tile, tid, rz, rdy, rp, rag, rgs);
-    for (int it = 0; tile < g.ntiles; ++it, tile += gridDim.x) {
-        float *Zs = lds + (it & 1) * BUF, *Ps = Zs + ZB;
-        cbf_stage<CO, CI, ZMODE, FULLR, NZ4, NP4>(g, tile, tid, Zs, Ps, rz, rdy, rp, rag, rgs, k1, k2, k3);
-        __syncthreads();
-        {
-            // next tile's loads (the last iteration re-reads its own tile: keeps the loads unconditional)
-            const int nxt = tile + (int)gridDim.x < g.ntiles ? tile + (int)gridDim.x : tile;
-            cbf_issue_loads<CO, CI, ZMODE, FULLR, NZ4, NP4>(g, nxt, tid, rz, rdy, rp, rag, rgs);
+        for (int q = 0; q < W4; ++q) {
+            const int f = tid + q * 512;
+            *reinterpret_cast<float4 *>(Ws + (f / (CI / 4)) * LDW + (f % (CI / 4)) * 4) = wv[q];
         }
-        const int row0 = tile * 64;
-        if (do_d) {
+    }
+
+    if (do_d) {
+        // ---------------- producer + data-gradient waves ------------------------------------------------
+        // They win the matrix-pipe arbitration (older waves), finish their 64-deep MFMA chain in about half a tile period
+        // and spend the rest of it on the epilogue and on staging the NEXT tile into the other LDS buffer, while the
+        // weight-gradient wave of the same SIMD still has the pipe busy.  (s_setprio for these waves: no effect, measured.)
+        const int zc4 = (tid % (CO / 4)) * 4, pc4 = (tid % (CI / 4)) * 4;
+        const float4 k1 = *reinterpret_cast<const float4 *>(g.dz.k1 + zc4);
+        const float4 k2 = *reinterpret_cast<const float4 *>(g.dz.k2 + zc4);
+        const float4 k3 = *reinterpret_cast<const float4 *>(g.dz.k3 + zc4);
+        const float4 sc4 = *reinterpret_cast<const float4 *>(g.scale_prev + pc4);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(g.shift_prev + pc4);
+        const float scd = g.scale_prev[cb * 32 + l31], shd = g.shift_prev[cb * 32 + l31];
+        // byte offsets inside a tile that never change: fragment element 0 / transposed piece 0 of this lane, staging slots
+        const unsigned qvo = ((rb * 32 + 4 * h) * CI + cb * 32 + l31) * 4;
+        const unsigned ovo = ((rb * 32 + (lane >> 3)) * CI + cb * 32 + (lane & 7) * 4) * 4;
+        const unsigned zvo = ((tid / (CO / 4)) * CO + zc4) * 4, pvo = ((tid / (CI / 4)) * CI + pc4) * 4, avo = zc4 * 4;
+        CbfRsrc rs;
+        rs.z = make_rsrc(g.dz.z, (unsigned)R * CO * 4);
+        rs.dy = make_rsrc(ZMODE == DZ_BN ? g.dz.dy : g.dz.z, (unsigned)R * CO * 4);
+        rs.zprev = make_rsrc(g.zprev, (unsigned)R * CI * 4);
+        rs.dyprev = make_rsrc(g.dyprev, (unsigned)R * CI * 4);
+        const unsigned nclouds = ZMODE == DZ_POOL ? (unsigned)((R + g.dz.npts - 1) / g.dz.npts) : 1u;
+        rs.argsel = make_rsrc(ZMODE == DZ_POOL ? (const void *)g.dz.argsel : (const void *)g.dz.z, nclouds * CO * 4);
+        rs.gsel = make_rsrc(ZMODE == DZ_POOL ? (const void *)g.dz.gsel : (const void *)g.dz.z, nclouds * CO * 4);
+        // cloud b and tile-within-cloud of the current tile, advanced without divisions (DZ_POOL: one cloud per tile)
+        const int tpc = ZMODE == DZ_POOL ? g.dz.npts / TR : 1;
+        const int bstep = G / tpc, tstep = G - bstep * tpc;
+        int cloud = (int)blockIdx.x / tpc, tic = (int)blockIdx.x - cloud * tpc;
+        float4 rz[NZ4], rdy[NZ4], rp[NP4];
+        int4 rag = make_int4(0, 0, 0, 0);
+        float4 rgs = make_float4(0.f, 0.f, 0.f, 0.f);
+        float s0 = 0.f, s1 = 0.f;
+        // dYprev tile of the previous iteration, already transposed to 4 channels per lane, stored one iteration late:
+        // lane L, piece i -> row 8 i + (L >> 3), channels 4 (L & 7) .. +3 of the wave's 32 x 32 block
+        float4 vout[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vout[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int NWREG = WLDS ? 1 : CO / 2;
+        float wreg[NWREG];
+
+        int tile = blockIdx.x;
+        cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+        if (!WLDS) {  // dgrad B fragments in registers, k = 2 s + h (requested after the first tile)
+#pragma unroll
+            for (int s = 0; s < NWREG; ++s) wreg[s] = g.W[(size_t)(2 * s + h) * CI + cb * 32 + l31];
+        }
+        cbf_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, tile, tic * TR, tid, lds, lds + ZB, rz, rdy, rp, rag, rgs, k1, k2, k3, sc4,
+                                                      sh4);
+        __syncthreads();
+        for (int it = 0; tile < g.ntiles; ++it, tile += G) {
+            const float *Zs = lds + (it & 1) * BUF;
+            // dYprev of the previous tile goes out first: vmcnt retires in order, so stores issued after the loads below
+            // would be waited for together with them
+            if (it > 0) {
+                const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
+            }
+            // raw Zprev at this wave's dYprev fragment positions (ReLU mask, BatchNorm-backward sum): from global memory
+            // (L2-hot: the tile was fetched for the staging a moment ago), requested ahead of the MFMAs, used after them
+            float zq[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                zq[e] = buf_load1(rs.zprev, qvo + ((e & 3) + 8 * (e >> 2)) * (CI * 4), (unsigned)tile * (TR * CI * 4));
+            // next tile's operands (the last iteration re-reads its own tile: keeps the loads unconditional)
+            const bool more = tile + G < g.ntiles;
+            const int nxt = more ? tile + G : tile;
+            int ncloud = cloud, ntic = tic;
+            if (more) {
+                ncloud += bstep, ntic += tstep;
+                if (ntic >= tpc) ntic -= tpc, ++ncloud;
+            }
+            cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+            if (it == 1) SN_TL(5);
+
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
             const float *ap = Zs + (rb * 32 + l31) * LDZ + h;
+            const float *bp = Ws + h * LDW + cb * 32 + l31;
+            constexpr int GD = 8, NGD = CO / 2 / GD;  // 8 k-steps per group
+            static_assert(NGD % 2 == 0, "group count must be even");
+            float a0[GD], b0[GD], a1[GD], b1[GD];
+            cbf_dg_load<GD, WLDS, LDW>(a0, b0, ap, bp, 0);
 #pragma unroll
-            for (int s = 0; s < CO / 2; ++s) {
-                // bound how far ahead the scheduler hoists the LDS fragment reads (each costs a live register)
-                if ((s & 7) == 0) __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], wreg[s], acc, 0, 0, 0);
+            for (int gi = 0; gi < NGD; gi += 2) {
+                cbf_dg_load<GD, WLDS, LDW>(a1, b1, ap, bp, (gi + 1) * GD);
+                __builtin_amdgcn_sched_barrier(0);  // reads first, then the previous group's MFMAs
+#pragma unroll
+                for (int i = 0; i < GD; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], WLDS ? b0[i] : wreg[WLDS ? 0 : gi * GD + i], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gi + 2 < NGD) cbf_dg_load<GD, WLDS, LDW>(a0, b0, ap, bp, (gi + 2) * GD);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < GD; ++i)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], WLDS ? b1[i] : wreg[WLDS ? 0 : (gi + 1) * GD + i], acc, 0, 0,
+                                                               0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const float *zp = Ps + cb * 32 + l31;
-            float *out = g.dyprev + (size_t)row0 * CI + cb * 32 + l31;
+            if (it == 1) SN_TL(1);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rt = rb * 32 + frag_row(e, lane);
-                const float z = zp[rt * LDP];
+                const float z = zq[e];
                 const float v = fmaf(z, scd, shd) > 0.f ? acc[e] : 0.f;
                 s0 += v;
                 s1 += v * z;
-                if (FULLR || row0 + rt < R) out[(size_t)rt * CI] = v;
+                Ts[frag_row(e, lane) * 36 + l31] = v;  // a dword store per fragment element costs ~58 issue cycles per
+            }                                            // wave-instruction: transpose in LDS, store 16 bytes per lane
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vout[i] = *reinterpret_cast<const float4 *>(Ts + (8 * i + (lane >> 3)) * 36 + (lane & 7) * 4);
+            if (it == 1) SN_TL(2);
+            if (more) {
+                float *Zn = lds + ((it + 1) & 1) * BUF;
+                cbf_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, nxt, ntic * TR, tid, Zn, Zn + ZB, rz, rdy, rp, rag, rgs, k1, k2, k3,
+                                                              sc4, sh4);
             }
+            cloud = ncloud, tic = ntic;
+            if (it == 1) SN_TL(3);
+            __syncthreads();
+            if (it == 1) SN_TL(4);
         }
-        if (do_w) {
+        SN_TL(6);
+        if (tile != (int)blockIdx.x) {  // dYprev of the last tile
+            const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
+        }
+        // BatchNorm-backward sums of the layer below: halves of a wave, then the row blocks, fixed order
+        float *red = lds;  // [RB][2][CI]   (every wave is past its last LDS read: barrier at the end of the loop)
+        const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
+        if (lane < 32) {
+            red[(rb * 2 + 0) * CI + cb * 32 + lane] = t0;
+            red[(rb * 2 + 1) * CI + cb * 32 + lane] = t1;
+        }
+    } else {
+        // ---------------- weight-gradient waves ----------------------------------------------------------
+        f32x16 accw[NWT];
+#pragma unroll
+        for (int n = 0; n < NWT; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accw[n][e] = 0.f;
+        __syncthreads();
+        int tile = blockIdx.x;
+        for (int it = 0; tile < g.ntiles; ++it, tile += G) {
+            const float *Zs = lds + (it & 1) * BUF, *Ps = Zs + ZB;
             const float *ap = Zs + h * LDZ + cob * 32 + l31;
+            const float *bp = Ps + h * LDP + l31;
+            constexpr int GW = 2, NGW = TR / 2 / GW;  // 2 k-steps (NWT MFMAs each) per group
+            static_assert(NGW % 2 == 0, "group count must be even");
+            float a0[GW], b0[GW][NWT], a1[GW], b1[GW][NWT];
+            cbf_wg_load<GW, NWT, NCB, LDZ, LDP>(a0, b0, ap, bp, q0, 0);
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                if ((s & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-                const float a = ap[2 * s * LDZ];
-#pragma unroll
-                for (int n = 0; n < NWT; ++n) {
-                    const float zpv = Ps[(2 * s + h) * LDP + ((q0 + n) % NCB) * 32 + l31];
-                    const float b = fmaxf(fmaf(zpv, scw[n], shw[n]), 0.f);
-                    accw[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, accw[n], 0, 0, 0);
-                }
+            for (int gi = 0; gi < NGW; gi += 2) {
+                cbf_wg_load<GW, NWT, NCB, LDZ, LDP>(a1, b1, ap, bp, q0, (gi + 1) * GW);
+                __builtin_amdgcn_sched_barrier(0);
+                cbf_wg_mfma<GW, NWT>(accw, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (gi + 2 < NGW) cbf_wg_load<GW, NWT, NCB, LDZ, LDP>(a0, b0, ap, bp, q0, (gi + 2) * GW);
+                __builtin_amdgcn_sched_barrier(0);
+                cbf_wg_mfma<GW, NWT>(accw, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            if (it == 1) SN_TL(1);
+            __syncthreads();
+            if (it == 1) SN_TL(4);
         }
-    }
-
-    // weight-gradient partial of this workgroup
-    if (do_w) {
+        SN_TL(6);
+        // weight-gradient partial of this workgroup
         float *P = g.part + (size_t)blockIdx.x * CO * CI;
 #pragma unroll
         for (int n = 0; n < NWT; ++n) {
@@ -918,22 +1115,17 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
             for (int e = 0; e < 16; ++e) P[(size_t)(cob * 32 + frag_row(e, lane)) * CI + col] = accw[n][e];
         }
     }
-    // BatchNorm-backward sums of the layer below: halves of a wave, then the two row blocks, fixed order
-    __syncthreads();
-    float *red = lds;  // [2 (rb)][2][CI]
-    if (do_d) {
-        const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
-        if (lane < 32) {
-            red[(rb * 2 + 0) * CI + cb * 32 + lane] = t0;
-            red[(rb * 2 + 1) * CI + cb * 32 + lane] = t1;
-        }
-    }
     __syncthreads();
     if (tid < CI) {
+        const float *red = lds;
         float *st = g.stats + (size_t)blockIdx.x * 2 * CI;
-        st[tid] = red[0 * CI + tid] + red[2 * CI + tid];
-        st[CI + tid] = red[1 * CI + tid] + red[3 * CI + tid];
+        float a0 = red[tid], a1 = red[CI + tid];
+        if (RB == 2) a0 += red[2 * CI + tid], a1 += red[3 * CI + tid];
+        st[tid] = a0;
+        st[CI + tid] = a1;
     }
+    SN_TL_DRAIN();
+    SN_TL(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1731,7 +1923,7 @@ static int conv_bwd_fused_groups(int R) { return std::min((R + 63) / 64, device_
 template <int CI, int CO, int ZMODE>
 static void launch_conv_bwd_fused_t(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)2 * 64 * (CO + 2 + CI + 2) * sizeof(float);
+    constexpr size_t lds = CbfShape<CI, CO>::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {  // more than 64 KB of dynamic LDS must be requested explicitly
         (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<CI, CO, ZMODE, true>,
@@ -1757,9 +1949,10 @@ static int launch_conv_bwd_fused(int R, int Ci, int Co, int dz_mode, const float
     a.dz.gsel = gsel, a.dz.argsel = argsel;
     a.W = W, a.zprev = zprev, a.scale_prev = coef_prev, a.shift_prev = coef_prev + Ci;
     a.dyprev = dyprev, a.stats = stats, a.part = part;
-    a.ntiles = (R + 63) / 64;
+    const int TR = (Ci == 128 && Co == 128) ? 32 : 64;  // CbfShape<Ci, Co>::TR
+    a.ntiles = (R + TR - 1) / TR;
     const int G = conv_bwd_fused_groups(R);
-    const bool fullr = R % 64 == 0;
+    const bool fullr = R % TR == 0;
 #define SN_CBF(CI_, CO_)                                                                       \
     do {                                                                                       \
         if (dz_mode == DZ_BN) launch_conv_bwd_fused_t<CI_, CO_, DZ_BN>(a, G, fullr, st);        \
@@ -2055,11 +2248,12 @@ extern "C" int sn_pool_backward(int B, int C, const float *g, const float *poole
 #ifdef SN_TIMELINE
 extern "C" int sn_debug_timeline(unsigned long long *host, int nblocks, int clear)
 {
+    if (clear == 2) return hipMemcpyFromSymbol(host, HIP_SYMBOL(sn::sn_hw_buf), sizeof(unsigned) * 8 * (size_t)nblocks) != hipSuccess;
     if (clear) {
         void *p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(sn::sn_tl_buf)) != hipSuccess) return 1;
-        return hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 8) != hipSuccess;
+        return hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 16) != hipSuccess;
     }
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(sn::sn_tl_buf), sizeof(unsigned long long) * 8 * (size_t)nblocks) != hipSuccess;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(sn::sn_tl_buf), sizeof(unsigned long long) * 16 * (size_t)nblocks) != hipSuccess;
 }
 #endif

@@ -18,9 +18,39 @@ def P(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def dump_fused(name, nblocks):
+    torch.cuda.synchronize()
+    host = np.zeros((nblocks, 16), dtype=np.uint64)
+    assert lib.sn_debug_timeline(host.ctypes.data_as(vp), nblocks, 0) == 0
+    t = host.astype(np.float64) / 100.0
+    valid = host[:, 0] > 0
+    t0 = t[valid, 0].min()
+    names = ["start", "it1 MFMAs done", "it1 epilogue done", "it1 next tile staged", "it1 barrier passed", "-", "loop done", "end (drained)"]
+    print("== %s: %d workgroups, span %.2f us" % (name, valid.sum(), t[valid, 7].max() - t0))
+    hw = np.zeros((nblocks, 8), dtype=np.uint32)
+    assert lib.sn_debug_timeline(hw.ctypes.data_as(vp), nblocks, 2) == 0
+    simd = (hw >> 4) & 3
+    waveid = hw & 15
+    cu = (hw >> 8) & 15
+    print("  wave -> SIMD of the first workgroups:", [list(map(int, simd[i])) for i in range(4)], " same CU:", bool((cu[:, :1] == cu).all()))
+    for w, label in ((0, "dgrad wave 0"), (8, "wgrad wave 4")):
+        print("  [%s]" % label)
+        prev = None
+        order = [0, 5, 1, 2, 3, 4, 6, 7]
+        nm2 = dict(zip(range(8), names)); nm2.update({5: "it1 stores/loads issued", 1: "it1 MFMAs done", 2: "it1 epilogue done", 3: "it1 next tile staged", 4: "it1 barrier passed"})
+        for sidx in order:
+            nm = nm2[sidx]
+            col = t[valid, w + sidx]
+            if not (host[valid, w + sidx] > 0).all():
+                continue
+            d = (col - prev) if prev is not None else (col - t0)
+            print("     %-26s +%.2f (p10 %.2f p90 %.2f)   abs med %.2f" % (nm, np.median(d), np.percentile(d, 10), np.percentile(d, 90), np.median(col - t0)))
+            prev = col
+
+
 def dump(name, nblocks):
     torch.cuda.synchronize()
-    host = np.zeros((nblocks, 8), dtype=np.uint64)
+    host = np.zeros((nblocks, 16), dtype=np.uint64)
     rc = lib.sn_debug_timeline(host.ctypes.data_as(vp), nblocks, 0)
     assert rc == 0
     t = host[:, :6].astype(np.float64) / 100.0  # 100 MHz -> us
@@ -34,10 +64,10 @@ def dump(name, nblocks):
     print("== %s: %d workgroups, span %.2f us (first start -> last end)" % (name, valid.sum(), t[valid, 5].max() - t0))
     for k in sorted(set(kind[valid])):
         m = valid & (kind == k)
-        label = {0: "fwd", 1: "wgrad", 2: "dgrad"}[k]
+        label = {0: "fwd", 1: "wgrad", 2: "dgrad", 3: "fused bwd"}[k]
         st = t[m, 0] - t0
         print("  [%s] n=%d start: min %.2f med %.2f p90 %.2f max %.2f" % (label, m.sum(), st.min(), np.median(st), np.percentile(st, 90), st.max()))
-        names = ["loaded", "mfma_done", "stores_issued", "drained", "end"]
+        names = ["loaded", "mfma_done", "stores_issued", "drained", "end"] if k != 3 else ["tile0 staged", "tile0 computed", "tile1 staged", "all tiles done", "end"]
         prev = t[m, 0]
         for s, nm in zip(range(1, 6), names):
             if not (host[m, s] > 0).all():
@@ -113,17 +143,20 @@ def bwd(R, Ci, Co, mode, B=32):
     run()
     nw = ((Co + 63) // 64) * ((Ci + 63) // 64) * ns
     nd = ((R + 63) // 64) * ((Ci + 63) // 64)
-    dump("linear_bwd R=%d %d->%d mode %d" % (R, Ci, Co, mode), min(16384, nw + nd))
+    (dump_fused if FUSED else dump)("linear_bwd R=%d %d->%d mode %d" % (R, Ci, Co, mode), 256 if FUSED else min(16384, nw + nd))
 
+
+FUSED = True
 
 if __name__ == "__main__":
     lib.sn_debug_timeline.argtypes = [vp, i, i]
     lib.sn_linear_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
     lib.sn_linear_backward.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
     R = 32 * 1024
-    fwd(R, 64, 64)
-    fwd(R, 64, 128)
-    fwd(R, 128, 128)
+    if len(sys.argv) < 2:
+        fwd(R, 64, 64)
+        fwd(R, 64, 128)
+        fwd(R, 128, 128)
     bwd(R, 64, 64, 1)
     bwd(R, 64, 128, 1)
     bwd(R, 128, 128, 2)
