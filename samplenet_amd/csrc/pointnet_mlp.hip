@@ -1160,6 +1160,7 @@ template <int AMODE, bool VEC>
 __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
 {
     __shared__ float lds[3 * 16 * 64];
+    SN_TL(0);
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int R = g.a.rows, Co = g.w.co, Ci = g.w.ci;
@@ -1200,10 +1201,16 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
                 b[t] = wrow[k < Ci ? k : 0] * ((colok && k < Ci) ? 1.f : 0.f);
             }
         }
+#ifdef SN_TIMELINE
+        SN_TL_DRAIN();
+        SN_TL(1);
+#endif
 #pragma unroll
         for (int t = 0; t < KP; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
     }
+    SN_TL(2);
     wave_sum_to_wave0(acc, lds);
+    SN_TL(3);
     if (wave != 0) return;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -1238,9 +1245,137 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
             }
         }
     }
+    SN_TL_DRAIN();
+    SN_TL(5);
 }
 
 // dYprev[R<=32][Ci] = mask . (dZ . W) ; stats [1][2][Ci]
+// small_fwd_kernel with both operands staged through LDS (Ci % 64 == 0, Ci <= 512).  In the register-direct version every
+// lane fetches its own 128-byte stretch of a row: 64 cache lines per wave-instruction, 16 such instructions per wave --
+// measured 3.4 us from launch to "operands landed" for a 32 x 256 x 256 layer.  Here the 256 threads fetch the two 32-row
+// slabs with fully coalesced 16-byte loads (BatchNorm + ReLU of the previous layer applied on the way), fragments come
+// from LDS as ds_read_b128 (row pitch Ci + 4: conflict-free), and the output tile leaves as 16-byte stores.
+template <int AMODE>
+__global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    SN_TL(0);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = g.a.rows, Co = g.w.co, Ci = g.w.ci;
+    const int LD = Ci + 4;
+    float *As = sm, *Ws = sm + 32 * LD, *red = Ws + 32 * LD, *Ts = red + 3 * 16 * 64;
+    const int col0 = blockIdx.x * 32;
+    const int col = col0 + l31;
+    const bool colok = col < Co;
+    const int ccol = colok ? col : 0;
+    // epilogue inputs first: loads issued after the MFMAs would each expose a full memory latency
+    const float bias = g.bias ? g.bias[ccol] : 0.f;
+    float bn_g = 0.f, bn_b = 0.f, bn_rm = 0.f, bn_rv = 0.f;
+    if (g.bn.coef) {
+        bn_g = g.bn.gamma[ccol], bn_b = g.bn.beta[ccol];
+        if (g.bn.running_mean) bn_rm = g.bn.running_mean[ccol], bn_rv = g.bn.running_var[ccol];
+    }
+    // ---- stage: thread -> (row = tid / (Ci/4) + q * rows_per_pass, 4 channels at c4), the same c4 for every q
+    const int q4 = Ci / 4, rpp = 256 / q4, npass = 32 / rpp;  // Ci = 256: 64, 4, 8
+    const int c4 = (tid % q4) * 4, r0 = tid / q4;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (AMODE == ACT_BN_RELU) {
+        sc4 = *reinterpret_cast<const float4 *>(g.a.scale + c4);
+        sh4 = *reinterpret_cast<const float4 *>(g.a.shift + c4);
+    }
+    constexpr int MAXP = 16;  // Ci >= 64 -> at most 16 passes per operand
+    float4 av[MAXP], wv[MAXP];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q)
+        if (q < npass) {
+            const int r = r0 + q * rpp;
+            av[q] = *reinterpret_cast<const float4 *>(g.a.z + (size_t)min(r, R - 1) * Ci + c4);
+            wv[q] = *reinterpret_cast<const float4 *>(g.w.w + (size_t)min(col0 + r, Co - 1) * Ci + c4);
+        }
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q)
+        if (q < npass) {
+            const int r = r0 + q * rpp;
+            float4 a = av[q];
+            if (AMODE == ACT_BN_RELU) {
+                a.x = fmaxf(fmaf(a.x, sc4.x, sh4.x), 0.f), a.y = fmaxf(fmaf(a.y, sc4.y, sh4.y), 0.f);
+                a.z = fmaxf(fmaf(a.z, sc4.z, sh4.z), 0.f), a.w = fmaxf(fmaf(a.w, sc4.w, sh4.w), 0.f);
+            }
+            const float ma = r < R ? 1.f : 0.f, mw = col0 + r < Co ? 1.f : 0.f;
+            a.x *= ma, a.y *= ma, a.z *= ma, a.w *= ma;
+            float4 w = wv[q];
+            w.x *= mw, w.y *= mw, w.z *= mw, w.w *= mw;
+            *reinterpret_cast<float4 *>(As + r * LD + c4) = a;
+            *reinterpret_cast<float4 *>(Ws + r * LD + c4) = w;
+        }
+    __syncthreads();
+    SN_TL(1);
+    // ---- MFMA: the four waves split K; lane (l31, h) walks k = kb .. kb + kph - 1 of row / column l31
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int kph = Ci / 8, kb = wave * (Ci / 4) + h * kph;
+    const float *ap = As + l31 * LD + kb, *bp = Ws + l31 * LD + kb;
+
+    for (int t = 0; t < kph; t += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(ap + t), b = *reinterpret_cast<const float4 *>(bp + t);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    SN_TL(2);
+    wave_sum_to_wave0(acc, red);
+    SN_TL(3);
+    if (wave != 0) return;
+    float s0 = 0.f, s1 = 0.f;
+    const bool vec_out = Co % 32 == 0;  // whole 32-column blocks, 16-byte aligned rows
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = frag_row(e, lane);
+        const float v = acc[e] + bias;
+        if (row < R && colok) {
+            s0 += v;
+            s1 += v * v;
+            if (!vec_out) g.z[(size_t)row * Co + col] = v;
+        }
+        Ts[row * 36 + l31] = v;
+    }
+    if (vec_out) {  // transposed through LDS: 4 x 16-byte stores per lane instead of 16 dword stores
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + (lane >> 3);
+            const float4 v = *reinterpret_cast<const float4 *>(Ts + row * 36 + (lane & 7) * 4);
+            if (row < R) *reinterpret_cast<float4 *>(g.z + (size_t)row * Co + col0 + (lane & 7) * 4) = v;
+        }
+    }
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    if (g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Co + col] = s1;
+    if (g.bn.coef) {  // this workgroup holds every row of its 32 columns: their batch statistics are complete here
+        if (blockIdx.x == 0 && lane == 0 && g.bn.num_batches_tracked) *g.bn.num_batches_tracked += 1;
+        if (lane < 32 && colok) {  // same arithmetic as bn_finalize_channel, on the prefetched parameters
+            const double mean = (double)s0 / (double)g.bn.R;
+            double var = (double)s1 / (double)g.bn.R - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)g.bn.eps));
+            const float sc = bn_g * invstd;
+            g.bn.coef[col] = sc;
+            g.bn.coef[Co + col] = bn_b - (float)mean * sc;
+            g.bn.coef[2 * Co + col] = (float)mean;
+            g.bn.coef[3 * Co + col] = invstd;
+            if (g.bn.running_mean) {
+                const double unbiased = g.bn.R > 1 ? var * (double)g.bn.R / (double)(g.bn.R - 1) : var;
+                g.bn.running_mean[col] = (1.f - g.bn.momentum) * bn_rm + g.bn.momentum * (float)mean;
+                g.bn.running_var[col] = (1.f - g.bn.momentum) * bn_rv + g.bn.momentum * (float)unbiased;
+            }
+        }
+    }
+    SN_TL_DRAIN();
+    SN_TL(5);
+}
+
 template <int ZMODE, int PMODE, bool VEC>
 __device__ __forceinline__ void small_dgrad_body(const DgradArgs &g, int bx, float *lds)
 {
@@ -1288,10 +1423,16 @@ __device__ __forceinline__ void small_dgrad_body(const DgradArgs &g, int bx, flo
                 b[t] = g.w.w[ok ? (size_t)k * Ci + col : 0] * (ok ? 1.f : 0.f);
             }
         }
+#ifdef SN_TIMELINE
+        SN_TL_DRAIN();
+        SN_TL(1);
+#endif
 #pragma unroll
         for (int t = 0; t < KP; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
     }
+    SN_TL(2);
     wave_sum_to_wave0(acc, lds);
+    SN_TL(3);
     if (wave != 0) return;
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -1764,7 +1905,17 @@ static void launch_fwd(const FwdArgs &g, hipStream_t st)
         return;
     }
     if (R <= 32) {
-        if (Ci % 64 == 0)
+        static const bool use_lds = !(getenv("SN_SMALL_FWD_DIRECT") && getenv("SN_SMALL_FWD_DIRECT")[0] == '1');
+        if (use_lds && Ci % 64 == 0 && Ci <= 512) {
+            const size_t lds = ((size_t)64 * (Ci + 4) + 3 * 16 * 64 + 32 * 36) * sizeof(float);
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void *)small_fwd_lds_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(((size_t)64 * 516 + 3 * 16 * 64 + 32 * 36) * sizeof(float)));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((small_fwd_lds_kernel<AMODE>), dim3((Co + 31) / 32), dim3(256), lds, st, g);
+        } else if (Ci % 64 == 0)
             hipLaunchKernelGGL((small_fwd_kernel<AMODE, true>), dim3((Co + 31) / 32), dim3(256), 0, st, g);
         else
             hipLaunchKernelGGL((small_fwd_kernel<AMODE, false>), dim3((Co + 31) / 32), dim3(256), 0, st, g);

@@ -106,6 +106,39 @@ def fwd(R, Ci, Co, reps=3):
     dump("linear_fwd R=%d %d->%d" % (R, Ci, Co), ((R + 63) // 64) * ((Co + 63) // 64))
 
 
+def small_fwd(R, Ci, Co):
+    global FUSED
+    dev = "cuda"
+    a = torch.randn(R, Ci, device=dev)
+    coef = torch.rand(4, Ci, device=dev) + 0.5
+    W = torch.randn(Co, Ci, device=dev) * 0.1
+    b = torch.randn(Co, device=dev)
+    z = torch.empty(R, Co, device=dev)
+    stats = torch.empty(1, 2, Co, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for r in range(3):
+        assert lib.sn_linear_forward(R, Ci, Co, P(a), P(coef), P(W), P(b), P(z), P(stats), vp(st)) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        lib.sn_linear_forward(R, Ci, Co, P(a), P(coef), P(W), P(b), P(z), P(stats), vp(st))
+    e1.record()
+    torch.cuda.synchronize()
+    print("small fwd %dx%d->%d: %.2f us/launch back-to-back" % (R, Ci, Co, e0.elapsed_time(e1) * 1e3 / 20))
+    # cold: touch a lot of other memory first
+    junk = torch.empty(64 << 20, device=dev); junk.fill_(1.0); torch.cuda.synchronize()
+    lib.sn_debug_timeline(None, 0, 1)
+    lib.sn_linear_forward(R, Ci, Co, P(a), P(coef), P(W), P(b), P(z), P(stats), vp(st))
+    torch.cuda.synchronize()
+    nb = (Co + 31) // 32
+    host = np.zeros((nb, 16), dtype=np.uint64)
+    assert lib.sn_debug_timeline(host.ctypes.data_as(vp), nb, 0) == 0
+    t = host.astype(np.float64) / 100.0
+    t0 = t[:, 0].min()
+    for nm, sidx in (("start", 0), ("loads landed", 1), ("MFMAs done", 2), ("wave sum done", 3), ("end", 5)):
+        print("     %-16s abs med %.2f  (max %.2f)" % (nm, np.median(t[:, sidx] - t0), (t[:, sidx] - t0).max()))
+
+
 def bwd(R, Ci, Co, mode, B=32):
     dev = "cuda"
     npts = R // B
@@ -153,6 +186,10 @@ if __name__ == "__main__":
     lib.sn_linear_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
     lib.sn_linear_backward.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
     R = 32 * 1024
+    if len(sys.argv) > 1 and sys.argv[1] == "small":
+        small_fwd(32, 256, 256)
+        small_fwd(32, 128, 256)
+        sys.exit(0)
     if len(sys.argv) < 2:
         fwd(R, 64, 64)
         fwd(R, 64, 128)
