@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured by a float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz (dense fp32 matrix peak)
 
 
 def geometry_bytes_fwd(N, M, K):
@@ -55,6 +56,58 @@ def time_pairscan_kernel(net, pool, K, reps=50):
         e1.record()
         torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+
+
+def time_conv5_backward_kernel(B, N, reps=50):
+    """Average duration of the dominant kernel of the step -- sn::conv_bwd_fused_kernel<128,128,DZ_POOL>, the backward of
+    the last 1x1 convolution (128 -> bottleneck 128 channels over B*N rows): data gradient + weight gradient from one
+    pass -- measured with HIP events on the stream it is launched on, launches back to back, on tensors of the bench's
+    shapes (values do not matter for its duration).  Algorithmic work per launch: 2*R*Ci*Co (dgrad) + 2*R*Ci*Co (wgrad)."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    R, Ci, Co = B * N, 128, 128
+    g = torch.Generator(device=dev).manual_seed(7)
+    z = torch.randn(R, Co, device=dev, generator=g)
+    zprev = torch.randn(R, Ci, device=dev, generator=g)
+    kc = torch.randn(3, Co, device=dev, generator=g)
+    gsel = torch.randn(B, Co, device=dev, generator=g)
+    argsel = torch.randint(0, N, (B, Co), device=dev, generator=g, dtype=torch.int32)
+    W = torch.randn(Co, Ci, device=dev, generator=g) * 0.1
+    coefp = torch.rand(4, Ci, device=dev, generator=g) + 0.5
+    dyprev = torch.empty(R, Ci, device=dev)
+    stats = torch.empty(lib.sn_linear_stats_blocks(R), 2, Ci, device=dev)
+    part = torch.empty(lib.sn_linear_wgrad_splits(R, Ci, Co, 0) * Co * Ci, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        check(lib.sn_conv_backward_partials(R, Ci, Co, 2, None, ptr(z), ptr(kc), ptr(gsel), ptr(argsel), N, ptr(W), ptr(zprev),
+                                            ptr(coefp), ptr(dyprev), ptr(stats), ptr(part), st), "sn_conv_backward_partials")
+
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, 4.0 * R * Ci * Co
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/: FETCH_SIZE x 2 + WRITE_SIZE, KiB, as
+    MI355X_MICROARCH.md prescribes for gfx950), or None when no profile of that kernel is on disk."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except OSError:
+        return None
+    for name, row in table.items():
+        if kernel_prefix in name and "hbm_traffic_bytes_per_launch" in row:
+            return row["hbm_traffic_bytes_per_launch"]
+    return None
 
 
 def main():
@@ -127,6 +180,8 @@ def main():
         kern_ms = time_pairscan_kernel(net, pool, K)
         alg = geometry_bytes_fwd(N, M, K) * B
         achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        conv_ms, conv_flop = time_conv5_backward_kernel(B, N)
+        conv_tf = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         out = {
             "metric": "point-clouds/sec fwd+bwd, Bx1024->64 soft-proj+Chamfer",
             "value": value, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -138,11 +193,19 @@ def main():
                        "parallelism": "dp%d" % world, "grad_allreduce": "1 flat bucket, RCCL" if world > 1 else "none",
                        "execution": "eager launches" if args.no_graph else "whole step replayed as one hipGraph",
                        "mlp": "torch.nn (A/B)" if args.torch_mlp else "hand-written fp32 MFMA kernels"},
-            "roofline": {"kernel": "sn::pairscan_kernel<16,true,true> (kNN + soft projection + both Chamfer directions)",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms,
-                         "note": "geometric kernel of the path; the MLP GEMM kernels are listed in profiles/"},
+            # the dominant kernel of the step (largest share of GPU time in profiles/): backward of the last 1x1 convolution
+            "roofline": {"kernel": "sn::conv_bwd_fused_kernel<128,128,DZ_POOL> (conv5 backward: dgrad + wgrad, fp32 MFMA)",
+                         "bound": "mfma", "achieved": conv_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": conv_tf / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": pmc_traffic("conv_bwd_fused_kernel<128, 128"),
+                         "algorithmic_flop_per_launch": conv_flop, "avg_launch_ms": conv_ms,
+                         "note": "peak = dense fp32 matrix rate at 2.4 GHz; under sustained MFMA load the chip clocks "
+                                 "~2.18 GHz (143 TFLOP/s attainable, tools/micro/mfma_issue.hip)"},
+            # the geometric kernel of the path (SURVEY 8d's per-cloud byte count applies to it)
+            "roofline_geometry": {"kernel": "sn::pairscan_kernel<16,true,true> (kNN + soft projection + both Chamfer directions)",
+                                  "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("pairscan_kernel<16"),
+                                  "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_reference_model import time_cpu_baseline

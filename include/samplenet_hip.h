@@ -122,6 +122,27 @@ int sn_sampler_loss_forward(int nproj, const float *proj, const float *lsimp, co
 int sn_sampler_loss_backward(int nproj, const float *grad_loss, const float *temperature, float alpha, float lmbda,
                              float min_sigma, float *grad_proj, float *grad_lsimp, float *grad_T, sn_stream_t stream);
 
+/* The sampler's training-step loss with the benchmark's stand-in task term, in the fewest launches the dependencies allow
+ * (the op-by-op route above computes the same numbers):
+ *   sn_pairscan_forward_partial   pair scan that leaves the per-point minima as G = sn_pairscan_colmin_splits(B,N,M) partial
+ *                                 key sets (workspace [B][G][N] u64); SN_ERR_UNSUPPORTED when G <= 1
+ *   sn_sampler_step_loss_forward  finishes dist_p / idx_p from those partials while reducing the loss; loss[0] = L,
+ *                                 loss[1] = L_simp; partial: B*4 floats; argmax1: B ints
+ *   sn_sampler_step_loss_backward grad_Q (B,3,M) = d L / d simplified cloud, grad_T; gsig_scratch: B*sn_soft_bwd_splits(B,M) */
+int sn_pairscan_colmin_splits(int B, int N, int M);
+int sn_pairscan_forward_partial(int B, int N, int M, int K, const float *P, int p_layout, const float *Q, int q_layout,
+                                int *knn_idx, float *dist_q, int *idx_q, float *proj, int proj_layout,
+                                const float *temperature, float min_sigma, void *workspace, long long workspace_bytes,
+                                sn_stream_t stream);
+int sn_sampler_step_loss_forward(int B, int M, int N, int G, const float *dist_q, const void *colmin_ws, const float *proj,
+                                 const float *temperature, float alpha, float lmbda, float weight, float min_sigma,
+                                 float *dist_p, int *idx_p, int *argmax1, float *partial, float *loss, sn_stream_t stream);
+int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
+                                  const int *knn_idx, const int *idx_q, const int *idx_p, const int *argmax1,
+                                  const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
+                                  const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T,
+                                  sn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.
  * Replaces knn_cuda.KNN(k)(ref, query) (soft_projection.py:11-14) and knn_point
@@ -258,6 +279,11 @@ int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const float *dy, cons
                        const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                        const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, sn_stream_t stream);
 int sn_linear_wgrad_splits(int R, int Ci, int Co, int with_bias);
+/* the fused data+weight gradient kernel of a 64/128-channel 1x1 convolution on its own: dYprev, stats partials [G][2][Ci],
+ * dW partials [G][Co][Ci], G = sn_linear_wgrad_splits(R,Ci,Co,0); SN_ERR_UNSUPPORTED for other shapes */
+int sn_conv_backward_partials(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                              const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                              const float *coef_prev, float *dyprev, float *stats, float *part, sn_stream_t stream);
 int sn_linear_wgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                     const float *gsel, const int *argsel, int npts, const float *aprev, const float *coef_prev,
                     float *part, float *dW, float *db, sn_stream_t stream);

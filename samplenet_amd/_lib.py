@@ -34,6 +34,11 @@ PROTOTYPES = {
     "sn_simplification_loss_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp],
     "sn_sampler_loss_forward": [_i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
     "sn_sampler_loss_backward": [_i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp],
+    "sn_pairscan_colmin_splits": [_i, _i, _i],
+    "sn_pairscan_forward_partial": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, ctypes.c_longlong, _vp],
+    "sn_sampler_step_loss_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_sampler_step_loss_backward": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp,
+                                      _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -56,6 +61,7 @@ PROTOTYPES = {
     "sn_bn_backward_coef": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_dgrad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_conv_backward_partials": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_wgrad_splits": [_i, _i, _i, _i],
     "sn_linear_wgrad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],

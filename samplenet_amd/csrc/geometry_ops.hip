@@ -31,6 +31,7 @@ struct ImplicitGrad {
     const float *gL;
     const int *argmax_t, *argmax_s;
     float ct, cmax_t, cs, cmax_s;
+    float gscale = 1.f;  // upstream gradient = *gL * gscale (rounded once, like a separate scaling op in front would)
 };
 
 __global__ void __launch_bounds__(256) chamfer_bwd_kernel(int nt, int ns, const float *__restrict__ T,
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256) chamfer_bwd_kernel(int nt, int ns, const 
     float gLv = 0.f;
     int amt = -1, ams = -1;
     if (implicit) {
-        gLv = *ig.gL;
+        gLv = *ig.gL * ig.gscale;
         if (ig.argmax_t) amt = ig.argmax_t[b];
         if (ig.argmax_s) ams = ig.argmax_s[b];
     } else {
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(256) chamfer_bwd_reg_kernel(int nt, int ns, co
     float gLv = 0.f;
     int amt = -1, ams = -1;
     if (implicit) {
-        gLv = *ig.gL;
+        gLv = *ig.gL * ig.gscale;
         if (ig.argmax_t) amt = ig.argmax_t[b];
         if (ig.argmax_s) ams = ig.argmax_s[b];
     } else {
@@ -201,6 +202,11 @@ struct SoftBwdArgs {
     int gq_layout;
     float *grad_P;  // (b,3,n) channel-major in split mode, p_layout in fused mode; atomics
     float *grad_sigma_partial;
+    // fused mode, grad_proj == NULL: the upstream gradient is the same for every element, *gconst / gconst_div
+    // (the sampler step's mean(proj) term); accumulate_q: add to grad_Q instead of overwriting it
+    const float *gconst;
+    float gconst_div;
+    int accumulate_q;
 };
 
 template <bool FUSED>
@@ -243,10 +249,14 @@ __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
         float gw;  // d loss / d w_t
         float go0 = 0.f, go1 = 0.f, go2 = 0.f;
         if (FUSED) {
-            const float *gp = a.grad_proj + (size_t)b * 3 * m;
-            go0 = gp[pt_off(a.gproj_layout, m, j, 0)];
-            go1 = gp[pt_off(a.gproj_layout, m, j, 1)];
-            go2 = gp[pt_off(a.gproj_layout, m, j, 2)];
+            if (a.grad_proj) {
+                const float *gp = a.grad_proj + (size_t)b * 3 * m;
+                go0 = gp[pt_off(a.gproj_layout, m, j, 0)];
+                go1 = gp[pt_off(a.gproj_layout, m, j, 1)];
+                go2 = gp[pt_off(a.gproj_layout, m, j, 2)];
+            } else {
+                go0 = go1 = go2 = *a.gconst / a.gconst_div;
+            }
             gw = (go0 * gx + go1 * gy) + go2 * gz;
         } else {
             gw = act ? a.grad_weights[((size_t)b * m + j) * K + lane] : 0.f;
@@ -267,7 +277,8 @@ __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
         gsig += asg;
         if (a.grad_Q && lane < 3) {
             const float o = lane == 0 ? aqx : (lane == 1 ? aqy : aqz);
-            a.grad_Q[(size_t)b * 3 * m + pt_off(a.gq_layout, m, j, lane)] = o;
+            float *dst = a.grad_Q + (size_t)b * 3 * m + pt_off(a.gq_layout, m, j, lane);
+            *dst = a.accumulate_q ? *dst + o : o;
         }
         if (a.grad_P && act) {
             float *gpb = a.grad_P + (size_t)b * 3 * n;
@@ -602,7 +613,8 @@ extern "C" int sn_sampler_loss_backward(int nproj, const float *grad_loss, const
 //   dT = (sum partial) * 2T * [T^2 > min_sigma]   (torch.max splits the gradient evenly on an exact tie)
 __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float *__restrict__ partial,
                                                          const float *__restrict__ temperature, float min_sigma,
-                                                         float *__restrict__ grad_T)
+                                                         float *__restrict__ grad_T, const float *__restrict__ gsigma_direct,
+                                                         float direct_scale)
 {
     __shared__ float red[256];
     float acc = 0.f;
@@ -615,7 +627,9 @@ __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float
     if (threadIdx.x == 0) {
         const float T = *temperature, t2 = T * T;
         const float w = t2 > min_sigma ? 1.f : (t2 == min_sigma ? 0.5f : 0.f);
-        grad_T[0] = red[0] * w * 2.0f * T;
+        // + d loss / d sigma of a term that depends on sigma directly (lmbda * sigma in the sampler step's loss)
+        const float direct = gsigma_direct ? *gsigma_direct * direct_scale : 0.f;
+        grad_T[0] = red[0] * w * 2.0f * T + direct * w * 2.0f * T;
     }
 }
 
@@ -624,7 +638,7 @@ extern "C" int sn_sigma_grad(int nparts, const float *partial, const float *temp
 {
     SN_REQUIRE(nparts >= 1 && partial && temperature && grad_T, "bad argument");
     hipLaunchKernelGGL(sigma_grad_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nparts, partial, temperature,
-                       min_sigma, grad_T);
+                       min_sigma, grad_T, (const float *)nullptr, 0.f);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -760,6 +774,124 @@ extern "C" int sn_grouping_operation_grad(int b, int c, int n, int m, int nsampl
     SN_REQUIRE(grad_out && idx, "null pointer");
     hipLaunchKernelGGL(grouping_operation_grad_kernel, dim3(grid_for(tot), b), dim3(256), 0, (hipStream_t)stream, c,
                        n, m, nsample, grad_out, idx, grad_features);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The sampler's training-step loss in as few launches as the data dependencies allow (engine fast path; the op-by-op
+// route through sn_simplification_loss_* / sn_sampler_loss_* / sn_soft_project_backward computes the same numbers):
+//   L = alpha * (mean dq + mean_b max_m dq + weight * mean dp) + lmbda * max(T^2, min_sigma) + mean(proj)
+// forward : [per cloud: finish the per-point minima from the pair scan's G partial key sets -> dp / ip, and reduce
+//            sum dq, max dq (+ first argmax), sum dp, sum proj]  ->  [combine the clouds in order -> L]
+// backward: [Chamfer backward with implicit upstream gradients (scaled by alpha) -> grad_Q]
+//           [soft-projection backward with the constant upstream gradient g / nproj, ADDED to grad_Q; sigma partials]
+//           [sigma partials + the direct lmbda term -> grad_T]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) step_loss_partial_kernel(int M, int N, int G, int nproj, const float *__restrict__ dq,
+                                                                const sn_u64 *__restrict__ ws, const float *__restrict__ proj,
+                                                                float *__restrict__ dp, int *__restrict__ ip,
+                                                                float *__restrict__ part, int *__restrict__ argmax1)
+{
+    __shared__ float r0[256], r1[256], r2[256], r3[256];
+    __shared__ int ri[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float s1 = 0.f, mx = -INFINITY, s2 = 0.f, sp = 0.f;
+    int am = 0;
+    for (int j = t; j < M; j += 256) {
+        const float v = dq[(size_t)b * M + j];
+        s1 += v;
+        if (v > mx) mx = v, am = j;
+    }
+    for (int n = t; n < N; n += 256) {
+        sn_u64 k = kKeyInf;
+        for (int g = 0; g < G; ++g) {  // minimum of (distance, query) keys = lowest query on ties
+            const sn_u64 v = ws[((size_t)b * G + g) * N + n];
+            k = v < k ? v : k;
+        }
+        const float d = key_dist(k);
+        dp[(size_t)b * N + n] = d;
+        ip[(size_t)b * N + n] = key_index(k);
+        s2 += d;
+    }
+    for (int i = t; i < nproj; i += 256) sp += proj[(size_t)b * nproj + i];
+    r0[t] = s1, r1[t] = mx, r2[t] = s2, r3[t] = sp, ri[t] = am;
+    for (int s = 128; s > 0; s >>= 1) {
+        __syncthreads();
+        if (t < s) {
+            r0[t] += r0[t + s];
+            r2[t] += r2[t + s];
+            r3[t] += r3[t + s];
+            if (r1[t + s] > r1[t] || (r1[t + s] == r1[t] && ri[t + s] < ri[t])) r1[t] = r1[t + s], ri[t] = ri[t + s];
+        }
+    }
+    if (t == 0) {
+        part[b * 4 + 0] = r0[0], part[b * 4 + 1] = r1[0], part[b * 4 + 2] = r2[0], part[b * 4 + 3] = r3[0];
+        argmax1[b] = ri[0];
+    }
+}
+
+__global__ void __launch_bounds__(64) step_loss_final_kernel(int B, int M, int N, int nproj, float w, float alpha, float lmbda,
+                                                             float min_sigma, const float *__restrict__ part,
+                                                             const float *__restrict__ temperature, float *__restrict__ loss)
+{
+    if (threadIdx.x != 0) return;
+    float s1 = 0.f, mx = 0.f, s2 = 0.f, sp = 0.f;
+    for (int b = 0; b < B; ++b) s1 += part[b * 4], mx += part[b * 4 + 1], s2 += part[b * 4 + 2], sp += part[b * 4 + 3];
+    const float c12 = s1 / ((float)B * (float)M), cmax = mx / (float)B, c21 = s2 / ((float)B * (float)N);
+    const float lsimp = c12 + cmax + w * c21;
+    const float T = *temperature;
+    loss[0] = alpha * lsimp + lmbda * fmaxf(T * T, min_sigma) + sp / ((float)B * (float)nproj);
+    loss[1] = lsimp;
+}
+
+extern "C" int sn_sampler_step_loss_forward(int B, int M, int N, int G, const float *dist_q, const void *colmin_ws,
+                                            const float *proj, const float *temperature, float alpha, float lmbda,
+                                            float weight, float min_sigma, float *dist_p, int *idx_p, int *argmax1,
+                                            float *partial, float *loss, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && M >= 1 && N >= 1 && G >= 1, "bad size");
+    SN_REQUIRE(dist_q && colmin_ws && proj && temperature && dist_p && idx_p && argmax1 && partial && loss, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(step_loss_partial_kernel, dim3(B), dim3(256), 0, st, M, N, G, 3 * M, dist_q, (const sn_u64 *)colmin_ws,
+                       proj, dist_p, idx_p, partial, argmax1);
+    hipLaunchKernelGGL(step_loss_final_kernel, dim3(1), dim3(64), 0, st, B, M, N, 3 * M, weight, alpha, lmbda, min_sigma,
+                       partial, temperature, loss);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// grad_Q (B,3,M) channel-major (the FC head's layout), grad_T (1).  P: (B,N,3) or (B,3,N) by p_layout; Q: (B,3,M).
+// gsig_scratch: B * sn_soft_bwd_splits(B, M) floats.
+extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
+                                             const int *knn_idx, const int *idx_q, const int *idx_p, const int *argmax1,
+                                             const float *temperature, float min_sigma, float alpha, float lmbda,
+                                             float weight, const float *grad_loss, float *grad_Q, float *gsig_scratch,
+                                             float *grad_T, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64, "bad size");
+    SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
+    SN_REQUIRE(P && Q && knn_idx && idx_q && idx_p && argmax1 && temperature && grad_loss && grad_Q && gsig_scratch && grad_T,
+               "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    // 1. alpha * d L_simp / d Q   (targets = Q, channel-major; sources = P)
+    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (1024 + B - 1) / B)); };
+    // same roundings as the op-by-op route: (alpha * g) first, then the per-term coefficients
+    const float c1 = 1.0f / ((float)B * (float)M), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)N);
+    ImplicitGrad ig{grad_loss, argmax1, nullptr, c1, cm, c2, 0.f, alpha};
+    launch_chamfer_bwd(B, ysplit(M), M, N, Q, P, nullptr, idx_q, nullptr, idx_p, grad_Q, 1, ig, st, 1);
+    // 2. + d mean(proj) / d Q, and the sigma partials
+    SoftBwdArgs a{};
+    a.P = P, a.Q = Q, a.idx = knn_idx, a.temperature = temperature, a.min_sigma = min_sigma;
+    a.p_layout = p_layout, a.q_layout = SN_LAYOUT_BCN, a.n = N, a.m = M, a.k = K;
+    a.grad_proj = nullptr, a.gconst = grad_loss, a.gconst_div = (float)(B * 3 * M);
+    a.grad_Q = grad_Q, a.gq_layout = SN_LAYOUT_BCN, a.accumulate_q = 1;
+    a.grad_P = nullptr, a.grad_sigma_partial = gsig_scratch;
+    const int splits = sn_soft_bwd_splits(B, M);
+    hipLaunchKernelGGL(soft_bwd_kernel<true>, dim3(B, splits), dim3(256), 0, st, a);
+    // 3. grad_T from the sigma partials and the direct lmbda * sigma term
+    hipLaunchKernelGGL(sigma_grad_kernel, dim3(1), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
+                       grad_loss, lmbda);
     SN_LAUNCH_CHECK();
     return 0;
 }

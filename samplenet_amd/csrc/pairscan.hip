@@ -353,6 +353,17 @@ static int launch_pairscan(const PairscanArgs &a, int waves, int ysplit, hipStre
     return 0;
 }
 
+// number of workgroups the queries of one cloud are spread over (single-chunk path, N <= 2048): the batch alone cannot
+// fill the chip at B = 32, so aim at >= 2 workgroups per CU
+int pairscan_ysplit(int B, int N, int M, bool colmin)
+{
+    if (N > kWave * 32) return 1;
+    const int ppl = N <= 64 ? 1 : (N <= 256 ? 4 : (N <= 1024 ? 16 : 32));
+    const int maxw = max_threads(ppl, colmin) / kWave;
+    const int want = (512 + B - 1) / std::max(B, 1);
+    return std::max(1, std::min(want, (M + maxw - 1) / maxw));
+}
+
 // Host-side dispatch.  colmin => dist_p / idx_p requested.  ws/ws_bytes: optional scratch that lets the queries of a
 // cloud be spread over several workgroups even when column minima are wanted (partials + a finalize kernel).
 int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finalize, int *used_split, hipStream_t st)
@@ -364,9 +375,7 @@ int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finaliz
         // single chunk: the whole cloud lives in the wave's registers
         const int ppl = N <= 64 ? 1 : (N <= 256 ? 4 : (N <= 1024 ? 16 : 32));
         const int maxw = max_threads(ppl, colmin) / kWave;
-        // spread the queries of a cloud over several workgroups when the batch alone cannot fill the chip
-        const int want = (512 + a.B - 1) / a.B;  // aim at >= 2 workgroups per CU
-        int ysplit = std::max(1, std::min(want, (M + maxw - 1) / maxw));
+        int ysplit = pairscan_ysplit(a.B, N, M, colmin);
         if (colmin && ysplit > 1) {
             const long long need = (long long)a.B * ysplit * N * 8;
             if (!ws || ws_bytes < need) ysplit = 1;
@@ -488,4 +497,39 @@ extern "C" int sn_knn(int b, int n, int m, int k, const float *xyz1, int layout1
     SN_REQUIRE(k >= 1, "k must be >= 1");
     return sn_pairscan_forward(b, n, m, k, xyz1, layout1, xyz2, layout2, idx, dist, nullptr, nullptr, nullptr,
                                nullptr, nullptr, 0, nullptr, nullptr, 0.f, stream);
+}
+
+// Pair scan whose per-point minima are left as PARTIAL (distance,index) keys, one set per workgroup of a cloud:
+// workspace [B][G][N] u64 with G = sn_pairscan_colmin_splits(B, N, M) (> 1, else use sn_pairscan_forward).  The consumer
+// (sn_sampler_step_loss_forward) takes the minimum over G while it reduces the loss: one launch less than finalising here.
+extern "C" int sn_pairscan_colmin_splits(int B, int N, int M)
+{
+    if (B < 1 || N < 1 || M < 1) return 0;
+    return sn::pairscan_ysplit(B, N, M, true);
+}
+
+extern "C" int sn_pairscan_forward_partial(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
+                                           int q_layout, int *knn_idx, float *dist_q, int *idx_q, float *proj,
+                                           int proj_layout, const float *temperature, float min_sigma, void *workspace,
+                                           long long workspace_bytes, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && K <= N, "bad size");
+    SN_REQUIRE(P && Q && workspace && temperature, "null pointer");
+    SN_REQUIRE(p_layout == SN_LAYOUT_BNC || p_layout == SN_LAYOUT_BCN, "bad p_layout");
+    SN_REQUIRE(q_layout == SN_LAYOUT_BNC || q_layout == SN_LAYOUT_BCN, "bad q_layout");
+    const int G = sn_pairscan_colmin_splits(B, N, M);
+    if (G <= 1 || N > sn::kWave * 32)
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pairscan_forward_partial: this shape runs as one workgroup per cloud");
+    SN_REQUIRE(workspace_bytes >= (long long)B * G * N * 8, "workspace too small");
+    PairscanArgs a{};
+    a.P = P, a.Q = Q, a.p_layout = p_layout, a.q_layout = q_layout;
+    a.B = B, a.N = N, a.M = M, a.K = K;
+    a.knn_idx = knn_idx, a.dist_q = dist_q, a.idx_q = idx_q;
+    a.proj = proj, a.proj_layout = proj_layout, a.temperature = temperature, a.min_sigma = min_sigma;
+    int used = 0;
+    int rc = sn::pairscan_dispatch(a, workspace, workspace_bytes, false, &used, (hipStream_t)stream);
+    if (rc) return rc;
+    SN_REQUIRE(used == G, "internal: split mismatch");
+    SN_LAUNCH_CHECK();
+    return 0;
 }

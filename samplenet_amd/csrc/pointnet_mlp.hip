@@ -1541,35 +1541,65 @@ __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const 
                                                            const float *__restrict__ W, const float *__restrict__ bias,
                                                            float *__restrict__ z, float *__restrict__ stats)
 {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, rq = threadIdx.x >> 6;
-    const int co = blockIdx.y * 64 + cl;
+    // thread -> 4 consecutive channels (c4) x row slot rs (16 slots): 16-byte stores, a wave writes 4 whole 256-byte rows
+    // per instruction (dword stores cost ~58 issue cycles per wave-instruction: the 16-per-thread version was issue-bound)
+    __shared__ float red[2][16][64];
+    const int q = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int cl = q * 4, co = blockIdx.y * 64 + cl;
     const int row0 = blockIdx.x * 64;
-    const bool ok = co < Co;
-    const float w0 = ok ? W[co * 3 + 0] : 0.f, w1 = ok ? W[co * 3 + 1] : 0.f, w2 = ok ? W[co * 3 + 2] : 0.f;
-    const float b = (ok && bias) ? bias[co] : 0.f;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int r = row0 + rq + 4 * i;
+    const bool vec = (Co & 3) == 0 && co + 3 < Co;
+    float w[4][3], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = min(co + j, Co - 1);
+        const float m = co + j < Co ? 1.f : 0.f;
+        w[j][0] = W[c * 3 + 0] * m, w[j][1] = W[c * 3 + 1] * m, w[j][2] = W[c * 3 + 2] * m;
+        b[j] = bias ? bias[c] * m : 0.f;
+    }
+    float xs[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = min(row0 + rs + 16 * i, R - 1);
+        xs[i][0] = x[(size_t)r * 3], xs[i][1] = x[(size_t)r * 3 + 1], xs[i][2] = x[(size_t)r * 3 + 2];
+    }
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + rs + 16 * i;
+        const float m = r < R ? 1.f : 0.f;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = (fmaf(w[j][2], xs[i][2], fmaf(w[j][1], xs[i][1], w[j][0] * xs[i][0])) + b[j]) * m;
+            s0[j] += v[j];
+            s1[j] += v[j] * v[j];
+        }
         if (r < R) {
-            const float v = fmaf(w2, x[(size_t)r * 3 + 2], fmaf(w1, x[(size_t)r * 3 + 1], w0 * x[(size_t)r * 3])) + b;
-            if (ok) z[(size_t)r * Co + co] = v;
-            s0 += v;
-            s1 += v * v;
+            if (vec) {
+                *reinterpret_cast<float4 *>(z + (size_t)r * Co + co) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (co + j < Co) z[(size_t)r * Co + co + j] = v[j];
+            }
         }
     }
-    red[0][rq][cl] = s0, red[1][rq][cl] = s1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[0][rs][cl + j] = s0[j], red[1][rs][cl + j] = s1[j];
     __syncthreads();
-    if (rq == 0 && ok && stats) {
-        float *st = stats + (size_t)blockIdx.x * 2 * Co;
-        st[co] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-        st[Co + co] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    if (threadIdx.x < 64 && stats) {
+        const int c = blockIdx.y * 64 + threadIdx.x;
+        if (c < Co) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a0 += red[0][k][threadIdx.x], a1 += red[1][k][threadIdx.x];
+            float *st = stats + (size_t)blockIdx.x * 2 * Co;
+            st[c] = a0;
+            st[Co + c] = a1;
+        }
     }
 }
 
-// dW[co][0..2] partial over a split of the rows: sum_r dZ[r][co] * x[r][c], dZ = k1 dY + k2 Z + k3.
-// part layout [split][Co][3] (reduced by wgrad_reduce_kernel).
 __global__ void __launch_bounds__(256) conv_in3_wgrad_kernel(int R, int Co, int rows_per_split, const float *__restrict__ x,
                                                              const float *__restrict__ dy, const float *__restrict__ z,
                                                              const float *__restrict__ kcoef, float *__restrict__ part)
@@ -2187,6 +2217,25 @@ extern "C" int sn_linear_wgrad(int R, int Ci, int Co, int dz_mode, const float *
         if (pm) launch_wgrad<DZ_POOL, ACT_BN_RELU>(g, R, Ci, Co, with_bias, dW, db, st);
         else launch_wgrad<DZ_POOL, ACT_NONE>(g, R, Ci, Co, with_bias, dW, db, st);
     }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The fused convolution backward on its own (what sn_linear_backward / sn_layer_backward launch first for 64 / 128-channel
+// layers): dYprev, BatchNorm-backward partial sums [G][2][Ci] and dW partials [G][Co][Ci] with
+// G = sn_linear_wgrad_splits(R, Ci, Co, 0); the caller reduces the partials (sn_linear_backward does).  Returns
+// SN_ERR_UNSUPPORTED for shapes the fused kernel does not serve.
+extern "C" int sn_conv_backward_partials(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
+                                         const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
+                                         const float *coef_prev, float *dyprev, float *stats, float *part, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(W && zprev && dyprev && part && stats && z && kcoef && coef_prev, "null pointer");
+    SN_REQUIRE((dz_mode == DZ_BN && dy) || (dz_mode == DZ_POOL && gsel && argsel), "bad dz_mode / missing gradient source");
+    if (!conv_bwd_fused_ok(R, Ci, Co, dz_mode, npts, coef_prev, kcoef, nullptr))
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_backward_partials: shape not served by the fused kernel");
+    launch_conv_bwd_fused(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev, stats, part,
+                          (hipStream_t)stream);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -16,9 +16,10 @@ import torch
 
 class SamplerTrainStep:
     def __init__(self, net, example_x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=None, reducer=None,
-                 use_graph=True, warmup=3):
+                 use_graph=True, warmup=3, fused_loss=True):
         self.net, self.reducer = net, reducer
         self.alpha, self.lmbda, self.gamma, self.delta = alpha, lmbda, gamma, delta
+        self.fused_loss = fused_loss  # False: compose the loss op by op through the module's own methods (A/B, tests)
         self.task_loss = task_loss  # None: the benchmark's stand-in mean(proj), fused with the loss weighting
         self.x = example_x.clone()
         self._one = torch.ones((), device=example_x.device, dtype=torch.float32)
@@ -27,8 +28,35 @@ class SamplerTrainStep:
         if use_graph:
             self._capture(warmup)
 
+    def _fast_path(self):
+        """forward + loss behind one autograd node (ops.SamplerStepLossFunction): the benchmark's stand-in task term,
+        training mode with projection, (B,N,3) input, and a batch small enough that the pair scan splits clouds."""
+        net = self.net
+        if not self.fused_loss or self.task_loss is not None or not net.training or net.skip_projection or \
+                net.input_shape != "bnc":
+            return False
+        from ._lib import lib
+
+        B, N, _ = self.x.shape
+        return lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1
+
     def _step(self):
         net, x = self.net, self.x
+        if self._fast_path():
+            from . import ops
+
+            T = net.project._temperature
+            t_sink = None
+            if self.reducer is not None and T.requires_grad and T.grad is not None:
+                t_sink = T.grad.view(-1)[:1]  # a view of the flat bucket: written in place, nothing to zero or accumulate
+            elif self.reducer is not None:
+                self.reducer.zero_grad()
+            y = net._features(x.permute(0, 2, 1), x)  # (B,3,M)
+            weight = self.gamma + self.delta * net.num_out_points
+            loss, _proj = ops.SamplerStepLossFunction.apply(y, x, T, net.project._group_size, net.project._min_sigma_f,
+                                                            self.alpha, self.lmbda, weight, t_sink)
+            loss.backward(self._one)  # preallocated upstream gradient: no ones_like fill per step
+            return loss.detach()
         if self.reducer is not None:
             self.reducer.zero_grad()
         simp, proj = net(x)

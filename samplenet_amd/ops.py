@@ -404,6 +404,76 @@ class SamplerLossFunction(torch.autograd.Function):
         return gls.reshape(lshape), gT.reshape(temperature.shape), gproj, None, None, None
 
 
+class SamplerStepLossFunction(torch.autograd.Function):
+    """The whole loss side of the sampler's training step behind ONE autograd node (engine fast path):
+        simp = y (B,3,M) from the FC head;  proj = SoftProjection(x, simp)                       (soft_projection.py:138-152)
+        L = alpha * simplification_loss(x, simp) + lmbda * sigma + mean(proj)                    (main.py:507-531)
+    forward : pair scan (per-point minima left as partials) -> per-cloud reduction -> combine     = 3 launches
+    backward: Chamfer backward (implicit gradients) -> soft-projection backward (+=) -> grad_T    = 3 launches
+    Same numbers as SoftProjectFunction + SimplificationLossFunction + SamplerLossFunction composed by autograd.
+    t_sink: optional tensor the temperature gradient is written into (p.grad view of a flat bucket); then no gradient is
+    returned for the temperature."""
+
+    @staticmethod
+    def forward(ctx, y_bcn, x_bnc, temperature, K, min_sigma, alpha, lmbda, weight, t_sink=None):
+        _need_gpu(y_bcn, x_bnc, temperature)
+        y, x = _f32c(y_bcn), _f32c(x_bnc)
+        B, _, M = y.shape
+        N = x.shape[1]
+        dev = y.device
+        G = lib.sn_pairscan_colmin_splits(B, N, M)
+        if G <= 1:
+            raise ValueError("SamplerStepLossFunction needs a batch small enough for split clouds (use the op-by-op path)")
+        proj = torch.empty(B, M, 3, device=dev, dtype=torch.float32)
+        idx = torch.empty(B, M, K, device=dev, dtype=torch.int32)
+        dq = torch.empty(B, M, device=dev, dtype=torch.float32)
+        iq = torch.empty(B, M, device=dev, dtype=torch.int32)
+        dp = torch.empty(B, N, device=dev, dtype=torch.float32)
+        ip = torch.empty(B, N, device=dev, dtype=torch.int32)
+        ws = torch.empty(B * G * N, device=dev, dtype=torch.int64)
+        argmax1 = torch.empty(B, device=dev, dtype=torch.int32)
+        partial = torch.empty(B * 4, device=dev, dtype=torch.float32)
+        loss = torch.empty(2, device=dev, dtype=torch.float32)
+        T = temperature.detach().float().reshape(1)
+        with torch.cuda.device(dev):
+            st = _stream(y)
+            check(lib.sn_pairscan_forward_partial(B, N, M, K, ptr(x), BNC, ptr(y), BCN, ptr(idx), ptr(dq), ptr(iq), ptr(proj), BNC,
+                                                  ptr(T), float(min_sigma), ptr(ws), ws.numel() * 8, st),
+                  "sn_pairscan_forward_partial")
+            check(lib.sn_sampler_step_loss_forward(B, M, N, G, ptr(dq), ptr(ws), ptr(proj), ptr(T), float(alpha), float(lmbda),
+                                                   float(weight), float(min_sigma), ptr(dp), ptr(ip), ptr(argmax1), ptr(partial),
+                                                   ptr(loss), st), "sn_sampler_step_loss_forward")
+        ctx.save_for_backward(x, y, idx, iq, ip, argmax1, temperature)
+        ctx.cfg = (K, float(min_sigma), float(alpha), float(lmbda), float(weight))
+        ctx.t_sink = t_sink
+        ctx.mark_non_differentiable(proj)
+        ctx.set_materialize_grads(False)
+        return loss[0], proj
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gproj=None):
+        x, y, idx, iq, ip, argmax1, temperature = ctx.saved_tensors
+        if grad_loss is None:
+            return (None,) * 9
+        K, min_sigma, alpha, lmbda, weight = ctx.cfg
+        B, _, M = y.shape
+        N = x.shape[1]
+        dev = y.device
+        gQ = torch.empty_like(y)
+        gsig = torch.empty(B * lib.sn_soft_bwd_splits(B, M), device=dev, dtype=torch.float32)
+        gT = ctx.t_sink if ctx.t_sink is not None else torch.empty(1, device=dev, dtype=torch.float32)
+        gl = grad_loss.contiguous().float().reshape(1)
+        T = temperature.detach().float().reshape(1)
+        with torch.cuda.device(dev):
+            check(lib.sn_sampler_step_loss_backward(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(ip), ptr(argmax1),
+                                                    ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
+                                                    _stream(y)), "sn_sampler_step_loss_backward")
+        g_temp = None
+        if ctx.t_sink is None and ctx.needs_input_grad[2]:
+            g_temp = gT.reshape(temperature.shape)
+        return (gQ if ctx.needs_input_grad[0] else None), None, g_temp, None, None, None, None, None, None
+
+
 # --------------------------------------------------------------------------------------------- EMD
 def approx_match(xyz1, xyz2):
     """xyz1 (B,n,3), xyz2 (B,m,3) -> match (B,m,n); no gradient (tf_approxmatch.py:13-24)."""

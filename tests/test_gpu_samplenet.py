@@ -166,3 +166,40 @@ def test_fused_sampler_loss_equals_composition():
                           task_loss=lambda p: p.mean())(x)
     assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
     assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("B,N,M,K", [(6, 512, 64, 8), (32, 1024, 64, 8), (3, 320, 20, 5)])
+def test_single_node_step_loss_equals_composition(B, N, M, K):
+    """engine fast path (ops.SamplerStepLossFunction: pair scan with partial per-point minima -> loss -> 3-launch backward)
+    against (a) the same engine composing the loss through the module's own forward / get_simplification_loss and
+    (b) the plain op-by-op expression: loss within 1e-6 relative, every gradient (MLP, temperature) within fp32 rounding;
+    also without a flat gradient bucket (gradients through autograd's accumulation)."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(B + N)
+    net_a = SampleNet(M, 128, group_size=K, initial_temperature=0.7, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b, net_c, net_d = copy.deepcopy(net_a), copy.deepcopy(net_a), copy.deepcopy(net_a)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    kw = dict(alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, use_graph=False)
+    red_a, red_b, red_c = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b), FlatGradAllReducer(net_c)
+    step_a = SamplerTrainStep(net_a, x, reducer=red_a, **kw)
+    assert step_a._fast_path()
+    la = step_a(x)
+    lb = SamplerTrainStep(net_b, x, reducer=red_b, fused_loss=False, **kw)(x)
+    lc = SamplerTrainStep(net_c, x, reducer=red_c, task_loss=lambda p: p.mean(), **kw)(x)
+    ld = SamplerTrainStep(net_d, x, reducer=None, **kw)(x)
+    for other in (lb, lc, ld):
+        assert abs(float(la) - float(other)) <= 1e-6 * max(1.0, abs(float(other)))
+    assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(red_a.flat, red_c.flat, rtol=1e-5, atol=1e-8)
+    ga = {n: p.grad for n, p in net_a.named_parameters()}
+    for n, p in net_d.named_parameters():
+        assert p.grad is not None, n
+        assert torch.allclose(ga[n], p.grad, rtol=1e-5, atol=1e-8), n
+    # BatchNorm running statistics moved identically
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), n
