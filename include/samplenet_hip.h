@@ -269,6 +269,9 @@ int sn_pool_forward(int B, int N, int C, const float *z, const float *coef, floa
                     float *zsel, sn_stream_t stream);
 int sn_pool_backward(int B, int C, const float *g, const float *pooled, const float *zsel, float *gsel,
                      float *stats, sn_stream_t stream);
+/* sn_pool_backward + sn_bn_backward_coef of the last conv layer (R = B * N rows seen by its BatchNorm) in one launch */
+int sn_pool_backward_bn(int B, int C, long long R, const float *g, const float *pooled, const float *zsel, float *gsel,
+                        const float *coef, float *dgamma, float *dbeta, float *dbias, float *kcoef, sn_stream_t stream);
 int sn_bn_backward_coef(int nblk, int C, long long R, const float *stats, const float *coef, float *dgamma,
                         float *dbeta, float *dbias, float *kcoef, sn_stream_t stream);
 int sn_linear_dgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,

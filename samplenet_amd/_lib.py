@@ -58,6 +58,7 @@ PROTOTYPES = {
     "sn_bn_eval_coef": [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "sn_pool_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_pool_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_pool_backward_bn": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_backward_coef": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_dgrad": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

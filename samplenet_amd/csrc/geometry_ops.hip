@@ -788,22 +788,24 @@ extern "C" int sn_grouping_operation_grad(int b, int c, int n, int m, int nsampl
 //           [soft-projection backward with the constant upstream gradient g / nproj, ADDED to grad_Q; sigma partials]
 //           [sigma partials + the direct lmbda term -> grad_T]
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) step_loss_partial_kernel(int M, int N, int G, int nproj, const float *__restrict__ dq,
-                                                                const sn_u64 *__restrict__ ws, const float *__restrict__ proj,
-                                                                float *__restrict__ dp, int *__restrict__ ip,
-                                                                float *__restrict__ part, int *__restrict__ argmax1)
+__global__ void __launch_bounds__(1024) step_loss_partial_kernel(int M, int N, int G, int nproj, const float *__restrict__ dq,
+                                                                 const sn_u64 *__restrict__ ws, const float *__restrict__ proj,
+                                                                 float *__restrict__ dp, int *__restrict__ ip,
+                                                                 float *__restrict__ part, int *__restrict__ argmax1)
 {
-    __shared__ float r0[256], r1[256], r2[256], r3[256];
-    __shared__ int ri[256];
+    // one workgroup of 1024 threads per cloud: at N = 1024 every thread finishes one point (its G keys in flight together)
+    constexpr int NT = 1024;
+    __shared__ float r0[NT], r1[NT], r2[NT], r3[NT];
+    __shared__ int ri[NT];
     const int b = blockIdx.x, t = threadIdx.x;
     float s1 = 0.f, mx = -INFINITY, s2 = 0.f, sp = 0.f;
     int am = 0;
-    for (int j = t; j < M; j += 256) {
+    for (int j = t; j < M; j += NT) {
         const float v = dq[(size_t)b * M + j];
         s1 += v;
         if (v > mx) mx = v, am = j;
     }
-    for (int n = t; n < N; n += 256) {
+    for (int n = t; n < N; n += NT) {
         sn_u64 k = kKeyInf;
         for (int g = 0; g < G; ++g) {  // minimum of (distance, query) keys = lowest query on ties
             const sn_u64 v = ws[((size_t)b * G + g) * N + n];
@@ -814,9 +816,9 @@ __global__ void __launch_bounds__(256) step_loss_partial_kernel(int M, int N, in
         ip[(size_t)b * N + n] = key_index(k);
         s2 += d;
     }
-    for (int i = t; i < nproj; i += 256) sp += proj[(size_t)b * nproj + i];
+    for (int i = t; i < nproj; i += NT) sp += proj[(size_t)b * nproj + i];
     r0[t] = s1, r1[t] = mx, r2[t] = s2, r3[t] = sp, ri[t] = am;
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = NT / 2; s > 0; s >>= 1) {
         __syncthreads();
         if (t < s) {
             r0[t] += r0[t + s];
@@ -835,12 +837,22 @@ __global__ void __launch_bounds__(64) step_loss_final_kernel(int B, int M, int N
                                                              float min_sigma, const float *__restrict__ part,
                                                              const float *__restrict__ temperature, float *__restrict__ loss)
 {
-    if (threadIdx.x != 0) return;
+    // lane b carries clouds b, b + 64, ...; the lanes are then combined by a fixed xor tree (all loads in flight at once;
+    // a single thread walking the B partials pays one memory round trip per cloud)
+    const int t = threadIdx.x;
     float s1 = 0.f, mx = 0.f, s2 = 0.f, sp = 0.f;
-    for (int b = 0; b < B; ++b) s1 += part[b * 4], mx += part[b * 4 + 1], s2 += part[b * 4 + 2], sp += part[b * 4 + 3];
+    for (int b = t; b < B; b += 64) s1 += part[b * 4], mx += part[b * 4 + 1], s2 += part[b * 4 + 2], sp += part[b * 4 + 3];
+    const float T = *temperature;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        mx += __shfl_xor(mx, o);
+        s2 += __shfl_xor(s2, o);
+        sp += __shfl_xor(sp, o);
+    }
+    if (t != 0) return;
     const float c12 = s1 / ((float)B * (float)M), cmax = mx / (float)B, c21 = s2 / ((float)B * (float)N);
     const float lsimp = c12 + cmax + w * c21;
-    const float T = *temperature;
     loss[0] = alpha * lsimp + lmbda * fmaxf(T * T, min_sigma) + sp / ((float)B * (float)nproj);
     loss[1] = lsimp;
 }
@@ -853,7 +865,7 @@ extern "C" int sn_sampler_step_loss_forward(int B, int M, int N, int G, const fl
     SN_REQUIRE(B >= 1 && M >= 1 && N >= 1 && G >= 1, "bad size");
     SN_REQUIRE(dist_q && colmin_ws && proj && temperature && dist_p && idx_p && argmax1 && partial && loss, "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(step_loss_partial_kernel, dim3(B), dim3(256), 0, st, M, N, G, 3 * M, dist_q, (const sn_u64 *)colmin_ws,
+    hipLaunchKernelGGL(step_loss_partial_kernel, dim3(B), dim3(1024), 0, st, M, N, G, 3 * M, dist_q, (const sn_u64 *)colmin_ws,
                        proj, dist_p, idx_p, partial, argmax1);
     hipLaunchKernelGGL(step_loss_final_kernel, dim3(1), dim3(64), 0, st, B, M, N, 3 * M, weight, alpha, lmbda, min_sigma,
                        partial, temperature, loss);

@@ -1630,25 +1630,33 @@ __global__ void __launch_bounds__(256) conv_in3_wgrad_kernel(int R, int Co, int 
 
 // partials [nsplit][Co][Ce] -> dW [Co][Ci], db [Co] (Ce = Ci + 1).  64 elements x 4 split-slices per workgroup;
 // slices and the final 4-way sum run in a fixed order: deterministic.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(int nsplit, int Co, int Ci, int Ce, const float *__restrict__ part,
-                                                           float *__restrict__ dW, float *__restrict__ db)
+__global__ void __launch_bounds__(1024) wgrad_reduce_kernel(int nsplit, int Co, int Ci, int Ce, const float *__restrict__ part,
+                                                            float *__restrict__ dW, float *__restrict__ db)
 {
-    __shared__ float red[4][64];
+    // 64 elements x 16 split-slices per workgroup, 8 independent loads in flight per thread (fixed-order sums)
+    __shared__ float red[16][64];
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + el;
     const size_t stride = (size_t)Co * Ce;
     float acc = 0.f;
     if (e < Co * Ce) {
-        int s = sl;
-        for (; s + 12 < nsplit; s += 16)
-            acc += (part[(size_t)s * stride + e] + part[(size_t)(s + 4) * stride + e]) +
-                   (part[(size_t)(s + 8) * stride + e] + part[(size_t)(s + 12) * stride + e]);
-        for (; s < nsplit; s += 4) acc += part[(size_t)s * stride + e];
+        const float *p = part + e;
+        int sp = sl;
+        for (; sp + 7 * 16 < nsplit; sp += 8 * 16) {
+            const float v0 = p[(size_t)sp * stride], v1 = p[(size_t)(sp + 16) * stride];
+            const float v2 = p[(size_t)(sp + 32) * stride], v3 = p[(size_t)(sp + 48) * stride];
+            const float v4 = p[(size_t)(sp + 64) * stride], v5 = p[(size_t)(sp + 80) * stride];
+            const float v6 = p[(size_t)(sp + 96) * stride], v7 = p[(size_t)(sp + 112) * stride];
+            acc += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+        }
+        for (; sp < nsplit; sp += 16) acc += p[(size_t)sp * stride];
     }
     red[sl][el] = acc;
     __syncthreads();
     if (sl == 0 && e < Co * Ce) {
-        const float tot = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += red[q][el];
         const int o = e / Ce, i = e - o * Ce;
         if (i < Ci)
             dW[(size_t)o * Ci + i] = tot;
@@ -1849,7 +1857,7 @@ __global__ void __launch_bounds__(1024) pool_fwd_kernel(int N, int C, const floa
 // (one partial block: sum_b gsel, sum_b gsel * zsel), summed over b in ascending order.
 __global__ void __launch_bounds__(1024) pool_bwd_kernel(int B, int C, const float *__restrict__ g,
                                                         const float *__restrict__ pooled, const float *__restrict__ zsel,
-                                                        float *__restrict__ gsel, float *__restrict__ stats)
+                                                        float *__restrict__ gsel, float *__restrict__ stats, BnBwd bb)
 {
     // 64 channels x 16 batch slices per workgroup; slices and the final 16-way sum run in a fixed order
     __shared__ float red[2][16][64];
@@ -1870,8 +1878,9 @@ __global__ void __launch_bounds__(1024) pool_bwd_kernel(int B, int C, const floa
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) a0 += red[0][q][cl], a1 += red[1][q][cl];
-        stats[c] = a0;
-        stats[C + c] = a1;
+        if (stats) stats[c] = a0, stats[C + c] = a1;
+        // the workgroup holds every cloud of its channels: the BatchNorm backward of the last conv layer completes here
+        if (bb.coef) bn_backward_channel(bb, C, c, (double)a0, (double)a1);
     }
 }
 
@@ -2180,7 +2189,7 @@ static void launch_wgrad(WgradArgs &g, int R, int Ci, int Co, int with_bias, flo
     if (ZMODE == DZ_BN && PMODE == ACT_NONE && Ci == 3 && !with_bias) {  // xyz input layer
         hipLaunchKernelGGL(conv_in3_wgrad_kernel, dim3(nsplit, (Co + 63) / 64), dim3(256), 0, st, R, Co, rps, g.prev.z, g.dz.dy,
                            g.dz.z, g.dz.k1, g.part);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * 3 + 63) / 64), dim3(256), 0, st, nsplit, Co, 3, 3, g.part, dW, db);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * 3 + 63) / 64), dim3(1024), 0, st, nsplit, Co, 3, 3, g.part, dW, db);
         return;
     }
     dim3 grid((Co + TileW::BM - 1) / TileW::BM, (g.ncols + TileW::BN - 1) / TileW::BN, nsplit);
@@ -2188,7 +2197,7 @@ static void launch_wgrad(WgradArgs &g, int R, int Ci, int Co, int with_bias, flo
     const bool full = !with_bias && Co % TileW::BM == 0 && Ci % TileW::BN == 0 && R % rps == 0;
     SN_LAUNCH_T(linear_wgrad_kernel, TileW, full, grid, g, ZMODE, PMODE);
     const int tot = Co * g.ncols;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(256), 0, st, nsplit, Co, Ci, g.ncols, g.part, dW, db);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((tot + 63) / 64), dim3(1024), 0, st, nsplit, Co, Ci, g.ncols, g.part, dW, db);
 }
 
 // part: scratch of sn_linear_wgrad_splits(...) * Co * (Ci + with_bias) floats.  db may be NULL (no bias column).
@@ -2254,7 +2263,7 @@ extern "C" int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const floa
         SN_REQUIRE(stats && z && (dz_mode != DZ_BN || dy) && (dz_mode != DZ_POOL || (gsel && argsel)), "null pointer");
         const int G = launch_conv_bwd_fused(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev,
                                             stats, part, (hipStream_t)stream);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, Co, Ci, Ci,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(1024), 0, (hipStream_t)stream, G, Co, Ci, Ci,
                            part, dW, nullptr);
         SN_LAUNCH_CHECK();
         return 0;
@@ -2288,7 +2297,7 @@ extern "C" int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const floa
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_BN, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
     else
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_POOL, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(256), 0, st, nsplit, Co, Ci, Ci, part, dW, nullptr);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(1024), 0, st, nsplit, Co, Ci, Ci, part, dW, nullptr);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -2440,7 +2449,20 @@ extern "C" int sn_pool_backward(int B, int C, const float *g, const float *poole
 {
     SN_REQUIRE(B >= 1 && C >= 1 && g && pooled && zsel && gsel && stats, "bad argument");
     hipLaunchKernelGGL(pool_bwd_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, B, C, g, pooled, zsel,
-                       gsel, stats);
+                       gsel, stats, BnBwd{});
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// sn_pool_backward + sn_bn_backward_coef of the last conv layer in one launch (R = rows the BatchNorm saw = B * N)
+extern "C" int sn_pool_backward_bn(int B, int C, long long R, const float *g, const float *pooled, const float *zsel,
+                                   float *gsel, const float *coef, float *dgamma, float *dbeta, float *dbias, float *kcoef,
+                                   sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && C >= 1 && R >= 1 && g && pooled && zsel && gsel && coef && dgamma && dbeta && kcoef, "bad argument");
+    const BnBwd bb{coef, dgamma, dbeta, dbias, kcoef, R};
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, B, C, g, pooled, zsel,
+                       gsel, (float *)nullptr, bb);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -259,10 +259,12 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
     # ---- max-pool + last conv layer's BatchNorm ----
     C5 = convs[4].Co
     gsel = _empty((B, C5), grad_y)
-    stats = _empty((1, 2, C5), grad_y)
-    check(lib.sn_pool_backward(B, C5, ptr(g_pool), ptr(saved["pooled"]), ptr(saved["zsel"]), ptr(gsel), ptr(stats),
-                               _st(grad_y)), "sn_pool_backward")
-    dgamma, dbeta, dbias, kcoef = _bn_bwd(convs[4], R, stats, 1, cc[4], sink, bn_c[4], names_c[4])
+    L5 = convs[4]
+    dgamma, dbeta = _out(sink, bn_c[4] + ".weight", L5.bn.weight), _out(sink, bn_c[4] + ".bias", L5.bn.bias)
+    dbias = _out(sink, names_c[4] + ".bias", L5.b)
+    kcoef = _empty((3, C5), grad_y)
+    check(lib.sn_pool_backward_bn(B, C5, R, ptr(g_pool), ptr(saved["pooled"]), ptr(saved["zsel"]), ptr(gsel), ptr(cc[4]),
+                                  ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(kcoef), _st(grad_y)), "sn_pool_backward_bn")
     grads[bn_c[4] + ".weight"], grads[bn_c[4] + ".bias"], grads[names_c[4] + ".bias"] = dgamma, dbeta, dbias
 
     # ---- conv stack (rows = B*N): conv5 -> ... -> conv2 (each also finishes the BatchNorm of the layer below), conv1 ----
