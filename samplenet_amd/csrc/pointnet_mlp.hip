@@ -516,23 +516,40 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
 
     float s0[T::TN], s1[T::TN];
+    // FULL tiles leave as 16-byte stores: each 32 x 32 fragment is transposed through a per-wave LDS scratch (a dword
+    // store per fragment element costs ~58 issue cycles per wave-instruction: 16 of them per fragment were issue-bound)
+    float *Ts = lds + 2 * T::WR * T::BN + wave * (32 * 36);  // behind column_reduce2's area; staging buffers are dead
+    static_assert(2 * T::WR * T::BN + T::WR * T::WC * 32 * 36 <= T::LDS_FLOATS, "transpose scratch must fit the staging LDS");
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
         const float bias = biasv[j];
         s0[j] = 0.f, s1[j] = 0.f;
 #pragma unroll
-        for (int i = 0; i < T::TM; ++i)
+        for (int i = 0; i < T::TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
                 const float v = acc[i][j][e] + bias;
                 if (FULL || (row < R && col < Co)) {
-                    g.z[(size_t)row * Co + col] = v;
+                    if (FULL)
+                        Ts[frag_row(e, lane) * 36 + (lane & 31)] = v;
+                    else
+                        g.z[(size_t)row * Co + col] = v;
                     s0[j] += v;
                     s1[j] += v * v;
                 }
             }
+            if (FULL) {
+                float *zt = g.z + (size_t)(row0 + (wr * T::TM + i) * 32) * Co + col0 + (wc * T::TN + j) * 32 + (lane & 7) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rt = 8 * q + (lane >> 3);
+                    *reinterpret_cast<float4 *>(zt + (size_t)rt * Co) =
+                        *reinterpret_cast<const float4 *>(Ts + rt * 36 + (lane & 7) * 4);
+                }
+            }
+        }
     }
     SN_TL(3);
     SN_TL_DRAIN();
@@ -880,6 +897,21 @@ __device__ __forceinline__ void cbf_wg_mfma(f32x16 (&acc)[NWT], const float (&a)
         for (int n = 0; n < NWT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i][n], acc[n], 0, 0, 0);
 }
 
+// W[k = co][j = ci] -> LDS (pitch LDW), by all 512 threads
+template <int CI, int CO, int LDW>
+__device__ __forceinline__ void cbf_stage_w(const float *__restrict__ W, float *__restrict__ Ws, int tid)
+{
+    constexpr int W4 = CO * CI / 4 / 512;
+    float4 wv[W4];
+#pragma unroll
+    for (int q = 0; q < W4; ++q) wv[q] = *reinterpret_cast<const float4 *>(W + (size_t)(tid + q * 512) * 4);
+#pragma unroll
+    for (int q = 0; q < W4; ++q) {
+        const int f = tid + q * 512;
+        *reinterpret_cast<float4 *>(Ws + (f / (CI / 4)) * LDW + (f % (CI / 4)) * 4) = wv[q];
+    }
+}
+
 // Tile height and the home of W by shape: CO = 128 -> W in LDS (its 64 B-fragment registers per dgrad wave do not fit
 // next to the prefetch registers); 128 x 128 channels -> 32-row tiles so that W and two tile buffers fit in 160 KB.
 template <int CI, int CO>
@@ -926,18 +958,6 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
 #ifdef SN_TIMELINE
     sn_hw_record();
 #endif
-    if (WLDS) {  // W[k = co][j = ci] -> LDS, all eight waves
-        constexpr int W4 = CO * CI / 4 / 512;
-        float4 wv[W4];
-#pragma unroll
-        for (int q = 0; q < W4; ++q) wv[q] = *reinterpret_cast<const float4 *>(g.W + (size_t)(tid + q * 512) * 4);
-#pragma unroll
-        for (int q = 0; q < W4; ++q) {
-            const int f = tid + q * 512;
-            *reinterpret_cast<float4 *>(Ws + (f / (CI / 4)) * LDW + (f % (CI / 4)) * 4) = wv[q];
-        }
-    }
-
     if (do_d) {
         // ---------------- producer + data-gradient waves ------------------------------------------------
         // They win the matrix-pipe arbitration (older waves), finish their 64-deep MFMA chain in about half a tile period
@@ -980,6 +1000,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
 
         int tile = blockIdx.x;
         cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+        if (WLDS) cbf_stage_w<CI, CO, LDW>(g.W, Ws, tid);  // requested after the first tile: its staging does not wait for W
         if (!WLDS) {  // dgrad B fragments in registers, k = 2 s + h (requested after the first tile)
 #pragma unroll
             for (int s = 0; s < NWREG; ++s) wreg[s] = g.W[(size_t)(2 * s + h) * CI + cb * 32 + l31];
@@ -1075,6 +1096,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
         }
     } else {
         // ---------------- weight-gradient waves ----------------------------------------------------------
+        if (WLDS) cbf_stage_w<CI, CO, LDW>(g.W, Ws, tid);
         f32x16 accw[NWT];
 #pragma unroll
         for (int n = 0; n < NWT; ++n)
@@ -1106,13 +1128,21 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
             if (it == 1) SN_TL(4);
         }
         SN_TL(6);
-        // weight-gradient partial of this workgroup
+        // weight-gradient partial of this workgroup: each 32 x 32 fragment transposed through LDS (the tile buffers are
+        // dead: every wave is past the loop's last barrier), 4 x 16-byte stores per lane instead of 16 dword stores
         float *P = g.part + (size_t)blockIdx.x * CO * CI;
+        float *Tw = lds + 4 * CI + (wave - 4) * (32 * 36);  // behind the dgrad waves' statistics area [RB][2][CI]
 #pragma unroll
         for (int n = 0; n < NWT; ++n) {
-            const int col = ((q0 + n) % NCB) * 32 + l31;
+            const int colb = ((q0 + n) % NCB) * 32;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) P[(size_t)(cob * 32 + frag_row(e, lane)) * CI + col] = accw[n][e];
+            for (int e = 0; e < 16; ++e) Tw[frag_row(e, lane) * 36 + l31] = accw[n][e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rt = 8 * i + (lane >> 3);
+                *reinterpret_cast<float4 *>(P + (size_t)(cob * 32 + rt) * CI + colb + (lane & 7) * 4) =
+                    *reinterpret_cast<const float4 *>(Tw + rt * 36 + (lane & 7) * 4);
+            }
         }
     }
     __syncthreads();
