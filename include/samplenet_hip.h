@@ -151,6 +151,13 @@ int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, in
 int sn_knn(int b, int n, int m, int k, const float *xyz1, int layout1, const float *xyz2, int layout2,
            int *idx, float *dist, sn_stream_t stream);
 
+/* Inference matching on the device (registration/src/sputils.py:7-41 nn_matching / _fps_from_given_pc / _unique, called
+ * from samplenet.py:119-141): idx (B,k) = nearest input point of every generated point; complete_fps != 0: first
+ * occurrences in order, then farthest-point completion to k points with numpy's float64 distances and first-maximum
+ * argmax -- exact index parity.  xyz: (B,N,3) or (B,3,N) by layout; out (B,k,3).  k <= 1024, N <= 8192. */
+int sn_nn_matching(int B, int N, int k, const float *xyz, int layout, const int *idx, int complete_fps, float *out,
+                   sn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * group_point gather / scatter-add.
  * (a) TF layout: points (b,n,c), idx (b,m,nsample) -> out (b,m,nsample,c).

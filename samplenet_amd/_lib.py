@@ -40,6 +40,7 @@ PROTOTYPES = {
     "sn_sampler_step_loss_backward": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp,
                                       _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
+    "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],
     "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_grouping_operation": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

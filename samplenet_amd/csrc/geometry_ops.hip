@@ -907,3 +907,136 @@ extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const f
     SN_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Inference matching on the device: sputils.nn_matching (registration/src/sputils.py:7-41).
+//   idx (B,k): nearest input point of every generated point.  complete_fps: keep the first occurrences in order
+//   (np.unique(return_index) + sort), then farthest-point-complete to k points of the SAME cloud -- numpy computes the
+//   distances in float64 ((p0 - points)**2).sum(1), argmax takes the first maximum; reproduced exactly: fp64
+//   ((dx*dx + dy*dy) + dz*dz) without contraction, ties -> lowest point index.
+// One workgroup of 1024 threads per cloud, PPT points per thread with their running minimum distance in registers; a
+// farthest-point step = wave max (DPP/shuffle) -> 16 wave results through LDS -> every thread reads the winner.
+// ------------------------------------------------------------------------------------------------
+template <int PPT>
+__global__ void __launch_bounds__(1024) nn_matching_kernel(int N, int K, int layout, int complete_fps,
+                                                           const float *__restrict__ xyz, const int *__restrict__ idx,
+                                                           float *__restrict__ out)
+{
+    constexpr int NT = 1024;
+    __shared__ int s_sel[1024];      // selected point indices, first-occurrence order then FPS picks (K <= 1024)
+    __shared__ int s_first[1024];    // 1 if idx[j] is a first occurrence
+    __shared__ double s_wmax[16];
+    __shared__ int s_warg[16];
+    __shared__ int s_t;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float *P = xyz + (size_t)b * 3 * N;
+    const int *id = idx + (size_t)b * K;
+    float *o = out + (size_t)b * K * 3;
+
+    if (!complete_fps) {
+        for (int j = t; j < K; j += NT) {
+            const int p = id[j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[j * 3 + c] = P[pt_off(layout, N, p, c)];
+        }
+        return;
+    }
+    // ---- unique, first-occurrence order
+    for (int j = t; j < K; j += NT) {
+        const int v = id[j];
+        int first = 1;
+        for (int q = 0; q < j; ++q) first &= (id[q] != v);
+        s_first[j] = first;
+    }
+    __syncthreads();
+    if (t == 0) {  // K is small (64): a sequential compaction keeps the order trivially right
+        int n = 0;
+        for (int j = 0; j < K; ++j)
+            if (s_first[j]) s_sel[n++] = id[j];
+        s_t = n;
+    }
+    __syncthreads();
+    const int nseed = s_t;
+    // ---- this thread's points and their distance to the seed set
+    double px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int p = min(t + i * NT, N - 1);
+        px[i] = (double)P[pt_off(layout, N, p, 0)];
+        py[i] = (double)P[pt_off(layout, N, p, 1)];
+        pz[i] = (double)P[pt_off(layout, N, p, 2)];
+        dist[i] = INFINITY;
+    }
+    for (int q = 0; q < nseed; ++q) {
+        const int sp = s_sel[q];
+        const double sx = (double)P[pt_off(layout, N, sp, 0)], sy = (double)P[pt_off(layout, N, sp, 1)],
+                     sz = (double)P[pt_off(layout, N, sp, 2)];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const double dx = sx - px[i], dy = sy - py[i], dz = sz - pz[i];
+            const double d = (dx * dx + dy * dy) + dz * dz;
+            dist[i] = d < dist[i] ? d : dist[i];
+        }
+    }
+    // ---- farthest-point completion
+    for (int j = nseed; j < K; ++j) {
+        double best = -1.0;
+        int arg = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = t + i * NT;
+            if (p < N && (dist[i] > best)) best = dist[i], arg = p;  // ascending p within the thread: first maximum
+        }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            const double ob = __shfl_xor(best, ofs);
+            const int oa = __shfl_xor(arg, ofs);
+            if (ob > best || (ob == best && oa < arg)) best = ob, arg = oa;
+        }
+        if (lane == 0) s_wmax[wave] = best, s_warg[wave] = arg;
+        __syncthreads();
+        best = s_wmax[0], arg = s_warg[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) {
+            const double ob = s_wmax[w];
+            const int oa = s_warg[w];
+            if (ob > best || (ob == best && oa < arg)) best = ob, arg = oa;
+        }
+        if (t == 0) s_sel[j] = arg;
+        const double sx = (double)P[pt_off(layout, N, arg, 0)], sy = (double)P[pt_off(layout, N, arg, 1)],
+                     sz = (double)P[pt_off(layout, N, arg, 2)];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const double dx = sx - px[i], dy = sy - py[i], dz = sz - pz[i];
+            const double d = (dx * dx + dy * dy) + dz * dz;
+            dist[i] = d < dist[i] ? d : dist[i];
+        }
+        __syncthreads();  // s_wmax / s_warg are rewritten by the next step
+    }
+    __syncthreads();
+    for (int j = t; j < K; j += NT) {
+        const int p = s_sel[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[j * 3 + c] = P[pt_off(layout, N, p, c)];
+    }
+}
+
+// xyz: (B,N,3) for SN_LAYOUT_BNC or (B,3,N) for SN_LAYOUT_BCN; idx (B,k) int32 in [0,N); out (B,k,3) fp32.
+extern "C" int sn_nn_matching(int B, int N, int k, const float *xyz, int layout, const int *idx, int complete_fps, float *out,
+                              sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 0 && N >= 1 && k >= 1, "bad size");
+    if (B == 0) return 0;
+    SN_REQUIRE(xyz && idx && out, "null pointer");
+    SN_REQUIRE(layout == SN_LAYOUT_BNC || layout == SN_LAYOUT_BCN, "bad layout");
+    if (k > 1024 || N > 8192) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_nn_matching: k <= 1024 and N <= 8192");
+    hipStream_t st = (hipStream_t)stream;
+#define SN_NM(PPT_) hipLaunchKernelGGL(nn_matching_kernel<PPT_>, dim3(B), dim3(1024), 0, st, N, k, layout, complete_fps, xyz, idx, out)
+    if (N <= 1024) SN_NM(1);
+    else if (N <= 2048) SN_NM(2);
+    else if (N <= 4096) SN_NM(4);
+    else SN_NM(8);
+#undef SN_NM
+    SN_LAUNCH_CHECK();
+    return 0;
+}

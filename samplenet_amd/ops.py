@@ -98,6 +98,23 @@ def knn(k, ref, query, ref_layout=BCN, query_layout=BCN, return_dist=True):
     return idx, dist
 
 
+def nn_matching(xyz, idx, k, complete_fps=True, layout=BNC):
+    """Device-side sputils.nn_matching (sputils.py:31-41): xyz (B,N,3) [BNC] or (B,3,N) [BCN], idx (B,k) -> (B,k,3) float32.
+    Same points as the numpy routine (float64 distances, first-maximum argmax, first-occurrence unique)."""
+    _need_gpu(xyz, idx)
+    xyz = _f32c(xyz.detach())
+    idx = idx.detach().reshape(idx.shape[0], -1).contiguous().int()
+    B = xyz.shape[0]
+    N = xyz.shape[1] if layout == BNC else xyz.shape[2]
+    if idx.shape[1] != k:
+        raise ValueError("nn_matching: idx must hold k indices per cloud")
+    out = torch.empty(B, k, 3, device=xyz.device, dtype=torch.float32)
+    with torch.cuda.device(xyz.device):
+        check(lib.sn_nn_matching(B, N, k, ptr(xyz), layout, ptr(idx), 1 if complete_fps else 0, ptr(out), _stream(xyz)),
+              "sn_nn_matching")
+    return out
+
+
 # --------------------------------------------------------------------------------------------- gather ops
 class GroupPointFunction(torch.autograd.Function):
     """points (B,n,c), idx (B,m,ns) int32 -> (B,m,ns,c)   [tf_grouping.py:46-61]"""

@@ -82,6 +82,7 @@ class SampleNet(nn.Module):
         self.output_shape = output_shape
 
         self._scan = None  # Chamfer products of the last training forward (see get_simplification_loss)
+        self.device_matching = True  # eval branch: nn_matching / FPS completion on the GPU (False: numpy, as the reference)
 
     # ------------------------------------------------------------------------------------------ MLP
     def _features(self, x, x_bnc=None):
@@ -130,10 +131,14 @@ class SampleNet(nn.Module):
                 proj = simp
         else:  # inference: nearest-neighbour matching + FPS completion (samplenet.py:119-141)
             idx, _ = ops.knn(1, x.contiguous(), y.contiguous(), ops.BCN, ops.BCN, return_dist=False)  # (B,M,1)
-            x_np = x.permute(0, 2, 1).cpu().detach().numpy()
-            idx_np = idx.squeeze(2).cpu().numpy()
-            z = sputils.nn_matching(x_np, idx_np, self.num_out_points, complete_fps=self.complete_fps)
-            match = torch.tensor(z, dtype=torch.float32).to(x.device)  # B x M x 3
+            if self.device_matching and self.num_out_points <= 1024 and x.shape[2] <= 8192:
+                # unique + farthest-point completion on the device (same points as sputils.nn_matching)
+                match = ops.nn_matching(x.contiguous(), idx, self.num_out_points, self.complete_fps, ops.BCN)
+            else:  # the reference's host round trip (samplenet.py:124-133)
+                x_np = x.permute(0, 2, 1).cpu().detach().numpy()
+                idx_np = idx.squeeze(2).cpu().numpy()
+                z = sputils.nn_matching(x_np, idx_np, self.num_out_points, complete_fps=self.complete_fps)
+                match = torch.tensor(z, dtype=torch.float32).to(x.device)  # B x M x 3
 
         if self.output_shape == "bnc":
             simp = simp.permute(0, 2, 1)

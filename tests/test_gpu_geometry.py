@@ -340,8 +340,49 @@ def test_fused_simplification_loss_channel_major_sample(shape):
     _, _, d1, i1, d2, i2 = ops.chamfer_forward_impl(ts.detach(), tr)
     la = ops.SimplificationLossFunction.apply(ts, tr, d1, i1, d2, i2, 1.5)
     lb = ops.SimplificationLossFunction.apply(tsT, tr, d1, i1, d2, i2, 1.5, ops.BCN)
-    assert float(la) == float(lb)
+    assert float(la.detach()) == float(lb.detach())
     (ga,) = torch.autograd.grad(la, [ts], torch.tensor(0.3, device="cuda"))
     (gb,) = torch.autograd.grad(lb, [tsT], torch.tensor(0.3, device="cuda"))
     assert gb.shape == tsT.shape
     assert torch.equal(ga.permute(0, 2, 1), gb)
+
+
+# ------------------------------------------------------------------------------------------ device-side inference matching (row f2)
+@pytest.mark.parametrize("B,N,k,dup", [(4, 1024, 64, 0.4), (3, 1500, 100, 0.7), (2, 100, 32, 0.9), (5, 4100, 64, 0.2),
+                                       (2, 64, 64, 0.0)])
+@pytest.mark.parametrize("layout", ["bnc", "bcn"])
+def test_nn_matching_device_equals_numpy(oracle, B, N, k, dup, layout):
+    """ops.nn_matching (sn_nn_matching: first-occurrence unique + farthest-point completion in one kernel per cloud)
+    returns exactly the points of the reference's numpy routine (sputils.py:7-41, restated in samplenet_amd/sputils.py
+    and oracle.nn_matching): float64 distances, first-maximum argmax -- for many duplicates, none, N not a multiple of
+    the workgroup size, and both cloud layouts; complete_fps=False is the plain gather."""
+    from samplenet_amd import ops, sputils
+
+    rng = np.random.default_rng(B * 1000 + N + k)
+    pc = (rng.random((B, N, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    idx = rng.integers(0, N, size=(B, k))
+    ndup = int(dup * k)
+    if ndup:
+        idx[:, -ndup:] = idx[:, :ndup]  # repeat earlier picks
+        idx = np.stack([rng.permutation(row) for row in idx])
+    ref = sputils.nn_matching(pc, idx, k, complete_fps=True)
+    ora = oracle.nn_matching(pc, idx.astype(np.int64), k, True)
+    assert np.array_equal(ref, ora)
+    x = dev(pc) if layout == "bnc" else dev(np.ascontiguousarray(pc.transpose(0, 2, 1)))
+    lay = ops.BNC if layout == "bnc" else ops.BCN
+    got = ops.nn_matching(x, torch.from_numpy(idx).cuda(), k, True, lay).cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == (B, k, 3)
+    assert np.array_equal(got.astype(np.float64), ref)
+    plain = ops.nn_matching(x, torch.from_numpy(idx).cuda(), k, False, lay).cpu().numpy()
+    assert np.array_equal(plain.astype(np.float64), sputils.nn_matching(pc, idx, k, complete_fps=False))
+
+
+def test_nn_matching_device_equals_reference_golden(golden):
+    """the golden vectors produced by the reference's own sputils.nn_matching (tests/golden/make_golden.py)."""
+    from samplenet_amd import ops
+
+    g = golden("nn_matching_reference.npz")
+    k = g["idx"].shape[1]
+    x, idx = dev(g["pc"].astype(np.float32)), torch.from_numpy(g["idx"]).cuda()
+    assert np.array_equal(ops.nn_matching(x, idx, k, True).cpu().numpy().astype(np.float64), g["out_fps"])
+    assert np.array_equal(ops.nn_matching(x, idx, k, False).cpu().numpy().astype(np.float64), g["out_nofps"])
