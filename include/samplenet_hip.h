@@ -261,6 +261,15 @@ int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, const float *co
                         const float *bias, float *z, float *stats, const float *gamma, const float *beta,
                         float eps, float momentum, float *running_mean, float *running_var,
                         long long *num_batches_tracked, float *coef, sn_stream_t stream);
+/* sn_layer_forward_bn of the last conv layer with the max-pool over the npts points of every cloud folded in (the forward
+ * epilogue leaves per-block maxima / minima, the BatchNorm finalisation picks): pooled / argsel / zsel as sn_pool_forward;
+ * pool_val / pool_idx: scratch of sn_linear_stats_blocks(R) * 2 * Co elements each.  SN_ERR_UNSUPPORTED unless R, npts, Ci,
+ * Co are multiples of 64. */
+int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
+                            const float *bias, float *z, float *stats, const float *gamma, const float *beta, float eps,
+                            float momentum, float *running_mean, float *running_var, long long *num_batches_tracked,
+                            float *coef, float *pool_val, int *pool_idx, float *pooled, int *argsel, float *zsel,
+                            sn_stream_t stream);
 int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                       const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                       const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,

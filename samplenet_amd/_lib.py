@@ -52,6 +52,8 @@ PROTOTYPES = {
     "sn_soft_project_backward": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_linear_stats_blocks": [_i],
     "sn_layer_forward_bn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sn_conv_forward_bn_pool": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp],
     "sn_layer_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, _vp],
     "sn_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

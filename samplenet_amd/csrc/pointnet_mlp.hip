@@ -422,7 +422,7 @@ __device__ __forceinline__ BnFwdIn bn_fwd_inputs(const BnFwd &bn, int c)
     if (bn.running_mean) in.rmean = bn.running_mean[c], in.rvar = bn.running_var[c];
     return in;
 }
-__device__ __forceinline__ void bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss, const BnFwdIn &in)
+__device__ __forceinline__ float2 bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss, const BnFwdIn &in)
 {
     const double mean = s / (double)bn.R;
     double var = ss / (double)bn.R - mean * mean;
@@ -438,6 +438,7 @@ __device__ __forceinline__ void bn_finalize_channel(const BnFwd &bn, int C, int 
         bn.running_mean[c] = (1.f - bn.momentum) * in.rmean + bn.momentum * (float)mean;
         bn.running_var[c] = (1.f - bn.momentum) * in.rvar + bn.momentum * (float)unbiased;
     }
+    return make_float2(sc, in.beta - (float)mean * sc);  // (scale, shift)
 }
 __device__ __forceinline__ void bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss)
 {
@@ -482,6 +483,11 @@ struct FwdArgs {
     float *z;
     float *stats;  // may be null
     BnFwd bn;      // small-R kernels only: finalise the BatchNorm in the epilogue (bn.coef != NULL)
+    // last conv layer (FULL tiles, 64-row blocks inside one cloud): per block and column the maximum and minimum of the
+    // pre-BN output with their first row -- the max-pool over the points is then finished by bn_finalize_pool_kernel
+    float *pool_val;  // [gridDim.x][2][Co]  (max, min)
+    int *pool_idx;    // [gridDim.x][2][Co]  row index inside the cloud
+    int pool_npts;
 };
 
 template <class T, bool FULL, int AMODE>
@@ -516,6 +522,9 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
 
     float s0[T::TN], s1[T::TN];
+    float pmax[T::TN], pmin[T::TN];
+    int imax[T::TN], imin[T::TN];
+    const bool pool = FULL && g.pool_val != nullptr;
     // FULL tiles leave as 16-byte stores: each 32 x 32 fragment is transposed through a per-wave LDS scratch (a dword
     // store per fragment element costs ~58 issue cycles per wave-instruction: 16 of them per fragment were issue-bound)
     float *Ts = lds + 2 * T::WR * T::BN + wave * (32 * 36);  // behind column_reduce2's area; staging buffers are dead
@@ -525,6 +534,7 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
         const float bias = biasv[j];
         s0[j] = 0.f, s1[j] = 0.f;
+        pmax[j] = -INFINITY, pmin[j] = INFINITY, imax[j] = 0, imin[j] = 0;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i) {
 #pragma unroll
@@ -538,6 +548,10 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
                         g.z[(size_t)row * Co + col] = v;
                     s0[j] += v;
                     s1[j] += v * v;
+                    if (FULL && pool) {  // rows ascend with e inside a lane: strict compares keep the first occurrence
+                        if (v > pmax[j]) pmax[j] = v, imax[j] = row;
+                        if (v < pmin[j]) pmin[j] = v, imin[j] = row;
+                    }
                 }
             }
             if (FULL) {
@@ -557,6 +571,42 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
     if (g.stats) {
         float *st = g.stats + (size_t)blockIdx.x * 2 * Co;
         column_reduce2<T>(s0, s1, lds, st, st + Co, col0, Co);
+    }
+    if (FULL && pool) {
+        // block maximum / minimum per column with the first row that attains it: halves of a wave, then the row waves
+        __syncthreads();
+        float *pv = lds;                                               // [WR][2][BN]
+        int *pi = reinterpret_cast<int *>(lds + T::WR * 2 * T::BN);    // [WR][2][BN]
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            const float om = __shfl_xor(pmax[j], 32), on = __shfl_xor(pmin[j], 32);
+            const int oim = __shfl_xor(imax[j], 32), oin = __shfl_xor(imin[j], 32);
+            if (om > pmax[j] || (om == pmax[j] && oim < imax[j])) pmax[j] = om, imax[j] = oim;
+            if (on < pmin[j] || (on == pmin[j] && oin < imin[j])) pmin[j] = on, imin[j] = oin;
+            if (lane < 32) {
+                const int c = (wc * T::TN + j) * 32 + lane;
+                pv[(wr * 2 + 0) * T::BN + c] = pmax[j], pv[(wr * 2 + 1) * T::BN + c] = pmin[j];
+                pi[(wr * 2 + 0) * T::BN + c] = imax[j], pi[(wr * 2 + 1) * T::BN + c] = imin[j];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < T::BN) {
+            const int c = threadIdx.x;
+            float vm = pv[c], vn = pv[T::BN + c];
+            int im = pi[c], in_ = pi[T::BN + c];
+#pragma unroll
+            for (int r = 1; r < T::WR; ++r) {  // row waves hold ascending rows: strict compares keep the first occurrence
+                const float a = pv[(r * 2 + 0) * T::BN + c], b2 = pv[(r * 2 + 1) * T::BN + c];
+                const int ia = pi[(r * 2 + 0) * T::BN + c], ib = pi[(r * 2 + 1) * T::BN + c];
+                if (a > vm || (a == vm && ia < im)) vm = a, im = ia;
+                if (b2 < vn || (b2 == vn && ib < in_)) vn = b2, in_ = ib;
+            }
+            const int cloud0 = (row0 / g.pool_npts) * g.pool_npts;
+            float *ov = g.pool_val + (size_t)blockIdx.x * 2 * Co + col0 + c;
+            int *oi = g.pool_idx + (size_t)blockIdx.x * 2 * Co + col0 + c;
+            ov[0] = vm, ov[Co] = vn;
+            oi[0] = im - cloud0, oi[Co] = in_ - cloud0;
+        }
     }
     SN_TL(5);
 }
@@ -1753,6 +1803,61 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(int nblk, int C, cons
     bn_finalize_channel(bn, C, c, s, ss, in);
 }
 
+// bn_finalize_kernel of the LAST conv layer + the max-pool over the points: the forward epilogue left, per 64-row block and
+// channel, the maximum and the minimum of the pre-BN output (pool_val / pool_idx); with the sign of the BatchNorm scale
+// known here, pooled[b][c] = relu(scale * (scale >= 0 ? max_n z : min_n z) + shift) is a pick over the cloud's blocks.
+// (Replaces a separate 16 MB pass over the layer's output.)
+__global__ void __launch_bounds__(1024) bn_finalize_pool_kernel(int nblk, int C, const float *__restrict__ stats, BnFwd bn, int B,
+                                                                int bpc, const float *__restrict__ pool_val,
+                                                                const int *__restrict__ pool_idx, float *__restrict__ pooled,
+                                                                int *__restrict__ argsel, float *__restrict__ zsel)
+{
+    __shared__ float s_sc[kChan], s_sh[kChan];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
+    double s, ss;
+    const int cl = threadIdx.x & (kChan - 1);
+    const int c = blockIdx.x * kChan + cl;
+    BnFwdIn in{};
+    if (threadIdx.x < kChan && c < C) in = bn_fwd_inputs(bn, c);  // in flight during the reduction
+    if (partial_sums(nblk, C, stats, blockIdx.x, s, ss)) {
+        const float2 cf = bn_finalize_channel(bn, C, c, s, ss, in);
+        s_sc[cl] = cf.x, s_sh[cl] = cf.y;
+    }
+    __syncthreads();
+    if (c >= C) return;
+    const float sc = s_sc[cl], sh = s_sh[cl];
+    const int sel = sc >= 0.f ? 0 : 1;  // max or min
+    // thread -> (channel cl, cloud slot, quarter of the cloud's blocks): the quarter's partials are loaded together, the four
+    // quarters (lane bits 3 and 4) are combined by shuffles; blocks hold ascending rows, so on ties the lower index wins
+    const int quarter = (threadIdx.x >> 3) & 3, bslot = threadIdx.x >> 5;
+    const int per = (bpc + 3) / 4, q0 = quarter * per, q1 = min(bpc, q0 + per);
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int b = b0 + bslot;
+        float best = sel == 0 ? -INFINITY : INFINITY;
+        int arg = 0x7fffffff;
+        if (b < B) {
+#pragma unroll 4
+            for (int q = q0; q < q1; ++q) {
+                const size_t o = ((size_t)(b * bpc + q) * 2 + sel) * C + c;
+                const float v = pool_val[o];
+                const int i = pool_idx[o];
+                if (sel == 0 ? (v > best || (v == best && i < arg)) : (v < best || (v == best && i < arg))) best = v, arg = i;
+            }
+        }
+#pragma unroll
+        for (int ofs = 8; ofs <= 16; ofs <<= 1) {
+            const float ob = __shfl_xor(best, ofs);
+            const int oa = __shfl_xor(arg, ofs);
+            if (sel == 0 ? (ob > best || (ob == best && oa < arg)) : (ob < best || (ob == best && oa < arg))) best = ob, arg = oa;
+        }
+        if (quarter == 0 && b < B) {
+            pooled[(size_t)b * C + c] = fmaxf(fmaf(best, sc, sh), 0.f);
+            argsel[(size_t)b * C + c] = arg;
+            zsel[(size_t)b * C + c] = best;
+        }
+    }
+}
+
 // eval: coefficients from the running statistics
 __global__ void bn_eval_coef_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                     const float *__restrict__ running_mean, const float *__restrict__ running_var,
@@ -2045,6 +2150,35 @@ extern "C" int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, cons
         launch_fwd<ACT_NONE>(g, st);
     if (R > 32)
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((Co + kChan - 1) / kChan), dim3(1024), 0, st, sn_linear_stats_blocks(R), Co, stats, bn);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// sn_layer_forward_bn for the last conv layer, with the max-pool over the npts points of every cloud folded in:
+// pooled / argsel / zsel as sn_pool_forward.  pool_val (floats) / pool_idx (ints): scratch of sn_linear_stats_blocks(R)*2*Co
+// elements each.  Needs R % 64 == 0, npts % 64 == 0, Co % 64 == 0, Ci % 64 == 0 (else SN_ERR_UNSUPPORTED: call
+// sn_layer_forward_bn + sn_pool_forward).
+extern "C" int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
+                                       const float *bias, float *z, float *stats, const float *gamma, const float *beta,
+                                       float eps, float momentum, float *running_mean, float *running_var,
+                                       long long *num_batches_tracked, float *coef, float *pool_val, int *pool_idx,
+                                       float *pooled, int *argsel, float *zsel, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1 && npts >= 1, "bad size");
+    SN_REQUIRE(ain && W && z && stats && gamma && beta && coef && pool_val && pool_idx && pooled && argsel && zsel && coef_prev,
+               "null pointer");
+    if (R <= 64 || R % 64 || npts % 64 || R % npts || Co % 64 || Ci % 64)
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_forward_bn_pool: needs 64-aligned rows / points / channels");
+    FwdArgs g{};
+    g.a = make_act(ain, coef_prev, R, Ci);
+    g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+    g.bias = bias, g.z = z, g.stats = stats;
+    g.pool_val = pool_val, g.pool_idx = pool_idx, g.pool_npts = npts;
+    const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
+    hipStream_t st = (hipStream_t)stream;
+    launch_fwd<ACT_BN_RELU>(g, st);
+    hipLaunchKernelGGL(bn_finalize_pool_kernel, dim3((Co + kChan - 1) / kChan), dim3(1024), 0, st, sn_linear_stats_blocks(R), Co,
+                       stats, bn, R / npts, npts / 64, pool_val, pool_idx, pooled, argsel, zsel);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -65,6 +65,25 @@ def _layer_fwd_bn(R, L, a_in, coef_prev):
     return z, coef
 
 
+def _layer_fwd_bn_pool(R, npts, L, a_in, coef_prev, pooled, argsel, zsel):
+    """_layer_fwd_bn of the last conv layer + the max-pool over the points (sn_conv_forward_bn_pool)."""
+    bn = L.bn
+    z = _empty((R, L.Co), a_in)
+    coef = _empty((4, L.Co), a_in)
+    nblk = lib.sn_linear_stats_blocks(R)
+    stats = _empty((nblk, 2, L.Co), a_in)
+    pool_val = _empty((nblk, 2, L.Co), a_in)
+    pool_idx = _empty((nblk, 2, L.Co), a_in, torch.int32)
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    upd = bn.track_running_stats
+    check(lib.sn_conv_forward_bn_pool(R, L.Ci, L.Co, npts, ptr(a_in), ptr(coef_prev), ptr(L.W), ptr(L.b), ptr(z), ptr(stats),
+                                      ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(mom),
+                                      ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None,
+                                      ptr(bn.num_batches_tracked) if upd else None, ptr(coef), ptr(pool_val), ptr(pool_idx),
+                                      ptr(pooled), ptr(argsel), ptr(zsel), _st(a_in)), "sn_conv_forward_bn_pool")
+    return z, coef
+
+
 def _bn_coef(L, R, stats, nblk, training):
     bn = L.bn
     C = L.Co
@@ -89,8 +108,16 @@ def forward_impl(net, x_bnc, training):
     saved = {"x": x_bnc, "B": B, "N": N, "zc": [], "cc": [], "zf": [], "cf": []}
     use_batch_stats = training
     a_in, coef_prev = x_bnc.view(R, 3), None
-    for L in convs:
-        if training:
+    C5 = convs[-1].Co
+    pooled = _empty((B, C5), x_bnc)
+    argsel = _empty((B, C5), x_bnc, torch.int32)
+    zsel = _empty((B, C5), x_bnc)
+    # last conv layer: the max-pool is folded into its epilogue + BatchNorm finalisation when the shapes are 64-aligned
+    fuse_pool = training and R > 64 and N % 64 == 0 and C5 % 64 == 0 and convs[-1].Ci % 64 == 0 and FUSE_POOL
+    for li, L in enumerate(convs):
+        if training and fuse_pool and li == len(convs) - 1:
+            z, coef = _layer_fwd_bn_pool(R, N, L, a_in, coef_prev, pooled, argsel, zsel)
+        elif training:
             z, coef = _layer_fwd_bn(R, L, a_in, coef_prev)
         else:
             z, stats, nblk = _linear_fwd(R, L, a_in, coef_prev, use_batch_stats)
@@ -98,12 +125,9 @@ def forward_impl(net, x_bnc, training):
         saved["zc"].append(z)
         saved["cc"].append(coef)
         a_in, coef_prev = z, coef
-    C5 = convs[-1].Co
-    pooled = _empty((B, C5), x_bnc)
-    argsel = _empty((B, C5), x_bnc, torch.int32)
-    zsel = _empty((B, C5), x_bnc)
-    check(lib.sn_pool_forward(B, N, C5, ptr(a_in), ptr(coef_prev), ptr(pooled), ptr(argsel), ptr(zsel), _st(x_bnc)),
-          "sn_pool_forward")
+    if not fuse_pool:
+        check(lib.sn_pool_forward(B, N, C5, ptr(a_in), ptr(coef_prev), ptr(pooled), ptr(argsel), ptr(zsel), _st(x_bnc)),
+              "sn_pool_forward")
     saved.update(pooled=pooled, argsel=argsel, zsel=zsel)
     a_in, coef_prev = pooled, None
     for L in fcs[:-1]:
@@ -130,6 +154,7 @@ _SIDE = {}
 # measured on MI355X / ROCm 7.2: inside a replayed hipGraph the fork/join edges cost more than the overlap buys
 # (0.73 vs 0.60 ms per step at B = 32), so the side stream is opt-in
 USE_SIDE_STREAM = os.environ.get("SAMPLENET_AMD_WGRAD_SIDE_STREAM", "0") != "0"
+FUSE_POOL = os.environ.get("SAMPLENET_AMD_FUSE_POOL", "1") != "0"  # A/B switch for the pooling fused into the last conv layer
 
 
 def _side_stream(dev):

@@ -176,3 +176,36 @@ def test_fused_conv_backward_exact_small_integers(shape, mode, B, npts):
     assert torch.equal(dW.double(), ref_dW)
     assert torch.equal(stats.double().sum(0)[0], ref_dyp.sum(0))
     assert torch.equal(stats.double().sum(0)[1], (ref_dyp * zprev.double()).sum(0))
+
+
+@pytest.mark.parametrize("B,N", [(32, 1024), (5, 320), (2, 64)])
+def test_fused_pooling_equals_separate_pass(B, N):
+    """The max-pool folded into the last conv layer (per-block max / min in the GEMM epilogue, pick in the BatchNorm
+    finalisation: sn_conv_forward_bn_pool) returns bit-for-bit what the separate pass over the layer's output does
+    (sn_layer_forward_bn + sn_pool_forward): pooled values, the selected row of every (cloud, channel) -- first row on
+    ties -- its pre-BN value, the BatchNorm coefficients and the running statistics."""
+    import copy
+
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(B * 7 + N)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    with torch.no_grad():
+        net_a.bn5.weight[::3] *= -1.0  # negative BatchNorm scales: the pool must pick the minimum there
+    net_b = copy.deepcopy(net_a)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    x[:, N // 2:N // 2 + 8] = x[:, :8]  # duplicated points: exact ties in every channel
+    old = pointnet.FUSE_POOL
+    try:
+        pointnet.FUSE_POOL = True
+        ya, sa = pointnet.forward_impl(net_a, x.contiguous(), True)
+        pointnet.FUSE_POOL = False
+        yb, sb = pointnet.forward_impl(net_b, x.contiguous(), True)
+    finally:
+        pointnet.FUSE_POOL = old
+    for k in ("pooled", "argsel", "zsel"):
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(sa["cc"][4], sb["cc"][4])
+    assert torch.equal(ya, yb)
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), n
