@@ -616,20 +616,22 @@ __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float
                                                          float *__restrict__ grad_T, const float *__restrict__ gsigma_direct,
                                                          float direct_scale)
 {
-    __shared__ float red[256];
+    // fixed-order reduction: strided per-thread sums, xor tree inside each wave, the four wave totals in order
+    __shared__ float red[4];
+    const float T = *temperature;
+    const float direct = gsigma_direct ? *gsigma_direct * direct_scale : 0.f;  // in flight during the reduction
     float acc = 0.f;
     for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
-    red[threadIdx.x] = acc;
-    for (int s = 128; s > 0; s >>= 1) {
-        __syncthreads();
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const float T = *temperature, t2 = T * T;
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        const float t2 = T * T;
         const float w = t2 > min_sigma ? 1.f : (t2 == min_sigma ? 0.5f : 0.f);
         // + d loss / d sigma of a term that depends on sigma directly (lmbda * sigma in the sampler step's loss)
-        const float direct = gsigma_direct ? *gsigma_direct * direct_scale : 0.f;
-        grad_T[0] = red[0] * w * 2.0f * T + direct * w * 2.0f * T;
+        grad_T[0] = tot * w * 2.0f * T + direct * w * 2.0f * T;
     }
 }
 

@@ -16,15 +16,22 @@ import torch
 
 class SamplerTrainStep:
     def __init__(self, net, example_x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=None, reducer=None,
-                 use_graph=True, warmup=3, fused_loss=True):
+                 use_graph=True, warmup=3, fused_loss=True, input_ring=None):
         self.net, self.reducer = net, reducer
         self.alpha, self.lmbda, self.gamma, self.delta = alpha, lmbda, gamma, delta
         self.fused_loss = fused_loss  # False: compose the loss op by op through the module's own methods (A/B, tests)
         self.task_loss = task_loss  # None: the benchmark's stand-in mean(proj), fused with the loss weighting
-        self.x = example_x.clone()
+        # input_ring: optional list of device tensors (shape of example_x) that the caller fills IN PLACE -- e.g. the
+        # host-to-device targets of its data loader.  One graph is captured per entry (all sharing one memory pool) and
+        # replay(i) runs the step on entry i without the copy into a static buffer that __call__(x) needs.
+        self.ring = list(input_ring) if input_ring is not None else None
+        if self.ring is not None and use_graph and reducer is None:
+            raise ValueError("input_ring needs a gradient sink (FlatGradAllReducer): the graphs must write one set of .grad tensors")
+        self.x = example_x.clone() if self.ring is None else self.ring[0]
         self._one = torch.ones((), device=example_x.device, dtype=torch.float32)
         self.graph = None
         self.loss = None
+        self._ring_graphs, self._ring_loss = [], []
         if use_graph:
             self._capture(warmup)
 
@@ -86,13 +93,41 @@ class SamplerTrainStep:
                     for p in self.net.parameters():
                         p.grad = None
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        if self.ring is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._step()
+            return
+        pool = torch.cuda.graph_pool_handle()
+        for buf in self.ring:
+            if buf.shape != self.ring[0].shape or buf.device != self.ring[0].device or not buf.is_contiguous():
+                raise ValueError("input_ring entries must be contiguous tensors of one shape on one device")
+            self.x = buf
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                loss = self._step()
+            self._ring_graphs.append(g)
+            self._ring_loss.append(loss)
+        self.graph = self._ring_graphs[0]
+        self.loss = self._ring_loss[0]
+
+    def replay(self, i):
+        """One step on ring entry i (whatever the caller wrote into input_ring[i]); returns the (static) loss tensor."""
+        if self._ring_graphs:
+            self._ring_graphs[i].replay()
+            self.loss = self._ring_loss[i]
+        else:
+            self.x = self.ring[i]
             self.loss = self._step()
+        if self.reducer is not None:
+            self.reducer.reduce()
+        return self.loss
 
     def __call__(self, x):
         """Runs one step on batch x (same shape as example_x); returns the (static) loss tensor.
         Gradients are in p.grad afterwards (cross-rank averaged when a reducer is attached)."""
+        if self.ring is not None:
+            raise RuntimeError("this step was built on an input ring: fill input_ring[i] in place and call replay(i)")
         self.x.copy_(x, non_blocking=True)
         if self.graph is not None:
             self.graph.replay()

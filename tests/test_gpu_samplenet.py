@@ -203,3 +203,29 @@ def test_single_node_step_loss_equals_composition(B, N, M, K):
     # BatchNorm running statistics moved identically
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         assert torch.equal(ba, bb), n
+
+
+def test_input_ring_replay_equals_copy_in():
+    """SamplerTrainStep built on an input ring (one captured graph per resident batch, no staging copy) gives the same
+    loss and gradients per batch as the single-graph step that copies the batch into its static buffer."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(5)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    ring = [torch.rand(8, 1024, 3, device="cuda") - 0.5 for _ in range(3)]
+    red_a, red_b = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b)
+    step_a = SamplerTrainStep(net_a, ring[0], reducer=red_a, input_ring=ring)
+    step_b = SamplerTrainStep(net_b, ring[0], reducer=red_b)
+    for i in (0, 1, 2, 1, 0):
+        la = step_a.replay(i).clone()
+        ga = red_a.flat.clone()
+        lb = step_b(ring[i]).clone()
+        assert torch.equal(la, lb) and torch.equal(ga, red_b.flat), i
+    ring[1].mul_(0.5)  # the caller rewrites a ring entry in place: the next replay sees it
+    la, lb = step_a.replay(1).clone(), step_b(ring[1]).clone()
+    assert torch.equal(la, lb) and torch.equal(red_a.flat, red_b.flat)
