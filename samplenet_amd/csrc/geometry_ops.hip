@@ -8,6 +8,7 @@
 //                         propagate / project_and_propagate actions (soft_projection.py:101-136)
 //   group_point*, grouping_operation*   tf_grouping_g.cu:40-78 and the pointnet2 layout twin
 #include <algorithm>
+#include <cstdlib>
 
 #include "sn_common.h"
 
@@ -166,6 +167,15 @@ __global__ void __launch_bounds__(256) chamfer_bwd_reg_kernel(int nt, int ns, co
         if (lane < 3) gradT[o0 + lane * os] = lane == 0 ? ax : (lane == 1 ? ay : az);
     }
 }
+
+// workgroups (of 4 waves) the targets of all clouds are spread over: every wave loads the whole source set into registers
+// before its first target, so fewer, longer-lived waves amortise that load (1024 groups = one target per wave at the
+// sampler's sizes: measured 9 us; SN_CHAMFER_BWD_GROUPS overrides for experiments)
+static const int kChamferBwdGroups = [] {
+    const char *e = getenv("SN_CHAMFER_BWD_GROUPS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 1024;  // swept 64..1024 at B = 32: 1024 is fastest
+}();
 
 static void launch_chamfer_bwd(int b, int ysplit, int nt, int ns, const float *T, const float *S, const float *gT,
                                const int *idxT, const float *gS, const int *idxS, float *gradT, int own_first,
@@ -457,7 +467,7 @@ extern "C" int sn_chamfer_backward(int b, int n, const float *xyz1, int m, const
     if (b == 0 || n == 0 || m == 0) return 0;
     SN_REQUIRE(xyz1 && xyz2 && grad_dist1 && grad_dist2 && idx1 && idx2, "null input");
     hipStream_t st = (hipStream_t)stream;
-    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (1024 + b - 1) / b)); };
+    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (kChamferBwdGroups + b - 1) / b)); };
     const ImplicitGrad none{};
     if (grad_xyz1) launch_chamfer_bwd(b, ysplit(n), n, m, xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, 1, none, st);
     if (grad_xyz2) launch_chamfer_bwd(b, ysplit(m), m, n, xyz2, xyz1, grad_dist2, idx2, grad_dist1, idx1, grad_xyz2, 0, none, st);
@@ -533,7 +543,7 @@ extern "C" int sn_simplification_loss_backward(int B, int n1, const float *xyz1,
     SN_REQUIRE(B >= 1 && n1 >= 1 && n2 >= 1, "bad size");
     SN_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && argmax1 && grad_loss, "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (1024 + B - 1) / B)); };
+    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (kChamferBwdGroups + B - 1) / B)); };
     const float c1 = 1.0f / ((float)B * (float)n1), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)n2);
     if (grad_xyz1) {
         ImplicitGrad ig{grad_loss, argmax1, nullptr, c1, cm, c2, 0.f};
@@ -889,7 +899,7 @@ extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const f
                "null pointer");
     hipStream_t st = (hipStream_t)stream;
     // 1. alpha * d L_simp / d Q   (targets = Q, channel-major; sources = P)
-    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (1024 + B - 1) / B)); };
+    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (kChamferBwdGroups + B - 1) / B)); };
     // same roundings as the op-by-op route: (alpha * g) first, then the per-term coefficients
     const float c1 = 1.0f / ((float)B * (float)M), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)N);
     ImplicitGrad ig{grad_loss, argmax1, nullptr, c1, cm, c2, 0.f, alpha};

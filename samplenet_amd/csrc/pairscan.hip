@@ -24,6 +24,7 @@
 // Multi-chunk mode (N > 64*PPL_MAX): the wave walks the cloud in chunks keeping its running top-K
 // in LDS; column minima are then produced by a second launch with the roles swapped.
 #include <algorithm>
+#include <cstdlib>
 
 #include "sn_common.h"
 
@@ -381,7 +382,7 @@ int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finaliz
             if (!ws || ws_bytes < need) ysplit = 1;
         }
         const int qpb = (M + ysplit - 1) / ysplit;
-        const int waves = std::max(1, std::min(maxw, qpb));
+        const int waves = std::max(1, std::min(maxw, qpb));  // one query per wave at the sampler's sizes (swept 2 / 4 / 8: 8 is fastest)
         a.colmin_ws = (colmin && ysplit > 1) ? (sn_u64 *)ws : nullptr;
         if (used_split) *used_split = ysplit;
 #define SN_PS(PPL_)                                                                      \
