@@ -216,6 +216,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 was busy with the roofline timing loops: leave together
         dist.destroy_process_group()
 
 

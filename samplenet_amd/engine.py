@@ -32,6 +32,8 @@ class SamplerTrainStep:
         self.graph = None
         self.loss = None
         self._ring_graphs, self._ring_loss = [], []
+        if use_graph and reducer is not None:
+            reducer.disable_overlap()  # the graph replays backward without Python: one all-reduce after the replay
         if use_graph:
             self._capture(warmup)
 
@@ -95,7 +97,7 @@ class SamplerTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         if self.ring is None:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = self._step()
             return
         pool = torch.cuda.graph_pool_handle()
@@ -104,7 +106,8 @@ class SamplerTrainStep:
                 raise ValueError("input_ring entries must be contiguous tensors of one shape on one device")
             self.x = buf
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            # thread_local: API calls of other threads (the RCCL watchdog polling events) must not invalidate the capture
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 loss = self._step()
             self._ring_graphs.append(g)
             self._ring_loss.append(loss)

@@ -58,6 +58,16 @@ class FlatGradAllReducer:
         if self.overlap:
             module._after_fc_grads = self._early_ready
 
+    def disable_overlap(self):
+        """Single collective per step (what a captured whole-step graph needs: the early all-reduce is issued from inside
+        backward, which the graph replays without Python)."""
+        if self._early_work is not None:
+            self._early_work.wait()
+            self._early_work = None
+        self.overlap = False
+        if getattr(self.module, "_after_fc_grads", None) is not None:
+            self.module._after_fc_grads = None
+
     def zero_grad(self):
         for v in self._autograd_slices:
             v.zero_()
