@@ -333,7 +333,7 @@ class PointNetMLPFunction(torch.autograd.Function):
         sink = getattr(net, "_grad_sink", None)
         with torch.cuda.device(grad_y.device):
             grads = backward_impl(net, ctx.saved, grad_y, sink, getattr(net, "_after_fc_grads", None))
-        ctx.saved = None
+        # (ctx.saved stays: a retained graph may run backward again)
         # gradients written straight into a sink are not handed to autograd (nothing left to accumulate)
         return (None, None, None) + tuple(None if (sink is not None and n in sink) else grads[n] for n in PARAM_ORDER)
 

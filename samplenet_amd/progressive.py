@@ -1,0 +1,65 @@
+"""Progressive SampleNet for the PyTorch surface.
+
+The reference ships the progressive sampler only as TF graphs (classification/train_samplenet_progressive.py:157-234,
+reconstruction/src/samplenet_progressive_pointnet_ae.py:77-100,165-173); its semantics:
+  * the sampler emits the LARGEST set once (MAX_NUM_OUT_POINTS points), the whole set is soft-projected once;
+  * every nested size s in {min, 2 min, ..., max} uses the PREFIX [:s] of the simplified / projected points:
+    the task network is fed projected[:, :s], the simplification loss of size s is taken on simplified[:, :s]
+    with pc_size = s (its delta term);
+  * classification: total simplification loss = SUM over sizes; auto-encoder variant: MEAN over sizes.
+This module is that layer over the HIP hot path: SampleNetProgressive is a SampleNet whose losses take a list of sizes.
+The query->point products (dist / idx per simplified point) do not depend on the prefix, so they come from forward()'s
+pair scan; the point->query side of every prefix is one Chamfer scan on the prefix (sizes are few).
+"""
+import torch
+
+from . import ops
+from .samplenet import SampleNet
+
+
+def progressive_sizes(min_points, max_points):
+    """{min, 2 min, 4 min, ... <= max} as classification/train_samplenet_progressive.py:181-199 builds it."""
+    if min_points < 1 or max_points < min_points:
+        raise ValueError("need 1 <= min_points <= max_points")
+    sizes, b = [], min_points
+    while b <= max_points:
+        sizes.append(b)
+        b *= 2
+    return sizes
+
+
+class SampleNetProgressive(SampleNet):
+    """SampleNet(num_out_points = the largest size) + prefix-wise losses.
+
+    forward(x) -> (simp, proj) exactly as SampleNet; slice both with [:, :s] (output_shape 'bnc') for the task network.
+    """
+
+    def __init__(self, sizes, bottleneck_size, group_size, **kw):
+        sizes = sorted(int(s) for s in sizes)
+        if not sizes or sizes[0] < 1 or len(set(sizes)) != len(sizes):
+            raise ValueError("sizes must be distinct positive integers")
+        super().__init__(sizes[-1], bottleneck_size, group_size, **kw)
+        self.sizes = sizes
+        self.name = "samplenet_progressive"
+
+    def prefix(self, pc, size):
+        """The first `size` points of a (B,M,3) ['bnc'] or (B,3,M) ['bcn'] cloud in the module's output layout."""
+        return pc[:, :size, :] if self.output_shape == "bnc" else pc[:, :, :size]
+
+    def get_progressive_simplification_loss(self, ref_pc, samp_pc, gamma=1, delta=0, reduction="sum"):
+        """sum (classification) or mean (auto-encoder) over the sizes of
+        get_simplification_loss(ref_pc, samp_pc[:, :s], s, gamma, delta)      [ref_pc, samp_pc: (B,N,3), (B,M,3)]"""
+        if reduction not in ("sum", "mean"):
+            raise ValueError("reduction must be 'sum' or 'mean'")
+        if self.skip_projection or not self.training:
+            return torch.tensor(0).to(ref_pc)
+        total = None
+        for s in self.sizes:
+            sl = samp_pc[:, :s, :].contiguous()
+            if s == samp_pc.shape[1]:
+                term = self.get_simplification_loss(ref_pc, samp_pc, s, gamma, delta)  # reuses forward()'s scan
+            else:
+                _, _, d1, i1, d2, i2 = ops.chamfer_forward_impl(sl.detach(), ref_pc.detach())
+                term = ops.SimplificationLossFunction.apply(sl, ref_pc, d1, i1, d2, i2, gamma + delta * s)
+            total = term if total is None else total + term
+        return total / len(self.sizes) if reduction == "mean" else total

@@ -229,3 +229,43 @@ def test_input_ring_replay_equals_copy_in():
     ring[1].mul_(0.5)  # the caller rewrites a ring entry in place: the next replay sees it
     la, lb = step_a.replay(1).clone(), step_b(ring[1]).clone()
     assert torch.equal(la, lb) and torch.equal(red_a.flat, red_b.flat)
+
+
+@pytest.mark.parametrize("reduction", ["sum", "mean"])
+def test_progressive_sampler_losses(oracle, reduction):
+    """SampleNetProgressive (row f3; semantics of classification/train_samplenet_progressive.py:157-234 and
+    reconstruction/src/samplenet_progressive_pointnet_ae.py:77-100,165-173): the loss over the nested prefixes equals the
+    op-by-op composition on the oracle's Chamfer distances, and its gradient equals autograd through the plain
+    ChamferDistance composition."""
+    from samplenet_amd import ChamferDistance, SampleNetProgressive, progressive_sizes
+
+    sizes = progressive_sizes(8, 64)
+    assert sizes == [8, 16, 32, 64]
+    torch.manual_seed(11)
+    net = SampleNetProgressive(sizes, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    x = torch.rand(6, 512, 3, device="cuda") - 0.5
+    simp, proj = net(x)
+    assert simp.shape == (6, 64, 3) and net.prefix(proj, 16).shape == (6, 16, 3)
+    gamma, delta = 1.0, 0.02
+    loss = net.get_progressive_simplification_loss(x, simp, gamma, delta, reduction)
+    # gradients are compared at the FC head's last layer (the full-size term hangs off the head's (B,3,M) output directly,
+    # see SampleNet.get_simplification_loss, so it does not pass through `simp`)
+    params = [net.fc4.weight, net.fc4.bias]
+    g = torch.autograd.grad(loss, params, retain_graph=True)
+    # reference composition (samplenet.py:171-181 per prefix) through ChamferDistance + autograd
+    cd = ChamferDistance()
+    tot = 0.0
+    ref = 0.0
+    for s in sizes:
+        c1, c2 = cd(simp[:, :s, :].contiguous(), x)
+        tot = tot + c1.mean() + c1.max(1)[0].mean() + (gamma + delta * s) * c2.mean()
+        od1, _, od2, _ = oracle.chamfer_forward(simp.detach()[:, :s, :].contiguous().cpu().numpy(), x.cpu().numpy())
+        ref += od1.mean(dtype=np.float64) + od1.max(1).mean(dtype=np.float64) + (gamma + delta * s) * od2.mean(dtype=np.float64)
+    if reduction == "mean":
+        tot, ref = tot / len(sizes), ref / len(sizes)
+    g2 = torch.autograd.grad(tot, params)
+    assert abs(float(loss.detach()) - ref) <= 1e-6 * max(1.0, abs(ref))
+    for a, b in zip(g, g2):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-8)
+    net.eval()
+    assert float(net.get_progressive_simplification_loss(x, simp.detach())) == 0.0
