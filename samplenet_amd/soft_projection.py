@@ -53,7 +53,11 @@ class SoftProjection(nn.Module):
     # -- fused hot path -------------------------------------------------------------------------
     def project(self, point_cloud, query_cloud, hard=False):
         if hard:
-            raise NotImplementedError
+            # classification/soft_projection.py:73-76: the softmax weights become one_hot(argmax) -> every query moves onto
+            # its nearest input point (first of the K neighbours on ties); the registration reference raises
+            # NotImplementedError here (soft_projection.py:144-145).  No gradient reaches the query (one_hot has none).
+            idx, _ = ops.knn(1, point_cloud, query_cloud, ops.BCN, ops.BCN, return_dist=False)  # (B,M,1)
+            return ops.grouping_operation(point_cloud.contiguous(), idx).squeeze(3)  # (B,3,M)
         proj, _idx = ops.SoftProjectFunction.apply(point_cloud, query_cloud, self._temperature, self._min_sigma_f,
                                                    self._group_size, False)
         return proj

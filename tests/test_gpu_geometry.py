@@ -386,3 +386,20 @@ def test_nn_matching_device_equals_reference_golden(golden):
     x, idx = dev(g["pc"].astype(np.float32)), torch.from_numpy(g["idx"]).cuda()
     assert np.array_equal(ops.nn_matching(x, idx, k, True).cpu().numpy().astype(np.float64), g["out_fps"])
     assert np.array_equal(ops.nn_matching(x, idx, k, False).cpu().numpy().astype(np.float64), g["out_nofps"])
+
+
+def test_hard_projection_is_nearest_input_point(oracle):
+    """SoftProjection.project(hard=True) (row f4; TF semantics classification/soft_projection.py:73-76: one_hot(argmax) of the
+    softmax weights): every query lands on its nearest input point -- bit-exact with the oracle's 1-NN gather."""
+    from samplenet_amd import SoftProjection
+
+    rng = np.random.default_rng(3)
+    pc = (rng.random((4, 700, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    q = (rng.random((4, 50, 3), dtype=np.float32) - 0.5).astype(np.float32)
+    sp = SoftProjection(8, initial_temperature=0.3).cuda()
+    P = dev(np.ascontiguousarray(pc.transpose(0, 2, 1)))
+    Q = dev(np.ascontiguousarray(q.transpose(0, 2, 1)))
+    out = sp.project(P, Q, hard=True)
+    _, idx = oracle.knn(1, pc, q)
+    want = np.take_along_axis(pc, idx[:, :, :1].astype(np.int64).repeat(3, axis=2), axis=1)  # (B,M,3)
+    assert np.array_equal(out.permute(0, 2, 1).cpu().numpy(), want)
