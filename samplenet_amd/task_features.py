@@ -1,0 +1,130 @@
+"""PointNetFeatures of the registration task network on the HIP MLP kernels.
+
+Drop-in for `registration/models/pcrnet.py:8-41` (same constructor, parameter names conv1..conv5 -> state_dict
+compatible): five 1x1 convolutions 3 -> 64 -> 64 -> 64 -> 128 -> bottleneck with ReLU and NO BatchNorm, then the max over
+the points.  It is the other half of every real sampler training step: PCRNet is frozen, but the gradient of the task
+loss reaches the sampler THROUGH it, so forward and the data gradient matter (weight gradients are produced too, for
+training the task network itself).
+
+Built on the same C-ABI entries as the sampler's own feature extractor (samplenet_amd/pointnet.py): the fused
+`act = relu(scale * z + shift)` operand mode with scale = 1, shift = 0 is exactly ReLU (fma(z, 1, 0) == z), and the
+pooling / sparse last-layer gradient use the BatchNorm-free coefficients k = (1, 0, 0).
+"""
+import torch
+import torch.nn as nn
+
+from ._lib import check, lib, ptr
+
+_DZ_PLAIN, _DZ_POOL = 0, 2
+
+
+def _st(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ident(c, like):
+    coef = torch.zeros(4, c, device=like.device, dtype=torch.float32)
+    coef[0].fill_(1.0)  # scale = 1, shift = 0 (rows 2, 3 unused)
+    return coef
+
+
+class _FeaturesFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_bnc, *wb):
+        B, N, _ = x_bnc.shape
+        R = B * N
+        Ws, bs = wb[0::2], wb[1::2]
+        zs, a_in, coef_prev = [], x_bnc.reshape(R, 3), None
+        idents = []
+        with torch.cuda.device(x_bnc.device):
+            st = _st(x_bnc)
+            for W, b in zip(Ws, bs):
+                Co, Ci = W.shape[0], W.shape[1]
+                z = torch.empty(R, Co, device=x_bnc.device, dtype=torch.float32)
+                check(lib.sn_linear_forward(R, Ci, Co, ptr(a_in), ptr(coef_prev), ptr(W), ptr(b), ptr(z), None, st),
+                      "sn_linear_forward")
+                zs.append(z)
+                coef_prev = _ident(Co, z)
+                idents.append(coef_prev)
+                a_in = z
+            C = Ws[-1].shape[0]
+            pooled = torch.empty(B, C, device=x_bnc.device, dtype=torch.float32)
+            argsel = torch.empty(B, C, device=x_bnc.device, dtype=torch.int32)
+            zsel = torch.empty(B, C, device=x_bnc.device, dtype=torch.float32)
+            check(lib.sn_pool_forward(B, N, C, ptr(zs[-1]), ptr(idents[-1]), ptr(pooled), ptr(argsel), ptr(zsel), st),
+                  "sn_pool_forward")
+        ctx.save_for_backward(x_bnc, pooled, argsel, zsel, *zs, *idents, *Ws)
+        ctx.nl = len(Ws)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, g):
+        nl = ctx.nl
+        saved = ctx.saved_tensors
+        x_bnc, pooled, argsel, zsel = saved[:4]
+        zs, idents, Ws = saved[4:4 + nl], saved[4 + nl:4 + 2 * nl], saved[4 + 2 * nl:]
+        B, N, _ = x_bnc.shape
+        R = B * N
+        dev = x_bnc.device
+        g = g.contiguous().float()
+        grads = [None] * (2 * nl)
+        with torch.cuda.device(dev):
+            st = _st(x_bnc)
+            C = Ws[-1].shape[0]
+            gsel = torch.empty(B, C, device=dev, dtype=torch.float32)
+            scratch = torch.empty(2 * C, device=dev, dtype=torch.float32)
+            check(lib.sn_pool_backward(B, C, ptr(g), ptr(pooled), ptr(zsel), ptr(gsel), ptr(scratch), st), "sn_pool_backward")
+            dy = None
+            for i in range(nl - 1, -1, -1):
+                W = Ws[i]
+                Co, Ci = W.shape[0], W.shape[1]
+                mode = _DZ_POOL if i == nl - 1 else _DZ_PLAIN
+                kcoef = None
+                if mode == _DZ_POOL:  # dZ = 1 * dY_sparse + 0 * Z + 0
+                    kcoef = torch.zeros(3, Co, device=dev, dtype=torch.float32)
+                    kcoef[0].fill_(1.0)
+                aprev = zs[i - 1] if i > 0 else x_bnc.reshape(R, 3)
+                cprev = idents[i - 1] if i > 0 else None
+                gs, ag = (gsel, argsel) if mode == _DZ_POOL else (None, None)
+                if ctx.needs_input_grad[1 + 2 * i] or ctx.needs_input_grad[2 + 2 * i]:
+                    ns = lib.sn_linear_wgrad_splits(R, Ci, Co, 1)
+                    part = torch.empty(ns * Co * (Ci + 1), device=dev, dtype=torch.float32)
+                    dW = torch.empty_like(W)
+                    db = torch.empty(Co, device=dev, dtype=torch.float32)
+                    check(lib.sn_linear_wgrad(R, Ci, Co, mode, ptr(dy), ptr(zs[i]), ptr(kcoef), ptr(gs), ptr(ag), N, ptr(aprev),
+                                              ptr(cprev), ptr(part), ptr(dW), ptr(db), st), "sn_linear_wgrad")
+                    grads[2 * i], grads[2 * i + 1] = dW, db
+                if i > 0 or ctx.needs_input_grad[0]:
+                    dyprev = torch.empty(R, Ci, device=dev, dtype=torch.float32)
+                    nblk = lib.sn_linear_stats_blocks(R)
+                    stats = torch.empty(nblk * 2 * Ci, device=dev, dtype=torch.float32) if i > 0 else None
+                    check(lib.sn_linear_dgrad(R, Ci, Co, mode, ptr(dy), ptr(zs[i]), ptr(kcoef), ptr(gs), ptr(ag), N, ptr(W),
+                                              ptr(aprev), ptr(cprev), ptr(dyprev), ptr(stats), st), "sn_linear_dgrad")
+                    dy = dyprev
+        gx = dy.reshape(B, N, 3) if ctx.needs_input_grad[0] else None
+        return (gx,) + tuple(grads)
+
+
+class PointNetFeatures(nn.Module):
+    def __init__(self, bottleneck_size=1024, input_shape="bcn"):
+        super().__init__()
+        if input_shape not in ["bcn", "bnc"]:
+            raise ValueError("allowed shape are 'bcn' (batch * channels * num_in_points), 'bnc' ")
+        self.input_shape = input_shape
+        self.conv1 = torch.nn.Conv1d(3, 64, 1)
+        self.conv2 = torch.nn.Conv1d(64, 64, 1)
+        self.conv3 = torch.nn.Conv1d(64, 64, 1)
+        self.conv4 = torch.nn.Conv1d(64, 128, 1)
+        self.conv5 = torch.nn.Conv1d(128, bottleneck_size, 1)
+
+    def forward(self, x):
+        if self.input_shape == "bcn":
+            x = x.permute(0, 2, 1)
+        if x.shape[2] != 3:
+            raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
+        if not x.is_cuda:
+            raise RuntimeError("samplenet_amd.task_features runs on the GPU only; no CPU fallback exists")
+        wb = []
+        for conv in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
+            wb += [conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1]), conv.bias]
+        return _FeaturesFunction.apply(x.contiguous().float(), *wb)

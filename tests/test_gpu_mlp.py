@@ -209,3 +209,33 @@ def test_fused_pooling_equals_separate_pass(B, N):
     assert torch.equal(ya, yb)
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         assert torch.equal(ba, bb), n
+
+
+@pytest.mark.parametrize("B,N,shape", [(4, 1024, "bcn"), (3, 64, "bnc"), (2, 200, "bcn")])
+def test_task_network_features_vs_torch(B, N, shape):
+    """samplenet_amd.task_features.PointNetFeatures (rows a12 / f1: registration/models/pcrnet.py:8-41 -- five 1x1 convs with
+    ReLU, no BatchNorm, max over points, bottleneck 1024) against the same module on torch.nn: forward 1e-5, gradient to
+    the input cloud (the path the sampler's task loss takes) and to the weights within fp32 GEMM rounding."""
+    import torch.nn.functional as F
+
+    from samplenet_amd.task_features import PointNetFeatures
+
+    torch.manual_seed(N)
+    net = PointNetFeatures(1024, shape).cuda()
+    x = (torch.rand(B, 3, N, device="cuda") - 0.5) if shape == "bcn" else (torch.rand(B, N, 3, device="cuda") - 0.5)
+    x.requires_grad_(True)
+    y = net(x)
+    assert y.shape == (B, 1024)
+    xr = x.detach().clone().requires_grad_(True)
+    h = xr if shape == "bcn" else xr.permute(0, 2, 1)
+    for conv in (net.conv1, net.conv2, net.conv3, net.conv4, net.conv5):
+        h = F.relu(conv(h))
+    yr = torch.max(h, 2)[0]
+    assert torch.allclose(y, yr, rtol=1e-5, atol=1e-6)
+    w = torch.randn_like(y)
+    params = [net.conv1.weight, net.conv3.weight, net.conv5.weight, net.conv5.bias]
+    got = torch.autograd.grad((y * w).sum(), [x] + params)
+    want = torch.autograd.grad((yr * w).sum(), [xr] + params)
+    for a, b in zip(got, want):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a.reshape(b.shape) - b).abs().max()) <= 2e-4 * scale
