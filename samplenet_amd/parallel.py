@@ -29,6 +29,8 @@ class FlatGradAllReducer:
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self._early_avg = False
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         early = [(n, p) for n, p in named if n.startswith(("fc", "bn_fc"))]
         other = [(n, p) for n, p in named if n.startswith("project")]
@@ -78,20 +80,29 @@ class FlatGradAllReducer:
         cur = torch.cuda.current_stream()
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
-            self._early_work = dist.all_reduce(self.flat[: self.n_early], group=self.group, async_op=True)
+            self._early_avg = self._avg
+            self._early_work = dist.all_reduce(self.flat[: self.n_early], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM,
+                                               group=self.group, async_op=True)
 
     def reduce(self):
         """Call after backward(): on return (stream-ordered) every .grad holds the cross-rank mean."""
         if self.world == 1:
             return
+        # RCCL averages inside the collective (ReduceOp.AVG): no separate scaling kernel; gloo (CPU tests) sums, then scales
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if self._early_work is not None:
-            dist.all_reduce(self.flat[self.n_early:], group=self.group)
+            dist.all_reduce(self.flat[self.n_early:], op=op, group=self.group)
             self._early_work.wait()
             torch.cuda.current_stream().wait_stream(self._side)
             self._early_work = None
+            if not self._avg:
+                self.flat.mul_(1.0 / self.world)
+            elif not self._early_avg:
+                self.flat[: self.n_early].mul_(1.0 / self.world)
         else:
-            dist.all_reduce(self.flat, group=self.group)
-        self.flat.mul_(1.0 / self.world)
+            dist.all_reduce(self.flat, op=op, group=self.group)
+            if not self._avg:
+                self.flat.mul_(1.0 / self.world)
 
 
 def shard_batch(x, rank, world):
