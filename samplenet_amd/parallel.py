@@ -89,20 +89,25 @@ class FlatGradAllReducer:
         if self.world == 1:
             return
         # RCCL averages inside the collective (ReduceOp.AVG): no separate scaling kernel; gloo (CPU tests) sums, then scales
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if self._early_work is not None:
-            dist.all_reduce(self.flat[self.n_early:], op=op, group=self.group)
+            self._all_reduce_mean(self.flat[self.n_early:])
             self._early_work.wait()
             torch.cuda.current_stream().wait_stream(self._side)
             self._early_work = None
-            if not self._avg:
-                self.flat.mul_(1.0 / self.world)
-            elif not self._early_avg:
+            if not self._early_avg:
                 self.flat[: self.n_early].mul_(1.0 / self.world)
         else:
-            dist.all_reduce(self.flat, op=op, group=self.group)
-            if not self._avg:
-                self.flat.mul_(1.0 / self.world)
+            self._all_reduce_mean(self.flat)
+
+    def _all_reduce_mean(self, t):
+        if self._avg:
+            try:
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+                return
+            except (RuntimeError, ValueError):  # a backend build without AVG: raised before anything is enqueued
+                self._avg = False
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        t.mul_(1.0 / self.world)
 
 
 def shard_batch(x, rank, world):
