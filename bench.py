@@ -36,23 +36,50 @@ def geometry_bytes_fwd(N, M, K):
 
 
 def time_pairscan_kernel(net, pool, K, reps=50):
-    """Average duration of the geometric kernel (sn_pairscan_forward: kNN + soft projection + both Chamfer
-    directions) measured with HIP events on the stream it is launched on, on the bench's own inputs, launches
-    back to back (so the bracket holds kernel time, not Python launch overhead)."""
-    from samplenet_amd import ops
+    """Average duration of the geometric kernel of the step -- sn::pairscan_kernel as sn_pairscan_forward_partial launches
+    it: kNN + soft projection + both Chamfer directions (the per-point side as partial keys) -- measured with HIP events on
+    the stream it is launched on, on the bench's own inputs, launched back to back through the C ABI (ctypes: the host
+    side stays ahead of the 11 us kernel)."""
+    from samplenet_amd._lib import check, lib, ptr
 
     with torch.no_grad():
         x = pool[0]
-        simp, _ = net(x)
-        P = x.permute(0, 2, 1).contiguous()
-        Q = simp.permute(0, 2, 1).contiguous()
-        T = net.project._temperature.detach()
+        B, N, _ = x.shape
+        y = net._features(x.permute(0, 2, 1), x).contiguous()  # (B,3,M)
+        M = y.shape[2]
+        dev = x.device
+        G = lib.sn_pairscan_colmin_splits(B, N, M)
+        T = net.project._temperature.detach().float().reshape(1)
+        if G <= 1:  # batch so large that a cloud is one workgroup: the step then uses the finalising entry point
+            from samplenet_amd import ops
+
+            P, Q = x.contiguous(), y
+            for _ in range(5):
+                ops.SoftProjectFunction.apply(P, Q, T, 1e-2, K, True, ops.BNC, ops.BNC)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.SoftProjectFunction.apply(P, Q, T, 1e-2, K, True, ops.BNC, ops.BNC)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        proj = torch.empty(B, M, 3, device=dev)
+        idx = torch.empty(B, M, K, device=dev, dtype=torch.int32)
+        dq = torch.empty(B, M, device=dev)
+        iq = torch.empty(B, M, device=dev, dtype=torch.int32)
+        ws = torch.empty(B * max(G, 1) * N, device=dev, dtype=torch.int64)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def launch():
+            check(lib.sn_pairscan_forward_partial(B, N, M, K, ptr(x), 0, ptr(y), 1, ptr(idx), ptr(dq), ptr(iq), ptr(proj), 0,
+                                                  ptr(T), 1e-2, ptr(ws), ws.numel() * 8, st), "sn_pairscan_forward_partial")
+
         for _ in range(5):
-            ops.SoftProjectFunction.apply(P, Q, T, 1e-2, K, True)
+            launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            ops.SoftProjectFunction.apply(P, Q, T, 1e-2, K, True)
+            launch()
         e1.record()
         torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
