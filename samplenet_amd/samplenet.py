@@ -46,27 +46,18 @@ class SampleNet(nn.Module):
         self.num_out_points = num_out_points
         self.name = "samplenet"
 
-        # parameter names / shapes as samplenet.py:40-59 (state_dict compatibility)
-        self.conv1 = torch.nn.Conv1d(3, 64, 1)
-        self.conv2 = torch.nn.Conv1d(64, 64, 1)
-        self.conv3 = torch.nn.Conv1d(64, 64, 1)
-        self.conv4 = torch.nn.Conv1d(64, 128, 1)
-        self.conv5 = torch.nn.Conv1d(128, bottleneck_size, 1)
-
-        self.bn1 = nn.BatchNorm1d(64)
-        self.bn2 = nn.BatchNorm1d(64)
-        self.bn3 = nn.BatchNorm1d(64)
-        self.bn4 = nn.BatchNorm1d(128)
-        self.bn5 = nn.BatchNorm1d(bottleneck_size)
-
-        self.fc1 = nn.Linear(bottleneck_size, 256)
-        self.fc2 = nn.Linear(256, 256)
-        self.fc3 = nn.Linear(256, 256)
-        self.fc4 = nn.Linear(256, 3 * num_out_points)
-
-        self.bn_fc1 = nn.BatchNorm1d(256)
-        self.bn_fc2 = nn.BatchNorm1d(256)
-        self.bn_fc3 = nn.BatchNorm1d(256)
+        # Layers registered under the reference's names and in its order (samplenet.py:40-59): checkpoints are
+        # interchangeable.  Widths: 3 -> 64 -> 64 -> 64 -> 128 -> bottleneck over the points, then 256 -> 256 -> 256 -> 3*M.
+        conv_widths = (3, 64, 64, 64, 128, bottleneck_size)
+        fc_widths = (bottleneck_size, 256, 256, 256, 3 * num_out_points)
+        for i in range(1, len(conv_widths)):
+            self.add_module("conv%d" % i, nn.Conv1d(conv_widths[i - 1], conv_widths[i], kernel_size=1))
+        for i in range(1, len(conv_widths)):
+            self.add_module("bn%d" % i, nn.BatchNorm1d(conv_widths[i]))
+        for i in range(1, len(fc_widths)):
+            self.add_module("fc%d" % i, nn.Linear(fc_widths[i - 1], fc_widths[i]))
+        for i in range(1, len(fc_widths) - 1):
+            self.add_module("bn_fc%d" % i, nn.BatchNorm1d(fc_widths[i]))
 
         self.project = SoftProjection(group_size, initial_temperature, is_temperature_trainable, min_sigma)
         self.skip_projection = skip_projection
@@ -91,76 +82,57 @@ class SampleNet(nn.Module):
             if x_bnc is None:
                 x_bnc = x.permute(0, 2, 1)
             return pointnet.pointnet_head(self, x_bnc)
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        y = F.relu(self.bn3(self.conv3(y)))
-        y = F.relu(self.bn4(self.conv4(y)))
-        y = F.relu(self.bn5(self.conv5(y)))  # Batch x bottleneck x NumInPoints
-        y = torch.max(y, 2)[0]  # Batch x bottleneck
-        y = F.relu(self.bn_fc1(self.fc1(y)))
-        y = F.relu(self.bn_fc2(self.fc2(y)))
-        y = F.relu(self.bn_fc3(self.fc3(y)))
+        # torch.nn route (A/B reference for the HIP kernels): conv/bn/relu x5, max over the points, fc/bn/relu x3, fc
+        y = x
+        for i in range(1, 6):
+            y = F.relu(getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(y)))
+        y = y.max(dim=2).values  # (B, bottleneck)
+        for i in range(1, 4):
+            y = F.relu(getattr(self, "bn_fc%d" % i)(getattr(self, "fc%d" % i)(y)))
         y = self.fc4(y)
         return y.view(-1, 3, self.num_out_points)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor):
-        x_in = x
-        if self.input_shape == "bnc":
-            x = x.permute(0, 2, 1)
-        if x.shape[1] != 3:
+        """x in `input_shape` -> (simplified cloud, projected cloud [train] | matched cloud [eval]) in `output_shape`
+        (samplenet.py:85-142).  Internally the head's output y is (B,3,M); the cloud is used in whichever layout it came."""
+        cloud_is_bnc = self.input_shape == "bnc"
+        out_is_bnc = self.output_shape == "bnc"
+        x_bcn = x.permute(0, 2, 1) if cloud_is_bnc else x
+        if x_bcn.shape[1] != 3:
             raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
-
-        y = self._features(x, x_in if self.input_shape == "bnc" else None)
-        simp = y
-        match = None
-        proj = None
-        scan = None
-
-        proj_is_out_layout = False
-        if self.training:
-            if not self.skip_projection:
-                # the pair-scan kernel reads the cloud and writes the projection in either layout: no transposed copies
-                bnc_in, bnc_out = self.input_shape == "bnc", self.output_shape == "bnc"
-                proj, _idx, dq, iq, dp, ip = self.project.project_with_chamfer(
-                    x_in.contiguous() if bnc_in else x.contiguous(), y.contiguous(),
-                    ops.BNC if bnc_in else ops.BCN, ops.BNC if bnc_out else ops.BCN)
-                proj_is_out_layout = True
-                scan = (dq, iq, dp, ip)
-            else:
-                proj = simp
-        else:  # inference: nearest-neighbour matching + FPS completion (samplenet.py:119-141)
-            idx, _ = ops.knn(1, x.contiguous(), y.contiguous(), ops.BCN, ops.BCN, return_dist=False)  # (B,M,1)
-            if self.device_matching and self.num_out_points <= 1024 and x.shape[2] <= 8192:
-                # unique + farthest-point completion on the device (same points as sputils.nn_matching)
-                match = ops.nn_matching(x.contiguous(), idx, self.num_out_points, self.complete_fps, ops.BCN)
-            else:  # the reference's host round trip (samplenet.py:124-133)
-                x_np = x.permute(0, 2, 1).cpu().detach().numpy()
-                idx_np = idx.squeeze(2).cpu().numpy()
-                z = sputils.nn_matching(x_np, idx_np, self.num_out_points, complete_fps=self.complete_fps)
-                match = torch.tensor(z, dtype=torch.float32).to(x.device)  # B x M x 3
-
-        if self.output_shape == "bnc":
-            simp = simp.permute(0, 2, 1)
-            if proj is not None and not proj_is_out_layout:
-                proj = proj.permute(0, 2, 1)
-        elif self.output_shape == "bcn" and match is not None:
-            match = match.permute(0, 2, 1)
-            match = match.contiguous()
-
-        simp = simp.contiguous()
-        if proj is not None:
-            proj = proj.contiguous()
-        if match is not None:
-            match = match.contiguous()
-
+        y = self._features(x_bcn, x if cloud_is_bnc else None)  # (B,3,M)
+        simp = (y.permute(0, 2, 1) if out_is_bnc else y).contiguous()
         self._scan = None
-        if scan is not None:
-            # remember which tensors the scan belongs to: the input cloud and the simplified cloud we return
-            self._scan = (x_in, x_in._version, simp, scan, y)
+        if self.training:
+            second = self._project_training(x, x_bcn, y, simp, cloud_is_bnc, out_is_bnc)
+        else:
+            second = self._match_inference(x_bcn, y, out_is_bnc)
+        return simp, second
 
-        out = proj if self.training else match
-        return simp, out
+    def _project_training(self, x, x_bcn, y, simp, cloud_is_bnc, out_is_bnc):
+        if self.skip_projection:
+            return simp
+        # one pair scan: projection + both Chamfer directions; it reads the cloud and writes the projection in either
+        # layout, so nothing is transposed.  The Chamfer products are remembered for get_simplification_loss().
+        cloud = (x if cloud_is_bnc else x_bcn).contiguous()
+        proj, _idx, dq, iq, dp, ip = self.project.project_with_chamfer(
+            cloud, y.contiguous(), ops.BNC if cloud_is_bnc else ops.BCN, ops.BNC if out_is_bnc else ops.BCN)
+        self._scan = (x, x._version, simp, (dq, iq, dp, ip), y)
+        return proj.contiguous()
+
+    def _match_inference(self, x_bcn, y, out_is_bnc):
+        """Nearest input point of every generated point, duplicates replaced by farthest-point picks (samplenet.py:119-141)."""
+        M = self.num_out_points
+        idx, _ = ops.knn(1, x_bcn.contiguous(), y.contiguous(), ops.BCN, ops.BCN, return_dist=False)  # (B,M,1)
+        if self.device_matching and M <= 1024 and x_bcn.shape[2] <= 8192:
+            # SURVEY 8 row f2: unique + farthest-point completion on the device (same points as sputils.nn_matching)
+            match = ops.nn_matching(x_bcn.contiguous(), idx, M, self.complete_fps, ops.BCN)
+        else:  # host round trip through numpy, as the reference does it
+            pts = x_bcn.permute(0, 2, 1).detach().cpu().numpy()
+            picked = sputils.nn_matching(pts, idx.squeeze(2).cpu().numpy(), M, complete_fps=self.complete_fps)
+            match = torch.as_tensor(picked, dtype=torch.float32).to(x_bcn.device)
+        return (match if out_is_bnc else match.permute(0, 2, 1)).contiguous()  # match is (B,M,3)
 
     def sample(self, x):
         simp, proj = self.__call__(x)

@@ -1,61 +1,77 @@
-"""Host-side utilities shared with the train scripts -- same names and behaviour as
-registration/src/sputils.py (nn_matching :31-41, get_parser :45-61), re-implemented.
+"""Host-side helpers that the train scripts import from `src.sputils` -- same public names and behaviour as
+registration/src/sputils.py (`nn_matching` :31-41 with its farthest-point completion :7-28, `get_parser` :45-61), written
+independently.  The GPU version of the matching is `samplenet_amd.ops.nn_matching` (sn_nn_matching); this numpy one is the
+host fallback of the eval branch and the comparison point of the tests.
 """
 import argparse
 
 import numpy as np
 
-
-def _calc_distances(p0, points):
-    return ((p0 - points) ** 2).sum(axis=1)
+__all__ = ["nn_matching", "get_parser"]
 
 
-def _fps_from_given_pc(pts, k, given_pc):
-    """Farthest-point completion of `given_pc` to k points drawn from pts (sputils.py:11-23)."""
-    out = np.zeros((k, 3))
-    t = np.size(given_pc) // 3
-    out[0:t] = given_pc
-    dist = _calc_distances(out[0], pts)
-    for i in range(1, t):
-        dist = np.minimum(dist, _calc_distances(out[i], pts))
-    for i in range(t, k):
-        out[i] = pts[np.argmax(dist)]
-        dist = np.minimum(dist, _calc_distances(out[i], pts))
-    return out
+def _sqdist_to(point, cloud):
+    """float64 squared distance of every cloud point to `point`, accumulated x, y, z in that order."""
+    delta = np.asarray(point, dtype=np.float64)[None, :] - cloud
+    return (delta[:, 0] * delta[:, 0] + delta[:, 1] * delta[:, 1]) + delta[:, 2] * delta[:, 2]
 
 
-def _unique(arr):
-    """Unique values in first-occurrence order (sputils.py:26-28)."""
-    _, first = np.unique(arr, return_index=True)
-    return arr[np.sort(first)]
+def _first_occurrences(indices):
+    """The distinct values of `indices` in the order in which they first appear."""
+    seen, kept = set(), []
+    for v in np.asarray(indices).tolist():
+        if v not in seen:
+            seen.add(v)
+            kept.append(v)
+    return np.asarray(kept, dtype=np.asarray(indices).dtype)
+
+
+def _complete_by_farthest_points(cloud, seeds, k):
+    """`seeds` (t,3), then k - t more points of `cloud`, each the one farthest from everything chosen so far
+    (first maximum on ties) -- the reference's _fps_from_given_pc."""
+    chosen = np.zeros((k, 3), dtype=np.float64)
+    t = int(np.size(seeds) // 3)
+    chosen[:t] = seeds
+    nearest = _sqdist_to(chosen[0], cloud)
+    for i in range(1, k):
+        if i >= t:
+            chosen[i] = cloud[int(np.argmax(nearest))]
+        nearest = np.minimum(nearest, _sqdist_to(chosen[i], cloud))
+    return chosen
 
 
 def nn_matching(full_pc, idx, k, complete_fps=True):
-    """full_pc (B,N,3), idx (B,k) -> matched points (B,k,3) (sputils.py:31-41)."""
-    batch_size = np.size(full_pc, 0)
-    out_pc = np.zeros((full_pc.shape[0], k, 3))
-    for ii in range(batch_size):
-        best_idx = idx[ii]
+    """full_pc (B,N,3), idx (B,k) nearest-input-point indices -> (B,k,3) float64 matched points.
+    complete_fps: duplicates are dropped (first occurrence kept) and the set is refilled to k points by farthest-point
+    sampling of the same cloud; otherwise a plain gather."""
+    full_pc = np.asarray(full_pc)
+    idx = np.asarray(idx)
+    matched = np.zeros((full_pc.shape[0], k, 3), dtype=np.float64)
+    for b, (cloud, picks) in enumerate(zip(full_pc, idx)):
         if complete_fps:
-            best_idx = _unique(best_idx)
-            out_pc[ii] = _fps_from_given_pc(full_pc[ii], k, full_pc[ii][best_idx])
+            matched[b] = _complete_by_farthest_points(cloud, cloud[_first_occurrences(picks)], k)
         else:
-            out_pc[ii] = full_pc[ii][best_idx]
-    return out_pc[:, 0:k, :]
+            matched[b] = cloud[picks][:k]
+    return matched
 
 
-# fmt: off
+# (flags, keyword arguments) of every option of the reference parser, registration/src/sputils.py:45-61
+_SAMPLER_OPTIONS = (
+    (("--skip-projection",), dict(action="store_true", help="train without the soft projection")),
+    (("-in", "--num-in-points"), dict(type=int, default=1024, help="points per input cloud [1024]")),
+    (("-out", "--num-out-points"), dict(type=int, default=64, help="points per sampled cloud, 2..1024 [64]")),
+    (("--bottleneck-size",), dict(type=int, default=128, help="width of the sampler's global feature [128]")),
+    (("--alpha",), dict(type=float, default=0.01, help="weight of the simplification loss [0.01]")),
+    (("--gamma",), dict(type=float, default=1, help="constant weight of the reverse Chamfer term [1]")),
+    (("--delta",), dict(type=float, default=0, help="per-output-point weight of the reverse Chamfer term [0]")),
+    (("-gs", "--projection-group-size"), dict(type=int, default=8, help="neighbours used by the soft projection [8]")),
+    (("--lmbda",), dict(type=float, default=0.01, help="weight of the projection (temperature) loss [0.01]")),
+)
+
+
 def get_parser():
-    """Argument parser with exactly the flags of registration/src/sputils.py:45-61."""
+    """ArgumentParser carrying the sampler options of the reference (same flags, types and defaults)."""
     parser = argparse.ArgumentParser("SampleNet: Differentiable Point Cloud Sampling")
-    parser.add_argument("--skip-projection", action="store_true", help="Do not project points in training")
-    parser.add_argument("-in", "--num-in-points", type=int, default=1024, help="Number of input Points [default: 1024]")
-    parser.add_argument("-out", "--num-out-points", type=int, default=64, help="Number of output points [2, 1024] [default: 64]")
-    parser.add_argument("--bottleneck-size", type=int, default=128, help="bottleneck size [default: 128]")
-    parser.add_argument("--alpha", type=float, default=0.01, help="Simplification regularization loss weight [default: 0.01]")
-    parser.add_argument("--gamma", type=float, default=1, help="Lb constant regularization loss weight [default: 1]")
-    parser.add_argument("--delta", type=float, default=0, help="Lb linear regularization loss weight [default: 0]")
-    parser.add_argument("-gs", "--projection-group-size", type=int, default=8, help="Neighborhood size in Soft Projection [default: 8]")
-    parser.add_argument("--lmbda", type=float, default=0.01, help="Projection regularization loss weight [default: 0.01]")
+    for flags, kwargs in _SAMPLER_OPTIONS:
+        parser.add_argument(*flags, **kwargs)
     return parser
-# fmt: on
