@@ -1,0 +1,1 @@
+"""Test-infrastructure package: CPU oracle of the reference ops (never imported by the product path)."""
