@@ -74,10 +74,28 @@ __device__ __forceinline__ int merge_topk(sn_u64 *list, int cnt, int K, int lane
 
 // Load this lane's PPL points of the chunk starting at c0 (point i*64+lane); lanes past the end of
 // the cloud get +inf coordinates, i.e. distance +inf: never selected.
+struct sn_xyz {
+    float x, y, z;
+};
+
 template <int PPL>
 __device__ __forceinline__ void load_chunk(float (&px)[PPL], float (&py)[PPL], float (&pz)[PPL],
                                            const float *__restrict__ Pb, int layout, int N, int c0, int lane)
 {
+    if (layout == SN_LAYOUT_BNC) {
+        // point-major cloud: one 12-byte load per point (global_load_dwordx3; consecutive lanes read consecutive points)
+        // instead of three strided dword loads -- 16 instead of 48 memory instructions per lane for a 1024-point cloud
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            const int n = c0 + i * kWave + lane;
+            const bool ok = n < N;
+            const sn_xyz v = *reinterpret_cast<const sn_xyz *>(Pb + (size_t)(ok ? n : 0) * 3);
+            px[i] = ok ? v.x : INFINITY;
+            py[i] = ok ? v.y : INFINITY;
+            pz[i] = ok ? v.z : INFINITY;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const int n = c0 + i * kWave + lane;
