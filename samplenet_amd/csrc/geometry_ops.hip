@@ -28,6 +28,10 @@ namespace sn {
 // Implicit upstream gradients (fused simplification loss, samplenet.py:171-181): with gL = d loss / d (scalar loss),
 //   g(dist of target j)  = gL * (ct + (j == argmax_t[b] ? cmax_t : 0)),   g(dist of source l) = gL * (cs + (l == argmax_s[b] ? cmax_s : 0))
 // so no per-point gradient tensors are materialised.  gL == NULL: explicit gT / gS arrays are used.
+struct sn_xyz3 {
+    float x, y, z;
+};
+
 struct ImplicitGrad {
     const float *gL;
     const int *argmax_t, *argmax_s;
@@ -134,7 +138,8 @@ __global__ void __launch_bounds__(256) chamfer_bwd_reg_kernel(int nt, int ns, co
     for (int i = 0; i < PPL; ++i) {
         const int l = i * 64 + lane;
         const int lc = l < ns ? l : 0;
-        sx[i] = S[lc * 3 + 0], sy[i] = S[lc * 3 + 1], sz[i] = S[lc * 3 + 2];
+        const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)lc * 3);  // one 12-byte load per source point
+        sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
         is[i] = l < ns ? idxS[lc] : -1;
         gg[i] = (implicit ? gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) : gS[lc]) * 2;
     }
