@@ -1577,6 +1577,21 @@ __device__ __forceinline__ void small_wgrad_body(const WgradArgs &g, float *__re
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
     (void)R;
+    if (Ce == Ci && (Ci & 31) == 0 && m0 + 32 <= Co) {
+        // whole 32 x 32 tile of dW: transpose through LDS and store 16 bytes per lane (16 dword stores per wave cost ~58
+        // issue cycles each -- the four waves of a workgroup were store-issue-bound)
+        __shared__ float tw[4][32 * 36];
+        float *T = tw[threadIdx.x >> 6];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) T[frag_row(e, lane) * 36 + l31] = acc[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rt = 8 * i + (lane >> 3);
+            *reinterpret_cast<float4 *>(dW + (size_t)(m0 + rt) * Ci + n0 + (lane & 7) * 4) =
+                *reinterpret_cast<const float4 *>(T + rt * 36 + (lane & 7) * 4);
+        }
+        return;
+    }
     const int col = n0 + l31;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
