@@ -224,6 +224,74 @@ struct SoftBwdArgs {
     int accumulate_q;
 };
 
+// One query of the soft-projection backward, executed by a whole wave (lane t < K = neighbour t): returns the gradient to
+// the query (aq*, wave-uniform) and its share of d loss / d sigma; accumulates grad_P if requested.
+template <bool FUSED>
+__device__ __forceinline__ void soft_bwd_query(const SoftBwdArgs &a, int b, int j, int lane, float sigma,
+                                               const float *__restrict__ Pb, const float *__restrict__ Qb, float &aqx_o,
+                                               float &aqy_o, float &aqz_o, float &asg_o)
+{
+    const int n = a.n, m = a.m, K = a.k;
+    const float qx = Qb[pt_off(a.q_layout, m, j, 0)];
+    const float qy = Qb[pt_off(a.q_layout, m, j, 1)];
+    const float qz = Qb[pt_off(a.q_layout, m, j, 2)];
+    const bool act = lane < K;
+    const int id = act ? a.idx[((size_t)b * m + j) * K + lane] : 0;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (act) {
+        gx = Pb[pt_off(a.p_layout, n, id, 0)];
+        gy = Pb[pt_off(a.p_layout, n, id, 1)];
+        gz = Pb[pt_off(a.p_layout, n, id, 2)];
+    }
+    const float dx = gx - qx, dy = gy - qy, dz = gz - qz;
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    const float s = act ? -(d / sigma) : -INFINITY;
+    float mx = readlane_f(s, 0);  // neighbours are stored ascending in distance; the scan below only matters
+    for (int t = 1; t < K; ++t) mx = fmaxf(mx, readlane_f(s, t));  // if a caller passes unsorted indices
+    const float e = act ? expf(s - mx) : 0.f;
+    float den = 0.f;
+    for (int t = 0; t < K; ++t) den += readlane_f(e, t);
+    const float w = e / den;
+
+    float gw;  // d loss / d w_t
+    float go0 = 0.f, go1 = 0.f, go2 = 0.f;
+    if (FUSED) {
+        if (a.grad_proj) {
+            const float *gp = a.grad_proj + (size_t)b * 3 * m;
+            go0 = gp[pt_off(a.gproj_layout, m, j, 0)];
+            go1 = gp[pt_off(a.gproj_layout, m, j, 1)];
+            go2 = gp[pt_off(a.gproj_layout, m, j, 2)];
+        } else {
+            go0 = go1 = go2 = *a.gconst / a.gconst_div;
+        }
+        gw = (go0 * gx + go1 * gy) + go2 * gz;
+    } else {
+        gw = act ? a.grad_weights[((size_t)b * m + j) * K + lane] : 0.f;
+    }
+    float dot = 0.f;
+    for (int t = 0; t < K; ++t) dot += readlane_f(w, t) * readlane_f(gw, t);
+    const float gs = act ? w * (gw - dot) : 0.f;  // softmax backward
+    const float gd = -gs / sigma;                 // s = -d / sigma
+    const float cx = 2.0f * gd * dx, cy = 2.0f * gd * dy, cz = 2.0f * gd * dz;
+    const float sg = act ? gs * d / (sigma * sigma) : 0.f;
+    float aqx = 0.f, aqy = 0.f, aqz = 0.f, asg = 0.f;
+    for (int t = 0; t < K; ++t) {
+        aqx -= readlane_f(cx, t);
+        aqy -= readlane_f(cy, t);
+        aqz -= readlane_f(cz, t);
+        asg += readlane_f(sg, t);
+    }
+    if (a.grad_P && act) {
+        float *gpb = a.grad_P + (size_t)b * 3 * n;
+        const int lay = FUSED ? a.p_layout : SN_LAYOUT_BCN;
+        const float ex = FUSED ? go0 * w : 0.f, ey = FUSED ? go1 * w : 0.f, ez = FUSED ? go2 * w : 0.f;
+        atomicAdd(&gpb[pt_off(lay, n, id, 0)], ex + cx);
+        atomicAdd(&gpb[pt_off(lay, n, id, 1)], ey + cy);
+        atomicAdd(&gpb[pt_off(lay, n, id, 2)], ez + cz);
+    }
+    aqx_o = aqx, aqy_o = aqy, aqz_o = aqz, asg_o = asg;
+}
+
 template <bool FUSED>
 __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
 {
@@ -232,7 +300,7 @@ __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
-    const int n = a.n, m = a.m, K = a.k;
+    const int n = a.n, m = a.m;
     const float *__restrict__ Pb = a.P + (size_t)b * 3 * n;
     const float *__restrict__ Qb = a.Q + (size_t)b * 3 * m;
     const float T = *a.temperature;
@@ -240,68 +308,13 @@ __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
     float gsig = 0.f;  // this wave's share of d loss / d sigma
 
     for (int j = blockIdx.y * nwaves + wave; j < m; j += gridDim.y * nwaves) {
-        const float qx = Qb[pt_off(a.q_layout, m, j, 0)];
-        const float qy = Qb[pt_off(a.q_layout, m, j, 1)];
-        const float qz = Qb[pt_off(a.q_layout, m, j, 2)];
-        const bool act = lane < K;
-        const int id = act ? a.idx[((size_t)b * m + j) * K + lane] : 0;
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        if (act) {
-            gx = Pb[pt_off(a.p_layout, n, id, 0)];
-            gy = Pb[pt_off(a.p_layout, n, id, 1)];
-            gz = Pb[pt_off(a.p_layout, n, id, 2)];
-        }
-        const float dx = gx - qx, dy = gy - qy, dz = gz - qz;
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        const float s = act ? -(d / sigma) : -INFINITY;
-        float mx = readlane_f(s, 0);  // neighbours are stored ascending in distance; the scan below only matters
-        for (int t = 1; t < K; ++t) mx = fmaxf(mx, readlane_f(s, t));  // if a caller passes unsorted indices
-        const float e = act ? expf(s - mx) : 0.f;
-        float den = 0.f;
-        for (int t = 0; t < K; ++t) den += readlane_f(e, t);
-        const float w = e / den;
-
-        float gw;  // d loss / d w_t
-        float go0 = 0.f, go1 = 0.f, go2 = 0.f;
-        if (FUSED) {
-            if (a.grad_proj) {
-                const float *gp = a.grad_proj + (size_t)b * 3 * m;
-                go0 = gp[pt_off(a.gproj_layout, m, j, 0)];
-                go1 = gp[pt_off(a.gproj_layout, m, j, 1)];
-                go2 = gp[pt_off(a.gproj_layout, m, j, 2)];
-            } else {
-                go0 = go1 = go2 = *a.gconst / a.gconst_div;
-            }
-            gw = (go0 * gx + go1 * gy) + go2 * gz;
-        } else {
-            gw = act ? a.grad_weights[((size_t)b * m + j) * K + lane] : 0.f;
-        }
-        float dot = 0.f;
-        for (int t = 0; t < K; ++t) dot += readlane_f(w, t) * readlane_f(gw, t);
-        const float gs = act ? w * (gw - dot) : 0.f;  // softmax backward
-        const float gd = -gs / sigma;                 // s = -d / sigma
-        const float cx = 2.0f * gd * dx, cy = 2.0f * gd * dy, cz = 2.0f * gd * dz;
-        const float sg = act ? gs * d / (sigma * sigma) : 0.f;
-        float aqx = 0.f, aqy = 0.f, aqz = 0.f, asg = 0.f;
-        for (int t = 0; t < K; ++t) {
-            aqx -= readlane_f(cx, t);
-            aqy -= readlane_f(cy, t);
-            aqz -= readlane_f(cz, t);
-            asg += readlane_f(sg, t);
-        }
+        float aqx, aqy, aqz, asg;
+        soft_bwd_query<FUSED>(a, b, j, lane, sigma, Pb, Qb, aqx, aqy, aqz, asg);
         gsig += asg;
         if (a.grad_Q && lane < 3) {
             const float o = lane == 0 ? aqx : (lane == 1 ? aqy : aqz);
             float *dst = a.grad_Q + (size_t)b * 3 * m + pt_off(a.gq_layout, m, j, lane);
             *dst = a.accumulate_q ? *dst + o : o;
-        }
-        if (a.grad_P && act) {
-            float *gpb = a.grad_P + (size_t)b * 3 * n;
-            const int lay = FUSED ? a.p_layout : SN_LAYOUT_BCN;
-            const float ex = FUSED ? go0 * w : 0.f, ey = FUSED ? go1 * w : 0.f, ez = FUSED ? go2 * w : 0.f;
-            atomicAdd(&gpb[pt_off(lay, n, id, 0)], ex + cx);
-            atomicAdd(&gpb[pt_off(lay, n, id, 1)], ey + cy);
-            atomicAdd(&gpb[pt_off(lay, n, id, 2)], ez + cz);
         }
     }
     // fixed-order block reduction of the sigma gradient: wave 0..3 in order
@@ -457,6 +470,74 @@ static inline unsigned grid_for(size_t tot, int block = 256, unsigned cap = 4096
 }  // namespace sn
 
 using namespace sn;
+
+// Chamfer backward (implicit upstream gradients, targets = the simplified cloud) + soft-projection backward of the same
+// query in ONE launch: a wave finishes the Chamfer gradient of target j exactly as chamfer_bwd_reg_kernel does, then runs
+// the soft-projection backward of query j (same point: the simplified cloud is both) and stores the sum -- the same
+// numbers as the two launches with accumulate_q (chamfer term first, soft term added), one kernel boundary less.
+template <int PPL>
+__global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, const float *__restrict__ T,
+                                                               const float *__restrict__ S, const int *__restrict__ idxT,
+                                                               const int *__restrict__ idxS, float *__restrict__ gradT,
+                                                               ImplicitGrad ig, SoftBwdArgs sa)
+{
+    __shared__ float s_part[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x;
+    T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
+    idxT += (size_t)b * nt, idxS += (size_t)b * ns;
+    const float gLv = *ig.gL * ig.gscale;
+    const int amt = ig.argmax_t ? ig.argmax_t[b] : -1, ams = ig.argmax_s ? ig.argmax_s[b] : -1;
+    gradT += (size_t)b * nt * 3;
+    const float Tm = *sa.temperature;
+    const float sigma = fmaxf(Tm * Tm, sa.min_sigma);
+    float gsig = 0.f;
+
+    float sx[PPL], sy[PPL], sz[PPL], gg[PPL];
+    int is[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int l = i * 64 + lane;
+        const int lc = l < ns ? l : 0;
+        const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)lc * 3);
+        sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
+        is[i] = l < ns ? idxS[lc] : -1;
+        gg[i] = gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) * 2;
+    }
+    for (int j = blockIdx.y * nwaves + wave; j < nt; j += gridDim.y * nwaves) {
+        const float tx = T[j], ty = T[j + nt], tz = T[j + 2 * nt];  // targets channel-major (3, nt)
+        const int j2 = idxT[j];
+        const float g = gLv * (ig.ct + (j == amt ? ig.cmax_t : 0.f)) * 2;
+        float ax = g * (tx - S[j2 * 3 + 0]), ay = g * (ty - S[j2 * 3 + 1]), az = g * (tz - S[j2 * 3 + 2]);  // own term first
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            sn_u64 mask = __ballot(is[i] == j);
+            if (mask) {
+                const float cx = gg[i] * (sx[i] - tx), cy = gg[i] * (sy[i] - ty), cz = gg[i] * (sz[i] - tz);
+                while (mask) {
+                    const int t = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    ax -= readlane_f(cx, t);
+                    ay -= readlane_f(cy, t);
+                    az -= readlane_f(cz, t);
+                }
+            }
+        }
+        float qx, qy, qz, asg;
+        soft_bwd_query<true>(sa, b, j, lane, sigma, S, T, qx, qy, qz, asg);
+        gsig += asg;
+        if (lane < 3) gradT[j + lane * nt] = lane == 0 ? ax + qx : (lane == 1 ? ay + qy : az + qz);
+    }
+    if (lane == 0) s_part[wave] = gsig;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int w2 = 0; w2 < nwaves; ++w2) tot += s_part[w2];
+        sa.grad_sigma_partial[(size_t)b * gridDim.y + blockIdx.y] = tot;
+    }
+}
 
 // workgroups per cloud of the soft-projection backward kernels; grad_sigma_partial holds b * this many floats
 extern "C" int sn_soft_bwd_splits(int b, int m)
@@ -903,21 +984,34 @@ extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const f
     SN_REQUIRE(P && Q && knn_idx && idx_q && idx_p && argmax1 && temperature && grad_loss && grad_Q && gsig_scratch && grad_T,
                "null pointer");
     hipStream_t st = (hipStream_t)stream;
-    // 1. alpha * d L_simp / d Q   (targets = Q, channel-major; sources = P)
-    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (kChamferBwdGroups + B - 1) / B)); };
     // same roundings as the op-by-op route: (alpha * g) first, then the per-term coefficients
     const float c1 = 1.0f / ((float)B * (float)M), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)N);
     ImplicitGrad ig{grad_loss, argmax1, nullptr, c1, cm, c2, 0.f, alpha};
-    launch_chamfer_bwd(B, ysplit(M), M, N, Q, P, nullptr, idx_q, nullptr, idx_p, grad_Q, 1, ig, st, 1);
-    // 2. + d mean(proj) / d Q, and the sigma partials
     SoftBwdArgs a{};
     a.P = P, a.Q = Q, a.idx = knn_idx, a.temperature = temperature, a.min_sigma = min_sigma;
     a.p_layout = p_layout, a.q_layout = SN_LAYOUT_BCN, a.n = N, a.m = M, a.k = K;
     a.grad_proj = nullptr, a.gconst = grad_loss, a.gconst_div = (float)(B * 3 * M);
     a.grad_Q = grad_Q, a.gq_layout = SN_LAYOUT_BCN, a.accumulate_q = 1;
     a.grad_P = nullptr, a.grad_sigma_partial = gsig_scratch;
-    const int splits = sn_soft_bwd_splits(B, M);
-    hipLaunchKernelGGL(soft_bwd_kernel<true>, dim3(B, splits), dim3(256), 0, st, a);
+    int splits = sn_soft_bwd_splits(B, M);
+    if (N <= 2048) {
+        // 1+2. alpha * d L_simp / d Q  +  d mean(proj) / d Q  (and the sigma partials) in one launch
+        splits = std::max(1, std::min((M + 3) / 4, (kChamferBwdGroups + B - 1) / B));
+        splits = std::min(splits, sn_soft_bwd_splits(B, M));  // gsig_scratch is sized by the caller for that many
+        const dim3 grid(B, splits), block(256);
+#define SN_CS(PPL_) hipLaunchKernelGGL(chamfer_soft_bwd_kernel<PPL_>, grid, block, 0, st, M, N, Q, P, idx_q, idx_p, grad_Q, ig, a)
+        if (N <= 64) SN_CS(1);
+        else if (N <= 256) SN_CS(4);
+        else if (N <= 1024) SN_CS(16);
+        else SN_CS(32);
+#undef SN_CS
+    } else {
+        // 1. alpha * d L_simp / d Q   (targets = Q, channel-major; sources = P)
+        auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (kChamferBwdGroups + B - 1) / B)); };
+        launch_chamfer_bwd(B, ysplit(M), M, N, Q, P, nullptr, idx_q, nullptr, idx_p, grad_Q, 1, ig, st, 1);
+        // 2. + d mean(proj) / d Q, and the sigma partials
+        hipLaunchKernelGGL(soft_bwd_kernel<true>, dim3(B, splits), dim3(256), 0, st, a);
+    }
     // 3. grad_T from the sigma partials and the direct lmbda * sigma term
     hipLaunchKernelGGL(sigma_grad_kernel, dim3(1), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
                        grad_loss, lmbda);
