@@ -273,7 +273,10 @@ int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, c
 int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                       const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                       const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,
-                      float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef, sn_stream_t stream);
+                      float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef, long long prev_bn_rows,
+                      sn_stream_t stream);
+/* prev_bn_rows (R <= 32 only, 0 = R): rows seen by the BatchNorm of the layer below when they differ from R -- the FC head's
+ * first layer on top of the max-pool: zprev = pooled pre-BN values (B rows), BatchNorm over B*N rows; replaces sn_pool_backward */
 int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
                       const float *bias, float *z, float *stats, sn_stream_t stream);
 int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,

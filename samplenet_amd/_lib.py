@@ -55,7 +55,7 @@ PROTOTYPES = {
     "sn_conv_forward_bn_pool": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp],
     "sn_layer_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                          _vp, _vp],
+                          _vp, ctypes.c_longlong, _vp],
     "sn_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_finalize": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_eval_coef": [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp],

@@ -2490,14 +2490,18 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
                                  const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                                  const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,
                                  float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef,
-                                 sn_stream_t stream)
+                                 long long prev_bn_rows, sn_stream_t stream)
 {
     SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
     SN_REQUIRE(W && zprev && dyprev && dW, "null pointer");
     SN_REQUIRE(dz_mode >= DZ_PLAIN && dz_mode <= DZ_POOL, "bad dz_mode");
-    SN_REQUIRE(!coef_prev || (stats && prev_dgamma && prev_dbeta && prev_kcoef), "previous-layer BatchNorm outputs missing");
+    SN_REQUIRE(!coef_prev || ((stats || R <= 32) && prev_dgamma && prev_dbeta && prev_kcoef), "previous-layer BatchNorm outputs missing");
+    SN_REQUIRE(prev_bn_rows == 0 || R <= 32, "prev_bn_rows applies to the register-resident (R <= 32) path only");
     hipStream_t st = (hipStream_t)stream;
-    const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, (long long)R};
+    // prev_bn_rows: rows the BatchNorm of the layer below averaged over when they are not this layer's R -- the FC head's
+    // first layer sits on the max-pool of the last conv layer: zprev = the pooled pre-BN values (B rows), its BatchNorm saw
+    // B * N rows; the ReLU mask / sums of the dgrad epilogue are then exactly the pooling backward
+    const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, prev_bn_rows > 0 ? prev_bn_rows : (long long)R};
     if (R <= 32) {
         DgradArgs g{};
         g.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);

@@ -225,7 +225,7 @@ def _bn_bwd(L, R, stats, nblk, coef, sink=None, bn_name="", lin_name=""):
 
 
 def _layer_bwd(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, Lprev, sink, name, bn_prev, lin_prev,
-               with_bias):
+               with_bias, prev_bn_rows=0):
     """Backward of layer `name`: dW (db when with_bias), dYprev and -- when the layer below (Lprev) has a BatchNorm --
     that BatchNorm's dgamma / dbeta, the bias gradient of the layer below, and its dZ coefficients (kcoef)."""
     dW = _out(sink, name + ".weight", L.W)
@@ -242,7 +242,7 @@ def _layer_bwd(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, L
         kc = _empty((3, L.Ci), L.W)
     check(lib.sn_layer_backward(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(L.W),
                                 ptr(zprev), ptr(coef_prev), ptr(dyprev), ptr(stats), ptr(part), ptr(dW), ptr(db), ptr(dg),
-                                ptr(dbt), ptr(dbs), ptr(kc), _st(L.W)), "sn_layer_backward")
+                                ptr(dbt), ptr(dbs), ptr(kc), int(prev_bn_rows), _st(L.W)), "sn_layer_backward")
     return dW, db, dyprev, dg, dbt, dbs, kc
 
 
@@ -266,31 +266,35 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
     for j in (3, 2, 1, 0):
         L = fcs[j]
         mode = DZ_PLAIN if j == 3 else DZ_BN
-        zprev, cprev, Lprev = (zf[j - 1], cf[j - 1], fcs[j - 1]) if j > 0 else (saved["pooled"], None, None)
+        if j > 0:
+            zprev, cprev, Lprev, bnp, linp, rows = zf[j - 1], cf[j - 1], fcs[j - 1], bn_f[j - 1], names_f[j - 1], 0
+        elif B > 32:  # the epilogue trick needs the register-resident (R <= 32) kernels: separate pooling backward below
+            zprev, cprev, Lprev, bnp, linp, rows = saved["pooled"], None, None, None, None, 0
+        else:
+            # fc1 sits on the max-pool: its "previous layer" is conv5 seen through the selected points -- the ReLU mask and
+            # BatchNorm-backward sums of the dgrad epilogue over zsel ARE the pooling backward (no separate launch)
+            zprev, cprev, Lprev, bnp, linp, rows = saved["zsel"], cc[4], convs[4], bn_c[4], names_c[4], R
         dW, db, dy, dg, dbt, dbs, kc = _layer_bwd(B, L, mode, dy, zf[j] if j < 3 else None, kcoef, None, None, 1, zprev, cprev,
-                                                  Lprev, sink, names_f[j], bn_f[j - 1] if j > 0 else "", names_f[j - 1] if j > 0 else "",
-                                                  j == 3)
+                                                  Lprev, sink, names_f[j], bnp, linp, j == 3, rows)
         grads[names_f[j] + ".weight"] = dW
         if db is not None:
             grads[names_f[j] + ".bias"] = db
-        if j > 0:
-            grads[bn_f[j - 1] + ".weight"], grads[bn_f[j - 1] + ".bias"], grads[names_f[j - 1] + ".bias"] = dg, dbt, dbs
+        if bnp is not None:
+            grads[bnp + ".weight"], grads[bnp + ".bias"], grads[linp + ".bias"] = dg, dbt, dbs
         kcoef = kc
-    g_pool = dy  # (B, C5): gradient w.r.t. the pooled features
+    gsel = dy  # (B, C5): gradient at the selected (max-pooled) points, already masked; kcoef = conv5's BatchNorm backward
     if after_fc is not None:
         _join_side(grad_y.device)
         after_fc()
-
-    # ---- max-pool + last conv layer's BatchNorm ----
-    C5 = convs[4].Co
-    gsel = _empty((B, C5), grad_y)
-    L5 = convs[4]
-    dgamma, dbeta = _out(sink, bn_c[4] + ".weight", L5.bn.weight), _out(sink, bn_c[4] + ".bias", L5.bn.bias)
-    dbias = _out(sink, names_c[4] + ".bias", L5.b)
-    kcoef = _empty((3, C5), grad_y)
-    check(lib.sn_pool_backward_bn(B, C5, R, ptr(g_pool), ptr(saved["pooled"]), ptr(saved["zsel"]), ptr(gsel), ptr(cc[4]),
-                                  ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(kcoef), _st(grad_y)), "sn_pool_backward_bn")
-    grads[bn_c[4] + ".weight"], grads[bn_c[4] + ".bias"], grads[names_c[4] + ".bias"] = dgamma, dbeta, dbias
+    if B > 32:  # dy is the gradient w.r.t. the pooled features: max-pool + conv5's BatchNorm backward in their own launch
+        C5, L5, g_pool = convs[4].Co, convs[4], dy
+        gsel = _empty((B, C5), grad_y)
+        dgamma, dbeta = _out(sink, bn_c[4] + ".weight", L5.bn.weight), _out(sink, bn_c[4] + ".bias", L5.bn.bias)
+        dbias = _out(sink, names_c[4] + ".bias", L5.b)
+        kcoef = _empty((3, C5), grad_y)
+        check(lib.sn_pool_backward_bn(B, C5, R, ptr(g_pool), ptr(saved["pooled"]), ptr(saved["zsel"]), ptr(gsel), ptr(cc[4]),
+                                      ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(kcoef), _st(grad_y)), "sn_pool_backward_bn")
+        grads[bn_c[4] + ".weight"], grads[bn_c[4] + ".bias"], grads[names_c[4] + ".bias"] = dgamma, dbeta, dbias
 
     # ---- conv stack (rows = B*N): conv5 -> ... -> conv2 (each also finishes the BatchNorm of the layer below), conv1 ----
     dy = None
