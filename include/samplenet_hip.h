@@ -136,12 +136,16 @@ int sn_pairscan_forward_partial(int B, int N, int M, int K, const float *P, int 
                                 sn_stream_t stream);
 int sn_sampler_step_loss_forward(int B, int M, int N, int G, const float *dist_q, const void *colmin_ws, const float *proj,
                                  const float *temperature, float alpha, float lmbda, float weight, float min_sigma,
-                                 float *dist_p, int *idx_p, int *argmax1, float *partial, float *loss, sn_stream_t stream);
+                                 float *dist_p, int *idx_p, int *argmax1, float *partial, float *loss, int defer_value,
+                                 sn_stream_t stream);
 int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
                                   const int *knn_idx, const int *idx_q, const int *idx_p, const int *argmax1,
                                   const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
                                   const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T,
-                                  sn_stream_t stream);
+                                  const float *deferred_partial, float *deferred_loss, sn_stream_t stream);
+/* defer_value != 0: the forward leaves loss[] unwritten; pass its `partial` and `loss` to the backward call as
+ * deferred_partial / deferred_loss and the scalar is combined by an extra wave of the backward's first launch (the
+ * gradients do not depend on it) -- for callers that always run the backward (samplenet_amd.engine).  Else pass NULLs. */
 
 /* ---------------------------------------------------------------------------------------------
  * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.

@@ -471,6 +471,36 @@ static inline unsigned grid_for(size_t tot, int block = 256, unsigned cap = 4096
 
 using namespace sn;
 
+// scalar of the sampler step's loss from the per-cloud partials (see sn_sampler_step_loss_forward)
+struct StepLossFinal {
+    int B, M, N, nproj;
+    float w, alpha, lmbda, min_sigma;
+    const float *part;
+    const float *temperature;
+    float *loss;  // NULL: nothing to do
+};
+
+// one wave: lane b carries clouds b, b + 64, ...; the lanes are then combined by a fixed xor tree (all loads in flight at
+// once; a single thread walking the B partials pays one memory round trip per cloud)
+__device__ __forceinline__ void step_loss_final(const StepLossFinal &f, int t)
+{
+    float s1 = 0.f, mx = 0.f, s2 = 0.f, sp = 0.f;
+    for (int b = t; b < f.B; b += 64) s1 += f.part[b * 4], mx += f.part[b * 4 + 1], s2 += f.part[b * 4 + 2], sp += f.part[b * 4 + 3];
+    const float T = *f.temperature;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        mx += __shfl_xor(mx, o);
+        s2 += __shfl_xor(s2, o);
+        sp += __shfl_xor(sp, o);
+    }
+    if (t != 0) return;
+    const float c12 = s1 / ((float)f.B * (float)f.M), cmax = mx / (float)f.B, c21 = s2 / ((float)f.B * (float)f.N);
+    const float lsimp = c12 + cmax + f.w * c21;
+    f.loss[0] = f.alpha * lsimp + f.lmbda * fmaxf(T * T, f.min_sigma) + sp / ((float)f.B * (float)f.nproj);
+    f.loss[1] = lsimp;
+}
+
 // Chamfer backward (implicit upstream gradients, targets = the simplified cloud) + soft-projection backward of the same
 // query in ONE launch: a wave finishes the Chamfer gradient of target j exactly as chamfer_bwd_reg_kernel does, then runs
 // the soft-projection backward of query j (same point: the simplified cloud is both) and stores the sum -- the same
@@ -479,13 +509,18 @@ template <int PPL>
 __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, const float *__restrict__ T,
                                                                const float *__restrict__ S, const int *__restrict__ idxT,
                                                                const int *__restrict__ idxS, float *__restrict__ gradT,
-                                                               ImplicitGrad ig, SoftBwdArgs sa)
+                                                               ImplicitGrad ig, SoftBwdArgs sa, StepLossFinal fin)
 {
     __shared__ float s_part[4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
+    const int nsplit = fin.loss ? (int)gridDim.y - 1 : (int)gridDim.y;  // the last y-slice only combines the loss value
+    if ((int)blockIdx.y == nsplit) {
+        if (b == 0 && wave == 0) step_loss_final(fin, lane);
+        return;
+    }
     T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
     idxT += (size_t)b * nt, idxS += (size_t)b * ns;
     const float gLv = *ig.gL * ig.gscale;
@@ -506,7 +541,7 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
         is[i] = l < ns ? idxS[lc] : -1;
         gg[i] = gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) * 2;
     }
-    for (int j = blockIdx.y * nwaves + wave; j < nt; j += gridDim.y * nwaves) {
+    for (int j = blockIdx.y * nwaves + wave; j < nt; j += nsplit * nwaves) {
         const float tx = T[j], ty = T[j + nt], tz = T[j + 2 * nt];  // targets channel-major (3, nt)
         const int j2 = idxT[j];
         const float g = gLv * (ig.ct + (j == amt ? ig.cmax_t : 0.f)) * 2;
@@ -535,7 +570,7 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
     if (threadIdx.x == 0) {
         float tot = 0.f;
         for (int w2 = 0; w2 < nwaves; ++w2) tot += s_part[w2];
-        sa.grad_sigma_partial[(size_t)b * gridDim.y + blockIdx.y] = tot;
+        sa.grad_sigma_partial[(size_t)b * nsplit + blockIdx.y] = tot;
     }
 }
 
@@ -931,42 +966,24 @@ __global__ void __launch_bounds__(1024) step_loss_partial_kernel(int M, int N, i
     }
 }
 
-__global__ void __launch_bounds__(64) step_loss_final_kernel(int B, int M, int N, int nproj, float w, float alpha, float lmbda,
-                                                             float min_sigma, const float *__restrict__ part,
-                                                             const float *__restrict__ temperature, float *__restrict__ loss)
-{
-    // lane b carries clouds b, b + 64, ...; the lanes are then combined by a fixed xor tree (all loads in flight at once;
-    // a single thread walking the B partials pays one memory round trip per cloud)
-    const int t = threadIdx.x;
-    float s1 = 0.f, mx = 0.f, s2 = 0.f, sp = 0.f;
-    for (int b = t; b < B; b += 64) s1 += part[b * 4], mx += part[b * 4 + 1], s2 += part[b * 4 + 2], sp += part[b * 4 + 3];
-    const float T = *temperature;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o);
-        mx += __shfl_xor(mx, o);
-        s2 += __shfl_xor(s2, o);
-        sp += __shfl_xor(sp, o);
-    }
-    if (t != 0) return;
-    const float c12 = s1 / ((float)B * (float)M), cmax = mx / (float)B, c21 = s2 / ((float)B * (float)N);
-    const float lsimp = c12 + cmax + w * c21;
-    loss[0] = alpha * lsimp + lmbda * fmaxf(T * T, min_sigma) + sp / ((float)B * (float)nproj);
-    loss[1] = lsimp;
-}
+__global__ void __launch_bounds__(64) step_loss_final_kernel(StepLossFinal f) { step_loss_final(f, threadIdx.x); }
 
 extern "C" int sn_sampler_step_loss_forward(int B, int M, int N, int G, const float *dist_q, const void *colmin_ws,
                                             const float *proj, const float *temperature, float alpha, float lmbda,
                                             float weight, float min_sigma, float *dist_p, int *idx_p, int *argmax1,
-                                            float *partial, float *loss, sn_stream_t stream)
+                                            float *partial, float *loss, int defer_value, sn_stream_t stream)
 {
     SN_REQUIRE(B >= 1 && M >= 1 && N >= 1 && G >= 1, "bad size");
     SN_REQUIRE(dist_q && colmin_ws && proj && temperature && dist_p && idx_p && argmax1 && partial && loss, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(step_loss_partial_kernel, dim3(B), dim3(1024), 0, st, M, N, G, 3 * M, dist_q, (const sn_u64 *)colmin_ws,
                        proj, dist_p, idx_p, partial, argmax1);
-    hipLaunchKernelGGL(step_loss_final_kernel, dim3(1), dim3(64), 0, st, B, M, N, 3 * M, weight, alpha, lmbda, min_sigma,
-                       partial, temperature, loss);
+    // defer_value: the scalar is combined by an extra wave of sn_sampler_step_loss_backward's first launch (the gradients do
+    // not need it; a launch of its own costs ~4.7 us inside the step's graph) -- only for callers that always run backward
+    if (!defer_value) {
+        const StepLossFinal f{B, M, N, 3 * M, weight, alpha, lmbda, min_sigma, partial, temperature, loss};
+        hipLaunchKernelGGL(step_loss_final_kernel, dim3(1), dim3(64), 0, st, f);
+    }
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -977,9 +994,11 @@ extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const f
                                              const int *knn_idx, const int *idx_q, const int *idx_p, const int *argmax1,
                                              const float *temperature, float min_sigma, float alpha, float lmbda,
                                              float weight, const float *grad_loss, float *grad_Q, float *gsig_scratch,
-                                             float *grad_T, sn_stream_t stream)
+                                             float *grad_T, const float *deferred_partial, float *deferred_loss,
+                                             sn_stream_t stream)
 {
     SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64, "bad size");
+    SN_REQUIRE(!deferred_loss || deferred_partial, "deferred loss value needs the forward's partials");
     SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
     SN_REQUIRE(P && Q && knn_idx && idx_q && idx_p && argmax1 && temperature && grad_loss && grad_Q && gsig_scratch && grad_T,
                "null pointer");
@@ -998,8 +1017,10 @@ extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const f
         // 1+2. alpha * d L_simp / d Q  +  d mean(proj) / d Q  (and the sigma partials) in one launch
         splits = std::max(1, std::min((M + 3) / 4, (kChamferBwdGroups + B - 1) / B));
         splits = std::min(splits, sn_soft_bwd_splits(B, M));  // gsig_scratch is sized by the caller for that many
-        const dim3 grid(B, splits), block(256);
-#define SN_CS(PPL_) hipLaunchKernelGGL(chamfer_soft_bwd_kernel<PPL_>, grid, block, 0, st, M, N, Q, P, idx_q, idx_p, grad_Q, ig, a)
+        const StepLossFinal fin{B, M, N, 3 * M, weight, alpha, lmbda, min_sigma, deferred_partial, temperature, deferred_loss};
+        const dim3 grid(B, splits + (deferred_loss ? 1 : 0)), block(256);
+#define SN_CS(PPL_) \
+    hipLaunchKernelGGL(chamfer_soft_bwd_kernel<PPL_>, grid, block, 0, st, M, N, Q, P, idx_q, idx_p, grad_Q, ig, a, fin)
         if (N <= 64) SN_CS(1);
         else if (N <= 256) SN_CS(4);
         else if (N <= 1024) SN_CS(16);
@@ -1011,6 +1032,10 @@ extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const f
         launch_chamfer_bwd(B, ysplit(M), M, N, Q, P, nullptr, idx_q, nullptr, idx_p, grad_Q, 1, ig, st, 1);
         // 2. + d mean(proj) / d Q, and the sigma partials
         hipLaunchKernelGGL(soft_bwd_kernel<true>, dim3(B, splits), dim3(256), 0, st, a);
+        if (deferred_loss) {
+            const StepLossFinal fin{B, M, N, 3 * M, weight, alpha, lmbda, min_sigma, deferred_partial, temperature, deferred_loss};
+            hipLaunchKernelGGL(step_loss_final_kernel, dim3(1), dim3(64), 0, st, fin);
+        }
     }
     // 3. grad_T from the sigma partials and the direct lmbda * sigma term
     hipLaunchKernelGGL(sigma_grad_kernel, dim3(1), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,

@@ -63,7 +63,7 @@ class SamplerTrainStep:
             y = net._features(x.permute(0, 2, 1), x)  # (B,3,M)
             weight = self.gamma + self.delta * net.num_out_points
             loss, _proj = ops.SamplerStepLossFunction.apply(y, x, T, net.project._group_size, net.project._min_sigma_f,
-                                                            self.alpha, self.lmbda, weight, t_sink)
+                                                            self.alpha, self.lmbda, weight, t_sink, True)
             loss.backward(self._one)  # preallocated upstream gradient: no ones_like fill per step
             return loss.detach()
         if self.reducer is not None:

@@ -432,7 +432,7 @@ class SamplerStepLossFunction(torch.autograd.Function):
     returned for the temperature."""
 
     @staticmethod
-    def forward(ctx, y_bcn, x_bnc, temperature, K, min_sigma, alpha, lmbda, weight, t_sink=None):
+    def forward(ctx, y_bcn, x_bnc, temperature, K, min_sigma, alpha, lmbda, weight, t_sink=None, defer_value=False):
         _need_gpu(y_bcn, x_bnc, temperature)
         y, x = _f32c(y_bcn), _f32c(x_bnc)
         B, _, M = y.shape
@@ -459,8 +459,10 @@ class SamplerStepLossFunction(torch.autograd.Function):
                   "sn_pairscan_forward_partial")
             check(lib.sn_sampler_step_loss_forward(B, M, N, G, ptr(dq), ptr(ws), ptr(proj), ptr(T), float(alpha), float(lmbda),
                                                    float(weight), float(min_sigma), ptr(dp), ptr(ip), ptr(argmax1), ptr(partial),
-                                                   ptr(loss), st), "sn_sampler_step_loss_forward")
+                                                   ptr(loss), 1 if defer_value else 0, st), "sn_sampler_step_loss_forward")
         ctx.save_for_backward(x, y, idx, iq, ip, argmax1, temperature)
+        # defer_value: the loss VALUE is written by the backward's first launch (engine: backward always follows)
+        ctx.deferred = (partial, loss) if defer_value else (None, None)
         ctx.cfg = (K, float(min_sigma), float(alpha), float(lmbda), float(weight))
         ctx.t_sink = t_sink
         ctx.mark_non_differentiable(proj)
@@ -471,8 +473,9 @@ class SamplerStepLossFunction(torch.autograd.Function):
     def backward(ctx, grad_loss, _gproj=None):
         x, y, idx, iq, ip, argmax1, temperature = ctx.saved_tensors
         if grad_loss is None:
-            return (None,) * 9
+            return (None,) * 10
         K, min_sigma, alpha, lmbda, weight = ctx.cfg
+        dpart, dloss = ctx.deferred
         B, _, M = y.shape
         N = x.shape[1]
         dev = y.device
@@ -484,11 +487,11 @@ class SamplerStepLossFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             check(lib.sn_sampler_step_loss_backward(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(ip), ptr(argmax1),
                                                     ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
-                                                    _stream(y)), "sn_sampler_step_loss_backward")
+                                                    ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_backward")
         g_temp = None
         if ctx.t_sink is None and ctx.needs_input_grad[2]:
             g_temp = gT.reshape(temperature.shape)
-        return (gQ if ctx.needs_input_grad[0] else None), None, g_temp, None, None, None, None, None, None
+        return (gQ if ctx.needs_input_grad[0] else None), None, g_temp, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------- EMD
