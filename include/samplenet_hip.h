@@ -134,6 +134,14 @@ int sn_pairscan_forward_partial(int B, int N, int M, int K, const float *P, int 
                                 int *knn_idx, float *dist_q, int *idx_q, float *proj, int proj_layout,
                                 const float *temperature, float min_sigma, void *workspace, long long workspace_bytes,
                                 sn_stream_t stream);
+/* sn_pairscan_forward_partial with the queries PRODUCED inside the scan by the head's last fully connected layer
+ * (samplenet.py:103-104): q[b][c][j] = fc_bias[c*M+j] + sum_k relu(fc_z[b][k]*fc_scale[k] + fc_shift[k]) * fc_w[c*M+j][k];
+ * q_out (B,3,M) receives the simplified cloud.  Kfc % 4 == 0.  One launch less than FC layer + scan. */
+int sn_pairscan_forward_partial_fc(int B, int N, int M, int K, const float *P, int p_layout, const float *fc_z,
+                                   const float *fc_scale, const float *fc_shift, const float *fc_w, const float *fc_bias,
+                                   int Kfc, float *q_out, int *knn_idx, float *dist_q, int *idx_q, float *proj,
+                                   int proj_layout, const float *temperature, float min_sigma, void *workspace,
+                                   long long workspace_bytes, sn_stream_t stream);
 int sn_sampler_step_loss_forward(int B, int M, int N, int G, const float *dist_q, const void *colmin_ws, const float *proj,
                                  const float *temperature, float alpha, float lmbda, float weight, float min_sigma,
                                  float *dist_p, int *idx_p, int *argmax1, float *partial, float *loss, int defer_value,

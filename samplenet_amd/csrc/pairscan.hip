@@ -178,7 +178,51 @@ struct PairscanArgs {
     float min_sigma;
     sn_u64 *colmin_ws;  // [B][gridDim.y][N] partial column minima as (distance, query) keys when the queries of a
                         // cloud are spread over several workgroups (gridDim.y > 1); finalised by colmin_finalize_kernel
+    // Optional: the queries are not read but PRODUCED here, as the last fully connected layer of the sampler's head
+    // (samplenet.py:103-104: y = fc4(relu(bn_fc3(z3))), y.view(B, 3, M)): query j of cloud b has coordinate c =
+    // bias[c*M + j] + sum_k relu(z3[b][k] * scale[k] + shift[k]) * W[c*M + j][k].  The wave that scans query j computes it
+    // (3 rows x fc_k MACs spread over the lanes) and stores it to q_out in q_layout.
+    const float *fc_z, *fc_scale, *fc_shift, *fc_w, *fc_bias;
+    int fc_k;
+    float *q_out;
 };
+
+// coordinate c of query j (see PairscanArgs::fc_w): lane partial sums in k order, then a fixed xor tree
+__device__ __forceinline__ void fc_query(const PairscanArgs &a, int b, int j, int lane, float &qx, float &qy, float &qz)
+{
+    const int Kf = a.fc_k, M = a.M;
+    const float *z = a.fc_z + (size_t)b * Kf;
+    const float *w0 = a.fc_w + (size_t)j * Kf, *w1 = w0 + (size_t)M * Kf, *w2 = w1 + (size_t)M * Kf;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = lane * 4; k < Kf; k += kWave * 4) {
+        const float4 zv = *reinterpret_cast<const float4 *>(z + k);
+        const float4 sc = *reinterpret_cast<const float4 *>(a.fc_scale + k);
+        const float4 sh = *reinterpret_cast<const float4 *>(a.fc_shift + k);
+        const float4 u = *reinterpret_cast<const float4 *>(w0 + k);
+        const float4 v = *reinterpret_cast<const float4 *>(w1 + k);
+        const float4 w = *reinterpret_cast<const float4 *>(w2 + k);
+        const float ax = fmaxf(fmaf(zv.x, sc.x, sh.x), 0.f), ay = fmaxf(fmaf(zv.y, sc.y, sh.y), 0.f);
+        const float az = fmaxf(fmaf(zv.z, sc.z, sh.z), 0.f), aw = fmaxf(fmaf(zv.w, sc.w, sh.w), 0.f);
+        s0 = fmaf(aw, u.w, fmaf(az, u.z, fmaf(ay, u.y, fmaf(ax, u.x, s0))));
+        s1 = fmaf(aw, v.w, fmaf(az, v.z, fmaf(ay, v.y, fmaf(ax, v.x, s1))));
+        s2 = fmaf(aw, w.w, fmaf(az, w.z, fmaf(ay, w.y, fmaf(ax, w.x, s2))));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    qx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s0 + a.fc_bias[j])));
+    qy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s1 + a.fc_bias[M + j])));
+    qz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s2 + a.fc_bias[2 * M + j])));
+    if (lane == 0) {
+        float *qo = a.q_out + (size_t)b * 3 * M;
+        qo[pt_off(a.q_layout, M, j, 0)] = qx;
+        qo[pt_off(a.q_layout, M, j, 1)] = qy;
+        qo[pt_off(a.q_layout, M, j, 2)] = qz;
+    }
+}
 
 template <int PPL, bool SINGLE, bool COLMIN, int LOGG>
 __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(PairscanArgs a)
@@ -222,9 +266,14 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
     if (SINGLE) load_chunk<PPL>(px, py, pz, Pb, a.p_layout, N, 0, lane);
 
     for (int j = q0 + wave; j < q1; j += nwaves) {  // wave-uniform
-        const float qx = Qb[pt_off(a.q_layout, M, j, 0)];
-        const float qy = Qb[pt_off(a.q_layout, M, j, 1)];
-        const float qz = Qb[pt_off(a.q_layout, M, j, 2)];
+        float qx, qy, qz;
+        if (a.fc_w) {
+            fc_query(a, b, j, lane, qx, qy, qz);
+        } else {
+            qx = Qb[pt_off(a.q_layout, M, j, 0)];
+            qy = Qb[pt_off(a.q_layout, M, j, 1)];
+            qz = Qb[pt_off(a.q_layout, M, j, 2)];
+        }
         int cnt = 0;
         float thr_run = INFINITY;
 
@@ -545,6 +594,39 @@ extern "C" int sn_pairscan_forward_partial(int B, int N, int M, int K, const flo
     a.B = B, a.N = N, a.M = M, a.K = K;
     a.knn_idx = knn_idx, a.dist_q = dist_q, a.idx_q = idx_q;
     a.proj = proj, a.proj_layout = proj_layout, a.temperature = temperature, a.min_sigma = min_sigma;
+    int used = 0;
+    int rc = sn::pairscan_dispatch(a, workspace, workspace_bytes, false, &used, (hipStream_t)stream);
+    if (rc) return rc;
+    SN_REQUIRE(used == G, "internal: split mismatch");
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// sn_pairscan_forward_partial whose queries are produced in the scan itself by the head's last fully connected layer
+// (PairscanArgs::fc_w): z3 (B, Kfc) pre-BatchNorm output of the layer before, scale/shift (Kfc) its BatchNorm as an affine
+// map, W (3M, Kfc), bias (3M).  q_out (B,3,M) receives the simplified cloud.  One launch less than FC layer + scan.
+extern "C" int sn_pairscan_forward_partial_fc(int B, int N, int M, int K, const float *P, int p_layout, const float *fc_z,
+                                              const float *fc_scale, const float *fc_shift, const float *fc_w,
+                                              const float *fc_bias, int Kfc, float *q_out, int *knn_idx, float *dist_q,
+                                              int *idx_q, float *proj, int proj_layout, const float *temperature,
+                                              float min_sigma, void *workspace, long long workspace_bytes,
+                                              sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && K <= N, "bad size");
+    SN_REQUIRE(P && fc_z && fc_scale && fc_shift && fc_w && fc_bias && q_out && workspace && temperature, "null pointer");
+    SN_REQUIRE(Kfc >= 4 && Kfc % 4 == 0, "Kfc must be a multiple of 4");
+    SN_REQUIRE(p_layout == SN_LAYOUT_BNC || p_layout == SN_LAYOUT_BCN, "bad p_layout");
+    const int G = sn_pairscan_colmin_splits(B, N, M);
+    if (G <= 1 || N > sn::kWave * 32)
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pairscan_forward_partial_fc: this shape runs as one workgroup per cloud");
+    SN_REQUIRE(workspace_bytes >= (long long)B * G * N * 8, "workspace too small");
+    PairscanArgs a{};
+    a.P = P, a.Q = q_out, a.p_layout = p_layout, a.q_layout = SN_LAYOUT_BCN;
+    a.B = B, a.N = N, a.M = M, a.K = K;
+    a.knn_idx = knn_idx, a.dist_q = dist_q, a.idx_q = idx_q;
+    a.proj = proj, a.proj_layout = proj_layout, a.temperature = temperature, a.min_sigma = min_sigma;
+    a.fc_z = fc_z, a.fc_scale = fc_scale, a.fc_shift = fc_shift, a.fc_w = fc_w, a.fc_bias = fc_bias, a.fc_k = Kfc;
+    a.q_out = q_out;
     int used = 0;
     int rc = sn::pairscan_dispatch(a, workspace, workspace_bytes, false, &used, (hipStream_t)stream);
     if (rc) return rc;

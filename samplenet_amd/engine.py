@@ -16,10 +16,11 @@ import torch
 
 class SamplerTrainStep:
     def __init__(self, net, example_x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=None, reducer=None,
-                 use_graph=True, warmup=3, fused_loss=True, input_ring=None):
+                 use_graph=True, warmup=3, fused_loss=True, input_ring=None, fused_head=True):
         self.net, self.reducer = net, reducer
         self.alpha, self.lmbda, self.gamma, self.delta = alpha, lmbda, gamma, delta
         self.fused_loss = fused_loss  # False: compose the loss op by op through the module's own methods (A/B, tests)
+        self.fused_head = fused_head  # fast path only: fc4's forward computed inside the pair scan (fused_step.py)
         self.task_loss = task_loss  # None: the benchmark's stand-in mean(proj), fused with the loss weighting
         # input_ring: optional list of device tensors (shape of example_x) that the caller fills IN PLACE -- e.g. the
         # host-to-device targets of its data loader.  One graph is captured per entry (all sharing one memory pool) and
@@ -60,10 +61,15 @@ class SamplerTrainStep:
                 t_sink = T.grad.view(-1)[:1]  # a view of the flat bucket: written in place, nothing to zero or accumulate
             elif self.reducer is not None:
                 self.reducer.zero_grad()
-            y = net._features(x.permute(0, 2, 1), x)  # (B,3,M)
             weight = self.gamma + self.delta * net.num_out_points
-            loss, _proj = ops.SamplerStepLossFunction.apply(y, x, T, net.project._group_size, net.project._min_sigma_f,
-                                                            self.alpha, self.lmbda, weight, t_sink, True)
+            if self.fused_head and net.use_hip_mlp:
+                from .fused_step import sampler_step
+
+                loss, _y, _proj = sampler_step(net, x, self.alpha, self.lmbda, weight, t_sink, True)  # fc4 inside the scan
+            else:
+                y = net._features(x.permute(0, 2, 1), x)  # (B,3,M)
+                loss, _proj = ops.SamplerStepLossFunction.apply(y, x, T, net.project._group_size, net.project._min_sigma_f,
+                                                                self.alpha, self.lmbda, weight, t_sink, True)
             loss.backward(self._one)  # preallocated upstream gradient: no ones_like fill per step
             return loss.detach()
         if self.reducer is not None:

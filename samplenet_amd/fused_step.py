@@ -1,0 +1,65 @@
+"""The sampler's whole training step -- PointNet head, soft projection, loss -- behind ONE autograd node.
+
+    y    = head(x)                          samplenet.py:90-104   (conv/bn/relu x5, max-pool, fc/bn/relu x3, fc4)
+    proj = SoftProjection(x, y)             soft_projection.py:138-152
+    L    = alpha * L_simp(x, y) + lmbda * sigma + mean(proj)        main.py:507-531 with the benchmark's stand-in task term
+
+Why one node: the head's last layer (fc4: 32 x 256 -> 192 at the benchmark shape) is a launch of its own that only
+produces the 64 query points per cloud the pair scan then reads back.  Here the wave that scans query j computes its three
+coordinates itself (sn_pairscan_forward_partial_fc), so fc4's forward launch disappears; its backward is unchanged
+(pointnet.backward_impl receives d L / d y from the loss kernels).  Used by engine.SamplerTrainStep's fast path; the
+op-by-op modules (SampleNet.forward + get_simplification_loss + get_projection_loss) compute the same step.
+"""
+import torch
+
+from . import ops, pointnet
+
+
+class SamplerStepFunction(torch.autograd.Function):
+    """loss, simp (B,3,M), proj (B,M,3) = step(net, x (B,N,3)); differentiable w.r.t. the head's parameters and the
+    projection temperature (simp / proj are returned detached: the loss is the only differentiable output)."""
+
+    @staticmethod
+    def forward(ctx, net, x_bnc, temperature, K, min_sigma, alpha, lmbda, weight, t_sink, defer_value, *params):
+        ops._need_gpu(x_bnc, temperature)
+        x = ops._f32c(x_bnc)
+        B = x.shape[0]
+        M = net.num_out_points
+        with torch.cuda.device(x.device):
+            _, saved = pointnet.forward_impl(net, x, True, skip_last=True)
+            fc4 = net.fc4
+            y = torch.empty(B, 3, M, device=x.device, dtype=torch.float32)
+            fc = (saved["zf"][2], saved["cf"][2], fc4.weight.detach(), fc4.bias.detach())
+            loss, proj, state = ops.step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value)
+        ctx.net, ctx.saved, ctx.state = net, saved, state
+        ctx.x, ctx.y, ctx.temperature = x, y, temperature
+        ctx.cfg = (K, float(min_sigma), float(alpha), float(lmbda), float(weight))
+        ctx.t_sink = t_sink
+        ctx.mark_non_differentiable(y, proj)
+        ctx.set_materialize_grads(False)
+        return loss[0], y, proj
+
+    @staticmethod
+    def backward(ctx, grad_loss, _gy=None, _gproj=None):
+        nparams = len(pointnet.PARAM_ORDER)
+        if grad_loss is None:
+            return (None,) * (10 + nparams)
+        net = ctx.net
+        sink = getattr(net, "_grad_sink", None)
+        with torch.cuda.device(ctx.y.device):
+            gQ, gT = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink)
+            grads = pointnet.backward_impl(net, ctx.saved, gQ.view(gQ.shape[0], -1), sink, getattr(net, "_after_fc_grads", None))
+        g_temp = None
+        if ctx.t_sink is None and ctx.needs_input_grad[2]:
+            g_temp = gT.reshape(ctx.temperature.shape)
+        return (None, None, g_temp) + (None,) * 7 + tuple(
+            None if (sink is not None and n in sink) else grads[n] for n in pointnet.PARAM_ORDER)
+
+
+def sampler_step(net, x_bnc, alpha, lmbda, weight, t_sink=None, defer_value=False):
+    """-> (loss, simp (B,3,M), proj (B,M,3)) for a training-mode SampleNet with projection on a (B,N,3) batch."""
+    sd = dict(net.named_parameters())
+    params = [sd[n] for n in pointnet.PARAM_ORDER]
+    proj = net.project
+    return SamplerStepFunction.apply(net, x_bnc, proj._temperature, proj._group_size, proj._min_sigma_f, alpha, lmbda, weight,
+                                     t_sink, defer_value, *params)

@@ -435,34 +435,10 @@ class SamplerStepLossFunction(torch.autograd.Function):
     def forward(ctx, y_bcn, x_bnc, temperature, K, min_sigma, alpha, lmbda, weight, t_sink=None, defer_value=False):
         _need_gpu(y_bcn, x_bnc, temperature)
         y, x = _f32c(y_bcn), _f32c(x_bnc)
-        B, _, M = y.shape
-        N = x.shape[1]
-        dev = y.device
-        G = lib.sn_pairscan_colmin_splits(B, N, M)
-        if G <= 1:
-            raise ValueError("SamplerStepLossFunction needs a batch small enough for split clouds (use the op-by-op path)")
-        proj = torch.empty(B, M, 3, device=dev, dtype=torch.float32)
-        idx = torch.empty(B, M, K, device=dev, dtype=torch.int32)
-        dq = torch.empty(B, M, device=dev, dtype=torch.float32)
-        iq = torch.empty(B, M, device=dev, dtype=torch.int32)
-        dp = torch.empty(B, N, device=dev, dtype=torch.float32)
-        ip = torch.empty(B, N, device=dev, dtype=torch.int32)
-        ws = torch.empty(B * G * N, device=dev, dtype=torch.int64)
-        argmax1 = torch.empty(B, device=dev, dtype=torch.int32)
-        partial = torch.empty(B * 4, device=dev, dtype=torch.float32)
-        loss = torch.empty(2, device=dev, dtype=torch.float32)
-        T = temperature.detach().float().reshape(1)
-        with torch.cuda.device(dev):
-            st = _stream(y)
-            check(lib.sn_pairscan_forward_partial(B, N, M, K, ptr(x), BNC, ptr(y), BCN, ptr(idx), ptr(dq), ptr(iq), ptr(proj), BNC,
-                                                  ptr(T), float(min_sigma), ptr(ws), ws.numel() * 8, st),
-                  "sn_pairscan_forward_partial")
-            check(lib.sn_sampler_step_loss_forward(B, M, N, G, ptr(dq), ptr(ws), ptr(proj), ptr(T), float(alpha), float(lmbda),
-                                                   float(weight), float(min_sigma), ptr(dp), ptr(ip), ptr(argmax1), ptr(partial),
-                                                   ptr(loss), 1 if defer_value else 0, st), "sn_sampler_step_loss_forward")
-        ctx.save_for_backward(x, y, idx, iq, ip, argmax1, temperature)
-        # defer_value: the loss VALUE is written by the backward's first launch (engine: backward always follows)
-        ctx.deferred = (partial, loss) if defer_value else (None, None)
+        with torch.cuda.device(y.device):
+            loss, proj, state = step_loss_forward(x, y, None, temperature, K, min_sigma, alpha, lmbda, weight, defer_value)
+        ctx.save_for_backward(x, y, temperature, *state[:4])
+        ctx.deferred = state[4]
         ctx.cfg = (K, float(min_sigma), float(alpha), float(lmbda), float(weight))
         ctx.t_sink = t_sink
         ctx.mark_non_differentiable(proj)
@@ -471,27 +447,74 @@ class SamplerStepLossFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss, _gproj=None):
-        x, y, idx, iq, ip, argmax1, temperature = ctx.saved_tensors
+        x, y, temperature, idx, iq, ip, argmax1 = ctx.saved_tensors
         if grad_loss is None:
             return (None,) * 10
-        K, min_sigma, alpha, lmbda, weight = ctx.cfg
-        dpart, dloss = ctx.deferred
-        B, _, M = y.shape
-        N = x.shape[1]
-        dev = y.device
-        gQ = torch.empty_like(y)
-        gsig = torch.empty(B * lib.sn_soft_bwd_splits(B, M), device=dev, dtype=torch.float32)
-        gT = ctx.t_sink if ctx.t_sink is not None else torch.empty(1, device=dev, dtype=torch.float32)
-        gl = grad_loss.contiguous().float().reshape(1)
-        T = temperature.detach().float().reshape(1)
-        with torch.cuda.device(dev):
-            check(lib.sn_sampler_step_loss_backward(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(ip), ptr(argmax1),
-                                                    ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
-                                                    ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_backward")
+        with torch.cuda.device(y.device):
+            gQ, gT = step_loss_backward(x, y, temperature, (idx, iq, ip, argmax1, ctx.deferred), ctx.cfg, grad_loss, ctx.t_sink)
         g_temp = None
         if ctx.t_sink is None and ctx.needs_input_grad[2]:
             g_temp = gT.reshape(temperature.shape)
         return (gQ if ctx.needs_input_grad[0] else None), None, g_temp, None, None, None, None, None, None, None
+
+
+def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value):
+    """Forward launches of the sampler step's loss side (SamplerStepLossFunction / fused_step.SamplerStepFunction).
+    x (B,N,3), y (B,3,M): the simplified cloud -- read when fc is None, otherwise WRITTEN by the pair scan from
+    fc = (z3 (B,Kfc), coef3 (>=2*Kfc: scale | shift), W4 (3M,Kfc), b4 (3M)).  Caller holds the device guard.
+    -> loss (2,), proj (B,M,3), state = (idx, iq, ip, argmax1, (partial, loss) | (None, None))."""
+    B, _, M = y.shape
+    N = x.shape[1]
+    dev = y.device
+    G = lib.sn_pairscan_colmin_splits(B, N, M)
+    if G <= 1:
+        raise ValueError("the single-node step loss needs a batch small enough for split clouds (use the op-by-op path)")
+    proj = torch.empty(B, M, 3, device=dev, dtype=torch.float32)
+    idx = torch.empty(B, M, K, device=dev, dtype=torch.int32)
+    dq = torch.empty(B, M, device=dev, dtype=torch.float32)
+    iq = torch.empty(B, M, device=dev, dtype=torch.int32)
+    dp = torch.empty(B, N, device=dev, dtype=torch.float32)
+    ip = torch.empty(B, N, device=dev, dtype=torch.int32)
+    ws = torch.empty(B * G * N, device=dev, dtype=torch.int64)
+    argmax1 = torch.empty(B, device=dev, dtype=torch.int32)
+    partial = torch.empty(B * 4, device=dev, dtype=torch.float32)
+    loss = torch.empty(2, device=dev, dtype=torch.float32)
+    T = temperature.detach().float().reshape(1)
+    st = _stream(y)
+    if fc is None:
+        check(lib.sn_pairscan_forward_partial(B, N, M, K, ptr(x), BNC, ptr(y), BCN, ptr(idx), ptr(dq), ptr(iq), ptr(proj), BNC,
+                                              ptr(T), float(min_sigma), ptr(ws), ws.numel() * 8, st),
+              "sn_pairscan_forward_partial")
+    else:
+        z3, coef3, W4, b4 = fc
+        Kfc = z3.shape[1]
+        check(lib.sn_pairscan_forward_partial_fc(B, N, M, K, ptr(x), BNC, ptr(z3), ptr(coef3), coef3.data_ptr() + 4 * Kfc,
+                                                 ptr(W4), ptr(b4), Kfc, ptr(y), ptr(idx), ptr(dq), ptr(iq), ptr(proj), BNC,
+                                                 ptr(T), float(min_sigma), ptr(ws), ws.numel() * 8, st),
+              "sn_pairscan_forward_partial_fc")
+    check(lib.sn_sampler_step_loss_forward(B, M, N, G, ptr(dq), ptr(ws), ptr(proj), ptr(T), float(alpha), float(lmbda),
+                                           float(weight), float(min_sigma), ptr(dp), ptr(ip), ptr(argmax1), ptr(partial),
+                                           ptr(loss), 1 if defer_value else 0, st), "sn_sampler_step_loss_forward")
+    # defer_value: the loss VALUE is written by the backward's first launch (engine: backward always follows)
+    return loss, proj, (idx, iq, ip, argmax1, (partial, loss) if defer_value else (None, None))
+
+
+def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink):
+    """Backward launches of the sampler step's loss side -> (grad_Q (B,3,M), grad_T (1,)).  Caller holds the device guard."""
+    idx, iq, ip, argmax1, (dpart, dloss) = state
+    K, min_sigma, alpha, lmbda, weight = cfg
+    B, _, M = y.shape
+    N = x.shape[1]
+    dev = y.device
+    gQ = torch.empty_like(y)
+    gsig = torch.empty(B * lib.sn_soft_bwd_splits(B, M), device=dev, dtype=torch.float32)
+    gT = t_sink if t_sink is not None else torch.empty(1, device=dev, dtype=torch.float32)
+    gl = grad_loss.contiguous().float().reshape(1)
+    T = temperature.detach().float().reshape(1)
+    check(lib.sn_sampler_step_loss_backward(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(ip), ptr(argmax1),
+                                            ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
+                                            ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_backward")
+    return gQ, gT
 
 
 # --------------------------------------------------------------------------------------------- EMD

@@ -100,8 +100,10 @@ def _bn_coef(L, R, stats, nblk, training):
     return coef
 
 
-def forward_impl(net, x_bnc, training):
-    """x (B,N,3) contiguous -> y (B, 3*M) and the tensors backward needs."""
+def forward_impl(net, x_bnc, training, skip_last=False):
+    """x (B,N,3) contiguous -> y (B, 3*M) and the tensors backward needs.
+    skip_last: stop before fc4 and return None for y -- the caller produces it from saved["zf"][2] / saved["cf"][2] (the
+    pair scan of the fused sampler step computes its own queries, fused_step.py)."""
     convs, fcs = _layers(net)
     B, N, _ = x_bnc.shape
     R = B * N
@@ -139,6 +141,8 @@ def forward_impl(net, x_bnc, training):
         saved["zf"].append(z)
         saved["cf"].append(coef)
         a_in, coef_prev = z, coef
+    if skip_last:
+        return None, saved
     y, _, _ = _linear_fwd(B, fcs[-1], a_in, coef_prev, False)
     return y, saved
 

@@ -161,7 +161,8 @@ def test_fused_sampler_loss_equals_composition():
     net_b = copy.deepcopy(net_a)
     x = torch.rand(6, 512, 3, device="cuda") - 0.5
     red_a, red_b = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b)
-    la = SamplerTrainStep(net_a, x, alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, reducer=red_a, use_graph=False)(x)
+    la = SamplerTrainStep(net_a, x, alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, reducer=red_a, use_graph=False,
+                          fused_head=False)(x)
     lb = SamplerTrainStep(net_b, x, alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, reducer=red_b, use_graph=False,
                           task_loss=lambda p: p.mean())(x)
     assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
@@ -186,12 +187,12 @@ def test_single_node_step_loss_equals_composition(B, N, M, K):
     x = torch.rand(B, N, 3, device="cuda") - 0.5
     kw = dict(alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, use_graph=False)
     red_a, red_b, red_c = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b), FlatGradAllReducer(net_c)
-    step_a = SamplerTrainStep(net_a, x, reducer=red_a, **kw)
+    step_a = SamplerTrainStep(net_a, x, reducer=red_a, fused_head=False, **kw)
     assert step_a._fast_path()
     la = step_a(x)
     lb = SamplerTrainStep(net_b, x, reducer=red_b, fused_loss=False, **kw)(x)
     lc = SamplerTrainStep(net_c, x, reducer=red_c, task_loss=lambda p: p.mean(), **kw)(x)
-    ld = SamplerTrainStep(net_d, x, reducer=None, **kw)(x)
+    ld = SamplerTrainStep(net_d, x, reducer=None, fused_head=False, **kw)(x)
     for other in (lb, lc, ld):
         assert abs(float(la) - float(other)) <= 1e-6 * max(1.0, abs(float(other)))
     assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
@@ -203,6 +204,49 @@ def test_single_node_step_loss_equals_composition(B, N, M, K):
     # BatchNorm running statistics moved identically
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         assert torch.equal(ba, bb), n
+
+
+@pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (6, 512, 64, 8), (3, 320, 20, 5)])
+def test_head_fused_into_scan(B, N, M, K):
+    """fused_step.SamplerStepFunction (fc4's forward computed by the pair-scan waves: sn_pairscan_forward_partial_fc) against
+    the same step with fc4 as its own launch.  The query coordinates come out of a different summation order (lane
+    partials + xor tree instead of the MFMA k-chain), so: simplified cloud within 2e-6, loss within 1e-5 relative,
+    every gradient within 1e-4 of its tensor's norm (+1e-6 of the largest gradient norm: the biases in
+    front of a BatchNorm have zero true gradient, what is stored there is rounding noise); also without a flat gradient bucket."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.fused_step import sampler_step
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(B + N + 1)
+    net_a = SampleNet(M, 128, group_size=K, initial_temperature=0.7, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    kw = dict(alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, use_graph=False)
+    red_a, red_b = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b)
+    la = SamplerTrainStep(net_a, x, reducer=red_a, fused_head=True, **kw)(x)
+    lb = SamplerTrainStep(net_b, x, reducer=red_b, fused_head=False, **kw)(x)
+    assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+    gb = {n: p.grad for n, p in net_b.named_parameters()}  # views of red_b.flat
+    gmax = max(float(g.norm()) for g in gb.values())
+    for n, p in net_a.named_parameters():
+        assert float((p.grad - gb[n]).norm()) <= 1e-4 * float(gb[n].norm()) + 1e-6 * gmax, n
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), n  # BatchNorm statistics do not depend on fc4
+    # direct call without a bucket: loss, simplified cloud and projection come back; gradients arrive through autograd
+    loss, y, proj = sampler_step(net_c, x, 0.3, 0.7, 1.0 + 0.01 * M)
+    with torch.no_grad():
+        net_b.zero_grad()
+        y_ref = net_b._features(x.permute(0, 2, 1), x)
+    assert y.shape == (B, 3, M) and proj.shape == (B, M, 3)
+    assert float((y - y_ref).abs().max()) <= 2e-6
+    assert abs(float(loss) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+    loss.backward()
+    for n, p in net_c.named_parameters():
+        assert p.grad is not None, n
+        assert float((p.grad - gb[n]).norm()) <= 1e-4 * float(gb[n].norm()) + 1e-6 * gmax, n
 
 
 def test_input_ring_replay_equals_copy_in():

@@ -1,4 +1,4 @@
-python -m pytest tests -m gpu -q 2>&1 | grep -E "^E  |passed|failed|Error|^FAILED" | head -30
+python -m pytest tests -m gpu -q 2>&1 | grep -E "^E  |passed|failed|Error|^FAILED" | head -40
 python bench.py --steps 300 --warmup 30 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print('graph', d['value'], d['ms_per_step'])"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-graph > /tmp/bench_prof.log 2>&1
