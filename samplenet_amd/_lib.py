@@ -58,6 +58,8 @@ PROTOTYPES = {
                                 _vp, _vp, _vp, _vp],
     "sn_layer_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, ctypes.c_longlong, _vp],
+    "sn_layer_backward_in3_stats_floats": [_i, _i, _i],
+    "sn_layer_backward_in3": [_i, _i, _i] + [_vp] * 18 + [_vp],
     "sn_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_finalize": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_eval_coef": [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
@@ -75,7 +77,7 @@ PROTOTYPES = {
     "sn_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong,
-             "sn_pairscan_workspace_bytes": ctypes.c_longlong}
+             "sn_pairscan_workspace_bytes": ctypes.c_longlong, "sn_layer_backward_in3_stats_floats": ctypes.c_longlong}
 
 
 class SampleNetHipError(RuntimeError):

@@ -459,7 +459,7 @@ __device__ __forceinline__ BnBwdIn bn_bwd_inputs(const BnBwd &bb, int C, int c)
 {
     return BnBwdIn{bb.coef[c], bb.coef[2 * C + c], bb.coef[3 * C + c]};
 }
-__device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz, const BnBwdIn &in)
+__device__ __forceinline__ float3 bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz, const BnBwdIn &in)
 {
     const double scale = in.scale, mean = in.mean, invstd = in.invstd;
     const double dg = invstd * (sz - mean * s);
@@ -470,6 +470,7 @@ __device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int 
     const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
     bb.kcoef[c] = k1, bb.kcoef[C + c] = k2, bb.kcoef[2 * C + c] = k3;
     if (bb.dbias) bb.dbias[c] = (float)((double)k1 * s + (double)k2 * (double)bb.R * mean + (double)bb.R * (double)k3);
+    return make_float3(k1, k2, k3);
 }
 __device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz)
 {
@@ -808,6 +809,7 @@ struct ConvBwdArgs {
     const float *zprev, *scale_prev, *shift_prev;
     float *dyprev, *stats, *part;
     int ntiles;
+    const float *xin;  // IN3 only: (R,3) input of the layer below when that layer is the xyz input layer
 };
 
 // Global-memory access of the dgrad waves goes through raw buffer instructions: resource (SGPRs) + per-lane byte offset
@@ -974,13 +976,23 @@ struct CbfShape {
     static constexpr int BUF = TR * (LDZ + LDP);
     static constexpr int WSZ = WLDS ? CO * LDW : 0;
     static constexpr int TSZ = 4 * 32 * 36;  // per dgrad wave: 32 x 32 output fragment, transposed for 16-byte stores
+    static constexpr int XSZ = 2 * 3 * TR;   // IN3: the xyz rows of two tiles, coordinate-major [2][3][TR]
     static constexpr size_t LDS_BYTES = ((size_t)2 * BUF + WSZ + TSZ) * sizeof(float);
+    static constexpr size_t LDS_BYTES_IN3 = LDS_BYTES + XSZ * sizeof(float);
 };
 
-template <int CI, int CO, int ZMODE, bool FULLR>
+// IN3: the layer below is the xyz input layer (3 input channels, conv_in3_fwd_kernel).  Its weight gradient
+//   dW_in[c][d] = sum_r dZprev[r][c] x[r][d],   dZprev = k1 g + k2 Zprev + k3,  Zprev[r][c] = W_in[c] . x_r + b_in[c]
+// needs no pass of its own over the 8 MB of g = dYprev: with Gx[c][d] = sum_r g[r][c] x[r][d] accumulated HERE (3 more
+// sums per channel next to the two BatchNorm-backward sums) and the second moments of x,
+//   dW_in[c][d] = k1 Gx[c][d] + k2 (sum_e W_in[c][e] Sxx[e][d] + b_in[c] Sx[d]) + k3 Sx[d]        (post_bwd_in3_kernel).
+// Statistics partial per workgroup: [6][CI] = sum g, sum g Z, Gx[0..2], (Sx[3], Sxx[6] upper triangle, 0 ...).
+template <int CI, int CO, int ZMODE, bool FULLR, bool IN3 = false>
 __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
 {
     using S = CbfShape<CI, CO>;
+    static_assert(!IN3 || (S::TR == 64 && ZMODE == DZ_BN), "IN3: 64-row tiles (one row per lane for the moments)");
+    constexpr int NST = IN3 ? 5 : 2;  // per-channel sums of the dgrad epilogue
     constexpr int TR = S::TR, LDZ = S::LDZ, LDP = S::LDP, LDW = S::LDW;
     constexpr int ZB = TR * LDZ, BUF = S::BUF;
     constexpr int NZ4 = TR * CO / 4 / 256, NP4 = TR * CI / 4 / 256;  // float4 per dgrad-wave thread per tile
@@ -996,6 +1008,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *Ts = lds + 2 * BUF + S::WSZ + (wave & 3) * (32 * 36);  // this dgrad wave's transpose scratch [32][36]
+    float *Xs = lds + 2 * BUF + S::WSZ + S::TSZ;                    // IN3: [2][3][TR]
     const int R = g.dz.rows;
     const bool do_d = wave < 4;
     const int dwv = wave & 3;
@@ -1032,6 +1045,21 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
         const unsigned nclouds = ZMODE == DZ_POOL ? (unsigned)((R + g.dz.npts - 1) / g.dz.npts) : 1u;
         rs.argsel = make_rsrc(ZMODE == DZ_POOL ? (const void *)g.dz.argsel : (const void *)g.dz.z, nclouds * CO * 4);
         rs.gsel = make_rsrc(ZMODE == DZ_POOL ? (const void *)g.dz.gsel : (const void *)g.dz.z, nclouds * CO * 4);
+        // IN3: the tile's 3 TR input floats are one contiguous stretch: threads 0 .. 3 TR / 4 - 1 fetch 16 bytes each and
+        // scatter them coordinate-major into LDS (fixed per-thread slots)
+        const sn_rsrc rsx = make_rsrc(IN3 ? (const void *)g.xin : (const void *)g.dz.z, (unsigned)R * 12);
+        const bool xthr = IN3 && tid < 3 * TR / 4;
+        int xslot[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid * 4 + j;
+            xslot[j] = (i % 3) * TR + i / 3;
+        }
+        float4 rx = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
+        float mom[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mom[k] = 0.f;
         // cloud b and tile-within-cloud of the current tile, advanced without divisions (DZ_POOL: one cloud per tile)
         const int tpc = ZMODE == DZ_POOL ? g.dz.npts / TR : 1;
         const int bstep = G / tpc, tstep = G - bstep * tpc;
@@ -1050,6 +1078,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
 
         int tile = blockIdx.x;
         cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+        if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)tile * (TR * 12));
         if (WLDS) cbf_stage_w<CI, CO, LDW>(g.W, Ws, tid);  // requested after the first tile: its staging does not wait for W
         if (!WLDS) {  // dgrad B fragments in registers, k = 2 s + h (requested after the first tile)
 #pragma unroll
@@ -1057,6 +1086,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
         }
         cbf_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, tile, tic * TR, tid, lds, lds + ZB, rz, rdy, rp, rag, rgs, k1, k2, k3, sc4,
                                                       sh4);
+        if (xthr) Xs[xslot[0]] = rx.x, Xs[xslot[1]] = rx.y, Xs[xslot[2]] = rx.z, Xs[xslot[3]] = rx.w;
         __syncthreads();
         for (int it = 0; tile < g.ntiles; ++it, tile += G) {
             const float *Zs = lds + (it & 1) * BUF;
@@ -1082,6 +1112,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
                 if (ntic >= tpc) ntic -= tpc, ++ncloud;
             }
             cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+            if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)nxt * (TR * 12));
             if (it == 1) SN_TL(5);
 
             f32x16 acc;
@@ -1116,8 +1147,29 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
                 const float v = fmaf(z, scd, shd) > 0.f ? acc[e] : 0.f;
                 s0 += v;
                 s1 += v * z;
+                if (IN3) acc[e] = v;
                 Ts[frag_row(e, lane) * 36 + l31] = v;  // a dword store per fragment element costs ~58 issue cycles per
             }                                            // wave-instruction: transpose in LDS, store 16 bytes per lane
+            if (IN3) {
+                // rows of fragment elements 4 q .. 4 q + 3 are consecutive (frag_row): one 16-byte LDS read per coordinate
+                const float *Xc = Xs + (it & 1) * (3 * TR);
+                const float *xp = Xc + rb * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xp + 8 * q);
+                    const float4 x1 = *reinterpret_cast<const float4 *>(xp + TR + 8 * q);
+                    const float4 x2 = *reinterpret_cast<const float4 *>(xp + 2 * TR + 8 * q);
+                    gx0 = fmaf(acc[4 * q + 3], x0.w, fmaf(acc[4 * q + 2], x0.z, fmaf(acc[4 * q + 1], x0.y, fmaf(acc[4 * q], x0.x, gx0))));
+                    gx1 = fmaf(acc[4 * q + 3], x1.w, fmaf(acc[4 * q + 2], x1.z, fmaf(acc[4 * q + 1], x1.y, fmaf(acc[4 * q], x1.x, gx1))));
+                    gx2 = fmaf(acc[4 * q + 3], x2.w, fmaf(acc[4 * q + 2], x2.z, fmaf(acc[4 * q + 1], x2.y, fmaf(acc[4 * q], x2.x, gx2))));
+                }
+                if (wave == 0) {  // moments of x: lane = row of the tile (rows past R were fetched as zeros)
+                    const float a = Xc[lane], b = Xc[TR + lane], c = Xc[2 * TR + lane];
+                    mom[0] += a, mom[1] += b, mom[2] += c;
+                    mom[3] = fmaf(a, a, mom[3]), mom[4] = fmaf(a, b, mom[4]), mom[5] = fmaf(a, c, mom[5]);
+                    mom[6] = fmaf(b, b, mom[6]), mom[7] = fmaf(b, c, mom[7]), mom[8] = fmaf(c, c, mom[8]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) vout[i] = *reinterpret_cast<const float4 *>(Ts + (8 * i + (lane >> 3)) * 36 + (lane & 7) * 4);
             if (it == 1) SN_TL(2);
@@ -1125,6 +1177,10 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
                 float *Zn = lds + ((it + 1) & 1) * BUF;
                 cbf_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, nxt, ntic * TR, tid, Zn, Zn + ZB, rz, rdy, rp, rag, rgs, k1, k2, k3,
                                                               sc4, sh4);
+                if (xthr) {
+                    float *Xn = Xs + ((it + 1) & 1) * (3 * TR);
+                    Xn[xslot[0]] = rx.x, Xn[xslot[1]] = rx.y, Xn[xslot[2]] = rx.z, Xn[xslot[3]] = rx.w;
+                }
             }
             cloud = ncloud, tic = ntic;
             if (it == 1) SN_TL(3);
@@ -1138,11 +1194,28 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
             for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
         }
         // BatchNorm-backward sums of the layer below: halves of a wave, then the row blocks, fixed order
-        float *red = lds;  // [RB][2][CI]   (every wave is past its last LDS read: barrier at the end of the loop)
+        float *red = lds;  // [RB][NST][CI]   (every wave is past its last LDS read: barrier at the end of the loop)
         const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
         if (lane < 32) {
-            red[(rb * 2 + 0) * CI + cb * 32 + lane] = t0;
-            red[(rb * 2 + 1) * CI + cb * 32 + lane] = t1;
+            red[(rb * NST + 0) * CI + cb * 32 + lane] = t0;
+            red[(rb * NST + 1) * CI + cb * 32 + lane] = t1;
+        }
+        if (IN3) {
+            const float u0 = gx0 + __shfl_xor(gx0, 32), u1 = gx1 + __shfl_xor(gx1, 32), u2 = gx2 + __shfl_xor(gx2, 32);
+            if (lane < 32) {
+                red[(rb * NST + 2) * CI + cb * 32 + lane] = u0;
+                red[(rb * NST + 3) * CI + cb * 32 + lane] = u1;
+                red[(rb * NST + 4) * CI + cb * 32 + lane] = u2;
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    float m = mom[k];
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) m += __shfl_xor(m, o);
+                    if (lane == 0) red[RB * NST * CI + k] = m;
+                }
+            }
         }
     } else {
         // ---------------- weight-gradient waves ----------------------------------------------------------
@@ -1181,7 +1254,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
         // weight-gradient partial of this workgroup: each 32 x 32 fragment transposed through LDS (the tile buffers are
         // dead: every wave is past the loop's last barrier), 4 x 16-byte stores per lane instead of 16 dword stores
         float *P = g.part + (size_t)blockIdx.x * CO * CI;
-        float *Tw = lds + 4 * CI + (wave - 4) * (32 * 36);  // behind the dgrad waves' statistics area [RB][2][CI]
+        float *Tw = lds + RB * NST * CI + 16 + (wave - 4) * (32 * 36);  // behind the dgrad waves' statistics area
 #pragma unroll
         for (int n = 0; n < NWT; ++n) {
             const int colb = ((q0 + n) % NCB) * 32;
@@ -1198,11 +1271,14 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
     __syncthreads();
     if (tid < CI) {
         const float *red = lds;
-        float *st = g.stats + (size_t)blockIdx.x * 2 * CI;
-        float a0 = red[tid], a1 = red[CI + tid];
-        if (RB == 2) a0 += red[2 * CI + tid], a1 += red[3 * CI + tid];
-        st[tid] = a0;
-        st[CI + tid] = a1;
+        float *st = g.stats + (size_t)blockIdx.x * (IN3 ? 6 : 2) * CI;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            float a = red[k * CI + tid];
+            if (RB == 2) a += red[(NST + k) * CI + tid];
+            st[k * CI + tid] = a;
+        }
+        if (IN3) st[5 * CI + tid] = tid < 9 ? red[RB * NST * CI + tid] : 0.f;
     }
     SN_TL_DRAIN();
     SN_TL(7);
@@ -1767,26 +1843,28 @@ __global__ void __launch_bounds__(1024) wgrad_reduce_kernel(int nsplit, int Co, 
 // with the usual 256..512 row blocks every thread has at most 8 loads, all in flight together -- one memory round trip),
 // in double, fixed order.  Returns true on the threads (slice 0) that hold the totals.
 constexpr int kSlices = 128, kChan = 8;
-__device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__restrict__ stats, int cblock, double &s0, double &s1)
+typedef double PsRed[kSlices][kChan];
+typedef double PsRed2[16][kChan];
+__device__ __forceinline__ bool partial_sums_in(PsRed *red, PsRed2 *red2, int nblk, int C, const float *__restrict__ stats,
+                                                int cblock, double &s0, double &s1, int bstride)
 {
-    __shared__ double red[2][kSlices][kChan];
-    __shared__ double red2[2][16][kChan];
+    const size_t bs = bstride > 0 ? (size_t)bstride : (size_t)2 * C;  // floats between the partials of consecutive blocks
     const int cl = threadIdx.x & (kChan - 1), sl = threadIdx.x >> 3;
     const int c = cblock * kChan + cl;
     double a0 = 0.0, a1 = 0.0;
     if (c < C) {
         int b = sl;
         for (; b + 3 * kSlices < nblk; b += 4 * kSlices) {  // 8 independent loads in flight
-            const float x0 = stats[((size_t)b * 2 + 0) * C + c], y0 = stats[((size_t)b * 2 + 1) * C + c];
-            const float x1 = stats[((size_t)(b + kSlices) * 2 + 0) * C + c], y1 = stats[((size_t)(b + kSlices) * 2 + 1) * C + c];
-            const float x2 = stats[((size_t)(b + 2 * kSlices) * 2 + 0) * C + c], y2 = stats[((size_t)(b + 2 * kSlices) * 2 + 1) * C + c];
-            const float x3 = stats[((size_t)(b + 3 * kSlices) * 2 + 0) * C + c], y3 = stats[((size_t)(b + 3 * kSlices) * 2 + 1) * C + c];
+            const float x0 = stats[(size_t)b * bs + c], y0 = stats[(size_t)b * bs + C + c];
+            const float x1 = stats[(size_t)(b + kSlices) * bs + c], y1 = stats[(size_t)(b + kSlices) * bs + C + c];
+            const float x2 = stats[(size_t)(b + 2 * kSlices) * bs + c], y2 = stats[(size_t)(b + 2 * kSlices) * bs + C + c];
+            const float x3 = stats[(size_t)(b + 3 * kSlices) * bs + c], y3 = stats[(size_t)(b + 3 * kSlices) * bs + C + c];
             a0 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
             a1 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
         }
         for (; b < nblk; b += kSlices) {
-            a0 += (double)stats[((size_t)b * 2 + 0) * C + c];
-            a1 += (double)stats[((size_t)b * 2 + 1) * C + c];
+            a0 += (double)stats[(size_t)b * bs + c];
+            a1 += (double)stats[(size_t)b * bs + C + c];
         }
     }
     red[0][sl][cl] = a0, red[1][sl][cl] = a1;
@@ -1803,6 +1881,13 @@ __device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__res
 #pragma unroll
     for (int q = 0; q < 16; ++q) s0 += red2[0][q][cl], s1 += red2[1][q][cl];
     return true;
+}
+
+__device__ __forceinline__ bool partial_sums(int nblk, int C, const float *__restrict__ stats, int cblock, double &s0, double &s1)
+{
+    __shared__ double red[2][kSlices][kChan];
+    __shared__ double red2[2][16][kChan];
+    return partial_sums_in(red, red2, nblk, C, stats, cblock, s0, s1, 0);
 }
 
 // training: batch statistics from the forward partials -> coef [4][C] = scale, shift, mean, invstd;
@@ -1945,6 +2030,118 @@ __global__ void __launch_bounds__(1024) post_bwd_kernel(int nred, int nsplit, in
     if (threadIdx.x < kChan && c < C) in = bn_bwd_inputs(bb, C, c);
     if (!partial_sums(nblk, C, stats, cblock, s, sz)) return;
     bn_backward_channel(bb, C, c, s, sz, in);
+}
+
+// post_bwd_kernel behind the IN3 variant of conv_bwd_fused_kernel (statistics partials [nblk][6][C], see there): the BatchNorm
+// workgroups also finish the weight gradient of the xyz input layer below, in closed form and in double:
+//   dW_in[c][d] = k1 Gx[c][d] + k2 (sum_e W_in[c][e] Sxx[e][d] + b_in[c] Sx[d]) + k3 Sx[d]
+__global__ void __launch_bounds__(1024) post_bwd_in3_kernel(int nred, int nsplit, int Co, int Ci, const float *__restrict__ part,
+                                                            float *__restrict__ dW, int nblk, int C,
+                                                            const float *__restrict__ stats, BnBwd bb,
+                                                            const float *__restrict__ W_in, const float *__restrict__ b_in,
+                                                            float *__restrict__ dW_in)
+{
+    if ((int)blockIdx.x < nred) {
+        __shared__ float red[16][64];
+        const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const int e = blockIdx.x * 64 + el;
+        const size_t stride = (size_t)Co * Ci;
+        float acc = 0.f;
+        if (e < Co * Ci) {
+            const float *p = part + e;
+            int sp = sl;
+            for (; sp + 7 * 16 < nsplit; sp += 8 * 16) {
+                const float v0 = p[(size_t)sp * stride], v1 = p[(size_t)(sp + 16) * stride];
+                const float v2 = p[(size_t)(sp + 32) * stride], v3 = p[(size_t)(sp + 48) * stride];
+                const float v4 = p[(size_t)(sp + 64) * stride], v5 = p[(size_t)(sp + 80) * stride];
+                const float v6 = p[(size_t)(sp + 96) * stride], v7 = p[(size_t)(sp + 112) * stride];
+                acc += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+            }
+            for (; sp < nsplit; sp += 16) acc += p[(size_t)sp * stride];
+        }
+        red[sl][el] = acc;
+        __syncthreads();
+        if (sl == 0 && e < Co * Ci) {
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += red[q][el];
+            dW[e] = tot;
+        }
+        return;
+    }
+    // one memory round trip for everything this workgroup needs: thread (channel cl, slice sl) loads the five sums of its
+    // channel from blocks sl, sl + 128, ...; threads 0 .. 575 also load the nine moments (9 x 64 slices)
+    __shared__ double mred[9][64];
+    __shared__ double mtot[9];
+    __shared__ double red[5][kSlices][kChan];
+    __shared__ double red2[5][16][kChan];
+    const int cblock = (int)blockIdx.x - nred;
+    const int cl = threadIdx.x & (kChan - 1), sl = threadIdx.x >> 3;
+    const int c = cblock * kChan + cl;
+    const size_t bs = (size_t)6 * C;
+    BnBwdIn in{};
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f, bi = 0.f;
+    if (threadIdx.x < kChan && c < C) {
+        in = bn_bwd_inputs(bb, C, c);
+        w0 = W_in[c * 3], w1 = W_in[c * 3 + 1], w2 = W_in[c * 3 + 2];
+        if (b_in) bi = b_in[c];
+    }
+    double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c < C) {
+        int b = sl;
+        for (; b + kSlices < nblk; b += 2 * kSlices) {  // 10 independent loads in flight
+            float u[5], v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) u[k] = stats[(size_t)b * bs + k * C + c], v[k] = stats[(size_t)(b + kSlices) * bs + k * C + c];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a[k] += (double)u[k] + (double)v[k];
+        }
+        for (; b < nblk; b += kSlices) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a[k] += (double)stats[(size_t)b * bs + k * C + c];
+        }
+    }
+    double ma = 0.0;
+    if (threadIdx.x < 9 * 64) {
+        const int m = threadIdx.x >> 6, ms = threadIdx.x & 63;
+        for (int b = ms; b < nblk; b += 64) ma += (double)stats[(size_t)b * bs + 5 * C + m];
+        mred[m][ms] = ma;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) red[k][sl][cl] = a[k];
+    __syncthreads();
+    if (sl < 16) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[k][sl * 8 + q][cl];
+            red2[k][sl][cl] = t;
+        }
+    } else if (threadIdx.x >= 512 && threadIdx.x < 512 + 9) {
+        const int m = threadIdx.x - 512;
+        double t = 0.0;
+        for (int q = 0; q < 64; ++q) t += mred[m][q];
+        mtot[m] = t;
+    }
+    __syncthreads();
+    const bool own = sl == 0 && c < C;
+    double s = 0.0, sz = 0.0, g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    if (own) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            s += red2[0][q][cl], sz += red2[1][q][cl], g0 += red2[2][q][cl], g1 += red2[3][q][cl], g2 += red2[4][q][cl];
+    }
+    if (!own) return;
+    const float3 k = bn_backward_channel(bb, C, c, s, sz, in);
+    const double Sx[3] = {mtot[0], mtot[1], mtot[2]};
+    const double Sxx[3][3] = {{mtot[3], mtot[4], mtot[5]}, {mtot[4], mtot[6], mtot[7]}, {mtot[5], mtot[7], mtot[8]}};
+    const double gx[3] = {g0, g1, g2};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double zx = (double)w0 * Sxx[0][d] + (double)w1 * Sxx[1][d] + (double)w2 * Sxx[2][d] + (double)bi * Sx[d];
+        dW_in[c * 3 + d] = (float)((double)k.x * gx[d] + (double)k.y * zx + (double)k.z * Sx[d]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2582,6 +2779,54 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
     const int nred = (Co * Ci + 63) / 64;
     hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, nsplit, Co, Ci, part, dW, nblk, Ci,
                        stats, bb);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// sn_layer_backward for the layer that sits on the xyz input layer (Ci -> Co on top of 3 -> Ci): the fused backward
+// also accumulates what the input layer's weight gradient needs (conv_bwd_fused_kernel IN3, post_bwd_in3_kernel), so that
+// gradient costs no pass of its own over dYprev.  stats: sn_layer_backward_in3_stats_floats(R, Ci, Co) floats (0 = shape
+// not supported: use sn_layer_backward + sn_linear_wgrad).
+extern "C" long long sn_layer_backward_in3_stats_floats(int R, int Ci, int Co)
+{
+    if (R < 1 || !(Ci == 64 && Co == 64) || !conv_bwd_fused_shape(R, Ci, Co)) return 0;
+    return (long long)conv_bwd_fused_groups(R) * 6 * Ci;
+}
+
+extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z, const float *kcoef, const float *W,
+                                     const float *zprev, const float *coef_prev, float *dyprev, float *stats, float *part,
+                                     float *dW, float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef,
+                                     const float *x_in, const float *W_in, const float *b_in, float *dW_in, sn_stream_t stream)
+{
+    SN_REQUIRE(sn_layer_backward_in3_stats_floats(R, Ci, Co) > 0, "shape not supported by the input-layer variant");
+    SN_REQUIRE(dy && z && kcoef && W && zprev && coef_prev && dyprev && stats && part && dW, "null pointer");
+    SN_REQUIRE(prev_dgamma && prev_dbeta && prev_kcoef && x_in && W_in && dW_in, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    ConvBwdArgs a{};
+    a.dz.mode = DZ_BN, a.dz.dy = dy, a.dz.z = z, a.dz.rows = R, a.dz.ch = Co, a.dz.npts = 1;
+    a.dz.k1 = kcoef, a.dz.k2 = kcoef + Co, a.dz.k3 = kcoef + 2 * Co;
+    a.W = W, a.zprev = zprev, a.scale_prev = coef_prev, a.shift_prev = coef_prev + Ci;
+    a.dyprev = dyprev, a.stats = stats, a.part = part, a.xin = x_in;
+    constexpr int TR = CbfShape<64, 64>::TR;
+    a.ntiles = (R + TR - 1) / TR;
+    const int G = conv_bwd_fused_groups(R);
+    constexpr size_t lds = CbfShape<64, 64>::LDS_BYTES_IN3;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<64, 64, DZ_BN, true, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<64, 64, DZ_BN, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (R % TR == 0)
+        hipLaunchKernelGGL((conv_bwd_fused_kernel<64, 64, DZ_BN, true, true>), dim3(G), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL((conv_bwd_fused_kernel<64, 64, DZ_BN, false, true>), dim3(G), dim3(512), lds, st, a);
+    const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, (long long)R};
+    const int nred = (Co * Ci + 63) / 64;
+    hipLaunchKernelGGL(post_bwd_in3_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW, G,
+                       Ci, stats, bb, W_in, b_in, dW_in);
     SN_LAUNCH_CHECK();
     return 0;
 }

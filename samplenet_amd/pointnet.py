@@ -158,6 +158,7 @@ _SIDE = {}
 # measured on MI355X / ROCm 7.2: inside a replayed hipGraph the fork/join edges cost more than the overlap buys
 # (0.73 vs 0.60 ms per step at B = 32), so the side stream is opt-in
 USE_SIDE_STREAM = os.environ.get("SAMPLENET_AMD_WGRAD_SIDE_STREAM", "0") != "0"
+IN3_CLOSED_FORM = os.environ.get("SAMPLENET_AMD_IN3_CLOSED_FORM", "1") != "0"
 FUSE_POOL = os.environ.get("SAMPLENET_AMD_FUSE_POOL", "1") != "0"  # A/B switch for the pooling fused into the last conv layer
 
 
@@ -302,8 +303,27 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
 
     # ---- conv stack (rows = B*N): conv5 -> ... -> conv2 (each also finishes the BatchNorm of the layer below), conv1 ----
     dy = None
+    in3_floats = lib.sn_layer_backward_in3_stats_floats(R, convs[1].Ci, convs[1].Co) if (IN3_CLOSED_FORM and convs[0].Ci == 3) else 0
     for i in (4, 3, 2, 1):
         L = convs[i]
+        if i == 1 and in3_floats > 0:
+            # conv2 sits on the xyz input layer: its fused backward also yields conv1's weight gradient (closed form from
+            # three extra per-channel sums + the moments of x: no pass of its own over dY1)
+            Lp = convs[0]
+            dW = _out(sink, names_c[1] + ".weight", L.W)
+            dW0 = _out(sink, names_c[0] + ".weight", Lp.W)
+            dg, dbt = _out(sink, bn_c[0] + ".weight", Lp.bn.weight), _out(sink, bn_c[0] + ".bias", Lp.bn.bias)
+            dbs = _out(sink, names_c[0] + ".bias", Lp.b)
+            dy1 = _empty((R, L.Ci), L.W)
+            stats = _empty((in3_floats,), L.W)
+            part = _empty((lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 0) * L.Co * L.Ci,), L.W)
+            kc = _empty((3, L.Ci), L.W)
+            check(lib.sn_layer_backward_in3(R, L.Ci, L.Co, ptr(dy), ptr(zc[1]), ptr(kcoef), ptr(L.W), ptr(zc[0]), ptr(cc[0]),
+                                            ptr(dy1), ptr(stats), ptr(part), ptr(dW), ptr(dg), ptr(dbt), ptr(dbs), ptr(kc),
+                                            ptr(saved["x"]), ptr(Lp.W), ptr(Lp.b), ptr(dW0), _st(L.W)), "sn_layer_backward_in3")
+            grads[names_c[1] + ".weight"], grads[names_c[0] + ".weight"] = dW, dW0
+            grads[bn_c[0] + ".weight"], grads[bn_c[0] + ".bias"], grads[names_c[0] + ".bias"] = dg, dbt, dbs
+            break
         mode = DZ_POOL if i == 4 else DZ_BN
         gs, ag = (gsel, saved["argsel"]) if i == 4 else (None, None)
         dW, _, dy, dg, dbt, dbs, kc = _layer_bwd(R, L, mode, dy, zc[i], kcoef, gs, ag, N, zc[i - 1], cc[i - 1], convs[i - 1],
@@ -311,8 +331,9 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
         grads[names_c[i] + ".weight"] = dW
         grads[bn_c[i - 1] + ".weight"], grads[bn_c[i - 1] + ".bias"], grads[names_c[i - 1] + ".bias"] = dg, dbt, dbs
         kcoef = kc
-    dW, _ = _wgrad(R, convs[0], DZ_BN, dy, zc[0], kcoef, None, None, N, saved["x"].view(R, 3), None, False, sink, names_c[0])
-    grads[names_c[0] + ".weight"] = dW
+    else:
+        dW, _ = _wgrad(R, convs[0], DZ_BN, dy, zc[0], kcoef, None, None, N, saved["x"].view(R, 3), None, False, sink, names_c[0])
+        grads[names_c[0] + ".weight"] = dW
     _join_side(grad_y.device)  # all weight gradients complete before backward returns on the main stream
     return grads
 

@@ -211,6 +211,43 @@ def test_fused_pooling_equals_separate_pass(B, N):
         assert torch.equal(ba, bb), n
 
 
+@pytest.mark.parametrize("B,N", [(32, 1024), (5, 320), (3, 330), (33, 1024)])
+def test_input_layer_weight_gradient_closed_form(B, N):
+    """conv1's weight gradient taken out of conv2's fused backward (three extra per-channel sums + the moments of x,
+    combined in double: sn_layer_backward_in3) against the separate pass over dY1 (sn_layer_backward + sn_linear_wgrad):
+    conv1.weight within 2e-5 of its norm (different summation order, same cancellation), every other gradient bit-equal
+    (the dgrad / wgrad arithmetic of conv2 is unchanged).  R = B*N both a multiple of the 64-row tile and not."""
+    import copy
+
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(B + N)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    with torch.no_grad():
+        net_a.bn1.weight[::4] *= -1.0
+        net_a.bn1.bias.add_(0.1 * torch.randn_like(net_a.bn1.bias))
+    net_b = copy.deepcopy(net_a)
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5) * torch.tensor([1.0, 0.6, 1.4], device="cuda") + 0.05
+    from samplenet_amd._lib import lib
+    assert lib.sn_layer_backward_in3_stats_floats(B * N, 64, 64) > 0
+    g = torch.randn(B, 3, 64, device="cuda")
+    old = pointnet.IN3_CLOSED_FORM
+    try:
+        pointnet.IN3_CLOSED_FORM = True
+        (net_a._features(x.permute(0, 2, 1), x) * g).sum().backward()
+        pointnet.IN3_CLOSED_FORM = False
+        (net_b._features(x.permute(0, 2, 1), x) * g).sum().backward()
+    finally:
+        pointnet.IN3_CLOSED_FORM = old
+    for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        if n.startswith("project"):
+            continue
+        if n == "conv1.weight":
+            assert _rel(pa.grad, pb.grad) <= 2e-5, (n, _rel(pa.grad, pb.grad))
+        else:
+            assert torch.equal(pa.grad, pb.grad), n
+
+
 @pytest.mark.parametrize("B,N,shape", [(4, 1024, "bcn"), (3, 64, "bnc"), (2, 200, "bcn")])
 def test_task_network_features_vs_torch(B, N, shape):
     """samplenet_amd.task_features.PointNetFeatures (rows a12 / f1: registration/models/pcrnet.py:8-41 -- five 1x1 convs with
