@@ -289,11 +289,12 @@ int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const
                       sn_stream_t stream);
 /* sn_layer_backward (dz_mode = SN_DZ_BN) for the layer that sits on the xyz input layer (3 -> Ci, x_in (R,3), W_in (Ci,3),
  * b_in (Ci) or NULL): also returns dW_in (Ci,3), the input layer's weight gradient, in closed form from three extra
- * per-channel sums and the second moments of x_in accumulated by the same kernel -- no separate pass over dYprev.
+ * per-channel sums and the second moments of x_in accumulated by the same kernel -- no separate pass over dYprev, which
+ * is not written at all (the input layer has no gradient to pass further down).
  * stats: sn_layer_backward_in3_stats_floats(R, Ci, Co) floats; that function returns 0 when the shape is not supported. */
 long long sn_layer_backward_in3_stats_floats(int R, int Ci, int Co);
 int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z, const float *kcoef, const float *W,
-                          const float *zprev, const float *coef_prev, float *dyprev, float *stats, float *part, float *dW,
+                          const float *zprev, const float *coef_prev, float *stats, float *part, float *dW,
                           float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef, const float *x_in,
                           const float *W_in, const float *b_in, float *dW_in, sn_stream_t stream);
 /* prev_bn_rows (R <= 32 only, 0 = R): rows seen by the BatchNorm of the layer below when they differ from R -- the FC head's

@@ -59,7 +59,7 @@ PROTOTYPES = {
     "sn_layer_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                           _vp, ctypes.c_longlong, _vp],
     "sn_layer_backward_in3_stats_floats": [_i, _i, _i],
-    "sn_layer_backward_in3": [_i, _i, _i] + [_vp] * 18 + [_vp],
+    "sn_layer_backward_in3": [_i, _i, _i] + [_vp] * 17 + [_vp],
     "sn_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_finalize": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_eval_coef": [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp],

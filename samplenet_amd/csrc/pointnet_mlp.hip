@@ -1092,7 +1092,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
             const float *Zs = lds + (it & 1) * BUF;
             // dYprev of the previous tile goes out first: vmcnt retires in order, so stores issued after the loads below
             // would be waited for together with them
-            if (it > 0) {
+            if (!IN3 && it > 0) {  // (IN3: nobody reads dYprev -- the input layer's weight gradient comes from the sums below)
                 const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
@@ -1148,8 +1148,8 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
                 s0 += v;
                 s1 += v * z;
                 if (IN3) acc[e] = v;
-                Ts[frag_row(e, lane) * 36 + l31] = v;  // a dword store per fragment element costs ~58 issue cycles per
-            }                                            // wave-instruction: transpose in LDS, store 16 bytes per lane
+                if (!IN3) Ts[frag_row(e, lane) * 36 + l31] = v;  // a dword store per fragment element costs ~58 issue cycles
+            }                                                      // per wave-instruction: transpose in LDS, 16-byte stores
             if (IN3) {
                 // rows of fragment elements 4 q .. 4 q + 3 are consecutive (frag_row): one 16-byte LDS read per coordinate
                 const float *Xc = Xs + (it & 1) * (3 * TR);
@@ -1170,8 +1170,10 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
                     mom[6] = fmaf(b, b, mom[6]), mom[7] = fmaf(b, c, mom[7]), mom[8] = fmaf(c, c, mom[8]);
                 }
             }
+            if (!IN3) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) vout[i] = *reinterpret_cast<const float4 *>(Ts + (8 * i + (lane >> 3)) * 36 + (lane & 7) * 4);
+                for (int i = 0; i < 4; ++i) vout[i] = *reinterpret_cast<const float4 *>(Ts + (8 * i + (lane >> 3)) * 36 + (lane & 7) * 4);
+            }
             if (it == 1) SN_TL(2);
             if (more) {
                 float *Zn = lds + ((it + 1) & 1) * BUF;
@@ -1188,7 +1190,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
             if (it == 1) SN_TL(4);
         }
         SN_TL(6);
-        if (tile != (int)blockIdx.x) {  // dYprev of the last tile
+        if (!IN3 && tile != (int)blockIdx.x) {  // dYprev of the last tile
             const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
@@ -2785,7 +2787,7 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
 
 // sn_layer_backward for the layer that sits on the xyz input layer (Ci -> Co on top of 3 -> Ci): the fused backward
 // also accumulates what the input layer's weight gradient needs (conv_bwd_fused_kernel IN3, post_bwd_in3_kernel), so that
-// gradient costs no pass of its own over dYprev.  stats: sn_layer_backward_in3_stats_floats(R, Ci, Co) floats (0 = shape
+// gradient costs no pass of its own over dYprev -- which is then not even written (8 MB less traffic).  stats: sn_layer_backward_in3_stats_floats(R, Ci, Co) floats (0 = shape
 // not supported: use sn_layer_backward + sn_linear_wgrad).
 extern "C" long long sn_layer_backward_in3_stats_floats(int R, int Ci, int Co)
 {
@@ -2794,19 +2796,19 @@ extern "C" long long sn_layer_backward_in3_stats_floats(int R, int Ci, int Co)
 }
 
 extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z, const float *kcoef, const float *W,
-                                     const float *zprev, const float *coef_prev, float *dyprev, float *stats, float *part,
+                                     const float *zprev, const float *coef_prev, float *stats, float *part,
                                      float *dW, float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef,
                                      const float *x_in, const float *W_in, const float *b_in, float *dW_in, sn_stream_t stream)
 {
     SN_REQUIRE(sn_layer_backward_in3_stats_floats(R, Ci, Co) > 0, "shape not supported by the input-layer variant");
-    SN_REQUIRE(dy && z && kcoef && W && zprev && coef_prev && dyprev && stats && part && dW, "null pointer");
+    SN_REQUIRE(dy && z && kcoef && W && zprev && coef_prev && stats && part && dW, "null pointer");
     SN_REQUIRE(prev_dgamma && prev_dbeta && prev_kcoef && x_in && W_in && dW_in, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     ConvBwdArgs a{};
     a.dz.mode = DZ_BN, a.dz.dy = dy, a.dz.z = z, a.dz.rows = R, a.dz.ch = Co, a.dz.npts = 1;
     a.dz.k1 = kcoef, a.dz.k2 = kcoef + Co, a.dz.k3 = kcoef + 2 * Co;
     a.W = W, a.zprev = zprev, a.scale_prev = coef_prev, a.shift_prev = coef_prev + Ci;
-    a.dyprev = dyprev, a.stats = stats, a.part = part, a.xin = x_in;
+    a.dyprev = nullptr, a.stats = stats, a.part = part, a.xin = x_in;  // dYprev is not materialised: nothing reads it
     constexpr int TR = CbfShape<64, 64>::TR;
     a.ntiles = (R + TR - 1) / TR;
     const int G = conv_bwd_fused_groups(R);

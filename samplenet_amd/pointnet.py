@@ -314,12 +314,11 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
             dW0 = _out(sink, names_c[0] + ".weight", Lp.W)
             dg, dbt = _out(sink, bn_c[0] + ".weight", Lp.bn.weight), _out(sink, bn_c[0] + ".bias", Lp.bn.bias)
             dbs = _out(sink, names_c[0] + ".bias", Lp.b)
-            dy1 = _empty((R, L.Ci), L.W)
             stats = _empty((in3_floats,), L.W)
             part = _empty((lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 0) * L.Co * L.Ci,), L.W)
             kc = _empty((3, L.Ci), L.W)
             check(lib.sn_layer_backward_in3(R, L.Ci, L.Co, ptr(dy), ptr(zc[1]), ptr(kcoef), ptr(L.W), ptr(zc[0]), ptr(cc[0]),
-                                            ptr(dy1), ptr(stats), ptr(part), ptr(dW), ptr(dg), ptr(dbt), ptr(dbs), ptr(kc),
+                                            ptr(stats), ptr(part), ptr(dW), ptr(dg), ptr(dbt), ptr(dbs), ptr(kc),
                                             ptr(saved["x"]), ptr(Lp.W), ptr(Lp.b), ptr(dW0), _st(L.W)), "sn_layer_backward_in3")
             grads[names_c[1] + ".weight"], grads[names_c[0] + ".weight"] = dW, dW0
             grads[bn_c[0] + ".weight"], grads[bn_c[0] + ".bias"], grads[names_c[0] + ".bias"] = dg, dbt, dbs
