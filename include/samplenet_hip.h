@@ -282,6 +282,20 @@ int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, c
                             float momentum, float *running_mean, float *running_var, long long *num_batches_tracked,
                             float *coef, float *pool_val, int *pool_idx, float *pooled, int *argsel, float *zsel,
                             sn_stream_t stream);
+/* The training-mode conv stack (conv/bn/relu x nlayers on the xyz cloud + max over the points, samplenet.py:90-95) in one
+ * call and nlayers + 1 launches.  Batch statistics travel as 64-bit fixed-point sums accumulated with integer atomics
+ * (order-independent, hence deterministic); each layer finalises the BatchNorm of its input itself, so no reduction launch
+ * sits between layers.  channels [nlayers+1] = 3, C1..Cn (64 or 128 each); N % 64 == 0 (query _supported first).
+ * Arrays of nlayers device pointers: W (C_{l+1},C_l), bias, gamma, beta, running_mean, running_var, num_batches_tracked,
+ * z (B*N,C_{l+1}) pre-BN outputs, coef (4,C_{l+1}); eps / momentum: host arrays.  acc: sn_conv_stack_acc_elems(nlayers) long long of persistent
+ * device scratch, zero before the first call (every call leaves it zero).  pool_val / pool_idx: (B*N/64)*2*Cn scratch. */
+int sn_conv_stack_forward_supported(int B, int N, int nlayers, const int *channels);
+long long sn_conv_stack_acc_elems(int nlayers);
+int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
+                             const float *const *bias, const float *const *gamma, const float *const *beta,
+                             float *const *running_mean, float *const *running_var, long long *const *num_batches_tracked,
+                             const float *eps, const float *momentum, float *const *z, float *const *coef, long long *acc,
+                             float *pool_val, int *pool_idx, float *pooled, int *argsel, float *zsel, sn_stream_t stream);
 int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                       const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                       const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,

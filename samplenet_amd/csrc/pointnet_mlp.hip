@@ -57,7 +57,32 @@ __device__ __forceinline__ float4 ld4_guard(const float *__restrict__ p, size_t 
     return v;
 }
 
-enum { ACT_NONE = 0, ACT_BN_RELU = 1 };
+enum { ACT_NONE = 0, ACT_BN_RELU = 1, ACT_BN_RELU_FX = 2 };
+
+// Batch statistics as 64-bit fixed point (2^-26 units) accumulated with integer atomics: integer addition is associative,
+// so the totals do not depend on the order the workgroups arrive in (deterministic, unlike floating-point atomics), and the
+// CONSUMER of the statistics (the next layer's GEMM) can finalise the BatchNorm itself from 2 C numbers -- no
+// partials-reduction launch between two layers.  Range +-1.4e11, resolution 1.5e-8 per contribution.
+constexpr double kFxScale = 67108864.0;
+// Same-address device-scope atomics serialise at the memory side (~20 ns per 128-byte line operation, measured: 512
+// workgroups adding into one set of 2 C sums cost ~10 us per layer): the workgroups spread over kFxSlots copies
+// (swept 4 / 8 / 16 / 32: 243.5 / 240.3 / 239.2 / 255.5 us per step).
+#ifndef SN_FX_SLOTS
+#define SN_FX_SLOTS 16
+#endif
+constexpr int kFxSlots = SN_FX_SLOTS;
+constexpr int kFxLayer = kFxSlots * 256;  // long long per layer: [kFxSlots][2][128]
+__device__ __forceinline__ void fx_add(long long *acc, float v)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)__double2ll_rn((double)v * kFxScale));
+}
+__device__ __forceinline__ double fx_get(const long long *acc)  // total over the slots
+{
+    long long t = 0;
+#pragma unroll
+    for (int q = 0; q < kFxSlots; ++q) t += acc[q * 256];
+    return (double)t * (1.0 / kFxScale);
+}
 enum { DZ_PLAIN = 0, DZ_BN = 1, DZ_POOL = 2 };
 
 // activation of the previous layer, rows x channels, channel-contiguous: a = relu(scale[c]*z + shift[c]) or raw
@@ -366,7 +391,8 @@ __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 
 
 // Deterministic per-column reduction of two per-lane partials over the block's rows:
 // halves of a wave (same column) -> wave rows in index order -> out0/out1[col] (valid for tid < BN).
-template <class T>
+// FX: out0 / out1 are fixed-point accumulators (long long, see fx_add) that receive the block's sums by integer atomics.
+template <class T, bool FX = false>
 __device__ __forceinline__ void column_reduce2(float (&p0)[T::TN], float (&p1)[T::TN], float *lds, float *out0,
                                                float *out1, int col0, int ncols)
 {
@@ -392,8 +418,13 @@ __device__ __forceinline__ void column_reduce2(float (&p0)[T::TN], float (&p1)[T
             a0 += red[(r * 2 + 0) * T::BN + tid];
             a1 += red[(r * 2 + 1) * T::BN + tid];
         }
-        out0[col0 + tid] = a0;
-        out1[col0 + tid] = a1;
+        if (FX) {
+            fx_add(reinterpret_cast<long long *>(out0) + col0 + tid, a0);
+            fx_add(reinterpret_cast<long long *>(out1) + col0 + tid, a1);
+        } else {
+            out0[col0 + tid] = a0;
+            out1[col0 + tid] = a1;
+        }
     }
 }
 
@@ -489,6 +520,15 @@ struct FwdArgs {
     float *pool_val;  // [gridDim.x][2][Co]  (max, min)
     int *pool_idx;    // [gridDim.x][2][Co]  row index inside the cloud
     int pool_npts;
+    // fixed-point statistics chain (ACT_BN_RELU_FX, sn_conv_stack_forward_bn): the input's BatchNorm is finalised HERE from
+    // acc_in [2][Ci] (every workgroup computes the Ci coefficient pairs into LDS; workgroup (0,0) also stores coef_prev and
+    // updates the running statistics), this layer's sums go to acc_out [2][Co] by integer atomics, and zero_ptr [zero_n]
+    // (the accumulators the PREVIOUS kernel consumed: nobody touches them during this launch) is cleared for the next step.
+    const long long *acc_in;
+    BnFwd bn_prev;
+    long long *acc_out;
+    long long *zero_ptr;
+    int zero_n;
 };
 
 template <class T, bool FULL, int AMODE>
@@ -518,9 +558,48 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         const int col = col0 + (wc * T::TN + j) * 32 + (lane & 31);
         biasv[j] = g.bias ? g.bias[(FULL || col < Co) ? col : 0] : 0.f;
     }
-    gemm_tile<T, true, true>(
-        acc, Ci, [&](int x, int k) { return a.template load_c4<FULL, AMODE>(row0 + x, k); },
-        [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
+    if (AMODE == ACT_BN_RELU_FX) {
+        // finalise the input's BatchNorm from its fixed-point sums (same arithmetic as bn_finalize_channel)
+        float *cf = lds + T::LDS_FLOATS;  // [2][Ci] scale | shift
+        const BnFwd bp = g.bn_prev;
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int c = threadIdx.x; c < Ci; c += T::THREADS) {
+            const double mean = fx_get(g.acc_in + c) / (double)bp.R;
+            double var = fx_get(g.acc_in + 128 + c) / (double)bp.R - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)bp.eps));
+            const float sc = bp.gamma[c] * invstd, sh = bp.beta[c] - (float)mean * sc;
+            cf[c] = sc, cf[Ci + c] = sh;
+            if (first) {
+                bp.coef[c] = sc, bp.coef[Ci + c] = sh, bp.coef[2 * Ci + c] = (float)mean, bp.coef[3 * Ci + c] = invstd;
+                if (bp.running_mean) {
+                    const double unbiased = bp.R > 1 ? var * (double)bp.R / (double)(bp.R - 1) : var;
+                    bp.running_mean[c] = (1.f - bp.momentum) * bp.running_mean[c] + bp.momentum * (float)mean;
+                    bp.running_var[c] = (1.f - bp.momentum) * bp.running_var[c] + bp.momentum * (float)unbiased;
+                }
+            }
+        }
+        if (first) {
+            if (threadIdx.x == 0 && bp.num_batches_tracked) *bp.num_batches_tracked += 1;
+            for (int i = threadIdx.x; i < g.zero_n; i += T::THREADS) g.zero_ptr[i] = 0;
+        }
+        __syncthreads();
+        static_assert(FULL || AMODE != ACT_BN_RELU_FX, "fixed-point statistics chain: full tiles only");
+        gemm_tile<T, true, true>(
+            acc, Ci,
+            [&](int x, int k) {
+                float4 v = *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k);
+                const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
+                v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+                return v;
+            },
+            [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
+    } else {
+        gemm_tile<T, true, true>(
+            acc, Ci, [&](int x, int k) { return a.template load_c4<FULL, AMODE == ACT_BN_RELU_FX ? ACT_BN_RELU : AMODE>(row0 + x, k); },
+            [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
+    }
 
     float s0[T::TN], s1[T::TN];
     float pmax[T::TN], pmin[T::TN];
@@ -569,7 +648,10 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
     SN_TL(3);
     SN_TL_DRAIN();
     SN_TL(4);
-    if (g.stats) {
+    if (g.acc_out) {
+        long long *ao = g.acc_out + (blockIdx.x % kFxSlots) * 256;
+        column_reduce2<T, true>(s0, s1, lds, reinterpret_cast<float *>(ao), reinterpret_cast<float *>(ao + 128), col0, Co);
+    } else if (g.stats) {
         float *st = g.stats + (size_t)blockIdx.x * 2 * Co;
         column_reduce2<T>(s0, s1, lds, st, st + Co, col0, Co);
     }
@@ -1712,7 +1794,8 @@ __global__ void __launch_bounds__(256) small_bwd_kernel(DgradArgs d, WgradArgs w
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const float *__restrict__ x,
                                                            const float *__restrict__ W, const float *__restrict__ bias,
-                                                           float *__restrict__ z, float *__restrict__ stats)
+                                                           float *__restrict__ z, float *__restrict__ stats,
+                                                           long long *__restrict__ acc_out = nullptr)
 {
     // thread -> 4 consecutive channels (c4) x row slot rs (16 slots): 16-byte stores, a wave writes 4 whole 256-byte rows
     // per instruction (dword stores cost ~58 issue cycles per wave-instruction: the 16-per-thread version was issue-bound)
@@ -1760,15 +1843,21 @@ __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[0][rs][cl + j] = s0[j], red[1][rs][cl + j] = s1[j];
     __syncthreads();
-    if (threadIdx.x < 64 && stats) {
+    if (threadIdx.x < 64 && (stats || acc_out)) {
         const int c = blockIdx.y * 64 + threadIdx.x;
         if (c < Co) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) a0 += red[0][k][threadIdx.x], a1 += red[1][k][threadIdx.x];
-            float *st = stats + (size_t)blockIdx.x * 2 * Co;
-            st[c] = a0;
-            st[Co + c] = a1;
+            if (acc_out) {  // fixed-point statistics chain (sn_conv_stack_forward_bn)
+                long long *ao = acc_out + (blockIdx.x % kFxSlots) * 256;
+                fx_add(ao + c, a0);
+                fx_add(ao + 128 + c, a1);
+            } else {
+                float *st = stats + (size_t)blockIdx.x * 2 * Co;
+                st[c] = a0;
+                st[Co + c] = a1;
+            }
         }
     }
 }
@@ -1912,7 +2001,9 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(int nblk, int C, cons
 __global__ void __launch_bounds__(1024) bn_finalize_pool_kernel(int nblk, int C, const float *__restrict__ stats, BnFwd bn, int B,
                                                                 int bpc, const float *__restrict__ pool_val,
                                                                 const int *__restrict__ pool_idx, float *__restrict__ pooled,
-                                                                int *__restrict__ argsel, float *__restrict__ zsel)
+                                                                int *__restrict__ argsel, float *__restrict__ zsel,
+                                                                long long *__restrict__ acc = nullptr,
+                                                                long long *__restrict__ zero_ptr = nullptr, int zero_n = 0)
 {
     __shared__ float s_sc[kChan], s_sh[kChan];
     if (blockIdx.x == 0 && threadIdx.x == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
@@ -1921,7 +2012,19 @@ __global__ void __launch_bounds__(1024) bn_finalize_pool_kernel(int nblk, int C,
     const int c = blockIdx.x * kChan + cl;
     BnFwdIn in{};
     if (threadIdx.x < kChan && c < C) in = bn_fwd_inputs(bn, c);  // in flight during the reduction
-    if (partial_sums(nblk, C, stats, blockIdx.x, s, ss)) {
+    if (acc) {
+        // fixed-point statistics chain: the sums are complete in acc [2][C]; this workgroup is the only reader of its
+        // channels, so it clears them for the next step; workgroup 0 clears what the previous kernel consumed
+        if (threadIdx.x < kChan && c < C) {
+            s = fx_get(acc + c), ss = fx_get(acc + 128 + c);
+#pragma unroll
+            for (int q = 0; q < kFxSlots; ++q) acc[q * 256 + c] = 0, acc[q * 256 + 128 + c] = 0;
+            const float2 cf = bn_finalize_channel(bn, C, c, s, ss, in);
+            s_sc[cl] = cf.x, s_sh[cl] = cf.y;
+        }
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_ptr[i] = 0;
+    } else if (partial_sums(nblk, C, stats, blockIdx.x, s, ss)) {
         const float2 cf = bn_finalize_channel(bn, C, c, s, ss, in);
         s_sc[cl] = cf.x, s_sh[cl] = cf.y;
     }
@@ -2393,6 +2496,69 @@ extern "C" int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const fl
     launch_fwd<ACT_BN_RELU>(g, st);
     hipLaunchKernelGGL(bn_finalize_pool_kernel, dim3((Co + kChan - 1) / kChan), dim3(1024), 0, st, sn_linear_stats_blocks(R), Co,
                        stats, bn, R / npts, npts / 64, pool_val, pool_idx, pooled, argsel, zsel);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The whole training-mode conv stack of the PointNet head (samplenet.py:90-95: conv/bn/relu x nlayers on (B, 3, N), then
+// the max over the points) as ONE call and nlayers + 1 launches: xyz layer, nlayers - 1 GEMM layers, pool / last-BatchNorm
+// finalisation.  Batch statistics travel as fixed-point sums (fx_add): each GEMM finalises the BatchNorm of its INPUT in
+// its prologue, so no reduction launch sits between two layers.  channels [nlayers + 1] = 3, C1, ..., Cn.
+// acc: persistent scratch of sn_conv_stack_acc_elems(nlayers) long long, ZERO before the first call; every call leaves it zero again.
+// Per layer l: W[l] (C_{l+1}, C_l), bias[l], gamma / beta / running_mean / running_var [l] (C_{l+1}), z[l] (B*N, C_{l+1})
+// pre-BatchNorm output, coef[l] (4, C_{l+1}).  Outputs pooled / zsel (B, Cn), argsel (B, Cn) as sn_pool_forward.
+extern "C" int sn_conv_stack_forward_supported(int B, int N, int nlayers, const int *channels)
+{
+    if (B < 1 || N < 1 || nlayers < 2 || !channels || channels[0] != 3) return 0;
+    const long long R = (long long)B * N;
+    if (R <= 64 || R > (1ll << 30) || N % 64) return 0;
+    for (int l = 1; l <= nlayers; ++l)
+        if (channels[l] % 64 || channels[l] > 128) return 0;
+    return 1;
+}
+
+extern "C" long long sn_conv_stack_acc_elems(int nlayers) { return nlayers > 0 ? (long long)nlayers * kFxLayer : 0; }
+
+extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
+                                        const float *const *bias, const float *const *gamma, const float *const *beta,
+                                        float *const *running_mean, float *const *running_var,
+                                        long long *const *num_batches_tracked, const float *eps, const float *momentum,
+                                        float *const *z, float *const *coef, long long *acc, float *pool_val, int *pool_idx,
+                                        float *pooled, int *argsel, float *zsel, sn_stream_t stream)
+{
+    if (!sn_conv_stack_forward_supported(B, N, nlayers, channels))
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_stack_forward_bn: needs N % 64 == 0 and 64 / 128 channels");
+    SN_REQUIRE(x && W && gamma && beta && eps && momentum && z && coef && acc && pool_val && pool_idx && pooled && argsel && zsel,
+               "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = B * N;
+    auto bn_of = [&](int l) {
+        return BnFwd{gamma[l], beta[l], running_mean ? running_mean[l] : nullptr, running_var ? running_var[l] : nullptr,
+                     num_batches_tracked ? num_batches_tracked[l] : nullptr, coef[l], eps[l], momentum[l], (long long)R};
+    };
+    for (int l = 0; l < nlayers; ++l) SN_REQUIRE(W[l] && gamma[l] && beta[l] && z[l] && coef[l], "null pointer");
+    // layer 0: xyz input
+    hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3(R / 64, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
+                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc);
+    using T = TileBig;
+    for (int l = 1; l < nlayers; ++l) {
+        const int Ci = channels[l], Co = channels[l + 1];
+        FwdArgs g{};
+        g.a = make_act(z[l - 1], nullptr, R, Ci);
+        g.w.w = W[l], g.w.co = Co, g.w.ci = Ci;
+        g.bias = bias ? bias[l] : nullptr, g.z = z[l], g.stats = nullptr;
+        g.acc_in = acc + (size_t)(l - 1) * kFxLayer, g.bn_prev = bn_of(l - 1), g.acc_out = acc + (size_t)l * kFxLayer;
+        if (l >= 2) g.zero_ptr = acc + (size_t)(l - 2) * kFxLayer, g.zero_n = kFxLayer;
+        if (l == nlayers - 1) g.pool_val = pool_val, g.pool_idx = pool_idx, g.pool_npts = N;
+        const dim3 grid(R / T::BM, Co / T::BN);
+        const size_t lds = shaped_lds(lds_bytes<T>() + (size_t)2 * Ci * sizeof(float), grid);
+        hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX>), grid, dim3(T::THREADS), lds, st, g);
+    }
+    const int Cn = channels[nlayers];
+    long long *zp = nlayers >= 2 ? acc + (size_t)(nlayers - 2) * kFxLayer : nullptr;
+    hipLaunchKernelGGL(bn_finalize_pool_kernel, dim3((Cn + kChan - 1) / kChan), dim3(1024), 0, st, 0, Cn, (const float *)nullptr,
+                       bn_of(nlayers - 1), B, N / 64, pool_val, pool_idx, pooled, argsel, zsel, acc + (size_t)(nlayers - 1) * kFxLayer, zp,
+                       zp ? kFxLayer : 0);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -100,6 +100,51 @@ def _bn_coef(L, R, stats, nblk, training):
     return coef
 
 
+def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel):
+    """Training forward of the conv stack + max-pool as one call (sn_conv_stack_forward_bn: batch statistics as fixed-point
+    sums, every layer finalises the BatchNorm of its input -- no reduction launch between layers).  Fills saved["zc"] /
+    saved["cc"]; returns False when the shapes are not supported (the per-layer path runs instead)."""
+    import ctypes
+
+    n = len(convs)
+    chans = (ctypes.c_int * (n + 1))(convs[0].Ci, *[L.Co for L in convs])
+    if any(L.bn.momentum is None or not L.bn.track_running_stats for L in convs):
+        return False
+    if not lib.sn_conv_stack_forward_supported(B, N, n, chans):
+        return False
+    R = B * N
+    acc = getattr(net, "_fx_acc", None)
+    nacc = lib.sn_conv_stack_acc_elems(n)
+    if acc is None or acc.device != x_bnc.device or acc.numel() != nacc:
+        acc = torch.zeros(nacc, device=x_bnc.device, dtype=torch.int64)  # persistent: every call leaves it zero
+        net._fx_acc = acc
+    zs = [_empty((R, L.Co), x_bnc) for L in convs]
+    cs = [_empty((4, L.Co), x_bnc) for L in convs]
+    Cn = convs[-1].Co
+    nblk = lib.sn_linear_stats_blocks(R)
+    pool_val = _empty((nblk, 2, Cn), x_bnc)
+    pool_idx = _empty((nblk, 2, Cn), x_bnc, torch.int32)
+    VP = ctypes.c_void_p * n
+
+    def arr(ts):
+        return VP(*[ptr(t) for t in ts])
+
+    eps = (ctypes.c_float * n)(*[float(L.bn.eps) for L in convs])
+    mom = (ctypes.c_float * n)(*[float(L.bn.momentum) for L in convs])
+    try:
+        check(lib.sn_conv_stack_forward_bn(B, N, n, chans, ptr(x_bnc), arr([L.W for L in convs]), arr([L.b for L in convs]),
+                                           arr([L.bn.weight for L in convs]), arr([L.bn.bias for L in convs]),
+                                           arr([L.bn.running_mean for L in convs]), arr([L.bn.running_var for L in convs]),
+                                           arr([L.bn.num_batches_tracked for L in convs]), eps, mom, arr(zs), arr(cs), ptr(acc),
+                                           ptr(pool_val), ptr(pool_idx), ptr(pooled), ptr(argsel), ptr(zsel), _st(x_bnc)),
+              "sn_conv_stack_forward_bn")
+    except Exception:
+        acc.zero_()  # a launch failed half way: do not leave partial sums behind
+        raise
+    saved["zc"], saved["cc"] = zs, cs
+    return True
+
+
 def forward_impl(net, x_bnc, training, skip_last=False):
     """x (B,N,3) contiguous -> y (B, 3*M) and the tensors backward needs.
     skip_last: stop before fc4 and return None for y -- the caller produces it from saved["zf"][2] / saved["cf"][2] (the
@@ -116,6 +161,8 @@ def forward_impl(net, x_bnc, training, skip_last=False):
     zsel = _empty((B, C5), x_bnc)
     # last conv layer: the max-pool is folded into its epilogue + BatchNorm finalisation when the shapes are 64-aligned
     fuse_pool = training and R > 64 and N % 64 == 0 and C5 % 64 == 0 and convs[-1].Ci % 64 == 0 and FUSE_POOL
+    if fuse_pool and FX_STATS and _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel):
+        convs = []  # the whole stack ran as one call (fixed-point statistics chain)
     for li, L in enumerate(convs):
         if training and fuse_pool and li == len(convs) - 1:
             z, coef = _layer_fwd_bn_pool(R, N, L, a_in, coef_prev, pooled, argsel, zsel)
@@ -158,6 +205,7 @@ _SIDE = {}
 # measured on MI355X / ROCm 7.2: inside a replayed hipGraph the fork/join edges cost more than the overlap buys
 # (0.73 vs 0.60 ms per step at B = 32), so the side stream is opt-in
 USE_SIDE_STREAM = os.environ.get("SAMPLENET_AMD_WGRAD_SIDE_STREAM", "0") != "0"
+FX_STATS = os.environ.get("SAMPLENET_AMD_FX_STATS", "1") != "0"  # fixed-point statistics chain in the conv stack
 IN3_CLOSED_FORM = os.environ.get("SAMPLENET_AMD_IN3_CLOSED_FORM", "1") != "0"
 FUSE_POOL = os.environ.get("SAMPLENET_AMD_FUSE_POOL", "1") != "0"  # A/B switch for the pooling fused into the last conv layer
 

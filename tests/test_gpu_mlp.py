@@ -195,20 +195,71 @@ def test_fused_pooling_equals_separate_pass(B, N):
     net_b = copy.deepcopy(net_a)
     x = torch.rand(B, N, 3, device="cuda") - 0.5
     x[:, N // 2:N // 2 + 8] = x[:, :8]  # duplicated points: exact ties in every channel
-    old = pointnet.FUSE_POOL
+    old, old_fx = pointnet.FUSE_POOL, pointnet.FX_STATS
     try:
+        pointnet.FX_STATS = False  # (the fixed-point statistics chain has its own test below)
         pointnet.FUSE_POOL = True
         ya, sa = pointnet.forward_impl(net_a, x.contiguous(), True)
         pointnet.FUSE_POOL = False
         yb, sb = pointnet.forward_impl(net_b, x.contiguous(), True)
     finally:
-        pointnet.FUSE_POOL = old
+        pointnet.FUSE_POOL, pointnet.FX_STATS = old, old_fx
     for k in ("pooled", "argsel", "zsel"):
         assert torch.equal(sa[k], sb[k]), k
     assert torch.equal(sa["cc"][4], sb["cc"][4])
     assert torch.equal(ya, yb)
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         assert torch.equal(ba, bb), n
+
+
+@pytest.mark.parametrize("B,N", [(32, 1024), (5, 320), (2, 64), (48, 512)])
+def test_fixed_point_statistics_chain(B, N):
+    """sn_conv_stack_forward_bn (batch statistics as 64-bit fixed-point sums via integer atomics, each layer finalising the
+    BatchNorm of its input; 6 launches for the conv stack) against the per-layer path (partials + bn_finalize launches):
+    BatchNorm coefficients and running statistics within 1e-6 relative, layer outputs within 1e-5, same pooled points;
+    and bit-for-bit reproducible from run to run (integer accumulation does not depend on the arrival order), with the
+    persistent accumulators left at zero."""
+    import copy
+
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(B * 3 + N)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    with torch.no_grad():
+        net_a.bn2.weight[::3] *= -1.0
+        net_a.bn5.weight[::5] *= -1.0
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5).contiguous()
+    old = pointnet.FX_STATS
+    try:
+        pointnet.FX_STATS = True
+        ya, sa = pointnet.forward_impl(net_a, x, True)
+        assert hasattr(net_a, "_fx_acc") and int(net_a._fx_acc.abs().sum()) == 0
+        yc, sc = pointnet.forward_impl(net_c, x, True)
+        pointnet.FX_STATS = False
+        yb, sb = pointnet.forward_impl(net_b, x, True)
+    finally:
+        pointnet.FX_STATS = old
+    assert not hasattr(net_b, "_fx_acc")
+    for l in range(5):
+        assert torch.equal(sa["zc"][l], sc["zc"][l]) and torch.equal(sa["cc"][l], sc["cc"][l]), l  # run-to-run
+        assert torch.allclose(sa["cc"][l], sb["cc"][l], rtol=2e-6, atol=1e-7), l
+        assert _rel(sa["zc"][l], sb["zc"][l]) <= 1e-5, l
+    assert torch.equal(ya, yc) and torch.equal(sa["argsel"], sc["argsel"])
+    assert float((sa["argsel"] == sb["argsel"]).float().mean()) >= 0.995
+    assert _rel(sa["pooled"], sb["pooled"]) <= 1e-5 and _rel(ya, yb) <= 1e-4
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        if ba.dtype == torch.long:
+            assert int(ba) == int(bb), n
+        else:
+            assert torch.allclose(ba, bb, rtol=2e-6, atol=1e-8), n
+    # a second step on the same module: accumulators were left clean
+    pointnet.FX_STATS, keep = True, pointnet.FX_STATS
+    try:
+        y2, s2 = pointnet.forward_impl(net_a, x, True)
+    finally:
+        pointnet.FX_STATS = keep
+    assert torch.equal(s2["zc"][4], sa["zc"][4]) and torch.equal(s2["cc"][4][:2], sa["cc"][4][:2])
 
 
 @pytest.mark.parametrize("B,N", [(32, 1024), (5, 320), (3, 330), (33, 1024)])
