@@ -296,6 +296,19 @@ int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, con
                              float *const *running_mean, float *const *running_var, long long *const *num_batches_tracked,
                              const float *eps, const float *momentum, float *const *z, float *const *coef, long long *acc,
                              float *pool_val, int *pool_idx, float *pooled, int *argsel, float *zsel, sn_stream_t stream);
+/* Backward of the conv stack, the mirror of sn_conv_stack_forward_bn, in nlayers launches: one fused dgrad + wgrad kernel
+ * per GEMM layer (top first) and one closing kernel that reduces every layer's weight-gradient partials and finishes the
+ * xyz layer (BatchNorm backward, closed-form weight gradient).  The BatchNorm-backward sums travel between the kernels as
+ * fixed-point atomics; each kernel derives its own layer's dZ coefficients in its prologue.
+ * gsel / argsel (B,Cn), kcoef_top (3,Cn): pooled gradient at the selected points and the top BatchNorm's dZ coefficients
+ * (sn_layer_backward with prev_bn_rows, or sn_pool_backward_bn).  dW: nlayers outputs; dgamma / dbeta / dbias: outputs for
+ * layers 0 .. nlayers-2.  acc: sn_conv_stack_acc_elems(nlayers) long long of persistent zeroed scratch (its own buffer, not
+ * the forward's); scratch: sn_conv_stack_backward_scratch_floats(...) floats (0 = shape not supported). */
+long long sn_conv_stack_backward_scratch_floats(int B, int N, int nlayers, const int *channels);
+int sn_conv_stack_backward(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
+                           const float *bias0, const float *const *z, const float *const *coef, const float *gsel,
+                           const int *argsel, const float *kcoef_top, long long *acc, float *scratch, float *const *dW,
+                           float *const *dgamma, float *const *dbeta, float *const *dbias, sn_stream_t stream);
 int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                       const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                       const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,

@@ -490,18 +490,29 @@ __device__ __forceinline__ BnBwdIn bn_bwd_inputs(const BnBwd &bb, int C, int c)
 {
     return BnBwdIn{bb.coef[c], bb.coef[2 * C + c], bb.coef[3 * C + c]};
 }
-__device__ __forceinline__ float3 bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz, const BnBwdIn &in)
+struct BnBwdOut {
+    float k1, k2, k3, dgamma, dbeta, dbias;
+};
+__device__ __forceinline__ BnBwdOut bn_backward_coefs(long long R, double s, double sz, const BnBwdIn &in)
 {
     const double scale = in.scale, mean = in.mean, invstd = in.invstd;
     const double dg = invstd * (sz - mean * s);
-    bb.dgamma[c] = (float)dg;
-    bb.dbeta[c] = (float)s;
-    const double rinv = 1.0 / (double)bb.R;
-    const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
-    const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
-    bb.kcoef[c] = k1, bb.kcoef[C + c] = k2, bb.kcoef[2 * C + c] = k3;
-    if (bb.dbias) bb.dbias[c] = (float)((double)k1 * s + (double)k2 * (double)bb.R * mean + (double)bb.R * (double)k3);
-    return make_float3(k1, k2, k3);
+    const double rinv = 1.0 / (double)R;
+    BnBwdOut o;
+    o.dgamma = (float)dg, o.dbeta = (float)s;
+    o.k1 = (float)scale, o.k2 = (float)(-scale * invstd * dg * rinv);
+    o.k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
+    o.dbias = (float)((double)o.k1 * s + (double)o.k2 * (double)R * mean + (double)R * (double)o.k3);
+    return o;
+}
+__device__ __forceinline__ float3 bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz, const BnBwdIn &in)
+{
+    const BnBwdOut o = bn_backward_coefs(bb.R, s, sz, in);
+    bb.dgamma[c] = o.dgamma;
+    bb.dbeta[c] = o.dbeta;
+    bb.kcoef[c] = o.k1, bb.kcoef[C + c] = o.k2, bb.kcoef[2 * C + c] = o.k3;
+    if (bb.dbias) bb.dbias[c] = o.dbias;
+    return make_float3(o.k1, o.k2, o.k3);
 }
 __device__ __forceinline__ void bn_backward_channel(const BnBwd &bb, int C, int c, double s, double sz)
 {
@@ -892,6 +903,16 @@ struct ConvBwdArgs {
     float *dyprev, *stats, *part;
     int ntiles;
     const float *xin;  // IN3 only: (R,3) input of the layer below when that layer is the xyz input layer
+    // fixed-point statistics chain of the backward (sn_conv_stack_backward), the mirror of the forward's:
+    //  acc_in  (DZ_BN): sums (sum dY, sum dY Z) of THIS layer's BatchNorm, left by the kernel of the layer above; every
+    //          workgroup derives k1..k3 from them in its prologue, workgroup 0 also stores dgamma / dbeta / dbias (bb_in)
+    //          and clears zero_ptr (what the previous kernel consumed);
+    //  acc_out: the sums for the BatchNorm of the layer below go there by integer atomics instead of to `stats`.
+    const long long *acc_in;
+    BnBwd bb_in;
+    long long *acc_out;
+    long long *zero_ptr;
+    int zero_n;
 };
 
 // Global-memory access of the dgrad waves goes through raw buffer instructions: resource (SGPRs) + per-lane byte offset
@@ -1109,9 +1130,13 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
         // and spend the rest of it on the epilogue and on staging the NEXT tile into the other LDS buffer, while the
         // weight-gradient wave of the same SIMD still has the pipe busy.  (s_setprio for these waves: no effect, measured.)
         const int zc4 = (tid % (CO / 4)) * 4, pc4 = (tid % (CI / 4)) * 4;
-        const float4 k1 = *reinterpret_cast<const float4 *>(g.dz.k1 + zc4);
-        const float4 k2 = *reinterpret_cast<const float4 *>(g.dz.k2 + zc4);
-        const float4 k3 = *reinterpret_cast<const float4 *>(g.dz.k3 + zc4);
+        const bool fxin = ZMODE == DZ_BN && g.acc_in != nullptr;
+        float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f), k2 = k1, k3 = k1;
+        if (!fxin) {
+            k1 = *reinterpret_cast<const float4 *>(g.dz.k1 + zc4);
+            k2 = *reinterpret_cast<const float4 *>(g.dz.k2 + zc4);
+            k3 = *reinterpret_cast<const float4 *>(g.dz.k3 + zc4);
+        }
         const float4 sc4 = *reinterpret_cast<const float4 *>(g.scale_prev + pc4);
         const float4 sh4 = *reinterpret_cast<const float4 *>(g.shift_prev + pc4);
         const float scd = g.scale_prev[cb * 32 + l31], shd = g.shift_prev[cb * 32 + l31];
@@ -1165,6 +1190,15 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
         if (!WLDS) {  // dgrad B fragments in registers, k = 2 s + h (requested after the first tile)
 #pragma unroll
             for (int s = 0; s < NWREG; ++s) wreg[s] = g.W[(size_t)(2 * s + h) * CI + cb * 32 + l31];
+        }
+        if (fxin) {
+            // k1..k3 of this layer's BatchNorm backward: derived by the weight-gradient waves (idle until the first tile is
+            // staged) from the fixed-point sums while the loads above are in flight
+            const float *Ks = lds + 2 * BUF + S::WSZ;  // the transpose scratch is idle until the first epilogue
+            __syncthreads();
+            k1 = *reinterpret_cast<const float4 *>(Ks + zc4);
+            k2 = *reinterpret_cast<const float4 *>(Ks + CO + zc4);
+            k3 = *reinterpret_cast<const float4 *>(Ks + 2 * CO + zc4);
         }
         cbf_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, tile, tic * TR, tid, lds, lds + ZB, rz, rdy, rp, rag, rgs, k1, k2, k3, sc4,
                                                       sh4);
@@ -1303,6 +1337,25 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
         }
     } else {
         // ---------------- weight-gradient waves ----------------------------------------------------------
+        if (ZMODE == DZ_BN && g.acc_in != nullptr) {
+            // this layer's BatchNorm backward from the fixed-point sums, for the dgrad waves' first staging
+            float *Ks = lds + 2 * BUF + S::WSZ;
+            const int c = tid - 256;
+            if (c < CO) {
+                const BnBwd bb = g.bb_in;
+                const double su = fx_get(g.acc_in + c), sz = fx_get(g.acc_in + 128 + c);
+                const BnBwdOut o = bn_backward_coefs(bb.R, su, sz, bn_bwd_inputs(bb, CO, c));
+                Ks[c] = o.k1, Ks[CO + c] = o.k2, Ks[2 * CO + c] = o.k3;
+                if (blockIdx.x == 0) {
+                    bb.dgamma[c] = o.dgamma, bb.dbeta[c] = o.dbeta;
+                    if (bb.dbias) bb.dbias[c] = o.dbias;
+                    if (bb.kcoef) bb.kcoef[c] = o.k1, bb.kcoef[CO + c] = o.k2, bb.kcoef[2 * CO + c] = o.k3;
+                }
+            }
+            if (blockIdx.x == 0)
+                for (int i = tid - 256; i < g.zero_n; i += 256) g.zero_ptr[i] = 0;
+            __syncthreads();
+        }
         if (WLDS) cbf_stage_w<CI, CO, LDW>(g.W, Ws, tid);
         f32x16 accw[NWT];
 #pragma unroll
@@ -1356,11 +1409,15 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
     if (tid < CI) {
         const float *red = lds;
         float *st = g.stats + (size_t)blockIdx.x * (IN3 ? 6 : 2) * CI;
+        long long *ao = g.acc_out + (blockIdx.x % kFxSlots) * 256;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             float a = red[k * CI + tid];
             if (RB == 2) a += red[(NST + k) * CI + tid];
-            st[k * CI + tid] = a;
+            if (!IN3 && g.acc_out)
+                fx_add(ao + k * 128 + tid, a);
+            else
+                st[k * CI + tid] = a;
         }
         if (IN3) st[5 * CI + tid] = tid < 9 ? red[RB * NST * CI + tid] : 0.f;
     }
@@ -2140,20 +2197,44 @@ __global__ void __launch_bounds__(1024) post_bwd_kernel(int nred, int nsplit, in
 // post_bwd_kernel behind the IN3 variant of conv_bwd_fused_kernel (statistics partials [nblk][6][C], see there): the BatchNorm
 // workgroups also finish the weight gradient of the xyz input layer below, in closed form and in double:
 //   dW_in[c][d] = k1 Gx[c][d] + k2 (sum_e W_in[c][e] Sxx[e][d] + b_in[c] Sx[d]) + k3 Sx[d]
+// Several weight-gradient reductions in one launch (sn_conv_stack_backward: the partials of every conv layer are reduced
+// at the end of the backward, not between its kernels).
+struct MultiRed {
+    int n;              // layers (<= 4); n == 0: single reduction described by the scalar arguments
+    int first[5];       // first workgroup of layer i; first[n] = total
+    const float *part[4];
+    float *dW[4];
+    int elems[4];       // Co * Ci
+    long long *zero_ptr;
+    int zero_n;
+};
+
 __global__ void __launch_bounds__(1024) post_bwd_in3_kernel(int nred, int nsplit, int Co, int Ci, const float *__restrict__ part,
                                                             float *__restrict__ dW, int nblk, int C,
                                                             const float *__restrict__ stats, BnBwd bb,
                                                             const float *__restrict__ W_in, const float *__restrict__ b_in,
-                                                            float *__restrict__ dW_in)
+                                                            float *__restrict__ dW_in, MultiRed mr)
 {
     if ((int)blockIdx.x < nred) {
         __shared__ float red[16][64];
         const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-        const int e = blockIdx.x * 64 + el;
-        const size_t stride = (size_t)Co * Ci;
+        int blk = blockIdx.x, nel = Co * Ci;
+        const float *pp = part;
+        float *out = dW;
+        if (mr.n > 0) {
+            int li = 0;
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (q < mr.n && blk >= mr.first[q]) li = q;
+            blk -= mr.first[li], nel = mr.elems[li], pp = mr.part[li], out = mr.dW[li];
+            if (blockIdx.x == 0)
+                for (int i = threadIdx.x; i < mr.zero_n; i += 1024) mr.zero_ptr[i] = 0;
+        }
+        const int e = blk * 64 + el;
+        const size_t stride = (size_t)nel;
         float acc = 0.f;
-        if (e < Co * Ci) {
-            const float *p = part + e;
+        if (e < nel) {
+            const float *p = pp + e;
             int sp = sl;
             for (; sp + 7 * 16 < nsplit; sp += 8 * 16) {
                 const float v0 = p[(size_t)sp * stride], v1 = p[(size_t)(sp + 16) * stride];
@@ -2166,11 +2247,11 @@ __global__ void __launch_bounds__(1024) post_bwd_in3_kernel(int nred, int nsplit
         }
         red[sl][el] = acc;
         __syncthreads();
-        if (sl == 0 && e < Co * Ci) {
+        if (sl == 0 && e < nel) {
             float tot = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) tot += red[q][el];
-            dW[e] = tot;
+            out[e] = tot;
         }
         return;
     }
@@ -2675,11 +2756,13 @@ static void launch_conv_bwd_fused_t(const ConvBwdArgs &a, int G, bool fullr, hip
 // returns the number of workgroups (= partials in `stats` and `part`)
 static int launch_conv_bwd_fused(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                                  const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
-                                 const float *coef_prev, float *dyprev, float *stats, float *part, hipStream_t st)
+                                 const float *coef_prev, float *dyprev, float *stats, float *part, hipStream_t st,
+                                 const ConvBwdArgs *fx = nullptr)
 {
     ConvBwdArgs a{};
+    if (fx) a.acc_in = fx->acc_in, a.bb_in = fx->bb_in, a.acc_out = fx->acc_out, a.zero_ptr = fx->zero_ptr, a.zero_n = fx->zero_n;
     a.dz.mode = dz_mode, a.dz.dy = dy, a.dz.z = z, a.dz.rows = R, a.dz.ch = Co, a.dz.npts = npts > 0 ? npts : 1;
-    a.dz.k1 = kcoef, a.dz.k2 = kcoef + Co, a.dz.k3 = kcoef + 2 * Co;
+    a.dz.k1 = kcoef, a.dz.k2 = kcoef ? kcoef + Co : nullptr, a.dz.k3 = kcoef ? kcoef + 2 * Co : nullptr;
     a.dz.gsel = gsel, a.dz.argsel = argsel;
     a.W = W, a.zprev = zprev, a.scale_prev = coef_prev, a.shift_prev = coef_prev + Ci;
     a.dyprev = dyprev, a.stats = stats, a.part = part;
@@ -2961,18 +3044,15 @@ extern "C" long long sn_layer_backward_in3_stats_floats(int R, int Ci, int Co)
     return (long long)conv_bwd_fused_groups(R) * 6 * Ci;
 }
 
-extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z, const float *kcoef, const float *W,
-                                     const float *zprev, const float *coef_prev, float *stats, float *part,
-                                     float *dW, float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef,
-                                     const float *x_in, const float *W_in, const float *b_in, float *dW_in, sn_stream_t stream)
+static void launch_conv_bwd_in3(int R, const float *dy, const float *z, const float *kcoef, const float *W, const float *zprev,
+                                const float *coef_prev, float *stats, float *part, const float *x_in, hipStream_t st,
+                                const ConvBwdArgs *fx = nullptr)
 {
-    SN_REQUIRE(sn_layer_backward_in3_stats_floats(R, Ci, Co) > 0, "shape not supported by the input-layer variant");
-    SN_REQUIRE(dy && z && kcoef && W && zprev && coef_prev && stats && part && dW, "null pointer");
-    SN_REQUIRE(prev_dgamma && prev_dbeta && prev_kcoef && x_in && W_in && dW_in, "null pointer");
-    hipStream_t st = (hipStream_t)stream;
+    constexpr int Ci = 64, Co = 64;
     ConvBwdArgs a{};
+    if (fx) a.acc_in = fx->acc_in, a.bb_in = fx->bb_in, a.acc_out = nullptr, a.zero_ptr = fx->zero_ptr, a.zero_n = fx->zero_n;
     a.dz.mode = DZ_BN, a.dz.dy = dy, a.dz.z = z, a.dz.rows = R, a.dz.ch = Co, a.dz.npts = 1;
-    a.dz.k1 = kcoef, a.dz.k2 = kcoef + Co, a.dz.k3 = kcoef + 2 * Co;
+    a.dz.k1 = kcoef, a.dz.k2 = kcoef ? kcoef + Co : nullptr, a.dz.k3 = kcoef ? kcoef + 2 * Co : nullptr;
     a.W = W, a.zprev = zprev, a.scale_prev = coef_prev, a.shift_prev = coef_prev + Ci;
     a.dyprev = nullptr, a.stats = stats, a.part = part, a.xin = x_in;  // dYprev is not materialised: nothing reads it
     constexpr int TR = CbfShape<64, 64>::TR;
@@ -2991,10 +3071,108 @@ extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, con
         hipLaunchKernelGGL((conv_bwd_fused_kernel<64, 64, DZ_BN, true, true>), dim3(G), dim3(512), lds, st, a);
     else
         hipLaunchKernelGGL((conv_bwd_fused_kernel<64, 64, DZ_BN, false, true>), dim3(G), dim3(512), lds, st, a);
+}
+
+extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z, const float *kcoef, const float *W,
+                                     const float *zprev, const float *coef_prev, float *stats, float *part,
+                                     float *dW, float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef,
+                                     const float *x_in, const float *W_in, const float *b_in, float *dW_in, sn_stream_t stream)
+{
+    SN_REQUIRE(sn_layer_backward_in3_stats_floats(R, Ci, Co) > 0, "shape not supported by the input-layer variant");
+    SN_REQUIRE(dy && z && kcoef && W && zprev && coef_prev && stats && part && dW, "null pointer");
+    SN_REQUIRE(prev_dgamma && prev_dbeta && prev_kcoef && x_in && W_in && dW_in, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    launch_conv_bwd_in3(R, dy, z, kcoef, W, zprev, coef_prev, stats, part, x_in, st);
+    const int G = conv_bwd_fused_groups(R);
     const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, (long long)R};
     const int nred = (Co * Ci + 63) / 64;
     hipLaunchKernelGGL(post_bwd_in3_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW, G,
-                       Ci, stats, bb, W_in, b_in, dW_in);
+                       Ci, stats, bb, W_in, b_in, dW_in, MultiRed{});
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of the whole conv stack (the mirror of sn_conv_stack_forward_bn) in nlayers launches: one fused dgrad + wgrad
+// kernel per GEMM layer, top first, and ONE closing kernel that reduces every layer's weight-gradient partials and
+// finishes the xyz layer (BatchNorm backward + closed-form weight gradient).  Between the kernels the BatchNorm-backward
+// sums travel as fixed-point atomics (acc): each kernel derives its own layer's dZ coefficients in its prologue.
+// Inputs: x (B*N,3); per layer W, z (pre-BN outputs), coef (4,C); gsel / argsel (B,Cn) + kcoef_top (3,Cn): the pooled
+// gradient at the selected points and the top BatchNorm's dZ coefficients (from the FC side: sn_layer_backward with
+// prev_bn_rows, or sn_pool_backward_bn).  Outputs: dW per layer; dgamma / dbeta / dbias for layers 0 .. nlayers-2.
+// acc: sn_conv_stack_acc_elems(nlayers) long long, zero before the first call (left zero); scratch: see _scratch_floats.
+static bool conv_stack_backward_ok(int B, int N, int nlayers, const int *ch)
+{
+    if (!sn_conv_stack_forward_supported(B, N, nlayers, ch) || nlayers < 3 || nlayers > 5) return false;
+    const int R = B * N;
+    if (ch[1] != 64 || ch[2] != 64 || R < 256) return false;
+    for (int l = 1; l < nlayers; ++l)
+        if (!conv_bwd_fused_shape(R, ch[l], ch[l + 1])) return false;
+    return true;
+}
+
+extern "C" long long sn_conv_stack_backward_scratch_floats(int B, int N, int nlayers, const int *channels)
+{
+    if (!conv_stack_backward_ok(B, N, nlayers, channels)) return 0;
+    const long long R = (long long)B * N, G = conv_bwd_fused_groups((int)R);
+    long long n = 0;
+    for (int l = 1; l < nlayers; ++l) n += G * channels[l] * channels[l + 1];  // weight-gradient partials
+    for (int l = 2; l < nlayers; ++l) n += R * channels[l];                     // dY of layers 1 .. nlayers-2 ... (dY_{l-1})
+    n += G * 6 * 64 + 3 * 64;                                                   // xyz-layer statistics partials, its kcoef
+    return n;
+}
+
+extern "C" int sn_conv_stack_backward(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
+                                      const float *bias0, const float *const *z, const float *const *coef, const float *gsel,
+                                      const int *argsel, const float *kcoef_top, long long *acc, float *scratch,
+                                      float *const *dW, float *const *dgamma, float *const *dbeta, float *const *dbias,
+                                      sn_stream_t stream)
+{
+    if (!conv_stack_backward_ok(B, N, nlayers, channels))
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_stack_backward: shape not supported (use the per-layer entries)");
+    SN_REQUIRE(x && W && z && coef && gsel && argsel && kcoef_top && acc && scratch && dW && dgamma && dbeta && dbias, "null pointer");
+    for (int l = 0; l < nlayers; ++l) SN_REQUIRE(W[l] && z[l] && coef[l] && dW[l], "null pointer");
+    for (int l = 0; l + 1 < nlayers; ++l) SN_REQUIRE(dgamma[l] && dbeta[l] && dbias[l], "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int R = B * N, G = conv_bwd_fused_groups(R);
+    const int *ch = channels;
+    float *part[5] = {}, *dy[5] = {};
+    float *p = scratch;
+    for (int l = 1; l < nlayers; ++l) part[l] = p, p += (size_t)G * ch[l] * ch[l + 1];
+    for (int l = 2; l < nlayers; ++l) dy[l - 1] = p, p += (size_t)R * ch[l];  // dy[l-1]: gradient at layer l-1's activations
+    float *stats0 = p;
+    p += (size_t)G * 6 * 64;
+    float *kcoef0 = p;
+    auto accb = [&](int l) { return acc + (size_t)l * kFxLayer; };
+    for (int L = nlayers - 1; L >= 1; --L) {
+        const int Ci = ch[L], Co = ch[L + 1];
+        ConvBwdArgs fx{};
+        const bool top = L == nlayers - 1;
+        if (!top) {
+            fx.acc_in = accb(L);
+            fx.bb_in = BnBwd{coef[L], dgamma[L], dbeta[L], dbias[L], nullptr, (long long)R};
+            if (L + 1 <= nlayers - 2) fx.zero_ptr = accb(L + 1), fx.zero_n = kFxLayer;
+        }
+        if (L >= 2) {
+            fx.acc_out = accb(L - 1);
+            launch_conv_bwd_fused(R, Ci, Co, top ? DZ_POOL : DZ_BN, top ? nullptr : dy[L], z[L], top ? kcoef_top : nullptr,
+                                  top ? gsel : nullptr, top ? argsel : nullptr, N, W[L], z[L - 1], coef[L - 1], dy[L - 1], nullptr,
+                                  part[L], st, &fx);
+        } else {
+            launch_conv_bwd_in3(R, dy[1], z[1], nullptr, W[1], z[0], coef[0], stats0, part[1], x, st, &fx);
+        }
+    }
+    MultiRed mr{};
+    mr.n = nlayers - 1;
+    int nb = 0;
+    for (int l = 1; l < nlayers; ++l) {
+        mr.first[l - 1] = nb, mr.part[l - 1] = part[l], mr.dW[l - 1] = dW[l], mr.elems[l - 1] = ch[l] * ch[l + 1];
+        nb += (ch[l] * ch[l + 1] + 63) / 64;
+    }
+    mr.first[nlayers - 1] = nb;
+    mr.zero_ptr = accb(1), mr.zero_n = kFxLayer;
+    const BnBwd bb0{coef[0], dgamma[0], dbeta[0], dbias[0], kcoef0, (long long)R};
+    hipLaunchKernelGGL(post_bwd_in3_kernel, dim3(nb + (64 + kChan - 1) / kChan), dim3(1024), 0, st, nb, G, 64, 64, part[1], dW[1], G,
+                       64, stats0, bb0, W[0], bias0, dW[0], mr);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -299,6 +299,49 @@ def _layer_bwd(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, L
     return dW, db, dyprev, dg, dbt, dbs, kc
 
 
+def _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef_top, sink, grads, names_c, bn_c):
+    """Backward of the conv stack as one call (sn_conv_stack_backward: 5 launches, BatchNorm-backward sums as fixed-point
+    atomics, every weight-gradient partial reduced by the closing kernel).  Returns False when the shapes are not
+    supported (the per-layer path runs instead)."""
+    import ctypes
+
+    n = len(convs)
+    B, N = saved["B"], saved["N"]
+    chans = (ctypes.c_int * (n + 1))(convs[0].Ci, *[L.Co for L in convs])
+    nscr = lib.sn_conv_stack_backward_scratch_floats(B, N, n, chans)
+    if nscr <= 0:
+        return False
+    x = saved["x"]
+    acc = getattr(net, "_fx_acc_b", None)
+    nacc = lib.sn_conv_stack_acc_elems(n)
+    if acc is None or acc.device != x.device or acc.numel() != nacc:
+        acc = torch.zeros(nacc, device=x.device, dtype=torch.int64)  # persistent: every call leaves it zero
+        net._fx_acc_b = acc
+    scratch = _empty((nscr,), x)
+    VP = ctypes.c_void_p * n
+
+    def arr(ts):
+        return VP(*[ptr(t) for t in ts])
+
+    dW = [_out(sink, names_c[i] + ".weight", convs[i].W) for i in range(n)]
+    dg = [_out(sink, bn_c[i] + ".weight", convs[i].bn.weight) for i in range(n - 1)]
+    dbt = [_out(sink, bn_c[i] + ".bias", convs[i].bn.bias) for i in range(n - 1)]
+    dbs = [_out(sink, names_c[i] + ".bias", convs[i].b) for i in range(n - 1)]
+    try:
+        check(lib.sn_conv_stack_backward(B, N, n, chans, ptr(x), arr([L.W for L in convs]), ptr(convs[0].b), arr(saved["zc"]),
+                                         arr(saved["cc"]), ptr(gsel), ptr(saved["argsel"]), ptr(kcoef_top), ptr(acc), ptr(scratch),
+                                         arr(dW), arr(dg + [None]), arr(dbt + [None]), arr(dbs + [None]), _st(x)),
+              "sn_conv_stack_backward")
+    except Exception:
+        acc.zero_()
+        raise
+    for i in range(n):
+        grads[names_c[i] + ".weight"] = dW[i]
+    for i in range(n - 1):
+        grads[bn_c[i] + ".weight"], grads[bn_c[i] + ".bias"], grads[names_c[i] + ".bias"] = dg[i], dbt[i], dbs[i]
+    return True
+
+
 def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
     """-> dict parameter-name -> gradient tensor (every parameter of the MLP).
     sink: optional dict name -> preallocated tensor the gradient is written into (overwritten, not accumulated).
@@ -350,6 +393,9 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
         grads[bn_c[4] + ".weight"], grads[bn_c[4] + ".bias"], grads[names_c[4] + ".bias"] = dgamma, dbeta, dbias
 
     # ---- conv stack (rows = B*N): conv5 -> ... -> conv2 (each also finishes the BatchNorm of the layer below), conv1 ----
+    if FX_STATS and IN3_CLOSED_FORM and _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef, sink, grads, names_c, bn_c):
+        _join_side(grad_y.device)
+        return grads
     dy = None
     in3_floats = lib.sn_layer_backward_in3_stats_floats(R, convs[1].Ci, convs[1].Co) if (IN3_CLOSED_FORM and convs[0].Ci == 3) else 0
     for i in (4, 3, 2, 1):

@@ -282,14 +282,15 @@ def test_input_layer_weight_gradient_closed_form(B, N):
     from samplenet_amd._lib import lib
     assert lib.sn_layer_backward_in3_stats_floats(B * N, 64, 64) > 0
     g = torch.randn(B, 3, 64, device="cuda")
-    old = pointnet.IN3_CLOSED_FORM
+    old, old_fx = pointnet.IN3_CLOSED_FORM, pointnet.FX_STATS
     try:
+        pointnet.FX_STATS = False  # per-layer entries on both sides (the one-call stack has its own test below)
         pointnet.IN3_CLOSED_FORM = True
         (net_a._features(x.permute(0, 2, 1), x) * g).sum().backward()
         pointnet.IN3_CLOSED_FORM = False
         (net_b._features(x.permute(0, 2, 1), x) * g).sum().backward()
     finally:
-        pointnet.IN3_CLOSED_FORM = old
+        pointnet.IN3_CLOSED_FORM, pointnet.FX_STATS = old, old_fx
     for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
         if n.startswith("project"):
             continue
@@ -297,6 +298,43 @@ def test_input_layer_weight_gradient_closed_form(B, N):
             assert _rel(pa.grad, pb.grad) <= 2e-5, (n, _rel(pa.grad, pb.grad))
         else:
             assert torch.equal(pa.grad, pb.grad), n
+
+
+@pytest.mark.parametrize("B,N", [(32, 1024), (5, 320), (33, 1024), (4, 64)])
+def test_conv_stack_one_call_backward(B, N):
+    """sn_conv_stack_forward_bn + sn_conv_stack_backward (5 + 5 launches, statistics as fixed-point atomics, one closing
+    reduction of all weight-gradient partials) against the per-layer entries (partials + reduction launches): every
+    gradient within 1e-4 of its norm (+ noise floor for the zero-gradient biases), bit-for-bit reproducible from run to
+    run, persistent accumulators left at zero."""
+    import copy
+
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(B * 5 + N)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    with torch.no_grad():
+        net_a.bn3.weight[::4] *= -1.0
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    g = torch.randn(B, 3, 64, device="cuda")
+    old = pointnet.FX_STATS
+    try:
+        pointnet.FX_STATS = True
+        (net_a._features(x.permute(0, 2, 1), x) * g).sum().backward()
+        (net_c._features(x.permute(0, 2, 1), x) * g).sum().backward()
+        pointnet.FX_STATS = False
+        (net_b._features(x.permute(0, 2, 1), x) * g).sum().backward()
+    finally:
+        pointnet.FX_STATS = old
+    assert hasattr(net_a, "_fx_acc_b") and int(net_a._fx_acc_b.abs().sum()) == 0 and int(net_a._fx_acc.abs().sum()) == 0
+    gb = {n: p.grad for n, p in net_b.named_parameters() if p.grad is not None}
+    gmax = max(float(v.norm()) for v in gb.values())
+    gc = dict(net_c.named_parameters())
+    for n, p in net_a.named_parameters():
+        if n.startswith("project"):
+            continue
+        assert torch.equal(p.grad, gc[n].grad), n  # run to run
+        assert float((p.grad - gb[n]).norm()) <= 1e-4 * float(gb[n].norm()) + 1e-6 * gmax, n
 
 
 @pytest.mark.parametrize("B,N,shape", [(4, 1024, "bcn"), (3, 64, "bnc"), (2, 200, "bcn")])

@@ -190,6 +190,11 @@ if __name__ == "__main__":
         small_fwd(32, 256, 256)
         small_fwd(32, 128, 256)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fwd":
+        fwd(R, 64, 64)
+        fwd(R, 64, 128)
+        fwd(R, 128, 128)
+        sys.exit(0)
     if len(sys.argv) < 2:
         fwd(R, 64, 64)
         fwd(R, 64, 128)
