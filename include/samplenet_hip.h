@@ -151,6 +151,14 @@ int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, in
                                   const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
                                   const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T,
                                   const float *deferred_partial, float *deferred_loss, sn_stream_t stream);
+/* The two calls above for callers that always run the backward right behind sn_pairscan_forward_partial[_fc] (engine): the
+ * per-cloud reduction of the forward is folded into the backward's first launch and the loss value is combined in the
+ * sigma-gradient launch: 2 launches after the scan.  partial: B*4 floats of scratch; loss: 2 floats.  N <= 2048. */
+int sn_sampler_step_loss_fold(int B, int N, int M, int K, const float *P, int p_layout, const float *Q, const int *knn_idx,
+                              const float *dist_q, const int *idx_q, const void *colmin_ws, int G, const float *proj,
+                              const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
+                              const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T, float *partial,
+                              float *loss, sn_stream_t stream);
 /* defer_value != 0: the forward leaves loss[] unwritten; pass its `partial` and `loss` to the backward call as
  * deferred_partial / deferred_loss and the scalar is combined by an extra wave of the backward's first launch (the
  * gradients do not depend on it) -- for callers that always run the backward (samplenet_amd.engine).  Else pass NULLs. */

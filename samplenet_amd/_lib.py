@@ -41,6 +41,8 @@ PROTOTYPES = {
     "sn_sampler_step_loss_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sn_sampler_step_loss_backward": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp],
+    "sn_sampler_step_loss_fold": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],
     "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

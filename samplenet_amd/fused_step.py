@@ -10,9 +10,15 @@ coordinates itself (sn_pairscan_forward_partial_fc), so fc4's forward launch dis
 (pointnet.backward_impl receives d L / d y from the loss kernels).  Used by engine.SamplerTrainStep's fast path; the
 op-by-op modules (SampleNet.forward + get_simplification_loss + get_projection_loss) compute the same step.
 """
+import os
+
 import torch
 
 from . import ops, pointnet
+
+# per-cloud loss reduction inside the backward's first launch (sn_sampler_step_loss_fold): one launch less, but every one of
+# the 512 workgroups then re-reduces its cloud's 64 KB of partial keys -- measured +2.2 us per step at B = 32, so OFF
+FOLD_LOSS = os.environ.get("SAMPLENET_AMD_FOLD_LOSS", "0") == "1"
 
 
 class SamplerStepFunction(torch.autograd.Function):
@@ -30,7 +36,8 @@ class SamplerStepFunction(torch.autograd.Function):
             fc4 = net.fc4
             y = torch.empty(B, 3, M, device=x.device, dtype=torch.float32)
             fc = (saved["zf"][2], saved["cf"][2], fc4.weight.detach(), fc4.bias.detach())
-            loss, proj, state = ops.step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value)
+            loss, proj, state = ops.step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value,
+                                                      fold=bool(defer_value) and FOLD_LOSS and x.shape[1] <= 2048)
         ctx.net, ctx.saved, ctx.state = net, saved, state
         ctx.x, ctx.y, ctx.temperature = x, y, temperature
         ctx.cfg = (K, float(min_sigma), float(alpha), float(lmbda), float(weight))

@@ -458,11 +458,13 @@ class SamplerStepLossFunction(torch.autograd.Function):
         return (gQ if ctx.needs_input_grad[0] else None), None, g_temp, None, None, None, None, None, None, None
 
 
-def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value):
+def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value, fold=False):
     """Forward launches of the sampler step's loss side (SamplerStepLossFunction / fused_step.SamplerStepFunction).
     x (B,N,3), y (B,3,M): the simplified cloud -- read when fc is None, otherwise WRITTEN by the pair scan from
     fc = (z3 (B,Kfc), coef3 (>=2*Kfc: scale | shift), W4 (3M,Kfc), b4 (3M)).  Caller holds the device guard.
-    -> loss (2,), proj (B,M,3), state = (idx, iq, ip, argmax1, (partial, loss) | (None, None))."""
+    -> loss (2,), proj (B,M,3), state = (idx, iq, ip, argmax1, (partial, loss) | (None, None)).
+    fold (needs N <= 2048; the backward must follow): only the pair scan runs here, the reduction and the loss value are
+    produced by the backward's launches (sn_sampler_step_loss_fold)."""
     B, _, M = y.shape
     N = x.shape[1]
     dev = y.device
@@ -492,6 +494,9 @@ def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight,
                                                  ptr(W4), ptr(b4), Kfc, ptr(y), ptr(idx), ptr(dq), ptr(iq), ptr(proj), BNC,
                                                  ptr(T), float(min_sigma), ptr(ws), ws.numel() * 8, st),
               "sn_pairscan_forward_partial_fc")
+    if fold:
+        # the per-cloud reduction runs inside the backward's first launch (sn_sampler_step_loss_fold): nothing more here
+        return loss, proj, (idx, iq, None, None, (partial, loss), (dq, ws, proj, G))
     check(lib.sn_sampler_step_loss_forward(B, M, N, G, ptr(dq), ptr(ws), ptr(proj), ptr(T), float(alpha), float(lmbda),
                                            float(weight), float(min_sigma), ptr(dp), ptr(ip), ptr(argmax1), ptr(partial),
                                            ptr(loss), 1 if defer_value else 0, st), "sn_sampler_step_loss_forward")
@@ -501,7 +506,7 @@ def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight,
 
 def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink):
     """Backward launches of the sampler step's loss side -> (grad_Q (B,3,M), grad_T (1,)).  Caller holds the device guard."""
-    idx, iq, ip, argmax1, (dpart, dloss) = state
+    idx, iq, ip, argmax1, (dpart, dloss) = state[:5]
     K, min_sigma, alpha, lmbda, weight = cfg
     B, _, M = y.shape
     N = x.shape[1]
@@ -511,6 +516,12 @@ def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink):
     gT = t_sink if t_sink is not None else torch.empty(1, device=dev, dtype=torch.float32)
     gl = grad_loss.contiguous().float().reshape(1)
     T = temperature.detach().float().reshape(1)
+    if len(state) > 5:
+        dq, ws, proj, G = state[5]
+        check(lib.sn_sampler_step_loss_fold(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(dq), ptr(iq), ptr(ws), G, ptr(proj),
+                                            ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
+                                            ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_fold")
+        return gQ, gT
     check(lib.sn_sampler_step_loss_backward(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(ip), ptr(argmax1),
                                             ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
                                             ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_backward")

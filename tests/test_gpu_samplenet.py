@@ -249,6 +249,36 @@ def test_head_fused_into_scan(B, N, M, K):
         assert float((p.grad - gb[n]).norm()) <= 1e-4 * float(gb[n].norm()) + 1e-6 * gmax, n
 
 
+@pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (6, 512, 64, 8), (3, 320, 20, 5), (4, 2048, 32, 8)])
+def test_loss_reduction_folded_into_backward(B, N, M, K):
+    """sn_sampler_step_loss_fold (the per-cloud reduction of the forward done by the workgroups of the backward's first
+    launch, loss value combined in the sigma-gradient launch) against the forward / backward pair: gradients bit-equal
+    (same nearest-query indices, same argmax), loss value within 1e-6 relative (different summation order)."""
+    import copy
+
+    from samplenet_amd import SampleNet, fused_step
+
+    torch.manual_seed(B + N + 7)
+    net_a = SampleNet(M, 128, group_size=K, initial_temperature=0.6, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    x[:, N // 2:N // 2 + 4] = x[:, :4]  # duplicated points: ties between partial keys
+    old = fused_step.FOLD_LOSS
+    try:
+        fused_step.FOLD_LOSS = True
+        la, ya, pa = fused_step.sampler_step(net_a, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
+        la.backward()
+        fused_step.FOLD_LOSS = False
+        lb, yb, pb = fused_step.sampler_step(net_b, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
+        lb.backward()
+    finally:
+        fused_step.FOLD_LOSS = old
+    assert torch.equal(ya, yb) and torch.equal(pa, pb)
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+    for (n, p), (_, q) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert p.grad is not None and torch.equal(p.grad, q.grad), n
+
+
 def test_input_ring_replay_equals_copy_in():
     """SamplerTrainStep built on an input ring (one captured graph per resident batch, no staging copy) gives the same
     loss and gradients per batch as the single-graph step that copies the batch into its static buffer."""
