@@ -128,3 +128,56 @@ class PointNetFeatures(nn.Module):
         for conv in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
             wb += [conv.weight.reshape(conv.weight.shape[0], conv.weight.shape[1]), conv.bias]
         return _FeaturesFunction.apply(x.contiguous().float(), *wb)
+
+
+class PCRNet(nn.Module):
+    """Drop-in for `registration/models/pcrnet.py:44-82` (same constructor, attribute and parameter names -> state_dict
+    compatible, same `forward(x0, x1) -> (twist (B,7), pre_normalized_quat (B,4))`): the two feature extractions run on the
+    HIP MLP kernels (`PointNetFeatures` above, the 99 % of the network's arithmetic), the six-layer FC trunk on B rows is
+    plain library GEMMs (torch.nn.Linear -> rocBLAS), the quaternion normalisation is torch."""
+
+    def __init__(self, bottleneck_size=1024, input_shape="bcn"):
+        super().__init__()
+        if input_shape not in ["bcn", "bnc"]:
+            raise ValueError("allowed shape are 'bcn' (batch * channels * num_in_points), 'bnc' ")
+        self.input_shape = input_shape
+        self.feat = PointNetFeatures(bottleneck_size, input_shape)
+        self.fc1 = nn.Linear(bottleneck_size * 2, 1024)
+        self.fc2 = nn.Linear(1024, 1024)
+        self.fc3 = nn.Linear(1024, 512)
+        self.fc4 = nn.Linear(512, 512)
+        self.fc5 = nn.Linear(512, 256)
+        self.fc6 = nn.Linear(256, 7)
+
+    def forward(self, x0, x1):
+        y = torch.cat([self.feat(x0), self.feat(x1)], dim=1)
+        for fc in (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5):
+            y = torch.relu(fc(y))
+        y = self.fc6(y)  # (B, 7)
+        pre_normalized_quat = y[:, 0:4]
+        normalized_quat = torch.nn.functional.normalize(pre_normalized_quat, dim=1)
+        return torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat
+
+
+def qrot(q, v):
+    """Rotate v (*,3) by the quaternion q (*,4), (w, x, y, z) order -- registration/src/quaternion.py:35-53."""
+    qvec = q[..., 1:]
+    uv = torch.cross(qvec, v, dim=-1)
+    uuv = torch.cross(qvec, uv, dim=-1)
+    return v + 2 * (q[..., :1] * uv + uuv)
+
+
+def pcrnet_chamfer_loss(model, p0, p1):
+    """The Chamfer term of the registration task loss (`registration/main.py:557-577`, `--loss-type 1`):
+    twist = model(p0, p1); p1_est = rotate(p0) by the estimated quaternion (QuaternionTransform.rotate,
+    qdataset.py:97-119: rotation only); loss = mean d(p1 -> p1_est) + mean d(p1_est -> p1) on the HIP Chamfer kernels.
+    p0 template / p1 source, (B,N,3).  Returns (chamfer_loss, qnorm_loss, twist).  The rotation-matrix error terms of
+    `--loss-type 0` go through kornia in the reference (not installed here) and stay with the caller."""
+    from .chamfer_distance import ChamferDistance
+
+    twist, pre_normalized_quat = model(p0, p1)
+    qnorm_loss = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
+    quat = twist[:, 0:4].unsqueeze(1).expand(-1, p0.shape[1], -1)
+    p1_est = qrot(quat, p0)
+    c01, c10 = ChamferDistance()(p1.contiguous(), p1_est.contiguous())
+    return torch.mean(c01) + torch.mean(c10), qnorm_loss, twist

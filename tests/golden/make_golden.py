@@ -257,6 +257,36 @@ def golden_nn_matching(sputils):
          out_nofps=sputils.nn_matching(pc, idx, k, complete_fps=False))
 
 
+def golden_pcrnet(ChamferDistance):
+    """registration/models/pcrnet.py (PCRNet) + src/quaternion.py (qrot) imported and run as they are; the task loss as
+    main.py:557-577 composes it for --loss-type 1 (QuaternionTransform itself needs kornia: its rotate() is the qrot call
+    of qdataset.py:106-109, restated here).  Weights: default torch init under a fixed seed -- only their checksums are
+    stored (the test rebuilds the same module the same way)."""
+    sys.path.insert(0, os.path.join(REF, "registration"))
+    pcr = importlib.import_module("models.pcrnet")
+    Q = importlib.import_module("src.quaternion")
+    torch.manual_seed(21)
+    model = pcr.PCRNet(bottleneck_size=256, input_shape="bnc")
+    B, N = 3, 160
+    g = torch.Generator().manual_seed(22)
+    p0 = (torch.rand(B, N, 3, generator=g) - 0.5).requires_grad_(True)
+    ang = torch.tensor([0.3, -0.5, 0.8])
+    R = torch.stack([torch.tensor([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+                     for a in ang.tolist()])
+    p1 = (torch.bmm(p0.detach(), R.transpose(1, 2)) + 0.01 * torch.randn(B, N, 3, generator=g)).contiguous()
+    twist, pre = model(p0, p1)
+    qnorm = torch.mean((torch.sum(pre ** 2, dim=1) - 1) ** 2)
+    quat = twist[:, 0:4].unsqueeze(1).expand([-1, N, -1]).contiguous()
+    p1_est = Q.qrot(quat, p0)
+    c01, c10 = ChamferDistance()(p1, p1_est)
+    loss = torch.mean(c01) + torch.mean(c10)
+    loss.backward()
+    sums = {("w_" + n.replace(".", "_")): np.float64(p.detach().double().abs().sum()) for n, p in model.named_parameters()}
+    gn = {("g_" + n.replace(".", "_")): p.grad.numpy() for n, p in model.named_parameters() if n in ("feat.conv1.weight", "fc6.weight", "fc6.bias")}
+    save("pcrnet_reference.npz", p0=p0.detach().numpy(), p1=p1.numpy(), twist=twist.detach().numpy(), pre=pre.detach().numpy(),
+         loss=np.float32(loss.item()), qnorm=np.float32(qnorm.item()), grad_p0=p0.grad.numpy(), **sums, **gn)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout not found: " + REF
     O.build(ref=True)
@@ -269,5 +299,6 @@ if __name__ == "__main__":
     golden_chamfer(ChamferDistance)
     golden_samplenet(sn_mod.SampleNet)
     golden_nn_matching(sputils)
+    golden_pcrnet(ChamferDistance)
     left = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc") or f == "__pycache__"]
     assert not left, "bytecode leaked into the reference tree: %s" % left[:3]

@@ -365,3 +365,31 @@ def test_task_network_features_vs_torch(B, N, shape):
     for a, b in zip(got, want):
         scale = float(b.abs().max()) + 1e-12
         assert float((a.reshape(b.shape) - b).abs().max()) <= 2e-4 * scale
+
+
+def test_pcrnet_task_loss_matches_reference(golden):
+    """Row f1: the registration task network and the Chamfer term of its loss (registration/models/pcrnet.py:44-82,
+    main.py:557-577 with --loss-type 1) against the REFERENCE modules run on CPU (tests/golden/make_golden.py:golden_pcrnet:
+    reference PCRNet + reference qrot + the reference's own compiled Chamfer): same default-initialised weights (checked by
+    checksum), twist / pre-normalised quaternion / loss within 1e-5, the gradient that flows back to the (sampled) template
+    cloud and the weight gradients within 2e-4 of their norms."""
+    from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss
+
+    g = golden("pcrnet_reference.npz")
+    torch.manual_seed(21)
+    model = PCRNet(bottleneck_size=256, input_shape="bnc")
+    for n, p in model.named_parameters():
+        assert abs(float(p.detach().double().abs().sum()) - float(g["w_" + n.replace(".", "_")])) <= 1e-9 * max(1.0, float(g["w_" + n.replace(".", "_")])), n
+    model = model.cuda()
+    p0 = torch.from_numpy(g["p0"]).cuda().requires_grad_(True)
+    p1 = torch.from_numpy(g["p1"]).cuda()
+    loss, qnorm, twist = pcrnet_chamfer_loss(model, p0, p1)
+    assert torch.allclose(twist.detach().cpu(), torch.from_numpy(g["twist"]), rtol=1e-5, atol=1e-6)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
+    assert abs(float(qnorm) - float(g["qnorm"])) <= 1e-5 * max(1.0, abs(float(g["qnorm"])))
+    loss.backward()
+    assert _rel(p0.grad.cpu(), torch.from_numpy(g["grad_p0"])) <= 2e-4
+    for n, p in model.named_parameters():
+        key = "g_" + n.replace(".", "_")
+        if key in g.files:
+            assert _rel(p.grad.cpu(), torch.from_numpy(g[key])) <= 2e-4, n

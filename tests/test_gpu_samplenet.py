@@ -343,3 +343,51 @@ def test_progressive_sampler_losses(oracle, reduction):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-8)
     net.eval()
     assert float(net.get_progressive_simplification_loss(x, simp.detach())) == 0.0
+
+
+def test_sampler_step_with_registration_task_loss():
+    """registration/main.py:507-531 end to end on the HIP path: sampler forward -> frozen PCRNet on the projected cloud ->
+    Chamfer task loss, + alpha * L_simp + lmbda * L_proj, backward into the sampler (engine general path, task_loss given).
+    The same step with the task network's feature extractor on torch.nn (conv1d + relu + max) must give the same loss and
+    sampler gradients (1e-5 / 2e-3 of the norm: the gradient passes two max-pools and a kNN softmax)."""
+    import copy
+
+    import torch.nn.functional as F
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss
+
+    torch.manual_seed(3)
+    B, N, M = 4, 512, 64
+    net_a = SampleNet(M, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    pcr = PCRNet(bottleneck_size=256, input_shape="bnc").cuda().eval()
+    for p in pcr.parameters():
+        p.requires_grad_(False)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    target = x[:, torch.randperm(N, device="cuda")[:M]].contiguous()
+
+    class TorchFeat(torch.nn.Module):  # the reference's PointNetFeatures.forward (pcrnet.py:23-41) on the same weights
+        def __init__(self, f):
+            super().__init__()
+            self.f = f
+
+        def forward(self, p):
+            y = p.permute(0, 2, 1)
+            for c in (self.f.conv1, self.f.conv2, self.f.conv3, self.f.conv4, self.f.conv5):
+                y = F.relu(F.conv1d(y, c.weight, c.bias))
+            return torch.max(y, 2)[0].contiguous()
+
+    pcr_t = copy.copy(pcr)
+    pcr_t._modules = dict(pcr._modules)
+    pcr_t._modules["feat"] = TorchFeat(pcr.feat)
+    kw = dict(alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, use_graph=False)
+    la = SamplerTrainStep(net_a, x, task_loss=lambda proj: pcrnet_chamfer_loss(pcr, proj, target)[0], **kw)(x)
+    lb = SamplerTrainStep(net_b, x, task_loss=lambda proj: pcrnet_chamfer_loss(pcr_t, proj, target)[0], **kw)(x)
+    assert torch.isfinite(la) and abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+    gb = {n: p.grad for n, p in net_b.named_parameters()}
+    gmax = max(float(v.norm()) for v in gb.values())
+    for n, p in net_a.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        assert float((p.grad - gb[n]).norm()) <= 2e-3 * float(gb[n].norm()) + 1e-5 * gmax, n
