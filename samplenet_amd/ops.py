@@ -115,6 +115,19 @@ def nn_matching(xyz, idx, k, complete_fps=True, layout=BNC):
     return out
 
 
+def emd_matching(full_pc, gen_pc):
+    """Device-side `emd_matching` of the TF sampler (classification/models/samplenet_model.py:152-167, the same three steps
+    as reconstruction/src/samplenet_pointnet_ae.py:111-116): match = approx_match(full_pc, gen_pc) (B,k,N); every generated
+    point takes the input point it is matched to most strongly (argmax over the N inputs, first maximum); repeats are
+    dropped in first-occurrence order and the set is completed to k points by farthest-point sampling (sn_nn_matching).
+    full_pc (B,N,3), gen_pc (B,k,3) -> (B,k,3) points of full_pc.  Nothing leaves the GPU."""
+    _need_gpu(full_pc, gen_pc)
+    k = gen_pc.shape[1]
+    match = approx_match(full_pc, gen_pc)          # (B, k, N)
+    idx = torch.argmax(match, dim=2).int()         # first maximum, as tf.argmax / numpy
+    return nn_matching(full_pc, idx, k, complete_fps=True)
+
+
 # --------------------------------------------------------------------------------------------- gather ops
 class GroupPointFunction(torch.autograd.Function):
     """points (B,n,c), idx (B,m,ns) int32 -> (B,m,ns,c)   [tf_grouping.py:46-61]"""
