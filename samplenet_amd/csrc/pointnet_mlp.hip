@@ -59,30 +59,71 @@ __device__ __forceinline__ float4 ld4_guard(const float *__restrict__ p, size_t 
 
 enum { ACT_NONE = 0, ACT_BN_RELU = 1, ACT_BN_RELU_FX = 2 };
 
-// Batch statistics as 64-bit fixed point (2^-26 units) accumulated with integer atomics: integer addition is associative,
-// so the totals do not depend on the order the workgroups arrive in (deterministic, unlike floating-point atomics), and the
-// CONSUMER of the statistics (the next layer's GEMM) can finalise the BatchNorm itself from 2 C numbers -- no
-// partials-reduction launch between two layers.  Range +-1.4e11, resolution 1.5e-8 per contribution.
-constexpr double kFxScale = 67108864.0;
+// Batch statistics as fixed point accumulated with INTEGER atomics: integer addition is associative, so the totals do not
+// depend on the order the workgroups arrive in (deterministic, unlike floating-point atomics), and the CONSUMER of the
+// statistics (the next layer's GEMM) can finalise the BatchNorm itself from 2 C numbers -- no partials-reduction launch
+// between two layers.  A contribution v (an fp32 block sum) is q = v * 2^SHIFT as an integer (exact: v has 24 significant
+// bits; sub-resolution tails are rounded to nearest).  |q| < 2^50 -- every realistic value -- goes into the signed "lo"
+// accumulator with ONE atomic (<= 2^13 contributions: the sum stays below 2^63).  Larger ones are split q = hi * 2^50 + lo
+// (0 <= lo < 2^50) over the lo and a "hi" accumulator (one pair of hi rows per layer, shared by all slots: rare).
+// Nothing can overflow for |v| * 2^SHIFT < 2^100; beyond that, or for a non-finite v, the poison word is set
+// and the consumer produces NaN coefficients (loud) instead of wrapped sums.  SHIFT = 32 forward (resolution 2.3e-10,
+// single-atomic path up to |v| < 2^18), 60 backward (gradient sums down to 1e-18, single-atomic path up to 1e-3).
+// The total IS the exact sum of the block sums -- better than the double-precision reduction of partials it replaces.
 // Same-address device-scope atomics serialise at the memory side (~20 ns per 128-byte line operation, measured: 512
-// workgroups adding into one set of 2 C sums cost ~10 us per layer): the workgroups spread over kFxSlots copies
+// workgroups adding into one set of sums cost ~10 us per layer): the workgroups spread over kFxSlots copies
 // (swept 4 / 8 / 16 / 32: 243.5 / 240.3 / 239.2 / 255.5 us per step).
 #ifndef SN_FX_SLOTS
 #define SN_FX_SLOTS 16
 #endif
 constexpr int kFxSlots = SN_FX_SLOTS;
-constexpr int kFxLayer = kFxSlots * 256;  // long long per layer: [kFxSlots][2][128]
-__device__ __forceinline__ void fx_add(long long *acc, float v)
+constexpr int kFxRow = 128;                           // channels per row (C <= 128)
+constexpr int kFxHi = kFxSlots * 2 * kFxRow;          // lo rows [slot][stat][128], then ONE pair of hi rows [stat][128]
+constexpr int kFxPoison = kFxHi + 2 * kFxRow;         // (large contributions are rare: they all share slot-less hi rows, so
+constexpr int kFxLayer = kFxPoison + 64;              //  consumers read them unconditionally -- no flag, no branch)
+constexpr int kFxShiftFwd = 32, kFxShiftBwd = 60;
+constexpr double kFx2p50 = 1125899906842624.0;
+template <int SHIFT>
+__device__ __forceinline__ void fx_add(long long *layer, int slot, int stat, int c, float v)
 {
-    atomicAdd(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)__double2ll_rn((double)v * kFxScale));
+    const double d = (double)v * (double)(1ull << 30) * (double)(1ull << (SHIFT - 30));  // exact power-of-two scaling
+    long long *lo = layer + (slot * 2 + stat) * kFxRow + c;
+    if (fabs(d) < kFx2p50) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(lo), (unsigned long long)__double2ll_rn(d));
+    } else if (fabs(d) < kFx2p50 * kFx2p50) {
+        const double h = floor(d * (1.0 / kFx2p50));
+        atomicAdd(reinterpret_cast<unsigned long long *>(lo), (unsigned long long)__double2ll_rn(d - h * kFx2p50));
+        atomicAdd(reinterpret_cast<unsigned long long *>(layer + kFxHi + stat * kFxRow + c), (unsigned long long)(long long)h);
+    } else {  // (also NaN)
+        layer[kFxPoison] = 1;
+    }
 }
-__device__ __forceinline__ double fx_get(const long long *acc)  // total over the slots
+// both totals of channel c (stat 0, stat 1) over the slots, in ONE batch of loads and without a branch: reading the
+// statistics one after the other, or behind a "hi rows in use" flag test, costs a second memory round trip per consumer
+// (+6 us per step, measured).
+template <int SHIFT>
+__device__ __forceinline__ void fx_get2(const long long *layer, int c, double &t0, double &t1)
 {
-    long long t = 0;
+    const long long poison = layer[kFxPoison];
+    long long a = 0, b = 0;
 #pragma unroll
-    for (int q = 0; q < kFxSlots; ++q) t += acc[q * 256];
-    return (double)t * (1.0 / kFxScale);
+    for (int q = 0; q < kFxSlots; ++q) a += layer[(q * 2 + 0) * kFxRow + c], b += layer[(q * 2 + 1) * kFxRow + c];
+    const long long ha = layer[kFxHi + c], hb = layer[kFxHi + kFxRow + c];
+    const double x = (double)a + (double)ha * kFx2p50, y = (double)b + (double)hb * kFx2p50;
+    const double sc = (1.0 / (double)(1ull << 30)) * (1.0 / (double)(1ull << (SHIFT - 30)));
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    t0 = poison ? nan : x * sc;
+    t1 = poison ? nan : y * sc;
 }
+// every workgroup clears its share of the accumulators the PREVIOUS kernel consumed (nobody touches them in this launch)
+__device__ __forceinline__ void fx_clear_share(long long *p, int n, int block, int nblocks, int tid, int nthreads)
+{
+    if (!p || tid < 0) return;
+    const int per = (n + nblocks - 1) / nblocks;
+    const int end = min(n, (block + 1) * per);
+    for (int i = block * per + tid; i < end; i += nthreads) p[i] = 0;
+}
+
 enum { DZ_PLAIN = 0, DZ_BN = 1, DZ_POOL = 2 };
 
 // activation of the previous layer, rows x channels, channel-contiguous: a = relu(scale[c]*z + shift[c]) or raw
@@ -418,9 +459,11 @@ __device__ __forceinline__ void column_reduce2(float (&p0)[T::TN], float (&p1)[T
             a0 += red[(r * 2 + 0) * T::BN + tid];
             a1 += red[(r * 2 + 1) * T::BN + tid];
         }
-        if (FX) {
-            fx_add(reinterpret_cast<long long *>(out0) + col0 + tid, a0);
-            fx_add(reinterpret_cast<long long *>(out1) + col0 + tid, a1);
+        if (FX) {  // out0 = the layer's accumulator block, out1 unused
+            long long *layer = reinterpret_cast<long long *>(out0);
+            const int slot = blockIdx.x % kFxSlots;
+            fx_add<kFxShiftFwd>(layer, slot, 0, col0 + tid, a0);
+            fx_add<kFxShiftFwd>(layer, slot, 1, col0 + tid, a1);
         } else {
             out0[col0 + tid] = a0;
             out1[col0 + tid] = a1;
@@ -575,8 +618,10 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         const BnFwd bp = g.bn_prev;
         const bool first = blockIdx.x == 0 && blockIdx.y == 0;
         for (int c = threadIdx.x; c < Ci; c += T::THREADS) {
-            const double mean = fx_get(g.acc_in + c) / (double)bp.R;
-            double var = fx_get(g.acc_in + 128 + c) / (double)bp.R - mean * mean;
+            double sum1, sum2;
+            fx_get2<kFxShiftFwd>(g.acc_in, c, sum1, sum2);
+            const double mean = sum1 / (double)bp.R;
+            double var = sum2 / (double)bp.R - mean * mean;
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)bp.eps));
             const float sc = bp.gamma[c] * invstd, sh = bp.beta[c] - (float)mean * sc;
@@ -590,10 +635,8 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
                 }
             }
         }
-        if (first) {
-            if (threadIdx.x == 0 && bp.num_batches_tracked) *bp.num_batches_tracked += 1;
-            for (int i = threadIdx.x; i < g.zero_n; i += T::THREADS) g.zero_ptr[i] = 0;
-        }
+        if (first && threadIdx.x == 0 && bp.num_batches_tracked) *bp.num_batches_tracked += 1;
+        fx_clear_share(g.zero_ptr, g.zero_n, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, threadIdx.x, T::THREADS);
         __syncthreads();
         static_assert(FULL || AMODE != ACT_BN_RELU_FX, "fixed-point statistics chain: full tiles only");
         gemm_tile<T, true, true>(
@@ -660,8 +703,7 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
     SN_TL_DRAIN();
     SN_TL(4);
     if (g.acc_out) {
-        long long *ao = g.acc_out + (blockIdx.x % kFxSlots) * 256;
-        column_reduce2<T, true>(s0, s1, lds, reinterpret_cast<float *>(ao), reinterpret_cast<float *>(ao + 128), col0, Co);
+        column_reduce2<T, true>(s0, s1, lds, reinterpret_cast<float *>(g.acc_out), nullptr, col0, Co);
     } else if (g.stats) {
         float *st = g.stats + (size_t)blockIdx.x * 2 * Co;
         column_reduce2<T>(s0, s1, lds, st, st + Co, col0, Co);
@@ -1343,7 +1385,8 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
             const int c = tid - 256;
             if (c < CO) {
                 const BnBwd bb = g.bb_in;
-                const double su = fx_get(g.acc_in + c), sz = fx_get(g.acc_in + 128 + c);
+                double su, sz;
+                fx_get2<kFxShiftBwd>(g.acc_in, c, su, sz);
                 const BnBwdOut o = bn_backward_coefs(bb.R, su, sz, bn_bwd_inputs(bb, CO, c));
                 Ks[c] = o.k1, Ks[CO + c] = o.k2, Ks[2 * CO + c] = o.k3;
                 if (blockIdx.x == 0) {
@@ -1352,8 +1395,7 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
                     if (bb.kcoef) bb.kcoef[c] = o.k1, bb.kcoef[CO + c] = o.k2, bb.kcoef[2 * CO + c] = o.k3;
                 }
             }
-            if (blockIdx.x == 0)
-                for (int i = tid - 256; i < g.zero_n; i += 256) g.zero_ptr[i] = 0;
+            fx_clear_share(g.zero_ptr, g.zero_n, blockIdx.x, gridDim.x, tid - 256, 256);
             __syncthreads();
         }
         if (WLDS) cbf_stage_w<CI, CO, LDW>(g.W, Ws, tid);
@@ -1409,13 +1451,12 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
     if (tid < CI) {
         const float *red = lds;
         float *st = g.stats + (size_t)blockIdx.x * (IN3 ? 6 : 2) * CI;
-        long long *ao = g.acc_out + (blockIdx.x % kFxSlots) * 256;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             float a = red[k * CI + tid];
             if (RB == 2) a += red[(NST + k) * CI + tid];
             if (!IN3 && g.acc_out)
-                fx_add(ao + k * 128 + tid, a);
+                fx_add<kFxShiftBwd>(g.acc_out, blockIdx.x % kFxSlots, k, tid, a);
             else
                 st[k * CI + tid] = a;
         }
@@ -1852,8 +1893,12 @@ __global__ void __launch_bounds__(256) small_bwd_kernel(DgradArgs d, WgradArgs w
 __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const float *__restrict__ x,
                                                            const float *__restrict__ W, const float *__restrict__ bias,
                                                            float *__restrict__ z, float *__restrict__ stats,
-                                                           long long *__restrict__ acc_out = nullptr)
+                                                           long long *__restrict__ acc_out = nullptr,
+                                                           long long *__restrict__ clear_flags = nullptr)
 {
+    // (statistics chain: the poison word of the LAST layer's accumulators, read by every workgroup of the previous
+    // step's closing kernel, is reset here, by the first kernel of the next step)
+    if (clear_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) clear_flags[0] = 0;
     // thread -> 4 consecutive channels (c4) x row slot rs (16 slots): 16-byte stores, a wave writes 4 whole 256-byte rows
     // per instruction (dword stores cost ~58 issue cycles per wave-instruction: the 16-per-thread version was issue-bound)
     __shared__ float red[2][16][64];
@@ -1907,9 +1952,8 @@ __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const 
 #pragma unroll
             for (int k = 0; k < 16; ++k) a0 += red[0][k][threadIdx.x], a1 += red[1][k][threadIdx.x];
             if (acc_out) {  // fixed-point statistics chain (sn_conv_stack_forward_bn)
-                long long *ao = acc_out + (blockIdx.x % kFxSlots) * 256;
-                fx_add(ao + c, a0);
-                fx_add(ao + 128 + c, a1);
+                fx_add<kFxShiftFwd>(acc_out, blockIdx.x % kFxSlots, 0, c, a0);
+                fx_add<kFxShiftFwd>(acc_out, blockIdx.x % kFxSlots, 1, c, a1);
             } else {
                 float *st = stats + (size_t)blockIdx.x * 2 * Co;
                 st[c] = a0;
@@ -2073,14 +2117,15 @@ __global__ void __launch_bounds__(1024) bn_finalize_pool_kernel(int nblk, int C,
         // fixed-point statistics chain: the sums are complete in acc [2][C]; this workgroup is the only reader of its
         // channels, so it clears them for the next step; workgroup 0 clears what the previous kernel consumed
         if (threadIdx.x < kChan && c < C) {
-            s = fx_get(acc + c), ss = fx_get(acc + 128 + c);
+            fx_get2<kFxShiftFwd>(acc, c, s, ss);
 #pragma unroll
-            for (int q = 0; q < kFxSlots; ++q) acc[q * 256 + c] = 0, acc[q * 256 + 128 + c] = 0;
+            for (int q = 0; q < kFxSlots * 2 + 2; ++q) acc[q * kFxRow + c] = 0;  // lo rows and the two hi rows
+            // the poison word is cleared by the FIRST kernel of the next step (conv_in3_fwd_kernel): every workgroup of this
+            // launch must be able to see it
             const float2 cf = bn_finalize_channel(bn, C, c, s, ss, in);
             s_sc[cl] = cf.x, s_sh[cl] = cf.y;
         }
-        if (blockIdx.x == 0)
-            for (int i = threadIdx.x; i < zero_n; i += blockDim.x) zero_ptr[i] = 0;
+        fx_clear_share(zero_ptr, zero_n, blockIdx.x, gridDim.x, threadIdx.x, 1024);
     } else if (partial_sums(nblk, C, stats, blockIdx.x, s, ss)) {
         const float2 cf = bn_finalize_channel(bn, C, c, s, ss, in);
         s_sc[cl] = cf.x, s_sh[cl] = cf.y;
@@ -2620,7 +2665,7 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
     for (int l = 0; l < nlayers; ++l) SN_REQUIRE(W[l] && gamma[l] && beta[l] && z[l] && coef[l], "null pointer");
     // layer 0: xyz input
     hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3(R / 64, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
-                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc);
+                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * kFxLayer + kFxPoison);
     using T = TileBig;
     for (int l = 1; l < nlayers; ++l) {
         const int Ci = channels[l], Co = channels[l + 1];

@@ -262,6 +262,61 @@ def test_fixed_point_statistics_chain(B, N):
     assert torch.equal(s2["zc"][4], sa["zc"][4]) and torch.equal(s2["cc"][4][:2], sa["cc"][4][:2])
 
 
+@pytest.mark.parametrize("scale", [3.0e3, 2.0e5, 1.0e-4])
+def test_fixed_point_statistics_range(scale):
+    """The fixed-point accumulators are exact over the whole fp32 range that matters: unnormalised clouds (coordinates in
+    the thousands: block sums beyond 2^18 take the split lo / hi path), tiny ones (sums far below 1), and gradients scaled
+    accordingly -- forward coefficients and all gradients still agree with the partial-sum path; a non-finite input poisons
+    the statistics (NaN BatchNorm coefficients / running statistics, never a wrapped sum), and the step after it is clean."""
+    import copy
+
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(17)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    x = ((torch.rand(8, 512, 3, device="cuda") - 0.5) * scale).contiguous()
+    g = torch.randn(8, 3, 64, device="cuda") * (1.0 / scale)
+    old = pointnet.FX_STATS
+    try:
+        pointnet.FX_STATS = True
+        ya = net_a._features(x.permute(0, 2, 1), x)
+        (ya * g).sum().backward()
+        pointnet.FX_STATS = False
+        yb = net_b._features(x.permute(0, 2, 1), x)
+        (yb * g).sum().backward()
+    finally:
+        pointnet.FX_STATS = old
+    assert torch.isfinite(ya).all() and _rel(ya, yb) <= 1e-4
+    for l in (1, 2, 3, 4, 5):
+        ra, rb = getattr(net_a, "bn%d" % l).running_var, getattr(net_b, "bn%d" % l).running_var
+        assert torch.allclose(ra, rb, rtol=2e-6, atol=0), l
+    gb = {n: p.grad for n, p in net_b.named_parameters() if p.grad is not None}
+    gmax = max(float(v.norm()) for v in gb.values())
+    for n, p in net_a.named_parameters():
+        if not n.startswith("project"):
+            assert float((p.grad - gb[n]).norm()) <= 1e-4 * float(gb[n].norm()) + 1e-6 * gmax, n
+    # poison: a non-finite coordinate -> NaN output, accumulators clean for the next step
+    xbad = x.clone()
+    xbad[0, 0, 0] = float("inf")
+    old = pointnet.FX_STATS
+    try:
+        pointnet.FX_STATS = True
+        with torch.no_grad():
+            net_a._features(xbad.permute(0, 2, 1), xbad)
+            # (the kernels' ReLU is fmaxf(v, 0), which maps NaN to 0, so the OUTPUT may stay finite -- as on the partial-sum
+            # path; what must not happen is a wrapped, plausible-looking statistic)
+            assert not torch.isfinite(net_a.bn1.running_mean).all() or not torch.isfinite(net_a.bn1.running_var).all()
+            net_a.load_state_dict(net_b.state_dict())  # the poisoned step wrote NaN running statistics
+            net_c = copy.deepcopy(net_b)
+            y2 = net_a._features(x.permute(0, 2, 1), x)
+            pointnet.FX_STATS = False
+            y3 = net_c._features(x.permute(0, 2, 1), x)
+    finally:
+        pointnet.FX_STATS = old
+    assert torch.isfinite(y2).all() and _rel(y2, y3) <= 1e-4
+
+
 @pytest.mark.parametrize("B,N", [(32, 1024), (5, 320), (3, 330), (33, 1024)])
 def test_input_layer_weight_gradient_closed_form(B, N):
     """conv1's weight gradient taken out of conv2's fused backward (three extra per-channel sums + the moments of x,
