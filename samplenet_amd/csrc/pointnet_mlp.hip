@@ -126,6 +126,10 @@ __device__ __forceinline__ void fx_clear_share(long long *p, int n, int block, i
 
 enum { DZ_PLAIN = 0, DZ_BN = 1, DZ_POOL = 2 };
 
+// ReLU that propagates NaN like torch.relu (fmaxf(NaN, 0) is 0: a diverged run or poisoned statistics would turn into
+// plausible-looking zeros instead of a NaN loss)
+__device__ __forceinline__ float relu_np(float u) { return u < 0.f ? 0.f : u; }
+
 // activation of the previous layer, rows x channels, channel-contiguous: a = relu(scale[c]*z + shift[c]) or raw
 struct ActSrc {
     const float *z;      // [rows][ch]
@@ -143,7 +147,7 @@ struct ActSrc {
         float v = z[o];
         if (MODE == ACT_BN_RELU) {
             const int cc = ok ? c : 0;
-            v = fmaxf(fmaf(v, scale[cc], shift[cc]), 0.f);
+            v = relu_np(fmaf(v, scale[cc], shift[cc]));
         }
         v *= ok ? 1.f : 0.f;  // mask by multiplication (see small_fwd_kernel): keeps the loads unconditional
         return (ones_col >= 0 && c == ones_col && r < rows) ? 1.f : v;
@@ -159,10 +163,10 @@ struct ActSrc {
             if (MODE == ACT_BN_RELU) {
                 const float4 s = *reinterpret_cast<const float4 *>(scale + c);
                 const float4 t = *reinterpret_cast<const float4 *>(shift + c);
-                v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f);
-                v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
-                v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f);
-                v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+                v.x = relu_np(fmaf(v.x, s.x, t.x));
+                v.y = relu_np(fmaf(v.y, s.y, t.y));
+                v.z = relu_np(fmaf(v.z, s.z, t.z));
+                v.w = relu_np(fmaf(v.w, s.w, t.w));
             }
             return v;
         }
@@ -174,10 +178,10 @@ struct ActSrc {
             v = ld4_guard(z, (size_t)r * ch + c, valid, al);
             if (MODE == ACT_BN_RELU) {
                 const float4 s = ld4_guard(scale, c, valid, al), t = ld4_guard(shift, c, valid, al);
-                v.x = fmaxf(fmaf(v.x, s.x, t.x), 0.f);
-                v.y = fmaxf(fmaf(v.y, s.y, t.y), 0.f);
-                v.z = fmaxf(fmaf(v.z, s.z, t.z), 0.f);
-                v.w = fmaxf(fmaf(v.w, s.w, t.w), 0.f);
+                v.x = relu_np(fmaf(v.x, s.x, t.x));
+                v.y = relu_np(fmaf(v.y, s.y, t.y));
+                v.z = relu_np(fmaf(v.z, s.z, t.z));
+                v.w = relu_np(fmaf(v.w, s.w, t.w));
             }
             if (valid < 2) v.y = 0.f;
             if (valid < 3) v.z = 0.f;
@@ -644,8 +648,8 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
             [&](int x, int k) {
                 float4 v = *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k);
                 const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
-                v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+                v.x = relu_np(fmaf(v.x, sc.x, sh.x)), v.y = relu_np(fmaf(v.y, sc.y, sh.y));
+                v.z = relu_np(fmaf(v.z, sc.z, sh.z)), v.w = relu_np(fmaf(v.w, sc.w, sh.w));
                 return v;
             },
             [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
@@ -1054,9 +1058,9 @@ __device__ __forceinline__ void cbf_stage(const ConvBwdArgs &g, int tile, int n0
         // the wgrad B operand is the ACTIVATION relu(bn(Zprev)): transformed here, once, by all eight waves (in the MFMA
         // loop the two VALU ops per fragment serialised with the wave's own MFMAs -- measured 3x slower)
         float *o = Ps + (pr + q * PSTEP) * LDP + pc4;
-        *reinterpret_cast<float2 *>(o) = make_float2(fmaxf(fmaf(rp[q].x, sc4.x, sh4.x), 0.f), fmaxf(fmaf(rp[q].y, sc4.y, sh4.y), 0.f));
+        *reinterpret_cast<float2 *>(o) = make_float2(relu_np(fmaf(rp[q].x, sc4.x, sh4.x)), relu_np(fmaf(rp[q].y, sc4.y, sh4.y)));
         *reinterpret_cast<float2 *>(o + 2) =
-            make_float2(fmaxf(fmaf(rp[q].z, sc4.z, sh4.z), 0.f), fmaxf(fmaf(rp[q].w, sc4.w, sh4.w), 0.f));
+            make_float2(relu_np(fmaf(rp[q].z, sc4.z, sh4.z)), relu_np(fmaf(rp[q].w, sc4.w, sh4.w)));
     }
 }
 
@@ -1637,8 +1641,8 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
             const int r = r0 + q * rpp;
             float4 a = av[q];
             if (AMODE == ACT_BN_RELU) {
-                a.x = fmaxf(fmaf(a.x, sc4.x, sh4.x), 0.f), a.y = fmaxf(fmaf(a.y, sc4.y, sh4.y), 0.f);
-                a.z = fmaxf(fmaf(a.z, sc4.z, sh4.z), 0.f), a.w = fmaxf(fmaf(a.w, sc4.w, sh4.w), 0.f);
+                a.x = relu_np(fmaf(a.x, sc4.x, sh4.x)), a.y = relu_np(fmaf(a.y, sc4.y, sh4.y));
+                a.z = relu_np(fmaf(a.z, sc4.z, sh4.z)), a.w = relu_np(fmaf(a.w, sc4.w, sh4.w));
             }
             const float ma = r < R ? 1.f : 0.f, mw = col0 + r < Co ? 1.f : 0.f;
             a.x *= ma, a.y *= ma, a.z *= ma, a.w *= ma;
@@ -2158,7 +2162,7 @@ __global__ void __launch_bounds__(1024) bn_finalize_pool_kernel(int nblk, int C,
             if (sel == 0 ? (ob > best || (ob == best && oa < arg)) : (ob < best || (ob == best && oa < arg))) best = ob, arg = oa;
         }
         if (quarter == 0 && b < B) {
-            pooled[(size_t)b * C + c] = fmaxf(fmaf(best, sc, sh), 0.f);
+            pooled[(size_t)b * C + c] = relu_np(fmaf(best, sc, sh));
             argsel[(size_t)b * C + c] = arg;
             zsel[(size_t)b * C + c] = best;
         }
@@ -2425,7 +2429,7 @@ __global__ void __launch_bounds__(1024) pool_fwd_kernel(int N, int C, const floa
         const float sc = coef[c], sh = coef[C + c];
         const bool up = sc >= 0.f;
         const float zs = up ? vmax : vmin;
-        pooled[(size_t)b * C + c] = fmaxf(fmaf(zs, sc, sh), 0.f);
+        pooled[(size_t)b * C + c] = relu_np(fmaf(zs, sc, sh));
         argsel[(size_t)b * C + c] = up ? imax : imin;
         zsel[(size_t)b * C + c] = zs;
     }

@@ -267,7 +267,7 @@ def test_fixed_point_statistics_range(scale):
     """The fixed-point accumulators are exact over the whole fp32 range that matters: unnormalised clouds (coordinates in
     the thousands: block sums beyond 2^18 take the split lo / hi path), tiny ones (sums far below 1), and gradients scaled
     accordingly -- forward coefficients and all gradients still agree with the partial-sum path; a non-finite input poisons
-    the statistics (NaN BatchNorm coefficients / running statistics, never a wrapped sum), and the step after it is clean."""
+    the statistics (NaN BatchNorm coefficients -> NaN output, never a wrapped sum), and the step after it is clean."""
     import copy
 
     from samplenet_amd import SampleNet, pointnet
@@ -303,9 +303,8 @@ def test_fixed_point_statistics_range(scale):
     try:
         pointnet.FX_STATS = True
         with torch.no_grad():
-            net_a._features(xbad.permute(0, 2, 1), xbad)
-            # (the kernels' ReLU is fmaxf(v, 0), which maps NaN to 0, so the OUTPUT may stay finite -- as on the partial-sum
-            # path; what must not happen is a wrapped, plausible-looking statistic)
+            ybad = net_a._features(xbad.permute(0, 2, 1), xbad)
+            assert torch.isnan(ybad).any()  # NaN coefficients + NaN-propagating ReLU: loud, as torch's own modules
             assert not torch.isfinite(net_a.bn1.running_mean).all() or not torch.isfinite(net_a.bn1.running_var).all()
             net_a.load_state_dict(net_b.state_dict())  # the poisoned step wrote NaN running statistics
             net_c = copy.deepcopy(net_b)
