@@ -501,6 +501,47 @@ __device__ __forceinline__ void step_loss_final(const StepLossFinal &f, int t)
     f.loss[1] = lsimp;
 }
 
+// keys mode of the step loss (sn_pairscan_forward_keys): loss value from the scan's query-side partials and the backward's
+// per-cloud sum of dist_p
+struct StepLossKeysFinal {
+    int B, G, M, N, nproj;
+    float w, alpha, lmbda, min_sigma;
+    const float *qpart;   // [B][G][2]  (sum dist_q, sum proj)
+    const sn_u64 *qmax;   // [B][G]     max (dist_q, ~query) key
+    const float *dpsum;   // [B]
+    const float *temperature;
+    float *loss;          // NULL: nothing to do
+    sn_u64 *keys;         // [nkeys] inverted per-point keys, re-zeroed for the next step
+    long long nkeys;
+};
+__device__ __forceinline__ void step_loss_keys_final(const StepLossKeysFinal &f, int t)
+{
+    float s1 = 0.f, mx = 0.f, s2 = 0.f, sp = 0.f;
+    for (int b = t; b < f.B; b += 64) {
+        float a1 = 0.f, ap = 0.f;
+        sn_u64 mk = 0;
+        for (int g = 0; g < f.G; ++g) {
+            const size_t o = (size_t)b * f.G + g;
+            a1 += f.qpart[o * 2], ap += f.qpart[o * 2 + 1];
+            mk = f.qmax[o] > mk ? f.qmax[o] : mk;
+        }
+        s1 += a1, sp += ap, mx += key_dist(mk), s2 += f.dpsum[b];
+    }
+    const float T = *f.temperature;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        mx += __shfl_xor(mx, o);
+        s2 += __shfl_xor(s2, o);
+        sp += __shfl_xor(sp, o);
+    }
+    if (t != 0) return;
+    const float c12 = s1 / ((float)f.B * (float)f.M), cmax = mx / (float)f.B, c21 = s2 / ((float)f.B * (float)f.N);
+    const float lsimp = c12 + cmax + f.w * c21;
+    f.loss[0] = f.alpha * lsimp + f.lmbda * fmaxf(T * T, f.min_sigma) + sp / ((float)f.B * (float)f.nproj);
+    f.loss[1] = lsimp;
+}
+
 // Chamfer backward (implicit upstream gradients, targets = the simplified cloud) + soft-projection backward of the same
 // query in ONE launch: a wave finishes the Chamfer gradient of target j exactly as chamfer_bwd_reg_kernel does, then runs
 // the soft-projection backward of query j (same point: the simplified cloud is both) and stores the sum -- the same
@@ -516,6 +557,12 @@ struct StepLossFold {
     const float *proj;  // [B][nproj]
     int nproj;
     float *part;        // [B][4]
+    // keys mode (sn_pairscan_forward_keys + sn_sampler_step_loss_keys): the per-point minima are already complete, as
+    // INVERTED (distance, query) keys [B][ns]; the argmax of dist_q comes from the scan's per-workgroup maxima qmax [B][G];
+    // the y == 0 workgroup leaves sum dist_p of its cloud in dpsum [B]
+    const sn_u64 *keys;
+    const sn_u64 *qmax;
+    float *dpsum;
 };
 
 template <int PPL>
@@ -586,10 +633,27 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
         }
         __syncthreads();  // s_part is reused below
     }
+    if (fold.keys) {
+        if (wave == 0) {  // argmax of dist_q: maximum of the (dist_q, ~query) keys of the cloud's scan workgroups
+            sn_u64 mk = 0;
+            for (int g = lane; g < fold.G; g += 64) {
+                const sn_u64 v = fold.qmax[(size_t)b * fold.G + g];
+                mk = v > mk ? v : mk;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned hi = __shfl_xor((unsigned)(mk >> 32), o), lo = __shfl_xor((unsigned)mk, o);
+                const sn_u64 v = ((sn_u64)hi << 32) | lo;
+                mk = v > mk ? v : mk;
+            }
+            if (lane == 0) s_am = (int)(0xFFFFFFFFu - (unsigned)mk);
+        }
+        __syncthreads();
+    }
     T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
     idxT += (size_t)b * nt, idxS += (size_t)b * ns;
     const float gLv = *ig.gL * ig.gscale;
-    const int amt = fold.ws ? s_am : (ig.argmax_t ? ig.argmax_t[b] : -1), ams = ig.argmax_s ? ig.argmax_s[b] : -1;
+    const int amt = (fold.ws || fold.keys) ? s_am : (ig.argmax_t ? ig.argmax_t[b] : -1), ams = ig.argmax_s ? ig.argmax_s[b] : -1;
     gradT += (size_t)b * nt * 3;
     const float Tm = *sa.temperature;
     const float sigma = fmaxf(Tm * Tm, sa.min_sigma);
@@ -597,14 +661,26 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
 
     float sx[PPL], sy[PPL], sz[PPL], gg[PPL];
     int is[PPL];
+    float dpl = 0.f;
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const int l = i * 64 + lane;
         const int lc = l < ns ? l : 0;
         const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)lc * 3);
         sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
-        is[i] = l < ns ? (fold.ws ? s_ip[lc] : idxS[lc]) : -1;
+        if (fold.keys) {
+            const sn_u64 k = ~fold.keys[(size_t)b * ns + lc];
+            is[i] = l < ns ? key_index(k) : -1;
+            dpl += l < ns ? key_dist(k) : 0.f;
+        } else {
+            is[i] = l < ns ? (fold.ws ? s_ip[lc] : idxS[lc]) : -1;
+        }
         gg[i] = gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) * 2;
+    }
+    if (fold.keys && blockIdx.y == 0 && wave == 0) {  // sum dist_p of the cloud (for the loss value), fixed order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dpl += __shfl_xor(dpl, o);
+        if (lane == 0) fold.dpsum[b] = dpl;
     }
     for (int j = blockIdx.y * nwaves + wave; j < nt; j += nsplit * nwaves) {
         const float tx = T[j], ty = T[j + nt], tz = T[j + 2 * nt];  // targets channel-major (3, nt)
@@ -810,10 +886,21 @@ extern "C" int sn_sampler_loss_backward(int nproj, const float *grad_loss, const
 __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float *__restrict__ partial,
                                                          const float *__restrict__ temperature, float min_sigma,
                                                          float *__restrict__ grad_T, const float *__restrict__ gsigma_direct,
-                                                         float direct_scale, StepLossFinal fin = StepLossFinal{})
+                                                         float direct_scale, StepLossFinal fin = StepLossFinal{},
+                                                         StepLossKeysFinal kf = StepLossKeysFinal{})
 {
     if (fin.loss && blockIdx.x == 1) {  // second workgroup (fold mode): the step's loss value from the per-cloud partials
         if (threadIdx.x < 64) step_loss_final(fin, threadIdx.x);
+        return;
+    }
+    if (kf.loss && blockIdx.x >= 1) {  // keys mode: workgroup 1 combines the loss value, the others re-zero the key table
+        if (blockIdx.x == 1) {
+            if (threadIdx.x < 64) step_loss_keys_final(kf, threadIdx.x);
+        } else {
+            const long long nb = gridDim.x - 2, per = (kf.nkeys + nb - 1) / nb;
+            const long long i0 = (long long)(blockIdx.x - 2) * per, i1 = i0 + per < kf.nkeys ? i0 + per : kf.nkeys;
+            for (long long i = i0 + threadIdx.x; i < i1; i += 256) kf.keys[i] = 0;
+        }
         return;
     }
     // fixed-order reduction: strided per-thread sums, xor tree inside each wave, the four wave totals in order
@@ -1154,6 +1241,51 @@ extern "C" int sn_sampler_step_loss_fold(int B, int N, int M, int K, const float
     const StepLossFinal fin{B, M, N, 3 * M, weight, alpha, lmbda, min_sigma, partial, temperature, loss};
     hipLaunchKernelGGL(sigma_grad_kernel, dim3(2), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
                        grad_loss, lmbda, fin);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Loss side of the sampler step behind sn_pairscan_forward_keys (engine): backward + loss value in 2 launches, nothing
+// between the scan and the backward.  colmin_keys / qpart / qmax as the scan left them; colmin_keys is zero again afterwards.
+// dpsum: B floats of scratch; loss[0] = L, loss[1] = L_simp.  N <= 2048.
+extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
+                                         const int *knn_idx, const int *idx_q, void *colmin_keys, const float *qpart,
+                                         const void *qmax, int G, const float *temperature, float min_sigma, float alpha,
+                                         float lmbda, float weight, const float *grad_loss, float *grad_Q,
+                                         float *gsig_scratch, float *grad_T, float *dpsum, float *loss, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && G >= 1, "bad size");
+    SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
+    SN_REQUIRE(P && Q && knn_idx && idx_q && colmin_keys && qpart && qmax && temperature && grad_loss && grad_Q && gsig_scratch &&
+                   grad_T && dpsum && loss,
+               "null pointer");
+    if (N > 2048) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_sampler_step_loss_keys: N <= 2048");
+    hipStream_t st = (hipStream_t)stream;
+    const float c1 = 1.0f / ((float)B * (float)M), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)N);
+    ImplicitGrad ig{grad_loss, nullptr, nullptr, c1, cm, c2, 0.f, alpha};
+    SoftBwdArgs a{};
+    a.P = P, a.Q = Q, a.idx = knn_idx, a.temperature = temperature, a.min_sigma = min_sigma;
+    a.p_layout = p_layout, a.q_layout = SN_LAYOUT_BCN, a.n = N, a.m = M, a.k = K;
+    a.grad_proj = nullptr, a.gconst = grad_loss, a.gconst_div = (float)(B * 3 * M);
+    a.grad_Q = grad_Q, a.gq_layout = SN_LAYOUT_BCN, a.accumulate_q = 1;
+    a.grad_P = nullptr, a.grad_sigma_partial = gsig_scratch;
+    int splits = std::max(1, std::min((M + 3) / 4, (kChamferBwdGroups + B - 1) / B));
+    splits = std::min(splits, sn_soft_bwd_splits(B, M));
+    StepLossFold fold{};
+    fold.G = G, fold.keys = (const sn_u64 *)colmin_keys, fold.qmax = (const sn_u64 *)qmax, fold.dpsum = dpsum;
+    const dim3 grid(B, splits), block(256);
+#define SN_CS(PPL_)                                                                                                        \
+    hipLaunchKernelGGL(chamfer_soft_bwd_kernel<PPL_>, grid, block, 0, st, M, N, Q, P, idx_q, (const int *)nullptr, grad_Q, ig, a, \
+                       StepLossFinal{}, fold)
+    if (N <= 64) SN_CS(1);
+    else if (N <= 256) SN_CS(4);
+    else if (N <= 1024) SN_CS(16);
+    else SN_CS(32);
+#undef SN_CS
+    const StepLossKeysFinal kf{B, G, M, N, 3 * M, weight, alpha, lmbda, min_sigma, qpart, (const sn_u64 *)qmax, dpsum, temperature,
+                               loss, (sn_u64 *)colmin_keys, (long long)B * N};
+    hipLaunchKernelGGL(sigma_grad_kernel, dim3(2 + 64), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
+                       grad_loss, lmbda, StepLossFinal{}, kf);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -185,6 +185,14 @@ struct PairscanArgs {
     const float *fc_z, *fc_scale, *fc_shift, *fc_w, *fc_bias;
     int fc_k;
     float *q_out;
+    // Optional (gridDim.y > 1): the per-point minima are combined ACROSS the workgroups of a cloud by 64-bit atomicMax on
+    // INVERTED keys (max of ~key = min of key; max / min are associative and commutative, so the result does not depend on
+    // the arrival order) into colmin_keys [B][N], which the caller keeps zeroed between steps -- no partial key sets, no
+    // finalisation launch.  Each workgroup then also leaves its share of the step loss's query-side reductions:
+    // qpart [B][gridDim.y][2] = (sum dist_q, sum proj) over its queries, qmax [B][gridDim.y] = max of (dist_q, ~query) keys.
+    sn_u64 *colmin_keys;
+    float *qpart;
+    sn_u64 *qmax;
 };
 
 // coordinate c of query j (see PairscanArgs::fc_w): lane partial sums in k order, then a fixed xor tree
@@ -265,6 +273,8 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
     }
     if (SINGLE) load_chunk<PPL>(px, py, pz, Pb, a.p_layout, N, 0, lane);
 
+    float wsum_dq = 0.f, wsum_pj = 0.f;  // colmin_keys mode: this wave's share of sum dist_q, sum proj, max (dist_q, ~query)
+    sn_u64 wmax = 0;
     for (int j = q0 + wave; j < q1; j += nwaves) {  // wave-uniform
         float qx, qy, qz;
         if (a.fc_w) {
@@ -339,6 +349,9 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
         if (lane == 0) {
             if (a.dist_q) a.dist_q[qrow] = nd;
             if (a.idx_q) a.idx_q[qrow] = nidx;
+            wsum_dq += nd;
+            const sn_u64 kq = make_key(nd, (int)(0xFFFFFFFFu - (unsigned)j));  // larger distance first, then lower query
+            wmax = kq > wmax ? kq : wmax;
         }
         if (want_soft) {
             float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -366,6 +379,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                     const float o = lane == 0 ? ox : (lane == 1 ? oy : oz);
                     a.proj[(size_t)b * 3 * M + pt_off(a.proj_layout, M, j, lane)] = o;
                 }
+                if (lane == 0) wsum_pj += (ox + oy) + oz;
             }
         }
     }
@@ -380,6 +394,26 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                 const sn_u64 k = colmin[n];
                 if (a.dist_p) a.dist_p[(size_t)b * N + n] = key_dist(k);
                 if (a.idx_p) a.idx_p[(size_t)b * N + n] = key_index(k);
+            }
+        } else if (a.colmin_keys) {  // combine with the cloud's other workgroups in place (see PairscanArgs)
+            sn_u64 *kk = a.colmin_keys + (size_t)b * N;
+            for (int n = threadIdx.x; n < N; n += blockDim.x) atomicMax(kk + n, ~colmin[n]);
+            // query-side reductions of this workgroup, waves in order
+            __syncthreads();  // colmin[] is free now: reuse its first words
+            float *wq = reinterpret_cast<float *>(colmin);           // [nwaves][2]
+            sn_u64 *wk = colmin + nwaves;                            // [nwaves]  (behind the 2 * nwaves floats)
+            if (lane == 0) wq[wave * 2] = wsum_dq, wq[wave * 2 + 1] = wsum_pj, wk[wave] = wmax;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float sd = 0.f, sp = 0.f;
+                sn_u64 mk = 0;
+                for (int w2 = 0; w2 < nwaves; ++w2) {
+                    sd += wq[w2 * 2], sp += wq[w2 * 2 + 1];
+                    mk = wk[w2] > mk ? wk[w2] : mk;
+                }
+                const size_t o = (size_t)b * gridDim.y + blockIdx.y;
+                a.qpart[o * 2] = sd, a.qpart[o * 2 + 1] = sp;
+                a.qmax[o] = mk;
             }
         } else {  // this workgroup saw only its share of the queries: publish partial keys
             sn_u64 *ws = a.colmin_ws + ((size_t)b * gridDim.y + blockIdx.y) * N;
@@ -436,7 +470,7 @@ int pairscan_ysplit(int B, int N, int M, bool colmin)
 // cloud be spread over several workgroups even when column minima are wanted (partials + a finalize kernel).
 int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finalize, int *used_split, hipStream_t st)
 {
-    const bool colmin = a.dist_p || a.idx_p || (ws && !finalize);
+    const bool colmin = a.dist_p || a.idx_p || (ws && !finalize) || a.colmin_keys;
     const int N = a.N, M = a.M;
     if (used_split) *used_split = 1;
     if (N <= kWave * 32) {
@@ -444,13 +478,13 @@ int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finaliz
         const int ppl = N <= 64 ? 1 : (N <= 256 ? 4 : (N <= 1024 ? 16 : 32));
         const int maxw = max_threads(ppl, colmin) / kWave;
         int ysplit = pairscan_ysplit(a.B, N, M, colmin);
-        if (colmin && ysplit > 1) {
+        if (colmin && ysplit > 1 && !a.colmin_keys) {
             const long long need = (long long)a.B * ysplit * N * 8;
             if (!ws || ws_bytes < need) ysplit = 1;
         }
         const int qpb = (M + ysplit - 1) / ysplit;
         const int waves = std::max(1, std::min(maxw, qpb));  // one query per wave at the sampler's sizes (swept 2 / 4 / 8: 8 is fastest)
-        a.colmin_ws = (colmin && ysplit > 1) ? (sn_u64 *)ws : nullptr;
+        a.colmin_ws = (colmin && ysplit > 1 && !a.colmin_keys) ? (sn_u64 *)ws : nullptr;
         if (used_split) *used_split = ysplit;
 #define SN_PS(PPL_)                                                                      \
     (colmin ? launch_pairscan<PPL_, true, true>(a, waves, ysplit, st)                    \
@@ -462,7 +496,7 @@ int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finaliz
             default: SN_PS(32); break;
         }
 #undef SN_PS
-        if (colmin && ysplit > 1 && finalize)
+        if (colmin && ysplit > 1 && finalize && !a.colmin_keys)
             hipLaunchKernelGGL(colmin_finalize_kernel, dim3((N + 255) / 256, a.B), dim3(256), 0, st, N, ysplit,
                                (const sn_u64 *)ws, a.dist_p, a.idx_p);
         return 0;
@@ -596,6 +630,42 @@ extern "C" int sn_pairscan_forward_partial(int B, int N, int M, int K, const flo
     a.proj = proj, a.proj_layout = proj_layout, a.temperature = temperature, a.min_sigma = min_sigma;
     int used = 0;
     int rc = sn::pairscan_dispatch(a, workspace, workspace_bytes, false, &used, (hipStream_t)stream);
+    if (rc) return rc;
+    SN_REQUIRE(used == G, "internal: split mismatch");
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Pair scan for callers that run the sampler step's backward right behind it (engine): per-point minima combined across a
+// cloud's workgroups by atomicMax on inverted keys in colmin_keys [B][N] (u64, ZERO on entry; sn_sampler_step_loss_keys
+// leaves it zero again), query-side loss partials in qpart [B][G][2] / qmax [B][G], G = sn_pairscan_colmin_splits(B,N,M) > 1.
+// Queries: Q (B,3,M), or -- fc_w != NULL -- produced by the head's last layer as in sn_pairscan_forward_partial_fc (Q then
+// receives them).  One launch; the loss side needs no reduction launch of its own.
+extern "C" int sn_pairscan_forward_keys(int B, int N, int M, int K, const float *P, int p_layout, float *Q, const float *fc_z,
+                                        const float *fc_scale, const float *fc_shift, const float *fc_w, const float *fc_bias,
+                                        int Kfc, int *knn_idx, float *dist_q, int *idx_q, float *proj, int proj_layout,
+                                        const float *temperature, float min_sigma, void *colmin_keys, float *qpart, void *qmax,
+                                        sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && K <= N, "bad size");
+    SN_REQUIRE(P && Q && dist_q && proj && temperature && colmin_keys && qpart && qmax, "null pointer");
+    SN_REQUIRE(!fc_w || (fc_z && fc_scale && fc_shift && fc_bias && Kfc >= 4 && Kfc % 4 == 0), "bad fc operands");
+    SN_REQUIRE(p_layout == SN_LAYOUT_BNC || p_layout == SN_LAYOUT_BCN, "bad p_layout");
+    const int G = sn_pairscan_colmin_splits(B, N, M);
+    if (G <= 1 || N > sn::kWave * 32)
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pairscan_forward_keys: this shape runs as one workgroup per cloud");
+    PairscanArgs a{};
+    a.P = P, a.Q = Q, a.p_layout = p_layout, a.q_layout = SN_LAYOUT_BCN;
+    a.B = B, a.N = N, a.M = M, a.K = K;
+    a.knn_idx = knn_idx, a.dist_q = dist_q, a.idx_q = idx_q;
+    a.proj = proj, a.proj_layout = proj_layout, a.temperature = temperature, a.min_sigma = min_sigma;
+    if (fc_w) {
+        a.fc_z = fc_z, a.fc_scale = fc_scale, a.fc_shift = fc_shift, a.fc_w = fc_w, a.fc_bias = fc_bias, a.fc_k = Kfc;
+        a.q_out = Q;
+    }
+    a.colmin_keys = (sn_u64 *)colmin_keys, a.qpart = qpart, a.qmax = (sn_u64 *)qmax;
+    int used = 0;
+    int rc = sn::pairscan_dispatch(a, nullptr, 0, false, &used, (hipStream_t)stream);
     if (rc) return rc;
     SN_REQUIRE(used == G, "internal: split mismatch");
     SN_LAUNCH_CHECK();

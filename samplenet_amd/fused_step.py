@@ -19,6 +19,9 @@ from . import ops, pointnet
 # per-cloud loss reduction inside the backward's first launch (sn_sampler_step_loss_fold): one launch less, but every one of
 # the 512 workgroups then re-reduces its cloud's 64 KB of partial keys -- measured +2.2 us per step at B = 32, so OFF
 FOLD_LOSS = os.environ.get("SAMPLENET_AMD_FOLD_LOSS", "0") == "1"
+# per-point minima combined across a cloud's scan workgroups by atomicMax on inverted keys: no reduction launch between the
+# scan and the backward (sn_pairscan_forward_keys / sn_sampler_step_loss_keys)
+KEYS_LOSS = os.environ.get("SAMPLENET_AMD_KEYS_LOSS", "1") != "0"
 
 
 class SamplerStepFunction(torch.autograd.Function):
@@ -36,8 +39,18 @@ class SamplerStepFunction(torch.autograd.Function):
             fc4 = net.fc4
             y = torch.empty(B, 3, M, device=x.device, dtype=torch.float32)
             fc = (saved["zf"][2], saved["cf"][2], fc4.weight.detach(), fc4.bias.detach())
+            keys = None
+            if defer_value and KEYS_LOSS and x.shape[1] <= 2048:
+                # persistent zeroed table of inverted per-point keys (every step leaves it zero again)
+                keys = getattr(net, "_colmin_keys", None)
+                if keys is None or keys.device != x.device or keys.numel() != B * x.shape[1]:
+                    keys = torch.zeros(B * x.shape[1], device=x.device, dtype=torch.int64)
+                    net._colmin_keys = keys
+                elif getattr(net, "_colmin_keys_pending", False):
+                    keys.zero_()  # a forward whose backward never ran left its minima behind
+                net._colmin_keys_pending = True
             loss, proj, state = ops.step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value,
-                                                      fold=bool(defer_value) and FOLD_LOSS and x.shape[1] <= 2048)
+                                                      fold=bool(defer_value) and FOLD_LOSS and x.shape[1] <= 2048, keys=keys)
         ctx.net, ctx.saved, ctx.state = net, saved, state
         ctx.x, ctx.y, ctx.temperature = x, y, temperature
         ctx.cfg = (K, float(min_sigma), float(alpha), float(lmbda), float(weight))
@@ -53,8 +66,14 @@ class SamplerStepFunction(torch.autograd.Function):
             return (None,) * (10 + nparams)
         net = ctx.net
         sink = getattr(net, "_grad_sink", None)
+        if len(ctx.state) > 5 and ctx.state[5][0] == "keys":
+            if getattr(ctx, "keys_consumed", False):
+                raise RuntimeError("SamplerStepFunction: the key table of this forward was already consumed by a backward "
+                                   "(set SAMPLENET_AMD_KEYS_LOSS=0 to backpropagate the same step twice)")
+            ctx.keys_consumed = True
         with torch.cuda.device(ctx.y.device):
             gQ, gT = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink)
+            net._colmin_keys_pending = False  # (the backward's last launch re-zeroed the key table)
             grads = pointnet.backward_impl(net, ctx.saved, gQ.view(gQ.shape[0], -1), sink, getattr(net, "_after_fc_grads", None))
         g_temp = None
         if ctx.t_sink is None and ctx.needs_input_grad[2]:

@@ -471,7 +471,7 @@ class SamplerStepLossFunction(torch.autograd.Function):
         return (gQ if ctx.needs_input_grad[0] else None), None, g_temp, None, None, None, None, None, None, None
 
 
-def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value, fold=False):
+def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value, fold=False, keys=None):
     """Forward launches of the sampler step's loss side (SamplerStepLossFunction / fused_step.SamplerStepFunction).
     x (B,N,3), y (B,3,M): the simplified cloud -- read when fc is None, otherwise WRITTEN by the pair scan from
     fc = (z3 (B,Kfc), coef3 (>=2*Kfc: scale | shift), W4 (3M,Kfc), b4 (3M)).  Caller holds the device guard.
@@ -496,6 +496,18 @@ def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight,
     loss = torch.empty(2, device=dev, dtype=torch.float32)
     T = temperature.detach().float().reshape(1)
     st = _stream(y)
+    if keys is not None:
+        # keys mode: the scan combines the per-point minima in place (atomicMax on inverted keys in the caller's persistent,
+        # zeroed table) -- no partial key sets, nothing between the scan and the backward (sn_sampler_step_loss_keys)
+        qpart = torch.empty(B * G * 2, device=dev, dtype=torch.float32)
+        qmax = torch.empty(B * G, device=dev, dtype=torch.int64)
+        z3, coef3, W4, b4 = fc if fc is not None else (None, None, None, None)
+        Kfc = z3.shape[1] if fc is not None else 0
+        check(lib.sn_pairscan_forward_keys(B, N, M, K, ptr(x), BNC, ptr(y), ptr(z3), ptr(coef3),
+                                           (coef3.data_ptr() + 4 * Kfc) if fc is not None else None, ptr(W4), ptr(b4), Kfc,
+                                           ptr(idx), ptr(dq), ptr(iq), ptr(proj), BNC, ptr(T), float(min_sigma), ptr(keys),
+                                           ptr(qpart), ptr(qmax), st), "sn_pairscan_forward_keys")
+        return loss, proj, (idx, iq, None, None, (partial, loss), ("keys", keys, qpart, qmax, G))
     if fc is None:
         check(lib.sn_pairscan_forward_partial(B, N, M, K, ptr(x), BNC, ptr(y), BCN, ptr(idx), ptr(dq), ptr(iq), ptr(proj), BNC,
                                               ptr(T), float(min_sigma), ptr(ws), ws.numel() * 8, st),
@@ -529,6 +541,12 @@ def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink):
     gT = t_sink if t_sink is not None else torch.empty(1, device=dev, dtype=torch.float32)
     gl = grad_loss.contiguous().float().reshape(1)
     T = temperature.detach().float().reshape(1)
+    if len(state) > 5 and state[5][0] == "keys":
+        _, keys, qpart, qmax, G = state[5]
+        check(lib.sn_sampler_step_loss_keys(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(keys), ptr(qpart), ptr(qmax), G,
+                                            ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
+                                            ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_keys")
+        return gQ, gT
     if len(state) > 5:
         dq, ws, proj, G = state[5]
         check(lib.sn_sampler_step_loss_fold(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(dq), ptr(iq), ptr(ws), G, ptr(proj),

@@ -279,6 +279,43 @@ def test_loss_reduction_folded_into_backward(B, N, M, K):
         assert p.grad is not None and torch.equal(p.grad, q.grad), n
 
 
+@pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (6, 512, 64, 8), (3, 320, 20, 5), (4, 2048, 32, 8)])
+def test_scan_with_atomic_key_combine(B, N, M, K):
+    """sn_pairscan_forward_keys + sn_sampler_step_loss_keys (per-point minima combined across a cloud's scan workgroups by
+    atomicMax on inverted keys -- order-independent -- no reduction launch between scan and backward) against the
+    partial-keys path: gradients bit-equal (same nearest-query indices incl. ties, same argmax), loss value within 1e-6
+    relative, reproducible run to run, the persistent key table zero again after the step."""
+    import copy
+
+    from samplenet_amd import SampleNet, fused_step
+
+    torch.manual_seed(B + N + 11)
+    net_a = SampleNet(M, 128, group_size=K, initial_temperature=0.6, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    x[:, N // 2:N // 2 + 4] = x[:, :4]  # duplicated points: ties between the workgroups' keys
+    old = fused_step.KEYS_LOSS, fused_step.FOLD_LOSS
+    try:
+        fused_step.FOLD_LOSS = False
+        fused_step.KEYS_LOSS = True
+        la, ya, pa = fused_step.sampler_step(net_a, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
+        la.backward()
+        lc, yc, pc = fused_step.sampler_step(net_c, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
+        lc.backward()
+        fused_step.KEYS_LOSS = False
+        lb, yb, pb = fused_step.sampler_step(net_b, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
+        lb.backward()
+    finally:
+        fused_step.KEYS_LOSS, fused_step.FOLD_LOSS = old
+    assert hasattr(net_a, "_colmin_keys") and int(net_a._colmin_keys.abs().sum()) == 0
+    assert torch.equal(ya, yb) and torch.equal(pa, pb)
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb))) and float(la) == float(lc)
+    gc = dict(net_c.named_parameters())
+    for (n, p), (_, q) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert p.grad is not None and torch.equal(p.grad, q.grad), n
+        assert torch.equal(p.grad, gc[n].grad), n
+
+
 def test_input_ring_replay_equals_copy_in():
     """SamplerTrainStep built on an input ring (one captured graph per resident batch, no staging copy) gives the same
     loss and gradients per batch as the single-graph step that copies the batch into its static buffer."""
