@@ -2198,6 +2198,44 @@ __global__ void __launch_bounds__(1024) bn_bwd_coef_kernel(int nblk, int C, cons
     bn_backward_channel(bb, C, c, s, sz, in);
 }
 
+// dW[e] = sum over the nsplit partials part[sp][e], for the 256 elements of workgroup-block `blk`: 4 consecutive elements per
+// thread (16-byte loads), 16 split-slices per workgroup, fixed-order sums.  nel % 4 == 0.
+__device__ __forceinline__ void wgrad_reduce_block(int blk, int nel, int nsplit, const float *__restrict__ pp, float *__restrict__ out)
+{
+    __shared__ float4 red[16][64];
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blk * 256 + el * 4;
+    const size_t stride = (size_t)nel;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < nel) {
+        const float *p = pp + e;
+        int sp = sl;
+        for (; sp + 3 * 16 < nsplit; sp += 4 * 16) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(p + (size_t)sp * stride);
+            const float4 v1 = *reinterpret_cast<const float4 *>(p + (size_t)(sp + 16) * stride);
+            const float4 v2 = *reinterpret_cast<const float4 *>(p + (size_t)(sp + 32) * stride);
+            const float4 v3 = *reinterpret_cast<const float4 *>(p + (size_t)(sp + 48) * stride);
+            acc.x += (v0.x + v1.x) + (v2.x + v3.x), acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+            acc.z += (v0.z + v1.z) + (v2.z + v3.z), acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; sp < nsplit; sp += 16) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)sp * stride);
+            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+    }
+    red[sl][el] = acc;
+    __syncthreads();
+    if (sl == 0 && e < nel) {
+        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = red[q][el];
+            tot.x += v.x, tot.y += v.y, tot.z += v.z, tot.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + e) = tot;
+    }
+}
+
 // wgrad_reduce of layer i and the BatchNorm backward coefficients of layer i-1 depend on the same launch (the combined
 // backward kernel of layer i) and on nothing else: one launch for both.  Workgroups [0, nred) reduce, the rest do BN.
 __global__ void __launch_bounds__(1024) post_bwd_kernel(int nred, int nsplit, int Co, int Ci, const float *__restrict__ part,
@@ -2205,6 +2243,10 @@ __global__ void __launch_bounds__(1024) post_bwd_kernel(int nred, int nsplit, in
                                                         const float *__restrict__ stats, BnBwd bb)
 {
     if ((int)blockIdx.x < nred) {
+        if ((Co * Ci) % 4 == 0) {
+            wgrad_reduce_block(blockIdx.x, Co * Ci, nsplit, part, dW);
+            return;
+        }
         // 64 elements x 16 split-slices per workgroup, 8 independent loads in flight per thread (fixed-order sums)
         __shared__ float red[16][64];
         const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -2265,8 +2307,6 @@ __global__ void __launch_bounds__(1024) post_bwd_in3_kernel(int nred, int nsplit
                                                             float *__restrict__ dW_in, MultiRed mr)
 {
     if ((int)blockIdx.x < nred) {
-        __shared__ float red[16][64];
-        const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
         int blk = blockIdx.x, nel = Co * Ci;
         const float *pp = part;
         float *out = dW;
@@ -2279,29 +2319,7 @@ __global__ void __launch_bounds__(1024) post_bwd_in3_kernel(int nred, int nsplit
             if (blockIdx.x == 0)
                 for (int i = threadIdx.x; i < mr.zero_n; i += 1024) mr.zero_ptr[i] = 0;
         }
-        const int e = blk * 64 + el;
-        const size_t stride = (size_t)nel;
-        float acc = 0.f;
-        if (e < nel) {
-            const float *p = pp + e;
-            int sp = sl;
-            for (; sp + 7 * 16 < nsplit; sp += 8 * 16) {
-                const float v0 = p[(size_t)sp * stride], v1 = p[(size_t)(sp + 16) * stride];
-                const float v2 = p[(size_t)(sp + 32) * stride], v3 = p[(size_t)(sp + 48) * stride];
-                const float v4 = p[(size_t)(sp + 64) * stride], v5 = p[(size_t)(sp + 80) * stride];
-                const float v6 = p[(size_t)(sp + 96) * stride], v7 = p[(size_t)(sp + 112) * stride];
-                acc += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
-            }
-            for (; sp < nsplit; sp += 16) acc += p[(size_t)sp * stride];
-        }
-        red[sl][el] = acc;
-        __syncthreads();
-        if (sl == 0 && e < nel) {
-            float tot = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) tot += red[q][el];
-            out[e] = tot;
-        }
+        wgrad_reduce_block(blk, nel, nsplit, pp, out);
         return;
     }
     // one memory round trip for everything this workgroup needs: thread (channel cl, slice sl) loads the five sums of its
@@ -3037,7 +3055,7 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
         SN_REQUIRE(z && (dz_mode != DZ_BN || dy) && (dz_mode != DZ_POOL || (gsel && argsel)), "null pointer");
         const int G = launch_conv_bwd_fused(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev,
                                             stats, part, st);
-        const int nred = (Co * Ci + 63) / 64;
+        const int nred = (Co * Ci) % 4 == 0 ? (Co * Ci + 255) / 256 : (Co * Ci + 63) / 64;
         hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW,
                            G, Ci, stats, bb);
         SN_LAUNCH_CHECK();
@@ -3076,7 +3094,7 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_BN, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
     else
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_POOL, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
-    const int nred = (Co * Ci + 63) / 64;
+    const int nred = (Co * Ci) % 4 == 0 ? (Co * Ci + 255) / 256 : (Co * Ci + 63) / 64;
     hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, nsplit, Co, Ci, part, dW, nblk, Ci,
                        stats, bb);
     SN_LAUNCH_CHECK();
@@ -3134,7 +3152,7 @@ extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, con
     launch_conv_bwd_in3(R, dy, z, kcoef, W, zprev, coef_prev, stats, part, x_in, st);
     const int G = conv_bwd_fused_groups(R);
     const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, (long long)R};
-    const int nred = (Co * Ci + 63) / 64;
+    const int nred = (Co * Ci + 255) / 256;
     hipLaunchKernelGGL(post_bwd_in3_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW, G,
                        Ci, stats, bb, W_in, b_in, dW_in, MultiRed{});
     SN_LAUNCH_CHECK();
@@ -3215,7 +3233,7 @@ extern "C" int sn_conv_stack_backward(int B, int N, int nlayers, const int *chan
     int nb = 0;
     for (int l = 1; l < nlayers; ++l) {
         mr.first[l - 1] = nb, mr.part[l - 1] = part[l], mr.dW[l - 1] = dW[l], mr.elems[l - 1] = ch[l] * ch[l + 1];
-        nb += (ch[l] * ch[l + 1] + 63) / 64;
+        nb += (ch[l] * ch[l + 1] + 255) / 256;
     }
     mr.first[nlayers - 1] = nb;
     mr.zero_ptr = accb(1), mr.zero_n = kFxLayer;
