@@ -634,6 +634,19 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
         __syncthreads();  // s_part is reused below
     }
     if (fold.keys) {
+        // nearest query of every point of the cloud, fetched ONCE per workgroup (the four waves all need all of them; keys that
+        // were updated by device-scope atomics are slow to read: 4 x 8 KB per workgroup cost +4 us) and handed over in LDS
+        float sdp = 0.f;
+        for (int n = threadIdx.x; n < ns; n += 256) {
+            const sn_u64 k = ~fold.keys[(size_t)b * ns + n];
+            s_ip[n] = key_index(k);
+            sdp += key_dist(k);
+        }
+        if (blockIdx.y == 0) {  // sum dist_p of the cloud (for the loss value), fixed order
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sdp += __shfl_xor(sdp, o);
+            if (lane == 0) s_red[2][wave] = sdp;
+        }
         if (wave == 0) {  // argmax of dist_q: maximum of the (dist_q, ~query) keys of the cloud's scan workgroups
             sn_u64 mk = 0;
             for (int g = lane; g < fold.G; g += 64) {
@@ -649,6 +662,7 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
             if (lane == 0) s_am = (int)(0xFFFFFFFFu - (unsigned)mk);
         }
         __syncthreads();
+        if (blockIdx.y == 0 && threadIdx.x == 0) fold.dpsum[b] = (s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3]);
     }
     T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
     idxT += (size_t)b * nt, idxS += (size_t)b * ns;
@@ -661,27 +675,16 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
 
     float sx[PPL], sy[PPL], sz[PPL], gg[PPL];
     int is[PPL];
-    float dpl = 0.f;
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const int l = i * 64 + lane;
         const int lc = l < ns ? l : 0;
         const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)lc * 3);
         sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
-        if (fold.keys) {
-            const sn_u64 k = ~fold.keys[(size_t)b * ns + lc];
-            is[i] = l < ns ? key_index(k) : -1;
-            dpl += l < ns ? key_dist(k) : 0.f;
-        } else {
-            is[i] = l < ns ? (fold.ws ? s_ip[lc] : idxS[lc]) : -1;
-        }
+        is[i] = l < ns ? ((fold.ws || fold.keys) ? s_ip[lc] : idxS[lc]) : -1;
         gg[i] = gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) * 2;
     }
-    if (fold.keys && blockIdx.y == 0 && wave == 0) {  // sum dist_p of the cloud (for the loss value), fixed order
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dpl += __shfl_xor(dpl, o);
-        if (lane == 0) fold.dpsum[b] = dpl;
-    }
+
     for (int j = blockIdx.y * nwaves + wave; j < nt; j += nsplit * nwaves) {
         const float tx = T[j], ty = T[j + nt], tz = T[j + 2 * nt];  // targets channel-major (3, nt)
         const int j2 = idxT[j];
