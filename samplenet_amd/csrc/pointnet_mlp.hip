@@ -2698,6 +2698,16 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         g.acc_in = acc + (size_t)(l - 1) * kFxLayer, g.bn_prev = bn_of(l - 1), g.acc_out = acc + (size_t)l * kFxLayer;
         if (l >= 2) g.zero_ptr = acc + (size_t)(l - 2) * kFxLayer, g.zero_n = kFxLayer;
         if (l == nlayers - 1) g.pool_val = pool_val, g.pool_idx = pool_idx, g.pool_npts = N;
+        static const bool wide = !(getenv("SN_FWD_WIDE_TILE") && getenv("SN_FWD_WIDE_TILE")[0] == '0');
+        if (Co == 128 && wide) {
+            // 128 output channels: one 512-thread workgroup per 64 rows computes all of them -- the input tile is fetched
+            // once instead of once per 64-column block, and half as many workgroups run the statistics prologue
+            using TW = Tile<64, 128, 2, 4>;
+            const dim3 grid(R / TW::BM, 1);
+            const size_t lds = shaped_lds(lds_bytes<TW>() + (size_t)2 * Ci * sizeof(float), grid);
+            hipLaunchKernelGGL((linear_fwd_kernel<TW, true, ACT_BN_RELU_FX>), grid, dim3(TW::THREADS), lds, st, g);
+            continue;
+        }
         const dim3 grid(R / T::BM, Co / T::BN);
         const size_t lds = shaped_lds(lds_bytes<T>() + (size_t)2 * Ci * sizeof(float), grid);
         hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX>), grid, dim3(T::THREADS), lds, st, g);
