@@ -164,7 +164,9 @@ int sn_sampler_step_loss_fold(int B, int N, int M, int K, const float *P, int p_
  * order-independent: deterministic) in colmin_keys [B][N] -- u64, zero on entry, zero again after
  * sn_sampler_step_loss_keys -- and leaves the query-side loss partials qpart [B][G][2] floats / qmax [B][G] u64,
  * G = sn_pairscan_colmin_splits(B,N,M) > 1.  Q (B,3,M) is read, or written when fc_w != NULL (queries produced by the
- * head's last layer as in sn_pairscan_forward_partial_fc).  dpsum: B floats of scratch; loss: 2 floats.  N <= 2048. */
+ * head's last layer as in sn_pairscan_forward_partial_fc).  dpsum: B floats of scratch; loss: 2 floats.  N <= 2048.
+ * tail_stream (optional): the launch that produces grad_T / loss and resets colmin_keys goes there behind an event (it is
+ * off the step's critical path); the caller makes `stream` wait for tail_stream before using those or ending a capture. */
 int sn_pairscan_forward_keys(int B, int N, int M, int K, const float *P, int p_layout, float *Q, const float *fc_z,
                              const float *fc_scale, const float *fc_shift, const float *fc_w, const float *fc_bias, int Kfc,
                              int *knn_idx, float *dist_q, int *idx_q, float *proj, int proj_layout, const float *temperature,
@@ -173,7 +175,7 @@ int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float *P, int p_
                               const int *idx_q, void *colmin_keys, const float *qpart, const void *qmax, int G,
                               const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
                               const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T, float *dpsum,
-                              float *loss, sn_stream_t stream);
+                              float *loss, sn_stream_t stream, sn_stream_t tail_stream);
 /* defer_value != 0: the forward leaves loss[] unwritten; pass its `partial` and `loss` to the backward call as
  * deferred_partial / deferred_loss and the scalar is combined by an extra wave of the backward's first launch (the
  * gradients do not depend on it) -- for callers that always run the backward (samplenet_amd.engine).  Else pass NULLs. */

@@ -1255,7 +1255,8 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
                                          const int *knn_idx, const int *idx_q, void *colmin_keys, const float *qpart,
                                          const void *qmax, int G, const float *temperature, float min_sigma, float alpha,
                                          float lmbda, float weight, const float *grad_loss, float *grad_Q,
-                                         float *gsig_scratch, float *grad_T, float *dpsum, float *loss, sn_stream_t stream)
+                                         float *gsig_scratch, float *grad_T, float *dpsum, float *loss, sn_stream_t stream,
+                                         sn_stream_t tail_stream)
 {
     SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && G >= 1, "bad size");
     SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
@@ -1264,6 +1265,11 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
                "null pointer");
     if (N > 2048) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_sampler_step_loss_keys: N <= 2048");
     hipStream_t st = (hipStream_t)stream;
+    // tail_stream (optional, != stream): the second launch -- sigma gradient, loss value, key-table reset: nothing on the
+    // step's critical path reads its outputs -- is enqueued there behind an event, so that it runs BESIDE the FC head's
+    // backward instead of in front of it.  The caller joins tail_stream back (stream waits for it) before it uses grad_T /
+    // loss / the key table or ends a graph capture.
+    hipStream_t tail = tail_stream ? (hipStream_t)tail_stream : st;
     const float c1 = 1.0f / ((float)B * (float)M), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)N);
     ImplicitGrad ig{grad_loss, nullptr, nullptr, c1, cm, c2, 0.f, alpha};
     SoftBwdArgs a{};
@@ -1287,7 +1293,17 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
 #undef SN_CS
     const StepLossKeysFinal kf{B, G, M, N, 3 * M, weight, alpha, lmbda, min_sigma, qpart, (const sn_u64 *)qmax, dpsum, temperature,
                                loss, (sn_u64 *)colmin_keys, (long long)B * N};
-    hipLaunchKernelGGL(sigma_grad_kernel, dim3(2 + 64), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
+    if (tail != st) {
+        static hipEvent_t ev[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 15;
+        if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess)
+            return sn_set_error(SN_ERR_BAD_ARGUMENT, "sn_sampler_step_loss_keys: cannot create the fork event");
+        if (hipEventRecord(ev[dev], st) != hipSuccess || hipStreamWaitEvent(tail, ev[dev], 0) != hipSuccess)
+            return sn_set_error(SN_ERR_BAD_ARGUMENT, "sn_sampler_step_loss_keys: cannot fork onto tail_stream");
+    }
+    hipLaunchKernelGGL(sigma_grad_kernel, dim3(2 + 64), dim3(256), 0, tail, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
                        grad_loss, lmbda, StepLossFinal{}, kf);
     SN_LAUNCH_CHECK();
     return 0;

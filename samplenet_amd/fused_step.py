@@ -22,6 +22,9 @@ FOLD_LOSS = os.environ.get("SAMPLENET_AMD_FOLD_LOSS", "0") == "1"
 # per-point minima combined across a cloud's scan workgroups by atomicMax on inverted keys: no reduction launch between the
 # scan and the backward (sn_pairscan_forward_keys / sn_sampler_step_loss_keys)
 KEYS_LOSS = os.environ.get("SAMPLENET_AMD_KEYS_LOSS", "1") != "0"
+# sigma-gradient / loss-value launch on a side stream beside the MLP backward (it is off the critical path): inside the
+# captured graph the fork / join costs far more than the 5 us launch it hides (measured +36 us per step) -> OFF
+TAIL_STREAM = os.environ.get("SAMPLENET_AMD_TAIL_STREAM", "0") == "1"
 
 
 class SamplerStepFunction(torch.autograd.Function):
@@ -72,9 +75,16 @@ class SamplerStepFunction(torch.autograd.Function):
                                    "(set SAMPLENET_AMD_KEYS_LOSS=0 to backpropagate the same step twice)")
             ctx.keys_consumed = True
         with torch.cuda.device(ctx.y.device):
-            gQ, gT = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink)
+            keys_mode = len(ctx.state) > 5 and ctx.state[5][0] == "keys"
+            # keys mode: the sigma-gradient / loss-value / key-reset launch runs on a side stream beside the MLP backward
+            tail = ops.tail_stream(ctx.y.device) if (keys_mode and TAIL_STREAM) else None
+            res = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink, tail)
+            gQ, gT = res[0], res[1]
             net._colmin_keys_pending = False  # (the backward's last launch re-zeroed the key table)
             grads = pointnet.backward_impl(net, ctx.saved, gQ.view(gQ.shape[0], -1), sink, getattr(net, "_after_fc_grads", None))
+            if tail is not None:
+                torch.cuda.current_stream().wait_stream(tail)  # join (also what ends the fork inside a graph capture)
+            del res  # (scratch of the side-stream launch: released only behind the join)
         g_temp = None
         if ctx.t_sink is None and ctx.needs_input_grad[2]:
             g_temp = gT.reshape(ctx.temperature.shape)

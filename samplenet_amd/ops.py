@@ -529,7 +529,19 @@ def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight,
     return loss, proj, (idx, iq, ip, argmax1, (partial, loss) if defer_value else (None, None))
 
 
-def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink):
+_TAIL_STREAMS = {}
+
+
+def tail_stream(device):
+    """Side stream (one per device) for launches that are off the step's critical path (sn_sampler_step_loss_keys)."""
+    st = _TAIL_STREAMS.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _TAIL_STREAMS[device] = st
+    return st
+
+
+def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, tail=None):
     """Backward launches of the sampler step's loss side -> (grad_Q (B,3,M), grad_T (1,)).  Caller holds the device guard."""
     idx, iq, ip, argmax1, (dpart, dloss) = state[:5]
     K, min_sigma, alpha, lmbda, weight = cfg
@@ -545,7 +557,11 @@ def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink):
         _, keys, qpart, qmax, G = state[5]
         check(lib.sn_sampler_step_loss_keys(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(keys), ptr(qpart), ptr(qmax), G,
                                             ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
-                                            ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_keys")
+                                            ptr(dpart), ptr(dloss), _stream(y), tail.cuda_stream if tail is not None else None),
+              "sn_sampler_step_loss_keys")
+        if tail is not None:
+            # the launch on the side stream still reads these: hand them to the caller, who drops them after the join
+            return gQ, gT, (gsig, gl, T)
         return gQ, gT
     if len(state) > 5:
         dq, ws, proj, G = state[5]
