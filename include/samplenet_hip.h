@@ -166,7 +166,9 @@ int sn_sampler_step_loss_fold(int B, int N, int M, int K, const float *P, int p_
  * G = sn_pairscan_colmin_splits(B,N,M) > 1.  Q (B,3,M) is read, or written when fc_w != NULL (queries produced by the
  * head's last layer as in sn_pairscan_forward_partial_fc).  dpsum: B floats of scratch; loss: 2 floats.  N <= 2048.
  * tail_stream (optional): the launch that produces grad_T / loss and resets colmin_keys goes there behind an event (it is
- * off the step's critical path); the caller makes `stream` wait for tail_stream before using those or ending a capture. */
+ * off the step's critical path); the caller makes `stream` wait for tail_stream before using those or ending a capture.
+ * deferred_tail (optional, host buffer of sn_step_tail_bytes() bytes): that launch is not issued at all; its description is
+ * written there and handed to sn_conv_stack_backward(step_tail) of the same step, whose closing kernel runs it. */
 int sn_pairscan_forward_keys(int B, int N, int M, int K, const float *P, int p_layout, float *Q, const float *fc_z,
                              const float *fc_scale, const float *fc_shift, const float *fc_w, const float *fc_bias, int Kfc,
                              int *knn_idx, float *dist_q, int *idx_q, float *proj, int proj_layout, const float *temperature,
@@ -175,7 +177,8 @@ int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float *P, int p_
                               const int *idx_q, void *colmin_keys, const float *qpart, const void *qmax, int G,
                               const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
                               const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T, float *dpsum,
-                              float *loss, sn_stream_t stream, sn_stream_t tail_stream);
+                              float *loss, sn_stream_t stream, sn_stream_t tail_stream, void *deferred_tail);
+int sn_step_tail_bytes(void);
 /* defer_value != 0: the forward leaves loss[] unwritten; pass its `partial` and `loss` to the backward call as
  * deferred_partial / deferred_loss and the scalar is combined by an extra wave of the backward's first launch (the
  * gradients do not depend on it) -- for callers that always run the backward (samplenet_amd.engine).  Else pass NULLs. */
@@ -333,7 +336,8 @@ long long sn_conv_stack_backward_scratch_floats(int B, int N, int nlayers, const
 int sn_conv_stack_backward(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
                            const float *bias0, const float *const *z, const float *const *coef, const float *gsel,
                            const int *argsel, const float *kcoef_top, long long *acc, float *scratch, float *const *dW,
-                           float *const *dgamma, float *const *dbeta, float *const *dbias, sn_stream_t stream);
+                           float *const *dgamma, float *const *dbeta, float *const *dbias, const void *step_tail,
+                           sn_stream_t stream);
 int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                       const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                       const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,

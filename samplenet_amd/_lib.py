@@ -46,7 +46,8 @@ PROTOTYPES = {
     "sn_pairscan_forward_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp,
                                  _vp, _vp],
     "sn_sampler_step_loss_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp],
+                                  _vp, _vp, _vp, _vp, _vp],
+    "sn_step_tail_bytes": [],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],
     "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -67,7 +68,7 @@ PROTOTYPES = {
     "sn_conv_stack_forward_supported": [_i, _i, _i, _vp],
     "sn_conv_stack_acc_elems": [_i],
     "sn_conv_stack_backward_scratch_floats": [_i, _i, _i, _vp],
-    "sn_conv_stack_backward": [_i, _i, _i] + [_vp] * 16,
+    "sn_conv_stack_backward": [_i, _i, _i] + [_vp] * 17,
     "sn_conv_stack_forward_bn": [_i, _i, _i] + [_vp] * 20,
     "sn_layer_backward_in3_stats_floats": [_i, _i, _i],
     "sn_layer_backward_in3": [_i, _i, _i] + [_vp] * 17 + [_vp],

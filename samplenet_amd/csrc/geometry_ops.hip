@@ -9,8 +9,10 @@
 //   group_point*, grouping_operation*   tf_grouping_g.cu:40-78 and the pointnet2 layout twin
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "sn_common.h"
+#include "step_tail.h"
 
 #pragma clang fp contract(off)  // reference arithmetic is product-then-sum (no FMA)
 
@@ -501,47 +503,6 @@ __device__ __forceinline__ void step_loss_final(const StepLossFinal &f, int t)
     f.loss[1] = lsimp;
 }
 
-// keys mode of the step loss (sn_pairscan_forward_keys): loss value from the scan's query-side partials and the backward's
-// per-cloud sum of dist_p
-struct StepLossKeysFinal {
-    int B, G, M, N, nproj;
-    float w, alpha, lmbda, min_sigma;
-    const float *qpart;   // [B][G][2]  (sum dist_q, sum proj)
-    const sn_u64 *qmax;   // [B][G]     max (dist_q, ~query) key
-    const float *dpsum;   // [B]
-    const float *temperature;
-    float *loss;          // NULL: nothing to do
-    sn_u64 *keys;         // [nkeys] inverted per-point keys, re-zeroed for the next step
-    long long nkeys;
-};
-__device__ __forceinline__ void step_loss_keys_final(const StepLossKeysFinal &f, int t)
-{
-    float s1 = 0.f, mx = 0.f, s2 = 0.f, sp = 0.f;
-    for (int b = t; b < f.B; b += 64) {
-        float a1 = 0.f, ap = 0.f;
-        sn_u64 mk = 0;
-        for (int g = 0; g < f.G; ++g) {
-            const size_t o = (size_t)b * f.G + g;
-            a1 += f.qpart[o * 2], ap += f.qpart[o * 2 + 1];
-            mk = f.qmax[o] > mk ? f.qmax[o] : mk;
-        }
-        s1 += a1, sp += ap, mx += key_dist(mk), s2 += f.dpsum[b];
-    }
-    const float T = *f.temperature;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s1 += __shfl_xor(s1, o);
-        mx += __shfl_xor(mx, o);
-        s2 += __shfl_xor(s2, o);
-        sp += __shfl_xor(sp, o);
-    }
-    if (t != 0) return;
-    const float c12 = s1 / ((float)f.B * (float)f.M), cmax = mx / (float)f.B, c21 = s2 / ((float)f.B * (float)f.N);
-    const float lsimp = c12 + cmax + f.w * c21;
-    f.loss[0] = f.alpha * lsimp + f.lmbda * fmaxf(T * T, f.min_sigma) + sp / ((float)f.B * (float)f.nproj);
-    f.loss[1] = lsimp;
-}
-
 // Chamfer backward (implicit upstream gradients, targets = the simplified cloud) + soft-projection backward of the same
 // query in ONE launch: a wave finishes the Chamfer gradient of target j exactly as chamfer_bwd_reg_kernel does, then runs
 // the soft-projection backward of query j (same point: the simplified cloud is both) and stores the sum -- the same
@@ -890,7 +851,7 @@ __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float
                                                          const float *__restrict__ temperature, float min_sigma,
                                                          float *__restrict__ grad_T, const float *__restrict__ gsigma_direct,
                                                          float direct_scale, StepLossFinal fin = StepLossFinal{},
-                                                         StepLossKeysFinal kf = StepLossKeysFinal{})
+                                                         sn::StepLossKeysFinal kf = sn::StepLossKeysFinal{})
 {
     if (fin.loss && blockIdx.x == 1) {  // second workgroup (fold mode): the step's loss value from the per-cloud partials
         if (threadIdx.x < 64) step_loss_final(fin, threadIdx.x);
@@ -898,7 +859,7 @@ __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float
     }
     if (kf.loss && blockIdx.x >= 1) {  // keys mode: workgroup 1 combines the loss value, the others re-zero the key table
         if (blockIdx.x == 1) {
-            if (threadIdx.x < 64) step_loss_keys_final(kf, threadIdx.x);
+            if (threadIdx.x < 64) sn::step_loss_keys_final(kf, threadIdx.x);
         } else {
             const long long nb = gridDim.x - 2, per = (kf.nkeys + nb - 1) / nb;
             const long long i0 = (long long)(blockIdx.x - 2) * per, i1 = i0 + per < kf.nkeys ? i0 + per : kf.nkeys;
@@ -906,23 +867,8 @@ __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float
         }
         return;
     }
-    // fixed-order reduction: strided per-thread sums, xor tree inside each wave, the four wave totals in order
     __shared__ float red[4];
-    const float T = *temperature;
-    const float direct = gsigma_direct ? *gsigma_direct * direct_scale : 0.f;  // in flight during the reduction
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-        const float t2 = T * T;
-        const float w = t2 > min_sigma ? 1.f : (t2 == min_sigma ? 0.5f : 0.f);
-        // + d loss / d sigma of a term that depends on sigma directly (lmbda * sigma in the sampler step's loss)
-        grad_T[0] = tot * w * 2.0f * T + direct * w * 2.0f * T;
-    }
+    sn::sigma_grad_block(nparts, partial, temperature, min_sigma, grad_T, gsigma_direct, direct_scale, red);
 }
 
 extern "C" int sn_sigma_grad(int nparts, const float *partial, const float *temperature, float min_sigma, float *grad_T,
@@ -1256,7 +1202,7 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
                                          const void *qmax, int G, const float *temperature, float min_sigma, float alpha,
                                          float lmbda, float weight, const float *grad_loss, float *grad_Q,
                                          float *gsig_scratch, float *grad_T, float *dpsum, float *loss, sn_stream_t stream,
-                                         sn_stream_t tail_stream)
+                                         sn_stream_t tail_stream, void *deferred_tail)
 {
     SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && G >= 1, "bad size");
     SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
@@ -1293,6 +1239,16 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
 #undef SN_CS
     const StepLossKeysFinal kf{B, G, M, N, 3 * M, weight, alpha, lmbda, min_sigma, qpart, (const sn_u64 *)qmax, dpsum, temperature,
                                loss, (sn_u64 *)colmin_keys, (long long)B * N};
+    if (deferred_tail) {
+        // the caller hands this blob to a later launch of the same step (sn_conv_stack_backward runs it in two extra
+        // workgroups of its closing kernel): no launch of its own for the sigma gradient / loss value / key reset
+        StepTail t{};
+        t.nparts = B * splits, t.gsig = gsig_scratch, t.temperature = temperature, t.min_sigma = min_sigma, t.grad_T = grad_T;
+        t.grad_loss = grad_loss, t.lmbda = lmbda, t.kf = kf;
+        memcpy(deferred_tail, &t, sizeof(t));
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
     if (tail != st) {
         static hipEvent_t ev[16] = {};
         int dev = 0;
@@ -1308,6 +1264,8 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
     SN_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int sn_step_tail_bytes(void) { return (int)sizeof(sn::StepTail); }
 
 // ------------------------------------------------------------------------------------------------
 // Inference matching on the device: sputils.nn_matching (registration/src/sputils.py:7-41).

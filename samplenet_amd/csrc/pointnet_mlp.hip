@@ -29,8 +29,10 @@
 // the matrix pipe.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "sn_common.h"
+#include "step_tail.h"
 
 namespace sn {
 
@@ -2304,8 +2306,27 @@ __global__ void __launch_bounds__(1024) post_bwd_in3_kernel(int nred, int nsplit
                                                             float *__restrict__ dW, int nblk, int C,
                                                             const float *__restrict__ stats, BnBwd bb,
                                                             const float *__restrict__ W_in, const float *__restrict__ b_in,
-                                                            float *__restrict__ dW_in, MultiRed mr)
+                                                            float *__restrict__ dW_in, MultiRed mr, StepTail tail)
 {
+    // optional riders (engine path): the loss side's scalar tail in two extra workgroups at the end of the grid, and the
+    // reset of its key table spread over the reduction workgroups
+    if (tail.nparts > 0) {
+        const int nbn = (C + kChan - 1) / kChan;
+        if ((int)blockIdx.x == nred + nbn) {
+            __shared__ float tred[4];
+            sigma_grad_block(tail.nparts, tail.gsig, tail.temperature, tail.min_sigma, tail.grad_T, tail.grad_loss, tail.lmbda, tred);
+            return;
+        }
+        if ((int)blockIdx.x == nred + nbn + 1) {
+            if (threadIdx.x < 64) step_loss_keys_final(tail.kf, threadIdx.x);
+            return;
+        }
+        if ((int)blockIdx.x < nred) {
+            const long long per = (tail.kf.nkeys + nred - 1) / nred;
+            const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < tail.kf.nkeys ? i0 + per : tail.kf.nkeys;
+            for (long long i = i0 + threadIdx.x; i < i1; i += 1024) tail.kf.keys[i] = 0;
+        }
+    }
     if ((int)blockIdx.x < nred) {
         int blk = blockIdx.x, nel = Co * Ci;
         const float *pp = part;
@@ -3164,7 +3185,7 @@ extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, con
     const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, (long long)R};
     const int nred = (Co * Ci + 255) / 256;
     hipLaunchKernelGGL(post_bwd_in3_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW, G,
-                       Ci, stats, bb, W_in, b_in, dW_in, MultiRed{});
+                       Ci, stats, bb, W_in, b_in, dW_in, MultiRed{}, StepTail{});
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -3177,6 +3198,8 @@ extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, con
 // gradient at the selected points and the top BatchNorm's dZ coefficients (from the FC side: sn_layer_backward with
 // prev_bn_rows, or sn_pool_backward_bn).  Outputs: dW per layer; dgamma / dbeta / dbias for layers 0 .. nlayers-2.
 // acc: sn_conv_stack_acc_elems(nlayers) long long, zero before the first call (left zero); scratch: see _scratch_floats.
+// step_tail (optional): blob of sn_step_tail_bytes() bytes filled by sn_sampler_step_loss_keys(..., deferred_tail): the loss
+// side's sigma gradient / loss value / key-table reset ride in the closing kernel instead of a launch of their own.
 static bool conv_stack_backward_ok(int B, int N, int nlayers, const int *ch)
 {
     if (!sn_conv_stack_forward_supported(B, N, nlayers, ch) || nlayers < 3 || nlayers > 5) return false;
@@ -3202,7 +3225,7 @@ extern "C" int sn_conv_stack_backward(int B, int N, int nlayers, const int *chan
                                       const float *bias0, const float *const *z, const float *const *coef, const float *gsel,
                                       const int *argsel, const float *kcoef_top, long long *acc, float *scratch,
                                       float *const *dW, float *const *dgamma, float *const *dbeta, float *const *dbias,
-                                      sn_stream_t stream)
+                                      const void *step_tail, sn_stream_t stream)
 {
     if (!conv_stack_backward_ok(B, N, nlayers, channels))
         return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_stack_backward: shape not supported (use the per-layer entries)");
@@ -3248,8 +3271,10 @@ extern "C" int sn_conv_stack_backward(int B, int N, int nlayers, const int *chan
     mr.first[nlayers - 1] = nb;
     mr.zero_ptr = accb(1), mr.zero_n = kFxLayer;
     const BnBwd bb0{coef[0], dgamma[0], dbeta[0], dbias[0], kcoef0, (long long)R};
-    hipLaunchKernelGGL(post_bwd_in3_kernel, dim3(nb + (64 + kChan - 1) / kChan), dim3(1024), 0, st, nb, G, 64, 64, part[1], dW[1], G,
-                       64, stats0, bb0, W[0], bias0, dW[0], mr);
+    StepTail tail{};
+    if (step_tail) memcpy(&tail, step_tail, sizeof(tail));  // blob filled by sn_sampler_step_loss_keys (sn_step_tail_bytes())
+    hipLaunchKernelGGL(post_bwd_in3_kernel, dim3(nb + (64 + kChan - 1) / kChan + (tail.nparts > 0 ? 2 : 0)), dim3(1024), 0, st, nb, G,
+                       64, 64, part[1], dW[1], G, 64, stats0, bb0, W[0], bias0, dW[0], mr, tail);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -25,6 +25,9 @@ KEYS_LOSS = os.environ.get("SAMPLENET_AMD_KEYS_LOSS", "1") != "0"
 # sigma-gradient / loss-value launch on a side stream beside the MLP backward (it is off the critical path): inside the
 # captured graph the fork / join costs far more than the 5 us launch it hides (measured +36 us per step) -> OFF
 TAIL_STREAM = os.environ.get("SAMPLENET_AMD_TAIL_STREAM", "0") == "1"
+# the loss side's scalar tail (sigma gradient, loss value, key-table reset) rides in the closing kernel of the conv stack's
+# backward instead of a launch of its own
+DEFER_TAIL = os.environ.get("SAMPLENET_AMD_DEFER_TAIL", "1") != "0"
 
 
 class SamplerStepFunction(torch.autograd.Function):
@@ -78,10 +81,17 @@ class SamplerStepFunction(torch.autograd.Function):
             keys_mode = len(ctx.state) > 5 and ctx.state[5][0] == "keys"
             # keys mode: the sigma-gradient / loss-value / key-reset launch runs on a side stream beside the MLP backward
             tail = ops.tail_stream(ctx.y.device) if (keys_mode and TAIL_STREAM) else None
-            res = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink, tail)
+            # ... or, better, inside the closing kernel of the conv stack's backward: no launch of its own at all
+            blob = None
+            if keys_mode and DEFER_TAIL and tail is None and pointnet.conv_stack_backward_supported(net, ctx.x.shape[0], ctx.x.shape[1]):
+                import ctypes
+
+                blob = ctypes.create_string_buffer(ops.lib.sn_step_tail_bytes())
+            res = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink, tail, blob)
             gQ, gT = res[0], res[1]
             net._colmin_keys_pending = False  # (the backward's last launch re-zeroed the key table)
-            grads = pointnet.backward_impl(net, ctx.saved, gQ.view(gQ.shape[0], -1), sink, getattr(net, "_after_fc_grads", None))
+            grads = pointnet.backward_impl(net, ctx.saved, gQ.view(gQ.shape[0], -1), sink, getattr(net, "_after_fc_grads", None),
+                                           step_tail=blob)
             if tail is not None:
                 torch.cuda.current_stream().wait_stream(tail)  # join (also what ends the fork inside a graph capture)
             del res  # (scratch of the side-stream launch: released only behind the join)

@@ -541,7 +541,7 @@ def tail_stream(device):
     return st
 
 
-def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, tail=None):
+def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, tail=None, deferred_tail=None):
     """Backward launches of the sampler step's loss side -> (grad_Q (B,3,M), grad_T (1,)).  Caller holds the device guard."""
     idx, iq, ip, argmax1, (dpart, dloss) = state[:5]
     K, min_sigma, alpha, lmbda, weight = cfg
@@ -557,9 +557,9 @@ def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, tail=No
         _, keys, qpart, qmax, G = state[5]
         check(lib.sn_sampler_step_loss_keys(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(keys), ptr(qpart), ptr(qmax), G,
                                             ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
-                                            ptr(dpart), ptr(dloss), _stream(y), tail.cuda_stream if tail is not None else None),
-              "sn_sampler_step_loss_keys")
-        if tail is not None:
+                                            ptr(dpart), ptr(dloss), _stream(y), tail.cuda_stream if tail is not None else None,
+                                            deferred_tail), "sn_sampler_step_loss_keys")
+        if tail is not None or deferred_tail is not None:
             # the launch on the side stream still reads these: hand them to the caller, who drops them after the join
             return gQ, gT, (gsig, gl, T)
         return gQ, gT

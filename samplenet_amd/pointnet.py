@@ -299,7 +299,19 @@ def _layer_bwd(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, L
     return dW, db, dyprev, dg, dbt, dbs, kc
 
 
-def _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef_top, sink, grads, names_c, bn_c):
+def conv_stack_backward_supported(net, B, N):
+    """True when backward_impl will run the conv stack through sn_conv_stack_backward (whose closing kernel can carry the
+    loss side's deferred tail, fused_step.py)."""
+    import ctypes
+
+    if not (FX_STATS and IN3_CLOSED_FORM):
+        return False
+    convs, _ = _layers(net)
+    chans = (ctypes.c_int * (len(convs) + 1))(convs[0].Ci, *[L.Co for L in convs])
+    return lib.sn_conv_stack_backward_scratch_floats(B, N, len(convs), chans) > 0
+
+
+def _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef_top, sink, grads, names_c, bn_c, step_tail=None):
     """Backward of the conv stack as one call (sn_conv_stack_backward: 5 launches, BatchNorm-backward sums as fixed-point
     atomics, every weight-gradient partial reduced by the closing kernel).  Returns False when the shapes are not
     supported (the per-layer path runs instead)."""
@@ -330,7 +342,7 @@ def _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef_top, sink, grads, names_c,
     try:
         check(lib.sn_conv_stack_backward(B, N, n, chans, ptr(x), arr([L.W for L in convs]), ptr(convs[0].b), arr(saved["zc"]),
                                          arr(saved["cc"]), ptr(gsel), ptr(saved["argsel"]), ptr(kcoef_top), ptr(acc), ptr(scratch),
-                                         arr(dW), arr(dg + [None]), arr(dbt + [None]), arr(dbs + [None]), _st(x)),
+                                         arr(dW), arr(dg + [None]), arr(dbt + [None]), arr(dbs + [None]), step_tail, _st(x)),
               "sn_conv_stack_backward")
     except Exception:
         acc.zero_()
@@ -342,7 +354,7 @@ def _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef_top, sink, grads, names_c,
     return True
 
 
-def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
+def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
     """-> dict parameter-name -> gradient tensor (every parameter of the MLP).
     sink: optional dict name -> preallocated tensor the gradient is written into (overwritten, not accumulated).
     after_fc: optional callback invoked once all FC-head gradients have been enqueued (DP overlap point)."""
@@ -393,9 +405,11 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None):
         grads[bn_c[4] + ".weight"], grads[bn_c[4] + ".bias"], grads[names_c[4] + ".bias"] = dgamma, dbeta, dbias
 
     # ---- conv stack (rows = B*N): conv5 -> ... -> conv2 (each also finishes the BatchNorm of the layer below), conv1 ----
-    if FX_STATS and IN3_CLOSED_FORM and _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef, sink, grads, names_c, bn_c):
+    if FX_STATS and IN3_CLOSED_FORM and _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef, sink, grads, names_c, bn_c, step_tail):
         _join_side(grad_y.device)
         return grads
+    if step_tail is not None:
+        raise RuntimeError("backward_impl: a deferred step tail needs the one-call conv stack backward (conv_stack_backward_supported)")
     dy = None
     in3_floats = lib.sn_layer_backward_in3_stats_floats(R, convs[1].Ci, convs[1].Co) if (IN3_CLOSED_FORM and convs[0].Ci == 3) else 0
     for i in (4, 3, 2, 1):
