@@ -122,18 +122,103 @@ def time_conv5_backward_kernel(B, N, reps=50):
     return e0.elapsed_time(e1) / reps, 4.0 * R * Ci * Co
 
 
+def time_pairscan_saturated(K, Bsat=4096, N=1024, M=64, reps=10):
+    """The same geometric kernel at a saturating batch ("report the HBM fraction at B=32 and at a saturating
+    batch"): sn_pairscan_forward_ws on Bsat clouds (every cloud one workgroup, per-point minima finalised in the kernel)."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.rand(Bsat, N, 3, device=dev, generator=g) - 0.5
+    y = torch.rand(Bsat, 3, M, device=dev, generator=g) - 0.5
+    T = torch.ones(1, device=dev)
+    proj = torch.empty(Bsat, M, 3, device=dev)
+    idx = torch.empty(Bsat, M, K, device=dev, dtype=torch.int32)
+    dq, iq = torch.empty(Bsat, M, device=dev), torch.empty(Bsat, M, device=dev, dtype=torch.int32)
+    dp, ip = torch.empty(Bsat, N, device=dev), torch.empty(Bsat, N, device=dev, dtype=torch.int32)
+    wsb = lib.sn_pairscan_workspace_bytes(Bsat, N, M)
+    ws = torch.empty(max(wsb // 8, 1), device=dev, dtype=torch.int64)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        check(lib.sn_pairscan_forward_ws(Bsat, N, M, K, ptr(x), 0, ptr(y), 1, ptr(idx), None, ptr(dq), ptr(iq), ptr(dp), ptr(ip),
+                                         ptr(proj), 0, None, ptr(T), 1e-2, ptr(ws) if wsb else None, wsb, st), "sn_pairscan_forward_ws")
+
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, Bsat
+
+
+def time_module_surface(dev, B, N, M, K, steps=60):
+    """Secondary leg: what a user of the drop-in module surface gets (registration/main.py:507-531 + 557-577), driver-timed:
+      eager  -- plain  simp, proj = net(x); alpha*get_simplification_loss + lmbda*get_projection_loss + task; backward()
+                launched op by op from Python with the frozen PCRNet's Chamfer loss as the task term (host-bound);
+      graph  -- the same general (any task_loss) path captured once by engine.SamplerTrainStep and replayed.
+    Not the headline value: the headline path fuses the benchmark's stand-in task term mean(proj) into the step."""
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss
+
+    torch.manual_seed(0)
+    net = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc").to(dev).train()
+    pcr = PCRNet(bottleneck_size=1024, input_shape="bnc").to(dev).eval()
+    for p in pcr.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand(B, N, 3, device=dev, generator=g) - 0.5        # source cloud p1 (sampled)
+    template = torch.rand(B, N, 3, device=dev, generator=g) - 0.5  # template cloud p0 (complete, NUM_SAMPLED_CLOUDS == 1)
+
+    def task(proj):  # main.py:557-577 with the sampled source in place of p1
+        return pcrnet_chamfer_loss(pcr, template, proj)[0]
+
+    def eager_step():
+        for p in net.parameters():
+            p.grad = None
+        simp, proj = net(x)
+        loss = 0.01 * net.get_simplification_loss(x, simp, M, 1, 0) + 0.01 * net.get_projection_loss() + task(proj)
+        loss.backward()
+        return loss
+
+    out = {}
+    for name in ("eager", "graph"):
+        if name == "graph":
+            st = SamplerTrainStep(net, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=task, use_graph=True)
+            run = lambda: st(x)  # noqa: E731
+        else:
+            run = eager_step
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(loss).item()
+        out[name] = {"value": B * steps / dt, "unit": "point-clouds/s", "ms_per_step": dt / steps * 1e3}
+    out["task_loss"] = "frozen PCRNet (bottleneck 1024) on (template 1024 pts, projected 64 pts) + Chamfer(projected, rotated template)"
+    return out
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/: FETCH_SIZE x 2 + WRITE_SIZE, KiB, as
     MI355X_MICROARCH.md prescribes for gfx950), or None when no profile of that kernel is on disk."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
-    try:
-        with open(path) as f:
-            table = json.load(f)
-    except OSError:
-        return None
-    for name, row in table.items():
-        if kernel_prefix in name and "hbm_traffic_bytes_per_launch" in row:
-            return row["hbm_traffic_bytes_per_launch"]
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
+        try:
+            with open(path) as f:
+                table = json.load(f)
+        except OSError:
+            continue
+        for name, row in table.items():
+            if kernel_prefix in name and "hbm_traffic_bytes_per_launch" in row:
+                return row["hbm_traffic_bytes_per_launch"]
     return None
 
 
@@ -145,8 +230,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
-    ap.add_argument("--torch-mlp", action="store_true", help="A/B: feature extractor through torch.nn instead of the HIP MLP")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--no-module-surface", action="store_true", help="skip the secondary module-surface leg")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="world size 1 under torchrun: still issue the gradient all-reduce (single-GPU exercise of the RCCL path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,7 +246,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or (args.force_collective and "MASTER_PORT" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -171,8 +258,8 @@ def main():
     B, N, M, K = args.batch, 1024, 64, 8
     torch.manual_seed(0)  # identical replicas on every rank (registration/main.py:18 seeds 0 as well)
     net = SampleNet(M, 128, group_size=K, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-2,
-                    input_shape="bnc", output_shape="bnc", use_hip_mlp=not args.torch_mlp).to(dev).train()
-    reducer = FlatGradAllReducer(net)
+                    input_shape="bnc", output_shape="bnc").to(dev).train()
+    reducer = FlatGradAllReducer(net, force_collective=args.force_collective)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank data shard
     pool = [torch.rand(B, N, 3, device=dev, generator=g) - 0.5 for _ in range(8)]
     # sampler loss weights of registration/src/sputils.py:53-59: alpha=0.01, lmbda=0.01, gamma=1, delta=0
@@ -211,6 +298,11 @@ def main():
         achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         conv_ms, conv_flop = time_conv5_backward_kernel(B, N)
         conv_tf = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        sat_ms, Bsat = time_pairscan_saturated(K)
+        sat_gbs = geometry_bytes_fwd(N, M, K) * Bsat / (sat_ms * 1e-3) / 1e9
+        # MLP work of the whole step: 3 x 67.93 MFLOP per cloud (forward + data gradient + weight gradient)
+        step_flop = 3 * 2 * 33_964_032 * B
+        step_tf = step_flop / (ms * 1e-3) / 1e12
         out = {
             "metric": "point-clouds/sec fwd+bwd, Bx1024->64 soft-proj+Chamfer",
             "value": value, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -219,9 +311,11 @@ def main():
             "config": {"workload": "BASELINE configs[1]: SampleNet sampler train step (fwd + simplification/projection "
                                    "losses + bwd), B=%d per GPU, 1024->64 points, K=8, bottleneck 128; no optimizer step" % B,
                        "batch_per_gpu": B, "global_batch": B * world, "n_in": N, "n_out": M, "group_size": K,
-                       "parallelism": "dp%d" % world, "grad_allreduce": "1 flat bucket, RCCL" if world > 1 else "none",
+                       "parallelism": "dp%d" % world,
+                       "grad_allreduce": ("flat bucket over RCCL: FC-head segment between the step's two graphs on a side stream, "
+                                          "conv segment after") if reducer.collective else "none",
                        "execution": "eager launches" if args.no_graph else "whole step replayed as one hipGraph",
-                       "mlp": "torch.nn (A/B)" if args.torch_mlp else "hand-written fp32 MFMA kernels"},
+                       "mlp": "hand-written fp32 MFMA kernels"},
             # the dominant kernel of the step (largest share of GPU time in profiles/): backward of the last 1x1 convolution
             "roofline": {"kernel": "sn::conv_bwd_fused_kernel<128,128,DZ_POOL> (conv5 backward: dgrad + wgrad, fp32 MFMA)",
                          "bound": "mfma", "achieved": conv_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -234,8 +328,16 @@ def main():
             "roofline_geometry": {"kernel": "sn::pairscan_kernel<16,true,true> (kNN + soft projection + both Chamfer directions)",
                                   "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("pairscan_kernel<16"),
-                                  "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms},
+                                  "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms,
+                                  "saturating_batch": {"batch": Bsat, "achieved": sat_gbs, "frac": sat_gbs / HBM_PEAK_GBS,
+                                                       "clouds_per_s": Bsat / (sat_ms * 1e-3), "avg_launch_ms": sat_ms}},
+            # the whole step against the fp32 matrix peak: MLP flops per step / step time (the geometric and scalar kernels, the
+            # launch gaps and the dependency chain are all in the denominator)
+            "step_mfma": {"flop_per_step": step_flop, "achieved": step_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": step_tf / MFMA_F32_PEAK_TFLOPS},
         }
+        if world == 1 and not args.no_module_surface:
+            out["module_surface"] = time_module_surface(dev, B, N, M, K)
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_reference_model import time_cpu_baseline
 

@@ -151,24 +151,14 @@ int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, in
                                   const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
                                   const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T,
                                   const float *deferred_partial, float *deferred_loss, sn_stream_t stream);
-/* The two calls above for callers that always run the backward right behind sn_pairscan_forward_partial[_fc] (engine): the
- * per-cloud reduction of the forward is folded into the backward's first launch and the loss value is combined in the
- * sigma-gradient launch: 2 launches after the scan.  partial: B*4 floats of scratch; loss: 2 floats.  N <= 2048. */
-int sn_sampler_step_loss_fold(int B, int N, int M, int K, const float *P, int p_layout, const float *Q, const int *knn_idx,
-                              const float *dist_q, const int *idx_q, const void *colmin_ws, int G, const float *proj,
-                              const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
-                              const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T, float *partial,
-                              float *loss, sn_stream_t stream);
 /* The same step with NO launch between the scan and the backward (engine default): sn_pairscan_forward_keys combines the
  * per-point minima across a cloud's workgroups by 64-bit atomicMax on inverted (distance, query) keys (max / min are
  * order-independent: deterministic) in colmin_keys [B][N] -- u64, zero on entry, zero again after
  * sn_sampler_step_loss_keys -- and leaves the query-side loss partials qpart [B][G][2] floats / qmax [B][G] u64,
  * G = sn_pairscan_colmin_splits(B,N,M) > 1.  Q (B,3,M) is read, or written when fc_w != NULL (queries produced by the
  * head's last layer as in sn_pairscan_forward_partial_fc).  dpsum: B floats of scratch; loss: 2 floats.  N <= 2048.
- * tail_stream (optional): the launch that produces grad_T / loss and resets colmin_keys goes there behind an event (it is
- * off the step's critical path); the caller makes `stream` wait for tail_stream before using those or ending a capture.
- * deferred_tail (optional, host buffer of sn_step_tail_bytes() bytes): that launch is not issued at all; its description is
- * written there and handed to sn_conv_stack_backward(step_tail) of the same step, whose closing kernel runs it. */
+ * deferred_tail (optional, host buffer of sn_step_tail_bytes() bytes): the launch that produces grad_T / loss and resets
+ * colmin_keys is not issued at all; its description is written there and handed to sn_conv_stack_backward(step_tail) of the same step, whose closing kernel runs it. */
 int sn_pairscan_forward_keys(int B, int N, int M, int K, const float *P, int p_layout, float *Q, const float *fc_z,
                              const float *fc_scale, const float *fc_shift, const float *fc_w, const float *fc_bias, int Kfc,
                              int *knn_idx, float *dist_q, int *idx_q, float *proj, int proj_layout, const float *temperature,
@@ -177,7 +167,7 @@ int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float *P, int p_
                               const int *idx_q, void *colmin_keys, const float *qpart, const void *qmax, int G,
                               const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
                               const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T, float *dpsum,
-                              float *loss, sn_stream_t stream, sn_stream_t tail_stream, void *deferred_tail);
+                              float *loss, sn_stream_t stream, void *deferred_tail);
 int sn_step_tail_bytes(void);
 /* defer_value != 0: the forward leaves loss[] unwritten; pass its `partial` and `loss` to the backward call as
  * deferred_partial / deferred_loss and the scalar is combined by an extra wave of the backward's first launch (the
@@ -353,8 +343,10 @@ int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z
                           const float *zprev, const float *coef_prev, float *stats, float *part, float *dW,
                           float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef, const float *x_in,
                           const float *W_in, const float *b_in, float *dW_in, sn_stream_t stream);
-/* prev_bn_rows (R <= 32 only, 0 = R): rows seen by the BatchNorm of the layer below when they differ from R -- the FC head's
- * first layer on top of the max-pool: zprev = pooled pre-BN values (B rows), BatchNorm over B*N rows; replaces sn_pool_backward */
+/* prev_bn_rows (> 0: R <= 32 only; 0 = R): rows seen by the BatchNorm of the layer below when they differ from R -- the FC head's
+ * first layer on top of the max-pool: zprev = pooled pre-BN values (B rows), BatchNorm over B*N rows; replaces sn_pool_backward.
+ * prev_bn_rows < 0 (any R): that BatchNorm normalised with FIXED statistics (eval mode: coef_prev from sn_bn_eval_coef), so its
+ * backward is dZ = scale * dY (k2 = k3 = 0); dgamma / dbeta as usual.  Likewise R < 0 in sn_pool_backward_bn. */
 int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
                       const float *bias, float *z, float *stats, sn_stream_t stream);
 int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,

@@ -41,12 +41,10 @@ PROTOTYPES = {
     "sn_sampler_step_loss_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sn_sampler_step_loss_backward": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp],
-    "sn_sampler_step_loss_fold": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp],
     "sn_pairscan_forward_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp,
                                  _vp, _vp],
     "sn_sampler_step_loss_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp, _vp],
+                                  _vp, _vp, _vp, _vp],
     "sn_step_tail_bytes": [],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],

@@ -507,20 +507,12 @@ __device__ __forceinline__ void step_loss_final(const StepLossFinal &f, int t)
 // query in ONE launch: a wave finishes the Chamfer gradient of target j exactly as chamfer_bwd_reg_kernel does, then runs
 // the soft-projection backward of query j (same point: the simplified cloud is both) and stores the sum -- the same
 // numbers as the two launches with accumulate_q (chamfer term first, soft term added), one kernel boundary less.
-// Optional: the forward's per-cloud reduction folded in (engine path: no launch between the pair scan and the backward).
-// Every workgroup of cloud b finishes the per-point nearest query of ITS cloud from the scan's G partial key sets into LDS
-// (what step_loss_partial_kernel writes to dist_p / idx_p) and takes the argmax of dist_q itself; the y == 0 workgroup
-// also leaves the cloud's loss partials (sum dq, max dq, sum dp, sum proj) for the value combined by the NEXT launch.
+// Optional (engine path: no launch between the pair scan and the backward), keys mode = sn_pairscan_forward_keys +
+// sn_sampler_step_loss_keys: the per-point minima are already complete, as INVERTED (distance, query) keys [B][ns]; the argmax
+// of dist_q comes from the scan's per-workgroup maxima qmax [B][G]; the y == 0 workgroup leaves sum dist_p of its cloud in
+// dpsum [B].  keys == NULL: idxS / argmax come from memory.
 struct StepLossFold {
-    const sn_u64 *ws;   // [B][G][ns] partial (distance, query) keys; NULL: idxS / argmax come from memory
     int G;
-    const float *dq;    // [B][nt]
-    const float *proj;  // [B][nproj]
-    int nproj;
-    float *part;        // [B][4]
-    // keys mode (sn_pairscan_forward_keys + sn_sampler_step_loss_keys): the per-point minima are already complete, as
-    // INVERTED (distance, query) keys [B][ns]; the argmax of dist_q comes from the scan's per-workgroup maxima qmax [B][G];
-    // the y == 0 workgroup leaves sum dist_p of its cloud in dpsum [B]
     const sn_u64 *keys;
     const sn_u64 *qmax;
     float *dpsum;
@@ -545,54 +537,6 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
     if ((int)blockIdx.y == nsplit) {
         if (b == 0 && wave == 0) step_loss_final(fin, lane);
         return;
-    }
-    if (fold.ws) {
-        const bool lead = blockIdx.y == 0;
-        // per-point nearest query: minimum of the G (distance, query) keys = lowest query on ties
-        float sdp = 0.f;
-        const sn_u64 *wb = fold.ws + (size_t)b * fold.G * ns;
-        for (int n = threadIdx.x; n < ns; n += 256) {
-            sn_u64 k = kKeyInf;
-            for (int g = 0; g < fold.G; ++g) {
-                const sn_u64 v = wb[(size_t)g * ns + n];
-                k = v < k ? v : k;
-            }
-            s_ip[n] = key_index(k);
-            sdp += key_dist(k);
-        }
-        // argmax of dist_q (first maximum) by wave 0; the lead workgroup also needs its sum and maximum
-        float sq = 0.f, spj = 0.f;
-        if (wave == 0) {
-            float mx = -INFINITY;
-            int am = 0;
-            for (int j = lane; j < nt; j += 64) {
-                const float v = fold.dq[(size_t)b * nt + j];
-                sq += v;
-                if (v > mx) mx = v, am = j;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float om = __shfl_xor(mx, o);
-                const int oa = __shfl_xor(am, o);
-                sq += __shfl_xor(sq, o);
-                if (om > mx || (om == mx && oa < am)) mx = om, am = oa;
-            }
-            if (lane == 0) s_am = am, s_red[1][0] = mx, s_red[0][0] = sq;
-        }
-        if (lead) {
-            for (int i = threadIdx.x; i < fold.nproj; i += 256) spj += fold.proj[(size_t)b * fold.nproj + i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sdp += __shfl_xor(sdp, o), spj += __shfl_xor(spj, o);
-            if (lane == 0) s_red[2][wave] = sdp, s_part[wave] = spj;
-        }
-        __syncthreads();
-        if (lead && threadIdx.x == 0) {
-            float *pt = fold.part + (size_t)b * 4;
-            pt[0] = s_red[0][0], pt[1] = s_red[1][0];
-            pt[2] = (s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3]);
-            pt[3] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-        }
-        __syncthreads();  // s_part is reused below
     }
     if (fold.keys) {
         // nearest query of every point of the cloud, fetched ONCE per workgroup (the four waves all need all of them; keys that
@@ -628,7 +572,7 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
     T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
     idxT += (size_t)b * nt, idxS += (size_t)b * ns;
     const float gLv = *ig.gL * ig.gscale;
-    const int amt = (fold.ws || fold.keys) ? s_am : (ig.argmax_t ? ig.argmax_t[b] : -1), ams = ig.argmax_s ? ig.argmax_s[b] : -1;
+    const int amt = fold.keys ? s_am : (ig.argmax_t ? ig.argmax_t[b] : -1), ams = ig.argmax_s ? ig.argmax_s[b] : -1;
     gradT += (size_t)b * nt * 3;
     const float Tm = *sa.temperature;
     const float sigma = fmaxf(Tm * Tm, sa.min_sigma);
@@ -642,7 +586,7 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
         const int lc = l < ns ? l : 0;
         const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)lc * 3);
         sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
-        is[i] = l < ns ? ((fold.ws || fold.keys) ? s_ip[lc] : idxS[lc]) : -1;
+        is[i] = l < ns ? (fold.keys ? s_ip[lc] : idxS[lc]) : -1;
         gg[i] = gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) * 2;
     }
 
@@ -1149,51 +1093,6 @@ extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const f
     return 0;
 }
 
-// sn_sampler_step_loss_forward + sn_sampler_step_loss_backward for callers that ALWAYS run the backward right behind the pair
-// scan (engine): the forward's per-cloud reduction is folded into the backward's first launch (every workgroup finishes
-// its cloud's per-point minima from the scan's partial keys in LDS) and the loss value is combined by a second workgroup
-// of the sigma-gradient launch -- 2 launches for the loss side after the scan instead of 3.  colmin_ws / G as produced by
-// sn_pairscan_forward_partial; partial: B*4 floats of scratch; loss[0] = L, loss[1] = L_simp.  N <= 2048.
-extern "C" int sn_sampler_step_loss_fold(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
-                                         const int *knn_idx, const float *dist_q, const int *idx_q, const void *colmin_ws,
-                                         int G, const float *proj, const float *temperature, float min_sigma, float alpha,
-                                         float lmbda, float weight, const float *grad_loss, float *grad_Q,
-                                         float *gsig_scratch, float *grad_T, float *partial, float *loss, sn_stream_t stream)
-{
-    SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && G >= 1, "bad size");
-    SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
-    SN_REQUIRE(P && Q && knn_idx && dist_q && idx_q && colmin_ws && proj && temperature && grad_loss && grad_Q && gsig_scratch &&
-                   grad_T && partial && loss,
-               "null pointer");
-    if (N > 2048) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_sampler_step_loss_fold: N <= 2048 (use the forward / backward pair)");
-    hipStream_t st = (hipStream_t)stream;
-    const float c1 = 1.0f / ((float)B * (float)M), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)N);
-    ImplicitGrad ig{grad_loss, nullptr, nullptr, c1, cm, c2, 0.f, alpha};
-    SoftBwdArgs a{};
-    a.P = P, a.Q = Q, a.idx = knn_idx, a.temperature = temperature, a.min_sigma = min_sigma;
-    a.p_layout = p_layout, a.q_layout = SN_LAYOUT_BCN, a.n = N, a.m = M, a.k = K;
-    a.grad_proj = nullptr, a.gconst = grad_loss, a.gconst_div = (float)(B * 3 * M);
-    a.grad_Q = grad_Q, a.gq_layout = SN_LAYOUT_BCN, a.accumulate_q = 1;
-    a.grad_P = nullptr, a.grad_sigma_partial = gsig_scratch;
-    int splits = std::max(1, std::min((M + 3) / 4, (kChamferBwdGroups + B - 1) / B));
-    splits = std::min(splits, sn_soft_bwd_splits(B, M));
-    const StepLossFold fold{(const sn_u64 *)colmin_ws, G, dist_q, proj, 3 * M, partial};
-    const dim3 grid(B, splits), block(256);
-#define SN_CS(PPL_)                                                                                                        \
-    hipLaunchKernelGGL(chamfer_soft_bwd_kernel<PPL_>, grid, block, 0, st, M, N, Q, P, idx_q, (const int *)nullptr, grad_Q, ig, a, \
-                       StepLossFinal{}, fold)
-    if (N <= 64) SN_CS(1);
-    else if (N <= 256) SN_CS(4);
-    else if (N <= 1024) SN_CS(16);
-    else SN_CS(32);
-#undef SN_CS
-    const StepLossFinal fin{B, M, N, 3 * M, weight, alpha, lmbda, min_sigma, partial, temperature, loss};
-    hipLaunchKernelGGL(sigma_grad_kernel, dim3(2), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
-                       grad_loss, lmbda, fin);
-    SN_LAUNCH_CHECK();
-    return 0;
-}
-
 // Loss side of the sampler step behind sn_pairscan_forward_keys (engine): backward + loss value in 2 launches, nothing
 // between the scan and the backward.  colmin_keys / qpart / qmax as the scan left them; colmin_keys is zero again afterwards.
 // dpsum: B floats of scratch; loss[0] = L, loss[1] = L_simp.  N <= 2048.
@@ -1202,7 +1101,7 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
                                          const void *qmax, int G, const float *temperature, float min_sigma, float alpha,
                                          float lmbda, float weight, const float *grad_loss, float *grad_Q,
                                          float *gsig_scratch, float *grad_T, float *dpsum, float *loss, sn_stream_t stream,
-                                         sn_stream_t tail_stream, void *deferred_tail)
+                                         void *deferred_tail)
 {
     SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && G >= 1, "bad size");
     SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
@@ -1211,11 +1110,6 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
                "null pointer");
     if (N > 2048) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_sampler_step_loss_keys: N <= 2048");
     hipStream_t st = (hipStream_t)stream;
-    // tail_stream (optional, != stream): the second launch -- sigma gradient, loss value, key-table reset: nothing on the
-    // step's critical path reads its outputs -- is enqueued there behind an event, so that it runs BESIDE the FC head's
-    // backward instead of in front of it.  The caller joins tail_stream back (stream waits for it) before it uses grad_T /
-    // loss / the key table or ends a graph capture.
-    hipStream_t tail = tail_stream ? (hipStream_t)tail_stream : st;
     const float c1 = 1.0f / ((float)B * (float)M), cm = 1.0f / (float)B, c2 = weight / ((float)B * (float)N);
     ImplicitGrad ig{grad_loss, nullptr, nullptr, c1, cm, c2, 0.f, alpha};
     SoftBwdArgs a{};
@@ -1249,17 +1143,7 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
         SN_LAUNCH_CHECK();
         return 0;
     }
-    if (tail != st) {
-        static hipEvent_t ev[16] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        dev &= 15;
-        if (!ev[dev] && hipEventCreateWithFlags(&ev[dev], hipEventDisableTiming) != hipSuccess)
-            return sn_set_error(SN_ERR_BAD_ARGUMENT, "sn_sampler_step_loss_keys: cannot create the fork event");
-        if (hipEventRecord(ev[dev], st) != hipSuccess || hipStreamWaitEvent(tail, ev[dev], 0) != hipSuccess)
-            return sn_set_error(SN_ERR_BAD_ARGUMENT, "sn_sampler_step_loss_keys: cannot fork onto tail_stream");
-    }
-    hipLaunchKernelGGL(sigma_grad_kernel, dim3(2 + 64), dim3(256), 0, tail, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
+    hipLaunchKernelGGL(sigma_grad_kernel, dim3(2 + 64), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
                        grad_loss, lmbda, StepLossFinal{}, kf);
     SN_LAUNCH_CHECK();
     return 0;

@@ -209,8 +209,9 @@ __device__ __forceinline__ void fc_query(const PairscanArgs &a, int b, int j, in
         const float4 u = *reinterpret_cast<const float4 *>(w0 + k);
         const float4 v = *reinterpret_cast<const float4 *>(w1 + k);
         const float4 w = *reinterpret_cast<const float4 *>(w2 + k);
-        const float ax = fmaxf(fmaf(zv.x, sc.x, sh.x), 0.f), ay = fmaxf(fmaf(zv.y, sc.y, sh.y), 0.f);
-        const float az = fmaxf(fmaf(zv.z, sc.z, sh.z), 0.f), aw = fmaxf(fmaf(zv.w, sc.w, sh.w), 0.f);
+        // (u < 0 ? 0 : u, not fmaxf: a NaN from diverged BatchNorm statistics must reach the loss, as in the MLP kernels)
+        const float ux = fmaf(zv.x, sc.x, sh.x), uy = fmaf(zv.y, sc.y, sh.y), uz = fmaf(zv.z, sc.z, sh.z), uw = fmaf(zv.w, sc.w, sh.w);
+        const float ax = ux < 0.f ? 0.f : ux, ay = uy < 0.f ? 0.f : uy, az = uz < 0.f ? 0.f : uz, aw = uw < 0.f ? 0.f : uw;
         s0 = fmaf(aw, u.w, fmaf(az, u.z, fmaf(ay, u.y, fmaf(ax, u.x, s0))));
         s1 = fmaf(aw, v.w, fmaf(az, v.z, fmaf(ay, v.y, fmaf(ax, v.x, s1))));
         s2 = fmaf(aw, w.w, fmaf(az, w.z, fmaf(ay, w.y, fmaf(ax, w.x, s2))));
@@ -631,8 +632,8 @@ extern "C" int sn_pairscan_forward_partial(int B, int N, int M, int K, const flo
     int used = 0;
     int rc = sn::pairscan_dispatch(a, workspace, workspace_bytes, false, &used, (hipStream_t)stream);
     if (rc) return rc;
-    SN_REQUIRE(used == G, "internal: split mismatch");
-    SN_LAUNCH_CHECK();
+    SN_LAUNCH_CHECK();  // (first: SN_REQUIRE discards the pending launch status)
+    if (used != G) return sn_set_error(SN_ERR_BAD_ARGUMENT, "%s: internal: split mismatch", __func__);
     return 0;
 }
 
@@ -667,8 +668,8 @@ extern "C" int sn_pairscan_forward_keys(int B, int N, int M, int K, const float 
     int used = 0;
     int rc = sn::pairscan_dispatch(a, nullptr, 0, false, &used, (hipStream_t)stream);
     if (rc) return rc;
-    SN_REQUIRE(used == G, "internal: split mismatch");
-    SN_LAUNCH_CHECK();
+    SN_LAUNCH_CHECK();  // (first: SN_REQUIRE discards the pending launch status)
+    if (used != G) return sn_set_error(SN_ERR_BAD_ARGUMENT, "%s: internal: split mismatch", __func__);
     return 0;
 }
 
@@ -700,7 +701,7 @@ extern "C" int sn_pairscan_forward_partial_fc(int B, int N, int M, int K, const 
     int used = 0;
     int rc = sn::pairscan_dispatch(a, workspace, workspace_bytes, false, &used, (hipStream_t)stream);
     if (rc) return rc;
-    SN_REQUIRE(used == G, "internal: split mismatch");
-    SN_LAUNCH_CHECK();
+    SN_LAUNCH_CHECK();  // (first: SN_REQUIRE discards the pending launch status)
+    if (used != G) return sn_set_error(SN_ERR_BAD_ARGUMENT, "%s: internal: split mismatch", __func__);
     return 0;
 }

@@ -546,7 +546,9 @@ __device__ __forceinline__ BnBwdOut bn_backward_coefs(long long R, double s, dou
 {
     const double scale = in.scale, mean = in.mean, invstd = in.invstd;
     const double dg = invstd * (sz - mean * s);
-    const double rinv = 1.0 / (double)R;
+    // R <= 0: the forward normalised with FIXED statistics (eval mode, running mean / variance): dZ = scale * dY, no
+    // dependence of the statistics on Z -> k2 = k3 = 0; dgamma / dbeta keep their form (mean, invstd = the fixed ones)
+    const double rinv = R > 0 ? 1.0 / (double)R : 0.0;
     BnBwdOut o;
     o.dgamma = (float)dg, o.dbeta = (float)s;
     o.k1 = (float)scale, o.k2 = (float)(-scale * invstd * dg * rinv);
@@ -1572,9 +1574,22 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
     if (g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Co + col] = s1;
     if (g.bn.coef) {  // this workgroup holds every row of its 32 columns: their batch statistics are complete here
         if (blockIdx.x == 0 && lane == 0 && g.bn.num_batches_tracked) *g.bn.num_batches_tracked += 1;
+        // Two-pass variance: the rows are all in this wave's registers, so the squares are summed around the mean.  (The FC head
+        // sits behind the max-pool: its pre-BN features are nearly the same for every cloud of a batch -- |mean| / std of 10..100 --
+        // and E[z^2] - mean^2 from fp32 sums then loses 2..4 digits of the variance; measured 5x the error of torch's CPU path
+        // at the head's output before this.)
+        const float meanf = s0 / (float)g.bn.R;
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float d = (acc[e] + bias) - meanf;
+            if (frag_row(e, lane) < R && colok) s2 += d * d;
+        }
+        s2 += __shfl_xor(s2, 32);
         if (lane < 32 && colok) {  // same arithmetic as bn_finalize_channel, on the prefetched parameters
             const double mean = (double)s0 / (double)g.bn.R;
-            double var = (double)s1 / (double)g.bn.R - mean * mean;
+            const double dm = mean - (double)meanf;  // sum (z - meanf)^2 = sum (z - mean)^2 + R dm^2
+            double var = (double)s2 / (double)g.bn.R - dm * dm;
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)g.bn.eps));
             const float sc = bn_g * invstd;
@@ -1699,9 +1714,22 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
     if (g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Co + col] = s1;
     if (g.bn.coef) {  // this workgroup holds every row of its 32 columns: their batch statistics are complete here
         if (blockIdx.x == 0 && lane == 0 && g.bn.num_batches_tracked) *g.bn.num_batches_tracked += 1;
+        // Two-pass variance: the rows are all in this wave's registers, so the squares are summed around the mean.  (The FC head
+        // sits behind the max-pool: its pre-BN features are nearly the same for every cloud of a batch -- |mean| / std of 10..100 --
+        // and E[z^2] - mean^2 from fp32 sums then loses 2..4 digits of the variance; measured 5x the error of torch's CPU path
+        // at the head's output before this.)
+        const float meanf = s0 / (float)g.bn.R;
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float d = (acc[e] + bias) - meanf;
+            if (frag_row(e, lane) < R && colok) s2 += d * d;
+        }
+        s2 += __shfl_xor(s2, 32);
         if (lane < 32 && colok) {  // same arithmetic as bn_finalize_channel, on the prefetched parameters
             const double mean = (double)s0 / (double)g.bn.R;
-            double var = (double)s1 / (double)g.bn.R - mean * mean;
+            const double dm = mean - (double)meanf;  // sum (z - meanf)^2 = sum (z - mean)^2 + R dm^2
+            double var = (double)s2 / (double)g.bn.R - dm * dm;
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)g.bn.eps));
             const float sc = bn_g * invstd;
@@ -1778,7 +1806,7 @@ __device__ __forceinline__ void small_dgrad_body(const DgradArgs &g, int bx, flo
     wave_sum_to_wave0(acc, lds);
     SN_TL(3);
     if (wave != 0) return;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s1c = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int row = frag_row(e, lane);
@@ -1789,19 +1817,21 @@ __device__ __forceinline__ void small_dgrad_body(const DgradArgs &g, int bx, flo
                 v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
                 s0 += v;
                 s1 += v * zp;
+                s1c += v * (zp - pmean);  // centred: sum g (z - mean) without the cancellation of sum g z - mean sum g
             }
             g.dyprev[(size_t)row * Ci + col] = v;
         }
     }
     s0 += __shfl_xor(s0, 32);
     s1 += __shfl_xor(s1, 32);
+    s1c += __shfl_xor(s1c, 32);
     if (masked && g.stats && lane < 32 && colok) g.stats[col] = s0, g.stats[Ci + col] = s1;
     if (masked && g.bb.coef && lane < 32 && colok) {  // bn_backward_channel on the prefetched mean / invstd
-        const double scale = sc, mean = pmean, invstd = pinv, s = s0, sz = s1;
-        const double dg = invstd * (sz - mean * s);
+        const double scale = sc, mean = pmean, invstd = pinv, s = s0;
+        const double dg = invstd * (double)s1c;
         g.bb.dgamma[col] = (float)dg;
         g.bb.dbeta[col] = (float)s;
-        const double rinv = 1.0 / (double)g.bb.R;
+        const double rinv = g.bb.R > 0 ? 1.0 / (double)g.bb.R : 0.0;  // R <= 0: fixed statistics (see bn_backward_coefs)
         const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
         const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
         g.bb.kcoef[col] = k1, g.bb.kcoef[Ci + col] = k2, g.bb.kcoef[2 * Ci + col] = k3;
@@ -3042,12 +3072,14 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
     SN_REQUIRE(W && zprev && dyprev && dW, "null pointer");
     SN_REQUIRE(dz_mode >= DZ_PLAIN && dz_mode <= DZ_POOL, "bad dz_mode");
     SN_REQUIRE(!coef_prev || ((stats || R <= 32) && prev_dgamma && prev_dbeta && prev_kcoef), "previous-layer BatchNorm outputs missing");
-    SN_REQUIRE(prev_bn_rows == 0 || R <= 32, "prev_bn_rows applies to the register-resident (R <= 32) path only");
+    SN_REQUIRE(prev_bn_rows <= 0 || R <= 32, "prev_bn_rows > 0 applies to the register-resident (R <= 32) path only");
     hipStream_t st = (hipStream_t)stream;
     // prev_bn_rows: rows the BatchNorm of the layer below averaged over when they are not this layer's R -- the FC head's
     // first layer sits on the max-pool of the last conv layer: zprev = the pooled pre-BN values (B rows), its BatchNorm saw
     // B * N rows; the ReLU mask / sums of the dgrad epilogue are then exactly the pooling backward
-    const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, prev_bn_rows > 0 ? prev_bn_rows : (long long)R};
+    // prev_bn_rows < 0: that BatchNorm ran on fixed (running) statistics -- eval-mode backward, dZ = scale * dY
+    const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef,
+                   prev_bn_rows > 0 ? prev_bn_rows : (prev_bn_rows < 0 ? -1ll : (long long)R)};
     if (R <= 32) {
         DgradArgs g{};
         g.dz = make_dz(dz_mode, dy, z, kcoef, gsel, argsel, R, Co, npts);
@@ -3335,8 +3367,8 @@ extern "C" int sn_pool_backward_bn(int B, int C, long long R, const float *g, co
                                    float *gsel, const float *coef, float *dgamma, float *dbeta, float *dbias, float *kcoef,
                                    sn_stream_t stream)
 {
-    SN_REQUIRE(B >= 1 && C >= 1 && R >= 1 && g && pooled && zsel && gsel && coef && dgamma && dbeta && kcoef, "bad argument");
-    const BnBwd bb{coef, dgamma, dbeta, dbias, kcoef, R};
+    SN_REQUIRE(B >= 1 && C >= 1 && R != 0 && g && pooled && zsel && gsel && coef && dgamma && dbeta && kcoef, "bad argument");
+    const BnBwd bb{coef, dgamma, dbeta, dbias, kcoef, R};  // R < 0: fixed statistics (eval-mode backward)
     hipLaunchKernelGGL(pool_bwd_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, B, C, g, pooled, zsel,
                        gsel, (float *)nullptr, bb);
     SN_LAUNCH_CHECK();

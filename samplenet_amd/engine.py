@@ -16,7 +16,7 @@ import torch
 
 class SamplerTrainStep:
     def __init__(self, net, example_x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=None, reducer=None,
-                 use_graph=True, warmup=3, fused_loss=True, input_ring=None, fused_head=True):
+                 use_graph=True, warmup=3, fused_loss=True, input_ring=None, fused_head=True, overlap_allreduce=None):
         self.net, self.reducer = net, reducer
         self.alpha, self.lmbda, self.gamma, self.delta = alpha, lmbda, gamma, delta
         self.fused_loss = fused_loss  # False: compose the loss op by op through the module's own methods (A/B, tests)
@@ -32,9 +32,17 @@ class SamplerTrainStep:
         self._one = torch.ones((), device=example_x.device, dtype=torch.float32)
         self.graph = None
         self.loss = None
-        self._ring_graphs, self._ring_loss = [], []
+        self._ring_graphs, self._ring_loss, self._ring_outputs = [], [], []
+        self.outputs = None  # (simplified, projected) clouds of the last step (static tensors under graph replay)
         if use_graph and reducer is not None:
-            reducer.disable_overlap()  # the graph replays backward without Python: one all-reduce after the replay
+            reducer.disable_overlap()  # the graph replays backward without Python: the engine places the collectives
+        # Captured step + gradient collective (N > 1): the step is captured as TWO graphs split where the FC head's gradients
+        # (86 % of the bucket) are final; between the replays their all-reduce starts on the reducer's side stream and runs
+        # beside the conv stack's backward (graph 2); the rest of the bucket follows graph 2.  Stream-ordered: no host sync.
+        if overlap_allreduce is None:
+            overlap_allreduce = True
+        self.split = bool(use_graph and overlap_allreduce and reducer is not None and reducer.collective and self._fast_path()
+                          and fused_head and getattr(net, "use_hip_mlp", False))
         if use_graph:
             self._capture(warmup)
 
@@ -50,31 +58,45 @@ class SamplerTrainStep:
         B, N, _ = self.x.shape
         return lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1
 
-    def _step(self):
+    def _step(self, boundary=None):
+        """One step (eager, or under capture).  boundary: callable invoked where the FC head's gradients are complete --
+        set while capturing the split step; the node then runs without autograd (same thread: a capture may only be ended by
+        the thread that began it, and autograd would run the backward on its device thread)."""
         net, x = self.net, self.x
+        if self.reducer is not None:
+            self.reducer.begin_step()  # this step's backward overwrites the kernel-written gradient views
         if self._fast_path():
             from . import ops
 
             T = net.project._temperature
             t_sink = None
-            if self.reducer is not None and T.requires_grad and T.grad is not None:
+            if self.reducer is not None and T.requires_grad:
+                self.reducer._rebind()  # (after an optimizer.zero_grad(): T.grad is the bucket's view again)
                 t_sink = T.grad.view(-1)[:1]  # a view of the flat bucket: written in place, nothing to zero or accumulate
             elif self.reducer is not None:
                 self.reducer.zero_grad()
             weight = self.gamma + self.delta * net.num_out_points
+            if boundary is not None:
+                from . import fused_step
+
+                loss, y, proj = fused_step.sampler_step_direct(net, x, self.alpha, self.lmbda, weight, t_sink, self._one, boundary)
+                self.outputs = (y, proj)
+                return loss
             if self.fused_head and net.use_hip_mlp:
                 from .fused_step import sampler_step
 
-                loss, _y, _proj = sampler_step(net, x, self.alpha, self.lmbda, weight, t_sink, True)  # fc4 inside the scan
+                loss, y, proj = sampler_step(net, x, self.alpha, self.lmbda, weight, t_sink, True)  # fc4 inside the scan
             else:
                 y = net._features(x.permute(0, 2, 1), x)  # (B,3,M)
-                loss, _proj = ops.SamplerStepLossFunction.apply(y, x, T, net.project._group_size, net.project._min_sigma_f,
-                                                                self.alpha, self.lmbda, weight, t_sink, True)
+                loss, proj = ops.SamplerStepLossFunction.apply(y, x, T, net.project._group_size, net.project._min_sigma_f,
+                                                               self.alpha, self.lmbda, weight, t_sink, True)
+            self.outputs = (y.detach(), proj.detach())  # simplified cloud (B,3,M), projected cloud (B,M,3)
             loss.backward(self._one)  # preallocated upstream gradient: no ones_like fill per step
             return loss.detach()
         if self.reducer is not None:
             self.reducer.zero_grad()
         simp, proj = net(x)
+        self.outputs = (simp.detach(), proj.detach())  # in the module's output_shape
         lsimp = net.get_simplification_loss(x, simp, net.num_out_points, self.gamma, self.delta)
         if self.task_loss is None and net.training and not net.skip_projection:
             # alpha * L_simp + lmbda * sigma + mean(proj) in one fused kernel pair (same value as the composition below)
@@ -87,6 +109,38 @@ class SamplerTrainStep:
             loss = self.alpha * lsimp + self.lmbda * net.get_projection_loss() + task
         loss.backward(self._one)  # preallocated upstream gradient: no ones_like fill per step
         return loss.detach()
+
+    def _capture_step(self, pool):
+        """Captures one step on self.x -> ([graph] | [graph 1, graph 2], loss, outputs)."""
+        if not self.split:
+            g = torch.cuda.CUDAGraph()
+            # thread_local: API calls of other threads (the RCCL watchdog polling events) must not invalidate the capture
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                loss = self._step()
+            return [g], loss, self.outputs
+        import gc
+
+        graphs = [torch.cuda.CUDAGraph()]
+
+        def boundary():  # FC-head gradients enqueued: close graph 1, open graph 2 on the same stream
+            graphs[-1].capture_end()
+            graphs.append(torch.cuda.CUDAGraph())
+            graphs[-1].capture_begin(pool=pool, capture_error_mode="thread_local")
+
+        torch.cuda.synchronize()
+        gc.collect()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap), torch.no_grad():
+            graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
+            try:
+                loss = self._step(boundary)
+            finally:
+                graphs[-1].capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        if len(graphs) != 2:
+            raise RuntimeError("split capture: the FC / conv boundary was not reached exactly once")
+        return graphs, loss, self.outputs
 
     def _capture(self, warmup):
         if self.reducer is None:
@@ -101,30 +155,34 @@ class SamplerTrainStep:
                     for p in self.net.parameters():
                         p.grad = None
         torch.cuda.current_stream().wait_stream(side)
-        if self.ring is None:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.loss = self._step()
-            return
         pool = torch.cuda.graph_pool_handle()
-        for buf in self.ring:
-            if buf.shape != self.ring[0].shape or buf.device != self.ring[0].device or not buf.is_contiguous():
+        bufs = self.ring if self.ring is not None else [self.x]
+        for buf in bufs:
+            if buf.shape != bufs[0].shape or buf.device != bufs[0].device or not buf.is_contiguous():
                 raise ValueError("input_ring entries must be contiguous tensors of one shape on one device")
             self.x = buf
-            g = torch.cuda.CUDAGraph()
-            # thread_local: API calls of other threads (the RCCL watchdog polling events) must not invalidate the capture
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                loss = self._step()
-            self._ring_graphs.append(g)
+            graphs, loss, outputs = self._capture_step(pool)
+            self._ring_graphs.append(graphs)
             self._ring_loss.append(loss)
-        self.graph = self._ring_graphs[0]
+            self._ring_outputs.append(outputs)
+        self.x = bufs[0]
+        self.graph = self._ring_graphs[0][0]
         self.loss = self._ring_loss[0]
+
+    def _replay_graphs(self, i):
+        graphs = self._ring_graphs[i]
+        graphs[0].replay()
+        if len(graphs) == 2:
+            self.reducer.reduce_early_async()  # FC-head segment: all-reduce on the side stream beside graph 2
+            graphs[1].replay()
+        self.loss, self.outputs = self._ring_loss[i], self._ring_outputs[i]
 
     def replay(self, i):
         """One step on ring entry i (whatever the caller wrote into input_ring[i]); returns the (static) loss tensor."""
+        if self.ring is None:
+            raise RuntimeError("replay(i) needs an input ring; call the step with a batch instead")
         if self._ring_graphs:
-            self._ring_graphs[i].replay()
-            self.loss = self._ring_loss[i]
+            self._replay_graphs(i)
         else:
             self.x = self.ring[i]
             self.loss = self._step()
@@ -138,8 +196,8 @@ class SamplerTrainStep:
         if self.ring is not None:
             raise RuntimeError("this step was built on an input ring: fill input_ring[i] in place and call replay(i)")
         self.x.copy_(x, non_blocking=True)
-        if self.graph is not None:
-            self.graph.replay()
+        if self._ring_graphs:
+            self._replay_graphs(0)
         else:
             self.loss = self._step()
         if self.reducer is not None:

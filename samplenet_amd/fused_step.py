@@ -10,24 +10,25 @@ coordinates itself (sn_pairscan_forward_partial_fc), so fc4's forward launch dis
 (pointnet.backward_impl receives d L / d y from the loss kernels).  Used by engine.SamplerTrainStep's fast path; the
 op-by-op modules (SampleNet.forward + get_simplification_loss + get_projection_loss) compute the same step.
 """
-import os
+import weakref
 
 import torch
 
 from . import ops, pointnet
 
-# per-cloud loss reduction inside the backward's first launch (sn_sampler_step_loss_fold): one launch less, but every one of
-# the 512 workgroups then re-reduces its cloud's 64 KB of partial keys -- measured +2.2 us per step at B = 32, so OFF
-FOLD_LOSS = os.environ.get("SAMPLENET_AMD_FOLD_LOSS", "0") == "1"
-# per-point minima combined across a cloud's scan workgroups by atomicMax on inverted keys: no reduction launch between the
-# scan and the backward (sn_pairscan_forward_keys / sn_sampler_step_loss_keys)
-KEYS_LOSS = os.environ.get("SAMPLENET_AMD_KEYS_LOSS", "1") != "0"
-# sigma-gradient / loss-value launch on a side stream beside the MLP backward (it is off the critical path): inside the
-# captured graph the fork / join costs far more than the 5 us launch it hides (measured +36 us per step) -> OFF
-TAIL_STREAM = os.environ.get("SAMPLENET_AMD_TAIL_STREAM", "0") == "1"
-# the loss side's scalar tail (sigma gradient, loss value, key-table reset) rides in the closing kernel of the conv stack's
-# backward instead of a launch of its own
-DEFER_TAIL = os.environ.get("SAMPLENET_AMD_DEFER_TAIL", "1") != "0"
+# Test hooks (no environment switches; the defaults are the product path).  KEYS_LOSS: per-point minima combined across a
+# cloud's scan workgroups by atomicMax on inverted keys -- no reduction launch between the scan and the backward
+# (sn_pairscan_forward_keys / sn_sampler_step_loss_keys); False = the partial-key route every N > 2048 batch takes.
+# DEFER_TAIL: the loss side's scalar tail (sigma gradient, loss value, key-table reset) rides in the closing kernel of the conv
+# stack's backward instead of a launch of its own; False = the route unsupported conv-stack shapes take.
+KEYS_LOSS = True
+DEFER_TAIL = True
+
+
+class _KeyToken:
+    """Identity of the forward that currently owns a module's persistent key table (held by its ctx)."""
+
+    __slots__ = ("__weakref__",)
 
 
 class SamplerStepFunction(torch.autograd.Function):
@@ -46,21 +47,32 @@ class SamplerStepFunction(torch.autograd.Function):
             y = torch.empty(B, 3, M, device=x.device, dtype=torch.float32)
             fc = (saved["zf"][2], saved["cf"][2], fc4.weight.detach(), fc4.bias.detach())
             keys = None
+            token = None
             if defer_value and KEYS_LOSS and x.shape[1] <= 2048:
-                # persistent zeroed table of inverted per-point keys (every step leaves it zero again)
+                # persistent zeroed table of inverted per-point keys (every step's backward leaves it zero again).  It belongs
+                # to ONE forward at a time: a second forward before the owner's backward (two sampler passes under one loss,
+                # main.py:516-524) gets a private table instead of clobbering the owner's minima; an owner that was dropped
+                # without a backward is detected through its dead token and the table is cleaned.
                 keys = getattr(net, "_colmin_keys", None)
                 if keys is None or keys.device != x.device or keys.numel() != B * x.shape[1]:
                     keys = torch.zeros(B * x.shape[1], device=x.device, dtype=torch.int64)
-                    net._colmin_keys = keys
-                elif getattr(net, "_colmin_keys_pending", False):
-                    keys.zero_()  # a forward whose backward never ran left its minima behind
-                net._colmin_keys_pending = True
+                    net._colmin_keys, net._colmin_keys_owner = keys, None
+                owner = getattr(net, "_colmin_keys_owner", None)
+                if owner is not None and owner() is None:
+                    keys.zero_()  # the forward that owned the table never ran its backward
+                    owner = None
+                token = _KeyToken()
+                if owner is None:
+                    net._colmin_keys_owner = weakref.ref(token)
+                else:
+                    keys = torch.zeros(B * x.shape[1], device=x.device, dtype=torch.int64)
             loss, proj, state = ops.step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value,
-                                                      fold=bool(defer_value) and FOLD_LOSS and x.shape[1] <= 2048, keys=keys)
+                                                      keys=keys)
         ctx.net, ctx.saved, ctx.state = net, saved, state
         ctx.x, ctx.y, ctx.temperature = x, y, temperature
         ctx.cfg = (K, float(min_sigma), float(alpha), float(lmbda), float(weight))
         ctx.t_sink = t_sink
+        ctx.keys_token = token
         ctx.mark_non_differentiable(y, proj)
         ctx.set_materialize_grads(False)
         return loss[0], y, proj
@@ -71,35 +83,36 @@ class SamplerStepFunction(torch.autograd.Function):
         if grad_loss is None:
             return (None,) * (10 + nparams)
         net = ctx.net
-        sink = getattr(net, "_grad_sink", None)
+        sink, owner = pointnet.sink_for_backward(net)
         if len(ctx.state) > 5 and ctx.state[5][0] == "keys":
             if getattr(ctx, "keys_consumed", False):
                 raise RuntimeError("SamplerStepFunction: the key table of this forward was already consumed by a backward "
-                                   "(set SAMPLENET_AMD_KEYS_LOSS=0 to backpropagate the same step twice)")
+                                   "(call the step again instead of backpropagating one forward twice)")
             ctx.keys_consumed = True
         with torch.cuda.device(ctx.y.device):
             keys_mode = len(ctx.state) > 5 and ctx.state[5][0] == "keys"
-            # keys mode: the sigma-gradient / loss-value / key-reset launch runs on a side stream beside the MLP backward
-            tail = ops.tail_stream(ctx.y.device) if (keys_mode and TAIL_STREAM) else None
-            # ... or, better, inside the closing kernel of the conv stack's backward: no launch of its own at all
+            # keys mode: the sigma-gradient / loss-value / key-reset work rides in the closing kernel of the conv stack's backward
             blob = None
-            if keys_mode and DEFER_TAIL and tail is None and pointnet.conv_stack_backward_supported(net, ctx.x.shape[0], ctx.x.shape[1]):
+            if keys_mode and DEFER_TAIL and pointnet.conv_stack_backward_supported(net, ctx.x.shape[0], ctx.x.shape[1]):
                 import ctypes
 
                 blob = ctypes.create_string_buffer(ops.lib.sn_step_tail_bytes())
-            res = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink, tail, blob)
+            res = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink, blob)
             gQ, gT = res[0], res[1]
-            net._colmin_keys_pending = False  # (the backward's last launch re-zeroed the key table)
-            grads = pointnet.backward_impl(net, ctx.saved, gQ.view(gQ.shape[0], -1), sink, getattr(net, "_after_fc_grads", None),
-                                           step_tail=blob)
-            if tail is not None:
-                torch.cuda.current_stream().wait_stream(tail)  # join (also what ends the fork inside a graph capture)
-            del res  # (scratch of the side-stream launch: released only behind the join)
+            if keys_mode:  # (the backward's last launch re-zeroed the key table: hand the persistent one back)
+                kown = getattr(net, "_colmin_keys_owner", None)
+                if kown is not None and kown() is ctx.keys_token:
+                    net._colmin_keys_owner = None
+            grads = pointnet.backward_impl(net, ctx.saved, gQ.view(gQ.shape[0], -1), sink,
+                                           getattr(net, "_after_fc_grads", None) if sink is not None else None, step_tail=blob)
+            if owner is not None:
+                owner.commit(None if sink is not None else grads)
+            del res  # (scratch the deferred tail reads: released only behind the conv backward)
         g_temp = None
         if ctx.t_sink is None and ctx.needs_input_grad[2]:
             g_temp = gT.reshape(ctx.temperature.shape)
         return (None, None, g_temp) + (None,) * 7 + tuple(
-            None if (sink is not None and n in sink) else grads[n] for n in pointnet.PARAM_ORDER)
+            None if (owner is not None and n in owner) else grads[n] for n in pointnet.PARAM_ORDER)
 
 
 def sampler_step(net, x_bnc, alpha, lmbda, weight, t_sink=None, defer_value=False):
@@ -109,3 +122,37 @@ def sampler_step(net, x_bnc, alpha, lmbda, weight, t_sink=None, defer_value=Fals
     proj = net.project
     return SamplerStepFunction.apply(net, x_bnc, proj._temperature, proj._group_size, proj._min_sigma_f, alpha, lmbda, weight,
                                      t_sink, defer_value, *params)
+
+
+class _DirectCtx:
+    """Stand-in for the autograd context when the engine runs the node's forward / backward itself (split capture)."""
+
+    needs_input_grad = (False,) * 64
+
+    def mark_non_differentiable(self, *a):
+        pass
+
+    def set_materialize_grads(self, v):
+        pass
+
+
+def sampler_step_direct(net, x_bnc, alpha, lmbda, weight, t_sink, grad_loss, after_fc):
+    """forward + backward of SamplerStepFunction without autograd, on the calling thread; every gradient must have a sink
+    (FlatGradAllReducer bucket).  after_fc() is invoked once the FC head's gradients have been enqueued."""
+    sink = getattr(net, "_grad_sink", None)
+    if sink is None or (net.project._temperature.requires_grad and t_sink is None):
+        raise RuntimeError("sampler_step_direct needs a gradient sink for every parameter (FlatGradAllReducer)")
+    sd = dict(net.named_parameters())
+    params = [sd[n] for n in pointnet.PARAM_ORDER]
+    proj = net.project
+    ctx = _DirectCtx()
+    prev = getattr(net, "_after_fc_grads", None)
+    net._after_fc_grads = after_fc
+    try:
+        with torch.no_grad():
+            loss, y, p = SamplerStepFunction.forward(ctx, net, x_bnc, proj._temperature, proj._group_size, proj._min_sigma_f, alpha,
+                                                     lmbda, weight, t_sink, True, *params)
+            SamplerStepFunction.backward(ctx, grad_loss)
+    finally:
+        net._after_fc_grads = prev
+    return loss, y, p

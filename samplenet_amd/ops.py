@@ -471,13 +471,13 @@ class SamplerStepLossFunction(torch.autograd.Function):
         return (gQ if ctx.needs_input_grad[0] else None), None, g_temp, None, None, None, None, None, None, None
 
 
-def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value, fold=False, keys=None):
+def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value, keys=None):
     """Forward launches of the sampler step's loss side (SamplerStepLossFunction / fused_step.SamplerStepFunction).
     x (B,N,3), y (B,3,M): the simplified cloud -- read when fc is None, otherwise WRITTEN by the pair scan from
     fc = (z3 (B,Kfc), coef3 (>=2*Kfc: scale | shift), W4 (3M,Kfc), b4 (3M)).  Caller holds the device guard.
-    -> loss (2,), proj (B,M,3), state = (idx, iq, ip, argmax1, (partial, loss) | (None, None)).
-    fold (needs N <= 2048; the backward must follow): only the pair scan runs here, the reduction and the loss value are
-    produced by the backward's launches (sn_sampler_step_loss_fold)."""
+    -> loss (2,), proj (B,M,3), state = (idx, iq, ip, argmax1, (partial, loss) | (None, None)[, keys-mode record]).
+    keys (needs N <= 2048; the backward must follow): zeroed (B*N) int64 table; only the pair scan runs here, the per-point
+    minima are combined in the table and the loss value is produced by the backward's launches (sn_sampler_step_loss_keys)."""
     B, _, M = y.shape
     N = x.shape[1]
     dev = y.device
@@ -519,9 +519,6 @@ def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight,
                                                  ptr(W4), ptr(b4), Kfc, ptr(y), ptr(idx), ptr(dq), ptr(iq), ptr(proj), BNC,
                                                  ptr(T), float(min_sigma), ptr(ws), ws.numel() * 8, st),
               "sn_pairscan_forward_partial_fc")
-    if fold:
-        # the per-cloud reduction runs inside the backward's first launch (sn_sampler_step_loss_fold): nothing more here
-        return loss, proj, (idx, iq, None, None, (partial, loss), (dq, ws, proj, G))
     check(lib.sn_sampler_step_loss_forward(B, M, N, G, ptr(dq), ptr(ws), ptr(proj), ptr(T), float(alpha), float(lmbda),
                                            float(weight), float(min_sigma), ptr(dp), ptr(ip), ptr(argmax1), ptr(partial),
                                            ptr(loss), 1 if defer_value else 0, st), "sn_sampler_step_loss_forward")
@@ -529,19 +526,7 @@ def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight,
     return loss, proj, (idx, iq, ip, argmax1, (partial, loss) if defer_value else (None, None))
 
 
-_TAIL_STREAMS = {}
-
-
-def tail_stream(device):
-    """Side stream (one per device) for launches that are off the step's critical path (sn_sampler_step_loss_keys)."""
-    st = _TAIL_STREAMS.get(device)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _TAIL_STREAMS[device] = st
-    return st
-
-
-def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, tail=None, deferred_tail=None):
+def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, deferred_tail=None):
     """Backward launches of the sampler step's loss side -> (grad_Q (B,3,M), grad_T (1,)).  Caller holds the device guard."""
     idx, iq, ip, argmax1, (dpart, dloss) = state[:5]
     K, min_sigma, alpha, lmbda, weight = cfg
@@ -557,17 +542,10 @@ def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, tail=No
         _, keys, qpart, qmax, G = state[5]
         check(lib.sn_sampler_step_loss_keys(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(keys), ptr(qpart), ptr(qmax), G,
                                             ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
-                                            ptr(dpart), ptr(dloss), _stream(y), tail.cuda_stream if tail is not None else None,
-                                            deferred_tail), "sn_sampler_step_loss_keys")
-        if tail is not None or deferred_tail is not None:
-            # the launch on the side stream still reads these: hand them to the caller, who drops them after the join
+                                            ptr(dpart), ptr(dloss), _stream(y), deferred_tail), "sn_sampler_step_loss_keys")
+        if deferred_tail is not None:
+            # the deferred launch (closing kernel of the conv backward) still reads these: the caller keeps them until then
             return gQ, gT, (gsig, gl, T)
-        return gQ, gT
-    if len(state) > 5:
-        dq, ws, proj, G = state[5]
-        check(lib.sn_sampler_step_loss_fold(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(dq), ptr(iq), ptr(ws), G, ptr(proj),
-                                            ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
-                                            ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_fold")
         return gQ, gT
     check(lib.sn_sampler_step_loss_backward(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(ip), ptr(argmax1),
                                             ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),

@@ -4,11 +4,13 @@ bucket all-reduced per step over RCCL/xGMI (torch.distributed backend "nccl" == 
 The reference has no distributed code at all; this is the new multi-GPU layer around the
 unmodified module surface.  Design for xGMI (point-to-point, 7 links x ~153 GB/s per GPU):
   * SampleNet has 249,793 fp32 parameters (~1 MB): the exchange is latency-bound, so all gradients
-    live in ONE flat buffer (param.grad are views into it) and the whole step costs exactly one
-    all-reduce -- no per-parameter collectives, no bucket-size tuning;
+    live in ONE flat buffer (param.grad are views into it) and the whole step costs at most two
+    collectives -- no per-parameter collectives, no bucket-size tuning;
   * the FC head's gradients (86 % of the bytes) are complete before the conv stack's backward
     starts: with `overlap=True` they are reduced on a side stream while the conv backward runs,
-    the conv gradients follow at the end (two collectives, the first one hidden).
+    the conv gradients follow at the end (two collectives, the first one hidden).  Under a captured
+    step (engine.SamplerTrainStep) the same split is made at graph level: graph 1 = forward .. FC
+    backward, graph 2 = conv backward, the first collective launched between them on the side stream;
   * BatchNorm uses per-rank batch statistics (each replica behaves exactly like the reference at its
     local batch size); SyncBatchNorm is not applied.
 """
@@ -19,16 +21,20 @@ import torch.distributed as dist
 class FlatGradAllReducer:
     """Keeps every parameter's .grad as a view into one flat fp32 buffer and averages it across ranks.
 
-    The MLP gradients are WRITTEN into the views by the HIP backward kernels themselves (module._grad_sink), so
-    there is no per-parameter accumulate / copy kernel; only the temperature goes through autograd's accumulate
-    and is zeroed by zero_grad().  Layout: [FC head | temperature | conv stack] -- the first segment is complete
-    before the conv stack's backward starts.
+    The MLP gradients are WRITTEN into the views by the HIP backward kernels themselves (module._grad_sink, a
+    pointnet.GradSink: overwrite on the first backward of a step, accumulate on further ones, views re-bound after
+    optimizer.zero_grad()), so there is no per-parameter accumulate / copy kernel; only the temperature goes through
+    autograd's accumulate.  Layout: [FC head | temperature | conv stack] -- the first segment is complete before the
+    conv stack's backward starts.
+
+    force_collective: issue the collectives even at world size 1 (single-GPU exercise of the RCCL path: tests, bench).
     """
 
-    def __init__(self, module, process_group=None, overlap=True):
+    def __init__(self, module, process_group=None, overlap=True, force_collective=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force_collective = bool(force_collective and dist.is_initialized())
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._early_avg = False
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
@@ -40,29 +46,36 @@ class FlatGradAllReducer:
         total = sum(p.numel() for _, p in order)
         dev = order[0][1].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        # the HIP MLP writes its gradients itself; anything else (the CPU model of the gloo test) goes through autograd
+        hip_mlp = bool(getattr(module, "use_hip_mlp", False)) and dev.type == "cuda"
         sink, off = {}, 0
-        self._autograd_slices = []
+        self._autograd = []  # (parameter, view): gradients that arrive through autograd's accumulate
         for n, p in order:
             view = self.flat[off:off + p.numel()].view_as(p)
             p.grad = view
-            if n.startswith("project"):
-                self._autograd_slices.append(view)
+            if n.startswith("project") or not hip_mlp:
+                self._autograd.append((p, view))
             else:
                 sink[n] = view
             off += p.numel()
-        if getattr(module, "use_hip_mlp", False):
-            module._grad_sink = sink
-        else:  # torch MLP: every gradient arrives through autograd's accumulate
-            self._autograd_slices = [self.flat]
-        self.overlap = bool(overlap and self.world > 1 and dev.type == "cuda" and getattr(module, "use_hip_mlp", False))
-        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        if sink:
+            from .pointnet import GradSink
+
+            params = dict(named)
+            module._grad_sink = GradSink(sink, {n: params[n] for n in sink})
+        self.overlap = bool(overlap and self.collective and dev.type == "cuda" and hip_mlp)
+        self._side = torch.cuda.Stream(device=dev) if (self.collective and dev.type == "cuda") else None
         self._early_work = None
         if self.overlap:
             module._after_fc_grads = self._early_ready
 
+    @property
+    def collective(self):
+        return self.world > 1 or self.force_collective
+
     def disable_overlap(self):
-        """Single collective per step (what a captured whole-step graph needs: the early all-reduce is issued from inside
-        backward, which the graph replays without Python)."""
+        """No collective from inside backward (a captured step replays backward without Python; the engine splits the
+        step into two graphs at the same point instead)."""
         if self._early_work is not None:
             self._early_work.wait()
             self._early_work = None
@@ -70,23 +83,54 @@ class FlatGradAllReducer:
         if getattr(self.module, "_after_fc_grads", None) is not None:
             self.module._after_fc_grads = None
 
-    def zero_grad(self):
-        for v in self._autograd_slices:
-            v.zero_()
+    def begin_step(self):
+        """The next backward overwrites the kernel-written views (no fill needed)."""
+        sink = getattr(self.module, "_grad_sink", None)
+        if sink is not None:
+            sink.reset()
 
-    def _early_ready(self):
-        if torch.cuda.is_current_stream_capturing():
-            return
+    def zero_grad(self):
+        """Start of a step: begin_step() + zero the autograd-accumulated slices.  optimizer.zero_grad() -- either flavour --
+        works too (pointnet.GradSink and _rebind() below take the views back); this is just the cheapest form."""
+        for _, v in self._autograd:
+            v.zero_()
+        self.begin_step()
+
+    def _rebind(self):
+        """Gradients autograd accumulated into tensors of its own (after zero_grad(set_to_none=True)) move into the bucket."""
+        for p, view in self._autograd:
+            g = p.grad
+            if g is None:
+                view.zero_()
+            elif g.data_ptr() == view.data_ptr():
+                continue
+            else:
+                view.copy_(g)
+            p.grad = view
+
+    # ---------------------------------------------------------------------------------------- collectives
+    def _op(self):
+        return dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+
+    def reduce_early_async(self):
+        """All-reduce of the FC-head segment on the side stream, ordered after everything enqueued on the current stream so
+        far; reduce() joins it.  (Eager backward calls this through module._after_fc_grads; the captured step between its
+        two graphs.)"""
         cur = torch.cuda.current_stream()
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             self._early_avg = self._avg
-            self._early_work = dist.all_reduce(self.flat[: self.n_early], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM,
-                                               group=self.group, async_op=True)
+            self._early_work = dist.all_reduce(self.flat[: self.n_early], op=self._op(), group=self.group, async_op=True)
+
+    def _early_ready(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        self.reduce_early_async()
 
     def reduce(self):
         """Call after backward(): on return (stream-ordered) every .grad holds the cross-rank mean."""
-        if self.world == 1:
+        self._rebind()
+        if not self.collective:
             return
         # RCCL averages inside the collective (ReduceOp.AVG): no separate scaling kernel; gloo (CPU tests) sums, then scales
         if self._early_work is not None:
@@ -94,7 +138,7 @@ class FlatGradAllReducer:
             self._early_work.wait()
             torch.cuda.current_stream().wait_stream(self._side)
             self._early_work = None
-            if not self._early_avg:
+            if not self._early_avg and self.world > 1:
                 self.flat[: self.n_early].mul_(1.0 / self.world)
         else:
             self._all_reduce_mean(self.flat)
@@ -107,7 +151,8 @@ class FlatGradAllReducer:
             except (RuntimeError, ValueError):  # a backend build without AVG: raised before anything is enqueued
                 self._avg = False
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        t.mul_(1.0 / self.world)
+        if self.world > 1:
+            t.mul_(1.0 / self.world)
 
 
 def shard_batch(x, rank, world):

@@ -6,8 +6,6 @@ Replaces the torch.nn call chain of registration/src/samplenet.py:90-104
 while the parameters stay ordinary nn.Conv1d / nn.BatchNorm1d / nn.Linear members of the module
 (state_dict compatibility).  Host side: buffer allocation and launch sequencing only.
 """
-import os
-
 import torch
 
 from ._lib import check, lib, ptr
@@ -49,6 +47,16 @@ def _linear_fwd(R, L, a_in, coef_prev, want_stats):
     return z, stats, nblk
 
 
+def _momentum(bn):
+    """torch.nn.BatchNorm semantics: momentum=None means a cumulative moving average, factor 1 / (num_batches_tracked + 1)
+    for this step (the kernels increment the counter themselves)."""
+    if bn.momentum is not None:
+        return float(bn.momentum)
+    if not bn.track_running_stats or bn.num_batches_tracked is None:
+        return 0.0
+    return 1.0 / (float(bn.num_batches_tracked.item()) + 1.0)  # (host read: not capturable; momentum=None is rare)
+
+
 def _layer_fwd_bn(R, L, a_in, coef_prev):
     """Training forward of a layer with BatchNorm: pre-BN output z and coef (scale, shift, mean, invstd); running
     statistics updated in place.  One launch when R <= 32 (finalisation fused), GEMM + bn_finalize otherwise."""
@@ -56,7 +64,7 @@ def _layer_fwd_bn(R, L, a_in, coef_prev):
     z = _empty((R, L.Co), a_in)
     coef = _empty((4, L.Co), a_in)
     stats = _empty((lib.sn_linear_stats_blocks(R), 2, L.Co), a_in)
-    mom = bn.momentum if bn.momentum is not None else 0.1
+    mom = _momentum(bn)
     upd = bn.track_running_stats
     check(lib.sn_layer_forward_bn(R, L.Ci, L.Co, ptr(a_in), ptr(coef_prev), ptr(L.W), ptr(L.b), ptr(z), ptr(stats),
                                   ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(mom),
@@ -74,7 +82,7 @@ def _layer_fwd_bn_pool(R, npts, L, a_in, coef_prev, pooled, argsel, zsel):
     stats = _empty((nblk, 2, L.Co), a_in)
     pool_val = _empty((nblk, 2, L.Co), a_in)
     pool_idx = _empty((nblk, 2, L.Co), a_in, torch.int32)
-    mom = bn.momentum if bn.momentum is not None else 0.1
+    mom = _momentum(bn)
     upd = bn.track_running_stats
     check(lib.sn_conv_forward_bn_pool(R, L.Ci, L.Co, npts, ptr(a_in), ptr(coef_prev), ptr(L.W), ptr(L.b), ptr(z), ptr(stats),
                                       ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(mom),
@@ -89,7 +97,7 @@ def _bn_coef(L, R, stats, nblk, training):
     C = L.Co
     coef = _empty((4, C), L.W)
     if training or not bn.track_running_stats:
-        mom = bn.momentum if bn.momentum is not None else 0.1
+        mom = _momentum(bn)
         upd = training and bn.track_running_stats
         check(lib.sn_bn_finalize(nblk, C, R, ptr(stats), ptr(bn.weight), ptr(bn.bias), float(bn.eps), float(mom),
                                  ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None,
@@ -152,7 +160,7 @@ def forward_impl(net, x_bnc, training, skip_last=False):
     convs, fcs = _layers(net)
     B, N, _ = x_bnc.shape
     R = B * N
-    saved = {"x": x_bnc, "B": B, "N": N, "zc": [], "cc": [], "zf": [], "cf": []}
+    saved = {"x": x_bnc, "B": B, "N": N, "zc": [], "cc": [], "zf": [], "cf": [], "training": bool(training)}
     use_batch_stats = training
     a_in, coef_prev = x_bnc.view(R, 3), None
     C5 = convs[-1].Co
@@ -194,6 +202,58 @@ def forward_impl(net, x_bnc, training, skip_last=False):
     return y, saved
 
 
+class GradSink(dict):
+    """name -> preallocated gradient tensor (views of a flat all-reduce bucket, parallel.FlatGradAllReducer) that the
+    backward kernels write into directly, with torch's .grad semantics kept intact:
+
+      * the first backward after reset() -- or after the parameters' .grad were set to None (optimizer.zero_grad(), whose
+        default is set_to_none=True) -- OVERWRITES the views: no zero fill, no accumulate kernel;
+      * any further backward before the next reset (two sampler forwards under one loss, registration/main.py:516-524;
+        gradient accumulation over micro-batches; a retained graph) ACCUMULATES: the kernels write fresh tensors that are
+        added to the views;
+      * afterwards every parameter's .grad IS its view again (re-bound if zero_grad() had dropped it), so optimizer.step()
+        sees the gradients and the bucket stays the single all-reduce operand.
+    """
+
+    def __init__(self, views, params):
+        super().__init__(views)
+        self.params = params  # name -> nn.Parameter
+        self.written = False
+
+    def reset(self):
+        self.written = False
+
+    def direct(self):
+        """True: this backward may write into the views (nothing to preserve in them)."""
+        return (not self.written) or all(self.params[n].grad is None for n in self)
+
+    def commit(self, fresh=None):
+        """After the kernels ran.  fresh: name -> gradient tensor when the backward could not write in place."""
+        for n, view in self.items():
+            p = self.params[n]
+            mine = p.grad is not None and p.grad.data_ptr() == view.data_ptr() and p.grad.shape == view.shape
+            if fresh is not None:
+                if p.grad is None:
+                    view.copy_(fresh[n])
+                elif mine:
+                    view.add_(fresh[n])
+                else:  # somebody assigned another tensor as .grad: fold it in, then take the slot back
+                    torch.add(p.grad, fresh[n], out=view)
+            elif p.grad is not None and not mine:
+                view.add_(p.grad)
+            if not mine:
+                p.grad = view
+        self.written = True
+
+
+def sink_for_backward(net):
+    """-> (sink the kernels may write into | None, GradSink to commit afterwards | None)."""
+    sink = getattr(net, "_grad_sink", None)
+    if sink is None:
+        return None, None
+    return (sink if sink.direct() else None), sink
+
+
 def _out(sink, name, like):
     """Gradient destination: the caller-provided sink tensor (e.g. a view of a flat all-reduce bucket) or a fresh one."""
     if sink is not None and name in sink:
@@ -201,47 +261,22 @@ def _out(sink, name, like):
     return torch.empty_like(like)
 
 
-_SIDE = {}
-# measured on MI355X / ROCm 7.2: inside a replayed hipGraph the fork/join edges cost more than the overlap buys
-# (0.73 vs 0.60 ms per step at B = 32), so the side stream is opt-in
-USE_SIDE_STREAM = os.environ.get("SAMPLENET_AMD_WGRAD_SIDE_STREAM", "0") != "0"
-FX_STATS = os.environ.get("SAMPLENET_AMD_FX_STATS", "1") != "0"  # fixed-point statistics chain in the conv stack
-IN3_CLOSED_FORM = os.environ.get("SAMPLENET_AMD_IN3_CLOSED_FORM", "1") != "0"
-FUSE_POOL = os.environ.get("SAMPLENET_AMD_FUSE_POOL", "1") != "0"  # A/B switch for the pooling fused into the last conv layer
-
-
-def _side_stream(dev):
-    """Second stream per device: a layer's weight-gradient GEMM is independent of its data-gradient GEMM, so the two
-    run concurrently (fork / join around the wgrad launch; under hipGraph capture this becomes a parallel branch)."""
-    s = _SIDE.get(dev)
-    if s is None:
-        s = _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return s
+# Test hooks (no environment switches; the defaults are the product path, False = the route shapes outside the fast paths'
+# support take anyway).  FX_STATS: conv stack as one call with BatchNorm statistics as fixed-point atomics; IN3_CLOSED_FORM:
+# conv1's weight gradient in closed form out of conv2's backward; FUSE_POOL: max-pool folded into the last conv layer.
+FX_STATS = True
+IN3_CLOSED_FORM = True
+FUSE_POOL = True
 
 
 def _wgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, aprev, coef_prev, with_bias, sink=None, name=""):
-    dev = L.W.device
-    main = torch.cuda.current_stream(dev)
     dW = _out(sink, name + ".weight", L.W)
     db = _out(sink, name + ".bias", L.b) if with_bias else None
     nsplit = lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 1 if with_bias else 0)
-    side = _side_stream(dev) if USE_SIDE_STREAM else main
-    if side is not main:
-        side.wait_stream(main)  # fork: everything enqueued so far (dy, kcoef, ...) is visible to the side stream
-    with torch.cuda.stream(side):
-        part = _empty((nsplit * L.Co * (L.Ci + (1 if with_bias else 0)),), L.W)
-        check(lib.sn_linear_wgrad(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(aprev),
-                                  ptr(coef_prev), ptr(part), ptr(dW), ptr(db), side.cuda_stream), "sn_linear_wgrad")
-    if side is not main:
-        for t in (dy, z, kcoef, gsel, argsel, aprev, coef_prev, dW, db):
-            if t is not None:
-                t.record_stream(side)  # allocated on the main stream, read / written on the side stream
+    part = _empty((nsplit * L.Co * (L.Ci + (1 if with_bias else 0)),), L.W)
+    check(lib.sn_linear_wgrad(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(aprev),
+                              ptr(coef_prev), ptr(part), ptr(dW), ptr(db), _st(L.W)), "sn_linear_wgrad")
     return dW, db
-
-
-def _join_side(dev):
-    if USE_SIDE_STREAM:
-        torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
 
 
 def _dgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev):
@@ -368,6 +403,10 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
     grads = {}
     grad_y = grad_y.contiguous()
     zf, cf, zc, cc = saved["zf"], saved["cf"], saved["zc"], saved["cc"]
+    # eval-mode forward (running statistics): every BatchNorm backward is dZ = scale * dY -- the kernels take "rows < 0" for
+    # that (no batch-statistics terms); the fixed-point / closed-form fast paths assume batch statistics and are skipped
+    fixed = not saved.get("training", True)
+    bn_rows = -1 if fixed else 0
 
     # ---- FC head (rows = B): fc4 -> fc3 -> fc2 -> fc1 -> pooled features ----
     dy, kcoef = grad_y, None
@@ -375,13 +414,13 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
         L = fcs[j]
         mode = DZ_PLAIN if j == 3 else DZ_BN
         if j > 0:
-            zprev, cprev, Lprev, bnp, linp, rows = zf[j - 1], cf[j - 1], fcs[j - 1], bn_f[j - 1], names_f[j - 1], 0
+            zprev, cprev, Lprev, bnp, linp, rows = zf[j - 1], cf[j - 1], fcs[j - 1], bn_f[j - 1], names_f[j - 1], bn_rows
         elif B > 32:  # the epilogue trick needs the register-resident (R <= 32) kernels: separate pooling backward below
             zprev, cprev, Lprev, bnp, linp, rows = saved["pooled"], None, None, None, None, 0
         else:
             # fc1 sits on the max-pool: its "previous layer" is conv5 seen through the selected points -- the ReLU mask and
             # BatchNorm-backward sums of the dgrad epilogue over zsel ARE the pooling backward (no separate launch)
-            zprev, cprev, Lprev, bnp, linp, rows = saved["zsel"], cc[4], convs[4], bn_c[4], names_c[4], R
+            zprev, cprev, Lprev, bnp, linp, rows = saved["zsel"], cc[4], convs[4], bn_c[4], names_c[4], (-1 if fixed else R)
         dW, db, dy, dg, dbt, dbs, kc = _layer_bwd(B, L, mode, dy, zf[j] if j < 3 else None, kcoef, None, None, 1, zprev, cprev,
                                                   Lprev, sink, names_f[j], bnp, linp, j == 3, rows)
         grads[names_f[j] + ".weight"] = dW
@@ -392,7 +431,6 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
         kcoef = kc
     gsel = dy  # (B, C5): gradient at the selected (max-pooled) points, already masked; kcoef = conv5's BatchNorm backward
     if after_fc is not None:
-        _join_side(grad_y.device)
         after_fc()
     if B > 32:  # dy is the gradient w.r.t. the pooled features: max-pool + conv5's BatchNorm backward in their own launch
         C5, L5, g_pool = convs[4].Co, convs[4], dy
@@ -400,18 +438,17 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
         dgamma, dbeta = _out(sink, bn_c[4] + ".weight", L5.bn.weight), _out(sink, bn_c[4] + ".bias", L5.bn.bias)
         dbias = _out(sink, names_c[4] + ".bias", L5.b)
         kcoef = _empty((3, C5), grad_y)
-        check(lib.sn_pool_backward_bn(B, C5, R, ptr(g_pool), ptr(saved["pooled"]), ptr(saved["zsel"]), ptr(gsel), ptr(cc[4]),
+        check(lib.sn_pool_backward_bn(B, C5, -1 if fixed else R, ptr(g_pool), ptr(saved["pooled"]), ptr(saved["zsel"]), ptr(gsel), ptr(cc[4]),
                                       ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(kcoef), _st(grad_y)), "sn_pool_backward_bn")
         grads[bn_c[4] + ".weight"], grads[bn_c[4] + ".bias"], grads[names_c[4] + ".bias"] = dgamma, dbeta, dbias
 
     # ---- conv stack (rows = B*N): conv5 -> ... -> conv2 (each also finishes the BatchNorm of the layer below), conv1 ----
-    if FX_STATS and IN3_CLOSED_FORM and _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef, sink, grads, names_c, bn_c, step_tail):
-        _join_side(grad_y.device)
+    if not fixed and FX_STATS and IN3_CLOSED_FORM and _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef, sink, grads, names_c, bn_c, step_tail):
         return grads
     if step_tail is not None:
         raise RuntimeError("backward_impl: a deferred step tail needs the one-call conv stack backward (conv_stack_backward_supported)")
     dy = None
-    in3_floats = lib.sn_layer_backward_in3_stats_floats(R, convs[1].Ci, convs[1].Co) if (IN3_CLOSED_FORM and convs[0].Ci == 3) else 0
+    in3_floats = lib.sn_layer_backward_in3_stats_floats(R, convs[1].Ci, convs[1].Co) if (IN3_CLOSED_FORM and convs[0].Ci == 3 and not fixed) else 0
     for i in (4, 3, 2, 1):
         L = convs[i]
         if i == 1 and in3_floats > 0:
@@ -434,14 +471,13 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
         mode = DZ_POOL if i == 4 else DZ_BN
         gs, ag = (gsel, saved["argsel"]) if i == 4 else (None, None)
         dW, _, dy, dg, dbt, dbs, kc = _layer_bwd(R, L, mode, dy, zc[i], kcoef, gs, ag, N, zc[i - 1], cc[i - 1], convs[i - 1],
-                                                 sink, names_c[i], bn_c[i - 1], names_c[i - 1], False)
+                                                 sink, names_c[i], bn_c[i - 1], names_c[i - 1], False, bn_rows)
         grads[names_c[i] + ".weight"] = dW
         grads[bn_c[i - 1] + ".weight"], grads[bn_c[i - 1] + ".bias"], grads[names_c[i - 1] + ".bias"] = dg, dbt, dbs
         kcoef = kc
     else:
         dW, _ = _wgrad(R, convs[0], DZ_BN, dy, zc[0], kcoef, None, None, N, saved["x"].view(R, 3), None, False, sink, names_c[0])
         grads[names_c[0] + ".weight"] = dW
-    _join_side(grad_y.device)  # all weight gradients complete before backward returns on the main stream
     return grads
 
 
@@ -466,12 +502,14 @@ class PointNetMLPFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_y):
         net = ctx.net
-        sink = getattr(net, "_grad_sink", None)
+        sink, owner = sink_for_backward(net)
         with torch.cuda.device(grad_y.device):
-            grads = backward_impl(net, ctx.saved, grad_y, sink, getattr(net, "_after_fc_grads", None))
+            grads = backward_impl(net, ctx.saved, grad_y, sink, getattr(net, "_after_fc_grads", None) if sink is not None else None)
+            if owner is not None:
+                owner.commit(None if sink is not None else grads)
         # (ctx.saved stays: a retained graph may run backward again)
-        # gradients written straight into a sink are not handed to autograd (nothing left to accumulate)
-        return (None, None, None) + tuple(None if (sink is not None and n in sink) else grads[n] for n in PARAM_ORDER)
+        # gradients that went into the sink are not handed to autograd (nothing left to accumulate)
+        return (None, None, None) + tuple(None if (owner is not None and n in owner) else grads[n] for n in PARAM_ORDER)
 
 
 def pointnet_head(net, x_bnc):

@@ -9,15 +9,14 @@ What changes underneath (MI355X-native):
     instead of recomputing the distance matrix (the reference computes it three times);
   * ChamferDistance / SoftProjection / kNN run on libsamplenet_hip.so (no third-party knn_cuda /
     pointnet2 packages, no JIT-compiled extension);
-  * the PointNet feature extractor runs through samplenet_amd.pointnet (hand-written MFMA kernels)
-    when enabled, else through torch.nn (identical parameters either way).
+  * the PointNet feature extractor runs through samplenet_amd.pointnet (hand-written fp32 MFMA kernels); the
+    parameters stay ordinary nn.Conv1d / nn.BatchNorm1d / nn.Linear members, so checkpoints are interchangeable.
 """
 import warnings
 
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops, pointnet, sputils
 from .chamfer_distance import ChamferDistance
@@ -37,12 +36,9 @@ class SampleNet(nn.Module):
         output_shape="bcn",
         complete_fps=True,
         skip_projection=False,
-        use_hip_mlp=True,
     ):
         super().__init__()
-        # use_hip_mlp=False routes the feature extractor through torch.nn (MIOpen / rocBLAS); it exists for
-        # A/B parity tests of the hand-written MFMA kernels -- the geometric ops are on HIP either way.
-        self.use_hip_mlp = use_hip_mlp
+        self.use_hip_mlp = True  # the feature extractor runs on the hand-written MFMA kernels (there is no other route here)
         self.num_out_points = num_out_points
         self.name = "samplenet"
 
@@ -78,19 +74,9 @@ class SampleNet(nn.Module):
     # ------------------------------------------------------------------------------------------ MLP
     def _features(self, x, x_bnc=None):
         """PointNet feature extractor + FC head: x (B,3,N) -> y (B,3,M)   (samplenet.py:90-104)."""
-        if self.use_hip_mlp:
-            if x_bnc is None:
-                x_bnc = x.permute(0, 2, 1)
-            return pointnet.pointnet_head(self, x_bnc)
-        # torch.nn route (A/B reference for the HIP kernels): conv/bn/relu x5, max over the points, fc/bn/relu x3, fc
-        y = x
-        for i in range(1, 6):
-            y = F.relu(getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(y)))
-        y = y.max(dim=2).values  # (B, bottleneck)
-        for i in range(1, 4):
-            y = F.relu(getattr(self, "bn_fc%d" % i)(getattr(self, "fc%d" % i)(y)))
-        y = self.fc4(y)
-        return y.view(-1, 3, self.num_out_points)
+        if x_bnc is None:
+            x_bnc = x.permute(0, 2, 1)
+        return pointnet.pointnet_head(self, x_bnc)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor):

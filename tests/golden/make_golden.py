@@ -51,7 +51,13 @@ def install_shims():
         def __call__(self, ref, query):
             if not self.t:
                 ref, query = ref.permute(0, 2, 1), query.permute(0, 2, 1)
-            d, i = O.knn(self.k, ref.detach().contiguous().numpy(), query.detach().contiguous().numpy())
+            if ref.dtype == torch.float64:  # the fp64 "exact" run of golden_samplenet_c2: same (distance, index) order
+                r, q = ref.detach().numpy(), query.detach().numpy()
+                dd = ((q[:, :, None, :] - r[:, None, :, :]) ** 2).sum(-1)  # (B,M,N)
+                i = np.argsort(dd, axis=2, kind="stable")[:, :, :self.k]
+                d = np.take_along_axis(dd, i, 2)
+            else:
+                d, i = O.knn(self.k, ref.detach().contiguous().numpy(), query.detach().contiguous().numpy())
             d = torch.from_numpy(np.sqrt(d))
             i = torch.from_numpy(i.astype(np.int64))
             if not self.t:
@@ -99,6 +105,9 @@ def install_shims():
 
     class ChamferDistance(torch.nn.Module):
         def forward(self, xyz1, xyz2):
+            if xyz1.dtype == torch.float64:  # fp64 "exact" run only: the same minima through plain torch + autograd
+                dd = ((xyz1[:, :, None, :] - xyz2[:, None, :, :]) ** 2).sum(-1)
+                return dd.min(2)[0], dd.min(1)[0]
             d1, d2, self.last_idx1, self.last_idx2 = ChamferDistanceFunction.apply(xyz1, xyz2)
             return d1, d2
 
@@ -247,6 +256,92 @@ def golden_samplenet(SampleNet):
     save("samplenet_reference.npz", **out)
 
 
+def _c2_case(SampleNet, B, N, M, K, perturb, seed):
+    """One C2 step through the reference module in fp32 and fp64 -> (results per precision, fixture arrays of the fp32 run)."""
+    res, out = {}, {}
+    for prec in ("f32", "f64"):
+        torch.manual_seed(0)
+        net = SampleNet(M, 128, group_size=K, initial_temperature=1.0, is_temperature_trainable=True,
+                        min_sigma=1e-2, input_shape="bnc", output_shape="bnc")
+        x = torch.rand(B, N, 3) - 0.5
+        if perturb:
+            torch.manual_seed(100 + seed)
+            with torch.no_grad():
+                for nme, p in net.named_parameters():
+                    if "bn" in nme:
+                        p.add_(0.1 * torch.randn_like(p))
+                net.project._temperature.fill_(0.3)
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        if prec == "f64":
+            net = net.double()
+            net.project._min_sigma = net.project._min_sigma.double()
+            x = x.double()
+        net.train()
+        simp, proj = net(x)
+        lsimp = net.get_simplification_loss(x, simp, M, 1.0, 0.0)
+        lproj = net.get_projection_loss()
+        loss = 0.01 * lsimp + 0.01 * lproj + proj.mean()
+        loss.backward()
+        res[prec] = dict(simp=simp, proj=proj, lsimp=lsimp, lproj=lproj, loss=loss,
+                         grads={k: p.grad for k, p in net.named_parameters()})
+        if prec == "f32":
+            for k, v in sd0.items():
+                out["sd_" + k] = v.numpy()
+            out["x"] = x.numpy()
+            out["cfg"] = np.array([B, N, M, K, 128, 0])
+            for k, v in net.state_dict().items():
+                if "running" in k:
+                    out["sd1_" + k] = v.numpy()
+    return res, out
+
+
+def golden_samplenet_c2(SampleNet):
+    """Config C2 = BASELINE configs[1], the headline workload (B=32, 1024 -> 64): the sampler's training step exactly as
+    bench.py times it -- L = 0.01 * L_simp(gamma=1, delta=0) + 0.01 * L_proj + mean(proj), default torch init under seed 0,
+    T = 1 -- for K = 8 (registration default) and K = 7 (classification default, train_samplenet.py:46; BatchNorm affine
+    parameters and the temperature moved off their trivial initial values).  Each case is run twice through the reference
+    module: in fp32 (the reference as users run it) and in fp64 (same weights and input cast up: the exact answer that both
+    the reference's fp32 run and the HIP path approximate; kNN / Chamfer shims switch to plain fp64 numpy / torch there).
+    Stored: input, initial state_dict (shared by both cases where equal), simp / proj / losses / every gradient, fp32 + fp64."""
+    out = {}
+    for tag, (B, N, M, K, perturb) in {"k8": (32, 1024, 64, 8, False), "k7": (32, 1024, 64, 7, True)}.items():
+        # A fixture must not sit on a discontinuity of the step (a ReLU input or max-pool pair within rounding of a tie, a
+        # neighbour swap): there the reference's OWN fp32 and fp64 runs disagree by ~1e-2 in the gradients and nothing can
+        # be pinned.  The perturbation seed is therefore advanced until they agree to 3e-4 (recorded in <tag>_seed).
+        for seed in range(16):
+            res, tmp = _c2_case(SampleNet, B, N, M, K, perturb, seed)
+            g32 = np.concatenate([v.numpy().ravel() for v in res["f32"]["grads"].values()]).astype(np.float64)
+            g64 = np.concatenate([v.numpy().ravel() for v in res["f64"]["grads"].values()])
+            gap = np.linalg.norm(g32 - g64) / np.linalg.norm(g64)
+            print(tag, "seed", seed, "reference fp32 vs fp64 gradient gap %.3g" % gap)
+            if gap < 3e-4:
+                break
+        else:
+            raise RuntimeError("no well-conditioned fixture found")
+        for k, v in tmp.items():
+            if k.startswith("sd_"):
+                if tag == "k8" or not np.array_equal(v, out["k8_" + k]):
+                    out[f"{tag}_{k}"] = v
+            else:
+                out[f"{tag}_{k}"] = v
+        out[f"{tag}_seed"] = np.array(seed)
+        for prec, r in res.items():
+            sfx = "" if prec == "f32" else "_f64"
+            for k in ("simp", "proj", "lsimp", "lproj", "loss"):
+                v = r[k].detach().numpy()
+                out[f"{tag}_{k}{sfx}"] = v if v.ndim == 0 else v.astype(np.float32)  # (fp64 scalars stay fp64)
+            for k, gr in r["grads"].items():
+                out[f"{tag}_grad{sfx}_{k}"] = gr.numpy().astype(np.float32)
+        # how far the reference's own fp32 run is from exact arithmetic -- printed for the record (the tests recompute it)
+        g32 = np.concatenate([v.numpy().ravel() for v in res["f32"]["grads"].values()]).astype(np.float64)
+        g64 = np.concatenate([v.numpy().ravel() for v in res["f64"]["grads"].values()])
+        print(tag, "reference fp32 vs fp64: simp max|d| %.3g  loss |d| %.3g  grad rel %.3g" % (
+            np.abs(res["f32"]["simp"].detach().numpy() - res["f64"]["simp"].detach().numpy()).max(),
+            abs(float(res["f32"]["loss"]) - float(res["f64"]["loss"])), np.linalg.norm(g32 - g64) / np.linalg.norm(g64)))
+    np.savez_compressed(os.path.join(HERE, "samplenet_c2_reference.npz"), **out)
+    print("wrote tests/golden/samplenet_c2_reference.npz (%d arrays)" % len(out))
+
+
 def golden_nn_matching(sputils):
     rng = np.random.default_rng(3)
     B, N, k = 3, 200, 32
@@ -294,11 +389,11 @@ if __name__ == "__main__":
     sp_mod = importlib.import_module("src.soft_projection")
     sn_mod = importlib.import_module("src.samplenet")
     sputils = importlib.import_module("src.sputils")
-    golden_known_answers()
-    golden_softproj(sp_mod.SoftProjection)
-    golden_chamfer(ChamferDistance)
-    golden_samplenet(sn_mod.SampleNet)
-    golden_nn_matching(sputils)
-    golden_pcrnet(ChamferDistance)
+    jobs = {"known": golden_known_answers, "softproj": lambda: golden_softproj(sp_mod.SoftProjection),
+            "chamfer": lambda: golden_chamfer(ChamferDistance), "samplenet": lambda: golden_samplenet(sn_mod.SampleNet),
+            "c2": lambda: golden_samplenet_c2(sn_mod.SampleNet), "nn_matching": lambda: golden_nn_matching(sputils),
+            "pcrnet": lambda: golden_pcrnet(ChamferDistance)}
+    for name in (sys.argv[1:] or list(jobs)):  # python make_golden.py [job ...]   (default: all)
+        jobs[name]()
     left = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc") or f == "__pycache__"]
     assert not left, "bytecode leaked into the reference tree: %s" % left[:3]

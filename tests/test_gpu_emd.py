@@ -38,6 +38,32 @@ def test_emd_matches_oracle(oracle, shape):
     np.testing.assert_allclose(g2.cpu().numpy(), og2 * gc[:, None, None], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("b", [2])
+def test_emd_config4_size_matches_oracle(oracle, b):
+    """BASELINE configs[3] / SURVEY C4: n = m = 2048 (reconstruction/src/samplenet_pointnet_ae.py:129-131 calls
+    approx_match / match_cost on 2048-point clouds) against the oracle's sequential restatement of tf_approxmatch_g.cu:1-295:
+    match per entry, cost, both gradients.  Clouds as in the reference's own harness (uniform(0,1), approxmatch.cpp:131-144)."""
+    from samplenet_amd import ops
+
+    n = m = 2048
+    rng = np.random.default_rng(2048)
+    x1 = rng.random((b, n, 3), dtype=np.float32)
+    x2 = rng.random((b, m, 3), dtype=np.float32)
+    om = oracle.approxmatch(x1, x2)
+    t1, t2 = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
+    match = ops.approx_match(t1, t2)
+    mh = match.cpu().numpy()
+    np.testing.assert_allclose(mh, om, rtol=0, atol=5e-4)
+    assert np.mean(np.abs(mh - om)) < 1e-7
+    cost = ops.match_cost(t1, t2, match)
+    np.testing.assert_allclose(cost.detach().cpu().numpy(), oracle.matchcost(x1, x2, mh), rtol=1e-5)
+    np.testing.assert_allclose(cost.detach().cpu().numpy(), oracle.matchcost(x1, x2, om), rtol=1e-5)
+    g1, g2 = torch.autograd.grad(cost.sum(), [t1, t2])
+    og1, og2 = oracle.matchcost_grad(x1, x2, mh)
+    np.testing.assert_allclose(g1.cpu().numpy(), og1, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(g2.cpu().numpy(), og2, rtol=1e-4, atol=1e-5)
+
+
 def test_emd_full_size_properties():
     """Config 4 size (n = m = 2048): transport-plan marginals -- every xyz1 point ships mass 1, every xyz2 point
     receives n/m -- and permutation equivariance of the cost."""

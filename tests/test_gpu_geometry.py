@@ -191,7 +191,11 @@ def test_grouping_operation_and_grad(oracle):
 
 # ------------------------------------------------------------------------------------------ SoftProjection
 @pytest.mark.parametrize("cfg", [(4, 1024, 64, 8, 1.0), (2, 1024, 64, 7, 0.3), (2, 2048, 64, 16, 0.05), (1, 33, 7, 16, 1.0),
-                                 (3, 200, 24, 1, 0.5)])
+                                 (3, 200, 24, 1, 0.5),
+                                 # the progressive sampler's output sizes at N = 1024
+                                 (2, 1024, 256, 8, 1.0), (2, 1024, 128, 8, 0.3), (3, 1024, 32, 8, 1.0), (32, 1024, 256, 7, 0.1),
+                                 # C4's sampler shape: 2048 -> 64, K = 16 at a full batch of 50
+                                 (50, 2048, 64, 16, 1.0)])
 def test_soft_project_fused_vs_oracle(oracle, cfg):
     from samplenet_amd import ops
 

@@ -1,0 +1,164 @@
+"""The headline workload (BASELINE configs[1] = SURVEY C2: B=32, 1024 -> 64, K=8 and K=7) against the REFERENCE module.
+
+tests/golden/samplenet_c2_reference.npz holds the sampler's training step exactly as bench.py times it
+    L = 0.01 * L_simp(gamma=1, delta=0) + 0.01 * L_proj + mean(proj)
+run through registration/src/samplenet.py on CPU twice: in fp32 (the reference as it is used) and in fp64 (same weights
+and input cast up -- the exact answer both fp32 implementations approximate).  Here the same step runs through the path
+bench.py measures -- engine.SamplerTrainStep on an input ring: fused_step.SamplerStepFunction (fc4 inside the pair scan,
+per-point minima as atomically combined keys, loss tail inside the conv backward's closing kernel), gradients written
+into the flat all-reduce bucket, replayed as a hipGraph -- and, for comparison, through the plain module surface.
+
+Bars.  Integer / index work is bit-exact against the oracle on the simplified cloud the step produced; the geometric
+floating-point results on that cloud are within 1e-6.  Against the reference RUN the simplified cloud itself differs
+by the summation order of ~450 fp32 dot products per output through 8 BatchNorms (the reference's own fp32 run sits
+1.5e-5 from exact arithmetic), so every comparison is made twice: against the reference's fp32 outputs with a fixed bar,
+and against the fp64 outputs with the bar "no further from exact than a small multiple of the reference's own fp32 error".
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ALPHA, LMBDA, GAMMA, DELTA = 0.01, 0.01, 1.0, 0.0
+
+
+def _net(g, tag):
+    from samplenet_amd import SampleNet
+
+    B, N, M, K, bneck, _ = [int(v) for v in g[f"{tag}_cfg"]]
+    net = SampleNet(M, bneck, group_size=K, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-2,
+                    input_shape="bnc", output_shape="bnc")
+    sd = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("k8_sd_")}
+    sd.update({k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}_sd_")})  # entries that differ
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return net.cuda().train(), (B, N, M, K)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b)), float(np.linalg.norm(b))
+
+
+def _selection_flips(oracle, xn, simp_a, simp_b, K):
+    """How many discrete selections differ between two simplified clouds (B,M,3) against the same input cloud."""
+    _, ka = oracle.knn(K, xn, np.ascontiguousarray(simp_a))
+    _, kb = oracle.knn(K, xn, np.ascontiguousarray(simp_b))
+    a1, ai1, a2, ai2 = oracle.chamfer_forward(np.ascontiguousarray(simp_a), xn)
+    b1, bi1, b2, bi2 = oracle.chamfer_forward(np.ascontiguousarray(simp_b), xn)
+    return {"knn": int((np.sort(ka, 2) != np.sort(kb, 2)).any(2).sum()), "idx1": int((ai1 != bi1).sum()),
+            "idx2": int((ai2 != bi2).sum()), "argmax": int((a1.argmax(1) != b1.argmax(1)).sum())}
+
+
+def _check_against_reference(g, tag, oracle, x, y_bcn, proj_bmc, loss, lsimp, grads, K, M, sigma):
+    """Shared assertions: (simp, proj, loss, every gradient) of one HIP step vs the golden fp32 / fp64 reference runs."""
+    simp = y_bcn.permute(0, 2, 1).contiguous().cpu().numpy()  # (B,M,3) as the reference returns it
+    ref32, ref64 = g[f"{tag}_simp"], g[f"{tag}_simp_f64"]
+    ref_err = np.abs(ref32.astype(np.float64) - ref64).max()
+    e_simp32, e_simp64 = np.abs(simp - ref32).max(), np.abs(simp - ref64).max()
+    print("\n[%s] simp max|d|: vs ref fp32 %.2e, vs fp64 %.2e (reference fp32 vs fp64 %.2e)" % (tag, e_simp32, e_simp64, ref_err))
+    print("[%s] loss %.9f  ref fp32 %.9f  fp64 %.9f" % (tag, float(loss), float(g[f"{tag}_loss"]), float(g[f"{tag}_loss_f64"])))
+    if lsimp is not None:
+        print("[%s] lsimp %.8f  ref fp32 %.8f  fp64 %.8f" % (tag, float(lsimp), float(g[f"{tag}_lsimp"]), float(g[f"{tag}_lsimp_f64"])))
+    # measured 2.0e-5 / 1.3e-5: the HIP head is as close to exact arithmetic as the reference's own fp32 (MKL) run
+    assert e_simp32 <= 5e-5 and e_simp64 <= 2 * ref_err + 5e-6
+    # discrete selections of the geometry (kNN sets, both Chamfer argmins, the arg-max of the max term) on OUR simplified cloud
+    # vs on the reference's: a 1e-5 shift of a query flips a handful of near-ties; each flip re-routes a gradient contribution
+    # (the max term carries 1/B of the loss on ONE point), which is what bounds the gradient agreement below
+    xn = x.cpu().numpy()
+    flips = _selection_flips(oracle, xn, simp, ref32, K)
+    print("[%s] selection flips vs the reference's simplified cloud: %s" % (tag, flips))
+    assert flips["knn"] <= 12 and flips["idx1"] <= 2 and flips["idx2"] <= 40 and flips["argmax"] <= 1
+    # the geometry of THIS simplified cloud, restated by the oracle: indices bit-exact, projection / loss 1e-6
+    _, oidx = oracle.knn(K, xn, simp)
+    oproj, _, _ = oracle.softproj_forward(xn.transpose(0, 2, 1), simp.transpose(0, 2, 1), oidx, sigma)
+    np.testing.assert_allclose(proj_bmc.cpu().numpy(), oproj.transpose(0, 2, 1), rtol=0, atol=1e-6)
+    od1, _, od2, _ = oracle.chamfer_forward(simp, xn)
+    olsimp = od1.mean(dtype=np.float64) + od1.max(1).mean(dtype=np.float64) + (GAMMA + DELTA * M) * od2.mean(dtype=np.float64)
+    oloss = ALPHA * olsimp + LMBDA * sigma + oproj.mean(dtype=np.float64)
+    assert abs(float(loss) - oloss) <= 1e-6 * max(1.0, abs(oloss))
+    if lsimp is not None:
+        assert abs(float(lsimp) - olsimp) <= 1e-6 * max(1.0, abs(olsimp))
+        assert abs(float(lsimp) - float(g[f"{tag}_lsimp"])) <= 1e-5 * float(g[f"{tag}_lsimp"])
+    # against the reference run: north_star's 1e-5 on the loss
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) <= 1e-5 * max(1.0, abs(float(g[f"{tag}_loss"])))
+    assert abs(float(loss) - float(g[f"{tag}_loss_f64"])) <= 1e-5
+    # projected cloud against the reference run: a 1e-5 shift of a query can swap its K-th / (K+1)-th neighbour, where the
+    # projection is discontinuous -- all but a handful of the 6144 coordinates agree to 1e-4
+    close = np.isclose(proj_bmc.cpu().numpy(), g[f"{tag}_proj"], rtol=0, atol=1e-4)
+    assert close.mean() >= 0.995, close.mean()
+    # gradients: per tensor, relative to its norm.  Biases in front of a BatchNorm have zero true gradient (1e-15 in fp64):
+    # both sides hold rounding noise there.
+    gmax = max(np.linalg.norm(g[k].astype(np.float64)) for k in g.files if k.startswith(f"{tag}_grad_f64_"))
+    bad, worst = [], (0.0, "")
+    for name, got in grads.items():
+        r32 = g[f"{tag}_grad_{name}"].astype(np.float64)
+        r64 = g[f"{tag}_grad_f64_{name}"].astype(np.float64)
+        got = got.detach().cpu().numpy().astype(np.float64)
+        n64 = np.linalg.norm(r64)
+        if n64 < 1e-9 * gmax:
+            if np.linalg.norm(got) > 1e-5 * gmax:
+                bad.append((name, "zero-gradient bias", np.linalg.norm(got)))
+            continue
+        e32, e64 = np.linalg.norm(got - r32), np.linalg.norm(got - r64)
+        eref = np.linalg.norm(r32 - r64)  # the reference's own fp32 error
+        worst = max(worst, (e64 / n64, name))
+        # fixed bar against the fp32 reference run.  No selection flips (K=8 fixture): measured 1-3e-5 on the bench path, 9e-5
+        # through the module surface -> 3e-4.  With flips (K=7 fixture: the arg-max of the max term or a Chamfer argmin lands
+        # on another point; the REFERENCE's own fp32 and fp64 runs differ by 5e-3 for the same reason): measured 1.4e-2 -> 3e-2.
+        clean = flips["knn"] + flips["idx1"] + flips["argmax"] == 0  # (an idx2 flip moves 1/(B*N) of the loss: negligible)
+        bar32 = 3e-4 if clean else 3e-2
+        print("[%s] grad %-22s vs ref fp32 %.2e  vs fp64 %.2e  (reference fp32 vs fp64 %.2e)" % (tag, name, e32 / n64, e64 / n64, eref / n64))
+        if e32 > bar32 * n64 or e64 > max(4 * eref, bar32 * n64):
+            bad.append((name, e32 / n64, e64 / n64, eref / n64))
+    assert not bad, bad
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["k8", "k7"])
+def test_bench_path_matches_reference_c2(golden, oracle, tag):
+    """bench.py's own execution path (graph replay of the fused step on an input ring, gradients in the flat bucket)."""
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    g = golden("samplenet_c2_reference.npz")
+    net, (B, N, M, K) = _net(g, tag)
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    ring = [x.clone(), (torch.rand_like(x) - 0.5)]
+    red = FlatGradAllReducer(net)
+    step = SamplerTrainStep(net, ring[0], alpha=ALPHA, lmbda=LMBDA, gamma=GAMMA, delta=DELTA, reducer=red, use_graph=True,
+                            input_ring=ring)
+    assert step._fast_path() and step._ring_graphs, "this test must exercise the path bench.py times"
+    step.replay(1)           # another batch in between: the replay of entry 0 must not depend on what ran before
+    loss = step.replay(0)
+    torch.cuda.synchronize()
+    y, proj = step.outputs
+    grads = {n: p.grad for n, p in net.named_parameters()}
+    assert all(gr is not None and gr.untyped_storage().data_ptr() == red.flat.untyped_storage().data_ptr() for gr in grads.values())
+    sigma = float(net.project.sigma())
+    worst = _check_against_reference(g, tag, oracle, x, y, proj, loss, None, grads, K, M, sigma)
+    print("bench path %s: worst gradient error vs fp64 %.2e (%s)" % (tag, worst[0], worst[1]))
+    # BatchNorm running statistics: warm-up (3) + capture (0 executions) + 2 replays moved them; one more step from the golden's
+    # state is checked by the module-surface test below
+
+
+@pytest.mark.parametrize("tag", ["k8", "k7"])
+def test_module_surface_matches_reference_c2(golden, oracle, tag):
+    """The same step through the drop-in module surface (forward + get_simplification_loss + get_projection_loss +
+    autograd), as registration/main.py:507-531 issues it."""
+    g = golden("samplenet_c2_reference.npz")
+    net, (B, N, M, K) = _net(g, tag)
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    simp, proj = net(x)
+    lsimp = net.get_simplification_loss(x, simp, M, GAMMA, DELTA)
+    lproj = net.get_projection_loss()
+    loss = ALPHA * lsimp + LMBDA * lproj + proj.mean()
+    loss.backward()
+    assert abs(float(lproj.detach()) - float(g[f"{tag}_lproj"])) <= 1e-7
+    grads = {n: p.grad for n, p in net.named_parameters()}
+    _check_against_reference(g, tag, oracle, x, simp.detach().permute(0, 2, 1), proj.detach(), loss.detach(), lsimp.detach(),
+                             grads, K, M, float(lproj.detach()))
+    for k in g.files:  # BatchNorm running statistics after exactly one training step
+        if k.startswith(f"{tag}_sd1_"):
+            np.testing.assert_allclose(net.state_dict()[k[len(tag) + 5:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6)

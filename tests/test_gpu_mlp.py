@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from torch_mlp import torch_mlp_copy
+
 pytestmark = pytest.mark.gpu
 
 
@@ -14,15 +16,14 @@ def _pair(B, N, M, K, bneck, shape, seed=0):
     from samplenet_amd import SampleNet
 
     torch.manual_seed(seed)
-    hip = SampleNet(M, bneck, group_size=K, input_shape=shape, output_shape=shape, use_hip_mlp=True).cuda()
+    hip = SampleNet(M, bneck, group_size=K, input_shape=shape, output_shape=shape).cuda()
     with torch.no_grad():
         for n, p in hip.named_parameters():
             if "bn" in n:
                 p.add_(0.2 * torch.randn_like(p))
         hip.bn3.weight[:5] *= -1.0  # negative BatchNorm scale: the fused max-pool must then select the minimum
         hip.bn5.weight[:7] *= -1.0
-    ref = copy.deepcopy(hip)
-    ref.use_hip_mlp = False
+    ref = torch_mlp_copy(hip)
     x = torch.rand(B, N, 3, device="cuda") - 0.5
     if shape == "bcn":
         x = x.permute(0, 2, 1).contiguous()

@@ -1,0 +1,81 @@
+"""The RCCL path on ONE GPU (SURVEY 8e "test without a cluster"): torch.distributed backend "nccl" (= RCCL on ROCm) with
+world_size 1 and FlatGradAllReducer(force_collective=True), so that all_reduce(AVG) really is issued on the flat gradient
+bucket -- eager with the early (FC-head) collective on the side stream, and under the captured step, both as one graph +
+one collective and as the split pair of graphs with the first collective between them.  With one rank AVG is the identity:
+every variant must leave exactly the gradients of the collective-free step."""
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rccl():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+
+
+def _nets(n):
+    from samplenet_amd import SampleNet
+
+    torch.manual_seed(0)
+    net = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    return [net] + [copy.deepcopy(net) for _ in range(n - 1)]
+
+
+def test_eager_step_with_collectives(rccl):
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    na, nb, nc = _nets(3)
+    x = torch.rand(32, 1024, 3, device="cuda") - 0.5
+    ra = FlatGradAllReducer(na)                                         # no collective at world size 1
+    rb = FlatGradAllReducer(nb, force_collective=True, overlap=True)    # FC-head bucket early on the side stream + the rest
+    rc = FlatGradAllReducer(nc, force_collective=True, overlap=False)   # one collective over the whole bucket
+    assert not ra.collective and rb.collective and rb.overlap and not rc.overlap
+    for red, net in ((ra, na), (rb, nb), (rc, nc)):
+        step = SamplerTrainStep(net, x, reducer=red, use_graph=False)
+        for _ in range(2):
+            loss = step(x)
+        torch.cuda.synchronize()
+        red.loss = float(loss)
+    assert ra.loss == rb.loss == rc.loss
+    assert torch.equal(ra.flat, rb.flat) and torch.equal(ra.flat, rc.flat)
+    assert float(ra.flat.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_captured_step_with_collectives(rccl, overlap):
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    na, nb = _nets(2)
+    ring_a = [torch.rand(32, 1024, 3, device="cuda") - 0.5 for _ in range(3)]
+    ring_b = [t.clone() for t in ring_a]
+    ra = FlatGradAllReducer(na)
+    rb = FlatGradAllReducer(nb, force_collective=True)
+    sa = SamplerTrainStep(na, ring_a[0], reducer=ra, input_ring=ring_a)
+    sb = SamplerTrainStep(nb, ring_b[0], reducer=rb, input_ring=ring_b, overlap_allreduce=overlap)
+    assert not sa.split and sb.split == overlap
+    assert all(len(g) == (2 if overlap else 1) for g in sb._ring_graphs)
+    for i in (0, 1, 2, 1, 0, 0):
+        la, lb = sa.replay(i), sb.replay(i)
+        torch.cuda.synchronize()
+        assert float(la) == float(lb), i
+        assert torch.equal(ra.flat, rb.flat), i
+    for (n, a), (_, b) in zip(na.named_buffers(), nb.named_buffers()):
+        assert torch.equal(a, b), n  # BatchNorm running statistics moved identically

@@ -250,36 +250,6 @@ def test_head_fused_into_scan(B, N, M, K):
 
 
 @pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (6, 512, 64, 8), (3, 320, 20, 5), (4, 2048, 32, 8)])
-def test_loss_reduction_folded_into_backward(B, N, M, K):
-    """sn_sampler_step_loss_fold (the per-cloud reduction of the forward done by the workgroups of the backward's first
-    launch, loss value combined in the sigma-gradient launch) against the forward / backward pair: gradients bit-equal
-    (same nearest-query indices, same argmax), loss value within 1e-6 relative (different summation order)."""
-    import copy
-
-    from samplenet_amd import SampleNet, fused_step
-
-    torch.manual_seed(B + N + 7)
-    net_a = SampleNet(M, 128, group_size=K, initial_temperature=0.6, input_shape="bnc", output_shape="bnc").cuda().train()
-    net_b = copy.deepcopy(net_a)
-    x = torch.rand(B, N, 3, device="cuda") - 0.5
-    x[:, N // 2:N // 2 + 4] = x[:, :4]  # duplicated points: ties between partial keys
-    old = fused_step.FOLD_LOSS
-    try:
-        fused_step.FOLD_LOSS = True
-        la, ya, pa = fused_step.sampler_step(net_a, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
-        la.backward()
-        fused_step.FOLD_LOSS = False
-        lb, yb, pb = fused_step.sampler_step(net_b, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
-        lb.backward()
-    finally:
-        fused_step.FOLD_LOSS = old
-    assert torch.equal(ya, yb) and torch.equal(pa, pb)
-    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
-    for (n, p), (_, q) in zip(net_a.named_parameters(), net_b.named_parameters()):
-        assert p.grad is not None and torch.equal(p.grad, q.grad), n
-
-
-@pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (6, 512, 64, 8), (3, 320, 20, 5), (4, 2048, 32, 8)])
 def test_scan_with_atomic_key_combine(B, N, M, K):
     """sn_pairscan_forward_keys + sn_sampler_step_loss_keys (per-point minima combined across a cloud's scan workgroups by
     atomicMax on inverted keys -- order-independent -- no reduction launch between scan and backward) against the
@@ -294,9 +264,8 @@ def test_scan_with_atomic_key_combine(B, N, M, K):
     net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
     x = torch.rand(B, N, 3, device="cuda") - 0.5
     x[:, N // 2:N // 2 + 4] = x[:, :4]  # duplicated points: ties between the workgroups' keys
-    old = fused_step.KEYS_LOSS, fused_step.FOLD_LOSS
+    old = fused_step.KEYS_LOSS
     try:
-        fused_step.FOLD_LOSS = False
         fused_step.KEYS_LOSS = True
         la, ya, pa = fused_step.sampler_step(net_a, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
         la.backward()
@@ -306,7 +275,7 @@ def test_scan_with_atomic_key_combine(B, N, M, K):
         lb, yb, pb = fused_step.sampler_step(net_b, x, 0.3, 0.7, 1.0 + 0.01 * M, None, True)
         lb.backward()
     finally:
-        fused_step.KEYS_LOSS, fused_step.FOLD_LOSS = old
+        fused_step.KEYS_LOSS = old
     assert hasattr(net_a, "_colmin_keys") and int(net_a._colmin_keys.abs().sum()) == 0
     assert torch.equal(ya, yb) and torch.equal(pa, pb)
     assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb))) and float(la) == float(lc)
@@ -428,3 +397,134 @@ def test_sampler_step_with_registration_task_loss():
     for n, p in net_a.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
         assert float((p.grad - gb[n]).norm()) <= 2e-3 * float(gb[n].norm()) + 1e-5 * gmax, n
+
+
+# ------------------------------------------------------------------------------------------ gradient-sink semantics
+def _plain_grads(net, xs, loss_of):
+    """Gradients of sum_i loss_of(net(x_i)) on a copy WITHOUT a gradient sink: every backward hands its gradients to
+    autograd, which accumulates them -- the semantics the sink has to reproduce."""
+    import copy
+
+    ref = copy.deepcopy(net).train()
+    ref.__dict__.pop("_grad_sink", None)
+    tot = 0.0
+    for x in xs:
+        tot = tot + loss_of(ref, x)
+    tot.backward()
+    return {n: p.grad for n, p in ref.named_parameters()}
+
+
+def _module_loss(net, x):
+    simp, proj = net(x)
+    return 0.01 * net.get_simplification_loss(x, simp, net.num_out_points, 1, 0) + 0.01 * net.get_projection_loss() + proj.mean()
+
+
+@pytest.mark.parametrize("set_to_none", [True, False])
+def test_flat_bucket_survives_optimizer_zero_grad_and_accumulates(set_to_none):
+    """registration/main.py:346 calls optimizer.zero_grad() (default set_to_none=True) and, with NUM_SAMPLED_CLOUDS == 2
+    (main.py:516-524), runs the sampler TWICE under one loss.  With a FlatGradAllReducer attached the HIP backward writes
+    into views of the flat bucket; afterwards every p.grad must be that view again, hold the SUM of both passes, and the
+    optimizer must move every parameter (not only the temperature)."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(2)
+    net = SampleNet(32, 64, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    xs = [torch.rand(8, 256, 3, device="cuda") - 0.5 for _ in range(2)]
+    want = _plain_grads(net, xs, _module_loss)
+    red = FlatGradAllReducer(net)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    for rep in range(2):  # the second round starts from the gradients of the first: zero_grad must really reset
+        opt.zero_grad(set_to_none=set_to_none)
+        loss = _module_loss(net, xs[0]) + _module_loss(net, xs[1])
+        loss.backward()
+        red.reduce()
+        gmax = max(float(g.norm()) for g in want.values())
+        for n, p in net.named_parameters():
+            assert p.grad is not None, n
+            assert p.grad.untyped_storage().data_ptr() == red.flat.untyped_storage().data_ptr(), n
+            assert float((p.grad - want[n]).norm()) <= 1e-5 * float(want[n].norm()) + 1e-7 * gmax, (rep, n)
+    opt.step()
+    moved = [n for n, p in net.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert len(moved) >= 30, moved  # (biases in front of a BatchNorm have ~zero gradient and may stay)
+
+
+def test_fused_step_twice_before_backward_keeps_both_key_tables():
+    """Two fused sampler steps whose backward runs only after both forwards: the second forward must not clobber the first
+    one's per-point minima (it gets a private key table); gradients = sum of the two separately computed steps."""
+    import copy
+
+    from samplenet_amd import SampleNet, fused_step
+
+    torch.manual_seed(4)
+    net = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    ref = copy.deepcopy(net)
+    xs = [torch.rand(8, 1024, 3, device="cuda") - 0.5 for _ in range(2)]
+    l0, _, _ = fused_step.sampler_step(net, xs[0], 0.01, 0.01, 1.0, None, True)
+    l1, _, _ = fused_step.sampler_step(net, xs[1], 0.01, 0.01, 1.0, None, True)
+    (l0 + l1).backward()
+    assert int(net._colmin_keys.abs().sum()) == 0 and net._colmin_keys_owner is None
+    want = {}
+    for x in xs:
+        ref.load_state_dict(net.state_dict())  # (same parameters; running statistics do not enter training-mode gradients)
+        for p in ref.parameters():
+            p.grad = None
+        l, _, _ = fused_step.sampler_step(ref, x, 0.01, 0.01, 1.0, None, True)
+        l.backward()
+        for n, p in ref.named_parameters():
+            want[n] = want.get(n, 0) + p.grad
+    for n, p in net.named_parameters():
+        assert torch.allclose(p.grad, want[n], rtol=1e-5, atol=1e-8), n
+    # a forward whose backward never runs must not poison the next step
+    l2, _, _ = fused_step.sampler_step(net, xs[0], 0.01, 0.01, 1.0, None, True)
+    del l2
+    import gc
+
+    gc.collect()
+    for p in net.parameters():
+        p.grad = None
+    l3, _, _ = fused_step.sampler_step(net, xs[0], 0.01, 0.01, 1.0, None, True)
+    l3.backward()
+    for p in ref.parameters():
+        p.grad = None
+    l4, _, _ = fused_step.sampler_step(ref, xs[0], 0.01, 0.01, 1.0, None, True)
+    l4.backward()
+    assert float(l3) == float(l4)
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.equal(p.grad, q.grad), n
+
+
+def test_eval_mode_backward_uses_running_statistics():
+    """A backward through an eval-mode sampler (frozen-BatchNorm fine-tuning): the forward normalises with the running
+    statistics, so dZ = scale * dY -- no batch-statistics terms.  Against torch.nn in eval mode on the same weights."""
+    from torch_mlp import torch_mlp_copy
+
+    from samplenet_amd import SampleNet
+
+    for B, N in [(6, 256), (40, 128)]:
+        torch.manual_seed(B)
+        net = SampleNet(16, 64, group_size=4, input_shape="bnc", output_shape="bnc").cuda()
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.normal_(0, 0.2)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.add_(0.2 * torch.randn_like(m.weight))
+        ref = torch_mlp_copy(net)
+        net.eval(), ref.eval()
+        x = torch.rand(B, N, 3, device="cuda") - 0.5
+        gy = torch.randn(B, 3, 16, device="cuda")
+        ya = net._features(x.permute(0, 2, 1), x)
+        yb = ref._features(x.permute(0, 2, 1))
+        assert float((ya - yb).norm()) <= 1e-4 * float(yb.norm())
+        (ya * gy).sum().backward()
+        (yb * gy).sum().backward()
+        gb = {n: p.grad for n, p in ref.named_parameters()}
+        for n, p in net.named_parameters():
+            if n.startswith("project"):
+                continue
+            assert p.grad is not None, n
+            assert float((p.grad - gb[n]).norm()) <= 1e-3 * float(gb[n].norm()) + 1e-6, (B, n)
