@@ -163,6 +163,7 @@ def time_module_surface(dev, B, N, M, K, steps=60):
     Not the headline value: the headline path fuses the benchmark's stand-in task term mean(proj) into the step."""
     from samplenet_amd import SampleNet
     from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
     from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss
 
     torch.manual_seed(0)
@@ -188,7 +189,12 @@ def time_module_surface(dev, B, N, M, K, steps=60):
     out = {}
     for name in ("eager", "graph"):
         if name == "graph":
-            st = SamplerTrainStep(net, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=task, use_graph=True)
+            # a fresh replica with a gradient bucket (what a data-parallel user holds): the captured backward writes the MLP
+            # gradients in place, and no autograd state of the eager leg (created on another stream) is alive during capture
+            gnet = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc").to(dev).train()
+            gnet.load_state_dict(net.state_dict())
+            st = SamplerTrainStep(gnet, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=task,
+                                  reducer=FlatGradAllReducer(gnet), use_graph=True)
             run = lambda: st(x)  # noqa: E731
         else:
             run = eager_step
@@ -201,6 +207,7 @@ def time_module_surface(dev, B, N, M, K, steps=60):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert torch.isfinite(loss).item()
+        del loss
         out[name] = {"value": B * steps / dt, "unit": "point-clouds/s", "ms_per_step": dt / steps * 1e3}
     out["task_loss"] = "frozen PCRNet (bottleneck 1024) on (template 1024 pts, projected 64 pts) + Chamfer(projected, rotated template)"
     return out
@@ -232,6 +239,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-module-surface", action="store_true", help="skip the secondary module-surface leg")
+    ap.add_argument("--no-overlap-allreduce", action="store_true",
+                    help="N > 1: one graph + one collective after it instead of two graphs with the first collective between")
     ap.add_argument("--force-collective", action="store_true",
                     help="world size 1 under torchrun: still issue the gradient all-reduce (single-GPU exercise of the RCCL path)")
     args = ap.parse_args()
@@ -266,7 +275,7 @@ def main():
     # the 8 resident batches are the step's input ring (a data loader would write its H2D copies into them): one graph per
     # entry, no copy into a staging buffer on the timed path
     train_step = SamplerTrainStep(net, pool[0], alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=reducer,
-                                  use_graph=not args.no_graph, input_ring=pool)
+                                  use_graph=not args.no_graph, input_ring=pool, overlap_allreduce=not args.no_overlap_allreduce)
 
     def step(i):
         return train_step.replay(i % len(pool))
@@ -312,8 +321,9 @@ def main():
                                    "losses + bwd), B=%d per GPU, 1024->64 points, K=8, bottleneck 128; no optimizer step" % B,
                        "batch_per_gpu": B, "global_batch": B * world, "n_in": N, "n_out": M, "group_size": K,
                        "parallelism": "dp%d" % world,
-                       "grad_allreduce": ("flat bucket over RCCL: FC-head segment between the step's two graphs on a side stream, "
-                                          "conv segment after") if reducer.collective else "none",
+                       "grad_allreduce": ("none" if not reducer.collective else
+                                          "flat bucket over RCCL: FC-head segment between the step's two graphs on a side stream, "
+                                          "conv segment after" if train_step.split else "flat bucket over RCCL: one collective after the step"),
                        "execution": "eager launches" if args.no_graph else "whole step replayed as one hipGraph",
                        "mlp": "hand-written fp32 MFMA kernels"},
             # the dominant kernel of the step (largest share of GPU time in profiles/): backward of the last 1x1 convolution

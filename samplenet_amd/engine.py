@@ -40,7 +40,7 @@ class SamplerTrainStep:
         # (86 % of the bucket) are final; between the replays their all-reduce starts on the reducer's side stream and runs
         # beside the conv stack's backward (graph 2); the rest of the bucket follows graph 2.  Stream-ordered: no host sync.
         if overlap_allreduce is None:
-            overlap_allreduce = True
+            overlap_allreduce = False
         self.split = bool(use_graph and overlap_allreduce and reducer is not None and reducer.collective and self._fast_path()
                           and fused_head and getattr(net, "use_hip_mlp", False))
         if use_graph:

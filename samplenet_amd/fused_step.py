@@ -79,7 +79,7 @@ class SamplerStepFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss, _gy=None, _gproj=None):
-        nparams = len(pointnet.PARAM_ORDER)
+        nparams = len(pointnet.param_order(ctx.net))
         if grad_loss is None:
             return (None,) * (10 + nparams)
         net = ctx.net
@@ -112,13 +112,13 @@ class SamplerStepFunction(torch.autograd.Function):
         if ctx.t_sink is None and ctx.needs_input_grad[2]:
             g_temp = gT.reshape(ctx.temperature.shape)
         return (None, None, g_temp) + (None,) * 7 + tuple(
-            None if (owner is not None and n in owner) else grads[n] for n in pointnet.PARAM_ORDER)
+            None if (owner is not None and n in owner) else grads[n] for n in pointnet.param_order(net))
 
 
 def sampler_step(net, x_bnc, alpha, lmbda, weight, t_sink=None, defer_value=False):
     """-> (loss, simp (B,3,M), proj (B,M,3)) for a training-mode SampleNet with projection on a (B,N,3) batch."""
     sd = dict(net.named_parameters())
-    params = [sd[n] for n in pointnet.PARAM_ORDER]
+    params = [sd[n] for n in pointnet.param_order(net)]
     proj = net.project
     return SamplerStepFunction.apply(net, x_bnc, proj._temperature, proj._group_size, proj._min_sigma_f, alpha, lmbda, weight,
                                      t_sink, defer_value, *params)
@@ -143,7 +143,7 @@ def sampler_step_direct(net, x_bnc, alpha, lmbda, weight, t_sink, grad_loss, aft
     if sink is None or (net.project._temperature.requires_grad and t_sink is None):
         raise RuntimeError("sampler_step_direct needs a gradient sink for every parameter (FlatGradAllReducer)")
     sd = dict(net.named_parameters())
-    params = [sd[n] for n in pointnet.PARAM_ORDER]
+    params = [sd[n] for n in pointnet.param_order(net)]
     proj = net.project
     ctx = _DirectCtx()
     prev = getattr(net, "_after_fc_grads", None)

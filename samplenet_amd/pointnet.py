@@ -22,20 +22,54 @@ def _empty(shape, like, dtype=torch.float32):
 
 
 class _Layer:
-    """Plain record of one GEMM layer's tensors."""
+    """Plain record of one GEMM layer's tensors (name / bn_name: the module attribute names = state_dict prefixes)."""
 
-    __slots__ = ("W", "b", "bn", "Ci", "Co")
+    __slots__ = ("name", "bn_name", "W", "b", "bn", "Ci", "Co")
 
-    def __init__(self, lin, bn):
+    def __init__(self, name, lin, bn_name, bn):
+        self.name, self.bn_name = name, bn_name
         self.W, self.b, self.bn = lin.weight, lin.bias, bn
         self.Co, self.Ci = lin.weight.shape[0], lin.weight.shape[1]
 
 
 def _layers(net):
-    convs = [_Layer(net.conv1, net.bn1), _Layer(net.conv2, net.bn2), _Layer(net.conv3, net.bn3),
-             _Layer(net.conv4, net.bn4), _Layer(net.conv5, net.bn5)]
-    fcs = [_Layer(net.fc1, net.bn_fc1), _Layer(net.fc2, net.bn_fc2), _Layer(net.fc3, net.bn_fc3), _Layer(net.fc4, None)]
+    """conv1..conv5 (each with its BatchNorm) and fc1..fcK of the sampler.  Hidden FC layers carry a BatchNorm in the
+    registration / classification samplers (samplenet.py:52-59) and none in the reconstruction sampler (samplers.py:33-38);
+    the last FC layer is always returned without one -- a BatchNorm behind it (classification/models/samplenet_model.py:
+    100-108) is applied by the caller on the head's output (pointnet_head)."""
+    convs = [_Layer("conv%d" % i, getattr(net, "conv%d" % i), "bn%d" % i, getattr(net, "bn%d" % i)) for i in range(1, 6)]
+    nfc = getattr(net, "num_fc_layers", 4)
+    fcs = [_Layer("fc%d" % i, getattr(net, "fc%d" % i), "bn_fc%d" % i, getattr(net, "bn_fc%d" % i, None) if i < nfc else None)
+           for i in range(1, nfc + 1)]
     return convs, fcs
+
+
+def param_order(net):
+    """Names of the parameters the MLP node differentiates, in the order they are passed to / returned from it."""
+    convs, fcs = _layers(net)
+    names = []
+    for L in convs + fcs:
+        names += [L.name + ".weight", L.name + ".bias"]
+    for L in convs + fcs:
+        if L.bn is not None:
+            names += [L.bn_name + ".weight", L.bn_name + ".bias"]
+    return names
+
+
+_IDENT = {}
+
+
+def _identity_coef(C, like):
+    """BatchNorm coefficient block (scale, shift, mean, invstd) = (1, 0, 0, 1): a ReLU layer without BatchNorm, expressed in
+    the operand / backward modes of the GEMM kernels (with "fixed statistics" rows < 0 its backward is dZ = relu' * dY)."""
+    key = (C, like.device)
+    t = _IDENT.get(key)
+    if t is None:
+        t = torch.zeros(4, C, device=like.device, dtype=torch.float32)
+        t[0].fill_(1.0)
+        t[3].fill_(1.0)
+        _IDENT[key] = t
+    return t
 
 
 def _linear_fwd(R, L, a_in, coef_prev, want_stats):
@@ -188,7 +222,10 @@ def forward_impl(net, x_bnc, training, skip_last=False):
     saved.update(pooled=pooled, argsel=argsel, zsel=zsel)
     a_in, coef_prev = pooled, None
     for L in fcs[:-1]:
-        if training:
+        if L.bn is None:  # ReLU layer without BatchNorm
+            z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False)
+            coef = _identity_coef(L.Co, z)
+        elif training:
             z, coef = _layer_fwd_bn(B, L, a_in, coef_prev)
         else:
             z, stats, nblk = _linear_fwd(B, L, a_in, coef_prev, use_batch_stats)
@@ -325,7 +362,11 @@ def _layer_bwd(R, L, mode, dy, z, kcoef, gsel, argsel, npts, zprev, coef_prev, L
     part = _empty((nsplit * L.Co * (L.Ci + (1 if with_bias else 0)),), L.W)
     dg = dbt = dbs = kc = None
     if has_bn:
-        dg, dbt = _out(sink, bn_prev + ".weight", Lprev.bn.weight), _out(sink, bn_prev + ".bias", Lprev.bn.bias)
+        if Lprev.bn is not None:
+            dg, dbt = _out(sink, bn_prev + ".weight", Lprev.bn.weight), _out(sink, bn_prev + ".bias", Lprev.bn.bias)
+        else:  # identity coefficients (no BatchNorm below): only the bias gradient of the layer below is meaningful
+            dg, dbt = _empty((L.Ci,), L.W), _empty((L.Ci,), L.W)
+            prev_bn_rows = -1
         dbs = _out(sink, lin_prev + ".bias", Lprev.b)
         kc = _empty((3, L.Ci), L.W)
     check(lib.sn_layer_backward(R, L.Ci, L.Co, mode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(L.W),
@@ -394,10 +435,9 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
     sink: optional dict name -> preallocated tensor the gradient is written into (overwritten, not accumulated).
     after_fc: optional callback invoked once all FC-head gradients have been enqueued (DP overlap point)."""
     convs, fcs = _layers(net)
-    names_c = ["conv1", "conv2", "conv3", "conv4", "conv5"]
-    bn_c = ["bn1", "bn2", "bn3", "bn4", "bn5"]
-    names_f = ["fc1", "fc2", "fc3", "fc4"]
-    bn_f = ["bn_fc1", "bn_fc2", "bn_fc3"]
+    names_c, bn_c = [L.name for L in convs], [L.bn_name for L in convs]
+    names_f, bn_f = [L.name for L in fcs], [L.bn_name for L in fcs]
+    nf = len(fcs)
     B, N = saved["B"], saved["N"]
     R = B * N
     grads = {}
@@ -410,9 +450,9 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
 
     # ---- FC head (rows = B): fc4 -> fc3 -> fc2 -> fc1 -> pooled features ----
     dy, kcoef = grad_y, None
-    for j in (3, 2, 1, 0):
+    for j in range(nf - 1, -1, -1):
         L = fcs[j]
-        mode = DZ_PLAIN if j == 3 else DZ_BN
+        mode = DZ_PLAIN if j == nf - 1 else DZ_BN
         if j > 0:
             zprev, cprev, Lprev, bnp, linp, rows = zf[j - 1], cf[j - 1], fcs[j - 1], bn_f[j - 1], names_f[j - 1], bn_rows
         elif B > 32:  # the epilogue trick needs the register-resident (R <= 32) kernels: separate pooling backward below
@@ -421,13 +461,15 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
             # fc1 sits on the max-pool: its "previous layer" is conv5 seen through the selected points -- the ReLU mask and
             # BatchNorm-backward sums of the dgrad epilogue over zsel ARE the pooling backward (no separate launch)
             zprev, cprev, Lprev, bnp, linp, rows = saved["zsel"], cc[4], convs[4], bn_c[4], names_c[4], (-1 if fixed else R)
-        dW, db, dy, dg, dbt, dbs, kc = _layer_bwd(B, L, mode, dy, zf[j] if j < 3 else None, kcoef, None, None, 1, zprev, cprev,
-                                                  Lprev, sink, names_f[j], bnp, linp, j == 3, rows)
+        dW, db, dy, dg, dbt, dbs, kc = _layer_bwd(B, L, mode, dy, zf[j] if j < nf - 1 else None, kcoef, None, None, 1, zprev, cprev,
+                                                  Lprev, sink, names_f[j], bnp, linp, j == nf - 1, rows)
         grads[names_f[j] + ".weight"] = dW
         if db is not None:
             grads[names_f[j] + ".bias"] = db
-        if bnp is not None:
-            grads[bnp + ".weight"], grads[bnp + ".bias"], grads[linp + ".bias"] = dg, dbt, dbs
+        if linp is not None:
+            grads[linp + ".bias"] = dbs
+            if Lprev.bn is not None:
+                grads[bnp + ".weight"], grads[bnp + ".bias"] = dg, dbt
         kcoef = kc
     gsel = dy  # (B, C5): gradient at the selected (max-pooled) points, already masked; kcoef = conv5's BatchNorm backward
     if after_fc is not None:
@@ -481,14 +523,6 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
     return grads
 
 
-PARAM_ORDER = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv3.weight", "conv3.bias",
-               "conv4.weight", "conv4.bias", "conv5.weight", "conv5.bias",
-               "bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias", "bn3.weight", "bn3.bias", "bn4.weight", "bn4.bias",
-               "bn5.weight", "bn5.bias",
-               "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias",
-               "bn_fc1.weight", "bn_fc1.bias", "bn_fc2.weight", "bn_fc2.bias", "bn_fc3.weight", "bn_fc3.bias"]
-
-
 class PointNetMLPFunction(torch.autograd.Function):
     """y (B, 3M) = head(x (B,N,3)); differentiable w.r.t. all 34 parameter tensors (x is data: no gradient)."""
 
@@ -509,7 +543,7 @@ class PointNetMLPFunction(torch.autograd.Function):
                 owner.commit(None if sink is not None else grads)
         # (ctx.saved stays: a retained graph may run backward again)
         # gradients that went into the sink are not handed to autograd (nothing left to accumulate)
-        return (None, None, None) + tuple(None if (owner is not None and n in owner) else grads[n] for n in PARAM_ORDER)
+        return (None, None, None) + tuple(None if (owner is not None and n in owner) else grads[n] for n in param_order(net))
 
 
 def pointnet_head(net, x_bnc):
@@ -520,10 +554,13 @@ def pointnet_head(net, x_bnc):
         raise TypeError("expected float32")
     x_bnc = x_bnc.contiguous()
     sd = dict(net.named_parameters())
-    params = [sd[n] for n in PARAM_ORDER]
+    params = [sd[n] for n in param_order(net)]
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         y = PointNetMLPFunction.apply(net, x_bnc, net.training, *params)
     else:
         with torch.cuda.device(x_bnc.device):
             y, _ = forward_impl(net, x_bnc, net.training)
+    last_bn = getattr(net, "bn_fc%d" % getattr(net, "num_fc_layers", 4), None)
+    if last_bn is not None:  # classification sampler: BatchNorm (no activation) on the head's output, B x 3M values: torch
+        y = last_bn(y)
     return y.view(-1, 3, net.num_out_points)

@@ -5,9 +5,10 @@ rocprofv3 trace of the graph replay (bench_graph_kernel_stats.csv), HBM traffic 
 import csv
 import json
 import os
+import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prof = os.path.join(root, "profiles", "r01")
+prof = os.path.join(root, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01")
 rows = [r for r in csv.DictReader(open(os.path.join(prof, "bench_graph_kernel_stats.csv")))]
 pmc = json.load(open(os.path.join(prof, "pmc_summary.json")))
 bench = json.load(open(os.path.join(prof, "bench_n1.json")))

@@ -17,13 +17,13 @@ for f in glob.glob(os.path.join(src, "pmc_*.csv")):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, v in agg.items():
-    if "sn::" not in k and not k.startswith(("simp", "sigma", "step_loss", "sampler_loss")):
+    if "sn::" not in k and not k.startswith(("simp", "sigma", "step_loss", "sampler_loss", "void sn", "void chamfer")):
         continue
     d = {c: sum(x) / len(x) for c, x in v.items()}
     d["launches"] = max(len(x) for x in v.values())
     d["hbm_traffic_bytes_per_launch"] = (2 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024
     out[k] = {kk: round(vv, 1) for kk, vv in d.items()}
-dst = os.path.join(root, "profiles", "r01", "pmc_summary.json")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles", "r01", "pmc_summary.json")
 json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
 for k in sorted(out, key=lambda n: -out[n]["hbm_traffic_bytes_per_launch"])[:12]:
     print("%-90s %8.2f MB/launch" % (k[:90], out[k]["hbm_traffic_bytes_per_launch"] / 1e6))

@@ -8,13 +8,19 @@ import glob
 import json
 import os
 
+import sys
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# usage: summarize_sq.py [csv-glob] [kernel-name-substring] [output json]
+pattern = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmcb_*.csv")
+needle = sys.argv[2] if len(sys.argv) > 2 else "conv_bwd_fused"
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(root, "profiles", "r01", "conv_bwd_fused_sq_counters.json")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(root, "gpurun_out", "pmcb_*.csv")):
+for f in glob.glob(pattern):
     for r in csv.DictReader(open(f)):
-        if "conv_bwd_fused" in r["Kernel_Name"]:
+        if needle in r["Kernel_Name"]:
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"note": "rocprofv3 --pmc, three passes of 8 SQ counters each (tools/gpu_pmc_bwd.sh), means over 10 launches at R = 32768; "
+out = {"note": "rocprofv3 --pmc, three passes of 8 SQ counters each (tools/gpu_pmc_bwd.sh), means over the launches of the profiled loop at R = 32768; "
                "SQ_* wave counters are in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over all SIMDs", "kernels": {}}
 for k, v in sorted(agg.items()):
     d = {c: int(round(sum(x) / len(x))) for c, x in sorted(v.items())}
@@ -30,4 +36,4 @@ for k, v in sorted(agg.items()):
     d["derived"] = der
     out["kernels"][k] = d
     print(k[:80], der)
-json.dump(out, open(os.path.join(root, "profiles", "r01", "conv_bwd_fused_sq_counters.json"), "w"), indent=1)
+json.dump(out, open(dst, "w"), indent=1)
