@@ -98,6 +98,14 @@ int sn_chamfer_backward(int b, int n, const float *xyz1, int m, const float *xyz
                         const float *grad_dist2, const int *idx2,
                         float *grad_xyz1, float *grad_xyz2, sn_stream_t stream);
 
+/* Progressive sampler (classification/train_samplenet_progressive.py:194-234: the nested prefixes Q[:, :s_j] of ONE simplified
+ * cloud each take the simplification loss): the per-POINT side of every prefix's Chamfer products from one pass over the
+ * M x N distances.  P (B,N,3), Q (B,M,3); prefix_sizes[nprefix] HOST array, ascending, last == M, nprefix <= 16;
+ * dist / idx: (nprefix, B, N) -- slice j equals sn_chamfer_forward(Q[:, :s_j], P)'s dist2 / idx2 bit for bit.
+ * (The per-query side does not depend on the prefix: slice dist1 / idx1 of the full scan.) */
+int sn_prefix_point_minima(int B, int N, int M, int nprefix, const int *prefix_sizes, const float *P, const float *Q,
+                           float *dist, int *idx, sn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused simplification loss of the sampler (registration/src/samplenet.py:171-181; TF twin
  * classification/models/samplenet_model.py:176-188):

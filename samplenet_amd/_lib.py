@@ -46,6 +46,7 @@ PROTOTYPES = {
     "sn_sampler_step_loss_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp],
     "sn_step_tail_bytes": [],
+    "sn_prefix_point_minima": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],
     "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

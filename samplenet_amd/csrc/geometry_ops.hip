@@ -1283,3 +1283,60 @@ extern "C" int sn_nn_matching(int B, int N, int k, const float *xyz, int layout,
     SN_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Progressive sampler: nearest QUERY of every point for every nested prefix Q[:s_j] of the simplified cloud,
+// from ONE pass over the M x N distances -- a thread owns a point, walks the queries in index order with a running
+// (minimum, first argmin) and emits it whenever a prefix ends.  Same expression / strict-< tie rule as the Chamfer scan
+// (chamfer_distance.cpp:59-112), so dist / idx of prefix j equal sn_chamfer_forward(Q[:, :s_j], P)'s dist2 / idx2 bit for bit.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxPrefixes = 16;
+struct PrefixEnds {
+    int n;
+    int end[kMaxPrefixes];  // ascending, end[n-1] == M
+};
+
+__global__ void __launch_bounds__(256) prefix_colmin_kernel(int N, int M, const float *__restrict__ P, const float *__restrict__ Q,
+                                                            PrefixEnds pe, float *__restrict__ dist, int *__restrict__ idx,
+                                                            size_t stride)
+{
+    extern __shared__ float q_lds[];  // [M][3]
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < M * 3; i += blockDim.x) q_lds[i] = Q[(size_t)b * M * 3 + i];
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const sn_xyz3 pv = *reinterpret_cast<const sn_xyz3 *>(P + ((size_t)b * N + n) * 3);
+    float best = 0.f;
+    int besti = 0, j = 0;
+    for (int m = 0; m < M; ++m) {
+        const float dx = q_lds[m * 3 + 0] - pv.x, dy = q_lds[m * 3 + 1] - pv.y, dz = q_lds[m * 3 + 2] - pv.z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        if (m == 0 || d < best) best = d, besti = m;
+        if (m + 1 == pe.end[j]) {
+            dist[j * stride + (size_t)b * N + n] = best;
+            idx[j * stride + (size_t)b * N + n] = besti;
+            ++j;
+        }
+    }
+}
+
+extern "C" int sn_prefix_point_minima(int B, int N, int M, int nprefix, const int *prefix_sizes, const float *P, const float *Q,
+                                      float *dist, int *idx, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && nprefix >= 1 && nprefix <= kMaxPrefixes, "bad size");
+    SN_REQUIRE(prefix_sizes && P && Q && dist && idx, "null pointer");
+    SN_REQUIRE((size_t)M * 12 <= 64 * 1024, "at most 5461 queries (LDS-staged)");
+    PrefixEnds pe{};
+    pe.n = nprefix;
+    for (int j = 0; j < nprefix; ++j) {
+        pe.end[j] = prefix_sizes[j];
+        SN_REQUIRE(pe.end[j] >= 1 && (j == 0 || pe.end[j] > pe.end[j - 1]), "prefix sizes must be ascending");
+    }
+    SN_REQUIRE(pe.end[nprefix - 1] == M, "the last prefix is the whole simplified cloud");
+    const dim3 grid((N + 255) / 256, B), block(256);
+    hipLaunchKernelGGL(prefix_colmin_kernel, grid, block, (size_t)M * 12, (hipStream_t)stream, N, M, P, Q, pe, dist, idx,
+                       (size_t)B * N);
+    SN_LAUNCH_CHECK();
+    return 0;
+}

@@ -51,7 +51,7 @@ class SamplerTrainStep:
         training mode with projection, (B,N,3) input, and a batch small enough that the pair scan splits clouds."""
         net = self.net
         if not self.fused_loss or self.task_loss is not None or not net.training or net.skip_projection or \
-                net.input_shape != "bnc":
+                net.input_shape != "bnc" or not getattr(net, "standard_arch", True):
             return False
         from ._lib import lib
 

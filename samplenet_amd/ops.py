@@ -78,6 +78,24 @@ def chamfer_distance(xyz1, xyz2, return_idx=False):
     return (d1, d2, i1, i2) if return_idx else (d1, d2)
 
 
+def prefix_point_minima(ref_pc, samp_pc, sizes):
+    """Nearest simplified point of every input point for each nested prefix samp_pc[:, :s] (one launch, no gradient):
+    ref_pc (B,N,3), samp_pc (B,M,3), sizes ascending with sizes[-1] == M -> dist (S,B,N) float32, idx (S,B,N) int32."""
+    import ctypes
+
+    _need_gpu(ref_pc, samp_pc)
+    P, Q = _f32c(ref_pc.detach()), _f32c(samp_pc.detach())
+    B, N, _ = P.shape
+    M = Q.shape[1]
+    S = len(sizes)
+    dist = torch.empty(S, B, N, device=P.device, dtype=torch.float32)
+    idx = torch.empty(S, B, N, device=P.device, dtype=torch.int32)
+    arr = (ctypes.c_int * S)(*[int(v) for v in sizes])
+    with torch.cuda.device(P.device):
+        check(lib.sn_prefix_point_minima(B, N, M, S, arr, ptr(P), ptr(Q), ptr(dist), ptr(idx), _stream(P)), "sn_prefix_point_minima")
+    return dist, idx
+
+
 # --------------------------------------------------------------------------------------------- kNN
 def knn(k, ref, query, ref_layout=BCN, query_layout=BCN, return_dist=True):
     """K nearest `ref` points of every `query` point (no gradient).

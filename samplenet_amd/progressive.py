@@ -9,7 +9,8 @@ reconstruction/src/samplenet_progressive_pointnet_ae.py:77-100,165-173); its sem
   * classification: total simplification loss = SUM over sizes; auto-encoder variant: MEAN over sizes.
 This module is that layer over the HIP hot path: SampleNetProgressive is a SampleNet whose losses take a list of sizes.
 The query->point products (dist / idx per simplified point) do not depend on the prefix, so they come from forward()'s
-pair scan; the point->query side of every prefix is one Chamfer scan on the prefix (sizes are few).
+pair scan; the point->query side of EVERY prefix comes from one more pass over the distances (sn_prefix_point_minima:
+running minimum over the queries in index order, emitted at each prefix end).
 """
 import torch
 
@@ -53,13 +54,25 @@ class SampleNetProgressive(SampleNet):
             raise ValueError("reduction must be 'sum' or 'mean'")
         if self.skip_projection or not self.training:
             return torch.tensor(0).to(ref_pc)
+        # One pass over the M x N distances serves every prefix: the per-query products (dist1 / idx1) do not
+        # depend on the prefix -- they are forward()'s scan (or one Chamfer scan) sliced -- and the per-point products of all
+        # prefixes come from ops.prefix_point_minima's running minimum in one launch.
+        M = samp_pc.shape[1]
+        if self.sizes[-1] != M:
+            raise ValueError("samp_pc must hold the largest size (%d points)" % self.sizes[-1])
+        scan = self._scan_hit(ref_pc, samp_pc)
+        if scan is not None:
+            dq, iq = scan[0], scan[1]
+        else:
+            _, _, dq, iq, _, _ = ops.chamfer_forward_impl(samp_pc.detach(), ref_pc.detach())
+        d2, i2 = ops.prefix_point_minima(ref_pc, samp_pc, self.sizes)
         total = None
-        for s in self.sizes:
-            sl = samp_pc[:, :s, :].contiguous()
-            if s == samp_pc.shape[1]:
-                term = self.get_simplification_loss(ref_pc, samp_pc, s, gamma, delta)  # reuses forward()'s scan
+        for j, s in enumerate(self.sizes):
+            if s == M and scan is not None and not ref_pc.requires_grad:
+                term = self.get_simplification_loss(ref_pc, samp_pc, s, gamma, delta)  # hangs off the head's (B,3,M) output
             else:
-                _, _, d1, i1, d2, i2 = ops.chamfer_forward_impl(sl.detach(), ref_pc.detach())
-                term = ops.SimplificationLossFunction.apply(sl, ref_pc, d1, i1, d2, i2, gamma + delta * s)
+                sl = samp_pc[:, :s, :].contiguous()
+                term = ops.SimplificationLossFunction.apply(sl, ref_pc, dq[:, :s].contiguous(), iq[:, :s].contiguous(), d2[j], i2[j],
+                                                            gamma + delta * s)
             total = term if total is None else total + term
         return total / len(self.sizes) if reduction == "mean" else total

@@ -36,26 +36,48 @@ class SampleNet(nn.Module):
         output_shape="bcn",
         complete_fps=True,
         skip_projection=False,
+        conv_widths=(64, 64, 64, 128),
+        fc_widths=(256, 256, 256),
+        fc_batchnorm=True,
+        last_fc_batchnorm=False,
+        temperature_floor=None,
     ):
+        """Arguments up to skip_projection: registration/src/samplenet.py:23-37.  The keyword-only-in-spirit rest selects the
+        sampler variants of the TF packages (same layer names, so the registration defaults stay state_dict compatible):
+          reconstruction (reconstruction/src/samplers.py:23-38, soft_projection.py:51-54):
+              conv_widths=(64, 128, 128, 256), fc_widths=(256, 256), fc_batchnorm=False, temperature_floor=1e-2, min_sigma=0
+          classification (classification/models/samplenet_model.py:30-108, soft_projection.py:41):
+              last_fc_batchnorm=True, min_sigma=0
+        """
         super().__init__()
         self.use_hip_mlp = True  # the feature extractor runs on the hand-written MFMA kernels (there is no other route here)
         self.num_out_points = num_out_points
         self.name = "samplenet"
 
         # Layers registered under the reference's names and in its order (samplenet.py:40-59): checkpoints are
-        # interchangeable.  Widths: 3 -> 64 -> 64 -> 64 -> 128 -> bottleneck over the points, then 256 -> 256 -> 256 -> 3*M.
-        conv_widths = (3, 64, 64, 64, 128, bottleneck_size)
-        fc_widths = (bottleneck_size, 256, 256, 256, 3 * num_out_points)
+        # interchangeable.  Default widths: 3 -> 64 -> 64 -> 64 -> 128 -> bottleneck over the points, then 256 -> 256 -> 256 -> 3*M.
+        if len(conv_widths) != 4:
+            raise ValueError("conv_widths: four hidden widths (the fifth conv layer ends in bottleneck_size)")
+        conv_widths = (3,) + tuple(int(w) for w in conv_widths) + (bottleneck_size,)
+        fc_widths = (bottleneck_size,) + tuple(int(w) for w in fc_widths) + (3 * num_out_points,)
+        self.num_fc_layers = len(fc_widths) - 1
         for i in range(1, len(conv_widths)):
             self.add_module("conv%d" % i, nn.Conv1d(conv_widths[i - 1], conv_widths[i], kernel_size=1))
         for i in range(1, len(conv_widths)):
             self.add_module("bn%d" % i, nn.BatchNorm1d(conv_widths[i]))
         for i in range(1, len(fc_widths)):
             self.add_module("fc%d" % i, nn.Linear(fc_widths[i - 1], fc_widths[i]))
-        for i in range(1, len(fc_widths) - 1):
-            self.add_module("bn_fc%d" % i, nn.BatchNorm1d(fc_widths[i]))
+        if fc_batchnorm:
+            for i in range(1, len(fc_widths) - 1):
+                self.add_module("bn_fc%d" % i, nn.BatchNorm1d(fc_widths[i]))
+        if last_fc_batchnorm:
+            self.add_module("bn_fc%d" % self.num_fc_layers, nn.BatchNorm1d(fc_widths[-1]))
+        # the fused single-node step (engine fast path) is specialised to the registration architecture
+        self.standard_arch = (conv_widths[1:5] == (64, 64, 64, 128) and fc_widths[1:-1] == (256, 256, 256) and fc_batchnorm
+                              and not last_fc_batchnorm and temperature_floor is None)
 
-        self.project = SoftProjection(group_size, initial_temperature, is_temperature_trainable, min_sigma)
+        self.project = SoftProjection(group_size, initial_temperature, is_temperature_trainable, min_sigma,
+                                      temperature_floor=temperature_floor)
         self.skip_projection = skip_projection
         self.complete_fps = complete_fps
 

@@ -19,9 +19,12 @@ def knn_point(group_size, point_cloud, query_cloud):
 
 
 class SoftProjection(nn.Module):
-    def __init__(self, group_size, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-4):
-        """Computes a soft nearest neighbor point cloud (arguments as soft_projection.py:23-44)."""
+    def __init__(self, group_size, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-4, temperature_floor=None):
+        """Computes a soft nearest neighbor point cloud (arguments as soft_projection.py:23-44).
+        temperature_floor (not in the registration module): the reconstruction package clamps the temperature itself,
+        sigma = max(T, floor)^2 (reconstruction/src/soft_projection.py:51-54, floor 1e-2); None: sigma = max(T^2, min_sigma)."""
         super().__init__()
+        self._temperature_floor = None if temperature_floor is None else float(temperature_floor)
         self._group_size = group_size
         self._temperature = torch.nn.Parameter(
             torch.tensor(initial_temperature, requires_grad=is_temperature_trainable, dtype=torch.float32))
@@ -42,7 +45,17 @@ class SoftProjection(nn.Module):
             raise ValueError(
                 "action should be one of the following: 'project', 'propagate', 'project_and_propagate'")
 
+    def _t(self):
+        """The temperature the kernels square: the parameter itself, or max(T, floor) for the reconstruction variant (a torch
+        op: its gradient gate is autograd's)."""
+        if self._temperature_floor is None:
+            return self._temperature
+        return torch.clamp(self._temperature, min=self._temperature_floor)
+
     def sigma(self):
+        if self._temperature_floor is not None:
+            t = self._t()
+            return torch.clamp(t * t, min=self._min_sigma_f)
         device = self._temperature.device
         ms = self._min_sigma_dev.get(device)
         if ms is None:
@@ -58,7 +71,7 @@ class SoftProjection(nn.Module):
             # NotImplementedError here (soft_projection.py:144-145).  No gradient reaches the query (one_hot has none).
             idx, _ = ops.knn(1, point_cloud, query_cloud, ops.BCN, ops.BCN, return_dist=False)  # (B,M,1)
             return ops.grouping_operation(point_cloud.contiguous(), idx).squeeze(3)  # (B,3,M)
-        proj, _idx = ops.SoftProjectFunction.apply(point_cloud, query_cloud, self._temperature, self._min_sigma_f,
+        proj, _idx = ops.SoftProjectFunction.apply(point_cloud, query_cloud, self._t(), self._min_sigma_f,
                                                    self._group_size, False)
         return proj
 
@@ -66,13 +79,13 @@ class SoftProjection(nn.Module):
         """project() plus both nearest-neighbour directions between query_cloud and point_cloud from the same
         distance scan: returns proj, idx (B,M,K), dist_q (B,M), idx_q, dist_p (B,N), idx_p.
         point_cloud may be given point-major ((B,N,3), p_layout=BNC) and proj requested point-major ((B,M,3))."""
-        return ops.SoftProjectFunction.apply(point_cloud, query_cloud, self._temperature, self._min_sigma_f,
+        return ops.SoftProjectFunction.apply(point_cloud, query_cloud, self._t(), self._min_sigma_f,
                                              self._group_size, True, p_layout, out_layout)
 
     # -- split path (features) ------------------------------------------------------------------
     def _weights(self, point_cloud, query_cloud):
         idx, _ = ops.knn(self._group_size, point_cloud, query_cloud, ops.BCN, ops.BCN, return_dist=False)
-        w = ops.SoftWeightsFunction.apply(point_cloud, query_cloud, idx, self._temperature, self._min_sigma_f)
+        w = ops.SoftWeightsFunction.apply(point_cloud, query_cloud, idx, self._t(), self._min_sigma_f)
         return idx, w
 
     def propagate(self, point_cloud, point_features, query_cloud):

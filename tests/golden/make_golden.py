@@ -382,6 +382,64 @@ def golden_pcrnet(ChamferDistance):
          loss=np.float32(loss.item()), qnorm=np.float32(qnorm.item()), grad_p0=p0.grad.numpy(), **sums, **gn)
 
 
+def golden_loaders():
+    """Row f4 (reconstruction/src/in_out.py): PLY fixtures WRITTEN by the reference's vendored plyfile package (ascii,
+    binary_little_endian, binary_big_endian; vertices + colours + triangle faces) under tests/golden/ply/<syn_id>/<model>.ply
+    with what the same package reads back; and the outputs of the reference's own split_data / PointCloudDataSet -- their
+    source is lifted out of in_out.py with ast (importing the module would start its dataset download)."""
+    import shutil
+
+    sys.path.insert(0, os.path.join(REF, "reconstruction", "external", "python_plyfile"))
+    plyfile = importlib.import_module("plyfile")
+    root = os.path.join(HERE, "ply")
+    shutil.rmtree(root, ignore_errors=True)
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = [("02691156", "a1", True, "<", 12), ("02691156", "b2", False, "<", 12), ("03001627", "c3", False, ">", 12),
+             ("03001627", "d4", True, "<", 12), ("04379243", "e5", False, "<", 12)]
+    for syn, model, text, order, n in cases:
+        os.makedirs(os.path.join(root, syn), exist_ok=True)
+        v = np.empty(n, dtype=[("x", "f4"), ("y", "f4"), ("z", "f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+        for c in "xyz":
+            v[c] = rng.random(n, dtype=np.float32) - 0.5
+        for c in ("red", "green", "blue"):
+            v[c] = rng.integers(0, 256, n)
+        faces = np.empty(5, dtype=[("vertex_indices", "i4", (3,))])
+        faces["vertex_indices"] = rng.integers(0, n, (5, 3))
+        path = os.path.join(root, syn, model + ".ply")
+        plyfile.PlyData([plyfile.PlyElement.describe(v, "vertex"), plyfile.PlyElement.describe(faces, "face")],
+                        text=text, byte_order=order).write(path)
+        back = plyfile.PlyData.read(path)
+        pts = np.vstack([back["vertex"]["x"], back["vertex"]["y"], back["vertex"]["z"]]).T
+        out[f"{syn}_{model}_points"] = pts
+        out[f"{syn}_{model}_faces"] = np.vstack(back["face"]["vertex_indices"])
+        out[f"{syn}_{model}_color"] = np.hstack([np.vstack(back["vertex"][c]) for c in ("red", "green", "blue")])
+    # reference split_data / PointCloudDataSet, lifted by ast
+    src = open(os.path.join(REF, "reconstruction/src/in_out.py")).read()
+    tree = ast.parse(src)
+    ns = {"np": np, "range": range, "object": object}
+    for node in tree.body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in ("split_data", "PointCloudDataSet"):
+            exec(compile(ast.Module([node], []), "in_out.py", "exec"), ns)
+    data = rng.random((23, 6, 3), dtype=np.float32)
+    labels = np.array(["m%d" % i for i in range(23)], dtype=object)
+    tr, va, te, perm = ns["split_data"](data, (0.85, 0.05, 0.10), 42)
+    out.update(split_data=data, split_train=tr, split_val=va, split_test=te, split_perm=perm)
+    ds = ns["PointCloudDataSet"](data, labels=labels, init_shuffle=False)
+    np.random.seed(7)
+    ds.shuffle_points(seed=3)
+    seq = []
+    for _ in range(7):  # crosses two epoch boundaries
+        pc, lb, _ = ds.next_batch(8, seed=11)
+        seq.append(pc.copy())
+    out["ds_batches"] = np.stack(seq)
+    out["ds_epochs"] = np.array(ds.epochs_completed)
+    fe, fl, _ = ds.full_epoch_data(shuffle=True, seed=13)
+    out["ds_full_epoch"] = fe
+    out["ds_full_labels"] = np.array([str(v) for v in fl])
+    save("loaders_reference.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout not found: " + REF
     O.build(ref=True)
@@ -392,7 +450,7 @@ if __name__ == "__main__":
     jobs = {"known": golden_known_answers, "softproj": lambda: golden_softproj(sp_mod.SoftProjection),
             "chamfer": lambda: golden_chamfer(ChamferDistance), "samplenet": lambda: golden_samplenet(sn_mod.SampleNet),
             "c2": lambda: golden_samplenet_c2(sn_mod.SampleNet), "nn_matching": lambda: golden_nn_matching(sputils),
-            "pcrnet": lambda: golden_pcrnet(ChamferDistance)}
+            "pcrnet": lambda: golden_pcrnet(ChamferDistance), "loaders": golden_loaders}
     for name in (sys.argv[1:] or list(jobs)):  # python make_golden.py [job ...]   (default: all)
         jobs[name]()
     left = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc") or f == "__pycache__"]

@@ -407,3 +407,24 @@ def test_hard_projection_is_nearest_input_point(oracle):
     _, idx = oracle.knn(1, pc, q)
     want = np.take_along_axis(pc, idx[:, :, :1].astype(np.int64).repeat(3, axis=2), axis=1)  # (B,M,3)
     assert np.array_equal(out.permute(0, 2, 1).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("B,N,M,sizes", [(4, 1024, 256, [32, 64, 128, 256]), (2, 300, 50, [1, 7, 50]), (32, 1024, 64, [8, 16, 32, 64]),
+                                          (1, 2048, 1024, [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024])])
+def test_prefix_point_minima_match_chamfer_per_prefix(oracle, B, N, M, sizes):
+    """sn_prefix_point_minima (progressive sampler): the per-point Chamfer products of every nested prefix from ONE
+    pass == the oracle's Chamfer scan of that prefix, bit for bit (distances and first-minimum indices, duplicated points
+    included); the full-size slice also equals the HIP pair scan's."""
+    from samplenet_amd import ops
+
+    rng = np.random.default_rng(N + M)
+    P = (rng.random((B, N, 3), dtype=np.float32) - 0.5)
+    Q = (P[:, rng.permutation(N)[:M]] + 0.02 * rng.standard_normal((B, M, 3))).astype(np.float32)
+    Q[:, M // 2] = Q[:, 0]  # duplicated query: the lower index must win in every prefix that holds both
+    d, i = ops.prefix_point_minima(dev(P), dev(Q), sizes)
+    for j, s in enumerate(sizes):
+        _, _, od2, oi2 = oracle.chamfer_forward(np.ascontiguousarray(Q[:, :s]), P)
+        assert np.array_equal(d[j].cpu().numpy(), od2), s
+        assert np.array_equal(i[j].cpu().numpy(), oi2), s
+    _, _, _, _, hd2, hi2 = ops.chamfer_forward_impl(dev(Q), dev(P))
+    assert torch.equal(d[-1], hd2) and torch.equal(i[-1], hi2)

@@ -448,3 +448,51 @@ def test_pcrnet_task_loss_matches_reference(golden):
         key = "g_" + n.replace(".", "_")
         if key in g.files:
             assert _rel(p.grad.cpu(), torch.from_numpy(g[key])) <= 2e-4, n
+
+
+VARIANTS = {
+    # reconstruction/src/samplers.py:23-38 (+ soft_projection.py:51-54): wider conv stack, two FC layers without BatchNorm
+    "reconstruction": dict(conv_widths=(64, 128, 128, 256), fc_widths=(256, 256), fc_batchnorm=False, temperature_floor=1e-2,
+                           min_sigma=0.0),
+    # classification/models/samplenet_model.py:30-108: registration widths + BatchNorm on the last FC layer
+    "classification": dict(last_fc_batchnorm=True, min_sigma=0.0),
+}
+
+
+@pytest.mark.parametrize("variant", ["reconstruction", "classification"])
+@pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (50, 2048, 64, 16), (6, 320, 32, 5)])
+def test_sampler_variants_vs_torch(variant, B, N, M, K):
+    """The TF packages' sampler architectures (SURVEY C4 / config #4 sampler) through the same HIP kernels: head output,
+    every parameter gradient and the whole module step (projection + losses + temperature gradient with the variant's
+    sigma rule) against the torch.nn op chain on the same weights."""
+    from samplenet_amd import SampleNet
+
+    torch.manual_seed(B + N)
+    net = SampleNet(M, 128, group_size=K, initial_temperature=0.5, input_shape="bnc", output_shape="bnc", **VARIANTS[variant]).cuda().train()
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "bn" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    ref = torch_mlp_copy(net).train()
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+
+    def step(m, xx):
+        simp, proj = m(xx)
+        return 0.01 * m.get_simplification_loss(xx, simp, M, 1, 0.01) + 0.01 * m.get_projection_loss() + proj.mean(), simp
+
+    la, sa = step(net, x)
+    lb, sb = step(ref, x)
+    la.backward(), lb.backward()
+    assert float((sa - sb).abs().max()) <= (2e-4 if B >= 16 else 2e-3)
+    assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(lb)))
+    gb = {n: p.grad for n, p in ref.named_parameters()}
+    gmax = max(float(g.norm()) for g in gb.values())
+    for n, p in net.named_parameters():
+        assert p.grad is not None, n
+        assert float((p.grad - gb[n]).norm()) <= (5e-3 if B >= 16 else 1e-1) * float(gb[n].norm()) + 1e-5 * gmax, n
+    assert set(dict(net.named_parameters())) == set(gb)
+    # sigma rule of the variant
+    if variant == "reconstruction":
+        with torch.no_grad():
+            net.project._temperature.fill_(-0.3)
+        assert abs(float(net.get_projection_loss()) - 1e-4) < 1e-9  # max(T, 1e-2)^2

@@ -311,21 +311,23 @@ def test_input_ring_replay_equals_copy_in():
     assert torch.equal(la, lb) and torch.equal(red_a.flat, red_b.flat)
 
 
+@pytest.mark.parametrize("cfg", [(6, 512, 8, 64), (8, 1024, 32, 256)])  # the second: SURVEY C5, 1024 -> {32, 64, 128, 256}
 @pytest.mark.parametrize("reduction", ["sum", "mean"])
-def test_progressive_sampler_losses(oracle, reduction):
+def test_progressive_sampler_losses(oracle, reduction, cfg):
     """SampleNetProgressive (row f3; semantics of classification/train_samplenet_progressive.py:157-234 and
     reconstruction/src/samplenet_progressive_pointnet_ae.py:77-100,165-173): the loss over the nested prefixes equals the
     op-by-op composition on the oracle's Chamfer distances, and its gradient equals autograd through the plain
     ChamferDistance composition."""
     from samplenet_amd import ChamferDistance, SampleNetProgressive, progressive_sizes
 
-    sizes = progressive_sizes(8, 64)
-    assert sizes == [8, 16, 32, 64]
+    Bp, Np, smin, smax = cfg
+    sizes = progressive_sizes(smin, smax)
+    assert sizes == ([8, 16, 32, 64] if smin == 8 else [32, 64, 128, 256])
     torch.manual_seed(11)
     net = SampleNetProgressive(sizes, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
-    x = torch.rand(6, 512, 3, device="cuda") - 0.5
+    x = torch.rand(Bp, Np, 3, device="cuda") - 0.5
     simp, proj = net(x)
-    assert simp.shape == (6, 64, 3) and net.prefix(proj, 16).shape == (6, 16, 3)
+    assert simp.shape == (Bp, smax, 3) and net.prefix(proj, sizes[1]).shape == (Bp, sizes[1], 3)
     gamma, delta = 1.0, 0.02
     loss = net.get_progressive_simplification_loss(x, simp, gamma, delta, reduction)
     # gradients are compared at the FC head's last layer (the full-size term hangs off the head's (B,3,M) output directly,

@@ -14,9 +14,15 @@ class TorchMLPSampleNet(SampleNet):
         for i in range(1, 6):
             y = F.relu(getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(y)))
         y = y.max(dim=2).values  # (B, bottleneck)
-        for i in range(1, 4):
-            y = F.relu(getattr(self, "bn_fc%d" % i)(getattr(self, "fc%d" % i)(y)))
-        y = self.fc4(y)
+        nfc = self.num_fc_layers
+        for i in range(1, nfc):
+            y = getattr(self, "fc%d" % i)(y)
+            bn = getattr(self, "bn_fc%d" % i, None)
+            y = F.relu(bn(y) if bn is not None else y)
+        y = getattr(self, "fc%d" % nfc)(y)
+        bn = getattr(self, "bn_fc%d" % nfc, None)  # classification variant: BatchNorm on the head's output
+        if bn is not None:
+            y = bn(y)
         return y.view(-1, 3, self.num_out_points)
 
 
