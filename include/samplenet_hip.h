@@ -360,6 +360,11 @@ int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef
 int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,
                    float eps, float momentum, float *running_mean, float *running_var,
                    long long *num_batches_tracked, float *coef, sn_stream_t stream);
+/* sn_bn_finalize for a SHORT matrix z (R, C) (the FC head at batches above 32): statistics in two passes over z itself (mean,
+ * then squares around it) instead of from sum / sum-of-squares partials -- behind the max-pool |mean| / std reaches 10..100. */
+int sn_bn_batch_stats_twopass(int R, int C, const float *z, const float *gamma, const float *beta, float eps, float momentum,
+                              float *running_mean, float *running_var, long long *num_batches_tracked, float *coef,
+                              sn_stream_t stream);
 int sn_bn_eval_coef(int C, const float *gamma, const float *beta, float eps, const float *running_mean,
                     const float *running_var, float *coef, sn_stream_t stream);
 int sn_pool_forward(int B, int N, int C, const float *z, const float *coef, float *pooled, int *argsel,

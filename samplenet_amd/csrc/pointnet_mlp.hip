@@ -502,11 +502,16 @@ __device__ __forceinline__ BnFwdIn bn_fwd_inputs(const BnFwd &bn, int c)
     if (bn.running_mean) in.rmean = bn.running_mean[c], in.rvar = bn.running_var[c];
     return in;
 }
+__device__ __forceinline__ float2 bn_finalize_channel_mv(const BnFwd &bn, int C, int c, double mean, double var, const BnFwdIn &in);
 __device__ __forceinline__ float2 bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss, const BnFwdIn &in)
 {
     const double mean = s / (double)bn.R;
     double var = ss / (double)bn.R - mean * mean;
     if (var < 0.0) var = 0.0;
+    return bn_finalize_channel_mv(bn, C, c, mean, var, in);
+}
+__device__ __forceinline__ float2 bn_finalize_channel_mv(const BnFwd &bn, int C, int c, double mean, double var, const BnFwdIn &in)
+{
     const float invstd = (float)(1.0 / sqrt(var + (double)bn.eps));
     const float sc = in.gamma * invstd;
     bn.coef[c] = sc;
@@ -2201,6 +2206,39 @@ __global__ void __launch_bounds__(1024) bn_finalize_pool_kernel(int nblk, int C,
     }
 }
 
+// Batch statistics of a SHORT activation matrix (the FC head at batches above 32: R rows, a few hundred at most) straight from
+// z in two passes -- mean, then the squares around it, in double.  Behind the max-pool the head's features are nearly the same
+// for every cloud (|mean| / std of 10..100): E[z^2] - mean^2 from fp32 block sums loses 2..4 digits of the variance there.
+__global__ void __launch_bounds__(256) bn_twopass_kernel(int R, int C, const float *__restrict__ z, BnFwd bn)
+{
+    __shared__ double red[4][64];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
+    const int lane = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < C;
+    BnFwdIn in{};
+    if (ok && stripe == 0) in = bn_fwd_inputs(bn, c);
+    double s = 0.0;
+    if (ok)
+        for (int r = stripe; r < R; r += 4) s += (double)z[(size_t)r * C + c];
+    red[stripe][lane] = s;
+    __syncthreads();
+    const double mean = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (double)R;
+    __syncthreads();
+    double q = 0.0;
+    if (ok)
+        for (int r = stripe; r < R; r += 4) {
+            const double d = (double)z[(size_t)r * C + c] - mean;
+            q += d * d;
+        }
+    red[stripe][lane] = q;
+    __syncthreads();
+    if (stripe == 0 && ok) {
+        const double var = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (double)R;
+        bn_finalize_channel_mv(bn, C, c, mean, var, in);
+    }
+}
+
 // eval: coefficients from the running statistics
 __global__ void bn_eval_coef_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                     const float *__restrict__ running_mean, const float *__restrict__ running_var,
@@ -3318,6 +3356,19 @@ extern "C" int sn_bn_finalize(int nblk, int C, long long R, const float *stats, 
     SN_REQUIRE(nblk >= 1 && C >= 1 && R >= 1 && stats && gamma && beta && coef, "bad argument");
     const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, R};
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + kChan - 1) / kChan), dim3(1024), 0, (hipStream_t)stream, nblk, C, stats, bn);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Training-mode BatchNorm of a SHORT activation matrix z (R, C) -- the FC head at batches above 32 -- with two-pass statistics
+// (bn_twopass_kernel); outputs as sn_bn_finalize.
+extern "C" int sn_bn_batch_stats_twopass(int R, int C, const float *z, const float *gamma, const float *beta, float eps,
+                                         float momentum, float *running_mean, float *running_var,
+                                         long long *num_batches_tracked, float *coef, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && C >= 1 && z && gamma && beta && coef, "bad argument");
+    const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
+    hipLaunchKernelGGL(bn_twopass_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, R, C, z, bn);
     SN_LAUNCH_CHECK();
     return 0;
 }

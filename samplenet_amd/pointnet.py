@@ -225,6 +225,16 @@ def forward_impl(net, x_bnc, training, skip_last=False):
         if L.bn is None:  # ReLU layer without BatchNorm
             z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False)
             coef = _identity_coef(L.Co, z)
+        elif training and B > 32:
+            # the GEMM, then two-pass batch statistics from z itself (above 32 rows the statistics are not complete inside one
+            # workgroup, and sum / sum-of-squares partials lose digits on the head's nearly-constant features)
+            z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False)
+            coef = _empty((4, L.Co), z)
+            bn, upd = L.bn, L.bn.track_running_stats
+            check(lib.sn_bn_batch_stats_twopass(B, L.Co, ptr(z), ptr(bn.weight), ptr(bn.bias), float(bn.eps), _momentum(bn),
+                                                ptr(bn.running_mean) if upd else None, ptr(bn.running_var) if upd else None,
+                                                ptr(bn.num_batches_tracked) if upd else None, ptr(coef), _st(z)),
+                  "sn_bn_batch_stats_twopass")
         elif training:
             z, coef = _layer_fwd_bn(B, L, a_in, coef_prev)
         else:

@@ -93,6 +93,21 @@ class SampleNet(nn.Module):
         self._scan = None  # Chamfer products of the last training forward (see get_simplification_loss)
         self.device_matching = True  # eval branch: nn_matching / FPS completion on the GPU (False: numpy, as the reference)
 
+    # per-step / per-attachment state that must not travel with a copy of the module (graph tensors, views of another
+    # module's gradient bucket, persistent kernel scratch)
+    _TRANSIENT = ("_scan", "_grad_sink", "_after_fc_grads", "_colmin_keys", "_colmin_keys_owner", "_fx_acc", "_fx_acc_b")
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._TRANSIENT:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._scan = None
+        return new
+
     # ------------------------------------------------------------------------------------------ MLP
     def _features(self, x, x_bnc=None):
         """PointNet feature extractor + FC head: x (B,3,N) -> y (B,3,M)   (samplenet.py:90-104)."""
