@@ -360,6 +360,18 @@ int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef
 int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,
                    float eps, float momentum, float *running_mean, float *running_var,
                    long long *num_batches_tracked, float *coef, sn_stream_t stream);
+/* The FC head's BatchNorm + ReLU layers (R <= 32 rows; a0 (R, C0) -> H -> ... -> H, nl layers) as ONE launch: the H / 32
+ * workgroups of a layer stay resident and exchange each layer's activations through xbuf with write-through stores and an
+ * arrival counter instead of ending the kernel per layer.  Per layer l: W[l] (H, K), bias, BatchNorm parameters / running
+ * statistics (training-mode update as sn_layer_forward_bn), outputs z[l] (R, H) pre-BN and coef[l] (4, H).  Bit-identical to
+ * nl calls of sn_layer_forward_bn.  xbuf: 2 * 32 * H floats of scratch; sync: 16 unsigned, PERSISTENT and zero-initialised
+ * once by the caller (epoch + monotonic arrival counters; sync[15] != 0 afterwards = a poll timed out: results invalid). */
+int sn_fc_chain_forward_supported(int R, int C0, int H, int nl);
+int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0, const float *const *W, const float *const *bias,
+                        const float *const *gamma, const float *const *beta, float *const *running_mean,
+                        float *const *running_var, long long *const *num_batches_tracked, const float *eps,
+                        const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
+                        sn_stream_t stream);
 /* sn_bn_finalize for a SHORT matrix z (R, C) (the FC head at batches above 32): statistics in two passes over z itself (mean,
  * then squares around it) instead of from sum / sum-of-squares partials -- behind the max-pool |mean| / std reaches 10..100. */
 int sn_bn_batch_stats_twopass(int R, int C, const float *z, const float *gamma, const float *beta, float eps, float momentum,

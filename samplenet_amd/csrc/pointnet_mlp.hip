@@ -1753,6 +1753,197 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
     SN_TL(5);
 }
 
+// ------------------------------------------------------------------------------------------------
+// FC head forward as ONE launch (rows R <= 32, hidden width H, nl BatchNorm + ReLU layers): the H / 32 workgroups of a layer
+// keep running and hand the layer's activations to each other through HBM instead of ending the kernel after every layer --
+// a dependent launch of an 8-workgroup kernel costs 6-9 us here (launch boundary + cold operand fetch + store drain), a seam
+// 1.2-1.8 us (tools/micro/xcd_exchange.hip).  Per workgroup: every layer's 32-column weight slice is fetched into LDS at
+// the START (all fetches in flight at once, none behind a dependency); per layer: MFMA over K split across the 4 waves ->
+// wave 0: bias, two-pass BatchNorm statistics (all rows are local), coefficients, pre-BN tile -> every thread publishes
+// 16 bytes of the ACTIVATED 32 x 32 tile with a write-through (sc1) store -> drained -> one arrival atomic -> poll -> every
+// thread gathers the full 32 x H activation with 8 sc1 16-byte loads in flight (MI355X_MICROARCH.md, inter-workgroup
+// visibility: sc1 stores + sc1 loads need no fence).  Workgroups sit on ONE XCD (grid of 8 x H/32, blocks with b % 8 != 0
+// exit: observed placement b % 8 -> XCD, a speed matter only).  Arrival counters are monotonic over launches: the epoch word
+// is read by every workgroup before its first arrival and advanced by workgroup 0 after the first seam (no reset, no host
+// involvement: safe under graph replay).  A poll that exceeds its bound sets the error word instead of hanging the GPU.
+// Arithmetic (K split, summation order, BatchNorm expressions) is that of small_fwd_lds_kernel: results are bit-identical
+// to the layer-by-layer launches.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFcChainMaxLayers = 4;
+struct FcChainLayer {
+    const float *W, *bias, *gamma, *beta;
+    float *running_mean, *running_var;
+    long long *num_batches_tracked;
+    float *z, *coef;  // outputs: pre-BN (R, H) and (4, H)
+    float eps, momentum;
+};
+struct FcChainArgs {
+    const float *a0;  // (R, C0): input of the first layer, used as is (pooled features)
+    int R, C0, H, nl;
+    FcChainLayer L[kFcChainMaxLayers];
+    float *xbuf;     // [2][32][H] exchange slabs
+    unsigned *sync;  // [0] epoch, [1 + s] arrivals at seam s, [15] error flag -- persistent, zero-initialised once
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1_b128(float *p, f32x4v v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+__global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ unsigned s_epoch;
+    if (blockIdx.x & 7) return;
+    const int wg = blockIdx.x >> 3, nwg = g.H / 32;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = g.R, H = g.H, C0 = g.C0, nl = g.nl;
+    const int LDA = (C0 > H ? C0 : H) + 4;
+    float *As = sm;                 // [32][LDA]
+    float *W0s = As + 32 * LDA;     // [32][C0 + 4]            weight slice of layer 0
+    float *Whs = W0s + 32 * (C0 + 4);  // [nl - 1][32][H + 4]  weight slices of layers 1 ..
+    float *red = Whs + (size_t)(nl - 1) * 32 * (H + 4);  // [3][16][64]
+    float *Ts = red + 3 * 16 * 64;                                         // [32][36] pre-BN tile
+    float *Ta = Ts + 32 * 36;                                              // [32][36] activated tile
+    const int col0 = wg * 32, col = col0 + l31;
+    if (tid == 0) s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- every layer's weight slice + the first operand: all fetches issued up front, staged into LDS as they land
+    {
+        const int q4 = C0 / 4, rpp = 256 / q4, npass = 32 / rpp;
+        const int c4 = (tid % q4) * 4, r0 = tid / q4;
+        for (int q = 0; q < npass; ++q) {
+            const int r = r0 + q * rpp;
+            float4 a = *reinterpret_cast<const float4 *>(g.a0 + (size_t)min(r, R - 1) * C0 + c4);
+            const float ma = r < R ? 1.f : 0.f;
+            a.x *= ma, a.y *= ma, a.z *= ma, a.w *= ma;
+            *reinterpret_cast<float4 *>(As + r * LDA + c4) = a;
+            *reinterpret_cast<float4 *>(W0s + r * (C0 + 4) + c4) =
+                *reinterpret_cast<const float4 *>(g.L[0].W + (size_t)(col0 + r) * C0 + c4);
+        }
+        const int hq4 = H / 4, hrpp = 256 / hq4, hnpass = 32 / hrpp;
+        const int hc4 = (tid % hq4) * 4, hr0 = tid / hq4;
+        for (int l = 1; l < nl; ++l)
+            for (int q = 0; q < hnpass; ++q) {
+                const int r = hr0 + q * hrpp;
+                *reinterpret_cast<float4 *>(Whs + (size_t)(l - 1) * 32 * (H + 4) + r * (H + 4) + hc4) =
+                    *reinterpret_cast<const float4 *>(g.L[l].W + (size_t)(col0 + r) * H + hc4);
+            }
+    }
+    __syncthreads();
+    const unsigned epoch = s_epoch;
+
+    for (int l = 0; l < nl; ++l) {
+        const FcChainLayer &Lr = g.L[l];
+        const int K = l == 0 ? C0 : H, LDW = K + 4;
+        // epilogue inputs first (their latency hides under the MFMAs)
+        const float bias = Lr.bias[col], bn_g = Lr.gamma[col], bn_b = Lr.beta[col];
+        float bn_rm = 0.f, bn_rv = 0.f;
+        if (Lr.running_mean) bn_rm = Lr.running_mean[col], bn_rv = Lr.running_var[col];
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const int kph = K / 8, kb = wave * (K / 4) + h * kph;
+        const float *wsl = l == 0 ? W0s : Whs + (size_t)(l - 1) * 32 * (H + 4);
+        const float *ap = As + l31 * LDA + kb, *bp = wsl + l31 * LDW + kb;
+        for (int t = 0; t < kph; t += 4) {
+            const float4 a = *reinterpret_cast<const float4 *>(ap + t), b = *reinterpret_cast<const float4 *>(bp + t);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+        wave_sum_to_wave0(acc, red);
+        if (wave == 0) {
+            float s0 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = acc[e] + bias;
+                if (frag_row(e, lane) < R) s0 += v;
+            }
+            s0 += __shfl_xor(s0, 32);
+            const float meanf = s0 / (float)R;
+            float s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = (acc[e] + bias) - meanf;
+                if (frag_row(e, lane) < R) s2 += d * d;
+            }
+            s2 += __shfl_xor(s2, 32);
+            const double mean = (double)s0 / (double)R;
+            const double dm = mean - (double)meanf;
+            double var = (double)s2 / (double)R - dm * dm;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)Lr.eps));
+            const float sc = bn_g * invstd, sh = bn_b - (float)mean * sc;
+            if (lane < 32) {
+                Lr.coef[col] = sc, Lr.coef[H + col] = sh, Lr.coef[2 * H + col] = (float)mean, Lr.coef[3 * H + col] = invstd;
+                if (Lr.running_mean) {
+                    const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+                    Lr.running_mean[col] = (1.f - Lr.momentum) * bn_rm + Lr.momentum * (float)mean;
+                    Lr.running_var[col] = (1.f - Lr.momentum) * bn_rv + Lr.momentum * (float)unbiased;
+                }
+                if (wg == 0 && lane == 0 && Lr.num_batches_tracked) *Lr.num_batches_tracked += 1;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = frag_row(e, lane);
+                const float v = acc[e] + bias;
+                Ts[row * 36 + l31] = v;
+                Ta[row * 36 + l31] = row < R ? relu_np(fmaf(v, sc, sh)) : 0.f;
+            }
+        }
+        __syncthreads();
+        // the 32 x 32 tiles leave as 16-byte stores: thread -> (row = tid / 8, 4 columns at (tid % 8) * 4)
+        const int trow = tid >> 3, tc4 = (tid & 7) * 4;
+        if (trow < R) *reinterpret_cast<float4 *>(Lr.z + (size_t)trow * H + col0 + tc4) = *reinterpret_cast<const float4 *>(Ts + trow * 36 + tc4);
+        if (l == nl - 1) break;
+        float *xb = g.xbuf + (size_t)(l & 1) * 32 * H;
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(Ta + trow * 36 + tc4);
+            f32x4v vv = {v.x, v.y, v.z, v.w};
+            store_sc1_b128(xb + (size_t)trow * H + col0 + tc4, vv);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(g.sync + 1 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (epoch + 1u) * (unsigned)nwg;
+            int spins = 0;
+            while ((int)(__hip_atomic_load(g.sync + 1 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                if (++spins > (1 << 22)) {  // never on a healthy run: report instead of hanging the device
+                    __hip_atomic_store(g.sync + 15, 1u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (l == 0 && wg == 0) __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // gather the whole 32 x H activation (write-through data: sc1 loads read it from L2 / memory, never from a stale L1 line)
+        {
+            const int hq4 = H / 4;
+            f32x4v r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i;
+                const float *p = xb + (size_t)(idx / hq4) * H + (idx % hq4) * 4;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[i]) : "v"(p) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < 32 * hq4)
+                    *reinterpret_cast<float4 *>(As + (idx / hq4) * LDA + (idx % hq4) * 4) = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int ZMODE, int PMODE, bool VEC>
 __device__ __forceinline__ void small_dgrad_body(const DgradArgs &g, int bx, float *lds)
 {
@@ -2633,8 +2824,7 @@ static void launch_fwd(const FwdArgs &g, hipStream_t st)
         return;
     }
     if (R <= 32) {
-        static const bool use_lds = !(getenv("SN_SMALL_FWD_DIRECT") && getenv("SN_SMALL_FWD_DIRECT")[0] == '1');
-        if (use_lds && Ci % 64 == 0 && Ci <= 512) {
+        if (Ci % 64 == 0 && Ci <= 512) {
             const size_t lds = ((size_t)64 * (Ci + 4) + 3 * 16 * 64 + 32 * 36) * sizeof(float);
             static bool attr_done = false;
             if (!attr_done) {
@@ -2712,6 +2902,48 @@ extern "C" int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, cons
 // pooled / argsel / zsel as sn_pool_forward.  pool_val (floats) / pool_idx (ints): scratch of sn_linear_stats_blocks(R)*2*Co
 // elements each.  Needs R % 64 == 0, npts % 64 == 0, Co % 64 == 0, Ci % 64 == 0 (else SN_ERR_UNSUPPORTED: call
 // sn_layer_forward_bn + sn_pool_forward).
+static size_t fc_chain_fwd_lds(int C0, int H, int nl)
+{
+    const int LDA = (C0 > H ? C0 : H) + 4;
+    return ((size_t)32 * LDA + (size_t)32 * (C0 + 4) + (size_t)(nl - 1) * 32 * (H + 4) + 3 * 16 * 64 + 2 * 32 * 36) * sizeof(float);
+}
+
+// 1: sn_fc_chain_forward runs this FC head (R rows, C0 -> H -> ... -> H, nl BatchNorm + ReLU layers) as one launch
+extern "C" int sn_fc_chain_forward_supported(int R, int C0, int H, int nl)
+{
+    return R >= 1 && R <= 32 && nl >= 2 && nl <= kFcChainMaxLayers && H == 256 && (C0 == 64 || C0 == 128 || C0 == 256) &&
+           fc_chain_fwd_lds(C0, H, nl) <= (size_t)160 * 1024 - 64;
+}
+
+extern "C" int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0, const float *const *W, const float *const *bias,
+                                   const float *const *gamma, const float *const *beta, float *const *running_mean,
+                                   float *const *running_var, long long *const *num_batches_tracked, const float *eps,
+                                   const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
+                                   sn_stream_t stream)
+{
+    SN_REQUIRE(sn_fc_chain_forward_supported(R, C0, H, nl), "shape not supported (sn_fc_chain_forward_supported)");
+    SN_REQUIRE(a0 && W && bias && gamma && beta && eps && momentum && z && coef && xbuf && sync, "null pointer");
+    FcChainArgs g{};
+    g.a0 = a0, g.R = R, g.C0 = C0, g.H = H, g.nl = nl, g.xbuf = xbuf, g.sync = sync;
+    for (int l = 0; l < nl; ++l) {
+        SN_REQUIRE(W[l] && bias[l] && gamma[l] && beta[l] && z[l] && coef[l], "null layer pointer");
+        g.L[l] = FcChainLayer{W[l], bias[l], gamma[l], beta[l], running_mean ? running_mean[l] : nullptr,
+                              running_var ? running_var[l] : nullptr, num_batches_tracked ? num_batches_tracked[l] : nullptr,
+                              z[l], coef[l], eps[l], momentum[l]};
+    }
+    const size_t lds = fc_chain_fwd_lds(C0, H, nl);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        if (hipFuncSetAttribute((const void *)fc_chain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sn_set_error(SN_ERR_UNSUPPORTED, "sn_fc_chain_forward: %zu bytes of LDS refused", lds);
+        attr_lds = lds;
+    }
+    // 8 x (H / 32) blocks: block b lands on XCD b % 8, the b % 8 == 0 ones do the work -- all on one XCD (same L2)
+    hipLaunchKernelGGL(fc_chain_fwd_kernel, dim3(8 * (H / 32)), dim3(256), lds, (hipStream_t)stream, g);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
                                        const float *bias, float *z, float *stats, const float *gamma, const float *beta,
                                        float eps, float momentum, float *running_mean, float *running_var,

@@ -187,6 +187,43 @@ def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel):
     return True
 
 
+def _fc_chain_fwd(net, hidden, pooled, B, saved):
+    """The FC head's BatchNorm + ReLU layers as one launch (sn_fc_chain_forward).  Fills saved["zf"] / saved["cf"]; returns
+    False when the shape is not supported (the per-layer launches run instead)."""
+    import ctypes
+
+    n = len(hidden)
+    if n < 2 or any(L.bn is None or L.bn.momentum is None or not L.bn.track_running_stats for L in hidden):
+        return False
+    H, C0 = hidden[0].Co, hidden[0].Ci
+    if any(L.Co != H for L in hidden) or any(L.Ci != H for L in hidden[1:]):
+        return False
+    if not lib.sn_fc_chain_forward_supported(B, C0, H, n):
+        return False
+    sync = getattr(net, "_fc_sync", None)
+    if sync is None or sync.device != pooled.device:
+        sync = torch.zeros(16, device=pooled.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
+        net._fc_sync = sync
+    xbuf = _empty((2 * 32 * H,), pooled)
+    zs = [_empty((B, H), pooled) for _ in hidden]
+    cs = [_empty((4, H), pooled) for _ in hidden]
+    VP = ctypes.c_void_p * n
+
+    def arr(ts):
+        return VP(*[ptr(t) for t in ts])
+
+    eps = (ctypes.c_float * n)(*[float(L.bn.eps) for L in hidden])
+    mom = (ctypes.c_float * n)(*[float(L.bn.momentum) for L in hidden])
+    check(lib.sn_fc_chain_forward(B, C0, H, n, ptr(pooled), arr([L.W for L in hidden]), arr([L.b for L in hidden]),
+                                  arr([L.bn.weight for L in hidden]), arr([L.bn.bias for L in hidden]),
+                                  arr([L.bn.running_mean for L in hidden]), arr([L.bn.running_var for L in hidden]),
+                                  arr([L.bn.num_batches_tracked for L in hidden]), eps, mom, arr(zs), arr(cs), ptr(xbuf),
+                                  ptr(sync), _st(pooled)), "sn_fc_chain_forward")
+    saved["zf"], saved["cf"] = zs, cs
+    saved["fc_xbuf"] = xbuf  # (kept until backward: the launch reads it asynchronously)
+    return True
+
+
 def forward_impl(net, x_bnc, training, skip_last=False):
     """x (B,N,3) contiguous -> y (B, 3*M) and the tensors backward needs.
     skip_last: stop before fc4 and return None for y -- the caller produces it from saved["zf"][2] / saved["cf"][2] (the
@@ -221,7 +258,11 @@ def forward_impl(net, x_bnc, training, skip_last=False):
               "sn_pool_forward")
     saved.update(pooled=pooled, argsel=argsel, zsel=zsel)
     a_in, coef_prev = pooled, None
-    for L in fcs[:-1]:
+    hidden = fcs[:-1]
+    if training and FC_CHAIN and _fc_chain_fwd(net, hidden, pooled, B, saved):
+        a_in, coef_prev = saved["zf"][-1], saved["cf"][-1]
+        hidden = []
+    for L in hidden:
         if L.bn is None:  # ReLU layer without BatchNorm
             z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False)
             coef = _identity_coef(L.Co, z)
@@ -314,6 +355,7 @@ def _out(sink, name, like):
 FX_STATS = True
 IN3_CLOSED_FORM = True
 FUSE_POOL = True
+FC_CHAIN = True  # the FC head's hidden layers as one launch with in-kernel hand-offs (sn_fc_chain_forward)
 
 
 def _wgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, aprev, coef_prev, with_bias, sink=None, name=""):

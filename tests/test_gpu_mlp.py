@@ -503,3 +503,35 @@ def test_sampler_variants_vs_torch(variant, B, N, M, K):
         with torch.no_grad():
             net.project._temperature.fill_(-0.3)
         assert abs(float(net.get_projection_loss()) - 1e-4) < 1e-9  # max(T, 1e-2)^2
+
+
+@pytest.mark.parametrize("B,bneck", [(32, 128), (4, 128), (17, 256), (32, 64)])
+def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
+    """sn_fc_chain_forward (the FC head's three BatchNorm + ReLU layers as ONE launch, activations handed between the
+    resident workgroups through write-through stores + arrival counters) against the layer-by-layer launches: pre-BN outputs,
+    BatchNorm coefficients, running statistics and the head's output bit for bit; repeated calls (monotonic epoch counters)
+    and the error word stays clear."""
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(B + bneck)
+    net_a = SampleNet(64, bneck, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    xs = [(torch.rand(B, 256, 3, device="cuda") - 0.5).contiguous() for _ in range(4)]
+    old = pointnet.FC_CHAIN
+    try:
+        for x in xs:
+            pointnet.FC_CHAIN = True
+            ya, sa = pointnet.forward_impl(net_a, x, True)
+            pointnet.FC_CHAIN = False
+            yb, sb = pointnet.forward_impl(net_b, x, True)
+            assert "fc_xbuf" in sa and "fc_xbuf" not in sb
+            for l in range(3):
+                assert torch.equal(sa["zf"][l], sb["zf"][l]), l
+                assert torch.equal(sa["cf"][l], sb["cf"][l]), l
+            assert torch.equal(ya, yb)
+    finally:
+        pointnet.FC_CHAIN = old
+    torch.cuda.synchronize()
+    assert int(net_a._fc_sync[15]) == 0 and int(net_a._fc_sync[0]) == len(xs)
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), n
