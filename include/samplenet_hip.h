@@ -372,6 +372,21 @@ int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0, const flo
                         float *const *running_var, long long *const *num_batches_tracked, const float *eps,
                         const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
                         sn_stream_t stream);
+/* The FC head's backward (R <= 32 rows) as ONE launch, the mirror of sn_fc_chain_forward.  Stage s = GEMM layer, TOP first:
+ * W[s] (Co[s], Ci[s]); below it: zprev[s] (R, Ci[s]) pre-BN output seen through coefprev[s] (4, Ci[s]) (the pooled-feature
+ * stage: zsel with the last conv layer's coefficients and bn_rows[s] = B * N; bn_rows < 0: fixed statistics); outputs per
+ * stage: dW[s], the layer below's dgamma / dbeta / dbias; db_top: bias gradient of the top layer; aprev[s] / araw[s]: the
+ * weight-gradient operand (zprev with ReLU(BN) applied, or a raw input such as the pooled features).  Last stage also
+ * returns gout (R, Ci) = the masked gradient and kout (3, Ci) = the dZ coefficients of the BatchNorm below (what
+ * sn_conv_stack_backward takes as gsel / kcoef_top).  gy: (R, Co[0]).  Bit-identical to the sn_layer_backward chain.
+ * xbuf: ns * 32 * 256 floats of scratch; sync: 16 unsigned of its OWN persistent zero-initialised state (launch epoch, one
+ * monotonic arrival counter per stage, epoch-reader count; sync[15] != 0 afterwards = a poll timed out: results invalid). */
+int sn_fc_chain_backward_supported(int R, int ns, const int *Co, const int *Ci);
+int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci, const float *gy, const float *const *W,
+                         const float *const *zprev, const float *const *coefprev, const long long *bn_rows,
+                         float *const *dgamma, float *const *dbeta, float *const *dbias, float *const *dW, float *db_top,
+                         const float *const *aprev, const int *araw, float *gout, float *kout, float *xbuf,
+                         unsigned *sync, sn_stream_t stream);
 /* sn_bn_finalize for a SHORT matrix z (R, C) (the FC head at batches above 32): statistics in two passes over z itself (mean,
  * then squares around it) instead of from sum / sum-of-squares partials -- behind the max-pool |mean| / std reaches 10..100. */
 int sn_bn_batch_stats_twopass(int R, int C, const float *z, const float *gamma, const float *beta, float eps, float momentum,

@@ -1788,7 +1788,10 @@ struct FcChainArgs {
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_sc1_b128(float *p, f32x4v v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // s_nop: a VMEM store of more than 8 bytes still reads its upper data registers for a few cycles after issue; the compiler
+    // pads that hazard for its own instructions but cannot see into inline asm (observed: bytes 8..15 of the store corrupted in
+    // the lanes whose data registers the next VALU instruction rewrote)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(p), "v"(v) : "memory");
 }
 
 __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
@@ -2033,6 +2036,316 @@ __device__ __forceinline__ void small_dgrad_body(const DgradArgs &g, int bx, flo
         g.bb.kcoef[col] = k1, g.bb.kcoef[Ci + col] = k2, g.bb.kcoef[2 * Ci + col] = k3;
         if (g.bb.dbias)
             g.bb.dbias[col] = (float)((double)k1 * s + (double)k2 * (double)g.bb.R * mean + (double)g.bb.R * (double)k3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FC head backward as ONE launch (rows R <= 32, every width <= 256): the mirror of fc_chain_fwd_kernel.  Stage s is the
+// backward of GEMM layer l (top layer first).  16 resident workgroups on one XCD in two roles:
+//   * 8 DATA-GRADIENT workgroups form the dependency chain: workgroup j owns columns [32 j, 32 j + 32) -- dZ_l (32 x Co, in
+//     LDS) times the column slice of W_l (staged TRANSPOSED in LDS, fetched one stage ahead), ReLU mask and BatchNorm backward
+//     of the layer below in wave 0's epilogue (statistics are per column over the rows: local) -> its 32 x 32 tile of
+//     dZ_{l-1} leaves as write-through stores into the stage's own slab, drained, one arrival atomic; poll; gather dZ_{l-1}.
+//   * 8 WEIGHT-GRADIENT workgroups hang off that chain without being on it: workgroup j waits for the stage's arrivals, takes
+//     tile j of dZ_l (stage 0: straight from the incoming gradient) and computes rows [32 j, 32 j + 32) of
+//     dW_l = dZ_l^T . A_{l-1} (operands of A_{l-1} prefetched from the forward's tensors), one wave per 32 x 32 tile.
+// Splitting the roles matters because ONE CU moves only ~50-100 GB/s: with both jobs on the same 8 CUs every stage pulled
+// ~160 KB through one CU and the launch was no faster than the four it replaces (measured 36 us); the chain workgroups now
+// move ~70 KB per stage.  Nothing but the parameter gradients, the pooled-feature gradient (gsel) and the top conv
+// BatchNorm's dZ coefficients goes back to HBM as tensors.  Synchronisation: one slab and one monotonic arrival counter per
+// stage (no reuse inside a launch); the launch epoch (sync[0]) is read by all 16 workgroups, each confirms on sync[14], and
+// chain workgroup 0 advances it at its end once all 16 confirmations are in.  Arithmetic (K split over the waves, MFMA order,
+// epilogue expressions) is that of small_dgrad_body / small_wgrad_body.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFcBwdMaxStages = 5;
+struct FcBwdStage {
+    const float *W;  // (Co, Ci) of the layer this stage differentiates
+    int Co, Ci;
+    const float *zprev, *coefprev;  // layer below: pre-BN output (R, Ci) at this layer's inputs and its (4, Ci) coefficients
+    long long bn_rows;              // rows the BatchNorm below averaged over (R, B * N behind the max-pool, < 0: fixed statistics)
+    float *dgamma, *dbeta, *dbias;  // of the layer below
+    float *dW, *db;                 // of this layer (db: top layer only)
+    const float *aprev;             // wgrad operand: zprev (relu(bn(.)) applied) or, araw != 0, the raw input (pooled features)
+    int araw;
+    float *gout, *kout;  // optional (last stage): masked gradient (R, Ci) and kcoef (3, Ci) of the layer below to HBM
+};
+struct FcBwdArgs {
+    const float *gy;  // (R, Co of stage 0): gradient w.r.t. the head's output
+    int R, ns;
+    FcBwdStage S[kFcBwdMaxStages];
+    float *xbuf;     // [ns][32][256] hand-off slabs, one per stage
+    unsigned *sync;  // [0] epoch, [1 + s] arrivals of stage s, [14] epoch readers, [15] error flag -- persistent, zeroed once
+};
+
+__device__ __forceinline__ bool fc_wait_arrivals(unsigned *ctr, unsigned target)
+{
+    int spins = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (++spins > (1 << 22)) return false;  // never on a healthy run: report instead of hanging the device
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ unsigned s_epoch;
+    if (blockIdx.x & 7) return;
+    const int wgi = blockIdx.x >> 3;  // 0..7 data-gradient chain, 8..15 weight gradients
+    constexpr int NWG = 8, LD = 256 + 4;
+    const bool chain = wgi < NWG;
+    const int wg = chain ? wgi : wgi - NWG;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = g.R, ns = g.ns;
+    const int col0 = wg * 32, col = col0 + l31;
+    if (tid == 0) {
+        s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(g.sync + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned epoch = s_epoch;
+    const unsigned target = (epoch + 1u) * (unsigned)NWG;
+
+    if (!chain) {
+        // ================================================================== weight-gradient workgroup
+        float *Tz = sm;            // [32][36] tile wg of dZ_l
+        float *Tw = sm + 32 * 36;  // [4][32][36] output tiles on their way out
+        for (int s = 0; s < ns; ++s) {
+            const FcBwdStage &S = g.S[s];
+            const int Co = S.Co, Ci = S.Ci, tiles_n = Ci / 32;
+            if (col0 >= Co) continue;  // (this layer has fewer than 32 (wg + 1) outputs)
+            // operand tiles of A_{l-1} first: they do not depend on the chain
+            float bw[2][16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int tn = wave + 4 * i;
+                if (tn < tiles_n) {
+                    const int n = tn * 32 + l31;
+                    float sc = 1.f, sh = 0.f;
+                    if (!S.araw) sc = S.coefprev[n], sh = S.coefprev[Ci + n];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int r = h * 16 + t;
+                        float v = S.aprev[(size_t)(r < R ? r : 0) * Ci + n];
+                        if (!S.araw) v = relu_np(fmaf(v, sc, sh));
+                        bw[i][t] = r < R ? v : 0.f;
+                    }
+                }
+            }
+            // tile wg of dZ_l: stage 0 from the incoming gradient, else from the slab the chain filled in stage s - 1
+            const int trow = tid >> 3, tc4 = (tid & 7) * 4;
+            if (s == 0) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (trow < R) v = *reinterpret_cast<const float4 *>(g.gy + (size_t)trow * Co + col0 + tc4);
+                *reinterpret_cast<float4 *>(Tz + trow * 36 + tc4) = v;
+            } else {
+                if (tid == 0 && !fc_wait_arrivals(g.sync + s, target))  // sync[1 + (s - 1)]
+                    __hip_atomic_store(g.sync + 15, 16u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const float *p = g.xbuf + (size_t)(s - 1) * 32 * 256 + (size_t)trow * Co + col0 + tc4;
+                f32x4v v;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+                *reinterpret_cast<float4 *>(Tz + trow * 36 + tc4) = make_float4(v.x, v.y, v.z, v.w);
+            }
+            __syncthreads();
+            float a[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a[t] = Tz[(h * 16 + t) * 36 + l31];
+            float *T = Tw + wave * 32 * 36;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int tn = wave + 4 * i;
+                if (tn < tiles_n) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bw[i][t], acc, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) T[frag_row(e, lane) * 36 + l31] = acc[e];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rt = 8 * q + (lane >> 3);
+                        *reinterpret_cast<float4 *>(S.dW + (size_t)(col0 + rt) * Ci + tn * 32 + (lane & 7) * 4) =
+                            *reinterpret_cast<const float4 *>(T + rt * 36 + (lane & 7) * 4);
+                    }
+                }
+            }
+            if (S.db && wave == 0) {  // bias gradient of the top layer: the ones-column MFMA of small_wgrad_body
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], (l31 == 0 && h * 16 + t < R) ? 1.f : 0.f, acc, 0, 0, 0);
+                if (l31 == 0)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) S.db[col0 + frag_row(e, lane)] = acc[e];
+            }
+            __syncthreads();  // Tz is rewritten by the next stage
+        }
+        return;
+    }
+
+    // ====================================================================== data-gradient chain workgroup
+    float *dZs = sm;                 // [32][LD]   dZ of the current layer, all columns
+    float *Wt0 = dZs + 32 * LD;      // [2][32][LD] transposed weight slices (ci within the tile, co)
+    float *red = Wt0 + 2 * 32 * LD;  // [3][16][64]
+    float *Ta = red + 3 * 16 * 64;   // [32][36]   this workgroup's tile of dZ of the layer below
+    // ---- stage 0 operands: dZ of the top layer straight from HBM, its weight slice (transposed)
+    {
+        const FcBwdStage &S = g.S[0];
+        const int q4 = S.Co / 4;  // float4 per row
+        for (int idx = tid; idx < 32 * q4; idx += 256) {
+            const int r = idx / q4, c4 = (idx % q4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R) v = *reinterpret_cast<const float4 *>(g.gy + (size_t)r * S.Co + c4);
+            *reinterpret_cast<float4 *>(dZs + r * LD + c4) = v;
+        }
+        if (col0 < S.Ci)
+            for (int idx = tid; idx < S.Co * 8; idx += 256) {
+                const int co = idx >> 3, c4 = (idx & 7) * 4;
+                const float4 w = *reinterpret_cast<const float4 *>(S.W + (size_t)co * S.Ci + col0 + c4);
+                Wt0[(c4 + 0) * LD + co] = w.x, Wt0[(c4 + 1) * LD + co] = w.y, Wt0[(c4 + 2) * LD + co] = w.z, Wt0[(c4 + 3) * LD + co] = w.w;
+            }
+    }
+    __syncthreads();
+
+    for (int s = 0; s < ns; ++s) {
+        const FcBwdStage &S = g.S[s];
+        const int Co = S.Co, Ci = S.Ci;
+        const bool has_tile = col0 < Ci, more = s + 1 < ns;
+        float *Wt = Wt0 + (size_t)(s & 1) * 32 * LD, *Wtn = Wt0 + (size_t)((s + 1) & 1) * 32 * LD;
+        // ---- prefetches: next stage's weight slice; wave 0: the epilogue's inputs
+        float4 wn[8];
+        bool next_tile = false;
+        int nCo = 0, nCi = 0;
+        if (more) {
+            const FcBwdStage &N = g.S[s + 1];
+            nCo = N.Co, nCi = N.Ci;
+            next_tile = col0 < nCi;
+            if (next_tile)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int idx = tid + 256 * i;
+                    if (idx < nCo * 8) wn[i] = *reinterpret_cast<const float4 *>(N.W + (size_t)(idx >> 3) * nCi + col0 + (idx & 7) * 4);
+                }
+        }
+        float zpv[16], esc = 0.f, esh = 0.f, pmean = 0.f, pinv = 0.f;
+        if (has_tile && wave == 0) {
+            esc = S.coefprev[col], esh = S.coefprev[Ci + col], pmean = S.coefprev[2 * Ci + col], pinv = S.coefprev[3 * Ci + col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = frag_row(e, lane);
+                zpv[e] = S.zprev[row < R ? (size_t)row * Ci + col : 0];
+            }
+        }
+        // ---- data gradient tile
+        if (has_tile) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int k0 = wave * 2 * KP; k0 < Co; k0 += 4 * 2 * KP) {
+                const int kb = k0 + h * KP;
+                const float *ap = dZs + l31 * LD + kb, *bp = Wt + l31 * LD + kb;
+#pragma unroll
+                for (int t = 0; t < KP; t += 4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(ap + t), b = *reinterpret_cast<const float4 *>(bp + t);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+                }
+            }
+            wave_sum_to_wave0(acc, red);
+            if (wave == 0) {
+                float s0 = 0.f, s1c = 0.f, gv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = frag_row(e, lane);
+                    float v = 0.f;
+                    if (row < R) {
+                        v = (fmaf(zpv[e], esc, esh) > 0.f) ? acc[e] : 0.f;
+                        s0 += v;
+                        s1c += v * (zpv[e] - pmean);
+                    }
+                    gv[e] = v;
+                }
+                s0 += __shfl_xor(s0, 32);
+                s1c += __shfl_xor(s1c, 32);
+                const double scale = esc, mean = pmean, invstd = pinv, sd = s0;
+                const double dg = invstd * (double)s1c;
+                const double rinv = S.bn_rows > 0 ? 1.0 / (double)S.bn_rows : 0.0;
+                const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
+                const float k3 = (float)(scale * (invstd * mean * dg * rinv - sd * rinv));
+                if (lane < 32) {
+                    S.dgamma[col] = (float)dg, S.dbeta[col] = (float)sd;
+                    if (S.dbias)
+                        S.dbias[col] = (float)((double)k1 * sd + (double)k2 * (double)S.bn_rows * mean + (double)S.bn_rows * (double)k3);
+                    if (S.kout) S.kout[col] = k1, S.kout[Ci + col] = k2, S.kout[2 * Ci + col] = k3;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = frag_row(e, lane);
+                    if (S.gout && row < R) S.gout[(size_t)row * Ci + col] = gv[e];
+                    Ta[row * 36 + l31] = row < R ? fmaf(k1, gv[e], fmaf(k2, zpv[e], k3)) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (!more) break;
+        // ---- hand the tile of dZ of the layer below over (write-through), drained, then arrive
+        float *xb = g.xbuf + (size_t)s * 32 * 256;
+        if (has_tile) {
+            const int trow = tid >> 3, tc4 = (tid & 7) * 4;
+            const float4 v = *reinterpret_cast<const float4 *>(Ta + trow * 36 + tc4);
+            f32x4v vv = {v.x, v.y, v.z, v.w};
+            store_sc1_b128(xb + (size_t)trow * Ci + col0 + tc4, vv);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(g.sync + 1 + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- next stage's weight slice into the other LDS buffer while the others arrive
+        if (next_tile)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < nCo * 8) {
+                    const int co = idx >> 3, c4 = (idx & 7) * 4;
+                    Wtn[(c4 + 0) * LD + co] = wn[i].x, Wtn[(c4 + 1) * LD + co] = wn[i].y;
+                    Wtn[(c4 + 2) * LD + co] = wn[i].z, Wtn[(c4 + 3) * LD + co] = wn[i].w;
+                }
+            }
+        if (tid == 0 && !fc_wait_arrivals(g.sync + 1 + s, target))
+            __hip_atomic_store(g.sync + 15, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        {   // gather dZ of the layer below (32 x Ci; Ci = 256: 8 loads per thread, 128: 4)
+            const int q4 = Ci / 4, nld = (32 * q4) / 256;
+            f32x4v r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nld) {
+                    const int idx = tid + 256 * i;
+                    const float *p = xb + (size_t)(idx / q4) * Ci + (idx % q4) * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[i]) : "v"(p) : "memory");
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < nld) {
+                    const int idx = tid + 256 * i;
+                    *reinterpret_cast<float4 *>(dZs + (idx / q4) * LD + (idx % q4) * 4) = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
+                }
+        }
+        __syncthreads();
+    }
+    // the next launch may only see the advanced epoch once all 16 workgroups of this one have read the current value
+    if (wgi == 0 && tid == 0) {
+        if (!fc_wait_arrivals(g.sync + 14, (epoch + 1u) * 16u))
+            __hip_atomic_store(g.sync + 15, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2940,6 +3253,49 @@ extern "C" int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0
     }
     // 8 x (H / 32) blocks: block b lands on XCD b % 8, the b % 8 == 0 ones do the work -- all on one XCD (same L2)
     hipLaunchKernelGGL(fc_chain_fwd_kernel, dim3(8 * (H / 32)), dim3(256), lds, (hipStream_t)stream, g);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// 1: sn_fc_chain_backward runs this FC head's backward (ns GEMM layers, top first: Co[s] x Ci[s]) as one launch
+extern "C" int sn_fc_chain_backward_supported(int R, int ns, const int *Co, const int *Ci)
+{
+    if (R < 1 || R > 32 || ns < 2 || ns > kFcBwdMaxStages || !Co || !Ci) return 0;
+    for (int s = 0; s < ns; ++s) {
+        if (Co[s] < 64 || Co[s] > 256 || Co[s] % 64 || Ci[s] < 32 || Ci[s] > 256 || Ci[s] % 32) return 0;
+        if (s > 0 && Co[s] != Ci[s - 1]) return 0;
+        if (s + 1 < ns && Ci[s] != 256) return 0;  // the hand-off slabs and the gather are sized for 256 columns
+    }
+    return 1;
+}
+
+extern "C" int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci, const float *gy, const float *const *W,
+                                    const float *const *zprev, const float *const *coefprev, const long long *bn_rows,
+                                    float *const *dgamma, float *const *dbeta, float *const *dbias, float *const *dW, float *db_top,
+                                    const float *const *aprev, const int *araw, float *gout, float *kout, float *xbuf,
+                                    unsigned *sync, sn_stream_t stream)
+{
+    SN_REQUIRE(sn_fc_chain_backward_supported(R, ns, Co, Ci), "shape not supported (sn_fc_chain_backward_supported)");
+    SN_REQUIRE(gy && W && zprev && coefprev && bn_rows && dgamma && dbeta && dbias && dW && aprev && araw && xbuf && sync, "null pointer");
+    FcBwdArgs g{};
+    g.gy = gy, g.R = R, g.ns = ns, g.xbuf = xbuf, g.sync = sync;
+    for (int s = 0; s < ns; ++s) {
+        SN_REQUIRE(W[s] && zprev[s] && coefprev[s] && dgamma[s] && dbeta[s] && dW[s] && aprev[s], "null stage pointer");
+        FcBwdStage &S = g.S[s];
+        S.W = W[s], S.Co = Co[s], S.Ci = Ci[s], S.zprev = zprev[s], S.coefprev = coefprev[s], S.bn_rows = bn_rows[s];
+        S.dgamma = dgamma[s], S.dbeta = dbeta[s], S.dbias = dbias[s], S.dW = dW[s], S.db = s == 0 ? db_top : nullptr;
+        S.aprev = aprev[s], S.araw = araw[s];
+        S.gout = s == ns - 1 ? gout : nullptr, S.kout = s == ns - 1 ? kout : nullptr;
+    }
+    const size_t lds = ((size_t)3 * 32 * 260 + 3 * 16 * 64 + 32 * 36) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)fc_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sn_set_error(SN_ERR_UNSUPPORTED, "sn_fc_chain_backward: %zu bytes of LDS refused", lds);
+        attr_done = true;
+    }
+    // 128 blocks: b % 8 == 0 -> XCD 0; b / 8 = 0..7 the chain, 8..15 the weight-gradient workgroups
+    hipLaunchKernelGGL(fc_chain_bwd_kernel, dim3(128), dim3(256), lds, (hipStream_t)stream, g);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -220,7 +220,7 @@ def _fc_chain_fwd(net, hidden, pooled, B, saved):
                                   arr([L.bn.num_batches_tracked for L in hidden]), eps, mom, arr(zs), arr(cs), ptr(xbuf),
                                   ptr(sync), _st(pooled)), "sn_fc_chain_forward")
     saved["zf"], saved["cf"] = zs, cs
-    saved["fc_xbuf"] = xbuf  # (kept until backward: the launch reads it asynchronously)
+    saved["fc_chain"] = xbuf  # (scratch of the asynchronous launch)
     return True
 
 
@@ -482,6 +482,67 @@ def _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef_top, sink, grads, names_c,
     return True
 
 
+def _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed):
+    """The FC head's backward as one launch (sn_fc_chain_backward).  Fills `grads` for every FC parameter and for the last
+    conv layer's BatchNorm / bias; returns (gsel, kcoef_top) for the conv stack's backward, or False when the shape is not
+    supported (the per-layer launches run instead)."""
+    import ctypes
+
+    nf = len(fcs)
+    B, R = saved["B"], saved["B"] * saved["N"]
+    Co = (ctypes.c_int * nf)(*[fcs[j].Co for j in range(nf - 1, -1, -1)])
+    Ci = (ctypes.c_int * nf)(*[fcs[j].Ci for j in range(nf - 1, -1, -1)])
+    if nf > 5 or not lib.sn_fc_chain_backward_supported(B, nf, Co, Ci):
+        return False
+    zf, cf, cc = saved["zf"], saved["cf"], saved["cc"]
+    like = grad_y
+    sync = getattr(net, "_fc_sync_b", None)
+    if sync is None or sync.device != like.device:
+        sync = torch.zeros(16, device=like.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
+        net._fc_sync_b = sync
+    xbuf = _empty((nf * 32 * 256,), like)
+    L5 = convs[-1]
+    C5 = L5.Co
+    gsel, kcoef = _empty((B, C5), like), _empty((3, C5), like)
+    W, zprev, coefprev, rows, dg, dbt, dbs, dW, aprev, araw = [], [], [], [], [], [], [], [], [], []
+    keep = []
+    for j in range(nf - 1, -1, -1):
+        L = fcs[j]
+        W.append(L.W)
+        dW.append(_out(sink, L.name + ".weight", L.W))
+        grads[L.name + ".weight"] = dW[-1]
+        if j > 0:
+            Lp = fcs[j - 1]
+            zprev.append(zf[j - 1]), coefprev.append(cf[j - 1]), aprev.append(zf[j - 1]), araw.append(0)
+            rows.append(-1 if (fixed or Lp.bn is None) else B)
+            if Lp.bn is not None:
+                dg.append(_out(sink, Lp.bn_name + ".weight", Lp.bn.weight)), dbt.append(_out(sink, Lp.bn_name + ".bias", Lp.bn.bias))
+                grads[Lp.bn_name + ".weight"], grads[Lp.bn_name + ".bias"] = dg[-1], dbt[-1]
+            else:  # identity coefficients: nothing to learn there
+                dg.append(_empty((Lp.Co,), like)), dbt.append(_empty((Lp.Co,), like))
+                keep += [dg[-1], dbt[-1]]
+            dbs.append(_out(sink, Lp.name + ".bias", Lp.b))
+            grads[Lp.name + ".bias"] = dbs[-1]
+        else:  # fc1 sits on the max-pool: the layer "below" is the last conv layer seen through the selected points
+            zprev.append(saved["zsel"]), coefprev.append(cc[-1]), aprev.append(saved["pooled"]), araw.append(1)
+            rows.append(-1 if fixed else R)
+            dg.append(_out(sink, L5.bn_name + ".weight", L5.bn.weight)), dbt.append(_out(sink, L5.bn_name + ".bias", L5.bn.bias))
+            dbs.append(_out(sink, L5.name + ".bias", L5.b))
+            grads[L5.bn_name + ".weight"], grads[L5.bn_name + ".bias"], grads[L5.name + ".bias"] = dg[-1], dbt[-1], dbs[-1]
+    db_top = _out(sink, fcs[-1].name + ".bias", fcs[-1].b)
+    grads[fcs[-1].name + ".bias"] = db_top
+    VP = ctypes.c_void_p * nf
+
+    def arr(ts):
+        return VP(*[ptr(t) for t in ts])
+
+    check(lib.sn_fc_chain_backward(B, nf, Co, Ci, ptr(grad_y), arr(W), arr(zprev), arr(coefprev), (ctypes.c_longlong * nf)(*rows),
+                                   arr(dg), arr(dbt), arr(dbs), arr(dW), ptr(db_top), arr(aprev), (ctypes.c_int * nf)(*araw),
+                                   ptr(gsel), ptr(kcoef), ptr(xbuf), ptr(sync), _st(like)), "sn_fc_chain_backward")
+    saved["fc_chain_b"] = (xbuf, keep)  # (scratch of the asynchronous launch)
+    return gsel, kcoef
+
+
 def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
     """-> dict parameter-name -> gradient tensor (every parameter of the MLP).
     sink: optional dict name -> preallocated tensor the gradient is written into (overwritten, not accumulated).
@@ -502,7 +563,10 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
 
     # ---- FC head (rows = B): fc4 -> fc3 -> fc2 -> fc1 -> pooled features ----
     dy, kcoef = grad_y, None
-    for j in range(nf - 1, -1, -1):
+    chain = FC_CHAIN and B <= 32 and _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed)
+    if chain:
+        dy, kcoef = chain
+    for j in (range(nf - 1, -1, -1) if not chain else ()):
         L = fcs[j]
         mode = DZ_PLAIN if j == nf - 1 else DZ_BN
         if j > 0:

@@ -524,7 +524,7 @@ def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
             ya, sa = pointnet.forward_impl(net_a, x, True)
             pointnet.FC_CHAIN = False
             yb, sb = pointnet.forward_impl(net_b, x, True)
-            assert "fc_xbuf" in sa and "fc_xbuf" not in sb
+            assert "fc_chain" in sa and "fc_chain" not in sb
             for l in range(3):
                 assert torch.equal(sa["zf"][l], sb["zf"][l]), l
                 assert torch.equal(sa["cf"][l], sb["cf"][l]), l
@@ -535,3 +535,46 @@ def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
     assert int(net_a._fc_sync[15]) == 0 and int(net_a._fc_sync[0]) == len(xs)
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         assert torch.equal(ba, bb), n
+
+
+@pytest.mark.parametrize("B,bneck,variant,training", [(32, 128, None, True), (4, 128, None, True), (17, 256, None, True),
+                                                     (32, 128, "reconstruction", True), (32, 128, None, False)])
+def test_fc_chain_backward_equals_per_layer_launches(B, bneck, variant, training):
+    """sn_fc_chain_backward (the FC head's whole backward -- data gradients, BatchNorm backward, weight and bias gradients,
+    pooling backward -- as ONE launch with in-kernel hand-offs) against the layer-by-layer launches on the same saved
+    forward: every parameter gradient of the head and of the conv stack (the top layer's bit for bit), repeatedly; error
+    word clear."""
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(B + bneck + 3)
+    kw = VARIANTS[variant] if variant else {}
+    net = SampleNet(64, bneck, group_size=8, input_shape="bnc", output_shape="bnc", **kw).cuda().train(training)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.add_(0.2 * torch.randn_like(m.weight))
+    old = pointnet.FC_CHAIN
+    try:
+        for rep in range(3):
+            x = (torch.rand(B, 256, 3, device="cuda") - 0.5).contiguous()
+            gy = torch.randn(B, 192, device="cuda")
+            pointnet.FC_CHAIN = True
+            _, saved = pointnet.forward_impl(net, x, training)
+            ga = pointnet.backward_impl(net, saved, gy)
+            assert "fc_chain_b" in saved
+            pointnet.FC_CHAIN = False
+            gb = pointnet.backward_impl(net, saved, gy)
+            assert set(ga) == set(gb) and len(ga) == len(pointnet.param_order(net))
+            # same arithmetic, but the compiler contracts the two epilogues' sums differently: last-bit differences in the
+            # BatchNorm-backward coefficients, which everything below inherits (the biases in front of a BatchNorm hold pure
+            # rounding noise on both sides: absolute floor relative to the largest gradient)
+            gmax = max(float(v.abs().max()) for v in gb.values())
+            for n in ga:
+                assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * float(gb[n].abs().max()) + 3e-6 * gmax, (rep, n)
+            assert torch.equal(ga["fc4.weight" if "fc4.weight" in ga else "fc3.weight"], gb["fc4.weight" if "fc4.weight" in gb else "fc3.weight"])
+    finally:
+        pointnet.FC_CHAIN = old
+    torch.cuda.synchronize()
+    assert int(net._fc_sync_b[15]) == 0 and int(net._fc_sync_b[0]) == 3

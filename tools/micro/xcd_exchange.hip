@@ -9,7 +9,7 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void store_sc1(f4 *p, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_sc1(f4 *p, f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(p), "v"(v) : "memory"); }
 
 template <bool PINNED>
 __global__ void __launch_bounds__(256) seam_kernel(int iters, f4 *buf, unsigned *counter, float *out, int *err)
