@@ -46,9 +46,37 @@ __device__ __forceinline__ float emd_sq(float ax, float ay, float az, float bx, 
     return (dx * dx + dy * dy) + dz * dz;
 }
 
-// The reference op uses __expf (tf_approxmatch_g.cu:49).  The auction amplifies exp rounding through its
-// 10 levels, so the correctly-rounded expf is used: it keeps `match` within ~1e-6 of the fp32 restatement.
-__device__ __forceinline__ float emd_exp(float x) { return expf(x); }
+// exp for the auction.  The reference op uses __expf (tf_approxmatch_g.cu:49), a 2-ulp hardware approximation; its CPU twin
+// (and the oracle) use expf.  The auction amplifies exp rounding through its 10 levels (plain v_exp_f32(x log2 e) -- what
+// __expf is -- moves ~2 % of the argmax picks of emd_matching and breaks the 5e-4 per-entry bar held here), so the hardware
+// exponential is used with a compensated argument: y = x log2(e) is split into its rounded value and the rounding residual
+// (one extra fma + the low word of log2 e), 2^y comes from v_exp_f32 (1 ulp) and the residual is applied as 1 + r ln 2 --
+// ~2 ulp overall at ~8 VALU operations instead of libm's ~20.  The level sweeps are VALU-bound on exactly this, so they
+// work on PAIRS of points with the packed fp32 instructions of gfx950 (v_pk_mul / v_pk_add / v_pk_fma: two lanes of one
+// 64-bit register pair per issue): everything but v_exp_f32 itself and the two sequential accumulations costs half.
+// exp(0) == 1 exactly (level 0 multiplies by zero), large negative arguments underflow to 0 like expf.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v emd_exp2(f2v x)
+{
+    constexpr float kLog2eHi = 1.44269502162933349609375f, kLog2eLo = 1.925963033500966e-8f, kLn2 = 0.693147180559945309f;
+    const f2v y = x * kLog2eHi;
+    const f2v r = __builtin_elementwise_fma(x, (f2v)(kLog2eHi), -y) + x * kLog2eLo;
+    const f2v e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+    return e * __builtin_elementwise_fma(r, (f2v)(kLn2), (f2v)(1.0f));
+}
+__device__ __forceinline__ float emd_exp(float x)
+{
+    constexpr float kLog2eHi = 1.44269502162933349609375f, kLog2eLo = 1.925963033500966e-8f, kLn2 = 0.693147180559945309f;
+    const float y = x * kLog2eHi;
+    const float r = __builtin_fmaf(x, kLog2eHi, -y) + x * kLog2eLo;
+    return __builtin_amdgcn_exp2f(y) * __builtin_fmaf(r, kLn2, 1.0f);
+}
+// squared distances of one point (ax, ay, az) to a PAIR of points: same expression / roundings as emd_sq, per lane
+__device__ __forceinline__ f2v emd_sq2(float ax, float ay, float az, f2v bx, f2v by, f2v bz)
+{
+    const f2v dx = bx - ax, dy = by - ay, dz = bz - az;
+    return (dx * dx + dy * dy) + dz * dz;
+}
 
 // Workspace layout per cloud (floats): remainL[n] remainR[m] ratioL[kLevels][n] ratioR[kLevels][m]
 __host__ __device__ inline size_t emd_ws_floats(int n, int m) { return (size_t)(n + m) * (1 + kLevels); }
@@ -79,17 +107,51 @@ __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, c
         x1 = X1[k * 3 + 0], y1 = X1[k * 3 + 1], z1 = X1[k * 3 + 2];
         if (do3) rl = ratioL[(size_t)(li - 1) * n + k];
     }
-    float sum3 = 0.f;  // pass 3 accumulator (suml = 0)
-    for (int l0 = 0; do3 && l0 < m; l0 += kTile) {
-        const int lend = min(m, l0 + kTile) - l0;
+    // ONE sweep over the other cloud feeds both sums (the squared distance is shared; each sum still adds its terms in
+    // ascending l, so the results are those of the two separate sweeps):
+    //   sum3 = sum_l exp(lev3 d) ratioL'[k] ratioR'[l]   (pass 3 of the previous level)      -> remainL
+    //   sum1 = 1e-9 + sum_l exp(lev1 d) remainR[l]       (pass 1 of this level; remainR was finished by the previous
+    //                                                     level's pass 2, it does not depend on remainL)
+    // (Two threads per point -- half sums combined at the end -- to raise the ~1.5 waves per SIMD at B = 50 were measured
+    //  SLOWER, 4.2 vs 3.9 ms: the sweep is bound by VALU issue, not by latency.)
+    // LDS tiles hold PAIRS of points in register-pair order: tileA[q] = {x_l, x_l+1, y_l, y_l+1}, tileB[q] = {z_l, z_l+1,
+    // w_l, w_l+1} (w = remainR), tileC[q] = {w3_l, w3_l+1} (w3 = ratioR'); an odd tail is padded with a zero-weight point.
+    float4 *tileA = tile, *tileB = tile + kTile / 2;
+    __shared__ float2 tileC[kTile / 2];
+    float sum3 = 0.f, sum1 = 1e-9f;
+    for (int l0 = 0; l0 < m; l0 += kTile) {
+        const int lend = min(m, l0 + kTile) - l0, npair = (lend + 1) >> 1;
         __syncthreads();
-        for (int l = threadIdx.x; l < lend; l += blockDim.x)
-            tile[l] = make_float4(X2[(l0 + l) * 3 + 0], X2[(l0 + l) * 3 + 1], X2[(l0 + l) * 3 + 2], rR3[l0 + l]);
+        for (int q = threadIdx.x; q < npair; q += blockDim.x) {
+            const int la = l0 + 2 * q, lb = la + 1;
+            const bool okb = 2 * q + 1 < lend;
+            const float xb = okb ? X2[lb * 3 + 0] : 0.f, yb = okb ? X2[lb * 3 + 1] : 0.f, zb = okb ? X2[lb * 3 + 2] : 0.f;
+            tileA[q] = make_float4(X2[la * 3 + 0], xb, X2[la * 3 + 1], yb);
+            tileB[q] = make_float4(X2[la * 3 + 2], zb, li == 0 ? multiR : remainR[la], okb ? (li == 0 ? multiR : remainR[lb]) : 0.f);
+            if (do3) tileC[q] = make_float2(rR3[la], okb ? rR3[lb] : 0.f);
+        }
         __syncthreads();
-        for (int l = 0; l < lend; ++l) {
-            const float4 t = tile[l];
-            const float w = emd_exp(lev3 * emd_sq(x1, y1, z1, t.x, t.y, t.z)) * rl * t.w;
-            sum3 += w;
+        if (do3) {
+            const f2v l3 = (f2v)(lev3), l1 = (f2v)(lev1);
+            for (int q = 0; q < npair; ++q) {
+                const float4 ta = tileA[q], tb = tileB[q];
+                const float2 tc = tileC[q];
+                const f2v d2 = emd_sq2(x1, y1, z1, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y});
+                const f2v w3 = emd_exp2(l3 * d2) * rl * (f2v){tc.x, tc.y};
+                const f2v w1 = emd_exp2(l1 * d2) * (f2v){tb.z, tb.w};
+                sum3 += w3.x;
+                sum3 += w3.y;
+                sum1 += w1.x;
+                sum1 += w1.y;
+            }
+        } else {
+            const f2v l1 = (f2v)(lev1);
+            for (int q = 0; q < npair; ++q) {
+                const float4 ta = tileA[q], tb = tileB[q];
+                const f2v w1 = emd_exp2(l1 * emd_sq2(x1, y1, z1, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y})) * (f2v){tb.z, tb.w};
+                sum1 += w1.x;
+                sum1 += w1.y;
+            }
         }
     }
     float remL = multiL;
@@ -99,21 +161,6 @@ __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, c
     }
     if (li == 0 && blockIdx.x == 0)
         for (int l = threadIdx.x; l < m; l += blockDim.x) remainR[l] = multiR;
-    float sum1 = 1e-9f;
-    for (int l0 = 0; l0 < m; l0 += kTile) {
-        const int lend = min(m, l0 + kTile) - l0;
-        __syncthreads();
-        for (int l = threadIdx.x; l < lend; l += blockDim.x)
-            tile[l] = make_float4(X2[(l0 + l) * 3 + 0], X2[(l0 + l) * 3 + 1], X2[(l0 + l) * 3 + 2],
-                                  li == 0 ? multiR : remainR[l0 + l]);
-        __syncthreads();
-        for (int l = 0; l < lend; ++l) {
-            const float4 t = tile[l];
-            const float d = lev1 * emd_sq(x1, y1, z1, t.x, t.y, t.z);
-            const float w = emd_exp(d) * t.w;
-            sum1 += w;
-        }
-    }
     if (k < n) ratioL[(size_t)li * n + k] = remL / sum1;
 }
 
@@ -134,16 +181,26 @@ __global__ void __launch_bounds__(256) emd_pass_l_kernel(int n, int m, int li, c
     float x2 = 0, y2 = 0, z2 = 0;
     if (l < m) x2 = X2[l * 3 + 0], y2 = X2[l * 3 + 1], z2 = X2[l * 3 + 2];
     float sumr = 0.f;
+    float4 *tileA = tile, *tileB = tile + kTile / 2;  // pairs of xyz1 points, as in emd_pass_k_kernel (w = ratioL)
+    const f2v lv = (f2v)(level);
     for (int k0 = 0; k0 < n; k0 += kTile) {
-        const int kend = min(n, k0 + kTile) - k0;
+        const int kend = min(n, k0 + kTile) - k0, npair = (kend + 1) >> 1;
         __syncthreads();
-        for (int k = threadIdx.x; k < kend; k += blockDim.x)
-            tile[k] = make_float4(X1[(k0 + k) * 3 + 0], X1[(k0 + k) * 3 + 1], X1[(k0 + k) * 3 + 2], ratioL[k0 + k]);
+        for (int q = threadIdx.x; q < npair; q += blockDim.x) {
+            const int ka = k0 + 2 * q, kb = ka + 1;
+            const bool okb = 2 * q + 1 < kend;
+            const float xb = okb ? X1[kb * 3 + 0] : 0.f, yb = okb ? X1[kb * 3 + 1] : 0.f, zb = okb ? X1[kb * 3 + 2] : 0.f;
+            tileA[q] = make_float4(X1[ka * 3 + 0], xb, X1[ka * 3 + 1], yb);
+            tileB[q] = make_float4(X1[ka * 3 + 2], zb, ratioL[ka], okb ? ratioL[kb] : 0.f);
+        }
         __syncthreads();
-        for (int k = 0; k < kend; ++k) {
-            const float4 t = tile[k];
-            const float w = emd_exp(level * emd_sq(t.x, t.y, t.z, x2, y2, z2)) * t.w;
-            sumr += w;
+        for (int q = 0; q < npair; ++q) {
+            const float4 ta = tileA[q], tb = tileB[q];
+            // (x2 - x1)^2 ...: the pair is the FIRST operand of emd_sq here; squares are sign-symmetric, so the packed form
+            // (pair - point) gives the same values
+            const f2v w = emd_exp2(lv * emd_sq2(x2, y2, z2, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y})) * (f2v){tb.z, tb.w};
+            sumr += w.x;
+            sumr += w.y;
         }
     }
     if (l < m) {
@@ -177,9 +234,11 @@ __global__ void __launch_bounds__(256) emd_materialize_kernel(int n, int m, cons
         const float d2 = emd_sq(x1, y1, z1, X2[l * 3 + 0], X2[l * 3 + 1], X2[l * 3 + 2]);
         float acc = 0.f;
 #pragma unroll
-        for (int li = 0; li < kLevels; ++li) {
-            const float w = emd_exp(emd_level(li) * d2) * rl[li] * ratioR[(size_t)li * m + l];
-            acc += w;
+        for (int li = 0; li < kLevels; li += 2) {  // two levels per packed issue; the terms still enter acc in level order
+            const f2v lv = {emd_level(li), emd_level(li + 1)};
+            const f2v w = emd_exp2(lv * d2) * (f2v){rl[li], rl[li + 1]} * (f2v){ratioR[(size_t)li * m + l], ratioR[(size_t)(li + 1) * m + l]};
+            acc += w.x;
+            acc += w.y;
         }
         Mb[(size_t)l * n + k] = acc;
     }

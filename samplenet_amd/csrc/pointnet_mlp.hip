@@ -433,6 +433,49 @@ __device__ __forceinline__ void gemm_tile(f32x16 (&acc)[T::TM][T::TN], int K, co
     SN_TL(2);
 }
 
+// gemm_tile for the fixed-point statistics chain: the first chunk of both operands was fetched RAW by the caller (in flight
+// while it finalised the input's BatchNorm -- two memory round trips overlapped instead of chained), and the A operand is
+// transformed (BatchNorm + ReLU: xa(v, k)) on its way from registers to LDS.
+template <class T, class FA, class FB, class XA>
+__device__ __forceinline__ void gemm_tile_x(f32x16 (&acc)[T::TM][T::TN], int K, const FA &fa, const FB &fb, const XA &xa,
+                                            float4 (&ra)[T::A4], float4 (&rb)[T::B4], float *lds)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    constexpr int LDA = T::BM + 1, LDB = T::BN + 1;
+    float *As = lds, *Bs = lds + BK * T::LDA;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int q = 0; q < T::A4; ++q) {
+            constexpr bool exact = (T::BM * BK / 4) % T::THREADS == 0;
+            const int f = tid + q * T::THREADS;
+            if (exact || f < T::BM * BK / 4) ra[q] = xa(ra[q], k0 + (f % (BK / 4)) * 4);
+        }
+        stage_store<T::BM, LDA, T::A4, T::THREADS, true>(As, ra, tid);
+        stage_store<T::BN, LDB, T::B4, T::THREADS, true>(Bs, rb, tid);
+        __syncthreads();
+        if (k0 == 0) SN_TL(1);
+        if (k0 + BK < K) fetch_chunk<T, true, true>(ra, rb, fa, fb, k0 + BK, tid);  // loads in flight under the MFMAs
+        const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[T::TM], b[T::TN];
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i) a[i] = As[(2 * s + h) * LDA + (wr * T::TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) b[j] = Bs[(2 * s + h) * LDB + (wc * T::TN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    SN_TL(2);
+}
+
 // C/D fragment coordinates of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
@@ -626,42 +669,64 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         biasv[j] = g.bias ? g.bias[(FULL || col < Co) ? col : 0] : 0.f;
     }
     if (AMODE == ACT_BN_RELU_FX) {
-        // finalise the input's BatchNorm from its fixed-point sums (same arithmetic as bn_finalize_channel)
+        // finalise the input's BatchNorm from its fixed-point sums (same arithmetic as bn_finalize_channel).  Order of the
+        // memory operations: (1) the accumulator words of this thread's channel, (2) the first chunk of both GEMM operands,
+        // RAW -- then the coefficients are computed while (2) is still in flight (loads return in order: waiting for (1)
+        // does not wait for (2)).  Chaining the two round trips cost ~2 us per layer.
+        static_assert(FULL || AMODE != ACT_BN_RELU_FX, "fixed-point statistics chain: full tiles only");
         float *cf = lds + T::LDS_FLOATS;  // [2][Ci] scale | shift
         const BnFwd bp = g.bn_prev;
         const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-        for (int c = threadIdx.x; c < Ci; c += T::THREADS) {
-            double sum1, sum2;
-            fx_get2<kFxShiftFwd>(g.acc_in, c, sum1, sum2);
+        const int c = threadIdx.x;  // THREADS >= Ci (<= 128)
+        long long lo0[kFxSlots], lo1[kFxSlots], ha = 0, hb = 0, poison = 0;
+        float bg = 0.f, bb = 0.f, brm = 0.f, brv = 0.f;
+        if (c < Ci) {
+            poison = g.acc_in[kFxPoison];
+#pragma unroll
+            for (int q = 0; q < kFxSlots; ++q) lo0[q] = g.acc_in[(q * 2 + 0) * kFxRow + c], lo1[q] = g.acc_in[(q * 2 + 1) * kFxRow + c];
+            ha = g.acc_in[kFxHi + c], hb = g.acc_in[kFxHi + kFxRow + c];
+            bg = bp.gamma[c], bb = bp.beta[c];
+            if (first && bp.running_mean) brm = bp.running_mean[c], brv = bp.running_var[c];
+        }
+        const auto fa = [&](int x, int k) { return *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k); };
+        const auto fb = [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); };
+        float4 ra[T::A4], rb[T::B4];
+        fetch_chunk<T, true, true>(ra, rb, fa, fb, 0, threadIdx.x);
+        if (c < Ci) {
+            long long sa = 0, sb = 0;
+#pragma unroll
+            for (int q = 0; q < kFxSlots; ++q) sa += lo0[q], sb += lo1[q];
+            const double x = (double)sa + (double)ha * kFx2p50, y = (double)sb + (double)hb * kFx2p50;
+            const double scl = (1.0 / (double)(1ull << 30)) * (1.0 / (double)(1ull << (kFxShiftFwd - 30)));
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+            const double sum1 = poison ? nan : x * scl, sum2 = poison ? nan : y * scl;
             const double mean = sum1 / (double)bp.R;
             double var = sum2 / (double)bp.R - mean * mean;
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)bp.eps));
-            const float sc = bp.gamma[c] * invstd, sh = bp.beta[c] - (float)mean * sc;
+            const float sc = bg * invstd, sh = bb - (float)mean * sc;
             cf[c] = sc, cf[Ci + c] = sh;
             if (first) {
                 bp.coef[c] = sc, bp.coef[Ci + c] = sh, bp.coef[2 * Ci + c] = (float)mean, bp.coef[3 * Ci + c] = invstd;
                 if (bp.running_mean) {
                     const double unbiased = bp.R > 1 ? var * (double)bp.R / (double)(bp.R - 1) : var;
-                    bp.running_mean[c] = (1.f - bp.momentum) * bp.running_mean[c] + bp.momentum * (float)mean;
-                    bp.running_var[c] = (1.f - bp.momentum) * bp.running_var[c] + bp.momentum * (float)unbiased;
+                    bp.running_mean[c] = (1.f - bp.momentum) * brm + bp.momentum * (float)mean;
+                    bp.running_var[c] = (1.f - bp.momentum) * brv + bp.momentum * (float)unbiased;
                 }
             }
         }
         if (first && threadIdx.x == 0 && bp.num_batches_tracked) *bp.num_batches_tracked += 1;
         fx_clear_share(g.zero_ptr, g.zero_n, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, threadIdx.x, T::THREADS);
         __syncthreads();
-        static_assert(FULL || AMODE != ACT_BN_RELU_FX, "fixed-point statistics chain: full tiles only");
-        gemm_tile<T, true, true>(
-            acc, Ci,
-            [&](int x, int k) {
-                float4 v = *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k);
+        gemm_tile_x<T>(
+            acc, Ci, fa, fb,
+            [&](float4 v, int k) {
                 const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
                 v.x = relu_np(fmaf(v.x, sc.x, sh.x)), v.y = relu_np(fmaf(v.y, sc.y, sh.y));
                 v.z = relu_np(fmaf(v.z, sc.z, sh.z)), v.w = relu_np(fmaf(v.w, sc.w, sh.w));
                 return v;
             },
-            [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
+            ra, rb, lds);
     } else {
         gemm_tile<T, true, true>(
             acc, Ci, [&](int x, int k) { return a.template load_c4<FULL, AMODE == ACT_BN_RELU_FX ? ACT_BN_RELU : AMODE>(row0 + x, k); },
