@@ -177,12 +177,8 @@ __global__ void __launch_bounds__(256) chamfer_bwd_reg_kernel(int nt, int ns, co
 
 // workgroups (of 4 waves) the targets of all clouds are spread over: every wave loads the whole source set into registers
 // before its first target, so fewer, longer-lived waves amortise that load (1024 groups = one target per wave at the
-// sampler's sizes: measured 9 us; SN_CHAMFER_BWD_GROUPS overrides for experiments)
-static const int kChamferBwdGroups = [] {
-    const char *e = getenv("SN_CHAMFER_BWD_GROUPS");
-    const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 1024;  // swept 64..1024 at B = 32: 1024 is fastest
-}();
+// sampler's sizes: measured 9 us; swept 64..1024 at B = 32: 1024 is fastest)
+static const int kChamferBwdGroups = 1024;
 
 static void launch_chamfer_bwd(int b, int ysplit, int nt, int ns, const float *T, const float *S, const float *gT,
                                const int *idxT, const float *gS, const int *idxS, float *gradT, int own_first,

@@ -3440,8 +3440,7 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         g.acc_in = acc + (size_t)(l - 1) * kFxLayer, g.bn_prev = bn_of(l - 1), g.acc_out = acc + (size_t)l * kFxLayer;
         if (l >= 2) g.zero_ptr = acc + (size_t)(l - 2) * kFxLayer, g.zero_n = kFxLayer;
         if (l == nlayers - 1) g.pool_val = pool_val, g.pool_idx = pool_idx, g.pool_npts = N;
-        static const bool wide = !(getenv("SN_FWD_WIDE_TILE") && getenv("SN_FWD_WIDE_TILE")[0] == '0');
-        if (Co == 128 && wide) {
+        if (Co == 128) {
             // 128 output channels: one 512-thread workgroup per 64 rows computes all of them -- the input tile is fetched
             // once instead of once per 64-column block, and half as many workgroups run the statistics prologue
             using TW = Tile<64, 128, 2, 4>;
@@ -3536,19 +3535,9 @@ static int device_cus()
     return n;
 }
 
-static bool conv_bwd_fused_enabled()
-{
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("SN_NO_FUSED_CONV_BWD");
-        on = (e && e[0] == '1') ? 0 : 1;
-    }
-    return on == 1;
-}
-
 static bool conv_bwd_fused_shape(int R, int Ci, int Co)
 {
-    return conv_bwd_fused_enabled() && R >= 256 && ((Ci == 64 && (Co == 64 || Co == 128)) || (Ci == 128 && Co == 128));
+    return R >= 256 && ((Ci == 64 && (Co == 64 || Co == 128)) || (Ci == 128 && Co == 128));
 }
 
 // persistent workgroups: one per CU (each walks over ceil(tiles / groups) 64-row tiles)
