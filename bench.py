@@ -239,8 +239,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-module-surface", action="store_true", help="skip the secondary module-surface leg")
-    ap.add_argument("--no-overlap-allreduce", action="store_true",
-                    help="N > 1: one graph + one collective after it instead of two graphs with the first collective between")
+    ap.add_argument("--overlap-allreduce", action="store_true",
+                    help="N > 1: capture the step as two graphs and launch the FC-head segment's all-reduce between them on a side "
+                         "stream (default: one graph, one collective after it -- measured faster at world size 1)")
+    ap.add_argument("--no-probes", action="store_true",
+                    help="profiling runs: only the timed steps (no roofline kernel probes, no cpu_baseline, no module-surface leg)")
     ap.add_argument("--force-collective", action="store_true",
                     help="world size 1 under torchrun: still issue the gradient all-reduce (single-GPU exercise of the RCCL path)")
     args = ap.parse_args()
@@ -275,7 +278,7 @@ def main():
     # the 8 resident batches are the step's input ring (a data loader would write its H2D copies into them): one graph per
     # entry, no copy into a staging buffer on the timed path
     train_step = SamplerTrainStep(net, pool[0], alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=reducer,
-                                  use_graph=not args.no_graph, input_ring=pool, overlap_allreduce=not args.no_overlap_allreduce)
+                                  use_graph=not args.no_graph, input_ring=pool, overlap_allreduce=args.overlap_allreduce)
 
     def step(i):
         return train_step.replay(i % len(pool))
@@ -299,7 +302,9 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(loss).item()
 
-    if rank == 0:
+    if rank == 0 and args.no_probes:
+        print(json.dumps({"value": world * B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "note": "--no-probes run"}), flush=True)
+    elif rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         kern_ms = time_pairscan_kernel(net, pool, K)

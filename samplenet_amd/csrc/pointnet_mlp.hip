@@ -2259,21 +2259,40 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
     float *Wt0 = dZs + 32 * LD;      // [2][32][LD] transposed weight slices (ci within the tile, co)
     float *red = Wt0 + 2 * 32 * LD;  // [3][16][64]
     float *Ta = red + 3 * 16 * 64;   // [32][36]   this workgroup's tile of dZ of the layer below
-    // ---- stage 0 operands: dZ of the top layer straight from HBM, its weight slice (transposed)
+    // ---- stage 0 operands: dZ of the top layer straight from HBM, its weight slice (transposed).  ALL loads are issued before
+    // the first LDS write, unconditionally (out-of-range slots re-read a valid address): a loop of load -> store iterations, or
+    // a load behind a branch, makes every iteration pay its own memory round trip (measured: 4.2 us for this block before)
     {
         const FcBwdStage &S = g.S[0];
-        const int q4 = S.Co / 4;  // float4 per row
-        for (int idx = tid; idx < 32 * q4; idx += 256) {
-            const int r = idx / q4, c4 = (idx % q4) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < R) v = *reinterpret_cast<const float4 *>(g.gy + (size_t)r * S.Co + c4);
-            *reinterpret_cast<float4 *>(dZs + r * LD + c4) = v;
+        const int q4 = S.Co / 4, ng = 32 * q4, nw = S.Co * 8;  // float4 per row; float4 of the gradient / of the weight slice
+        const bool wt = col0 < S.Ci;
+        float4 gv[8], wv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = min(tid + 256 * i, ng - 1), r = idx / q4;
+            gv[i] = *reinterpret_cast<const float4 *>(g.gy + (size_t)min(r, R - 1) * S.Co + (idx % q4) * 4);
         }
-        if (col0 < S.Ci)
-            for (int idx = tid; idx < S.Co * 8; idx += 256) {
-                const int co = idx >> 3, c4 = (idx & 7) * 4;
-                const float4 w = *reinterpret_cast<const float4 *>(S.W + (size_t)co * S.Ci + col0 + c4);
-                Wt0[(c4 + 0) * LD + co] = w.x, Wt0[(c4 + 1) * LD + co] = w.y, Wt0[(c4 + 2) * LD + co] = w.z, Wt0[(c4 + 3) * LD + co] = w.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = min(tid + 256 * i, nw - 1);
+            wv[i] = *reinterpret_cast<const float4 *>(S.W + (size_t)(idx >> 3) * S.Ci + (wt ? col0 : 0) + (idx & 7) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < ng) {
+                const int r = idx / q4;
+                *reinterpret_cast<float4 *>(dZs + r * LD + (idx % q4) * 4) = r < R ? gv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (wt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < nw) {
+                    const int co = idx >> 3, c4 = (idx & 7) * 4;
+                    Wt0[(c4 + 0) * LD + co] = wv[i].x, Wt0[(c4 + 1) * LD + co] = wv[i].y, Wt0[(c4 + 2) * LD + co] = wv[i].z, Wt0[(c4 + 3) * LD + co] = wv[i].w;
+                }
             }
     }
     __syncthreads();
@@ -2284,18 +2303,20 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
         const bool has_tile = col0 < Ci, more = s + 1 < ns;
         float *Wt = Wt0 + (size_t)(s & 1) * 32 * LD, *Wtn = Wt0 + (size_t)((s + 1) & 1) * 32 * LD;
         // ---- prefetches: next stage's weight slice; wave 0: the epilogue's inputs
-        float4 wn[8];
+        // (waves 1..3 fetch and later stage the slice: wave 0 is busy with the epilogue and the polling)
+        constexpr int NWN = 11;  // ceil(256 rows x 8 float4 / 192 threads)
+        float4 wn[NWN];
         bool next_tile = false;
         int nCo = 0, nCi = 0;
         if (more) {
             const FcBwdStage &N = g.S[s + 1];
             nCo = N.Co, nCi = N.Ci;
             next_tile = col0 < nCi;
-            if (next_tile)
+            if (next_tile && wave != 0)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int idx = tid + 256 * i;
-                    if (idx < nCo * 8) wn[i] = *reinterpret_cast<const float4 *>(N.W + (size_t)(idx >> 3) * nCi + col0 + (idx & 7) * 4);
+                for (int i = 0; i < NWN; ++i) {  // unconditional (clamped): a load behind a branch is waited for on the spot
+                    const int idx = min((tid - 64) + 192 * i, nCo * 8 - 1);
+                    wn[i] = *reinterpret_cast<const float4 *>(N.W + (size_t)(idx >> 3) * nCi + col0 + (idx & 7) * 4);
                 }
         }
         float zpv[16], esc = 0.f, esh = 0.f, pmean = 0.f, pinv = 0.f;
@@ -2325,6 +2346,18 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 }
             }
             wave_sum_to_wave0(acc, red);
+            // the next stage's weight slice goes into the other LDS buffer NOW: waves 1..3 have nothing else to do while wave 0
+            // runs the epilogue (wave 0's quarter follows its epilogue) -- behind the arrival it sat on the chain's critical path
+            if (wave != 0 && next_tile)
+#pragma unroll
+                for (int i = 0; i < NWN; ++i) {
+                    const int idx = (tid - 64) + 192 * i;
+                    if (idx < nCo * 8) {
+                        const int co = idx >> 3, c4 = (idx & 7) * 4;
+                        Wtn[(c4 + 0) * LD + co] = wn[i].x, Wtn[(c4 + 1) * LD + co] = wn[i].y;
+                        Wtn[(c4 + 2) * LD + co] = wn[i].z, Wtn[(c4 + 3) * LD + co] = wn[i].w;
+                    }
+                }
             if (wave == 0) {
                 float s0 = 0.f, s1c = 0.f, gv[16];
 #pragma unroll
@@ -2372,11 +2405,11 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(g.sync + 1 + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- next stage's weight slice into the other LDS buffer while the others arrive
-        if (next_tile)
+        // ---- (a workgroup without a tile in this stage had no MFMA phase to stage the next slice under: do it here)
+        if (next_tile && !has_tile && wave != 0)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = tid + 256 * i;
+            for (int i = 0; i < NWN; ++i) {
+                const int idx = (tid - 64) + 192 * i;
                 if (idx < nCo * 8) {
                     const int co = idx >> 3, c4 = (idx & 7) * 4;
                     Wtn[(c4 + 0) * LD + co] = wn[i].x, Wtn[(c4 + 1) * LD + co] = wn[i].y;

@@ -14,7 +14,7 @@ tail -c 300 $OUT/bench_n1_rccl_forced.json; echo
 python tools/pairscan_scaling.py > $OUT/pairscan_scaling.txt 2>&1; cat $OUT/pairscan_scaling.txt
 python tools/emd_bench.py > $OUT/emd_bench.txt 2>&1; cat $OUT/emd_bench.txt
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --no-module-surface"
+B="--no-probes"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_graph -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 $B > /tmp/prof_graph.log 2>&1
 cp /tmp/prof_graph/bench_kernel_stats.csv $OUT/bench_graph_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_eager -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 $B --no-graph > /tmp/prof_eager.log 2>&1

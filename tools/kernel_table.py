@@ -31,6 +31,8 @@ tot = 0.0
 lines = []
 for r in mine:
     per_step = int(r["Calls"]) / steps
+    if per_step < 0.5:  # (warm-up / probe launches that are not part of the step)
+        continue
     avg = float(r["AverageNs"]) / 1e3
     t = pmc.get(r["Name"], {}).get("hbm_traffic_bytes_per_launch")
     n = max(1, round(per_step))
