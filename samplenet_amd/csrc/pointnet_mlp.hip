@@ -1848,7 +1848,28 @@ struct FcChainArgs {
     FcChainLayer L[kFcChainMaxLayers];
     float *xbuf;     // [2][32][H] exchange slabs
     unsigned *sync;  // [0] epoch, [1 + s] arrivals at seam s, [15] error flag -- persistent, zero-initialised once
+    double rinv_rows, unbias;  // 1 / R and R / (R - 1) (1 when R == 1)
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's GLOBAL loads and stores
+// (s_waitcnt vmcnt(0) in front of s_barrier): every barrier of the chain kernels then exposed the full latency of the operand
+// prefetches in flight across it (timestamps: ~1.7 us per "MFMA phase" that holds 0.4 us of MFMAs).  Global data never
+// crosses these barriers (hand-offs are drained explicitly before their arrival atomics).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wave_sum_to_wave0_lds(f32x16 &acc, float *lds)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave > 0)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lds[((wave - 1) * 16 + e) * 64 + lane] = acc[e];
+    lds_barrier();
+    if (wave == 0)
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += lds[(w * 16 + e) * 64 + lane];
+}
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_sc1_b128(float *p, f32x4v v)
@@ -1859,6 +1880,9 @@ __device__ __forceinline__ void store_sc1_b128(float *p, f32x4v v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(p), "v"(v) : "memory");
 }
 
+// C0T / NLT > 0: input width / layer count known at compile time (the sampler's 128 -> 256 x 3 head): the operand fetches then
+// unroll into ONE batch of loads; 0: run-time loops.
+template <int C0T, int NLT>
 __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1867,7 +1891,7 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
     const int wg = blockIdx.x >> 3, nwg = g.H / 32;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int R = g.R, H = g.H, C0 = g.C0, nl = g.nl;
+    const int R = g.R, H = g.H, C0 = C0T > 0 ? C0T : g.C0, nl = NLT > 0 ? NLT : g.nl;
     const int LDA = (C0 > H ? C0 : H) + 4;
     float *As = sm;                 // [32][LDA]
     float *W0s = As + 32 * LDA;     // [32][C0 + 4]            weight slice of layer 0
@@ -1879,6 +1903,39 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
     if (tid == 0) s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- every layer's weight slice + the first operand: all fetches issued up front, staged into LDS as they land
+    if (C0T > 0 && NLT > 0) {
+        // compile-time shape: every load of the kernel's operands is issued before the first LDS write (no loop-carried
+        // load -> store dependencies, no branches around loads), layer 0's operands first
+        constexpr int q4 = (C0T > 0 ? C0T : 128) / 4, rpp = 256 / q4, npass = 32 / rpp;
+        constexpr int NH = NLT > 1 ? NLT - 1 : 1;
+        const int c4 = (tid % q4) * 4, r0 = tid / q4;
+        const int hq4 = 64, hc4 = (tid % hq4) * 4, hr0 = tid / hq4;  // H = 256: 4 rows per pass, 8 passes
+        float4 av[npass], wv[npass], wh[NH][8];
+#pragma unroll
+        for (int q = 0; q < npass; ++q) {
+            const int r = r0 + q * rpp;
+            av[q] = *reinterpret_cast<const float4 *>(g.a0 + (size_t)min(r, R - 1) * C0 + c4);
+            wv[q] = *reinterpret_cast<const float4 *>(g.L[0].W + (size_t)(col0 + r) * C0 + c4);
+        }
+#pragma unroll
+        for (int l = 1; l < NLT; ++l)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wh[l - 1][q] = *reinterpret_cast<const float4 *>(g.L[l].W + (size_t)(col0 + hr0 + q * 4) * H + hc4);
+#pragma unroll
+        for (int q = 0; q < npass; ++q) {
+            const int r = r0 + q * rpp;
+            float4 a = av[q];
+            const float ma = r < R ? 1.f : 0.f;
+            a.x *= ma, a.y *= ma, a.z *= ma, a.w *= ma;
+            *reinterpret_cast<float4 *>(As + r * LDA + c4) = a;
+            *reinterpret_cast<float4 *>(W0s + r * (C0 + 4) + c4) = wv[q];
+        }
+#pragma unroll
+        for (int l = 1; l < NLT; ++l)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<float4 *>(Whs + (size_t)(l - 1) * 32 * (H + 4) + (hr0 + q * 4) * (H + 4) + hc4) = wh[l - 1][q];
+    } else
     {
         const int q4 = C0 / 4, rpp = 256 / q4, npass = 32 / rpp;
         const int c4 = (tid % q4) * 4, r0 = tid / q4;
@@ -1900,7 +1957,7 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
                     *reinterpret_cast<const float4 *>(g.L[l].W + (size_t)(col0 + r) * H + hc4);
             }
     }
-    __syncthreads();
+    lds_barrier();
     const unsigned epoch = s_epoch;
 
     for (int l = 0; l < nl; ++l) {
@@ -1923,7 +1980,7 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
-        wave_sum_to_wave0(acc, red);
+        wave_sum_to_wave0_lds(acc, red);
         if (wave == 0) {
             float s0 = 0.f;
 #pragma unroll
@@ -1940,16 +1997,18 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
                 if (frag_row(e, lane) < R) s2 += d * d;
             }
             s2 += __shfl_xor(s2, 32);
-            const double mean = (double)s0 / (double)R;
+            // (reciprocals from the host, invstd in fp32 as torch computes it: three double divisions and a double square root
+            //  per layer cost ~0.7 us of the chain's critical path)
+            const double mean = (double)s0 * g.rinv_rows;
             const double dm = mean - (double)meanf;
-            double var = (double)s2 / (double)R - dm * dm;
+            double var = (double)s2 * g.rinv_rows - dm * dm;
             if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)Lr.eps));
+            const float invstd = 1.0f / sqrtf((float)(var + (double)Lr.eps));
             const float sc = bn_g * invstd, sh = bn_b - (float)mean * sc;
             if (lane < 32) {
                 Lr.coef[col] = sc, Lr.coef[H + col] = sh, Lr.coef[2 * H + col] = (float)mean, Lr.coef[3 * H + col] = invstd;
                 if (Lr.running_mean) {
-                    const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+                    const double unbiased = var * g.unbias;
                     Lr.running_mean[col] = (1.f - Lr.momentum) * bn_rm + Lr.momentum * (float)mean;
                     Lr.running_var[col] = (1.f - Lr.momentum) * bn_rv + Lr.momentum * (float)unbiased;
                 }
@@ -1963,7 +2022,7 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
                 Ta[row * 36 + l31] = row < R ? relu_np(fmaf(v, sc, sh)) : 0.f;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // the 32 x 32 tiles leave as 16-byte stores: thread -> (row = tid / 8, 4 columns at (tid % 8) * 4)
         const int trow = tid >> 3, tc4 = (tid & 7) * 4;
         if (trow < R) *reinterpret_cast<float4 *>(Lr.z + (size_t)trow * H + col0 + tc4) = *reinterpret_cast<const float4 *>(Ts + trow * 36 + tc4);
@@ -1975,7 +2034,7 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
             store_sc1_b128(xb + (size_t)trow * H + col0 + tc4, vv);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             __hip_atomic_fetch_add(g.sync + 1 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = (epoch + 1u) * (unsigned)nwg;
@@ -1989,7 +2048,7 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
             }
             if (l == 0 && wg == 0) __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();
+        lds_barrier();
         // gather the whole 32 x H activation (write-through data: sc1 loads read it from L2 / memory, never from a stale L1 line)
         {
             const int hq4 = H / 4;
@@ -2008,7 +2067,7 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
                     *reinterpret_cast<float4 *>(As + (idx / hq4) * LDA + (idx % hq4) * 4) = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -2128,6 +2187,7 @@ struct FcBwdStage {
     int Co, Ci;
     const float *zprev, *coefprev;  // layer below: pre-BN output (R, Ci) at this layer's inputs and its (4, Ci) coefficients
     long long bn_rows;              // rows the BatchNorm below averaged over (R, B * N behind the max-pool, < 0: fixed statistics)
+    double rinv;                    // 1 / bn_rows (0 for fixed statistics): from the host, a double division costs ~0.2 us here
     float *dgamma, *dbeta, *dbias;  // of the layer below
     float *dW, *db;                 // of this layer (db: top layer only)
     const float *aprev;             // wgrad operand: zprev (relu(bn(.)) applied) or, araw != 0, the raw input (pooled features)
@@ -2169,7 +2229,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
         s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(g.sync + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
+    lds_barrier();
     const unsigned epoch = s_epoch;
     const unsigned target = (epoch + 1u) * (unsigned)NWG;
 
@@ -2208,13 +2268,13 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
             } else {
                 if (tid == 0 && !fc_wait_arrivals(g.sync + s, target))  // sync[1 + (s - 1)]
                     __hip_atomic_store(g.sync + 15, 16u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
+                lds_barrier();
                 const float *p = g.xbuf + (size_t)(s - 1) * 32 * 256 + (size_t)trow * Co + col0 + tc4;
                 f32x4v v;
                 asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
                 *reinterpret_cast<float4 *>(Tz + trow * 36 + tc4) = make_float4(v.x, v.y, v.z, v.w);
             }
-            __syncthreads();
+            lds_barrier();
             float a[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) a[t] = Tz[(h * 16 + t) * 36 + l31];
@@ -2249,7 +2309,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) S.db[col0 + frag_row(e, lane)] = acc[e];
             }
-            __syncthreads();  // Tz is rewritten by the next stage
+            lds_barrier();  // Tz is rewritten by the next stage
         }
         return;
     }
@@ -2295,7 +2355,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 }
             }
     }
-    __syncthreads();
+    lds_barrier();
 
     for (int s = 0; s < ns; ++s) {
         const FcBwdStage &S = g.S[s];
@@ -2345,7 +2405,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
                 }
             }
-            wave_sum_to_wave0(acc, red);
+            wave_sum_to_wave0_lds(acc, red);
             // the next stage's weight slice goes into the other LDS buffer NOW: waves 1..3 have nothing else to do while wave 0
             // runs the epilogue (wave 0's quarter follows its epilogue) -- behind the arrival it sat on the chain's critical path
             if (wave != 0 && next_tile)
@@ -2375,7 +2435,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 s1c += __shfl_xor(s1c, 32);
                 const double scale = esc, mean = pmean, invstd = pinv, sd = s0;
                 const double dg = invstd * (double)s1c;
-                const double rinv = S.bn_rows > 0 ? 1.0 / (double)S.bn_rows : 0.0;
+                const double rinv = S.rinv;
                 const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
                 const float k3 = (float)(scale * (invstd * mean * dg * rinv - sd * rinv));
                 if (lane < 32) {
@@ -2392,7 +2452,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (!more) break;
         // ---- hand the tile of dZ of the layer below over (write-through), drained, then arrive
         float *xb = g.xbuf + (size_t)s * 32 * 256;
@@ -2403,7 +2463,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
             store_sc1_b128(xb + (size_t)trow * Ci + col0 + tc4, vv);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) __hip_atomic_fetch_add(g.sync + 1 + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- (a workgroup without a tile in this stage had no MFMA phase to stage the next slice under: do it here)
         if (next_tile && !has_tile && wave != 0)
@@ -2418,7 +2478,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
             }
         if (tid == 0 && !fc_wait_arrivals(g.sync + 1 + s, target))
             __hip_atomic_store(g.sync + 15, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
+        lds_barrier();
         {   // gather dZ of the layer below (32 x Ci; Ci = 256: 8 loads per thread, 128: 4)
             const int q4 = Ci / 4, nld = (32 * q4) / 256;
             f32x4v r[8];
@@ -2437,7 +2497,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                     *reinterpret_cast<float4 *>(dZs + (idx / q4) * LD + (idx % q4) * 4) = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
                 }
         }
-        __syncthreads();
+        lds_barrier();
     }
     // the next launch may only see the advanced epoch once all 16 workgroups of this one have read the current value
     if (wgi == 0 && tid == 0) {
@@ -3345,12 +3405,21 @@ extern "C" int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0
     const size_t lds = fc_chain_fwd_lds(C0, H, nl);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        if (hipFuncSetAttribute((const void *)fc_chain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)fc_chain_fwd_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)fc_chain_fwd_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)fc_chain_fwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return sn_set_error(SN_ERR_UNSUPPORTED, "sn_fc_chain_forward: %zu bytes of LDS refused", lds);
         attr_lds = lds;
     }
     // 8 x (H / 32) blocks: block b lands on XCD b % 8, the b % 8 == 0 ones do the work -- all on one XCD (same L2)
-    hipLaunchKernelGGL(fc_chain_fwd_kernel, dim3(8 * (H / 32)), dim3(256), lds, (hipStream_t)stream, g);
+    g.rinv_rows = 1.0 / (double)R, g.unbias = R > 1 ? (double)R / (double)(R - 1) : 1.0;
+    const dim3 grid(8 * (H / 32)), block(256);
+    if (C0 == 128 && nl == 3)
+        hipLaunchKernelGGL((fc_chain_fwd_kernel<128, 3>), grid, block, lds, (hipStream_t)stream, g);
+    else if (C0 == 256 && nl == 3)
+        hipLaunchKernelGGL((fc_chain_fwd_kernel<256, 3>), grid, block, lds, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL((fc_chain_fwd_kernel<0, 0>), grid, block, lds, (hipStream_t)stream, g);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -3381,6 +3450,7 @@ extern "C" int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci,
         SN_REQUIRE(W[s] && zprev[s] && coefprev[s] && dgamma[s] && dbeta[s] && dW[s] && aprev[s], "null stage pointer");
         FcBwdStage &S = g.S[s];
         S.W = W[s], S.Co = Co[s], S.Ci = Ci[s], S.zprev = zprev[s], S.coefprev = coefprev[s], S.bn_rows = bn_rows[s];
+        S.rinv = bn_rows[s] > 0 ? 1.0 / (double)bn_rows[s] : 0.0;
         S.dgamma = dgamma[s], S.dbeta = dbeta[s], S.dbias = dbias[s], S.dW = dW[s], S.db = s == 0 ? db_top : nullptr;
         S.aprev = aprev[s], S.araw = araw[s];
         S.gout = s == ns - 1 ? gout : nullptr, S.kout = s == ns - 1 ? kout : nullptr;

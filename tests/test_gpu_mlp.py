@@ -509,8 +509,8 @@ def test_sampler_variants_vs_torch(variant, B, N, M, K):
 def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
     """sn_fc_chain_forward (the FC head's three BatchNorm + ReLU layers as ONE launch, activations handed between the
     resident workgroups through write-through stores + arrival counters) against the layer-by-layer launches: pre-BN outputs,
-    BatchNorm coefficients, running statistics and the head's output bit for bit; repeated calls (monotonic epoch counters)
-    and the error word stays clear."""
+    BatchNorm coefficients, running statistics and the head's output; repeated calls (monotonic epoch counters) and the
+    error word stays clear."""
     from samplenet_amd import SampleNet, pointnet
 
     torch.manual_seed(B + bneck)
@@ -525,16 +525,21 @@ def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
             pointnet.FC_CHAIN = False
             yb, sb = pointnet.forward_impl(net_b, x, True)
             assert "fc_chain" in sa and "fc_chain" not in sb
+            # same GEMM arithmetic (layer 0's pre-BN output is bit-identical); the chain finishes the BatchNorm with fp32
+            # 1 / sqrt (as torch does) and host-side reciprocals instead of double divisions: coefficients within 2 ulp,
+            # which the following layers inherit
+            assert torch.equal(sa["zf"][0], sb["zf"][0])
             for l in range(3):
-                assert torch.equal(sa["zf"][l], sb["zf"][l]), l
-                assert torch.equal(sa["cf"][l], sb["cf"][l]), l
-            assert torch.equal(ya, yb)
+                tol = 3e-7 if l == 0 else 1e-5  # (layers 1.. see inputs that already differ by an ulp or two)
+                assert torch.allclose(sa["cf"][l], sb["cf"][l], rtol=tol, atol=tol), l
+                assert float((sa["zf"][l] - sb["zf"][l]).abs().max()) <= 1e-5 * float(sb["zf"][l].abs().max()), l
+            assert float((ya - yb).abs().max()) <= 1e-5 * float(yb.abs().max())
     finally:
         pointnet.FC_CHAIN = old
     torch.cuda.synchronize()
     assert int(net_a._fc_sync[15]) == 0 and int(net_a._fc_sync[0]) == len(xs)
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
-        assert torch.equal(ba, bb), n
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6), n
 
 
 @pytest.mark.parametrize("B,bneck,variant,training", [(32, 128, None, True), (4, 128, None, True), (17, 256, None, True),
