@@ -132,6 +132,23 @@ enum { DZ_PLAIN = 0, DZ_BN = 1, DZ_POOL = 2 };
 // plausible-looking zeros instead of a NaN loss)
 __device__ __forceinline__ float relu_np(float u) { return u < 0.f ? 0.f : u; }
 
+// Double-precision reciprocal and reciprocal square root from an fp32 hardware seed and two Newton steps (error ~1e-16: the
+// result equals the quotient a / x or 1 / sqrt(x) to within one double ulp, i.e. the fp32 coefficients derived from it are
+// the same).  The library routines cost ~40 / ~80 double-rate instructions and sat on the critical path of every kernel that
+// finalises a BatchNorm in its prologue or epilogue (~0.5 us each, measured on the FC chain).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = (double)(1.0f / (float)x);
+    r = r * (2.0 - x * r);
+    return r * (2.0 - x * r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = (double)(1.0f / sqrtf((float)x));
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y * (1.5 - 0.5 * x * y * y);
+}
+
 // activation of the previous layer, rows x channels, channel-contiguous: a = relu(scale[c]*z + shift[c]) or raw
 struct ActSrc {
     const float *z;      // [rows][ch]
@@ -548,21 +565,22 @@ __device__ __forceinline__ BnFwdIn bn_fwd_inputs(const BnFwd &bn, int c)
 __device__ __forceinline__ float2 bn_finalize_channel_mv(const BnFwd &bn, int C, int c, double mean, double var, const BnFwdIn &in);
 __device__ __forceinline__ float2 bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss, const BnFwdIn &in)
 {
-    const double mean = s / (double)bn.R;
-    double var = ss / (double)bn.R - mean * mean;
+    const double rR = fast_rcp((double)bn.R);
+    const double mean = s * rR;
+    double var = ss * rR - mean * mean;
     if (var < 0.0) var = 0.0;
     return bn_finalize_channel_mv(bn, C, c, mean, var, in);
 }
 __device__ __forceinline__ float2 bn_finalize_channel_mv(const BnFwd &bn, int C, int c, double mean, double var, const BnFwdIn &in)
 {
-    const float invstd = (float)(1.0 / sqrt(var + (double)bn.eps));
+    const float invstd = (float)fast_rsqrt(var + (double)bn.eps);
     const float sc = in.gamma * invstd;
     bn.coef[c] = sc;
     bn.coef[C + c] = in.beta - (float)mean * sc;
     bn.coef[2 * C + c] = (float)mean;
     bn.coef[3 * C + c] = invstd;
     if (bn.running_mean) {
-        const double unbiased = bn.R > 1 ? var * (double)bn.R / (double)(bn.R - 1) : var;
+        const double unbiased = bn.R > 1 ? var * (double)bn.R * fast_rcp((double)(bn.R - 1)) : var;
         bn.running_mean[c] = (1.f - bn.momentum) * in.rmean + bn.momentum * (float)mean;
         bn.running_var[c] = (1.f - bn.momentum) * in.rvar + bn.momentum * (float)unbiased;
     }
@@ -596,7 +614,7 @@ __device__ __forceinline__ BnBwdOut bn_backward_coefs(long long R, double s, dou
     const double dg = invstd * (sz - mean * s);
     // R <= 0: the forward normalised with FIXED statistics (eval mode, running mean / variance): dZ = scale * dY, no
     // dependence of the statistics on Z -> k2 = k3 = 0; dgamma / dbeta keep their form (mean, invstd = the fixed ones)
-    const double rinv = R > 0 ? 1.0 / (double)R : 0.0;
+    const double rinv = R > 0 ? fast_rcp((double)R) : 0.0;
     BnBwdOut o;
     o.dgamma = (float)dg, o.dbeta = (float)s;
     o.k1 = (float)scale, o.k2 = (float)(-scale * invstd * dg * rinv);
@@ -700,16 +718,17 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
             const double scl = (1.0 / (double)(1ull << 30)) * (1.0 / (double)(1ull << (kFxShiftFwd - 30)));
             const double nan = __longlong_as_double(0x7ff8000000000000ll);
             const double sum1 = poison ? nan : x * scl, sum2 = poison ? nan : y * scl;
-            const double mean = sum1 / (double)bp.R;
-            double var = sum2 / (double)bp.R - mean * mean;
+            const double rR = fast_rcp((double)bp.R);
+            const double mean = sum1 * rR;
+            double var = sum2 * rR - mean * mean;
             if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)bp.eps));
+            const float invstd = (float)fast_rsqrt(var + (double)bp.eps);
             const float sc = bg * invstd, sh = bb - (float)mean * sc;
             cf[c] = sc, cf[Ci + c] = sh;
             if (first) {
                 bp.coef[c] = sc, bp.coef[Ci + c] = sh, bp.coef[2 * Ci + c] = (float)mean, bp.coef[3 * Ci + c] = invstd;
                 if (bp.running_mean) {
-                    const double unbiased = bp.R > 1 ? var * (double)bp.R / (double)(bp.R - 1) : var;
+                    const double unbiased = bp.R > 1 ? var * (double)bp.R * fast_rcp((double)(bp.R - 1)) : var;
                     bp.running_mean[c] = (1.f - bp.momentum) * brm + bp.momentum * (float)mean;
                     bp.running_var[c] = (1.f - bp.momentum) * brv + bp.momentum * (float)unbiased;
                 }
@@ -1657,18 +1676,19 @@ __global__ void __launch_bounds__(256) small_fwd_kernel(FwdArgs g)
         }
         s2 += __shfl_xor(s2, 32);
         if (lane < 32 && colok) {  // same arithmetic as bn_finalize_channel, on the prefetched parameters
-            const double mean = (double)s0 / (double)g.bn.R;
+            const double rR = fast_rcp((double)g.bn.R);
+            const double mean = (double)s0 * rR;
             const double dm = mean - (double)meanf;  // sum (z - meanf)^2 = sum (z - mean)^2 + R dm^2
-            double var = (double)s2 / (double)g.bn.R - dm * dm;
+            double var = (double)s2 * rR - dm * dm;
             if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)g.bn.eps));
+            const float invstd = (float)fast_rsqrt(var + (double)g.bn.eps);
             const float sc = bn_g * invstd;
             g.bn.coef[col] = sc;
             g.bn.coef[Co + col] = bn_b - (float)mean * sc;
             g.bn.coef[2 * Co + col] = (float)mean;
             g.bn.coef[3 * Co + col] = invstd;
             if (g.bn.running_mean) {
-                const double unbiased = g.bn.R > 1 ? var * (double)g.bn.R / (double)(g.bn.R - 1) : var;
+                const double unbiased = g.bn.R > 1 ? var * (double)g.bn.R * fast_rcp((double)(g.bn.R - 1)) : var;
                 g.bn.running_mean[col] = (1.f - g.bn.momentum) * bn_rm + g.bn.momentum * (float)mean;
                 g.bn.running_var[col] = (1.f - g.bn.momentum) * bn_rv + g.bn.momentum * (float)unbiased;
             }
@@ -1797,18 +1817,19 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
         }
         s2 += __shfl_xor(s2, 32);
         if (lane < 32 && colok) {  // same arithmetic as bn_finalize_channel, on the prefetched parameters
-            const double mean = (double)s0 / (double)g.bn.R;
+            const double rR = fast_rcp((double)g.bn.R);
+            const double mean = (double)s0 * rR;
             const double dm = mean - (double)meanf;  // sum (z - meanf)^2 = sum (z - mean)^2 + R dm^2
-            double var = (double)s2 / (double)g.bn.R - dm * dm;
+            double var = (double)s2 * rR - dm * dm;
             if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)g.bn.eps));
+            const float invstd = (float)fast_rsqrt(var + (double)g.bn.eps);
             const float sc = bn_g * invstd;
             g.bn.coef[col] = sc;
             g.bn.coef[Co + col] = bn_b - (float)mean * sc;
             g.bn.coef[2 * Co + col] = (float)mean;
             g.bn.coef[3 * Co + col] = invstd;
             if (g.bn.running_mean) {
-                const double unbiased = g.bn.R > 1 ? var * (double)g.bn.R / (double)(g.bn.R - 1) : var;
+                const double unbiased = g.bn.R > 1 ? var * (double)g.bn.R * fast_rcp((double)(g.bn.R - 1)) : var;
                 g.bn.running_mean[col] = (1.f - g.bn.momentum) * bn_rm + g.bn.momentum * (float)mean;
                 g.bn.running_var[col] = (1.f - g.bn.momentum) * bn_rv + g.bn.momentum * (float)unbiased;
             }
@@ -1997,13 +2018,13 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
                 if (frag_row(e, lane) < R) s2 += d * d;
             }
             s2 += __shfl_xor(s2, 32);
-            // (reciprocals from the host, invstd in fp32 as torch computes it: three double divisions and a double square root
+            // (reciprocals from the host, Newton-refined reciprocal square root: three double divisions and a double square root
             //  per layer cost ~0.7 us of the chain's critical path)
             const double mean = (double)s0 * g.rinv_rows;
             const double dm = mean - (double)meanf;
             double var = (double)s2 * g.rinv_rows - dm * dm;
             if (var < 0.0) var = 0.0;
-            const float invstd = 1.0f / sqrtf((float)(var + (double)Lr.eps));
+            const float invstd = (float)fast_rsqrt(var + (double)Lr.eps);
             const float sc = bn_g * invstd, sh = bn_b - (float)mean * sc;
             if (lane < 32) {
                 Lr.coef[col] = sc, Lr.coef[H + col] = sh, Lr.coef[2 * H + col] = (float)mean, Lr.coef[3 * H + col] = invstd;
@@ -2154,7 +2175,7 @@ __device__ __forceinline__ void small_dgrad_body(const DgradArgs &g, int bx, flo
         const double dg = invstd * (double)s1c;
         g.bb.dgamma[col] = (float)dg;
         g.bb.dbeta[col] = (float)s;
-        const double rinv = g.bb.R > 0 ? 1.0 / (double)g.bb.R : 0.0;  // R <= 0: fixed statistics (see bn_backward_coefs)
+        const double rinv = g.bb.R > 0 ? fast_rcp((double)g.bb.R) : 0.0;  // R <= 0: fixed statistics (see bn_backward_coefs)
         const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
         const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
         g.bb.kcoef[col] = k1, g.bb.kcoef[Ci + col] = k2, g.bb.kcoef[2 * Ci + col] = k3;
