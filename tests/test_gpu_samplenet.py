@@ -530,3 +530,43 @@ def test_eval_mode_backward_uses_running_statistics():
                 continue
             assert p.grad is not None, n
             assert float((p.grad - gb[n]).norm()) <= 1e-3 * float(gb[n].norm()) + 1e-6, (B, n)
+
+
+def test_device_batch_ring_feeds_the_captured_step():
+    """samplenet_amd.data.DeviceBatchRing (pinned staging + asynchronous H2D copies on its own stream) as the input ring of the
+    captured step: batches drawn from a PointCloudDataSet, copy of batch t+1 issued before the step on batch t -- same losses
+    and gradients as feeding the same batches synchronously."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.data import DeviceBatchRing, PointCloudDataSet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    rng = np.random.default_rng(0)
+    clouds = (rng.random((40, 1024, 3), dtype=np.float32) - 0.5)
+    ds = PointCloudDataSet(clouds, init_shuffle=False)
+    B, steps = 8, 6
+    batches = [ds.next_batch(B)[0].copy() for _ in range(steps)]
+    torch.manual_seed(9)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    ring = DeviceBatchRing(B, 1024, "cuda", depth=2)
+    red_a, red_b = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b)
+    ring.load(0, batches[0])
+    ring.ready(0)
+    torch.cuda.synchronize()
+    step_a = SamplerTrainStep(net_a, ring.tensors[0], reducer=red_a, input_ring=ring.tensors)
+    step_b = SamplerTrainStep(net_b, ring.tensors[0].clone(), reducer=red_b)
+    net_b.load_state_dict(net_a.state_dict())
+    ring.load(0, batches[0])
+    for t in range(steps):
+        i = t % 2
+        if t + 1 < steps:
+            ring.load((i + 1) % 2, batches[t + 1])  # overlaps the step below
+        ring.ready(i)
+        la = step_a.replay(i).clone()
+        ring.release(i)
+        ga = red_a.flat.clone()
+        lb = step_b(torch.from_numpy(batches[t]).cuda())
+        assert torch.equal(la, lb) and torch.equal(ga, red_b.flat), t
