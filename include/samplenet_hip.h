@@ -268,6 +268,14 @@ int sn_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, cons
                  float *cost, float *workspace, sn_stream_t stream);
 int sn_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
                       float *grad1, float *grad2, sn_stream_t stream);
+/* EMD loss in one call, without the (b,m,n) match matrix: cost (b) = match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) as
+ * reconstruction/src/samplenet_pointnet_ae.py:129-131 composes it, and -- when grad1 (b,n,3) / grad2 (b,m,3) are given -- the
+ * gradient of each cost w.r.t. its clouds with match held constant (tf_approxmatch.py:54-64).  match[l,k] is re-evaluated
+ * from the per-level ratio vectors inside the sweeps: 839 MB never written at B = 50, 2048 x 2048.  cost and grad1 are
+ * bit-identical to sn_matchcost / sn_matchcost_grad on the materialised match; grad2 sums in a different order (1e-5).
+ * temp: sn_workspace_bytes("emd_loss", b, n, m, 0) bytes. */
+int sn_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
+                float *temp, sn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PointNet feature extractor + FC head (registration/src/samplenet.py:40-59, :90-104): every layer is a

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "sn_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sn_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_matchcost_grad": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_emd_loss": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong,
              "sn_pairscan_workspace_bytes": ctypes.c_longlong, "sn_layer_backward_in3_stats_floats": ctypes.c_longlong,

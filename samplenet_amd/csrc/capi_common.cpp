@@ -28,5 +28,6 @@ extern "C" long long sn_workspace_bytes(const char *op, int B, int N, int M, int
     // implementation keeps the ratio vectors of all 10 levels so that `match` is written once.
     if (!strcmp(op, "approxmatch")) return sn_emd_workspace_floats(B, N, M) * 4;
     if (!strcmp(op, "matchcost")) return (long long)B * ((N + 255) / 256) * 4;  // per-workgroup partial sums
+    if (!strcmp(op, "emd_loss")) return sn_emd_workspace_floats(B, N, M) * 4 + (long long)B * ((N + 255) / 256) * 4;
     return 0;
 }

@@ -343,6 +343,86 @@ __global__ void __launch_bounds__(256) emd_grad2_kernel(int n, int m, const floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// EMD loss without the match matrix (what reconstruction/src/samplenet_pointnet_ae.py:129-131 wants: match_cost(approx_match)
+// and its gradient): match[l,k] = sum_levels exp(level d) ratioL_lev[k] ratioR_lev[l] is re-evaluated from the per-level ratio
+// vectors (packed: two levels per issue) inside the cost / gradient sweeps instead of being written (839 MB at B = 50,
+// 2048 x 2048) and read back three times.  The exponentials are evaluated twice (once per reduction axis); the sweeps
+// are VALU-bound like the level passes.
+//   emd_loss_k_kernel: thread per xyz1 point k, sequential over l (the order of emd_cost_partial_kernel / emd_grad1_kernel:
+//                      cost and grad1 are bit-identical to sn_matchcost / sn_matchcost_grad on the materialised match)
+//   emd_loss_l_kernel: thread per xyz2 point l, sequential over k -> grad2
+// LDS tile of the other cloud: per point {x, y, z, pad} + its 10 ratios.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLossTile = 256;
+template <bool KSIDE>
+__global__ void __launch_bounds__(256) emd_loss_sweep_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                             const float *__restrict__ xyz2, const float *__restrict__ ws,
+                                                             float *__restrict__ partial, float *__restrict__ grad)
+{
+    __shared__ float4 tpt[kLossTile];
+    __shared__ float trat[kLevels][kLossTile];
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const int nself = KSIDE ? n : m, nother = KSIDE ? m : n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // k (KSIDE) or l
+    const float *Xs = (KSIDE ? xyz1 : xyz2) + (size_t)b * nself * 3;
+    const float *Xo = (KSIDE ? xyz2 : xyz1) + (size_t)b * nother * 3;
+    const float *base = ws + (size_t)b * emd_ws_floats(n, m);
+    const float *ratioL = base + n + m, *ratioR = ratioL + (size_t)kLevels * n;
+    const float *rself = KSIDE ? ratioL : ratioR, *rother = KSIDE ? ratioR : ratioL;
+    float xs = 0, ys = 0, zs = 0, rs[kLevels];
+#pragma unroll
+    for (int li = 0; li < kLevels; ++li) rs[li] = 0.f;
+    if (i < nself) {
+        xs = Xs[i * 3 + 0], ys = Xs[i * 3 + 1], zs = Xs[i * 3 + 2];
+#pragma unroll
+        for (int li = 0; li < kLevels; ++li) rs[li] = rself[(size_t)li * nself + i];
+    }
+    float sub = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int o0 = 0; o0 < nother; o0 += kLossTile) {
+        const int oend = min(nother, o0 + kLossTile) - o0;
+        __syncthreads();
+        for (int o = threadIdx.x; o < oend; o += blockDim.x) {
+            tpt[o] = make_float4(Xo[(o0 + o) * 3 + 0], Xo[(o0 + o) * 3 + 1], Xo[(o0 + o) * 3 + 2], 0.f);
+#pragma unroll
+            for (int li = 0; li < kLevels; ++li) trat[li][o] = rother[(size_t)li * nother + o0 + o];
+        }
+        __syncthreads();
+        for (int o = 0; o < oend; ++o) {
+            const float4 t = tpt[o];
+            // emd_sq(x1, x2): (x2 - x1)^2 ... -- sign-symmetric, so one expression serves both sides
+            const float ex = xs - t.x, ey = ys - t.y, ez = zs - t.z;  // x_self - x_other: the gradient's direction
+            const float d2 = (ex * ex + ey * ey) + ez * ez;
+            float mt = 0.f;  // match[l,k], levels in order (as emd_materialize_kernel)
+#pragma unroll
+            for (int li = 0; li < kLevels; li += 2) {
+                const f2v lv = {emd_level(li), emd_level(li + 1)};
+                const f2v rl = KSIDE ? (f2v){rs[li], rs[li + 1]} : (f2v){trat[li][o], trat[li + 1][o]};
+                const f2v rr = KSIDE ? (f2v){trat[li][o], trat[li + 1][o]} : (f2v){rs[li], rs[li + 1]};
+                const f2v w = emd_exp2(lv * d2) * rl * rr;
+                mt += w.x;
+                mt += w.y;
+            }
+            if (KSIDE) sub += sqrtf(d2) * mt;  // cost (tf_approxmatch_g.cu:183-213)
+            const float g = mt * rsqrtf(fmaxf(d2, 1e-20f));  // (:229-291)
+            gx += ex * g, gy += ey * g, gz += ez * g;
+        }
+    }
+    if (grad && i < nself) {
+        float *go = grad + ((size_t)b * nself + i) * 3;
+        go[0] = gx, go[1] = gy, go[2] = gz;
+    }
+    if (KSIDE && partial) {
+        red[threadIdx.x] = i < nself ? sub : 0.f;
+        for (int s = 128; s > 0; s >>= 1) {
+            __syncthreads();
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        }
+        if (threadIdx.x == 0) partial[(size_t)b * gridDim.x + blockIdx.x] = red[0];
+    }
+}
+
 }  // namespace sn
 
 using namespace sn;
@@ -401,6 +481,33 @@ extern "C" int sn_matchcost_grad(int b, int n, int m, const float *xyz1, const f
     hipStream_t st = (hipStream_t)stream;
     if (grad1) hipLaunchKernelGGL(emd_grad1_kernel, dim3((n + 255) / 256, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad1);
     if (grad2) hipLaunchKernelGGL(emd_grad2_kernel, dim3((m + 3) / 4, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// cost (b) = match_cost(approx_match(xyz1, xyz2)) and its gradients without materialising match (see emd_loss_sweep_kernel).
+// temp: sn_workspace_bytes("emd_loss", b, n, m, 0) bytes.  grad1 / grad2 may be NULL.
+extern "C" int sn_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
+                           float *temp, sn_stream_t stream)
+{
+    SN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+    if (b == 0) return 0;
+    SN_REQUIRE(cost, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0 || m == 0) {
+        hipError_t e = hipMemsetAsync(cost, 0, sizeof(float) * b, st);
+        return e == hipSuccess ? 0 : sn_set_error((int)e, "sn_emd_loss: %s", hipGetErrorString(e));
+    }
+    SN_REQUIRE(xyz1 && xyz2 && temp, "null pointer");
+    int rc = sn_approxmatch(b, n, m, xyz1, xyz2, nullptr, temp, stream);  // the 20 level passes; no materialisation
+    if (rc) return rc;
+    float *partial = temp + sn_emd_workspace_floats(b, n, m);
+    const int nparts = (n + 255) / 256;
+    hipLaunchKernelGGL((emd_loss_sweep_kernel<true>), dim3(nparts, b), dim3(256), 0, st, n, m, xyz1, xyz2, temp, partial, grad1);
+    hipLaunchKernelGGL(emd_cost_final_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, nparts, partial, cost);
+    if (grad2)
+        hipLaunchKernelGGL((emd_loss_sweep_kernel<false>), dim3((m + 255) / 256, b), dim3(256), 0, st, n, m, xyz1, xyz2, temp,
+                           (float *)nullptr, grad2);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -616,3 +616,34 @@ class MatchCostFunction(torch.autograd.Function):
 
 
 match_cost = MatchCostFunction.apply
+
+
+class EmdLossFunction(torch.autograd.Function):
+    """cost (B,) = match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) in one call, WITHOUT the (B,m,n) match matrix
+    (sn_emd_loss): forward runs the auction and one cost / gradient sweep per cloud; backward scales the saved gradients
+    (match is a constant of the gradient, tf_approxmatch.py:54-64)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        _need_gpu(xyz1, xyz2)
+        x1, x2 = _f32c(xyz1), _f32c(xyz2)
+        b, n, _ = x1.shape
+        m = x2.shape[1]
+        cost = torch.empty(b, device=x1.device, dtype=torch.float32)
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g1 = torch.empty_like(x1) if need1 else None
+        g2 = torch.empty_like(x2) if need2 else None
+        ws = torch.empty(max(1, lib.sn_workspace_bytes(b"emd_loss", b, n, m, 0) // 4), device=x1.device, dtype=torch.float32)
+        with torch.cuda.device(x1.device):
+            check(lib.sn_emd_loss(b, n, m, ptr(x1), ptr(x2), ptr(cost), ptr(g1), ptr(g2), ptr(ws), _stream(x1)), "sn_emd_loss")
+        ctx.save_for_backward(g1, g2)
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        g1, g2 = ctx.saved_tensors
+        gc = grad_cost.reshape(-1, 1, 1)
+        return (g1 * gc if g1 is not None else None), (g2 * gc if g2 is not None else None)
+
+
+emd_loss = EmdLossFunction.apply

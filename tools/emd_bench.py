@@ -36,3 +36,12 @@ for (B, n, m) in [(32, 1024, 64), (8, 2048, 2048), (50, 2048, 2048)]:
           "cost+grad %7.1f us   row sums of match: %.4f..%.4f" %
           (B, n, m, t_match * 1e3, t_match * 1e3 / B, mb, mb / t_match, t_cost * 1e3, t_grad * 1e3,
            float(match.sum(2).min()), float(match.sum(2).max())))
+
+# the loss without the match matrix (sn_emd_loss: auction + two sweeps) against the three-call composition
+for (B, n, m) in [(50, 2048, 2048)]:
+    a = (torch.rand(B, n, 3, device="cuda") - 0.5).requires_grad_(True)
+    b = (torch.rand(B, m, 3, device="cuda") - 0.5).requires_grad_(True)
+    t_fused, _ = timed(lambda: torch.autograd.grad(ops.emd_loss(a, b).sum(), [a, b]), 5)
+    t_three, _ = timed(lambda: torch.autograd.grad(ops.match_cost(a, b, ops.approx_match(a, b)).sum(), [a, b]), 5)
+    print("B=%3d n=%4d m=%4d: emd loss + gradients: no-materialise %8.1f us, approx_match + match_cost + grad %8.1f us" %
+          (B, n, m, t_fused * 1e3, t_three * 1e3))
