@@ -322,7 +322,8 @@ int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, c
  * sits between layers.  channels [nlayers+1] = 3, C1..Cn (64 or 128 each); N % 64 == 0 (query _supported first).
  * Arrays of nlayers device pointers: W (C_{l+1},C_l), bias, gamma, beta, running_mean, running_var, num_batches_tracked,
  * z (B*N,C_{l+1}) pre-BN outputs, coef (4,C_{l+1}); eps / momentum: host arrays.  acc: sn_conv_stack_acc_elems(nlayers) long long of persistent
- * device scratch, zero before the first call (every call leaves it zero).  pool_val / pool_idx: (B*N/64)*2*Cn scratch. */
+ * device scratch, zero before the first call (every call leaves it zero).  pool_val / pool_idx: (B*N/64)*2*Cn scratch.
+ * pooled = argsel = zsel = NULL: stop after the last GEMM; sn_fc_chain_forward_pool must follow (it finishes the pool). */
 int sn_conv_stack_forward_supported(int B, int N, int nlayers, const int *channels);
 long long sn_conv_stack_acc_elems(int nlayers);
 int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
@@ -380,6 +381,22 @@ int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0, const flo
                         float *const *running_var, long long *const *num_batches_tracked, const float *eps,
                         const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
                         sn_stream_t stream);
+/* sn_fc_chain_forward with the tail of the conv stack in front (samplenet.py:90-101: bn5 / relu / max over the points /
+ * fc1..fc3): call sn_conv_stack_forward_bn with pooled = argsel = zsel = NULL -- it then stops after its last GEMM, leaving
+ * the last layer's fixed-point sums in acc and the block maxima / minima in pool_val / pool_idx -- and this entry right after:
+ * its first stage finalises that BatchNorm (gamma5 .. coef5, clearing acc), picks the max-pool (pooled / argsel / zsel as
+ * sn_pool_forward) and hands pooled to the FC layers through the same in-kernel exchange.  B <= 32 clouds, N <= 1024
+ * (N % 64 == 0), conv stack of nconv layers ending in C0 = 128 channels, H = 256, nl = 3 (query _supported).  Same results as
+ * the two separate calls. */
+int sn_fc_chain_forward_pool_supported(int B, int N, int C0, int H, int nl);
+int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc, const float *pool_val, const int *pool_idx,
+                             const float *gamma5, const float *beta5, float *running_mean5, float *running_var5,
+                             long long *num_batches_tracked5, float eps5, float momentum5, float *coef5, float *pooled,
+                             int *argsel, float *zsel, int H, int nl, const float *const *W, const float *const *bias,
+                             const float *const *gamma, const float *const *beta, float *const *running_mean,
+                             float *const *running_var, long long *const *num_batches_tracked, const float *eps,
+                             const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
+                             sn_stream_t stream);
 /* The FC head's backward (R <= 32 rows) as ONE launch, the mirror of sn_fc_chain_forward.  Stage s = GEMM layer, TOP first:
  * W[s] (Co[s], Ci[s]); below it: zprev[s] (R, Ci[s]) pre-BN output seen through coefprev[s] (4, Ci[s]) (the pooled-feature
  * stage: zsel with the last conv layer's coefficients and bn_rows[s] = B * N; bn_rows < 0: fixed statistics); outputs per

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "sn_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_finalize": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_fc_chain_forward_supported": [_i, _i, _i, _i],
+    "sn_fc_chain_forward_pool_supported": [_i, _i, _i, _i, _i],
+    "sn_fc_chain_forward_pool": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i] + [_vp] * 14,
     "sn_fc_chain_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_fc_chain_backward_supported": [_i, _i, _vp, _vp],
     "sn_fc_chain_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -103,6 +103,31 @@ __device__ __forceinline__ void fx_add(long long *layer, int slot, int stat, int
 // both totals of channel c (stat 0, stat 1) over the slots, in ONE batch of loads and without a branch: reading the
 // statistics one after the other, or behind a "hi rows in use" flag test, costs a second memory round trip per consumer
 // (+6 us per step, measured).
+// (the loads and the arithmetic separately, for callers that want other fetches issued between the two)
+struct FxRaw2 {
+    long long lo[kFxSlots][2], hi[2], poison;
+};
+__device__ __forceinline__ FxRaw2 fx_load2(const long long *layer, int c)
+{
+    FxRaw2 r;
+    r.poison = layer[kFxPoison];
+#pragma unroll
+    for (int q = 0; q < kFxSlots; ++q) r.lo[q][0] = layer[(q * 2 + 0) * kFxRow + c], r.lo[q][1] = layer[(q * 2 + 1) * kFxRow + c];
+    r.hi[0] = layer[kFxHi + c], r.hi[1] = layer[kFxHi + kFxRow + c];
+    return r;
+}
+template <int SHIFT>
+__device__ __forceinline__ void fx_total2(const FxRaw2 &r, double &t0, double &t1)
+{
+    long long a = 0, b = 0;
+#pragma unroll
+    for (int q = 0; q < kFxSlots; ++q) a += r.lo[q][0], b += r.lo[q][1];
+    const double x = (double)a + (double)r.hi[0] * kFx2p50, y = (double)b + (double)r.hi[1] * kFx2p50;
+    const double sc = (1.0 / (double)(1ull << 30)) * (1.0 / (double)(1ull << (SHIFT - 30)));
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    t0 = r.poison ? nan : x * sc;
+    t1 = r.poison ? nan : y * sc;
+}
 template <int SHIFT>
 __device__ __forceinline__ void fx_get2(const long long *layer, int c, double &t0, double &t1)
 {
@@ -562,19 +587,24 @@ __device__ __forceinline__ BnFwdIn bn_fwd_inputs(const BnFwd &bn, int c)
     if (bn.running_mean) in.rmean = bn.running_mean[c], in.rvar = bn.running_var[c];
     return in;
 }
-__device__ __forceinline__ float2 bn_finalize_channel_mv(const BnFwd &bn, int C, int c, double mean, double var, const BnFwdIn &in);
-__device__ __forceinline__ float2 bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss, const BnFwdIn &in)
+// (write = false: the value only -- several threads of a workgroup may evaluate the same channel, one of them stores)
+__device__ __forceinline__ float2 bn_finalize_channel_mv(const BnFwd &bn, int C, int c, double mean, double var, const BnFwdIn &in,
+                                                         bool write = true);
+__device__ __forceinline__ float2 bn_finalize_channel(const BnFwd &bn, int C, int c, double s, double ss, const BnFwdIn &in,
+                                                      bool write = true)
 {
     const double rR = fast_rcp((double)bn.R);
     const double mean = s * rR;
     double var = ss * rR - mean * mean;
     if (var < 0.0) var = 0.0;
-    return bn_finalize_channel_mv(bn, C, c, mean, var, in);
+    return bn_finalize_channel_mv(bn, C, c, mean, var, in, write);
 }
-__device__ __forceinline__ float2 bn_finalize_channel_mv(const BnFwd &bn, int C, int c, double mean, double var, const BnFwdIn &in)
+__device__ __forceinline__ float2 bn_finalize_channel_mv(const BnFwd &bn, int C, int c, double mean, double var, const BnFwdIn &in,
+                                                         bool write)
 {
     const float invstd = (float)fast_rsqrt(var + (double)bn.eps);
     const float sc = in.gamma * invstd;
+    if (!write) return make_float2(sc, in.beta - (float)mean * sc);
     bn.coef[c] = sc;
     bn.coef[C + c] = in.beta - (float)mean * sc;
     bn.coef[2 * C + c] = (float)mean;
@@ -1863,9 +1893,21 @@ struct FcChainLayer {
     float *z, *coef;  // outputs: pre-BN (R, H) and (4, H)
     float eps, momentum;
 };
+// POOL variant: the last conv layer's BatchNorm finalisation + max-pool pick (bn_finalize_pool_kernel) as stage -1 of the chain
+struct FcChainPool {
+    long long *acc;        // fixed-point statistics of the last conv layer (cleared here: this launch is their only reader)
+    long long *zero_ptr;   // the accumulators the PREVIOUS kernel consumed
+    int zero_n, bpc;       // 64-row blocks per cloud (<= 16)
+    const float *pool_val;  // [R * bpc][2][C0] block maxima / minima of the pre-BN output ...
+    const int *pool_idx;    // ... and their rows
+    BnFwd bn;
+    float *pooled, *zsel;  // (R, C0)
+    int *argsel;
+};
 struct FcChainArgs {
     const float *a0;  // (R, C0): input of the first layer, used as is (pooled features)
     int R, C0, H, nl;
+    FcChainPool P;
     FcChainLayer L[kFcChainMaxLayers];
     float *xbuf;     // [2][32][H] exchange slabs
     unsigned *sync;  // [0] epoch, [1 + s] arrivals at seam s, [15] error flag -- persistent, zero-initialised once
@@ -1903,8 +1945,24 @@ __device__ __forceinline__ void store_sc1_b128(float *p, f32x4v v)
 
 // C0T / NLT > 0: input width / layer count known at compile time (the sampler's 128 -> 256 x 3 head): the operand fetches then
 // unroll into ONE batch of loads; 0: run-time loops.
-template <int C0T, int NLT>
-__global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
+// One seam of the chain kernels: arrive at counter `ctr`, wait until all nwg workgroups of this launch have (counters are
+// monotonic over launches: target = (epoch + 1) * nwg).  Called by thread 0 between two lds_barrier().
+__device__ __forceinline__ void fc_chain_seam(unsigned *sync, int ctr, unsigned epoch, int nwg, unsigned errcode)
+{
+    __hip_atomic_fetch_add(sync + ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (epoch + 1u) * (unsigned)nwg;
+    int spins = 0;
+    while ((int)(__hip_atomic_load(sync + ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (++spins > (1 << 22)) {  // never on a healthy run: report instead of hanging the device
+            __hip_atomic_store(sync + 15, errcode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int C0T, int NLT, bool POOL = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) fc_chain_fwd_kernel(FcChainArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ unsigned s_epoch;
@@ -1924,7 +1982,121 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
     if (tid == 0) s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- every layer's weight slice + the first operand: all fetches issued up front, staged into LDS as they land
-    if (C0T > 0 && NLT > 0) {
+    if (POOL) {
+        // ---- stage -1: BatchNorm of the last conv layer from its fixed-point sums + the max-pool pick over the cloud's
+        // 64-row blocks -> pooled (R, C0), handed to the other workgroups like a layer's activations.  Workgroup wg owns
+        // channels [16 wg, 16 wg + 16): thread -> (channel cl, clouds j and j + 16).  The block MAXIMA are fetched
+        // speculatively together with everything else (the pick needs the sign of the BatchNorm scale: negative -> the
+        // minima are fetched in a second, rare, round trip).  Every thread evaluates its channel's coefficients itself
+        // (16-fold redundant loads of the same sums: cheaper than a broadcast through LDS behind a barrier).
+        constexpr int CP = C0T > 0 ? C0T : 128, NH = NLT > 1 ? NLT - 1 : 1;
+        const FcChainPool &P = g.P;
+        const int cl = tid & 15, c = wg * 16 + cl, j = tid >> 4, bpc = P.bpc;
+        const FxRaw2 fx = fx_load2(P.acc, c);
+        float pv[2][16];
+        int pi[2][16];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const size_t o = ((size_t)(min(j + 16 * u, R - 1) * bpc + min(q, bpc - 1)) * 2) * CP + c;
+                pv[u][q] = P.pool_val[o], pi[u][q] = P.pool_idx[o];
+            }
+        const BnFwdIn in{P.bn.gamma[c], P.bn.beta[c], P.bn.running_mean[c], P.bn.running_var[c]};  // (host: never NULL here)
+        constexpr int q4 = CP / 4, rpp = 256 / q4, npass = 32 / rpp;
+        const int c4 = (tid % q4) * 4, r0 = tid / q4;
+        const int hc4 = (tid % 64) * 4, hr0 = tid / 64;
+        f32x4v wv[npass], wh[NH][8];  // (native vectors: arrays of the float4 STRUCT end up in scratch across the asm)
+#pragma unroll
+        for (int q = 0; q < npass; ++q) wv[q] = *reinterpret_cast<const f32x4v *>(g.L[0].W + (size_t)(col0 + r0 + q * rpp) * C0 + c4);
+#pragma unroll
+        for (int l = 1; l < NLT; ++l)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wh[l - 1][q] = *reinterpret_cast<const f32x4v *>(g.L[l].W + (size_t)(col0 + hr0 + q * 4) * H + hc4);
+        // every fetch of the kernel is in flight now; nothing below may be hoisted between them (the compiler otherwise waits
+        // for the sums before it issues the rest: two round trips)
+        asm volatile("" ::: "memory");
+        double s, ss;
+        fx_total2<kFxShiftFwd>(fx, s, ss);
+        const bool writer = j == 0;
+        const float2 cf = bn_finalize_channel(P.bn, CP, c, s, ss, in, writer);
+        if (wg == 0 && tid == 0 && P.bn.num_batches_tracked) *P.bn.num_batches_tracked += 1;
+        const float sc = cf.x, sh = cf.y;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int b = j + 16 * u;
+            float best = -INFINITY;
+            int arg = 0x7fffffff;
+            if (sc >= 0.f) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float v = pv[u][q];
+                    const int i = pi[u][q];
+                    if (q < bpc && (v > best || (v == best && i < arg))) best = v, arg = i;
+                }
+            } else {
+                best = INFINITY;
+                for (int q = 0; q < bpc; ++q) {
+                    const size_t o = ((size_t)(min(b, R - 1) * bpc + q) * 2 + 1) * CP + c;
+                    const float v = P.pool_val[o];
+                    const int i = P.pool_idx[o];
+                    if (v < best || (v == best && i < arg)) best = v, arg = i;
+                }
+            }
+            const float pooled = relu_np(fmaf(best, sc, sh));
+            Ta[b * 16 + cl] = b < R ? pooled : 0.f;  // [32 clouds][16 channels] tile of this workgroup
+            if (b < R) {
+                P.pooled[(size_t)b * CP + c] = pooled;
+                P.argsel[(size_t)b * CP + c] = arg;
+                P.zsel[(size_t)b * CP + c] = best;
+            }
+        }
+        // the tile leaves as 16-byte write-through stores into this workgroup's OWN 2 KB of the exchange slab (tile-major
+        // [wg][32][16]: no 128-byte line has two writers.  Published as 4-byte stores straight into pooled (R, 128), where two
+        // workgroups share every line, readers intermittently saw stale halves.)  Slab 1: first reused at layer 1's seam,
+        // which every workgroup reaches after it has gathered this.
+        lds_barrier();
+        float *xp = g.xbuf + (size_t)32 * H;
+        if (tid < 128) {
+            const float4 v = *reinterpret_cast<const float4 *>(Ta + tid * 4);
+            f32x4v vv = {v.x, v.y, v.z, v.w};
+            store_sc1_b128(xp + (size_t)wg * 512 + tid * 4, vv);
+        }
+        // the weight slices (the bulk of the bytes, last to arrive) go to LDS while the tile drains
+#pragma unroll
+        for (int q = 0; q < npass; ++q) *reinterpret_cast<f32x4v *>(W0s + (r0 + q * rpp) * (C0 + 4) + c4) = wv[q];
+#pragma unroll
+        for (int l = 1; l < NLT; ++l)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                *reinterpret_cast<f32x4v *>(Whs + (size_t)(l - 1) * 32 * (H + 4) + (hr0 + q * 4) * (H + 4) + hc4) = wh[l - 1][q];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();  // every wave's loads of the sums have returned: they can be cleared for the next step
+        if (writer)
+#pragma unroll
+            for (int q = 0; q < kFxSlots * 2 + 2; ++q) P.acc[q * kFxRow + c] = 0;  // lo rows and the two hi rows (the poison
+                                                                                 // word: first kernel of the next step)
+        fx_clear_share(P.zero_ptr, P.zero_n, wg, nwg, tid, 256);
+        if (tid == 0) {
+            fc_chain_seam(g.sync, 8, s_epoch, nwg, 9u);
+            if (wg == 0) __hip_atomic_store(g.sync, s_epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_barrier();
+        {
+            f32x4v r[npass];
+#pragma unroll
+            for (int q = 0; q < npass; ++q) {
+                const float *p = xp + (size_t)(c4 >> 4) * 512 + (r0 + q * rpp) * 16 + (c4 & 15);
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[q]) : "v"(p) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < npass; ++q) {
+                const int rr = r0 + q * rpp;
+                *reinterpret_cast<float4 *>(As + rr * LDA + c4) = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);  // (rows >= R: zeros)
+            }
+        }
+    } else if (C0T > 0 && NLT > 0) {
         // compile-time shape: every load of the kernel's operands is issued before the first LDS write (no loop-carried
         // load -> store dependencies, no branches around loads), layer 0's operands first
         constexpr int q4 = (C0T > 0 ? C0T : 128) / 4, rpp = 256 / q4, npass = 32 / rpp;
@@ -2057,17 +2229,8 @@ __global__ void __launch_bounds__(256) fc_chain_fwd_kernel(FcChainArgs g)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         if (tid == 0) {
-            __hip_atomic_fetch_add(g.sync + 1 + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = (epoch + 1u) * (unsigned)nwg;
-            int spins = 0;
-            while ((int)(__hip_atomic_load(g.sync + 1 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                if (++spins > (1 << 22)) {  // never on a healthy run: report instead of hanging the device
-                    __hip_atomic_store(g.sync + 15, 1u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (l == 0 && wg == 0) __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fc_chain_seam(g.sync, 1 + l, epoch, nwg, 1u + (unsigned)l);
+            if (!POOL && l == 0 && wg == 0) __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lds_barrier();
         // gather the whole 32 x H activation (write-through data: sc1 loads read it from L2 / memory, never from a stale L1 line)
@@ -3445,6 +3608,55 @@ extern "C" int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0
     return 0;
 }
 
+// sn_fc_chain_forward with the tail of the conv stack in front: sn_conv_stack_forward_bn called with pooled = argsel = zsel =
+// NULL stops after its last GEMM; this launch then finalises that layer's BatchNorm from the fixed-point sums in acc (clearing
+// them), picks the max-pool from pool_val / pool_idx and runs the FC head on the result -- one launch and one ~2 us seam
+// instead of a 6 us kernel and its boundary.  B <= 32 clouds of N <= 1024 points (N % 64 == 0), nconv conv layers ending in
+// 128 channels, FC head 128 -> 256 x 3.  gamma5 .. coef5: the last conv layer's BatchNorm as in sn_conv_stack_forward_bn.
+extern "C" int sn_fc_chain_forward_pool_supported(int B, int N, int C0, int H, int nl)
+{
+    return B >= 1 && B <= 32 && N >= 64 && N <= 1024 && N % 64 == 0 && C0 == 128 && H == 256 && nl == 3;
+}
+
+extern "C" int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc, const float *pool_val, const int *pool_idx,
+                                        const float *gamma5, const float *beta5, float *running_mean5, float *running_var5,
+                                        long long *num_batches_tracked5, float eps5, float momentum5, float *coef5, float *pooled,
+                                        int *argsel, float *zsel, int H, int nl, const float *const *W, const float *const *bias,
+                                        const float *const *gamma, const float *const *beta, float *const *running_mean,
+                                        float *const *running_var, long long *const *num_batches_tracked, const float *eps,
+                                        const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
+                                        sn_stream_t stream)
+{
+    constexpr int C0 = 128;
+    SN_REQUIRE(sn_fc_chain_forward_pool_supported(B, N, C0, H, nl) && nconv >= 2, "shape not supported (sn_fc_chain_forward_pool_supported)");
+    SN_REQUIRE(acc && pool_val && pool_idx && gamma5 && beta5 && running_mean5 && running_var5 && coef5 && pooled && argsel && zsel,
+               "null pointer");
+    SN_REQUIRE(W && bias && gamma && beta && eps && momentum && z && coef && xbuf && sync, "null pointer");
+    FcChainArgs g{};
+    g.a0 = pooled, g.R = B, g.C0 = C0, g.H = H, g.nl = nl, g.xbuf = xbuf, g.sync = sync;
+    g.P.acc = acc + (size_t)(nconv - 1) * kFxLayer, g.P.zero_ptr = acc + (size_t)(nconv - 2) * kFxLayer, g.P.zero_n = kFxLayer;
+    g.P.bpc = N / 64, g.P.pool_val = pool_val, g.P.pool_idx = pool_idx;
+    g.P.bn = BnFwd{gamma5, beta5, running_mean5, running_var5, num_batches_tracked5, coef5, eps5, momentum5, (long long)B * N};
+    g.P.pooled = pooled, g.P.argsel = argsel, g.P.zsel = zsel;
+    for (int l = 0; l < nl; ++l) {
+        SN_REQUIRE(W[l] && bias[l] && gamma[l] && beta[l] && z[l] && coef[l], "null layer pointer");
+        g.L[l] = FcChainLayer{W[l], bias[l], gamma[l], beta[l], running_mean ? running_mean[l] : nullptr,
+                              running_var ? running_var[l] : nullptr, num_batches_tracked ? num_batches_tracked[l] : nullptr,
+                              z[l], coef[l], eps[l], momentum[l]};
+    }
+    const size_t lds = fc_chain_fwd_lds(C0, H, nl);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)fc_chain_fwd_kernel<128, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sn_set_error(SN_ERR_UNSUPPORTED, "sn_fc_chain_forward_pool: %zu bytes of LDS refused", lds);
+        attr_done = true;
+    }
+    g.rinv_rows = 1.0 / (double)B, g.unbias = B > 1 ? (double)B / (double)(B - 1) : 1.0;
+    hipLaunchKernelGGL((fc_chain_fwd_kernel<128, 3, true>), dim3(8 * (H / 32)), dim3(256), lds, (hipStream_t)stream, g);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 // 1: sn_fc_chain_backward runs this FC head's backward (ns GEMM layers, top first: Co[s] x Ci[s]) as one launch
 extern "C" int sn_fc_chain_backward_supported(int R, int ns, const int *Co, const int *Ci)
 {
@@ -3542,8 +3754,8 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
 {
     if (!sn_conv_stack_forward_supported(B, N, nlayers, channels))
         return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_stack_forward_bn: needs N % 64 == 0 and 64 / 128 channels");
-    SN_REQUIRE(x && W && gamma && beta && eps && momentum && z && coef && acc && pool_val && pool_idx && pooled && argsel && zsel,
-               "null pointer");
+    SN_REQUIRE(x && W && gamma && beta && eps && momentum && z && coef && acc && pool_val && pool_idx, "null pointer");
+    SN_REQUIRE((pooled && argsel && zsel) || (!pooled && !argsel && !zsel), "pooled / argsel / zsel: all or none");
     hipStream_t st = (hipStream_t)stream;
     const int R = B * N;
     auto bn_of = [&](int l) {
@@ -3579,6 +3791,10 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
     }
     const int Cn = channels[nlayers];
     long long *zp = nlayers >= 2 ? acc + (size_t)(nlayers - 2) * kFxLayer : nullptr;
+    if (!pooled) {  // the last BatchNorm + the pool pick run as the first stage of sn_fc_chain_forward_pool
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(bn_finalize_pool_kernel, dim3((Cn + kChan - 1) / kChan), dim3(1024), 0, st, 0, Cn, (const float *)nullptr,
                        bn_of(nlayers - 1), B, N / 64, pool_val, pool_idx, pooled, argsel, zsel, acc + (size_t)(nlayers - 1) * kFxLayer, zp,
                        zp ? kFxLayer : 0);

@@ -142,10 +142,12 @@ def _bn_coef(L, R, stats, nblk, training):
     return coef
 
 
-def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel):
+def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_pool=False):
     """Training forward of the conv stack + max-pool as one call (sn_conv_stack_forward_bn: batch statistics as fixed-point
     sums, every layer finalises the BatchNorm of its input -- no reduction launch between layers).  Fills saved["zc"] /
-    saved["cc"]; returns False when the shapes are not supported (the per-layer path runs instead)."""
+    saved["cc"]; returns False when the shapes are not supported (the per-layer path runs instead).
+    defer_pool: stop after the last GEMM -- the last BatchNorm and the pool pick run as the first stage of the FC chain
+    (_fc_chain_fwd with saved["pool_tail"])."""
     import ctypes
 
     n = len(convs)
@@ -178,28 +180,41 @@ def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel):
                                            arr([L.bn.weight for L in convs]), arr([L.bn.bias for L in convs]),
                                            arr([L.bn.running_mean for L in convs]), arr([L.bn.running_var for L in convs]),
                                            arr([L.bn.num_batches_tracked for L in convs]), eps, mom, arr(zs), arr(cs), ptr(acc),
-                                           ptr(pool_val), ptr(pool_idx), ptr(pooled), ptr(argsel), ptr(zsel), _st(x_bnc)),
+                                           ptr(pool_val), ptr(pool_idx), *([None] * 3 if defer_pool else
+                                                                          [ptr(pooled), ptr(argsel), ptr(zsel)]), _st(x_bnc)),
               "sn_conv_stack_forward_bn")
     except Exception:
         acc.zero_()  # a launch failed half way: do not leave partial sums behind
         raise
     saved["zc"], saved["cc"] = zs, cs
+    if defer_pool:
+        saved["pool_tail"] = (acc, pool_val, pool_idx, convs[-1], n, N, argsel, zsel)
     return True
 
 
-def _fc_chain_fwd(net, hidden, pooled, B, saved):
-    """The FC head's BatchNorm + ReLU layers as one launch (sn_fc_chain_forward).  Fills saved["zf"] / saved["cf"]; returns
-    False when the shape is not supported (the per-layer launches run instead)."""
-    import ctypes
-
+def _fc_chain_shape(hidden, B):
+    """(C0, H, n) when sn_fc_chain_forward can run these hidden FC layers on B rows, else None."""
     n = len(hidden)
     if n < 2 or any(L.bn is None or L.bn.momentum is None or not L.bn.track_running_stats for L in hidden):
-        return False
+        return None
     H, C0 = hidden[0].Co, hidden[0].Ci
     if any(L.Co != H for L in hidden) or any(L.Ci != H for L in hidden[1:]):
-        return False
+        return None
     if not lib.sn_fc_chain_forward_supported(B, C0, H, n):
+        return None
+    return C0, H, n
+
+
+def _fc_chain_fwd(net, hidden, pooled, B, saved):
+    """The FC head's BatchNorm + ReLU layers as one launch (sn_fc_chain_forward; with saved["pool_tail"] from a deferred
+    conv stack: sn_fc_chain_forward_pool, which also finishes the last conv BatchNorm and the max-pool).  Fills saved["zf"] /
+    saved["cf"]; returns False when the shape is not supported (the per-layer launches run instead)."""
+    import ctypes
+
+    shape = _fc_chain_shape(hidden, B)
+    if shape is None:
         return False
+    C0, H, n = shape
     sync = getattr(net, "_fc_sync", None)
     if sync is None or sync.device != pooled.device:
         sync = torch.zeros(16, device=pooled.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
@@ -214,11 +229,24 @@ def _fc_chain_fwd(net, hidden, pooled, B, saved):
 
     eps = (ctypes.c_float * n)(*[float(L.bn.eps) for L in hidden])
     mom = (ctypes.c_float * n)(*[float(L.bn.momentum) for L in hidden])
-    check(lib.sn_fc_chain_forward(B, C0, H, n, ptr(pooled), arr([L.W for L in hidden]), arr([L.b for L in hidden]),
-                                  arr([L.bn.weight for L in hidden]), arr([L.bn.bias for L in hidden]),
-                                  arr([L.bn.running_mean for L in hidden]), arr([L.bn.running_var for L in hidden]),
-                                  arr([L.bn.num_batches_tracked for L in hidden]), eps, mom, arr(zs), arr(cs), ptr(xbuf),
-                                  ptr(sync), _st(pooled)), "sn_fc_chain_forward")
+    layer_args = (arr([L.W for L in hidden]), arr([L.b for L in hidden]),
+                  arr([L.bn.weight for L in hidden]), arr([L.bn.bias for L in hidden]),
+                  arr([L.bn.running_mean for L in hidden]), arr([L.bn.running_var for L in hidden]),
+                  arr([L.bn.num_batches_tracked for L in hidden]), eps, mom, arr(zs), arr(cs), ptr(xbuf), ptr(sync), _st(pooled))
+    tail = saved.pop("pool_tail", None)
+    if tail is not None:
+        acc, pool_val, pool_idx, L5, nconv, N, argsel, zsel = tail
+        bn5 = L5.bn
+        try:
+            check(lib.sn_fc_chain_forward_pool(B, N, nconv, ptr(acc), ptr(pool_val), ptr(pool_idx), ptr(bn5.weight), ptr(bn5.bias),
+                                               ptr(bn5.running_mean), ptr(bn5.running_var), ptr(bn5.num_batches_tracked),
+                                               float(bn5.eps), float(bn5.momentum), ptr(saved["cc"][-1]), ptr(pooled), ptr(argsel),
+                                               ptr(zsel), H, n, *layer_args), "sn_fc_chain_forward_pool")
+        except Exception:
+            acc.zero_()
+            raise
+    else:
+        check(lib.sn_fc_chain_forward(B, C0, H, n, ptr(pooled), *layer_args), "sn_fc_chain_forward")
     saved["zf"], saved["cf"] = zs, cs
     saved["fc_chain"] = xbuf  # (scratch of the asynchronous launch)
     return True
@@ -240,7 +268,10 @@ def forward_impl(net, x_bnc, training, skip_last=False):
     zsel = _empty((B, C5), x_bnc)
     # last conv layer: the max-pool is folded into its epilogue + BatchNorm finalisation when the shapes are 64-aligned
     fuse_pool = training and R > 64 and N % 64 == 0 and C5 % 64 == 0 and convs[-1].Ci % 64 == 0 and FUSE_POOL
-    if fuse_pool and FX_STATS and _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel):
+    # ... and its BatchNorm finalisation + pool pick into the FC chain when that one runs (B <= 32, the 128 -> 256 x 3 head)
+    shape = _fc_chain_shape(fcs[:-1], B) if training and FC_CHAIN and POOL_IN_CHAIN else None
+    defer_pool = shape is not None and bool(lib.sn_fc_chain_forward_pool_supported(B, N, *shape))
+    if fuse_pool and FX_STATS and _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_pool):
         convs = []  # the whole stack ran as one call (fixed-point statistics chain)
     for li, L in enumerate(convs):
         if training and fuse_pool and li == len(convs) - 1:
@@ -356,6 +387,7 @@ FX_STATS = True
 IN3_CLOSED_FORM = True
 FUSE_POOL = True
 FC_CHAIN = True  # the FC head's hidden layers as one launch with in-kernel hand-offs (sn_fc_chain_forward)
+POOL_IN_CHAIN = True  # ... with the last conv BatchNorm + max-pool pick as its first stage (sn_fc_chain_forward_pool)
 
 
 def _wgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, aprev, coef_prev, with_bias, sink=None, name=""):

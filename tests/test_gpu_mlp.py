@@ -542,6 +542,46 @@ def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6), n
 
 
+@pytest.mark.parametrize("B,N", [(32, 1024), (32, 256), (5, 1024), (2, 64), (17, 704)])
+def test_pool_stage_of_the_fc_chain_equals_the_separate_launch(B, N):
+    """sn_fc_chain_forward_pool (last conv BatchNorm from the fixed-point sums + max-pool pick as the first stage of the FC
+    chain) against sn_conv_stack_forward_bn's own finalisation launch + sn_fc_chain_forward: bit for bit -- pooled features,
+    selected rows, pre-BN values, bn5 coefficients, every FC layer, running statistics -- with negative BatchNorm scales on
+    some channels (those pick the block MINIMA), repeatedly, and the statistics accumulators are left zero."""
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(B * 7 + N)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    with torch.no_grad():
+        net_a.bn5.weight[::5] *= -1.0
+        net_a.bn5.weight[3] = 0.0
+        net_a.bn5.bias.normal_(0, 0.1)
+    net_b = copy.deepcopy(net_a)
+    old = pointnet.POOL_IN_CHAIN
+    try:
+        for rep in range(3):
+            x = (torch.rand(B, N, 3, device="cuda") - 0.5).contiguous()
+            pointnet.POOL_IN_CHAIN = True
+            ya, sa = pointnet.forward_impl(net_a, x, True)
+            pointnet.POOL_IN_CHAIN = False
+            yb, sb = pointnet.forward_impl(net_b, x, True)
+            assert "fc_chain" in sa and "fc_chain" in sb
+            for k in ("pooled", "argsel", "zsel"):
+                assert torch.equal(sa[k], sb[k]), k
+            assert torch.equal(sa["cc"][-1], sb["cc"][-1])
+            for l in range(3):
+                assert torch.equal(sa["zf"][l], sb["zf"][l]) and torch.equal(sa["cf"][l], sb["cf"][l]), l
+            assert torch.equal(ya, yb)
+            assert int(net_a._fx_acc.abs().max()) == 0 and int(net_b._fx_acc.abs().max()) == 0
+    finally:
+        pointnet.POOL_IN_CHAIN = old
+    assert int(net_a._fc_sync[15]) == 0 and int(net_a._fc_sync[0]) == 3 and int(net_a._fc_sync[8]) == 3 * 8
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        # (bn5's running statistics: same expression compiled into two kernels -- the momentum blend contracts into a
+        #  different fma; one ulp)
+        assert torch.equal(ba, bb) or (n.startswith("bn5.running") and torch.allclose(ba, bb, rtol=2.5e-7, atol=1e-9)), n
+
+
 @pytest.mark.parametrize("B,bneck,variant,training", [(32, 128, None, True), (4, 128, None, True), (17, 256, None, True),
                                                      (32, 128, "reconstruction", True), (32, 128, None, False)])
 def test_fc_chain_backward_equals_per_layer_launches(B, bneck, variant, training):
