@@ -38,6 +38,9 @@ namespace sn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef SN_BF16X3
+#define SN_BF16X3 1  // conv-stack GEMMs: fp32 products as split-bf16 products on the bf16 matrix cores (gemm_tile_bx3)
+#endif
 constexpr int BK = 64;   // K chunk (one chunk covers the 64-channel layers: a single exposed global-load latency)
 constexpr int LPAD = 4;  // LDS row padding (floats): keeps rows 16-B aligned for the float4 staging stores
 
@@ -518,6 +521,120 @@ __device__ __forceinline__ void gemm_tile_x(f32x16 (&acc)[T::TM][T::TN], int K, 
     SN_TL(2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix cores.  Every fp32 operand is split into three bf16 numbers, a = a1 + a2 + a3 (round to
+// nearest each time: a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2); 8 significant bits each, the sum is exact to
+// the last bit or two of a), and a . b is accumulated in fp32 from the six products a_i b_j with i + j <= 4; the three
+// dropped ones are below 2^-23 |a b|.  v_mfma_f32_32x32x16_bf16 multiplies bf16 exactly and accumulates in fp32, and issues
+// 16x faster per flop than v_mfma_f32_32x32x2_f32: six of them cover K = 16 in 192 cycles per SIMD, the fp32 MFMA takes 512.
+// Measured against fp64 on this layer's shapes the result is as close as the fp32 MFMA's (tools/micro/bf16x3_gemm.hip: mean
+// error 1.3-2.0e-8 vs 1.7-1.9e-8 of sum |a b|, max 1.1-1.8e-7 vs 1.3-1.9e-7; nine products change nothing) at 2.5x the rate
+// (392 vs 155 fp32-equivalent TFLOP/s with operands in registers).
+// Operand fragments of the 32x32x16 form: lane -> row / column (lane & 31), 8 consecutive k at 8 (lane >> 5): a 16-byte
+// LDS read per plane from a row-major [x][k] bf16 image -- both operands of the forward GEMM are k-contiguous in memory,
+// so the staging is a straight copy (no transposes).  C/D layout as the fp32 form.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BKX = 32;       // K chunk of the split-bf16 path
+constexpr int LDX = BKX + 8;  // LDS row pitch in bf16: 80 bytes -- 16 consecutive rows' 16-byte fragments tile all 64 banks
+
+__device__ __forceinline__ void split3(float a, __bf16 &h1, __bf16 &h2, __bf16 &h3)
+{
+    h1 = (__bf16)a;
+    const float r1 = a - (float)h1;
+    h2 = (__bf16)r1;
+    h3 = (__bf16)(r1 - (float)h2);
+}
+// 4 consecutive k of one row -> the three planes' images (8 bytes each)
+template <int BX>
+__device__ __forceinline__ void stage_split(__bf16 *__restrict__ P, int x, int k4, const float4 v)
+{
+    bf16x4 p1, p2, p3;
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        __bf16 h1, h2, h3;
+        split3(e[t], h1, h2, h3);
+        p1[t] = h1, p2[t] = h2, p3[t] = h3;
+    }
+    *reinterpret_cast<bf16x4 *>(P + (0 * BX + x) * LDX + k4) = p1;
+    *reinterpret_cast<bf16x4 *>(P + (1 * BX + x) * LDX + k4) = p2;
+    *reinterpret_cast<bf16x4 *>(P + (2 * BX + x) * LDX + k4) = p3;
+}
+template <class T>
+struct Bx3 {
+    static constexpr int A4 = T::BM * BKX / 4 / T::THREADS, B4 = T::BN * BKX / 4 / T::THREADS;
+    static_assert(A4 * T::THREADS * 4 == T::BM * BKX && B4 * T::THREADS * 4 == T::BN * BKX, "tile must divide among the threads");
+    static constexpr size_t LDS_BYTES = (size_t)(T::BM + T::BN) * 3 * LDX * 2;
+};
+template <class T, class FA, class FB>
+__device__ __forceinline__ void fetch_chunk_x(float4 (&ra)[Bx3<T>::A4], float4 (&rb)[Bx3<T>::B4], const FA &fa, const FB &fb,
+                                              int k0, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < Bx3<T>::A4; ++q) {
+        const int f = tid + q * T::THREADS;
+        ra[q] = fa(f / (BKX / 4), k0 + (f % (BKX / 4)) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < Bx3<T>::B4; ++q) {
+        const int f = tid + q * T::THREADS;
+        rb[q] = fb(f / (BKX / 4), k0 + (f % (BKX / 4)) * 4);
+    }
+}
+// gemm_tile_x on the bf16 matrix cores: acc += xa(A) (BM x K) . B^T (BN x K), both k-contiguous; ra / rb hold the first chunk
+template <class T, class FA, class FB, class XA>
+__device__ __forceinline__ void gemm_tile_bx3(f32x16 (&acc)[T::TM][T::TN], int K, const FA &fa, const FB &fb, const XA &xa,
+                                              float4 (&ra)[Bx3<T>::A4], float4 (&rb)[Bx3<T>::B4], float *lds)
+{
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    __bf16 *Ap = reinterpret_cast<__bf16 *>(lds), *Bp = Ap + 3 * T::BM * LDX;
+    for (int k0 = 0; k0 < K; k0 += BKX) {
+#pragma unroll
+        for (int q = 0; q < Bx3<T>::A4; ++q) {
+            const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
+            stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[q], k0 + k4));
+        }
+#pragma unroll
+        for (int q = 0; q < Bx3<T>::B4; ++q) {
+            const int f = tid + q * T::THREADS;
+            stage_split<T::BN>(Bp, f / (BKX / 4), (f % (BKX / 4)) * 4, rb[q]);
+        }
+        __syncthreads();
+        if (k0 == 0) SN_TL(1);
+        if (k0 + BKX < K) fetch_chunk_x<T>(ra, rb, fa, fb, k0 + BKX, tid);  // loads in flight under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BKX / 16; ++kk) {
+            bf16x8 a[3][T::TM], b[3][T::TN];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+                    a[p][i] = *reinterpret_cast<const bf16x8 *>(Ap + (p * T::BM + (wr * T::TM + i) * 32 + l31) * LDX + kk * 16 + 8 * h);
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j)
+                    b[p][j] = *reinterpret_cast<const bf16x8 *>(Bp + (p * T::BN + (wc * T::TN + j) * 32 + l31) * LDX + kk * 16 + 8 * h);
+            }
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j) {  // smallest products first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    SN_TL(2);
+}
+
 // C/D fragment coordinates of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 __device__ __forceinline__ int frag_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
@@ -738,8 +855,13 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         }
         const auto fa = [&](int x, int k) { return *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k); };
         const auto fb = [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); };
+#if SN_BF16X3
+        float4 ra[Bx3<T>::A4], rb[Bx3<T>::B4];
+        fetch_chunk_x<T>(ra, rb, fa, fb, 0, threadIdx.x);
+#else
         float4 ra[T::A4], rb[T::B4];
         fetch_chunk<T, true, true>(ra, rb, fa, fb, 0, threadIdx.x);
+#endif
         if (c < Ci) {
             long long sa = 0, sb = 0;
 #pragma unroll
@@ -767,7 +889,11 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         if (first && threadIdx.x == 0 && bp.num_batches_tracked) *bp.num_batches_tracked += 1;
         fx_clear_share(g.zero_ptr, g.zero_n, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, threadIdx.x, T::THREADS);
         __syncthreads();
+#if SN_BF16X3
+        gemm_tile_bx3<T>(
+#else
         gemm_tile_x<T>(
+#endif
             acc, Ci, fa, fb,
             [&](float4 v, int k) {
                 const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
@@ -777,9 +903,16 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
             },
             ra, rb, lds);
     } else {
-        gemm_tile<T, true, true>(
-            acc, Ci, [&](int x, int k) { return a.template load_c4<FULL, AMODE == ACT_BN_RELU_FX ? ACT_BN_RELU : AMODE>(row0 + x, k); },
-            [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); }, lds);
+        const auto fa = [&](int x, int k) { return a.template load_c4<FULL, AMODE == ACT_BN_RELU_FX ? ACT_BN_RELU : AMODE>(row0 + x, k); };
+        const auto fb = [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); };
+#if SN_BF16X3
+        if (FULL && Ci % BKX == 0) {  // same arithmetic as the statistics-chain path above
+            float4 ra[Bx3<T>::A4], rb[Bx3<T>::B4];
+            fetch_chunk_x<T>(ra, rb, fa, fb, 0, threadIdx.x);
+            gemm_tile_bx3<T>(acc, Ci, fa, fb, [](float4 v, int) { return v; }, ra, rb, lds);
+        } else
+#endif
+            gemm_tile<T, true, true>(acc, Ci, fa, fb, lds);
     }
 
     float s0[T::TN], s1[T::TN];
