@@ -41,6 +41,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SN_BF16X3
 #define SN_BF16X3 1  // conv-stack GEMMs: fp32 products as split-bf16 products on the bf16 matrix cores (gemm_tile_bx3)
 #endif
+#ifndef SN_FWD_KT128
+#define SN_FWD_KT128 0  // 128 input channels: chunk-by-chunk prefetch (fetching the whole K = 128 up front measured slower)
+#endif
+#ifndef SN_FWD_TW
+#define SN_FWD_TW Tile<64, 128, 2, 4>  // conv layers with 128 output channels: one 512-thread workgroup per 64 rows (Tile<64, 128, 2, 2>,
+                                       // 32 x 64 per wave, half the LDS fragment traffic: 17.5 vs 15.8 us on the 128 -> 128 layer)
+#endif
 constexpr int BK = 64;   // K chunk (one chunk covers the 64-channel layers: a single exposed global-load latency)
 constexpr int LPAD = 4;  // LDS row padding (floats): keeps rows 16-B aligned for the float4 staging stores
 
@@ -562,6 +569,22 @@ __device__ __forceinline__ void stage_split(__bf16 *__restrict__ P, int x, int k
     *reinterpret_cast<bf16x4 *>(P + (1 * BX + x) * LDX + k4) = p2;
     *reinterpret_cast<bf16x4 *>(P + (2 * BX + x) * LDX + k4) = p3;
 }
+// same with an explicit plane stride and row pitch (elements)
+template <int PLANE, int PITCH>
+__device__ __forceinline__ void stage_split_p(__bf16 *__restrict__ P, int x, int k4, const float4 v)
+{
+    bf16x4 p1, p2, p3;
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        __bf16 h1, h2, h3;
+        split3(e[t], h1, h2, h3);
+        p1[t] = h1, p2[t] = h2, p3[t] = h3;
+    }
+    *reinterpret_cast<bf16x4 *>(P + x * PITCH + k4) = p1;
+    *reinterpret_cast<bf16x4 *>(P + PLANE + x * PITCH + k4) = p2;
+    *reinterpret_cast<bf16x4 *>(P + 2 * PLANE + x * PITCH + k4) = p3;
+}
 template <class T>
 struct Bx3 {
     static constexpr int A4 = T::BM * BKX / 4 / T::THREADS, B4 = T::BN * BKX / 4 / T::THREADS;
@@ -583,55 +606,81 @@ __device__ __forceinline__ void fetch_chunk_x(float4 (&ra)[Bx3<T>::A4], float4 (
         rb[q] = fb(f / (BKX / 4), k0 + (f % (BKX / 4)) * 4);
     }
 }
-// gemm_tile_x on the bf16 matrix cores: acc += xa(A) (BM x K) . B^T (BN x K), both k-contiguous; ra / rb hold the first chunk
-template <class T, class FA, class FB, class XA>
-__device__ __forceinline__ void gemm_tile_bx3(f32x16 (&acc)[T::TM][T::TN], int K, const FA &fa, const FB &fb, const XA &xa,
-                                              float4 (&ra)[Bx3<T>::A4], float4 (&rb)[Bx3<T>::B4], float *lds)
+// one K chunk: registers -> split -> LDS -> barrier -> [prefetch()] -> MFMAs -> barrier
+template <class T, class XA, class PF>
+__device__ __forceinline__ void bx3_chunk(f32x16 (&acc)[T::TM][T::TN], int k0, const XA &xa, const float4 (&ra)[Bx3<T>::A4],
+                                          const float4 (&rb)[Bx3<T>::B4], float *lds, const PF &prefetch)
 {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / T::WC, wc = wave % T::WC;
     __bf16 *Ap = reinterpret_cast<__bf16 *>(lds), *Bp = Ap + 3 * T::BM * LDX;
-    for (int k0 = 0; k0 < K; k0 += BKX) {
 #pragma unroll
-        for (int q = 0; q < Bx3<T>::A4; ++q) {
-            const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
-            stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[q], k0 + k4));
-        }
+    for (int q = 0; q < Bx3<T>::A4; ++q) {
+        const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
+        stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[q], k0 + k4));
+    }
 #pragma unroll
-        for (int q = 0; q < Bx3<T>::B4; ++q) {
-            const int f = tid + q * T::THREADS;
-            stage_split<T::BN>(Bp, f / (BKX / 4), (f % (BKX / 4)) * 4, rb[q]);
-        }
-        __syncthreads();
-        if (k0 == 0) SN_TL(1);
-        if (k0 + BKX < K) fetch_chunk_x<T>(ra, rb, fa, fb, k0 + BKX, tid);  // loads in flight under the MFMAs
+    for (int q = 0; q < Bx3<T>::B4; ++q) {
+        const int f = tid + q * T::THREADS;
+        stage_split<T::BN>(Bp, f / (BKX / 4), (f % (BKX / 4)) * 4, rb[q]);
+    }
+    __syncthreads();
+    prefetch();
 #pragma unroll
-        for (int kk = 0; kk < BKX / 16; ++kk) {
-            bf16x8 a[3][T::TM], b[3][T::TN];
+    for (int kk = 0; kk < BKX / 16; ++kk) {
+        bf16x8 a[3][T::TM], b[3][T::TN];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                for (int i = 0; i < T::TM; ++i)
-                    a[p][i] = *reinterpret_cast<const bf16x8 *>(Ap + (p * T::BM + (wr * T::TM + i) * 32 + l31) * LDX + kk * 16 + 8 * h);
-#pragma unroll
-                for (int j = 0; j < T::TN; ++j)
-                    b[p][j] = *reinterpret_cast<const bf16x8 *>(Bp + (p * T::BN + (wc * T::TN + j) * 32 + l31) * LDX + kk * 16 + 8 * h);
-            }
+        for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int i = 0; i < T::TM; ++i)
+                a[p][i] = *reinterpret_cast<const bf16x8 *>(Ap + (p * T::BM + (wr * T::TM + i) * 32 + l31) * LDX + kk * 16 + 8 * h);
 #pragma unroll
-                for (int j = 0; j < T::TN; ++j) {  // smallest products first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
-                }
+            for (int j = 0; j < T::TN; ++j)
+                b[p][j] = *reinterpret_cast<const bf16x8 *>(Bp + (p * T::BN + (wc * T::TN + j) * 32 + l31) * LDX + kk * 16 + 8 * h);
         }
-        __syncthreads();
+        // smallest products first; the tiles of a wave interleaved (independent accumulators back to back)
+#define SN_BX3_TERM(PA, PB)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < T::TM; ++i) _Pragma("unroll") for (int j = 0; j < T::TN; ++j) acc[i][j] = \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0)
+        SN_BX3_TERM(0, 2);
+        SN_BX3_TERM(2, 0);
+        SN_BX3_TERM(1, 1);
+        SN_BX3_TERM(0, 1);
+        SN_BX3_TERM(1, 0);
+        SN_BX3_TERM(0, 0);
+#undef SN_BX3_TERM
     }
+    __syncthreads();
+}
+// gemm_tile_x on the bf16 matrix cores: acc += xa(A) (BM x K) . B^T (BN x K), both k-contiguous; ra / rb hold the first chunk,
+// the next one is fetched under the MFMAs of the current
+template <class T, class FA, class FB, class XA>
+__device__ __forceinline__ void gemm_tile_bx3(f32x16 (&acc)[T::TM][T::TN], int K, const FA &fa, const FB &fb, const XA &xa,
+                                              float4 (&ra)[Bx3<T>::A4], float4 (&rb)[Bx3<T>::B4], float *lds)
+{
+    for (int k0 = 0; k0 < K; k0 += BKX) {
+        float4 na[Bx3<T>::A4], nb[Bx3<T>::B4];
+        bx3_chunk<T>(acc, k0, xa, ra, rb, lds, [&] {
+            if (k0 + BKX < K) fetch_chunk_x<T>(na, nb, fa, fb, k0 + BKX, threadIdx.x);
+        });
+        if (k0 + BKX < K) {
+#pragma unroll
+            for (int q = 0; q < Bx3<T>::A4; ++q) ra[q] = na[q];
+#pragma unroll
+            for (int q = 0; q < Bx3<T>::B4; ++q) rb[q] = nb[q];
+        }
+    }
+    SN_TL(2);
+}
+// K known at compile time (NCH chunks): the caller fetched ALL of both operands into registers up front -- one memory round
+// trip for the whole tile instead of one per chunk (a chunk's 12 MFMAs per wave are far shorter than a fetch)
+template <class T, int NCH, class XA>
+__device__ __forceinline__ void gemm_tile_bx3_all(f32x16 (&acc)[T::TM][T::TN], const XA &xa, const float4 (&ra)[NCH][Bx3<T>::A4],
+                                                  const float4 (&rb)[NCH][Bx3<T>::B4], float *lds)
+{
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) bx3_chunk<T>(acc, ch * BKX, xa, ra[ch], rb[ch], lds, [] {});
     SN_TL(2);
 }
 
@@ -806,7 +855,8 @@ struct FwdArgs {
     int zero_n;
 };
 
-template <class T, bool FULL, int AMODE>
+// KT > 0 (statistics-chain path): the input width, known at compile time -- both operands are fetched whole, up front
+template <class T, bool FULL, int AMODE, int KT = 0>
 __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -856,8 +906,10 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         const auto fa = [&](int x, int k) { return *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k); };
         const auto fb = [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); };
 #if SN_BF16X3
-        float4 ra[Bx3<T>::A4], rb[Bx3<T>::B4];
-        fetch_chunk_x<T>(ra, rb, fa, fb, 0, threadIdx.x);
+        constexpr int NCH = KT > 0 ? KT / BKX : 1;
+        float4 ra[NCH][Bx3<T>::A4], rb[NCH][Bx3<T>::B4];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) fetch_chunk_x<T>(ra[ch], rb[ch], fa, fb, ch * BKX, threadIdx.x);
 #else
         float4 ra[T::A4], rb[T::B4];
         fetch_chunk<T, true, true>(ra, rb, fa, fb, 0, threadIdx.x);
@@ -889,19 +941,20 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         if (first && threadIdx.x == 0 && bp.num_batches_tracked) *bp.num_batches_tracked += 1;
         fx_clear_share(g.zero_ptr, g.zero_n, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, threadIdx.x, T::THREADS);
         __syncthreads();
+        const auto xa = [&](float4 v, int k) {
+            const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
+            v.x = relu_np(fmaf(v.x, sc.x, sh.x)), v.y = relu_np(fmaf(v.y, sc.y, sh.y));
+            v.z = relu_np(fmaf(v.z, sc.z, sh.z)), v.w = relu_np(fmaf(v.w, sc.w, sh.w));
+            return v;
+        };
 #if SN_BF16X3
-        gemm_tile_bx3<T>(
+        if (KT > 0)
+            gemm_tile_bx3_all<T, NCH>(acc, xa, ra, rb, lds);
+        else
+            gemm_tile_bx3<T>(acc, Ci, fa, fb, xa, ra[0], rb[0], lds);
 #else
-        gemm_tile_x<T>(
+        gemm_tile_x<T>(acc, Ci, fa, fb, xa, ra, rb, lds);
 #endif
-            acc, Ci, fa, fb,
-            [&](float4 v, int k) {
-                const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
-                v.x = relu_np(fmaf(v.x, sc.x, sh.x)), v.y = relu_np(fmaf(v.y, sc.y, sh.y));
-                v.z = relu_np(fmaf(v.z, sc.z, sh.z)), v.w = relu_np(fmaf(v.w, sc.w, sh.w));
-                return v;
-            },
-            ra, rb, lds);
     } else {
         const auto fa = [&](int x, int k) { return a.template load_c4<FULL, AMODE == ACT_BN_RELU_FX ? ACT_BN_RELU : AMODE>(row0 + x, k); };
         const auto fb = [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); };
@@ -1724,6 +1777,388 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
     }
     SN_TL_DRAIN();
     SN_TL(7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_bwd_fused_kernel on the bf16 matrix cores (split-bf16 products, see gemm_tile_bx3): same walk over the row tiles, same
+// wave roles, same epilogues and outputs.  What changes:
+//  * the tile buffers hold three bf16 planes of dZ [TR][CO] and of the activation relu(bn(Zprev)) [TR][CI], row-major
+//    (pitch + 8 elements): the producer waves split every element once, on its way into LDS;
+//  * dgrad (K = co): A fragment = 16-byte reads of a dZ row; B = W^T, split and kept in registers for the whole kernel
+//    (3 * CO / 16 fragments of 8 bf16 per lane);
+//  * wgrad (K = tile rows): both operands are needed k(row)-major -- the transposing LDS read ds_read_b64_tr_b16 delivers,
+//    from the same row-major images, 4 consecutive rows of one channel per lane (within a 16-lane group, lane l supplies
+//    the address of row (l >> 2), channels 4 (l & 3) .. +3 and receives channel l, rows 0..3: checked on the hardware);
+//  * six MFMAs (32 cycles each) per K = 16 instead of eight fp32 ones (64 cycles each).
+// Shapes: 64 -> 64 and 128 -> 128 channels (the 64 -> 128 layer's planes do not fit 160 KB of LDS at 64-row tiles).
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16 *p, int pitch)  // rows r .. r+3 and r+4 .. r+7 of this lane's channel
+{
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * pitch));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int CI, int CO>
+struct CbxShape {
+    static constexpr bool BOTH = CI == 128 && CO == 128;
+    static constexpr int TR = BOTH ? 32 : 64;
+    static constexpr int LDZ = CO + 8, LDP = CI + 8;                // bf16 pitches
+    static constexpr int ZPL = TR * LDZ, PPL = TR * LDP;            // one plane
+    static constexpr int BUF = 3 * (ZPL + PPL);                     // bf16 elements per tile buffer
+    static constexpr int TSZ = 4 * 32 * 36;                         // floats: per dgrad wave 32 x 32 transpose scratch
+    static constexpr int XSZ = 2 * 3 * TR;
+    static constexpr size_t TOFF = (size_t)2 * BUF * 2;             // byte offset of the float areas behind the tile buffers
+    static constexpr size_t LDS_BYTES = TOFF + TSZ * sizeof(float);
+    static constexpr size_t LDS_BYTES_IN3 = LDS_BYTES + XSZ * sizeof(float);
+    static_assert(LDS_BYTES_IN3 <= 160 * 1024, "tile buffers exceed the LDS");
+};
+
+template <int CO, int CI, int TR, int ZMODE, bool FULLR, int NZ4, int NP4>
+__device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0, int tid, __bf16 *__restrict__ Zb,
+                                          __bf16 *__restrict__ Pb, const float4 (&rz)[NZ4], const float4 (&rdy)[NZ4],
+                                          const float4 (&rp)[NP4], const int4 &rag, const float4 &rgs, const float4 &k1,
+                                          const float4 &k2, const float4 &k3, const float4 &sc4, const float4 &sh4)
+{
+    constexpr int ZSTEP = 256 / (CO / 4), PSTEP = 256 / (CI / 4);
+    constexpr int LDZ = CO + 8, LDP = CI + 8;
+    const int R = g.dz.rows;
+    const int row0 = tile * TR;
+    const int zc4 = (tid % (CO / 4)) * 4, zr = tid / (CO / 4);
+    const int pc4 = (tid % (CI / 4)) * 4, pr = tid / (CI / 4);
+#pragma unroll
+    for (int q = 0; q < NZ4; ++q) {
+        const int rt = zr + q * ZSTEP;
+        float4 d;
+        if (ZMODE == DZ_POOL) {
+            const int n = n0 + rt;
+            d.x = rag.x == n ? rgs.x : 0.f;
+            d.y = rag.y == n ? rgs.y : 0.f;
+            d.z = rag.z == n ? rgs.z : 0.f;
+            d.w = rag.w == n ? rgs.w : 0.f;
+        } else {
+            d = rdy[q];
+        }
+        float4 v = make_float4(fmaf(k1.x, d.x, fmaf(k2.x, rz[q].x, k3.x)), fmaf(k1.y, d.y, fmaf(k2.y, rz[q].y, k3.y)),
+                               fmaf(k1.z, d.z, fmaf(k2.z, rz[q].z, k3.z)), fmaf(k1.w, d.w, fmaf(k2.w, rz[q].w, k3.w)));
+        if (!FULLR) {
+            const float m = row0 + rt < R ? 1.f : 0.f;
+            v.x *= m, v.y *= m, v.z *= m, v.w *= m;
+        }
+        stage_split_p<TR * LDZ, LDZ>(Zb, rt, zc4, v);
+    }
+#pragma unroll
+    for (int q = 0; q < NP4; ++q) {
+        const float4 a = make_float4(relu_np(fmaf(rp[q].x, sc4.x, sh4.x)), relu_np(fmaf(rp[q].y, sc4.y, sh4.y)),
+                                     relu_np(fmaf(rp[q].z, sc4.z, sh4.z)), relu_np(fmaf(rp[q].w, sc4.w, sh4.w)));
+        stage_split_p<TR * LDP, LDP>(Pb, pr + q * PSTEP, pc4, a);
+    }
+}
+
+template <int CI, int CO, int ZMODE, bool FULLR, bool IN3 = false>
+__global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
+{
+    using S = CbxShape<CI, CO>;
+    static_assert(!IN3 || (S::TR == 64 && ZMODE == DZ_BN), "IN3: 64-row tiles (one row per lane for the moments)");
+    constexpr int NST = IN3 ? 5 : 2;
+    constexpr int TR = S::TR, LDZ = S::LDZ, LDP = S::LDP, ZPL = S::ZPL, PPL = S::PPL, BUF = S::BUF;
+    constexpr int NZ4 = TR * CO / 4 / 256, NP4 = TR * CI / 4 / 256;
+    constexpr int NCB = CI / 32, NOB = CO / 32, RB = TR / 32;
+    constexpr int NDW = RB * NCB;
+    constexpr int NWT = NOB * NCB / 4;
+    constexpr int KD = CO / 16, KW = TR / 16;  // K = 16 steps of a dgrad tile / of a row tile's wgrad
+    static_assert((CI == 64 || CI == 128) && (CO == 64 || CO == 128), "instantiated for 64 / 128 channels");
+    static_assert(NDW == 4 && NZ4 >= 1 && NP4 >= 1 && NWT >= 1, "wave roles below assume four dgrad tiles per row tile");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16 *Lb = reinterpret_cast<__bf16 *>(lds);
+    float *Tf = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + S::TOFF);  // float areas behind the tile buffers
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *Ts = Tf + (wave & 3) * (32 * 36);
+    float *Xs = Tf + S::TSZ;
+    const int R = g.dz.rows;
+    const bool do_d = wave < 4;
+    const int dwv = wave & 3;
+    const int rb = dwv % RB, cb = dwv / RB;
+    const int q0 = dwv * NWT;
+    const int cob = q0 / NCB;
+    const int G = gridDim.x;
+
+    if (do_d) {
+        // ---------------- producer + data-gradient waves ------------------------------------------------
+        const int zc4 = (tid % (CO / 4)) * 4, pc4 = (tid % (CI / 4)) * 4;
+        const bool fxin = ZMODE == DZ_BN && g.acc_in != nullptr;
+        float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f), k2 = k1, k3 = k1;
+        if (!fxin) {
+            k1 = *reinterpret_cast<const float4 *>(g.dz.k1 + zc4);
+            k2 = *reinterpret_cast<const float4 *>(g.dz.k2 + zc4);
+            k3 = *reinterpret_cast<const float4 *>(g.dz.k3 + zc4);
+        }
+        const float4 sc4 = *reinterpret_cast<const float4 *>(g.scale_prev + pc4);
+        const float4 sh4 = *reinterpret_cast<const float4 *>(g.shift_prev + pc4);
+        const float scd = g.scale_prev[cb * 32 + l31], shd = g.shift_prev[cb * 32 + l31];
+        const unsigned qvo = ((rb * 32 + 4 * h) * CI + cb * 32 + l31) * 4;
+        const unsigned ovo = ((rb * 32 + (lane >> 3)) * CI + cb * 32 + (lane & 7) * 4) * 4;
+        const unsigned zvo = ((tid / (CO / 4)) * CO + zc4) * 4, pvo = ((tid / (CI / 4)) * CI + pc4) * 4, avo = zc4 * 4;
+        CbfRsrc rs;
+        rs.z = make_rsrc(g.dz.z, (unsigned)R * CO * 4);
+        rs.dy = make_rsrc(ZMODE == DZ_BN ? g.dz.dy : g.dz.z, (unsigned)R * CO * 4);
+        rs.zprev = make_rsrc(g.zprev, (unsigned)R * CI * 4);
+        rs.dyprev = make_rsrc(g.dyprev, (unsigned)R * CI * 4);
+        const unsigned nclouds = ZMODE == DZ_POOL ? (unsigned)((R + g.dz.npts - 1) / g.dz.npts) : 1u;
+        rs.argsel = make_rsrc(ZMODE == DZ_POOL ? (const void *)g.dz.argsel : (const void *)g.dz.z, nclouds * CO * 4);
+        rs.gsel = make_rsrc(ZMODE == DZ_POOL ? (const void *)g.dz.gsel : (const void *)g.dz.z, nclouds * CO * 4);
+        const sn_rsrc rsx = make_rsrc(IN3 ? (const void *)g.xin : (const void *)g.dz.z, (unsigned)R * 12);
+        const bool xthr = IN3 && tid < 3 * TR / 4;
+        int xslot[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid * 4 + j;
+            xslot[j] = (i % 3) * TR + i / 3;
+        }
+        float4 rx = make_float4(0.f, 0.f, 0.f, 0.f);
+        float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
+        float mom[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mom[k] = 0.f;
+        const int tpc = ZMODE == DZ_POOL ? g.dz.npts / TR : 1;
+        const int bstep = G / tpc, tstep = G - bstep * tpc;
+        int cloud = (int)blockIdx.x / tpc, tic = (int)blockIdx.x - cloud * tpc;
+        float4 rz[NZ4], rdy[NZ4], rp[NP4];
+        int4 rag = make_int4(0, 0, 0, 0);
+        float4 rgs = make_float4(0.f, 0.f, 0.f, 0.f);
+        float s0 = 0.f, s1 = 0.f;
+        float4 vout[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vout[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        int tile = blockIdx.x;
+        cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+        if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)tile * (TR * 12));
+        // W^T fragments of this wave's 32 input channels: W[co = 16 kk + 8 h + t][ci = cb 32 + l31] (requested after the first
+        // tile: its staging does not wait for them), split below once the first tile is staged
+        float wraw[KD][8];
+#pragma unroll
+        for (int kk = 0; kk < KD; ++kk)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) wraw[kk][t] = g.W[(size_t)(kk * 16 + 8 * h + t) * CI + cb * 32 + l31];
+        if (fxin) {
+            const float *Ks = Tf;  // the transpose scratch is idle until the first epilogue
+            __syncthreads();
+            k1 = *reinterpret_cast<const float4 *>(Ks + zc4);
+            k2 = *reinterpret_cast<const float4 *>(Ks + CO + zc4);
+            k3 = *reinterpret_cast<const float4 *>(Ks + 2 * CO + zc4);
+        }
+        cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, tile, tic * TR, tid, Lb, Lb + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3, sc4, sh4);
+        if (xthr) Xs[xslot[0]] = rx.x, Xs[xslot[1]] = rx.y, Xs[xslot[2]] = rx.z, Xs[xslot[3]] = rx.w;
+        bf16x8 wf[KD][3];
+#pragma unroll
+        for (int kk = 0; kk < KD; ++kk)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                __bf16 h1, h2, h3;
+                split3(wraw[kk][t], h1, h2, h3);
+                wf[kk][0][t] = h1, wf[kk][1][t] = h2, wf[kk][2][t] = h3;
+            }
+        __syncthreads();
+        for (int it = 0; tile < g.ntiles; ++it, tile += G) {
+            const __bf16 *Zb = Lb + (it & 1) * BUF;
+            if (!IN3 && it > 0) {
+                const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
+            }
+            float zq[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                zq[e] = buf_load1(rs.zprev, qvo + ((e & 3) + 8 * (e >> 2)) * (CI * 4), (unsigned)tile * (TR * CI * 4));
+            const bool more = tile + G < g.ntiles;
+            const int nxt = more ? tile + G : tile;
+            int ncloud = cloud, ntic = tic;
+            if (more) {
+                ncloud += bstep, ntic += tstep;
+                if (ntic >= tpc) ntic -= tpc, ++ncloud;
+            }
+            cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+            if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)nxt * (TR * 12));
+
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const __bf16 *ap = Zb + (rb * 32 + l31) * LDZ + 8 * h;
+#pragma unroll
+            for (int kk = 0; kk < KD; ++kk) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(ap + kk * 16);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(ap + ZPL + kk * 16);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(ap + 2 * ZPL + kk * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[kk][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][0], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float z = zq[e];
+                const float v = fmaf(z, scd, shd) > 0.f ? acc[e] : 0.f;
+                s0 += v;
+                s1 += v * z;
+                if (IN3) acc[e] = v;
+                if (!IN3) Ts[frag_row(e, lane) * 36 + l31] = v;
+            }
+            if (IN3) {
+                const float *Xc = Xs + (it & 1) * (3 * TR);
+                const float *xp = Xc + rb * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xp + 8 * q);
+                    const float4 x1 = *reinterpret_cast<const float4 *>(xp + TR + 8 * q);
+                    const float4 x2 = *reinterpret_cast<const float4 *>(xp + 2 * TR + 8 * q);
+                    gx0 = fmaf(acc[4 * q + 3], x0.w, fmaf(acc[4 * q + 2], x0.z, fmaf(acc[4 * q + 1], x0.y, fmaf(acc[4 * q], x0.x, gx0))));
+                    gx1 = fmaf(acc[4 * q + 3], x1.w, fmaf(acc[4 * q + 2], x1.z, fmaf(acc[4 * q + 1], x1.y, fmaf(acc[4 * q], x1.x, gx1))));
+                    gx2 = fmaf(acc[4 * q + 3], x2.w, fmaf(acc[4 * q + 2], x2.z, fmaf(acc[4 * q + 1], x2.y, fmaf(acc[4 * q], x2.x, gx2))));
+                }
+                if (wave == 0) {
+                    const float a = Xc[lane], b = Xc[TR + lane], c = Xc[2 * TR + lane];
+                    mom[0] += a, mom[1] += b, mom[2] += c;
+                    mom[3] = fmaf(a, a, mom[3]), mom[4] = fmaf(a, b, mom[4]), mom[5] = fmaf(a, c, mom[5]);
+                    mom[6] = fmaf(b, b, mom[6]), mom[7] = fmaf(b, c, mom[7]), mom[8] = fmaf(c, c, mom[8]);
+                }
+            }
+            if (!IN3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vout[i] = *reinterpret_cast<const float4 *>(Ts + (8 * i + (lane >> 3)) * 36 + (lane & 7) * 4);
+            }
+            if (more) {
+                __bf16 *Zn = Lb + ((it + 1) & 1) * BUF;
+                cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, nxt, ntic * TR, tid, Zn, Zn + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3,
+                                                              sc4, sh4);
+                if (xthr) {
+                    float *Xn = Xs + ((it + 1) & 1) * (3 * TR);
+                    Xn[xslot[0]] = rx.x, Xn[xslot[1]] = rx.y, Xn[xslot[2]] = rx.z, Xn[xslot[3]] = rx.w;
+                }
+            }
+            cloud = ncloud, tic = ntic;
+            __syncthreads();
+        }
+        if (!IN3 && tile != (int)blockIdx.x) {
+            const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
+        }
+        float *red = lds;  // [RB][NST][CI]   (every wave is past its last LDS read: barrier at the end of the loop)
+        const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
+        if (lane < 32) {
+            red[(rb * NST + 0) * CI + cb * 32 + lane] = t0;
+            red[(rb * NST + 1) * CI + cb * 32 + lane] = t1;
+        }
+        if (IN3) {
+            const float u0 = gx0 + __shfl_xor(gx0, 32), u1 = gx1 + __shfl_xor(gx1, 32), u2 = gx2 + __shfl_xor(gx2, 32);
+            if (lane < 32) {
+                red[(rb * NST + 2) * CI + cb * 32 + lane] = u0;
+                red[(rb * NST + 3) * CI + cb * 32 + lane] = u1;
+                red[(rb * NST + 4) * CI + cb * 32 + lane] = u2;
+            }
+            if (wave == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    float m = mom[k];
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) m += __shfl_xor(m, o);
+                    if (lane == 0) red[RB * NST * CI + k] = m;
+                }
+            }
+        }
+    } else {
+        // ---------------- weight-gradient waves ----------------------------------------------------------
+        if (ZMODE == DZ_BN && g.acc_in != nullptr) {
+            float *Ks = Tf;
+            const int c = tid - 256;
+            if (c < CO) {
+                const BnBwd bb = g.bb_in;
+                double su, sz;
+                fx_get2<kFxShiftBwd>(g.acc_in, c, su, sz);
+                const BnBwdOut o = bn_backward_coefs(bb.R, su, sz, bn_bwd_inputs(bb, CO, c));
+                Ks[c] = o.k1, Ks[CO + c] = o.k2, Ks[2 * CO + c] = o.k3;
+                if (blockIdx.x == 0) {
+                    bb.dgamma[c] = o.dgamma, bb.dbeta[c] = o.dbeta;
+                    if (bb.dbias) bb.dbias[c] = o.dbias;
+                    if (bb.kcoef) bb.kcoef[c] = o.k1, bb.kcoef[CO + c] = o.k2, bb.kcoef[2 * CO + c] = o.k3;
+                }
+            }
+            fx_clear_share(g.zero_ptr, g.zero_n, blockIdx.x, gridDim.x, tid - 256, 256);
+            __syncthreads();
+        }
+        f32x16 accw[NWT];
+#pragma unroll
+        for (int n = 0; n < NWT; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accw[n][e] = 0.f;
+        __syncthreads();
+        // transposing reads: this lane's row / channel offsets inside a [16 rows][32 channels] fragment block
+        const int trr = 8 * h + ((lane & 15) >> 2), trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        int tile = blockIdx.x;
+        for (int it = 0; tile < g.ntiles; ++it, tile += G) {
+            const __bf16 *Zb = Lb + (it & 1) * BUF, *Pb = Zb + 3 * ZPL;
+            const __bf16 *ap = Zb + trr * LDZ + cob * 32 + trc;
+            const __bf16 *bp = Pb + trr * LDP + trc;
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                bf16x8 a[3], b[3][NWT];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[p] = lds_tr8(ap + p * ZPL + kk * 16 * LDZ, LDZ);
+#pragma unroll
+                    for (int n = 0; n < NWT; ++n) b[p][n] = lds_tr8(bp + p * PPL + kk * 16 * LDP + ((q0 + n) % NCB) * 32, LDP);
+                }
+#define SN_BX3_TERM(PA, PB) \
+    _Pragma("unroll") for (int n = 0; n < NWT; ++n) accw[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB][n], accw[n], 0, 0, 0)
+                SN_BX3_TERM(0, 2);
+                SN_BX3_TERM(2, 0);
+                SN_BX3_TERM(1, 1);
+                SN_BX3_TERM(0, 1);
+                SN_BX3_TERM(1, 0);
+                SN_BX3_TERM(0, 0);
+#undef SN_BX3_TERM
+            }
+            __syncthreads();
+        }
+        float *P = g.part + (size_t)blockIdx.x * CO * CI;
+        float *Tw = lds + RB * NST * CI + 16 + (wave - 4) * (32 * 36);  // behind the dgrad waves' statistics area
+#pragma unroll
+        for (int n = 0; n < NWT; ++n) {
+            const int colb = ((q0 + n) % NCB) * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Tw[frag_row(e, lane) * 36 + l31] = accw[n][e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rt = 8 * i + (lane >> 3);
+                *reinterpret_cast<float4 *>(P + (size_t)(cob * 32 + rt) * CI + colb + (lane & 7) * 4) =
+                    *reinterpret_cast<const float4 *>(Tw + rt * 36 + (lane & 7) * 4);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < CI) {
+        const float *red = lds;
+        float *st = g.stats + (size_t)blockIdx.x * (IN3 ? 6 : 2) * CI;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            float a = red[k * CI + tid];
+            if (RB == 2) a += red[(NST + k) * CI + tid];
+            if (!IN3 && g.acc_out)
+                fx_add<kFxShiftBwd>(g.acc_out, blockIdx.x % kFxSlots, k, tid, a);
+            else
+                st[k * CI + tid] = a;
+        }
+        if (IN3) st[5 * CI + tid] = tid < 9 ? red[RB * NST * CI + tid] : 0.f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3912,15 +4347,21 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         if (Co == 128) {
             // 128 output channels: one 512-thread workgroup per 64 rows computes all of them -- the input tile is fetched
             // once instead of once per 64-column block, and half as many workgroups run the statistics prologue
-            using TW = Tile<64, 128, 2, 4>;
+            using TW = SN_FWD_TW;
             const dim3 grid(R / TW::BM, 1);
             const size_t lds = shaped_lds(lds_bytes<TW>() + (size_t)2 * Ci * sizeof(float), grid);
-            hipLaunchKernelGGL((linear_fwd_kernel<TW, true, ACT_BN_RELU_FX>), grid, dim3(TW::THREADS), lds, st, g);
+            if (Ci == 128)
+                hipLaunchKernelGGL((linear_fwd_kernel<TW, true, ACT_BN_RELU_FX, SN_FWD_KT128>), grid, dim3(TW::THREADS), lds, st, g);
+            else
+                hipLaunchKernelGGL((linear_fwd_kernel<TW, true, ACT_BN_RELU_FX, 64>), grid, dim3(TW::THREADS), lds, st, g);
             continue;
         }
         const dim3 grid(R / T::BM, Co / T::BN);
         const size_t lds = shaped_lds(lds_bytes<T>() + (size_t)2 * Ci * sizeof(float), grid);
-        hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX>), grid, dim3(T::THREADS), lds, st, g);
+        if (Ci == 128)
+            hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX, SN_FWD_KT128>), grid, dim3(T::THREADS), lds, st, g);
+        else
+            hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX, 64>), grid, dim3(T::THREADS), lds, st, g);
     }
     const int Cn = channels[nlayers];
     long long *zp = nlayers >= 2 ? acc + (size_t)(nlayers - 2) * kFxLayer : nullptr;
@@ -4017,8 +4458,30 @@ static bool conv_bwd_fused_shape(int R, int Ci, int Co)
 static int conv_bwd_fused_groups(int R) { return std::min((R + 63) / 64, device_cus()); }
 
 template <int CI, int CO, int ZMODE>
+static void launch_conv_bwd_bx3_t(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
+{
+    constexpr size_t lds = CbxShape<CI, CO>::LDS_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<CI, CO, ZMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<CI, CO, ZMODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (fullr)
+        hipLaunchKernelGGL((conv_bwd_bx3_kernel<CI, CO, ZMODE, true>), dim3(G), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL((conv_bwd_bx3_kernel<CI, CO, ZMODE, false>), dim3(G), dim3(512), lds, st, a);
+}
+
+template <int CI, int CO, int ZMODE>
 static void launch_conv_bwd_fused_t(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
 {
+#if SN_BF16X3
+    if (CI == CO) {  // (the 64 -> 128 layer's bf16 planes do not fit the LDS at 64-row tiles: fp32 MFMA kernel)
+        launch_conv_bwd_bx3_t<CI == CO ? CI : 64, CI == CO ? CO : 64, ZMODE>(a, G, fullr, st);
+        return;
+    }
+#endif
     constexpr size_t lds = CbfShape<CI, CO>::LDS_BYTES;
     static bool attr_done = false;
     if (!attr_done) {  // more than 64 KB of dynamic LDS must be requested explicitly
@@ -4339,21 +4802,27 @@ static void launch_conv_bwd_in3(int R, const float *dy, const float *z, const fl
     a.W = W, a.zprev = zprev, a.scale_prev = coef_prev, a.shift_prev = coef_prev + Ci;
     a.dyprev = nullptr, a.stats = stats, a.part = part, a.xin = x_in;  // dYprev is not materialised: nothing reads it
     constexpr int TR = CbfShape<64, 64>::TR;
+    static_assert(TR == CbxShape<64, 64>::TR, "same tiling in both kernels");
     a.ntiles = (R + TR - 1) / TR;
     const int G = conv_bwd_fused_groups(R);
+#if SN_BF16X3
+#define SN_CBF_IN3 conv_bwd_bx3_kernel
+    constexpr size_t lds = CbxShape<64, 64>::LDS_BYTES_IN3;
+#else
+#define SN_CBF_IN3 conv_bwd_fused_kernel
     constexpr size_t lds = CbfShape<64, 64>::LDS_BYTES_IN3;
+#endif
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<64, 64, DZ_BN, true, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<64, 64, DZ_BN, false, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)SN_CBF_IN3<64, 64, DZ_BN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)SN_CBF_IN3<64, 64, DZ_BN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     if (R % TR == 0)
-        hipLaunchKernelGGL((conv_bwd_fused_kernel<64, 64, DZ_BN, true, true>), dim3(G), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((SN_CBF_IN3<64, 64, DZ_BN, true, true>), dim3(G), dim3(512), lds, st, a);
     else
-        hipLaunchKernelGGL((conv_bwd_fused_kernel<64, 64, DZ_BN, false, true>), dim3(G), dim3(512), lds, st, a);
+        hipLaunchKernelGGL((SN_CBF_IN3<64, 64, DZ_BN, false, true>), dim3(G), dim3(512), lds, st, a);
+#undef SN_CBF_IN3
 }
 
 extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z, const float *kcoef, const float *W,
