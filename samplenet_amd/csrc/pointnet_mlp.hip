@@ -1313,13 +1313,15 @@ __device__ __forceinline__ void cbf_issue_loads(const CbfRsrc &rs, int tile, int
 {
     constexpr int ZSTEP = 256 / (CO / 4), PSTEP = 256 / (CI / 4);  // staged by the 256 threads of the dgrad waves
     const unsigned zso = (unsigned)tile * (TR * CO * 4), pso = (unsigned)tile * (TR * CI * 4);
+    // (the per-q strides ride in the SCALAR offset: as per-lane offsets they cost a VGPR each -- the split-bf16 kernel spilled them,
+    //  and a spilled address reloaded in front of a load waits for every request before it)
 #pragma unroll
     for (int q = 0; q < NZ4; ++q) {
-        rz[q] = buf_load4(rs.z, zvo + q * (ZSTEP * CO * 4), zso);
-        if (ZMODE == DZ_BN) rdy[q] = buf_load4(rs.dy, zvo + q * (ZSTEP * CO * 4), zso);
+        rz[q] = buf_load4(rs.z, zvo, zso + q * (ZSTEP * CO * 4));
+        if (ZMODE == DZ_BN) rdy[q] = buf_load4(rs.dy, zvo, zso + q * (ZSTEP * CO * 4));
     }
 #pragma unroll
-    for (int q = 0; q < NP4; ++q) rp[q] = buf_load4(rs.zprev, pvo + q * (PSTEP * CI * 4), pso);
+    for (int q = 0; q < NP4; ++q) rp[q] = buf_load4(rs.zprev, pvo, pso + q * (PSTEP * CI * 4));
     if (ZMODE == DZ_POOL) {  // the host guarantees npts % 64 == 0: one cloud (b) per tile
         rag = buf_load4i(rs.argsel, avo, (unsigned)b * (CO * 4));
         rgs = buf_load4(rs.gsel, avo, (unsigned)b * (CO * 4));
@@ -1971,12 +1973,12 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             if (!IN3 && it > 0) {
                 const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
+                for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * CI * 4));
             }
             float zq[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                zq[e] = buf_load1(rs.zprev, qvo + ((e & 3) + 8 * (e >> 2)) * (CI * 4), (unsigned)tile * (TR * CI * 4));
+                zq[e] = buf_load1(rs.zprev, qvo, (unsigned)tile * (TR * CI * 4) + ((e & 3) + 8 * (e >> 2)) * (CI * 4));
             const bool more = tile + G < g.ntiles;
             const int nxt = more ? tile + G : tile;
             int ncloud = cloud, ntic = tic;
@@ -1986,6 +1988,9 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             }
             cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
             if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)nxt * (TR * 12));
+            // the requests go out HERE: left alone, the scheduler sinks them below the MFMAs to their first use (the staging),
+            // and every tile pays a full memory round trip
+            __builtin_amdgcn_sched_barrier(0);
 
             f32x16 acc;
 #pragma unroll
@@ -2050,7 +2055,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         if (!IN3 && tile != (int)blockIdx.x) {
             const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo + i * (8 * CI * 4), oso);
+            for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * CI * 4));
         }
         float *red = lds;  // [RB][NST][CI]   (every wave is past its last LDS read: barrier at the end of the loop)
         const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
