@@ -1792,7 +1792,8 @@ __global__ void __launch_bounds__(512) conv_bwd_fused_kernel(ConvBwdArgs g)
 //    from the same row-major images, 4 consecutive rows of one channel per lane (within a 16-lane group, lane l supplies
 //    the address of row (l >> 2), channels 4 (l & 3) .. +3 and receives channel l, rows 0..3: checked on the hardware);
 //  * six MFMAs (32 cycles each) per K = 16 instead of eight fp32 ones (64 cycles each).
-// Shapes: 64 -> 64 and 128 -> 128 channels (the 64 -> 128 layer's planes do not fit 160 KB of LDS at 64-row tiles).
+// 64 -> 128 channels: 32-row tiles (two buffers of three planes must fit 160 KB), hence only two 32 x 32 dgrad tiles per row tile:
+// the four dgrad waves pair up on a tile, each takes half of K, and the upper half's partial tile is added through LDS.
 // ------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1807,8 +1808,8 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16 *p, int pitch)  // rows r
 
 template <int CI, int CO>
 struct CbxShape {
-    static constexpr bool BOTH = CI == 128 && CO == 128;
-    static constexpr int TR = BOTH ? 32 : 64;
+    static constexpr int TR = CO == 128 ? 32 : 64;                  // two tile buffers of three planes must fit the LDS
+    static constexpr int KS = (CI == 64 && CO == 128) ? 2 : 1;      // 32 x 64 dgrad block = two 32 x 32 tiles: four waves split K too
     static constexpr int LDZ = CO + 8, LDP = CI + 8;                // bf16 pitches
     static constexpr int ZPL = TR * LDZ, PPL = TR * LDP;            // one plane
     static constexpr int BUF = 3 * (ZPL + PPL);                     // bf16 elements per tile buffer
@@ -1870,11 +1871,12 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
     constexpr int TR = S::TR, LDZ = S::LDZ, LDP = S::LDP, ZPL = S::ZPL, PPL = S::PPL, BUF = S::BUF;
     constexpr int NZ4 = TR * CO / 4 / 256, NP4 = TR * CI / 4 / 256;
     constexpr int NCB = CI / 32, NOB = CO / 32, RB = TR / 32;
-    constexpr int NDW = RB * NCB;
+    constexpr int KS = S::KS;              // dgrad waves per 32 x 32 tile (each takes a K range; summed through LDS)
+    constexpr int NDW = RB * NCB * KS;
     constexpr int NWT = NOB * NCB / 4;
-    constexpr int KD = CO / 16, KW = TR / 16;  // K = 16 steps of a dgrad tile / of a row tile's wgrad
+    constexpr int KD = CO / 16 / KS, KW = TR / 16;  // K = 16 steps of a dgrad wave / of a row tile's wgrad
     static_assert((CI == 64 || CI == 128) && (CO == 64 || CO == 128), "instantiated for 64 / 128 channels");
-    static_assert(NDW == 4 && NZ4 >= 1 && NP4 >= 1 && NWT >= 1, "wave roles below assume four dgrad tiles per row tile");
+    static_assert(NDW == 4 && NZ4 >= 1 && NP4 >= 1 && NWT >= 1, "wave roles below assume four dgrad waves per row tile");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __bf16 *Lb = reinterpret_cast<__bf16 *>(lds);
     float *Tf = reinterpret_cast<float *>(reinterpret_cast<char *>(lds) + S::TOFF);  // float areas behind the tile buffers
@@ -1886,7 +1888,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
     const int R = g.dz.rows;
     const bool do_d = wave < 4;
     const int dwv = wave & 3;
-    const int rb = dwv % RB, cb = dwv / RB;
+    const int dt = dwv / KS, kh = dwv % KS;  // dgrad tile of this wave and its K range
+    const int rb = dt % RB, cb = dt / RB;
     const int q0 = dwv * NWT;
     const int cob = q0 / NCB;
     const int G = gridDim.x;
@@ -1948,7 +1951,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
         for (int kk = 0; kk < KD; ++kk)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) wraw[kk][t] = g.W[(size_t)(kk * 16 + 8 * h + t) * CI + cb * 32 + l31];
+            for (int t = 0; t < 8; ++t) wraw[kk][t] = g.W[(size_t)((kh * KD + kk) * 16 + 8 * h + t) * CI + cb * 32 + l31];
         if (fxin) {
             const float *Ks = Tf;  // the transpose scratch is idle until the first epilogue
             __syncthreads();
@@ -1970,15 +1973,16 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         __syncthreads();
         for (int it = 0; tile < g.ntiles; ++it, tile += G) {
             const __bf16 *Zb = Lb + (it & 1) * BUF;
-            if (!IN3 && it > 0) {
+            if (!IN3 && it > 0 && kh == 0) {
                 const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * CI * 4));
             }
             float zq[16];
+            if (KS == 1 || kh == 0)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                zq[e] = buf_load1(rs.zprev, qvo, (unsigned)tile * (TR * CI * 4) + ((e & 3) + 8 * (e >> 2)) * (CI * 4));
+                for (int e = 0; e < 16; ++e)
+                    zq[e] = buf_load1(rs.zprev, qvo, (unsigned)tile * (TR * CI * 4) + ((e & 3) + 8 * (e >> 2)) * (CI * 4));
             const bool more = tile + G < g.ntiles;
             const int nxt = more ? tile + G : tile;
             int ncloud = cloud, ntic = tic;
@@ -1995,7 +1999,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            const __bf16 *ap = Zb + (rb * 32 + l31) * LDZ + 8 * h;
+            const __bf16 *ap = Zb + (rb * 32 + l31) * LDZ + kh * KD * 16 + 8 * h;
 #pragma unroll
             for (int kk = 0; kk < KD; ++kk) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(ap + kk * 16);
@@ -2008,6 +2012,17 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][0], acc, 0, 0, 0);
             }
+            if (KS == 2) {  // the upper K range's partial tile joins the lower one's through the upper wave's scratch
+                float *Tx = Tf + (dwv | 1) * (32 * 36);
+                if (kh == 1)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) Tx[e * 64 + lane] = acc[e];
+                __syncthreads();
+                if (kh == 0)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] += Tx[e * 64 + lane];
+            }
+            if (kh == 0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float z = zq[e];
@@ -2040,6 +2055,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) vout[i] = *reinterpret_cast<const float4 *>(Ts + (8 * i + (lane >> 3)) * 36 + (lane & 7) * 4);
             }
+            }
             if (more) {
                 __bf16 *Zn = Lb + ((it + 1) & 1) * BUF;
                 cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, nxt, ntic * TR, tid, Zn, Zn + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3,
@@ -2052,14 +2068,14 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             cloud = ncloud, tic = ntic;
             __syncthreads();
         }
-        if (!IN3 && tile != (int)blockIdx.x) {
+        if (!IN3 && tile != (int)blockIdx.x && kh == 0) {
             const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * CI * 4));
         }
         float *red = lds;  // [RB][NST][CI]   (every wave is past its last LDS read: barrier at the end of the loop)
         const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
-        if (lane < 32) {
+        if (lane < 32 && kh == 0) {
             red[(rb * NST + 0) * CI + cb * 32 + lane] = t0;
             red[(rb * NST + 1) * CI + cb * 32 + lane] = t1;
         }
@@ -2132,6 +2148,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 SN_BX3_TERM(0, 0);
 #undef SN_BX3_TERM
             }
+            if (KS == 2) __syncthreads();  // (the dgrad waves' partial-tile hand-off)
             __syncthreads();
         }
         float *P = g.part + (size_t)blockIdx.x * CO * CI;
@@ -4482,10 +4499,8 @@ template <int CI, int CO, int ZMODE>
 static void launch_conv_bwd_fused_t(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
 {
 #if SN_BF16X3
-    if (CI == CO) {  // (the 64 -> 128 layer's bf16 planes do not fit the LDS at 64-row tiles: fp32 MFMA kernel)
-        launch_conv_bwd_bx3_t<CI == CO ? CI : 64, CI == CO ? CO : 64, ZMODE>(a, G, fullr, st);
-        return;
-    }
+    launch_conv_bwd_bx3_t<CI, CO, ZMODE>(a, G, fullr, st);
+    return;
 #endif
     constexpr size_t lds = CbfShape<CI, CO>::LDS_BYTES;
     static bool attr_done = false;
@@ -4515,7 +4530,11 @@ static int launch_conv_bwd_fused(int R, int Ci, int Co, int dz_mode, const float
     a.dz.gsel = gsel, a.dz.argsel = argsel;
     a.W = W, a.zprev = zprev, a.scale_prev = coef_prev, a.shift_prev = coef_prev + Ci;
     a.dyprev = dyprev, a.stats = stats, a.part = part;
+#if SN_BF16X3
+    const int TR = Co == 128 ? 32 : 64;  // CbxShape<Ci, Co>::TR
+#else
     const int TR = (Ci == 128 && Co == 128) ? 32 : 64;  // CbfShape<Ci, Co>::TR
+#endif
     a.ntiles = (R + TR - 1) / TR;
     const int G = conv_bwd_fused_groups(R);
     const bool fullr = R % TR == 0;
