@@ -28,6 +28,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured by a float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz (dense fp32 matrix peak)
+# The conv-stack GEMMs compute fp32 products as six bf16 products of three-way split operands on the bf16 matrix cores
+# (pointnet_mlp.hip, gemm_tile_bx3 / conv_bwd_bx3_kernel): their matrix-pipe ceiling is the dense bf16 peak / 6
+# (MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16; tools/micro/bf16x3_gemm.hip measures 392 fp32-equivalent TFLOP/s).
+MFMA_SPLIT_BF16_PEAK_TFLOPS = 2500.0 / 6.0
 
 
 def geometry_bytes_fwd(N, M, K):
@@ -86,10 +90,11 @@ def time_pairscan_kernel(net, pool, K, reps=50):
 
 
 def time_conv5_backward_kernel(B, N, reps=50):
-    """Average duration of the dominant kernel of the step -- sn::conv_bwd_fused_kernel<128,128,DZ_POOL>, the backward of
+    """Average duration of the heaviest GEMM kernel of the step -- sn::conv_bwd_bx3_kernel<128,128,DZ_POOL>, the backward of
     the last 1x1 convolution (128 -> bottleneck 128 channels over B*N rows): data gradient + weight gradient from one
     pass -- measured with HIP events on the stream it is launched on, launches back to back, on tensors of the bench's
-    shapes (values do not matter for its duration).  Algorithmic work per launch: 2*R*Ci*Co (dgrad) + 2*R*Ci*Co (wgrad)."""
+    shapes (values do not matter for its duration).  Algorithmic work per launch: 2*R*Ci*Co (dgrad) + 2*R*Ci*Co (wgrad)
+    flop; algorithmic bytes: Z (R*Co*4) and Zprev (R*Ci*4) in, dYprev (R*Ci*4) out."""
     from samplenet_amd._lib import check, lib, ptr
 
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -119,7 +124,7 @@ def time_conv5_backward_kernel(B, N, reps=50):
         launch()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps, 4.0 * R * Ci * Co
+    return e0.elapsed_time(e1) / reps, 4.0 * R * Ci * Co, 4.0 * R * (Co + 2 * Ci)
 
 
 def time_pairscan_saturated(K, Bsat=4096, N=1024, M=64, reps=10):
@@ -310,8 +315,11 @@ def main():
         kern_ms = time_pairscan_kernel(net, pool, K)
         alg = geometry_bytes_fwd(N, M, K) * B
         achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        conv_ms, conv_flop = time_conv5_backward_kernel(B, N)
+        conv_ms, conv_flop, conv_bytes = time_conv5_backward_kernel(B, N)
         conv_tf = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        conv_gbs = conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
+        # which roof is nearer: the split-bf16 matrix ceiling or HBM
+        conv_hbm_bound = conv_gbs / HBM_PEAK_GBS >= conv_tf / MFMA_SPLIT_BF16_PEAK_TFLOPS
         sat_ms, Bsat = time_pairscan_saturated(K)
         sat_gbs = geometry_bytes_fwd(N, M, K) * Bsat / (sat_ms * 1e-3) / 1e9
         # MLP work of the whole step: 3 x 67.93 MFLOP per cloud (forward + data gradient + weight gradient)
@@ -330,15 +338,25 @@ def main():
                                           "flat bucket over RCCL: FC-head segment between the step's two graphs on a side stream, "
                                           "conv segment after" if train_step.split else "flat bucket over RCCL: one collective after the step"),
                        "execution": "eager launches" if args.no_graph else "whole step replayed as one hipGraph",
-                       "mlp": "hand-written fp32 MFMA kernels"},
-            # the dominant kernel of the step (largest share of GPU time in profiles/): backward of the last 1x1 convolution
-            "roofline": {"kernel": "sn::conv_bwd_fused_kernel<128,128,DZ_POOL> (conv5 backward: dgrad + wgrad, fp32 MFMA)",
-                         "bound": "mfma", "achieved": conv_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": conv_tf / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("conv_bwd_fused_kernel<128, 128"),
-                         "algorithmic_flop_per_launch": conv_flop, "avg_launch_ms": conv_ms,
-                         "note": "peak = dense fp32 matrix rate at 2.4 GHz; under sustained MFMA load the chip clocks "
-                                 "~2.18 GHz (143 TFLOP/s attainable, tools/micro/mfma_issue.hip)"},
+                       "mlp": "hand-written MFMA kernels: conv stack = fp32 via split-bf16 products (fp32-accurate), FC head = fp32 MFMA"},
+            # the heaviest GEMM kernel of the step (most flops and most bytes of any launch): backward of the last 1x1 convolution.
+            # Both roofs are reported; "bound" names the nearer one.
+            "roofline": {"kernel": "sn::conv_bwd_bx3_kernel<128,128,DZ_POOL> (conv5 backward: dgrad + wgrad; fp32 products as "
+                                   "six bf16 MFMAs of three-way split operands)",
+                         "bound": "hbm" if conv_hbm_bound else "mfma",
+                         "achieved": conv_gbs if conv_hbm_bound else conv_tf,
+                         "peak": HBM_PEAK_GBS if conv_hbm_bound else MFMA_SPLIT_BF16_PEAK_TFLOPS,
+                         "unit": "GB/s" if conv_hbm_bound else "TFLOP/s",
+                         "frac": conv_gbs / HBM_PEAK_GBS if conv_hbm_bound else conv_tf / MFMA_SPLIT_BF16_PEAK_TFLOPS,
+                         "traffic": pmc_traffic("conv_bwd_bx3_kernel<128, 128"),
+                         "algorithmic_bytes_per_launch": conv_bytes, "algorithmic_flop_per_launch": conv_flop,
+                         "avg_launch_ms": conv_ms,
+                         "hbm": {"achieved": conv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": conv_gbs / HBM_PEAK_GBS},
+                         "mfma": {"achieved": conv_tf, "peak": MFMA_SPLIT_BF16_PEAK_TFLOPS, "unit": "fp32-equivalent TFLOP/s",
+                                  "frac": conv_tf / MFMA_SPLIT_BF16_PEAK_TFLOPS,
+                                  "vs_fp32_mfma_peak": conv_tf / MFMA_F32_PEAK_TFLOPS},
+                         "note": "matrix ceiling = dense bf16 MFMA peak / 6 products (tools/micro/bf16x3_gemm.hip: 392 "
+                                 "fp32-equivalent TFLOP/s measured, 155 for the fp32 MFMA)"},
             # the geometric kernel of the path (SURVEY 8d's per-cloud byte count applies to it)
             "roofline_geometry": {"kernel": "sn::pairscan_kernel<16,true,true> (kNN + soft projection + both Chamfer directions)",
                                   "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -349,7 +367,9 @@ def main():
             # the whole step against the fp32 matrix peak: MLP flops per step / step time (the geometric and scalar kernels, the
             # launch gaps and the dependency chain are all in the denominator)
             "step_mfma": {"flop_per_step": step_flop, "achieved": step_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": step_tf / MFMA_F32_PEAK_TFLOPS},
+                          "frac": step_tf / MFMA_F32_PEAK_TFLOPS,
+                          "note": "against the fp32 MFMA peak (the conv GEMMs run as split-bf16 products, ceiling %.0f; the FC "
+                                  "head on the fp32 MFMA)" % MFMA_SPLIT_BF16_PEAK_TFLOPS},
         }
         if world == 1 and not args.no_module_surface:
             out["module_surface"] = time_module_surface(dev, B, N, M, K)

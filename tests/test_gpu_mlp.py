@@ -108,7 +108,9 @@ def test_linear_kernels_exact_small_integers():
 
     g = torch.Generator(device="cuda").manual_seed(3)
     st = torch.cuda.current_stream().cuda_stream
-    for (R, Ci, Co) in [(300, 24, 40), (32, 128, 256), (1000, 3, 64), (129, 64, 128), (64, 256, 36)]:
+    # (the 64-aligned shapes take the split-bf16 path of the conv layers: small integers are exact in bf16 as well)
+    for (R, Ci, Co) in [(300, 24, 40), (32, 128, 256), (1000, 3, 64), (129, 64, 128), (64, 256, 36), (4096, 128, 128),
+                        (1024, 64, 64), (640, 64, 128)]:
         A = torch.randint(-4, 5, (R, Ci), device="cuda", generator=g).float()
         W = torch.randint(-4, 5, (Co, Ci), device="cuda", generator=g).float()
         b = torch.randint(-4, 5, (Co,), device="cuda", generator=g).float()
@@ -129,6 +131,32 @@ def test_linear_kernels_exact_small_integers():
         check(lib.sn_linear_wgrad(R, Ci, Co, 0, ptr(dZ), None, None, None, None, 1, ptr(A), None, ptr(part), ptr(dW), ptr(db), st))
         assert torch.equal(dW.double(), dZ.double().t() @ A.double())
         assert torch.equal(db.double(), dZ.double().sum(0))
+
+
+@pytest.mark.parametrize("R,Ci,Co", [(4096, 128, 128), (2048, 64, 128), (1024, 64, 64)])
+def test_split_bf16_products_are_fp32_accurate(R, Ci, Co):
+    """The conv-layer GEMMs run on the bf16 matrix cores with every fp32 operand split into three bf16 terms and six
+    products per K = 16 (gemm_tile_bx3): against the fp64 product of the same fp32 inputs the error must stay at the fp32
+    level -- within 4e-7 of sum |a b| per element, mean no worse than 1.5x the error of torch's own fp32 GEMM -- for
+    activation-like (non-negative, offset) and gradient-like (tiny, signed) operands."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    g = torch.Generator(device="cuda").manual_seed(R + Ci)
+    st = torch.cuda.current_stream().cuda_stream
+    for kind in ("activation", "gradient"):
+        if kind == "activation":
+            A = (torch.rand(R, Ci, device="cuda", generator=g) * 6.0 - 2.5).clamp_min(0.0)
+        else:
+            A = (torch.rand(R, Ci, device="cuda", generator=g) * 2.0 - 1.0) * 1e-3
+        W = (torch.rand(Co, Ci, device="cuda", generator=g) * 2.0 - 1.0) * 0.2
+        Z = torch.empty(R, Co, device="cuda")
+        check(lib.sn_linear_forward(R, Ci, Co, ptr(A), None, ptr(W), None, ptr(Z), None, st))
+        ref = A.double() @ W.double().t()
+        mag = A.double().abs() @ W.double().abs().t()
+        ours = ((Z.double() - ref).abs() / mag)
+        theirs = (((A @ W.t()).double() - ref).abs() / mag)
+        assert float(ours.max()) <= max(4e-7, 2.0 * float(theirs.max())), (kind, float(ours.max()), float(theirs.max()))
+        assert float(ours.mean()) <= 1.5 * float(theirs.mean()) + 1e-9, (kind, float(ours.mean()), float(theirs.mean()))
 
 
 @pytest.mark.parametrize("shape", [(64, 64), (64, 128), (128, 128)])
