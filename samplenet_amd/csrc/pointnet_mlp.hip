@@ -1894,6 +1894,10 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
     const int cob = q0 / NCB;
     const int G = gridDim.x;
 
+    SN_TL(0);
+#ifdef SN_TIMELINE
+    sn_hw_record();
+#endif
     if (do_d) {
         // ---------------- producer + data-gradient waves ------------------------------------------------
         const int zc4 = (tid % (CO / 4)) * 4, pc4 = (tid % (CI / 4)) * 4;
@@ -1995,6 +1999,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             // the requests go out HERE: left alone, the scheduler sinks them below the MFMAs to their first use (the staging),
             // and every tile pays a full memory round trip
             __builtin_amdgcn_sched_barrier(0);
+            if (it == 1) SN_TL(5);
 
             f32x16 acc;
 #pragma unroll
@@ -2012,6 +2017,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][0], acc, 0, 0, 0);
             }
+            if (it == 1) SN_TL(1);
             if (KS == 2) {  // the upper K range's partial tile joins the lower one's through the upper wave's scratch
                 float *Tx = Tf + (dwv | 1) * (32 * 36);
                 if (kh == 1)
@@ -2056,6 +2062,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 for (int i = 0; i < 4; ++i) vout[i] = *reinterpret_cast<const float4 *>(Ts + (8 * i + (lane >> 3)) * 36 + (lane & 7) * 4);
             }
             }
+            if (it == 1) SN_TL(2);
             if (more) {
                 __bf16 *Zn = Lb + ((it + 1) & 1) * BUF;
                 cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, nxt, ntic * TR, tid, Zn, Zn + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3,
@@ -2066,8 +2073,11 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 }
             }
             cloud = ncloud, tic = ntic;
+            if (it == 1) SN_TL(3);
             __syncthreads();
+            if (it == 1) SN_TL(4);
         }
+        SN_TL(6);
         if (!IN3 && tile != (int)blockIdx.x && kh == 0) {
             const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
 #pragma unroll
@@ -2148,9 +2158,12 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 SN_BX3_TERM(0, 0);
 #undef SN_BX3_TERM
             }
+            if (it == 1) SN_TL(1);
             if (KS == 2) __syncthreads();  // (the dgrad waves' partial-tile hand-off)
             __syncthreads();
+            if (it == 1) SN_TL(4);
         }
+        SN_TL(6);
         float *P = g.part + (size_t)blockIdx.x * CO * CI;
         float *Tw = lds + RB * NST * CI + 16 + (wave - 4) * (32 * 36);  // behind the dgrad waves' statistics area
 #pragma unroll
@@ -2181,6 +2194,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         }
         if (IN3) st[5 * CI + tid] = tid < 9 ? red[RB * NST * CI + tid] : 0.f;
     }
+    SN_TL_DRAIN();
+    SN_TL(7);
 }
 
 // ------------------------------------------------------------------------------------------------
