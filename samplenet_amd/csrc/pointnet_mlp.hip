@@ -3721,27 +3721,35 @@ __global__ void __launch_bounds__(1024) bn_bwd_coef_kernel(int nblk, int C, cons
 
 // dW[e] = sum over the nsplit partials part[sp][e], for the 256 elements of workgroup-block `blk`: 4 consecutive elements per
 // thread (16-byte loads), 16 split-slices per workgroup, fixed-order sums.  nel % 4 == 0.
+// Weight-gradient partials [nsplit][nel] -> their sum: a 1024-thread workgroup takes kRedElems consecutive elements, a thread
+// sums partials sl, sl + NSL, ... of its 4 elements with kRedFlight 16-byte loads in flight, then the slices are added in index
+// order (fixed summation order: run-to-run identical).  What matters is how many CONTIGUOUS bytes of one partial a workgroup
+// touches -- measured on the conv stack's 32 MB (256 partials): 512 B 14.5 us, 1 KB 10.7, 2 KB 9.1, 4 KB 13.7 (too few
+// workgroups), 8 KB 21.7; loads in flight (4 / 8 / 16) make no difference.
+constexpr int kRedElems = 512, kRedFlight = 8;  // (nel % 4 == 0)
 __device__ __forceinline__ void wgrad_reduce_block(int blk, int nel, int nsplit, const float *__restrict__ pp, float *__restrict__ out)
 {
-    __shared__ float4 red[16][64];
-    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blk * 256 + el * 4;
+    constexpr int EL4 = kRedElems / 4, NSL = 1024 / EL4, NF = kRedFlight;
+    __shared__ float4 red[NSL][EL4];
+    const int el = threadIdx.x % EL4, sl = threadIdx.x / EL4;
+    const int e = blk * kRedElems + el * 4;
     const size_t stride = (size_t)nel;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < nel) {
         const float *p = pp + e;
-        int sp = sl;
-        for (; sp + 3 * 16 < nsplit; sp += 4 * 16) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(p + (size_t)sp * stride);
-            const float4 v1 = *reinterpret_cast<const float4 *>(p + (size_t)(sp + 16) * stride);
-            const float4 v2 = *reinterpret_cast<const float4 *>(p + (size_t)(sp + 32) * stride);
-            const float4 v3 = *reinterpret_cast<const float4 *>(p + (size_t)(sp + 48) * stride);
-            acc.x += (v0.x + v1.x) + (v2.x + v3.x), acc.y += (v0.y + v1.y) + (v2.y + v3.y);
-            acc.z += (v0.z + v1.z) + (v2.z + v3.z), acc.w += (v0.w + v1.w) + (v2.w + v3.w);
-        }
-        for (; sp < nsplit; sp += 16) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)sp * stride);
-            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        for (int sp = sl; sp < nsplit; sp += NF * NSL) {
+            float4 v[NF];
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {  // (past the end: re-read the last partial, weighted 0 -- the loads stay unconditional)
+                const int s2 = sp + NSL * q;
+                v[q] = *reinterpret_cast<const float4 *>(p + (size_t)(s2 < nsplit ? s2 : nsplit - 1) * stride);
+            }
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+                const float m = sp + NSL * q < nsplit ? 1.f : 0.f;
+                acc.x = fmaf(v[q].x, m, acc.x), acc.y = fmaf(v[q].y, m, acc.y);
+                acc.z = fmaf(v[q].z, m, acc.z), acc.w = fmaf(v[q].w, m, acc.w);
+            }
         }
     }
     red[sl][el] = acc;
@@ -3749,7 +3757,7 @@ __device__ __forceinline__ void wgrad_reduce_block(int blk, int nel, int nsplit,
     if (sl == 0 && e < nel) {
         float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < NSL; ++q) {
             const float4 v = red[q][el];
             tot.x += v.x, tot.y += v.y, tot.z += v.z, tot.w += v.w;
         }
@@ -4773,7 +4781,7 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
         SN_REQUIRE(z && (dz_mode != DZ_BN || dy) && (dz_mode != DZ_POOL || (gsel && argsel)), "null pointer");
         const int G = launch_conv_bwd_fused(R, Ci, Co, dz_mode, dy, z, kcoef, gsel, argsel, npts, W, zprev, coef_prev, dyprev,
                                             stats, part, st);
-        const int nred = (Co * Ci) % 4 == 0 ? (Co * Ci + 255) / 256 : (Co * Ci + 63) / 64;
+        const int nred = (Co * Ci) % 4 == 0 ? (Co * Ci + kRedElems - 1) / kRedElems : (Co * Ci + 63) / 64;
         hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW,
                            G, Ci, stats, bb);
         SN_LAUNCH_CHECK();
@@ -4812,7 +4820,7 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_BN, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
     else
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_POOL, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
-    const int nred = (Co * Ci) % 4 == 0 ? (Co * Ci + 255) / 256 : (Co * Ci + 63) / 64;
+    const int nred = (Co * Ci) % 4 == 0 ? (Co * Ci + kRedElems - 1) / kRedElems : (Co * Ci + 63) / 64;
     hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, nsplit, Co, Ci, part, dW, nblk, Ci,
                        stats, bb);
     SN_LAUNCH_CHECK();
@@ -4876,7 +4884,7 @@ extern "C" int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, con
     launch_conv_bwd_in3(R, dy, z, kcoef, W, zprev, coef_prev, stats, part, x_in, st);
     const int G = conv_bwd_fused_groups(R);
     const BnBwd bb{coef_prev, prev_dgamma, prev_dbeta, prev_dbias, prev_kcoef, (long long)R};
-    const int nred = (Co * Ci + 255) / 256;
+    const int nred = (Co * Ci + kRedElems - 1) / kRedElems;
     hipLaunchKernelGGL(post_bwd_in3_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW, G,
                        Ci, stats, bb, W_in, b_in, dW_in, MultiRed{}, StepTail{});
     SN_LAUNCH_CHECK();
@@ -4959,7 +4967,7 @@ extern "C" int sn_conv_stack_backward(int B, int N, int nlayers, const int *chan
     int nb = 0;
     for (int l = 1; l < nlayers; ++l) {
         mr.first[l - 1] = nb, mr.part[l - 1] = part[l], mr.dW[l - 1] = dW[l], mr.elems[l - 1] = ch[l] * ch[l + 1];
-        nb += (ch[l] * ch[l + 1] + 255) / 256;
+        nb += (ch[l] * ch[l + 1] + kRedElems - 1) / kRedElems;
     }
     mr.first[nlayers - 1] = nb;
     mr.zero_ptr = accb(1), mr.zero_n = kFxLayer;
