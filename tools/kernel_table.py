@@ -25,7 +25,7 @@ for r in rows:
         pass
 mine = [r for r in rows if "sn::" in r["Name"] or r["Name"].startswith(("void chamfer", "sigma_grad", "step_loss", "void sn"))]
 # launches per step: the conv5 backward runs once per step (+ the roofline timing loop of bench.py: 50 launches + warm-up)
-ref = [r for r in mine if "conv_bwd_fused_kernel<64, 128" in r["Name"]][0]
+ref = [r for r in mine if "conv_bwd_bx3_kernel<64, 128" in r["Name"] or "conv_bwd_fused_kernel<64, 128" in r["Name"]][0]
 steps = int(ref["Calls"])
 tot = 0.0
 lines = []
