@@ -326,6 +326,9 @@ int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, c
  * pooled = argsel = zsel = NULL: stop after the last GEMM; sn_fc_chain_forward_pool must follow (it finishes the pool). */
 int sn_conv_stack_forward_supported(int B, int N, int nlayers, const int *channels);
 long long sn_conv_stack_acc_elems(int nlayers);
+/* the leading part of acc that holds the statistics accumulators (zero between calls); behind it: scratch of the forward (the
+ * layers' weights split into bf16 planes by the first kernel of the call) */
+long long sn_conv_stack_acc_sum_elems(int nlayers);
 int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
                              const float *const *bias, const float *const *gamma, const float *const *beta,
                              float *const *running_mean, float *const *running_var, long long *const *num_batches_tracked,

@@ -66,6 +66,7 @@ PROTOTYPES = {
                           _vp, ctypes.c_longlong, _vp],
     "sn_conv_stack_forward_supported": [_i, _i, _i, _vp],
     "sn_conv_stack_acc_elems": [_i],
+    "sn_conv_stack_acc_sum_elems": [_i],
     "sn_conv_stack_backward_scratch_floats": [_i, _i, _i, _vp],
     "sn_conv_stack_backward": [_i, _i, _i] + [_vp] * 17,
     "sn_conv_stack_forward_bn": [_i, _i, _i] + [_vp] * 20,
@@ -98,6 +99,7 @@ PROTOTYPES = {
 _RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong,
              "sn_pairscan_workspace_bytes": ctypes.c_longlong, "sn_layer_backward_in3_stats_floats": ctypes.c_longlong,
              "sn_conv_stack_acc_elems": ctypes.c_longlong,
+             "sn_conv_stack_acc_sum_elems": ctypes.c_longlong,
              "sn_conv_stack_backward_scratch_floats": ctypes.c_longlong}
 
 

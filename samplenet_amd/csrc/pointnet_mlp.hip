@@ -607,9 +607,24 @@ __device__ __forceinline__ void fetch_chunk_x(float4 (&ra)[Bx3<T>::A4], float4 (
     }
 }
 // one K chunk: registers -> split -> LDS -> barrier -> [prefetch()] -> MFMAs -> barrier
+template <class T, class XA, class SB, class PF>
+__device__ __forceinline__ void bx3_chunk_g(f32x16 (&acc)[T::TM][T::TN], int k0, const XA &xa, const float4 (&ra)[Bx3<T>::A4],
+                                            float *lds, const SB &stage_b, const PF &prefetch);
 template <class T, class XA, class PF>
 __device__ __forceinline__ void bx3_chunk(f32x16 (&acc)[T::TM][T::TN], int k0, const XA &xa, const float4 (&ra)[Bx3<T>::A4],
                                           const float4 (&rb)[Bx3<T>::B4], float *lds, const PF &prefetch)
+{
+    bx3_chunk_g<T>(acc, k0, xa, ra, lds, [&](__bf16 *Bp) {
+#pragma unroll
+        for (int q = 0; q < Bx3<T>::B4; ++q) {
+            const int f = threadIdx.x + q * T::THREADS;
+            stage_split<T::BN>(Bp, f / (BKX / 4), (f % (BKX / 4)) * 4, rb[q]);
+        }
+    }, prefetch);
+}
+template <class T, class XA, class SB, class PF>
+__device__ __forceinline__ void bx3_chunk_g(f32x16 (&acc)[T::TM][T::TN], int k0, const XA &xa, const float4 (&ra)[Bx3<T>::A4],
+                                            float *lds, const SB &stage_b, const PF &prefetch)
 {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -620,11 +635,7 @@ __device__ __forceinline__ void bx3_chunk(f32x16 (&acc)[T::TM][T::TN], int k0, c
         const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
         stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[q], k0 + k4));
     }
-#pragma unroll
-    for (int q = 0; q < Bx3<T>::B4; ++q) {
-        const int f = tid + q * T::THREADS;
-        stage_split<T::BN>(Bp, f / (BKX / 4), (f % (BKX / 4)) * 4, rb[q]);
-    }
+    stage_b(Bp);
     __syncthreads();
     prefetch();
 #pragma unroll
@@ -653,6 +664,35 @@ __device__ __forceinline__ void bx3_chunk(f32x16 (&acc)[T::TM][T::TN], int k0, c
     }
     __syncthreads();
 }
+// B operand already split (FwdArgs::wplanes): a thread copies ONE item of 8 consecutive k per plane and chunk -- BN rows x 4 items
+template <class T>
+struct Bx3P {
+    static constexpr int NB = T::BN * (BKX / 8) / T::THREADS;  // items per thread per chunk
+    static_assert(NB * T::THREADS == T::BN * (BKX / 8), "tile must divide among the threads");
+};
+template <class T>
+__device__ __forceinline__ void fetch_planes_x(bf16x8 (&rb)[Bx3P<T>::NB][3], const __bf16 *__restrict__ wp, int co, int ci, int col0,
+                                               int k0, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < Bx3P<T>::NB; ++q) {
+        const int f = tid + q * T::THREADS, x = f / (BKX / 8), k8 = (f % (BKX / 8)) * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            rb[q][p] = *reinterpret_cast<const bf16x8 *>(wp + ((size_t)p * co + col0 + x) * ci + k0 + k8);
+    }
+}
+template <class T>
+__device__ __forceinline__ void stage_planes_x(__bf16 *__restrict__ Bp, const bf16x8 (&rb)[Bx3P<T>::NB][3], int tid)
+{
+#pragma unroll
+    for (int q = 0; q < Bx3P<T>::NB; ++q) {
+        const int f = tid + q * T::THREADS, x = f / (BKX / 8), k8 = (f % (BKX / 8)) * 8;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8 *>(Bp + (p * T::BN + x) * LDX + k8) = rb[q][p];
+    }
+}
+
 // gemm_tile_x on the bf16 matrix cores: acc += xa(A) (BM x K) . B^T (BN x K), both k-contiguous; ra / rb hold the first chunk,
 // the next one is fetched under the MFMAs of the current
 template <class T, class FA, class FB, class XA>
@@ -681,6 +721,58 @@ __device__ __forceinline__ void gemm_tile_bx3_all(f32x16 (&acc)[T::TM][T::TN], c
 {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) bx3_chunk<T>(acc, ch * BKX, xa, ra[ch], rb[ch], lds, [] {});
+    SN_TL(2);
+}
+
+// the same two drivers with the B operand copied from pre-split planes (fetch_planes_x)
+template <class T, class FA>
+__device__ __forceinline__ void fetch_a_x(float4 (&ra)[Bx3<T>::A4], const FA &fa, int k0, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < Bx3<T>::A4; ++q) {
+        const int f = tid + q * T::THREADS;
+        ra[q] = fa(f / (BKX / 4), k0 + (f % (BKX / 4)) * 4);
+    }
+}
+template <class T, class FA, class XA>
+__device__ __forceinline__ void gemm_tile_bx3_p(f32x16 (&acc)[T::TM][T::TN], int K, const FA &fa, const XA &xa, const __bf16 *wp,
+                                                int co, int col0, float4 (&ra)[Bx3<T>::A4], bf16x8 (&rp)[Bx3P<T>::NB][3], float *lds)
+{
+    for (int k0 = 0; k0 < K; k0 += BKX) {
+        float4 na[Bx3<T>::A4];
+        bf16x8 np[Bx3P<T>::NB][3];
+        bx3_chunk_g<T>(acc, k0, xa, ra, lds, [&](__bf16 *Bp) { stage_planes_x<T>(Bp, rp, threadIdx.x); }, [&] {
+            if (k0 + BKX < K) {
+                fetch_a_x<T>(na, fa, k0 + BKX, threadIdx.x);
+                fetch_planes_x<T>(np, wp, co, K, col0, k0 + BKX, threadIdx.x);
+            }
+        });
+        if (k0 + BKX < K) {
+#pragma unroll
+            for (int q = 0; q < Bx3<T>::A4; ++q) ra[q] = na[q];
+#pragma unroll
+            for (int q = 0; q < Bx3P<T>::NB; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) rp[q][pl] = np[q][pl];
+        }
+    }
+    SN_TL(2);
+}
+// K known at compile time (NCH chunks of 32): the caller fetched the first TWO chunks up front (in flight during the statistics
+// prologue); chunk c + 2 is requested into the register set that the staging of chunk c has just consumed -- two chunk periods
+// for a fetch to land instead of one MFMA phase (12 MFMAs per wave are far shorter than a fetch).  For K = 64 that is the whole K.
+template <class T, int NCH, class FA, class XA>
+__device__ __forceinline__ void gemm_tile_bx3_ring_p(f32x16 (&acc)[T::TM][T::TN], const FA &fa, const XA &xa, const __bf16 *wp, int co,
+                                                     int col0, float4 (&ra)[2][Bx3<T>::A4], bf16x8 (&rp)[2][Bx3P<T>::NB][3], float *lds)
+{
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+        bx3_chunk_g<T>(acc, ch * BKX, xa, ra[ch & 1], lds, [&](__bf16 *Bp) { stage_planes_x<T>(Bp, rp[ch & 1], threadIdx.x); }, [&] {
+            if (ch + 2 < NCH) {
+                fetch_a_x<T>(ra[ch & 1], fa, (ch + 2) * BKX, threadIdx.x);
+                fetch_planes_x<T>(rp[ch & 1], wp, co, NCH * BKX, col0, (ch + 2) * BKX, threadIdx.x);
+            }
+        });
     SN_TL(2);
 }
 
@@ -853,11 +945,16 @@ struct FwdArgs {
     long long *acc_out;
     long long *zero_ptr;
     int zero_n;
+    // the weights already split into three bf16 planes [3][Co][Ci] (by the xyz-layer kernel of the same stack call, once per step):
+    // staged as straight copies.  NULL: every workgroup splits its W tile itself.
+    const __bf16 *wplanes;
 };
 
 // KT > 0 (statistics-chain path): the input width, known at compile time -- both operands are fetched whole, up front
-template <class T, bool FULL, int AMODE, int KT = 0>
-__global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
+// PLANES: FwdArgs::wplanes holds the weights pre-split (statistics-chain path)
+// (two 512-thread workgroups per CU need <= 128 registers: T::THREADS / 128 waves per SIMD at least)
+template <class T, bool FULL, int AMODE, int KT = 0, bool PLANES = false>
+__global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(T::THREADS / 128, 8))) linear_fwd_kernel(FwdArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     SN_TL(0);
@@ -906,10 +1003,19 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         const auto fa = [&](int x, int k) { return *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k); };
         const auto fb = [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); };
 #if SN_BF16X3
-        constexpr int NCH = KT > 0 ? KT / BKX : 1;
-        float4 ra[NCH][Bx3<T>::A4], rb[NCH][Bx3<T>::B4];
+        constexpr int NCHK = KT > 0 ? KT / BKX : 1;                        // chunks of the whole K (when known)
+        constexpr int NCH = PLANES ? (NCHK < 2 ? NCHK : 2) : NCHK;         // chunks fetched up front
+        float4 ra[PLANES ? 2 : NCH][Bx3<T>::A4], rb[PLANES ? 1 : NCH][Bx3<T>::B4];
+        bf16x8 rp[PLANES ? 2 : 1][Bx3P<T>::NB][3];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) fetch_chunk_x<T>(ra[ch], rb[ch], fa, fb, ch * BKX, threadIdx.x);
+        for (int ch = 0; ch < NCH; ++ch) {
+            if constexpr (PLANES) {
+                fetch_a_x<T>(ra[ch], fa, ch * BKX, threadIdx.x);
+                fetch_planes_x<T>(rp[ch], g.wplanes, Co, Ci, col0, ch * BKX, threadIdx.x);
+            } else {
+                fetch_chunk_x<T>(ra[ch], rb[ch], fa, fb, ch * BKX, threadIdx.x);
+            }
+        }
 #else
         float4 ra[T::A4], rb[T::B4];
         fetch_chunk<T, true, true>(ra, rb, fa, fb, 0, threadIdx.x);
@@ -941,6 +1047,7 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
         if (first && threadIdx.x == 0 && bp.num_batches_tracked) *bp.num_batches_tracked += 1;
         fx_clear_share(g.zero_ptr, g.zero_n, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, threadIdx.x, T::THREADS);
         __syncthreads();
+        SN_TL(1);
         const auto xa = [&](float4 v, int k) {
             const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
             v.x = relu_np(fmaf(v.x, sc.x, sh.x)), v.y = relu_np(fmaf(v.y, sc.y, sh.y));
@@ -948,10 +1055,16 @@ __global__ void __launch_bounds__(T::THREADS) linear_fwd_kernel(FwdArgs g)
             return v;
         };
 #if SN_BF16X3
-        if (KT > 0)
+        if constexpr (PLANES) {
+            if constexpr (KT > 0)
+                gemm_tile_bx3_ring_p<T, NCHK>(acc, fa, xa, g.wplanes, Co, col0, ra, rp, lds);
+            else
+                gemm_tile_bx3_p<T>(acc, Ci, fa, xa, g.wplanes, Co, col0, ra[0], rp[0], lds);
+        } else if constexpr (KT > 0) {
             gemm_tile_bx3_all<T, NCH>(acc, xa, ra, rb, lds);
-        else
+        } else {
             gemm_tile_bx3<T>(acc, Ci, fa, fb, xa, ra[0], rb[0], lds);
+        }
 #else
         gemm_tile_x<T>(acc, Ci, fa, fb, xa, ra, rb, lds);
 #endif
@@ -3382,12 +3495,46 @@ __global__ void __launch_bounds__(256) small_bwd_kernel(DgradArgs d, WgradArgs w
 // Workgroup = 64 rows x 64 output channels (thread = channel, 4 row groups), stats partial per workgroup row block
 // exactly like linear_fwd_kernel ([gridDim.x][2][Co], 64 rows per block).
 // ------------------------------------------------------------------------------------------------
+// Rider of the xyz-layer kernel (statistics-chain stack): the weights of the GEMM layers above it, split once per step into the
+// three bf16 planes the split-bf16 GEMMs consume ([3][Co][Ci] per layer, k-contiguous) -- otherwise every one of a layer's 512
+// workgroups splits the same W tile again (2/3 of their staging VALU work, which is as long as their MFMA phase).
+struct WSplitJob {
+    const float *w[4];
+    __bf16 *dst[4];
+    int elems[4];  // Co * Ci
+    int first[5];  // first 1024-element block of layer l in the job's block numbering; first[n] = number of blocks
+    int n;
+};
+__device__ __forceinline__ void wsplit_block(const WSplitJob &job, int blk, int tid)
+{
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < job.n && blk >= job.first[q]) l = q;
+    const int e = (blk - job.first[l]) * 1024 + tid * 4;
+    if (e >= job.elems[l]) return;
+    const float4 v = *reinterpret_cast<const float4 *>(job.w[l] + e);
+    bf16x4 p1, p2, p3;
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        __bf16 h1, h2, h3;
+        split3(f[t], h1, h2, h3);
+        p1[t] = h1, p2[t] = h2, p3[t] = h3;
+    }
+    __bf16 *d = job.dst[l] + e;
+    *reinterpret_cast<bf16x4 *>(d) = p1;
+    *reinterpret_cast<bf16x4 *>(d + job.elems[l]) = p2;
+    *reinterpret_cast<bf16x4 *>(d + 2 * (size_t)job.elems[l]) = p3;
+}
+
 __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const float *__restrict__ x,
                                                            const float *__restrict__ W, const float *__restrict__ bias,
                                                            float *__restrict__ z, float *__restrict__ stats,
                                                            long long *__restrict__ acc_out = nullptr,
-                                                           long long *__restrict__ clear_flags = nullptr)
+                                                           long long *__restrict__ clear_flags = nullptr, WSplitJob job = WSplitJob{})
 {
+    if (job.n > 0 && blockIdx.y == 0 && (int)blockIdx.x < job.first[job.n]) wsplit_block(job, blockIdx.x, threadIdx.x);
     // (statistics chain: the poison word of the LAST layer's accumulators, read by every workgroup of the previous
     // step's closing kernel, is reset here, by the first kernel of the next step)
     if (clear_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) clear_flags[0] = 0;
@@ -4356,7 +4503,14 @@ extern "C" int sn_conv_stack_forward_supported(int B, int N, int nlayers, const 
     return 1;
 }
 
-extern "C" long long sn_conv_stack_acc_elems(int nlayers) { return nlayers > 0 ? (long long)nlayers * kFxLayer : 0; }
+// (behind the accumulators: room for the split weights of the nlayers - 1 GEMM layers, 128 x 128 x 3 bf16 each -- scratch of the
+//  call, contents irrelevant between calls)
+constexpr long long kWPlaneLL = (long long)128 * 128 * 3 * 2 / 8;
+extern "C" long long sn_conv_stack_acc_sum_elems(int nlayers) { return nlayers > 0 ? (long long)nlayers * kFxLayer : 0; }
+extern "C" long long sn_conv_stack_acc_elems(int nlayers)
+{
+    return nlayers > 0 ? (long long)nlayers * kFxLayer + (long long)(nlayers - 1) * kWPlaneLL : 0;
+}
 
 extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
                                         const float *const *bias, const float *const *gamma, const float *const *beta,
@@ -4376,9 +4530,25 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
                      num_batches_tracked ? num_batches_tracked[l] : nullptr, coef[l], eps[l], momentum[l], (long long)R};
     };
     for (int l = 0; l < nlayers; ++l) SN_REQUIRE(W[l] && gamma[l] && beta[l] && z[l] && coef[l], "null pointer");
-    // layer 0: xyz input
+    // layer 0: xyz input (+ the weight split of the layers above, SN_BF16X3)
+    WSplitJob job{};
+    __bf16 *planes[8] = {nullptr};
+#if SN_BF16X3
+    if (nlayers - 1 <= 4) {
+        __bf16 *base = reinterpret_cast<__bf16 *>(acc + (size_t)nlayers * kFxLayer);
+        int nb = 0;
+        for (int l = 1; l < nlayers; ++l) {
+            const int li = l - 1, el = channels[l] * channels[l + 1];
+            planes[l] = base + (size_t)li * kWPlaneLL * 4;
+            job.w[li] = W[l], job.dst[li] = planes[l], job.elems[li] = el, job.first[li] = nb;
+            nb += (el + 1023) / 1024;
+        }
+        job.n = nlayers - 1, job.first[job.n] = nb;
+        if (nb > R / 64) job.n = 0;  // (cannot happen for R > 64 * 44; keep the planes off then)
+    }
+#endif
     hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3(R / 64, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
-                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * kFxLayer + kFxPoison);
+                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * kFxLayer + kFxPoison, job);
     using T = TileBig;
     for (int l = 1; l < nlayers; ++l) {
         const int Ci = channels[l], Co = channels[l + 1];
@@ -4389,24 +4559,30 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         g.acc_in = acc + (size_t)(l - 1) * kFxLayer, g.bn_prev = bn_of(l - 1), g.acc_out = acc + (size_t)l * kFxLayer;
         if (l >= 2) g.zero_ptr = acc + (size_t)(l - 2) * kFxLayer, g.zero_n = kFxLayer;
         if (l == nlayers - 1) g.pool_val = pool_val, g.pool_idx = pool_idx, g.pool_npts = N;
+        g.wplanes = job.n > 0 ? planes[l] : nullptr;
+        const bool pl = g.wplanes != nullptr;
         if (Co == 128) {
             // 128 output channels: one 512-thread workgroup per 64 rows computes all of them -- the input tile is fetched
             // once instead of once per 64-column block, and half as many workgroups run the statistics prologue
             using TW = SN_FWD_TW;
             const dim3 grid(R / TW::BM, 1);
             const size_t lds = shaped_lds(lds_bytes<TW>() + (size_t)2 * Ci * sizeof(float), grid);
-            if (Ci == 128)
-                hipLaunchKernelGGL((linear_fwd_kernel<TW, true, ACT_BN_RELU_FX, SN_FWD_KT128>), grid, dim3(TW::THREADS), lds, st, g);
-            else
-                hipLaunchKernelGGL((linear_fwd_kernel<TW, true, ACT_BN_RELU_FX, 64>), grid, dim3(TW::THREADS), lds, st, g);
+#define SN_FWD_FX(TT, KT_)                                                                                                \
+    do {                                                                                                                  \
+        if (pl) hipLaunchKernelGGL((linear_fwd_kernel<TT, true, ACT_BN_RELU_FX, KT_, SN_BF16X3 != 0>), grid, dim3(TT::THREADS), lds, st, g); \
+        else hipLaunchKernelGGL((linear_fwd_kernel<TT, true, ACT_BN_RELU_FX, KT_>), grid, dim3(TT::THREADS), lds, st, g);  \
+    } while (0)
+            if (Ci == 128 && pl) SN_FWD_FX(TW, 128);
+            else if (Ci == 128) SN_FWD_FX(TW, SN_FWD_KT128);
+            else SN_FWD_FX(TW, 64);
             continue;
         }
         const dim3 grid(R / T::BM, Co / T::BN);
         const size_t lds = shaped_lds(lds_bytes<T>() + (size_t)2 * Ci * sizeof(float), grid);
-        if (Ci == 128)
-            hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX, SN_FWD_KT128>), grid, dim3(T::THREADS), lds, st, g);
-        else
-            hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX, 64>), grid, dim3(T::THREADS), lds, st, g);
+        if (Ci == 128 && pl) SN_FWD_FX(T, 128);
+        else if (Ci == 128) SN_FWD_FX(T, SN_FWD_KT128);
+        else SN_FWD_FX(T, 64);
+#undef SN_FWD_FX
     }
     const int Cn = channels[nlayers];
     long long *zp = nlayers >= 2 ? acc + (size_t)(nlayers - 2) * kFxLayer : nullptr;

@@ -179,6 +179,63 @@ def bwd(R, Ci, Co, mode, B=32):
     (dump_fused if FUSED else dump)("linear_bwd R=%d %d->%d mode %d" % (R, Ci, Co, mode), 256 if FUSED else min(16384, nw + nd))
 
 
+def stack_fwd(B=32, N=1024):
+    """The conv stack's forward as the sampler runs it (sn_conv_stack_forward_bn, statistics-chain kernels).  The timeline
+    buffer is reset before the call and every GEMM kernel overwrites it, so the dump shows the LAST layer of the stack:
+    truncated stacks show the earlier ones."""
+    dev = "cuda"
+    lib.sn_conv_stack_acc_elems.restype = ctypes.c_longlong
+    lib.sn_conv_stack_forward_bn.argtypes = [i, i, i] + [vp] * 20
+    for nl, chans in ((5, [3, 64, 64, 64, 128, 128]), (4, [3, 64, 64, 64, 128]), (2, [3, 64, 64])):
+        R = B * N
+        x = torch.rand(B, N, 3, device=dev) - 0.5
+        Ws = [torch.randn(chans[l + 1], chans[l], device=dev) * 0.2 for l in range(nl)]
+        bs = [torch.randn(chans[l + 1], device=dev) * 0.1 for l in range(nl)]
+        gs = [torch.rand(chans[l + 1], device=dev) + 0.5 for l in range(nl)]
+        bes = [torch.randn(chans[l + 1], device=dev) * 0.1 for l in range(nl)]
+        rms = [torch.zeros(chans[l + 1], device=dev) for l in range(nl)]
+        rvs = [torch.ones(chans[l + 1], device=dev) for l in range(nl)]
+        nbt = [torch.zeros((), device=dev, dtype=torch.int64) for l in range(nl)]
+        zs = [torch.empty(R, chans[l + 1], device=dev) for l in range(nl)]
+        cs = [torch.empty(4, chans[l + 1], device=dev) for l in range(nl)]
+        acc = torch.zeros(lib.sn_conv_stack_acc_elems(nl), device=dev, dtype=torch.int64)
+        Cn = chans[-1]
+        pv = torch.empty(R // 64, 2, Cn, device=dev)
+        pi = torch.empty(R // 64, 2, Cn, device=dev, dtype=torch.int32)
+        pooled, zsel = torch.empty(B, Cn, device=dev), torch.empty(B, Cn, device=dev)
+        argsel = torch.empty(B, Cn, device=dev, dtype=torch.int32)
+        VP = vp * nl
+        arr = lambda ts: VP(*[t.data_ptr() for t in ts])  # noqa: E731
+        ch = (ctypes.c_int * (nl + 1))(*chans)
+        eps = (ctypes.c_float * nl)(*([1e-5] * nl))
+        mom = (ctypes.c_float * nl)(*([0.1] * nl))
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run():
+            rc = lib.sn_conv_stack_forward_bn(B, N, nl, ch, P(x), arr(Ws), arr(bs), arr(gs), arr(bes), arr(rms), arr(rvs), arr(nbt), eps, mom,
+                                              arr(zs), arr(cs), P(acc), P(pv), P(pi), P(pooled), P(argsel), P(zsel), vp(st))
+            assert rc == 0, rc
+
+        for _ in range(3):
+            run()
+        lib.sn_debug_timeline(None, 0, 1)
+        run()
+        torch.cuda.synchronize()
+        nb = 512
+        host = np.zeros((nb, 16), dtype=np.uint64)
+        assert lib.sn_debug_timeline(host.ctypes.data_as(vp), nb, 0) == 0
+        valid = host[:, 0] > 0
+        t = host.astype(np.float64) / 100.0
+        t0 = t[valid, 0].min()
+        last = max(sidx for sidx in range(7) if (host[valid, sidx] > 0).all())
+        print("== last GEMM layer of the %d-layer stack (%d -> %d channels): %d workgroups, span %.2f us" %
+              (nl, chans[-2], chans[-1], valid.sum(), t[valid, last].max() - t0))
+        for sidx in range(7):
+            if (host[valid, sidx] > 0).all():
+                col = t[valid, sidx] - t0
+                print("     slot %d   abs med %.2f  (p10 %.2f p90 %.2f)" % (sidx, np.median(col), np.percentile(col, 10), np.percentile(col, 90)))
+
+
 FUSED = True
 
 if __name__ == "__main__":
@@ -189,6 +246,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         small_fwd(32, 256, 256)
         small_fwd(32, 128, 256)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stack":
+        stack_fwd()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fwd":
         fwd(R, 64, 64)
