@@ -326,6 +326,10 @@ int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, c
  * pooled = argsel = zsel = NULL: stop after the last GEMM; sn_fc_chain_forward_pool must follow (it finishes the pool). */
 int sn_conv_stack_forward_supported(int B, int N, int nlayers, const int *channels);
 long long sn_conv_stack_acc_elems(int nlayers);
+/* 1: z[0] may be NULL in sn_conv_stack_forward_bn / sn_conv_stack_backward for this shape -- the xyz layer then runs as a
+ * statistics-only pass and its activation (B*N, C1) is never written: conv2's forward and backward rebuild it from the cloud
+ * with the xyz layer's own expression (bit-identical results, 8 MB less written and 16 MB less read per step at B = 32). */
+int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const int *channels);
 /* the leading part of acc that holds the statistics accumulators (zero between calls); behind it: scratch of the forward (the
  * layers' weights split into bf16 planes by the first kernel of the call) */
 long long sn_conv_stack_acc_sum_elems(int nlayers);

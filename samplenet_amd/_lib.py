@@ -66,6 +66,7 @@ PROTOTYPES = {
                           _vp, ctypes.c_longlong, _vp],
     "sn_conv_stack_forward_supported": [_i, _i, _i, _vp],
     "sn_conv_stack_acc_elems": [_i],
+    "sn_conv_stack_z1_free_supported": [_i, _i, _i, _vp],
     "sn_conv_stack_acc_sum_elems": [_i],
     "sn_conv_stack_backward_scratch_floats": [_i, _i, _i, _vp],
     "sn_conv_stack_backward": [_i, _i, _i] + [_vp] * 17,

@@ -948,12 +948,16 @@ struct FwdArgs {
     // the weights already split into three bf16 planes [3][Co][Ci] (by the xyz-layer kernel of the same stack call, once per step):
     // staged as straight copies.  NULL: every workgroup splits its W tile itself.
     const __bf16 *wplanes;
+    // IN3A (second layer of the stack): the input activation is not read from memory but rebuilt from the cloud -- Z1[r][c] =
+    // (W3[c] . x_r) + b3[c], the xyz layer's own expression (conv_in3_fwd_kernel), 3 FMAs per element instead of a 4-byte load:
+    // the stack never writes its first activation tensor.  x3 (R, 3), w3 (Ci, 3), b3 (Ci) or NULL.
+    const float *x3, *w3, *b3;
 };
 
 // KT > 0 (statistics-chain path): the input width, known at compile time -- both operands are fetched whole, up front
 // PLANES: FwdArgs::wplanes holds the weights pre-split (statistics-chain path)
 // (two 512-thread workgroups per CU need <= 128 registers: T::THREADS / 128 waves per SIMD at least)
-template <class T, bool FULL, int AMODE, int KT = 0, bool PLANES = false>
+template <class T, bool FULL, int AMODE, int KT = 0, bool PLANES = false, bool IN3A = false>
 __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(T::THREADS / 128, 8))) linear_fwd_kernel(FwdArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1000,8 +1004,31 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
             bg = bp.gamma[c], bb = bp.beta[c];
             if (first && bp.running_mean) brm = bp.running_mean[c], brv = bp.running_var[c];
         }
-        const auto fa = [&](int x, int k) { return *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k); };
+        static_assert(!IN3A || (PLANES && KT > 0 && SN_BF16X3), "IN3A: statistics-chain path with compile-time K");
+        // IN3A: the "fetch" of 4 consecutive channels of row x is the row's three coordinates; this thread's channels are the same
+        // in every item it stages (k4 = 4 (tid % 8), THREADS % 8 == 0), so its xyz-layer weights live in registers per chunk
+        const auto fa = [&](int x, int k) {
+            if constexpr (IN3A) {
+                const float *xr = g.x3 + (size_t)(row0 + x) * 3;
+                return make_float4(xr[0], xr[1], xr[2], 0.f);
+            } else {
+                return *reinterpret_cast<const float4 *>(a.z + (size_t)(row0 + x) * Ci + k);
+            }
+        };
         const auto fb = [&](int x, int k) { return w.template load_ci4<FULL>(col0 + x, k); };
+        constexpr int NW3 = IN3A ? KT / BKX : 1;
+        float w3r[NW3][4][3], b3r[NW3][4];
+        if constexpr (IN3A) {
+            const int k4 = (threadIdx.x % (BKX / 4)) * 4;
+#pragma unroll
+            for (int ch = 0; ch < NW3; ++ch)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cc = ch * BKX + k4 + j;
+                    w3r[ch][j][0] = g.w3[cc * 3], w3r[ch][j][1] = g.w3[cc * 3 + 1], w3r[ch][j][2] = g.w3[cc * 3 + 2];
+                    b3r[ch][j] = g.b3 ? g.b3[cc] : 0.f;
+                }
+        }
 #if SN_BF16X3
         constexpr int NCHK = KT > 0 ? KT / BKX : 1;                        // chunks of the whole K (when known)
         constexpr int NCH = PLANES ? (NCHK < 2 ? NCHK : 2) : NCHK;         // chunks fetched up front
@@ -1050,6 +1077,15 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
         SN_TL(1);
         const auto xa = [&](float4 v, int k) {
             const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
+            if constexpr (IN3A) {  // v = (x, y, z, -) of the row: the xyz layer's expression, bit for bit (conv_in3_fwd_kernel)
+#pragma clang fp contract(off)
+                const int ch = k / BKX;  // (a constant after unrolling)
+                const float x0 = v.x, x1 = v.y, x2 = v.z;
+                v.x = fmaf(w3r[ch][0][2], x2, fmaf(w3r[ch][0][1], x1, w3r[ch][0][0] * x0)) + b3r[ch][0];
+                v.y = fmaf(w3r[ch][1][2], x2, fmaf(w3r[ch][1][1], x1, w3r[ch][1][0] * x0)) + b3r[ch][1];
+                v.z = fmaf(w3r[ch][2][2], x2, fmaf(w3r[ch][2][1], x1, w3r[ch][2][0] * x0)) + b3r[ch][2];
+                v.w = fmaf(w3r[ch][3][2], x2, fmaf(w3r[ch][3][1], x1, w3r[ch][3][0] * x0)) + b3r[ch][3];
+            }
             v.x = relu_np(fmaf(v.x, sc.x, sh.x)), v.y = relu_np(fmaf(v.y, sc.y, sh.y));
             v.z = relu_np(fmaf(v.z, sc.z, sh.z)), v.w = relu_np(fmaf(v.w, sc.w, sh.w));
             return v;
@@ -1371,6 +1407,8 @@ struct ConvBwdArgs {
     float *dyprev, *stats, *part;
     int ntiles;
     const float *xin;  // IN3 only: (R,3) input of the layer below when that layer is the xyz input layer
+    const float *w_in, *b_in;  // IN3 with zprev == NULL (RZ1): the xyz layer's weights (CI, 3) / bias (CI) or NULL -- Zprev is rebuilt
+                               // from the cloud (Z1[r][c] = W_in[c] . x_r + b_in[c], conv_in3_fwd_kernel's expression) instead of read
     // fixed-point statistics chain of the backward (sn_conv_stack_backward), the mirror of the forward's:
     //  acc_in  (DZ_BN): sums (sum dY, sum dY Z) of THIS layer's BatchNorm, left by the kernel of the layer above; every
     //          workgroup derives k1..k3 from them in its prologue, workgroup 0 also stores dgamma / dbeta / dbias (bb_in)
@@ -1399,6 +1437,12 @@ __device__ __forceinline__ float4 buf_load4(sn_rsrc r, unsigned voff, unsigned s
     const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ float4 buf_load3(sn_rsrc r, unsigned voff, unsigned soff)  // (x, y, z, 0)
+{
+    const u32x3 x = __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, 0);
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), 0.f);
+}
 __device__ __forceinline__ int4 buf_load4i(sn_rsrc r, unsigned voff, unsigned soff)
 {
     const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
@@ -1419,7 +1463,7 @@ struct CbfRsrc {
     sn_rsrc z, dy, zprev, dyprev, argsel, gsel;
 };
 
-template <int CO, int CI, int TR, int ZMODE, int NZ4, int NP4>
+template <int CO, int CI, int TR, int ZMODE, int NZ4, int NP4, bool SKIP_P = false>
 __device__ __forceinline__ void cbf_issue_loads(const CbfRsrc &rs, int tile, int b, unsigned zvo, unsigned pvo, unsigned avo,
                                                 float4 (&rz)[NZ4], float4 (&rdy)[NZ4], float4 (&rp)[NP4], int4 &rag,
                                                 float4 &rgs)
@@ -1434,7 +1478,7 @@ __device__ __forceinline__ void cbf_issue_loads(const CbfRsrc &rs, int tile, int
         if (ZMODE == DZ_BN) rdy[q] = buf_load4(rs.dy, zvo, zso + q * (ZSTEP * CO * 4));
     }
 #pragma unroll
-    for (int q = 0; q < NP4; ++q) rp[q] = buf_load4(rs.zprev, pvo, pso + q * (PSTEP * CI * 4));
+    for (int q = 0; q < (SKIP_P ? 0 : NP4); ++q) rp[q] = buf_load4(rs.zprev, pvo, pso + q * (PSTEP * CI * 4));
     if (ZMODE == DZ_POOL) {  // the host guarantees npts % 64 == 0: one cloud (b) per tile
         rag = buf_load4i(rs.argsel, avo, (unsigned)b * (CO * 4));
         rgs = buf_load4(rs.gsel, avo, (unsigned)b * (CO * 4));
@@ -1930,15 +1974,17 @@ struct CbxShape {
     static constexpr int XSZ = 2 * 3 * TR;
     static constexpr size_t TOFF = (size_t)2 * BUF * 2;             // byte offset of the float areas behind the tile buffers
     static constexpr size_t LDS_BYTES = TOFF + TSZ * sizeof(float);
-    static constexpr size_t LDS_BYTES_IN3 = LDS_BYTES + XSZ * sizeof(float);
+    static constexpr size_t LDS_BYTES_IN3 = LDS_BYTES + (XSZ + 4 * CI) * sizeof(float);  // + coordinate rows, xyz-layer parameters (RZ1)
     static_assert(LDS_BYTES_IN3 <= 160 * 1024, "tile buffers exceed the LDS");
 };
 
-template <int CO, int CI, int TR, int ZMODE, bool FULLR, int NZ4, int NP4>
+// RZ1: rp[q] holds the xyz coordinates of the row; w3 -> the xyz layer's (w0, w1, w2, bias) of this thread's four channels, in LDS
+template <int CO, int CI, int TR, int ZMODE, bool FULLR, int NZ4, int NP4, bool RZ1 = false>
 __device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0, int tid, __bf16 *__restrict__ Zb,
                                           __bf16 *__restrict__ Pb, const float4 (&rz)[NZ4], const float4 (&rdy)[NZ4],
                                           const float4 (&rp)[NP4], const int4 &rag, const float4 &rgs, const float4 &k1,
-                                          const float4 &k2, const float4 &k3, const float4 &sc4, const float4 &sh4)
+                                          const float4 &k2, const float4 &k3, const float4 &sc4, const float4 &sh4,
+                                          const float4 *w3 = nullptr)
 {
     constexpr int ZSTEP = 256 / (CO / 4), PSTEP = 256 / (CI / 4);
     constexpr int LDZ = CO + 8, LDP = CI + 8;
@@ -1969,15 +2015,27 @@ __device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0
     }
 #pragma unroll
     for (int q = 0; q < NP4; ++q) {
-        const float4 a = make_float4(relu_np(fmaf(rp[q].x, sc4.x, sh4.x)), relu_np(fmaf(rp[q].y, sc4.y, sh4.y)),
-                                     relu_np(fmaf(rp[q].z, sc4.z, sh4.z)), relu_np(fmaf(rp[q].w, sc4.w, sh4.w)));
+        float4 zp = rp[q];
+        if (RZ1) {
+#pragma clang fp contract(off)
+            const float x0 = rp[q].x, x1 = rp[q].y, x2 = rp[q].z;
+            const float4 c0 = w3[0], c1 = w3[1], c2 = w3[2], c3 = w3[3];
+            zp.x = fmaf(c0.z, x2, fmaf(c0.y, x1, c0.x * x0)) + c0.w;
+            zp.y = fmaf(c1.z, x2, fmaf(c1.y, x1, c1.x * x0)) + c1.w;
+            zp.z = fmaf(c2.z, x2, fmaf(c2.y, x1, c2.x * x0)) + c2.w;
+            zp.w = fmaf(c3.z, x2, fmaf(c3.y, x1, c3.x * x0)) + c3.w;
+        }
+        const float4 a = make_float4(relu_np(fmaf(zp.x, sc4.x, sh4.x)), relu_np(fmaf(zp.y, sc4.y, sh4.y)),
+                                     relu_np(fmaf(zp.z, sc4.z, sh4.z)), relu_np(fmaf(zp.w, sc4.w, sh4.w)));
         stage_split_p<TR * LDP, LDP>(Pb, pr + q * PSTEP, pc4, a);
     }
 }
 
-template <int CI, int CO, int ZMODE, bool FULLR, bool IN3 = false>
+// RZ1 (IN3 only): Zprev is not read -- the producer rebuilds it from the tile's xyz rows (ConvBwdArgs::w_in)
+template <int CI, int CO, int ZMODE, bool FULLR, bool IN3 = false, bool RZ1 = false>
 __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 {
+    static_assert(!RZ1 || IN3, "RZ1: the layer below must be the xyz layer");
     using S = CbxShape<CI, CO>;
     static_assert(!IN3 || (S::TR == 64 && ZMODE == DZ_BN), "IN3: 64-row tiles (one row per lane for the moments)");
     constexpr int NST = IN3 ? 5 : 2;
@@ -2055,12 +2113,26 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         int4 rag = make_int4(0, 0, 0, 0);
         float4 rgs = make_float4(0.f, 0.f, 0.f, 0.f);
         float s0 = 0.f, s1 = 0.f;
+        // RZ1: the xyz layer's weights of the four channels this thread stages and of the channel its dYprev fragment column holds
+        // (w0, w1, w2, bias) per channel of the xyz layer, in LDS behind the coordinate rows: read at every use (20 registers otherwise)
+        float4 *W3s = reinterpret_cast<float4 *>(Xs + S::XSZ);
+        constexpr int PSTEPK = 256 / (CI / 4);
+        const unsigned xvo = (tid / (CI / 4)) * 12;
+        if (RZ1 && tid < CI)
+            W3s[tid] = make_float4(g.w_in[tid * 3], g.w_in[tid * 3 + 1], g.w_in[tid * 3 + 2], g.b_in ? g.b_in[tid] : 0.f);
+        const float4 *w3s = W3s + pc4;
+        // (RZ1) the rows' coordinates in place of the Zprev tile: 12 bytes per row instead of 16 per four channels
+        auto load_xyz_rows = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < NP4; ++q) rp[q] = buf_load3(rsx, xvo, (unsigned)t * (TR * 12) + q * (PSTEPK * 12));
+        };
         float4 vout[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) vout[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
         int tile = blockIdx.x;
-        cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+        cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+        if (RZ1) load_xyz_rows(tile);
         if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)tile * (TR * 12));
         // W^T fragments of this wave's 32 input channels: W[co = 16 kk + 8 h + t][ci = cb 32 + l31] (requested after the first
         // tile: its staging does not wait for them), split below once the first tile is staged
@@ -2076,7 +2148,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             k2 = *reinterpret_cast<const float4 *>(Ks + CO + zc4);
             k3 = *reinterpret_cast<const float4 *>(Ks + 2 * CO + zc4);
         }
-        cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, tile, tic * TR, tid, Lb, Lb + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3, sc4, sh4);
+        cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4, RZ1>(g, tile, tic * TR, tid, Lb, Lb + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3, sc4, sh4,
+                                                           w3s);
         if (xthr) Xs[xslot[0]] = rx.x, Xs[xslot[1]] = rx.y, Xs[xslot[2]] = rx.z, Xs[xslot[3]] = rx.w;
         bf16x8 wf[KD][3];
 #pragma unroll
@@ -2096,7 +2169,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * CI * 4));
             }
             float zq[16];
-            if (KS == 1 || kh == 0)
+            if (!RZ1 && (KS == 1 || kh == 0))
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     zq[e] = buf_load1(rs.zprev, qvo, (unsigned)tile * (TR * CI * 4) + ((e & 3) + 8 * (e >> 2)) * (CI * 4));
@@ -2107,7 +2180,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 ncloud += bstep, ntic += tstep;
                 if (ntic >= tpc) ntic -= tpc, ++ncloud;
             }
-            cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+            cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+            if (RZ1) load_xyz_rows(nxt);
             if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)nxt * (TR * 12));
             // the requests go out HERE: left alone, the scheduler sinks them below the MFMAs to their first use (the staging),
             // and every tile pays a full memory round trip
@@ -2142,12 +2216,28 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                     for (int e = 0; e < 16; ++e) acc[e] += Tx[e * 64 + lane];
             }
             if (kh == 0) {
+            if (RZ1) {  // Zprev at the fragment positions from the tile's coordinates in LDS (rows 4 q .. 4 q + 3 of a fragment are consecutive)
+#pragma clang fp contract(off)  // bit for bit the stored tensor: the bias add must not fuse with what consumes z below
+                const float4 wd = W3s[cb * 32 + l31];
+                const float w3d0 = wd.x, w3d1 = wd.y, w3d2 = wd.z, b3d = wd.w;
+                const float *xq = Xs + (it & 1) * (3 * TR) + rb * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 x0 = *reinterpret_cast<const float4 *>(xq + 8 * q);
+                    const float4 x1 = *reinterpret_cast<const float4 *>(xq + TR + 8 * q);
+                    const float4 x2 = *reinterpret_cast<const float4 *>(xq + 2 * TR + 8 * q);
+                    zq[4 * q + 0] = fmaf(w3d2, x2.x, fmaf(w3d1, x1.x, w3d0 * x0.x)) + b3d;
+                    zq[4 * q + 1] = fmaf(w3d2, x2.y, fmaf(w3d1, x1.y, w3d0 * x0.y)) + b3d;
+                    zq[4 * q + 2] = fmaf(w3d2, x2.z, fmaf(w3d1, x1.z, w3d0 * x0.z)) + b3d;
+                    zq[4 * q + 3] = fmaf(w3d2, x2.w, fmaf(w3d1, x1.w, w3d0 * x0.w)) + b3d;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float z = zq[e];
                 const float v = fmaf(z, scd, shd) > 0.f ? acc[e] : 0.f;
                 s0 += v;
-                s1 += v * z;
+                s1 = fmaf(v, z, s1);  // (explicit: the variants of this kernel must round the sum the same way)
                 if (IN3) acc[e] = v;
                 if (!IN3) Ts[frag_row(e, lane) * 36 + l31] = v;
             }
@@ -2178,8 +2268,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             if (it == 1) SN_TL(2);
             if (more) {
                 __bf16 *Zn = Lb + ((it + 1) & 1) * BUF;
-                cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4>(g, nxt, ntic * TR, tid, Zn, Zn + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3,
-                                                              sc4, sh4);
+                cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4, RZ1>(g, nxt, ntic * TR, tid, Zn, Zn + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3,
+                                                                   sc4, sh4, w3s);
                 if (xthr) {
                     float *Xn = Xs + ((it + 1) & 1) * (3 * TR);
                     Xn[xslot[0]] = rx.x, Xn[xslot[1]] = rx.y, Xn[xslot[2]] = rx.z, Xn[xslot[3]] = rx.w;
@@ -3571,7 +3661,7 @@ __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const 
             s0[j] += v[j];
             s1[j] += v[j] * v[j];
         }
-        if (r < R) {
+        if (r < R && z) {  // (z == NULL: statistics only -- the consumers rebuild the activation from the cloud, FwdArgs::x3)
             if (vec) {
                 *reinterpret_cast<float4 *>(z + (size_t)r * Co + co) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -4506,6 +4596,20 @@ extern "C" int sn_conv_stack_forward_supported(int B, int N, int nlayers, const 
 // (behind the accumulators: room for the split weights of the nlayers - 1 GEMM layers, 128 x 128 x 3 bf16 each -- scratch of the
 //  call, contents irrelevant between calls)
 constexpr long long kWPlaneLL = (long long)128 * 128 * 3 * 2 / 8;
+// 1: sn_conv_stack_forward_bn accepts z[0] == NULL for this shape (the xyz layer's activation is not materialised; conv2's
+// forward and sn_conv_stack_backward rebuild it from the cloud): 3 -> 64 -> 64 channels and enough row blocks for the weight split
+extern "C" int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const int *channels)
+{
+#if SN_BF16X3
+    if (!sn_conv_stack_forward_supported(B, N, nlayers, channels) || nlayers < 3 || nlayers - 1 > 4) return 0;
+    if (channels[1] != 64 || channels[2] != 64) return 0;
+    long long nb = 0;
+    for (int l = 1; l < nlayers; ++l) nb += ((long long)channels[l] * channels[l + 1] + 1023) / 1024;
+    return nb <= (long long)B * N / 64 ? 1 : 0;
+#else
+    return 0;
+#endif
+}
 extern "C" long long sn_conv_stack_acc_sum_elems(int nlayers) { return nlayers > 0 ? (long long)nlayers * kFxLayer : 0; }
 extern "C" long long sn_conv_stack_acc_elems(int nlayers)
 {
@@ -4529,7 +4633,13 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         return BnFwd{gamma[l], beta[l], running_mean ? running_mean[l] : nullptr, running_var ? running_var[l] : nullptr,
                      num_batches_tracked ? num_batches_tracked[l] : nullptr, coef[l], eps[l], momentum[l], (long long)R};
     };
-    for (int l = 0; l < nlayers; ++l) SN_REQUIRE(W[l] && gamma[l] && beta[l] && z[l] && coef[l], "null pointer");
+    for (int l = 0; l < nlayers; ++l) SN_REQUIRE(W[l] && gamma[l] && beta[l] && (z[l] || l == 0) && coef[l], "null pointer");
+    // z[0] == NULL: the first activation tensor is not materialised (its consumers rebuild it from the cloud)
+    const bool z1free = z[0] == nullptr;
+#if !SN_BF16X3
+    SN_REQUIRE(!z1free, "z[0] == NULL needs the split-bf16 build");
+#endif
+    SN_REQUIRE(!z1free || (channels[1] == 64 && channels[2] == 64), "z[0] == NULL: 3 -> 64 -> 64 channels only");
     // layer 0: xyz input (+ the weight split of the layers above, SN_BF16X3)
     WSplitJob job{};
     __bf16 *planes[8] = {nullptr};
@@ -4561,6 +4671,14 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         if (l == nlayers - 1) g.pool_val = pool_val, g.pool_idx = pool_idx, g.pool_npts = N;
         g.wplanes = job.n > 0 ? planes[l] : nullptr;
         const bool pl = g.wplanes != nullptr;
+        if (l == 1 && z1free) {
+            SN_REQUIRE(pl, "z[0] == NULL: the weight planes are missing");
+            g.x3 = x, g.w3 = W[0], g.b3 = bias ? bias[0] : nullptr;
+            const dim3 grid(R / T::BM, Co / T::BN);
+            const size_t lds = shaped_lds(lds_bytes<T>() + (size_t)2 * Ci * sizeof(float), grid);
+            hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX, 64, SN_BF16X3 != 0, SN_BF16X3 != 0>), grid, dim3(T::THREADS), lds, st, g);
+            continue;
+        }
         if (Co == 128) {
             // 128 output channels: one 512-thread workgroup per 64 rows computes all of them -- the input tile is fetched
             // once instead of once per 64-column block, and half as many workgroups run the statistics prologue
@@ -5015,10 +5133,11 @@ extern "C" long long sn_layer_backward_in3_stats_floats(int R, int Ci, int Co)
 
 static void launch_conv_bwd_in3(int R, const float *dy, const float *z, const float *kcoef, const float *W, const float *zprev,
                                 const float *coef_prev, float *stats, float *part, const float *x_in, hipStream_t st,
-                                const ConvBwdArgs *fx = nullptr)
+                                const ConvBwdArgs *fx = nullptr, const float *w_in = nullptr, const float *b_in = nullptr)
 {
     constexpr int Ci = 64, Co = 64;
     ConvBwdArgs a{};
+    a.w_in = w_in, a.b_in = b_in;  // (zprev == NULL: the xyz layer's parameters, Zprev is rebuilt from x_in)
     if (fx) a.acc_in = fx->acc_in, a.bb_in = fx->bb_in, a.acc_out = nullptr, a.zero_ptr = fx->zero_ptr, a.zero_n = fx->zero_n;
     a.dz.mode = DZ_BN, a.dz.dy = dy, a.dz.z = z, a.dz.rows = R, a.dz.ch = Co, a.dz.npts = 1;
     a.dz.k1 = kcoef, a.dz.k2 = kcoef ? kcoef + Co : nullptr, a.dz.k3 = kcoef ? kcoef + 2 * Co : nullptr;
@@ -5031,6 +5150,19 @@ static void launch_conv_bwd_in3(int R, const float *dy, const float *z, const fl
 #if SN_BF16X3
 #define SN_CBF_IN3 conv_bwd_bx3_kernel
     constexpr size_t lds = CbxShape<64, 64>::LDS_BYTES_IN3;
+    if (!zprev) {  // Zprev rebuilt from the cloud (the forward did not materialise it)
+        static bool attr_rz = false;
+        if (!attr_rz) {
+            (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<64, 64, DZ_BN, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<64, 64, DZ_BN, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_rz = true;
+        }
+        if (R % TR == 0)
+            hipLaunchKernelGGL((conv_bwd_bx3_kernel<64, 64, DZ_BN, true, true, true>), dim3(G), dim3(512), lds, st, a);
+        else
+            hipLaunchKernelGGL((conv_bwd_bx3_kernel<64, 64, DZ_BN, false, true, true>), dim3(G), dim3(512), lds, st, a);
+        return;
+    }
 #else
 #define SN_CBF_IN3 conv_bwd_fused_kernel
     constexpr size_t lds = CbfShape<64, 64>::LDS_BYTES_IN3;
@@ -5107,8 +5239,11 @@ extern "C" int sn_conv_stack_backward(int B, int N, int nlayers, const int *chan
     if (!conv_stack_backward_ok(B, N, nlayers, channels))
         return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_stack_backward: shape not supported (use the per-layer entries)");
     SN_REQUIRE(x && W && z && coef && gsel && argsel && kcoef_top && acc && scratch && dW && dgamma && dbeta && dbias, "null pointer");
-    for (int l = 0; l < nlayers; ++l) SN_REQUIRE(W[l] && z[l] && coef[l] && dW[l], "null pointer");
+    for (int l = 0; l < nlayers; ++l) SN_REQUIRE(W[l] && (z[l] || l == 0) && coef[l] && dW[l], "null pointer");
     for (int l = 0; l + 1 < nlayers; ++l) SN_REQUIRE(dgamma[l] && dbeta[l] && dbias[l], "null pointer");
+#if !SN_BF16X3
+    SN_REQUIRE(z[0], "z[0] == NULL needs the split-bf16 build");
+#endif
     hipStream_t st = (hipStream_t)stream;
     const int R = B * N, G = conv_bwd_fused_groups(R);
     const int *ch = channels;
@@ -5135,7 +5270,7 @@ extern "C" int sn_conv_stack_backward(int B, int N, int nlayers, const int *chan
                                   top ? gsel : nullptr, top ? argsel : nullptr, N, W[L], z[L - 1], coef[L - 1], dy[L - 1], nullptr,
                                   part[L], st, &fx);
         } else {
-            launch_conv_bwd_in3(R, dy[1], z[1], nullptr, W[1], z[0], coef[0], stats0, part[1], x, st, &fx);
+            launch_conv_bwd_in3(R, dy[1], z[1], nullptr, W[1], z[0], coef[0], stats0, part[1], x, st, &fx, W[0], bias0);
         }
     }
     MultiRed mr{};

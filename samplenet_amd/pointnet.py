@@ -163,6 +163,10 @@ def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_p
         acc = torch.zeros(nacc, device=x_bnc.device, dtype=torch.int64)  # persistent: every call leaves it zero
         net._fx_acc = acc
     zs = [_empty((R, L.Co), x_bnc) for L in convs]
+    if Z1_FREE and lib.sn_conv_stack_z1_free_supported(B, N, n, chans):
+        # the xyz layer's activation tensor is never written: conv2's forward and backward rebuild it from the cloud (same
+        # expression, bit for bit); the per-layer backward materialises it on demand (_z1)
+        zs[0] = None
     cs = [_empty((4, L.Co), x_bnc) for L in convs]
     Cn = convs[-1].Co
     nblk = lib.sn_linear_stats_blocks(R)
@@ -386,6 +390,7 @@ def _out(sink, name, like):
 FX_STATS = True
 IN3_CLOSED_FORM = True
 FUSE_POOL = True
+Z1_FREE = True  # one-call conv stack: the xyz layer's activation tensor is not materialised (rebuilt from the cloud where needed)
 FC_CHAIN = True  # the FC head's hidden layers as one launch with in-kernel hand-offs (sn_fc_chain_forward)
 POOL_IN_CHAIN = True  # ... with the last conv BatchNorm + max-pool pick as its first stage (sn_fc_chain_forward_pool)
 
@@ -588,6 +593,13 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
     grads = {}
     grad_y = grad_y.contiguous()
     zf, cf, zc, cc = saved["zf"], saved["cf"], saved["zc"], saved["cc"]
+
+    def _z1():
+        # the xyz layer's pre-BatchNorm output for the per-layer backward when the forward did not keep it (Z1_FREE)
+        if zc[0] is None:
+            zc[0] = _linear_fwd(R, convs[0], saved["x"].view(R, 3), None, False)[0]
+        return zc[0]
+
     # eval-mode forward (running statistics): every BatchNorm backward is dZ = scale * dY -- the kernels take "rows < 0" for
     # that (no batch-statistics terms); the fixed-point / closed-form fast paths assume batch statistics and are skipped
     fixed = not saved.get("training", True)
@@ -652,7 +664,7 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
             stats = _empty((in3_floats,), L.W)
             part = _empty((lib.sn_linear_wgrad_splits(R, L.Ci, L.Co, 0) * L.Co * L.Ci,), L.W)
             kc = _empty((3, L.Ci), L.W)
-            check(lib.sn_layer_backward_in3(R, L.Ci, L.Co, ptr(dy), ptr(zc[1]), ptr(kcoef), ptr(L.W), ptr(zc[0]), ptr(cc[0]),
+            check(lib.sn_layer_backward_in3(R, L.Ci, L.Co, ptr(dy), ptr(zc[1]), ptr(kcoef), ptr(L.W), ptr(_z1()), ptr(cc[0]),
                                             ptr(stats), ptr(part), ptr(dW), ptr(dg), ptr(dbt), ptr(dbs), ptr(kc),
                                             ptr(saved["x"]), ptr(Lp.W), ptr(Lp.b), ptr(dW0), _st(L.W)), "sn_layer_backward_in3")
             grads[names_c[1] + ".weight"], grads[names_c[0] + ".weight"] = dW, dW0
@@ -660,13 +672,13 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
             break
         mode = DZ_POOL if i == 4 else DZ_BN
         gs, ag = (gsel, saved["argsel"]) if i == 4 else (None, None)
-        dW, _, dy, dg, dbt, dbs, kc = _layer_bwd(R, L, mode, dy, zc[i], kcoef, gs, ag, N, zc[i - 1], cc[i - 1], convs[i - 1],
+        dW, _, dy, dg, dbt, dbs, kc = _layer_bwd(R, L, mode, dy, zc[i], kcoef, gs, ag, N, zc[i - 1] if i > 1 else _z1(), cc[i - 1], convs[i - 1],
                                                  sink, names_c[i], bn_c[i - 1], names_c[i - 1], False, bn_rows)
         grads[names_c[i] + ".weight"] = dW
         grads[bn_c[i - 1] + ".weight"], grads[bn_c[i - 1] + ".bias"], grads[names_c[i - 1] + ".bias"] = dg, dbt, dbs
         kcoef = kc
     else:
-        dW, _ = _wgrad(R, convs[0], DZ_BN, dy, zc[0], kcoef, None, None, N, saved["x"].view(R, 3), None, False, sink, names_c[0])
+        dW, _ = _wgrad(R, convs[0], DZ_BN, dy, _z1(), kcoef, None, None, N, saved["x"].view(R, 3), None, False, sink, names_c[0])
         grads[names_c[0] + ".weight"] = dW
     return grads
 

@@ -280,10 +280,14 @@ def test_fixed_point_statistics_chain(B, N):
     finally:
         pointnet.FX_STATS = old
     assert not hasattr(net_b, "_fx_acc")
+    # (the one-call stack does not materialise the xyz layer's activation where sn_conv_stack_z1_free_supported: Z1_FREE)
+    assert (sa["zc"][0] is None) == (B * N >= 64 * 44)
     for l in range(5):
-        assert torch.equal(sa["zc"][l], sc["zc"][l]) and torch.equal(sa["cc"][l], sc["cc"][l]), l  # run-to-run
+        assert torch.equal(sa["cc"][l], sc["cc"][l]), l  # run-to-run
         assert torch.allclose(sa["cc"][l], sb["cc"][l], rtol=2e-6, atol=1e-7), l
-        assert _rel(sa["zc"][l], sb["zc"][l]) <= 1e-5, l
+        if l > 0 or sa["zc"][0] is not None:
+            assert torch.equal(sa["zc"][l], sc["zc"][l]), l
+            assert _rel(sa["zc"][l], sb["zc"][l]) <= 1e-5, l
     assert torch.equal(ya, yc) and torch.equal(sa["argsel"], sc["argsel"])
     assert float((sa["argsel"] == sb["argsel"]).float().mean()) >= 0.995
     assert _rel(sa["pooled"], sb["pooled"]) <= 1e-5 and _rel(ya, yb) <= 1e-4
@@ -299,6 +303,49 @@ def test_fixed_point_statistics_chain(B, N):
     finally:
         pointnet.FX_STATS = keep
     assert torch.equal(s2["zc"][4], sa["zc"][4]) and torch.equal(s2["cc"][4][:2], sa["cc"][4][:2])
+
+
+@pytest.mark.parametrize("B,N", [(32, 1024), (5, 320), (3, 330)])
+def test_first_activation_rebuilt_from_the_cloud(B, N):
+    """Z1_FREE: the xyz layer runs as a statistics-only pass and conv2's forward / backward rebuild its activation from the
+    cloud with the same expression -- every output, every BatchNorm buffer and every gradient is bit-identical to the run that
+    writes and re-reads the 8 MB tensor; the per-layer backward (which needs the tensor) materialises it on demand."""
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(B + N)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    with torch.no_grad():
+        net_a.bn1.weight[::4] *= -1.0
+        net_a.bn1.bias.add_(0.1 * torch.randn_like(net_a.bn1.bias))
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    x = ((torch.rand(B, N, 3, device="cuda") - 0.5) * torch.tensor([1.0, 0.6, 1.4], device="cuda") + 0.05).contiguous()
+    g = torch.randn(B, 3, 64, device="cuda")
+    old, old_fx = pointnet.Z1_FREE, pointnet.FX_STATS
+    try:
+        pointnet.Z1_FREE = True
+        ya = net_a._features(x.permute(0, 2, 1), x)
+        (ya * g).sum().backward()
+        yc = net_c._features(x.permute(0, 2, 1), x)
+        pointnet.FX_STATS = False  # backward through the per-layer entries: needs Z1
+        (yc * g).sum().backward()
+        pointnet.FX_STATS = True
+        pointnet.Z1_FREE = False
+        yb = net_b._features(x.permute(0, 2, 1), x)
+        (yb * g).sum().backward()
+    finally:
+        pointnet.Z1_FREE, pointnet.FX_STATS = old, old_fx
+    assert torch.equal(ya, yb) and torch.equal(yc, yb)
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), n
+    gc = dict(net_c.named_parameters())
+    gmax = max(float(p.grad.norm()) for n, p in net_b.named_parameters() if p.grad is not None)
+    for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        if n.startswith("project"):
+            continue
+        assert torch.equal(pa.grad, pb.grad), n
+        # the per-layer backward of the third run rebuilt the tensor with the xyz kernel: same operands as the stack's kernels
+        floor = 2e-5 if (n.endswith(".bias") and n.startswith(("conv", "fc1", "fc2", "fc3"))) else 1e-6
+        assert float((gc[n].grad - pb.grad).norm()) <= 1e-4 * float(pb.grad.norm()) + floor * gmax, n
 
 
 @pytest.mark.parametrize("scale", [3.0e3, 2.0e5, 1.0e-4])
@@ -334,7 +381,10 @@ def test_fixed_point_statistics_range(scale):
     gmax = max(float(v.norm()) for v in gb.values())
     for n, p in net_a.named_parameters():
         if not n.startswith("project"):
-            assert float((p.grad - gb[n]).norm()) <= 1e-4 * float(gb[n].norm()) + 1e-6 * gmax, n
+            # (a bias in front of a BatchNorm has a zero gradient: what both paths return is the rounding noise of a
+            #  cancellation, a few 1e-6 of the largest gradient at these scales)
+            floor = 2e-5 if (n.endswith(".bias") and n.startswith(("conv", "fc1", "fc2", "fc3"))) else 1e-6
+            assert float((p.grad - gb[n]).norm()) <= 1e-4 * float(gb[n].norm()) + floor * gmax, n
     # poison: a non-finite coordinate -> NaN output, accumulators clean for the next step
     xbad = x.clone()
     xbad[0, 0, 0] = float("inf")

@@ -44,6 +44,7 @@ def main():
         o64 = torch_layers(n64, x.double().permute(0, 2, 1))
         ogpu = torch_layers(ngpu, x.permute(0, 2, 1))
         ocpu = torch_layers(ncpu, x.cpu().permute(0, 2, 1))
+        pointnet.Z1_FREE = False  # (this tool looks at every layer's output)
         y, saved = pointnet.forward_impl(net, x.contiguous(), True)
     hip = [z.view(B, N, -1).permute(0, 2, 1) for z in saved["zc"]] + list(saved["zf"]) + [y]
     names = ["conv1", "conv2", "conv3", "conv4", "conv5", "fc1", "fc2", "fc3", "fc4"]
