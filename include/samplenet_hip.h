@@ -323,7 +323,9 @@ int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, c
  * Arrays of nlayers device pointers: W (C_{l+1},C_l), bias, gamma, beta, running_mean, running_var, num_batches_tracked,
  * z (B*N,C_{l+1}) pre-BN outputs, coef (4,C_{l+1}); eps / momentum: host arrays.  acc: sn_conv_stack_acc_elems(nlayers) long long of persistent
  * device scratch, zero before the first call (every call leaves it zero).  pool_val / pool_idx: (B*N/64)*2*Cn scratch.
- * pooled = argsel = zsel = NULL: stop after the last GEMM; sn_fc_chain_forward_pool must follow (it finishes the pool). */
+ * pooled = argsel = zsel = NULL: stop after the last GEMM; sn_fc_chain_forward_pool must follow (it finishes the pool).  The last
+ * layer then leaves, instead of block partials, (B, 2, Cn) 64-bit keys in pool_val -- per cloud and channel (max Z, first row)
+ * and (min Z, first row), combined by atomicMax -- which sn_fc_chain_forward_pool decodes. */
 int sn_conv_stack_forward_supported(int B, int N, int nlayers, const int *channels);
 long long sn_conv_stack_acc_elems(int nlayers);
 /* 1: z[0] may be NULL in sn_conv_stack_forward_bn / sn_conv_stack_backward for this shape -- the xyz layer then runs as a
@@ -391,10 +393,10 @@ int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0, const flo
 /* sn_fc_chain_forward with the tail of the conv stack in front (samplenet.py:90-101: bn5 / relu / max over the points /
  * fc1..fc3): call sn_conv_stack_forward_bn with pooled = argsel = zsel = NULL -- it then stops after its last GEMM, leaving
  * the last layer's fixed-point sums in acc and the block maxima / minima in pool_val / pool_idx -- and this entry right after:
- * its first stage finalises that BatchNorm (gamma5 .. coef5, clearing acc), picks the max-pool (pooled / argsel / zsel as
- * sn_pool_forward) and hands pooled to the FC layers through the same in-kernel exchange.  B <= 32 clouds, N <= 1024
- * (N % 64 == 0), conv stack of nconv layers ending in C0 = 128 channels, H = 256, nl = 3 (query _supported).  Same results as
- * the two separate calls. */
+ * its first stage finalises that BatchNorm (gamma5 .. coef5, clearing acc) and decodes the max-pool from the keys (pooled /
+ * argsel / zsel as sn_pool_forward) in EVERY workgroup -- no exchange in front of fc1.  B <= 32 clouds, N % 64 == 0, conv stack
+ * of nconv layers ending in C0 = 128 channels, H = 256, nl = 3 (query _supported).  Same results as the two separate calls.
+ * pool_val: the keys; pool_idx: unused. */
 int sn_fc_chain_forward_pool_supported(int B, int N, int C0, int H, int nl);
 int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc, const float *pool_val, const int *pool_idx,
                              const float *gamma5, const float *beta5, float *running_mean5, float *running_var5,

@@ -952,7 +952,25 @@ struct FwdArgs {
     // (W3[c] . x_r) + b3[c], the xyz layer's own expression (conv_in3_fwd_kernel), 3 FMAs per element instead of a 4-byte load:
     // the stack never writes its first activation tensor.  x3 (R, 3), w3 (Ci, 3), b3 (Ci) or NULL.
     const float *x3, *w3, *b3;
+    // last conv layer in front of the FC chain's pool stage: instead of block partials (pool_val / pool_idx) the epilogue
+    // publishes, per cloud and channel, the maximum and the minimum of Z with its first row as 64-bit keys combined by atomicMax
+    // (order-independent; pool_keys [B][2][Co], zero before the launch): the consumer picks by the sign of the BatchNorm scale.
+    unsigned long long *pool_keys;
 };
+// (value, row) -> key: larger value first, then the LOWER row; value order via the usual sign flip of the float bits
+__device__ __forceinline__ unsigned long long pool_key(float v, int row)
+{
+    const unsigned u = __float_as_uint(v);
+    const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)o << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)row);
+}
+__device__ __forceinline__ void pool_key_decode(unsigned long long k, float &v, int &row)
+{
+    const unsigned o = (unsigned)(k >> 32);
+    const unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    v = __uint_as_float(u);
+    row = (int)(0xFFFFFFFFu - (unsigned)k);
+}
 
 // KT > 0 (statistics-chain path): the input width, known at compile time -- both operands are fetched whole, up front
 // PLANES: FwdArgs::wplanes holds the weights pre-split (statistics-chain path)
@@ -1120,7 +1138,7 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
     float s0[T::TN], s1[T::TN];
     float pmax[T::TN], pmin[T::TN];
     int imax[T::TN], imin[T::TN];
-    const bool pool = FULL && g.pool_val != nullptr;
+    const bool pool = FULL && (g.pool_val != nullptr || g.pool_keys != nullptr);
     // FULL tiles leave as 16-byte stores: each 32 x 32 fragment is transposed through a per-wave LDS scratch (a dword
     // store per fragment element costs ~58 issue cycles per wave-instruction: 16 of them per fragment were issue-bound)
     float *Ts = lds + 2 * T::WR * T::BN + wave * (32 * 36);  // behind column_reduce2's area; staging buffers are dead
@@ -1170,7 +1188,24 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
         float *st = g.stats + (size_t)blockIdx.x * 2 * Co;
         column_reduce2<T>(s0, s1, lds, st, st + Co, col0, Co);
     }
-    if (FULL && pool) {
+    if (FULL && pool && g.pool_keys) {
+        // per cloud and column: (maximum, first row) and (minimum, first row) of this wave's 32 rows straight into the cloud's
+        // keys (the tile lies inside one cloud: npts % 64 == 0)
+        const int cloud = row0 / g.pool_npts, cloud0 = cloud * g.pool_npts;
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) {
+            const float om = __shfl_xor(pmax[j], 32), on = __shfl_xor(pmin[j], 32);
+            const int oim = __shfl_xor(imax[j], 32), oin = __shfl_xor(imin[j], 32);
+            if (om > pmax[j] || (om == pmax[j] && oim < imax[j])) pmax[j] = om, imax[j] = oim;
+            if (on < pmin[j] || (on == pmin[j] && oin < imin[j])) pmin[j] = on, imin[j] = oin;
+            if (lane < 32) {
+                const int c = col0 + (wc * T::TN + j) * 32 + lane;
+                unsigned long long *kk = g.pool_keys + ((size_t)cloud * 2) * Co + c;
+                atomicMax(kk, pool_key(pmax[j], imax[j] - cloud0));
+                atomicMax(kk + Co, pool_key(-pmin[j], imin[j] - cloud0));
+            }
+        }
+    } else if (FULL && pool) {
         // block maximum / minimum per column with the first row that attains it: halves of a wave, then the row waves
         __syncthreads();
         float *pv = lds;                                               // [WR][2][BN]
@@ -2705,9 +2740,8 @@ struct FcChainLayer {
 struct FcChainPool {
     long long *acc;        // fixed-point statistics of the last conv layer (cleared here: this launch is their only reader)
     long long *zero_ptr;   // the accumulators the PREVIOUS kernel consumed
-    int zero_n, bpc;       // 64-row blocks per cloud (<= 16)
-    const float *pool_val;  // [R * bpc][2][C0] block maxima / minima of the pre-BN output ...
-    const int *pool_idx;    // ... and their rows
+    int zero_n;
+    const unsigned long long *keys;  // [R][2][C0] (max Z, first row) / (min Z, first row) keys left by the last conv layer
     BnFwd bn;
     float *pooled, *zsel;  // (R, C0)
     int *argsel;
@@ -2790,27 +2824,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (tid == 0) s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ---- every layer's weight slice + the first operand: all fetches issued up front, staged into LDS as they land
-    if (POOL) {
-        // ---- stage -1: BatchNorm of the last conv layer from its fixed-point sums + the max-pool pick over the cloud's
-        // 64-row blocks -> pooled (R, C0), handed to the other workgroups like a layer's activations.  Workgroup wg owns
-        // channels [16 wg, 16 wg + 16): thread -> (channel cl, clouds j and j + 16).  The block MAXIMA are fetched
-        // speculatively together with everything else (the pick needs the sign of the BatchNorm scale: negative -> the
-        // minima are fetched in a second, rare, round trip).  Every thread evaluates its channel's coefficients itself
-        // (16-fold redundant loads of the same sums: cheaper than a broadcast through LDS behind a barrier).
+    if constexpr (POOL) {
+        // ---- stage -1: BatchNorm of the last conv layer from its fixed-point sums + the max-pool pick.  The producing layer
+        // left, per cloud and channel, (max Z, first row) and (min Z, first row) as 64-bit keys (FwdArgs::pool_keys); EVERY
+        // workgroup finalises all C0 channels and decodes all R x C0 pooled features itself (32 KB of keys + 35 words of sums
+        // per channel, all requested up front together with the weight slices) -- no exchange, no seam in front of fc1.  The
+        // workgroup that owns a channel (16 per workgroup) stores its coefficients, running statistics and the pooled / argsel /
+        // zsel rows for the backward, and clears the sums after the first layer's seam (every workgroup has read them by then).
         constexpr int CP = C0T > 0 ? C0T : 128, NH = NLT > 1 ? NLT - 1 : 1;
+        static_assert(CP == 128, "pool stage: 128 pooled channels");
         const FcChainPool &P = g.P;
-        const int cl = tid & 15, c = wg * 16 + cl, j = tid >> 4, bpc = P.bpc;
-        const FxRaw2 fx = fx_load2(P.acc, c);
-        float pv[2][16];
-        int pi[2][16];
+        const int pc = tid & 127;                    // channel whose coefficients this thread computes (two threads per channel)
+        const FxRaw2 fx = fx_load2(P.acc, pc);
+        const BnFwdIn in{P.bn.gamma[pc], P.bn.beta[pc], P.bn.running_mean[pc], P.bn.running_var[pc]};  // (host: never NULL here)
+        // keys: thread -> cloud kb = tid >> 3, channels kc0 = 16 (tid & 7) .. + 15, both selections
+        const int kb = tid >> 3, kc0 = (tid & 7) * 16;
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 kmx[8], kmn[8];
+        {
+            const unsigned long long *kp = P.keys + ((size_t)min(kb, R - 1) * 2) * CP + kc0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const size_t o = ((size_t)(min(j + 16 * u, R - 1) * bpc + min(q, bpc - 1)) * 2) * CP + c;
-                pv[u][q] = P.pool_val[o], pi[u][q] = P.pool_idx[o];
-            }
-        const BnFwdIn in{P.bn.gamma[c], P.bn.beta[c], P.bn.running_mean[c], P.bn.running_var[c]};  // (host: never NULL here)
+            for (int q = 0; q < 8; ++q) kmx[q] = *reinterpret_cast<const u64x2 *>(kp + 2 * q), kmn[q] = *reinterpret_cast<const u64x2 *>(kp + CP + 2 * q);
+        }
         constexpr int q4 = CP / 4, rpp = 256 / q4, npass = 32 / rpp;
         const int c4 = (tid % q4) * 4, r0 = tid / q4;
         const int hc4 = (tid % 64) * 4, hr0 = tid / 64;
@@ -2821,56 +2856,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int l = 1; l < NLT; ++l)
 #pragma unroll
             for (int q = 0; q < 8; ++q) wh[l - 1][q] = *reinterpret_cast<const f32x4v *>(g.L[l].W + (size_t)(col0 + hr0 + q * 4) * H + hc4);
-        // every fetch of the kernel is in flight now; nothing below may be hoisted between them (the compiler otherwise waits
-        // for the sums before it issues the rest: two round trips)
+        // every fetch of the kernel is in flight now; nothing below may be hoisted between them
         asm volatile("" ::: "memory");
         double s, ss;
         fx_total2<kFxShiftFwd>(fx, s, ss);
-        const bool writer = j == 0;
-        const float2 cf = bn_finalize_channel(P.bn, CP, c, s, ss, in, writer);
+        const bool owner = tid < 128 && (pc >> 4) == wg;
+        const float2 cf = bn_finalize_channel(P.bn, CP, pc, s, ss, in, owner);
         if (wg == 0 && tid == 0 && P.bn.num_batches_tracked) *P.bn.num_batches_tracked += 1;
-        const float sc = cf.x, sh = cf.y;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int b = j + 16 * u;
-            float best = -INFINITY;
-            int arg = 0x7fffffff;
-            if (sc >= 0.f) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float v = pv[u][q];
-                    const int i = pi[u][q];
-                    if (q < bpc && (v > best || (v == best && i < arg))) best = v, arg = i;
-                }
-            } else {
-                best = INFINITY;
-                for (int q = 0; q < bpc; ++q) {
-                    const size_t o = ((size_t)(min(b, R - 1) * bpc + q) * 2 + 1) * CP + c;
-                    const float v = P.pool_val[o];
-                    const int i = P.pool_idx[o];
-                    if (v < best || (v == best && i < arg)) best = v, arg = i;
-                }
-            }
-            const float pooled = relu_np(fmaf(best, sc, sh));
-            Ta[b * 16 + cl] = b < R ? pooled : 0.f;  // [32 clouds][16 channels] tile of this workgroup
-            if (b < R) {
-                P.pooled[(size_t)b * CP + c] = pooled;
-                P.argsel[(size_t)b * CP + c] = arg;
-                P.zsel[(size_t)b * CP + c] = best;
-            }
-        }
-        // the tile leaves as 16-byte write-through stores into this workgroup's OWN 2 KB of the exchange slab (tile-major
-        // [wg][32][16]: no 128-byte line has two writers.  Published as 4-byte stores straight into pooled (R, 128), where two
-        // workgroups share every line, readers intermittently saw stale halves.)  Slab 1: first reused at layer 1's seam,
-        // which every workgroup reaches after it has gathered this.
+        float *cfs = Ta;  // [2][128] scale | shift (the tile scratch is idle until layer 0's epilogue)
+        if (tid < 128) cfs[pc] = cf.x, cfs[CP + pc] = cf.y;
         lds_barrier();
-        float *xp = g.xbuf + (size_t)32 * H;
-        if (tid < 128) {
-            const float4 v = *reinterpret_cast<const float4 *>(Ta + tid * 4);
-            f32x4v vv = {v.x, v.y, v.z, v.w};
-            store_sc1_b128(xp + (size_t)wg * 512 + tid * 4, vv);
+        {
+            float pooled[16], zs[16];
+            int ar[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int c = kc0 + 2 * q + t;
+                    const float sc = cfs[c], sh = cfs[CP + c];
+                    float v;
+                    int row;
+                    if (sc >= 0.f) {
+                        pool_key_decode(kmx[q][t], v, row);
+                    } else {
+                        pool_key_decode(kmn[q][t], v, row);
+                        v = -v;
+                    }
+                    zs[2 * q + t] = v, ar[2 * q + t] = row;
+                    pooled[2 * q + t] = kb < R ? relu_np(fmaf(v, sc, sh)) : 0.f;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4 *>(As + kb * LDA + kc0 + 4 * q) = make_float4(pooled[4 * q], pooled[4 * q + 1], pooled[4 * q + 2], pooled[4 * q + 3]);
+            if ((tid & 7) == wg && kb < R) {  // this workgroup's 16 channels of cloud kb: the rows the backward reads
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const size_t o = (size_t)kb * CP + kc0 + 4 * q;
+                    *reinterpret_cast<float4 *>(P.pooled + o) = make_float4(pooled[4 * q], pooled[4 * q + 1], pooled[4 * q + 2], pooled[4 * q + 3]);
+                    *reinterpret_cast<float4 *>(P.zsel + o) = make_float4(zs[4 * q], zs[4 * q + 1], zs[4 * q + 2], zs[4 * q + 3]);
+                    *reinterpret_cast<int4 *>(P.argsel + o) = make_int4(ar[4 * q], ar[4 * q + 1], ar[4 * q + 2], ar[4 * q + 3]);
+                }
+            }
         }
-        // the weight slices (the bulk of the bytes, last to arrive) go to LDS while the tile drains
 #pragma unroll
         for (int q = 0; q < npass; ++q) *reinterpret_cast<f32x4v *>(W0s + (r0 + q * rpp) * (C0 + 4) + c4) = wv[q];
 #pragma unroll
@@ -2878,33 +2906,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 *reinterpret_cast<f32x4v *>(Whs + (size_t)(l - 1) * 32 * (H + 4) + (hr0 + q * 4) * (H + 4) + hc4) = wh[l - 1][q];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();  // every wave's loads of the sums have returned: they can be cleared for the next step
-        if (writer)
-#pragma unroll
-            for (int q = 0; q < kFxSlots * 2 + 2; ++q) P.acc[q * kFxRow + c] = 0;  // lo rows and the two hi rows (the poison
-                                                                                 // word: first kernel of the next step)
         fx_clear_share(P.zero_ptr, P.zero_n, wg, nwg, tid, 256);
-        if (tid == 0) {
-            fc_chain_seam(g.sync, 8, s_epoch, nwg, 9u);
-            if (wg == 0) __hip_atomic_store(g.sync, s_epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        lds_barrier();
-        {
-            f32x4v r[npass];
-#pragma unroll
-            for (int q = 0; q < npass; ++q) {
-                const float *p = xp + (size_t)(c4 >> 4) * 512 + (r0 + q * rpp) * 16 + (c4 & 15);
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[q]) : "v"(p) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int q = 0; q < npass; ++q) {
-                const int rr = r0 + q * rpp;
-                *reinterpret_cast<float4 *>(As + rr * LDA + c4) = make_float4(r[q].x, r[q].y, r[q].z, r[q].w);  // (rows >= R: zeros)
-            }
-        }
-    } else if (C0T > 0 && NLT > 0) {
+    } else if constexpr (C0T > 0 && NLT > 0) {
         // compile-time shape: every load of the kernel's operands is issued before the first LDS write (no loop-carried
         // load -> store dependencies, no branches around loads), layer 0's operands first
         constexpr int q4 = (C0T > 0 ? C0T : 128) / 4, rpp = 256 / q4, npass = 32 / rpp;
@@ -3038,9 +3041,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         lds_barrier();
         if (tid == 0) {
             fc_chain_seam(g.sync, 1 + l, epoch, nwg, 1u + (unsigned)l);
-            if (!POOL && l == 0 && wg == 0) __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l == 0 && wg == 0) __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lds_barrier();
+        if (POOL && l == 0 && tid < 16) {  // every workgroup is past the pool stage: this one's 16 channels of the sums can go
+            const int c = wg * 16 + tid;
+#pragma unroll
+            for (int q = 0; q < kFxSlots * 2 + 2; ++q) g.P.acc[q * kFxRow + c] = 0;  // lo rows and the two hi rows (the poison
+        }                                                                           // word: first kernel of the next step)
         // gather the whole 32 x H activation (write-through data: sc1 loads read it from L2 / memory, never from a stale L1 line)
         {
             const int hq4 = H / 4;
@@ -3594,6 +3602,8 @@ struct WSplitJob {
     int elems[4];  // Co * Ci
     int first[5];  // first 1024-element block of layer l in the job's block numbering; first[n] = number of blocks
     int n;
+    unsigned long long *zero_keys;  // the last layer's pool keys (FwdArgs::pool_keys), cleared here for this call
+    int nkeys;
 };
 __device__ __forceinline__ void wsplit_block(const WSplitJob &job, int blk, int tid)
 {
@@ -3625,6 +3635,10 @@ __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const 
                                                            long long *__restrict__ clear_flags = nullptr, WSplitJob job = WSplitJob{})
 {
     if (job.n > 0 && blockIdx.y == 0 && (int)blockIdx.x < job.first[job.n]) wsplit_block(job, blockIdx.x, threadIdx.x);
+    if (job.zero_keys && blockIdx.y == 0) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < job.nkeys) job.zero_keys[i] = 0ull;
+    }
     // (statistics chain: the poison word of the LAST layer's accumulators, read by every workgroup of the previous
     // step's closing kernel, is reset here, by the first kernel of the next step)
     if (clear_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) clear_flags[0] = 0;
@@ -4465,7 +4479,7 @@ extern "C" int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0
 // 128 channels, FC head 128 -> 256 x 3.  gamma5 .. coef5: the last conv layer's BatchNorm as in sn_conv_stack_forward_bn.
 extern "C" int sn_fc_chain_forward_pool_supported(int B, int N, int C0, int H, int nl)
 {
-    return B >= 1 && B <= 32 && N >= 64 && N <= 1024 && N % 64 == 0 && C0 == 128 && H == 256 && nl == 3;
+    return B >= 1 && B <= 32 && N >= 64 && N % 64 == 0 && C0 == 128 && H == 256 && nl == 3;
 }
 
 extern "C" int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc, const float *pool_val, const int *pool_idx,
@@ -4485,7 +4499,8 @@ extern "C" int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc,
     FcChainArgs g{};
     g.a0 = pooled, g.R = B, g.C0 = C0, g.H = H, g.nl = nl, g.xbuf = xbuf, g.sync = sync;
     g.P.acc = acc + (size_t)(nconv - 1) * kFxLayer, g.P.zero_ptr = acc + (size_t)(nconv - 2) * kFxLayer, g.P.zero_n = kFxLayer;
-    g.P.bpc = N / 64, g.P.pool_val = pool_val, g.P.pool_idx = pool_idx;
+    g.P.keys = reinterpret_cast<const unsigned long long *>(pool_val);  // (B, 2, 128) keys: see sn_conv_stack_forward_bn, pooled == NULL
+    (void)pool_idx;
     g.P.bn = BnFwd{gamma5, beta5, running_mean5, running_var5, num_batches_tracked5, coef5, eps5, momentum5, (long long)B * N};
     g.P.pooled = pooled, g.P.argsel = argsel, g.P.zsel = zsel;
     for (int l = 0; l < nl; ++l) {
@@ -4657,6 +4672,10 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         if (nb > R / 64) job.n = 0;  // (cannot happen for R > 64 * 44; keep the planes off then)
     }
 #endif
+    if (!pooled) {  // the last layer publishes pool keys (B, 2, Cn) into pool_val: cleared by this call's first kernel
+        job.zero_keys = reinterpret_cast<unsigned long long *>(pool_val), job.nkeys = B * 2 * channels[nlayers];
+        SN_REQUIRE((long long)job.nkeys <= (long long)(R / 64) * 256, "too few rows to clear the pool keys");
+    }
     hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3(R / 64, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
                        bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * kFxLayer + kFxPoison, job);
     using T = TileBig;
@@ -4668,7 +4687,11 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         g.bias = bias ? bias[l] : nullptr, g.z = z[l], g.stats = nullptr;
         g.acc_in = acc + (size_t)(l - 1) * kFxLayer, g.bn_prev = bn_of(l - 1), g.acc_out = acc + (size_t)l * kFxLayer;
         if (l >= 2) g.zero_ptr = acc + (size_t)(l - 2) * kFxLayer, g.zero_n = kFxLayer;
-        if (l == nlayers - 1) g.pool_val = pool_val, g.pool_idx = pool_idx, g.pool_npts = N;
+        if (l == nlayers - 1) {
+            g.pool_npts = N;
+            if (pooled) g.pool_val = pool_val, g.pool_idx = pool_idx;
+            else g.pool_keys = reinterpret_cast<unsigned long long *>(pool_val);  // (the pool stage of the FC chain follows)
+        }
         g.wplanes = job.n > 0 ? planes[l] : nullptr;
         const bool pl = g.wplanes != nullptr;
         if (l == 1 && z1free) {

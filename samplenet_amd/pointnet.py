@@ -170,7 +170,8 @@ def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_p
     cs = [_empty((4, L.Co), x_bnc) for L in convs]
     Cn = convs[-1].Co
     nblk = lib.sn_linear_stats_blocks(R)
-    pool_val = _empty((nblk, 2, Cn), x_bnc)
+    # (defer_pool: the last layer leaves (B, 2, Cn) 64-bit keys here instead of the block partials)
+    pool_val = _empty((max(nblk, 2 * B) if defer_pool else nblk, 2, Cn), x_bnc)
     pool_idx = _empty((nblk, 2, Cn), x_bnc, torch.int32)
     VP = ctypes.c_void_p * n
 

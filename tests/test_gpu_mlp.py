@@ -632,10 +632,11 @@ def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
 
 @pytest.mark.parametrize("B,N", [(32, 1024), (32, 256), (5, 1024), (2, 64), (17, 704)])
 def test_pool_stage_of_the_fc_chain_equals_the_separate_launch(B, N):
-    """sn_fc_chain_forward_pool (last conv BatchNorm from the fixed-point sums + max-pool pick as the first stage of the FC
-    chain) against sn_conv_stack_forward_bn's own finalisation launch + sn_fc_chain_forward: bit for bit -- pooled features,
-    selected rows, pre-BN values, bn5 coefficients, every FC layer, running statistics -- with negative BatchNorm scales on
-    some channels (those pick the block MINIMA), repeatedly, and the statistics accumulators are left zero."""
+    """sn_fc_chain_forward_pool (last conv BatchNorm from the fixed-point sums + max-pool decoded from the per-cloud (value,
+    row) keys that conv5's epilogue combined by atomicMax, as the first stage of the FC chain) against the block-partial path
+    (sn_conv_stack_forward_bn's own finalisation launch + sn_fc_chain_forward): bit for bit -- pooled features, selected rows
+    (ties: the first row), pre-BN values, bn5 coefficients, every FC layer, running statistics -- with negative BatchNorm
+    scales on some channels (those pick the MINIMA) and a zero scale, repeatedly; the statistics accumulators are left zero."""
     from samplenet_amd import SampleNet, pointnet
 
     torch.manual_seed(B * 7 + N)
@@ -663,7 +664,7 @@ def test_pool_stage_of_the_fc_chain_equals_the_separate_launch(B, N):
             assert _acc_sums_zero(net_a._fx_acc) and _acc_sums_zero(net_b._fx_acc)
     finally:
         pointnet.POOL_IN_CHAIN = old
-    assert int(net_a._fc_sync[15]) == 0 and int(net_a._fc_sync[0]) == 3 and int(net_a._fc_sync[8]) == 3 * 8
+    assert int(net_a._fc_sync[15]) == 0 and int(net_a._fc_sync[0]) == 3
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         # (bn5's running statistics: same expression compiled into two kernels -- the momentum blend contracts into a
         #  different fma; one ulp)
