@@ -325,7 +325,8 @@ int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, c
  * device scratch, zero before the first call (every call leaves it zero).  pool_val / pool_idx: (B*N/64)*2*Cn scratch.
  * pooled = argsel = zsel = NULL: stop after the last GEMM; sn_fc_chain_forward_pool must follow (it finishes the pool).  The last
  * layer then leaves, instead of block partials, (B, 2, Cn) 64-bit keys in pool_val -- per cloud and channel (max Z, first row)
- * and (min Z, first row), combined by atomicMax -- which sn_fc_chain_forward_pool decodes. */
+ * and (min Z, first row), combined by atomicMax -- which sn_fc_chain_forward_pool decodes; pool_val must then hold at least
+ * 4 * B * Cn floats (16 bytes per cloud and channel: more than the block partials only when N < 128). */
 int sn_conv_stack_forward_supported(int B, int N, int nlayers, const int *channels);
 long long sn_conv_stack_acc_elems(int nlayers);
 /* 1: z[0] may be NULL in sn_conv_stack_forward_bn / sn_conv_stack_backward for this shape -- the xyz layer then runs as a
