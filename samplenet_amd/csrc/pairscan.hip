@@ -25,6 +25,7 @@
 // in LDS; column minima are then produced by a second launch with the roles swapped.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "sn_common.h"
 
@@ -35,6 +36,7 @@
 namespace sn {
 
 constexpr int kListCap = 192;  // per-wave candidate list entries (3 per lane)
+constexpr int kListPitch = kListCap + kWave;  // + one scrap entry per lane / overrun of the last round (branch-free compaction)
 
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, float py, float pz)
 {
@@ -124,6 +126,11 @@ __device__ __forceinline__ float dpp_f(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false));
 }
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppRowMirror = 0x140;
+// value of the lane below within the row of 16 (lane 0 of a row reads 0): one step of a sequential scan
+__device__ __forceinline__ float dpp_shr1(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+}
 
 // Threshold tau = max over the 2^LOGG lane groups (contiguous groups of 64 >> LOGG lanes) of the group minimum of x.
 // x >= +0 (or +inf), so the cross-row step can run on the SALU as unsigned integer min/max of the bit patterns.
@@ -149,10 +156,14 @@ __device__ __forceinline__ sn_u64 rank_to_lanes(sn_u64 mine, int cnt, int lane)
 {
     const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
     int rank = 0;
-    for (int u = 0; u < cnt; ++u) {
-        const sn_u64 ku = ((sn_u64)(unsigned)__builtin_amdgcn_readlane((int)hi, u) << 32) |
-                          (unsigned)__builtin_amdgcn_readlane((int)lo, u);
-        rank += (ku < mine) ? 1 : 0;
+    // four candidates per trip: lanes >= cnt hold kKeyInf (never smaller than anything), and cnt <= 64 keeps u + 3 <= 63
+    for (int u = 0; u < cnt; u += 4) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const sn_u64 ku = ((sn_u64)(unsigned)__builtin_amdgcn_readlane((int)hi, u + v) << 32) |
+                              (unsigned)__builtin_amdgcn_readlane((int)lo, u + v);
+            rank += (ku < mine) ? 1 : 0;
+        }
     }
     const int dst = (lane < cnt) ? rank : lane;  // lanes without a candidate keep to themselves (no collision)
     const unsigned plo = (unsigned)__builtin_amdgcn_ds_permute(dst << 2, (int)lo);
@@ -246,8 +257,8 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
     const int q0 = blockIdx.y * qpb;
     const int q1 = min(M, q0 + qpb);
 
-    sn_u64 *list = reinterpret_cast<sn_u64 *>(smem) + wave * kListCap;
-    sn_u64 *colmin = reinterpret_cast<sn_u64 *>(smem) + nwaves * kListCap;  // [64*PPL] when COLMIN
+    sn_u64 *list = reinterpret_cast<sn_u64 *>(smem) + wave * kListPitch;
+    sn_u64 *colmin = reinterpret_cast<sn_u64 *>(smem) + nwaves * kListPitch;  // [64*PPL] when COLMIN
 
     const float *__restrict__ Pb = a.P + (size_t)b * 3 * N;
     const float *__restrict__ Qb = a.Q + (size_t)b * 3 * M;
@@ -305,22 +316,60 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
             }
             // tau = max over the 2^LOGG lane groups of the group's minimum (2^LOGG >= K): >= K points lie at or below it
             float thr = fminf(group_minmax<LOGG>(lmin), thr_run);
-            // compact candidates (d <= thr) into the wave's LDS list
+            // compact candidates (d <= thr) into the wave's LDS list, round by round with a capacity check (a merge
+            // when the list would overflow): the general form
+            auto compact_checked = [&]() {
 #pragma unroll
-            for (int i = 0; i < PPL; ++i) {
-                const int n = c0 + i * kWave + lane;
-                const bool pred = (n < N) && (d[i] <= thr);
-                const sn_u64 mask = __ballot(pred);
-                if (mask != 0) {
-                    if (cnt + kWave > kListCap) {
-                        cnt = merge_topk(list, cnt, K, lane);
-                        if (cnt == K) thr = fminf(thr, key_dist(list[K - 1]));
+                for (int i = 0; i < PPL; ++i) {
+                    const int n = c0 + i * kWave + lane;
+                    const bool pred = (n < N) && (d[i] <= thr);
+                    const sn_u64 mask = __builtin_amdgcn_ballot_w64(pred);
+                    if (mask != 0) {
+                        if (cnt + kWave > kListCap) {
+                            cnt = merge_topk(list, cnt, K, lane);
+                            if (cnt == K) thr = fminf(thr, key_dist(list[K - 1]));
+                        }
+                        const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        if (pred) list[pos] = make_key(d[i], n);
+                        cnt += __builtin_popcountll(mask);
                     }
-                    const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (pred) list[pos] = make_key(d[i], n);
-                    cnt += __builtin_popcountll(mask);
                 }
+            };
+            if constexpr (SINGLE) {
+                // whole cloud in registers, list empty: the same rounds without a branch -- positions from a running
+                // count on the SALU, lanes without a candidate write a scrap entry behind the list.  The ~K..3K
+                // candidates of a real cloud fit the list; a round that starts within the list may run up to 64 entries
+                // past its end (the scrap entries' space), and the total tells (clouds of coincident points), in which
+                // case the checked form redoes the compaction.
+                auto compact_all = [&](auto full) {
+                    int base = 0;
+                    int lane_q = lane;  // re-materialised per query: keeps the PPL point indices out of long-lived registers
+                    asm volatile("" : "+v"(lane_q));
+#pragma unroll
+                    for (int i = 0; i < PPL; ++i) {
+                        const int n = i * kWave + lane_q;
+                        const bool pred = decltype(full)::value ? (d[i] <= thr) : ((n < N) && (d[i] <= thr));
+                        const sn_u64 mask = __builtin_amdgcn_ballot_w64(pred);
+                        const int at = base < kListCap ? base : kListCap;  // clamped only when the total overflows anyway
+                        const int pos = at + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        list[pred ? pos : kListCap + lane] = make_key(d[i], n);  // others: the lane's own scrap entry
+                        base += __builtin_popcountll(mask);
+                    }
+                    return base;
+                };
+                // (lanes past the end of a cloud hold +inf distances; they pass d <= thr only when thr itself is +inf,
+                //  so the bound check can go when every lane's every point exists)
+                const int total = (N == kWave * PPL) ? compact_all(std::true_type{}) : compact_all(std::false_type{});
+                if (total <= kListCap) {
+                    cnt = total;
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    compact_checked();
+                }
+            } else {
+                compact_checked();
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (!SINGLE) {
@@ -355,32 +404,60 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
             wmax = kq > wmax ? kq : wmax;
         }
         if (want_soft) {
-            float gx = 0.f, gy = 0.f, gz = 0.f;
-            if (lane < cnt) {
-                gx = Pb[pt_off(a.p_layout, N, nidx, 0)];
-                gy = Pb[pt_off(a.p_layout, N, nidx, 1)];
-                gz = Pb[pt_off(a.p_layout, N, nidx, 2)];
-            }
             const float s = (lane < cnt) ? -(nd / sigma) : -INFINITY;  // soft_projection.py:92-95
             const float mx = readlane_f(s, 0);  // neighbours ascend in distance: lane 0 holds the maximum of s
             const float e = (lane < cnt) ? expf(s - mx) : 0.f;
-            float den = 0.f;
-            for (int t = 0; t < K; ++t) den += readlane_f(e, t);
-            const float w = e / den;  // softmax over the K neighbours (:143)
-            if (a.weights && lane < K) a.weights[qrow * K + lane] = w;
-            if (a.proj) {
-                float ox = 0.f, oy = 0.f, oz = 0.f;
-                for (int t = 0; t < K; ++t) {  // ascending k, product then sum (:148-151)
-                    const float wt = readlane_f(w, t);
-                    ox += readlane_f(gx, t) * wt;
-                    oy += readlane_f(gy, t) * wt;
-                    oz += readlane_f(gz, t) * wt;
+            if constexpr (LOGG <= 4) {
+                // K <= 16: neighbour t sits in lane t of row 0.  Rows 0..2 (16 lanes each) take one coordinate each, and
+                // the ascending-k sums (denominator :143, weighted sum :148-151) run as sequential DPP scans inside the
+                // rows -- lane t adds its term to the running sum of lane t-1, the very order of the reference's loop --
+                // instead of K trips of v_readlane.  Steps past K-1 leave lane K-1 unchanged.
+                constexpr int kSteps = (1 << LOGG) - 1;
+                const int sub = lane & 15, row = lane >> 4;
+                const int nidx_r = __builtin_amdgcn_ds_bpermute(sub << 2, nidx);
+                float g = 0.f;
+                if (a.proj && row < 3 && sub < cnt) g = Pb[pt_off(a.p_layout, N, nidx_r, row)];
+                float den = e;
+#pragma unroll
+                for (int t = 0; t < kSteps; ++t) den = e + dpp_shr1(den);
+                const float w = e / readlane_f(den, K - 1);  // softmax over the K neighbours (:143)
+                if (a.weights && lane < K) a.weights[qrow * K + lane] = w;
+                if (a.proj) {
+                    const float term = g * __int_as_float(__builtin_amdgcn_ds_bpermute(sub << 2, __float_as_int(w)));
+                    float o = term;  // product then sum, ascending k
+#pragma unroll
+                    for (int t = 0; t < kSteps; ++t) o = term + dpp_shr1(o);
+                    if (row < 3 && sub == K - 1) a.proj[(size_t)b * 3 * M + pt_off(a.proj_layout, M, j, row)] = o;
+                    if (a.qpart) {
+                        const float ox = readlane_f(o, K - 1), oy = readlane_f(o, 16 + K - 1), oz = readlane_f(o, 32 + K - 1);
+                        if (lane == 0) wsum_pj += (ox + oy) + oz;
+                    }
                 }
-                if (lane < 3) {
-                    const float o = lane == 0 ? ox : (lane == 1 ? oy : oz);
-                    a.proj[(size_t)b * 3 * M + pt_off(a.proj_layout, M, j, lane)] = o;
+            } else {
+                float gx = 0.f, gy = 0.f, gz = 0.f;
+                if (lane < cnt) {
+                    gx = Pb[pt_off(a.p_layout, N, nidx, 0)];
+                    gy = Pb[pt_off(a.p_layout, N, nidx, 1)];
+                    gz = Pb[pt_off(a.p_layout, N, nidx, 2)];
                 }
-                if (lane == 0) wsum_pj += (ox + oy) + oz;
+                float den = 0.f;
+                for (int t = 0; t < K; ++t) den += readlane_f(e, t);
+                const float w = e / den;  // softmax over the K neighbours (:143)
+                if (a.weights && lane < K) a.weights[qrow * K + lane] = w;
+                if (a.proj) {
+                    float ox = 0.f, oy = 0.f, oz = 0.f;
+                    for (int t = 0; t < K; ++t) {  // ascending k, product then sum (:148-151)
+                        const float wt = readlane_f(w, t);
+                        ox += readlane_f(gx, t) * wt;
+                        oy += readlane_f(gy, t) * wt;
+                        oz += readlane_f(gz, t) * wt;
+                    }
+                    if (lane < 3) {
+                        const float o = lane == 0 ? ox : (lane == 1 ? oy : oz);
+                        a.proj[(size_t)b * 3 * M + pt_off(a.proj_layout, M, j, lane)] = o;
+                    }
+                    if (lane == 0) wsum_pj += (ox + oy) + oz;
+                }
             }
         }
     }
@@ -442,7 +519,7 @@ __global__ void __launch_bounds__(256) colmin_finalize_kernel(int N, int G, cons
 template <int PPL, bool SINGLE, bool COLMIN>
 static int launch_pairscan(const PairscanArgs &a, int waves, int ysplit, hipStream_t st)
 {
-    const size_t lds = (size_t)waves * kListCap * 8 + (COLMIN ? (size_t)kWave * PPL * 8 : 0);
+    const size_t lds = (size_t)waves * kListPitch * 8 + (COLMIN ? (size_t)kWave * PPL * 8 : 0);
     const dim3 grid(a.B, ysplit), block(waves * kWave);
     // number of lane groups for the threshold = power of two >= K (instantiated: 1, 8, 16, 64)
     if (a.K <= 1)
@@ -484,7 +561,11 @@ int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finaliz
             if (!ws || ws_bytes < need) ysplit = 1;
         }
         const int qpb = (M + ysplit - 1) / ysplit;
-        const int waves = std::max(1, std::min(maxw, qpb));  // one query per wave at the sampler's sizes (swept 2 / 4 / 8: 8 is fastest)
+        int waves = std::max(1, std::min(maxw, qpb));  // one query per wave at the sampler's sizes (swept 2 / 4 / 8: 8 is fastest)
+        // the batch alone fills the chip: workgroups of 4 waves pack a CU's register file better (the 1024-point variant
+        // holds 153 VGPRs -> 3 waves per SIMD = 12 per CU: three workgroups of 4 instead of one of 8; swept 8 / 6 / 4 /
+        // 3 / 2 at B = 8192: 10.1 / 8.4 / 15.0 / 14.4 / 14.3 M clouds/s)
+        if (ysplit == 1 && a.B >= 512) waves = std::min(waves, 4);
         a.colmin_ws = (colmin && ysplit > 1 && !a.colmin_keys) ? (sn_u64 *)ws : nullptr;
         if (used_split) *used_split = ysplit;
 #define SN_PS(PPL_)                                                                      \

@@ -137,6 +137,38 @@ def test_knn_all_points_identical(oracle):
     assert np.array_equal(oi[0, 0], np.arange(16))
 
 
+@pytest.mark.parametrize("n,k", [(1024, 8), (1024, 16), (1000, 8), (2048, 16)])
+@pytest.mark.parametrize("cluster", [70, 130, 150, 191, 192, 193, 260])
+def test_knn_cluster_of_coincident_points(oracle, n, k, cluster):
+    """`cluster` copies of one point, spread over every lane group of the scan, sit nearest to all queries: exactly that many
+    candidates pass the threshold filter -- sizes either side of one candidate per lane (64), of the point where a round of
+    the branch-free compaction runs past the list's end (128..192) and of the list itself (192: the checked form takes over).
+    Ties resolve to the lowest indices; the fused scan's other products must agree with the oracle too."""
+    from samplenet_amd import ops
+
+    rng = np.random.default_rng(cluster * 7 + k)
+    b, m = 3, 40
+    P = (rng.random((b, n, 3), dtype=np.float32) - 0.5) * 0.2 + 2.0   # far away
+    c = np.array([0.1, -0.2, 0.05], np.float32)
+    for bi in range(b):
+        lanes = np.arange(64) + 64 * rng.integers(0, n // 64, 64)  # a copy in every lane (point i sits in lane i % 64)
+        rest = rng.permutation(np.setdiff1d(np.arange(n), lanes))[:cluster - 64]
+        P[bi, np.concatenate([lanes, rest])] = c
+        assert int((P[bi] == c).all(1).sum()) == cluster
+    Q = (c + 0.01 * rng.standard_normal((b, m, 3))).astype(np.float32)
+    od, oi = oracle.knn(k, P, Q)
+    idx, d2 = ops.knn(k, dev(P), dev(Q), ops.BNC, ops.BNC)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d2.cpu().numpy(), od)
+    Pc, Qc = np.ascontiguousarray(P.transpose(0, 2, 1)), np.ascontiguousarray(Q.transpose(0, 2, 1))
+    oproj, _, _ = oracle.softproj_forward(Pc, Qc, oi, 1.0)
+    proj, idx2, dq, iq, dp, ip = ops.SoftProjectFunction.apply(dev(Pc), dev(Qc), torch.tensor(1.0, device="cuda"), 1e-2, k, True)
+    assert np.array_equal(idx2.cpu().numpy(), oi)
+    np.testing.assert_allclose(proj.cpu().numpy(), oproj, rtol=0, atol=1e-6)
+    ocd = oracle.chamfer_forward(Q, P)
+    assert np.array_equal(dq.cpu().numpy(), ocd[0]) and np.array_equal(iq.cpu().numpy(), ocd[1])
+    assert np.array_equal(dp.cpu().numpy(), ocd[2]) and np.array_equal(ip.cpu().numpy(), ocd[3])
+
+
 def test_knn_in_tree_definition_when_distinct(oracle):
     """Membership and order equal the in-tree TF definition (matrix + selection sort) on distinct distances."""
     from samplenet_amd import ops

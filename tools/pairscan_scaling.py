@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Pair-scan kernel (kNN + soft projection + both Chamfer directions) at growing batch: where the B = 32 launch sits on
-the kernel's own throughput curve.  Prints clouds/s and algorithmic GB/s (24,576 B per cloud at N=1024, M=64, K=8)."""
+the kernel's own throughput curve.  Prints clouds/s and algorithmic GB/s (24,576 B per cloud at N=1024, M=64, K=8).
+    python tools/pairscan_scaling.py [B ...]"""
 import os
 import sys
 
@@ -10,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from samplenet_amd._lib import check, lib, ptr  # noqa: E402
 
 N, M, K = 1024, 64, 8
-for B in (32, 128, 512, 2048, 8192):
+for B in ([int(v) for v in sys.argv[1:]] or [32, 128, 512, 2048, 8192]):
     dev = "cuda"
     x = torch.rand(B, N, 3, device=dev) - 0.5
     y = torch.rand(B, 3, M, device=dev) - 0.5
