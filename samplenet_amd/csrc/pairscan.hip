@@ -38,6 +38,24 @@ namespace sn {
 constexpr int kListCap = 192;  // per-wave candidate list entries (3 per lane)
 constexpr int kListPitch = kListCap + kWave;  // + one scrap entry per lane / overrun of the last round (branch-free compaction)
 
+// Debug build only (-DSN_PS_TIMELINE, tools/pairscan_timeline.py): thread 0 of every workgroup stamps the 100 MHz wall clock at
+// the phase boundaries of its first query.
+#ifdef SN_PS_TIMELINE
+__device__ unsigned long long g_ps_tl[8192 * 16];
+#define PS_TL(slot)                                                                                              \
+    do {                                                                                                         \
+        if (threadIdx.x == 0) g_ps_tl[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (slot)] = wall_clock64(); \
+    } while (0)
+#if SN_PS_TIMELINE >= 2  // serialise the phases: every stamp waits for the memory operations before it
+#define PS_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define PS_TL_DRAIN()
+#endif
+#else
+#define PS_TL(slot)
+#define PS_TL_DRAIN()
+#endif
+
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, float py, float pz)
 {
     const float dx = px - qx, dy = py - qy, dz = pz - qz;
@@ -98,17 +116,23 @@ __device__ __forceinline__ void load_chunk(float (&px)[PPL], float (&py)[PPL], f
         }
         return;
     }
+    // channel-major cloud: three coalesced dword loads per point, all 3 * PPL of them in flight before the first use
+    const float *__restrict__ Px = Pb, *__restrict__ Py = Pb + N, *__restrict__ Pz = Pb + 2 * (size_t)N;
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const int n = c0 + i * kWave + lane;
-        const bool ok = n < N;
-        const int nn = ok ? n : 0;
-        const float x = Pb[pt_off(layout, N, nn, 0)];
-        const float y = Pb[pt_off(layout, N, nn, 1)];
-        const float z = Pb[pt_off(layout, N, nn, 2)];
-        px[i] = ok ? x : INFINITY;
-        py[i] = ok ? y : INFINITY;
-        pz[i] = ok ? z : INFINITY;
+        const int nn = n < N ? n : 0;
+        px[i] = Px[nn];
+        py[i] = Py[nn];
+        pz[i] = Pz[nn];
+    }
+    asm volatile("" ::: "memory");  // (keeps the selects below from being paired with their loads, one wait per point)
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const bool ok = c0 + i * kWave + lane < N;
+        px[i] = ok ? px[i] : INFINITY;
+        py[i] = ok ? py[i] : INFINITY;
+        pz[i] = ok ? pz[i] : INFINITY;
     }
 }
 
@@ -150,24 +174,20 @@ __device__ __forceinline__ float group_minmax(float x)
     return __uint_as_float(t);
 }
 
-// Rank the wave's <= 64 candidates held one per lane (mine = key or kKeyInf) and move them to lane == rank:
-// afterwards lane t < min(cnt, 64) holds the t-th smallest key.  Keys are unique, so ranks are a permutation.
-__device__ __forceinline__ sn_u64 rank_to_lanes(sn_u64 mine, int cnt, int lane)
+// Rank the wave's cnt <= 64 candidates list[0..cnt) (entries list[cnt .. cnt+15] hold kKeyInf) and move them to lane ==
+// rank: afterwards lane t < min(cnt, 64) holds the t-th smallest key.  Keys are unique, so ranks are a permutation.  Every
+// lane reads the same entry (LDS broadcast) and counts the keys below its own: two VALU per candidate.
+__device__ __forceinline__ sn_u64 rank_to_lanes(const sn_u64 *list, int cnt, int lane)
 {
-    const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+    const sn_u64 mine = (lane < cnt) ? list[lane] : kKeyInf;
     int rank = 0;
-    // four candidates per trip: lanes >= cnt hold kKeyInf (never smaller than anything), and cnt <= 64 keeps u + 3 <= 63
-    for (int u = 0; u < cnt; u += 4) {
+    for (int u = 0; u < cnt; u += 16) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const sn_u64 ku = ((sn_u64)(unsigned)__builtin_amdgcn_readlane((int)hi, u + v) << 32) |
-                              (unsigned)__builtin_amdgcn_readlane((int)lo, u + v);
-            rank += (ku < mine) ? 1 : 0;
-        }
+        for (int v = 0; v < 16; ++v) rank += (list[u + v] < mine) ? 1 : 0;
     }
     const int dst = (lane < cnt) ? rank : lane;  // lanes without a candidate keep to themselves (no collision)
-    const unsigned plo = (unsigned)__builtin_amdgcn_ds_permute(dst << 2, (int)lo);
-    const unsigned phi = (unsigned)__builtin_amdgcn_ds_permute(dst << 2, (int)hi);
+    const unsigned plo = (unsigned)__builtin_amdgcn_ds_permute(dst << 2, (int)(unsigned)mine);
+    const unsigned phi = (unsigned)__builtin_amdgcn_ds_permute(dst << 2, (int)(unsigned)(mine >> 32));
     return ((sn_u64)phi << 32) | plo;
 }
 
@@ -227,12 +247,19 @@ __device__ __forceinline__ void fc_query(const PairscanArgs &a, int b, int j, in
         s1 = fmaf(aw, v.w, fmaf(az, v.z, fmaf(ay, v.y, fmaf(ax, v.x, s1))));
         s2 = fmaf(aw, w.w, fmaf(az, w.z, fmaf(ay, w.y, fmaf(ax, w.x, s2))));
     }
+    // xor tree 32, 16, 8, 4, 2, 1.  The last four levels stay inside a row of 16 lanes and run on the DPP path: after the
+    // level before, lanes l and l ^ 8 (then l ^ 4) hold the same value, so a rotation by 8 (by 4) hands every lane the very
+    // partner value of the xor butterfly -- same sums, same bits, no LDS round trip.
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
+    for (int o = 32; o >= 16; o >>= 1) {
         s0 += __shfl_xor(s0, o);
         s1 += __shfl_xor(s1, o);
         s2 += __shfl_xor(s2, o);
     }
+    s0 += dpp_f<0x128>(s0), s1 += dpp_f<0x128>(s1), s2 += dpp_f<0x128>(s2);                    // row_ror:8
+    s0 += dpp_f<0x124>(s0), s1 += dpp_f<0x124>(s1), s2 += dpp_f<0x124>(s2);                    // row_ror:4
+    s0 += dpp_f<kDppXor2>(s0), s1 += dpp_f<kDppXor2>(s1), s2 += dpp_f<kDppXor2>(s2);           // quad_perm [2,3,0,1]
+    s0 += dpp_f<kDppXor1>(s0), s1 += dpp_f<kDppXor1>(s1), s2 += dpp_f<kDppXor1>(s2);           // quad_perm [1,0,3,2]
     qx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s0 + a.fc_bias[j])));
     qy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s1 + a.fc_bias[M + j])));
     qz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s2 + a.fc_bias[2 * M + j])));
@@ -256,6 +283,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
     const int qpb = (M + gridDim.y - 1) / gridDim.y;
     const int q0 = blockIdx.y * qpb;
     const int q1 = min(M, q0 + qpb);
+    PS_TL(0);
 
     sn_u64 *list = reinterpret_cast<sn_u64 *>(smem) + wave * kListPitch;
     sn_u64 *colmin = reinterpret_cast<sn_u64 *>(smem) + nwaves * kListPitch;  // [64*PPL] when COLMIN
@@ -264,15 +292,11 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
     const float *__restrict__ Qb = a.Q + (size_t)b * 3 * M;
 
     const bool want_soft = (a.proj != nullptr) || (a.weights != nullptr);
-    float sigma = 1.0f;
-    if (want_soft) {
-        const float T = *a.temperature;
-        sigma = fmaxf(T * T, a.min_sigma);  // soft_projection.py:97-99
-    }
 
+    // (no barrier here: colmin[] is next touched behind the query loop, and the barrier in front of that use orders these
+    //  writes -- a barrier in the prologue would hold the cloud loads back until the slowest wave's arguments arrived)
     if (COLMIN) {
         for (int i = threadIdx.x; i < kWave * PPL; i += blockDim.x) colmin[i] = kKeyInf;
-        __syncthreads();
     }
 
     float px[PPL], py[PPL], pz[PPL];
@@ -284,6 +308,8 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
         ci[i] = 0;
     }
     if (SINGLE) load_chunk<PPL>(px, py, pz, Pb, a.p_layout, N, 0, lane);
+    PS_TL_DRAIN();
+    PS_TL(1);
 
     float wsum_dq = 0.f, wsum_pj = 0.f;  // colmin_keys mode: this wave's share of sum dist_q, sum proj, max (dist_q, ~query)
     sn_u64 wmax = 0;
@@ -296,8 +322,10 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
             qy = Qb[pt_off(a.q_layout, M, j, 1)];
             qz = Qb[pt_off(a.q_layout, M, j, 2)];
         }
+        if (j == q0) { PS_TL_DRAIN(); PS_TL(2); }
         int cnt = 0;
         float thr_run = INFINITY;
+        float temp_q = 1.0f;
 
         for (int c0 = 0; c0 < N; c0 += kWave * PPL) {
             if (!SINGLE) load_chunk<PPL>(px, py, pz, Pb, a.p_layout, N, c0, lane);
@@ -314,8 +342,16 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                     }
                 }
             }
+            // the temperature, for the softmax at the end of the query: read here, behind the cloud's and the query's
+            // loads and through a vector load (a scalar load in the prologue would hold all of them back until it lands)
+            if (want_soft && c0 == 0) {
+                int zero = 0;
+                asm volatile("" : "+v"(zero));
+                temp_q = a.temperature[zero];
+            }
             // tau = max over the 2^LOGG lane groups of the group's minimum (2^LOGG >= K): >= K points lie at or below it
             float thr = fminf(group_minmax<LOGG>(lmin), thr_run);
+            if (j == q0) PS_TL(3);
             // compact candidates (d <= thr) into the wave's LDS list, round by round with a capacity check (a merge
             // when the list would overflow): the general form
             auto compact_checked = [&]() {
@@ -354,6 +390,9 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                         const int at = base < kListCap ? base : kListCap;  // clamped only when the total overflows anyway
                         const int pos = at + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                        // (spelling the select out as v_cndmask on the ballot lets the rounds overlap -- compaction 0.92 ->
+                        //  0.64 us at B = 32 -- but costs 22 VGPRs: 2 instead of 3 waves per SIMD, 15 -> 12 M clouds/s
+                        //  when the batch fills the chip)
                         list[pred ? pos : kListCap + lane] = make_key(d[i], n);  // others: the lane's own scrap entry
                         base += __builtin_popcountll(mask);
                     }
@@ -364,6 +403,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                 const int total = (N == kWave * PPL) ? compact_all(std::true_type{}) : compact_all(std::false_type{});
                 if (total <= kListCap) {
                     cnt = total;
+                    if (lane < 16) list[total + lane] = kKeyInf;  // rank_to_lanes reads whole groups of 16
                 } else {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     compact_checked();
@@ -372,6 +412,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                 compact_checked();
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (j == q0) { PS_TL_DRAIN(); PS_TL(4); }
             if (!SINGLE) {
                 cnt = merge_topk(list, cnt, K, lane);
                 if (cnt == K) thr_run = key_dist(list[K - 1]);
@@ -381,7 +422,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
         sn_u64 key;
         if (SINGLE && cnt <= kWave) {
             // usual case (~K..3K candidates): one candidate per lane, ranked in registers, moved to lane == rank
-            key = rank_to_lanes((lane < cnt) ? list[lane] : kKeyInf, cnt, lane);
+            key = rank_to_lanes(list, cnt, lane);
             cnt = cnt < K ? cnt : K;
             if (lane >= cnt) key = kKeyInf;
         } else {
@@ -390,6 +431,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
         }
         const int nidx = (lane < cnt) ? key_index(key) : 0;
         const float nd = (lane < cnt) ? key_dist(key) : INFINITY;
+        if (j == q0) PS_TL(5);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const size_t qrow = (size_t)b * M + j;
         if (lane < K) {
@@ -404,6 +446,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
             wmax = kq > wmax ? kq : wmax;
         }
         if (want_soft) {
+            const float sigma = fmaxf(temp_q * temp_q, a.min_sigma);   // soft_projection.py:97-99
             const float s = (lane < cnt) ? -(nd / sigma) : -INFINITY;  // soft_projection.py:92-95
             const float mx = readlane_f(s, 0);  // neighbours ascend in distance: lane 0 holds the maximum of s
             const float e = (lane < cnt) ? expf(s - mx) : 0.f;
@@ -460,13 +503,20 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                 }
             }
         }
+        if (j == q0) { PS_TL_DRAIN(); PS_TL(6); }
     }
 
     if (COLMIN) {
-        // combine the waves' column minima: unsigned min of (distance, query index) keys
+        // this wave's share of the query-side reductions (keys mode), then the waves' column minima: unsigned min of
+        // (distance, query index) keys
+        float *wq = reinterpret_cast<float *>(colmin + kWave * PPL);  // [nwaves][2]
+        sn_u64 *wk = colmin + kWave * PPL + nwaves;                   // [nwaves]
+        if (a.colmin_keys && lane == 0) wq[wave * 2] = wsum_dq, wq[wave * 2 + 1] = wsum_pj, wk[wave] = wmax;
+        __syncthreads();  // colmin[] initialised by every wave
 #pragma unroll
         for (int i = 0; i < PPL; ++i) atomicMin(&colmin[i * kWave + lane], make_key(cd[i], ci[i]));
         __syncthreads();
+        PS_TL(7);
         if (gridDim.y == 1) {
             for (int n = threadIdx.x; n < N; n += blockDim.x) {
                 const sn_u64 k = colmin[n];
@@ -476,28 +526,34 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
         } else if (a.colmin_keys) {  // combine with the cloud's other workgroups in place (see PairscanArgs)
             sn_u64 *kk = a.colmin_keys + (size_t)b * N;
             for (int n = threadIdx.x; n < N; n += blockDim.x) atomicMax(kk + n, ~colmin[n]);
+            PS_TL_DRAIN();
+            PS_TL(8);
             // query-side reductions of this workgroup, waves in order
-            __syncthreads();  // colmin[] is free now: reuse its first words
-            float *wq = reinterpret_cast<float *>(colmin);           // [nwaves][2]
-            sn_u64 *wk = colmin + nwaves;                            // [nwaves]  (behind the 2 * nwaves floats)
-            if (lane == 0) wq[wave * 2] = wsum_dq, wq[wave * 2 + 1] = wsum_pj, wk[wave] = wmax;
-            __syncthreads();
-            if (threadIdx.x == 0) {
+            if (wave == 0) {  // lane w holds wave w's partials (one LDS round trip), summed in wave order
+                const bool has = lane < nwaves;
+                const float pd = has ? wq[lane * 2] : 0.f, pp = has ? wq[lane * 2 + 1] : 0.f;
+                const sn_u64 pk = has ? wk[lane] : 0;
                 float sd = 0.f, sp = 0.f;
                 sn_u64 mk = 0;
                 for (int w2 = 0; w2 < nwaves; ++w2) {
-                    sd += wq[w2 * 2], sp += wq[w2 * 2 + 1];
-                    mk = wk[w2] > mk ? wk[w2] : mk;
+                    sd += readlane_f(pd, w2), sp += readlane_f(pp, w2);
+                    const sn_u64 kw = ((sn_u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(pk >> 32), w2) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pk, w2);
+                    mk = kw > mk ? kw : mk;
                 }
-                const size_t o = (size_t)b * gridDim.y + blockIdx.y;
-                a.qpart[o * 2] = sd, a.qpart[o * 2 + 1] = sp;
-                a.qmax[o] = mk;
+                if (lane == 0) {
+                    const size_t o = (size_t)b * gridDim.y + blockIdx.y;
+                    a.qpart[o * 2] = sd, a.qpart[o * 2 + 1] = sp;
+                    a.qmax[o] = mk;
+                }
             }
         } else {  // this workgroup saw only its share of the queries: publish partial keys
             sn_u64 *ws = a.colmin_ws + ((size_t)b * gridDim.y + blockIdx.y) * N;
             for (int n = threadIdx.x; n < N; n += blockDim.x) ws[n] = colmin[n];
         }
     }
+    PS_TL_DRAIN();
+    PS_TL(9);
 }
 
 // dist_p / idx_p = minimum over the G partial keys of every point (min of (distance, query) keys = lowest query on ties)
@@ -519,7 +575,7 @@ __global__ void __launch_bounds__(256) colmin_finalize_kernel(int N, int G, cons
 template <int PPL, bool SINGLE, bool COLMIN>
 static int launch_pairscan(const PairscanArgs &a, int waves, int ysplit, hipStream_t st)
 {
-    const size_t lds = (size_t)waves * kListPitch * 8 + (COLMIN ? (size_t)kWave * PPL * 8 : 0);
+    const size_t lds = (size_t)waves * kListPitch * 8 + (COLMIN ? (size_t)kWave * PPL * 8 + (size_t)waves * 16 : 0);
     const dim3 grid(a.B, ysplit), block(waves * kWave);
     // number of lane groups for the threshold = power of two >= K (instantiated: 1, 8, 16, 64)
     if (a.K <= 1)
@@ -786,3 +842,15 @@ extern "C" int sn_pairscan_forward_partial_fc(int B, int N, int M, int K, const 
     if (used != G) return sn_set_error(SN_ERR_BAD_ARGUMENT, "%s: internal: split mismatch", __func__);
     return 0;
 }
+
+#ifdef SN_PS_TIMELINE
+// copies the first nblocks x 16 stamps of the last pair-scan launch to the host and clears them
+extern "C" int sn_debug_pairscan_timeline(void *host, int nblocks)
+{
+    if (nblocks < 0 || nblocks > 8192) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(sn::g_ps_tl), (size_t)nblocks * 16 * 8) != hipSuccess) return -3;
+    static unsigned long long zeros[8192 * 16];
+    return hipMemcpyToSymbol(HIP_SYMBOL(sn::g_ps_tl), zeros, sizeof(zeros)) == hipSuccess ? 0 : -4;
+}
+#endif
