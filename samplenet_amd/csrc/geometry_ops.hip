@@ -222,33 +222,82 @@ struct SoftBwdArgs {
     int accumulate_q;
 };
 
-// One query of the soft-projection backward, executed by a whole wave (lane t < K = neighbour t): returns the gradient to
-// the query (aq*, wave-uniform) and its share of d loss / d sigma; accumulates grad_P if requested.
+// One query of the soft-projection backward, executed by a whole wave: returns the gradient to the query (aq*,
+// wave-uniform) and its share of d loss / d sigma; accumulates grad_P if requested.  Three steps, so that a caller can
+// request the query's memory operands ahead of other work: the neighbour indices, the neighbours' coordinates, the math.
+//   K <= 16: every row of 16 lanes holds the K neighbours (lane t of a row = neighbour t) and the ascending-k sums run
+//            as sequential DPP scans inside the rows (lane t adds its term to lane t-1's running sum -- the order of the
+//            loops below), the four closing sums (gradient x, y, z and the sigma term) one per row;
+//   else   : lane t < K = neighbour t, sums by v_readlane loops.
+struct SoftQuery {
+    float qx, qy, qz;  // the query
+    int id;            // this lane's neighbour
+    float gx, gy, gz;  // its coordinates
+};
+
+__device__ __forceinline__ float dpp_row_shr1(float x)  // lane below within the row of 16; 0 into the row's lane 0
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_row_shr1_self(float x)  // ... the row's lane 0 reads itself
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x111, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ void soft_bwd_load_index(const SoftBwdArgs &a, int b, int j, int lane, const float *__restrict__ Qb,
+                                                    SoftQuery &q)
+{
+    const int m = a.m, K = a.k;
+    q.qx = Qb[pt_off(a.q_layout, m, j, 0)];
+    q.qy = Qb[pt_off(a.q_layout, m, j, 1)];
+    q.qz = Qb[pt_off(a.q_layout, m, j, 2)];
+    const int sub = K <= 16 ? (lane & 15) : lane;
+    q.id = sub < K ? a.idx[((size_t)b * m + j) * K + sub] : 0;
+}
+
+__device__ __forceinline__ void soft_bwd_load_points(const SoftBwdArgs &a, int lane, const float *__restrict__ Pb, SoftQuery &q)
+{
+    const int n = a.n, K = a.k;
+    const int sub = K <= 16 ? (lane & 15) : lane;
+    q.gx = q.gy = q.gz = 0.f;
+    if (sub < K) {
+        q.gx = Pb[pt_off(a.p_layout, n, q.id, 0)];
+        q.gy = Pb[pt_off(a.p_layout, n, q.id, 1)];
+        q.gz = Pb[pt_off(a.p_layout, n, q.id, 2)];
+    }
+}
+
 template <bool FUSED>
-__device__ __forceinline__ void soft_bwd_query(const SoftBwdArgs &a, int b, int j, int lane, float sigma,
-                                               const float *__restrict__ Pb, const float *__restrict__ Qb, float &aqx_o,
-                                               float &aqy_o, float &aqz_o, float &asg_o)
+__device__ __forceinline__ void soft_bwd_math(const SoftBwdArgs &a, int b, int j, int lane, float sigma, const SoftQuery &q,
+                                              float &aqx_o, float &aqy_o, float &aqz_o, float &asg_o)
 {
     const int n = a.n, m = a.m, K = a.k;
-    const float qx = Qb[pt_off(a.q_layout, m, j, 0)];
-    const float qy = Qb[pt_off(a.q_layout, m, j, 1)];
-    const float qz = Qb[pt_off(a.q_layout, m, j, 2)];
-    const bool act = lane < K;
-    const int id = act ? a.idx[((size_t)b * m + j) * K + lane] : 0;
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    if (act) {
-        gx = Pb[pt_off(a.p_layout, n, id, 0)];
-        gy = Pb[pt_off(a.p_layout, n, id, 1)];
-        gz = Pb[pt_off(a.p_layout, n, id, 2)];
-    }
-    const float dx = gx - qx, dy = gy - qy, dz = gz - qz;
+    const bool rows = K <= 16;
+    const int sub = rows ? (lane & 15) : lane;
+    const bool act = sub < K;
+    const int id = q.id;
+    const float gx = q.gx, gy = q.gy, gz = q.gz;
+    const float dx = gx - q.qx, dy = gy - q.qy, dz = gz - q.qz;
     const float d = (dx * dx + dy * dy) + dz * dz;
     const float s = act ? -(d / sigma) : -INFINITY;
-    float mx = readlane_f(s, 0);  // neighbours are stored ascending in distance; the scan below only matters
-    for (int t = 1; t < K; ++t) mx = fmaxf(mx, readlane_f(s, t));  // if a caller passes unsorted indices
+    float mx, den;
+    if (rows) {
+        mx = s;
+        for (int t = 1; t < K; ++t) mx = fmaxf(s, dpp_row_shr1_self(mx));
+        mx = readlane_f(mx, K - 1);
+    } else {
+        mx = readlane_f(s, 0);  // neighbours are stored ascending in distance; the scan below only matters
+        for (int t = 1; t < K; ++t) mx = fmaxf(mx, readlane_f(s, t));  // if a caller passes unsorted indices
+    }
     const float e = act ? expf(s - mx) : 0.f;
-    float den = 0.f;
-    for (int t = 0; t < K; ++t) den += readlane_f(e, t);
+    if (rows) {
+        den = e;
+        for (int t = 1; t < K; ++t) den = e + dpp_row_shr1(den);
+        den = readlane_f(den, K - 1);
+    } else {
+        den = 0.f;
+        for (int t = 0; t < K; ++t) den += readlane_f(e, t);
+    }
     const float w = e / den;
 
     float gw;  // d loss / d w_t
@@ -264,22 +313,40 @@ __device__ __forceinline__ void soft_bwd_query(const SoftBwdArgs &a, int b, int 
         }
         gw = (go0 * gx + go1 * gy) + go2 * gz;
     } else {
-        gw = act ? a.grad_weights[((size_t)b * m + j) * K + lane] : 0.f;
+        gw = act ? a.grad_weights[((size_t)b * m + j) * K + sub] : 0.f;
     }
-    float dot = 0.f;
-    for (int t = 0; t < K; ++t) dot += readlane_f(w, t) * readlane_f(gw, t);
+    float dot;
+    if (rows) {
+        const float wg = w * gw;
+        dot = wg;
+        for (int t = 1; t < K; ++t) dot = wg + dpp_row_shr1(dot);
+        dot = readlane_f(dot, K - 1);
+    } else {
+        dot = 0.f;
+        for (int t = 0; t < K; ++t) dot += readlane_f(w, t) * readlane_f(gw, t);
+    }
     const float gs = act ? w * (gw - dot) : 0.f;  // softmax backward
     const float gd = -gs / sigma;                 // s = -d / sigma
     const float cx = 2.0f * gd * dx, cy = 2.0f * gd * dy, cz = 2.0f * gd * dz;
     const float sg = act ? gs * d / (sigma * sigma) : 0.f;
     float aqx = 0.f, aqy = 0.f, aqz = 0.f, asg = 0.f;
-    for (int t = 0; t < K; ++t) {
-        aqx -= readlane_f(cx, t);
-        aqy -= readlane_f(cy, t);
-        aqz -= readlane_f(cz, t);
-        asg += readlane_f(sg, t);
+    if (rows) {
+        // row 0: 0 - cx_0 - cx_1 ..., row 1: cy, row 2: cz, row 3: 0 + sg_0 + sg_1 ...
+        const int row = lane >> 4;
+        const float v = row == 0 ? -cx : (row == 1 ? -cy : (row == 2 ? -cz : sg));
+        float acc = v;
+        for (int t = 1; t < K; ++t) acc = v + dpp_row_shr1(acc);
+        aqx = readlane_f(acc, K - 1), aqy = readlane_f(acc, 16 + K - 1), aqz = readlane_f(acc, 32 + K - 1);
+        asg = readlane_f(acc, 48 + K - 1);
+    } else {
+        for (int t = 0; t < K; ++t) {
+            aqx -= readlane_f(cx, t);
+            aqy -= readlane_f(cy, t);
+            aqz -= readlane_f(cz, t);
+            asg += readlane_f(sg, t);
+        }
     }
-    if (a.grad_P && act) {
+    if (a.grad_P && lane < K) {
         float *gpb = a.grad_P + (size_t)b * 3 * n;
         const int lay = FUSED ? a.p_layout : SN_LAYOUT_BCN;
         const float ex = FUSED ? go0 * w : 0.f, ey = FUSED ? go1 * w : 0.f, ez = FUSED ? go2 * w : 0.f;
@@ -288,6 +355,17 @@ __device__ __forceinline__ void soft_bwd_query(const SoftBwdArgs &a, int b, int 
         atomicAdd(&gpb[pt_off(lay, n, id, 2)], ez + cz);
     }
     aqx_o = aqx, aqy_o = aqy, aqz_o = aqz, asg_o = asg;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ void soft_bwd_query(const SoftBwdArgs &a, int b, int j, int lane, float sigma,
+                                               const float *__restrict__ Pb, const float *__restrict__ Qb, float &aqx_o,
+                                               float &aqy_o, float &aqz_o, float &asg_o)
+{
+    SoftQuery q;
+    soft_bwd_load_index(a, b, j, lane, Qb, q);
+    soft_bwd_load_points(a, lane, Pb, q);
+    soft_bwd_math<FUSED>(a, b, j, lane, sigma, q, aqx_o, aqy_o, aqz_o, asg_o);
 }
 
 template <bool FUSED>
@@ -514,6 +592,25 @@ struct StepLossFold {
     float *dpsum;
 };
 
+
+// Debug build only (-DSN_CS_TIMELINE=1|2, tools/pairscan_timeline.py): thread 0 of every workgroup of chamfer_soft_bwd_kernel
+// stamps the 100 MHz wall clock at the phase boundaries of its first query (2: every stamp first drains the memory counters).
+#ifdef SN_CS_TIMELINE
+__device__ unsigned long long g_cs_tl[8192 * 16];
+#define CS_TL(slot)                                                                                              \
+    do {                                                                                                         \
+        if (threadIdx.x == 0) g_cs_tl[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (slot)] = wall_clock64(); \
+    } while (0)
+#if SN_CS_TIMELINE >= 2
+#define CS_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define CS_TL_DRAIN()
+#endif
+#else
+#define CS_TL(slot)
+#define CS_TL_DRAIN()
+#endif
+
 template <int PPL>
 __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, const float *__restrict__ T,
                                                                const float *__restrict__ S, const int *__restrict__ idxT,
@@ -530,30 +627,79 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
     const int nsplit = fin.loss ? (int)gridDim.y - 1 : (int)gridDim.y;  // the last y-slice only combines the loss value
+    CS_TL(0);
     if ((int)blockIdx.y == nsplit) {
         if (b == 0 && wave == 0) step_loss_final(fin, lane);
         return;
     }
+    // ---- everything that does not wait for the keys is requested first (one memory round trip instead of a chain of them:
+    // cloud, scalars, the first query's coordinates / nearest point / neighbour indices), the loads that depend on those
+    // (the nearest point's and the neighbours' coordinates) while the keys are on their way
+    T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
+    idxT += (size_t)b * nt;
+    if (idxS) idxS += (size_t)b * ns;
+    gradT += (size_t)b * nt * 3;
+    float sx[PPL], sy[PPL], sz[PPL], gg[PPL];
+    int is[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int l = i * 64 + lane;
+        const int lc = l < ns ? l : 0;
+        const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)lc * 3);
+        sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
+    }
+    const float gLv = *ig.gL * ig.gscale;
+    const float Tm = *sa.temperature;
+    const float sigma = fmaxf(Tm * Tm, sa.min_sigma);
+    const int jfirst = blockIdx.y * nwaves + wave, jstep = nsplit * nwaves;
+    // the first query of this wave (the simplified cloud is target and query at once: T = sa.Q of this cloud)
+    float tx = 0.f, ty = 0.f, tz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
+    int j2 = 0;
+    SoftQuery sq{};
+    auto load_query = [&](int j) {
+        tx = T[j], ty = T[j + nt], tz = T[j + 2 * nt];  // targets channel-major (3, nt)
+        j2 = idxT[j];
+        soft_bwd_load_index(sa, b, j, lane, T, sq);
+    };
+    auto load_dependent = [&]() {
+        ox = S[j2 * 3 + 0], oy = S[j2 * 3 + 1], oz = S[j2 * 3 + 2];
+        soft_bwd_load_points(sa, lane, S, sq);
+    };
+    if (jfirst < nt) load_query(jfirst);
+
     if (fold.keys) {
         // nearest query of every point of the cloud, fetched ONCE per workgroup (the four waves all need all of them; keys that
         // were updated by device-scope atomics are slow to read: 4 x 8 KB per workgroup cost +4 us) and handed over in LDS
+        sn_u64 kv[PPL * 64 / 256 > 0 ? PPL * 64 / 256 : 1];
+#pragma unroll
+        for (int r = 0; r < (PPL * 64 + 255) / 256; ++r) {
+            const int n = threadIdx.x + r * 256;
+            kv[r] = n < ns ? fold.keys[(size_t)b * ns + n] : 0;
+        }
+        sn_u64 mk = 0;
+        if (wave == 0) {  // argmax of dist_q: maximum of the (dist_q, ~query) keys of the cloud's scan workgroups
+            for (int g = lane; g < fold.G; g += 64) {
+                const sn_u64 v = fold.qmax[(size_t)b * fold.G + g];
+                mk = v > mk ? v : mk;
+            }
+        }
+        if (jfirst < nt) load_dependent();
         float sdp = 0.f;
-        for (int n = threadIdx.x; n < ns; n += 256) {
-            const sn_u64 k = ~fold.keys[(size_t)b * ns + n];
-            s_ip[n] = key_index(k);
-            sdp += key_dist(k);
+#pragma unroll
+        for (int r = 0; r < (PPL * 64 + 255) / 256; ++r) {  // (ascending n per thread, as a strided loop would visit them)
+            const int n = threadIdx.x + r * 256;
+            if (n < ns) {
+                const sn_u64 k = ~kv[r];
+                s_ip[n] = key_index(k);
+                sdp += key_dist(k);
+            }
         }
         if (blockIdx.y == 0) {  // sum dist_p of the cloud (for the loss value), fixed order
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) sdp += __shfl_xor(sdp, o);
             if (lane == 0) s_red[2][wave] = sdp;
         }
-        if (wave == 0) {  // argmax of dist_q: maximum of the (dist_q, ~query) keys of the cloud's scan workgroups
-            sn_u64 mk = 0;
-            for (int g = lane; g < fold.G; g += 64) {
-                const sn_u64 v = fold.qmax[(size_t)b * fold.G + g];
-                mk = v > mk ? v : mk;
-            }
+        if (wave == 0) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const unsigned hi = __shfl_xor((unsigned)(mk >> 32), o), lo = __shfl_xor((unsigned)mk, o);
@@ -564,33 +710,30 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
         }
         __syncthreads();
         if (blockIdx.y == 0 && threadIdx.x == 0) fold.dpsum[b] = (s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3]);
+    } else if (jfirst < nt) {
+        load_dependent();
     }
-    T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
-    idxT += (size_t)b * nt, idxS += (size_t)b * ns;
-    const float gLv = *ig.gL * ig.gscale;
+    CS_TL(1);
     const int amt = fold.keys ? s_am : (ig.argmax_t ? ig.argmax_t[b] : -1), ams = ig.argmax_s ? ig.argmax_s[b] : -1;
-    gradT += (size_t)b * nt * 3;
-    const float Tm = *sa.temperature;
-    const float sigma = fmaxf(Tm * Tm, sa.min_sigma);
     float gsig = 0.f;
-
-    float sx[PPL], sy[PPL], sz[PPL], gg[PPL];
-    int is[PPL];
 #pragma unroll
     for (int i = 0; i < PPL; ++i) {
         const int l = i * 64 + lane;
         const int lc = l < ns ? l : 0;
-        const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)lc * 3);
-        sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
         is[i] = l < ns ? (fold.keys ? s_ip[lc] : idxS[lc]) : -1;
         gg[i] = gLv * (ig.cs + (l == ams ? ig.cmax_s : 0.f)) * 2;
     }
+    CS_TL_DRAIN();
+    CS_TL(2);
 
-    for (int j = blockIdx.y * nwaves + wave; j < nt; j += nsplit * nwaves) {
-        const float tx = T[j], ty = T[j + nt], tz = T[j + 2 * nt];  // targets channel-major (3, nt)
-        const int j2 = idxT[j];
+    for (int j = jfirst; j < nt; j += jstep) {
+        if (j != jfirst) {
+            load_query(j);
+            load_dependent();
+        }
         const float g = gLv * (ig.ct + (j == amt ? ig.cmax_t : 0.f)) * 2;
-        float ax = g * (tx - S[j2 * 3 + 0]), ay = g * (ty - S[j2 * 3 + 1]), az = g * (tz - S[j2 * 3 + 2]);  // own term first
+        float ax = g * (tx - ox), ay = g * (ty - oy), az = g * (tz - oz);  // own term first
+        if (j == (int)blockIdx.y * nwaves) { CS_TL_DRAIN(); CS_TL(3); }
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
             sn_u64 mask = __ballot(is[i] == j);
@@ -605,8 +748,10 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
                 }
             }
         }
+        if (j == (int)blockIdx.y * nwaves) CS_TL(4);
         float qx, qy, qz, asg;
-        soft_bwd_query<true>(sa, b, j, lane, sigma, S, T, qx, qy, qz, asg);
+        soft_bwd_math<true>(sa, b, j, lane, sigma, sq, qx, qy, qz, asg);
+        if (j == (int)blockIdx.y * nwaves) CS_TL(5);
         gsig += asg;
         if (lane < 3) gradT[j + lane * nt] = lane == 0 ? ax + qx : (lane == 1 ? ay + qy : az + qz);
     }
@@ -617,6 +762,8 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
         for (int w2 = 0; w2 < nwaves; ++w2) tot += s_part[w2];
         sa.grad_sigma_partial[(size_t)b * nsplit + blockIdx.y] = tot;
     }
+    CS_TL_DRAIN();
+    CS_TL(6);
 }
 
 // workgroups per cloud of the soft-projection backward kernels; grad_sigma_partial holds b * this many floats
@@ -1336,3 +1483,15 @@ extern "C" int sn_prefix_point_minima(int B, int N, int M, int nprefix, const in
     SN_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef SN_CS_TIMELINE
+// copies the first nblocks x 16 stamps of the last chamfer_soft_bwd_kernel launch to the host and clears them
+extern "C" int sn_debug_chamfer_soft_bwd_timeline(void *host, int nblocks)
+{
+    if (nblocks < 0 || nblocks > 8192) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cs_tl), (size_t)nblocks * 16 * 8) != hipSuccess) return -3;
+    static unsigned long long zeros[8192 * 16];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cs_tl), zeros, sizeof(zeros)) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Phase timeline of the pair-scan kernel as the engine launches it (queries produced by fc4 inside the scan, per-point
-minima combined by atomicMax on keys), from a debug build with -DSN_PS_TIMELINE=1 (stamps only) or =2 (every stamp first
-waits for the memory operations before it, i.e. serialised phases):
+"""Phase timelines of the pair-scan kernel and of the loss backward behind it (chamfer_soft_bwd_kernel) as the engine
+launches them (queries produced by fc4 inside the scan, per-point minima combined by atomicMax on keys), from a debug build
+with -DSN_PS_TIMELINE=L -DSN_CS_TIMELINE=L, L = 1 (stamps only) or 2 (every stamp first waits for the memory operations
+before it, i.e. serialised phases):
 
-    hipcc ... -DSN_PS_TIMELINE=2 pairscan.hip -> a library;   python tools/pairscan_timeline.py <that library> [B]
+    library built with those flags (pairscan.hip, geometry_ops.hip);   python tools/pairscan_timeline.py <that library> [B]
 
 Thread 0 of every workgroup stamps the 100 MHz wall clock; printed: median / p10 / p90 over the workgroups of the time
 between consecutive stamps, in microseconds."""
@@ -68,3 +69,38 @@ for s in range(1, 10):
     d = t[:, s] - t[:, s - 1]
     print("  %-32s +%.2f  (p10 %.2f  p90 %.2f)   at %.2f" % (names[s], np.median(d), np.percentile(d, 10), np.percentile(d, 90),
                                                             np.median(t[:, s] - t0)))
+
+
+# ---- the backward of the loss side behind it
+if hasattr(lib, "sn_debug_chamfer_soft_bwd_timeline"):
+    lib.sn_soft_bwd_splits.restype = ctypes.c_int
+    splits = min(max(1, min((M + 3) // 4, (512 + B - 1) // B)), lib.sn_soft_bwd_splits(B, M))
+    gl = torch.ones(1, device=dev)
+    gQ = torch.zeros(B, 3, M, device=dev)
+    gsig = torch.zeros(B * 64, device=dev)
+    gT, dps, loss = torch.zeros(1, device=dev), torch.zeros(B, device=dev), torch.zeros(2, device=dev)
+    cf = ctypes.c_float
+
+    def bwd():
+        launch()
+        rc = lib.sn_sampler_step_loss_keys(B, N, M, K, P(x), 0, P(Q), P(idx), P(iq), P(keys), P(qpart), P(qmax), G, P(T), cf(1e-2),
+                                           cf(0.01), cf(0.01), cf(1.0), P(gl), P(gQ), P(gsig), P(gT), P(dps), P(loss), st, None)
+        assert rc == 0, rc
+
+    for _ in range(3):
+        bwd()
+    nb = B * splits
+    h2 = np.zeros((nb, 16), dtype=np.uint64)
+    assert lib.sn_debug_chamfer_soft_bwd_timeline(h2.ctypes.data_as(vp), nb) == 0
+    bwd()
+    assert lib.sn_debug_chamfer_soft_bwd_timeline(h2.ctypes.data_as(vp), nb) == 0
+    t = h2.astype(np.float64) / 100.0
+    names = ["start", "keys -> LDS, barrier", "cloud in registers", "query + own term loaded", "matches accumulated",
+             "soft projection backward", "end"]
+    t0 = t[:, 0].min()
+    print("chamfer_soft_bwd_kernel: %d workgroups (%d per cloud); first start -> last end %.2f us; start spread p90 %.2f us" %
+          (nb, splits, t[:, 6].max() - t0, np.percentile(t[:, 0] - t0, 90)))
+    for s_ in range(1, 7):
+        d = t[:, s_] - t[:, s_ - 1]
+        print("  %-32s +%.2f  (p10 %.2f  p90 %.2f)   at %.2f" % (names[s_], np.median(d), np.percentile(d, 10), np.percentile(d, 90),
+                                                                np.median(t[:, s_] - t0)))
