@@ -70,7 +70,6 @@ for s in range(1, 10):
     print("  %-32s +%.2f  (p10 %.2f  p90 %.2f)   at %.2f" % (names[s], np.median(d), np.percentile(d, 10), np.percentile(d, 90),
                                                             np.median(t[:, s] - t0)))
 
-
 # ---- the backward of the loss side behind it
 if hasattr(lib, "sn_debug_chamfer_soft_bwd_timeline"):
     lib.sn_soft_bwd_splits.restype = ctypes.c_int
