@@ -407,6 +407,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
                 } else {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     compact_checked();
+                    if (cnt <= kWave && lane < 16) list[cnt + lane] = kKeyInf;  // (as above: the merges may leave <= 64 entries)
                 }
             } else {
                 compact_checked();
@@ -421,7 +422,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
         // ---- per-query outputs: lanes t < K hold neighbour t (ascending (distance, index)) ----
         sn_u64 key;
         if (SINGLE && cnt <= kWave) {
-            // usual case (~K..3K candidates): one candidate per lane, ranked in registers, moved to lane == rank
+            // usual case (~K..3K candidates): one candidate per lane, ranked by counting, moved to lane == rank
             key = rank_to_lanes(list, cnt, lane);
             cnt = cnt < K ? cnt : K;
             if (lane >= cnt) key = kKeyInf;

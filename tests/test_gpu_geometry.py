@@ -126,10 +126,14 @@ def test_knn_matches_oracle(oracle, cfg, layout):
     assert np.array_equal(d2.cpu().numpy(), od)
 
 
-def test_knn_all_points_identical(oracle):
+@pytest.mark.parametrize("n", [700, 714, 1024])
+def test_knn_all_points_identical(oracle, n):
+    """Every point passes the threshold filter: the candidate list overflows and the compaction falls back to its merging form.
+    n = 714 ends that form with a merge followed by a round of 10 candidates (26 entries: the rank-by-counting path behind a
+    fallback), n = 700 with 140 entries (the merge path), n = 1024 is the variant without bound checks."""
     from samplenet_amd import ops
 
-    P = np.full((2, 700, 3), 0.25, np.float32)
+    P = np.full((2, n, 3), 0.25, np.float32)
     Q = np.random.default_rng(0).random((2, 9, 3), dtype=np.float32)
     od, oi = oracle.knn(16, P, Q)
     idx, d2 = ops.knn(16, dev(P), dev(Q), ops.BNC, ops.BNC)
