@@ -108,11 +108,17 @@ __device__ __forceinline__ void load_chunk(float (&px)[PPL], float (&py)[PPL], f
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
             const int n = c0 + i * kWave + lane;
-            const bool ok = n < N;
-            const sn_xyz v = *reinterpret_cast<const sn_xyz *>(Pb + (size_t)(ok ? n : 0) * 3);
-            px[i] = ok ? v.x : INFINITY;
-            py[i] = ok ? v.y : INFINITY;
-            pz[i] = ok ? v.z : INFINITY;
+            const sn_xyz v = *reinterpret_cast<const sn_xyz *>(Pb + (size_t)(n < N ? n : 0) * 3);
+            px[i] = v.x, py[i] = v.y, pz[i] = v.z;
+        }
+        asm volatile("" ::: "memory");  // all PPL loads in flight before the first select waits for one (in every build: the
+                                        // debug build with the phase stamps otherwise paired each load with its select)
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            const bool ok = c0 + i * kWave + lane < N;
+            px[i] = ok ? px[i] : INFINITY;
+            py[i] = ok ? py[i] : INFINITY;
+            pz[i] = ok ? pz[i] : INFINITY;
         }
         return;
     }
