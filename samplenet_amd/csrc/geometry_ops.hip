@@ -626,8 +626,9 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
-    const int nsplit = fin.loss ? (int)gridDim.y - 1 : (int)gridDim.y;  // the last y-slice only combines the loss value
     CS_TL(0);
+    kernarg_warm_for<long long[7], ImplicitGrad, SoftBwdArgs, StepLossFinal, StepLossFold>();  // (-0.3 us: see sn_common.h)
+    const int nsplit = fin.loss ? (int)gridDim.y - 1 : (int)gridDim.y;  // the last y-slice only combines the loss value
     if ((int)blockIdx.y == nsplit) {
         if (b == 0 && wave == 0) step_loss_final(fin, lane);
         return;
@@ -666,6 +667,8 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
         soft_bwd_load_points(sa, lane, S, sq);
     };
     if (jfirst < nt) load_query(jfirst);
+    CS_TL_DRAIN();
+    CS_TL(8);
 
     if (fold.keys) {
         // nearest query of every point of the cloud, fetched ONCE per workgroup (the four waves all need all of them; keys that
@@ -674,7 +677,9 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
 #pragma unroll
         for (int r = 0; r < (PPL * 64 + 255) / 256; ++r) {
             const int n = threadIdx.x + r * 256;
-            kv[r] = n < ns ? fold.keys[(size_t)b * ns + n] : 0;
+            // (unconditional: the loads leave as ONE batch -- behind a select each waited for the one before it, 1.16 us
+            //  until the keys had landed against 0.36 us now)
+            kv[r] = fold.keys[(size_t)b * ns + (n < ns ? n : ns - 1)];
         }
         sn_u64 mk = 0;
         if (wave == 0) {  // argmax of dist_q: maximum of the (dist_q, ~query) keys of the cloud's scan workgroups
@@ -683,7 +688,13 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
                 mk = v > mk ? v : mk;
             }
         }
+#if defined(SN_CS_TIMELINE) && SN_CS_TIMELINE >= 2  // (the keys alone)
+        CS_TL_DRAIN();
+        CS_TL(11);
+#endif
         if (jfirst < nt) load_dependent();
+        CS_TL_DRAIN();
+        CS_TL(9);
         float sdp = 0.f;
 #pragma unroll
         for (int r = 0; r < (PPL * 64 + 255) / 256; ++r) {  // (ascending n per thread, as a strided loop would visit them)
@@ -708,6 +719,7 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
             }
             if (lane == 0) s_am = (int)(0xFFFFFFFFu - (unsigned)mk);
         }
+        CS_TL(10);
         __syncthreads();
         if (blockIdx.y == 0 && threadIdx.x == 0) fold.dpsum[b] = (s_red[2][0] + s_red[2][1]) + (s_red[2][2] + s_red[2][3]);
     } else if (jfirst < nt) {

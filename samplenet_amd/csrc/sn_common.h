@@ -44,6 +44,42 @@ __device__ __forceinline__ float readlane_f(float v, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// Touches every 64-byte line of the first BYTES bytes of the kernel-argument segment with one batch of scalar loads and waits
+// for them.  The compiler fetches kernel arguments lazily, group by group, next to their first use, and every group is a
+// scalar-memory round trip of its own (~0.2 us each on MI355X: tools/micro/kernarg_latency.hip) in front of the dependent
+// work; with the lines in the scalar cache those later fetches are hits.  Pays where the compiler's fetches are scattered through
+// a latency-bound prologue (loss backward, closing kernel of the step: -0.3 us each, same-box A/B); costs a round trip of its
+// own where they already leave as one batch (the GEMM kernels and the FC chains: 0 .. +0.7 us) -- not used there.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm()
+{
+    auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int L = (BYTES + 63) / 64;
+    static_assert(L >= 1 && L <= 8, "kernarg_warm: 1..8 lines");
+    int d0, d1, d2, d3, d4, d5, d6, d7;
+    // (one asm block: the destination registers stay reserved until the wait inside it)
+    asm volatile(
+        "s_load_dword %0, %8, 0x0\n\t"
+        ".if %9 > 1\n\t s_load_dword %1, %8, 0x40\n\t .endif\n\t"
+        ".if %9 > 2\n\t s_load_dword %2, %8, 0x80\n\t .endif\n\t"
+        ".if %9 > 3\n\t s_load_dword %3, %8, 0xc0\n\t .endif\n\t"
+        ".if %9 > 4\n\t s_load_dword %4, %8, 0x100\n\t .endif\n\t"
+        ".if %9 > 5\n\t s_load_dword %5, %8, 0x140\n\t .endif\n\t"
+        ".if %9 > 6\n\t s_load_dword %6, %8, 0x180\n\t .endif\n\t"
+        ".if %9 > 7\n\t s_load_dword %7, %8, 0x1c0\n\t .endif\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7)
+        : "s"(kp), "n"(L)
+        : "memory");
+}
+
+template <typename... Args>
+__device__ __forceinline__ void kernarg_warm_for()  // the argument types of the kernel (their sizes add up to its segment)
+{
+    constexpr int total = (int)(0 + ... + ((sizeof(Args) + 7) / 8 * 8));
+    kernarg_warm<(total < 512 ? total : 512)>();
+}
+
 // element offset of channel c of point i in a (N,3) [BNC] or (3,N) [BCN] cloud
 __device__ __forceinline__ int pt_off(int layout, int npts, int i, int c)
 {

@@ -99,6 +99,13 @@ if hasattr(lib, "sn_debug_chamfer_soft_bwd_timeline"):
     t0 = t[:, 0].min()
     print("chamfer_soft_bwd_kernel: %d workgroups (%d per cloud); first start -> last end %.2f us; start spread p90 %.2f us" %
           (nb, splits, t[:, 6].max() - t0, np.percentile(t[:, 0] - t0, 90)))
+    if (h2[:, 8] > 0).all():
+        print("  inside the first phase: cloud / scalars / first query requested and landed +%.2f, keys and dependent gathers landed "
+              "+%.2f, keys -> LDS and reductions +%.2f, barrier +%.2f" %
+              tuple(np.median(t[:, b_] - t[:, a_]) for a_, b_ in ((0, 8), (8, 9), (9, 10), (10, 1))))
+    if (h2[:, 11] > 0).all():
+        print("  (keys alone landed +%.2f after the first batch, dependent gathers +%.2f after them)" %
+              (np.median(t[:, 11] - t[:, 8]), np.median(t[:, 9] - t[:, 11])))
     for s_ in range(1, 7):
         d = t[:, s_] - t[:, s_ - 1]
         print("  %-32s +%.2f  (p10 %.2f  p90 %.2f)   at %.2f" % (names[s_], np.median(d), np.percentile(d, 10), np.percentile(d, 90),
