@@ -262,6 +262,26 @@ def test_soft_project_fused_vs_oracle(oracle, cfg):
     np.testing.assert_allclose(float(gT), ogT, rtol=1e-4, atol=1e-5)
 
 
+def test_fused_scan_when_the_batch_fills_the_chip(oracle):
+    """B >= 512: one workgroup per cloud, four waves with 16 queries each (pairscan_dispatch) -- every product of the scan
+    against the oracle on all 512 clouds."""
+    from samplenet_amd import ops
+
+    b, n, m, k = 512, 1024, 64, 8
+    Pn, _ = clouds(91, b, n, m)
+    Qn = (Pn[:, :m] + 0.02 * np.random.default_rng(3).standard_normal((b, m, 3))).astype(np.float32)
+    P = np.ascontiguousarray(Pn.transpose(0, 2, 1))
+    Q = np.ascontiguousarray(Qn.transpose(0, 2, 1))
+    _, oi = oracle.knn(k, Pn, Qn)
+    oproj, _, _ = oracle.softproj_forward(P, Q, oi, 1.0)
+    proj, idx, dq, iq, dp, ip = ops.SoftProjectFunction.apply(dev(P), dev(Q), torch.tensor(1.0, device="cuda"), 1e-2, k, True)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    np.testing.assert_allclose(proj.cpu().numpy(), oproj, rtol=0, atol=1e-6)
+    od = oracle.chamfer_forward(Qn, Pn)
+    assert np.array_equal(dq.cpu().numpy(), od[0]) and np.array_equal(iq.cpu().numpy(), od[1])
+    assert np.array_equal(dp.cpu().numpy(), od[2]) and np.array_equal(ip.cpu().numpy(), od[3])
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_soft_projection_module_matches_reference_golden(golden, tag):
     """All three actions + gradients against outputs of the reference module (tests/golden/make_golden.py)."""
