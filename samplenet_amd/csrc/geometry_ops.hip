@@ -627,7 +627,8 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
     CS_TL(0);
-    kernarg_warm_for<long long[7], ImplicitGrad, SoftBwdArgs, StepLossFinal, StepLossFold>();  // (-0.3 us: see sn_common.h)
+    kernarg_warm_for<24, int, int, const float *, const float *, const int *, const int *, float *, ImplicitGrad, SoftBwdArgs,
+                     StepLossFinal, StepLossFold>();  // (-0.3 us: see sn_common.h)
     const int nsplit = fin.loss ? (int)gridDim.y - 1 : (int)gridDim.y;  // the last y-slice only combines the loss value
     if ((int)blockIdx.y == nsplit) {
         if (b == 0 && wave == 0) step_loss_final(fin, lane);

@@ -4086,7 +4086,8 @@ __global__ void __launch_bounds__(1024) post_bwd_in3_kernel(int nred, int nsplit
                                                             const float *__restrict__ W_in, const float *__restrict__ b_in,
                                                             float *__restrict__ dW_in, MultiRed mr, StepTail tail)
 {
-    kernarg_warm_for<long long[10], BnBwd, MultiRed, StepTail>();  // (-0.3 us: see sn_common.h; no gain in the GEMM kernels)
+    kernarg_warm_for<0, int, int, int, int, const float *, float *, int, int, const float *, BnBwd, const float *, const float *, float *,
+                     MultiRed, StepTail>();  // (-0.3 us: see sn_common.h; no gain in the GEMM kernels)
     // optional riders (engine path): the loss side's scalar tail in two extra workgroups at the end of the grid, and the
     // reset of its key table spread over the reduction workgroups
     if (tail.nparts > 0) {

@@ -73,11 +73,17 @@ __device__ __forceinline__ void kernarg_warm()
         : "memory");
 }
 
-template <typename... Args>
-__device__ __forceinline__ void kernarg_warm_for()  // the argument types of the kernel (their sizes add up to its segment)
+// Args: the kernel's parameter types, in order.  IMPLICIT: bytes of the implicit arguments behind them that the kernel is known
+// to read (a kernel that uses gridDim / blockDim has the three block counts and three group sizes there: 24 bytes); 0 if unsure.
+template <int IMPLICIT, typename... Args>
+__device__ __forceinline__ void kernarg_warm_for()
 {
-    constexpr int total = (int)(0 + ... + ((sizeof(Args) + 7) / 8 * 8));
-    kernarg_warm<(total < 512 ? total : 512)>();
+    // the sizes alone (no padding) add up to a LOWER bound of the explicit argument area, so the last line touched -- the one
+    // that holds byte `total - 4` -- lies inside the segment whatever the layout
+    constexpr int total = (int)(0 + ... + sizeof(Args)) + IMPLICIT;
+    static_assert(total >= 4 && IMPLICIT >= 0 && IMPLICIT <= 24, "kernarg_warm_for: bad sizes");
+    constexpr int lines = (total - 4) / 64 + 1;
+    kernarg_warm<(lines < 8 ? lines : 8) * 64>();
 }
 
 // element offset of channel c of point i in a (N,3) [BNC] or (3,N) [BCN] cloud
