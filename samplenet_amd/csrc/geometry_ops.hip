@@ -493,18 +493,38 @@ __global__ void __launch_bounds__(256) group_point_kernel(int n, int c, int m, i
     }
 }
 
-__global__ void __launch_bounds__(256) group_point_grad_kernel(int n, int c, int m, int ns,
-                                                               const float *__restrict__ grad_out,
-                                                               const int *__restrict__ idx,
-                                                               float *__restrict__ grad_points)
+// Gradient of the two gathers: dst row r = sum of the src entries e whose index names r, added in ASCENDING entry order -- the
+// order of the reference's CPU loops (tf_grouping.cpp's group_point_grad_cpu; its GPU kernels, tf_grouping_g.cu:60-78, use
+// unordered float atomics), hence deterministic and bit-identical to the oracle.  A thread owns one destination row and walks
+// the cloud's ne = m * nsample indices adding the rare hits; no atomics, no memset (every row is written).  Indices outside
+// [0, n) name no row and are ignored.
+//   CHANNEL_MAJOR = false: src (ne, c) / dst (n, c)  [group_point];  true: src (c, ne) / dst (c, n)  [grouping_operation]
+template <bool CHANNEL_MAJOR>
+__global__ void __launch_bounds__(256) index_add_ordered_kernel(int n, int c, int ne, const int *__restrict__ idx,
+                                                                const float *__restrict__ src, float *__restrict__ dst)
 {
-    const int b = blockIdx.y;
-    const size_t tot = (size_t)m * ns * c;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
-        const int l = (int)(e % c);
-        const size_t jk = e / c;
-        const int ii = idx[(size_t)b * m * ns + jk];
-        atomicAdd(&grad_points[((size_t)b * n + ii) * c + l], grad_out[(size_t)b * tot + e]);
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int row0 = blockIdx.x * 256 + (threadIdx.x & ~63);  // this wave's 64 rows
+    const int row = row0 + lane;
+    const bool live = row < n;
+    idx += (size_t)b * ne;
+    src += (size_t)b * ne * c;
+    dst += (size_t)b * n * c;
+    auto d = [&](int l) -> float & { return dst[CHANNEL_MAJOR ? (size_t)l * n + row : (size_t)row * c + l]; };
+    if (live)
+        for (int l = 0; l < c; ++l) d(l) = 0.f;
+    // 64 indices per trip (one coalesced load); the wave then visits, in ascending order, only the entries that name one of
+    // ITS rows (on average one in n / 64), each handled by the lane that owns the row
+    for (int e0 = 0; e0 < ne; e0 += 64) {
+        const int mine = e0 + lane < ne ? idx[e0 + lane] : -1;
+        sn_u64 hits = __ballot((unsigned)(mine - row0) < 64u);
+        while (hits) {
+            const int t = __builtin_ctzll(hits);
+            hits &= hits - 1;
+            const int id = __builtin_amdgcn_readlane(mine, t), e = e0 + t;
+            if (live && id == row)
+                for (int l = 0; l < c; ++l) d(l) += src[CHANNEL_MAJOR ? (size_t)l * ne + e : (size_t)e * c + l];
+        }
     }
 }
 
@@ -519,21 +539,6 @@ __global__ void __launch_bounds__(256) grouping_operation_kernel(int c, int n, i
         const size_t jk = e % mk;
         const int ii = idx[(size_t)b * mk + jk];
         out[(size_t)b * tot + e] = feat[((size_t)b * c + ch) * n + ii];
-    }
-}
-
-__global__ void __launch_bounds__(256) grouping_operation_grad_kernel(int c, int n, int m, int ns,
-                                                                      const float *__restrict__ grad_out,
-                                                                      const int *__restrict__ idx,
-                                                                      float *__restrict__ grad_feat)
-{
-    const int b = blockIdx.y;
-    const size_t mk = (size_t)m * ns, tot = (size_t)c * mk;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(e / mk);
-        const size_t jk = e % mk;
-        const int ii = idx[(size_t)b * mk + jk];
-        atomicAdd(&grad_feat[((size_t)b * c + ch) * n + ii], grad_out[(size_t)b * tot + e]);
     }
 }
 
@@ -1075,13 +1080,9 @@ extern "C" int sn_group_point_grad(int b, int n, int c, int m, int nsample, cons
     SN_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 0 && nsample >= 0, "negative size");
     if (b == 0 || (size_t)n * c == 0) return 0;
     SN_REQUIRE(grad_points, "null pointer");
-    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, (hipStream_t)stream);
-    if (e != hipSuccess) return sn_set_error((int)e, "sn_group_point_grad: %s", hipGetErrorString(e));
-    const size_t tot = (size_t)m * nsample * c;
-    if (tot == 0) return 0;
-    SN_REQUIRE(grad_out && idx, "null pointer");
-    hipLaunchKernelGGL(group_point_grad_kernel, dim3(grid_for(tot), b), dim3(256), 0, (hipStream_t)stream, n, c, m,
-                       nsample, grad_out, idx, grad_points);
+    SN_REQUIRE((size_t)m * nsample == 0 || (grad_out && idx), "null pointer");
+    hipLaunchKernelGGL(index_add_ordered_kernel<false>, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, c,
+                       m * nsample, idx, grad_out, grad_points);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -1105,13 +1106,9 @@ extern "C" int sn_grouping_operation_grad(int b, int c, int n, int m, int nsampl
     SN_REQUIRE(b >= 0 && n >= 0 && c >= 0 && m >= 0 && nsample >= 0, "negative size");
     if (b == 0 || (size_t)n * c == 0) return 0;
     SN_REQUIRE(grad_features, "null pointer");
-    hipError_t e = hipMemsetAsync(grad_features, 0, sizeof(float) * (size_t)b * n * c, (hipStream_t)stream);
-    if (e != hipSuccess) return sn_set_error((int)e, "sn_grouping_operation_grad: %s", hipGetErrorString(e));
-    const size_t tot = (size_t)m * nsample * c;
-    if (tot == 0) return 0;
-    SN_REQUIRE(grad_out && idx, "null pointer");
-    hipLaunchKernelGGL(grouping_operation_grad_kernel, dim3(grid_for(tot), b), dim3(256), 0, (hipStream_t)stream, c,
-                       n, m, nsample, grad_out, idx, grad_features);
+    SN_REQUIRE((size_t)m * nsample == 0 || (grad_out && idx), "null pointer");
+    hipLaunchKernelGGL(index_add_ordered_kernel<true>, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, c,
+                       m * nsample, idx, grad_out, grad_features);
     SN_LAUNCH_CHECK();
     return 0;
 }
