@@ -528,6 +528,27 @@ __global__ void __launch_bounds__(256) index_add_ordered_kernel(int n, int c, in
     }
 }
 
+// Large gathers (PointNet++-sized grouping: n and m * nsample both in the tens of thousands): the ordered scan above costs
+// (n / 64) * ne index loads per cloud, so beyond kIndexAddOrderedWork the gradient is scattered with float atomics into a
+// zeroed destination -- what the reference's own GPU kernels do (tf_grouping_g.cu:60-78): same sums, unordered additions.
+constexpr long long kIndexAddOrderedWork = 1ll << 26;
+template <bool CHANNEL_MAJOR>
+__global__ void __launch_bounds__(256) index_add_atomic_kernel(int n, int c, long long ne, const int *__restrict__ idx,
+                                                               const float *__restrict__ src, float *__restrict__ dst)
+{
+    const int b = blockIdx.y;
+    idx += (size_t)b * ne;
+    src += (size_t)b * ne * c;
+    dst += (size_t)b * n * c;
+    const size_t tot = (size_t)ne * c;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = CHANNEL_MAJOR ? t % (size_t)ne : t / c;
+        const int l = (int)(CHANNEL_MAJOR ? t / (size_t)ne : t % c);
+        const int row = idx[e];
+        if ((unsigned)row < (unsigned)n) atomicAdd(&dst[CHANNEL_MAJOR ? (size_t)l * n + row : (size_t)row * c + l], src[t]);
+    }
+}
+
 __global__ void __launch_bounds__(256) grouping_operation_kernel(int c, int n, int m, int ns,
                                                                  const float *__restrict__ feat,
                                                                  const int *__restrict__ idx, float *__restrict__ out)
@@ -1061,6 +1082,25 @@ extern "C" int sn_weighted_gather_backward(int b, int c, int n, int m, int k, co
     return 0;
 }
 
+// dst (b, n, c) [or (b, c, n)] = index-add of src over idx (b, ne): ordered and deterministic up to kIndexAddOrderedWork
+// index loads per cloud, float atomics into a zeroed destination beyond
+template <bool CHANNEL_MAJOR>
+static int launch_index_add(int b, int n, int c, long long ne, const int *idx, const float *src, float *dst, hipStream_t st)
+{
+    SN_REQUIRE(ne <= 0x7fffffffll, "m * nsample must fit in 31 bits");
+    if ((long long)((n + 63) / 64) * ne <= kIndexAddOrderedWork) {
+        hipLaunchKernelGGL(index_add_ordered_kernel<CHANNEL_MAJOR>, dim3((n + 255) / 256, b), dim3(256), 0, st, n, c, (int)ne, idx,
+                           src, dst);
+    } else {
+        const hipError_t e = hipMemsetAsync(dst, 0, (size_t)b * n * c * sizeof(float), st);
+        if (e != hipSuccess) return sn_set_error((int)e, "%s: %s", __func__, hipGetErrorString(e));
+        hipLaunchKernelGGL(index_add_atomic_kernel<CHANNEL_MAJOR>, dim3(grid_for((size_t)ne * c), b), dim3(256), 0, st, n, c, ne,
+                           idx, src, dst);
+    }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sn_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
                               float *out, sn_stream_t stream)
 {
@@ -1081,10 +1121,7 @@ extern "C" int sn_group_point_grad(int b, int n, int c, int m, int nsample, cons
     if (b == 0 || (size_t)n * c == 0) return 0;
     SN_REQUIRE(grad_points, "null pointer");
     SN_REQUIRE((size_t)m * nsample == 0 || (grad_out && idx), "null pointer");
-    hipLaunchKernelGGL(index_add_ordered_kernel<false>, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, c,
-                       m * nsample, idx, grad_out, grad_points);
-    SN_LAUNCH_CHECK();
-    return 0;
+    return launch_index_add<false>(b, n, c, (long long)m * nsample, idx, grad_out, grad_points, (hipStream_t)stream);
 }
 
 extern "C" int sn_grouping_operation(int b, int c, int n, int m, int nsample, const float *features,
@@ -1107,10 +1144,7 @@ extern "C" int sn_grouping_operation_grad(int b, int c, int n, int m, int nsampl
     if (b == 0 || (size_t)n * c == 0) return 0;
     SN_REQUIRE(grad_features, "null pointer");
     SN_REQUIRE((size_t)m * nsample == 0 || (grad_out && idx), "null pointer");
-    hipLaunchKernelGGL(index_add_ordered_kernel<true>, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n, c,
-                       m * nsample, idx, grad_out, grad_features);
-    SN_LAUNCH_CHECK();
-    return 0;
+    return launch_index_add<true>(b, n, c, (long long)m * nsample, idx, grad_out, grad_features, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------

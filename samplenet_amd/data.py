@@ -124,220 +124,222 @@ def load_ply(file_name, with_faces=False, with_color=False):
 
 
 def files_in_subdirs(top_dir, search_pattern):
-    regex = re.compile(search_pattern)
-    for path, _, files in os.walk(top_dir):
-        for name in files:
-            full_name = osp.join(path, name)
-            if regex.search(full_name):
-                yield full_name
+    """Every file below top_dir whose full path matches the regular expression (in_out.py:134-140), in os.walk order."""
+    matches = re.compile(search_pattern).search
+    for folder, _, names in os.walk(top_dir):
+        yield from filter(matches, (osp.join(folder, n) for n in names))
 
 
 def pc_loader(f_name):
     """Point cloud saved under ShapeNet's folder scheme /syn_id/model_name.ply -> (points, model_id, syn_id)  (in_out.py:166-173)."""
-    tokens = f_name.split("/")
-    return load_ply(f_name), tokens[-1].split(".")[0], tokens[-2]
+    folder, leaf = osp.split(f_name)
+    return load_ply(f_name), leaf.split(".")[0], osp.basename(folder)
 
 
 def load_point_clouds_from_filenames(file_names, n_threads, loader, verbose=False):
-    """in_out.py:220-243 (the reference fans the files out over a multiprocessing.Pool; a thread pool gives the same order
-    without forking a process that holds a GPU context)."""
+    """-> (clouds (files, points, 3) float32, model names, class ids) in the order of file_names (in_out.py:220-243; the
+    reference fans the files out over a multiprocessing.Pool -- a thread pool keeps the order without forking a process that
+    holds a GPU context)."""
     from concurrent.futures import ThreadPoolExecutor
 
-    pc = loader(file_names[0])[0]
-    pclouds = np.empty([len(file_names), pc.shape[0], pc.shape[1]], dtype=np.float32)
-    model_names = np.empty([len(file_names)], dtype=object)
-    class_ids = np.empty([len(file_names)], dtype=object)
     with ThreadPoolExecutor(max_workers=max(1, int(n_threads))) as pool:
-        for i, data in enumerate(pool.map(loader, file_names)):
-            pclouds[i, :, :], model_names[i], class_ids[i] = data
-    if len(np.unique(model_names)) != len(pclouds):
+        loaded = list(pool.map(loader, file_names))
+    pclouds = np.stack([np.asarray(pc, dtype=np.float32) for pc, _, _ in loaded])
+    model_names = np.array([m for _, m, _ in loaded], dtype=object)
+    class_ids = np.array([c for _, _, c in loaded], dtype=object)
+    if len(set(model_names.tolist())) != len(loaded):
         warnings.warn("Point clouds with the same model name were loaded.")
     if verbose:
-        print("{0} pclouds were loaded. They belong in {1} shape-classes.".format(len(pclouds), len(np.unique(class_ids))))
+        print("{0} pclouds were loaded. They belong in {1} shape-classes.".format(len(loaded), len(set(class_ids.tolist()))))
     return pclouds, model_names, class_ids
 
 
+def _legacy_permutation(n, seed=None):
+    """A permutation of range(n) from numpy's GLOBAL legacy generator, consuming it exactly as the reference's
+    `perm = np.arange(n); np.random.shuffle(perm)` does (RandomState.permutation(int) is that pair of calls), after an
+    optional re-seed: the reconstruction scripts' splits and epoch orders depend on this stream."""
+    if seed is not None:
+        np.random.seed(seed)
+    return np.random.permutation(n)
+
+
 def split_data(data, split, seed, perm=None):
-    """in_out.py:246-275: the same np.random call sequence, hence the same permutation for a seed."""
-    assert sum(split) == 1.0, "data split does not sum to 1: %.2f" % sum(split)
-    num_examples = data.shape[0]
-    if perm is not None:
-        assert perm.shape[0] == data.shape[0], "perm.shape: %s data.shape: %s" % (perm.shape, data.shape)
-    else:
-        if seed is not None:
-            np.random.seed(seed)
-        perm = np.arange(num_examples)
-        np.random.shuffle(perm)
-    data = data[perm]
-    train_end = int(round(split[0] * num_examples))
-    val_end = int(round((split[0] + split[1]) * num_examples))
-    train_data, val_data, test_data = data[:train_end], data[train_end:val_end], data[val_end:]
-    counts = [train_data.shape[0], val_data.shape[0], test_data.shape[0]]
-    assert sum(counts) == num_examples, "data split (%d, %d, %d) does not sum to num_examples (%d)" % (*counts, num_examples)
-    return train_data, val_data, test_data, perm
+    """(train, val, test, perm): rows of `data` permuted (by `perm`, or by the seeded global generator) and cut at the
+    rounded cumulative fractions of `split`  (in_out.py:246-275)."""
+    n = data.shape[0]
+    if abs(sum(split) - 1.0) > 0:
+        raise AssertionError("data split does not sum to 1: %.2f" % sum(split))
+    if perm is None:
+        perm = _legacy_permutation(n, seed)
+    elif perm.shape[0] != n:
+        raise AssertionError("perm.shape: %s data.shape: %s" % (perm.shape, data.shape))
+    cuts = [int(round(split[0] * n)), int(round((split[0] + split[1]) * n))]
+    train, val, test = np.split(data[perm], cuts)
+    if train.shape[0] + val.shape[0] + test.shape[0] != n:
+        raise AssertionError("data split (%d, %d, %d) does not sum to num_examples (%d)" % (train.shape[0], val.shape[0], test.shape[0], n))
+    return train, val, test, perm
 
 
 class PointCloudDataSet(object):
-    """in_out.py:278-403 (MNIST-style epoch iterator over an (n, points, 3) array; labels; optional noisy copies)."""
+    """Epoch iterator over an (examples, points, 3) array with labels and optional noisy copies: the interface of
+    in_out.py:278-403 (attributes point_clouds / labels / noisy_point_clouds / num_examples / n_points / epochs_completed;
+    shuffle_data, shuffle_points, next_batch, full_epoch_data, merge), drawing from numpy's global generator in the same
+    order so that a seeded run visits the same batches."""
 
     def __init__(self, point_clouds, noise=None, labels=None, copy=True, init_shuffle=True):
-        self.num_examples = point_clouds.shape[0]
-        self.n_points = point_clouds.shape[1]
-        if labels is not None:
-            assert point_clouds.shape[0] == labels.shape[0], "points.shape: %s labels.shape: %s" % (point_clouds.shape, labels.shape)
-            self.labels = labels.copy() if copy else labels
-        else:
+        own = (lambda a: a.copy()) if copy else (lambda a: a)
+        self.num_examples, self.n_points = point_clouds.shape[0], point_clouds.shape[1]
+        if labels is None:
             self.labels = np.ones(self.num_examples, dtype=np.int8)
-        if noise is not None:
-            assert type(noise) is np.ndarray
-            self.noisy_point_clouds = noise.copy() if copy else noise
         else:
-            self.noisy_point_clouds = None
-        self.point_clouds = point_clouds.copy() if copy else point_clouds
-        self.epochs_completed = 0
-        self._index_in_epoch = 0
+            if labels.shape[0] != self.num_examples:
+                raise AssertionError("points.shape: %s labels.shape: %s" % (point_clouds.shape, labels.shape))
+            self.labels = own(labels)
+        if noise is not None and not isinstance(noise, np.ndarray):
+            raise AssertionError("noise must be a numpy array")
+        self.noisy_point_clouds = None if noise is None else own(noise)
+        self.point_clouds = own(point_clouds)
+        self.epochs_completed, self._cursor = 0, 0
         if init_shuffle:
             self.shuffle_data()
 
+    def _rows(self, order):
+        noisy = None if self.noisy_point_clouds is None else self.noisy_point_clouds[order]
+        return self.point_clouds[order], self.labels[order], noisy
+
     def shuffle_data(self, seed=None):
-        if seed is not None:
-            np.random.seed(seed)
-        perm = np.arange(self.num_examples)
-        np.random.shuffle(perm)
-        self.point_clouds = self.point_clouds[perm]
-        self.labels = self.labels[perm]
-        if self.noisy_point_clouds is not None:
-            self.noisy_point_clouds = self.noisy_point_clouds[perm]
+        """Re-orders the examples (clouds, labels and noisy copies alike)."""
+        self.point_clouds, self.labels, self.noisy_point_clouds = self._rows(_legacy_permutation(self.num_examples, seed))
         return self
 
     def shuffle_points(self, seed=None):
+        """Re-orders the points inside every cloud.  The reference keeps ONE index vector and shuffles it again for each
+        example, so example i's order is the composition of i + 1 shuffles: the orders are drawn first, then applied at once."""
         if seed is not None:
             np.random.seed(seed)
-        perm = np.arange(self.n_points)
-        for i in range(self.num_examples):
-            np.random.shuffle(perm)
-            self.point_clouds[i, :, :] = self.point_clouds[i, perm, :]
-            if self.noisy_point_clouds is not None:
-                self.noisy_point_clouds[i, :, :] = self.noisy_point_clouds[i, perm, :]
+        walk = np.arange(self.n_points)
+        order = np.empty((self.num_examples, self.n_points), dtype=np.intp)
+        for row in order:
+            np.random.shuffle(walk)
+            row[:] = walk
+        self.point_clouds = np.take_along_axis(self.point_clouds, order[:, :, None], axis=1)
+        if self.noisy_point_clouds is not None:
+            self.noisy_point_clouds = np.take_along_axis(self.noisy_point_clouds, order[:, :, None], axis=1)
         return self
 
     def next_batch(self, batch_size, seed=None):
-        """The next batch_size examples: (point_clouds, labels, noisy_point_clouds | None)."""
-        start = self._index_in_epoch
-        self._index_in_epoch += batch_size
-        if self._index_in_epoch > self.num_examples:
+        """(point_clouds, labels, noisy_point_clouds | None) of the next batch_size examples; an epoch that cannot supply a
+        full batch ends: the data are re-shuffled and the batch is taken from the start."""
+        if self._cursor + batch_size > self.num_examples:
             self.epochs_completed += 1
             self.shuffle_data(seed)
-            start = 0
-            self._index_in_epoch = batch_size
-        end = self._index_in_epoch
-        noisy = None if self.noisy_point_clouds is None else self.noisy_point_clouds[start:end]
-        return self.point_clouds[start:end], self.labels[start:end], noisy
+            self._cursor = 0
+        window = slice(self._cursor, self._cursor + batch_size)
+        self._cursor += batch_size
+        return self._rows(window)
 
     def full_epoch_data(self, shuffle=True, seed=None):
-        if shuffle and seed is not None:
-            np.random.seed(seed)
-        perm = np.arange(self.num_examples)
-        if shuffle:
-            np.random.shuffle(perm)
-        ns = None if self.noisy_point_clouds is None else self.noisy_point_clouds[perm]
-        return self.point_clouds[perm], self.labels[perm], ns
+        """The whole set at once (optionally in a fresh random order; the set's own order is untouched)."""
+        order = _legacy_permutation(self.num_examples, seed) if shuffle else np.arange(self.num_examples)
+        return self._rows(order)
 
     def merge(self, other_data_set):
-        self._index_in_epoch = 0
-        self.epochs_completed = 0
-        self.point_clouds = np.vstack((self.point_clouds, other_data_set.point_clouds))
-        labels_1 = self.labels.reshape([self.num_examples, 1])
-        labels_2 = other_data_set.labels.reshape([other_data_set.num_examples, 1])
-        self.labels = np.squeeze(np.vstack((labels_1, labels_2)))
+        """Appends another set's examples; the epoch state starts over."""
+        self.epochs_completed, self._cursor = 0, 0
+        self.point_clouds = np.concatenate([self.point_clouds, other_data_set.point_clouds], axis=0)
+        self.labels = np.concatenate([self.labels.reshape(self.num_examples), other_data_set.labels.reshape(other_data_set.num_examples)])
         if self.noisy_point_clouds is not None:
-            self.noisy_point_clouds = np.vstack((self.noisy_point_clouds, other_data_set.noisy_point_clouds))
+            self.noisy_point_clouds = np.concatenate([self.noisy_point_clouds, other_data_set.noisy_point_clouds], axis=0)
         self.num_examples = self.point_clouds.shape[0]
         return self
 
+    # (name the reference's scripts may poke at)
+    @property
+    def _index_in_epoch(self):
+        return self._cursor
+
+
+def _folder_clouds(top_dir, n_threads, file_ending, verbose):
+    names = list(files_in_subdirs(top_dir, file_ending))
+    return load_point_clouds_from_filenames(names, n_threads, loader=pc_loader, verbose=verbose)
+
 
 def load_all_point_clouds_under_folder(top_dir, n_threads=20, file_ending=".ply", verbose=False):
-    file_names = [f for f in files_in_subdirs(top_dir, file_ending)]
-    pclouds, model_ids, syn_ids = load_point_clouds_from_filenames(file_names, n_threads, loader=pc_loader, verbose=verbose)
+    """One PointCloudDataSet over every cloud below top_dir, labelled "<syn_id>_<model_id>"  (in_out.py:176-182)."""
+    pclouds, model_ids, syn_ids = _folder_clouds(top_dir, n_threads, file_ending, verbose)
     return PointCloudDataSet(pclouds, labels=syn_ids + "_" + model_ids, init_shuffle=False)
 
 
 def load_and_split_all_point_clouds_under_folder(top_dir, n_threads=20, file_ending=".ply", split=(0.85, 0.05, 0.10), seed=42,
                                                  verbose=False):
-    file_names = [f for f in files_in_subdirs(top_dir, file_ending)]
-    pclouds, model_ids, syn_ids = load_point_clouds_from_filenames(file_names, n_threads, loader=pc_loader, verbose=verbose)
-    pc_tr, pc_va, pc_te, perm = split_data(pclouds, split, seed)
-    mi_tr, mi_va, mi_te, _ = split_data(model_ids, split, seed, perm)
-    si_tr, si_va, si_te, _ = split_data(syn_ids, split, seed, perm)
-    return (PointCloudDataSet(pc_tr, labels=si_tr + "_" + mi_tr, init_shuffle=False),
-            PointCloudDataSet(pc_va, labels=si_va + "_" + mi_va, init_shuffle=False),
-            PointCloudDataSet(pc_te, labels=si_te + "_" + mi_te, init_shuffle=False))
+    """(train, val, test) PointCloudDataSets: one seeded permutation applied to clouds and labels  (in_out.py:185-217)."""
+    pclouds, model_ids, syn_ids = _folder_clouds(top_dir, n_threads, file_ending, verbose)
+    labels = syn_ids + "_" + model_ids
+    *clouds, perm = split_data(pclouds, split, seed)
+    *names, _ = split_data(labels, split, seed, perm)
+    return tuple(PointCloudDataSet(pc, labels=lb, init_shuffle=False) for pc, lb in zip(clouds, names))
 
 
 # ----------------------------------------------------------------------------------------------------- ModelNet40 (HDF5)
-def _get_data_files(list_filename):
-    with open(list_filename) as f:
-        return [line.rstrip()[5:] for line in f]
-
-
-def _load_data_file(name):
-    import h5py  # like the reference; not part of the build image (ModelNetCls raises ImportError there)
-
-    with h5py.File(name, "r") as f:
+def _h5_shard(path):
+    """(data (clouds, 2048, 3) float32, label (clouds, 1)) of one `ply_data_*.h5` shard -- through h5py like the reference
+    (registration/data/modelnet_loader_torch.py:26-30).  h5py is not part of this image: pass `shard_reader=` to ModelNetCls
+    to read shards converted to another container (tests use .npz twins of the same two arrays)."""
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("ModelNetCls reads HDF5 shards through h5py (not installed); convert the shards and pass "
+                          "shard_reader=, e.g. lambda p: (np.load(p)['data'], np.load(p)['label'])") from e
+    with h5py.File(path, "r") as f:
         return f["data"][:], f["label"][:]
 
 
 class ModelNetCls(object):
-    """registration/data/modelnet_loader_torch.py:32-127: ModelNet40 point clouds from the `modelnet40_ply_hdf5_2048` shards.
-    A map-style dataset (__getitem__ / __len__: usable with torch.utils.data.DataLoader as the reference's is).  The shards
-    must already be on disk under `base_dir` (the reference downloads them with curl; there is no network here:
-    download=True raises)."""
+    """ModelNet40 clouds from the `modelnet40_ply_hdf5_2048` shards as a map-style dataset (__getitem__ / __len__ for
+    torch.utils.data.DataLoader): constructor arguments, attributes (points, labels, num_points, classes, class_to_idx, shapes)
+    and item convention of registration/data/modelnet_loader_torch.py:32-127.  Every item is a fresh random subset / order of
+    its cloud's first num_points points (numpy's global generator, as the reference).  The shards must be on disk under
+    base_dir/folder (no network here: download=True only changes the error text).
+    shard_reader (new): callable path -> (data, label); default = h5py."""
 
     def __init__(self, num_points, transforms, train, download=False, cinfo=None, folder="modelnet10_hdf5_2048", url=None,
-                 include_shapes=False, base_dir=None):
-        self.transforms = transforms
-        self.folder = folder
+                 include_shapes=False, base_dir=None, shard_reader=None):
         base_dir = base_dir or os.getcwd()
-        self.data_dir = os.path.join(base_dir, self.folder)
-        if not os.path.exists(self.data_dir):
-            raise FileNotFoundError("ModelNet shards not found under %s%s" % (
-                self.data_dir, " (downloading is not supported: fetch %s there)" % url if download else ""))
-        self.train = train
-        self.files = _get_data_files(os.path.join(self.data_dir, "train_files.txt" if train else "test_files.txt"))
-        point_list, label_list = [], []
-        for f in self.files:
-            points, labels = _load_data_file(os.path.join(base_dir, f))
-            point_list.append(points)
-            label_list.append(labels)
-        self.points = np.concatenate(point_list, 0)
-        self.labels = np.concatenate(label_list, 0)
-        if np.ndim(self.labels) == 1:
-            self.labels = np.expand_dims(self.labels, axis=1)
+        self.transforms, self.folder, self.train = transforms, folder, train
+        self.data_dir = osp.join(base_dir, folder)
+        if not osp.isdir(self.data_dir):
+            hint = " (downloading is not supported: fetch %s there)" % url if download else ""
+            raise FileNotFoundError("ModelNet shards not found under %s%s" % (self.data_dir, hint))
+        split = "train" if train else "test"
+        with open(osp.join(self.data_dir, split + "_files.txt")) as f:
+            # the list files name the shards relative to a "data/" folder: "data/modelnet40_ply_hdf5_2048/ply_data_train0.h5"
+            self.files = [line.rstrip()[len("data/"):] for line in f if line.strip()]
+        read = shard_reader or _h5_shard
+        shards = [read(osp.join(base_dir, name)) for name in self.files]
+        self.points = np.concatenate([d for d, _ in shards], axis=0)
+        labels = np.concatenate([np.asarray(l) for _, l in shards], axis=0)
+        self.labels = labels[:, None] if labels.ndim == 1 else labels
         self.set_num_points(num_points)
         self.classes, self.class_to_idx = cinfo if cinfo is not None else (None, None)
-        self.shapes = []
         self.include_shapes = include_shapes
-        if self.include_shapes:
-            T = "train" if self.train else "test"
+        self.shapes = []
+        if include_shapes:
             for n in range(len(self.files)):
-                with open(os.path.join(self.data_dir, "ply_data_%s_%d_id2file.json" % (T, n)), "r") as f:
-                    self.shapes += json.load(f)
+                with open(osp.join(self.data_dir, "ply_data_%s_%d_id2file.json" % (split, n))) as f:
+                    self.shapes.extend(json.load(f))
+
+    def __len__(self):
+        return self.points.shape[0]
 
     def __getitem__(self, idx):
         import torch
 
-        pt_idxs = np.arange(0, self.num_points)
-        np.random.shuffle(pt_idxs)
-        current_points = self.points[idx, pt_idxs].copy()
-        label = torch.from_numpy(self.labels[idx]).type(torch.LongTensor)
+        order = np.random.permutation(self.num_points)  # (= arange + shuffle on the global generator)
+        cloud = self.points[idx, order].copy()
         if self.transforms is not None:
-            current_points = self.transforms(current_points)
-        if self.include_shapes:
-            return current_points, label, self.shapes[idx]
-        return current_points, label
-
-    def __len__(self):
-        return self.points.shape[0]
+            cloud = self.transforms(cloud)
+        label = torch.from_numpy(self.labels[idx]).type(torch.LongTensor)
+        return (cloud, label, self.shapes[idx]) if self.include_shapes else (cloud, label)
 
     def set_num_points(self, pts):
         self.num_points = min(self.points.shape[1], pts)
@@ -359,6 +361,7 @@ class DeviceBatchRing(object):
             ring.load((i + 1) % depth, ds.next_batch(B)[0])
             ring.ready(i)
             step.replay(i)
+            ring.release(i)      # the next load(i) must wait for this replay (an unreleased slot is overwritten under it)
     """
 
     def __init__(self, batch, n_points, device, depth=2):

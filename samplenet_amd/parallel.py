@@ -48,15 +48,23 @@ class FlatGradAllReducer:
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         # the HIP MLP writes its gradients itself; anything else (the CPU model of the gloo test) goes through autograd
         hip_mlp = bool(getattr(module, "use_hip_mlp", False)) and dev.type == "cuda"
+        # ... and of the HIP model only the parameters the MLP node differentiates (pointnet.param_order): a BatchNorm behind
+        # the last FC layer (classification sampler) is applied by torch on the head's output, its gradients come through
+        # autograd like the temperature's and must be zeroed / re-bound with them
+        kernel_written = set()
+        if hip_mlp:
+            from .pointnet import param_order
+
+            kernel_written = set(param_order(module))
         sink, off = {}, 0
         self._autograd = []  # (parameter, view): gradients that arrive through autograd's accumulate
         for n, p in order:
             view = self.flat[off:off + p.numel()].view_as(p)
             p.grad = view
-            if n.startswith("project") or not hip_mlp:
-                self._autograd.append((p, view))
-            else:
+            if n in kernel_written:
                 sink[n] = view
+            else:
+                self._autograd.append((p, view))
             off += p.numel()
         if sink:
             from .pointnet import GradSink
@@ -107,6 +115,14 @@ class FlatGradAllReducer:
             else:
                 view.copy_(g)
             p.grad = view
+        # the kernel-written views: after optimizer.zero_grad(set_to_none=True) a graph REPLAY has filled them without any
+        # Python running (GradSink.commit re-binds only while the backward executes eagerly or is being captured)
+        sink = getattr(self.module, "_grad_sink", None)
+        if sink is not None:
+            for n, view in sink.items():
+                p = sink.params[n]
+                if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                    p.grad = view
 
     # ---------------------------------------------------------------------------------------- collectives
     def _op(self):

@@ -21,6 +21,8 @@ with ast (the numbers are parsed, not retyped):
 """
 import ast
 import importlib
+import importlib.util
+import json
 import os
 import sys
 import types
@@ -440,6 +442,53 @@ def golden_loaders():
     save("loaders_reference.npz", **out)
 
 
+def golden_modelnet():
+    """Row f4 (registration/data/modelnet_loader_torch.py): the reference's ModelNetCls run on a tiny shard set.  h5py is not
+    installed here, so the module is imported with a stand-in `h5py` whose File(name) opens the .npz twin of a shard (same two
+    arrays, "data" and "label"); everything else -- file lists, concatenation, label shape, per-item point order from numpy's
+    global generator, the id2file shape names -- is the reference's own code.  Fixture tree: tests/golden/modelnet/."""
+    import shutil
+    import types
+
+    root = os.path.join(HERE, "modelnet")
+    folder = "modelnet40_ply_hdf5_2048"
+    shutil.rmtree(root, ignore_errors=True)
+    os.makedirs(os.path.join(root, folder))
+    rng = np.random.default_rng(17)
+    shards = {"train": [(5, 2), (4, 2)], "test": [(3, 1)]}  # (clouds, label ndim) per shard
+    for split, specs in shards.items():
+        names = []
+        for i, (n, nd) in enumerate(specs):
+            name = "ply_data_%s%d.npz" % (split, i)
+            lab = rng.integers(0, 40, (n, 1) if nd == 2 else (n,)).astype(np.uint8)
+            np.savez(os.path.join(root, folder, name), data=(rng.random((n, 40, 3), dtype=np.float32) - 0.5), label=lab)
+            names.append("data/%s/%s" % (folder, name))
+            with open(os.path.join(root, folder, "ply_data_%s_%d_id2file.json" % (split, i)), "w") as f:
+                json.dump(["%s/shape_%d_%d.ply" % (split, i, j) for j in range(n)], f)
+        with open(os.path.join(root, folder, split + "_files.txt"), "w") as f:
+            f.write("\n".join(names) + "\n")
+    fake = types.ModuleType("h5py")
+    fake.File = lambda name, *a, **k: np.load(name)
+    sys.modules["h5py"] = fake
+    try:
+        spec = importlib.util.spec_from_file_location("ref_modelnet_loader", os.path.join(REF, "registration/data/modelnet_loader_torch.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        del sys.modules["h5py"]
+    mod.BASE_DIR = root
+    out = {}
+    for split, train in (("train", True), ("test", False)):
+        ds = mod.ModelNetCls(24, None, train=train, download=False, folder=folder, include_shapes=True)
+        np.random.seed(5)
+        items = [ds[i] for i in range(len(ds))]
+        out[split + "_points"] = np.stack([it[0] for it in items])
+        out[split + "_labels"] = np.stack([it[1].numpy() for it in items])
+        out[split + "_shapes"] = np.array([it[2] for it in items])
+        out[split + "_all_points"], out[split + "_all_labels"] = ds.points, ds.labels
+    save("modelnet_reference.npz", **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference checkout not found: " + REF
     O.build(ref=True)
@@ -450,7 +499,7 @@ if __name__ == "__main__":
     jobs = {"known": golden_known_answers, "softproj": lambda: golden_softproj(sp_mod.SoftProjection),
             "chamfer": lambda: golden_chamfer(ChamferDistance), "samplenet": lambda: golden_samplenet(sn_mod.SampleNet),
             "c2": lambda: golden_samplenet_c2(sn_mod.SampleNet), "nn_matching": lambda: golden_nn_matching(sputils),
-            "pcrnet": lambda: golden_pcrnet(ChamferDistance), "loaders": golden_loaders}
+            "pcrnet": lambda: golden_pcrnet(ChamferDistance), "loaders": golden_loaders, "modelnet": golden_modelnet}
     for name in (sys.argv[1:] or list(jobs)):  # python make_golden.py [job ...]   (default: all)
         jobs[name]()
     left = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc") or f == "__pycache__"]

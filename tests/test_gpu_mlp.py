@@ -69,7 +69,10 @@ def test_mlp_forward_backward_vs_torch(cfg):
     e_h, e_r = _rel(y_h.detach(), y_d.detach()), _rel(y_r.detach(), y_d.detach())
     # BatchNorm over a batch of only 3-6 samples in the FC head amplifies fp32 summation-order noise (~3e-4 there)
     floor = 2e-4 if B >= 16 else 6e-4
-    assert e_h <= max(floor, 2 * e_r) or _rel(y_h.detach(), y_r.detach()) < floor, (e_h, e_r)
+    if B >= 16:  # ONE bar: as close to the fp64 run as torch's own fp32 path (factor 2), floor 2e-4
+        assert e_h <= max(floor, 2 * e_r), (e_h, e_r)
+    else:
+        assert e_h <= max(floor, 2 * e_r) or _rel(y_h.detach(), y_r.detach()) < floor, (e_h, e_r)
     g = torch.randn_like(y_r)
     (y_h * g).sum().backward()
     (y_r * g).sum().backward()
@@ -90,7 +93,10 @@ def test_mlp_forward_backward_vs_torch(cfg):
         err_hr = float((ph.grad.double() - pr.grad.double()).norm()) / nd
         # B < 16: a near-tie in the max-pool can resolve to a different point in one fp32 implementation than in the other
         # (and than in fp64); the gradient routed through it then moves early-layer gradients by a few per cent.
-        assert err_h <= max(floor, 2 * err_r) or err_hr <= (2e-3 if B >= 16 else 1e-1), (n, err_h, err_r, err_hr)
+        if B >= 16:  # ONE bar (no alternative): twice torch-fp32's own distance from the fp64 gradient, floor 2e-4
+            assert err_h <= max(floor, 2 * err_r), (n, err_h, err_r, err_hr)
+        else:
+            assert err_h <= max(floor, 2 * err_r) or err_hr <= 1e-1, (n, err_h, err_r, err_hr)
     for (n, bh), (_, bd) in zip(hip.named_buffers(), ref64.named_buffers()):
         if bh.dtype == torch.long:
             assert int(bh) == int(bd) == 1, n

@@ -96,3 +96,43 @@ def test_device_batch_ring_on_cpu():
     ring.release(1)
     with pytest.raises(ValueError):
         ring.load(0, a[:2])
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_modelnet_loader_matches_reference(golden, train):
+    """ModelNetCls against the REFERENCE class run on the same shard set (tests/golden/make_golden.py golden_modelnet: the
+    reference module imported with a stand-in h5py that opens the .npz twins of the shards).  Here the shards are read
+    through shard_reader= (h5py is not installed): everything but the h5py call itself is exercised -- file lists,
+    concatenation, label shape, per-item point order from numpy's global generator, shape names."""
+    g = golden("modelnet_reference.npz")
+    split = "train" if train else "test"
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "modelnet")
+
+    def npz(path):
+        with np.load(path) as f:
+            return f["data"], f["label"]
+
+    ds = D.ModelNetCls(24, None, train=train, folder="modelnet40_ply_hdf5_2048", include_shapes=True, base_dir=root, shard_reader=npz)
+    assert len(ds) == g[split + "_points"].shape[0] and ds.num_points == 24
+    assert np.array_equal(ds.points, g[split + "_all_points"]) and np.array_equal(ds.labels, g[split + "_all_labels"])
+    np.random.seed(5)
+    for i in range(len(ds)):
+        pts, lab, shape = ds[i]
+        assert np.array_equal(pts, g[split + "_points"][i]) and lab.dtype == __import__("torch").int64
+        assert np.array_equal(lab.numpy(), g[split + "_labels"][i]) and shape == str(g[split + "_shapes"][i])
+    ds.set_num_points(10 ** 6)
+    assert ds.num_points == 40
+    scaled = D.ModelNetCls(8, lambda c: c * 2, train=train, folder="modelnet40_ply_hdf5_2048", base_dir=root, shard_reader=npz)
+    np.random.seed(5)
+    pts, lab = scaled[0]
+    assert pts.shape == (8, 3) and np.array_equal(pts, 2 * ds.points[0][np.random.RandomState(5).permutation(8)])
+
+
+def test_modelnet_loader_without_h5py_says_so(tmp_path):
+    import importlib.util
+
+    if importlib.util.find_spec("h5py") is not None:
+        pytest.skip("h5py is installed here")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "modelnet")
+    with pytest.raises(ImportError, match="shard_reader"):
+        D.ModelNetCls(24, None, train=True, folder="modelnet40_ply_hdf5_2048", base_dir=root)

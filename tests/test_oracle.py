@@ -190,18 +190,21 @@ def test_softproj_matches_reference_module(oracle, golden, tag):
 
 # ------------------------------------------------------------------ EMD
 def test_approxmatch_vs_compiled_reference_cpu(oracle):
-    """Reference bar: |match_gpu - match_cpu| <= 1e-2 per entry (approxmatch.cpp:216-226); data recipe
-    approxmatch.cpp:131-144 (uniform(0,1), n = 4 m), shrunk so it runs in seconds."""
+    """The fp32 oracle (the GPU op's algorithm: 10 levels, single precision) against the reference's own double-precision CPU
+    functions compiled from approxmatch.cpp.  The reference's bar for this comparison is 1e-2 per entry
+    (approxmatch.cpp:216-226); what the oracle actually holds -- and what oracle/README.md and DESIGN.md 2 state -- is
+    5e-4 per entry (measured 3.8e-4 here; single vs double precision through 10 auction levels), 1e-6 on the cost.
+    Data recipe approxmatch.cpp:131-144 (uniform(0,1), n = 4 m), shrunk so it runs in seconds."""
     _need_ref(oracle)
     rng = np.random.default_rng(101)
     x1 = rng.random((2, 256, 3), dtype=np.float32)
     x2 = rng.random((2, 64, 3), dtype=np.float32)
     m = oracle.approxmatch(x1, x2)
     r = oracle.ref_approxmatch_cpu(x1, x2)
-    assert np.abs(m - r.transpose(0, 2, 1)).max() < 1e-2
+    assert np.abs(m - r.transpose(0, 2, 1)).max() < 5e-4
     np.testing.assert_allclose(m.sum(1), 1.0, atol=1e-3)   # each xyz1 point ships mass 1
     np.testing.assert_allclose(m.sum(2), 4.0, atol=1e-3)   # each xyz2 point receives n/m
-    np.testing.assert_allclose(oracle.matchcost(x1, x2, m), oracle.ref_matchcost_cpu(x1, x2, r), rtol=1e-4)
+    np.testing.assert_allclose(oracle.matchcost(x1, x2, m), oracle.ref_matchcost_cpu(x1, x2, r), rtol=5e-6)
     g1, g2 = oracle.matchcost_grad(x1, x2, m)
     np.testing.assert_allclose(g2, oracle.ref_matchcostgrad_cpu(x1, x2, r), atol=1e-3)
 
