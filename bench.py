@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- point-clouds/s of the SampleNet sampler training step (fwd + losses + bwd) on MI355X.
 
-    python bench.py --gpus 1 --steps 200 --warmup 50
+    python bench.py --gpus N --steps K --warmup W          N > 1: starts its own N ranks (one process per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (the same ranks under an external launcher)
 
 Unit of work: one step of the sampler as registration/main.py:500-531 issues it
     simp, proj = sampler(x)
@@ -25,6 +25,88 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+MIN_TIMED_S = 0.25  # the timed region never ends sooner, whatever --steps says (blocks of K steps are added)
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks here (one process per GPU over RCCL), pass
+    rank 0's JSON line through, return the launcher's exit code."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and "--launcher-selftest" not in argv:
+        print("bench.py --gpus %d: this node exposes %d GPU(s)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def csrc_sha16():
+    """Hash of the kernel sources + the C ABI headers: what a committed profile is a profile OF (the GPU box has no .git)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d, pat in (("samplenet_amd/csrc", (".hip", ".h", ".cpp")), ("include", (".h",))):
+        for name in sorted(os.listdir(os.path.join(ROOT, d))):
+            if name.endswith(pat):
+                with open(os.path.join(ROOT, d, name), "rb") as f:
+                    h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def profile_dir():
+    for rnd in ("r03", "r02", "r01"):
+        d = os.path.join(ROOT, "profiles", rnd)
+        if os.path.exists(os.path.join(d, "bench_graph_kernel_stats.csv")):
+            return rnd, d
+    return None, None
+
+
+def profile_provenance():
+    """Which committed rocprofv3 summary the `traffic` / longest-kernel fields come from, the kernel-source hash it was taken at
+    (profiles/rNN/PROFILE_SRC_SHA, written by tools/gpu_profile.sh) and whether the sources have changed since."""
+    rnd, d = profile_dir()
+    if rnd is None:
+        return {"dir": None, "stale": None}
+    sha = None
+    try:
+        sha = open(os.path.join(d, "PROFILE_SRC_SHA")).read().split()[0]
+    except OSError:
+        pass
+    now = csrc_sha16()
+    out = {"dir": "profiles/" + rnd, "src_sha16": sha, "current_src_sha16": now, "stale": (sha != now) if sha else None}
+    if out["stale"] or sha is None:
+        print("bench.py: WARNING: %s was taken at kernel sources %s, this run has %s -- its PMC traffic / kernel ranking may not "
+              "describe these kernels" % (out["dir"], sha, now), file=sys.stderr)
+    return out
+
+
+def longest_kernel_of_profile():
+    """(short name, avg us per launch, launches per step) of the kernel with the largest per-step time in the committed
+    rocprofv3 --kernel-trace --stats summary of `bench.py --no-probes`, or None."""
+    import csv
+
+    rnd, d = profile_dir()
+    if rnd is None:
+        return None
+    rows = [r for r in csv.DictReader(open(os.path.join(d, "bench_graph_kernel_stats.csv"))) if "sn::" in r["Name"]]
+    ref = [r for r in rows if "pairscan_kernel" in r["Name"]]
+    if not rows or not ref:
+        return None
+    steps = int(ref[0]["Calls"])
+    best = max(rows, key=lambda r: float(r["TotalDurationNs"]) if int(r["Calls"]) >= steps // 2 else 0.0)
+    name = best["Name"].replace("void ", "").replace("sn::", "")
+    return name[:name.index("(")] if "(" in name else name, float(best["AverageNs"]) / 1e3, max(1, round(int(best["Calls"]) / steps))
+
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured by a float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz (dense fp32 matrix peak)
@@ -160,12 +242,53 @@ def time_pairscan_saturated(K, Bsat=4096, N=1024, M=64, reps=10):
     return e0.elapsed_time(e1) / reps, Bsat
 
 
-def time_module_surface(dev, B, N, M, K, steps=60):
-    """Secondary leg: what a user of the drop-in module surface gets (registration/main.py:507-531 + 557-577), driver-timed:
+def _graph_replay_ms(fn, warm=3, reps=30):
+    """fn() -- one full training step built from autograd ops -- captured once as a hipGraph and replayed; ms per replay
+    (HIP events on the replay stream)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        out = fn()
+    for _ in range(3):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, out
+
+
+def _wall_ms(run, steps):
+    for _ in range(5):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, out
+
+
+def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
+    """Secondary legs: what a user of the drop-in module surface gets with a REAL task loss (registration/main.py:507-531 +
+    557-577: frozen PCRNet + Chamfer on the projected points), driver-timed:
       eager  -- plain  simp, proj = net(x); alpha*get_simplification_loss + lmbda*get_projection_loss + task; backward()
-                launched op by op from Python with the frozen PCRNet's Chamfer loss as the task term (host-bound);
-      graph  -- the same general (any task_loss) path captured once by engine.SamplerTrainStep and replayed.
-    Not the headline value: the headline path fuses the benchmark's stand-in task term mean(proj) into the step."""
+                launched op by op from Python (host-bound);
+      graph  -- engine.SamplerTrainStep(task_loss=...) captured once and replayed: the fused single-node step with the task
+                loss OUTSIDE the node -- proj is a differentiable output, the task gradient re-enters the loss backward as an
+                explicit tensor (same scan, fc4 inside the scan, deferred tail as the headline);
+      graph_general -- the same step on the op-by-op general path (fused_loss=False): what round 2 ran for any task loss;
+      task_only -- the task network's own forward + backward (PCRNet on (1024, 64)-point clouds + Chamfer), captured: the
+                part of `graph` that is not the sampler;
+      general_path_mean_proj -- the headline's stand-in task mean(proj) routed through the external-gradient path
+                (task_loss=lambda p: p.mean()): isolates what the mean(proj) specialisation of the headline is worth."""
     from samplenet_amd import SampleNet
     from samplenet_amd.engine import SamplerTrainStep
     from samplenet_amd.parallel import FlatGradAllReducer
@@ -191,37 +314,201 @@ def time_module_surface(dev, B, N, M, K, steps=60):
         loss.backward()
         return loss
 
+    def replica():
+        # a fresh replica with a gradient bucket (what a data-parallel user holds): the captured backward writes the MLP
+        # gradients in place, and no autograd state of the eager leg (created on another stream) is alive during capture
+        gnet = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc").to(dev).train()
+        gnet.load_state_dict(net.state_dict())
+        return gnet
+
     out = {}
-    for name in ("eager", "graph"):
-        if name == "graph":
-            # a fresh replica with a gradient bucket (what a data-parallel user holds): the captured backward writes the MLP
-            # gradients in place, and no autograd state of the eager leg (created on another stream) is alive during capture
-            gnet = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc").to(dev).train()
-            gnet.load_state_dict(net.state_dict())
-            st = SamplerTrainStep(gnet, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=task,
-                                  reducer=FlatGradAllReducer(gnet), use_graph=True)
-            run = lambda: st(x)  # noqa: E731
-        else:
-            run = eager_step
-        for _ in range(5):
-            run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = run()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        assert torch.isfinite(loss).item()
-        del loss
-        out[name] = {"value": B * steps / dt, "unit": "point-clouds/s", "ms_per_step": dt / steps * 1e3}
+    ms, loss = _wall_ms(eager_step, steps)
+    assert torch.isfinite(loss).item()
+    out["eager"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
+    for name, kw in (("graph", dict(task_loss=task)), ("graph_general", dict(task_loss=task, fused_loss=False)),
+                     ("general_path_mean_proj", dict(task_loss=lambda p: p.mean()))):
+        gnet = replica()
+        st = SamplerTrainStep(gnet, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=FlatGradAllReducer(gnet),
+                              use_graph=True, **kw)
+        ms, loss = _wall_ms(lambda: st(x), max(steps, 200))
+        assert torch.isfinite(loss).item(), name
+        st.check()
+        out[name] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms, "fast_path": bool(st._fast_path())}
+        del st, gnet
+    # the task network alone (forward + gradient to the 64 projected points), captured
+    q = (torch.rand(B, M, 3, device=dev, generator=g) - 0.5).requires_grad_(True)
+
+    def task_step():
+        q.grad = None
+        t = task(q)
+        t.backward()
+        return t
+
+    tms, _ = _graph_replay_ms(task_step)
+    out["task_only"] = {"ms_per_step": tms}
+    if headline_ms:
+        out["graph"]["vs_headline_plus_task"] = out["graph"]["ms_per_step"] / (headline_ms + tms)
     out["task_loss"] = "frozen PCRNet (bottleneck 1024) on (template 1024 pts, projected 64 pts) + Chamfer(projected, rotated template)"
     return out
+
+
+def time_config3_emd(dev, reps=5):
+    """BASELINE configs[3] (ShapeNet reconstruction, EMD loss): B = 50 clouds, approx_match / match_cost between the 2048-point
+    reconstruction and its 2048-point target (reconstruction/src/samplenet_pointnet_ae.py:118-131; kernels
+    classification/structural_losses/tf_approxmatch_g.cu).  Two forms, forward + gradients:
+      emd_loss   -- sn_emd_loss: the auction + two sweeps that re-evaluate match from the per-level ratio vectors; the
+                    (B, 2048, 2048) match matrix (839 MB) is never written;
+      three_call -- approx_match -> match_cost -> its gradient, the reference's op sequence (match written once, read twice).
+    Roofs: HBM on SURVEY 8d's algorithmic bytes (3 x 16.78 MB per cloud: the materialised form's minimum) and VALU issue --
+    the kernels are exponential-bound: 3 exp per pair and level x 10 levels + 10 (three_call) or 2 x 10 (emd_loss) per pair;
+    256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s, v_exp_f32 priced at 5/3 of a plain VALU op
+    (MI355X_MICROARCH.md).  `valu_busy_profiled`: SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the committed rocprofv3 --pmc pass."""
+    from samplenet_amd import ops
+
+    B, n, m = 50, 2048, 2048
+    g = torch.Generator(device=dev).manual_seed(3)
+    a = (torch.rand(B, n, 3, device=dev, generator=g) - 0.5).requires_grad_(True)
+    b = (torch.rand(B, m, 3, device=dev, generator=g) - 0.5).requires_grad_(True)
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    t_fused = timed(lambda: torch.autograd.grad(ops.emd_loss(a, b).sum(), [a, b]))
+    t_three = timed(lambda: torch.autograd.grad(ops.match_cost(a, b, ops.approx_match(a, b)).sum(), [a, b]))
+    t_match = timed(lambda: ops.approx_match(a, b))
+    pairs = float(B) * n * m
+    alg = 3.0 * pairs * 4.0  # SURVEY 8d: write match once + read it by cost and by grad
+    valu_peak = 256 * 4 * 32 * 2.4e9
+    out = {"workload": "BASELINE configs[3]: EMD loss fwd+grad, B=50, n=m=2048 (reconstruction/src/samplenet_pointnet_ae.py:118-131)"}
+    sq = None
+    try:
+        rnd, d = profile_dir()
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r03", "emd_sq_counters.json")))
+    except (OSError, ValueError):
+        pass
+    for name, ms, exps, traffic_key in (("emd_loss", t_fused, 50.0, "emd_loss"), ("three_call", t_three, 40.0, "three_call")):
+        lane_ops = pairs * (exps * (5.0 / 3.0) + 10 * 3 * 9.0 + 10.0)  # exps + ~9 packed-pair VALU slots per pair, level and pass
+        gbs = alg / (ms * 1e-3) / 1e9
+        out[name] = {"ms": ms, "clouds_per_s": B / (ms * 1e-3),
+                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                  "algorithmic_bytes": alg, "traffic": pmc_traffic_sum(traffic_key),
+                                  "note": "SURVEY 8d's minimum for the materialised form; emd_loss moves no match matrix at all"},
+                     "valu_issue": {"exp_per_pair": exps, "model_lane_ops": lane_ops, "achieved_lane_ops_per_s": lane_ops / (ms * 1e-3),
+                                    "peak_lane_ops_per_s": valu_peak, "frac": lane_ops / (ms * 1e-3) / valu_peak,
+                                    "valu_busy_profiled": (sq or {}).get(name)}}
+    out["approx_match_only_ms"] = t_match
+    return out
+
+
+def pmc_traffic_sum(key):
+    """HBM bytes per call of an EMD form from the committed PMC passes (profiles/r03/emd_pmc_summary.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03", "emd_pmc_summary.json"))).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def time_config5_progressive(dev, steps=40):
+    """BASELINE configs[4] on one GPU (per-rank work of the DP job): progressive SampleNet 1024 -> {32, 64, 128, 256} + the PCRNet
+    registration task (classification/train_samplenet_progressive.py:157-234 for the prefix semantics, registration/main.py:
+    507-531,557-577 for the task): the largest set sampled and projected once, the task network fed every prefix of the
+    projected points, simplification loss summed over the prefixes; B = 32.  Eager and captured."""
+    from samplenet_amd import SampleNetProgressive
+    from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss
+
+    B, N, K, sizes = 32, 1024, 8, [32, 64, 128, 256]
+    torch.manual_seed(0)
+    net = SampleNetProgressive(sizes, 128, group_size=K, input_shape="bnc", output_shape="bnc").to(dev).train()
+    pcr = PCRNet(bottleneck_size=1024, input_shape="bnc").to(dev).eval()
+    for p in pcr.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.rand(B, N, 3, device=dev, generator=g) - 0.5
+    template = torch.rand(B, N, 3, device=dev, generator=g) - 0.5
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        simp, proj = net(x)
+        loss = 0.01 * net.get_progressive_simplification_loss(x, simp, 1, 0, "sum") + 0.01 * net.get_projection_loss()
+        for s in sizes:
+            loss = loss + pcrnet_chamfer_loss(pcr, template, net.prefix(proj, s))[0]
+        loss.backward()
+        return loss
+
+    ems, loss = _wall_ms(step, steps)
+    assert torch.isfinite(loss).item()
+    gms, loss = _graph_replay_ms(step)
+    assert torch.isfinite(loss).item()
+    return {"workload": "BASELINE configs[4] per-rank: progressive SampleNet 1024 -> {32,64,128,256}, K=8, B=32, PCRNet + Chamfer "
+                        "task on every prefix, fwd + losses + bwd",
+            "eager": {"ms_per_step": ems, "value": B / ems * 1e3, "unit": "point-clouds/s"},
+            "graph": {"ms_per_step": gms, "value": B / gms * 1e3, "unit": "point-clouds/s"}}
+
+
+def time_batch_sweep(dev, N, M, K, batches=(32, 128, 512)):
+    """The whole sampler step (the headline's unit of work) at growing batches: B = 32 is latency-bound by construction (14
+    dependent launches), larger batches show what the kernels reach when fed.  Fractions: MLP flops / step time against the
+    fp32 MFMA peak; SURVEY 8d's algorithmic bytes (3.73 MB per cloud: activations written once and read once per consumer,
+    geometry 50.7 KB) / step time against 8 TB/s."""
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    out = []
+    for B in batches:
+        torch.manual_seed(0)
+        net = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc").to(dev).train()
+        g = torch.Generator(device=dev).manual_seed(77)
+        x = torch.rand(B, N, 3, device=dev, generator=g) - 0.5
+        st = SamplerTrainStep(net, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=FlatGradAllReducer(net), use_graph=True)
+        ms, loss = _wall_ms(lambda: st(x), max(20, min(300, int(6400 / B))))
+        assert torch.isfinite(loss).item()
+        flop = 3 * 2 * 33_964_032 * B
+        byts = (2 * 448 * N * 4 + 12 * N + 50_688) * B
+        out.append({"batch": B, "ms_per_step": ms, "clouds_per_s": B / ms * 1e3, "fused_single_node_step": bool(st._fast_path()),
+                    "mfma_frac_fp32_peak": flop / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                    "hbm_frac_algorithmic": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        del st, net
+    return out
+
+
+def time_fc_chain_backward(net, x, reps=20, inner=20):
+    """Average duration of sn::fc_chain_bwd_kernel (the FC head's backward as one launch) on the bench's shapes: `inner` launches
+    captured into a hipGraph (the host side allocates its outputs per call and would not keep ahead of a ~25 us kernel) and
+    replayed, HIP events around the replays.  -> (ms per launch, algorithmic bytes, flop)."""
+    from samplenet_amd import pointnet
+
+    B = x.shape[0]
+    with torch.no_grad():
+        _, saved = pointnet.forward_impl(net, x, True)
+        convs, fcs = pointnet._layers(net)
+        gy = torch.randn(B, fcs[-1].Co, device=x.device)
+
+        def launch():
+            for _ in range(inner):
+                if pointnet._fc_chain_bwd(net, convs, fcs, saved, gy, None, {}, False) is False:
+                    raise RuntimeError("fc chain backward not supported at this shape")
+
+        ms, _ = _graph_replay_ms(launch, warm=2, reps=reps)
+    wbytes = sum(L.Co * L.Ci for L in fcs) * 4
+    act = sum(B * (L.Co + L.Ci) for L in fcs) * 4
+    flop = sum(4.0 * B * L.Co * L.Ci for L in fcs)  # data gradient + weight gradient
+    return ms / inner, 2 * wbytes + act, flop
 
 
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/: FETCH_SIZE x 2 + WRITE_SIZE, KiB, as
     MI355X_MICROARCH.md prescribes for gfx950), or None when no profile of that kernel is on disk."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
         try:
             with open(path) as f:
@@ -243,32 +530,47 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
-    ap.add_argument("--no-module-surface", action="store_true", help="skip the secondary module-surface leg")
-    ap.add_argument("--overlap-allreduce", action="store_true",
-                    help="N > 1: capture the step as two graphs and launch the FC-head segment's all-reduce between them on a side "
-                         "stream (default: one graph, one collective after it -- measured faster at world size 1)")
+    ap.add_argument("--no-module-surface", action="store_true", help="skip the secondary module-surface legs")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip config3_emd / config5_progressive / batch_sweep")
+    ap.add_argument("--allreduce", choices=("graph", "graph-fork", "after", "split"), default="graph",
+                    help="N > 1, where the gradient collective runs: inside the step's graph at its end (default), inside it with "
+                         "the FC-head segment forked to a side stream, from Python after each replay, or between two graphs")
+    ap.add_argument("--overlap-allreduce", action="store_true", help="same as --allreduce split")
     ap.add_argument("--no-probes", action="store_true",
-                    help="profiling runs: only the timed steps (no roofline kernel probes, no cpu_baseline, no module-surface leg)")
+                    help="profiling runs: only the timed steps (no roofline kernel probes, no cpu_baseline, no secondary legs)")
     ap.add_argument("--force-collective", action="store_true",
-                    help="world size 1 under torchrun: still issue the gradient all-reduce (single-GPU exercise of the RCCL path)")
+                    help="world size 1: still issue the gradient all-reduce (single-GPU exercise of the RCCL path)")
+    ap.add_argument("--min-time", type=float, default=MIN_TIMED_S, help="minimum length of the timed region in seconds")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no measurement: the N ranks only rendezvous (gloo, CPU), all-reduce their ranks and rank 0 prints a JSON "
+                         "line -- exercises the --gpus N self-launch path on a host without GPUs (tests/)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_collective):
+        # `python bench.py --gpus N` as the driver contract spells it: start the ranks ourselves
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d inside a launcher with WORLD_SIZE=%d" % (args.gpus, world))
+    if args.launcher_selftest:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": world, "rank_sum": float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or (args.force_collective and "MASTER_PORT" in os.environ):
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import samplenet_amd
-    from samplenet_amd import SampleNet, ops
+    import samplenet_amd  # noqa: F401
+    from samplenet_amd import SampleNet
     from samplenet_amd.engine import SamplerTrainStep
     from samplenet_amd.parallel import FlatGradAllReducer
 
@@ -282,19 +584,34 @@ def main():
     # sampler loss weights of registration/src/sputils.py:53-59: alpha=0.01, lmbda=0.01, gamma=1, delta=0
     # the 8 resident batches are the step's input ring (a data loader would write its H2D copies into them): one graph per
     # entry, no copy into a staging buffer on the timed path
+    split = args.overlap_allreduce or args.allreduce == "split"
     train_step = SamplerTrainStep(net, pool[0], alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=reducer,
-                                  use_graph=not args.no_graph, input_ring=pool, overlap_allreduce=args.overlap_allreduce)
+                                  use_graph=not args.no_graph, input_ring=pool, overlap_allreduce=split,
+                                  allreduce="after" if split else args.allreduce)
 
     def step(i):
         return train_step.replay(i % len(pool))
 
+    # warm-up (also the estimate that sizes the timed region: never shorter than --min-time, whatever --steps says)
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
     for i in range(args.warmup):
         step(i)
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - tw) / max(args.warmup, 1)
+    blocks = 1
+    if args.warmup > 0 and est * args.steps < args.min_time:
+        blocks = int(args.min_time / (est * args.steps)) + 1
+    if world > 1:  # every rank must run the same number of steps
+        t = torch.tensor([blocks], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        blocks = int(t.item())
+    total_steps = args.steps * blocks
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(total_steps):
         loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -306,12 +623,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(loss).item()
+    train_step.check()  # FC-chain hand-off error words (a timed-out launch would also have left a NaN loss)
 
+    if not train_step.split and train_step.in_graph:
+        ar = "flat 1 MB bucket over RCCL, captured INSIDE the step's graph (%s)" % (
+            "FC-head segment forked to a side stream, joined at the end" if args.allreduce == "graph-fork" else "one collective at its end")
+    elif train_step.split:
+        ar = "flat bucket over RCCL: FC-head segment between the step's two graphs on a side stream, conv segment after"
+    else:
+        ar = "flat bucket over RCCL: one collective launched after each step"
     if rank == 0 and args.no_probes:
-        print(json.dumps({"value": world * B * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "note": "--no-probes run"}), flush=True)
+        print(json.dumps({"value": world * B * total_steps / dt, "ms_per_step": dt / total_steps * 1e3, "n_gpus": world,
+                          "grad_allreduce": ar if reducer.collective else "none", "note": "--no-probes run"}), flush=True)
     elif rank == 0:
-        ms = dt / args.steps * 1e3
-        value = world * B * args.steps / dt
+        ms = dt / total_steps * 1e3
+        value = world * B * total_steps / dt
+        prov = profile_provenance()
         kern_ms = time_pairscan_kernel(net, pool, K)
         alg = geometry_bytes_fwd(N, M, K) * B
         achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -325,20 +652,38 @@ def main():
         # MLP work of the whole step: 3 x 67.93 MFLOP per cloud (forward + data gradient + weight gradient)
         step_flop = 3 * 2 * 33_964_032 * B
         step_tf = step_flop / (ms * 1e-3) / 1e12
+        # the LONGEST kernel of the step per the committed rocprofv3 summary (not the heaviest): measured live when it is one
+        # this file has a probe for
+        longest = longest_kernel_of_profile()
+        longest_out = None
+        if longest is not None:
+            lname, lavg_us, lcalls = longest
+            longest_out = {"kernel": lname, "profile_avg_launch_us": lavg_us, "launches_per_step": lcalls, "profile": prov["dir"]}
+            if lname.startswith("fc_chain_bwd_kernel") and B <= 32:
+                fms, fbytes, fflop = time_fc_chain_backward(net, pool[0])
+                fg, ft = fbytes / (fms * 1e-3) / 1e9, fflop / (fms * 1e-3) / 1e12
+                longest_out.update({"bound": "hbm", "achieved": fg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fg / HBM_PEAK_GBS,
+                                    "avg_launch_ms": fms, "algorithmic_bytes_per_launch": fbytes,
+                                    "algorithmic_flop_per_launch": fflop, "traffic": pmc_traffic("fc_chain_bwd_kernel"),
+                                    "mfma": {"achieved": ft, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ft / MFMA_F32_PEAK_TFLOPS},
+                                    "note": "a dependency chain (4 GEMM stages of 32 rows handed between 8 workgroups inside one "
+                                            "launch): bound by hand-off latency, not by either roof"})
+            elif lname.startswith("conv_bwd_bx3_kernel<128, 128"):
+                longest_out["same_as"] = "roofline"
         out = {
             "metric": "point-clouds/sec fwd+bwd, Bx1024->64 soft-proj+Chamfer",
             "value": value, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "timed_steps": total_steps, "timed_region_s": dt,
             "config": {"workload": "BASELINE configs[1]: SampleNet sampler train step (fwd + simplification/projection "
                                    "losses + bwd), B=%d per GPU, 1024->64 points, K=8, bottleneck 128; no optimizer step" % B,
                        "batch_per_gpu": B, "global_batch": B * world, "n_in": N, "n_out": M, "group_size": K,
-                       "parallelism": "dp%d" % world,
-                       "grad_allreduce": ("none" if not reducer.collective else
-                                          "flat bucket over RCCL: FC-head segment between the step's two graphs on a side stream, "
-                                          "conv segment after" if train_step.split else "flat bucket over RCCL: one collective after the step"),
+                       "parallelism": "dp%d" % world, "rccl_ranks": world if reducer.collective else 0,
+                       "grad_allreduce": ar if reducer.collective else "none",
                        "execution": "eager launches" if args.no_graph else "whole step replayed as one hipGraph",
                        "mlp": "hand-written MFMA kernels: conv stack = fp32 via split-bf16 products (fp32-accurate), FC head = fp32 MFMA"},
+            "profile": prov,
             # the heaviest GEMM kernel of the step (most flops and most bytes of any launch): backward of the last 1x1 convolution.
             # Both roofs are reported; "bound" names the nearer one.
             "roofline": {"kernel": "sn::conv_bwd_bx3_kernel<128,128,DZ_POOL> (conv5 backward: dgrad + wgrad; fp32 products as "
@@ -355,8 +700,9 @@ def main():
                          "mfma": {"achieved": conv_tf, "peak": MFMA_SPLIT_BF16_PEAK_TFLOPS, "unit": "fp32-equivalent TFLOP/s",
                                   "frac": conv_tf / MFMA_SPLIT_BF16_PEAK_TFLOPS,
                                   "vs_fp32_mfma_peak": conv_tf / MFMA_F32_PEAK_TFLOPS},
-                         "note": "matrix ceiling = dense bf16 MFMA peak / 6 products (tools/micro/bf16x3_gemm.hip: 392 "
-                                 "fp32-equivalent TFLOP/s measured, 155 for the fp32 MFMA)"},
+                         "note": "the heaviest kernel (most bytes and flops of any launch); matrix ceiling = dense bf16 MFMA peak / 6 "
+                                 "products (tools/micro/bf16x3_gemm.hip: 392 fp32-equivalent TFLOP/s measured, 155 for the fp32 MFMA)"},
+            "roofline_longest": longest_out,
             # the geometric kernel of the path (SURVEY 8d's per-cloud byte count applies to it)
             "roofline_geometry": {"kernel": "sn::pairscan_kernel<16,true,true> (kNN + soft projection + both Chamfer directions)",
                                   "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -372,15 +718,20 @@ def main():
                                   "head on the fp32 MFMA)" % MFMA_SPLIT_BF16_PEAK_TFLOPS},
         }
         if world == 1 and not args.no_module_surface:
-            out["module_surface"] = time_module_surface(dev, B, N, M, K)
+            out["module_surface"] = time_module_surface(dev, B, N, M, K, headline_ms=ms)
+        if world == 1 and not args.no_extra_legs:
+            out["config3_emd"] = time_config3_emd(dev)
+            out["config5_progressive"] = time_config5_progressive(dev)
+            out["batch_sweep"] = time_batch_sweep(dev, N, M, K)
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_reference_model import time_cpu_baseline
 
             out["cpu_baseline"] = time_cpu_baseline(B, N, M, K, budget_s=args.cpu_budget)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()  # rank 0 was busy with the roofline timing loops: leave together
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()  # rank 0 was busy with the roofline timing loops: leave together
         dist.destroy_process_group()
 
 

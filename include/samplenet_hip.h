@@ -13,7 +13,12 @@
  *     most recent error of the calling thread is returned by sn_last_error_string().
  *
  * Each function names the reference interface it replaces (file:line under the
- * itailang/SampleNet checkout).
+ * itailang/SampleNet checkout).  THIS header is the drop-in boundary: the entries a binding of the
+ * reference's native interfaces (the `cd` pybind module, the TF op launchers, knn_cuda / pointnet2,
+ * the torch.nn layer chain of samplenet.py:90-104) would call.  The fused-step entry points that the
+ * host side of this package (samplenet_amd/{pointnet,fused_step,engine}.py) uses on top of them --
+ * multi-layer launches, the sampler step's single-node loss, their scratch-size queries -- are
+ * declared in samplenet_hip_internal.h; they carry no stability promise.
  */
 #ifndef SAMPLENET_HIP_H
 #define SAMPLENET_HIP_H
@@ -121,65 +126,6 @@ int sn_simplification_loss_backward(int B, int n1, const float *xyz1, int n2, co
                                     const int *idx2, const int *argmax1, float weight, const float *grad_loss,
                                     float *grad_xyz1, float *grad_xyz2, int layout1, sn_stream_t stream);
 /* layout1: 0 = xyz1 / grad_xyz1 are (B,n1,3); 1 = (B,3,n1), the layout the sampler's FC head emits (grad_xyz2 must be NULL) */
-
-/* The sampler's total loss with the benchmark's stand-in task term (registration/main.py:507-531):
- *     L = alpha * L_simp + lmbda * max(T^2, min_sigma) + mean(proj)        (all operands device scalars / tensors)
- * forward: loss (1 float).  backward: grad_proj (nproj floats, = grad_loss / nproj), grad_lsimp (1), grad_T (1). */
-int sn_sampler_loss_forward(int nproj, const float *proj, const float *lsimp, const float *temperature,
-                            float alpha, float lmbda, float min_sigma, float *loss, sn_stream_t stream);
-int sn_sampler_loss_backward(int nproj, const float *grad_loss, const float *temperature, float alpha, float lmbda,
-                             float min_sigma, float *grad_proj, float *grad_lsimp, float *grad_T, sn_stream_t stream);
-
-/* The sampler's training-step loss with the benchmark's stand-in task term, in the fewest launches the dependencies allow
- * (the op-by-op route above computes the same numbers):
- *   sn_pairscan_forward_partial   pair scan that leaves the per-point minima as G = sn_pairscan_colmin_splits(B,N,M) partial
- *                                 key sets (workspace [B][G][N] u64); SN_ERR_UNSUPPORTED when G <= 1
- *   sn_sampler_step_loss_forward  finishes dist_p / idx_p from those partials while reducing the loss; loss[0] = L,
- *                                 loss[1] = L_simp; partial: B*4 floats; argmax1: B ints
- *   sn_sampler_step_loss_backward grad_Q (B,3,M) = d L / d simplified cloud, grad_T; gsig_scratch: B*sn_soft_bwd_splits(B,M) */
-int sn_pairscan_colmin_splits(int B, int N, int M);
-int sn_pairscan_forward_partial(int B, int N, int M, int K, const float *P, int p_layout, const float *Q, int q_layout,
-                                int *knn_idx, float *dist_q, int *idx_q, float *proj, int proj_layout,
-                                const float *temperature, float min_sigma, void *workspace, long long workspace_bytes,
-                                sn_stream_t stream);
-/* sn_pairscan_forward_partial with the queries PRODUCED inside the scan by the head's last fully connected layer
- * (samplenet.py:103-104): q[b][c][j] = fc_bias[c*M+j] + sum_k relu(fc_z[b][k]*fc_scale[k] + fc_shift[k]) * fc_w[c*M+j][k];
- * q_out (B,3,M) receives the simplified cloud.  Kfc % 4 == 0.  One launch less than FC layer + scan. */
-int sn_pairscan_forward_partial_fc(int B, int N, int M, int K, const float *P, int p_layout, const float *fc_z,
-                                   const float *fc_scale, const float *fc_shift, const float *fc_w, const float *fc_bias,
-                                   int Kfc, float *q_out, int *knn_idx, float *dist_q, int *idx_q, float *proj,
-                                   int proj_layout, const float *temperature, float min_sigma, void *workspace,
-                                   long long workspace_bytes, sn_stream_t stream);
-int sn_sampler_step_loss_forward(int B, int M, int N, int G, const float *dist_q, const void *colmin_ws, const float *proj,
-                                 const float *temperature, float alpha, float lmbda, float weight, float min_sigma,
-                                 float *dist_p, int *idx_p, int *argmax1, float *partial, float *loss, int defer_value,
-                                 sn_stream_t stream);
-int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
-                                  const int *knn_idx, const int *idx_q, const int *idx_p, const int *argmax1,
-                                  const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
-                                  const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T,
-                                  const float *deferred_partial, float *deferred_loss, sn_stream_t stream);
-/* The same step with NO launch between the scan and the backward (engine default): sn_pairscan_forward_keys combines the
- * per-point minima across a cloud's workgroups by 64-bit atomicMax on inverted (distance, query) keys (max / min are
- * order-independent: deterministic) in colmin_keys [B][N] -- u64, zero on entry, zero again after
- * sn_sampler_step_loss_keys -- and leaves the query-side loss partials qpart [B][G][2] floats / qmax [B][G] u64,
- * G = sn_pairscan_colmin_splits(B,N,M) > 1.  Q (B,3,M) is read, or written when fc_w != NULL (queries produced by the
- * head's last layer as in sn_pairscan_forward_partial_fc).  dpsum: B floats of scratch; loss: 2 floats.  N <= 2048.
- * deferred_tail (optional, host buffer of sn_step_tail_bytes() bytes): the launch that produces grad_T / loss and resets
- * colmin_keys is not issued at all; its description is written there and handed to sn_conv_stack_backward(step_tail) of the same step, whose closing kernel runs it. */
-int sn_pairscan_forward_keys(int B, int N, int M, int K, const float *P, int p_layout, float *Q, const float *fc_z,
-                             const float *fc_scale, const float *fc_shift, const float *fc_w, const float *fc_bias, int Kfc,
-                             int *knn_idx, float *dist_q, int *idx_q, float *proj, int proj_layout, const float *temperature,
-                             float min_sigma, void *colmin_keys, float *qpart, void *qmax, sn_stream_t stream);
-int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float *P, int p_layout, const float *Q, const int *knn_idx,
-                              const int *idx_q, void *colmin_keys, const float *qpart, const void *qmax, int G,
-                              const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
-                              const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T, float *dpsum,
-                              float *loss, sn_stream_t stream, void *deferred_tail);
-int sn_step_tail_bytes(void);
-/* defer_value != 0: the forward leaves loss[] unwritten; pass its `partial` and `loss` to the backward call as
- * deferred_partial / deferred_loss and the scalar is combined by an extra wave of the backward's first launch (the
- * gradients do not depend on it) -- for callers that always run the backward (samplenet_amd.engine).  Else pass NULLs. */
 
 /* ---------------------------------------------------------------------------------------------
  * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.
@@ -300,157 +246,23 @@ int sn_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float
  *                      sn_linear_wgrad_splits(R,Ci,Co,db!=NULL) * Co * (Ci + (db!=NULL)) floats.
  * ------------------------------------------------------------------------------------------- */
 int sn_linear_stats_blocks(int R);
-/* layer-level entry points (what samplenet_amd/pointnet.py calls): a layer's forward INCLUDING its BatchNorm
- * finalisation, and a layer's backward (dW, optional db, dYprev) INCLUDING the BatchNorm backward coefficients of the
- * layer below; they pick the fused single-/dual-launch kernels by shape and fall back to the pieces above otherwise. */
-int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
-                        const float *bias, float *z, float *stats, const float *gamma, const float *beta,
-                        float eps, float momentum, float *running_mean, float *running_var,
-                        long long *num_batches_tracked, float *coef, sn_stream_t stream);
-/* sn_layer_forward_bn of the last conv layer with the max-pool over the npts points of every cloud folded in (the forward
- * epilogue leaves per-block maxima / minima, the BatchNorm finalisation picks): pooled / argsel / zsel as sn_pool_forward;
- * pool_val / pool_idx: scratch of sn_linear_stats_blocks(R) * 2 * Co elements each.  SN_ERR_UNSUPPORTED unless R, npts, Ci,
- * Co are multiples of 64. */
-int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
-                            const float *bias, float *z, float *stats, const float *gamma, const float *beta, float eps,
-                            float momentum, float *running_mean, float *running_var, long long *num_batches_tracked,
-                            float *coef, float *pool_val, int *pool_idx, float *pooled, int *argsel, float *zsel,
-                            sn_stream_t stream);
-/* The training-mode conv stack (conv/bn/relu x nlayers on the xyz cloud + max over the points, samplenet.py:90-95) in one
- * call and nlayers + 1 launches.  Batch statistics travel as 64-bit fixed-point sums accumulated with integer atomics
- * (order-independent, hence deterministic); each layer finalises the BatchNorm of its input itself, so no reduction launch
- * sits between layers.  channels [nlayers+1] = 3, C1..Cn (64 or 128 each); N % 64 == 0 (query _supported first).
- * Arrays of nlayers device pointers: W (C_{l+1},C_l), bias, gamma, beta, running_mean, running_var, num_batches_tracked,
- * z (B*N,C_{l+1}) pre-BN outputs, coef (4,C_{l+1}); eps / momentum: host arrays.  acc: sn_conv_stack_acc_elems(nlayers) long long of persistent
- * device scratch, zero before the first call (every call leaves it zero).  pool_val / pool_idx: (B*N/64)*2*Cn scratch.
- * pooled = argsel = zsel = NULL: stop after the last GEMM; sn_fc_chain_forward_pool must follow (it finishes the pool).  The last
- * layer then leaves, instead of block partials, (B, 2, Cn) 64-bit keys in pool_val -- per cloud and channel (max Z, first row)
- * and (min Z, first row), combined by atomicMax -- which sn_fc_chain_forward_pool decodes; pool_val must then hold at least
- * 4 * B * Cn floats (16 bytes per cloud and channel: more than the block partials only when N < 128). */
-int sn_conv_stack_forward_supported(int B, int N, int nlayers, const int *channels);
-long long sn_conv_stack_acc_elems(int nlayers);
-/* 1: z[0] may be NULL in sn_conv_stack_forward_bn / sn_conv_stack_backward for this shape -- the xyz layer then runs as a
- * statistics-only pass and its activation (B*N, C1) is never written: conv2's forward and backward rebuild it from the cloud
- * with the xyz layer's own expression (bit-identical results, 8 MB less written and 16 MB less read per step at B = 32). */
-int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const int *channels);
-/* the leading part of acc that holds the statistics accumulators (zero between calls); behind it: scratch of the forward (the
- * layers' weights split into bf16 planes by the first kernel of the call) */
-long long sn_conv_stack_acc_sum_elems(int nlayers);
-int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
-                             const float *const *bias, const float *const *gamma, const float *const *beta,
-                             float *const *running_mean, float *const *running_var, long long *const *num_batches_tracked,
-                             const float *eps, const float *momentum, float *const *z, float *const *coef, long long *acc,
-                             float *pool_val, int *pool_idx, float *pooled, int *argsel, float *zsel, sn_stream_t stream);
-/* Backward of the conv stack, the mirror of sn_conv_stack_forward_bn, in nlayers launches: one fused dgrad + wgrad kernel
- * per GEMM layer (top first) and one closing kernel that reduces every layer's weight-gradient partials and finishes the
- * xyz layer (BatchNorm backward, closed-form weight gradient).  The BatchNorm-backward sums travel between the kernels as
- * fixed-point atomics; each kernel derives its own layer's dZ coefficients in its prologue.
- * gsel / argsel (B,Cn), kcoef_top (3,Cn): pooled gradient at the selected points and the top BatchNorm's dZ coefficients
- * (sn_layer_backward with prev_bn_rows, or sn_pool_backward_bn).  dW: nlayers outputs; dgamma / dbeta / dbias: outputs for
- * layers 0 .. nlayers-2.  acc: sn_conv_stack_acc_elems(nlayers) long long of persistent zeroed scratch (its own buffer, not
- * the forward's); scratch: sn_conv_stack_backward_scratch_floats(...) floats (0 = shape not supported). */
-long long sn_conv_stack_backward_scratch_floats(int B, int N, int nlayers, const int *channels);
-int sn_conv_stack_backward(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
-                           const float *bias0, const float *const *z, const float *const *coef, const float *gsel,
-                           const int *argsel, const float *kcoef_top, long long *acc, float *scratch, float *const *dW,
-                           float *const *dgamma, float *const *dbeta, float *const *dbias, const void *step_tail,
-                           sn_stream_t stream);
-int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
-                      const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
-                      const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, float *db,
-                      float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef, long long prev_bn_rows,
-                      sn_stream_t stream);
-/* sn_layer_backward (dz_mode = SN_DZ_BN) for the layer that sits on the xyz input layer (3 -> Ci, x_in (R,3), W_in (Ci,3),
- * b_in (Ci) or NULL): also returns dW_in (Ci,3), the input layer's weight gradient, in closed form from three extra
- * per-channel sums and the second moments of x_in accumulated by the same kernel -- no separate pass over dYprev, which
- * is not written at all (the input layer has no gradient to pass further down).
- * stats: sn_layer_backward_in3_stats_floats(R, Ci, Co) floats; that function returns 0 when the shape is not supported. */
-long long sn_layer_backward_in3_stats_floats(int R, int Ci, int Co);
-int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z, const float *kcoef, const float *W,
-                          const float *zprev, const float *coef_prev, float *stats, float *part, float *dW,
-                          float *prev_dgamma, float *prev_dbeta, float *prev_dbias, float *prev_kcoef, const float *x_in,
-                          const float *W_in, const float *b_in, float *dW_in, sn_stream_t stream);
-/* prev_bn_rows (> 0: R <= 32 only; 0 = R): rows seen by the BatchNorm of the layer below when they differ from R -- the FC head's
- * first layer on top of the max-pool: zprev = pooled pre-BN values (B rows), BatchNorm over B*N rows; replaces sn_pool_backward.
- * prev_bn_rows < 0 (any R): that BatchNorm normalised with FIXED statistics (eval mode: coef_prev from sn_bn_eval_coef), so its
- * backward is dZ = scale * dY (k2 = k3 = 0); dgamma / dbeta as usual.  Likewise R < 0 in sn_pool_backward_bn. */
 int sn_linear_forward(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
                       const float *bias, float *z, float *stats, sn_stream_t stream);
 int sn_bn_finalize(int nblk, int C, long long R, const float *stats, const float *gamma, const float *beta,
                    float eps, float momentum, float *running_mean, float *running_var,
                    long long *num_batches_tracked, float *coef, sn_stream_t stream);
-/* The FC head's BatchNorm + ReLU layers (R <= 32 rows; a0 (R, C0) -> H -> ... -> H, nl layers) as ONE launch: the H / 32
- * workgroups of a layer stay resident and exchange each layer's activations through xbuf with write-through stores and an
- * arrival counter instead of ending the kernel per layer.  Per layer l: W[l] (H, K), bias, BatchNorm parameters / running
- * statistics (training-mode update as sn_layer_forward_bn), outputs z[l] (R, H) pre-BN and coef[l] (4, H).  Bit-identical to
- * nl calls of sn_layer_forward_bn.  xbuf: 2 * 32 * H floats of scratch; sync: 16 unsigned, PERSISTENT and zero-initialised
- * once by the caller (epoch + monotonic arrival counters; sync[15] != 0 afterwards = a poll timed out: results invalid). */
-int sn_fc_chain_forward_supported(int R, int C0, int H, int nl);
-int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0, const float *const *W, const float *const *bias,
-                        const float *const *gamma, const float *const *beta, float *const *running_mean,
-                        float *const *running_var, long long *const *num_batches_tracked, const float *eps,
-                        const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
-                        sn_stream_t stream);
-/* sn_fc_chain_forward with the tail of the conv stack in front (samplenet.py:90-101: bn5 / relu / max over the points /
- * fc1..fc3): call sn_conv_stack_forward_bn with pooled = argsel = zsel = NULL -- it then stops after its last GEMM, leaving
- * the last layer's fixed-point sums in acc and the block maxima / minima in pool_val / pool_idx -- and this entry right after:
- * its first stage finalises that BatchNorm (gamma5 .. coef5, clearing acc) and decodes the max-pool from the keys (pooled /
- * argsel / zsel as sn_pool_forward) in EVERY workgroup -- no exchange in front of fc1.  B <= 32 clouds, N % 64 == 0, conv stack
- * of nconv layers ending in C0 = 128 channels, H = 256, nl = 3 (query _supported).  Same results as the two separate calls.
- * pool_val: the keys; pool_idx: unused. */
-int sn_fc_chain_forward_pool_supported(int B, int N, int C0, int H, int nl);
-int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc, const float *pool_val, const int *pool_idx,
-                             const float *gamma5, const float *beta5, float *running_mean5, float *running_var5,
-                             long long *num_batches_tracked5, float eps5, float momentum5, float *coef5, float *pooled,
-                             int *argsel, float *zsel, int H, int nl, const float *const *W, const float *const *bias,
-                             const float *const *gamma, const float *const *beta, float *const *running_mean,
-                             float *const *running_var, long long *const *num_batches_tracked, const float *eps,
-                             const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
-                             sn_stream_t stream);
-/* The FC head's backward (R <= 32 rows) as ONE launch, the mirror of sn_fc_chain_forward.  Stage s = GEMM layer, TOP first:
- * W[s] (Co[s], Ci[s]); below it: zprev[s] (R, Ci[s]) pre-BN output seen through coefprev[s] (4, Ci[s]) (the pooled-feature
- * stage: zsel with the last conv layer's coefficients and bn_rows[s] = B * N; bn_rows < 0: fixed statistics); outputs per
- * stage: dW[s], the layer below's dgamma / dbeta / dbias; db_top: bias gradient of the top layer; aprev[s] / araw[s]: the
- * weight-gradient operand (zprev with ReLU(BN) applied, or a raw input such as the pooled features).  Last stage also
- * returns gout (R, Ci) = the masked gradient and kout (3, Ci) = the dZ coefficients of the BatchNorm below (what
- * sn_conv_stack_backward takes as gsel / kcoef_top).  gy: (R, Co[0]).  Bit-identical to the sn_layer_backward chain.
- * xbuf: ns * 32 * 256 floats of scratch; sync: 16 unsigned of its OWN persistent zero-initialised state (launch epoch, one
- * monotonic arrival counter per stage, epoch-reader count; sync[15] != 0 afterwards = a poll timed out: results invalid). */
-int sn_fc_chain_backward_supported(int R, int ns, const int *Co, const int *Ci);
-int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci, const float *gy, const float *const *W,
-                         const float *const *zprev, const float *const *coefprev, const long long *bn_rows,
-                         float *const *dgamma, float *const *dbeta, float *const *dbias, float *const *dW, float *db_top,
-                         const float *const *aprev, const int *araw, float *gout, float *kout, float *xbuf,
-                         unsigned *sync, sn_stream_t stream);
-/* sn_bn_finalize for a SHORT matrix z (R, C) (the FC head at batches above 32): statistics in two passes over z itself (mean,
- * then squares around it) instead of from sum / sum-of-squares partials -- behind the max-pool |mean| / std reaches 10..100. */
-int sn_bn_batch_stats_twopass(int R, int C, const float *z, const float *gamma, const float *beta, float eps, float momentum,
-                              float *running_mean, float *running_var, long long *num_batches_tracked, float *coef,
-                              sn_stream_t stream);
 int sn_bn_eval_coef(int C, const float *gamma, const float *beta, float eps, const float *running_mean,
                     const float *running_var, float *coef, sn_stream_t stream);
 int sn_pool_forward(int B, int N, int C, const float *z, const float *coef, float *pooled, int *argsel,
                     float *zsel, sn_stream_t stream);
 int sn_pool_backward(int B, int C, const float *g, const float *pooled, const float *zsel, float *gsel,
                      float *stats, sn_stream_t stream);
-/* sn_pool_backward + sn_bn_backward_coef of the last conv layer (R = B * N rows seen by its BatchNorm) in one launch */
-int sn_pool_backward_bn(int B, int C, long long R, const float *g, const float *pooled, const float *zsel, float *gsel,
-                        const float *coef, float *dgamma, float *dbeta, float *dbias, float *kcoef, sn_stream_t stream);
 int sn_bn_backward_coef(int nblk, int C, long long R, const float *stats, const float *coef, float *dgamma,
                         float *dbeta, float *dbias, float *kcoef, sn_stream_t stream);
 int sn_linear_dgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                     const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                     const float *coef_prev, float *dyprev, float *stats, sn_stream_t stream);
-/* dgrad + wgrad of one layer in ONE launch (both kinds of workgroups resident together); same arguments, no bias column */
-int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
-                       const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
-                       const float *coef_prev, float *dyprev, float *stats, float *part, float *dW, sn_stream_t stream);
 int sn_linear_wgrad_splits(int R, int Ci, int Co, int with_bias);
-/* the fused data+weight gradient kernel of a 64/128-channel 1x1 convolution on its own: dYprev, stats partials [G][2][Ci],
- * dW partials [G][Co][Ci], G = sn_linear_wgrad_splits(R,Ci,Co,0); SN_ERR_UNSUPPORTED for other shapes */
-int sn_conv_backward_partials(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
-                              const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
-                              const float *coef_prev, float *dyprev, float *stats, float *part, sn_stream_t stream);
 int sn_linear_wgrad(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                     const float *gsel, const int *argsel, int npts, const float *aprev, const float *coef_prev,
                     float *part, float *dW, float *db, sn_stream_t stream);

@@ -17,7 +17,8 @@ _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
 
-# name -> argument types (restype is int unless listed in _RESTYPES); mirrors include/samplenet_hip.h
+# name -> argument types (restype is int unless listed in _RESTYPES); mirrors include/samplenet_hip.h (the drop-in
+# boundary) and include/samplenet_hip_internal.h (the fused-step entry points behind it)
 PROTOTYPES = {
     "sn_abi_version": [],
     "sn_last_error_string": [],
@@ -44,8 +45,9 @@ PROTOTYPES = {
     "sn_pairscan_forward_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp,
                                  _vp, _vp],
     "sn_sampler_step_loss_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp],
+                                  _vp, _vp, _vp, _vp, _vp],
     "sn_step_tail_bytes": [],
+    "sn_step_tail_set_error_words": [_vp, _vp, _vp],
     "sn_prefix_point_minima": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],

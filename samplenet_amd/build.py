@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(ROOT, "include", "samplenet_hip.h"))
+    headers += [os.path.join(ROOT, "include", h) for h in ("samplenet_hip.h", "samplenet_hip_internal.h")]
     objs, rebuilt = [], False
     for src, extra in SOURCES:
         path = os.path.join(CSRC, src)

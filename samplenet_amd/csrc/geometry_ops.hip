@@ -233,6 +233,7 @@ struct SoftQuery {
     float qx, qy, qz;  // the query
     int id;            // this lane's neighbour
     float gx, gy, gz;  // its coordinates
+    float go0, go1, go2;  // fused mode with an explicit upstream gradient: d loss / d proj of this query
 };
 
 __device__ __forceinline__ float dpp_row_shr1(float x)  // lane below within the row of 16; 0 into the row's lane 0
@@ -253,6 +254,13 @@ __device__ __forceinline__ void soft_bwd_load_index(const SoftBwdArgs &a, int b,
     q.qz = Qb[pt_off(a.q_layout, m, j, 2)];
     const int sub = K <= 16 ? (lane & 15) : lane;
     q.id = sub < K ? a.idx[((size_t)b * m + j) * K + sub] : 0;
+    q.go0 = q.go1 = q.go2 = 0.f;
+    if (a.grad_proj) {  // (requested here, with the query's other first-round loads, not in front of its use)
+        const float *gp = a.grad_proj + (size_t)b * 3 * m;
+        q.go0 = gp[pt_off(a.gproj_layout, m, j, 0)];
+        q.go1 = gp[pt_off(a.gproj_layout, m, j, 1)];
+        q.go2 = gp[pt_off(a.gproj_layout, m, j, 2)];
+    }
 }
 
 __device__ __forceinline__ void soft_bwd_load_points(const SoftBwdArgs &a, int lane, const float *__restrict__ Pb, SoftQuery &q)
@@ -304,10 +312,7 @@ __device__ __forceinline__ void soft_bwd_math(const SoftBwdArgs &a, int b, int j
     float go0 = 0.f, go1 = 0.f, go2 = 0.f;
     if (FUSED) {
         if (a.grad_proj) {
-            const float *gp = a.grad_proj + (size_t)b * 3 * m;
-            go0 = gp[pt_off(a.gproj_layout, m, j, 0)];
-            go1 = gp[pt_off(a.gproj_layout, m, j, 1)];
-            go2 = gp[pt_off(a.gproj_layout, m, j, 2)];
+            go0 = q.go0, go1 = q.go1, go2 = q.go2;
         } else {
             go0 = go1 = go2 = *a.gconst / a.gconst_div;
         }
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__(256) soft_bwd_kernel(SoftBwdArgs a)
     const float *__restrict__ Pb = a.P + (size_t)b * 3 * n;
     const float *__restrict__ Qb = a.Q + (size_t)b * 3 * m;
     const float T = *a.temperature;
-    const float sigma = fmaxf(T * T, a.min_sigma);
+    const float sigma = sn_sigma(T, a.min_sigma);
     float gsig = 0.f;  // this wave's share of d loss / d sigma
 
     for (int j = blockIdx.y * nwaves + wave; j < m; j += gridDim.y * nwaves) {
@@ -416,7 +421,7 @@ __global__ void __launch_bounds__(256) soft_weights_fwd_kernel(int n, int m, int
     const int b = blockIdx.x;
     const float *Pb = P + (size_t)b * 3 * n, *Qb = Q + (size_t)b * 3 * m;
     const float T = *temperature;
-    const float sigma = fmaxf(T * T, min_sigma);
+    const float sigma = sn_sigma(T, min_sigma);
     for (int j = blockIdx.y * nwaves + wave; j < m; j += gridDim.y * nwaves) {
         const bool act = lane < K;
         const int id = act ? idx[((size_t)b * m + j) * K + lane] : 0;
@@ -599,7 +604,7 @@ __device__ __forceinline__ void step_loss_final(const StepLossFinal &f, int t)
     if (t != 0) return;
     const float c12 = s1 / ((float)f.B * (float)f.M), cmax = mx / (float)f.B, c21 = s2 / ((float)f.B * (float)f.N);
     const float lsimp = c12 + cmax + f.w * c21;
-    f.loss[0] = f.alpha * lsimp + f.lmbda * fmaxf(T * T, f.min_sigma) + sp / ((float)f.B * (float)f.nproj);
+    f.loss[0] = f.alpha * lsimp + f.lmbda * sn_sigma(T, f.min_sigma) + sp / ((float)f.B * (float)f.nproj);
     f.loss[1] = lsimp;
 }
 
@@ -678,7 +683,7 @@ __global__ void __launch_bounds__(256) chamfer_soft_bwd_kernel(int nt, int ns, c
     }
     const float gLv = *ig.gL * ig.gscale;
     const float Tm = *sa.temperature;
-    const float sigma = fmaxf(Tm * Tm, sa.min_sigma);
+    const float sigma = sn_sigma(Tm, sa.min_sigma);
     const int jfirst = blockIdx.y * nwaves + wave, jstep = nsplit * nwaves;
     // the first query of this wave (the simplified cloud is target and query at once: T = sa.Q of this cloud)
     float tx = 0.f, ty = 0.f, tz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
@@ -930,7 +935,7 @@ __global__ void __launch_bounds__(1024) sampler_loss_fwd_kernel(int nproj, const
     }
     if (threadIdx.x == 0) {
         const float T = *temperature;
-        loss[0] = alpha * lsimp[0] + lmbda * fmaxf(T * T, min_sigma) + red[0] / (float)nproj;
+        loss[0] = alpha * lsimp[0] + lmbda * sn_sigma(T, min_sigma) + red[0] / (float)nproj;
     }
 }
 
@@ -1288,7 +1293,7 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
                                          const void *qmax, int G, const float *temperature, float min_sigma, float alpha,
                                          float lmbda, float weight, const float *grad_loss, float *grad_Q,
                                          float *gsig_scratch, float *grad_T, float *dpsum, float *loss, sn_stream_t stream,
-                                         void *deferred_tail)
+                                         void *deferred_tail, const float *grad_proj)
 {
     SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && G >= 1, "bad size");
     SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
@@ -1302,7 +1307,9 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
     SoftBwdArgs a{};
     a.P = P, a.Q = Q, a.idx = knn_idx, a.temperature = temperature, a.min_sigma = min_sigma;
     a.p_layout = p_layout, a.q_layout = SN_LAYOUT_BCN, a.n = N, a.m = M, a.k = K;
-    a.grad_proj = nullptr, a.gconst = grad_loss, a.gconst_div = (float)(B * 3 * M);
+    // grad_proj (B,M,3), optional: the task loss's gradient w.r.t. the projected points (main.py:507-531: the task network
+    // sits on proj); NULL = the benchmark's stand-in term mean(proj) inside this loss, upstream gradient grad_loss / (3BM)
+    a.grad_proj = grad_proj, a.gproj_layout = SN_LAYOUT_BNC, a.gconst = grad_loss, a.gconst_div = (float)(B * 3 * M);
     a.grad_Q = grad_Q, a.gq_layout = SN_LAYOUT_BCN, a.accumulate_q = 1;
     a.grad_P = nullptr, a.grad_sigma_partial = gsig_scratch;
     int splits = std::max(1, std::min((M + 3) / 4, (kChamferBwdGroups + B - 1) / B));
@@ -1319,7 +1326,7 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
     else SN_CS(32);
 #undef SN_CS
     const StepLossKeysFinal kf{B, G, M, N, 3 * M, weight, alpha, lmbda, min_sigma, qpart, (const sn_u64 *)qmax, dpsum, temperature,
-                               loss, (sn_u64 *)colmin_keys, (long long)B * N};
+                               loss, (sn_u64 *)colmin_keys, (long long)B * N, grad_proj ? 0 : 1, {nullptr, nullptr}};
     if (deferred_tail) {
         // the caller hands this blob to a later launch of the same step (sn_conv_stack_backward runs it in two extra
         // workgroups of its closing kernel): no launch of its own for the sigma gradient / loss value / key reset
@@ -1337,6 +1344,19 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
 }
 
 extern "C" int sn_step_tail_bytes(void) { return (int)sizeof(sn::StepTail); }
+
+// Names the error words of the step's FC chain launches (sn_fc_chain_forward* / sn_fc_chain_backward: word 15 of their sync
+// buffers; either may be NULL) in a tail blob: the deferred loss value becomes NaN when one of them is set.
+extern "C" int sn_step_tail_set_error_words(void *tail_blob, const void *fwd_sync, const void *bwd_sync)
+{
+    SN_REQUIRE(tail_blob, "null blob");
+    StepTail t;
+    memcpy(&t, tail_blob, sizeof(t));
+    t.kf.chain_err[0] = fwd_sync ? (const unsigned *)fwd_sync + 15 : nullptr;
+    t.kf.chain_err[1] = bwd_sync ? (const unsigned *)bwd_sync + 15 : nullptr;
+    memcpy(tail_blob, &t, sizeof(t));
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Inference matching on the device: sputils.nn_matching (registration/src/sputils.py:7-41).

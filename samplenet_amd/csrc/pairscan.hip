@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
             wmax = kq > wmax ? kq : wmax;
         }
         if (want_soft) {
-            const float sigma = fmaxf(temp_q * temp_q, a.min_sigma);   // soft_projection.py:97-99
+            const float sigma = sn_sigma(temp_q, a.min_sigma);   // soft_projection.py:97-99
             const float s = (lane < cnt) ? -(nd / sigma) : -INFINITY;  // soft_projection.py:92-95
             const float mx = readlane_f(s, 0);  // neighbours ascend in distance: lane 0 holds the maximum of s
             const float e = (lane < cnt) ? expf(s - mx) : 0.f;

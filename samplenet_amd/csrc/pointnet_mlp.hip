@@ -2789,25 +2789,31 @@ __device__ __forceinline__ void store_sc1_b128(float *p, f32x4v v)
 // unroll into ONE batch of loads; 0: run-time loops.
 // One seam of the chain kernels: arrive at counter `ctr`, wait until all nwg workgroups of this launch have (counters are
 // monotonic over launches: target = (epoch + 1) * nwg).  Called by thread 0 between two lds_barrier().
-__device__ __forceinline__ void fc_chain_seam(unsigned *sync, int ctr, unsigned epoch, int nwg, unsigned errcode)
+// Returns true when the poll gave up (never on a healthy run: the workgroups of a chain launch must be resident together --
+// 8 or 16 workgroups of ~137 KB LDS on otherwise free CUs; a device kept full by other work can starve one of them).  The
+// caller then poisons its outputs with NaN, and the error word stays set for the loss tail / the host (sn_fc_chain_error).
+// Poll bound: sync[13] when non-zero (tests), else 2^22 polls (seconds).
+constexpr int kFcChainPolls = 1 << 22;
+__device__ __forceinline__ bool fc_chain_seam(unsigned *sync, int ctr, unsigned epoch, int nwg, unsigned errcode, int limit)
 {
     __hip_atomic_fetch_add(sync + ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = (epoch + 1u) * (unsigned)nwg;
     int spins = 0;
     while ((int)(__hip_atomic_load(sync + ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        if (++spins > (1 << 22)) {  // never on a healthy run: report instead of hanging the device
+        if (++spins > limit) {  // report instead of hanging the device
             __hip_atomic_store(sync + 15, errcode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
+            return true;
         }
         __builtin_amdgcn_s_sleep(1);
     }
+    return false;
 }
 
 template <int C0T, int NLT, bool POOL = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) fc_chain_fwd_kernel(FcChainArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ unsigned s_epoch;
+    __shared__ unsigned s_epoch, s_limit, s_bad;
     if (blockIdx.x & 7) return;
     const int wg = blockIdx.x >> 3, nwg = g.H / 32;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -2821,7 +2827,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     float *Ts = red + 3 * 16 * 64;                                         // [32][36] pre-BN tile
     float *Ta = Ts + 32 * 36;                                              // [32][36] activated tile
     const int col0 = wg * 32, col = col0 + l31;
-    if (tid == 0) s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        const unsigned lim = g.sync[13];  // (same line as the epoch: one round trip)
+        s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_limit = lim ? lim : (unsigned)kFcChainPolls, s_bad = 0;
+    }
 
     // ---- every layer's weight slice + the first operand: all fetches issued up front, staged into LDS as they land
     if constexpr (POOL) {
@@ -3029,7 +3039,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         lds_barrier();
         // the 32 x 32 tiles leave as 16-byte stores: thread -> (row = tid / 8, 4 columns at (tid % 8) * 4)
         const int trow = tid >> 3, tc4 = (tid & 7) * 4;
-        if (trow < R) *reinterpret_cast<float4 *>(Lr.z + (size_t)trow * H + col0 + tc4) = *reinterpret_cast<const float4 *>(Ts + trow * 36 + tc4);
+        if (trow < R) {
+            float4 zv = *reinterpret_cast<const float4 *>(Ts + trow * 36 + tc4);
+            // a seam of this launch timed out: what the layers above computed is built on incomplete activations -- the head's
+            // output must not look like a result (NaN flows through fc4 / the pair scan into the loss and every gradient)
+            if (l == nl - 1 && s_bad) zv.x = zv.y = zv.z = zv.w = __builtin_nanf("");
+            *reinterpret_cast<float4 *>(Lr.z + (size_t)trow * H + col0 + tc4) = zv;
+        }
         if (l == nl - 1) break;
         float *xb = g.xbuf + (size_t)(l & 1) * 32 * H;
         {
@@ -3040,7 +3056,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         if (tid == 0) {
-            fc_chain_seam(g.sync, 1 + l, epoch, nwg, 1u + (unsigned)l);
+            if (fc_chain_seam(g.sync, 1 + l, epoch, nwg, 1u + (unsigned)l, (int)s_limit)) s_bad = 1;
             if (l == 0 && wg == 0) __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lds_barrier();
@@ -3202,11 +3218,11 @@ struct FcBwdArgs {
     unsigned *sync;  // [0] epoch, [1 + s] arrivals of stage s, [14] epoch readers, [15] error flag -- persistent, zeroed once
 };
 
-__device__ __forceinline__ bool fc_wait_arrivals(unsigned *ctr, unsigned target)
+__device__ __forceinline__ bool fc_wait_arrivals(unsigned *ctr, unsigned target, int limit)
 {
     int spins = 0;
     while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        if (++spins > (1 << 22)) return false;  // never on a healthy run: report instead of hanging the device
+        if (++spins > limit) return false;  // never on a healthy run: report instead of hanging the device (fc_chain_seam)
         __builtin_amdgcn_s_sleep(1);
     }
     return true;
@@ -3215,7 +3231,7 @@ __device__ __forceinline__ bool fc_wait_arrivals(unsigned *ctr, unsigned target)
 __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    __shared__ unsigned s_epoch;
+    __shared__ unsigned s_epoch, s_limit, s_bad;
     if (blockIdx.x & 7) return;
     const int wgi = blockIdx.x >> 3;  // 0..7 data-gradient chain, 8..15 weight gradients
     constexpr int NWG = 8, LD = 256 + 4;
@@ -3226,12 +3242,16 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
     const int R = g.R, ns = g.ns;
     const int col0 = wg * 32, col = col0 + l31;
     if (tid == 0) {
+        const unsigned lim = g.sync[13];  // poll bound override (tests), same line as the epoch
         s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(g.sync + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_limit = lim ? lim : (unsigned)kFcChainPolls, s_bad = 0;
     }
     lds_barrier();
     const unsigned epoch = s_epoch;
     const unsigned target = (epoch + 1u) * (unsigned)NWG;
+    const int limit = (int)s_limit;
+    const float kNaN = __builtin_nanf("");
 
     if (!chain) {
         // ================================================================== weight-gradient workgroup
@@ -3266,8 +3286,10 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 if (trow < R) v = *reinterpret_cast<const float4 *>(g.gy + (size_t)trow * Co + col0 + tc4);
                 *reinterpret_cast<float4 *>(Tz + trow * 36 + tc4) = v;
             } else {
-                if (tid == 0 && !fc_wait_arrivals(g.sync + s, target))  // sync[1 + (s - 1)]
+                if (tid == 0 && !fc_wait_arrivals(g.sync + s, target, limit)) {  // sync[1 + (s - 1)]
                     __hip_atomic_store(g.sync + 15, 16u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_bad = 1;
+                }
                 lds_barrier();
                 const float *p = g.xbuf + (size_t)(s - 1) * 32 * 256 + (size_t)trow * Co + col0 + tc4;
                 f32x4v v;
@@ -3279,6 +3301,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
 #pragma unroll
             for (int t = 0; t < 16; ++t) a[t] = Tz[(h * 16 + t) * 36 + l31];
             float *T = Tw + wave * 32 * 36;
+            const bool bad = s_bad != 0;  // a hand-off this workgroup waited for never came: its gradients must not look like results
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int tn = wave + 4 * i;
@@ -3289,7 +3312,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
 #pragma unroll
                     for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bw[i][t], acc, 0, 0, 0);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) T[frag_row(e, lane) * 36 + l31] = acc[e];
+                    for (int e = 0; e < 16; ++e) T[frag_row(e, lane) * 36 + l31] = bad ? kNaN : acc[e];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int rt = 8 * q + (lane >> 3);
@@ -3447,7 +3470,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = frag_row(e, lane);
-                    if (S.gout && row < R) S.gout[(size_t)row * Ci + col] = gv[e];
+                    if (S.gout && row < R) S.gout[(size_t)row * Ci + col] = s_bad ? kNaN : gv[e];  // (a seam timed out: see fc_chain_seam)
                     Ta[row * 36 + l31] = row < R ? fmaf(k1, gv[e], fmaf(k2, zpv[e], k3)) : 0.f;
                 }
             }
@@ -3476,8 +3499,10 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                     Wtn[(c4 + 2) * LD + co] = wn[i].z, Wtn[(c4 + 3) * LD + co] = wn[i].w;
                 }
             }
-        if (tid == 0 && !fc_wait_arrivals(g.sync + 1 + s, target))
+        if (tid == 0 && !fc_wait_arrivals(g.sync + 1 + s, target, limit)) {
             __hip_atomic_store(g.sync + 15, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_bad = 1;
+        }
         lds_barrier();
         {   // gather dZ of the layer below (32 x Ci; Ci = 256: 8 loads per thread, 128: 4)
             const int q4 = Ci / 4, nld = (32 * q4) / 256;
@@ -3501,7 +3526,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
     }
     // the next launch may only see the advanced epoch once all 16 workgroups of this one have read the current value
     if (wgi == 0 && tid == 0) {
-        if (!fc_wait_arrivals(g.sync + 14, (epoch + 1u) * 16u))
+        if (!fc_wait_arrivals(g.sync + 14, (epoch + 1u) * 16u, limit))
             __hip_atomic_store(g.sync + 15, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "samplenet_hip.h"
+#include "samplenet_hip_internal.h"
 
 int sn_set_error(int code, const char *fmt, ...);
 
@@ -84,6 +85,14 @@ __device__ __forceinline__ void kernarg_warm_for()
     static_assert(total >= 4 && IMPLICIT >= 0 && IMPLICIT <= 24, "kernarg_warm_for: bad sizes");
     constexpr int lines = (total - 4) / 64 + 1;
     kernarg_warm<(lines < 8 ? lines : 8) * 64>();
+}
+
+// sigma = max(T^2, min_sigma) with torch.max's NaN behaviour (soft_projection.py:97-99: a NaN temperature gives a NaN sigma;
+// fmaxf alone would return min_sigma and hide a diverged parameter behind finite outputs)
+__device__ __forceinline__ float sn_sigma(float T, float min_sigma)
+{
+    const float t2 = T * T;
+    return t2 != t2 ? t2 : fmaxf(t2, min_sigma);
 }
 
 // element offset of channel c of point i in a (N,3) [BNC] or (3,N) [BCN] cloud

@@ -18,6 +18,11 @@ struct StepLossKeysFinal {
     float *loss;          // NULL: nothing to do
     sn_u64 *keys;         // [nkeys] inverted per-point keys, re-zeroed for the next step
     long long nkeys;
+    int with_mean_proj;   // 1: the loss carries the stand-in task term mean(proj); 0: the task loss lives outside (its gradient
+                          // arrives as an explicit grad_proj)
+    // error words of the step's FC chain launches (forward, backward; NULL: none): a non-zero word -- a hand-off between
+    // their workgroups timed out -- turns the loss value into NaN (sn_step_tail_set_error_words)
+    const unsigned *chain_err[2];
 };
 
 struct StepTail {         // plain data: also the blob sn_sampler_step_loss_keys hands to sn_conv_stack_backward
@@ -56,7 +61,12 @@ __device__ __forceinline__ void step_loss_keys_final(const StepLossKeysFinal &f,
     if (t != 0) return;
     const float c12 = s1 / ((float)f.B * (float)f.M), cmax = mx / (float)f.B, c21 = s2 / ((float)f.B * (float)f.N);
     const float lsimp = c12 + cmax + f.w * c21;
-    f.loss[0] = f.alpha * lsimp + f.lmbda * fmaxf(T * T, f.min_sigma) + sp / ((float)f.B * (float)f.nproj);
+    float L = f.alpha * lsimp + f.lmbda * sn_sigma(T, f.min_sigma);
+    if (f.with_mean_proj) L = L + sp / ((float)f.B * (float)f.nproj);
+    unsigned err = 0;
+    if (f.chain_err[0]) err |= *f.chain_err[0];
+    if (f.chain_err[1]) err |= *f.chain_err[1];
+    f.loss[0] = err ? __builtin_nanf("") : L;
     f.loss[1] = lsimp;
 }
 

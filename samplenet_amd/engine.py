@@ -16,7 +16,8 @@ import torch
 
 class SamplerTrainStep:
     def __init__(self, net, example_x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=None, reducer=None,
-                 use_graph=True, warmup=3, fused_loss=True, input_ring=None, fused_head=True, overlap_allreduce=None):
+                 use_graph=True, warmup=3, fused_loss=True, input_ring=None, fused_head=True, overlap_allreduce=None,
+                 allreduce="graph"):
         self.net, self.reducer = net, reducer
         self.alpha, self.lmbda, self.gamma, self.delta = alpha, lmbda, gamma, delta
         self.fused_loss = fused_loss  # False: compose the loss op by op through the module's own methods (A/B, tests)
@@ -42,21 +43,40 @@ class SamplerTrainStep:
         if overlap_allreduce is None:
             overlap_allreduce = False
         self.split = bool(use_graph and overlap_allreduce and reducer is not None and reducer.collective and self._fast_path()
-                          and fused_head and getattr(net, "use_hip_mlp", False))
+                          and task_loss is None and fused_head and getattr(net, "use_hip_mlp", False))
+        # Where the gradient collective of a captured step runs (N > 1):
+        #   "graph"      (default) INSIDE the step's one graph, at its end on the capturing stream: RCCL's kernel is one more
+        #                node of the replay -- no host-side launch path per step, nothing between the graph and the collective;
+        #   "graph-fork" inside the graph, the FC-head segment (86 % of the bytes) forked onto the reducer's side stream where
+        #                those gradients are final and joined at the end: hidden under the conv stack's backward at the price of
+        #                two cross-stream edges in the graph;
+        #   "after"      one collective launched from Python behind each replay (round-2 behaviour).
+        if allreduce not in ("graph", "graph-fork", "after"):
+            raise ValueError("allreduce: 'graph', 'graph-fork' or 'after'")
+        self.allreduce = allreduce
+        self.in_graph = bool(use_graph and not self.split and reducer is not None and reducer.collective and allreduce != "after")
         if use_graph:
             self._capture(warmup)
 
     def _fast_path(self):
-        """forward + loss behind one autograd node (ops.SamplerStepLossFunction): the benchmark's stand-in task term,
-        training mode with projection, (B,N,3) input, and a batch small enough that the pair scan splits clouds."""
+        """forward + loss behind one autograd node (fused_step.SamplerStepFunction / ops.SamplerStepLossFunction): training
+        mode with projection, (B,N,3) input, and a batch small enough that the pair scan splits clouds.  The task term is the
+        benchmark's stand-in mean(proj) inside the node, or any callable on the projected points OUTSIDE it (its gradient
+        enters the node's backward as an explicit tensor; needs the fc4-in-scan, keys-mode step)."""
         net = self.net
-        if not self.fused_loss or self.task_loss is not None or not net.training or net.skip_projection or \
+        if not self.fused_loss or not net.training or net.skip_projection or \
                 net.input_shape != "bnc" or not getattr(net, "standard_arch", True):
             return False
         from ._lib import lib
 
         B, N, _ = self.x.shape
-        return lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1
+        if lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) <= 1:
+            return False
+        if self.task_loss is not None:
+            from .fused_step import external_task_supported
+
+            return bool(self.fused_head and getattr(net, "use_hip_mlp", False) and external_task_supported(net, self.x))
+        return True
 
     def _step(self, boundary=None):
         """One step (eager, or under capture).  boundary: callable invoked where the FC head's gradients are complete --
@@ -82,6 +102,20 @@ class SamplerTrainStep:
                 loss, y, proj = fused_step.sampler_step_direct(net, x, self.alpha, self.lmbda, weight, t_sink, self._one, boundary)
                 self.outputs = (y, proj)
                 return loss
+            if self.task_loss is not None:
+                # main.py:507-531: the task network sits on the projected points.  The node returns a differentiable proj; the
+                # task loss's gradient re-enters its backward as an explicit tensor.  The node's loss VALUE is written by the
+                # backward's last launch (deferred tail), so the total is formed afterwards.
+                from .fused_step import sampler_step
+
+                loss, y, proj = sampler_step(net, x, self.alpha, self.lmbda, weight, t_sink, True, mean_proj=False)
+                task = self.task_loss(proj if net.output_shape == "bnc" else proj.permute(0, 2, 1))
+                self.outputs = (y.detach(), proj.detach())
+                if task.requires_grad:
+                    torch.autograd.backward([loss, task], [self._one, self._one.to(task.dtype)])
+                else:  # a task term that does not depend on the sampler: the projection branch gets a zero gradient
+                    loss.backward(self._one)
+                return loss.detach() + task.detach()
             if self.fused_head and net.use_hip_mlp:
                 from .fused_step import sampler_step
 
@@ -115,8 +149,20 @@ class SamplerTrainStep:
         if not self.split:
             g = torch.cuda.CUDAGraph()
             # thread_local: API calls of other threads (the RCCL watchdog polling events) must not invalidate the capture
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                loss = self._step()
+            fork = self.in_graph and self.allreduce == "graph-fork" and getattr(self.net, "use_hip_mlp", False)
+            prev = getattr(self.net, "_after_fc_grads", None)
+            if fork:
+                self.reducer.capture_fork = True
+                self.net._after_fc_grads = self.reducer._early_ready
+            try:
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    loss = self._step()
+                    if self.in_graph:
+                        self.reducer.reduce()  # captured: the collective(s) replay with the step
+            finally:
+                if fork:
+                    self.reducer.capture_fork = False
+                    self.net._after_fc_grads = prev
             return [g], loss, self.outputs
         import gc
 
@@ -151,6 +197,8 @@ class SamplerTrainStep:
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._step()
+                if self.in_graph:
+                    self.reducer.reduce()  # the communicator must exist before a collective can be captured
                 if self.reducer is None:
                     for p in self.net.parameters():
                         p.grad = None
@@ -187,8 +235,17 @@ class SamplerTrainStep:
             self.x = self.ring[i]
             self.loss = self._step()
         if self.reducer is not None:
-            self.reducer.reduce()
+            self.reducer.reduce(collective=not (self.in_graph and self._ring_graphs))
         return self.loss
+
+    def check(self):
+        """Host-side health check of the step's device-side launch state (the FC chain kernels' hand-off error words): raises
+        SampleNetHipError when a step since the last check ran on incomplete data (its loss was NaN-poisoned on the device
+        already).  Synchronises the device: call it where the loss is read back, not per step."""
+        from . import pointnet
+
+        if getattr(self.net, "use_hip_mlp", False):
+            pointnet.check_chain_errors(self.net)
 
     def __call__(self, x):
         """Runs one step on batch x (same shape as example_x); returns the (static) loss tensor.
@@ -201,5 +258,5 @@ class SamplerTrainStep:
         else:
             self.loss = self._step()
         if self.reducer is not None:
-            self.reducer.reduce()
+            self.reducer.reduce(collective=not (self.in_graph and self._ring_graphs))
         return self.loss

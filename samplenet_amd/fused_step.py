@@ -33,10 +33,17 @@ class _KeyToken:
 
 class SamplerStepFunction(torch.autograd.Function):
     """loss, simp (B,3,M), proj (B,M,3) = step(net, x (B,N,3)); differentiable w.r.t. the head's parameters and the
-    projection temperature (simp / proj are returned detached: the loss is the only differentiable output)."""
+    projection temperature.
+      mean_proj=True : loss = alpha * L_simp + lmbda * sigma + mean(proj) -- the benchmark's stand-in task term inside the node;
+                       simp / proj are returned detached, the loss is the only differentiable output.
+      mean_proj=False: loss = alpha * L_simp + lmbda * sigma, and proj is a DIFFERENTIABLE output: a task loss built on it
+                       outside the node (registration/main.py:507-531: the task network sits on the projected points) sends
+                       its gradient back in, and the loss backward takes it as an explicit upstream tensor
+                       (sn_sampler_step_loss_keys(grad_proj)) -- same scan, same fc4-in-scan, same deferred tail.  Needs the
+                       keys-mode step (defer_value, N <= 2048); the loss VALUE is valid once the backward ran."""
 
     @staticmethod
-    def forward(ctx, net, x_bnc, temperature, K, min_sigma, alpha, lmbda, weight, t_sink, defer_value, *params):
+    def forward(ctx, net, x_bnc, temperature, K, min_sigma, alpha, lmbda, weight, t_sink, defer_value, mean_proj, *params):
         ops._need_gpu(x_bnc, temperature)
         x = ops._f32c(x_bnc)
         B = x.shape[0]
@@ -73,16 +80,30 @@ class SamplerStepFunction(torch.autograd.Function):
         ctx.cfg = (K, float(min_sigma), float(alpha), float(lmbda), float(weight))
         ctx.t_sink = t_sink
         ctx.keys_token = token
-        ctx.mark_non_differentiable(y, proj)
+        ctx.mean_proj = bool(mean_proj)
+        if not mean_proj and keys is None:
+            raise RuntimeError("SamplerStepFunction: an outside task loss (mean_proj=False) needs the keys-mode step "
+                               "(defer_value=True, N <= 2048)")
+        if mean_proj:
+            ctx.mark_non_differentiable(y, proj)
+        else:
+            ctx.mark_non_differentiable(y)
         ctx.set_materialize_grads(False)
         return loss[0], y, proj
 
     @staticmethod
-    def backward(ctx, grad_loss, _gy=None, _gproj=None):
+    def backward(ctx, grad_loss, _gy=None, gproj=None):
         nparams = len(pointnet.param_order(ctx.net))
-        if grad_loss is None:
-            return (None,) * (10 + nparams)
+        if grad_loss is None and (ctx.mean_proj or gproj is None):
+            return (None,) * (11 + nparams)
         net = ctx.net
+        if ctx.mean_proj:
+            gproj = None
+        else:  # the loss here has no mean(proj) term: an absent upstream gradient is a zero one, not the implicit constant
+            B, _, M = ctx.y.shape
+            gproj = torch.zeros(B, M, 3, device=ctx.y.device) if gproj is None else ops._f32c(gproj)
+            if grad_loss is None:
+                grad_loss = torch.zeros((), device=ctx.y.device)
         sink, owner = pointnet.sink_for_backward(net)
         if len(ctx.state) > 5 and ctx.state[5][0] == "keys":
             if getattr(ctx, "keys_consumed", False):
@@ -97,7 +118,7 @@ class SamplerStepFunction(torch.autograd.Function):
                 import ctypes
 
                 blob = ctypes.create_string_buffer(ops.lib.sn_step_tail_bytes())
-            res = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink, blob)
+            res = ops.step_loss_backward(ctx.x, ctx.y, ctx.temperature, ctx.state, ctx.cfg, grad_loss, ctx.t_sink, blob, gproj)
             gQ, gT = res[0], res[1]
             if keys_mode:  # (the backward's last launch re-zeroed the key table: hand the persistent one back)
                 kown = getattr(net, "_colmin_keys_owner", None)
@@ -107,21 +128,29 @@ class SamplerStepFunction(torch.autograd.Function):
                                            getattr(net, "_after_fc_grads", None) if sink is not None else None, step_tail=blob)
             if owner is not None:
                 owner.commit(None if sink is not None else grads)
-            del res  # (scratch the deferred tail reads: released only behind the conv backward)
+            del res, gproj  # (scratch the deferred tail reads: released only behind the conv backward)
         g_temp = None
         if ctx.t_sink is None and ctx.needs_input_grad[2]:
             g_temp = gT.reshape(ctx.temperature.shape)
-        return (None, None, g_temp) + (None,) * 7 + tuple(
+        return (None, None, g_temp) + (None,) * 8 + tuple(
             None if (owner is not None and n in owner) else grads[n] for n in pointnet.param_order(net))
 
 
-def sampler_step(net, x_bnc, alpha, lmbda, weight, t_sink=None, defer_value=False):
-    """-> (loss, simp (B,3,M), proj (B,M,3)) for a training-mode SampleNet with projection on a (B,N,3) batch."""
+def sampler_step(net, x_bnc, alpha, lmbda, weight, t_sink=None, defer_value=False, mean_proj=True):
+    """-> (loss, simp (B,3,M), proj (B,M,3)) for a training-mode SampleNet with projection on a (B,N,3) batch.
+    mean_proj=False: proj is differentiable and the loss carries no task term (see SamplerStepFunction)."""
     sd = dict(net.named_parameters())
     params = [sd[n] for n in pointnet.param_order(net)]
     proj = net.project
     return SamplerStepFunction.apply(net, x_bnc, proj._temperature, proj._group_size, proj._min_sigma_f, alpha, lmbda, weight,
-                                     t_sink, defer_value, *params)
+                                     t_sink, defer_value, mean_proj, *params)
+
+
+def external_task_supported(net, x_bnc):
+    """True when sampler_step(..., defer_value=True, mean_proj=False) can run this batch (keys-mode scan: N <= 2048 and a batch
+    small enough that clouds are split over workgroups)."""
+    B, N, _ = x_bnc.shape
+    return bool(KEYS_LOSS and N <= 2048 and ops.lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1)
 
 
 class _DirectCtx:
@@ -151,7 +180,7 @@ def sampler_step_direct(net, x_bnc, alpha, lmbda, weight, t_sink, grad_loss, aft
     try:
         with torch.no_grad():
             loss, y, p = SamplerStepFunction.forward(ctx, net, x_bnc, proj._temperature, proj._group_size, proj._min_sigma_f, alpha,
-                                                     lmbda, weight, t_sink, True, *params)
+                                                     lmbda, weight, t_sink, True, True, *params)
             SamplerStepFunction.backward(ctx, grad_loss)
     finally:
         net._after_fc_grads = prev

@@ -28,9 +28,11 @@ class FlatGradAllReducer:
     conv stack's backward starts.
 
     force_collective: issue the collectives even at world size 1 (single-GPU exercise of the RCCL path: tests, bench).
+    kernel_written: names of the parameters whose gradients the module's backward writes into the views itself (default: what
+    pointnet.param_order names for the HIP model on a GPU, nothing otherwise).
     """
 
-    def __init__(self, module, process_group=None, overlap=True, force_collective=False):
+    def __init__(self, module, process_group=None, overlap=True, force_collective=False, kernel_written=None):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -51,11 +53,16 @@ class FlatGradAllReducer:
         # ... and of the HIP model only the parameters the MLP node differentiates (pointnet.param_order): a BatchNorm behind
         # the last FC layer (classification sampler) is applied by torch on the head's output, its gradients come through
         # autograd like the temperature's and must be zeroed / re-bound with them
-        kernel_written = set()
-        if hip_mlp:
+        # (kernel_written=: explicit list for modules whose backward fills the sink views itself -- the CPU stand-in of the
+        #  multi-process tests)
+        if kernel_written is not None:
+            kernel_written = set(kernel_written)
+        elif hip_mlp:
             from .pointnet import param_order
 
             kernel_written = set(param_order(module))
+        else:
+            kernel_written = set()
         sink, off = {}, 0
         self._autograd = []  # (parameter, view): gradients that arrive through autograd's accumulate
         for n, p in order:
@@ -74,6 +81,8 @@ class FlatGradAllReducer:
         self.overlap = bool(overlap and self.collective and dev.type == "cuda" and hip_mlp)
         self._side = torch.cuda.Stream(device=dev) if (self.collective and dev.type == "cuda") else None
         self._early_work = None
+        self._sentinel = None
+        self.capture_fork = False  # engine, "graph-fork" mode: the early collective may be issued while a graph is being captured
         if self.overlap:
             module._after_fc_grads = self._early_ready
 
@@ -116,13 +125,19 @@ class FlatGradAllReducer:
                 view.copy_(g)
             p.grad = view
         # the kernel-written views: after optimizer.zero_grad(set_to_none=True) a graph REPLAY has filled them without any
-        # Python running (GradSink.commit re-binds only while the backward executes eagerly or is being captured)
+        # Python running (GradSink.commit re-binds only while the backward executes eagerly or is being captured).
+        # zero_grad() drops all of them together: one sentinel decides whether the walk is needed (this runs per step)
         sink = getattr(self.module, "_grad_sink", None)
-        if sink is not None:
-            for n, view in sink.items():
-                p = sink.params[n]
-                if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                    p.grad = view
+        if sink:
+            if self._sentinel is None:
+                n0 = next(iter(sink))
+                self._sentinel = (sink.params[n0], sink[n0])
+            p0, v0 = self._sentinel
+            if p0.grad is None or p0.grad.data_ptr() != v0.data_ptr():
+                for n, view in sink.items():
+                    p = sink.params[n]
+                    if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                        p.grad = view
 
     # ---------------------------------------------------------------------------------------- collectives
     def _op(self):
@@ -139,14 +154,15 @@ class FlatGradAllReducer:
             self._early_work = dist.all_reduce(self.flat[: self.n_early], op=self._op(), group=self.group, async_op=True)
 
     def _early_ready(self):
-        if torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing() and not self.capture_fork:
             return
         self.reduce_early_async()
 
-    def reduce(self):
-        """Call after backward(): on return (stream-ordered) every .grad holds the cross-rank mean."""
+    def reduce(self, collective=True):
+        """Call after backward(): on return (stream-ordered) every .grad holds the cross-rank mean.
+        collective=False: only the .grad bookkeeping (the engine's captured step carries the collectives inside its graph)."""
         self._rebind()
-        if not self.collective:
+        if not collective or not self.collective:
             return
         # RCCL averages inside the collective (ReduceOp.AVG): no separate scaling kernel; gloo (CPU tests) sums, then scales
         if self._early_work is not None:

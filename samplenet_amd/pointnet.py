@@ -257,6 +257,47 @@ def _fc_chain_fwd(net, hidden, pooled, B, saved):
     return True
 
 
+_CHAIN_ERRORS = {1: "forward seam 0", 2: "forward seam 1", 3: "forward seam 2", 64: "epoch hand-over of the backward chain"}
+
+
+def chain_error_words(net):
+    """(forward, backward) error words of the module's FC chain launches as Python ints -- a HOST READ (synchronises the
+    stream): 0 = healthy.  See check_chain_errors."""
+    out = []
+    for name in ("_fc_sync", "_fc_sync_b"):
+        t = getattr(net, name, None)
+        out.append(int(t[15].item()) if t is not None else 0)
+    return tuple(out)
+
+
+def check_chain_errors(net, raise_error=True):
+    """The FC chain kernels (sn_fc_chain_forward / _backward: 8 and 16 workgroups that hand activations to each other inside
+    ONE launch) need their workgroups resident together; a device kept full by other work (another process, a collective's
+    persistent kernels on every CU) can starve one of them, the others' polls then give up instead of hanging the GPU.  The
+    kernels make that visible on the device -- NaN in place of their outputs, hence a NaN loss and NaN gradients, and a NaN loss
+    value from the fused step's tail -- and here on the host: a non-zero error word raises SampleNetHipError after the launch
+    state was re-armed (counters zeroed; the next step runs normally).  Costs a device synchronisation: call it where the loss
+    is read back anyway (engine.SamplerTrainStep.check(), bench.py after the timed loop), not per step."""
+    from ._lib import SampleNetHipError
+
+    words = chain_error_words(net)
+    if not any(words):
+        return False
+    for name in ("_fc_sync", "_fc_sync_b"):
+        t = getattr(net, name, None)
+        if t is not None:
+            limit = int(t[13].item())
+            t.zero_()  # epoch + monotonic arrival counters are out of step after a timeout: start over
+            t[13] = limit
+    if raise_error:
+        what = ["%s chain: %s" % (d, _CHAIN_ERRORS.get(w, "hand-off %d" % w)) for d, w in zip(("forward", "backward"), words) if w]
+        raise SampleNetHipError("FC chain launch timed out waiting for a co-resident workgroup (%s); its outputs were poisoned "
+                                "with NaN -- this step's loss / gradients are invalid.  The device was too busy to hold the "
+                                "chain's workgroups together (8 / 16 workgroups x 137 KB LDS); the launch state was reset."
+                                % "; ".join(what))
+    return True
+
+
 def forward_impl(net, x_bnc, training, skip_last=False):
     """x (B,N,3) contiguous -> y (B, 3*M) and the tensors backward needs.
     skip_last: stop before fc4 and return None for y -- the caller produces it from saved["zf"][2] / saved["cf"][2] (the
@@ -646,6 +687,9 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
         grads[bn_c[4] + ".weight"], grads[bn_c[4] + ".bias"], grads[names_c[4] + ".bias"] = dgamma, dbeta, dbias
 
     # ---- conv stack (rows = B*N): conv5 -> ... -> conv2 (each also finishes the BatchNorm of the layer below), conv1 ----
+    if step_tail is not None:  # the loss value the deferred tail writes turns NaN when a chain launch of this step timed out
+        check(lib.sn_step_tail_set_error_words(step_tail, ptr(getattr(net, "_fc_sync", None)), ptr(getattr(net, "_fc_sync_b", None))),
+              "sn_step_tail_set_error_words")
     if not fixed and FX_STATS and IN3_CLOSED_FORM and _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef, sink, grads, names_c, bn_c, step_tail):
         return grads
     if step_tail is not None:

@@ -384,6 +384,66 @@ def golden_pcrnet(ChamferDistance):
          loss=np.float32(loss.item()), qnorm=np.float32(qnorm.item()), grad_p0=p0.grad.numpy(), **sums, **gn)
 
 
+def golden_samplenet_task(SampleNet, ChamferDistance):
+    """The sampler's training step with the REAL task loss, as registration/main.py composes it (compute_samplenet_loss
+    :500-537 with NUM_SAMPLED_CLOUDS == 1, compute_pcrnet_loss :557-598 with --loss-type 1):
+        p1_simplified, p1_projected = sampler(p1)
+        L = pcrnet_chamfer(PCRNet(p0, p1_projected)) + ALPHA * simplification_loss + LMBDA * projection_loss
+    through the reference SampleNet, the reference PCRNet (frozen, default init under a fixed seed: the test rebuilds it the same
+    way, checksums stored) and the reference's compiled Chamfer, in fp32 and in fp64 (the exact answer).  B = 32, 1024 -> 64,
+    K = 8 (BASELINE configs[1] with the registration task on top)."""
+    sys.path.insert(0, os.path.join(REF, "registration"))
+    pcr_mod = importlib.import_module("models.pcrnet")
+    Q = importlib.import_module("src.quaternion")
+    B, N, M, K = 32, 1024, 64, 8
+    out, res = {}, {}
+    for prec in ("f32", "f64"):
+        torch.manual_seed(0)
+        net = SampleNet(M, 128, group_size=K, initial_temperature=1.0, is_temperature_trainable=True,
+                        min_sigma=1e-2, input_shape="bnc", output_shape="bnc")
+        p1 = torch.rand(B, N, 3) - 0.5          # source (sampled)
+        p0 = torch.rand(B, N, 3) - 0.5          # template (complete)
+        torch.manual_seed(31)
+        pcr = pcr_mod.PCRNet(bottleneck_size=1024, input_shape="bnc")
+        for q in pcr.parameters():
+            q.requires_grad_(False)
+        if prec == "f32":
+            for k, v in net.state_dict().items():
+                out["sd_" + k] = v.clone().numpy()
+            out["p0"], out["p1"] = p0.numpy(), p1.numpy()
+            for n, q in pcr.named_parameters():
+                out["pcrsum_" + n.replace(".", "_")] = np.float64(q.detach().double().abs().sum())
+        else:
+            net, pcr = net.double(), pcr.double()
+            net.project._min_sigma = net.project._min_sigma.double()
+            p0, p1 = p0.double(), p1.double()
+        net.train()
+        pcr.eval()
+        simp, proj = net(p1)
+        lsimp = net.get_simplification_loss(p1, simp, M, 1.0, 0.0)
+        lproj = net.get_projection_loss()
+        twist, pre = pcr(p0, proj)
+        quat = twist[:, 0:4].unsqueeze(1).expand([-1, N, -1]).contiguous()
+        p1_est = Q.qrot(quat, p0)
+        c01, c10 = ChamferDistance()(proj.contiguous(), p1_est.contiguous())
+        task = torch.mean(c01) + torch.mean(c10)
+        loss = task + 0.01 * lsimp + 0.01 * lproj
+        loss.backward()
+        res[prec] = {k: p.grad.numpy() for k, p in net.named_parameters()}
+        sfx = "" if prec == "f32" else "_f64"
+        for k, v in (("simp", simp), ("proj", proj), ("loss", loss), ("task", task), ("lsimp", lsimp), ("twist", twist)):
+            v = v.detach().numpy()
+            out[k + sfx] = v if v.ndim == 0 else v.astype(np.float32)
+        for k, gr in res[prec].items():
+            out["grad%s_%s" % (sfx, k)] = gr.astype(np.float32)
+    g32 = np.concatenate([v.ravel() for v in res["f32"].values()]).astype(np.float64)
+    g64 = np.concatenate([v.ravel() for v in res["f64"].values()])
+    print("task step: reference fp32 vs fp64 gradient gap %.3g, loss %.9f / %.9f" % (
+        np.linalg.norm(g32 - g64) / np.linalg.norm(g64), float(out["loss"]), float(out["loss_f64"])))
+    np.savez_compressed(os.path.join(HERE, "samplenet_task_reference.npz"), **out)
+    print("wrote tests/golden/samplenet_task_reference.npz (%d arrays)" % len(out))
+
+
 def golden_loaders():
     """Row f4 (reconstruction/src/in_out.py): PLY fixtures WRITTEN by the reference's vendored plyfile package (ascii,
     binary_little_endian, binary_big_endian; vertices + colours + triangle faces) under tests/golden/ply/<syn_id>/<model>.ply
@@ -499,7 +559,8 @@ if __name__ == "__main__":
     jobs = {"known": golden_known_answers, "softproj": lambda: golden_softproj(sp_mod.SoftProjection),
             "chamfer": lambda: golden_chamfer(ChamferDistance), "samplenet": lambda: golden_samplenet(sn_mod.SampleNet),
             "c2": lambda: golden_samplenet_c2(sn_mod.SampleNet), "nn_matching": lambda: golden_nn_matching(sputils),
-            "pcrnet": lambda: golden_pcrnet(ChamferDistance), "loaders": golden_loaders, "modelnet": golden_modelnet}
+            "pcrnet": lambda: golden_pcrnet(ChamferDistance), "loaders": golden_loaders, "modelnet": golden_modelnet,
+            "task": lambda: golden_samplenet_task(sn_mod.SampleNet, ChamferDistance)}
     for name in (sys.argv[1:] or list(jobs)):  # python make_golden.py [job ...]   (default: all)
         jobs[name]()
     left = [p for p, _, fs in os.walk(REF) for f in fs if f.endswith(".pyc") or f == "__pycache__"]

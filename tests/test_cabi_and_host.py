@@ -24,10 +24,13 @@ def libpath():
     return path
 
 
-def _header_functions():
-    text = open(os.path.join(ROOT, "include", "samplenet_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sn_[a-z0-9_]+)\s*\(", text)))
+def _header_functions(which=("samplenet_hip.h", "samplenet_hip_internal.h")):
+    names = set()
+    for h in which:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(sn_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(libpath):
@@ -45,6 +48,20 @@ def test_library_exports_every_declared_symbol(libpath):
     # reference op allocates (b,(n+m)*2) floats (tf_approxmatch.cpp:167-168); ours keeps all 10 levels' ratio vectors
     assert lib.sn_workspace_bytes(b"approxmatch", 2, 100, 50, 0) == 2 * (100 + 50) * 11 * 4
     assert lib.sn_workspace_bytes(b"matchcost", 3, 600, 50, 0) == 3 * 3 * 4
+
+
+def test_public_header_is_the_drop_in_boundary():
+    """include/samplenet_hip.h holds the entries that replace a reference interface and nothing of the fused-step
+    plumbing; samplenet_hip_internal.h holds the rest."""
+    public = set(_header_functions(("samplenet_hip.h",)))
+    internal = set(_header_functions(("samplenet_hip_internal.h",)))
+    assert not public & internal
+    for name in ("sn_pairscan_forward", "sn_knn", "sn_chamfer_forward", "sn_chamfer_backward", "sn_group_point", "sn_group_point_grad",
+                 "sn_grouping_operation", "sn_soft_project_backward", "sn_approxmatch", "sn_matchcost", "sn_matchcost_grad",
+                 "sn_linear_forward", "sn_linear_dgrad", "sn_linear_wgrad", "sn_abi_version", "sn_last_error_string"):
+        assert name in public, name  # SURVEY 8b's list of what a C-ABI replacement must export
+    assert not [n for n in public if re.search(r"step|fc_chain|conv_stack|_keys|_partial|tail", n)], public
+    assert len(public) <= 45
 
 
 def test_python_prototypes_cover_the_header(libpath):
@@ -102,3 +119,24 @@ def test_sputils_matches_reference_golden(golden):
     a = sputils.get_parser().parse_args([])
     assert (a.num_in_points, a.num_out_points, a.bottleneck_size, a.projection_group_size) == (1024, 64, 128, 8)
     assert (a.alpha, a.gamma, a.delta, a.lmbda, a.skip_projection) == (0.01, 1, 0, 0.01, False)
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus N` outside torch.distributed.run (the driver's call) starts its own N ranks and passes rank 0's
+    JSON line through -- exercised here with the launcher self-test (gloo, CPU; no measurement); without enough GPUs the
+    real call exits with a message and code 2, not a traceback."""
+    import json
+    import subprocess
+    import sys
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--launcher-selftest"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"launcher_selftest": True, "n_gpus": 2, "rank_sum": 1.0}
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 2 and "exposes 0 GPU" in r.stderr and "Traceback" not in r.stderr

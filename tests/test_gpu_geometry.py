@@ -196,6 +196,82 @@ def test_knn_compat_shim_interface(oracle):
     assert np.array_equal(i.cpu().numpy(), oi)
 
 
+def test_cd_plugin_surface_with_caller_allocated_outputs(oracle):
+    """samplenet_amd.compat.cd = the reference's pybind module `cd` (chamfer_distance.cpp:180-185) over the C ABI, driven the way
+    registration/src/chamfer_distance/chamfer_distance.py:14-66 drives it: the CALLER allocates every output (zeros, as the
+    reference does) and the functions write them in place.  Bit-exact against the oracle, forward and backward; a side
+    stream is honoured; CPU tensors raise."""
+    from samplenet_amd.compat import cd
+
+    rng = np.random.default_rng(4)
+    for (B, n, m) in [(32, 64, 1024), (3, 100, 37)]:
+        a, b = rng.random((B, n, 3), dtype=np.float32) - 0.5, rng.random((B, m, 3), dtype=np.float32) - 0.5
+        xyz1, xyz2 = dev(a), dev(b)
+        # chamfer_distance.py:21-34
+        dist1, dist2 = torch.zeros(B, n).cuda(), torch.zeros(B, m).cuda()
+        idx1, idx2 = torch.zeros(B, n, dtype=torch.int).cuda(), torch.zeros(B, m, dtype=torch.int).cuda()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            assert cd.forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2) is None
+        torch.cuda.current_stream().wait_stream(side)
+        od1, oi1, od2, oi2 = oracle.chamfer_forward(a, b)
+        assert np.array_equal(dist1.cpu().numpy(), od1) and np.array_equal(idx1.cpu().numpy(), oi1)
+        assert np.array_equal(dist2.cpu().numpy(), od2) and np.array_equal(idx2.cpu().numpy(), oi2)
+        # chamfer_distance.py:44-59
+        g1, g2 = rng.standard_normal((B, n)).astype(np.float32), rng.standard_normal((B, m)).astype(np.float32)
+        gradxyz1, gradxyz2 = torch.zeros(xyz1.size()).cuda(), torch.zeros(xyz2.size()).cuda()
+        assert cd.backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, dev(g1), dev(g2), idx1, idx2) is None
+        og1, og2 = oracle.chamfer_backward(a, b, g1, oi1, g2, oi2)
+        assert np.array_equal(gradxyz1.cpu().numpy(), og1) and np.array_equal(gradxyz2.cpu().numpy(), og2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        cd.forward(xyz1.cpu(), xyz2.cpu(), dist1.cpu(), dist2.cpu(), idx1.cpu(), idx2.cpu())
+    with pytest.raises(RuntimeError):
+        cd.forward_cuda(xyz1.cpu(), xyz2, dist1, dist2, idx1, idx2)
+    with pytest.raises(RuntimeError):
+        cd.forward_cuda(xyz1, xyz2, dist1, dist2, idx1.long(), idx2)
+
+
+def test_reference_call_pattern_over_the_compat_packages(oracle):
+    """INTEGRATION level 1: the reference's SoftProjection.project (registration/src/soft_projection.py:11-14, 75-99, 138-152),
+    restated here call for call in plain torch -- knn_cuda.KNN(k, transpose_mode=False)(ref, query), the permute / int cast,
+    pointnet2_utils.grouping_operation, softmax over the group -- with the two third-party names resolved through
+    samplenet_amd.compat.install().  (The reference file itself cannot be imported on the GPU box: /root/reference is not
+    there.)  Same projection and same gradients as the fused kernel path and the oracle."""
+    import importlib
+
+    from samplenet_amd import SoftProjection, compat
+
+    compat.install()
+    KNN = importlib.import_module("knn_cuda").KNN
+    grouping_operation = importlib.import_module("pointnet2.utils.pointnet2_utils").grouping_operation
+    rng = np.random.default_rng(12)
+    B, N, M, K, sigma = 4, 1024, 64, 8, 0.09
+    P, Q = rng.random((B, 3, N), dtype=np.float32) - 0.5, rng.random((B, 3, M), dtype=np.float32) - 0.5
+    pc, qc = dev(P), dev(Q).requires_grad_(True)
+    # soft_projection.py:11-14 + 75-90
+    _, idx = KNN(K, transpose_mode=False)(pc.contiguous(), qc.detach().contiguous())
+    idx = idx.permute(0, 2, 1).type(torch.int32)
+    grouped = grouping_operation(pc, idx.contiguous())                                   # (B,3,M,K)
+    # :92-95, 138-152
+    deltas = grouped - qc.unsqueeze(-1).expand_as(grouped)
+    dist = torch.sum(deltas ** 2, dim=1, keepdim=True) / sigma
+    weights = torch.softmax(-dist, dim=3).repeat(1, 3, 1, 1)
+    proj = torch.sum(grouped * weights, dim=3)
+    go = dev(rng.standard_normal((B, 3, M)).astype(np.float32))
+    (gq,) = torch.autograd.grad(proj, qc, go)
+    _, oidx = oracle.knn(K, P.transpose(0, 2, 1), Q.transpose(0, 2, 1))
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    oproj, _, _ = oracle.softproj_forward(P, Q, oidx, sigma)
+    np.testing.assert_allclose(proj.detach().cpu().numpy(), oproj, rtol=0, atol=1e-6)
+    sp = SoftProjection(K, initial_temperature=0.3, min_sigma=1e-4).cuda()
+    q2 = dev(Q).requires_grad_(True)
+    proj2 = sp(pc, q2)
+    (gq2,) = torch.autograd.grad(proj2, q2, go)
+    np.testing.assert_allclose(proj2.detach().cpu().numpy(), proj.detach().cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(gq2.cpu().numpy(), gq.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------ gathers
 @pytest.mark.parametrize("shape", [(3, 50, 6, 11, 4), (2, 1024, 3, 64, 8), (2, 300, 5, 130, 3), (1, 70, 1, 1, 1)])
 def test_group_point_and_grad(oracle, shape):
@@ -214,6 +290,29 @@ def test_group_point_and_grad(oracle, shape):
     go = rng.standard_normal((b, m, ns, c)).astype(np.float32)
     (g,) = torch.autograd.grad(out, t, dev(go))
     assert np.array_equal(g.cpu().numpy(), oracle.group_point_grad(pts.shape, idx, go))
+
+
+def test_large_grouping_gradients_take_the_atomic_route():
+    """PointNet++-sized grouping (n = 16384 rows, 16384 x 32 indices per cloud): the ordered scan would cost (n / 64) x ne index
+    loads per cloud, so beyond 2^26 of those the gradient is scattered with float atomics into a zeroed destination, like the
+    reference's own kernels (tf_grouping_g.cu:60-78) -- same sums, summation order free: compared with torch.index_add_ in fp64."""
+    from samplenet_amd import ops
+
+    b, n, c, m, ns = 2, 16384, 4, 16384, 32
+    assert (n // 64) * m * ns > 1 << 26
+    g = torch.Generator(device="cuda").manual_seed(8)
+    idx = torch.randint(0, n, (b, m, ns), device="cuda", generator=g, dtype=torch.int32)
+    go = torch.randn(b, m, ns, c, device="cuda", generator=g)
+    pts = torch.zeros(b, n, c, device="cuda", requires_grad=True)
+    (gp,) = torch.autograd.grad(ops.group_point(pts, idx), pts, go)
+    want = torch.zeros(b, n, c, device="cuda", dtype=torch.float64)
+    for i in range(b):
+        want[i].index_add_(0, idx[i].reshape(-1).long(), go[i].reshape(-1, c).double())
+    assert float((gp.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    feat = torch.zeros(b, c, n, device="cuda", requires_grad=True)
+    go2 = go.permute(0, 3, 1, 2).contiguous()  # (b, c, m, ns)
+    (gf,) = torch.autograd.grad(ops.grouping_operation(feat, idx), feat, go2)
+    assert float((gf.double() - want.permute(0, 2, 1)).abs().max()) <= 1e-4 * float(want.abs().max())
 
 
 @pytest.mark.parametrize("shape", [(2, 5, 64, 9, 8), (2, 3, 1024, 64, 8), (1, 7, 333, 200, 2)])

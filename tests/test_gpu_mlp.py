@@ -718,3 +718,76 @@ def test_fc_chain_backward_equals_per_layer_launches(B, bneck, variant, training
         pointnet.FC_CHAIN = old
     torch.cuda.synchronize()
     assert int(net._fc_sync_b[15]) == 0 and int(net._fc_sync_b[0]) == 3
+
+
+def _provoke(sync, counter):
+    """A hand-off of the NEXT chain launch that can never complete: its arrival counter lags a thousand arrivals behind what
+    the launch will wait for (the effect of a workgroup that is not resident), with a short poll bound instead of seconds."""
+    sync[13] = 3000
+    sync[counter] -= 1000
+
+
+@pytest.mark.parametrize("which", ["forward", "backward"])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_fc_chain_timeout_is_never_silent(which, use_graph):
+    """VERDICT r2 / ADVICE r2: a chain kernel whose inter-workgroup poll gives up used to set sync[15] and train on garbage with a
+    finite loss.  Now: the workgroups that saw the timeout write NaN instead of their outputs (forward: the head's last
+    activations -> NaN simplified cloud, NaN loss, NaN gradients; backward: NaN parameter gradients), the fused step's deferred
+    tail turns the loss VALUE into NaN from the error words, and the host check raises and re-arms the launch state -- after
+    which the step is healthy again and reproduces the loss it had before."""
+    from samplenet_amd import SampleNet, pointnet
+    from samplenet_amd._lib import SampleNetHipError
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(5)
+    net = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    red = FlatGradAllReducer(net)
+    x = torch.rand(32, 1024, 3, device="cuda") - 0.5
+    step = SamplerTrainStep(net, x, reducer=red, use_graph=use_graph)
+    assert step._fast_path()
+    good = float(step(x))
+    step.check()
+    assert good == good and pointnet.chain_error_words(net) == (0, 0)
+    flat_good = red.flat.clone()
+    if which == "forward":
+        _provoke(net._fc_sync, 1)       # seam 0 of the forward chain
+    else:
+        _provoke(net._fc_sync_b, 2)     # arrivals of the backward chain's second stage
+    loss = step(x)
+    torch.cuda.synchronize()
+    words = pointnet.chain_error_words(net)
+    assert words[0 if which == "forward" else 1] != 0, words
+    assert torch.isnan(loss).item(), float(loss)            # no finite loss on incomplete data
+    assert torch.isnan(red.flat).any().item()                # ... and no clean-looking gradients
+    with pytest.raises(SampleNetHipError, match="timed out"):
+        step.check()
+    assert pointnet.chain_error_words(net) == (0, 0)         # re-armed by the check
+    for t in (net._fc_sync, net._fc_sync_b):
+        t[13] = 0                                            # (default poll bound again)
+    again = step(x)
+    torch.cuda.synchronize()
+    step.check()
+    assert float(again) == good and torch.equal(red.flat, flat_good)
+
+
+def test_fc_chain_timeout_in_the_module_surface():
+    """The same through the plain module surface (no engine, no deferred tail): a timed-out forward chain yields a NaN
+    simplified cloud (hence NaN losses), pointnet.check_chain_errors raises."""
+    from samplenet_amd import SampleNet, pointnet
+    from samplenet_amd._lib import SampleNetHipError
+
+    torch.manual_seed(6)
+    net = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    x = torch.rand(16, 512, 3, device="cuda") - 0.5
+    simp, proj = net(x)
+    assert torch.isfinite(simp).all() and not pointnet.check_chain_errors(net)
+    _provoke(net._fc_sync, 2)
+    simp, proj = net(x)
+    loss = net.get_simplification_loss(x, simp, 64, 1, 0) + proj.mean()
+    assert torch.isnan(simp).any() and torch.isnan(loss)
+    with pytest.raises(SampleNetHipError):
+        pointnet.check_chain_errors(net)
+    net._fc_sync[13] = 0
+    simp, _ = net(x)
+    assert torch.isfinite(simp).all() and not pointnet.check_chain_errors(net)

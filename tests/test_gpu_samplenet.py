@@ -191,7 +191,7 @@ def test_single_node_step_loss_equals_composition(B, N, M, K):
     assert step_a._fast_path()
     la = step_a(x)
     lb = SamplerTrainStep(net_b, x, reducer=red_b, fused_loss=False, **kw)(x)
-    lc = SamplerTrainStep(net_c, x, reducer=red_c, task_loss=lambda p: p.mean(), **kw)(x)
+    lc = SamplerTrainStep(net_c, x, reducer=red_c, task_loss=lambda p: p.mean(), fused_loss=False, **kw)(x)  # general path
     ld = SamplerTrainStep(net_d, x, reducer=None, fused_head=False, **kw)(x)
     for other in (lb, lc, ld):
         assert abs(float(la) - float(other)) <= 1e-6 * max(1.0, abs(float(other)))
@@ -573,3 +573,111 @@ def test_device_batch_ring_feeds_the_captured_step():
         ga = red_a.flat.clone()
         lb = step_b(torch.from_numpy(batches[t]).cuda())
         assert torch.equal(la, lb) and torch.equal(ga, red_b.flat), t
+
+
+# ------------------------------------------------------------------------------------------ fused step + outside task loss
+@pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (6, 512, 64, 8), (3, 320, 20, 5)])
+def test_fused_step_with_external_task_gradient(B, N, M, K):
+    """engine fast path with a task loss OUTSIDE the node (fused_step.SamplerStepFunction(mean_proj=False): proj differentiable,
+    its upstream gradient an explicit operand of the loss backward) against
+      (a) the same node with the stand-in task mean(proj) inside (implicit constant gradient): same gradients (1e-6), loss 1e-6;
+      (b) the op-by-op general path with a NON-uniform task loss: bars of test_head_fused_into_scan (fc4 inside the scan);
+      (c) its own graph replay: bit-identical."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(B + N + 5)
+    net_a = SampleNet(M, 128, group_size=K, initial_temperature=0.7, input_shape="bnc", output_shape="bnc").cuda().train()
+    nets = [net_a] + [copy.deepcopy(net_a) for _ in range(5)]
+    reds = [FlatGradAllReducer(n) for n in nets]
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    w = torch.randn(B, M, 3, device="cuda")
+    kw = dict(alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01)
+
+    def task(p):
+        return (p * w).sum() / B + (p ** 2).mean()
+
+    s_in = SamplerTrainStep(nets[0], x, reducer=reds[0], use_graph=False, **kw)                                   # mean(proj) inside
+    s_out = SamplerTrainStep(nets[1], x, reducer=reds[1], use_graph=False, task_loss=lambda p: p.mean(), **kw)    # ... outside
+    assert s_in._fast_path() and s_out._fast_path()
+    l_in, l_out = s_in(x), s_out(x)
+    assert abs(float(l_in) - float(l_out)) <= 1e-6 * max(1.0, abs(float(l_in)))
+    assert torch.allclose(reds[0].flat, reds[1].flat, rtol=1e-6, atol=1e-9)
+    s_f = SamplerTrainStep(nets[2], x, reducer=reds[2], use_graph=False, task_loss=task, **kw)
+    s_g = SamplerTrainStep(nets[3], x, reducer=reds[3], use_graph=False, task_loss=task, fused_loss=False, **kw)
+    assert s_f._fast_path() and not s_g._fast_path()
+    lf, lg = s_f(x), s_g(x)
+    assert abs(float(lf) - float(lg)) <= 1e-5 * max(1.0, abs(float(lg)))
+    gg = {n: p.grad for n, p in nets[3].named_parameters()}
+    gmax = max(float(v.norm()) for v in gg.values())
+    for n, p in nets[2].named_parameters():
+        assert float((p.grad - gg[n]).norm()) <= 1e-4 * float(gg[n].norm()) + 1e-6 * gmax, n
+    s_c = SamplerTrainStep(nets[4], x, reducer=reds[4], use_graph=True, task_loss=task, **kw)
+    assert s_c._fast_path() and s_c._ring_graphs
+    for _ in range(2):
+        lc = s_c(x)
+    torch.cuda.synchronize()
+    # (the captured step ran warm-up + replays: BatchNorm running statistics differ, the batch-statistics forward does not)
+    assert float(lc) == float(lf) and torch.equal(reds[4].flat, reds[2].flat)
+    s_c.check()
+    # a task loss that does not touch proj at all: the projection branch gets a ZERO gradient (not the implicit constant)
+    s_z = SamplerTrainStep(nets[5], x, reducer=reds[5], use_graph=False, task_loss=lambda p: p.detach().sum() * 0 + 1.0, **kw)
+    lz = s_z(x)
+    assert torch.isfinite(lz) and abs(float(lz) - 1.0 - (float(l_in) - float(s_in.outputs[1].mean()))) <= 1e-5
+
+
+def test_captured_step_survives_optimizer_zero_grad():
+    """SamplerTrainStep(use_graph=True) + optimizer.zero_grad() (set_to_none=True) + replay + optimizer.step():
+    the replay writes the bucket views without any Python running, reduce() re-binds them -- every parameter must move."""
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(12)
+    net = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    red = FlatGradAllReducer(net)
+    x = torch.rand(32, 1024, 3, device="cuda") - 0.5
+    step = SamplerTrainStep(net, x, reducer=red, use_graph=True)
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    for _ in range(2):
+        opt.zero_grad()
+        assert all(p.grad is None for p in net.parameters())
+        step(x)
+        assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() == red.flat.untyped_storage().data_ptr()
+                   for p in net.parameters())
+        opt.step()
+    moved = {n for n, p in net.named_parameters() if not torch.equal(p.detach(), before[n])}
+    must = {n for n, _ in net.named_parameters() if not (n.endswith(".bias") and n.split(".")[0] in
+                                                         ("conv1", "conv2", "conv3", "conv4", "conv5", "fc1", "fc2", "fc3"))}
+    assert must <= moved, sorted(must - moved)
+
+
+def test_classification_variant_with_reducer_does_not_pile_up_gradients():
+    """last_fc_batchnorm=True puts a torch BatchNorm behind the head; its gradients arrive through autograd, so the
+    reducer must zero / re-bind them with the temperature instead of treating them as kernel-written.  Two identical steps must
+    leave identical buckets."""
+    from samplenet_amd import SampleNet
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(13)
+    net = SampleNet(32, 64, group_size=7, last_fc_batchnorm=True, min_sigma=0.0, input_shape="bnc", output_shape="bnc").cuda().train()
+    red = FlatGradAllReducer(net)
+    assert "bn_fc4.weight" not in net._grad_sink and any(p is net.bn_fc4.weight for p, _ in red._autograd)
+    x = torch.rand(8, 256, 3, device="cuda") - 0.5
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    flats = []
+    for _ in range(2):
+        opt.zero_grad()
+        _module_loss(net, x).backward()
+        red.reduce()
+        flats.append(red.flat.clone())
+    assert float(net.bn_fc4.weight.grad.abs().sum()) > 0
+    assert torch.allclose(flats[0], flats[1], rtol=1e-6, atol=1e-9)
+    red.zero_grad()  # the reducer's own flavour
+    _module_loss(net, x).backward()
+    red.reduce()
+    assert torch.allclose(red.flat, flats[0], rtol=1e-6, atol=1e-9)

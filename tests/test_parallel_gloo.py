@@ -78,3 +78,198 @@ def test_two_rank_gradient_average_equals_big_batch(tmp_path):
     with pytest.raises(ValueError):
         shard_batch(torch.zeros(7, 4, 3), 0, 2)
     assert torch.equal(shard_batch(x_all, 1, 2), x_all[4:])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The engine / reducer code path WITH the gradient-sink semantics (pointnet.GradSink: the first backward of a step overwrites the
+# bucket views, further ones accumulate, views are re-bound after optimizer.zero_grad()) under two ranks.  The HIP kernels
+# cannot run here, so `_SinkNet` stands in for the HIP model the way that matters to this code: its backward WRITES the
+# gradients of `fc.*` into module._grad_sink's views itself and hands nothing to autograd; `project.t` arrives through
+# autograd's accumulate like the temperature.
+class _SinkLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, W, b):
+        ctx.net = net
+        ctx.save_for_backward(x, W)
+        return x @ W.t() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        from samplenet_amd import pointnet
+
+        x, W = ctx.saved_tensors
+        fresh = {"fc.weight": g.t() @ x, "fc.bias": g.sum(0)}
+        sink, owner = pointnet.sink_for_backward(ctx.net)
+        if sink is not None:  # (the kernels' in-place route)
+            for n, v in fresh.items():
+                sink[n].copy_(v)
+        if owner is not None:
+            owner.commit(None if sink is not None else fresh)
+            return None, None, None, None
+        return None, None, fresh["fc.weight"], fresh["fc.bias"]
+
+
+class _Project(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.t = torch.nn.Parameter(torch.tensor(1.5))
+
+
+class _SinkNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc = torch.nn.Linear(6, 4)
+        self.project = _Project()
+
+    def forward(self, x):
+        return _SinkLinear.apply(self, x, self.fc.weight, self.fc.bias) * self.project.t
+
+
+def _sink_loss(net, x):
+    return (net(x) ** 2).mean()
+
+
+def _sink_worker(rank, world, port, x_all, state, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from samplenet_amd.parallel import FlatGradAllReducer, shard_batch
+
+    net = _SinkNet()
+    net.load_state_dict(state)
+    red = FlatGradAllReducer(net, kernel_written=["fc.weight", "fc.bias"])
+    assert set(net._grad_sink) == {"fc.weight", "fc.bias"} and [p is net.project.t for p, _ in red._autograd] == [True]
+    x = shard_batch(x_all, rank, world)
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    out = {}
+    # 1. plain step: zero_grad() of the reducer, one backward (overwrites the views), reduce
+    red.zero_grad()
+    _sink_loss(net, x).backward()
+    red.reduce()
+    out["plain"] = red.flat.clone()
+    # 2. optimizer.zero_grad() (set_to_none=True): the views are dropped; the backward's commit takes them back
+    opt.zero_grad()
+    assert net.fc.weight.grad is None and net.project.t.grad is None
+    _sink_loss(net, x).backward()
+    red.reduce()
+    assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in
+               [(net._grad_sink.params[n], v) for n, v in net._grad_sink.items()] + red._autograd)
+    out["after_zero_grad"] = red.flat.clone()
+    # 3. gradient accumulation over two micro-batches inside one step: the second backward must ADD
+    red.zero_grad()
+    h = x.shape[0] // 2
+    _sink_loss(net, x[:h]).backward()
+    _sink_loss(net, x[h:]).backward()
+    red.reduce()
+    out["accumulated"] = red.flat.clone()
+    # 4. a graph REPLAY writes the views without any Python running: after opt.zero_grad() reduce() alone re-binds them
+    opt.zero_grad()
+    for n, v in net._grad_sink.items():
+        v.fill_(float(rank + 1))
+    for _, v in red._autograd:
+        v.fill_(float(rank + 1))
+        net.project.t.grad = v
+    red.reduce()
+    assert all(net._grad_sink.params[n].grad.data_ptr() == v.data_ptr() for n, v in net._grad_sink.items())
+    out["replayed"] = red.flat.clone()
+    opt.step()  # every parameter has a gradient again
+    torch.save(out, os.path.join(out_dir, "sink%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sink_semantics(tmp_path):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(3)
+    net = _SinkNet()
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    x_all = torch.randn(8, 6)
+    mp.spawn(_sink_worker, args=(2, _free_port(), x_all, state, str(tmp_path)), nprocs=2, join=True)
+    o0, o1 = torch.load(tmp_path / "sink0.pt"), torch.load(tmp_path / "sink1.pt")
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+    single = FlatGradAllReducer(net, kernel_written=["fc.weight", "fc.bias"])
+    single.zero_grad()
+    _sink_loss(net, x_all).backward()
+    assert torch.allclose(o0["plain"], single.flat, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(o0["after_zero_grad"], single.flat, rtol=1e-5, atol=1e-7)
+    # two half-shard means summed = 2 x the shard mean
+    assert torch.allclose(o0["accumulated"], 2 * single.flat, rtol=1e-5, atol=1e-7)
+    assert torch.equal(o0["replayed"], torch.full_like(single.flat, 1.5))  # mean of rank + 1 over two ranks
+
+
+# The engine's own step loop (SamplerTrainStep: begin_step / zero_grad / loss composition / reduce) under two ranks, with the
+# CPU restatement of the module and an external task loss.
+def _engine_worker(rank, world, port, x_all, state, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer, shard_batch
+
+    torch.set_num_threads(1)
+    net = _engine_net(state)
+    red = FlatGradAllReducer(net)
+    x = shard_batch(x_all, rank, world)
+    step = SamplerTrainStep(net, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=lambda p: (p ** 2).mean(),
+                            reducer=red, use_graph=False, fused_loss=False)
+    assert not step.in_graph and not step.split
+    for _ in range(2):
+        loss = step(x)
+    torch.save((red.flat.clone(), loss.clone()), os.path.join(out_dir, "eng%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def _engine_net(state):
+    from oracle.cpu_reference_model import SampleNetCPU
+
+    class Net(SampleNetCPU):  # the attributes engine.SamplerTrainStep reads off a SampleNet
+        skip_projection, input_shape, output_shape = False, "bnc", "bnc"
+
+        def get_projection_loss(self):
+            return self.sigma()
+
+    net = Net(16, 32, 4)
+    net.load_state_dict(state)
+    net.eval()  # BatchNorm on running statistics: per-shard == whole-batch arithmetic
+    net.training = True  # ... but the engine's step is the training step
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.training = False
+    return net
+
+
+def test_two_rank_engine_step(tmp_path):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle.cpu_reference_model import SampleNetCPU
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    torch.manual_seed(1)
+    ref = SampleNetCPU(16, 32, 4)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    x_all = torch.rand(8, 128, 3) - 0.5
+    mp.spawn(_engine_worker, args=(2, _free_port(), x_all, state, str(tmp_path)), nprocs=2, join=True)
+    (f0, l0), (f1, l1) = torch.load(tmp_path / "eng0.pt"), torch.load(tmp_path / "eng1.pt")
+    assert torch.equal(f0, f1)
+    net = _engine_net(state)
+    red = FlatGradAllReducer(net)
+    step = SamplerTrainStep(net, x_all, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, task_loss=lambda p: (p ** 2).mean(),
+                            reducer=red, use_graph=False, fused_loss=False)
+    loss = step(x_all)
+    assert torch.allclose(f0, red.flat, rtol=1e-4, atol=1e-7)
+    assert abs(float(l0 + l1) / 2 - float(loss)) < 1e-5
