@@ -235,7 +235,7 @@ class SamplerTrainStep:
             self.x = self.ring[i]
             self.loss = self._step()
         if self.reducer is not None:
-            self.reducer.reduce(collective=not (self.in_graph and self._ring_graphs))
+            self.reducer.reduce(collective=not (self.in_graph and self._ring_graphs), replayed=bool(self._ring_graphs))
         return self.loss
 
     def check(self):
@@ -258,5 +258,5 @@ class SamplerTrainStep:
         else:
             self.loss = self._step()
         if self.reducer is not None:
-            self.reducer.reduce(collective=not (self.in_graph and self._ring_graphs))
+            self.reducer.reduce(collective=not (self.in_graph and self._ring_graphs), replayed=bool(self._ring_graphs))
         return self.loss

@@ -113,12 +113,15 @@ class FlatGradAllReducer:
             v.zero_()
         self.begin_step()
 
-    def _rebind(self):
-        """Gradients autograd accumulated into tensors of its own (after zero_grad(set_to_none=True)) move into the bucket."""
+    def _rebind(self, replayed=False):
+        """Gradients autograd accumulated into tensors of its own (after zero_grad(set_to_none=True)) move into the bucket.
+        replayed: a graph replay has just written EVERY view (also the autograd-accumulated ones: the capture recorded the
+        accumulation into the view) -- a dropped .grad is re-bound as it is instead of being taken for "no gradient"."""
         for p, view in self._autograd:
             g = p.grad
             if g is None:
-                view.zero_()
+                if not replayed:
+                    view.zero_()
             elif g.data_ptr() == view.data_ptr():
                 continue
             else:
@@ -158,10 +161,11 @@ class FlatGradAllReducer:
             return
         self.reduce_early_async()
 
-    def reduce(self, collective=True):
+    def reduce(self, collective=True, replayed=False):
         """Call after backward(): on return (stream-ordered) every .grad holds the cross-rank mean.
-        collective=False: only the .grad bookkeeping (the engine's captured step carries the collectives inside its graph)."""
-        self._rebind()
+        collective=False: only the .grad bookkeeping (the engine's captured step carries the collectives inside its graph);
+        replayed=True: the step was a graph replay (see _rebind)."""
+        self._rebind(replayed)
         if not collective or not self.collective:
             return
         # RCCL averages inside the collective (ReduceOp.AVG): no separate scaling kernel; gloo (CPU tests) sums, then scales

@@ -164,7 +164,7 @@ def test_fused_sampler_loss_equals_composition():
     la = SamplerTrainStep(net_a, x, alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, reducer=red_a, use_graph=False,
                           fused_head=False)(x)
     lb = SamplerTrainStep(net_b, x, alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, reducer=red_b, use_graph=False,
-                          task_loss=lambda p: p.mean())(x)
+                          task_loss=lambda p: p.mean(), fused_loss=False)(x)  # (the op-by-op general path)
     assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
     assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
 
