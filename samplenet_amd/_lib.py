@@ -11,7 +11,8 @@ import torch  # noqa: F401  -- first: its bundled HIP runtime (libamdhip64.so.7)
 # because the streams and device pointers handed to the library come from torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsamplenet_hip.so")
+# SAMPLENET_AMD_LIB: another build of the SAME library (same ABI; tools/build_variant.sh -- same-box A/B of a kernel change)
+LIB_PATH = os.environ.get("SAMPLENET_AMD_LIB") or os.path.join(_HERE, "lib", "libsamplenet_hip.so")
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

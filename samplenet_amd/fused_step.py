@@ -139,8 +139,7 @@ class SamplerStepFunction(torch.autograd.Function):
 def sampler_step(net, x_bnc, alpha, lmbda, weight, t_sink=None, defer_value=False, mean_proj=True):
     """-> (loss, simp (B,3,M), proj (B,M,3)) for a training-mode SampleNet with projection on a (B,N,3) batch.
     mean_proj=False: proj is differentiable and the loss carries no task term (see SamplerStepFunction)."""
-    sd = dict(net.named_parameters())
-    params = [sd[n] for n in pointnet.param_order(net)]
+    params = pointnet.param_list(net)
     proj = net.project
     return SamplerStepFunction.apply(net, x_bnc, proj._temperature, proj._group_size, proj._min_sigma_f, alpha, lmbda, weight,
                                      t_sink, defer_value, mean_proj, *params)
@@ -171,8 +170,7 @@ def sampler_step_direct(net, x_bnc, alpha, lmbda, weight, t_sink, grad_loss, aft
     sink = getattr(net, "_grad_sink", None)
     if sink is None or (net.project._temperature.requires_grad and t_sink is None):
         raise RuntimeError("sampler_step_direct needs a gradient sink for every parameter (FlatGradAllReducer)")
-    sd = dict(net.named_parameters())
-    params = [sd[n] for n in pointnet.param_order(net)]
+    params = pointnet.param_list(net)
     proj = net.project
     ctx = _DirectCtx()
     prev = getattr(net, "_after_fc_grads", None)

@@ -36,24 +36,46 @@ def _layers(net):
     """conv1..conv5 (each with its BatchNorm) and fc1..fcK of the sampler.  Hidden FC layers carry a BatchNorm in the
     registration / classification samplers (samplenet.py:52-59) and none in the reconstruction sampler (samplers.py:33-38);
     the last FC layer is always returned without one -- a BatchNorm behind it (classification/models/samplenet_model.py:
-    100-108) is applied by the caller on the head's output (pointnet_head)."""
+    100-108) is applied by the caller on the head's output (pointnet_head).
+    The records are kept on the module (this runs several times per step and nn.Module attribute lookups are slow) and
+    rebuilt when a layer's weight Parameter is no longer the one recorded (a layer was replaced)."""
+    d = net.__dict__
+    mods = d["_modules"]
+    cached = d.get("_sn_layer_records")
+    if cached is not None:
+        convs, fcs, _, _ = cached
+        if all(mods[L.name]._parameters["weight"] is L.W for L in convs) and all(mods[L.name]._parameters["weight"] is L.W for L in fcs):
+            return convs, fcs
     convs = [_Layer("conv%d" % i, getattr(net, "conv%d" % i), "bn%d" % i, getattr(net, "bn%d" % i)) for i in range(1, 6)]
     nfc = getattr(net, "num_fc_layers", 4)
     fcs = [_Layer("fc%d" % i, getattr(net, "fc%d" % i), "bn_fc%d" % i, getattr(net, "bn_fc%d" % i, None) if i < nfc else None)
            for i in range(1, nfc + 1)]
-    return convs, fcs
-
-
-def param_order(net):
-    """Names of the parameters the MLP node differentiates, in the order they are passed to / returned from it."""
-    convs, fcs = _layers(net)
     names = []
     for L in convs + fcs:
         names += [L.name + ".weight", L.name + ".bias"]
     for L in convs + fcs:
         if L.bn is not None:
             names += [L.bn_name + ".weight", L.bn_name + ".bias"]
-    return names
+    params = []
+    for L in convs + fcs:
+        params += [L.W, L.b]
+    for L in convs + fcs:
+        if L.bn is not None:
+            params += [L.bn.weight, L.bn.bias]
+    d["_sn_layer_records"] = (convs, fcs, tuple(names), tuple(params))
+    return convs, fcs
+
+
+def param_order(net):
+    """Names of the parameters the MLP node differentiates, in the order they are passed to / returned from it."""
+    _layers(net)
+    return net.__dict__["_sn_layer_records"][2]
+
+
+def param_list(net):
+    """The parameters param_order names, in that order."""
+    _layers(net)
+    return net.__dict__["_sn_layer_records"][3]
 
 
 _IDENT = {}
@@ -758,8 +780,7 @@ def pointnet_head(net, x_bnc):
     if x_bnc.dtype != torch.float32:
         raise TypeError("expected float32")
     x_bnc = x_bnc.contiguous()
-    sd = dict(net.named_parameters())
-    params = [sd[n] for n in param_order(net)]
+    params = param_list(net)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         y = PointNetMLPFunction.apply(net, x_bnc, net.training, *params)
     else:

@@ -1,14 +1,10 @@
-mkdir -p gpurun_out
-python -m pytest tests -m gpu -q --timeout 900 -s 2>&1 | grep -v "^\.*$" | tail -150 > gpurun_out/pytest_gpu.log
-grep -n "passed\|failed" gpurun_out/pytest_gpu.log | tail -3
-grep -n "^FAILED\|^ERROR" gpurun_out/pytest_gpu.log | head -20
-python -X faulthandler bench.py --steps 300 --warmup 30 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-echo "bench rc=$?"
-tail -25 gpurun_out/bench_default.err | cut -c1-400
-python - <<'PY'
-import json
-d = json.loads(open('gpurun_out/bench_default.json').read().strip().splitlines()[-1])
-print('headline', round(d['value']), round(d['ms_per_step'] * 1e3, 1), 'us', d['timed_steps'], d['timed_region_s'])
-for k in ('module_surface', 'config3_emd', 'config5_progressive', 'batch_sweep', 'roofline_longest', 'cpu_baseline'):
-    print(k, json.dumps(d.get(k))[:1500])
-PY
+for rep in 1 2; do
+for v in "" ps0; do
+  if [ -n "$v" ]; then export SAMPLENET_AMD_LIB=$PWD/tools/_dbg/libsamplenet_hip_$v.so; else unset SAMPLENET_AMD_LIB; fi
+  echo "== variant '${v:-packed}'"
+  timeout 200 python tools/pairscan_scaling.py 32 512 8192 2>&1 | grep "B="
+  timeout 200 python bench.py --steps 1500 --warmup 100 --no-probes 2>/dev/null | tail -1 | cut -c1-90
+done
+done
+unset SAMPLENET_AMD_LIB
+timeout 300 python -m pytest tests/test_gpu_geometry.py tests/test_gpu_headline.py tests/test_gpu_samplenet.py -q -m gpu -x 2>&1 | tail -3
