@@ -161,7 +161,8 @@ int sn_layer_backward_in3(int R, int Ci, int Co, const float *dy, const float *z
  * workgroups of a layer stay resident and exchange each layer's activations through xbuf with write-through stores and an
  * arrival counter instead of ending the kernel per layer.  Per layer l: W[l] (H, K), bias, BatchNorm parameters / running
  * statistics (training-mode update as sn_layer_forward_bn), outputs z[l] (R, H) pre-BN and coef[l] (4, H).  Bit-identical to
- * nl calls of sn_layer_forward_bn.  xbuf: 2 * 32 * H floats of scratch; sync: 16 unsigned, PERSISTENT and zero-initialised
+ * nl calls of sn_layer_forward_bn.  xbuf: 2 * 32 * H floats of scratch; sync: 16 WORDS of state spaced 128 bytes apart (16 x 32 unsigned = 2 KB; "sync[i]"
+ * below is the 32-bit word at byte offset 128 i: every counter on its own cache line), PERSISTENT and zero-initialised
  * once by the caller (epoch + monotonic arrival counters).  The workgroups of a launch must be RESIDENT TOGETHER (8 x ~137 KB
  * of LDS on otherwise free CUs).  A hand-off poll that gives up -- after sync[13] polls when that word is non-zero, else 2^22 --
  * sets sync[15] and the workgroup writes NaN instead of its outputs; afterwards the counters are out of step: the caller zeroes
@@ -195,7 +196,7 @@ int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc, const floa
  * weight-gradient operand (zprev with ReLU(BN) applied, or a raw input such as the pooled features).  Last stage also
  * returns gout (R, Ci) = the masked gradient and kout (3, Ci) = the dZ coefficients of the BatchNorm below (what
  * sn_conv_stack_backward takes as gsel / kcoef_top).  gy: (R, Co[0]).  Bit-identical to the sn_layer_backward chain.
- * xbuf: ns * 32 * 256 floats of scratch; sync: 16 unsigned of its OWN persistent zero-initialised state (launch epoch, one
+ * xbuf: ns * 32 * 256 floats of scratch; sync: 16 x 32 unsigned (same layout) of its OWN persistent zero-initialised state (launch epoch, one
  * monotonic arrival counter per stage, epoch-reader count; sync[13] / sync[15] and the NaN poisoning as sn_fc_chain_forward;
  * 16 workgroups must be resident together). */
 int sn_fc_chain_backward_supported(int R, int ns, const int *Co, const int *Ci);

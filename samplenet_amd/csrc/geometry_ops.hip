@@ -1352,8 +1352,8 @@ extern "C" int sn_step_tail_set_error_words(void *tail_blob, const void *fwd_syn
     SN_REQUIRE(tail_blob, "null blob");
     StepTail t;
     memcpy(&t, tail_blob, sizeof(t));
-    t.kf.chain_err[0] = fwd_sync ? (const unsigned *)fwd_sync + 15 : nullptr;
-    t.kf.chain_err[1] = bwd_sync ? (const unsigned *)bwd_sync + 15 : nullptr;
+    t.kf.chain_err[0] = fwd_sync ? (const unsigned *)fwd_sync + 15 * SN_FC_SYNC_STRIDE : nullptr;
+    t.kf.chain_err[1] = bwd_sync ? (const unsigned *)bwd_sync + 15 * SN_FC_SYNC_STRIDE : nullptr;
     memcpy(tail_blob, &t, sizeof(t));
     return 0;
 }

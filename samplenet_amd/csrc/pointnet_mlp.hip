@@ -370,10 +370,17 @@ __device__ __forceinline__ void sn_hw_record()
 #define SN_TL_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define SN_TL_ID(kind) sn_tl(7, ((unsigned long long)(kind) << 48) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) | \
                                     (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4))
+// the FC chain kernels: [kind 0 forward / 1 backward][workgroup 0..15][stamp 0..31], thread 0 of the workgroup
+__device__ unsigned long long sn_fc_tl_buf[2 * 16 * 32];
+#define FC_TL(kind, wg, k)                                                              \
+    do {                                                                                \
+        if (threadIdx.x == 0 && (wg) < 16 && (k) < 32) sn_fc_tl_buf[((kind)*16 + (wg)) * 32 + (k)] = wall_clock64(); \
+    } while (0)
 #else
 #define SN_TL(slot)
 #define SN_TL_DRAIN()
 #define SN_TL_ID(kind)
+#define FC_TL(kind, wg, k)
 #endif
 
 template <int BM_, int BN_, int WR_, int WC_>
@@ -2794,14 +2801,18 @@ __device__ __forceinline__ void store_sc1_b128(float *p, f32x4v v)
 // caller then poisons its outputs with NaN, and the error word stays set for the loss tail / the host (sn_fc_chain_error).
 // Poll bound: sync[13] when non-zero (tests), else 2^22 polls (seconds).
 constexpr int kFcChainPolls = 1 << 22;
+// the words of a chain launch's `sync` state sit 128 bytes apart (word i at sync[i * kFcSyncStride]): epoch, the per-seam
+// arrival counters, the poll bound and the error word each own a cache line -- 8..16 workgroups add to and poll different
+// counters at the same time, and on ONE line every poll queues behind the others' atomics
+constexpr int kFcSyncStride = SN_FC_SYNC_STRIDE;
 __device__ __forceinline__ bool fc_chain_seam(unsigned *sync, int ctr, unsigned epoch, int nwg, unsigned errcode, int limit)
 {
-    __hip_atomic_fetch_add(sync + ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(sync + ctr * kFcSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = (epoch + 1u) * (unsigned)nwg;
     int spins = 0;
-    while ((int)(__hip_atomic_load(sync + ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+    while ((int)(__hip_atomic_load(sync + ctr * kFcSyncStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         if (++spins > limit) {  // report instead of hanging the device
-            __hip_atomic_store(sync + 15, errcode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 15 * kFcSyncStride, errcode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -2827,8 +2838,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     float *Ts = red + 3 * 16 * 64;                                         // [32][36] pre-BN tile
     float *Ta = Ts + 32 * 36;                                              // [32][36] activated tile
     const int col0 = wg * 32, col = col0 + l31;
+    FC_TL(0, wg, 0);
     if (tid == 0) {
-        const unsigned lim = g.sync[13];  // (same line as the epoch: one round trip)
+        const unsigned lim = g.sync[13 * kFcSyncStride];
         s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_limit = lim ? lim : (unsigned)kFcChainPolls, s_bad = 0;
     }
@@ -2973,6 +2985,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     lds_barrier();
     const unsigned epoch = s_epoch;
+    FC_TL(0, wg, 1);
 
     for (int l = 0; l < nl; ++l) {
         const FcChainLayer &Lr = g.L[l];
@@ -2995,6 +3008,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
         wave_sum_to_wave0_lds(acc, red);
+        FC_TL(0, wg, 2 + 6 * l);
         if (wave == 0) {
             float s0 = 0.f;
 #pragma unroll
@@ -3037,6 +3051,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
         lds_barrier();
+        FC_TL(0, wg, 3 + 6 * l);
         // the 32 x 32 tiles leave as 16-byte stores: thread -> (row = tid / 8, 4 columns at (tid % 8) * 4)
         const int trow = tid >> 3, tc4 = (tid & 7) * 4;
         if (trow < R) {
@@ -3055,11 +3070,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
+        FC_TL(0, wg, 4 + 6 * l);
         if (tid == 0) {
             if (fc_chain_seam(g.sync, 1 + l, epoch, nwg, 1u + (unsigned)l, (int)s_limit)) s_bad = 1;
             if (l == 0 && wg == 0) __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lds_barrier();
+        FC_TL(0, wg, 5 + 6 * l);
         if (POOL && l == 0 && tid < 16) {  // every workgroup is past the pool stage: this one's 16 channels of the sums can go
             const int c = wg * 16 + tid;
 #pragma unroll
@@ -3076,6 +3093,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[i]) : "v"(p) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FC_TL(0, wg, 6 + 6 * l);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int idx = tid + 256 * i;
@@ -3084,7 +3102,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
         lds_barrier();
+        FC_TL(0, wg, 7 + 6 * l);
     }
+    SN_TL_DRAIN();
+    FC_TL(0, wg, 31);
 }
 
 template <int ZMODE, int PMODE, bool VEC>
@@ -3242,12 +3263,13 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
     const int R = g.R, ns = g.ns;
     const int col0 = wg * 32, col = col0 + l31;
     if (tid == 0) {
-        const unsigned lim = g.sync[13];  // poll bound override (tests), same line as the epoch
+        const unsigned lim = g.sync[13 * kFcSyncStride];  // poll bound override (tests)
         s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(g.sync + 14, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(g.sync + 14 * kFcSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_limit = lim ? lim : (unsigned)kFcChainPolls, s_bad = 0;
     }
     lds_barrier();
+    FC_TL(1, wgi, 0);
     const unsigned epoch = s_epoch;
     const unsigned target = (epoch + 1u) * (unsigned)NWG;
     const int limit = (int)s_limit;
@@ -3286,8 +3308,8 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 if (trow < R) v = *reinterpret_cast<const float4 *>(g.gy + (size_t)trow * Co + col0 + tc4);
                 *reinterpret_cast<float4 *>(Tz + trow * 36 + tc4) = v;
             } else {
-                if (tid == 0 && !fc_wait_arrivals(g.sync + s, target, limit)) {  // sync[1 + (s - 1)]
-                    __hip_atomic_store(g.sync + 15, 16u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0 && !fc_wait_arrivals(g.sync + s * kFcSyncStride, target, limit)) {  // sync[1 + (s - 1)]
+                    __hip_atomic_store(g.sync + 15 * kFcSyncStride, 16u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_bad = 1;
                 }
                 lds_barrier();
@@ -3333,7 +3355,10 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                     for (int e = 0; e < 16; ++e) S.db[col0 + frag_row(e, lane)] = acc[e];
             }
             lds_barrier();  // Tz is rewritten by the next stage
+            FC_TL(1, wgi, 2 + 6 * s);
         }
+        SN_TL_DRAIN();
+        FC_TL(1, wgi, 31);
         return;
     }
 
@@ -3379,6 +3404,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
             }
     }
     lds_barrier();
+    FC_TL(1, wgi, 1);
 
     for (int s = 0; s < ns; ++s) {
         const FcBwdStage &S = g.S[s];
@@ -3429,6 +3455,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 }
             }
             wave_sum_to_wave0_lds(acc, red);
+            FC_TL(1, wgi, 2 + 6 * s);
             // the next stage's weight slice goes into the other LDS buffer NOW: waves 1..3 have nothing else to do while wave 0
             // runs the epilogue (wave 0's quarter follows its epilogue) -- behind the arrival it sat on the chain's critical path
             if (wave != 0 && next_tile)
@@ -3476,6 +3503,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
             }
         }
         lds_barrier();
+        FC_TL(1, wgi, 3 + 6 * s);
         if (!more) break;
         // ---- hand the tile of dZ of the layer below over (write-through), drained, then arrive
         float *xb = g.xbuf + (size_t)s * 32 * 256;
@@ -3487,7 +3515,8 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-        if (tid == 0) __hip_atomic_fetch_add(g.sync + 1 + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FC_TL(1, wgi, 4 + 6 * s);
+        if (tid == 0) __hip_atomic_fetch_add(g.sync + (1 + s) * kFcSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- (a workgroup without a tile in this stage had no MFMA phase to stage the next slice under: do it here)
         if (next_tile && !has_tile && wave != 0)
 #pragma unroll
@@ -3499,11 +3528,12 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                     Wtn[(c4 + 2) * LD + co] = wn[i].z, Wtn[(c4 + 3) * LD + co] = wn[i].w;
                 }
             }
-        if (tid == 0 && !fc_wait_arrivals(g.sync + 1 + s, target, limit)) {
-            __hip_atomic_store(g.sync + 15, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !fc_wait_arrivals(g.sync + (1 + s) * kFcSyncStride, target, limit)) {
+            __hip_atomic_store(g.sync + 15 * kFcSyncStride, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_bad = 1;
         }
         lds_barrier();
+        FC_TL(1, wgi, 5 + 6 * s);
         {   // gather dZ of the layer below (32 x Ci; Ci = 256: 8 loads per thread, 128: 4)
             const int q4 = Ci / 4, nld = (32 * q4) / 256;
             f32x4v r[8];
@@ -3515,6 +3545,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[i]) : "v"(p) : "memory");
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FC_TL(1, wgi, 6 + 6 * s);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (i < nld) {
@@ -3523,11 +3554,14 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 }
         }
         lds_barrier();
+        FC_TL(1, wgi, 7 + 6 * s);
     }
+    SN_TL_DRAIN();
+    FC_TL(1, wgi, 31);
     // the next launch may only see the advanced epoch once all 16 workgroups of this one have read the current value
     if (wgi == 0 && tid == 0) {
-        if (!fc_wait_arrivals(g.sync + 14, (epoch + 1u) * 16u, limit))
-            __hip_atomic_store(g.sync + 15, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!fc_wait_arrivals(g.sync + 14 * kFcSyncStride, (epoch + 1u) * 16u, limit))
+            __hip_atomic_store(g.sync + 15 * kFcSyncStride, 64u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(g.sync, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -5419,6 +5453,11 @@ extern "C" int sn_pool_backward_bn(int B, int C, long long R, const float *g, co
 }
 
 #ifdef SN_TIMELINE
+extern "C" int sn_debug_fc_timeline(unsigned long long *host)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(sn::sn_fc_tl_buf), sizeof(unsigned long long) * 2 * 16 * 32) != hipSuccess;
+}
+
 extern "C" int sn_debug_timeline(unsigned long long *host, int nblocks, int clear)
 {
     if (clear == 2) return hipMemcpyFromSymbol(host, HIP_SYMBOL(sn::sn_hw_buf), sizeof(unsigned) * 8 * (size_t)nblocks) != hipSuccess;

@@ -209,7 +209,19 @@ class SamplerTrainStep:
             if buf.shape != bufs[0].shape or buf.device != bufs[0].device or not buf.is_contiguous():
                 raise ValueError("input_ring entries must be contiguous tensors of one shape on one device")
             self.x = buf
-            graphs, loss, outputs = self._capture_step(pool)
+            try:
+                graphs, loss, outputs = self._capture_step(pool)
+            except RuntimeError as e:
+                if not self.in_graph or self._ring_graphs:
+                    raise
+                # the collective could not be captured on this stack: one collective from Python behind every replay instead
+                import warnings
+
+                warnings.warn("SamplerTrainStep: capturing the gradient all-reduce inside the step graph failed (%s); falling "
+                              "back to allreduce='after'" % str(e).splitlines()[0])
+                torch.cuda.synchronize()
+                self.in_graph, self.allreduce = False, "after"
+                graphs, loss, outputs = self._capture_step(pool)
             self._ring_graphs.append(graphs)
             self._ring_loss.append(loss)
             self._ring_outputs.append(outputs)

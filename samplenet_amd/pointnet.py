@@ -11,6 +11,7 @@ import torch
 from ._lib import check, lib, ptr
 
 DZ_PLAIN, DZ_BN, DZ_POOL = 0, 1, 2
+SYNC_STRIDE = 32  # words between the words of a chain launch's sync state (sn_common.h: SN_FC_SYNC_STRIDE): [i, 0] is word i
 
 
 def _st(t):
@@ -244,7 +245,7 @@ def _fc_chain_fwd(net, hidden, pooled, B, saved):
     C0, H, n = shape
     sync = getattr(net, "_fc_sync", None)
     if sync is None or sync.device != pooled.device:
-        sync = torch.zeros(16, device=pooled.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
+        sync = torch.zeros(16, SYNC_STRIDE, device=pooled.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
         net._fc_sync = sync
     xbuf = _empty((2 * 32 * H,), pooled)
     zs = [_empty((B, H), pooled) for _ in hidden]
@@ -288,7 +289,7 @@ def chain_error_words(net):
     out = []
     for name in ("_fc_sync", "_fc_sync_b"):
         t = getattr(net, name, None)
-        out.append(int(t[15].item()) if t is not None else 0)
+        out.append(int(t[15, 0].item()) if t is not None else 0)
     return tuple(out)
 
 
@@ -308,9 +309,9 @@ def check_chain_errors(net, raise_error=True):
     for name in ("_fc_sync", "_fc_sync_b"):
         t = getattr(net, name, None)
         if t is not None:
-            limit = int(t[13].item())
+            limit = int(t[13, 0].item())
             t.zero_()  # epoch + monotonic arrival counters are out of step after a timeout: start over
-            t[13] = limit
+            t[13, 0] = limit
     if raise_error:
         what = ["%s chain: %s" % (d, _CHAIN_ERRORS.get(w, "hand-off %d" % w)) for d, w in zip(("forward", "backward"), words) if w]
         raise SampleNetHipError("FC chain launch timed out waiting for a co-resident workgroup (%s); its outputs were poisoned "
@@ -599,7 +600,7 @@ def _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed):
     like = grad_y
     sync = getattr(net, "_fc_sync_b", None)
     if sync is None or sync.device != like.device:
-        sync = torch.zeros(16, device=like.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
+        sync = torch.zeros(16, SYNC_STRIDE, device=like.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
         net._fc_sync_b = sync
     xbuf = _empty((nf * 32 * 256,), like)
     L5 = convs[-1]

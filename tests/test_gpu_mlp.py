@@ -631,7 +631,7 @@ def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
     finally:
         pointnet.FC_CHAIN = old
     torch.cuda.synchronize()
-    assert int(net_a._fc_sync[15]) == 0 and int(net_a._fc_sync[0]) == len(xs)
+    assert int(net_a._fc_sync[15, 0]) == 0 and int(net_a._fc_sync[0, 0]) == len(xs)
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-6), n
 
@@ -670,7 +670,7 @@ def test_pool_stage_of_the_fc_chain_equals_the_separate_launch(B, N):
             assert _acc_sums_zero(net_a._fx_acc) and _acc_sums_zero(net_b._fx_acc)
     finally:
         pointnet.POOL_IN_CHAIN = old
-    assert int(net_a._fc_sync[15]) == 0 and int(net_a._fc_sync[0]) == 3
+    assert int(net_a._fc_sync[15, 0]) == 0 and int(net_a._fc_sync[0, 0]) == 3
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         # (bn5's running statistics: same expression compiled into two kernels -- the momentum blend contracts into a
         #  different fma; one ulp)
@@ -717,14 +717,14 @@ def test_fc_chain_backward_equals_per_layer_launches(B, bneck, variant, training
     finally:
         pointnet.FC_CHAIN = old
     torch.cuda.synchronize()
-    assert int(net._fc_sync_b[15]) == 0 and int(net._fc_sync_b[0]) == 3
+    assert int(net._fc_sync_b[15, 0]) == 0 and int(net._fc_sync_b[0, 0]) == 3
 
 
 def _provoke(sync, counter):
     """A hand-off of the NEXT chain launch that can never complete: its arrival counter lags a thousand arrivals behind what
     the launch will wait for (the effect of a workgroup that is not resident), with a short poll bound instead of seconds."""
-    sync[13] = 3000
-    sync[counter] -= 1000
+    sync[13, 0] = 3000
+    sync[counter, 0] -= 1000
 
 
 @pytest.mark.parametrize("which", ["forward", "backward"])
@@ -764,7 +764,7 @@ def test_fc_chain_timeout_is_never_silent(which, use_graph):
         step.check()
     assert pointnet.chain_error_words(net) == (0, 0)         # re-armed by the check
     for t in (net._fc_sync, net._fc_sync_b):
-        t[13] = 0                                            # (default poll bound again)
+        t[13, 0] = 0                                         # (default poll bound again)
     again = step(x)
     torch.cuda.synchronize()
     step.check()
@@ -788,6 +788,6 @@ def test_fc_chain_timeout_in_the_module_surface():
     assert torch.isnan(simp).any() and torch.isnan(loss)
     with pytest.raises(SampleNetHipError):
         pointnet.check_chain_errors(net)
-    net._fc_sync[13] = 0
+    net._fc_sync[13, 0] = 0
     simp, _ = net(x)
     assert torch.isfinite(simp).all() and not pointnet.check_chain_errors(net)
