@@ -58,8 +58,12 @@ def test_eager_step_with_collectives(rccl):
     assert float(ra.flat.abs().sum()) > 0
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_captured_step_with_collectives(rccl, overlap):
+@pytest.mark.parametrize("mode", ["graph", "graph-fork", "after", "split"])
+def test_captured_step_with_collectives(rccl, mode):
+    """Where the gradient collective of a captured step runs: INSIDE the step's one graph at its end (engine default), inside
+    it with the FC-head segment forked to a side stream, from Python behind each replay, or between two graphs.  With one rank
+    AVG is the identity: every placement must leave exactly the gradients of the collective-free step, on every ring entry,
+    in any replay order."""
     from samplenet_amd.engine import SamplerTrainStep
     from samplenet_amd.parallel import FlatGradAllReducer
 
@@ -69,8 +73,11 @@ def test_captured_step_with_collectives(rccl, overlap):
     ra = FlatGradAllReducer(na)
     rb = FlatGradAllReducer(nb, force_collective=True)
     sa = SamplerTrainStep(na, ring_a[0], reducer=ra, input_ring=ring_a)
-    sb = SamplerTrainStep(nb, ring_b[0], reducer=rb, input_ring=ring_b, overlap_allreduce=overlap)
-    assert not sa.split and sb.split == overlap
+    overlap = mode == "split"
+    sb = SamplerTrainStep(nb, ring_b[0], reducer=rb, input_ring=ring_b, overlap_allreduce=overlap,
+                          allreduce="after" if overlap else mode)
+    assert not sa.split and not sa.in_graph and sb.split == overlap
+    assert sb.in_graph == (mode in ("graph", "graph-fork")) and sb.allreduce == ("after" if overlap else mode)
     assert all(len(g) == (2 if overlap else 1) for g in sb._ring_graphs)
     for i in (0, 1, 2, 1, 0, 0):
         la, lb = sa.replay(i), sb.replay(i)
@@ -79,3 +86,21 @@ def test_captured_step_with_collectives(rccl, overlap):
         assert torch.equal(ra.flat, rb.flat), i
     for (n, a), (_, b) in zip(na.named_buffers(), nb.named_buffers()):
         assert torch.equal(a, b), n  # BatchNorm running statistics moved identically
+
+
+def test_in_graph_collective_with_an_outside_task_loss(rccl):
+    """The captured fused step with a task loss outside the node (proj differentiable) and the all-reduce inside the graph."""
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    na, nb = _nets(2)
+    x = torch.rand(32, 1024, 3, device="cuda") - 0.5
+    w = torch.randn(32, 64, 3, device="cuda")
+    ra, rb = FlatGradAllReducer(na), FlatGradAllReducer(nb, force_collective=True)
+    sa = SamplerTrainStep(na, x, reducer=ra, task_loss=lambda p: (p * w).mean())
+    sb = SamplerTrainStep(nb, x, reducer=rb, task_loss=lambda p: (p * w).mean())
+    assert sa._fast_path() and sb._fast_path() and sb.in_graph and not sa.in_graph
+    for _ in range(3):
+        la, lb = sa(x), sb(x)
+    torch.cuda.synchronize()
+    assert float(la) == float(lb) and torch.equal(ra.flat, rb.flat) and float(ra.flat.abs().sum()) > 0
