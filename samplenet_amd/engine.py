@@ -228,6 +228,9 @@ class SamplerTrainStep:
         self.x = bufs[0]
         self.graph = self._ring_graphs[0][0]
         self.loss = self._ring_loss[0]
+        # the graphs hold raw pointers into the module's persistent forward buffers (pointnet._ForwardPlan): keep them alive
+        # for as long as the graphs, whatever happens to the module's own list
+        self._plan_refs = list(self.net.__dict__.get("_sn_plans", ()))
 
     def _replay_graphs(self, i):
         graphs = self._ring_graphs[i]

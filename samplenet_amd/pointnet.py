@@ -165,7 +165,7 @@ def _bn_coef(L, R, stats, nblk, training):
     return coef
 
 
-def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_pool=False):
+def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_pool=False, rec=None):
     """Training forward of the conv stack + max-pool as one call (sn_conv_stack_forward_bn: batch statistics as fixed-point
     sums, every layer finalises the BatchNorm of its input -- no reduction launch between layers).  Fills saved["zc"] /
     saved["cc"]; returns False when the shapes are not supported (the per-layer path runs instead).
@@ -203,17 +203,18 @@ def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_p
 
     eps = (ctypes.c_float * n)(*[float(L.bn.eps) for L in convs])
     mom = (ctypes.c_float * n)(*[float(L.bn.momentum) for L in convs])
+    args = [B, N, n, chans, ptr(x_bnc), arr([L.W for L in convs]), arr([L.b for L in convs]),
+            arr([L.bn.weight for L in convs]), arr([L.bn.bias for L in convs]),
+            arr([L.bn.running_mean for L in convs]), arr([L.bn.running_var for L in convs]),
+            arr([L.bn.num_batches_tracked for L in convs]), eps, mom, arr(zs), arr(cs), ptr(acc),
+            ptr(pool_val), ptr(pool_idx), *([None] * 3 if defer_pool else [ptr(pooled), ptr(argsel), ptr(zsel)]), _st(x_bnc)]
     try:
-        check(lib.sn_conv_stack_forward_bn(B, N, n, chans, ptr(x_bnc), arr([L.W for L in convs]), arr([L.b for L in convs]),
-                                           arr([L.bn.weight for L in convs]), arr([L.bn.bias for L in convs]),
-                                           arr([L.bn.running_mean for L in convs]), arr([L.bn.running_var for L in convs]),
-                                           arr([L.bn.num_batches_tracked for L in convs]), eps, mom, arr(zs), arr(cs), ptr(acc),
-                                           ptr(pool_val), ptr(pool_idx), *([None] * 3 if defer_pool else
-                                                                          [ptr(pooled), ptr(argsel), ptr(zsel)]), _st(x_bnc)),
-              "sn_conv_stack_forward_bn")
+        check(lib.sn_conv_stack_forward_bn(*args), "sn_conv_stack_forward_bn")
     except Exception:
         acc.zero_()  # a launch failed half way: do not leave partial sums behind
         raise
+    if rec is not None:  # (forward plan, see _ForwardPlan: argument 4 = the cloud, the last one = the stream)
+        rec.append((lib.sn_conv_stack_forward_bn, "sn_conv_stack_forward_bn", args, 4, acc, (pool_val, pool_idx)))
     saved["zc"], saved["cc"] = zs, cs
     if defer_pool:
         saved["pool_tail"] = (acc, pool_val, pool_idx, convs[-1], n, N, argsel, zsel)
@@ -233,7 +234,7 @@ def _fc_chain_shape(hidden, B):
     return C0, H, n
 
 
-def _fc_chain_fwd(net, hidden, pooled, B, saved):
+def _fc_chain_fwd(net, hidden, pooled, B, saved, rec=None):
     """The FC head's BatchNorm + ReLU layers as one launch (sn_fc_chain_forward; with saved["pool_tail"] from a deferred
     conv stack: sn_fc_chain_forward_pool, which also finishes the last conv BatchNorm and the max-pool).  Fills saved["zf"] /
     saved["cf"]; returns False when the shape is not supported (the per-layer launches run instead)."""
@@ -265,14 +266,17 @@ def _fc_chain_fwd(net, hidden, pooled, B, saved):
     if tail is not None:
         acc, pool_val, pool_idx, L5, nconv, N, argsel, zsel = tail
         bn5 = L5.bn
+        args = [B, N, nconv, ptr(acc), ptr(pool_val), ptr(pool_idx), ptr(bn5.weight), ptr(bn5.bias),
+                ptr(bn5.running_mean), ptr(bn5.running_var), ptr(bn5.num_batches_tracked),
+                float(bn5.eps), float(bn5.momentum), ptr(saved["cc"][-1]), ptr(pooled), ptr(argsel),
+                ptr(zsel), H, n, *layer_args]
         try:
-            check(lib.sn_fc_chain_forward_pool(B, N, nconv, ptr(acc), ptr(pool_val), ptr(pool_idx), ptr(bn5.weight), ptr(bn5.bias),
-                                               ptr(bn5.running_mean), ptr(bn5.running_var), ptr(bn5.num_batches_tracked),
-                                               float(bn5.eps), float(bn5.momentum), ptr(saved["cc"][-1]), ptr(pooled), ptr(argsel),
-                                               ptr(zsel), H, n, *layer_args), "sn_fc_chain_forward_pool")
+            check(lib.sn_fc_chain_forward_pool(*args), "sn_fc_chain_forward_pool")
         except Exception:
             acc.zero_()
             raise
+        if rec is not None:
+            rec.append((lib.sn_fc_chain_forward_pool, "sn_fc_chain_forward_pool", args, None, acc, ()))
     else:
         check(lib.sn_fc_chain_forward(B, C0, H, n, ptr(pooled), *layer_args), "sn_fc_chain_forward")
     saved["zf"], saved["cf"] = zs, cs
@@ -328,6 +332,13 @@ def forward_impl(net, x_bnc, training, skip_last=False):
     convs, fcs = _layers(net)
     B, N, _ = x_bnc.shape
     R = B * N
+    rec = None
+    if training and FORWARD_PLAN:
+        plan = _ForwardPlan.acquire(net, x_bnc, skip_last)
+        if plan is not None:
+            return plan.run(net, x_bnc)
+        if not torch.cuda.is_current_stream_capturing():  # (a plan's buffers must not come from a graph's private pool)
+            rec = []
     saved = {"x": x_bnc, "B": B, "N": N, "zc": [], "cc": [], "zf": [], "cf": [], "training": bool(training)}
     use_batch_stats = training
     a_in, coef_prev = x_bnc.view(R, 3), None
@@ -340,7 +351,7 @@ def forward_impl(net, x_bnc, training, skip_last=False):
     # ... and its BatchNorm finalisation + pool pick into the FC chain when that one runs (B <= 32, the 128 -> 256 x 3 head)
     shape = _fc_chain_shape(fcs[:-1], B) if training and FC_CHAIN and POOL_IN_CHAIN else None
     defer_pool = shape is not None and bool(lib.sn_fc_chain_forward_pool_supported(B, N, *shape))
-    if fuse_pool and FX_STATS and _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_pool):
+    if fuse_pool and FX_STATS and _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_pool, rec):
         convs = []  # the whole stack ran as one call (fixed-point statistics chain)
     for li, L in enumerate(convs):
         if training and fuse_pool and li == len(convs) - 1:
@@ -359,7 +370,7 @@ def forward_impl(net, x_bnc, training, skip_last=False):
     saved.update(pooled=pooled, argsel=argsel, zsel=zsel)
     a_in, coef_prev = pooled, None
     hidden = fcs[:-1]
-    if training and FC_CHAIN and _fc_chain_fwd(net, hidden, pooled, B, saved):
+    if training and FC_CHAIN and _fc_chain_fwd(net, hidden, pooled, B, saved, rec):
         a_in, coef_prev = saved["zf"][-1], saved["cf"][-1]
         hidden = []
     for L in hidden:
@@ -384,10 +395,111 @@ def forward_impl(net, x_bnc, training, skip_last=False):
         saved["zf"].append(z)
         saved["cf"].append(coef)
         a_in, coef_prev = z, coef
-    if skip_last:
-        return None, saved
-    y, _, _ = _linear_fwd(B, fcs[-1], a_in, coef_prev, False)
+    y = None
+    if not skip_last:
+        y, _, _ = _linear_fwd(B, fcs[-1], a_in, coef_prev, False)
+    if rec is not None and len(rec) == 2 and not convs and not hidden:
+        # the whole head ran as the two fused calls (+ the last layer): from now on steps of this shape replay them
+        _ForwardPlan.register(net, x_bnc, skip_last, rec, saved, fcs[-1])
     return y, saved
+
+
+class _Lease:
+    """Held by the `saved` record of a step that runs on a plan's buffers: the plan is free again when the record dies (the
+    autograd node that owns it was released, or a no-grad caller dropped it)."""
+
+    __slots__ = ("plan",)
+
+    def __init__(self, plan):
+        self.plan = plan
+        plan.busy = True
+
+    def __del__(self):
+        self.plan.busy = False
+
+
+class _ForwardPlan:
+    """The training forward of the head at one shape as a REPLAY: the C calls of the fused route (conv stack as one call, FC
+    chain with the pool stage, last layer) were recorded once together with the tensors they write; later steps of the same
+    shape re-issue them with the same argument arrays on the same buffers -- no per-step allocations, no rebuilding of ~25
+    pointer arrays (the eager module surface is host-bound: DESIGN.md 6).  Only the cloud pointer, the head's output (a fresh
+    tensor: the caller owns it) and the stream change per step.  A plan serves one step at a time: while a step's `saved`
+    record is alive (its backward has not run / its graph has not been released) the next forward of that shape records a
+    plan of its own (two sampler passes under one loss, main.py:516-524); at most kMaxPlans are kept per module.
+    Validity: the parameter / buffer tensors named by the recorded pointer arrays must still be the module's (identity and
+    data pointer are checked per step; SampleNet._apply drops the plans when the module is moved or cast)."""
+
+    kMaxPlans = 4
+    __slots__ = ("key", "busy", "calls", "saved", "sig", "last")
+
+    @staticmethod
+    def _signature(net):
+        convs, fcs = _layers(net)
+        sig = []
+        for L in convs + fcs:
+            sig += [L.W.data_ptr(), L.b.data_ptr()]
+            if L.bn is not None:
+                bn = L.bn
+                sig += [bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                        bn.num_batches_tracked.data_ptr(), bn.eps, bn.momentum]
+        return tuple(sig)
+
+    @staticmethod
+    def acquire(net, x, skip_last):
+        plans = net.__dict__.get("_sn_plans")
+        if not plans:
+            return None
+        key = (x.shape[0], x.shape[1], x.device, bool(skip_last))
+        sig = None
+        for plan in plans:
+            if plan.key == key and not plan.busy:
+                if sig is None:
+                    sig = _ForwardPlan._signature(net)
+                if plan.sig == sig:
+                    return plan
+        if sig is not None:  # stale plans of this shape (parameters were replaced): drop them
+            net.__dict__["_sn_plans"] = [q for q in plans if q.sig == sig or q.key != key]
+        return None
+
+    @staticmethod
+    def register(net, x, skip_last, rec, saved, last_layer):
+        plans = net.__dict__.setdefault("_sn_plans", [])
+        if len(plans) >= _ForwardPlan.kMaxPlans:
+            free = [q for q in plans if not q.busy]
+            if not free:
+                return
+            plans.remove(free[0])
+        plan = _ForwardPlan()
+        plan.key = (x.shape[0], x.shape[1], x.device, bool(skip_last))
+        plan.sig = _ForwardPlan._signature(net)
+        plan.calls = rec
+        plan.saved = dict(saved)
+        plan.saved.pop("_lease", None)
+        plan.saved["_bwd_cache"] = saved["_bwd_cache"] = {}  # static pieces of the backward's argument lists (_conv_stack_bwd_fx)
+        plan.last = None if skip_last else last_layer
+        plan.busy = False
+        saved["_lease"] = _Lease(plan)  # the recording step itself runs on these buffers
+        plans.append(plan)
+
+    def run(self, net, x):
+        st = _st(x)
+        saved = dict(self.saved)
+        saved["x"] = x
+        saved["zc"], saved["cc"] = list(saved["zc"]), list(saved["cc"])
+        saved["_lease"] = _Lease(self)
+        xp = x.data_ptr()
+        for fn, name, args, xpos, acc, _keep in self.calls:
+            if xpos is not None:
+                args[xpos] = xp
+            args[-1] = st
+            rc = fn(*args)
+            if rc != 0:
+                acc.zero_()
+                check(rc, name)
+        y = None
+        if self.last is not None:
+            y, _, _ = _linear_fwd(saved["B"], self.last, saved["zf"][-1], saved["cf"][-1], False)
+        return y, saved
 
 
 class GradSink(dict):
@@ -458,6 +570,7 @@ FUSE_POOL = True
 Z1_FREE = True  # one-call conv stack: the xyz layer's activation tensor is not materialised (rebuilt from the cloud where needed)
 FC_CHAIN = True  # the FC head's hidden layers as one launch with in-kernel hand-offs (sn_fc_chain_forward)
 POOL_IN_CHAIN = True  # ... with the last conv BatchNorm + max-pool pick as its first stage (sn_fc_chain_forward_pool)
+FORWARD_PLAN = True  # steps of a shape seen before replay the recorded C calls on recycled buffers (_ForwardPlan)
 
 
 def _wgrad(R, L, mode, dy, z, kcoef, gsel, argsel, npts, aprev, coef_prev, with_bias, sink=None, name=""):
@@ -549,29 +662,38 @@ def _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef_top, sink, grads, names_c,
 
     n = len(convs)
     B, N = saved["B"], saved["N"]
-    chans = (ctypes.c_int * (n + 1))(convs[0].Ci, *[L.Co for L in convs])
-    nscr = lib.sn_conv_stack_backward_scratch_floats(B, N, n, chans)
-    if nscr <= 0:
-        return False
     x = saved["x"]
-    acc = getattr(net, "_fx_acc_b", None)
-    nacc = lib.sn_conv_stack_acc_elems(n)
-    if acc is None or acc.device != x.device or acc.numel() != nacc:
-        acc = torch.zeros(nacc, device=x.device, dtype=torch.int64)  # persistent: every call leaves it zero
-        net._fx_acc_b = acc
-    scratch = _empty((nscr,), x)
     VP = ctypes.c_void_p * n
 
     def arr(ts):
         return VP(*[ptr(t) for t in ts])
 
+    # what does not change from step to step when the forward ran on a plan's buffers (saved["_bwd_cache"], shared by the
+    # steps of that plan): shape arrays, scratch, the pointer arrays of the weights and of the saved activations
+    cache = saved.get("_bwd_cache")
+    st = cache.get("conv") if cache is not None else None
+    if st is None:
+        chans = (ctypes.c_int * (n + 1))(convs[0].Ci, *[L.Co for L in convs])
+        nscr = lib.sn_conv_stack_backward_scratch_floats(B, N, n, chans)
+        if nscr <= 0:
+            return False
+        acc = getattr(net, "_fx_acc_b", None)
+        nacc = lib.sn_conv_stack_acc_elems(n)
+        if acc is None or acc.device != x.device or acc.numel() != nacc:
+            acc = torch.zeros(nacc, device=x.device, dtype=torch.int64)  # persistent: every call leaves it zero
+            net._fx_acc_b = acc
+        scratch = _empty((nscr,), x)
+        st = (chans, acc, scratch, arr([L.W for L in convs]), arr(saved["zc"]), arr(saved["cc"]))
+        if cache is not None:
+            cache["conv"] = st
+    chans, acc, scratch, W_arr, zc_arr, cc_arr = st
     dW = [_out(sink, names_c[i] + ".weight", convs[i].W) for i in range(n)]
     dg = [_out(sink, bn_c[i] + ".weight", convs[i].bn.weight) for i in range(n - 1)]
     dbt = [_out(sink, bn_c[i] + ".bias", convs[i].bn.bias) for i in range(n - 1)]
     dbs = [_out(sink, names_c[i] + ".bias", convs[i].b) for i in range(n - 1)]
     try:
-        check(lib.sn_conv_stack_backward(B, N, n, chans, ptr(x), arr([L.W for L in convs]), ptr(convs[0].b), arr(saved["zc"]),
-                                         arr(saved["cc"]), ptr(gsel), ptr(saved["argsel"]), ptr(kcoef_top), ptr(acc), ptr(scratch),
+        check(lib.sn_conv_stack_backward(B, N, n, chans, ptr(x), W_arr, ptr(convs[0].b), zc_arr, cc_arr, ptr(gsel),
+                                         ptr(saved["argsel"]), ptr(kcoef_top), ptr(acc), ptr(scratch),
                                          arr(dW), arr(dg + [None]), arr(dbt + [None]), arr(dbs + [None]), step_tail, _st(x)),
               "sn_conv_stack_backward")
     except Exception:
@@ -592,20 +714,31 @@ def _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed):
 
     nf = len(fcs)
     B, R = saved["B"], saved["B"] * saved["N"]
-    Co = (ctypes.c_int * nf)(*[fcs[j].Co for j in range(nf - 1, -1, -1)])
-    Ci = (ctypes.c_int * nf)(*[fcs[j].Ci for j in range(nf - 1, -1, -1)])
-    if nf > 5 or not lib.sn_fc_chain_backward_supported(B, nf, Co, Ci):
-        return False
     zf, cf, cc = saved["zf"], saved["cf"], saved["cc"]
     like = grad_y
-    sync = getattr(net, "_fc_sync_b", None)
-    if sync is None or sync.device != like.device:
-        sync = torch.zeros(16, SYNC_STRIDE, device=like.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
-        net._fc_sync_b = sync
-    xbuf = _empty((nf * 32 * 256,), like)
     L5 = convs[-1]
     C5 = L5.Co
-    gsel, kcoef = _empty((B, C5), like), _empty((3, C5), like)
+    VP = ctypes.c_void_p * nf
+
+    def arr(ts):
+        return VP(*[ptr(t) for t in ts])
+
+    cache = saved.get("_bwd_cache")
+    st = cache.get(("fc", fixed)) if cache is not None else None
+    if st is None:
+        Co = (ctypes.c_int * nf)(*[fcs[j].Co for j in range(nf - 1, -1, -1)])
+        Ci = (ctypes.c_int * nf)(*[fcs[j].Ci for j in range(nf - 1, -1, -1)])
+        if nf > 5 or not lib.sn_fc_chain_backward_supported(B, nf, Co, Ci):
+            return False
+        sync = getattr(net, "_fc_sync_b", None)
+        if sync is None or sync.device != like.device:
+            sync = torch.zeros(16, SYNC_STRIDE, device=like.device, dtype=torch.int32)  # persistent: epoch + monotonic arrival counters
+            net._fc_sync_b = sync
+        st = {"Co": Co, "Ci": Ci, "sync": sync, "xbuf": _empty((nf * 32 * 256,), like), "gsel": _empty((B, C5), like),
+              "kcoef": _empty((3, C5), like)}
+        if cache is not None:
+            cache[("fc", fixed)] = st
+    Co, Ci, sync, xbuf, gsel, kcoef = st["Co"], st["Ci"], st["sync"], st["xbuf"], st["gsel"], st["kcoef"]
     W, zprev, coefprev, rows, dg, dbt, dbs, dW, aprev, araw = [], [], [], [], [], [], [], [], [], []
     keep = []
     for j in range(nf - 1, -1, -1):
@@ -633,13 +766,12 @@ def _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed):
             grads[L5.bn_name + ".weight"], grads[L5.bn_name + ".bias"], grads[L5.name + ".bias"] = dg[-1], dbt[-1], dbs[-1]
     db_top = _out(sink, fcs[-1].name + ".bias", fcs[-1].b)
     grads[fcs[-1].name + ".bias"] = db_top
-    VP = ctypes.c_void_p * nf
-
-    def arr(ts):
-        return VP(*[ptr(t) for t in ts])
-
-    check(lib.sn_fc_chain_backward(B, nf, Co, Ci, ptr(grad_y), arr(W), arr(zprev), arr(coefprev), (ctypes.c_longlong * nf)(*rows),
-                                   arr(dg), arr(dbt), arr(dbs), arr(dW), ptr(db_top), arr(aprev), (ctypes.c_int * nf)(*araw),
+    ins = st.get("ins")
+    if ins is None:  # (pointer arrays of the operands: static with the plan's buffers)
+        ins = (arr(W), arr(zprev), arr(coefprev), (ctypes.c_longlong * nf)(*rows), arr(aprev), (ctypes.c_int * nf)(*araw))
+        st["ins"] = ins
+    check(lib.sn_fc_chain_backward(B, nf, Co, Ci, ptr(grad_y), ins[0], ins[1], ins[2], ins[3],
+                                   arr(dg), arr(dbt), arr(dbs), arr(dW), ptr(db_top), ins[4], ins[5],
                                    ptr(gsel), ptr(kcoef), ptr(xbuf), ptr(sync), _st(like)), "sn_fc_chain_backward")
     saved["fc_chain_b"] = (xbuf, keep)  # (scratch of the asynchronous launch)
     return gsel, kcoef

@@ -791,3 +791,56 @@ def test_fc_chain_timeout_in_the_module_surface():
     net._fc_sync[13, 0] = 0
     simp, _ = net(x)
     assert torch.isfinite(simp).all() and not pointnet.check_chain_errors(net)
+
+
+def test_forward_plan_replays_are_identical_and_isolated():
+    """pointnet._ForwardPlan: once a shape has been seen, the head's training forward re-issues the recorded C calls on
+    recycled buffers.  Same bits as the allocate-per-step route; a second forward before the first one's backward runs on
+    buffers of its own (two sampler passes under one loss, main.py:516-524); moving the module drops the plans."""
+    from samplenet_amd import SampleNet, pointnet
+
+    torch.manual_seed(31)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    xs = [(torch.rand(32, 1024, 3, device="cuda") - 0.5) for _ in range(4)]
+    gys = [torch.randn(32, 192, device="cuda") for _ in range(4)]
+    old = pointnet.FORWARD_PLAN
+    try:
+        for i, (x, gy) in enumerate(zip(xs, gys)):
+            pointnet.FORWARD_PLAN = True
+            ya, sa = pointnet.forward_impl(net_a, x, True)
+            ga = pointnet.backward_impl(net_a, sa, gy)
+            assert ("_lease" in sa) and len(net_a._sn_plans) == 1
+            pointnet.FORWARD_PLAN = False
+            yb, sb = pointnet.forward_impl(net_b, x, True)
+            gb = pointnet.backward_impl(net_b, sb, gy)
+            assert "_lease" not in sb
+            assert torch.equal(ya, yb), i
+            for n in ga:
+                assert torch.equal(ga[n], gb[n]), (i, n)
+            del sa, sb
+        for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+            assert torch.equal(ba, bb), n
+        # two forwards alive at once: the second must not run on the first one's buffers
+        pointnet.FORWARD_PLAN = True
+        y1, s1 = pointnet.forward_impl(net_a, xs[0], True)
+        z1 = [t.clone() for t in s1["zf"]]
+        y2, s2 = pointnet.forward_impl(net_a, xs[1], True)
+        assert len(net_a._sn_plans) == 2 and s1["zf"][0].data_ptr() != s2["zf"][0].data_ptr()
+        assert all(torch.equal(a, b) for a, b in zip(z1, s1["zf"]))
+        g1 = pointnet.backward_impl(net_a, s1, gys[0])
+        pointnet.FORWARD_PLAN = False
+        yr, sr = pointnet.forward_impl(net_b, xs[0], True)
+        pointnet.forward_impl(net_b, xs[1], True)  # (running statistics in step)
+        assert torch.equal(y1, yr)
+        del s1, s2, sr
+        pointnet.FORWARD_PLAN = True
+        assert not any(q.busy for q in net_a._sn_plans)
+        # skip_last (the fused step's form) has plans of its own; a moved / cast module starts over
+        _, s3 = pointnet.forward_impl(net_a, xs[2], True, skip_last=True)
+        assert len(net_a._sn_plans) == 3
+        del s3
+        net_a.float()
+        assert "_sn_plans" not in net_a.__dict__
+    finally:
+        pointnet.FORWARD_PLAN = old

@@ -77,17 +77,19 @@ def step():
     return loss
 
 
-for _ in range(10):
-    step()
-torch.cuda.synchronize()
-acc.clear()
-t0 = time.perf_counter()
-for _ in range(200):
-    step()
-torch.cuda.synchronize()
-print("eager %s: %.3f ms/step" % ("with PCRNet task" if with_task else "mean(proj)", (time.perf_counter() - t0) / 200 * 1e3))
-for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
-    print("   %-40s %.1f us/step" % (k, v / 200 * 1e6))
+for plan in (True, False, True, False):
+    pointnet.FORWARD_PLAN = plan
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    acc.clear()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        step()
+    torch.cuda.synchronize()
+    print("eager %s, forward plan %s: %.3f ms/step" % ("with PCRNet task" if with_task else "mean(proj)", plan, (time.perf_counter() - t0) / 300 * 1e3))
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:7]:
+        print("   %-40s %.1f us/step" % (k, v / 300 * 1e6))
 if len(sys.argv) > 2:
     pr = cProfile.Profile()
     pr.enable()
