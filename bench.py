@@ -279,8 +279,10 @@ def _wall_ms(run, steps):
 def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
     """Secondary legs: what a user of the drop-in module surface gets with a REAL task loss (registration/main.py:507-531 +
     557-577: frozen PCRNet + Chamfer on the projected points), driver-timed:
-      eager  -- plain  simp, proj = net(x); alpha*get_simplification_loss + lmbda*get_projection_loss + task; backward()
-                launched op by op from Python (host-bound);
+      eager_mean_proj -- the headline's own step (task term mean(proj)) through the plain module surface: simp, proj = net(x);
+                alpha*get_simplification_loss + lmbda*get_projection_loss + proj.mean(); backward() -- op by op from Python
+                (host-bound: what an unmodified train script gets without the engine);
+      eager  -- the same with the PCRNet task loss;
       graph  -- engine.SamplerTrainStep(task_loss=...) captured once and replayed: the fused single-node step with the task
                 loss OUTSIDE the node -- proj is a differentiable output, the task gradient re-enters the loss backward as an
                 explicit tensor (same scan, fc4 inside the scan, deferred tail as the headline);
@@ -321,7 +323,18 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
         gnet.load_state_dict(net.state_dict())
         return gnet
 
+    def eager_mean_proj_step():  # the headline's unit of work through the plain module surface
+        for p in net.parameters():
+            p.grad = None
+        simp, proj = net(x)
+        loss = 0.01 * net.get_simplification_loss(x, simp, M, 1, 0) + 0.01 * net.get_projection_loss() + proj.mean()
+        loss.backward()
+        return loss
+
     out = {}
+    ms, loss = _wall_ms(eager_mean_proj_step, max(steps, 200))
+    assert torch.isfinite(loss).item()
+    out["eager_mean_proj"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
     ms, loss = _wall_ms(eager_step, steps)
     assert torch.isfinite(loss).item()
     out["eager"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}

@@ -140,3 +140,18 @@ def test_bench_self_launches_its_ranks(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 2 and "exposes 0 GPU" in r.stderr and "Traceback" not in r.stderr
+
+
+def test_fp32_mfma_twin_of_the_conv_gemms_still_compiles(tmp_path):
+    """pointnet_mlp.hip carries a second implementation of the conv-stack GEMMs and of the fused conv backward on the fp32 MFMA
+    (-DSN_BF16X3=0: exact fp32 products instead of six bf16 products of three-way split operands) -- the arithmetic reference
+    of the split kernels (tests/test_gpu_mlp.py::test_fp32_mfma_twin_agrees_with_the_split_bf16_build runs it on the GPU).
+    It is not a product build, so nothing else would notice if it stopped compiling."""
+    import subprocess
+
+    src = os.path.join(ROOT, "samplenet_amd", "csrc", "pointnet_mlp.hip")
+    cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "-c", src, "-o", str(tmp_path / "pm0.o"), "-O3", "-std=c++17", "-fPIC",
+           "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "samplenet_amd", "csrc"),
+           "-Wall", "-Wno-unused-function", "-Werror", "-DSN_BF16X3=0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]

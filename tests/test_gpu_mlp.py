@@ -844,3 +844,57 @@ def test_forward_plan_replays_are_identical_and_isolated():
         assert "_sn_plans" not in net_a.__dict__
     finally:
         pointnet.FORWARD_PLAN = old
+
+
+def test_fp32_mfma_twin_agrees_with_the_split_bf16_build(tmp_path):
+    """The -DSN_BF16X3=0 build of pointnet_mlp.hip (conv GEMMs and fused conv backward on the exact fp32 MFMA) against the
+    product build (fp32 products as six bf16 products of split operands) through the same C entry points: one 64 -> 128 layer
+    forward and its fused backward at R = 4096 -- outputs within 1e-6 of the largest value, i.e. the split products are
+    fp32-accurate against the hardware's own fp32 matrix path."""
+    import ctypes
+    import subprocess
+
+    from samplenet_amd._lib import LIB_PATH, PROTOTYPES
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objs = [os.path.join(root, "samplenet_amd", "lib", n + ".o") for n in ("capi_common", "pairscan", "geometry_ops", "emd")]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("object files of the product build are not in the tree")
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(root, "include"),
+             "-I" + os.path.join(root, "samplenet_amd", "csrc"), "-Wno-unused-function"]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-c", os.path.join(root, "samplenet_amd", "csrc", "pointnet_mlp.hip"),
+                           "-o", str(tmp_path / "pm0.o"), "-DSN_BF16X3=0"] + flags, timeout=900)
+    so = str(tmp_path / "libsamplenet_hip_fp32.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, str(tmp_path / "pm0.o")] + objs, timeout=600)
+    libs = []
+    for path in (LIB_PATH, so):
+        L = ctypes.CDLL(path)
+        for name in ("sn_linear_forward", "sn_conv_backward_partials", "sn_linear_wgrad_splits", "sn_linear_stats_blocks"):
+            getattr(L, name).argtypes = PROTOTYPES[name]
+            getattr(L, name).restype = ctypes.c_int
+        libs.append(L)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    R, Ci, Co = 4096, 64, 128
+    a = torch.randn(R, Ci, device="cuda", generator=g)
+    coefp = torch.stack([torch.rand(Ci, device="cuda", generator=g) + 0.5, torch.randn(Ci, device="cuda", generator=g) * 0.1,
+                         torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda")]).contiguous()
+    W = torch.randn(Co, Ci, device="cuda", generator=g) * 0.1
+    b = torch.randn(Co, device="cuda", generator=g)
+    dy = torch.randn(R, Co, device="cuda", generator=g)
+    kc = torch.stack([torch.rand(Co, device="cuda", generator=g) + 0.5, torch.randn(Co, device="cuda", generator=g) * 0.01,
+                      torch.randn(Co, device="cuda", generator=g) * 0.01]).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for L in libs:
+        z = torch.empty(R, Co, device="cuda")
+        assert L.sn_linear_forward(R, Ci, Co, a.data_ptr(), coefp.data_ptr(), W.data_ptr(), b.data_ptr(), z.data_ptr(), None, st) == 0
+        G = L.sn_linear_wgrad_splits(R, Ci, Co, 0)
+        dyprev = torch.empty(R, Ci, device="cuda")
+        stats = torch.empty(L.sn_linear_stats_blocks(R), 2, Ci, device="cuda")
+        part = torch.zeros(G, Co, Ci, device="cuda")
+        assert L.sn_conv_backward_partials(R, Ci, Co, 1, dy.data_ptr(), z.data_ptr(), kc.data_ptr(), None, None, 1, W.data_ptr(),
+                                           a.data_ptr(), coefp.data_ptr(), dyprev.data_ptr(), stats.data_ptr(), part.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        outs.append((z, dyprev, part.sum(0)))
+    for (x, y, name) in zip(outs[0], outs[1], ("z", "dYprev", "dW")):
+        assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()) * (8 if name == "dW" else 1), name
