@@ -2,6 +2,7 @@
 PyTorch fp32 modules of the same network (the reference's own op chain, samplenet.py:90-104) on the same
 weights and inputs: outputs, BatchNorm running statistics, and the gradient of every parameter."""
 import copy
+import os
 
 import numpy as np
 import pytest
