@@ -142,6 +142,14 @@ int sn_knn(int b, int n, int m, int k, const float *xyz1, int layout1, const flo
 int sn_nn_matching(int B, int N, int k, const float *xyz, int layout, const int *idx, int complete_fps, float *out,
                    sn_stream_t stream);
 
+/* Rotation of every cloud by its own quaternion: out[b][n] = qrot(quat[b], v[b][n]) with quat (B,4) in
+ * (w, x, y, z) order, v / out (B,N,3) -- registration/src/quaternion.py:35-53 (qrot) as registration/main.py:569-571 uses it
+ * through QuaternionTransform.rotate (qdataset.py:106-109: the quaternion expanded over the points).  backward: grad_v (B,N,3)
+ * and grad_quat (B,4) (either may be NULL); deterministic (fixed-order per-cloud sums).  One launch each instead of ~8 / ~16. */
+int sn_qrot_forward(int B, int N, const float *quat, const float *v, float *out, sn_stream_t stream);
+int sn_qrot_backward(int B, int N, const float *quat, const float *v, const float *grad_out, float *grad_quat, float *grad_v,
+                     sn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * group_point gather / scatter-add.
  * (a) TF layout: points (b,n,c), idx (b,m,nsample) -> out (b,m,nsample,c).

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "sn_prefix_point_minima": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],
+    "sn_qrot_forward": [_i, _i, _vp, _vp, _vp, _vp],
+    "sn_qrot_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_group_point": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_group_point_grad": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_grouping_operation": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -1359,6 +1359,99 @@ extern "C" int sn_step_tail_set_error_words(void *tail_blob, const void *fwd_syn
 }
 
 // ------------------------------------------------------------------------------------------------
+// Rotation of a cloud by one quaternion per cloud (the registration task loss rotates the template by the
+// estimated pose -- registration/main.py:569-571 est_transform.rotate(p0) = src/quaternion.py:35-53 qrot with the quaternion
+// expanded over the points).  The reference composes it from two cross products, a scale and two adds per point on
+// materialised (B,N,4) / (B,N,3) tensors: ~8 launches forward, ~16 backward.  Here: one launch each way.
+//   out = v + 2 (w (u x v) + u x (u x v)),   q = (w, u)
+//   backward:  dv = g - 2 w (u x g) + 2 u x (u x g)                                   (rotation by the conjugate)
+//              dw = sum_n 2 (u x v_n) . g_n
+//              du = sum_n 2 w (v_n x g_n) + 2 (u . g_n) v_n + 2 (u . v_n) g_n - 4 (v_n . g_n) u
+// one workgroup per cloud; the per-cloud sums in a fixed order (strided per-thread partials, xor tree, waves in order).
+// ------------------------------------------------------------------------------------------------
+struct sn_v3 {
+    float x, y, z;
+};
+__device__ __forceinline__ sn_v3 cross3(sn_v3 a, sn_v3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float dot3(sn_v3 a, sn_v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+
+__global__ void __launch_bounds__(256) qrot_fwd_kernel(int N, const float *__restrict__ q, const float *__restrict__ v,
+                                                       float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const float w = q[b * 4];
+    const sn_v3 u{q[b * 4 + 1], q[b * 4 + 2], q[b * 4 + 3]};
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const sn_xyz3 p = *reinterpret_cast<const sn_xyz3 *>(v + ((size_t)b * N + n) * 3);
+        const sn_v3 x{p.x, p.y, p.z};
+        const sn_v3 uv = cross3(u, x), uuv = cross3(u, uv);
+        sn_xyz3 o;
+        o.x = x.x + 2.0f * (w * uv.x + uuv.x), o.y = x.y + 2.0f * (w * uv.y + uuv.y), o.z = x.z + 2.0f * (w * uv.z + uuv.z);
+        *reinterpret_cast<sn_xyz3 *>(out + ((size_t)b * N + n) * 3) = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) qrot_bwd_kernel(int N, const float *__restrict__ q, const float *__restrict__ v,
+                                                       const float *__restrict__ g, float *__restrict__ gq,
+                                                       float *__restrict__ gv)
+{
+    __shared__ float red[4][4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float w = q[b * 4];
+    const sn_v3 u{q[b * 4 + 1], q[b * 4 + 2], q[b * 4 + 3]};
+    float aw = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const sn_xyz3 gp = *reinterpret_cast<const sn_xyz3 *>(g + ((size_t)b * N + n) * 3);
+        const sn_v3 gg{gp.x, gp.y, gp.z};
+        if (gv) {
+            const sn_v3 ug = cross3(u, gg), uug = cross3(u, ug);
+            sn_xyz3 o;
+            o.x = gg.x + 2.0f * (uug.x - w * ug.x), o.y = gg.y + 2.0f * (uug.y - w * ug.y), o.z = gg.z + 2.0f * (uug.z - w * ug.z);
+            *reinterpret_cast<sn_xyz3 *>(gv + ((size_t)b * N + n) * 3) = o;
+        }
+        if (gq) {
+            const sn_xyz3 p = *reinterpret_cast<const sn_xyz3 *>(v + ((size_t)b * N + n) * 3);
+            const sn_v3 x{p.x, p.y, p.z};
+            const sn_v3 uv = cross3(u, x), vg = cross3(x, gg);
+            const float ug = dot3(u, gg), ux = dot3(u, x), xg = dot3(x, gg);
+            aw += 2.0f * dot3(uv, gg);
+            ax += 2.0f * (w * vg.x + ug * x.x + ux * gg.x) - 4.0f * xg * u.x;
+            ay += 2.0f * (w * vg.y + ug * x.y + ux * gg.y) - 4.0f * xg * u.y;
+            az += 2.0f * (w * vg.z + ug * x.z + ux * gg.z) - 4.0f * xg * u.z;
+        }
+    }
+    if (!gq) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        aw += __shfl_xor(aw, o), ax += __shfl_xor(ax, o), ay += __shfl_xor(ay, o), az += __shfl_xor(az, o);
+    }
+    if (lane == 0) red[wave][0] = aw, red[wave][1] = ax, red[wave][2] = ay, red[wave][3] = az;
+    __syncthreads();
+    if (threadIdx.x < 4) gq[b * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+extern "C" int sn_qrot_forward(int B, int N, const float *quat, const float *v, float *out, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 0 && N >= 0, "negative size");
+    if (B == 0 || N == 0) return 0;
+    SN_REQUIRE(quat && v && out, "null pointer");
+    hipLaunchKernelGGL(qrot_fwd_kernel, dim3(std::min((N + 255) / 256, 64), B), dim3(256), 0, (hipStream_t)stream, N, quat, v, out);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_qrot_backward(int B, int N, const float *quat, const float *v, const float *grad_out, float *grad_quat,
+                                float *grad_v, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 0 && N >= 0, "negative size");
+    if (B == 0) return 0;
+    SN_REQUIRE(quat && v && grad_out && (grad_quat || grad_v), "null pointer");
+    hipLaunchKernelGGL(qrot_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, quat, v, grad_out, grad_quat, grad_v);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Inference matching on the device: sputils.nn_matching (registration/src/sputils.py:7-41).
 //   idx (B,k): nearest input point of every generated point.  complete_fps: keep the first occurrences in order
 //   (np.unique(return_index) + sort), then farthest-point-complete to k points of the SAME cloud -- numpy computes the

@@ -899,3 +899,29 @@ def test_fp32_mfma_twin_agrees_with_the_split_bf16_build(tmp_path):
         outs.append((z, dyprev, part.sum(0)))
     for (x, y, name) in zip(outs[0], outs[1], ("z", "dYprev", "dW")):
         assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()) * (8 if name == "dW" else 1), name
+
+
+@pytest.mark.parametrize("B,N", [(32, 1024), (3, 160), (1, 1), (5, 777)])
+def test_qrot_cloud_equals_the_reference_composition(B, N):
+    """sn_qrot_forward / sn_qrot_backward (one launch each) against the reference's composition (src/quaternion.py:35-53: two
+    cross products, scale, adds -- task_features.qrot, the form the PCRNet golden pins) with the quaternion expanded over the
+    points: values, gradient to the points, gradient to the quaternion (a sum over the cloud), in fp32 against the same
+    composition in fp64; quaternions NOT normalised (the formula is used as it stands)."""
+    from samplenet_amd.task_features import qrot, qrot_cloud
+
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + N)
+    q = torch.randn(B, 4, device="cuda", generator=g).requires_grad_(True)
+    v = (torch.rand(B, N, 3, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    go = torch.randn(B, N, 3, device="cuda", generator=g)
+    out = qrot_cloud(q, v)
+    gq, gv = torch.autograd.grad(out, [q, v], go)
+    q64, v64 = q.detach().double().requires_grad_(True), v.detach().double().requires_grad_(True)
+    ref = qrot(q64.unsqueeze(1).expand(-1, N, -1), v64)
+    rq, rv = torch.autograd.grad(ref, [q64, v64], go.double())
+    assert float((out.double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert float((gv.double() - rv).abs().max()) <= 2e-6 * max(1.0, float(rv.abs().max()))
+    assert float((gq.double() - rq).abs().max()) <= 2e-6 * max(1.0, float(rq.abs().max())) * max(1, N) ** 0.5
+    # data-only cloud (the registration loop: the template is data): no gradient tensor for it
+    out2 = qrot_cloud(q, v.detach())
+    (gq2,) = torch.autograd.grad(out2, [q], go)
+    assert torch.equal(gq2, gq)
