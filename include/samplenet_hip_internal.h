@@ -226,6 +226,18 @@ int sn_conv_backward_partials(int R, int Ci, int Co, int dz_mode, const float *d
                               const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                               const float *coef_prev, float *dyprev, float *stats, float *part, sn_stream_t stream);
 
+/* Task network (registration/models/pcrnet.py:23-41 PointNetFeatures: 1x1 convolutions + ReLU without BatchNorm, max over the
+ * points) -- fused form of sn_linear_forward + sn_pool_forward:
+ *   sn_linear_forward_maxpool   last layer + max over the npts points of every cloud in one GEMM launch (+ a 2 KB-per-cloud key
+ *                               clear and a decode launch): pooled (B,Co) = relu(max_n Z), argsel / zsel (optional) as
+ *                               sn_pool_forward; z (R,Co) optional -- NULL: the activations are never written (a branch
+ *                               that needs no gradient).  coef_prev: the previous layer's (scale, shift) = (1, 0) table.
+ *                               keys: B * 2 * Co 64-bit words of scratch.  Query _supported (64-aligned shapes). */
+int sn_linear_forward_maxpool_supported(int R, int Ci, int Co, int npts);
+int sn_linear_forward_maxpool(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
+                              const float *bias, float *z, unsigned long long *keys, float *pooled, int *argsel, float *zsel,
+                              sn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

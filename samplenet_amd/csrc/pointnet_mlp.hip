@@ -963,6 +963,7 @@ struct FwdArgs {
     // publishes, per cloud and channel, the maximum and the minimum of Z with its first row as 64-bit keys combined by atomicMax
     // (order-independent; pool_keys [B][2][Co], zero before the launch): the consumer picks by the sign of the BatchNorm scale.
     unsigned long long *pool_keys;
+    int pool_max_only;  // the consumer's scale is known to be >= 0 (plain ReLU): the minima are not published
 };
 // (value, row) -> key: larger value first, then the LOWER row; value order via the usual sign flip of the float bits
 __device__ __forceinline__ unsigned long long pool_key(float v, int row)
@@ -1146,6 +1147,7 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
     float pmax[T::TN], pmin[T::TN];
     int imax[T::TN], imin[T::TN];
     const bool pool = FULL && (g.pool_val != nullptr || g.pool_keys != nullptr);
+    const bool store_z = g.z != nullptr;  // (sn_linear_forward_maxpool: only the per-cloud maxima leave the kernel)
     // FULL tiles leave as 16-byte stores: each 32 x 32 fragment is transposed through a per-wave LDS scratch (a dword
     // store per fragment element costs ~58 issue cycles per wave-instruction: 16 of them per fragment were issue-bound)
     float *Ts = lds + 2 * T::WR * T::BN + wave * (32 * 36);  // behind column_reduce2's area; staging buffers are dead
@@ -1163,9 +1165,9 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
                 const int row = row0 + (wr * T::TM + i) * 32 + frag_row(e, lane);
                 const float v = acc[i][j][e] + bias;
                 if (FULL || (row < R && col < Co)) {
-                    if (FULL)
-                        Ts[frag_row(e, lane) * 36 + (lane & 31)] = v;
-                    else
+                    if (FULL) {
+                        if (store_z) Ts[frag_row(e, lane) * 36 + (lane & 31)] = v;
+                    } else
                         g.z[(size_t)row * Co + col] = v;
                     s0[j] += v;
                     s1[j] += v * v;
@@ -1175,7 +1177,7 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
                     }
                 }
             }
-            if (FULL) {
+            if (FULL && store_z) {
                 float *zt = g.z + (size_t)(row0 + (wr * T::TM + i) * 32) * Co + col0 + (wc * T::TN + j) * 32 + (lane & 7) * 4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1209,7 +1211,7 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
                 const int c = col0 + (wc * T::TN + j) * 32 + lane;
                 unsigned long long *kk = g.pool_keys + ((size_t)cloud * 2) * Co + c;
                 atomicMax(kk, pool_key(pmax[j], imax[j] - cloud0));
-                atomicMax(kk + Co, pool_key(-pmin[j], imin[j] - cloud0));
+                if (!g.pool_max_only) atomicMax(kk + Co, pool_key(-pmin[j], imin[j] - cloud0));
             }
         }
     } else if (FULL && pool) {
@@ -4442,6 +4444,53 @@ extern "C" int sn_linear_forward(int R, int Ci, int Co, const float *ain, const 
         launch_fwd<ACT_BN_RELU>(g, st);
     else
         launch_fwd<ACT_NONE>(g, st);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- last layer of a BatchNorm-free ReLU stack + max over the points, WITHOUT its activation tensor (PCRNet's PointNetFeatures,
+// registration/models/pcrnet.py:23-41: the 128 -> 1024 layer on 32 x 1024 points is 134 MB that the reference writes, reads back
+// for the max and -- for the frozen template branch -- never needs again).  The GEMM's epilogue combines, per cloud and channel,
+// (max Z, first row) as 64-bit keys by atomicMax (order-independent); a small kernel decodes pooled = relu(max), the row and
+// the pre-activation value (what the pooling backward needs).  keys: B * 2 * Co u64 of scratch (cleared here).
+__global__ void __launch_bounds__(256) maxpool_keys_decode_kernel(int n, int Co, const unsigned long long *__restrict__ keys,
+                                                                  float *__restrict__ pooled, int *__restrict__ argsel,
+                                                                  float *__restrict__ zsel)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v;
+    int row;
+    pool_key_decode(keys[(size_t)(i / Co) * 2 * Co + i % Co], v, row);  // keys [B][2][Co]: the maxima are plane 0 (FwdArgs::pool_keys)
+    pooled[i] = relu_np(v);
+    if (argsel) argsel[i] = row;
+    if (zsel) zsel[i] = v;
+}
+
+extern "C" int sn_linear_forward_maxpool_supported(int R, int Ci, int Co, int npts)
+{
+    return R > 64 && npts >= 64 && npts % 64 == 0 && R % npts == 0 && R % TileBig::BM == 0 && Co % TileBig::BN == 0 && Ci % BK == 0;
+}
+
+extern "C" int sn_linear_forward_maxpool(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
+                                         const float *bias, float *z, unsigned long long *keys, float *pooled, int *argsel,
+                                         float *zsel, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1 && npts >= 1, "bad size");
+    SN_REQUIRE(ain && W && keys && pooled && coef_prev, "null pointer");
+    if (!sn_linear_forward_maxpool_supported(R, Ci, Co, npts))
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_linear_forward_maxpool: needs 64-aligned rows per cloud / channels");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = R / npts;
+    const hipError_t e = hipMemsetAsync(keys, 0, (size_t)B * 2 * Co * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return sn_set_error((int)e, "%s: %s", __func__, hipGetErrorString(e));
+    FwdArgs g{};
+    g.a = make_act(ain, coef_prev, R, Ci);
+    g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+    g.bias = bias, g.z = z, g.stats = nullptr;  // z == NULL: the activations are not written at all
+    g.pool_keys = keys, g.pool_npts = npts, g.pool_max_only = 1;
+    launch_fwd<ACT_BN_RELU>(g, st);
+    hipLaunchKernelGGL(maxpool_keys_decode_kernel, dim3((B * Co + 255) / 256), dim3(256), 0, st, B * Co, Co, keys, pooled, argsel, zsel);
     SN_LAUNCH_CHECK();
     return 0;
 }

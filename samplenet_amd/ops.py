@@ -39,8 +39,21 @@ def chamfer_forward_impl(xyz1, xyz2):
     idx1 = torch.empty(b, n, device=xyz1.device, dtype=torch.int32)
     idx2 = torch.empty(b, m, device=xyz1.device, dtype=torch.int32)
     with torch.cuda.device(xyz1.device):
-        check(lib.sn_chamfer_forward(b, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2),
-                                     _stream(xyz1)), "sn_chamfer_forward")
+        # sn_chamfer_forward's own role choice (lanes own the larger set), through the workspace form of the scan: with
+        # scratch for partial per-point minima the queries of a cloud spread over several workgroups -- at small batches the
+        # plain launcher signature (no scratch argument, as the reference's) leaves one workgroup per cloud: 32 of 256 CUs
+        if m >= n:
+            N, M, P, Q, dq, iq, dp, ip = m, n, xyz2, xyz1, dist1, idx1, dist2, idx2
+        else:
+            N, M, P, Q, dq, iq, dp, ip = n, m, xyz1, xyz2, dist2, idx2, dist1, idx1
+        wsb = lib.sn_pairscan_workspace_bytes(b, N, M) if (b > 0 and N > 0 and M > 0) else 0
+        if wsb > 0:
+            ws = torch.empty(wsb // 8, device=xyz1.device, dtype=torch.int64)
+            check(lib.sn_pairscan_forward_ws(b, N, M, 0, ptr(P), BNC, ptr(Q), BNC, None, None, ptr(dq), ptr(iq), ptr(dp), ptr(ip),
+                                             None, 0, None, None, 0.0, ptr(ws), wsb, _stream(xyz1)), "sn_pairscan_forward_ws")
+        else:
+            check(lib.sn_chamfer_forward(b, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2),
+                                         _stream(xyz1)), "sn_chamfer_forward")
     return xyz1, xyz2, dist1, idx1, dist2, idx2
 
 

@@ -22,6 +22,9 @@ def _st(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+# Test hooks (the defaults are the product path; False = the route other shapes take anyway)
+FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch (sn_linear_forward_maxpool)
+
 _CONST = {}  # (rows, channels, device) -> constant coefficient table, built once (never written afterwards)
 
 
@@ -52,23 +55,41 @@ class _FeaturesFunction(torch.autograd.Function):
         Ws, bs = wb[0::2], wb[1::2]
         zs, a_in, coef_prev = [], x_bnc.reshape(R, 3), None
         idents = []
+        need_grad = any(ctx.needs_input_grad)
         with torch.cuda.device(x_bnc.device):
             st = _st(x_bnc)
-            for W, b in zip(Ws, bs):
+            dev = x_bnc.device
+            C = Ws[-1].shape[0]
+            pooled = torch.empty(B, C, device=dev, dtype=torch.float32)
+            argsel = torch.empty(B, C, device=dev, dtype=torch.int32)
+            zsel = torch.empty(B, C, device=dev, dtype=torch.float32)
+            nl = len(Ws)
+            for li, (W, b) in enumerate(zip(Ws, bs)):
                 Co, Ci = W.shape[0], W.shape[1]
-                z = torch.empty(R, Co, device=x_bnc.device, dtype=torch.float32)
+                if li == nl - 1 and li > 0 and FUSE_MAXPOOL and lib.sn_linear_forward_maxpool_supported(R, Ci, Co, N):
+                    # last layer + max over the points in one GEMM: its activations are written only when a backward will
+                    # read them; the frozen / no-gradient branch (the registration loop's template cloud) never materialises them
+                    keep_z = need_grad  # (the dense backward of this layer reads them)
+                    z = torch.empty(R, Co, device=dev, dtype=torch.float32) if keep_z else None
+                    keys = torch.empty(B * 2 * Co, device=dev, dtype=torch.int64)
+                    check(lib.sn_linear_forward_maxpool(R, Ci, Co, N, ptr(a_in), ptr(coef_prev), ptr(W), ptr(b), ptr(z), ptr(keys),
+                                                        ptr(pooled), ptr(argsel), ptr(zsel), st), "sn_linear_forward_maxpool")
+                    zs.append(z)
+                    idents.append(_ident(Co, pooled))
+                    break
+                z = torch.empty(R, Co, device=dev, dtype=torch.float32)
                 check(lib.sn_linear_forward(R, Ci, Co, ptr(a_in), ptr(coef_prev), ptr(W), ptr(b), ptr(z), None, st),
                       "sn_linear_forward")
                 zs.append(z)
                 coef_prev = _ident(Co, z)
                 idents.append(coef_prev)
                 a_in = z
-            C = Ws[-1].shape[0]
-            pooled = torch.empty(B, C, device=x_bnc.device, dtype=torch.float32)
-            argsel = torch.empty(B, C, device=x_bnc.device, dtype=torch.int32)
-            zsel = torch.empty(B, C, device=x_bnc.device, dtype=torch.float32)
-            check(lib.sn_pool_forward(B, N, C, ptr(zs[-1]), ptr(idents[-1]), ptr(pooled), ptr(argsel), ptr(zsel), st),
-                  "sn_pool_forward")
+            else:
+                check(lib.sn_pool_forward(B, N, C, ptr(zs[-1]), ptr(idents[-1]), ptr(pooled), ptr(argsel), ptr(zsel), st),
+                      "sn_pool_forward")
+        ctx.zlast_missing = zs[-1] is None
+        if zs[-1] is None:
+            zs[-1] = pooled  # (placeholder in the saved list: never read -- no backward follows a no-gradient forward)
         ctx.save_for_backward(x_bnc, pooled, argsel, zsel, *zs, *idents, *Ws)
         ctx.nl = len(Ws)
         return pooled

@@ -925,3 +925,49 @@ def test_qrot_cloud_equals_the_reference_composition(B, N):
     out2 = qrot_cloud(q, v.detach())
     (gq2,) = torch.autograd.grad(out2, [q], go)
     assert torch.equal(gq2, gq)
+
+
+@pytest.mark.parametrize("B,N,bneck,grad_x", [(32, 64, 1024, True), (32, 1024, 1024, False), (3, 64, 256, True), (2, 128, 128, True),
+                                              (4, 40, 64, True)])
+def test_task_features_fused_maxpool_equals_the_layer_by_layer_route(B, N, bneck, grad_x):
+    """PointNetFeatures (the registration task network's extractor): last layer + max over the points as one GEMM launch
+    (sn_linear_forward_maxpool: per-cloud (max, first row) keys combined by atomicMax in the epilogue; without a gradient the
+    (B N, bottleneck) activations are never written) against sn_linear_forward + sn_pool_forward: pooled features bit-identical
+    (same GEMM, same maxima), gradients to the cloud and to the weights equal (the backward is the same kernels on the same
+    selected rows; a channel that is negative everywhere may name another row, its gradient is masked either way)."""
+    from samplenet_amd import task_features as TF
+
+    torch.manual_seed(B * 31 + N)
+    feat = TF.PointNetFeatures(bottleneck_size=bneck, input_shape="bnc").cuda()
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5).requires_grad_(grad_x)
+    go = torch.randn(B, bneck, device="cuda")
+    res = {}
+    old = TF.FUSE_MAXPOOL
+    try:
+        for tag, flag in (("fused", True), ("plain", False)):
+            TF.FUSE_MAXPOOL = flag
+            for trainable in (False, True):
+                for p in feat.parameters():
+                    p.requires_grad_(trainable)
+                    p.grad = None
+                if x.grad is not None:
+                    x.grad = None
+                if not trainable and not grad_x:
+                    with torch.no_grad():
+                        res[(tag, trainable)] = (feat(x), None, None)
+                    continue
+                y = feat(x)
+                y.backward(go)
+                res[(tag, trainable)] = (y.detach(), x.grad.clone() if grad_x else None,
+                                         [p.grad.clone() for p in feat.parameters()] if trainable else None)
+    finally:
+        TF.FUSE_MAXPOOL = old
+    for trainable in (False, True):
+        yf, gxf, gpf = res[("fused", trainable)]
+        yp, gxp, gpp = res[("plain", trainable)]
+        assert torch.equal(yf, yp), trainable
+        if gxf is not None:
+            assert float((gxf - gxp).norm()) <= 1e-6 * float(gxp.norm()) + 1e-9, trainable
+        if gpf is not None:
+            for a, b in zip(gpf, gpp):
+                assert float((a - b).norm()) <= 1e-6 * float(b.norm()) + 1e-9
