@@ -155,3 +155,24 @@ def test_fp32_mfma_twin_of_the_conv_gemms_still_compiles(tmp_path):
            "-Wall", "-Wno-unused-function", "-Werror", "-DSN_BF16X3=0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_bench_profile_provenance_helpers():
+    """bench.py's provenance fields: the kernel-source hash changes with the sources, the committed profile directory is found,
+    its longest kernel is parsed out of the rocprofv3 summary, and a hash mismatch is flagged as stale."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sha = bench.csrc_sha16()
+    assert re.fullmatch(r"[0-9a-f]{16}", sha)
+    rnd, d = bench.profile_dir()
+    assert rnd in ("r03", "r02", "r01") and os.path.isdir(d)
+    name, avg_us, calls = bench.longest_kernel_of_profile()
+    assert name and avg_us > 1.0 and calls >= 1
+    prov = bench.profile_provenance()
+    assert prov["dir"] == "profiles/" + rnd and prov["current_src_sha16"] == sha
+    if prov["src_sha16"] is not None:
+        assert prov["stale"] == (prov["src_sha16"] != sha)
+    assert bench.geometry_bytes_fwd(1024, 64, 8) == 24576  # SURVEY 8d's figure
