@@ -2785,6 +2785,58 @@ __device__ __forceinline__ void wave_sum_to_wave0_lds(f32x16 &acc, float *lds)
             for (int e = 0; e < 16; ++e) acc[e] += lds[(w * 16 + e) * 64 + lane];
 }
 
+// Cross-wave sum of the four K partials of a 32 x 32 tile with the RESULT SPREAD OVER THE FOUR WAVES (a reduce-scatter): every
+// wave publishes its 16 accumulator values per lane (4 x 16-byte LDS stores), then wave w sums the partials of columns
+// 8 w .. 8 w + 7 -- lane -> (column 8 w + (lane >> 3), rows 4 (lane & 7) .. + 3: four consecutive rows are four consecutive
+// accumulator registers of one source lane, i.e. one 16-byte read per partial) -- in wave order ((p0 + p1) + p2) + p3, the order
+// in which wave 0 used to add them alone.  The epilogue behind it (bias, BatchNorm statistics over the column's 32 rows = the 8
+// lanes of a column: three DPP steps, coefficients, activation) then runs on all four waves instead of one.
+constexpr int kRsPitch = 20;  // floats per lane in the exchange (16 + pad: 80-byte stride)
+constexpr int kRsFloats = 4 * 64 * kRsPitch;
+__device__ __forceinline__ float4 wave_reduce_scatter4(const f32x16 &acc, float *lds)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *mine = lds + ((size_t)wave * 64 + lane) * kRsPitch;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(mine + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    lds_barrier();
+    const int rg = lane & 7, src = (wave * 8 + (lane >> 3)) + 32 * (rg & 1);  // source lane: column + 32 * (row half)
+    const float *p = lds + (size_t)src * kRsPitch + 4 * (rg >> 1);
+    float4 v = *reinterpret_cast<const float4 *>(p);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float4 o = *reinterpret_cast<const float4 *>(p + (size_t)w * 64 * kRsPitch);
+        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+    }
+    return v;
+}
+// sum over the 8 lanes of a column group (lanes 8 c .. 8 c + 7), every lane receives the total: xor 1, xor 2 inside the quad,
+// then the mirrored lane of the other quad (which holds that quad's total)
+__device__ __forceinline__ float sum8_dpp(float x)
+{
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    return x;
+}
+
+// Sum of a column's 32 rows in the ORDER of the one-wave epilogue this replaces (small_fwd_lds_kernel, bit for bit): there a
+// lane held the 16 rows of its half (rows 8 g + 4 h + 0..3, g = 0..3) and added them in register order, then the two halves
+// were added.  Here the rows 4 rg .. 4 rg + 3 of lane rg belong to half h = rg & 1, group g = rg >> 1: the running sum of a half
+// walks over its four lanes (rg = h, h + 2, h + 4, h + 6) by DPP row_shr:2, each adding its four rows in order; the two ends
+// (rg = 6, 7) are added and handed to all 8 lanes.  v[i] must already be 0 for rows that do not exist.
+__device__ __forceinline__ float col_sum_seq(const float (&v)[4], int rg)
+{
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float in = g == 0 ? 0.f : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x112, 0xf, 0xf, true));  // row_shr:2
+        if ((rg >> 1) == g) a = (((in + v[0]) + v[1]) + v[2]) + v[3];
+    }
+    return sum8_dpp(rg >= 6 ? a : 0.f);  // = end(h = 0) + end(h = 1); the other lanes contribute exact zeros
+}
+
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_sc1_b128(float *p, f32x4v v)
 {
@@ -2836,10 +2888,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     float *As = sm;                 // [32][LDA]
     float *W0s = As + 32 * LDA;     // [32][C0 + 4]            weight slice of layer 0
     float *Whs = W0s + 32 * (C0 + 4);  // [nl - 1][32][H + 4]  weight slices of layers 1 ..
-    float *red = Whs + (size_t)(nl - 1) * 32 * (H + 4);  // [3][16][64]
-    float *Ts = red + 3 * 16 * 64;                                         // [32][36] pre-BN tile
+    float *red = Whs + (size_t)(nl - 1) * 32 * (H + 4);  // [4][64][kRsPitch]: the waves' K partials (wave_reduce_scatter4)
+    float *Ts = red + kRsFloats;                                           // [32][36] pre-BN tile
     float *Ta = Ts + 32 * 36;                                              // [32][36] activated tile
-    const int col0 = wg * 32, col = col0 + l31;
+    const int col0 = wg * 32;
     FC_TL(0, wg, 0);
     if (tid == 0) {
         const unsigned lim = g.sync[13 * kFcSyncStride];
@@ -2992,10 +3044,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     for (int l = 0; l < nl; ++l) {
         const FcChainLayer &Lr = g.L[l];
         const int K = l == 0 ? C0 : H, LDW = K + 4;
-        // epilogue inputs first (their latency hides under the MFMAs)
-        const float bias = Lr.bias[col], bn_g = Lr.gamma[col], bn_b = Lr.beta[col];
+        // epilogue inputs first (their latency hides under the MFMAs): this lane's epilogue column, see wave_reduce_scatter4
+        const int er0 = 4 * (lane & 7), ecl = wave * 8 + (lane >> 3), ecol = col0 + ecl;
+        const float ebias = Lr.bias[ecol], eg = Lr.gamma[ecol], eb = Lr.beta[ecol];
         float bn_rm = 0.f, bn_rv = 0.f;
-        if (Lr.running_mean) bn_rm = Lr.running_mean[col], bn_rv = Lr.running_var[col];
+        if (Lr.running_mean) bn_rm = Lr.running_mean[ecol], bn_rv = Lr.running_var[ecol];
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -3009,24 +3062,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
-        wave_sum_to_wave0_lds(acc, red);
+        const float4 zs4 = wave_reduce_scatter4(acc, red);
         FC_TL(0, wg, 2 + 6 * l);
-        if (wave == 0) {
-            float s0 = 0.f;
+        {
+            // this lane: column ecol, rows er0 .. er0 + 3
+            const float zv[4] = {zs4.x + ebias, zs4.y + ebias, zs4.z + ebias, zs4.w + ebias};
+            float t[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float v = acc[e] + bias;
-                if (frag_row(e, lane) < R) s0 += v;
-            }
-            s0 += __shfl_xor(s0, 32);
+            for (int i = 0; i < 4; ++i) t[i] = er0 + i < R ? zv[i] : 0.f;
+            const float s0 = col_sum_seq(t, lane & 7);
             const float meanf = s0 / (float)R;
-            float s2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float d = (acc[e] + bias) - meanf;
-                if (frag_row(e, lane) < R) s2 += d * d;
+            for (int i = 0; i < 4; ++i) {
+                const float d = zv[i] - meanf;
+                t[i] = er0 + i < R ? d * d : 0.f;
             }
-            s2 += __shfl_xor(s2, 32);
+            const float s2 = col_sum_seq(t, lane & 7);
             // (reciprocals from the host, Newton-refined reciprocal square root: three double divisions and a double square root
             //  per layer cost ~0.7 us of the chain's critical path)
             const double mean = (double)s0 * g.rinv_rows;
@@ -3034,22 +3085,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             double var = (double)s2 * g.rinv_rows - dm * dm;
             if (var < 0.0) var = 0.0;
             const float invstd = (float)fast_rsqrt(var + (double)Lr.eps);
-            const float sc = bn_g * invstd, sh = bn_b - (float)mean * sc;
-            if (lane < 32) {
-                Lr.coef[col] = sc, Lr.coef[H + col] = sh, Lr.coef[2 * H + col] = (float)mean, Lr.coef[3 * H + col] = invstd;
+            const float sc = eg * invstd, sh = eb - (float)mean * sc;
+            if ((lane & 7) == 0) {
+                Lr.coef[ecol] = sc, Lr.coef[H + ecol] = sh, Lr.coef[2 * H + ecol] = (float)mean, Lr.coef[3 * H + ecol] = invstd;
                 if (Lr.running_mean) {
                     const double unbiased = var * g.unbias;
-                    Lr.running_mean[col] = (1.f - Lr.momentum) * bn_rm + Lr.momentum * (float)mean;
-                    Lr.running_var[col] = (1.f - Lr.momentum) * bn_rv + Lr.momentum * (float)unbiased;
+                    Lr.running_mean[ecol] = (1.f - Lr.momentum) * bn_rm + Lr.momentum * (float)mean;
+                    Lr.running_var[ecol] = (1.f - Lr.momentum) * bn_rv + Lr.momentum * (float)unbiased;
                 }
-                if (wg == 0 && lane == 0 && Lr.num_batches_tracked) *Lr.num_batches_tracked += 1;
+                if (wg == 0 && tid == 0 && Lr.num_batches_tracked) *Lr.num_batches_tracked += 1;
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = frag_row(e, lane);
-                const float v = acc[e] + bias;
-                Ts[row * 36 + l31] = v;
-                Ta[row * 36 + l31] = row < R ? relu_np(fmaf(v, sc, sh)) : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int row = er0 + i;
+                Ts[row * 36 + ecl] = zv[i];
+                Ta[row * 36 + ecl] = row < R ? relu_np(fmaf(zv[i], sc, sh)) : 0.f;
             }
         }
         lds_barrier();
@@ -4534,7 +4584,7 @@ extern "C" int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, cons
 static size_t fc_chain_fwd_lds(int C0, int H, int nl)
 {
     const int LDA = (C0 > H ? C0 : H) + 4;
-    return ((size_t)32 * LDA + (size_t)32 * (C0 + 4) + (size_t)(nl - 1) * 32 * (H + 4) + 3 * 16 * 64 + 2 * 32 * 36) * sizeof(float);
+    return ((size_t)32 * LDA + (size_t)32 * (C0 + 4) + (size_t)(nl - 1) * 32 * (H + 4) + kRsFloats + 2 * 32 * 36) * sizeof(float);
 }
 
 // 1: sn_fc_chain_forward runs this FC head (R rows, C0 -> H -> ... -> H, nl BatchNorm + ReLU layers) as one launch

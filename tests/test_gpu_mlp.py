@@ -712,8 +712,10 @@ def test_fc_chain_backward_equals_per_layer_launches(B, bneck, variant, training
             # BatchNorm-backward coefficients, which everything below inherits (the biases in front of a BatchNorm hold pure
             # rounding noise on both sides: absolute floor relative to the largest gradient)
             gmax = max(float(v.abs().max()) for v in gb.values())
+            # (B < 16: BatchNorm over a handful of rows amplifies those last bits further -- measured up to 4.6e-5 at B = 4)
+            rel = 2e-5 if B >= 16 else 6e-5
             for n in ga:
-                assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * float(gb[n].abs().max()) + 3e-6 * gmax, (rep, n)
+                assert float((ga[n] - gb[n]).abs().max()) <= rel * float(gb[n].abs().max()) + 3e-6 * gmax, (rep, n)
             assert torch.equal(ga["fc4.weight" if "fc4.weight" in ga else "fc3.weight"], gb["fc4.weight" if "fc4.weight" in gb else "fc3.weight"])
     finally:
         pointnet.FC_CHAIN = old
