@@ -3313,7 +3313,7 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int R = g.R, ns = g.ns;
-    const int col0 = wg * 32, col = col0 + l31;
+    const int col0 = wg * 32;
     if (tid == 0) {
         const unsigned lim = g.sync[13 * kFcSyncStride];  // poll bound override (tests)
         s_epoch = __hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3417,8 +3417,8 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
     // ====================================================================== data-gradient chain workgroup
     float *dZs = sm;                 // [32][LD]   dZ of the current layer, all columns
     float *Wt0 = dZs + 32 * LD;      // [2][32][LD] transposed weight slices (ci within the tile, co)
-    float *red = Wt0 + 2 * 32 * LD;  // [3][16][64]
-    float *Ta = red + 3 * 16 * 64;   // [32][36]   this workgroup's tile of dZ of the layer below
+    float *red = Wt0 + 2 * 32 * LD;  // [4][64][kRsPitch]: the waves' K partials (wave_reduce_scatter4)
+    float *Ta = red + kRsFloats;     // [32][36]   this workgroup's tile of dZ of the layer below
     // ---- stage 0 operands: dZ of the top layer straight from HBM, its weight slice (transposed).  ALL loads are issued before
     // the first LDS write, unconditionally (out-of-range slots re-read a valid address): a loop of load -> store iterations, or
     // a load behind a branch, makes every iteration pay its own memory round trip (measured: 4.2 us for this block before)
@@ -3463,9 +3463,8 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
         const int Co = S.Co, Ci = S.Ci;
         const bool has_tile = col0 < Ci, more = s + 1 < ns;
         float *Wt = Wt0 + (size_t)(s & 1) * 32 * LD, *Wtn = Wt0 + (size_t)((s + 1) & 1) * 32 * LD;
-        // ---- prefetches: next stage's weight slice; wave 0: the epilogue's inputs
-        // (waves 1..3 fetch and later stage the slice: wave 0 is busy with the epilogue and the polling)
-        constexpr int NWN = 11;  // ceil(256 rows x 8 float4 / 192 threads)
+        // ---- prefetches: next stage's weight slice (all four waves fetch and later stage it); the epilogue's inputs
+        constexpr int NWN = 8;  // 256 rows x 8 float4 / 256 threads
         float4 wn[NWN];
         bool next_tile = false;
         int nCo = 0, nCi = 0;
@@ -3473,21 +3472,20 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
             const FcBwdStage &N = g.S[s + 1];
             nCo = N.Co, nCi = N.Ci;
             next_tile = col0 < nCi;
-            if (next_tile && wave != 0)
+            if (next_tile)
 #pragma unroll
                 for (int i = 0; i < NWN; ++i) {  // unconditional (clamped): a load behind a branch is waited for on the spot
-                    const int idx = min((tid - 64) + 192 * i, nCo * 8 - 1);
+                    const int idx = min(tid + 256 * i, nCo * 8 - 1);
                     wn[i] = *reinterpret_cast<const float4 *>(N.W + (size_t)(idx >> 3) * nCi + col0 + (idx & 7) * 4);
                 }
         }
-        float zpv[16], esc = 0.f, esh = 0.f, pmean = 0.f, pinv = 0.f;
-        if (has_tile && wave == 0) {
-            esc = S.coefprev[col], esh = S.coefprev[Ci + col], pmean = S.coefprev[2 * Ci + col], pinv = S.coefprev[3 * Ci + col];
+        // the epilogue runs on all four waves (wave_reduce_scatter4): this lane -> column ecol, rows er0 .. er0 + 3
+        const int er0 = 4 * (lane & 7), ecl = wave * 8 + (lane >> 3), ecol = col0 + ecl;
+        float zpv[4], esc = 0.f, esh = 0.f, pmean = 0.f, pinv = 0.f;
+        if (has_tile) {
+            esc = S.coefprev[ecol], esh = S.coefprev[Ci + ecol], pmean = S.coefprev[2 * Ci + ecol], pinv = S.coefprev[3 * Ci + ecol];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = frag_row(e, lane);
-                zpv[e] = S.zprev[row < R ? (size_t)row * Ci + col : 0];
-            }
+            for (int i = 0; i < 4; ++i) zpv[i] = S.zprev[er0 + i < R ? (size_t)(er0 + i) * Ci + ecol : 0];
         }
         // ---- data gradient tile
         if (has_tile) {
@@ -3506,51 +3504,35 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
                 }
             }
-            wave_sum_to_wave0_lds(acc, red);
+            const float4 dz4 = wave_reduce_scatter4(acc, red);
             FC_TL(1, wgi, 2 + 6 * s);
-            // the next stage's weight slice goes into the other LDS buffer NOW: waves 1..3 have nothing else to do while wave 0
-            // runs the epilogue (wave 0's quarter follows its epilogue) -- behind the arrival it sat on the chain's critical path
-            if (wave != 0 && next_tile)
+            {
+                const float dv[4] = {dz4.x, dz4.y, dz4.z, dz4.w};
+                float gv[4], t0[4], t1[4];
 #pragma unroll
-                for (int i = 0; i < NWN; ++i) {
-                    const int idx = (tid - 64) + 192 * i;
-                    if (idx < nCo * 8) {
-                        const int co = idx >> 3, c4 = (idx & 7) * 4;
-                        Wtn[(c4 + 0) * LD + co] = wn[i].x, Wtn[(c4 + 1) * LD + co] = wn[i].y;
-                        Wtn[(c4 + 2) * LD + co] = wn[i].z, Wtn[(c4 + 3) * LD + co] = wn[i].w;
-                    }
+                for (int i = 0; i < 4; ++i) {
+                    const bool live = er0 + i < R;
+                    gv[i] = (live && fmaf(zpv[i], esc, esh) > 0.f) ? dv[i] : 0.f;
+                    t0[i] = gv[i];
+                    t1[i] = live ? gv[i] * (zpv[i] - pmean) : 0.f;
                 }
-            if (wave == 0) {
-                float s0 = 0.f, s1c = 0.f, gv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = frag_row(e, lane);
-                    float v = 0.f;
-                    if (row < R) {
-                        v = (fmaf(zpv[e], esc, esh) > 0.f) ? acc[e] : 0.f;
-                        s0 += v;
-                        s1c += v * (zpv[e] - pmean);
-                    }
-                    gv[e] = v;
-                }
-                s0 += __shfl_xor(s0, 32);
-                s1c += __shfl_xor(s1c, 32);
+                const float s0 = col_sum_seq(t0, lane & 7), s1c = col_sum_seq(t1, lane & 7);
                 const double scale = esc, mean = pmean, invstd = pinv, sd = s0;
                 const double dg = invstd * (double)s1c;
                 const double rinv = S.rinv;
                 const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
                 const float k3 = (float)(scale * (invstd * mean * dg * rinv - sd * rinv));
-                if (lane < 32) {
-                    S.dgamma[col] = (float)dg, S.dbeta[col] = (float)sd;
+                if ((lane & 7) == 0) {
+                    S.dgamma[ecol] = (float)dg, S.dbeta[ecol] = (float)sd;
                     if (S.dbias)
-                        S.dbias[col] = (float)((double)k1 * sd + (double)k2 * (double)S.bn_rows * mean + (double)S.bn_rows * (double)k3);
-                    if (S.kout) S.kout[col] = k1, S.kout[Ci + col] = k2, S.kout[2 * Ci + col] = k3;
+                        S.dbias[ecol] = (float)((double)k1 * sd + (double)k2 * (double)S.bn_rows * mean + (double)S.bn_rows * (double)k3);
+                    if (S.kout) S.kout[ecol] = k1, S.kout[Ci + ecol] = k2, S.kout[2 * Ci + ecol] = k3;
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = frag_row(e, lane);
-                    if (S.gout && row < R) S.gout[(size_t)row * Ci + col] = s_bad ? kNaN : gv[e];  // (a seam timed out: see fc_chain_seam)
-                    Ta[row * 36 + l31] = row < R ? fmaf(k1, gv[e], fmaf(k2, zpv[e], k3)) : 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    const int row = er0 + i;
+                    if (S.gout && row < R) S.gout[(size_t)row * Ci + ecol] = s_bad ? kNaN : gv[i];  // (a seam timed out: see fc_chain_seam)
+                    Ta[row * 36 + ecl] = row < R ? fmaf(k1, gv[i], fmaf(k2, zpv[i], k3)) : 0.f;
                 }
             }
         }
@@ -3569,11 +3551,13 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
         lds_barrier();
         FC_TL(1, wgi, 4 + 6 * s);
         if (tid == 0) __hip_atomic_fetch_add(g.sync + (1 + s) * kFcSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- (a workgroup without a tile in this stage had no MFMA phase to stage the next slice under: do it here)
-        if (next_tile && !has_tile && wave != 0)
+        // ---- the next stage's weight slice goes into the other LDS buffer while the other workgroups' arrivals are awaited
+        // (the poll below cannot succeed sooner than the slowest of them: the staging is free there; in front of the hand-off
+        // it delayed this workgroup's own arrival)
+        if (next_tile)
 #pragma unroll
             for (int i = 0; i < NWN; ++i) {
-                const int idx = (tid - 64) + 192 * i;
+                const int idx = tid + 256 * i;
                 if (idx < nCo * 8) {
                     const int co = idx >> 3, c4 = (idx & 7) * 4;
                     Wtn[(c4 + 0) * LD + co] = wn[i].x, Wtn[(c4 + 1) * LD + co] = wn[i].y;
@@ -4713,7 +4697,7 @@ extern "C" int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci,
         S.aprev = aprev[s], S.araw = araw[s];
         S.gout = s == ns - 1 ? gout : nullptr, S.kout = s == ns - 1 ? kout : nullptr;
     }
-    const size_t lds = ((size_t)3 * 32 * 260 + 3 * 16 * 64 + 32 * 36) * sizeof(float);
+    const size_t lds = ((size_t)3 * 32 * 260 + kRsFloats + 32 * 36) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)fc_chain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
