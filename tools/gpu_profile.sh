@@ -8,8 +8,6 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python -c "import bench; print(bench.csrc_sha16())" > $OUT/PROFILE_SRC_SHA
-timeout 600 python bench.py --steps 300 --warmup 30 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
-tail -c 300 $OUT/bench_n1.json; echo
 for mode in graph after; do
   timeout 300 python bench.py --gpus 1 --force-collective --allreduce $mode --steps 1500 --warmup 100 --no-probes 2> $OUT/bench_n1_rccl_$mode.err | tail -1 > $OUT/bench_n1_rccl_$mode.json
   cat $OUT/bench_n1_rccl_$mode.json
@@ -54,4 +52,9 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_A
 done
 cd $GRAFT_REPO_ROOT
 python tools/summarize_emd.py $OUT $OUT 3
+# the bench line last, against THIS run's kernel stats: assemble profiles/<round>/ on the box first so that the line's
+# roofline_longest / profile.stale fields refer to the profile it is committed with
+bash tools/assemble_profile.sh $R > /dev/null 2>&1
+timeout 600 python bench.py --steps 300 --warmup 30 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+tail -c 300 $OUT/bench_n1.json; echo
 ls -la $OUT
