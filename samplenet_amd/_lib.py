@@ -88,6 +88,8 @@ PROTOTYPES = {
     "sn_fc_chain_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_forward_maxpool_supported": [_i, _i, _i, _i],
     "sn_linear_forward_maxpool": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_pool_dgrad_sparse_supported": [_i, _i, _i, _i],
+    "sn_pool_dgrad_sparse": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_batch_stats_twopass": [_i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_eval_coef": [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
     "sn_pool_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

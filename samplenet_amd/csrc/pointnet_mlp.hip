@@ -4529,6 +4529,95 @@ extern "C" int sn_linear_forward_maxpool(int R, int Ci, int Co, int npts, const 
     return 0;
 }
 
+// ---- data gradient of that last layer when its dZ is SPARSE (BatchNorm-free stack: dZ = dY through the max over the points has one
+// non-zero per cloud and channel -- the pooled element; with a BatchNorm the k2 Z + k3 terms make it dense and the GEMM kernels
+// apply).  dYprev[b, n, :] = relu'_prev . sum over the channels c whose maximum sits at point n of  gsel[b][c] * W[c][:],
+// gsel = pooled > 0 ? g : 0 (the pooling backward, folded in).  One workgroup per (cloud, 32 input channels): 16 groups of 32
+// lanes (two per wave); group q adds its channels (c = q, q + 16, ...: ascending) into its own copy of the cloud's (npts <= 64) x 32
+// tile in LDS -- a lane is the only writer of its column of its copy, so the read-modify-writes need no atomics and their order
+// is fixed; the 16 copies are summed in group order: deterministic, no workgroup talks to another.  The (row, gradient) pairs of
+// 32 channels sit one per lane and reach the half-waves as scalars (v_readlane) + one select; a wave's region is [64][2][32]
+// floats, so a lane's bank is its lane id whatever the rows are.  32 clouds x 1024 channels: 33 k rank-1 updates of 128 floats
+// instead of the dense (2048 x 1024) x (1024 x 128) GEMM with its 64 workgroups of 32 dependent K chunks (DESIGN 5a').
+constexpr int kPdsThreads = 512, kPdsGroups = 16, kPdsCi = 32, kPdsPts = 64, kPdsCh = 32;
+__global__ void __launch_bounds__(kPdsThreads) pool_dgrad_sparse_kernel(int npts, int Ci, int Co, const float *__restrict__ g,
+                                                                        const float *__restrict__ pooled, const int *__restrict__ argsel,
+                                                                        const float *__restrict__ W, const float *__restrict__ zprev,
+                                                                        const float *__restrict__ coef_prev, float *__restrict__ dyprev)
+{
+    __shared__ __attribute__((aligned(16))) float lds[8 * kPdsPts * 64];  // [wave][row][half][32]
+    const int b = blockIdx.x, ci0 = blockIdx.y * kPdsCi;
+    const int lane = threadIdx.x & 63, l = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave * 2 + hh;
+    const int ci = ci0 + l;
+    const bool act = ci < Ci;
+    float *out = lds + wave * (kPdsPts * 64) + hh * 32 + l;  // + row * 64
+    {
+        float4 *z4 = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < 8 * kPdsPts * 64 / 4; i += kPdsThreads) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();  // (another wave zeroed part of this wave's region)
+    const size_t bo = (size_t)b * Co;
+    for (int k0 = 0; k0 * kPdsGroups < Co; k0 += kPdsCh) {  // 32 channels of every group per pass
+        // every load of the pass leaves first: the lane's 32 weights, and the (row, gradient) pair of its group's l-th channel
+        float w[kPdsCh];
+#pragma unroll
+        for (int k = 0; k < kPdsCh; ++k) {
+            const int c = grp + kPdsGroups * (k0 + k);
+            w[k] = (act && c < Co) ? W[(size_t)c * Ci + ci] : 0.f;
+        }
+        int nv = 0;
+        float vv = 0.f;
+        {
+            const int c = grp + kPdsGroups * (k0 + l);
+            if (c < Co) {
+                const int nn = argsel[bo + c];
+                const float gv = pooled[bo + c] > 0.f ? g[bo + c] : 0.f;  // (the pooling backward: sn_pool_backward's expression)
+                const bool in = (unsigned)nn < (unsigned)npts;
+                nv = in ? nn : 0, vv = in ? gv : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPdsCh; ++k) {  // ascending channels: the order of every column's sum is fixed
+            const int na = __builtin_amdgcn_readlane(nv, k), nb = __builtin_amdgcn_readlane(nv, 32 + k);
+            const float va = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), k)),
+                        vb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), 32 + k));
+            float *o = out + (hh ? nb : na) * 64;
+            *o = fmaf(hh ? vb : va, w[k], *o);
+        }
+    }
+    __syncthreads();
+    const float *sc = coef_prev, *sh = coef_prev ? coef_prev + Ci : nullptr;
+    for (int e = threadIdx.x; e < npts * kPdsCi; e += kPdsThreads) {
+        const int n = e >> 5, col = e & 31;
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < kPdsGroups; ++q) a += lds[(q >> 1) * (kPdsPts * 64) + n * 64 + (q & 1) * 32 + col];
+        if (ci0 + col < Ci) {
+            const size_t o = ((size_t)b * npts + n) * Ci + ci0 + col;
+            if (zprev) a = fmaf(zprev[o], sc ? sc[ci0 + col] : 1.f, sh ? sh[ci0 + col] : 0.f) > 0.f ? a : 0.f;
+            dyprev[o] = a;
+        }
+    }
+}
+
+extern "C" int sn_pool_dgrad_sparse_supported(int B, int npts, int Ci, int Co)
+{
+    return B >= 1 && npts >= 1 && npts <= kPdsPts && Ci >= 1 && Co >= 1;
+}
+extern "C" int sn_pool_dgrad_sparse(int B, int npts, int Ci, int Co, const float *g, const float *pooled, const int *argsel,
+                                    const float *W, const float *zprev, const float *coef_prev, float *dyprev, sn_stream_t stream)
+{
+    SN_REQUIRE(g && pooled && argsel && W && dyprev, "null pointer");
+    if (!sn_pool_dgrad_sparse_supported(B, npts, Ci, Co))
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pool_dgrad_sparse: needs at most 64 points per cloud");
+    hipLaunchKernelGGL(pool_dgrad_sparse_kernel, dim3(B, (Ci + kPdsCi - 1) / kPdsCi), dim3(kPdsThreads), 0, (hipStream_t)stream, npts, Ci,
+                       Co, g, pooled, argsel, W, zprev, coef_prev, dyprev);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sn_linear_stats_blocks(int R);
 
 // Layer forward INCLUDING its BatchNorm finalisation (training): Z, then coef[4][Co] + running statistics.

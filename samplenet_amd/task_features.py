@@ -24,6 +24,7 @@ def _st(t):
 
 # Test hooks (the defaults are the product path; False = the route other shapes take anyway)
 FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch (sn_linear_forward_maxpool)
+SPARSE_POOL_DGRAD = True   # last layer's data gradient from the one non-zero per cloud and channel (sn_pool_dgrad_sparse)
 
 _CONST = {}  # (rows, channels, device) -> constant coefficient table, built once (never written afterwards)
 
@@ -41,6 +42,12 @@ def _unit_rows(rows, c, like):
         if not torch.cuda.is_current_stream_capturing():
             _CONST[key] = t
     return t
+
+
+def _sparse_last(ctx_needs, nl, B, N, Ws):
+    """The last layer's backward can take the sparse route: frozen weights of that layer, a layer below it, supported shape."""
+    return (SPARSE_POOL_DGRAD and nl > 1 and not ctx_needs[1 + 2 * (nl - 1)] and not ctx_needs[2 + 2 * (nl - 1)]
+            and bool(lib.sn_pool_dgrad_sparse_supported(B, N, Ws[-1].shape[1], Ws[-1].shape[0])))
 
 
 def _ident(c, like):
@@ -69,7 +76,8 @@ class _FeaturesFunction(torch.autograd.Function):
                 if li == nl - 1 and li > 0 and FUSE_MAXPOOL and lib.sn_linear_forward_maxpool_supported(R, Ci, Co, N):
                     # last layer + max over the points in one GEMM: its activations are written only when a backward will
                     # read them; the frozen / no-gradient branch (the registration loop's template cloud) never materialises them
-                    keep_z = need_grad  # (the dense backward of this layer reads them)
+                    # (the dense backward of this layer reads them; the sparse one -- frozen weights, <= 64 points -- does not)
+                    keep_z = need_grad and not _sparse_last(ctx.needs_input_grad, nl, B, N, Ws)
                     z = torch.empty(R, Co, device=dev, dtype=torch.float32) if keep_z else None
                     keys = torch.empty(B * 2 * Co, device=dev, dtype=torch.int64)
                     check(lib.sn_linear_forward_maxpool(R, Ci, Co, N, ptr(a_in), ptr(coef_prev), ptr(W), ptr(b), ptr(z), ptr(keys),
@@ -108,13 +116,25 @@ class _FeaturesFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _st(x_bnc)
             C = Ws[-1].shape[0]
-            gsel = torch.empty(B, C, device=dev, dtype=torch.float32)
-            scratch = torch.empty(2 * C, device=dev, dtype=torch.float32)
-            check(lib.sn_pool_backward(B, C, ptr(g), ptr(pooled), ptr(zsel), ptr(gsel), ptr(scratch), st), "sn_pool_backward")
+            sparse = _sparse_last(ctx.needs_input_grad, nl, B, N, Ws)
+            if ctx.zlast_missing and not sparse:
+                raise RuntimeError("PointNetFeatures: the last layer's activations were not kept (test hooks changed between "
+                                   "forward and backward?)")
+            gsel = scratch = None
+            if not sparse:
+                gsel = torch.empty(B, C, device=dev, dtype=torch.float32)
+                scratch = torch.empty(2 * C, device=dev, dtype=torch.float32)
+                check(lib.sn_pool_backward(B, C, ptr(g), ptr(pooled), ptr(zsel), ptr(gsel), ptr(scratch), st), "sn_pool_backward")
             dy = None
             for i in range(nl - 1, -1, -1):
                 W = Ws[i]
                 Co, Ci = W.shape[0], W.shape[1]
+                if sparse and i == nl - 1:
+                    # dZ of this layer is one non-zero per cloud and channel: pooling backward + data gradient in one launch
+                    dy = torch.empty(R, Ci, device=dev, dtype=torch.float32)
+                    check(lib.sn_pool_dgrad_sparse(B, N, Ci, Co, ptr(g), ptr(pooled), ptr(argsel), ptr(W), ptr(zs[i - 1]),
+                                                   ptr(idents[i - 1]), ptr(dy), st), "sn_pool_dgrad_sparse")
+                    continue
                 mode = _DZ_POOL if i == nl - 1 else _DZ_PLAIN
                 kcoef = None
                 if mode == _DZ_POOL:  # dZ = 1 * dY_sparse + 0 * Z + 0

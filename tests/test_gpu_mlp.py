@@ -973,3 +973,44 @@ def test_task_features_fused_maxpool_equals_the_layer_by_layer_route(B, N, bneck
         if gpf is not None:
             for a, b in zip(gpf, gpp):
                 assert float((a - b).norm()) <= 1e-6 * float(b.norm()) + 1e-9
+
+
+@pytest.mark.parametrize("B,N,bneck", [(32, 64, 1024), (5, 64, 512), (3, 40, 1024), (2, 17, 64)])
+def test_task_features_sparse_pool_dgrad(B, N, bneck):
+    """Frozen PointNetFeatures with at most 64 points per cloud (the sampled cloud of the registration step): the last layer's data
+    gradient from its one non-zero per cloud and channel (sn_pool_dgrad_sparse, pooling backward folded in, no (B N, bottleneck)
+    activation tensor at all) against the dense DZ_POOL GEMM route and against torch in fp64; run to run bit-identical (fixed
+    summation order: sixteen channel groups, each ascending, summed in group order)."""
+    import torch.nn.functional as F
+
+    from samplenet_amd import task_features as TF
+
+    torch.manual_seed(B * 7 + N)
+    feat = TF.PointNetFeatures(bottleneck_size=bneck, input_shape="bnc").cuda()
+    for p in feat.parameters():
+        p.requires_grad_(False)
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5).requires_grad_(True)
+    go = torch.randn(B, bneck, device="cuda")
+    assert TF.lib.sn_pool_dgrad_sparse_supported(B, N, 128, bneck)
+    got = {}
+    old = TF.SPARSE_POOL_DGRAD
+    try:
+        for tag, flag in (("sparse", True), ("sparse2", True), ("dense", False)):
+            TF.SPARSE_POOL_DGRAD = flag
+            y = feat(x)
+            (got[tag],) = torch.autograd.grad(y, [x], go)
+            got["y_" + tag] = y.detach()
+    finally:
+        TF.SPARSE_POOL_DGRAD = old
+    assert torch.equal(got["y_sparse"], got["y_dense"])
+    assert torch.equal(got["sparse"], got["sparse2"])
+    xr = x.detach().double().requires_grad_(True)
+    h = xr.permute(0, 2, 1)
+    for conv in (feat.conv1, feat.conv2, feat.conv3, feat.conv4, feat.conv5):
+        h = F.relu(F.conv1d(h, conv.weight.double(), conv.bias.double()))
+    (want,) = torch.autograd.grad(torch.max(h, 2)[0], [xr], go.double())
+    scale = float(want.abs().max())
+    e_sparse = float((got["sparse"].double() - want).abs().max())
+    e_dense = float((got["dense"].double() - want).abs().max())
+    assert e_sparse <= 2e-5 * scale and e_sparse <= 2 * e_dense + 1e-6 * scale, (e_sparse, e_dense, scale)
+    assert float((got["sparse"] - got["dense"]).norm()) <= 2e-5 * float(got["dense"].norm())
