@@ -238,6 +238,16 @@ int sn_linear_forward_maxpool(int R, int Ci, int Co, int npts, const float *ain,
                               const float *bias, float *z, unsigned long long *keys, float *pooled, int *argsel, float *zsel,
                               sn_stream_t stream);
 
+/*   sn_linear_forward_maxpool_wide   the same for a WIDE last layer (PCRNet: 128 -> 1024): a workgroup keeps the split A fragments
+ *                               of its 128 rows in registers for all of its columns, the weights are split once per call into
+ *                               wplanes (3 * Co * Ci bf16; planes_ready != 0: already holds the split of this W); the maxima
+ *                               leave as one key per column and min(128, npts) rows (scratch: _scratch_bytes) -- no atomics, no
+ *                               clear; results bit-identical to sn_linear_forward_maxpool.  Query _supported. */
+int sn_linear_forward_maxpool_wide_supported(int R, int Ci, int Co, int npts);
+long long sn_linear_forward_maxpool_wide_scratch_bytes(int R, int Ci, int Co, int npts);
+int sn_linear_forward_maxpool_wide(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
+                                   const float *bias, float *z, void *scratch, float *pooled, int *argsel, float *zsel,
+                                   void *wplanes, int planes_ready, sn_stream_t stream);
 /*   sn_pool_dgrad_sparse        data gradient of that last layer for a BatchNorm-free stack (dZ has ONE non-zero per cloud and
  *                               channel): dyprev (B*npts, Ci) = relu'_prev . sum_c [argsel[b][c] == n] (pooled > 0 ? g : 0)[b][c]
  *                               W[c][:] -- sn_pool_backward + sn_linear_dgrad(DZ_POOL) without the dense (R, Co) operand.

@@ -88,6 +88,9 @@ PROTOTYPES = {
     "sn_fc_chain_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_forward_maxpool_supported": [_i, _i, _i, _i],
     "sn_linear_forward_maxpool": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_linear_forward_maxpool_wide_supported": [_i, _i, _i, _i],
+    "sn_linear_forward_maxpool_wide_scratch_bytes": [_i, _i, _i, _i],
+    "sn_linear_forward_maxpool_wide": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sn_pool_dgrad_sparse_supported": [_i, _i, _i, _i],
     "sn_pool_dgrad_sparse": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_batch_stats_twopass": [_i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
@@ -107,7 +110,8 @@ PROTOTYPES = {
     "sn_emd_loss": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong,
-             "sn_pairscan_workspace_bytes": ctypes.c_longlong, "sn_layer_backward_in3_stats_floats": ctypes.c_longlong,
+             "sn_pairscan_workspace_bytes": ctypes.c_longlong, "sn_linear_forward_maxpool_wide_scratch_bytes": ctypes.c_longlong,
+             "sn_layer_backward_in3_stats_floats": ctypes.c_longlong,
              "sn_conv_stack_acc_elems": ctypes.c_longlong,
              "sn_conv_stack_acc_sum_elems": ctypes.c_longlong,
              "sn_conv_stack_backward_scratch_floats": ctypes.c_longlong}

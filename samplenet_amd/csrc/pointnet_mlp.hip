@@ -4529,6 +4529,275 @@ extern "C" int sn_linear_forward_maxpool(int R, int Ci, int Co, int npts, const 
     return 0;
 }
 
+// ---- the same layer as a WIDE product (Co >> 64: PCRNet's 128 -> 1024 on 32 x 1024 points is 8.6 GFLOP, 16 column blocks per row
+// tile).  linear_fwd_kernel runs it as 512 x 16 independent 64 x 64 tiles: every tile re-reads, re-activates and re-splits its A
+// rows and re-splits its W block (86 us = 100 fp32-equivalent TFLOP/s).  Here a workgroup of four waves owns 128 rows for ALL of
+// its columns: each wave activates and splits its 32 rows ONCE into the three bf16 planes' A fragments, which then stay in
+// registers (3 x K/16 x 16 bytes per lane); the weights arrive pre-split (split_planes_kernel, once per call) and only their
+// 64-column blocks move through LDS, double-buffered -- the next block's global loads are in flight under the current
+// block's 48 MFMAs per wave, one barrier per block.  Same six products per 16 k in the same order as gemm_tile_bx3: the
+// pre-activations, hence the pooled features, are bit-identical to linear_fwd_kernel's.  Epilogue per block: bias, (max, first
+// row) over the wave's 32 rows as a 64-bit key (a wave's rows lie in one cloud: npts % 32 == 0), the waves of one cloud combined
+// through LDS, ONE plain 8-byte store per column and min(128, npts) rows; the decode kernel takes the maximum over a cloud's
+// npts / 128 keys.  No atomics (one atomicMax per column and 32 rows = 1 M of them per call paced the kernel at 70 us whatever the
+// MFMAs did), no key clear.  Small R: the columns are split over gridDim.y so that the grid still covers the chip.
+constexpr int kWideRows = 128, kWideBN = 64;
+struct WideArgs {
+    const float *ain, *scale, *shift;  // (R, K) pre-activations of the layer below and its operand coefficients (NULL: identity)
+    const __bf16 *planes;               // [3][Co][K]
+    const float *bias;
+    float *z;                           // (R, Co) or NULL
+    unsigned long long *partial;        // [R / group_rows][Co]: (max, first row) keys of group_rows = min(128, npts) rows
+    int R, Co, npts, cols_per_wg, group_rows;
+};
+__global__ void __launch_bounds__(256) split_planes_kernel(int n, const float *__restrict__ W, __bf16 *__restrict__ planes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    __bf16 h1, h2, h3;
+    split3(W[i], h1, h2, h3);
+    planes[i] = h1, planes[(size_t)n + i] = h2, planes[2 * (size_t)n + i] = h3;
+}
+// STORE_Z: the pre-activations are written too (a backward through trainable weights will read them); ARG: the keys carry the row of
+// the maximum (only a backward needs it).  Software pipeline: the epilogue of block k (bias, maximum over the wave's rows, key) is
+// spread over the eight k-steps of block k + 1's MFMAs -- two waves share a SIMD and all eight meet at a barrier every block, so
+// an epilogue phase of its own is a phase in which no matrix instruction issues anywhere on the CU (measured: 63 us of which 31
+// were MFMA time); as fillers between MFMAs the same instructions are nearly free (MI355X_MICROARCH.md: <= 5 per gap).
+template <int K, bool STORE_Z, bool ARG>
+__global__ void __launch_bounds__(512) linear_fwd_wide_pool_kernel(WideArgs g)
+{
+    constexpr int KS = K / 16, PITCH = K + 8;            // 16 consecutive rows' 16-byte fragments tile all 64 banks (K % 32 == 0)
+    constexpr int NB = 3 * kWideBN * (K / 8) / 512;      // 16-byte items of a weight block per thread
+    constexpr int BUF = 3 * kWideBN * PITCH;             // bf16 elements per buffer
+    constexpr int EPK = 16 / KS;                         // epilogue elements per k-step
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ unsigned long long s_keys[2][4][kWideBN];
+    __bf16 *Bs = reinterpret_cast<__bf16 *>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // eight waves: row tile rw = wave & 3 (32 rows each), column half cw = wave >> 2 of every 64-column block
+    const int rw = wave & 3, cw = wave >> 2;
+    const int row0 = blockIdx.x * kWideRows + rw * 32;
+    const int cbeg = blockIdx.y * g.cols_per_wg, nblk = g.cols_per_wg / kWideBN;
+    const int Co = g.Co;
+    // per-thread item offsets of a weight block, fixed for the whole kernel: global (elements from the block's first column's row)
+    // and LDS (elements from the buffer)
+    int goff[NB], loff[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int f = tid + q * 512, p = f / (kWideBN * (K / 8)), r = f % (kWideBN * (K / 8)), x = r / (K / 8), k8 = (r % (K / 8)) * 8;
+        goff[q] = (p * Co + x) * K + k8;
+        loff[q] = (p * kWideBN + x) * PITCH + k8;
+    }
+    bf16x8 rb[NB];
+    const auto fetch_b = [&](int col0) {
+        const __bf16 *pb = g.planes + (size_t)col0 * K;  // (uniform)
+#pragma unroll
+        for (int q = 0; q < NB; ++q) rb[q] = *reinterpret_cast<const bf16x8 *>(pb + goff[q]);
+    };
+    const auto stage_b = [&](__bf16 *buf) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) *reinterpret_cast<bf16x8 *>(buf + loff[q]) = rb[q];
+    };
+    SN_TL(0);
+    // Column blocks are visited in an order rotated by the workgroup's row block: all workgroups run in step, and 256 of them
+    // asking the L2 for the SAME 48 KB at the same moment serialise on the few channels those lines live in
+    const int rot = (blockIdx.x / 8) % nblk;  // (workgroups b, b + 8, ... share an XCD and its L2)
+    const auto blk_col = [&](int blk) { return cbeg + ((blk + rot) % nblk) * kWideBN; };
+    fetch_b(blk_col(0));
+    // this wave's A fragments: lane -> row l31, 8 consecutive k at 16 kk + 8 h; activated and split once
+    bf16x8 a[3][KS];
+    {
+        const float *ar = g.ain + (size_t)(row0 + l31) * K + 8 * h;
+        float4 v[KS][2];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            v[kk][0] = *reinterpret_cast<const float4 *>(ar + kk * 16), v[kk][1] = *reinterpret_cast<const float4 *>(ar + kk * 16 + 4);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            float e[8] = {v[kk][0].x, v[kk][0].y, v[kk][0].z, v[kk][0].w, v[kk][1].x, v[kk][1].y, v[kk][1].z, v[kk][1].w};
+            if (g.scale) {
+                const float4 s0 = *reinterpret_cast<const float4 *>(g.scale + kk * 16 + 8 * h), s1 = *reinterpret_cast<const float4 *>(g.scale + kk * 16 + 8 * h + 4);
+                const float4 t0 = *reinterpret_cast<const float4 *>(g.shift + kk * 16 + 8 * h), t1 = *reinterpret_cast<const float4 *>(g.shift + kk * 16 + 8 * h + 4);
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                for (int t = 0; t < 8; ++t) e[t] = relu_np(fmaf(e[t], sc[t], sh[t]));
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                __bf16 h1, h2, h3;
+                split3(e[t], h1, h2, h3);
+                a[0][kk][t] = h1, a[1][kk][t] = h2, a[2][kk][t] = h3;
+            }
+        }
+    }
+    stage_b(Bs);
+    __syncthreads();
+    SN_TL(1);
+    const int rin0 = row0 % g.npts;                    // this wave's first row inside its cloud
+    const int wpg = g.group_rows / 32, ngrp = 4 / wpg;  // row waves per key group, key groups per workgroup
+    const int boff = (cw * 32 + l31) * PITCH + 8 * h;   // this lane's B fragment inside a plane of a buffer (k-step 0)
+    float *zrow = STORE_Z ? g.z + (size_t)(row0 + 4 * h) * Co + cw * 32 + l31 : nullptr;  // + frag rows, + col0
+    f32x16 accp;      // the previous block's accumulators, epilogue pending
+    float biasp = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accp[e] = 0.f;
+    // iteration blk: MFMAs of block blk (blk < nblk) + epilogue of block blk - 1 (blk > 0); the keys of block blk - 1 are
+    // published by the barrier that ends iteration blk and stored right behind it
+    for (int blk = 0; blk <= nblk; ++blk) {
+        const bool mm = blk < nblk, ep = blk > 0;
+        if (blk == 4) SN_TL(2);
+        const __bf16 *cur = Bs + (blk & 1) * BUF + boff;
+        const int col0 = blk_col(blk), colp = blk_col(blk - 1 + nblk);  // this block's first column, the previous block's
+        if (blk + 1 < nblk) fetch_b(blk_col(blk + 1));
+        const float biasv = (mm && g.bias) ? g.bias[col0 + cw * 32 + l31] : 0.f;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        bf16x8 b[2][3];
+        const auto load_b = [&](int kk, bf16x8 (&bb)[3]) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bb[p] = *reinterpret_cast<const bf16x8 *>(cur + p * kWideBN * PITCH + kk * 16);
+        };
+        float m = -INFINITY;
+        int im = 0;
+        if (mm) load_b(0, b[0]);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (mm) {
+                if (kk + 1 < KS) load_b(kk + 1, b[(kk + 1) & 1]);
+#ifdef SN_WIDE_NOMFMA
+#define SN_WIDE_TERM(PA, PB) acc[0] += (float)a[PA][kk][0] * (float)b[kk & 1][PB][0]
+#else
+#define SN_WIDE_TERM(PA, PB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][kk], b[kk & 1][PB], acc, 0, 0, 0)
+#endif
+                // the six MFMAs of a k-step run on ONE accumulator: kept back to back (a filler between two of them costs ~43 cycles,
+                // MI355X_MICROARCH.md); the fragment reads and the epilogue pieces go between the groups
+                __builtin_amdgcn_sched_barrier(0);
+                SN_WIDE_TERM(0, 2);
+                SN_WIDE_TERM(2, 0);
+                SN_WIDE_TERM(1, 1);
+                SN_WIDE_TERM(0, 1);
+                SN_WIDE_TERM(1, 0);
+                SN_WIDE_TERM(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#undef SN_WIDE_TERM
+            }
+            // the next block's weights (requested at the top of the iteration) go to the other buffer under the last MFMA groups; that
+            // buffer's readers passed the barrier that ended iteration blk - 1
+            if (kk == KS - 2 && blk + 1 < nblk) stage_b(Bs + ((blk + 1) & 1) * BUF);
+            if (ep) {
+#pragma unroll
+                for (int e = kk * EPK; e < (kk + 1) * EPK; ++e) {  // rows ascend with e inside a lane: strict compare = first occurrence
+                    const float v = accp[e] + biasp;
+                    if (STORE_Z) zrow[(size_t)((e & 3) + 8 * (e >> 2)) * Co + colp] = v;
+                    if (ARG) {
+                        if (v > m) m = v, im = (e & 3) + 8 * (e >> 2);
+                    } else {
+                        m = fmaxf(m, v);
+                    }
+                }
+            }
+        }
+        if (ep) {
+            if (ARG) im += 4 * h;
+            const float om = __shfl_xor(m, 32);
+            const int oim = __shfl_xor(im, 32);
+            if (om > m || (ARG && om == m && oim < im)) m = om, im = oim;
+            if (lane < 32) s_keys[blk & 1][rw][cw * 32 + l31] = pool_key(m, ARG ? rin0 + im : 0);
+        }
+        if (blk == 4) SN_TL(3);
+        accp = acc, biasp = biasv;
+        // LDS-only barrier (__syncthreads() would also wait for the block's global stores)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (blk == 4) SN_TL(5);
+        if (ep && tid < ngrp * kWideBN) {  // (s_keys[blk & 1] is rewritten two iterations on, behind another barrier)
+            const int grp = tid / kWideBN, c = tid % kWideBN;
+            unsigned long long k = s_keys[blk & 1][grp * wpg][c];
+            for (int w = 1; w < wpg; ++w) k = max(k, s_keys[blk & 1][grp * wpg + w][c]);
+            g.partial[((size_t)blockIdx.x * ngrp + grp) * Co + colp + c] = k;
+        }
+    }
+    SN_TL(6);
+}
+// pooled = relu(max over the cloud's P partial keys), the row and the pre-activation value (what the pooling backward needs)
+__global__ void __launch_bounds__(256) maxpool_partials_decode_kernel(int n, int Co, int P, const unsigned long long *__restrict__ partial,
+                                                                      float *__restrict__ pooled, int *__restrict__ argsel,
+                                                                      float *__restrict__ zsel)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / Co, c = i % Co;
+    unsigned long long k = partial[(size_t)b * P * Co + c];
+    for (int p = 1; p < P; ++p) k = max(k, partial[((size_t)b * P + p) * Co + c]);
+    float v;
+    int row;
+    pool_key_decode(k, v, row);
+    pooled[i] = relu_np(v);
+    if (argsel) argsel[i] = row;
+    if (zsel) zsel[i] = v;
+}
+
+extern "C" int sn_linear_forward_maxpool_wide_supported(int R, int Ci, int Co, int npts)
+{
+    // (below 128 row blocks the columns would have to be split four ways and more to cover the chip: the per-workgroup prologue
+    // -- activate and split 128 rows, ~6 us -- then outweighs what the 64 x 64 tile kernel re-does per tile)
+    return R >= 128 * kWideRows && R % kWideRows == 0 && npts >= 32 && npts % 32 == 0 && R % npts == 0 && (Ci == 64 || Ci == 128) &&
+           Co >= 8 * kWideBN && Co % kWideBN == 0;
+}
+static int wide_group_rows(int npts) { return npts % 128 == 0 ? 128 : npts % 64 == 0 ? 64 : 32; }
+extern "C" long long sn_linear_forward_maxpool_wide_scratch_bytes(int R, int Ci, int Co, int npts)
+{
+    (void)Ci;
+    return (long long)(R / wide_group_rows(npts)) * Co * (long long)sizeof(unsigned long long);
+}
+// wplanes: 3 * Co * Ci bf16 for the split weights; planes_ready != 0: it already holds the split of THIS W (a second cloud
+// through the same frozen layer).  scratch: _scratch_bytes (the per-group keys).
+extern "C" int sn_linear_forward_maxpool_wide(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
+                                              const float *bias, float *z, void *scratch, float *pooled, int *argsel, float *zsel,
+                                              void *wplanes, int planes_ready, sn_stream_t stream)
+{
+    SN_REQUIRE(ain && W && scratch && pooled && wplanes, "null pointer");
+    if (!sn_linear_forward_maxpool_wide_supported(R, Ci, Co, npts))
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_linear_forward_maxpool_wide: needs R %% 128 == 0, npts %% 32 == 0, Ci 64 / 128, Co %% 64 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = R / npts;
+    __bf16 *planes = (__bf16 *)wplanes;
+    if (!planes_ready) hipLaunchKernelGGL(split_planes_kernel, dim3((Co * Ci + 255) / 256), dim3(256), 0, st, Co * Ci, W, planes);
+    WideArgs g{};
+    g.ain = ain, g.scale = coef_prev, g.shift = coef_prev ? coef_prev + Ci : nullptr;
+    g.planes = planes, g.bias = bias, g.z = z, g.partial = (unsigned long long *)scratch, g.R = R, g.Co = Co, g.npts = npts;
+    g.group_rows = wide_group_rows(npts);
+    // columns per workgroup: all of them when the row blocks alone cover the chip, else split (a power-of-two number of 64-column blocks)
+    const int rb = R / kWideRows;
+    int cs = 1;
+    while (rb * cs < 256 && Co / (cs * 2) >= kWideBN && (Co / kWideBN) % (cs * 2) == 0) cs *= 2;
+    g.cols_per_wg = Co / cs;
+    const size_t lds = (size_t)2 * 3 * kWideBN * (Ci + 8) * sizeof(__bf16);
+    const bool sz = z != nullptr, arg = argsel != nullptr || sz;
+#define SN_WIDE_LAUNCH(KK, SZ, AR)                                                                                                  \
+    do {                                                                                                                            \
+        static bool attr = false;                                                                                                   \
+        if (!attr) {                                                                                                                \
+            if (hipFuncSetAttribute((const void *)linear_fwd_wide_pool_kernel<KK, SZ, AR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)(2 * 3 * kWideBN * (KK + 8) * 2)) != hipSuccess)                                           \
+                return sn_set_error(SN_ERR_UNSUPPORTED, "sn_linear_forward_maxpool_wide: cannot reserve LDS");                      \
+            attr = true;                                                                                                            \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((linear_fwd_wide_pool_kernel<KK, SZ, AR>), dim3(rb, cs), dim3(512), lds, st, g);                         \
+    } while (0)
+    if (Ci == 128) {
+        if (sz) SN_WIDE_LAUNCH(128, true, true); else if (arg) SN_WIDE_LAUNCH(128, false, true); else SN_WIDE_LAUNCH(128, false, false);
+    } else {
+        if (sz) SN_WIDE_LAUNCH(64, true, true); else if (arg) SN_WIDE_LAUNCH(64, false, true); else SN_WIDE_LAUNCH(64, false, false);
+    }
+#undef SN_WIDE_LAUNCH
+    hipLaunchKernelGGL(maxpool_partials_decode_kernel, dim3((B * Co + 255) / 256), dim3(256), 0, st, B * Co, Co, npts / g.group_rows,
+                       (const unsigned long long *)scratch, pooled, argsel, zsel);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- data gradient of that last layer when its dZ is SPARSE (BatchNorm-free stack: dZ = dY through the max over the points has one
 // non-zero per cloud and channel -- the pooled element; with a BatchNorm the k2 Z + k3 terms make it dense and the GEMM kernels
 // apply).  dYprev[b, n, :] = relu'_prev . sum over the channels c whose maximum sits at point n of  gsel[b][c] * W[c][:],

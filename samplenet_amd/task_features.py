@@ -10,6 +10,8 @@ Built on the same C-ABI entries as the sampler's own feature extractor (samplene
 `act = relu(scale * z + shift)` operand mode with scale = 1, shift = 0 is exactly ReLU (fma(z, 1, 0) == z), and the
 pooling / sparse last-layer gradient use the BatchNorm-free coefficients k = (1, 0, 0).
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -24,6 +26,7 @@ def _st(t):
 
 # Test hooks (the defaults are the product path; False = the route other shapes take anyway)
 FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch (sn_linear_forward_maxpool)
+WIDE_MAXPOOL = True        # ... as the wide kernel (A fragments resident, pre-split weight planes) where the shape allows
 SPARSE_POOL_DGRAD = True   # last layer's data gradient from the one non-zero per cloud and channel (sn_pool_dgrad_sparse)
 
 _CONST = {}  # (rows, channels, device) -> constant coefficient table, built once (never written afterwards)
@@ -42,6 +45,30 @@ def _unit_rows(rows, c, like):
         if not torch.cuda.is_current_stream_capturing():
             _CONST[key] = t
     return t
+
+
+_PLANES = {}  # id(weight parameter) -> (weak reference to it, its version, its three bf16 planes)
+
+
+def _weight_planes(W):
+    """Scratch for the split of W into three bf16 planes (sn_linear_forward_maxpool_wide) and whether it already holds the split
+    of this very W: eager calls reuse it while the parameter object is the same and its version counter stands still (the two
+    clouds of a registration step, every step of a frozen task network); under a stream capture the split is always recorded
+    -- a replay must see weights that were updated in place since."""
+    base = W._base if W._base is not None else W
+    hit = _PLANES.get(id(base))
+    capturing = torch.cuda.is_current_stream_capturing()
+    if hit is not None and hit[0]() is base and hit[2].numel() == 3 * W.numel() and hit[2].device == W.device:
+        ready = hit[1] == base._version and not capturing
+        if not capturing:
+            _PLANES[id(base)] = (hit[0], base._version, hit[2])
+        return hit[2], ready
+    planes = torch.empty(3 * W.numel(), device=W.device, dtype=torch.bfloat16)
+    if not capturing:
+        for k in [k for k, v in _PLANES.items() if v[0]() is None]:
+            del _PLANES[k]
+        _PLANES[id(base)] = (weakref.ref(base), base._version, planes)
+    return planes, False
 
 
 def _sparse_last(ctx_needs, nl, B, N, Ws):
@@ -79,9 +106,20 @@ class _FeaturesFunction(torch.autograd.Function):
                     # (the dense backward of this layer reads them; the sparse one -- frozen weights, <= 64 points -- does not)
                     keep_z = need_grad and not _sparse_last(ctx.needs_input_grad, nl, B, N, Ws)
                     z = torch.empty(R, Co, device=dev, dtype=torch.float32) if keep_z else None
-                    keys = torch.empty(B * 2 * Co, device=dev, dtype=torch.int64)
-                    check(lib.sn_linear_forward_maxpool(R, Ci, Co, N, ptr(a_in), ptr(coef_prev), ptr(W), ptr(b), ptr(z), ptr(keys),
-                                                        ptr(pooled), ptr(argsel), ptr(zsel), st), "sn_linear_forward_maxpool")
+                    if WIDE_MAXPOOL and lib.sn_linear_forward_maxpool_wide_supported(R, Ci, Co, N):
+                        planes, ready = _weight_planes(W)
+                        nb = lib.sn_linear_forward_maxpool_wide_scratch_bytes(R, Ci, Co, N)
+                        keys = torch.empty(nb // 8, device=dev, dtype=torch.int64)
+                        # (the rows of the maxima only where a backward will ask for them: the kernel then skips the argmax)
+                        check(lib.sn_linear_forward_maxpool_wide(R, Ci, Co, N, ptr(a_in), ptr(coef_prev), ptr(W), ptr(b), ptr(z),
+                                                                 ptr(keys), ptr(pooled), ptr(argsel) if need_grad else None,
+                                                                 ptr(zsel) if need_grad else None, ptr(planes), int(ready), st),
+                              "sn_linear_forward_maxpool_wide")
+                    else:
+                        keys = torch.empty(B * 2 * Co, device=dev, dtype=torch.int64)
+                        check(lib.sn_linear_forward_maxpool(R, Ci, Co, N, ptr(a_in), ptr(coef_prev), ptr(W), ptr(b), ptr(z),
+                                                            ptr(keys), ptr(pooled), ptr(argsel), ptr(zsel), st),
+                              "sn_linear_forward_maxpool")
                     zs.append(z)
                     idents.append(_ident(Co, pooled))
                     break

@@ -1014,3 +1014,43 @@ def test_task_features_sparse_pool_dgrad(B, N, bneck):
     e_dense = float((got["dense"].double() - want).abs().max())
     assert e_sparse <= 2e-5 * scale and e_sparse <= 2 * e_dense + 1e-6 * scale, (e_sparse, e_dense, scale)
     assert float((got["sparse"] - got["dense"]).norm()) <= 2e-5 * float(got["dense"].norm())
+
+
+@pytest.mark.parametrize("B,N,bneck,cin", [(32, 1024, 1024, 128), (16, 1024, 512, 128), (128, 128, 1024, 128), (256, 64, 512, 128),
+                                            (512, 32, 512, 128)])
+def test_task_features_wide_maxpool_is_bit_identical(B, N, bneck, cin):
+    """The wide last layer (sn_linear_forward_maxpool_wide: A fragments of 128 rows resident in registers for all columns, weights
+    split once into bf16 planes) against the 64 x 64 tile kernel (sn_linear_forward_maxpool): same six bf16 products per 16 k in the
+    same order, so pooled features, selected rows and pre-activations are EQUAL; the weight planes are re-split when the
+    weights change in place (version counter) and when a new parameter object takes an old one's place."""
+    from samplenet_amd import task_features as TF
+
+    assert TF.lib.sn_linear_forward_maxpool_wide_supported(B * N, cin, bneck, N)
+    torch.manual_seed(B + N)
+    feat = TF.PointNetFeatures(bottleneck_size=bneck, input_shape="bnc").cuda()
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    old = TF.WIDE_MAXPOOL
+    try:
+        out = {}
+        for tag, flag in (("wide", True), ("tile", False)):
+            TF.WIDE_MAXPOOL = flag
+            with torch.no_grad():
+                out[tag] = feat(x)
+            xg = x.clone().requires_grad_(True)
+            y = feat(xg)  # trainable weights: the activations are kept and read by the dense backward
+            y.sum().backward()
+            out[tag + "_y"], out[tag + "_gx"] = y.detach(), xg.grad.clone()
+            out[tag + "_gw"] = feat.conv5.weight.grad.clone()
+            feat.zero_grad(set_to_none=True)
+        assert torch.equal(out["wide"], out["tile"]) and torch.equal(out["wide_y"], out["tile_y"])
+        assert torch.equal(out["wide_gx"], out["tile_gx"]) and torch.equal(out["wide_gw"], out["tile_gw"])
+        # in-place weight update -> new planes
+        TF.WIDE_MAXPOOL = True
+        with torch.no_grad():
+            feat.conv5.weight.mul_(-0.5)
+            y1 = feat(x)
+            TF.WIDE_MAXPOOL = False
+            y2 = feat(x)
+        assert torch.equal(y1, y2) and not torch.equal(y1, out["wide"])
+    finally:
+        TF.WIDE_MAXPOOL = old
