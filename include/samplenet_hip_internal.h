@@ -257,6 +257,16 @@ int sn_pool_dgrad_sparse_supported(int B, int npts, int Ci, int Co);
 int sn_pool_dgrad_sparse(int B, int npts, int Ci, int Co, const float *g, const float *pooled, const int *argsel, const float *W,
                          const float *zprev, const float *coef_prev, float *dyprev, sn_stream_t stream);
 
+/* Linear layers on at most 32 rows (PCRNet's trunk, registration/models/pcrnet.py:56-77): out (R, N) = act((x . [gate > 0]) (R, K) .
+ * W^T + bias), the weight stream cut into (32-column tile) x (K slice) workgroups, slices summed in order by the last workgroup to
+ * arrive (deterministic); fp32 products as split-bf16 MFMAs.
+ *   transposed == 0: W (N, K) -- forward;  != 0: W (K, N) -- data gradient dX = (dY . [y > 0]) W with gate = the layer's output y
+ *   gate, bias: optional.  scratch: _scratch_bytes; counters: (N + 31) / 32 zeroed 32-bit words (left zeroed). */
+int sn_skinny_linear_supported(int R, int K, int N);
+long long sn_skinny_linear_scratch_bytes(int R, int K, int N);
+int sn_skinny_linear(int R, int K, int N, const float *x, const float *gate, const float *W, int transposed, const float *bias, int relu,
+                     float *out, float *scratch, unsigned *counters, sn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,9 @@ PROTOTYPES = {
     "sn_linear_forward_maxpool_wide_supported": [_i, _i, _i, _i],
     "sn_linear_forward_maxpool_wide_scratch_bytes": [_i, _i, _i, _i],
     "sn_linear_forward_maxpool_wide": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "sn_skinny_linear_supported": [_i, _i, _i],
+    "sn_skinny_linear_scratch_bytes": [_i, _i, _i],
+    "sn_skinny_linear": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "sn_pool_dgrad_sparse_supported": [_i, _i, _i, _i],
     "sn_pool_dgrad_sparse": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_batch_stats_twopass": [_i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
@@ -111,6 +114,7 @@ PROTOTYPES = {
 }
 _RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong,
              "sn_pairscan_workspace_bytes": ctypes.c_longlong, "sn_linear_forward_maxpool_wide_scratch_bytes": ctypes.c_longlong,
+             "sn_skinny_linear_scratch_bytes": ctypes.c_longlong,
              "sn_layer_backward_in3_stats_floats": ctypes.c_longlong,
              "sn_conv_stack_acc_elems": ctypes.c_longlong,
              "sn_conv_stack_acc_sum_elems": ctypes.c_longlong,

@@ -4798,6 +4798,191 @@ extern "C" int sn_linear_forward_maxpool_wide(int R, int Ci, int Co, int npts, c
     return 0;
 }
 
+// ---- Linear layers on at most 32 rows (PCRNet's trunk, registration/models/pcrnet.py:56-77: 2048 -> 1024 -> 1024 -> 512 -> 512 ->
+// 256 -> 7 on the batch's 32 feature vectors; forward and data gradient).  15.5 MB of weights against 1 MFLOP per row: the layer is
+// a weight STREAM, and a CU pulls only ~25 GB/s from memory -- so the product is cut into (32-column tile) x (K slice) workgroups
+// until the grid covers the chip (fc1: 32 x 8), four waves per workgroup each taking a quarter of the slice with ALL of its loads
+// issued up front (1, 2 or 4 k-steps of 16), fp32 products as six bf16 MFMAs of three-way split operands (split in registers:
+// the fragments are 8 consecutive k per lane, i.e. two 16-byte loads straight from the row-major operands, no LDS staging).
+// The four waves' partial tiles are summed through LDS (wave_reduce_scatter4), the S slices by the workgroup that arrives last
+// at the tile's counter (partials cross as write-through stores / sc1 loads, relaxed counter: see the FC chains) in slice order:
+// deterministic.  Epilogue: bias, ReLU.  out (R, N) = act((x . [gate > 0]) (R, K) . W^T + bias):
+//   wmode 0: W is (N, K) row-major -- forward, y = x W^T + b
+//   wmode 1: W is (K, N) row-major -- data gradient, dX = (dY . [y > 0]) W with gate = the layer's own (post-ReLU) output
+struct SkinnyArgs {
+    const float *x, *gate, *W, *bias;
+    float *out, *part;
+    unsigned *counter;
+    int R, K, N, S, kslice, wmode, relu;
+};
+template <int KSTEPS>
+__global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
+{
+    __shared__ __attribute__((aligned(16))) float red[kRsFloats];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, s = blockIdx.y, n0 = tile * 32;
+    const int K = g.K, N = g.N, R = g.R;
+    const int kw = g.kslice / 4;                                  // this wave's K range: KSTEPS steps of 16
+    const int kb = s * g.kslice + wave * kw;
+    const int m = l31, n = n0 + l31;
+    const bool mok = m < R, nok = n < N;
+    const bool kvec = (K & 3) == 0, nvec = true;
+    (void)nvec;
+    float ea[KSTEPS][8], eg[KSTEPS][8], eb[KSTEPS][8];
+#pragma unroll
+    for (int st = 0; st < KSTEPS; ++st) {
+        const int k8 = kb + st * 16 + 8 * h;
+        const bool full = k8 + 8 <= K && kvec;
+        // A: 8 consecutive k of row m of x (and of the gate)
+        if (full && mok) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(g.x + (size_t)m * K + k8), v1 = *reinterpret_cast<const float4 *>(g.x + (size_t)m * K + k8 + 4);
+            ea[st][0] = v0.x, ea[st][1] = v0.y, ea[st][2] = v0.z, ea[st][3] = v0.w, ea[st][4] = v1.x, ea[st][5] = v1.y, ea[st][6] = v1.z, ea[st][7] = v1.w;
+            if (g.gate) {
+                const float4 g0 = *reinterpret_cast<const float4 *>(g.gate + (size_t)m * K + k8), g1 = *reinterpret_cast<const float4 *>(g.gate + (size_t)m * K + k8 + 4);
+                eg[st][0] = g0.x, eg[st][1] = g0.y, eg[st][2] = g0.z, eg[st][3] = g0.w, eg[st][4] = g1.x, eg[st][5] = g1.y, eg[st][6] = g1.z, eg[st][7] = g1.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool ok = mok && k8 + t < K;
+                ea[st][t] = ok ? g.x[(size_t)m * K + k8 + t] : 0.f;
+                if (g.gate) eg[st][t] = ok ? g.gate[(size_t)m * K + k8 + t] : 0.f;
+            }
+        }
+        // B: 8 consecutive k of output column n
+        if (g.wmode == 0) {
+            if (full && nok) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(g.W + (size_t)n * K + k8), v1 = *reinterpret_cast<const float4 *>(g.W + (size_t)n * K + k8 + 4);
+                eb[st][0] = v0.x, eb[st][1] = v0.y, eb[st][2] = v0.z, eb[st][3] = v0.w, eb[st][4] = v1.x, eb[st][5] = v1.y, eb[st][6] = v1.z, eb[st][7] = v1.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) eb[st][t] = (nok && k8 + t < K) ? g.W[(size_t)n * K + k8 + t] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) eb[st][t] = (nok && k8 + t < K) ? g.W[(size_t)(k8 + t) * N + n] : 0.f;  // (lanes: consecutive n)
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < KSTEPS; ++st) {
+        bf16x8 a[3], b[3];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float av = g.gate ? (eg[st][t] > 0.f ? ea[st][t] : 0.f) : ea[st][t];
+            __bf16 h1, h2, h3;
+            split3(av, h1, h2, h3);
+            a[0][t] = h1, a[1][t] = h2, a[2][t] = h3;
+            split3(eb[st][t], h1, h2, h3);
+            b[0][t] = h1, b[1][t] = h2, b[2][t] = h3;
+        }
+#define SN_SK_TERM(PA, PB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB], acc, 0, 0, 0)
+        SN_SK_TERM(0, 2);
+        SN_SK_TERM(2, 0);
+        SN_SK_TERM(1, 1);
+        SN_SK_TERM(0, 1);
+        SN_SK_TERM(1, 0);
+        SN_SK_TERM(0, 0);
+#undef SN_SK_TERM
+    }
+    // wave w now holds column 8 w + (lane >> 3) of the tile, rows 4 (lane & 7) .. + 3
+    float4 v = wave_reduce_scatter4(acc, red);
+    const int S = g.S;
+    typedef float sk4 __attribute__((ext_vector_type(4)));
+    if (S > 1) {
+        float *P = g.part + ((size_t)s * gridDim.x + tile) * 1024 + (size_t)tid * 4;
+        const sk4 pv = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(P), "v"(pv) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(g.counter + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = t == (unsigned)(S - 1);
+            if (s_last) __hip_atomic_store(g.counter + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // armed for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        sk4 accv = {0.f, 0.f, 0.f, 0.f};
+        for (int q0 = 0; q0 < S; q0 += 8) {  // slices in ascending order, eight loads in flight
+            sk4 r[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int qq = min(q0 + q, S - 1);
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[q]) : "v"(g.part + ((size_t)qq * gridDim.x + tile) * 1024 + (size_t)tid * 4) : "memory");
+            }
+            // (the loaded registers are operands of the wait: register-only uses of them must not be scheduled above it)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q0 + q < S) accv = accv + r[q];
+        }
+        v = make_float4(accv.x, accv.y, accv.z, accv.w);
+    }
+    const int col = n0 + wave * 8 + (lane >> 3), r0 = 4 * (lane & 7);
+    if (col < N) {
+        const float bv = g.bias ? g.bias[col] : 0.f;
+        const float o[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (r0 + i < R) g.out[(size_t)(r0 + i) * N + col] = g.relu ? relu_np(o[i]) : o[i];
+    }
+}
+
+// S (K slices) and k-steps per wave for a (K, N) layer: as many workgroups as it takes to cover the chip, at most 4 k-steps a wave
+static void skinny_plan(int K, int N, int &S, int &ksteps)
+{
+    const int tiles = (N + 31) / 32;
+    const int k64 = (K + 63) / 64;  // 64-wide units: one k-step for each of the four waves
+    ksteps = 1;
+    S = k64;
+    while (S > 1 && tiles * S > 512 && ksteps < 4 && S % 2 == 0) S /= 2, ksteps *= 2;
+    while (S > 1 && tiles * S >= 512 && S % 2 == 0 && ksteps < 4) S /= 2, ksteps *= 2;
+    if (S * ksteps < k64) ksteps = (k64 + S - 1) / S;  // (odd unit counts)
+    if (ksteps == 3) ksteps = 4;
+}
+extern "C" int sn_skinny_linear_supported(int R, int K, int N)
+{
+    if (R < 1 || R > 32 || K < 1 || N < 1) return 0;
+    int S, ks;
+    skinny_plan(K, N, S, ks);
+    return ks <= 4;
+}
+extern "C" long long sn_skinny_linear_scratch_bytes(int R, int K, int N)
+{
+    (void)R;
+    int S, ks;
+    skinny_plan(K, N, S, ks);
+    return (long long)S * ((N + 31) / 32) * 1024 * (long long)sizeof(float);
+}
+// counters: (N + 31) / 32 zeroed 32-bit words (left zeroed).  transposed != 0: W is (K, N) (the data gradient through a layer
+// whose weight is (Co = K, Ci = N)).
+extern "C" int sn_skinny_linear(int R, int K, int N, const float *x, const float *gate, const float *W, int transposed, const float *bias,
+                                int relu, float *out, float *scratch, unsigned *counters, sn_stream_t stream)
+{
+    SN_REQUIRE(x && W && out && scratch && counters, "null pointer");
+    if (!sn_skinny_linear_supported(R, K, N)) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_skinny_linear: needs at most 32 rows");
+    SkinnyArgs g{};
+    g.x = x, g.gate = gate, g.W = W, g.bias = bias, g.out = out, g.part = scratch, g.counter = counters;
+    g.R = R, g.K = K, g.N = N, g.wmode = transposed ? 1 : 0, g.relu = relu;
+    int ks;
+    skinny_plan(K, N, g.S, ks);
+    g.kslice = ks * 64;
+    const dim3 grid((N + 31) / 32, g.S);
+    hipStream_t st = (hipStream_t)stream;
+    if (ks == 1)
+        hipLaunchKernelGGL(skinny_linear_kernel<1>, grid, dim3(256), 0, st, g);
+    else if (ks == 2)
+        hipLaunchKernelGGL(skinny_linear_kernel<2>, grid, dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL(skinny_linear_kernel<4>, grid, dim3(256), 0, st, g);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- data gradient of that last layer when its dZ is SPARSE (BatchNorm-free stack: dZ = dY through the max over the points has one
 // non-zero per cloud and channel -- the pooled element; with a BatchNorm the k2 Z + k3 terms make it dense and the GEMM kernels
 // apply).  dYprev[b, n, :] = relu'_prev . sum over the channels c whose maximum sits at point n of  gsel[b][c] * W[c][:],

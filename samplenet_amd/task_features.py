@@ -27,6 +27,7 @@ def _st(t):
 # Test hooks (the defaults are the product path; False = the route other shapes take anyway)
 FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch (sn_linear_forward_maxpool)
 WIDE_MAXPOOL = True        # ... as the wide kernel (A fragments resident, pre-split weight planes) where the shape allows
+FUSED_TRUNK = True         # frozen FC trunk on <= 32 rows through sn_skinny_linear (forward and data gradient), else torch.nn.Linear
 SPARSE_POOL_DGRAD = True   # last layer's data gradient from the one non-zero per cloud and channel (sn_pool_dgrad_sparse)
 
 _CONST = {}  # (rows, channels, device) -> constant coefficient table, built once (never written afterwards)
@@ -224,11 +225,65 @@ class PointNetFeatures(nn.Module):
         return _FeaturesFunction.apply(x.contiguous().float(), *wb)
 
 
+def _skinny_scratch(nbytes, ntiles, like):
+    """Slice partials + per-tile arrival counters of sn_skinny_linear (the counters start and are left at zero); one pair per
+    device and stream serves every layer (launches on a stream run one after the other); built for the call only while a
+    stream capture is under way (see _unit_rows)."""
+    key = ("skinny", like.device, torch.cuda.current_stream(like.device).cuda_stream)
+    t = _CONST.get(key)
+    if t is None or t[0].numel() * 4 < nbytes or t[1].numel() < ntiles:
+        t = (torch.empty(max(1, nbytes // 4), device=like.device, dtype=torch.float32),
+             torch.zeros(max(64, ntiles), device=like.device, dtype=torch.int32))
+        if not torch.cuda.is_current_stream_capturing():
+            _CONST[key] = t
+    return t
+
+
+def _skinny(x, gate, W, transposed, bias, relu):
+    """out (R, N) = act((x . [gate > 0]) W^T + bias) with W (N, K), or x W with W (K, N) when transposed."""
+    R, K = x.shape
+    N = W.shape[1] if transposed else W.shape[0]
+    out = torch.empty(R, N, device=x.device, dtype=torch.float32)
+    part, counters = _skinny_scratch(lib.sn_skinny_linear_scratch_bytes(R, K, N), (N + 31) // 32, x)
+    check(lib.sn_skinny_linear(R, K, N, ptr(x), ptr(gate), ptr(W), int(transposed), ptr(bias), int(relu), ptr(out), ptr(part),
+                               ptr(counters), _st(x)), "sn_skinny_linear")
+    return out
+
+
+class _TrunkFunction(torch.autograd.Function):
+    """PCRNet's FC trunk with FROZEN weights on at most 32 rows: y -> fc1 .. fc5 (ReLU) -> fc6, six sn_skinny_linear launches forward
+    and six for the data gradient (registration/models/pcrnet.py:56-77 as rocBLAS GEMMs + ReLU / mask kernels: 22 launches)."""
+
+    @staticmethod
+    def forward(ctx, y, *wb):
+        Ws, bs = wb[0::2], wb[1::2]
+        x = y.contiguous().float()
+        acts = []
+        with torch.cuda.device(x.device):
+            for i, (W, b) in enumerate(zip(Ws, bs)):
+                x = _skinny(x, None, W, False, b, i < len(Ws) - 1)
+                acts.append(x)
+        ctx.save_for_backward(*acts[:-1], *Ws)
+        ctx.nl = len(Ws)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        nl = ctx.nl
+        acts, Ws = ctx.saved_tensors[:nl - 1], ctx.saved_tensors[nl - 1:]
+        g = g.contiguous().float()
+        with torch.cuda.device(g.device):
+            for i in range(nl - 1, -1, -1):  # dX = (dY . [y_i > 0]) W_i; the last layer has no ReLU
+                g = _skinny(g, acts[i] if i < nl - 1 else None, Ws[i], True, None, False)
+        return (g,) + (None,) * (2 * nl)
+
+
 class PCRNet(nn.Module):
     """Drop-in for `registration/models/pcrnet.py:44-82` (same constructor, attribute and parameter names -> state_dict
     compatible, same `forward(x0, x1) -> (twist (B,7), pre_normalized_quat (B,4))`): the two feature extractions run on the
-    HIP MLP kernels (`PointNetFeatures` above, the 99 % of the network's arithmetic), the six-layer FC trunk on B rows is
-    plain library GEMMs (torch.nn.Linear -> rocBLAS), the quaternion normalisation is torch."""
+    HIP MLP kernels (`PointNetFeatures` above, the 99 % of the network's arithmetic); the six-layer FC trunk on B rows runs on
+    `sn_skinny_linear` (forward and data gradient) when its weights are frozen and B <= 32 -- the sampler's training step -- and
+    as plain library GEMMs (torch.nn.Linear -> rocBLAS) otherwise; the quaternion normalisation is torch."""
 
     def __init__(self, bottleneck_size=1024, input_shape="bcn"):
         super().__init__()
@@ -245,9 +300,17 @@ class PCRNet(nn.Module):
 
     def forward(self, x0, x1):
         y = torch.cat([self.feat(x0), self.feat(x1)], dim=1)
-        for fc in (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5):
-            y = torch.relu(fc(y))
-        y = self.fc6(y)  # (B, 7)
+        fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
+        frozen = not any(p.requires_grad for fc in fcs for p in fc.parameters())
+        if FUSED_TRUNK and frozen and y.is_cuda and y.shape[0] <= 32:
+            wb = []
+            for fc in fcs:
+                wb += [fc.weight, fc.bias]
+            y = _TrunkFunction.apply(y, *wb)  # (B, 7)
+        else:
+            for fc in fcs[:-1]:
+                y = torch.relu(fc(y))
+            y = self.fc6(y)  # (B, 7)
         pre_normalized_quat = y[:, 0:4]
         normalized_quat = torch.nn.functional.normalize(pre_normalized_quat, dim=1)
         return torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat

@@ -1054,3 +1054,48 @@ def test_task_features_wide_maxpool_is_bit_identical(B, N, bneck, cin):
         assert torch.equal(y1, y2) and not torch.equal(y1, out["wide"])
     finally:
         TF.WIDE_MAXPOOL = old
+
+
+@pytest.mark.parametrize("R", [32, 5])
+def test_skinny_linear_trunk_matches_torch(R):
+    """PCRNet's frozen FC trunk on sn_skinny_linear (2048 -> 1024 -> 1024 -> 512 -> 512 -> 256 -> 7 on <= 32 rows: K-sliced weight stream,
+    slices summed in order by the last workgroup to arrive) against torch.nn.Linear in fp64: output and the gradient to the input
+    features within fp32 GEMM rounding, and bit-identical run to run."""
+    from samplenet_amd import task_features as TF
+
+    torch.manual_seed(R)
+    net = TF.PCRNet(bottleneck_size=1024, input_shape="bnc").cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    y0 = torch.randn(R, 2048, device="cuda").requires_grad_(True)
+    fcs = [net.fc1, net.fc2, net.fc3, net.fc4, net.fc5, net.fc6]
+    wb = []
+    for fc in fcs:
+        wb += [fc.weight, fc.bias]
+    go = torch.randn(R, 7, device="cuda")
+    outs = []
+    for _ in range(2):
+        o = TF._TrunkFunction.apply(y0, *wb)
+        (gy,) = torch.autograd.grad(o, [y0], go)
+        outs.append((o.detach(), gy))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    yr = y0.detach().double().requires_grad_(True)
+    hcur = yr
+    for i, fc in enumerate(fcs):
+        hcur = torch.nn.functional.linear(hcur, fc.weight.double(), fc.bias.double())
+        if i < 5:
+            hcur = torch.relu(hcur)
+    (gr,) = torch.autograd.grad(hcur, [yr], go.double())
+    # torch fp32 for the yardstick
+    h32 = y0.detach().clone().requires_grad_(True)
+    t = h32
+    for i, fc in enumerate(fcs):
+        t = fc(t)
+        if i < 5:
+            t = torch.relu(t)
+    (g32,) = torch.autograd.grad(t, [h32], go)
+    eo, eo32 = float((outs[0][0].double() - hcur).abs().max()), float((t.double() - hcur).abs().max())
+    eg, eg32 = float((outs[0][1].double() - gr).abs().max()), float((g32.double() - gr).abs().max())
+    so, sg = float(hcur.abs().max()), float(gr.abs().max())
+    assert eo <= max(2 * eo32, 2e-6 * so), (eo, eo32, so)
+    assert eg <= max(2 * eg32, 2e-6 * sg), (eg, eg32, sg)
