@@ -128,6 +128,22 @@ int sn_simplification_loss_backward(int B, int n1, const float *xyz1, int n2, co
 /* layout1: 0 = xyz1 / grad_xyz1 are (B,n1,3); 1 = (B,3,n1), the layout the sampler's FC head emits (grad_xyz2 must be NULL) */
 
 /* ---------------------------------------------------------------------------------------------
+ * The registration task's own loss pieces (registration/main.py:557-577, compute_pcrnet_loss), one launch pair each:
+ *   sn_chamfer_mean_loss_*   chamfer_loss = mean(dist1) + mean(dist2) from the Chamfer products of (xyz1, xyz2) (main.py:573-577)
+ *                            and its gradients to either cloud (grad_loss: device scalar; either output may be NULL) -- the
+ *                            simplification loss without the maximum term.  partial: 3 B floats, argmax1: B ints of scratch.
+ *   sn_pcrnet_head_*         twist (B,7) = [normalize(y[:, 0:4]) | y[:, 4:7]] (models/pcrnet.py:78-82, F.normalize eps 1e-12) and
+ *                            qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2 (main.py:565; NULL: not wanted); backward: g_y (B,7) from
+ *                            g_twist (B,7) and the device scalar g_qnorm (either may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+int sn_chamfer_mean_loss_forward(int B, int n1, int n2, const float *dist1, const float *dist2, float *partial, int *argmax1,
+                                 float *loss, sn_stream_t stream);
+int sn_chamfer_mean_loss_backward(int B, int n1, const float *xyz1, int n2, const float *xyz2, const int *idx1, const int *idx2,
+                                  const float *grad_loss, float *grad_xyz1, float *grad_xyz2, sn_stream_t stream);
+int sn_pcrnet_head_forward(int B, const float *y, float *twist, float *qnorm, sn_stream_t stream);
+int sn_pcrnet_head_backward(int B, const float *y, const float *g_twist, const float *g_qnorm, float *g_y, sn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.
  * Replaces knn_cuda.KNN(k)(ref, query) (soft_projection.py:11-14) and knn_point
  * (tf_grouping.py:64-91).  idx (b,m,k) int32; dist (b,m,k) SQUARED distances (may be NULL).

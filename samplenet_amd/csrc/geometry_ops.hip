@@ -868,6 +868,7 @@ __global__ void __launch_bounds__(256) simp_loss_partial_kernel(int n1, int n2, 
     }
 }
 
+template <bool WITH_MAX>
 __global__ void __launch_bounds__(64) simp_loss_final_kernel(int B, int n1, int n2, float w, const float *__restrict__ part,
                                                              float *__restrict__ loss)
 {
@@ -875,7 +876,7 @@ __global__ void __launch_bounds__(64) simp_loss_final_kernel(int B, int n1, int 
     float s1 = 0.f, mx = 0.f, s2 = 0.f;
     for (int b = 0; b < B; ++b) s1 += part[b * 3], mx += part[b * 3 + 1], s2 += part[b * 3 + 2];
     const float c12 = s1 / ((float)B * (float)n1), cmax = mx / (float)B, c21 = s2 / ((float)B * (float)n2);
-    loss[0] = c12 + cmax + w * c21;
+    loss[0] = WITH_MAX ? c12 + cmax + w * c21 : c12 + w * c21;
 }
 
 extern "C" int sn_simplification_loss_forward(int B, int n1, int n2, const float *dist1, const float *dist2, float weight,
@@ -885,7 +886,7 @@ extern "C" int sn_simplification_loss_forward(int B, int n1, int n2, const float
     SN_REQUIRE(dist1 && dist2 && partial && argmax1 && loss, "null pointer");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(simp_loss_partial_kernel, dim3(B), dim3(256), 0, st, n1, n2, dist1, dist2, partial, argmax1);
-    hipLaunchKernelGGL(simp_loss_final_kernel, dim3(1), dim3(64), 0, st, B, n1, n2, weight, partial, loss);
+    hipLaunchKernelGGL(simp_loss_final_kernel<true>, dim3(1), dim3(64), 0, st, B, n1, n2, weight, partial, loss);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -910,6 +911,117 @@ extern "C" int sn_simplification_loss_backward(int B, int n1, const float *xyz1,
         ImplicitGrad ig{grad_loss, nullptr, argmax1, c2, 0.f, c1, cm};
         launch_chamfer_bwd(B, ysplit(n2), n2, n1, xyz2, xyz1, nullptr, idx2, nullptr, idx1, grad_xyz2, 0, ig, st);
     }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The Chamfer loss of the registration task (registration/main.py:573-577): mean(dist1) + mean(dist2) -- the simplification loss
+// without its maximum term; same kernels (partial: 3 B floats, argmax1: B ints of scratch), same implicit-gradient backward.
+extern "C" int sn_chamfer_mean_loss_forward(int B, int n1, int n2, const float *dist1, const float *dist2, float *partial,
+                                            int *argmax1, float *loss, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && n1 >= 1 && n2 >= 1, "bad size");
+    SN_REQUIRE(dist1 && dist2 && partial && argmax1 && loss, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(simp_loss_partial_kernel, dim3(B), dim3(256), 0, st, n1, n2, dist1, dist2, partial, argmax1);
+    hipLaunchKernelGGL(simp_loss_final_kernel<false>, dim3(1), dim3(64), 0, st, B, n1, n2, 1.0f, partial, loss);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_chamfer_mean_loss_backward(int B, int n1, const float *xyz1, int n2, const float *xyz2, const int *idx1,
+                                             const int *idx2, const float *grad_loss, float *grad_xyz1, float *grad_xyz2,
+                                             sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && n1 >= 1 && n2 >= 1, "bad size");
+    SN_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && grad_loss, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (kChamferBwdGroups + B - 1) / B)); };
+    const float c1 = 1.0f / ((float)B * (float)n1), c2 = 1.0f / ((float)B * (float)n2);
+    if (grad_xyz1) {
+        ImplicitGrad ig{grad_loss, nullptr, nullptr, c1, 0.f, c2, 0.f};
+        launch_chamfer_bwd(B, ysplit(n1), n1, n2, xyz1, xyz2, nullptr, idx1, nullptr, idx2, grad_xyz1, 1, ig, st);
+    }
+    if (grad_xyz2) {
+        ImplicitGrad ig{grad_loss, nullptr, nullptr, c2, 0.f, c1, 0.f};
+        launch_chamfer_bwd(B, ysplit(n2), n2, n1, xyz2, xyz1, nullptr, idx2, nullptr, idx1, grad_xyz2, 0, ig, st);
+    }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCRNet's output head (registration/models/pcrnet.py:78-82 + the QuaterNet regulariser of registration/main.py:565):
+//   twist (B,7) = [ y[:, 0:4] / max(||y[:, 0:4]||, 1e-12) | y[:, 4:7] ],   qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2
+// one single-workgroup launch forward, one backward (torch: slice, norm, clamp, expand, div, cat + pow, sum, sub, pow, mean and
+// their ~15 backward launches).  Sums over the batch run in a fixed order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pcrnet_head_fwd_kernel(int B, const float *__restrict__ y, float *__restrict__ twist,
+                                                              float *__restrict__ qnorm)
+{
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float *r = y + (size_t)b * 7;
+        const float n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+        const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        float *o = twist + (size_t)b * 7;
+        o[0] = r[0] * inv, o[1] = r[1] * inv, o[2] = r[2] * inv, o[3] = r[3] * inv, o[4] = r[4], o[5] = r[5], o[6] = r[6];
+        acc += (n2 - 1.0f) * (n2 - 1.0f);
+    }
+    if (!qnorm) return;
+    red[threadIdx.x] = acc;
+    for (int s = 128; s > 0; s >>= 1) {
+        __syncthreads();
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    }
+    if (threadIdx.x == 0) qnorm[0] = red[0] / (float)B;
+}
+
+__global__ void __launch_bounds__(256) pcrnet_head_bwd_kernel(int B, const float *__restrict__ y, const float *__restrict__ g_twist,
+                                                              const float *__restrict__ g_qnorm, float *__restrict__ g_y)
+{
+    const float gq = g_qnorm ? g_qnorm[0] : 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float *r = y + (size_t)b * 7;
+        const float n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+        const float nrm = sqrtf(n2);
+        float *o = g_y + (size_t)b * 7;
+        float gp[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g_twist) {
+            const float *gt = g_twist + (size_t)b * 7;
+            if (nrm > 1e-12f) {  // d(p / ||p||) = (g - q (q . g)) / ||p||
+                const float inv = 1.0f / nrm;
+                const float q[4] = {r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv};
+                const float dot = q[0] * gt[0] + q[1] * gt[1] + q[2] * gt[2] + q[3] * gt[3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gp[i] = (gt[i] - q[i] * dot) * inv;
+            } else {  // clamped denominator: p / 1e-12
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gp[i] = gt[i] * 1e12f;
+            }
+            o[4] = gt[4], o[5] = gt[5], o[6] = gt[6];
+        } else {
+            o[4] = 0.f, o[5] = 0.f, o[6] = 0.f;
+        }
+        const float cq = gq * 4.0f * (n2 - 1.0f) / (float)B;  // d/dp mean (||p||^2 - 1)^2 = 4 (||p||^2 - 1) p / B
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = gp[i] + cq * r[i];
+    }
+}
+
+extern "C" int sn_pcrnet_head_forward(int B, const float *y, float *twist, float *qnorm, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && y && twist, "bad argument");
+    hipLaunchKernelGGL(pcrnet_head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, y, twist, qnorm);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_pcrnet_head_backward(int B, const float *y, const float *g_twist, const float *g_qnorm, float *g_y, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && y && g_y, "bad argument");
+    hipLaunchKernelGGL(pcrnet_head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, y, g_twist, g_qnorm, g_y);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -86,6 +86,44 @@ class ChamferDistanceFunction(torch.autograd.Function):
                                      ctx.needs_input_grad[1])
 
 
+class ChamferMeanLossFunction(torch.autograd.Function):
+    """mean(dist1) + mean(dist2) of (xyz1, xyz2) as ONE differentiable scalar -- the Chamfer term of the registration task loss
+    (registration/main.py:573-577): scan, fused reduction, and a backward with implicit upstream gradients (no per-point
+    gradient tensors, no mean / add / expand / div launches)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1, xyz2, dist1, idx1, dist2, idx2 = chamfer_forward_impl(xyz1, xyz2)
+        B, n1 = dist1.shape
+        n2 = dist2.shape[1]
+        dev = dist1.device
+        partial = torch.empty(B * 3, device=dev, dtype=torch.float32)
+        argmax1 = torch.empty(B, device=dev, dtype=torch.int32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            check(lib.sn_chamfer_mean_loss_forward(B, n1, n2, ptr(dist1), ptr(dist2), ptr(partial), ptr(argmax1), ptr(loss),
+                                                   _stream(dist1)), "sn_chamfer_mean_loss_forward")
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        B, n1, _ = xyz1.shape
+        n2 = xyz2.shape[1]
+        g1 = torch.empty_like(xyz1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(xyz2) if ctx.needs_input_grad[1] else None
+        gl = grad_loss.contiguous().float()
+        with torch.cuda.device(xyz1.device):
+            check(lib.sn_chamfer_mean_loss_backward(B, n1, ptr(xyz1), n2, ptr(xyz2), ptr(idx1), ptr(idx2), ptr(gl), ptr(g1), ptr(g2),
+                                                    _stream(xyz1)), "sn_chamfer_mean_loss_backward")
+        return g1, g2
+
+
+def chamfer_mean_loss(xyz1, xyz2):
+    return ChamferMeanLossFunction.apply(xyz1, xyz2)
+
+
 def chamfer_distance(xyz1, xyz2, return_idx=False):
     d1, d2, i1, i2 = ChamferDistanceFunction.apply(xyz1, xyz2)
     return (d1, d2, i1, i2) if return_idx else (d1, d2)

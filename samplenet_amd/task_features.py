@@ -27,6 +27,7 @@ def _st(t):
 # Test hooks (the defaults are the product path; False = the route other shapes take anyway)
 FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch (sn_linear_forward_maxpool)
 WIDE_MAXPOOL = True        # ... as the wide kernel (A fragments resident, pre-split weight planes) where the shape allows
+FUSED_HEAD = True          # quaternion normalisation + regulariser as one launch (sn_pcrnet_head_*), else the torch op chain
 FUSED_TRUNK = True         # frozen FC trunk on <= 32 rows through sn_skinny_linear (forward and data gradient), else torch.nn.Linear
 SPARSE_POOL_DGRAD = True   # last layer's data gradient from the one non-zero per cloud and channel (sn_pool_dgrad_sparse)
 
@@ -278,6 +279,31 @@ class _TrunkFunction(torch.autograd.Function):
         return (g,) + (None,) * (2 * nl)
 
 
+class _HeadFunction(torch.autograd.Function):
+    """y (B,7) -> twist (B,7) = [normalize(y[:, 0:4]) | y[:, 4:7]], qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2 -- sn_pcrnet_head_*."""
+
+    @staticmethod
+    def forward(ctx, y):
+        y = y.contiguous().float()
+        B = y.shape[0]
+        twist = torch.empty_like(y)
+        qnorm = torch.empty((), device=y.device, dtype=torch.float32)
+        with torch.cuda.device(y.device):
+            check(lib.sn_pcrnet_head_forward(B, ptr(y), ptr(twist), ptr(qnorm), _st(y)), "sn_pcrnet_head_forward")
+        ctx.save_for_backward(y)
+        return twist, qnorm
+
+    @staticmethod
+    def backward(ctx, g_twist, g_qnorm):
+        (y,) = ctx.saved_tensors
+        gy = torch.empty_like(y)
+        gt = g_twist.contiguous().float() if g_twist is not None else None
+        gq = g_qnorm.contiguous().float() if g_qnorm is not None else None
+        with torch.cuda.device(y.device):
+            check(lib.sn_pcrnet_head_backward(y.shape[0], ptr(y), ptr(gt), ptr(gq), ptr(gy), _st(y)), "sn_pcrnet_head_backward")
+        return gy
+
+
 class PCRNet(nn.Module):
     """Drop-in for `registration/models/pcrnet.py:44-82` (same constructor, attribute and parameter names -> state_dict
     compatible, same `forward(x0, x1) -> (twist (B,7), pre_normalized_quat (B,4))`): the two feature extractions run on the
@@ -299,6 +325,12 @@ class PCRNet(nn.Module):
         self.fc6 = nn.Linear(256, 7)
 
     def forward(self, x0, x1):
+        twist, pre_normalized_quat, _ = self.forward_with_qnorm(x0, x1)
+        return twist, pre_normalized_quat
+
+    def forward_with_qnorm(self, x0, x1):
+        """forward() plus the QuaterNet regulariser mean((||pre_normalized_quat||^2 - 1)^2) of registration/main.py:565, which
+        the output head's kernel computes on the side."""
         y = torch.cat([self.feat(x0), self.feat(x1)], dim=1)
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
         frozen = not any(p.requires_grad for fc in fcs for p in fc.parameters())
@@ -312,8 +344,12 @@ class PCRNet(nn.Module):
                 y = torch.relu(fc(y))
             y = self.fc6(y)  # (B, 7)
         pre_normalized_quat = y[:, 0:4]
+        if FUSED_HEAD and y.is_cuda:
+            twist, qnorm = _HeadFunction.apply(y)
+            return twist, pre_normalized_quat, qnorm
         normalized_quat = torch.nn.functional.normalize(pre_normalized_quat, dim=1)
-        return torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat
+        qnorm = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
+        return torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat, qnorm
 
 
 def qrot(q, v):
@@ -365,10 +401,13 @@ def pcrnet_chamfer_loss(model, p0, p1):
     qdataset.py:97-119: rotation only); loss = mean d(p1 -> p1_est) + mean d(p1_est -> p1) on the HIP Chamfer kernels.
     p0 template / p1 source, (B,N,3).  Returns (chamfer_loss, qnorm_loss, twist).  The rotation-matrix error terms of
     `--loss-type 0` go through kornia in the reference (not installed here) and stay with the caller."""
-    from .chamfer_distance import ChamferDistance
+    from .ops import chamfer_mean_loss
 
-    twist, pre_normalized_quat = model(p0, p1)
-    qnorm_loss = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
+    if hasattr(model, "forward_with_qnorm"):
+        twist, _pre, qnorm_loss = model.forward_with_qnorm(p0, p1)
+    else:
+        twist, pre_normalized_quat = model(p0, p1)
+        qnorm_loss = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
     p1_est = qrot_cloud(twist[:, 0:4], p0)  # = qrot(twist[:, 0:4] expanded over the points, p0)
-    c01, c10 = ChamferDistance()(p1.contiguous(), p1_est.contiguous())
-    return torch.mean(c01) + torch.mean(c10), qnorm_loss, twist
+    # mean(d(p1 -> p1_est)) + mean(d(p1_est -> p1)): scan + one fused reduction, implicit-gradient backward
+    return chamfer_mean_loss(p1.contiguous(), p1_est.contiguous()), qnorm_loss, twist

@@ -1099,3 +1099,38 @@ def test_skinny_linear_trunk_matches_torch(R):
     so, sg = float(hcur.abs().max()), float(gr.abs().max())
     assert eo <= max(2 * eo32, 2e-6 * so), (eo, eo32, so)
     assert eg <= max(2 * eg32, 2e-6 * sg), (eg, eg32, sg)
+
+
+def test_pcrnet_head_and_chamfer_mean_loss_match_the_op_chain():
+    """The registration task's loss pieces as fused launches against the torch op chain of registration/main.py:557-577 and
+    models/pcrnet.py:78-82: twist = [normalize(y[:, :4]) | y[:, 4:]], qnorm = mean((||y[:, :4]||^2 - 1)^2) with gradients to y from
+    both outputs; chamfer_mean_loss = mean(d1) + mean(d2) with gradients to both clouds (equal to the unfused Chamfer path, whose
+    kernels it shares, up to the rounding of the mean's scaling)."""
+    from samplenet_amd import task_features as TF
+    from samplenet_amd.chamfer_distance import ChamferDistance
+    from samplenet_amd.ops import chamfer_mean_loss
+
+    torch.manual_seed(3)
+    B = 32
+    y = torch.randn(B, 7, device="cuda").requires_grad_(True)
+    wt, wq = torch.randn(B, 7, device="cuda"), 0.7
+    twist, qn = TF._HeadFunction.apply(y)
+    (gy,) = torch.autograd.grad((twist * wt).sum() + wq * qn, [y])
+    yr = y.detach().double().requires_grad_(True)
+    pre = yr[:, 0:4]
+    tr = torch.cat([torch.nn.functional.normalize(pre, dim=1), yr[:, 4:]], dim=1)
+    qr = torch.mean((torch.sum(pre ** 2, dim=1) - 1) ** 2)
+    (gr,) = torch.autograd.grad((tr * wt.double()).sum() + wq * qr, [yr])
+    assert float((twist.double() - tr).abs().max()) <= 2e-7
+    assert abs(float(qn) - float(qr)) <= 2e-6 * max(1.0, abs(float(qr)))
+    assert float((gy.double() - gr).abs().max()) <= 5e-6 * max(1.0, float(gr.abs().max()))
+
+    a = (torch.rand(B, 64, 3, device="cuda") - 0.5).requires_grad_(True)
+    b = (torch.rand(B, 1024, 3, device="cuda") - 0.5).requires_grad_(True)
+    loss = chamfer_mean_loss(a, b)
+    ga, gb = torch.autograd.grad(loss, [a, b])
+    d1, d2 = ChamferDistance()(a, b)
+    ref = torch.mean(d1) + torch.mean(d2)
+    ra, rb = torch.autograd.grad(ref, [a, b])
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
+    assert float((ga - ra).abs().max()) <= 1e-6 * float(ra.abs().max()) and float((gb - rb).abs().max()) <= 1e-6 * float(rb.abs().max())
