@@ -257,6 +257,16 @@ int sn_pool_dgrad_sparse_supported(int B, int npts, int Ci, int Co);
 int sn_pool_dgrad_sparse(int B, int npts, int Ci, int Co, const float *g, const float *pooled, const int *argsel, const float *W,
                          const float *zprev, const float *coef_prev, float *dyprev, sn_stream_t stream);
 
+/*   sn_pointnet_narrow_forward  the extractor's narrow front 3 -> 64 -> 64 -> 64 -> 128 (ReLU between, no BatchNorm: conv1..conv4 of
+ *                               registration/models/pcrnet.py:23-38) in one launch: a wave takes 32 rows through all four layers;
+ *                               every layer's pre-activations bit-identical to the layer-by-layer launches.  z1..z3 (R,64): all
+ *                               three (a backward will read them) or none; z4 (R,128).  wplanes: 3 * 16384 bf16 for the split
+ *                               weights (planes_ready != 0: already holds the split of these weights). */
+int sn_pointnet_narrow_forward_supported(int R, int c1, int c2, int c3, int c4);
+int sn_pointnet_narrow_forward(int R, const float *x, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                               const float *b3, const float *W4, const float *b4, void *wplanes, int planes_ready, float *z1, float *z2,
+                               float *z3, float *z4, sn_stream_t stream);
+
 /* Linear layers on at most 32 rows (PCRNet's trunk, registration/models/pcrnet.py:56-77): out (R, N) = act((x . [gate > 0]) (R, K) .
  * W^T + bias), the weight stream cut into (32-column tile) x (K slice) workgroups, slices summed in order by the last workgroup to
  * arrive (deterministic); fp32 products as split-bf16 MFMAs.

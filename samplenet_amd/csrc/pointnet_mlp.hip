@@ -4798,6 +4798,257 @@ extern "C" int sn_linear_forward_maxpool_wide(int R, int Ci, int Co, int npts, c
     return 0;
 }
 
+// ---- the narrow front of a BatchNorm-free extractor in ONE launch: 3 -> 64 -> 64 -> 64 -> 128 with ReLU between (PCRNet's
+// PointNetFeatures conv1..conv4, registration/models/pcrnet.py:23-38).  Without a BatchNorm a row's layers depend on nothing but
+// the row: a wave takes 32 rows from the three coordinates to the 128 pre-activations of conv4 -- conv1 on the VALU straight into
+// the A fragments of conv2 (conv_in3_fwd_kernel's expression), conv2..conv4 as split-bf16 MFMAs against weight planes staged
+// once per workgroup in LDS (110 KB), each layer's 32 x 64 output tile turned from the accumulator layout (lane = column) into the
+// next layer's fragment layout (lane = row) through a wave-private LDS tile, activated and split on the way.  Same products in
+// the same order as conv_in3_fwd_kernel / linear_fwd_kernel's gemm_tile_bx3: every layer's pre-activations are bit-identical to
+// the layer-by-layer launches.  z1..z3 are written only when a backward will read them (NULL otherwise): the frozen template
+// branch reads 12 bytes per point and writes conv4's 512.  (4 launches of 5-10 us each before.)
+constexpr int kNarrowRows = 128;
+struct NarrowArgs {
+    const float *x, *W1, *b1, *b2, *b3, *b4;
+    const __bf16 *P2, *P3, *P4;  // [3][64][64], [3][64][64], [3][128][64]
+    float *z1, *z2, *z3, *z4;
+    int R;
+};
+struct SplitJob3 {
+    const float *w[3];
+    __bf16 *dst[3];
+    int n[3];
+};
+__global__ void __launch_bounds__(256) split_planes3_kernel(SplitJob3 job)
+{
+    const int l = blockIdx.y, n = job.n[l];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    __bf16 h1, h2, h3;
+    split3(job.w[l][i], h1, h2, h3);
+    job.dst[l][i] = h1, job.dst[l][(size_t)n + i] = h2, job.dst[l][2 * (size_t)n + i] = h3;
+}
+template <bool STORE>
+__global__ void __launch_bounds__(256) pointnet_narrow_fwd_kernel(NarrowArgs g)
+{
+    constexpr int PW = 72;   // plane row pitch (bf16): K = 64 + 8 -- a b128 lane group's 16 rows tile all 64 banks
+    constexpr int PT = 68;   // transpose tile pitch (floats)
+    constexpr int N2 = 3 * 64 * PW, N4 = 3 * 128 * PW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16 *S2 = reinterpret_cast<__bf16 *>(lds), *S3 = S2 + N2, *S4 = S3 + N2;
+    float *W1s = reinterpret_cast<float *>(S4 + N4);  // [64][4] = (w0, w1, w2, b)
+    float *Tall = W1s + 64 * 4;                       // [4 waves][32][PT]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *T = Tall + wave * (32 * PT);
+    SN_TL(0);
+    // stage the planes (straight 16-byte copies: global [3][Co][64] -> LDS [3][Co][PW]) and conv1's weights
+    {
+        // (all 24 loads of a thread in flight before the first LDS store: one memory round trip, not one per item)
+        bf16x8 r2[6], r3[6], r4[12];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int f = tid + q * 256;
+            r2[q] = *reinterpret_cast<const bf16x8 *>(g.P2 + (size_t)f * 8), r3[q] = *reinterpret_cast<const bf16x8 *>(g.P3 + (size_t)f * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) r4[q] = *reinterpret_cast<const bf16x8 *>(g.P4 + (size_t)(tid + q * 256) * 8);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int f = tid + q * 256, row = f >> 3, k8 = (f & 7) * 8;  // row = plane * Co + column; global rows are 64 wide
+            *reinterpret_cast<bf16x8 *>(S2 + row * PW + k8) = r2[q];
+            *reinterpret_cast<bf16x8 *>(S3 + row * PW + k8) = r3[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int f = tid + q * 256, row = f >> 3, k8 = (f & 7) * 8;
+            *reinterpret_cast<bf16x8 *>(S4 + row * PW + k8) = r4[q];
+        }
+        if (tid < 64) {
+            W1s[tid * 4 + 0] = g.W1[tid * 3 + 0], W1s[tid * 4 + 1] = g.W1[tid * 3 + 1], W1s[tid * 4 + 2] = g.W1[tid * 3 + 2];
+            W1s[tid * 4 + 3] = g.b1 ? g.b1[tid] : 0.f;
+        }
+    }
+    const int row0 = blockIdx.x * kNarrowRows + wave * 32;
+    const int rrow = min(row0 + l31, g.R - 1);
+    const float x0 = g.x[(size_t)rrow * 3], x1 = g.x[(size_t)rrow * 3 + 1], x2 = g.x[(size_t)rrow * 3 + 2];
+    __syncthreads();
+    SN_TL(1);
+    const bool rok = row0 + l31 < g.R;
+    // conv1 straight into conv2's A fragments: lane -> row l31, channels 16 kk + 8 h + t
+    bf16x8 a[3][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        float e[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma clang fp contract(off)
+            const float4 w = *reinterpret_cast<const float4 *>(W1s + (kk * 16 + 8 * h + t) * 4);
+            e[t] = fmaf(w.z, x2, fmaf(w.y, x1, w.x * x0)) + w.w;  // (conv_in3_fwd_kernel's expression, bit for bit)
+        }
+        if (STORE && rok) {
+            float *zp = g.z1 + (size_t)(row0 + l31) * 64 + kk * 16 + 8 * h;
+            *reinterpret_cast<float4 *>(zp) = make_float4(e[0], e[1], e[2], e[3]);
+            *reinterpret_cast<float4 *>(zp + 4) = make_float4(e[4], e[5], e[6], e[7]);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            __bf16 h1, h2, h3;
+            split3(relu_np(e[t]), h1, h2, h3);
+            a[0][kk][t] = h1, a[1][kk][t] = h2, a[2][kk][t] = h3;
+        }
+    }
+    // one 64-wide layer: acc (two 32-column tiles) from the fragments a[][] and the planes S; bias; optional store; through T into
+    // the next layer's fragments
+    const auto layer64 = [&](const __bf16 *S, const float *bias, float *zout) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        // (all of the layer's B fragments requested before its first MFMA: 24 LDS reads in flight instead of six at a time in
+        // front of every k-step -- one wave per SIMD, nothing else hides an LDS read)
+        bf16x8 b[4][3][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[kk][p][j] = *reinterpret_cast<const bf16x8 *>(S + (p * 64 + j * 32 + l31) * PW + kk * 16 + 8 * h);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#define SN_NR_TERM(PA, PB) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][kk], b[kk][PB][j], acc[j], 0, 0, 0)
+            SN_NR_TERM(0, 2);
+            SN_NR_TERM(2, 0);
+            SN_NR_TERM(1, 1);
+            SN_NR_TERM(0, 1);
+            SN_NR_TERM(1, 0);
+            SN_NR_TERM(0, 0);
+#undef SN_NR_TERM
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = j * 32 + l31;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = frag_row(e, lane);
+                T[r * PT + n] = acc[j][e] + bv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(T + l31 * PT + kk * 16 + 8 * h), v1 = *reinterpret_cast<const float4 *>(T + l31 * PT + kk * 16 + 8 * h + 4);
+            if (STORE && rok) {  // (16-byte stores from the row layout: dword stores from the accumulator layout are issue-bound)
+                float *zp = zout + (size_t)(row0 + l31) * 64 + kk * 16 + 8 * h;
+                *reinterpret_cast<float4 *>(zp) = v0, *reinterpret_cast<float4 *>(zp + 4) = v1;
+            }
+            const float e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                __bf16 h1, h2, h3;
+                split3(relu_np(e[t]), h1, h2, h3);
+                a[0][kk][t] = h1, a[1][kk][t] = h2, a[2][kk][t] = h3;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    SN_TL(2);
+    layer64(S2, g.b2, g.z2);
+    SN_TL(3);
+    layer64(S3, g.b3, g.z3);
+    SN_TL(4);
+    // conv4: 128 columns, straight to memory in the accumulator layout (a lane's column, two rows per instruction: 128-byte runs)
+    {
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        bf16x8 b[2][3][4];  // one k-step ahead
+        const auto load_b4 = [&](int kk, bf16x8 (&bb)[3][4]) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bb[p][j] = *reinterpret_cast<const bf16x8 *>(S4 + (p * 128 + j * 32 + l31) * PW + kk * 16 + 8 * h);
+        };
+        load_b4(0, b[0]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) load_b4(kk + 1, b[(kk + 1) & 1]);
+#define SN_NR_TERM(PA, PB) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][kk], b[kk & 1][PB][j], acc[j], 0, 0, 0)
+            SN_NR_TERM(0, 2);
+            SN_NR_TERM(2, 0);
+            SN_NR_TERM(1, 1);
+            SN_NR_TERM(0, 1);
+            SN_NR_TERM(1, 0);
+            SN_NR_TERM(0, 0);
+#undef SN_NR_TERM
+        }
+        SN_TL(5);
+        // through the wave's tile in two 64-column halves, out as 16-byte stores (4 rows x 256 bytes per instruction): 64 dword
+        // stores per lane from the accumulator layout took 8 of the kernel's 17 us (store-issue-bound)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = hf * 2 + jj, n = j * 32 + l31;
+                const float bv = g.b4 ? g.b4[n] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) T[frag_row(e, lane) * PT + jj * 32 + l31] = acc[j][e] + bv;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = (lane >> 4) + 4 * i, c4 = (lane & 15) * 4;
+                const float4 v = *reinterpret_cast<const float4 *>(T + r * PT + c4);
+                if (row0 + r < g.R) *reinterpret_cast<float4 *>(g.z4 + (size_t)(row0 + r) * 128 + hf * 64 + c4) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    SN_TL(6);
+}
+
+extern "C" int sn_pointnet_narrow_forward_supported(int R, int c1, int c2, int c3, int c4)
+{
+    // (whole 64-row tiles: the layer-by-layer route runs ragged tiles on the fp32 MFMA, and the two routes are to stay bit-identical)
+    return R >= 64 && R % 64 == 0 && c1 == 64 && c2 == 64 && c3 == 64 && c4 == 128;
+}
+// The narrow front 3 -> 64 -> 64 -> 64 -> 128 (weights (64,3), (64,64), (64,64), (128,64), biases optional).  wplanes: 3 * (64*64 + 64*64 +
+// 128*64) bf16 of scratch for the split weights; planes_ready != 0: it already holds the split of THESE weights.  z1..z3 (R,64):
+// all three or none (NULL: not written); z4 (R,128).
+extern "C" int sn_pointnet_narrow_forward(int R, const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                                          const float *W3, const float *b3, const float *W4, const float *b4, void *wplanes,
+                                          int planes_ready, float *z1, float *z2, float *z3, float *z4, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && x && W1 && W2 && W3 && W4 && wplanes && z4, "bad argument");
+    SN_REQUIRE((z1 && z2 && z3) || (!z1 && !z2 && !z3), "z1..z3: all three or none");
+    hipStream_t st = (hipStream_t)stream;
+    __bf16 *P2 = (__bf16 *)wplanes, *P3 = P2 + 3 * 64 * 64, *P4 = P3 + 3 * 64 * 64;
+    if (!planes_ready) {
+        SplitJob3 job{{W2, W3, W4}, {P2, P3, P4}, {64 * 64, 64 * 64, 128 * 64}};
+        hipLaunchKernelGGL(split_planes3_kernel, dim3(128 * 64 / 256, 3), dim3(256), 0, st, job);
+    }
+    NarrowArgs g{x, W1, b1, b2, b3, b4, P2, P3, P4, z1, z2, z3, z4, R};
+    const size_t lds = (size_t)(2 * 3 * 64 * 72 + 3 * 128 * 72) * 2 + 64 * 4 * 4 + 4 * 32 * 68 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)pointnet_narrow_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)pointnet_narrow_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pointnet_narrow_forward: cannot reserve LDS");
+        attr = true;
+    }
+    const dim3 grid((R + kNarrowRows - 1) / kNarrowRows);
+    if (z1)
+        hipLaunchKernelGGL(pointnet_narrow_fwd_kernel<true>, grid, dim3(256), lds, st, g);
+    else
+        hipLaunchKernelGGL(pointnet_narrow_fwd_kernel<false>, grid, dim3(256), lds, st, g);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- Linear layers on at most 32 rows (PCRNet's trunk, registration/models/pcrnet.py:56-77: 2048 -> 1024 -> 1024 -> 512 -> 512 ->
 // 256 -> 7 on the batch's 32 feature vectors; forward and data gradient).  15.5 MB of weights against 1 MFLOP per row: the layer is
 // a weight STREAM, and a CU pulls only ~25 GB/s from memory -- so the product is cut into (32-column tile) x (K slice) workgroups

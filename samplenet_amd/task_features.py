@@ -26,6 +26,7 @@ def _st(t):
 
 # Test hooks (the defaults are the product path; False = the route other shapes take anyway)
 FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch (sn_linear_forward_maxpool)
+FUSE_NARROW = True         # conv1..conv4 (3 -> 64 -> 64 -> 64 -> 128) as one launch (sn_pointnet_narrow_forward)
 WIDE_MAXPOOL = True        # ... as the wide kernel (A fragments resident, pre-split weight planes) where the shape allows
 FUSED_HEAD = True          # quaternion normalisation + regulariser as one launch (sn_pcrnet_head_*), else the torch op chain
 FUSED_TRUNK = True         # frozen FC trunk on <= 32 rows through sn_skinny_linear (forward and data gradient), else torch.nn.Linear
@@ -49,27 +50,31 @@ def _unit_rows(rows, c, like):
     return t
 
 
-_PLANES = {}  # id(weight parameter) -> (weak reference to it, its version, its three bf16 planes)
+_PLANES = {}  # ids of the weight parameters -> (weak references to them, their versions, their bf16 planes)
 
 
-def _weight_planes(W):
-    """Scratch for the split of W into three bf16 planes (sn_linear_forward_maxpool_wide) and whether it already holds the split
-    of this very W: eager calls reuse it while the parameter object is the same and its version counter stands still (the two
-    clouds of a registration step, every step of a frozen task network); under a stream capture the split is always recorded
-    -- a replay must see weights that were updated in place since."""
-    base = W._base if W._base is not None else W
-    hit = _PLANES.get(id(base))
+def _weight_planes(*Ws):
+    """Scratch for the split of the weights Ws into three bf16 planes each (sn_linear_forward_maxpool_wide, sn_pointnet_narrow_forward)
+    and whether it already holds the split of these very weights: eager calls reuse it while the parameter objects are the same
+    and their version counters stand still (the two clouds of a registration step, every step of a frozen task network); under
+    a stream capture the split is always recorded -- a replay must see weights that were updated in place since."""
+    bases = [W._base if W._base is not None else W for W in Ws]
+    key = tuple(id(b) for b in bases)
+    vers = tuple(b._version for b in bases)
+    numel = 3 * sum(W.numel() for W in Ws)
+    hit = _PLANES.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
-    if hit is not None and hit[0]() is base and hit[2].numel() == 3 * W.numel() and hit[2].device == W.device:
-        ready = hit[1] == base._version and not capturing
+    if (hit is not None and all(r() is b for r, b in zip(hit[0], bases)) and hit[2].numel() == numel
+            and hit[2].device == Ws[0].device):
+        ready = hit[1] == vers and not capturing
         if not capturing:
-            _PLANES[id(base)] = (hit[0], base._version, hit[2])
+            _PLANES[key] = (hit[0], vers, hit[2])
         return hit[2], ready
-    planes = torch.empty(3 * W.numel(), device=W.device, dtype=torch.bfloat16)
+    planes = torch.empty(numel, device=Ws[0].device, dtype=torch.bfloat16)
     if not capturing:
-        for k in [k for k, v in _PLANES.items() if v[0]() is None]:
+        for k in [k for k, v in _PLANES.items() if any(r() is None for r in v[0])]:
             del _PLANES[k]
-        _PLANES[id(base)] = (weakref.ref(base), base._version, planes)
+        _PLANES[key] = (tuple(weakref.ref(b) for b in bases), vers, planes)
     return planes, False
 
 
@@ -100,7 +105,22 @@ class _FeaturesFunction(torch.autograd.Function):
             argsel = torch.empty(B, C, device=dev, dtype=torch.int32)
             zsel = torch.empty(B, C, device=dev, dtype=torch.float32)
             nl = len(Ws)
+            first = 0
+            if (FUSE_NARROW and nl == 5 and Ws[0].shape[1] == 3 and all(W.shape[1] == Wp.shape[0] for Wp, W in zip(Ws[:3], Ws[1:4]))
+                    and lib.sn_pointnet_narrow_forward_supported(R, *[W.shape[0] for W in Ws[:4]])):
+                # conv1..conv4 in one launch; their pre-activations are kept only where a backward will read them
+                planes, ready = _weight_planes(Ws[1], Ws[2], Ws[3])
+                z123 = [torch.empty(R, 64, device=dev, dtype=torch.float32) if need_grad else None for _ in range(3)]
+                z4 = torch.empty(R, 128, device=dev, dtype=torch.float32)
+                check(lib.sn_pointnet_narrow_forward(R, ptr(a_in), ptr(Ws[0]), ptr(bs[0]), ptr(Ws[1]), ptr(bs[1]), ptr(Ws[2]),
+                                                     ptr(bs[2]), ptr(Ws[3]), ptr(bs[3]), ptr(planes), int(ready), ptr(z123[0]),
+                                                     ptr(z123[1]), ptr(z123[2]), ptr(z4), st), "sn_pointnet_narrow_forward")
+                zs = z123 + [z4]
+                idents = [_ident(W.shape[0], z4) for W in Ws[:4]]
+                a_in, coef_prev, first = z4, idents[-1], 4
             for li, (W, b) in enumerate(zip(Ws, bs)):
+                if li < first:
+                    continue
                 Co, Ci = W.shape[0], W.shape[1]
                 if li == nl - 1 and li > 0 and FUSE_MAXPOOL and lib.sn_linear_forward_maxpool_supported(R, Ci, Co, N):
                     # last layer + max over the points in one GEMM: its activations are written only when a backward will
@@ -136,8 +156,7 @@ class _FeaturesFunction(torch.autograd.Function):
                 check(lib.sn_pool_forward(B, N, C, ptr(zs[-1]), ptr(idents[-1]), ptr(pooled), ptr(argsel), ptr(zsel), st),
                       "sn_pool_forward")
         ctx.zlast_missing = zs[-1] is None
-        if zs[-1] is None:
-            zs[-1] = pooled  # (placeholder in the saved list: never read -- no backward follows a no-gradient forward)
+        zs = [pooled if z is None else z for z in zs]  # (placeholders in the saved list: never read -- see keep_z / need_grad)
         ctx.save_for_backward(x_bnc, pooled, argsel, zsel, *zs, *idents, *Ws)
         ctx.nl = len(Ws)
         return pooled

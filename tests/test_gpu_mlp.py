@@ -1134,3 +1134,36 @@ def test_pcrnet_head_and_chamfer_mean_loss_match_the_op_chain():
     ra, rb = torch.autograd.grad(ref, [a, b])
     assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref))
     assert float((ga - ra).abs().max()) <= 1e-6 * float(ra.abs().max()) and float((gb - rb).abs().max()) <= 1e-6 * float(rb.abs().max())
+
+
+@pytest.mark.parametrize("B,N,grad", [(32, 1024, False), (32, 64, True), (3, 64, True), (5, 192, True), (3, 50, True), (2, 1024, True)])
+def test_task_features_narrow_front_is_bit_identical(B, N, grad):
+    """conv1..conv4 of PointNetFeatures as one launch (sn_pointnet_narrow_forward: a wave takes 32 rows through 3 -> 64 -> 64 -> 64 -> 128,
+    activations stay in registers / LDS) against the four layer launches: same products in the same order, so the pooled features
+    and -- through identical saved pre-activations -- every gradient are EQUAL (row counts that are not whole 64-row tiles keep the
+    layer-by-layer route)."""
+    from samplenet_amd import task_features as TF
+
+    assert bool(TF.lib.sn_pointnet_narrow_forward_supported(B * N, 64, 64, 64, 128)) == ((B * N) % 64 == 0)
+    torch.manual_seed(B * 13 + N)
+    feat = TF.PointNetFeatures(bottleneck_size=1024, input_shape="bnc").cuda()
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5).requires_grad_(grad)
+    go = torch.randn(B, 1024, device="cuda")
+    old = TF.FUSE_NARROW
+    res = {}
+    try:
+        for flag in (True, False):
+            TF.FUSE_NARROW = flag
+            if not grad:
+                for p in feat.parameters():
+                    p.requires_grad_(False)
+                with torch.no_grad():
+                    res[flag] = (feat(x),)
+                continue
+            y = feat(x)
+            gs = torch.autograd.grad(y, [x] + list(feat.parameters()), go)
+            res[flag] = (y.detach(),) + tuple(gs)
+    finally:
+        TF.FUSE_NARROW = old
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
