@@ -362,7 +362,54 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
     if headline_ms:
         out["graph"]["vs_headline_plus_task"] = out["graph"]["ms_per_step"] / (headline_ms + tms)
     out["task_loss"] = "frozen PCRNet (bottleneck 1024) on (template 1024 pts, projected 64 pts) + Chamfer(projected, rotated template)"
+    try:
+        out["task_roofline"] = _task_wide_layer_roofline(dev, B, N)
+    except Exception as e:  # noqa: BLE001
+        out["task_roofline"] = {"error": repr(e)[:200]}
     return out
+
+
+def _task_wide_layer_roofline(dev, B, N, Ci=128, Co=1024, reps=40):
+    """The task step's longest kernel against its roof: PCRNet's 128 -> 1024 layer on the template cloud + max over the points
+    (sn_linear_forward_maxpool_wide, pointnet_mlp.hip) -- 2 R Ci Co fp32-equivalent flops as split-bf16 products (ceiling
+    2.5 PF / 6 = 417 TFLOP/s), HIP events around back-to-back launches on the launch stream."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    R = B * N
+    if not lib.sn_linear_forward_maxpool_wide_supported(R, Ci, Co, N):
+        return {"skipped": "shape not on the wide kernel"}
+    gen = torch.Generator(device=dev).manual_seed(11)
+    a = torch.randn(R, Ci, device=dev, generator=gen)
+    coef = torch.zeros(4, Ci, device=dev)
+    coef[0] = 1
+    W = torch.randn(Co, Ci, device=dev, generator=gen) * 0.1
+    b = torch.randn(Co, device=dev, generator=gen)
+    pooled = torch.empty(B, Co, device=dev)
+    planes = torch.empty(3 * Co * Ci, device=dev, dtype=torch.bfloat16)
+    scratch = torch.empty(lib.sn_linear_forward_maxpool_wide_scratch_bytes(R, Ci, Co, N) // 8, device=dev, dtype=torch.int64)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def run(ready):
+        check(lib.sn_linear_forward_maxpool_wide(R, Ci, Co, N, ptr(a), ptr(coef), ptr(W), ptr(b), None, ptr(scratch), ptr(pooled), None,
+                                                 None, ptr(planes), ready, st), "sn_linear_forward_maxpool_wide")
+
+    run(0)
+    for _ in range(5):
+        run(1)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run(1)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    flop = 2.0 * R * Ci * Co
+    ach = flop / (ms * 1e-3) * 1e-12
+    return {"kernel": "linear_fwd_wide_pool_kernel<128> + key decode (PCRNet conv5 on the template cloud, max over the points fused)",
+            "bound": "mfma", "achieved": ach, "peak": 2500.0 / 6.0, "unit": "fp32-equivalent TFLOP/s (six bf16 products per fp32 product)",
+            "frac": ach / (2500.0 / 6.0), "avg_launch_ms": ms, "algorithmic_flop_per_launch": flop,
+            "algorithmic_bytes_per_launch": float(R * Ci * 4 + Co * Ci * 4 + B * Co * 4)}
 
 
 def time_config3_emd(dev, reps=5):
