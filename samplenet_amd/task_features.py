@@ -347,10 +347,16 @@ class PCRNet(nn.Module):
         twist, pre_normalized_quat, _ = self.forward_with_qnorm(x0, x1)
         return twist, pre_normalized_quat
 
-    def forward_with_qnorm(self, x0, x1):
+    def template_features(self, x0):
+        """self.feat(x0) for a caller that evaluates the network several times against the SAME template cloud within a step (the
+        progressive sampler's prefixes): pass the result as `feat0` and the template's extractor pass -- two thirds of the
+        network's arithmetic -- runs once."""
+        return self.feat(x0)
+
+    def forward_with_qnorm(self, x0, x1, feat0=None):
         """forward() plus the QuaterNet regulariser mean((||pre_normalized_quat||^2 - 1)^2) of registration/main.py:565, which
-        the output head's kernel computes on the side."""
-        y = torch.cat([self.feat(x0), self.feat(x1)], dim=1)
+        the output head's kernel computes on the side.  feat0: template_features(x0), computed by the caller (x0 is then unused)."""
+        y = torch.cat([self.feat(x0) if feat0 is None else feat0, self.feat(x1)], dim=1)
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
         frozen = not any(p.requires_grad for fc in fcs for p in fc.parameters())
         if FUSED_TRUNK and frozen and y.is_cuda and y.shape[0] <= 32:
@@ -414,16 +420,17 @@ def qrot_cloud(quat, v):
     return _QrotCloudFunction.apply(quat, v)
 
 
-def pcrnet_chamfer_loss(model, p0, p1):
+def pcrnet_chamfer_loss(model, p0, p1, template_features=None):
     """The Chamfer term of the registration task loss (`registration/main.py:557-577`, `--loss-type 1`):
     twist = model(p0, p1); p1_est = rotate(p0) by the estimated quaternion (QuaternionTransform.rotate,
     qdataset.py:97-119: rotation only); loss = mean d(p1 -> p1_est) + mean d(p1_est -> p1) on the HIP Chamfer kernels.
     p0 template / p1 source, (B,N,3).  Returns (chamfer_loss, qnorm_loss, twist).  The rotation-matrix error terms of
-    `--loss-type 0` go through kornia in the reference (not installed here) and stay with the caller."""
+    `--loss-type 0` go through kornia in the reference (not installed here) and stay with the caller.
+    template_features: model.template_features(p0), when several evaluations of a step share the template."""
     from .ops import chamfer_mean_loss
 
     if hasattr(model, "forward_with_qnorm"):
-        twist, _pre, qnorm_loss = model.forward_with_qnorm(p0, p1)
+        twist, _pre, qnorm_loss = model.forward_with_qnorm(p0, p1, feat0=template_features)
     else:
         twist, pre_normalized_quat = model(p0, p1)
         qnorm_loss = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)

@@ -1167,3 +1167,25 @@ def test_task_features_narrow_front_is_bit_identical(B, N, grad):
         TF.FUSE_NARROW = old
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+def test_pcrnet_shared_template_features():
+    """Several task evaluations against ONE template within a step (the progressive sampler's prefixes): the template's extractor
+    pass computed once (PCRNet.template_features) and handed to pcrnet_chamfer_loss gives the same losses and the same gradients to
+    the sampled clouds as recomputing it per evaluation."""
+    from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss
+
+    torch.manual_seed(1)
+    pcr = PCRNet(bottleneck_size=1024, input_shape="bnc").cuda().eval()
+    for p in pcr.parameters():
+        p.requires_grad_(False)
+    template = torch.rand(8, 1024, 3, device="cuda") - 0.5
+    qs = [(torch.rand(8, m, 3, device="cuda") - 0.5).requires_grad_(True) for m in (32, 64, 128)]
+    plain = sum(pcrnet_chamfer_loss(pcr, template, q)[0] for q in qs)
+    gp = torch.autograd.grad(plain, qs)
+    f0 = pcr.template_features(template)
+    shared = sum(pcrnet_chamfer_loss(pcr, template, q, template_features=f0)[0] for q in qs)
+    gs = torch.autograd.grad(shared, qs)
+    assert torch.equal(plain, shared)
+    for a, b in zip(gp, gs):
+        assert torch.equal(a, b)
