@@ -267,6 +267,13 @@ int sn_pointnet_narrow_forward(int R, const float *x, const float *W1, const flo
                                const float *b3, const float *W4, const float *b4, void *wplanes, int planes_ready, float *z1, float *z2,
                                float *z3, float *z4, sn_stream_t stream);
 
+/*   sn_pointnet_narrow_backward the data gradient back through that front in one launch (frozen weights): dx (R,3) from dz4 (R,128) =
+ *                               dL/d(conv4's pre-activations) and the saved z1..z3; wplanes_t: 3 * 16384 bf16 for the transposed split
+ *                               weights (planes_ready != 0: already there). */
+int sn_pointnet_narrow_backward_supported(int R, int c1, int c2, int c3, int c4);
+int sn_pointnet_narrow_backward(int R, const float *dz4, const float *z1, const float *z2, const float *z3, const float *W1, const float *W2,
+                                const float *W3, const float *W4, void *wplanes_t, int planes_ready, float *dx, sn_stream_t stream);
+
 /* Linear layers on at most 32 rows (PCRNet's trunk, registration/models/pcrnet.py:56-77): out (R, N) = act((x . [gate > 0]) (R, K) .
  * W^T + bias), the weight stream cut into (32-column tile) x (K slice) workgroups, slices summed in order by the last workgroup to
  * arrive (deterministic); fp32 products as split-bf16 MFMAs.

@@ -97,6 +97,8 @@ PROTOTYPES = {
     "sn_linear_forward_maxpool_wide": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sn_pointnet_narrow_forward_supported": [_i, _i, _i, _i, _i],
     "sn_pointnet_narrow_forward": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "sn_pointnet_narrow_backward_supported": [_i, _i, _i, _i, _i],
+    "sn_pointnet_narrow_backward": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sn_skinny_linear_supported": [_i, _i, _i],
     "sn_skinny_linear_scratch_bytes": [_i, _i, _i],
     "sn_skinny_linear": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],

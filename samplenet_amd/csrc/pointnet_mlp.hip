@@ -4666,11 +4666,7 @@ __global__ void __launch_bounds__(512) linear_fwd_wide_pool_kernel(WideArgs g)
         for (int kk = 0; kk < KS; ++kk) {
             if (mm) {
                 if (kk + 1 < KS) load_b(kk + 1, b[(kk + 1) & 1]);
-#ifdef SN_WIDE_NOMFMA
-#define SN_WIDE_TERM(PA, PB) acc[0] += (float)a[PA][kk][0] * (float)b[kk & 1][PB][0]
-#else
 #define SN_WIDE_TERM(PA, PB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][kk], b[kk & 1][PB], acc, 0, 0, 0)
-#endif
                 // the six MFMAs of a k-step run on ONE accumulator: kept back to back (a filler between two of them costs ~43 cycles,
                 // MI355X_MICROARCH.md); the fragment reads and the epilogue pieces go between the groups
                 __builtin_amdgcn_sched_barrier(0);
@@ -5049,6 +5045,222 @@ extern "C" int sn_pointnet_narrow_forward(int R, const float *x, const float *W1
     return 0;
 }
 
+// ---- the data gradient back through that narrow front in ONE launch (frozen weights: no weight gradients wanted): from dL/dz4
+// (R,128) -- what the pooled layer's backward hands down -- to the gradient of the cloud (R,3):
+//   dz3 = [z3 > 0] (dz4 W4),  dz2 = [z2 > 0] (dz3 W3),  dz1 = [z1 > 0] (dz2 W2),  dx = dz1 W1
+// the mirror of pointnet_narrow_fwd_kernel: a wave takes 32 rows, the weights arrive as TRANSPOSED bf16 planes ([3][Ci][Co]: the
+// B fragment of a data-gradient product is 8 consecutive output channels of one input channel), each product's 32 x 64 tile goes
+// through the wave's LDS tile into the row layout, where the ReLU mask of the layer below is applied from a 16-byte read of its
+// saved pre-activations; the 64 -> 3 product is 96 FMAs per lane and one cross-half add.  (4 launches of 5-7 us each before.)
+struct NarrowBwdArgs {
+    const float *dz4, *z1, *z2, *z3, *W1;
+    const __bf16 *Q4, *Q3, *Q2;  // transposed planes [3][64][128], [3][64][64], [3][64][64]
+    float *dx;
+    int R;
+};
+struct SplitJobT3 {
+    const float *w[3];
+    __bf16 *dst[3];
+    int co[3], ci[3];
+};
+__global__ void __launch_bounds__(256) split_planes_t3_kernel(SplitJobT3 job)
+{
+    const int l = blockIdx.y, co = job.co[l], ci = job.ci[l], n = co * ci;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // index into the TRANSPOSED image: i = c_in * co + c_out
+    if (i >= n) return;
+    const int c_in = i / co, c_out = i % co;
+    __bf16 h1, h2, h3;
+    split3(job.w[l][(size_t)c_out * ci + c_in], h1, h2, h3);
+    job.dst[l][i] = h1, job.dst[l][(size_t)n + i] = h2, job.dst[l][2 * (size_t)n + i] = h3;
+}
+__global__ void __launch_bounds__(256) pointnet_narrow_bwd_kernel(NarrowBwdArgs g)
+{
+    constexpr int P4 = 136, P3 = 72, PT = 68;  // plane row pitches (bf16) for K = 128 / 64, transpose tile pitch (floats)
+    constexpr int N4 = 3 * 64 * P4, N3 = 3 * 64 * P3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16 *S4 = reinterpret_cast<__bf16 *>(lds), *S3 = S4 + N4, *S2 = S3 + N3;
+    float *W1s = reinterpret_cast<float *>(S2 + N3);  // [64][4] = (w0, w1, w2, -)
+    float *Tall = W1s + 64 * 4;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *T = Tall + wave * (32 * PT);
+    const int row0 = blockIdx.x * kNarrowRows + wave * 32;
+    const int rrow = min(row0 + l31, g.R - 1);
+    const bool rok = row0 + l31 < g.R;
+    {
+        // every load of the prologue in flight at once: the planes (12 + 6 + 6 items of 16 bytes per thread) and this lane's 128
+        // gradient values (its row's k-groups)
+        bf16x8 r4[12], r3[6], r2[6];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) r4[q] = *reinterpret_cast<const bf16x8 *>(g.Q4 + (size_t)(tid + q * 256) * 8);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            r3[q] = *reinterpret_cast<const bf16x8 *>(g.Q3 + (size_t)(tid + q * 256) * 8);
+            r2[q] = *reinterpret_cast<const bf16x8 *>(g.Q2 + (size_t)(tid + q * 256) * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int f = tid + q * 256, row = f >> 4, k8 = (f & 15) * 8;  // row = plane * 64 + input channel; global rows are 128 wide
+            *reinterpret_cast<bf16x8 *>(S4 + row * P4 + k8) = r4[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int f = tid + q * 256, row = f >> 3, k8 = (f & 7) * 8;
+            *reinterpret_cast<bf16x8 *>(S3 + row * P3 + k8) = r3[q];
+            *reinterpret_cast<bf16x8 *>(S2 + row * P3 + k8) = r2[q];
+        }
+        if (tid < 64) W1s[tid * 4 + 0] = g.W1[tid * 3 + 0], W1s[tid * 4 + 1] = g.W1[tid * 3 + 1], W1s[tid * 4 + 2] = g.W1[tid * 3 + 2], W1s[tid * 4 + 3] = 0.f;
+    }
+    // dz4 -> A fragments (K = 128: eight k-steps)
+    bf16x8 a8[3][8];
+    {
+        const float *ar = g.dz4 + (size_t)rrow * 128 + 8 * h;
+        float4 v[8][2];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) v[kk][0] = *reinterpret_cast<const float4 *>(ar + kk * 16), v[kk][1] = *reinterpret_cast<const float4 *>(ar + kk * 16 + 4);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float e[8] = {v[kk][0].x, v[kk][0].y, v[kk][0].z, v[kk][0].w, v[kk][1].x, v[kk][1].y, v[kk][1].z, v[kk][1].w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                __bf16 h1, h2, h3;
+                split3(rok ? e[t] : 0.f, h1, h2, h3);
+                a8[0][kk][t] = h1, a8[1][kk][t] = h2, a8[2][kk][t] = h3;
+            }
+        }
+    }
+    __syncthreads();
+    // acc (two 32-column tiles) -> T -> this lane's row values d[kk][8], masked by the saved pre-activations zmask (R, 64)
+    float d[4][8];
+    const auto finish = [&](f32x16 (&acc)[2], const float *zmask) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) T[frag_row(e, lane) * PT + j * 32 + l31] = acc[j][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(T + l31 * PT + kk * 16 + 8 * h), v1 = *reinterpret_cast<const float4 *>(T + l31 * PT + kk * 16 + 8 * h + 4);
+            const float *zp = zmask + (size_t)rrow * 64 + kk * 16 + 8 * h;
+            const float4 z0 = *reinterpret_cast<const float4 *>(zp), z1 = *reinterpret_cast<const float4 *>(zp + 4);
+            const float e[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, zz[8] = {z0.x, z0.y, z0.z, z0.w, z1.x, z1.y, z1.z, z1.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) d[kk][t] = zz[t] > 0.f ? e[t] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    bf16x8 a[3][4];
+    const auto refrag = [&] {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                __bf16 h1, h2, h3;
+                split3(d[kk][t], h1, h2, h3);
+                a[0][kk][t] = h1, a[1][kk][t] = h2, a[2][kk][t] = h3;
+            }
+    };
+#define SN_NB_TERM(A, B, PA, PB) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[PA][kk], B[PB][j], acc[j], 0, 0, 0)
+    {   // dz3 = [z3 > 0] (dz4 . W4): K = 128
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        bf16x8 b[2][3][2];
+        const auto load_b = [&](int kk, bf16x8 (&bb)[3][2]) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bb[p][j] = *reinterpret_cast<const bf16x8 *>(S4 + (p * 64 + j * 32 + l31) * P4 + kk * 16 + 8 * h);
+        };
+        load_b(0, b[0]);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (kk + 1 < 8) load_b(kk + 1, b[(kk + 1) & 1]);
+            SN_NB_TERM(a8, b[kk & 1], 0, 2);
+            SN_NB_TERM(a8, b[kk & 1], 2, 0);
+            SN_NB_TERM(a8, b[kk & 1], 1, 1);
+            SN_NB_TERM(a8, b[kk & 1], 0, 1);
+            SN_NB_TERM(a8, b[kk & 1], 1, 0);
+            SN_NB_TERM(a8, b[kk & 1], 0, 0);
+        }
+        finish(acc, g.z3);
+    }
+    const auto layer64 = [&](const __bf16 *S, const float *zmask) {
+        refrag();
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        bf16x8 b[4][3][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[kk][p][j] = *reinterpret_cast<const bf16x8 *>(S + (p * 64 + j * 32 + l31) * P3 + kk * 16 + 8 * h);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            SN_NB_TERM(a, b[kk], 0, 2);
+            SN_NB_TERM(a, b[kk], 2, 0);
+            SN_NB_TERM(a, b[kk], 1, 1);
+            SN_NB_TERM(a, b[kk], 0, 1);
+            SN_NB_TERM(a, b[kk], 1, 0);
+            SN_NB_TERM(a, b[kk], 0, 0);
+        }
+        finish(acc, zmask);
+    };
+#undef SN_NB_TERM
+    layer64(S3, g.z2);  // dz2 = [z2 > 0] (dz3 . W3)
+    layer64(S2, g.z1);  // dz1 = [z1 > 0] (dz2 . W2)
+    // dx = dz1 . W1: this lane's 32 channels, then the other half of the row
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float4 w = *reinterpret_cast<const float4 *>(W1s + (kk * 16 + 8 * h + t) * 4);
+            s0 = fmaf(d[kk][t], w.x, s0), s1 = fmaf(d[kk][t], w.y, s1), s2 = fmaf(d[kk][t], w.z, s2);
+        }
+    s0 += __shfl_xor(s0, 32), s1 += __shfl_xor(s1, 32), s2 += __shfl_xor(s2, 32);
+    if (h == 0 && rok) {
+        float *o = g.dx + (size_t)(row0 + l31) * 3;
+        o[0] = s0, o[1] = s1, o[2] = s2;
+    }
+}
+
+extern "C" int sn_pointnet_narrow_backward_supported(int R, int c1, int c2, int c3, int c4)
+{
+    return R >= 1 && c1 == 64 && c2 == 64 && c3 == 64 && c4 == 128;
+}
+// dx (R,3) from dz4 (R,128) and the saved pre-activations z1..z3 (R,64).  wplanes_t: 3 * 16384 bf16 for the TRANSPOSED split weights
+// (planes_ready != 0: already holds them).
+extern "C" int sn_pointnet_narrow_backward(int R, const float *dz4, const float *z1, const float *z2, const float *z3, const float *W1,
+                                           const float *W2, const float *W3, const float *W4, void *wplanes_t, int planes_ready, float *dx,
+                                           sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && dz4 && z1 && z2 && z3 && W1 && W2 && W3 && W4 && wplanes_t && dx, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    __bf16 *Q4 = (__bf16 *)wplanes_t, *Q3 = Q4 + 3 * 128 * 64, *Q2 = Q3 + 3 * 64 * 64;
+    if (!planes_ready) {
+        SplitJobT3 job{{W4, W3, W2}, {Q4, Q3, Q2}, {128, 64, 64}, {64, 64, 64}};
+        hipLaunchKernelGGL(split_planes_t3_kernel, dim3(128 * 64 / 256, 3), dim3(256), 0, st, job);
+    }
+    NarrowBwdArgs g{dz4, z1, z2, z3, W1, Q4, Q3, Q2, dx, R};
+    const size_t lds = (size_t)(3 * 64 * 136 + 2 * 3 * 64 * 72) * 2 + 64 * 4 * 4 + 4 * 32 * 68 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void *)pointnet_narrow_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pointnet_narrow_backward: cannot reserve LDS");
+        attr = true;
+    }
+    hipLaunchKernelGGL(pointnet_narrow_bwd_kernel, dim3((R + kNarrowRows - 1) / kNarrowRows), dim3(256), lds, st, g);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- Linear layers on at most 32 rows (PCRNet's trunk, registration/models/pcrnet.py:56-77: 2048 -> 1024 -> 1024 -> 512 -> 512 ->
 // 256 -> 7 on the batch's 32 feature vectors; forward and data gradient).  15.5 MB of weights against 1 MFLOP per row: the layer is
 // a weight STREAM, and a CU pulls only ~25 GB/s from memory -- so the product is cut into (32-column tile) x (K slice) workgroups
@@ -5079,8 +5291,7 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
     const int kb = s * g.kslice + wave * kw;
     const int m = l31, n = n0 + l31;
     const bool mok = m < R, nok = n < N;
-    const bool kvec = (K & 3) == 0, nvec = true;
-    (void)nvec;
+    const bool kvec = (K & 3) == 0;
     float ea[KSTEPS][8], eg[KSTEPS][8], eb[KSTEPS][8];
 #pragma unroll
     for (int st = 0; st < KSTEPS; ++st) {
@@ -5183,17 +5394,16 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
     }
 }
 
-// S (K slices) and k-steps per wave for a (K, N) layer: as many workgroups as it takes to cover the chip, at most 4 k-steps a wave
+// S (K slices) and k-steps per wave for a (K, N) layer.  A slice is a multiple of 64 (one k-step of 16 for each of the four waves);
+// start from one k-step per wave (S = K / 64 slices: the most workgroups) and double the k-steps, halving S, while the grid stays
+// at 512 workgroups or more -- two per CU is where more of them stop buying memory parallelism; at most 4 k-steps a wave (the
+// kernel keeps all of a wave's loads in flight).
 static void skinny_plan(int K, int N, int &S, int &ksteps)
 {
     const int tiles = (N + 31) / 32;
-    const int k64 = (K + 63) / 64;  // 64-wide units: one k-step for each of the four waves
-    ksteps = 1;
-    S = k64;
-    while (S > 1 && tiles * S > 512 && ksteps < 4 && S % 2 == 0) S /= 2, ksteps *= 2;
-    while (S > 1 && tiles * S >= 512 && S % 2 == 0 && ksteps < 4) S /= 2, ksteps *= 2;
-    if (S * ksteps < k64) ksteps = (k64 + S - 1) / S;  // (odd unit counts)
-    if (ksteps == 3) ksteps = 4;
+    const int k64 = (K + 63) / 64;
+    S = k64, ksteps = 1;
+    while (S % 2 == 0 && ksteps < 4 && tiles * S >= 512) S /= 2, ksteps *= 2;
 }
 extern "C" int sn_skinny_linear_supported(int R, int K, int N)
 {

@@ -53,13 +53,14 @@ def _unit_rows(rows, c, like):
 _PLANES = {}  # ids of the weight parameters -> (weak references to them, their versions, their bf16 planes)
 
 
-def _weight_planes(*Ws):
+def _weight_planes(*Ws, tag=""):
     """Scratch for the split of the weights Ws into three bf16 planes each (sn_linear_forward_maxpool_wide, sn_pointnet_narrow_forward)
     and whether it already holds the split of these very weights: eager calls reuse it while the parameter objects are the same
     and their version counters stand still (the two clouds of a registration step, every step of a frozen task network); under
-    a stream capture the split is always recorded -- a replay must see weights that were updated in place since."""
+    a stream capture the split is always recorded -- a replay must see weights that were updated in place since.
+    tag: distinguishes the images kept of the same weights (the backward's transposed planes)."""
     bases = [W._base if W._base is not None else W for W in Ws]
-    key = tuple(id(b) for b in bases)
+    key = (tag,) + tuple(id(b) for b in bases)
     vers = tuple(b._version for b in bases)
     numel = 3 * sum(W.numel() for W in Ws)
     hit = _PLANES.get(key)
@@ -156,6 +157,7 @@ class _FeaturesFunction(torch.autograd.Function):
                 check(lib.sn_pool_forward(B, N, C, ptr(zs[-1]), ptr(idents[-1]), ptr(pooled), ptr(argsel), ptr(zsel), st),
                       "sn_pool_forward")
         ctx.zlast_missing = zs[-1] is None
+        ctx.zlast_missing_front = any(z is None for z in zs[:-1])
         zs = [pooled if z is None else z for z in zs]  # (placeholders in the saved list: never read -- see keep_z / need_grad)
         ctx.save_for_backward(x_bnc, pooled, argsel, zsel, *zs, *idents, *Ws)
         ctx.nl = len(Ws)
@@ -194,6 +196,17 @@ class _FeaturesFunction(torch.autograd.Function):
                     check(lib.sn_pool_dgrad_sparse(B, N, Ci, Co, ptr(g), ptr(pooled), ptr(argsel), ptr(W), ptr(zs[i - 1]),
                                                    ptr(idents[i - 1]), ptr(dy), st), "sn_pool_dgrad_sparse")
                     continue
+                if (i == 3 and nl == 5 and FUSE_NARROW and ctx.needs_input_grad[0] and not any(ctx.needs_input_grad[1:9])
+                        and Ws[0].shape[1] == 3 and lib.sn_pointnet_narrow_backward_supported(R, *[w.shape[0] for w in Ws[:4]])
+                        and not ctx.zlast_missing_front):
+                    # frozen conv1..conv4: their four data-gradient launches as one, straight to the gradient of the cloud
+                    planes, ready = _weight_planes(Ws[3], Ws[2], Ws[1], tag="T")
+                    dx = torch.empty(R, 3, device=dev, dtype=torch.float32)
+                    check(lib.sn_pointnet_narrow_backward(R, ptr(dy), ptr(zs[0]), ptr(zs[1]), ptr(zs[2]), ptr(Ws[0]), ptr(Ws[1]),
+                                                          ptr(Ws[2]), ptr(Ws[3]), ptr(planes), int(ready), ptr(dx), st),
+                          "sn_pointnet_narrow_backward")
+                    dy = dx
+                    break
                 mode = _DZ_POOL if i == nl - 1 else _DZ_PLAIN
                 kcoef = None
                 if mode == _DZ_POOL:  # dZ = 1 * dY_sparse + 0 * Z + 0

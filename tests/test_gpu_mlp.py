@@ -1189,3 +1189,37 @@ def test_pcrnet_shared_template_features():
     assert torch.equal(plain, shared)
     for a, b in zip(gp, gs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N", [(32, 64), (4, 256), (3, 50), (2, 1024)])
+def test_task_features_narrow_backward(B, N):
+    """Frozen PointNetFeatures: the data gradient through conv4..conv1 as one launch (sn_pointnet_narrow_backward, split-bf16 MFMAs
+    against transposed weight planes) against the four layer launches (fp32 MFMA) and against torch in fp64; bit-identical run to run."""
+    import torch.nn.functional as F
+
+    from samplenet_amd import task_features as TF
+
+    torch.manual_seed(B * 3 + N)
+    feat = TF.PointNetFeatures(bottleneck_size=1024, input_shape="bnc").cuda()
+    for p in feat.parameters():
+        p.requires_grad_(False)
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5).requires_grad_(True)
+    go = torch.randn(B, 1024, device="cuda")
+    old = TF.FUSE_NARROW
+    got = {}
+    try:
+        for tag, flag in (("fused", True), ("fused2", True), ("layers", False)):
+            TF.FUSE_NARROW = flag
+            (got[tag],) = torch.autograd.grad(feat(x), [x], go)
+    finally:
+        TF.FUSE_NARROW = old
+    assert torch.equal(got["fused"], got["fused2"])
+    xr = x.detach().double().requires_grad_(True)
+    hcur = xr.permute(0, 2, 1)
+    for conv in (feat.conv1, feat.conv2, feat.conv3, feat.conv4, feat.conv5):
+        hcur = F.relu(F.conv1d(hcur, conv.weight.double(), conv.bias.double()))
+    (want,) = torch.autograd.grad(torch.max(hcur, 2)[0], [xr], go.double())
+    scale = float(want.abs().max())
+    ef = float((got["fused"].double() - want).abs().max())
+    el = float((got["layers"].double() - want).abs().max())
+    assert ef <= max(2 * el, 2e-6 * scale), (ef, el, scale)
