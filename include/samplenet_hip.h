@@ -133,15 +133,18 @@ int sn_simplification_loss_backward(int B, int n1, const float *xyz1, int n2, co
  *                            and its gradients to either cloud (grad_loss: device scalar; either output may be NULL) -- the
  *                            simplification loss without the maximum term.  partial: 3 B floats, argmax1: B ints of scratch.
  *   sn_pcrnet_head_*         twist (B,7) = [normalize(y[:, 0:4]) | y[:, 4:7]] (models/pcrnet.py:78-82, F.normalize eps 1e-12) and
- *                            qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2 (main.py:565; NULL: not wanted); backward: g_y (B,7) from
- *                            g_twist (B,7) and the device scalar g_qnorm (either may be NULL).
+ *                            qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2 (main.py:565; NULL: not wanted); quat (B,4), optional: the
+ *                            normalised quaternion once more as a contiguous tensor (what QuaternionTransform.rotate consumes:
+ *                            no slice / copy launches around it); backward: g_y (B,7) from g_twist (B,7), g_quat (B,4) and the
+ *                            device scalar g_qnorm (each may be NULL).
  * ------------------------------------------------------------------------------------------- */
 int sn_chamfer_mean_loss_forward(int B, int n1, int n2, const float *dist1, const float *dist2, float *partial, int *argmax1,
                                  float *loss, sn_stream_t stream);
 int sn_chamfer_mean_loss_backward(int B, int n1, const float *xyz1, int n2, const float *xyz2, const int *idx1, const int *idx2,
                                   const float *grad_loss, float *grad_xyz1, float *grad_xyz2, sn_stream_t stream);
-int sn_pcrnet_head_forward(int B, const float *y, float *twist, float *qnorm, sn_stream_t stream);
-int sn_pcrnet_head_backward(int B, const float *y, const float *g_twist, const float *g_qnorm, float *g_y, sn_stream_t stream);
+int sn_pcrnet_head_forward(int B, const float *y, float *twist, float *quat, float *qnorm, sn_stream_t stream);
+int sn_pcrnet_head_backward(int B, const float *y, const float *g_twist, const float *g_quat, const float *g_qnorm, float *g_y,
+                            sn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.

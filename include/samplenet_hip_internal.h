@@ -283,6 +283,12 @@ int sn_skinny_linear_supported(int R, int K, int N);
 long long sn_skinny_linear_scratch_bytes(int R, int K, int N);
 int sn_skinny_linear(int R, int K, int N, const float *x, const float *gate, const float *W, int transposed, const float *bias, int relu,
                      float *out, float *scratch, unsigned *counters, sn_stream_t stream);
+/* two-part form: input columns k >= ksplit from x2 (R, K - ksplit) with x (R, ksplit) (x2 NULL: x is (R, K)); output columns n >= nsplit
+ * to out2 (R, N - nsplit) with out (R, nsplit) (nsplit 0: out is (R, N)); with nsplit > 0 either output may be NULL.  The trunk's
+ * first layer reads the two clouds' feature vectors where they lie and its data gradient hands each cloud its own gradient. */
+int sn_skinny_linear2(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *gate, const float *W, int transposed,
+                      const float *bias, int relu, float *out, float *out2, int nsplit, float *scratch, unsigned *counters,
+                      sn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -36,8 +36,8 @@ PROTOTYPES = {
     "sn_simplification_loss_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _vp],
     "sn_chamfer_mean_loss_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_chamfer_mean_loss_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "sn_pcrnet_head_forward": [_i, _vp, _vp, _vp, _vp],
-    "sn_pcrnet_head_backward": [_i, _vp, _vp, _vp, _vp, _vp],
+    "sn_pcrnet_head_forward": [_i, _vp, _vp, _vp, _vp, _vp],
+    "sn_pcrnet_head_backward": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_sampler_loss_forward": [_i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
     "sn_sampler_loss_backward": [_i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp],
     "sn_pairscan_colmin_splits": [_i, _i, _i],
@@ -102,6 +102,7 @@ PROTOTYPES = {
     "sn_skinny_linear_supported": [_i, _i, _i],
     "sn_skinny_linear_scratch_bytes": [_i, _i, _i],
     "sn_skinny_linear": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "sn_skinny_linear2": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "sn_pool_dgrad_sparse_supported": [_i, _i, _i, _i],
     "sn_pool_dgrad_sparse": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_batch_stats_twopass": [_i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],

@@ -957,7 +957,7 @@ extern "C" int sn_chamfer_mean_loss_backward(int B, int n1, const float *xyz1, i
 // their ~15 backward launches).  Sums over the batch run in a fixed order.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pcrnet_head_fwd_kernel(int B, const float *__restrict__ y, float *__restrict__ twist,
-                                                              float *__restrict__ qnorm)
+                                                              float *__restrict__ quat, float *__restrict__ qnorm)
 {
     __shared__ float red[256];
     float acc = 0.f;
@@ -965,8 +965,10 @@ __global__ void __launch_bounds__(256) pcrnet_head_fwd_kernel(int B, const float
         const float *r = y + (size_t)b * 7;
         const float n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
         const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        const float q0 = r[0] * inv, q1 = r[1] * inv, q2 = r[2] * inv, q3 = r[3] * inv;
         float *o = twist + (size_t)b * 7;
-        o[0] = r[0] * inv, o[1] = r[1] * inv, o[2] = r[2] * inv, o[3] = r[3] * inv, o[4] = r[4], o[5] = r[5], o[6] = r[6];
+        o[0] = q0, o[1] = q1, o[2] = q2, o[3] = q3, o[4] = r[4], o[5] = r[5], o[6] = r[6];
+        if (quat) quat[b * 4 + 0] = q0, quat[b * 4 + 1] = q1, quat[b * 4 + 2] = q2, quat[b * 4 + 3] = q3;
         acc += (n2 - 1.0f) * (n2 - 1.0f);
     }
     if (!qnorm) return;
@@ -979,7 +981,8 @@ __global__ void __launch_bounds__(256) pcrnet_head_fwd_kernel(int B, const float
 }
 
 __global__ void __launch_bounds__(256) pcrnet_head_bwd_kernel(int B, const float *__restrict__ y, const float *__restrict__ g_twist,
-                                                              const float *__restrict__ g_qnorm, float *__restrict__ g_y)
+                                                              const float *__restrict__ g_quat, const float *__restrict__ g_qnorm,
+                                                              float *__restrict__ g_y)
 {
     const float gq = g_qnorm ? g_qnorm[0] : 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
@@ -987,41 +990,42 @@ __global__ void __launch_bounds__(256) pcrnet_head_bwd_kernel(int B, const float
         const float n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
         const float nrm = sqrtf(n2);
         float *o = g_y + (size_t)b * 7;
-        float gp[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g_twist) {
-            const float *gt = g_twist + (size_t)b * 7;
-            if (nrm > 1e-12f) {  // d(p / ||p||) = (g - q (q . g)) / ||p||
-                const float inv = 1.0f / nrm;
-                const float q[4] = {r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv};
-                const float dot = q[0] * gt[0] + q[1] * gt[1] + q[2] * gt[2] + q[3] * gt[3];
+        // upstream gradient of the normalised quaternion: through twist[:, 0:4] and / or through the separate copy
+        float gt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gp[i] = (gt[i] - q[i] * dot) * inv;
-            } else {  // clamped denominator: p / 1e-12
+        for (int i = 0; i < 4; ++i) gt[i] = (g_twist ? g_twist[(size_t)b * 7 + i] : 0.f) + (g_quat ? g_quat[b * 4 + i] : 0.f);
+        float gp[4];
+        if (nrm > 1e-12f) {  // d(p / ||p||) = (g - q (q . g)) / ||p||
+            const float inv = 1.0f / nrm;
+            const float q[4] = {r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv};
+            const float dot = q[0] * gt[0] + q[1] * gt[1] + q[2] * gt[2] + q[3] * gt[3];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gp[i] = gt[i] * 1e12f;
-            }
-            o[4] = gt[4], o[5] = gt[5], o[6] = gt[6];
-        } else {
-            o[4] = 0.f, o[5] = 0.f, o[6] = 0.f;
+            for (int i = 0; i < 4; ++i) gp[i] = (gt[i] - q[i] * dot) * inv;
+        } else {  // clamped denominator: p / 1e-12
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gp[i] = gt[i] * 1e12f;
         }
+#pragma unroll
+        for (int i = 4; i < 7; ++i) o[i] = g_twist ? g_twist[(size_t)b * 7 + i] : 0.f;
         const float cq = gq * 4.0f * (n2 - 1.0f) / (float)B;  // d/dp mean (||p||^2 - 1)^2 = 4 (||p||^2 - 1) p / B
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = gp[i] + cq * r[i];
     }
 }
 
-extern "C" int sn_pcrnet_head_forward(int B, const float *y, float *twist, float *qnorm, sn_stream_t stream)
+extern "C" int sn_pcrnet_head_forward(int B, const float *y, float *twist, float *quat, float *qnorm, sn_stream_t stream)
 {
     SN_REQUIRE(B >= 1 && y && twist, "bad argument");
-    hipLaunchKernelGGL(pcrnet_head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, y, twist, qnorm);
+    hipLaunchKernelGGL(pcrnet_head_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, y, twist, quat, qnorm);
     SN_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int sn_pcrnet_head_backward(int B, const float *y, const float *g_twist, const float *g_qnorm, float *g_y, sn_stream_t stream)
+extern "C" int sn_pcrnet_head_backward(int B, const float *y, const float *g_twist, const float *g_quat, const float *g_qnorm, float *g_y,
+                                       sn_stream_t stream)
 {
     SN_REQUIRE(B >= 1 && y && g_y, "bad argument");
-    hipLaunchKernelGGL(pcrnet_head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, y, g_twist, g_qnorm, g_y);
+    hipLaunchKernelGGL(pcrnet_head_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, y, g_twist, g_quat, g_qnorm, g_y);
     SN_LAUNCH_CHECK();
     return 0;
 }

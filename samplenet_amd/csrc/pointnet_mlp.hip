@@ -5277,6 +5277,11 @@ struct SkinnyArgs {
     float *out, *part;
     unsigned *counter;
     int R, K, N, S, kslice, wmode, relu;
+    // two-part operands (the trunk's first layer reads the two clouds' feature vectors where they lie, its data gradient hands
+    // each cloud its own gradient -- no concatenation / slice copies around the trunk):
+    const float *x2;  // columns k >= ksplit of the input come from x2 (R, K - ksplit); x is then (R, ksplit).  NULL: x is (R, K)
+    float *out2;      // columns n >= nsplit of the output go to out2 (R, N - nsplit); out is then (R, nsplit).  Either may be NULL
+    int ksplit, nsplit;
 };
 template <int KSTEPS>
 __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
@@ -5298,8 +5303,14 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
         const int k8 = kb + st * 16 + 8 * h;
         const bool full = k8 + 8 <= K && kvec;
         // A: 8 consecutive k of row m of x (and of the gate)
+        const float *xs = g.x;
+        int ldx = K, kx = k8;
+        if (g.x2) {  // (ksplit is a multiple of 8: a fragment never straddles the two parts)
+            if (k8 >= g.ksplit) xs = g.x2, ldx = K - g.ksplit, kx = k8 - g.ksplit;
+            else ldx = g.ksplit;
+        }
         if (full && mok) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(g.x + (size_t)m * K + k8), v1 = *reinterpret_cast<const float4 *>(g.x + (size_t)m * K + k8 + 4);
+            const float4 v0 = *reinterpret_cast<const float4 *>(xs + (size_t)m * ldx + kx), v1 = *reinterpret_cast<const float4 *>(xs + (size_t)m * ldx + kx + 4);
             ea[st][0] = v0.x, ea[st][1] = v0.y, ea[st][2] = v0.z, ea[st][3] = v0.w, ea[st][4] = v1.x, ea[st][5] = v1.y, ea[st][6] = v1.z, ea[st][7] = v1.w;
             if (g.gate) {
                 const float4 g0 = *reinterpret_cast<const float4 *>(g.gate + (size_t)m * K + k8), g1 = *reinterpret_cast<const float4 *>(g.gate + (size_t)m * K + k8 + 4);
@@ -5309,7 +5320,7 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const bool ok = mok && k8 + t < K;
-                ea[st][t] = ok ? g.x[(size_t)m * K + k8 + t] : 0.f;
+                ea[st][t] = ok ? xs[(size_t)m * ldx + kx + t] : 0.f;
                 if (g.gate) eg[st][t] = ok ? g.gate[(size_t)m * K + k8 + t] : 0.f;
             }
         }
@@ -5388,9 +5399,16 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
     if (col < N) {
         const float bv = g.bias ? g.bias[col] : 0.f;
         const float o[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
+        float *dst = g.out;
+        int ldo = N, c = col;
+        if (g.nsplit > 0) {
+            if (col >= g.nsplit) dst = g.out2, ldo = N - g.nsplit, c = col - g.nsplit;
+            else ldo = g.nsplit;
+        }
+        if (dst)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (r0 + i < R) g.out[(size_t)(r0 + i) * N + col] = g.relu ? relu_np(o[i]) : o[i];
+            for (int i = 0; i < 4; ++i)
+                if (r0 + i < R) dst[(size_t)(r0 + i) * ldo + c] = g.relu ? relu_np(o[i]) : o[i];
     }
 }
 
@@ -5421,14 +5439,30 @@ extern "C" long long sn_skinny_linear_scratch_bytes(int R, int K, int N)
 }
 // counters: (N + 31) / 32 zeroed 32-bit words (left zeroed).  transposed != 0: W is (K, N) (the data gradient through a layer
 // whose weight is (Co = K, Ci = N)).
+extern "C" int sn_skinny_linear2(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *gate, const float *W,
+                                 int transposed, const float *bias, int relu, float *out, float *out2, int nsplit, float *scratch,
+                                 unsigned *counters, sn_stream_t stream);
 extern "C" int sn_skinny_linear(int R, int K, int N, const float *x, const float *gate, const float *W, int transposed, const float *bias,
                                 int relu, float *out, float *scratch, unsigned *counters, sn_stream_t stream)
 {
-    SN_REQUIRE(x && W && out && scratch && counters, "null pointer");
+    SN_REQUIRE(out, "null pointer");
+    return sn_skinny_linear2(R, K, N, x, nullptr, 0, gate, W, transposed, bias, relu, out, nullptr, 0, scratch, counters, stream);
+}
+// The two-part form: x2 / ksplit -- input columns k >= ksplit come from x2 (R, K - ksplit), x is (R, ksplit) (x2 == NULL: x is (R, K));
+// out2 / nsplit -- output columns n >= nsplit go to out2 (R, N - nsplit), out is (R, nsplit) (nsplit == 0: out is (R, N)); with
+// nsplit > 0 either output may be NULL (that part is not wanted).
+extern "C" int sn_skinny_linear2(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *gate, const float *W,
+                                 int transposed, const float *bias, int relu, float *out, float *out2, int nsplit, float *scratch,
+                                 unsigned *counters, sn_stream_t stream)
+{
+    SN_REQUIRE(x && W && scratch && counters, "null pointer");
+    SN_REQUIRE(!x2 || (ksplit > 0 && ksplit < K && ksplit % 8 == 0 && !gate), "x2: ksplit must be a multiple of 8 inside (0, K), no gate");
+    SN_REQUIRE(nsplit >= 0 && nsplit < N && (nsplit > 0 ? (out || out2) : out != nullptr), "bad output split");
     if (!sn_skinny_linear_supported(R, K, N)) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_skinny_linear: needs at most 32 rows");
     SkinnyArgs g{};
     g.x = x, g.gate = gate, g.W = W, g.bias = bias, g.out = out, g.part = scratch, g.counter = counters;
     g.R = R, g.K = K, g.N = N, g.wmode = transposed ? 1 : 0, g.relu = relu;
+    g.x2 = x2, g.ksplit = x2 ? ksplit : 0, g.out2 = out2, g.nsplit = nsplit;
     int ks;
     skinny_plan(K, N, g.S, ks);
     g.kslice = ks * 64;

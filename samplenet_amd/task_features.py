@@ -272,32 +272,45 @@ def _skinny_scratch(nbytes, ntiles, like):
     return t
 
 
-def _skinny(x, gate, W, transposed, bias, relu):
-    """out (R, N) = act((x . [gate > 0]) W^T + bias) with W (N, K), or x W with W (K, N) when transposed."""
-    R, K = x.shape
+def _skinny(x, gate, W, transposed, bias, relu, x2=None, split_out=None):
+    """out (R, N) = act((x . [gate > 0]) W^T + bias) with W (N, K), or x W with W (K, N) when transposed.  x2: the input is
+    [x | x2] (two tensors, never concatenated).  split_out = (n0, want0, want1): the output leaves as two tensors (R, n0) and
+    (R, N - n0), each only if wanted -> (out0 | None, out1 | None)."""
+    R = x.shape[0]
+    K = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     N = W.shape[1] if transposed else W.shape[0]
-    out = torch.empty(R, N, device=x.device, dtype=torch.float32)
     part, counters = _skinny_scratch(lib.sn_skinny_linear_scratch_bytes(R, K, N), (N + 31) // 32, x)
-    check(lib.sn_skinny_linear(R, K, N, ptr(x), ptr(gate), ptr(W), int(transposed), ptr(bias), int(relu), ptr(out), ptr(part),
-                               ptr(counters), _st(x)), "sn_skinny_linear")
-    return out
+    if split_out is None:
+        out, out2, nsplit = torch.empty(R, N, device=x.device, dtype=torch.float32), None, 0
+    else:
+        nsplit, want0, want1 = split_out
+        out = torch.empty(R, nsplit, device=x.device, dtype=torch.float32) if want0 else None
+        out2 = torch.empty(R, N - nsplit, device=x.device, dtype=torch.float32) if want1 else None
+    check(lib.sn_skinny_linear2(R, K, N, ptr(x), ptr(x2), x.shape[1] if x2 is not None else 0, ptr(gate), ptr(W), int(transposed),
+                                ptr(bias), int(relu), ptr(out), ptr(out2), nsplit, ptr(part), ptr(counters), _st(x)),
+          "sn_skinny_linear2")
+    return out if split_out is None else (out, out2)
 
 
 class _TrunkFunction(torch.autograd.Function):
-    """PCRNet's FC trunk with FROZEN weights on at most 32 rows: y -> fc1 .. fc5 (ReLU) -> fc6, six sn_skinny_linear launches forward
-    and six for the data gradient (registration/models/pcrnet.py:56-77 as rocBLAS GEMMs + ReLU / mask kernels: 22 launches)."""
+    """PCRNet's FC trunk with FROZEN weights on at most 32 rows: [f0 | f1] -> fc1 .. fc5 (ReLU) -> fc6, six sn_skinny_linear launches
+    forward and six for the data gradient (registration/models/pcrnet.py:56-77 as rocBLAS GEMMs + ReLU / mask kernels: 22 launches).
+    The two clouds' feature vectors are read where they lie and each receives its own gradient tensor (no cat / slice copies)."""
 
     @staticmethod
-    def forward(ctx, y, *wb):
+    def forward(ctx, f0, f1, *wb):
         Ws, bs = wb[0::2], wb[1::2]
-        x = y.contiguous().float()
+        f0, f1 = f0.contiguous().float(), f1.contiguous().float()
         acts = []
-        with torch.cuda.device(x.device):
-            for i, (W, b) in enumerate(zip(Ws, bs)):
-                x = _skinny(x, None, W, False, b, i < len(Ws) - 1)
+        with torch.cuda.device(f0.device):
+            x = _skinny(f0, None, Ws[0], False, bs[0], True, x2=f1)
+            acts.append(x)
+            for i in range(1, len(Ws)):
+                x = _skinny(x, None, Ws[i], False, bs[i], i < len(Ws) - 1)
                 acts.append(x)
         ctx.save_for_backward(*acts[:-1], *Ws)
         ctx.nl = len(Ws)
+        ctx.n0 = f0.shape[1]
         return x
 
     @staticmethod
@@ -306,33 +319,39 @@ class _TrunkFunction(torch.autograd.Function):
         acts, Ws = ctx.saved_tensors[:nl - 1], ctx.saved_tensors[nl - 1:]
         g = g.contiguous().float()
         with torch.cuda.device(g.device):
-            for i in range(nl - 1, -1, -1):  # dX = (dY . [y_i > 0]) W_i; the last layer has no ReLU
+            for i in range(nl - 1, 0, -1):  # dX = (dY . [y_i > 0]) W_i; the last layer has no ReLU
                 g = _skinny(g, acts[i] if i < nl - 1 else None, Ws[i], True, None, False)
-        return (g,) + (None,) * (2 * nl)
+            g0, g1 = _skinny(g, acts[0], Ws[0], True, None, False, split_out=(ctx.n0, ctx.needs_input_grad[0], ctx.needs_input_grad[1]))
+        return (g0, g1) + (None,) * (2 * nl)
 
 
 class _HeadFunction(torch.autograd.Function):
-    """y (B,7) -> twist (B,7) = [normalize(y[:, 0:4]) | y[:, 4:7]], qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2 -- sn_pcrnet_head_*."""
+    """y (B,7) -> twist (B,7) = [normalize(y[:, 0:4]) | y[:, 4:7]], quat (B,4) = the normalised quaternion as its own contiguous
+    tensor (for the rotation: no slice / copy launches, no zero-padded slice gradient), qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2
+    -- sn_pcrnet_head_*."""
 
     @staticmethod
     def forward(ctx, y):
         y = y.contiguous().float()
         B = y.shape[0]
         twist = torch.empty_like(y)
+        quat = torch.empty(B, 4, device=y.device, dtype=torch.float32)
         qnorm = torch.empty((), device=y.device, dtype=torch.float32)
         with torch.cuda.device(y.device):
-            check(lib.sn_pcrnet_head_forward(B, ptr(y), ptr(twist), ptr(qnorm), _st(y)), "sn_pcrnet_head_forward")
+            check(lib.sn_pcrnet_head_forward(B, ptr(y), ptr(twist), ptr(quat), ptr(qnorm), _st(y)), "sn_pcrnet_head_forward")
         ctx.save_for_backward(y)
-        return twist, qnorm
+        return twist, quat, qnorm
 
     @staticmethod
-    def backward(ctx, g_twist, g_qnorm):
+    def backward(ctx, g_twist, g_quat, g_qnorm):
         (y,) = ctx.saved_tensors
         gy = torch.empty_like(y)
         gt = g_twist.contiguous().float() if g_twist is not None else None
+        gqt = g_quat.contiguous().float() if g_quat is not None else None
         gq = g_qnorm.contiguous().float() if g_qnorm is not None else None
         with torch.cuda.device(y.device):
-            check(lib.sn_pcrnet_head_backward(y.shape[0], ptr(y), ptr(gt), ptr(gq), ptr(gy), _st(y)), "sn_pcrnet_head_backward")
+            check(lib.sn_pcrnet_head_backward(y.shape[0], ptr(y), ptr(gt), ptr(gqt), ptr(gq), ptr(gy), _st(y)),
+                  "sn_pcrnet_head_backward")
         return gy
 
 
@@ -357,7 +376,7 @@ class PCRNet(nn.Module):
         self.fc6 = nn.Linear(256, 7)
 
     def forward(self, x0, x1):
-        twist, pre_normalized_quat, _ = self.forward_with_qnorm(x0, x1)
+        twist, pre_normalized_quat = self.forward_with_qnorm(x0, x1)[:2]
         return twist, pre_normalized_quat
 
     def template_features(self, x0):
@@ -367,27 +386,29 @@ class PCRNet(nn.Module):
         return self.feat(x0)
 
     def forward_with_qnorm(self, x0, x1, feat0=None):
-        """forward() plus the QuaterNet regulariser mean((||pre_normalized_quat||^2 - 1)^2) of registration/main.py:565, which
-        the output head's kernel computes on the side.  feat0: template_features(x0), computed by the caller (x0 is then unused)."""
-        y = torch.cat([self.feat(x0) if feat0 is None else feat0, self.feat(x1)], dim=1)
+        """forward() plus the QuaterNet regulariser mean((||pre_normalized_quat||^2 - 1)^2) of registration/main.py:565 and the
+        normalised quaternion as a contiguous (B,4) tensor, both of which the output head's kernel produces on the side:
+        (twist, pre_normalized_quat, qnorm, quat).  feat0: template_features(x0), computed by the caller (x0 is then unused)."""
+        f0, f1 = (self.feat(x0) if feat0 is None else feat0), self.feat(x1)
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
         frozen = not any(p.requires_grad for fc in fcs for p in fc.parameters())
-        if FUSED_TRUNK and frozen and y.is_cuda and y.shape[0] <= 32:
+        if FUSED_TRUNK and frozen and f0.is_cuda and f0.shape[0] <= 32 and f0.shape[1] % 8 == 0:
             wb = []
             for fc in fcs:
                 wb += [fc.weight, fc.bias]
-            y = _TrunkFunction.apply(y, *wb)  # (B, 7)
+            y = _TrunkFunction.apply(f0, f1, *wb)  # (B, 7)
         else:
+            y = torch.cat([f0, f1], dim=1)
             for fc in fcs[:-1]:
                 y = torch.relu(fc(y))
             y = self.fc6(y)  # (B, 7)
         pre_normalized_quat = y[:, 0:4]
         if FUSED_HEAD and y.is_cuda:
-            twist, qnorm = _HeadFunction.apply(y)
-            return twist, pre_normalized_quat, qnorm
+            twist, quat, qnorm = _HeadFunction.apply(y)
+            return twist, pre_normalized_quat, qnorm, quat
         normalized_quat = torch.nn.functional.normalize(pre_normalized_quat, dim=1)
         qnorm = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
-        return torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat, qnorm
+        return torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat, qnorm, normalized_quat
 
 
 def qrot(q, v):
@@ -443,10 +464,11 @@ def pcrnet_chamfer_loss(model, p0, p1, template_features=None):
     from .ops import chamfer_mean_loss
 
     if hasattr(model, "forward_with_qnorm"):
-        twist, _pre, qnorm_loss = model.forward_with_qnorm(p0, p1, feat0=template_features)
+        twist, _pre, qnorm_loss, quat = model.forward_with_qnorm(p0, p1, feat0=template_features)
     else:
         twist, pre_normalized_quat = model(p0, p1)
         qnorm_loss = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
-    p1_est = qrot_cloud(twist[:, 0:4], p0)  # = qrot(twist[:, 0:4] expanded over the points, p0)
+        quat = twist[:, 0:4]
+    p1_est = qrot_cloud(quat, p0)  # = qrot(twist[:, 0:4] expanded over the points, p0)
     # mean(d(p1 -> p1_est)) + mean(d(p1_est -> p1)): scan + one fused reduction, implicit-gradient backward
     return chamfer_mean_loss(p1.contiguous(), p1_est.contiguous()), qnorm_loss, twist

@@ -1075,7 +1075,8 @@ def test_skinny_linear_trunk_matches_torch(R):
     go = torch.randn(R, 7, device="cuda")
     outs = []
     for _ in range(2):
-        o = TF._TrunkFunction.apply(y0, *wb)
+        fa, fb = y0[:, :1024], y0[:, 1024:]  # the two clouds' feature vectors, as two tensors
+        o = TF._TrunkFunction.apply(fa, fb, *wb)
         (gy,) = torch.autograd.grad(o, [y0], go)
         outs.append((o.detach(), gy))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
@@ -1114,13 +1115,15 @@ def test_pcrnet_head_and_chamfer_mean_loss_match_the_op_chain():
     B = 32
     y = torch.randn(B, 7, device="cuda").requires_grad_(True)
     wt, wq = torch.randn(B, 7, device="cuda"), 0.7
-    twist, qn = TF._HeadFunction.apply(y)
-    (gy,) = torch.autograd.grad((twist * wt).sum() + wq * qn, [y])
+    w4 = torch.randn(B, 4, device="cuda")
+    twist, quat, qn = TF._HeadFunction.apply(y)
+    assert torch.equal(quat, twist[:, 0:4])
+    (gy,) = torch.autograd.grad((twist * wt).sum() + wq * qn + (quat * w4).sum(), [y])
     yr = y.detach().double().requires_grad_(True)
     pre = yr[:, 0:4]
     tr = torch.cat([torch.nn.functional.normalize(pre, dim=1), yr[:, 4:]], dim=1)
     qr = torch.mean((torch.sum(pre ** 2, dim=1) - 1) ** 2)
-    (gr,) = torch.autograd.grad((tr * wt.double()).sum() + wq * qr, [yr])
+    (gr,) = torch.autograd.grad((tr * wt.double()).sum() + wq * qr + (tr[:, 0:4] * w4.double()).sum(), [yr])
     assert float((twist.double() - tr).abs().max()) <= 2e-7
     assert abs(float(qn) - float(qr)) <= 2e-6 * max(1.0, abs(float(qr)))
     assert float((gy.double() - gr).abs().max()) <= 5e-6 * max(1.0, float(gr.abs().max()))
