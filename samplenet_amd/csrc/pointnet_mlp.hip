@@ -5297,6 +5297,7 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
     const int m = l31, n = n0 + l31;
     const bool mok = m < R, nok = n < N;
     const bool kvec = (K & 3) == 0;
+    SN_TL(0);
     float ea[KSTEPS][8], eg[KSTEPS][8], eb[KSTEPS][8];
 #pragma unroll
     for (int st = 0; st < KSTEPS; ++st) {
@@ -5362,8 +5363,10 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
         SN_SK_TERM(0, 0);
 #undef SN_SK_TERM
     }
+    SN_TL(1);
     // wave w now holds column 8 w + (lane >> 3) of the tile, rows 4 (lane & 7) .. + 3
     float4 v = wave_reduce_scatter4(acc, red);
+    SN_TL(2);
     const int S = g.S;
     typedef float sk4 __attribute__((ext_vector_type(4)));
     if (S > 1) {
@@ -5372,12 +5375,14 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(P), "v"(pv) : "memory");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        SN_TL(3);
         if (tid == 0) {
             const unsigned t = __hip_atomic_fetch_add(g.counter + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = t == (unsigned)(S - 1);
             if (s_last) __hip_atomic_store(g.counter + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // armed for the next launch
         }
         __syncthreads();
+        SN_TL(4);
         if (!s_last) return;
         sk4 accv = {0.f, 0.f, 0.f, 0.f};
         for (int q0 = 0; q0 < S; q0 += 8) {  // slices in ascending order, eight loads in flight
@@ -5394,6 +5399,7 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
                 if (q0 + q < S) accv = accv + r[q];
         }
         v = make_float4(accv.x, accv.y, accv.z, accv.w);
+        SN_TL(5);
     }
     const int col = n0 + wave * 8 + (lane >> 3), r0 = 4 * (lane & 7);
     if (col < N) {
@@ -5414,14 +5420,16 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
 
 // S (K slices) and k-steps per wave for a (K, N) layer.  A slice is a multiple of 64 (one k-step of 16 for each of the four waves);
 // start from one k-step per wave (S = K / 64 slices: the most workgroups) and double the k-steps, halving S, while the grid stays
-// at 512 workgroups or more -- two per CU is where more of them stop buying memory parallelism; at most 4 k-steps a wave (the
-// kernel keeps all of a wave's loads in flight).
+// at 512 workgroups or more -- two per CU is where more of them stop buying memory parallelism -- or there are more than 8 slices;
+// at most 4 k-steps a wave (the kernel keeps all of a wave's loads in flight).
 static void skinny_plan(int K, int N, int &S, int &ksteps)
 {
     const int tiles = (N + 31) / 32;
     const int k64 = (K + 63) / 64;
     S = k64, ksteps = 1;
-    while (S % 2 == 0 && ksteps < 4 && tiles * S >= 512) S /= 2, ksteps *= 2;
+    while (S % 2 == 0 && ksteps < 4 && (tiles * S >= 512 || S > 8)) S /= 2, ksteps *= 2;
+    // (S > 8: the last workgroup of a tile sums the slices from one batch of eight loads in flight; a second batch is a second
+    // memory round trip -- tools/skinny_timeline.py: 1024 -> 512 with 16 slices spent 3.1 us there, 1.6 with 8)
 }
 extern "C" int sn_skinny_linear_supported(int R, int K, int N)
 {
