@@ -29,6 +29,11 @@ class SamplerTrainStep:
         self.ring = list(input_ring) if input_ring is not None else None
         if self.ring is not None and use_graph and reducer is None:
             raise ValueError("input_ring needs a gradient sink (FlatGradAllReducer): the graphs must write one set of .grad tensors")
+        if net.__dict__.get("_sn_sync_bn") is not None and use_graph:
+            # (statistics over all ranks: host-ordered collectives between the layers -- the step runs eagerly)
+            if self.ring is not None:
+                raise ValueError("input_ring needs the captured step; synchronised BatchNorm runs eagerly")
+            use_graph = False
         self.x = example_x.clone() if self.ring is None else self.ring[0]
         self._one = torch.ones((), device=example_x.device, dtype=torch.float32)
         self.graph = None
@@ -64,6 +69,8 @@ class SamplerTrainStep:
         benchmark's stand-in mean(proj) inside the node, or any callable on the projected points OUTSIDE it (its gradient
         enters the node's backward as an explicit tensor; needs the fc4-in-scan, keys-mode step)."""
         net = self.net
+        if net.__dict__.get("_sn_sync_bn") is not None:  # statistics over all ranks: collectives between the layers
+            return False
         if not self.fused_loss or not net.training or net.skip_projection or \
                 net.input_shape != "bnc" or not getattr(net, "standard_arch", True):
             return False

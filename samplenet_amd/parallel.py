@@ -11,8 +11,9 @@ unmodified module surface.  Design for xGMI (point-to-point, 7 links x ~153 GB/s
     the conv gradients follow at the end (two collectives, the first one hidden).  Under a captured
     step (engine.SamplerTrainStep) the same split is made at graph level: graph 1 = forward .. FC
     backward, graph 2 = conv backward, the first collective launched between them on the side stream;
-  * BatchNorm uses per-rank batch statistics (each replica behaves exactly like the reference at its
-    local batch size); SyncBatchNorm is not applied.
+  * BatchNorm uses per-rank batch statistics by default (each replica behaves exactly like the reference at its
+    local batch size); syncbn.convert_sync_batchnorm(net, group) switches the head to statistics over all ranks'
+    rows (W x B clouds train like one process with W B clouds; a parity mode on the layer-by-layer kernels).
 """
 import torch
 import torch.distributed as dist

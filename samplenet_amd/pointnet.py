@@ -914,7 +914,17 @@ def pointnet_head(net, x_bnc):
         raise TypeError("expected float32")
     x_bnc = x_bnc.contiguous()
     params = param_list(net)
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+    comm = net.__dict__.get("_sn_sync_bn") if net.training else None
+    if comm is not None:
+        # batch statistics over all ranks (syncbn.convert_sync_batchnorm): the layer-by-layer route with one collective per BatchNorm
+        from . import syncbn
+
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            y = syncbn.SyncBNMLPFunction.apply(net, x_bnc, comm, *params)
+        else:
+            with torch.cuda.device(x_bnc.device):
+                y, _ = syncbn.forward_sync(net, x_bnc, comm)
+    elif torch.is_grad_enabled() and any(p.requires_grad for p in params):
         y = PointNetMLPFunction.apply(net, x_bnc, net.training, *params)
     else:
         with torch.cuda.device(x_bnc.device):

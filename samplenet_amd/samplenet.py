@@ -96,7 +96,7 @@ class SampleNet(nn.Module):
     # per-step / per-attachment state that must not travel with a copy of the module (graph tensors, views of another
     # module's gradient bucket, persistent kernel scratch)
     _TRANSIENT = ("_scan", "_grad_sink", "_after_fc_grads", "_colmin_keys", "_colmin_keys_owner", "_fx_acc", "_fx_acc_b",
-                  "_fc_sync", "_fc_sync_b", "_sn_layer_records", "_sn_plans")
+                  "_fc_sync", "_fc_sync_b", "_sn_layer_records", "_sn_plans", "_sn_sync_bn")
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float() ...: parameter storage moves -- recorded pointer arrays and persistent scratch are void

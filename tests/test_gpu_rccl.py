@@ -104,3 +104,24 @@ def test_in_graph_collective_with_an_outside_task_loss(rccl):
         la, lb = sa(x), sb(x)
     torch.cuda.synchronize()
     assert float(la) == float(lb) and torch.equal(ra.flat, rb.flat) and float(ra.flat.abs().sum()) > 0
+
+
+def test_sync_batchnorm_over_rccl_at_world_size_one(rccl):
+    """syncbn.convert_sync_batchnorm through the real communicator (all_gather / all_reduce over RCCL) at world size 1, where the
+    statistics of "all ranks" are the local ones: the engine runs such a step eagerly (collectives between the layers), and loss and
+    gradients agree with the per-process-statistics step within the rounding of the layer-by-layer kernels."""
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+    from samplenet_amd.syncbn import convert_sync_batchnorm
+
+    na, nb = _nets(2)
+    convert_sync_batchnorm(nb)
+    x = torch.rand(32, 1024, 3, device="cuda") - 0.5
+    ra, rb = FlatGradAllReducer(na), FlatGradAllReducer(nb, force_collective=True)
+    sa = SamplerTrainStep(na, x, reducer=ra)
+    sb = SamplerTrainStep(nb, x, reducer=rb)
+    assert sa._fast_path() and not sb._fast_path() and sb.graph is None
+    la, lb = sa(x), sb(x)
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(la)))
+    assert float((ra.flat - rb.flat).norm()) <= 2e-4 * float(ra.flat.norm())

@@ -273,3 +273,52 @@ def test_two_rank_engine_step(tmp_path):
     loss = step(x_all)
     assert torch.allclose(f0, red.flat, rtol=1e-4, atol=1e-7)
     assert abs(float(l0 + l1) / 2 - float(loss)) < 1e-5
+
+
+def _syncbn_comm_worker(rank, world, port, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from samplenet_amd.syncbn import DistComm, combine_stats
+
+        comm = DistComm()
+        torch.manual_seed(7)
+        rows = torch.randn(world * 5, 3, dtype=torch.float64) * torch.tensor([1.0, 1e-3, 10.0]) + torch.tensor([0.0, 100.0, -3.0])
+        mine = rows[rank * 5:(rank + 1) * 5]
+        packed = torch.stack([mine.mean(0), mine.var(0, unbiased=False), torch.full((3,), 5.0, dtype=torch.float64)])
+        mean, var, total = combine_stats(comm.all_gather(packed), 1e-5)
+        ok = (torch.allclose(mean, rows.mean(0), rtol=1e-12, atol=1e-12) and torch.allclose(var, rows.var(0, unbiased=False), rtol=1e-9, atol=1e-15)
+              and float(total) == world * 5)
+        s = comm.all_reduce_sum(torch.full((2, 3), float(rank + 1)))
+        ok = ok and bool((s == sum(range(1, world + 1))).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_syncbn_communicator_and_statistics_merge_over_gloo():
+    """syncbn.DistComm (all_gather / all_reduce SUM of the per-layer statistics) and the parallel-variance merge over two gloo
+    ranks: the merged mean / biased variance equal those of the union of the ranks' rows, including a channel whose variance is
+    1e-10 of its squared mean."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_syncbn_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
