@@ -476,6 +476,36 @@ def pmc_traffic_sum(key):
         return None
 
 
+def time_config3_sampler(dev, steps=40):
+    """BASELINE configs[3], the sampler's side (the EMD leg above is the loss side): the reconstruction task's SampleNet
+    (reconstruction/src/samplers.py:23-38: conv widths 64, 128, 128, 256, bottleneck 128, FC 256, 256 without BatchNorm) on
+    B = 50 clouds of 2048 points -> 64, K = 8: forward + simplification / projection losses + backward, eager and captured.  Its
+    128 -> 256 -> 128 layers have no fused backward kernel (W^T fragments of 256 output channels do not fit the register budget of
+    conv_bwd_bx3_kernel): they run the generic dgrad / wgrad kernels, and the step is the op-by-op general path."""
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    B, N, M, K = 50, 2048, 64, 8
+    torch.manual_seed(0)
+    net = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc", conv_widths=(64, 128, 128, 256), fc_widths=(256, 256),
+                    fc_batchnorm=False, temperature_floor=1e-2, min_sigma=0.0).to(dev).train()
+    g = torch.Generator(device=dev).manual_seed(13)
+    x = torch.rand(B, N, 3, device=dev, generator=g) - 0.5
+    out = {"workload": "BASELINE configs[3], sampler side: reconstruction SampleNet (conv 64-128-128-256-128, FC 256-256 no BN), B=50, "
+                       "2048->64, K=8, fwd + losses + bwd"}
+    for name, use_graph in (("eager", False), ("graph", True)):
+        import copy
+
+        rep = copy.deepcopy(net)
+        st = SamplerTrainStep(rep, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=FlatGradAllReducer(rep), use_graph=use_graph)
+        ms, loss = _wall_ms(lambda: st(x), steps if not use_graph else max(steps, 100))
+        assert torch.isfinite(loss).item(), name
+        out[name] = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "point-clouds/s", "fast_path": bool(st._fast_path())}
+        del st, rep
+    return out
+
+
 def time_config5_progressive(dev, steps=40):
     """BASELINE configs[4] on one GPU (per-rank work of the DP job): progressive SampleNet 1024 -> {32, 64, 128, 256} + the PCRNet
     registration task (classification/train_samplenet_progressive.py:157-234 for the prefix semantics, registration/main.py:
@@ -803,6 +833,7 @@ def main():
             leg("module_surface", time_module_surface, dev, B, N, M, K, headline_ms=ms)
         if world == 1 and not args.no_extra_legs:
             leg("config3_emd", time_config3_emd, dev)
+            leg("config3_sampler", time_config3_sampler, dev)
             leg("config5_progressive", time_config5_progressive, dev)
             leg("batch_sweep", time_batch_sweep, dev, N, M, K)
         if world == 1 and not args.no_cpu_baseline:
