@@ -1463,6 +1463,11 @@ struct ConvBwdArgs {
     long long *acc_out;
     long long *zero_ptr;
     int zero_n;
+    // a 256-channel side as two passes of the 128 x 128 kernel (conv_bwd_bx3_kernel's GZ / GP / GW / DM): where a pass's
+    // weight-gradient partial and statistics lie inside the layer's [G][Co][Ci] / [G][2][Ci] blocks (0: the kernel's own CO CI / CI / CI),
+    // and the first pass's raw data gradient the second one adds (DM == 2; may be dyprev itself)
+    int part_wg_stride, part_ld, stats_ld;
+    const float *dyacc;
 };
 
 // Global-memory access of the dgrad waves goes through raw buffer instructions: resource (SGPRs) + per-lane byte offset
@@ -1504,25 +1509,25 @@ __device__ __forceinline__ void buf_store4(const float4 &v, sn_rsrc r, unsigned 
 }
 
 struct CbfRsrc {
-    sn_rsrc z, dy, zprev, dyprev, argsel, gsel;
+    sn_rsrc z, dy, zprev, dyprev, argsel, gsel, dyacc;
 };
 
-template <int CO, int CI, int TR, int ZMODE, int NZ4, int NP4, bool SKIP_P = false>
+template <int CO, int CI, int TR, int ZMODE, int NZ4, int NP4, bool SKIP_P = false, int GZ = CO, int GP = CI>
 __device__ __forceinline__ void cbf_issue_loads(const CbfRsrc &rs, int tile, int b, unsigned zvo, unsigned pvo, unsigned avo,
                                                 float4 (&rz)[NZ4], float4 (&rdy)[NZ4], float4 (&rp)[NP4], int4 &rag,
                                                 float4 &rgs)
 {
     constexpr int ZSTEP = 256 / (CO / 4), PSTEP = 256 / (CI / 4);  // staged by the 256 threads of the dgrad waves
-    const unsigned zso = (unsigned)tile * (TR * CO * 4), pso = (unsigned)tile * (TR * CI * 4);
+    const unsigned zso = (unsigned)tile * (TR * GZ * 4), pso = (unsigned)tile * (TR * GP * 4);  // (GZ / GP: global row strides)
     // (the per-q strides ride in the SCALAR offset: as per-lane offsets they cost a VGPR each -- the split-bf16 kernel spilled them,
     //  and a spilled address reloaded in front of a load waits for every request before it)
 #pragma unroll
     for (int q = 0; q < NZ4; ++q) {
-        rz[q] = buf_load4(rs.z, zvo, zso + q * (ZSTEP * CO * 4));
-        if (ZMODE == DZ_BN) rdy[q] = buf_load4(rs.dy, zvo, zso + q * (ZSTEP * CO * 4));
+        rz[q] = buf_load4(rs.z, zvo, zso + q * (ZSTEP * GZ * 4));
+        if (ZMODE == DZ_BN) rdy[q] = buf_load4(rs.dy, zvo, zso + q * (ZSTEP * GZ * 4));
     }
 #pragma unroll
-    for (int q = 0; q < (SKIP_P ? 0 : NP4); ++q) rp[q] = buf_load4(rs.zprev, pvo, pso + q * (PSTEP * CI * 4));
+    for (int q = 0; q < (SKIP_P ? 0 : NP4); ++q) rp[q] = buf_load4(rs.zprev, pvo, pso + q * (PSTEP * GP * 4));
     if (ZMODE == DZ_POOL) {  // the host guarantees npts % 64 == 0: one cloud (b) per tile
         rag = buf_load4i(rs.argsel, avo, (unsigned)b * (CO * 4));
         rgs = buf_load4(rs.gsel, avo, (unsigned)b * (CO * 4));
@@ -2076,9 +2081,15 @@ __device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0
 }
 
 // RZ1 (IN3 only): Zprev is not read -- the producer rebuilds it from the tile's xyz rows (ConvBwdArgs::w_in)
-template <int CI, int CO, int ZMODE, bool FULLR, bool IN3 = false, bool RZ1 = false>
+// GZ / GP / GW: global row strides (elements) of the dZ-side tensors (Z, dY), of Zprev / dYprev and of W -- a layer with 256 channels on one
+// side runs as two passes of the 128 x 128 instantiation over the halves of that side (the reconstruction sampler's 128 -> 256 -> 128):
+//   256 output channels: the passes take dZ columns / W rows [0,128) and [128,256); the data gradient is their SUM -- DM = 1 (first pass)
+//     stores it raw (no ReLU mask, no statistics), DM = 2 (second) adds ConvBwdArgs::dyacc at the fragment positions before the epilogue;
+//   256 input channels: the passes take W / Zprev / dYprev columns [0,128) and [128,256) and are independent (DM = 0).
+template <int CI, int CO, int ZMODE, bool FULLR, bool IN3 = false, bool RZ1 = false, int GZ = CO, int GP = CI, int GW = CI, int DM = 0>
 __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 {
+    static_assert(DM == 0 || (!IN3 && CbxShape<CI, CO>::KS == 1), "two-pass modes: plain 128 x 128 tiles");
     static_assert(!RZ1 || IN3, "RZ1: the layer below must be the xyz layer");
     using S = CbxShape<CI, CO>;
     static_assert(!IN3 || (S::TR == 64 && ZMODE == DZ_BN), "IN3: 64-row tiles (one row per lane for the moments)");
@@ -2126,14 +2137,17 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         const float4 sc4 = *reinterpret_cast<const float4 *>(g.scale_prev + pc4);
         const float4 sh4 = *reinterpret_cast<const float4 *>(g.shift_prev + pc4);
         const float scd = g.scale_prev[cb * 32 + l31], shd = g.shift_prev[cb * 32 + l31];
-        const unsigned qvo = ((rb * 32 + 4 * h) * CI + cb * 32 + l31) * 4;
-        const unsigned ovo = ((rb * 32 + (lane >> 3)) * CI + cb * 32 + (lane & 7) * 4) * 4;
-        const unsigned zvo = ((tid / (CO / 4)) * CO + zc4) * 4, pvo = ((tid / (CI / 4)) * CI + pc4) * 4, avo = zc4 * 4;
+        const unsigned qvo = ((rb * 32 + 4 * h) * GP + cb * 32 + l31) * 4;
+        const unsigned ovo = ((rb * 32 + (lane >> 3)) * GP + cb * 32 + (lane & 7) * 4) * 4;
+        const unsigned zvo = ((tid / (CO / 4)) * GZ + zc4) * 4, pvo = ((tid / (CI / 4)) * GP + pc4) * 4, avo = zc4 * 4;
         CbfRsrc rs;
-        rs.z = make_rsrc(g.dz.z, (unsigned)R * CO * 4);
-        rs.dy = make_rsrc(ZMODE == DZ_BN ? g.dz.dy : g.dz.z, (unsigned)R * CO * 4);
-        rs.zprev = make_rsrc(g.zprev, (unsigned)R * CI * 4);
-        rs.dyprev = make_rsrc(g.dyprev, (unsigned)R * CI * 4);
+        // (a pass over one half of a 256-channel side starts GZ / 2 or GP / 2 elements into the first row: the last row's range ends
+        //  that far behind the tensor -- never touched, every lane stays inside its half)
+        rs.z = make_rsrc(g.dz.z, (unsigned)R * GZ * 4);
+        rs.dy = make_rsrc(ZMODE == DZ_BN ? g.dz.dy : g.dz.z, (unsigned)R * GZ * 4);
+        rs.zprev = make_rsrc(g.zprev, (unsigned)R * GP * 4);
+        rs.dyprev = make_rsrc(g.dyprev, (unsigned)R * GP * 4);
+        rs.dyacc = make_rsrc(DM == 2 ? (const void *)g.dyacc : (const void *)g.zprev, (unsigned)R * GP * 4);
         const unsigned nclouds = ZMODE == DZ_POOL ? (unsigned)((R + g.dz.npts - 1) / g.dz.npts) : 1u;
         rs.argsel = make_rsrc(ZMODE == DZ_POOL ? (const void *)g.dz.argsel : (const void *)g.dz.z, nclouds * CO * 4);
         rs.gsel = make_rsrc(ZMODE == DZ_POOL ? (const void *)g.dz.gsel : (const void *)g.dz.z, nclouds * CO * 4);
@@ -2175,7 +2189,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         for (int i = 0; i < 4; ++i) vout[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
         int tile = blockIdx.x;
-        cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+        cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1, GZ, GP>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
         if (RZ1) load_xyz_rows(tile);
         if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)tile * (TR * 12));
         // W^T fragments of this wave's 32 input channels: W[co = 16 kk + 8 h + t][ci = cb 32 + l31] (requested after the first
@@ -2184,7 +2198,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
         for (int kk = 0; kk < KD; ++kk)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) wraw[kk][t] = g.W[(size_t)((kh * KD + kk) * 16 + 8 * h + t) * CI + cb * 32 + l31];
+            for (int t = 0; t < 8; ++t) wraw[kk][t] = g.W[(size_t)((kh * KD + kk) * 16 + 8 * h + t) * GW + cb * 32 + l31];
         if (fxin) {
             const float *Ks = Tf;  // the transpose scratch is idle until the first epilogue
             __syncthreads();
@@ -2208,15 +2222,19 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         for (int it = 0; tile < g.ntiles; ++it, tile += G) {
             const __bf16 *Zb = Lb + (it & 1) * BUF;
             if (!IN3 && it > 0 && kh == 0) {
-                const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
+                const unsigned oso = (unsigned)(tile - G) * (TR * GP * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * CI * 4));
+                for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * GP * 4));
             }
-            float zq[16];
-            if (!RZ1 && (KS == 1 || kh == 0))
+            float zq[16], pq[16];
+            if (!RZ1 && DM != 1 && (KS == 1 || kh == 0))
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    zq[e] = buf_load1(rs.zprev, qvo, (unsigned)tile * (TR * CI * 4) + ((e & 3) + 8 * (e >> 2)) * (CI * 4));
+                    zq[e] = buf_load1(rs.zprev, qvo, (unsigned)tile * (TR * GP * 4) + ((e & 3) + 8 * (e >> 2)) * (GP * 4));
+            if (DM == 2)  // the first pass's raw data gradient at this lane's fragment positions
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    pq[e] = buf_load1(rs.dyacc, qvo, (unsigned)tile * (TR * GP * 4) + ((e & 3) + 8 * (e >> 2)) * (GP * 4));
             const bool more = tile + G < g.ntiles;
             const int nxt = more ? tile + G : tile;
             int ncloud = cloud, ntic = tic;
@@ -2224,7 +2242,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 ncloud += bstep, ntic += tstep;
                 if (ntic >= tpc) ntic -= tpc, ++ncloud;
             }
-            cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+            cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1, GZ, GP>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
             if (RZ1) load_xyz_rows(nxt);
             if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)nxt * (TR * 12));
             // the requests go out HERE: left alone, the scheduler sinks them below the MFMAs to their first use (the staging),
@@ -2278,8 +2296,13 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if (DM == 1) {  // first of two passes over the output channels: the raw partial sum
+                    Ts[frag_row(e, lane) * 36 + l31] = acc[e];
+                    continue;
+                }
                 const float z = zq[e];
-                const float v = fmaf(z, scd, shd) > 0.f ? acc[e] : 0.f;
+                const float a = DM == 2 ? acc[e] + pq[e] : acc[e];
+                const float v = fmaf(z, scd, shd) > 0.f ? a : 0.f;
                 s0 += v;
                 s1 = fmaf(v, z, s1);  // (explicit: the variants of this kernel must round the sum the same way)
                 if (IN3) acc[e] = v;
@@ -2326,9 +2349,9 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         }
         SN_TL(6);
         if (!IN3 && tile != (int)blockIdx.x && kh == 0) {
-            const unsigned oso = (unsigned)(tile - G) * (TR * CI * 4);
+            const unsigned oso = (unsigned)(tile - G) * (TR * GP * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * CI * 4));
+            for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * GP * 4));
         }
         float *red = lds;  // [RB][NST][CI]   (every wave is past its last LDS read: barrier at the end of the loop)
         const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
@@ -2411,7 +2434,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             if (it == 1) SN_TL(4);
         }
         SN_TL(6);
-        float *P = g.part + (size_t)blockIdx.x * CO * CI;
+        const int pld = g.part_ld > 0 ? g.part_ld : CI;
+        float *P = g.part + (size_t)blockIdx.x * (g.part_wg_stride > 0 ? g.part_wg_stride : CO * CI);
         float *Tw = lds + RB * NST * CI + 16 + (wave - 4) * (32 * 36);  // behind the dgrad waves' statistics area
 #pragma unroll
         for (int n = 0; n < NWT; ++n) {
@@ -2421,15 +2445,16 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rt = 8 * i + (lane >> 3);
-                *reinterpret_cast<float4 *>(P + (size_t)(cob * 32 + rt) * CI + colb + (lane & 7) * 4) =
+                *reinterpret_cast<float4 *>(P + (size_t)(cob * 32 + rt) * pld + colb + (lane & 7) * 4) =
                     *reinterpret_cast<const float4 *>(Tw + rt * 36 + (lane & 7) * 4);
             }
         }
     }
     __syncthreads();
-    if (tid < CI) {
+    if (tid < CI && DM != 1) {
         const float *red = lds;
-        float *st = g.stats + (size_t)blockIdx.x * (IN3 ? 6 : 2) * CI;
+        const int sld = g.stats_ld > 0 ? g.stats_ld : CI;
+        float *st = g.stats + (size_t)blockIdx.x * (IN3 ? 6 : 2) * sld;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             float a = red[k * CI + tid];
@@ -2437,7 +2462,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             if (!IN3 && g.acc_out)
                 fx_add<kFxShiftBwd>(g.acc_out, blockIdx.x % kFxSlots, k, tid, a);
             else
-                st[k * CI + tid] = a;
+                st[k * sld + tid] = a;
         }
         if (IN3) st[5 * CI + tid] = tid < 9 ? red[RB * NST * CI + tid] : 0.f;
     }
@@ -6003,7 +6028,13 @@ static int device_cus()
 
 static bool conv_bwd_fused_shape(int R, int Ci, int Co)
 {
-    return R >= 256 && ((Ci == 64 && (Co == 64 || Co == 128)) || (Ci == 128 && Co == 128));
+    if (R < 256) return false;
+    if ((Ci == 64 && (Co == 64 || Co == 128)) || (Ci == 128 && Co == 128)) return true;
+#if SN_BF16X3
+    // 256 channels on one side (the reconstruction sampler's 128 -> 256 -> 128): two passes of the 128 x 128 kernel
+    if ((Ci == 128 && Co == 256) || (Ci == 256 && Co == 128)) return true;
+#endif
+    return false;
 }
 
 // persistent workgroups: one per CU (each walks over ceil(tiles / groups) 64-row tiles)
@@ -6024,6 +6055,27 @@ static void launch_conv_bwd_bx3_t(const ConvBwdArgs &a, int G, bool fullr, hipSt
     else
         hipLaunchKernelGGL((conv_bwd_bx3_kernel<CI, CO, ZMODE, false>), dim3(G), dim3(512), lds, st, a);
 }
+
+#if SN_BF16X3
+// one pass of the 128 x 128 kernel over a half of a 256-channel side (see conv_bwd_bx3_kernel)
+template <int ZMODE, int GZ, int GP, int GW, int DM>
+static void launch_conv_bwd_bx3_half(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
+{
+    constexpr size_t lds = CbxShape<128, 128>::LDS_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<128, 128, ZMODE, true, false, false, GZ, GP, GW, DM>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<128, 128, ZMODE, false, false, false, GZ, GP, GW, DM>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (fullr)
+        hipLaunchKernelGGL((conv_bwd_bx3_kernel<128, 128, ZMODE, true, false, false, GZ, GP, GW, DM>), dim3(G), dim3(512), lds, st, a);
+    else
+        hipLaunchKernelGGL((conv_bwd_bx3_kernel<128, 128, ZMODE, false, false, false, GZ, GP, GW, DM>), dim3(G), dim3(512), lds, st, a);
+}
+#endif
 
 template <int CI, int CO, int ZMODE>
 static void launch_conv_bwd_fused_t(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
@@ -6068,6 +6120,32 @@ static int launch_conv_bwd_fused(int R, int Ci, int Co, int dz_mode, const float
     a.ntiles = (R + TR - 1) / TR;
     const int G = conv_bwd_fused_groups(R);
     const bool fullr = R % TR == 0;
+#if SN_BF16X3
+    if (Co == 256 || Ci == 256) {
+        a.ntiles = (R + 31) / 32;  // (CbxShape<128, 128>::TR)
+        const bool f32 = R % 32 == 0;
+        for (int hh = 0; hh < 2; ++hh) {
+            ConvBwdArgs b = a;
+            if (Co == 256) {  // halves of the output channels: dZ columns / W rows; the data gradient is the sum of the passes
+                b.dz.z = z + 128 * hh, b.dz.dy = dy + 128 * hh, b.dz.ch = 128;
+                b.dz.k1 = kcoef + 128 * hh, b.dz.k2 = kcoef + 256 + 128 * hh, b.dz.k3 = kcoef + 512 + 128 * hh;
+                b.W = W + (size_t)128 * hh * 128;
+                b.part = part + (size_t)128 * hh * 128, b.part_wg_stride = 256 * 128, b.part_ld = 128;
+                b.dyacc = dyprev;  // (in place: a workgroup reads a tile's raw sums before it stores that tile's result)
+                if (hh == 0) launch_conv_bwd_bx3_half<DZ_BN, 256, 128, 128, 1>(b, G, f32, st);
+                else launch_conv_bwd_bx3_half<DZ_BN, 256, 128, 128, 2>(b, G, f32, st);
+            } else {  // halves of the input channels: W / Zprev / dYprev columns, independent
+                b.W = W + 128 * hh, b.zprev = zprev + 128 * hh, b.dyprev = dyprev + 128 * hh;
+                b.scale_prev = coef_prev + 128 * hh, b.shift_prev = coef_prev + 256 + 128 * hh;
+                b.stats = stats + 128 * hh, b.stats_ld = 256;
+                b.part = part + 128 * hh, b.part_wg_stride = 128 * 256, b.part_ld = 256;
+                if (dz_mode == DZ_BN) launch_conv_bwd_bx3_half<DZ_BN, 128, 256, 256, 0>(b, G, f32, st);
+                else launch_conv_bwd_bx3_half<DZ_POOL, 128, 256, 256, 0>(b, G, f32, st);
+            }
+        }
+        return G;
+    }
+#endif
 #define SN_CBF(CI_, CO_)                                                                       \
     do {                                                                                       \
         if (dz_mode == DZ_BN) launch_conv_bwd_fused_t<CI_, CO_, DZ_BN>(a, G, fullr, st);        \
@@ -6084,7 +6162,7 @@ static bool conv_bwd_fused_ok(int R, int Ci, int Co, int dz_mode, int npts, cons
                               const float *db)
 {
     return !db && coef_prev && kcoef && conv_bwd_fused_shape(R, Ci, Co) &&
-           (dz_mode == DZ_BN || (dz_mode == DZ_POOL && npts > 0 && npts % 64 == 0));
+           (dz_mode == DZ_BN || (dz_mode == DZ_POOL && npts > 0 && npts % 64 == 0 && Co != 256));  // (256 outputs: DZ_BN passes only)
 }
 
 extern "C" int sn_linear_wgrad_splits(int R, int Ci, int Co, int with_bias)

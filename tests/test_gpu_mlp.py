@@ -1226,3 +1226,57 @@ def test_task_features_narrow_backward(B, N):
     ef = float((got["fused"].double() - want).abs().max())
     el = float((got["layers"].double() - want).abs().max())
     assert ef <= max(2 * el, 2e-6 * scale), (ef, el, scale)
+
+
+@pytest.mark.parametrize("Ci,Co,R,mode", [(128, 256, 4096, "bn"), (128, 256, 2090, "bn"), (256, 128, 4096, "bn"), (256, 128, 2090, "bn"),
+                                         (256, 128, 2560, "pool")])
+def test_fused_conv_backward_two_passes_for_256_channels(Ci, Co, R, mode):
+    """The reconstruction sampler's 128 -> 256 -> 128 layers (reconstruction/src/samplers.py:23): a 256-channel side runs as two passes
+    of the fused 128 x 128 backward kernel (output-channel halves: raw partial data gradient + second pass that adds it; input-channel
+    halves: independent) -- sn_linear_backward's dYprev, dW and the (sum dYprev, sum dYprev Zprev) partials against fp64, ragged row
+    counts and the pooled form included."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    torch.manual_seed(Ci + R)
+    dev = "cuda"
+    z = torch.randn(R, Co, device=dev)
+    zprev = torch.randn(R, Ci, device=dev)
+    W = torch.randn(Co, Ci, device=dev) * 0.1
+    kcoef = torch.randn(3, Co, device=dev) * torch.tensor([[1.0], [0.05], [0.01]], device=dev)
+    coef_prev = torch.zeros(4, Ci, device=dev)
+    coef_prev[0] = torch.rand(Ci, device=dev) + 0.5
+    coef_prev[1] = torch.randn(Ci, device=dev) * 0.3
+    npts = 320
+    if mode == "pool":
+        B = R // npts
+        gsel = torch.randn(B, Co, device=dev)
+        argsel = torch.randint(0, npts, (B, Co), device=dev, dtype=torch.int32)
+        dy = None
+        d = torch.zeros(B, npts, Co, device=dev, dtype=torch.float64)
+        d.scatter_(1, argsel.long().unsqueeze(1), gsel.double().unsqueeze(1))
+        d = d.reshape(R, Co)
+        zmode = 2
+    else:
+        dy = torch.randn(R, Co, device=dev)
+        gsel = argsel = None
+        d = dy.double()
+        zmode = 1
+    dyprev = torch.empty(R, Ci, device=dev)
+    nblk = lib.sn_linear_stats_blocks(R)
+    stats = torch.zeros(nblk, 2, Ci, device=dev)
+    part = torch.empty(lib.sn_linear_wgrad_splits(R, Ci, Co, 0) * Co * Ci, device=dev)
+    dW = torch.empty(Co, Ci, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.sn_linear_backward(R, Ci, Co, zmode, ptr(dy), ptr(z), ptr(kcoef), ptr(gsel), ptr(argsel), npts, ptr(W), ptr(zprev),
+                                 ptr(coef_prev), ptr(dyprev), ptr(stats), ptr(part), ptr(dW), st), "sn_linear_backward")
+    k = kcoef.double()
+    dz = k[0] * d + k[1] * z.double() + k[2]
+    pre = coef_prev[0].double() * zprev.double() + coef_prev[1].double()
+    want_dy = (dz @ W.double()) * (pre > 0)
+    want_dw = dz.t() @ torch.relu(pre)
+    s = float(want_dy.abs().max())
+    assert float((dyprev.double() - want_dy).abs().max()) <= 2e-6 * s * (Co ** 0.5)
+    assert float((dW.double() - want_dw).abs().max()) <= 2e-6 * float(want_dw.abs().max()) * (R ** 0.5) / 8
+    got = stats.double().sum(0)
+    want_s = torch.stack([want_dy.sum(0), (want_dy * zprev.double()).sum(0)])
+    assert float((got - want_s).abs().max()) <= 1e-4 * float(want_s.abs().max())
