@@ -5308,7 +5308,10 @@ struct SkinnyArgs {
     float *out2;      // columns n >= nsplit of the output go to out2 (R, N - nsplit); out is then (R, nsplit).  Either may be NULL
     int ksplit, nsplit;
 };
-template <int KSTEPS>
+// RT: 32-row tiles per workgroup (R <= 32 RT): the weight fragments -- the traffic that bounds the layer -- are loaded and split once
+// and multiply every row tile (several task-network evaluations of one step batched into one trunk pass: PCRNet on the progressive
+// sampler's prefixes).
+template <int KSTEPS, int RT>
 __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
 {
     __shared__ __attribute__((aligned(16))) float red[kRsFloats];
@@ -5319,35 +5322,42 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
     const int K = g.K, N = g.N, R = g.R;
     const int kw = g.kslice / 4;                                  // this wave's K range: KSTEPS steps of 16
     const int kb = s * g.kslice + wave * kw;
-    const int m = l31, n = n0 + l31;
-    const bool mok = m < R, nok = n < N;
+    const int n = n0 + l31;
+    const bool nok = n < N;
     const bool kvec = (K & 3) == 0;
     SN_TL(0);
-    float ea[KSTEPS][8], eg[KSTEPS][8], eb[KSTEPS][8];
+    float ea[RT][KSTEPS][8], eg[RT][KSTEPS][8], eb[KSTEPS][8];
 #pragma unroll
     for (int st = 0; st < KSTEPS; ++st) {
         const int k8 = kb + st * 16 + 8 * h;
         const bool full = k8 + 8 <= K && kvec;
-        // A: 8 consecutive k of row m of x (and of the gate)
+        // A: 8 consecutive k of row m of x (and of the gate), for every row tile
         const float *xs = g.x;
         int ldx = K, kx = k8;
         if (g.x2) {  // (ksplit is a multiple of 8: a fragment never straddles the two parts)
             if (k8 >= g.ksplit) xs = g.x2, ldx = K - g.ksplit, kx = k8 - g.ksplit;
             else ldx = g.ksplit;
         }
-        if (full && mok) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(xs + (size_t)m * ldx + kx), v1 = *reinterpret_cast<const float4 *>(xs + (size_t)m * ldx + kx + 4);
-            ea[st][0] = v0.x, ea[st][1] = v0.y, ea[st][2] = v0.z, ea[st][3] = v0.w, ea[st][4] = v1.x, ea[st][5] = v1.y, ea[st][6] = v1.z, ea[st][7] = v1.w;
-            if (g.gate) {
-                const float4 g0 = *reinterpret_cast<const float4 *>(g.gate + (size_t)m * K + k8), g1 = *reinterpret_cast<const float4 *>(g.gate + (size_t)m * K + k8 + 4);
-                eg[st][0] = g0.x, eg[st][1] = g0.y, eg[st][2] = g0.z, eg[st][3] = g0.w, eg[st][4] = g1.x, eg[st][5] = g1.y, eg[st][6] = g1.z, eg[st][7] = g1.w;
-            }
-        } else {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const bool ok = mok && k8 + t < K;
-                ea[st][t] = ok ? xs[(size_t)m * ldx + kx + t] : 0.f;
-                if (g.gate) eg[st][t] = ok ? g.gate[(size_t)m * K + k8 + t] : 0.f;
+        for (int rt = 0; rt < RT; ++rt) {
+            const int m = rt * 32 + l31;
+            const bool mok = m < R;
+            if (full && mok) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(xs + (size_t)m * ldx + kx), v1 = *reinterpret_cast<const float4 *>(xs + (size_t)m * ldx + kx + 4);
+                ea[rt][st][0] = v0.x, ea[rt][st][1] = v0.y, ea[rt][st][2] = v0.z, ea[rt][st][3] = v0.w;
+                ea[rt][st][4] = v1.x, ea[rt][st][5] = v1.y, ea[rt][st][6] = v1.z, ea[rt][st][7] = v1.w;
+                if (g.gate) {
+                    const float4 g0 = *reinterpret_cast<const float4 *>(g.gate + (size_t)m * K + k8), g1 = *reinterpret_cast<const float4 *>(g.gate + (size_t)m * K + k8 + 4);
+                    eg[rt][st][0] = g0.x, eg[rt][st][1] = g0.y, eg[rt][st][2] = g0.z, eg[rt][st][3] = g0.w;
+                    eg[rt][st][4] = g1.x, eg[rt][st][5] = g1.y, eg[rt][st][6] = g1.z, eg[rt][st][7] = g1.w;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const bool ok = mok && k8 + t < K;
+                    ea[rt][st][t] = ok ? xs[(size_t)m * ldx + kx + t] : 0.f;
+                    if (g.gate) eg[rt][st][t] = ok ? g.gate[(size_t)m * K + k8 + t] : 0.f;
+                }
             }
         }
         // B: 8 consecutive k of output column n
@@ -5364,40 +5374,58 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
             for (int t = 0; t < 8; ++t) eb[st][t] = (nok && k8 + t < K) ? g.W[(size_t)(k8 + t) * N + n] : 0.f;  // (lanes: consecutive n)
         }
     }
-    f32x16 acc;
+    f32x16 acc[RT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
 #pragma unroll
     for (int st = 0; st < KSTEPS; ++st) {
-        bf16x8 a[3], b[3];
+        bf16x8 b[3];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const float av = g.gate ? (eg[st][t] > 0.f ? ea[st][t] : 0.f) : ea[st][t];
             __bf16 h1, h2, h3;
-            split3(av, h1, h2, h3);
-            a[0][t] = h1, a[1][t] = h2, a[2][t] = h3;
             split3(eb[st][t], h1, h2, h3);
             b[0][t] = h1, b[1][t] = h2, b[2][t] = h3;
         }
-#define SN_SK_TERM(PA, PB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB], acc, 0, 0, 0)
-        SN_SK_TERM(0, 2);
-        SN_SK_TERM(2, 0);
-        SN_SK_TERM(1, 1);
-        SN_SK_TERM(0, 1);
-        SN_SK_TERM(1, 0);
-        SN_SK_TERM(0, 0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float av = g.gate ? (eg[rt][st][t] > 0.f ? ea[rt][st][t] : 0.f) : ea[rt][st][t];
+                __bf16 h1, h2, h3;
+                split3(av, h1, h2, h3);
+                a[0][t] = h1, a[1][t] = h2, a[2][t] = h3;
+            }
+#define SN_SK_TERM(PA, PB) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB], acc[rt], 0, 0, 0)
+            SN_SK_TERM(0, 2);
+            SN_SK_TERM(2, 0);
+            SN_SK_TERM(1, 1);
+            SN_SK_TERM(0, 1);
+            SN_SK_TERM(1, 0);
+            SN_SK_TERM(0, 0);
 #undef SN_SK_TERM
+        }
     }
     SN_TL(1);
-    // wave w now holds column 8 w + (lane >> 3) of the tile, rows 4 (lane & 7) .. + 3
-    float4 v = wave_reduce_scatter4(acc, red);
+    // wave w now holds column 8 w + (lane >> 3) of each row tile, rows 4 (lane & 7) .. + 3
+    float4 v[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        if (rt > 0) lds_barrier();  // (the exchange area is read by other waves until they pass this point)
+        v[rt] = wave_reduce_scatter4(acc[rt], red);
+    }
     SN_TL(2);
     const int S = g.S;
     typedef float sk4 __attribute__((ext_vector_type(4)));
     if (S > 1) {
-        float *P = g.part + ((size_t)s * gridDim.x + tile) * 1024 + (size_t)tid * 4;
-        const sk4 pv = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(P), "v"(pv) : "memory");
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float *P = g.part + (((size_t)s * gridDim.x + tile) * RT + rt) * 1024 + (size_t)tid * 4;
+            const sk4 pv = {v[rt].x, v[rt].y, v[rt].z, v[rt].w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(P), "v"(pv) : "memory");
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         SN_TL(3);
@@ -5409,27 +5437,29 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
         __syncthreads();
         SN_TL(4);
         if (!s_last) return;
-        sk4 accv = {0.f, 0.f, 0.f, 0.f};
-        for (int q0 = 0; q0 < S; q0 += 8) {  // slices in ascending order, eight loads in flight
-            sk4 r[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int qq = min(q0 + q, S - 1);
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[q]) : "v"(g.part + ((size_t)qq * gridDim.x + tile) * 1024 + (size_t)tid * 4) : "memory");
+        for (int rt = 0; rt < RT; ++rt) {
+            sk4 accv = {0.f, 0.f, 0.f, 0.f};
+            for (int q0 = 0; q0 < S; q0 += 8) {  // slices in ascending order, eight loads in flight
+                sk4 r[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int qq = min(q0 + q, S - 1);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[q]) : "v"(g.part + (((size_t)qq * gridDim.x + tile) * RT + rt) * 1024 + (size_t)tid * 4) : "memory");
+                }
+                // (the loaded registers are operands of the wait: register-only uses of them must not be scheduled above it)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (q0 + q < S) accv = accv + r[q];
             }
-            // (the loaded registers are operands of the wait: register-only uses of them must not be scheduled above it)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q0 + q < S) accv = accv + r[q];
+            v[rt] = make_float4(accv.x, accv.y, accv.z, accv.w);
         }
-        v = make_float4(accv.x, accv.y, accv.z, accv.w);
         SN_TL(5);
     }
     const int col = n0 + wave * 8 + (lane >> 3), r0 = 4 * (lane & 7);
     if (col < N) {
         const float bv = g.bias ? g.bias[col] : 0.f;
-        const float o[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
         float *dst = g.out;
         int ldo = N, c = col;
         if (g.nsplit > 0) {
@@ -5438,8 +5468,12 @@ __global__ void __launch_bounds__(256) skinny_linear_kernel(SkinnyArgs g)
         }
         if (dst)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (r0 + i < R) dst[(size_t)(r0 + i) * ldo + c] = g.relu ? relu_np(o[i]) : o[i];
+            for (int rt = 0; rt < RT; ++rt) {
+                const float o[4] = {v[rt].x + bv, v[rt].y + bv, v[rt].z + bv, v[rt].w + bv};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (rt * 32 + r0 + i < R) dst[(size_t)(rt * 32 + r0 + i) * ldo + c] = g.relu ? relu_np(o[i]) : o[i];
+            }
     }
 }
 
@@ -5458,17 +5492,17 @@ static void skinny_plan(int K, int N, int &S, int &ksteps)
 }
 extern "C" int sn_skinny_linear_supported(int R, int K, int N)
 {
-    if (R < 1 || R > 32 || K < 1 || N < 1) return 0;
+    if (R < 1 || R > 128 || K < 1 || N < 1) return 0;
     int S, ks;
     skinny_plan(K, N, S, ks);
     return ks <= 4;
 }
 extern "C" long long sn_skinny_linear_scratch_bytes(int R, int K, int N)
 {
-    (void)R;
     int S, ks;
     skinny_plan(K, N, S, ks);
-    return (long long)S * ((N + 31) / 32) * 1024 * (long long)sizeof(float);
+    const int rt = R <= 32 ? 1 : R <= 64 ? 2 : 4;
+    return (long long)S * ((N + 31) / 32) * rt * 1024 * (long long)sizeof(float);
 }
 // counters: (N + 31) / 32 zeroed 32-bit words (left zeroed).  transposed != 0: W is (K, N) (the data gradient through a layer
 // whose weight is (Co = K, Ci = N)).
@@ -5491,7 +5525,7 @@ extern "C" int sn_skinny_linear2(int R, int K, int N, const float *x, const floa
     SN_REQUIRE(x && W && scratch && counters, "null pointer");
     SN_REQUIRE(!x2 || (ksplit > 0 && ksplit < K && ksplit % 8 == 0 && !gate), "x2: ksplit must be a multiple of 8 inside (0, K), no gate");
     SN_REQUIRE(nsplit >= 0 && nsplit < N && (nsplit > 0 ? (out || out2) : out != nullptr), "bad output split");
-    if (!sn_skinny_linear_supported(R, K, N)) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_skinny_linear: needs at most 32 rows");
+    if (!sn_skinny_linear_supported(R, K, N)) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_skinny_linear: needs at most 128 rows");
     SkinnyArgs g{};
     g.x = x, g.gate = gate, g.W = W, g.bias = bias, g.out = out, g.part = scratch, g.counter = counters;
     g.R = R, g.K = K, g.N = N, g.wmode = transposed ? 1 : 0, g.relu = relu;
@@ -5501,12 +5535,16 @@ extern "C" int sn_skinny_linear2(int R, int K, int N, const float *x, const floa
     g.kslice = ks * 64;
     const dim3 grid((N + 31) / 32, g.S);
     hipStream_t st = (hipStream_t)stream;
-    if (ks == 1)
-        hipLaunchKernelGGL(skinny_linear_kernel<1>, grid, dim3(256), 0, st, g);
-    else if (ks == 2)
-        hipLaunchKernelGGL(skinny_linear_kernel<2>, grid, dim3(256), 0, st, g);
-    else
-        hipLaunchKernelGGL(skinny_linear_kernel<4>, grid, dim3(256), 0, st, g);
+#define SN_SK_LAUNCH(RT_)                                                                                 \
+    do {                                                                                                  \
+        if (ks == 1) hipLaunchKernelGGL((skinny_linear_kernel<1, RT_>), grid, dim3(256), 0, st, g);       \
+        else if (ks == 2) hipLaunchKernelGGL((skinny_linear_kernel<2, RT_>), grid, dim3(256), 0, st, g);  \
+        else hipLaunchKernelGGL((skinny_linear_kernel<4, RT_>), grid, dim3(256), 0, st, g);               \
+    } while (0)
+    if (R <= 32) SN_SK_LAUNCH(1);
+    else if (R <= 64) SN_SK_LAUNCH(2);
+    else SN_SK_LAUNCH(4);
+#undef SN_SK_LAUNCH
     SN_LAUNCH_CHECK();
     return 0;
 }

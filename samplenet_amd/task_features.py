@@ -385,6 +385,35 @@ class PCRNet(nn.Module):
         network's arithmetic -- runs once."""
         return self.feat(x0)
 
+    def forward_multi(self, x0, x1_list, feat0=None):
+        """forward_with_qnorm for several source clouds against ONE template (the progressive sampler's prefixes) with the FC trunk
+        run once on all of them: the trunk is a stream of 15.5 MB of weights per pass whatever the number of rows, so E evaluations of
+        B clouds cost one pass on E B rows (at most 128) instead of E passes.  -> list of (twist, pre_normalized_quat, qnorm, quat)."""
+        E = len(x1_list)
+        f0 = self.template_features(x0) if feat0 is None else feat0
+        B = f0.shape[0]
+        fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
+        frozen = not any(p.requires_grad for fc in fcs for p in fc.parameters())
+        if not (FUSED_TRUNK and frozen and f0.is_cuda and E * B <= 128 and f0.shape[1] % 8 == 0 and E > 1):
+            return [self.forward_with_qnorm(x0, x1, feat0=f0) for x1 in x1_list]
+        f1 = torch.cat([self.feat(x1) for x1 in x1_list], dim=0)
+        wb = []
+        for fc in fcs:
+            wb += [fc.weight, fc.bias]
+        y = _TrunkFunction.apply(f0.repeat(E, 1), f1, *wb)  # (E B, 7)
+        out = []
+        for e in range(E):
+            ye = y[e * B:(e + 1) * B]
+            if FUSED_HEAD:
+                twist, quat, qnorm = _HeadFunction.apply(ye)
+            else:
+                pre = ye[:, 0:4]
+                quat = torch.nn.functional.normalize(pre, dim=1)
+                qnorm = torch.mean((torch.sum(pre ** 2, dim=1) - 1) ** 2)
+                twist = torch.cat([quat, ye[:, 4:]], dim=1)
+            out.append((twist, ye[:, 0:4], qnorm, quat))
+        return out
+
     def forward_with_qnorm(self, x0, x1, feat0=None):
         """forward() plus the QuaterNet regulariser mean((||pre_normalized_quat||^2 - 1)^2) of registration/main.py:565 and the
         normalised quaternion as a contiguous (B,4) tensor, both of which the output head's kernel produces on the side:
@@ -392,7 +421,7 @@ class PCRNet(nn.Module):
         f0, f1 = (self.feat(x0) if feat0 is None else feat0), self.feat(x1)
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
         frozen = not any(p.requires_grad for fc in fcs for p in fc.parameters())
-        if FUSED_TRUNK and frozen and f0.is_cuda and f0.shape[0] <= 32 and f0.shape[1] % 8 == 0:
+        if FUSED_TRUNK and frozen and f0.is_cuda and f0.shape[0] <= 128 and f0.shape[1] % 8 == 0:
             wb = []
             for fc in fcs:
                 wb += [fc.weight, fc.bias]
@@ -409,6 +438,20 @@ class PCRNet(nn.Module):
         normalized_quat = torch.nn.functional.normalize(pre_normalized_quat, dim=1)
         qnorm = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
         return torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat, qnorm, normalized_quat
+
+
+def pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features=None):
+    """pcrnet_chamfer_loss for several source clouds against one template, the network evaluated by model.forward_multi (one
+    trunk pass for all of them).  -> list of (chamfer_loss, qnorm_loss, twist)."""
+    from .ops import chamfer_mean_loss
+
+    if not hasattr(model, "forward_multi"):
+        return [pcrnet_chamfer_loss(model, p0, p1, template_features) for p1 in p1_list]
+    out = []
+    for p1, (twist, _pre, qnorm, quat) in zip(p1_list, model.forward_multi(p0, p1_list, feat0=template_features)):
+        p1_est = qrot_cloud(quat, p0)
+        out.append((chamfer_mean_loss(p1.contiguous(), p1_est.contiguous()), qnorm, twist))
+    return out
 
 
 def qrot(q, v):

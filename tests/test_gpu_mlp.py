@@ -1192,6 +1192,25 @@ def test_pcrnet_shared_template_features():
     assert torch.equal(plain, shared)
     for a, b in zip(gp, gs):
         assert torch.equal(a, b)
+    # ... and with the FC trunk run ONCE on all evaluations' rows (3 x 8 = 24 -> one row tile; the K-slice sums see the same operands
+    # in the same order, so nothing changes), then on 3 x 32 = 96 rows (three row tiles per workgroup)
+    from samplenet_amd.task_features import pcrnet_chamfer_loss_multi
+
+    multi = sum(t for t, _, _ in pcrnet_chamfer_loss_multi(pcr, template, qs, template_features=f0))
+    gm = torch.autograd.grad(multi, qs)
+    assert torch.equal(plain, multi)
+    for a, b in zip(gp, gm):
+        assert torch.equal(a, b)
+    t32 = torch.rand(32, 1024, 3, device="cuda") - 0.5
+    q32 = [(torch.rand(32, m, 3, device="cuda") - 0.5).requires_grad_(True) for m in (32, 64, 128)]
+    one = [pcrnet_chamfer_loss(pcr, t32, q) for q in q32]
+    many = pcrnet_chamfer_loss_multi(pcr, t32, q32)
+    for (la, qa, ta), (lb, qb, tb) in zip(one, many):
+        assert torch.equal(la, lb) and torch.equal(qa, qb) and torch.equal(ta, tb)
+    ga = torch.autograd.grad(sum(l for l, _, _ in one), q32)
+    gb = torch.autograd.grad(sum(l for l, _, _ in many), q32)
+    for a, b in zip(ga, gb):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("B,N", [(32, 64), (4, 256), (3, 50), (2, 1024)])
