@@ -232,11 +232,12 @@ int sn_conv_backward_partials(int R, int Ci, int Co, int dz_mode, const float *d
  *                               clear and a decode launch): pooled (B,Co) = relu(max_n Z), argsel / zsel (optional) as
  *                               sn_pool_forward; z (R,Co) optional -- NULL: the activations are never written (a branch
  *                               that needs no gradient).  coef_prev: the previous layer's (scale, shift) = (1, 0) table.
- *                               keys: B * 2 * Co 64-bit words of scratch.  Query _supported (64-aligned shapes). */
+ *                               keys: B * 2 * Co 64-bit words of scratch, cleared here unless keys_cleared != 0 (an earlier launch
+ *                               on the stream did: sn_pointnet_narrow_forward's zero_keys).  Query _supported (64-aligned shapes). */
 int sn_linear_forward_maxpool_supported(int R, int Ci, int Co, int npts);
 int sn_linear_forward_maxpool(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
                               const float *bias, float *z, unsigned long long *keys, float *pooled, int *argsel, float *zsel,
-                              sn_stream_t stream);
+                              int keys_cleared, sn_stream_t stream);
 
 /*   sn_linear_forward_maxpool_wide   the same for a WIDE last layer (PCRNet: 128 -> 1024): a workgroup keeps the split A fragments
  *                               of its 128 rows in registers for all of its columns, the weights are split once per call into
@@ -261,11 +262,13 @@ int sn_pool_dgrad_sparse(int B, int npts, int Ci, int Co, const float *g, const 
  *                               registration/models/pcrnet.py:23-38) in one launch: a wave takes 32 rows through all four layers;
  *                               every layer's pre-activations bit-identical to the layer-by-layer launches.  z1..z3 (R,64): all
  *                               three (a backward will read them) or none; z4 (R,128).  wplanes: 3 * 16384 bf16 for the split
- *                               weights (planes_ready != 0: already holds the split of these weights). */
+ *                               weights (planes_ready != 0: already holds the split of these weights).  zero_keys / zero_n: optional
+ *                               rider -- that many 64-bit words are cleared (the key scratch of the sn_linear_forward_maxpool
+ *                               that follows). */
 int sn_pointnet_narrow_forward_supported(int R, int c1, int c2, int c3, int c4);
 int sn_pointnet_narrow_forward(int R, const float *x, const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
                                const float *b3, const float *W4, const float *b4, void *wplanes, int planes_ready, float *z1, float *z2,
-                               float *z3, float *z4, sn_stream_t stream);
+                               float *z3, float *z4, unsigned long long *zero_keys, int zero_n, sn_stream_t stream);
 
 /*   sn_pointnet_narrow_backward the data gradient back through that front in one launch (frozen weights): dx (R,3) from dz4 (R,128) =
  *                               dL/d(conv4's pre-activations) and the saved z1..z3; wplanes_t: 3 * 16384 bf16 for the transposed split

@@ -91,12 +91,12 @@ PROTOTYPES = {
     "sn_fc_chain_backward_supported": [_i, _i, _vp, _vp],
     "sn_fc_chain_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_forward_maxpool_supported": [_i, _i, _i, _i],
-    "sn_linear_forward_maxpool": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_linear_forward_maxpool": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sn_linear_forward_maxpool_wide_supported": [_i, _i, _i, _i],
     "sn_linear_forward_maxpool_wide_scratch_bytes": [_i, _i, _i, _i],
     "sn_linear_forward_maxpool_wide": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sn_pointnet_narrow_forward_supported": [_i, _i, _i, _i, _i],
-    "sn_pointnet_narrow_forward": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "sn_pointnet_narrow_forward": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sn_pointnet_narrow_backward_supported": [_i, _i, _i, _i, _i],
     "sn_pointnet_narrow_backward": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sn_skinny_linear_supported": [_i, _i, _i],

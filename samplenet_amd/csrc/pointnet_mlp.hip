@@ -4533,7 +4533,7 @@ extern "C" int sn_linear_forward_maxpool_supported(int R, int Ci, int Co, int np
 
 extern "C" int sn_linear_forward_maxpool(int R, int Ci, int Co, int npts, const float *ain, const float *coef_prev, const float *W,
                                          const float *bias, float *z, unsigned long long *keys, float *pooled, int *argsel,
-                                         float *zsel, sn_stream_t stream)
+                                         float *zsel, int keys_cleared, sn_stream_t stream)
 {
     SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1 && npts >= 1, "bad size");
     SN_REQUIRE(ain && W && keys && pooled && coef_prev, "null pointer");
@@ -4541,8 +4541,10 @@ extern "C" int sn_linear_forward_maxpool(int R, int Ci, int Co, int npts, const 
         return sn_set_error(SN_ERR_UNSUPPORTED, "sn_linear_forward_maxpool: needs 64-aligned rows per cloud / channels");
     hipStream_t st = (hipStream_t)stream;
     const int B = R / npts;
-    const hipError_t e = hipMemsetAsync(keys, 0, (size_t)B * 2 * Co * sizeof(unsigned long long), st);
-    if (e != hipSuccess) return sn_set_error((int)e, "%s: %s", __func__, hipGetErrorString(e));
+    if (!keys_cleared) {  // (keys_cleared: an earlier launch on the stream zeroed them -- sn_pointnet_narrow_forward's rider)
+        const hipError_t e = hipMemsetAsync(keys, 0, (size_t)B * 2 * Co * sizeof(unsigned long long), st);
+        if (e != hipSuccess) return sn_set_error((int)e, "%s: %s", __func__, hipGetErrorString(e));
+    }
     FwdArgs g{};
     g.a = make_act(ain, coef_prev, R, Ci);
     g.w.w = W, g.w.co = Co, g.w.ci = Ci;
@@ -4834,6 +4836,8 @@ struct NarrowArgs {
     const __bf16 *P2, *P3, *P4;  // [3][64][64], [3][64][64], [3][128][64]
     float *z1, *z2, *z3, *z4;
     int R;
+    unsigned long long *zero_keys;  // rider: a scratch the NEXT launch wants cleared (the pooled layer's per-cloud keys), zero_n words
+    int zero_n;
 };
 struct SplitJob3 {
     const float *w[3];
@@ -4863,6 +4867,8 @@ __global__ void __launch_bounds__(256) pointnet_narrow_fwd_kernel(NarrowArgs g)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *T = Tall + wave * (32 * PT);
     SN_TL(0);
+    if (g.zero_keys)
+        for (int i = blockIdx.x * 256 + tid; i < g.zero_n; i += gridDim.x * 256) g.zero_keys[i] = 0ull;
     // stage the planes (straight 16-byte copies: global [3][Co][64] -> LDS [3][Co][PW]) and conv1's weights
     {
         // (all 24 loads of a thread in flight before the first LDS store: one memory round trip, not one per item)
@@ -5042,7 +5048,8 @@ extern "C" int sn_pointnet_narrow_forward_supported(int R, int c1, int c2, int c
 // all three or none (NULL: not written); z4 (R,128).
 extern "C" int sn_pointnet_narrow_forward(int R, const float *x, const float *W1, const float *b1, const float *W2, const float *b2,
                                           const float *W3, const float *b3, const float *W4, const float *b4, void *wplanes,
-                                          int planes_ready, float *z1, float *z2, float *z3, float *z4, sn_stream_t stream)
+                                          int planes_ready, float *z1, float *z2, float *z3, float *z4, unsigned long long *zero_keys,
+                                          int zero_n, sn_stream_t stream)
 {
     SN_REQUIRE(R >= 1 && x && W1 && W2 && W3 && W4 && wplanes && z4, "bad argument");
     SN_REQUIRE((z1 && z2 && z3) || (!z1 && !z2 && !z3), "z1..z3: all three or none");
@@ -5052,7 +5059,7 @@ extern "C" int sn_pointnet_narrow_forward(int R, const float *x, const float *W1
         SplitJob3 job{{W2, W3, W4}, {P2, P3, P4}, {64 * 64, 64 * 64, 128 * 64}};
         hipLaunchKernelGGL(split_planes3_kernel, dim3(128 * 64 / 256, 3), dim3(256), 0, st, job);
     }
-    NarrowArgs g{x, W1, b1, b2, b3, b4, P2, P3, P4, z1, z2, z3, z4, R};
+    NarrowArgs g{x, W1, b1, b2, b3, b4, P2, P3, P4, z1, z2, z3, z4, R, zero_keys, zero_keys ? zero_n : 0};
     const size_t lds = (size_t)(2 * 3 * 64 * 72 + 3 * 128 * 72) * 2 + 64 * 4 * 4 + 4 * 32 * 68 * 4;
     static bool attr = false;
     if (!attr) {

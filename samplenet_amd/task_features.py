@@ -107,15 +107,23 @@ class _FeaturesFunction(torch.autograd.Function):
             zsel = torch.empty(B, C, device=dev, dtype=torch.float32)
             nl = len(Ws)
             first = 0
+            tile_keys = None
             if (FUSE_NARROW and nl == 5 and Ws[0].shape[1] == 3 and all(W.shape[1] == Wp.shape[0] for Wp, W in zip(Ws[:3], Ws[1:4]))
                     and lib.sn_pointnet_narrow_forward_supported(R, *[W.shape[0] for W in Ws[:4]])):
                 # conv1..conv4 in one launch; their pre-activations are kept only where a backward will read them
                 planes, ready = _weight_planes(Ws[1], Ws[2], Ws[3])
                 z123 = [torch.empty(R, 64, device=dev, dtype=torch.float32) if need_grad else None for _ in range(3)]
                 z4 = torch.empty(R, 128, device=dev, dtype=torch.float32)
+                # (rider: the key scratch of the pooled layer's tile kernel, where that one follows, is cleared by this launch)
+                Cl, Cil = Ws[4].shape
+                tile_keys = None
+                if (FUSE_MAXPOOL and lib.sn_linear_forward_maxpool_supported(R, Cil, Cl, N)
+                        and not (WIDE_MAXPOOL and lib.sn_linear_forward_maxpool_wide_supported(R, Cil, Cl, N))):
+                    tile_keys = torch.empty(B * 2 * Cl, device=dev, dtype=torch.int64)
                 check(lib.sn_pointnet_narrow_forward(R, ptr(a_in), ptr(Ws[0]), ptr(bs[0]), ptr(Ws[1]), ptr(bs[1]), ptr(Ws[2]),
                                                      ptr(bs[2]), ptr(Ws[3]), ptr(bs[3]), ptr(planes), int(ready), ptr(z123[0]),
-                                                     ptr(z123[1]), ptr(z123[2]), ptr(z4), st), "sn_pointnet_narrow_forward")
+                                                     ptr(z123[1]), ptr(z123[2]), ptr(z4), ptr(tile_keys),
+                                                     tile_keys.numel() if tile_keys is not None else 0, st), "sn_pointnet_narrow_forward")
                 zs = z123 + [z4]
                 idents = [_ident(W.shape[0], z4) for W in Ws[:4]]
                 a_in, coef_prev, first = z4, idents[-1], 4
@@ -139,9 +147,9 @@ class _FeaturesFunction(torch.autograd.Function):
                                                                  ptr(zsel) if need_grad else None, ptr(planes), int(ready), st),
                               "sn_linear_forward_maxpool_wide")
                     else:
-                        keys = torch.empty(B * 2 * Co, device=dev, dtype=torch.int64)
+                        keys = tile_keys if tile_keys is not None else torch.empty(B * 2 * Co, device=dev, dtype=torch.int64)
                         check(lib.sn_linear_forward_maxpool(R, Ci, Co, N, ptr(a_in), ptr(coef_prev), ptr(W), ptr(b), ptr(z),
-                                                            ptr(keys), ptr(pooled), ptr(argsel), ptr(zsel), st),
+                                                            ptr(keys), ptr(pooled), ptr(argsel), ptr(zsel), int(tile_keys is not None), st),
                               "sn_linear_forward_maxpool")
                     zs.append(z)
                     idents.append(_ident(Co, pooled))
@@ -324,6 +332,7 @@ class _TrunkFunction(torch.autograd.Function):
         ctx.save_for_backward(*acts[:-1], *Ws)
         ctx.nl = len(Ws)
         ctx.n0 = f0.shape[1]
+        ctx.sc = sc  # (the backward's launches reuse the pair: the counters are back at zero)
         return x
 
     @staticmethod
@@ -332,7 +341,7 @@ class _TrunkFunction(torch.autograd.Function):
         acts, Ws = ctx.saved_tensors[:nl - 1], ctx.saved_tensors[nl - 1:]
         g = g.contiguous().float()
         with torch.cuda.device(g.device):
-            sc = _trunk_scratch(g.shape[0], Ws, g)
+            sc = ctx.sc if ctx.sc[0].device == g.device else _trunk_scratch(g.shape[0], Ws, g)
             for i in range(nl - 1, 0, -1):  # dX = (dY . [y_i > 0]) W_i; the last layer has no ReLU
                 g = _skinny(g, acts[i] if i < nl - 1 else None, Ws[i], True, None, False, scratch=sc)
             g0, g1 = _skinny(g, acts[0], Ws[0], True, None, False, split_out=(ctx.n0, ctx.needs_input_grad[0], ctx.needs_input_grad[1]),
@@ -355,6 +364,7 @@ class _HeadFunction(torch.autograd.Function):
         with torch.cuda.device(y.device):
             check(lib.sn_pcrnet_head_forward(B, ptr(y), ptr(twist), ptr(quat), ptr(qnorm), _st(y)), "sn_pcrnet_head_forward")
         ctx.save_for_backward(y)
+        ctx.set_materialize_grads(False)  # (an unused output's gradient arrives as None, not as a zero-filled tensor: a fill launch each)
         return twist, quat, qnorm
 
     @staticmethod
