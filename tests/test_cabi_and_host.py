@@ -176,3 +176,41 @@ def test_bench_profile_provenance_helpers():
     if prov["src_sha16"] is not None:
         assert prov["stale"] == (prov["src_sha16"] != sha)
     assert bench.geometry_bytes_fwd(1024, 64, 8) == 24576  # SURVEY 8d's figure
+
+
+def test_weight_plane_cache_semantics(monkeypatch):
+    """task_features._weight_planes (host logic, no kernel): the scratch for the split weight planes is reused while the parameter
+    OBJECT and its version counter are unchanged, flagged stale after an in-place update, separate per tag (transposed planes),
+    never reported ready while a stream capture is under way, and dropped when another parameter object takes an old one's id."""
+    import gc
+
+    import torch
+
+    from samplenet_amd import task_features as TF
+
+    capturing = {"on": False}
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing["on"])
+    TF._PLANES.clear()
+    W = torch.nn.Parameter(torch.randn(8, 4))
+    p1, r1 = TF._weight_planes(W.reshape(8, 4))
+    p2, r2 = TF._weight_planes(W.reshape(8, 4))  # another view object of the same parameter
+    assert not r1 and r2 and p1 is p2 and p1.numel() == 3 * 32 and p1.dtype == torch.bfloat16
+    with torch.no_grad():
+        W.mul_(2.0)
+    p3, r3 = TF._weight_planes(W.reshape(8, 4))
+    assert p3 is p1 and not r3  # same scratch, contents stale
+    assert TF._weight_planes(W.reshape(8, 4))[1]
+    pt, rt = TF._weight_planes(W.reshape(8, 4), tag="T")
+    assert pt is not p1 and not rt
+    capturing["on"] = True
+    pc, rc = TF._weight_planes(W.reshape(8, 4))
+    assert pc is p1 and not rc  # a capture always records the split
+    capturing["on"] = False
+    W2, W3 = torch.nn.Parameter(torch.randn(8, 4)), torch.nn.Parameter(torch.randn(8, 4))
+    pm, rm = TF._weight_planes(W2, W3)
+    assert pm.numel() == 3 * 64 and not rm and TF._weight_planes(W2, W3)[1]
+    n_before = len(TF._PLANES)
+    del W2, W3
+    gc.collect()
+    TF._weight_planes(torch.nn.Parameter(torch.randn(2, 2)))  # (a new entry sweeps those whose parameters are gone)
+    assert len(TF._PLANES) <= n_before
