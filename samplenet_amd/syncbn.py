@@ -51,6 +51,14 @@ class DistComm:
 def convert_sync_batchnorm(net, process_group=None, comm=None):
     """Switch the sampler's head to batch statistics over all ranks (training mode only; eval uses the running statistics as
     always).  Returns net.  comm: a communicator with all_gather / all_reduce_sum / world (default: DistComm(process_group))."""
+    last = "bn_fc%d" % getattr(net, "num_fc_layers", 4)
+    last_bn = getattr(net, last, None)
+    if last_bn is not None and not isinstance(last_bn, torch.nn.SyncBatchNorm):
+        # the classification sampler's BatchNorm on the head's OUTPUT is a torch module (pointnet_head applies it): torch's own
+        # synchronised form takes its place (same parameter / buffer names)
+        if comm is not None:
+            raise NotImplementedError("convert_sync_batchnorm: the output BatchNorm (%s) needs a torch.distributed process group" % last)
+        setattr(net, last, torch.nn.SyncBatchNorm.convert_sync_batchnorm(last_bn, process_group))
     net.__dict__["_sn_sync_bn"] = comm if comm is not None else DistComm(process_group)
     return net
 
