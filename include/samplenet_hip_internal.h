@@ -253,7 +253,7 @@ int sn_linear_forward_maxpool_wide(int R, int Ci, int Co, int npts, const float 
  *                               channel): dyprev (B*npts, Ci) = relu'_prev . sum_c [argsel[b][c] == n] (pooled > 0 ? g : 0)[b][c]
  *                               W[c][:] -- sn_pool_backward + sn_linear_dgrad(DZ_POOL) without the dense (R, Co) operand.
  *                               zprev / coef_prev (scale | shift): the previous layer's pre-activations and operand
- *                               coefficients for its ReLU mask (NULL: no mask).  Deterministic.  Query _supported (npts <= 64). */
+ *                               coefficients for its ReLU mask (NULL: no mask).  Deterministic.  Query _supported (npts <= 256). */
 int sn_pool_dgrad_sparse_supported(int B, int npts, int Ci, int Co);
 int sn_pool_dgrad_sparse(int B, int npts, int Ci, int Co, const float *g, const float *pooled, const int *argsel, const float *W,
                          const float *zprev, const float *coef_prev, float *dyprev, sn_stream_t stream);

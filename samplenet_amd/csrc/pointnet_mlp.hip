@@ -5559,7 +5559,7 @@ extern "C" int sn_skinny_linear2(int R, int K, int N, const float *x, const floa
 // ---- data gradient of that last layer when its dZ is SPARSE (BatchNorm-free stack: dZ = dY through the max over the points has one
 // non-zero per cloud and channel -- the pooled element; with a BatchNorm the k2 Z + k3 terms make it dense and the GEMM kernels
 // apply).  dYprev[b, n, :] = relu'_prev . sum over the channels c whose maximum sits at point n of  gsel[b][c] * W[c][:],
-// gsel = pooled > 0 ? g : 0 (the pooling backward, folded in).  One workgroup per (cloud, 32 input channels): 16 groups of 32
+// gsel = pooled > 0 ? g : 0 (the pooling backward, folded in).  One workgroup per (cloud, 32 input channels, 64 rows): 16 groups of 32
 // lanes (two per wave); group q adds its channels (c = q, q + 16, ...: ascending) into its own copy of the cloud's (npts <= 64) x 32
 // tile in LDS -- a lane is the only writer of its column of its copy, so the read-modify-writes need no atomics and their order
 // is fixed; the 16 copies are summed in group order: deterministic, no workgroup talks to another.  The (row, gradient) pairs of
@@ -5574,6 +5574,7 @@ __global__ void __launch_bounds__(kPdsThreads) pool_dgrad_sparse_kernel(int npts
 {
     __shared__ __attribute__((aligned(16))) float lds[8 * kPdsPts * 64];  // [wave][row][half][32]
     const int b = blockIdx.x, ci0 = blockIdx.y * kPdsCi;
+    const int r0 = blockIdx.z * kPdsPts, nch = min(kPdsPts, npts - r0);  // this workgroup's rows of the cloud (clouds of up to 256 points)
     const int lane = threadIdx.x & 63, l = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave * 2 + hh;
@@ -5601,8 +5602,8 @@ __global__ void __launch_bounds__(kPdsThreads) pool_dgrad_sparse_kernel(int npts
             if (c < Co) {
                 const int nn = argsel[bo + c];
                 const float gv = pooled[bo + c] > 0.f ? g[bo + c] : 0.f;  // (the pooling backward: sn_pool_backward's expression)
-                const bool in = (unsigned)nn < (unsigned)npts;
-                nv = in ? nn : 0, vv = in ? gv : 0.f;
+                const bool in = (unsigned)(nn - r0) < (unsigned)nch;
+                nv = in ? nn - r0 : 0, vv = in ? gv : 0.f;
             }
         }
 #pragma unroll
@@ -5610,19 +5611,20 @@ __global__ void __launch_bounds__(kPdsThreads) pool_dgrad_sparse_kernel(int npts
             const int na = __builtin_amdgcn_readlane(nv, k), nb = __builtin_amdgcn_readlane(nv, 32 + k);
             const float va = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), k)),
                         vb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), 32 + k));
+            if (va == 0.f && vb == 0.f) continue;  // (scalars: neither half-wave's channel has its maximum in this workgroup's rows)
             float *o = out + (hh ? nb : na) * 64;
             *o = fmaf(hh ? vb : va, w[k], *o);
         }
     }
     __syncthreads();
     const float *sc = coef_prev, *sh = coef_prev ? coef_prev + Ci : nullptr;
-    for (int e = threadIdx.x; e < npts * kPdsCi; e += kPdsThreads) {
+    for (int e = threadIdx.x; e < nch * kPdsCi; e += kPdsThreads) {
         const int n = e >> 5, col = e & 31;
         float a = 0.f;
 #pragma unroll
         for (int q = 0; q < kPdsGroups; ++q) a += lds[(q >> 1) * (kPdsPts * 64) + n * 64 + (q & 1) * 32 + col];
         if (ci0 + col < Ci) {
-            const size_t o = ((size_t)b * npts + n) * Ci + ci0 + col;
+            const size_t o = ((size_t)b * npts + r0 + n) * Ci + ci0 + col;
             if (zprev) a = fmaf(zprev[o], sc ? sc[ci0 + col] : 1.f, sh ? sh[ci0 + col] : 0.f) > 0.f ? a : 0.f;
             dyprev[o] = a;
         }
@@ -5631,15 +5633,15 @@ __global__ void __launch_bounds__(kPdsThreads) pool_dgrad_sparse_kernel(int npts
 
 extern "C" int sn_pool_dgrad_sparse_supported(int B, int npts, int Ci, int Co)
 {
-    return B >= 1 && npts >= 1 && npts <= kPdsPts && Ci >= 1 && Co >= 1;
+    return B >= 1 && npts >= 1 && npts <= 4 * kPdsPts && Ci >= 1 && Co >= 1;  // (beyond 256 points the dense kernels are ahead)
 }
 extern "C" int sn_pool_dgrad_sparse(int B, int npts, int Ci, int Co, const float *g, const float *pooled, const int *argsel,
                                     const float *W, const float *zprev, const float *coef_prev, float *dyprev, sn_stream_t stream)
 {
     SN_REQUIRE(g && pooled && argsel && W && dyprev, "null pointer");
     if (!sn_pool_dgrad_sparse_supported(B, npts, Ci, Co))
-        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pool_dgrad_sparse: needs at most 64 points per cloud");
-    hipLaunchKernelGGL(pool_dgrad_sparse_kernel, dim3(B, (Ci + kPdsCi - 1) / kPdsCi), dim3(kPdsThreads), 0, (hipStream_t)stream, npts, Ci,
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pool_dgrad_sparse: needs at most 256 points per cloud");
+    hipLaunchKernelGGL(pool_dgrad_sparse_kernel, dim3(B, (Ci + kPdsCi - 1) / kPdsCi, (npts + kPdsPts - 1) / kPdsPts), dim3(kPdsThreads), 0, (hipStream_t)stream, npts, Ci,
                        Co, g, pooled, argsel, W, zprev, coef_prev, dyprev);
     SN_LAUNCH_CHECK();
     return 0;

@@ -975,9 +975,10 @@ def test_task_features_fused_maxpool_equals_the_layer_by_layer_route(B, N, bneck
                 assert float((a - b).norm()) <= 1e-6 * float(b.norm()) + 1e-9
 
 
-@pytest.mark.parametrize("B,N,bneck", [(32, 64, 1024), (5, 64, 512), (3, 40, 1024), (2, 17, 64)])
+@pytest.mark.parametrize("B,N,bneck", [(32, 64, 1024), (5, 64, 512), (3, 40, 1024), (2, 17, 64), (8, 128, 1024), (4, 256, 1024), (3, 200, 512)])
 def test_task_features_sparse_pool_dgrad(B, N, bneck):
-    """Frozen PointNetFeatures with at most 64 points per cloud (the sampled cloud of the registration step): the last layer's data
+    """Frozen PointNetFeatures with at most 256 points per cloud (the sampled cloud of the registration step, the progressive
+    sampler's prefixes): the last layer's data
     gradient from its one non-zero per cloud and channel (sn_pool_dgrad_sparse, pooling backward folded in, no (B N, bottleneck)
     activation tensor at all) against the dense DZ_POOL GEMM route and against torch in fp64; run to run bit-identical (fixed
     summation order: sixteen channel groups, each ascending, summed in group order)."""
