@@ -1,4 +1,4 @@
-"""PointNetFeatures of the registration task network on the HIP MLP kernels.
+"""The registration task network -- PointNetFeatures, PCRNet, its Chamfer loss -- on HIP kernels.
 
 Drop-in for `registration/models/pcrnet.py:8-41` (same constructor, parameter names conv1..conv5 -> state_dict
 compatible): five 1x1 convolutions 3 -> 64 -> 64 -> 64 -> 128 -> bottleneck with ReLU and NO BatchNorm, then the max over
@@ -29,7 +29,7 @@ FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch
 FUSE_NARROW = True         # conv1..conv4 (3 -> 64 -> 64 -> 64 -> 128) as one launch (sn_pointnet_narrow_forward)
 WIDE_MAXPOOL = True        # ... as the wide kernel (A fragments resident, pre-split weight planes) where the shape allows
 FUSED_HEAD = True          # quaternion normalisation + regulariser as one launch (sn_pcrnet_head_*), else the torch op chain
-FUSED_TRUNK = True         # frozen FC trunk on <= 32 rows through sn_skinny_linear (forward and data gradient), else torch.nn.Linear
+FUSED_TRUNK = True         # frozen FC trunk on <= 128 rows through sn_skinny_linear (forward and data gradient), else torch.nn.Linear
 SPARSE_POOL_DGRAD = True   # last layer's data gradient from the one non-zero per cloud and channel (sn_pool_dgrad_sparse)
 
 _CONST = {}  # (rows, channels, device) -> constant coefficient table, built once (never written afterwards)
@@ -313,7 +313,7 @@ def _skinny(x, gate, W, transposed, bias, relu, x2=None, split_out=None, scratch
 
 
 class _TrunkFunction(torch.autograd.Function):
-    """PCRNet's FC trunk with FROZEN weights on at most 32 rows: [f0 | f1] -> fc1 .. fc5 (ReLU) -> fc6, six sn_skinny_linear launches
+    """PCRNet's FC trunk with FROZEN weights on at most 128 rows: [f0 | f1] -> fc1 .. fc5 (ReLU) -> fc6, six sn_skinny_linear launches
     forward and six for the data gradient (registration/models/pcrnet.py:56-77 as rocBLAS GEMMs + ReLU / mask kernels: 22 launches).
     The two clouds' feature vectors are read where they lie and each receives its own gradient tensor (no cat / slice copies)."""
 
