@@ -280,9 +280,10 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
     """Secondary legs: what a user of the drop-in module surface gets with a REAL task loss (registration/main.py:507-531 +
     557-577: frozen PCRNet + Chamfer on the projected points), driver-timed:
       eager_mean_proj -- the headline's own step (task term mean(proj)) through the plain module surface: simp, proj = net(x);
-                alpha*get_simplification_loss + lmbda*get_projection_loss + proj.mean(); backward() -- op by op from Python
-                (host-bound: what an unmodified train script gets without the engine);
-      eager  -- the same with the PCRNet task loss;
+                alpha*get_simplification_loss + lmbda*get_projection_loss + proj.mean(); backward() -- what an unmodified
+                train script gets without the engine: since round 4 those calls replay two captured graphs (surface.py);
+      eager  -- the same with the PCRNet task loss (the task network's own launches stay op by op);
+      op_by_op_mean_proj / op_by_op -- the two legs above with graph_surface = False (every call launched from Python);
       graph  -- engine.SamplerTrainStep(task_loss=...) captured once and replayed: the fused single-node step with the task
                 loss OUTSIDE the node -- proj is a differentiable output, the task gradient re-enters the loss backward as an
                 explicit tensor (same scan, fc4 inside the scan, deferred tail as the headline);
@@ -332,12 +333,27 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
         return loss
 
     out = {}
+    # the script's calls op by op (graph_surface off: what every round before the captured surface measured) ...
+    net.graph_surface = False
     ms, loss = _wall_ms(eager_mean_proj_step, max(steps, 200))
     assert torch.isfinite(loss).item()
-    out["eager_mean_proj"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
+    out["op_by_op_mean_proj"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
     ms, loss = _wall_ms(eager_step, steps)
     assert torch.isfinite(loss).item()
-    out["eager"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
+    out["op_by_op"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
+    # ... and the SAME unmodified calls on the captured surface (samplenet_amd/surface.py: two hipGraphs behind net(x), the loss
+    # getters and backward(); the default)
+    net.graph_surface = True
+    ms, loss = _wall_ms(eager_mean_proj_step, max(steps, 400))
+    assert torch.isfinite(loss).item()
+    net.check()
+    from samplenet_amd import surface
+
+    captured = any(isinstance(p, surface._Plan) for p in net.__dict__.get("_sn_surface", {}).values())
+    out["eager_mean_proj"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms, "captured_surface": captured}
+    ms, loss = _wall_ms(eager_step, max(steps, 200))
+    assert torch.isfinite(loss).item()
+    out["eager"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms, "captured_surface": captured}
     for name, kw in (("graph", dict(task_loss=task)), ("graph_general", dict(task_loss=task, fused_loss=False)),
                      ("general_path_mean_proj", dict(task_loss=lambda p: p.mean()))):
         gnet = replica()

@@ -68,10 +68,25 @@ int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float *P, int p_
                               const int *idx_q, void *colmin_keys, const float *qpart, const void *qmax, int G,
                               const float *temperature, float min_sigma, float alpha, float lmbda, float weight,
                               const float *grad_loss, float *grad_Q, float *gsig_scratch, float *grad_T, float *dpsum,
-                              float *loss, sn_stream_t stream, void *deferred_tail, const float *grad_proj);
+                              float *loss, sn_stream_t stream, void *deferred_tail, const float *grad_proj,
+                              const float *grad_sigma);
 /* grad_proj (B,M,3), optional: gradient of a task loss that lives OUTSIDE this node w.r.t. the projected points (the task
  * network of registration/main.py:507-531 sits on proj); the loss value then carries no mean(proj) term.  NULL: the
  * benchmark's stand-in term mean(proj) is part of the loss and its gradient grad_loss / (3 B M) is implicit. */
+/* grad_sigma (1 float, optional): upstream gradient of sigma = max(T^2, min_sigma) as an OUTPUT of the caller's node (the
+ * drop-in surface: the script forms lmbda * get_projection_loss() itself); grad_T's direct term is then grad_sigma * d sigma / dT
+ * instead of lmbda * grad_loss * d sigma / dT. */
+/* The drop-in module surface on captured work (samplenet_amd/surface.py; registration/main.py:507-531 calls net(x), the two
+ * loss getters and backward() itself): values of L_simp and sigma right behind sn_pairscan_forward_keys -- values[0] = L_simp
+ * (samplenet.py:171-181 with `weight` = gamma + delta * pc_size), [1] = sigma, [2..4] = mean dist_q, mean_b max_m dist_q,
+ * mean dist_p; simp_bnc (optional): y_bcn (B,3,M) transposed to (B,M,3); dpsum: B floats of scratch; the key table is read,
+ * not reset.  sn_surface_gather_upstream: the node's three upstream gradients (each optional: NULL = zero) into the static
+ * operands of the captured backward: scalars[0] = d / d L_simp, scalars[1] = d / d sigma, proj_out (nproj floats). */
+int sn_surface_values_keys(int B, int N, int M, int G, const void *colmin_keys, const float *qpart, const void *qmax,
+                           const float *temperature, float min_sigma, float weight, const float *y_bcn, float *simp_bnc,
+                           float *dpsum, float *values, sn_stream_t stream);
+int sn_surface_gather_upstream(int nproj, const float *g_lsimp, const float *g_sigma, const float *g_proj, float *scalars,
+                               float *proj_out, sn_stream_t stream);
 int sn_step_tail_bytes(void);
 /* Names the error words of the step's FC chain launches (the `sync` buffers of sn_fc_chain_forward[_pool] /
  * sn_fc_chain_backward, either may be NULL) in a deferred-tail blob: the loss value the tail writes is NaN when a hand-off

@@ -50,7 +50,9 @@ PROTOTYPES = {
     "sn_pairscan_forward_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp,
                                  _vp, _vp],
     "sn_sampler_step_loss_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp, _vp],
+                                  _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_surface_values_keys": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sn_surface_gather_upstream": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_step_tail_bytes": [],
     "sn_step_tail_set_error_words": [_vp, _vp, _vp],
     "sn_prefix_point_minima": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1409,7 +1409,7 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
                                          const void *qmax, int G, const float *temperature, float min_sigma, float alpha,
                                          float lmbda, float weight, const float *grad_loss, float *grad_Q,
                                          float *gsig_scratch, float *grad_T, float *dpsum, float *loss, sn_stream_t stream,
-                                         void *deferred_tail, const float *grad_proj)
+                                         void *deferred_tail, const float *grad_proj, const float *grad_sigma)
 {
     SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && K >= 1 && K <= 64 && G >= 1, "bad size");
     SN_REQUIRE(p_layout == SN_LAYOUT_BNC, "the reference cloud must be (B,N,3) here");
@@ -1448,13 +1448,110 @@ extern "C" int sn_sampler_step_loss_keys(int B, int N, int M, int K, const float
         // workgroups of its closing kernel): no launch of its own for the sigma gradient / loss value / key reset
         StepTail t{};
         t.nparts = B * splits, t.gsig = gsig_scratch, t.temperature = temperature, t.min_sigma = min_sigma, t.grad_T = grad_T;
-        t.grad_loss = grad_loss, t.lmbda = lmbda, t.kf = kf;
+        // (grad_sigma: sigma is an output of the caller's node with an upstream gradient of its own -- the drop-in surface,
+        //  where the script forms lmbda * get_projection_loss() itself; else the direct term is lmbda * grad_loss)
+        t.grad_loss = grad_sigma ? grad_sigma : grad_loss, t.lmbda = grad_sigma ? 1.f : lmbda, t.kf = kf;
         memcpy(deferred_tail, &t, sizeof(t));
         SN_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL(sigma_grad_kernel, dim3(2 + 64), dim3(256), 0, st, B * splits, gsig_scratch, temperature, min_sigma, grad_T,
-                       grad_loss, lmbda, StepLossFinal{}, kf);
+                       grad_sigma ? grad_sigma : grad_loss, grad_sigma ? 1.f : lmbda, StepLossFinal{}, kf);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The drop-in module surface on captured work (samplenet_amd/surface.py): registration/main.py:507-531 calls net(x), then
+// get_simplification_loss() / get_projection_loss(), weights them itself and calls backward().  The forward graph therefore
+// needs the VALUES of L_simp and sigma right behind the keys-mode scan (the engine's fused step gets them from the backward's
+// tail), and the backward graph takes three upstream gradients (d / d L_simp, d / d sigma, d / d proj) from device memory.
+//   sn_surface_values_keys:  [per cloud: sum of the per-point minima out of the key table (same order as the loss backward's
+//                            own sum: strided per-thread sums, xor tree, waves in order); simplified cloud (B,3,M) -> (B,M,3)]
+//                            -> [one wave: the clouds in the order of step_loss_keys_final]   values[0] = L_simp,
+//                            values[1] = sigma, values[2..4] = mean dist_q, mean_b max dist_q, mean dist_p
+//   sn_surface_gather_upstream: the three upstream gradients into the static operands of the captured backward (an absent one
+//                            becomes zero) -- one launch instead of three copies
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) surface_cloud_values_kernel(int N, int M, const sn_u64 *__restrict__ keys,
+                                                                   const float *__restrict__ y_bcn, float *__restrict__ simp_bnc,
+                                                                   float *__restrict__ dpsum)
+{
+    __shared__ float red[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float sdp = 0.f;
+    for (int n = t; n < N; n += 256) sdp += key_dist(~keys[(size_t)b * N + n]);
+    if (simp_bnc)
+        for (int i = t; i < 3 * M; i += 256) simp_bnc[(size_t)b * 3 * M + i] = y_bcn[(size_t)b * 3 * M + (i % 3) * M + i / 3];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sdp += __shfl_xor(sdp, o);
+    if ((t & 63) == 0) red[t >> 6] = sdp;
+    __syncthreads();
+    if (t == 0) dpsum[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(64) surface_values_final_kernel(int B, int G, int M, int N, float w, float min_sigma,
+                                                                  const float *__restrict__ qpart, const sn_u64 *__restrict__ qmax,
+                                                                  const float *__restrict__ dpsum,
+                                                                  const float *__restrict__ temperature, float *__restrict__ values)
+{
+    const int t = threadIdx.x;
+    float s1 = 0.f, mx = 0.f, s2 = 0.f;
+    for (int b = t; b < B; b += 64) {
+        float a1 = 0.f;
+        sn_u64 mk = 0;
+        for (int g = 0; g < G; ++g) {
+            const size_t o = (size_t)b * G + g;
+            a1 += qpart[o * 2];
+            mk = qmax[o] > mk ? qmax[o] : mk;
+        }
+        s1 += a1, mx += key_dist(mk), s2 += dpsum[b];
+    }
+    const float T = *temperature;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        mx += __shfl_xor(mx, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (t != 0) return;
+    const float c12 = s1 / ((float)B * (float)M), cmax = mx / (float)B, c21 = s2 / ((float)B * (float)N);
+    values[0] = c12 + cmax + w * c21;
+    values[1] = sn_sigma(T, min_sigma);
+    values[2] = c12, values[3] = cmax, values[4] = c21;
+}
+
+extern "C" int sn_surface_values_keys(int B, int N, int M, int G, const void *colmin_keys, const float *qpart, const void *qmax,
+                                      const float *temperature, float min_sigma, float weight, const float *y_bcn,
+                                      float *simp_bnc, float *dpsum, float *values, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && M >= 1 && G >= 1, "bad size");
+    SN_REQUIRE(colmin_keys && qpart && qmax && temperature && dpsum && values && (y_bcn || !simp_bnc), "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(surface_cloud_values_kernel, dim3(B), dim3(256), 0, st, N, M, (const sn_u64 *)colmin_keys, y_bcn, simp_bnc,
+                       dpsum);
+    hipLaunchKernelGGL(surface_values_final_kernel, dim3(1), dim3(64), 0, st, B, G, M, N, weight, min_sigma, qpart,
+                       (const sn_u64 *)qmax, dpsum, temperature, values);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) surface_gather_upstream_kernel(int nproj, const float *__restrict__ g_lsimp,
+                                                                      const float *__restrict__ g_sigma,
+                                                                      const float *__restrict__ g_proj, float *__restrict__ scalars,
+                                                                      float *__restrict__ proj_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nproj) proj_out[i] = g_proj ? g_proj[i] : 0.f;
+    if (i == 0) scalars[0] = g_lsimp ? *g_lsimp : 0.f, scalars[1] = g_sigma ? *g_sigma : 0.f;
+}
+
+extern "C" int sn_surface_gather_upstream(int nproj, const float *g_lsimp, const float *g_sigma, const float *g_proj,
+                                          float *scalars, float *proj_out, sn_stream_t stream)
+{
+    SN_REQUIRE(nproj >= 1 && scalars && proj_out, "bad argument");
+    hipLaunchKernelGGL(surface_gather_upstream_kernel, dim3((nproj + 255) / 256), dim3(256), 0, (hipStream_t)stream, nproj,
+                       g_lsimp, g_sigma, g_proj, scalars, proj_out);
     SN_LAUNCH_CHECK();
     return 0;
 }

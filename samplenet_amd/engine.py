@@ -86,6 +86,12 @@ class SamplerTrainStep:
         return True
 
     def _step(self, boundary=None):
+        from . import surface
+
+        with surface.suspended():  # the engine places the launches itself: the module surface stays op by op under it
+            return self._step_impl(boundary)
+
+    def _step_impl(self, boundary=None):
         """One step (eager, or under capture).  boundary: callable invoked where the FC head's gradients are complete --
         set while capturing the split step; the node then runs without autograd (same thread: a capture may only be ended by
         the thread that began it, and autograd would run the backward on its device thread)."""

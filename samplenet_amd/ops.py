@@ -595,10 +595,12 @@ def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight,
     return loss, proj, (idx, iq, ip, argmax1, (partial, loss) if defer_value else (None, None))
 
 
-def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, deferred_tail=None, grad_proj=None):
+def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, deferred_tail=None, grad_proj=None, grad_sigma=None):
     """Backward launches of the sampler step's loss side -> (grad_Q (B,3,M), grad_T (1,)).  Caller holds the device guard.
     grad_proj (B,M,3), keys mode only: gradient of an outside task loss w.r.t. the projected points; the step's own loss then
-    has no mean(proj) term (None: that stand-in term is part of the loss, its gradient implicit)."""
+    has no mean(proj) term (None: that stand-in term is part of the loss, its gradient implicit).
+    grad_sigma (1,), keys mode only: upstream gradient of sigma as an output of its own (the drop-in surface); the direct term of
+    grad_T is then grad_sigma * d sigma / dT instead of lmbda * grad_loss * d sigma / dT."""
     idx, iq, ip, argmax1, (dpart, dloss) = state[:5]
     K, min_sigma, alpha, lmbda, weight = cfg
     B, _, M = y.shape
@@ -613,14 +615,14 @@ def step_loss_backward(x, y, temperature, state, cfg, grad_loss, t_sink, deferre
         _, keys, qpart, qmax, G = state[5]
         check(lib.sn_sampler_step_loss_keys(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(keys), ptr(qpart), ptr(qmax), G,
                                             ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
-                                            ptr(dpart), ptr(dloss), _stream(y), deferred_tail, ptr(grad_proj)),
+                                            ptr(dpart), ptr(dloss), _stream(y), deferred_tail, ptr(grad_proj), ptr(grad_sigma)),
               "sn_sampler_step_loss_keys")
         if deferred_tail is not None:
             # the deferred launch (closing kernel of the conv backward) still reads these: the caller keeps them until then
             return gQ, gT, (gsig, gl, T)
         return gQ, gT
-    if grad_proj is not None:
-        raise ValueError("step_loss_backward: an explicit grad_proj needs the keys-mode step")
+    if grad_proj is not None or grad_sigma is not None:
+        raise ValueError("step_loss_backward: an explicit grad_proj / grad_sigma needs the keys-mode step")
     check(lib.sn_sampler_step_loss_backward(B, N, M, K, ptr(x), BNC, ptr(y), ptr(idx), ptr(iq), ptr(ip), ptr(argmax1),
                                             ptr(T), min_sigma, alpha, lmbda, weight, ptr(gl), ptr(gQ), ptr(gsig), ptr(gT),
                                             ptr(dpart), ptr(dloss), _stream(y)), "sn_sampler_step_loss_backward")

@@ -325,19 +325,22 @@ def check_chain_errors(net, raise_error=True):
     return True
 
 
-def forward_impl(net, x_bnc, training, skip_last=False):
+def forward_impl(net, x_bnc, training, skip_last=False, use_plan=True):
     """x (B,N,3) contiguous -> y (B, 3*M) and the tensors backward needs.
     skip_last: stop before fc4 and return None for y -- the caller produces it from saved["zf"][2] / saved["cf"][2] (the
-    pair scan of the fused sampler step computes its own queries, fused_step.py)."""
+    pair scan of the fused sampler step computes its own queries, fused_step.py).
+    use_plan=False: never run on / record a _ForwardPlan (callers that capture the launches into a graph of their own and keep
+    the returned tensors alive themselves: surface.py)."""
     convs, fcs = _layers(net)
     B, N, _ = x_bnc.shape
     R = B * N
     rec = None
-    if training and FORWARD_PLAN:
-        plan = _ForwardPlan.acquire(net, x_bnc, skip_last)
+    if training and FORWARD_PLAN and use_plan:
+        capturing = torch.cuda.is_current_stream_capturing()
+        plan = _ForwardPlan.acquire(net, x_bnc, skip_last, capturing)
         if plan is not None:
             return plan.run(net, x_bnc)
-        if not torch.cuda.is_current_stream_capturing():  # (a plan's buffers must not come from a graph's private pool)
+        if not capturing:  # (a plan's buffers must not come from a graph's private pool)
             rec = []
     saved = {"x": x_bnc, "B": B, "N": N, "zc": [], "cc": [], "zf": [], "cf": [], "training": bool(training)}
     use_batch_stats = training
@@ -427,10 +430,18 @@ class _ForwardPlan:
     record is alive (its backward has not run / its graph has not been released) the next forward of that shape records a
     plan of its own (two sampler passes under one loss, main.py:516-524); at most kMaxPlans are kept per module.
     Validity: the parameter / buffer tensors named by the recorded pointer arrays must still be the module's (identity and
-    data pointer are checked per step; SampleNet._apply drops the plans when the module is moved or cast)."""
+    data pointer are checked per step; SampleNet._apply drops the plans when the module is moved or cast).
+
+    A plan that a stream CAPTURE ran on has its buffer addresses baked into somebody's graph (engine.SamplerTrainStep, bench's
+    graph legs, a user's own torch.cuda.graph around the step): from then on it is `captured` -- never evicted, never dropped
+    as stale, kept alive for the life of the process (_PINNED: a replay of that graph must not touch freed memory, whatever
+    happens to the module's own list), and never handed to an EAGER forward again (an eager step's saved activations would be
+    overwritten by the next replay of the graph); later captures may share it (the ring of graphs of one engine runs them one
+    after the other)."""
 
     kMaxPlans = 4
-    __slots__ = ("key", "busy", "calls", "saved", "sig", "last")
+    _PINNED = []
+    __slots__ = ("key", "busy", "calls", "saved", "sig", "last", "captured")
 
     @staticmethod
     def _signature(net):
@@ -445,31 +456,35 @@ class _ForwardPlan:
         return tuple(sig)
 
     @staticmethod
-    def acquire(net, x, skip_last):
+    def acquire(net, x, skip_last, capturing=False):
         plans = net.__dict__.get("_sn_plans")
         if not plans:
             return None
         key = (x.shape[0], x.shape[1], x.device, bool(skip_last))
         sig = None
         for plan in plans:
-            if plan.key == key and not plan.busy:
+            if plan.key == key and not plan.busy and (capturing or not plan.captured):
                 if sig is None:
                     sig = _ForwardPlan._signature(net)
                 if plan.sig == sig:
+                    if capturing and not plan.captured:
+                        plan.captured = True
+                        _ForwardPlan._PINNED.append(plan)
                     return plan
-        if sig is not None:  # stale plans of this shape (parameters were replaced): drop them
+        if sig is not None:  # stale plans of this shape (parameters were replaced): drop them (a captured one only leaves the list)
             net.__dict__["_sn_plans"] = [q for q in plans if q.sig == sig or q.key != key]
         return None
 
     @staticmethod
     def register(net, x, skip_last, rec, saved, last_layer):
         plans = net.__dict__.setdefault("_sn_plans", [])
-        if len(plans) >= _ForwardPlan.kMaxPlans:
-            free = [q for q in plans if not q.busy]
+        if len([q for q in plans if not q.captured]) >= _ForwardPlan.kMaxPlans:
+            free = [q for q in plans if not q.busy and not q.captured]
             if not free:
                 return
             plans.remove(free[0])
         plan = _ForwardPlan()
+        plan.captured = False
         plan.key = (x.shape[0], x.shape[1], x.device, bool(skip_last))
         plan.sig = _ForwardPlan._signature(net)
         plan.calls = rec

@@ -42,6 +42,7 @@ class SampleNetProgressive(SampleNet):
         super().__init__(sizes[-1], bottleneck_size, group_size, **kw)
         self.sizes = sizes
         self.name = "samplenet_progressive"
+        self.graph_surface = False  # the prefix losses hang off slices of the simplified cloud and reuse forward()'s scan
 
     def prefix(self, pc, size):
         """The first `size` points of a (B,M,3) ['bnc'] or (B,3,M) ['bcn'] cloud in the module's output layout."""

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops, pointnet, sputils
+from . import ops, pointnet, sputils, surface
 from .chamfer_distance import ChamferDistance
 from .soft_projection import SoftProjection
 
@@ -91,18 +91,30 @@ class SampleNet(nn.Module):
         self.output_shape = output_shape
 
         self._scan = None  # Chamfer products of the last training forward (see get_simplification_loss)
+        # training steps of one configuration run on captured work behind forward() / the loss getters (surface.py: outputs are
+        # static tensors, gradients are written straight into .grad); False: every call op by op
+        self.graph_surface = True
         self.device_matching = True  # eval branch: nn_matching / FPS completion on the GPU (False: numpy, as the reference)
 
     # per-step / per-attachment state that must not travel with a copy of the module (graph tensors, views of another
     # module's gradient bucket, persistent kernel scratch)
     _TRANSIENT = ("_scan", "_grad_sink", "_after_fc_grads", "_colmin_keys", "_colmin_keys_owner", "_fx_acc", "_fx_acc_b",
-                  "_fc_sync", "_fc_sync_b", "_sn_layer_records", "_sn_plans", "_sn_sync_bn")
+                  "_fc_sync", "_fc_sync_b", "_sn_layer_records", "_sn_plans", "_sn_sync_bn", "_sn_surface", "_sn_surface_live")
 
     def _apply(self, fn, *args, **kwargs):
-        # .to() / .cuda() / .float() ...: parameter storage moves -- recorded pointer arrays and persistent scratch are void
-        for k in ("_sn_plans", "_sn_layer_records"):
+        # .to() / .cuda() / .float() ...: parameter storage moves -- recorded pointer arrays, captured graphs and persistent
+        # scratch are void
+        for k in ("_sn_plans", "_sn_layer_records", "_sn_surface", "_sn_surface_live"):
             self.__dict__.pop(k, None)
         return super()._apply(fn, *args, **kwargs)
+
+    def __getstate__(self):
+        # pickling (torch.save(module)): graphs, pointer arrays and views of foreign buckets stay behind
+        return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._scan = None
 
     def __deepcopy__(self, memo):
         import copy
@@ -126,6 +138,12 @@ class SampleNet(nn.Module):
     def forward(self, x: torch.Tensor):
         """x in `input_shape` -> (simplified cloud, projected cloud [train] | matched cloud [eval]) in `output_shape`
         (samplenet.py:85-142).  Internally the head's output y is (B,3,M); the cloud is used in whichever layout it came."""
+        self.__dict__["_sn_surface_live"] = None
+        if self.training:
+            out = surface.try_forward(self, x)  # captured forward of this configuration (None: op by op below)
+            if out is not None:
+                self._scan = None
+                return out
         cloud_is_bnc = self.input_shape == "bnc"
         out_is_bnc = self.output_shape == "bnc"
         x_bcn = x.permute(0, 2, 1) if cloud_is_bnc else x
@@ -164,6 +182,12 @@ class SampleNet(nn.Module):
             match = torch.as_tensor(picked, dtype=torch.float32).to(x_bcn.device)
         return (match if out_is_bnc else match.permute(0, 2, 1)).contiguous()  # match is (B,M,3)
 
+    def check(self):
+        """Host-side health check of the FC chain launches' hand-off state (pointnet.check_chain_errors): raises
+        SampleNetHipError when a step since the last check ran on incomplete data (its outputs / gradients were NaN-poisoned on
+        the device already) and re-arms the launch state.  Synchronises the device: call it where the loss is read back."""
+        return pointnet.check_chain_errors(self)
+
     def sample(self, x):
         simp, proj = self.__call__(x)
         return proj
@@ -185,6 +209,10 @@ class SampleNet(nn.Module):
         if self.skip_projection or not self.training:
             return torch.tensor(0).to(ref_pc)
         # ref_pc and samp_pc are B x N x 3 matrices
+        if self.__dict__.get("_sn_surface_live") is not None:
+            loss = surface.simplification_loss(self, ref_pc, samp_pc, gamma + delta * pc_size)
+            if loss is not None:  # (an output of the captured forward's own autograd node)
+                return loss
         scan = self._scan_hit(ref_pc, samp_pc)
         if scan is not None:  # Chamfer products of this very pair were produced by forward()'s pair scan
             dq, iq, dp, ip, y_bcn = scan
@@ -199,6 +227,10 @@ class SampleNet(nn.Module):
         return ops.SimplificationLossFunction.apply(samp_pc, ref_pc, dq, iq, dp, ip, gamma + delta * pc_size)
 
     def get_projection_loss(self):
+        if self.__dict__.get("_sn_surface_live") is not None and self.training and not self.skip_projection:
+            sigma = surface.projection_loss(self)
+            if sigma is not None:
+                return sigma
         sigma = self.project.sigma()
         if self.skip_projection or not self.training:
             return torch.tensor(0).to(sigma)

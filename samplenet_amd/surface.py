@@ -1,0 +1,411 @@
+"""Captured work behind the drop-in module surface.
+
+An unmodified training script (registration/main.py:507-531, 346-351) drives the sampler like this:
+
+    simp, proj = sampler(x)
+    l_simp = sampler.get_simplification_loss(x, simp, M, gamma, delta)
+    l_proj = sampler.get_projection_loss()
+    loss   = task(proj) + ALPHA * l_simp + LMBDA * l_proj
+    optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+Issued op by op that is ~70 kernel launches behind ~0.8 ms of Python for 0.18 ms of GPU work.  Here the same four calls run
+on TWO hipGraphs per configuration (batch shape, device, parameter storage):
+
+    forward graph   conv stack (6 launches) -> FC chain (1) -> keys-mode pair scan with fc4 inside (1) -> values of L_simp and
+                    sigma + the (B,M,3) copy of the simplified cloud (2)          [the launches of fused_step.SamplerStepFunction]
+    backward graph  Chamfer + soft-projection backward (1) -> FC chain backward (1) -> conv stack backward with the step
+                    tail (5); gradients land in one flat bucket whose views become the parameters' .grad
+
+behind ONE autograd node with four differentiable outputs (simp, proj, L_simp, sigma): the two loss getters hand out the
+node's own outputs, so whatever the script does with them (weights, sums, a task network on proj) reaches the node's backward
+as three upstream gradients, which one small launch gathers into the static operands of the backward graph.
+
+A configuration is captured after WARM_STEPS eager steps.  Everything irregular takes the eager route on the same data and
+stays correct: a second forward before the first one's backward (main.py:516-524) runs op by op, an upstream gradient on
+`simp` itself or a loss weight other than the captured one runs the backward launches eagerly on the graph's activations,
+a changed parameter storage / device / dtype drops the graphs (SampleNet._apply; pointer signature checked per step).
+
+Outputs are STATIC tensors: the next training forward of the same configuration overwrites simp / proj / the loss values in
+place (as torch.cuda.make_graphed_callables does); clone what must outlive a step.  Gradients are written straight into
+.grad (views of the plan's bucket; torch semantics kept: overwrite when .grad is None, accumulate otherwise) -- no
+AccumulateGrad nodes run, so per-parameter autograd hooks do not fire: set `net.graph_surface = False` for tooling that needs
+them (torch DistributedDataParallel; samplenet_amd.parallel.FlatGradAllReducer takes the engine route instead).
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import ops, pointnet
+from ._lib import check, lib, ptr
+
+ENABLED = True   # test hook / global switch (per module: net.graph_surface)
+WARM_STEPS = 2   # eager steps of a configuration before its graphs are captured
+_suspend = 0
+
+
+class suspended:
+    """with surface.suspended(): the module surface runs op by op (callers that place the launches themselves: the engine)."""
+
+    def __enter__(self):
+        global _suspend
+        _suspend += 1
+
+    def __exit__(self, *exc):
+        global _suspend
+        _suspend -= 1
+
+
+class _Token:
+    __slots__ = ("__weakref__",)
+
+
+class _Live:
+    """What the loss getters need to recognise the tensors of the last captured forward."""
+
+    __slots__ = ("x", "x_version", "simp", "lsimp", "sigma", "plan", "t_version")
+
+
+class _Guard:
+    """What a plan's graphs have baked in, in a form that is cheap to re-check per step (~10 us): the sub-modules are still
+    the module's, every parameter / buffer is still the object at the address the graphs read and write, every parameter
+    still wants its gradient, the BatchNorm constants are unchanged."""
+
+    def __init__(self, net):
+        self.mods, self.tens, self.consts = [], [], []
+        for name, m in net._modules.items():
+            self.mods.append((net._modules, name, m))
+            for d in (m._parameters, m._buffers):
+                for k, t in d.items():
+                    if t is not None:
+                        self.tens.append((d, k, t, t.data_ptr(), t.requires_grad))
+            if isinstance(m, torch.nn.BatchNorm1d):
+                self.consts.append((m, m.eps, m.momentum, m.track_running_stats))
+
+    def ok(self):
+        for d, k, m in self.mods:
+            if d.get(k) is not m:
+                return False
+        for d, k, t, p, rg in self.tens:
+            if d.get(k) is not t or t.data_ptr() != p or t.requires_grad != rg:
+                return False
+        for m, eps, mom, trs in self.consts:
+            if m.eps != eps or m.momentum != mom or m.track_running_stats != trs:
+                return False
+        return True
+
+
+class _Plan:
+    def __init__(self, net, x, weight):
+        self.net_ref = weakref.ref(net)
+        self.weight = float(weight)
+        self.owner = None
+        B, N, _ = x.shape
+        M, K = net.num_out_points, net.project._group_size
+        self.shape = (B, N, M, K)
+        dev = x.device
+        self.dev = dev
+        self.min_sigma = net.project._min_sigma_f
+        params = pointnet.param_list(net)
+        names = pointnet.param_order(net)
+        T = net.project._temperature
+        total = sum(p.numel() for p in params)
+        with torch.cuda.device(dev):
+            self.x = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+            self.up_scalars = torch.zeros(2, device=dev, dtype=torch.float32)
+            self.up_proj = torch.zeros(B, M, 3, device=dev, dtype=torch.float32)
+            self.keys = torch.zeros(B * N, device=dev, dtype=torch.int64)
+            self.bucket = torch.zeros(total + 1, device=dev, dtype=torch.float32)
+            self.views, self.view_list, off = {}, [], 0
+            for n, p in zip(names, params):
+                v = self.bucket[off:off + p.numel()].view(p.shape)
+                self.views[n] = v
+                self.view_list.append(v)
+                off += p.numel()
+            self.t_sink = self.bucket[total:total + 1]
+            self.t_view = self.t_sink.view(T.shape)
+            self.params = list(params)
+            self.grad_pairs = list(zip(self.params, self.view_list))
+            if T.requires_grad:
+                self.grad_pairs.append((T, self.t_view))
+            self._capture(net, x)
+        self.guard = _Guard(net)
+
+    # ---- the launches (eager warm-up, then captured) ------------------------------------------------------------------
+    def _forward_body(self, net):
+        B, N, M, K = self.shape
+        x = self.x
+        _, saved = pointnet.forward_impl(net, x, True, skip_last=True, use_plan=False)
+        fc4 = net.fc4
+        T = net.project._temperature
+        self.y = torch.empty(B, 3, M, device=self.dev, dtype=torch.float32)
+        fc = (saved["zf"][2], saved["cf"][2], fc4.weight.detach(), fc4.bias.detach())
+        _, proj, state = ops.step_loss_forward(x, self.y, fc, T, K, self.min_sigma, 1.0, 0.0, self.weight, True, keys=self.keys)
+        _, keys, qpart, qmax, G = state[5]
+        self.simp = torch.empty(B, M, 3, device=self.dev, dtype=torch.float32)
+        self.values = torch.empty(8, device=self.dev, dtype=torch.float32)
+        self.dpsum = torch.empty(B, device=self.dev, dtype=torch.float32)
+        check(lib.sn_surface_values_keys(B, N, M, G, ptr(keys), ptr(qpart), ptr(qmax), ptr(T.detach().reshape(1)), self.min_sigma,
+                                         self.weight, ptr(self.y), ptr(self.simp), ptr(self.dpsum), ptr(self.values),
+                                         torch.cuda.current_stream(self.dev).cuda_stream), "sn_surface_values_keys")
+        self.saved, self.state, self.proj = saved, state, proj
+
+    def _backward_body(self, net):
+        B, N, M, K = self.shape
+        T = net.project._temperature
+        blob = None
+        if pointnet.conv_stack_backward_supported(net, B, N):
+            blob = ctypes.create_string_buffer(lib.sn_step_tail_bytes())
+        cfg = (K, self.min_sigma, 1.0, 0.0, self.weight)
+        res = ops.step_loss_backward(self.x, self.y, T, self.state, cfg, self.up_scalars[0:1], self.t_sink, blob, self.up_proj,
+                                     grad_sigma=self.up_scalars[1:2])
+        gQ = res[0]
+        grads = pointnet.backward_impl(net, self.saved, gQ.view(B, -1), self.views, None, step_tail=blob)
+        missing = [n for n in self.views if grads.get(n) is not self.views[n]]
+        if missing:
+            raise RuntimeError("surface: the backward did not write %s into the gradient bucket" % missing[:3])
+        self.bwd_keep = (res, grads)
+
+    def _capture(self, net, x):
+        cur = torch.cuda.current_stream(self.dev)
+        bufs = [b for b in net.buffers()]
+        kept = [b.clone() for b in bufs]
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            # one eager pass of exactly these launches (every kernel of the graphs has run once; the step's persistent scratch
+            # exists); the running statistics it advanced are put back -- the warm-up is not a training step
+            self.x.copy_(x)
+            self._forward_body(net)
+            self._backward_body(net)
+            for b, c in zip(bufs, kept):
+                b.copy_(c)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.saved = self.state = self.bwd_keep = None
+        self.pool = torch.cuda.graph_pool_handle()
+        self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.gf, pool=self.pool, capture_error_mode="thread_local"):
+            self._forward_body(net)
+        with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local"):
+            self._backward_body(net)
+        self.v_lsimp, self.v_sigma = self.values[0], self.values[1]
+
+    # ---- per step ---------------------------------------------------------------------------------------------------
+    def busy(self):
+        o = self.owner
+        if o is None:
+            return False
+        if o() is None:  # the forward that owned the activations was dropped without a backward: its scan left the keys behind
+            self.keys.zero_()
+            self.owner = None
+            return False
+        return True
+
+    def commit_begin(self):
+        """-> (mode, old): 0 every .grad is None (the views become the gradients), 1 every .grad IS its view (accumulate into
+        the bucket), 2 anything else (per parameter)."""
+        nnone = nours = 0
+        for p, v in self.grad_pairs:
+            g = p.grad
+            if g is None:
+                nnone += 1
+            elif g is v:
+                nours += 1
+        n = len(self.grad_pairs)
+        if nnone == n:
+            return 0, None
+        old = self.bucket.clone() if nours else None
+        return (1 if nours == n else 2), old
+
+    def commit_end(self, mode, old):
+        if mode == 0:
+            for p, v in self.grad_pairs:
+                p.grad = v
+        elif mode == 1:
+            self.bucket.add_(old)
+        else:
+            off = 0
+            for p, v in self.grad_pairs:
+                g = p.grad
+                if g is None:
+                    p.grad = v
+                elif g is v:
+                    v.add_(old[off:off + v.numel()].view(v.shape))
+                else:
+                    p.grad = g + v
+                off += v.numel()
+
+
+class _SurfaceFunction(torch.autograd.Function):
+    """simp (B,M,3), proj (B,M,3), L_simp (), sigma () = step(x); backward = the captured backward (see the module docstring)."""
+
+    @staticmethod
+    def forward(ctx, plan, net, x, _anchor):
+        with torch.cuda.device(plan.dev):
+            plan.x.copy_(x, non_blocking=True)
+            plan.gf.replay()
+        token = _Token()
+        plan.owner = weakref.ref(token)
+        ctx.plan, ctx.net, ctx.token = plan, net, token
+        ctx.weight = None  # set by a getter that was asked for another loss weight than the captured one
+        ctx.done = False
+        ctx.set_materialize_grads(False)
+        return plan.simp.detach(), plan.proj.detach(), plan.v_lsimp.detach(), plan.v_sigma.detach()
+
+    @staticmethod
+    def backward(ctx, g_simp, g_proj, g_lsimp, g_sigma):
+        plan, net = ctx.plan, ctx.net
+        if ctx.done:
+            raise RuntimeError("samplenet_amd.surface: this forward was already backpropagated (its activations are static "
+                               "buffers of a captured graph; call the sampler again instead of retaining the graph)")
+        if plan.owner is None or plan.owner() is not ctx.token:
+            raise RuntimeError("samplenet_amd.surface: the captured activations of this forward were overwritten")
+        ctx.done = True
+        B, N, M, K = plan.shape
+        T = net.project._temperature
+        with torch.cuda.device(plan.dev):
+            st = torch.cuda.current_stream(plan.dev).cuda_stream
+            if g_proj is not None:
+                g_proj = ops._f32c(g_proj)
+            if g_lsimp is not None:
+                g_lsimp = ops._f32c(g_lsimp)
+            if g_sigma is not None:
+                g_sigma = ops._f32c(g_sigma)
+            if g_simp is None and ctx.weight is None:
+                check(lib.sn_surface_gather_upstream(B * M * 3, ptr(g_lsimp), ptr(g_sigma), ptr(g_proj), ptr(plan.up_scalars),
+                                                     ptr(plan.up_proj), st), "sn_surface_gather_upstream")
+                mode, old = plan.commit_begin()
+                plan.gb.replay()
+                plan.commit_end(mode, old)
+            else:
+                # irregular upstream (a gradient on the simplified cloud itself / another loss weight): the same launches,
+                # eagerly, on the graph's activations
+                zero = torch.zeros(1, device=plan.dev)
+                gl = g_lsimp.reshape(1) if g_lsimp is not None else zero
+                gs = g_sigma.reshape(1) if g_sigma is not None else zero
+                gp = g_proj if g_proj is not None else torch.zeros(B, M, 3, device=plan.dev)
+                w = plan.weight if ctx.weight is None else ctx.weight
+                res = ops.step_loss_backward(plan.x, plan.y, T, plan.state, (K, plan.min_sigma, 1.0, 0.0, w), gl, None, None, gp,
+                                             grad_sigma=gs)
+                gQ, gT = res[0], res[1]
+                if g_simp is not None:
+                    gQ = gQ + ops._f32c(g_simp).permute(0, 2, 1)
+                grads = pointnet.backward_impl(net, plan.saved, gQ.reshape(B, -1).contiguous(), None, None)
+                for n, p in zip(pointnet.param_order(net), plan.params):
+                    p.grad = grads[n] if p.grad is None else p.grad + grads[n]
+                if T.requires_grad:
+                    gT = gT.reshape(T.shape)
+                    T.grad = gT.clone() if T.grad is None else T.grad + gT
+        plan.owner = None
+        return None, None, None, None
+
+
+def _supported(net, x):
+    if not (getattr(net, "graph_surface", True) and net.use_hip_mlp and getattr(net, "standard_arch", False)) or net.skip_projection:
+        return False
+    if net.input_shape != "bnc" or net.output_shape != "bnc":
+        return False
+    if not torch.is_grad_enabled() or not x.is_cuda or x.requires_grad or x.dtype != torch.float32 or x.dim() != 3 or x.shape[2] != 3:
+        return False
+    d = net.__dict__
+    if d.get("_sn_sync_bn") is not None or d.get("_grad_sink") is not None or d.get("_after_fc_grads") is not None:
+        return False
+    if net._forward_hooks or net._forward_pre_hooks or net._backward_hooks:
+        return False
+    return True
+
+
+def try_forward(net, x):
+    """-> (simp, proj) from the captured forward, or None: the caller runs the op-by-op forward."""
+    if not ENABLED or _suspend or not _supported(net, x):
+        return None
+    if torch.cuda.is_current_stream_capturing():  # somebody captures the step themselves: plain launches for their graph
+        return None
+    table = net.__dict__.setdefault("_sn_surface", {})
+    key = (x.shape[0], x.shape[1], x.device)
+    ent = table.get(key)
+    if ent is False:
+        return None
+    if not isinstance(ent, _Plan):
+        n = (ent or 0) + 1
+        if n <= WARM_STEPS:
+            table[key] = n
+            return None
+        from .fused_step import external_task_supported
+
+        T = net.project._temperature
+        params = pointnet.param_list(net)
+        ok = (external_task_supported(net, x) and all(p.requires_grad for p in params) and T.dim() == 0 and
+              all(L.bn is not None and L.bn.momentum is not None and L.bn.track_running_stats
+                  for L in sum(pointnet._layers(net), [])[:-1]))
+        if ok:
+            try:
+                ent = _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
+            except Exception as e:  # noqa: BLE001 -- a configuration that cannot be captured stays on the op-by-op route
+                import warnings
+
+                warnings.warn("samplenet_amd.surface: capture failed, this configuration stays op by op (%s)" % repr(e)[:300])
+                torch.cuda.synchronize(x.device)
+                ok = False
+        if not ok:
+            table[key] = False
+            return None
+        table[key] = ent
+    plan = ent
+    if plan.busy():
+        return None
+    if not plan.guard.ok():  # a parameter / buffer / layer was replaced: new graphs after the warm steps (this is the first)
+        table[key] = 1
+        return None
+    # (one differentiable input is enough to make the outputs differentiable: the gradients do not travel through autograd)
+    simp, proj, lsimp, sigma = _SurfaceFunction.apply(plan, net, x, plan.params[0])
+    live = _Live()
+    live.x, live.x_version, live.simp, live.lsimp, live.sigma, live.plan = x, x._version, simp, lsimp, sigma, plan
+    live.t_version = net.project._temperature._version
+    net.__dict__["_sn_surface_live"] = live
+    return simp, proj
+
+
+class _ReweightFunction(torch.autograd.Function):
+    """L_simp for another weight than the captured one, from the captured components; tells the node's backward."""
+
+    @staticmethod
+    def forward(ctx, lsimp, value, node_ctx, weight):
+        ctx.node_ctx, ctx.weight = node_ctx, weight
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.node_ctx.weight = ctx.weight
+        return g, None, None, None
+
+
+def simplification_loss(net, ref_pc, samp_pc, weight):
+    """The captured forward's L_simp when (ref_pc, samp_pc) are the tensors that forward consumed / returned, else None."""
+    live = net.__dict__.get("_sn_surface_live")
+    if live is None or samp_pc is not live.simp:
+        return None
+    x = live.x
+    same = ref_pc is x or (ref_pc.data_ptr() == x.data_ptr() and ref_pc.shape == x.shape and ref_pc.stride() == x.stride())
+    if not same or x._version != live.x_version or live.plan.owner is None:
+        return None
+    weight = float(weight)
+    net.__dict__["_sn_surface_weight"] = weight
+    if weight == live.plan.weight:
+        return live.lsimp
+    # another loss weight than the captured one: value from the components, eager backward this step, new graphs afterwards
+    v = live.plan.values
+    value = v[2] + v[3] + weight * v[4]
+    table = net.__dict__.get("_sn_surface", {})
+    for k, p in list(table.items()):
+        if p is live.plan:
+            table[k] = WARM_STEPS  # recaptured (with this weight) by the next forward
+    return _ReweightFunction.apply(live.lsimp, value, live.lsimp.grad_fn, weight)  # (a Function's ctx IS its outputs' grad_fn)
+
+
+def projection_loss(net):
+    live = net.__dict__.get("_sn_surface_live")
+    if live is None or live.plan.owner is None or net.project._temperature._version != live.t_version:
+        return None
+    return live.sigma

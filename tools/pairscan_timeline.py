@@ -83,7 +83,7 @@ if hasattr(lib, "sn_debug_chamfer_soft_bwd_timeline"):
     def bwd():
         launch()
         rc = lib.sn_sampler_step_loss_keys(B, N, M, K, P(x), 0, P(Q), P(idx), P(iq), P(keys), P(qpart), P(qmax), G, P(T), cf(1e-2),
-                                           cf(0.01), cf(0.01), cf(1.0), P(gl), P(gQ), P(gsig), P(gT), P(dps), P(loss), st, None)
+                                           cf(0.01), cf(0.01), cf(1.0), P(gl), P(gQ), P(gsig), P(gT), P(dps), P(loss), st, None, None, None)
         assert rc == 0, rc
 
     for _ in range(3):
