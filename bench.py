@@ -334,7 +334,7 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
 
     out = {}
     # the script's calls op by op (graph_surface off: what every round before the captured surface measured) ...
-    net.graph_surface = False
+    net.graph_surface = pcr.graph_surface = False
     ms, loss = _wall_ms(eager_mean_proj_step, max(steps, 200))
     assert torch.isfinite(loss).item()
     out["op_by_op_mean_proj"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
@@ -343,7 +343,7 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
     out["op_by_op"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
     # ... and the SAME unmodified calls on the captured surface (samplenet_amd/surface.py: two hipGraphs behind net(x), the loss
     # getters and backward(); the default)
-    net.graph_surface = True
+    net.graph_surface = pcr.graph_surface = True  # (graphed.py: the frozen task network's term replays two graphs of its own)
     ms, loss = _wall_ms(eager_mean_proj_step, max(steps, 400))
     assert torch.isfinite(loss).item()
     net.check()

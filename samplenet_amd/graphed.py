@@ -1,0 +1,185 @@
+"""Captured work behind a FROZEN network's call: the task side of the reference's training step.
+
+registration/main.py:557-577 evaluates the frozen task network on the sampled cloud in every sampler step
+(twist = model(p0, p1); p1_est = rotate(p0); Chamfer(p1, p1_est)): ~32 launches behind ~0.5 ms of Python and autograd for
+0.27 ms of GPU work.  `call(owner, tag, fn, args)` runs such a pure function of tensors -- no parameter of `owner` wants a
+gradient, the outputs depend on nothing but the arguments and the (frozen) parameters -- on two hipGraphs per configuration
+once it has been seen WARM_STEPS times, the way torch.cuda.make_graphed_callables would, but transparently:
+
+    forward graph   fn(*static copies of the arguments)                      -> static outputs
+    backward graph  torch.autograd.grad(outputs, arguments, static upstream) -> static argument gradients
+
+behind one autograd node.  Anything irregular runs fn eagerly: a second call before the first one's backward, another
+thread's capture in progress, a parameter that was replaced or unfrozen (guard), no_grad.  Parameters updated IN PLACE are
+seen by the replays (the kernels read them where they lie; bf16 weight planes are re-split inside a captured call,
+task_features._weight_planes).  Outputs and argument gradients are STATIC tensors, overwritten by the next call of the same
+configuration (as with make_graphed_callables): clone what must outlive a step.
+"""
+import weakref
+
+import torch
+
+from . import surface
+
+WARM_STEPS = 2
+
+
+class _Token:
+    __slots__ = ("__weakref__",)
+
+
+class _ModuleGuard:
+    """Every parameter / buffer of the module tree is still the object at the address the graphs read, and still frozen."""
+
+    def __init__(self, module):
+        self.mods, self.tens = [], []
+        for m in module.modules():
+            for name, child in m._modules.items():
+                self.mods.append((m._modules, name, child))
+            for d in (m._parameters, m._buffers):
+                for k, t in d.items():
+                    if t is not None:
+                        self.tens.append((d, k, t, t.data_ptr()))
+
+    def ok(self):
+        for d, k, m in self.mods:
+            if d.get(k) is not m:
+                return False
+        for d, k, t, p in self.tens:
+            if d.get(k) is not t or t.data_ptr() != p or t.requires_grad:
+                return False
+        return True
+
+
+def _flat(out):
+    return tuple(out) if isinstance(out, (tuple, list)) else (out,)
+
+
+class _Plan:
+    def __init__(self, owner, fn, args):
+        dev = args[0].device
+        self.dev = dev
+        self.owner_token = None
+        with torch.cuda.device(dev):
+            self.ins = [torch.empty(a.shape, device=dev, dtype=a.dtype).requires_grad_(a.requires_grad) for a in args]
+            self.ins_req = [s for s in self.ins if s.requires_grad]
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                with torch.no_grad():
+                    for s, a in zip(self.ins, args):
+                        s.copy_(a)
+                for _ in range(2):  # eager passes of exactly these launches: lazy caches (constant tables, weight planes) exist
+                    outs = _flat(fn(*self.ins))
+                    req = [o for o in outs if o.requires_grad]
+                    torch.autograd.grad(req, self.ins_req, [torch.ones_like(o) for o in req], allow_unused=True)
+                del outs, req
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.pool = torch.cuda.graph_pool_handle()
+            self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.gf, pool=self.pool, capture_error_mode="thread_local"):
+                out = fn(*self.ins)
+            self.single = not isinstance(out, (tuple, list))
+            self.outs = _flat(out)
+            self.req = [i for i, o in enumerate(self.outs) if o.requires_grad]
+            self.gouts = [torch.zeros_like(self.outs[i]) for i in self.req]
+            with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local"):
+                self.gins = torch.autograd.grad([self.outs[i] for i in self.req], self.ins_req, self.gouts, allow_unused=True)
+        self.guard = _ModuleGuard(owner)
+
+    def busy(self):
+        o = self.owner_token
+        if o is None:
+            return False
+        if o() is None:
+            self.owner_token = None
+            return False
+        return True
+
+
+class _GraphedFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, *args):
+        with torch.cuda.device(plan.dev), torch.no_grad():
+            for s, a in zip(plan.ins, args):
+                if a.data_ptr() != s.data_ptr():
+                    s.copy_(a, non_blocking=True)
+            plan.gf.replay()
+        token = _Token()
+        plan.owner_token = weakref.ref(token)
+        ctx.plan, ctx.token, ctx.done = plan, token, False
+        outs = tuple(o.detach() for o in plan.outs)
+        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if i not in plan.req])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        plan = ctx.plan
+        if ctx.done or plan.owner_token is None or plan.owner_token() is not ctx.token:
+            raise RuntimeError("samplenet_amd.graphed: this call was already backpropagated or its captured activations were "
+                               "overwritten (they are static buffers of a graph; evaluate the network again)")
+        ctx.done = True
+        with torch.cuda.device(plan.dev), torch.no_grad():
+            for i, sg in zip(plan.req, plan.gouts):
+                g = gouts[i]
+                if g is None:
+                    sg.zero_()
+                else:
+                    sg.copy_(g, non_blocking=True)
+            plan.gb.replay()
+        plan.owner_token = None
+        it = iter(plan.gins)
+        return (None,) + tuple((next(it) if s.requires_grad else None) for s in plan.ins)
+
+
+def call(owner, tag, fn, args):
+    """fn(*args) on the captured graphs of this configuration, or None: the caller runs fn(*args) itself.
+    owner: the frozen nn.Module whose parameters fn reads (the plans live in its __dict__); args: CUDA tensors, at least one of
+    which wants a gradient; fn must be a pure function of them."""
+    if not surface.ENABLED or surface._suspend or not getattr(owner, "graph_surface", True) or not torch.is_grad_enabled():
+        return None
+    dev = None
+    any_grad = False
+    for a in args:
+        if not isinstance(a, torch.Tensor) or not a.is_cuda or (dev is not None and a.device != dev) or not a.is_contiguous():
+            return None
+        dev = a.device
+        any_grad = any_grad or a.requires_grad
+    if not any_grad or torch.cuda.is_current_stream_capturing():
+        return None
+    table = owner.__dict__.setdefault("_sn_graphed", {})
+    key = (tag,) + tuple((tuple(a.shape), a.dtype, a.device, a.requires_grad) for a in args)
+    ent = table.get(key)
+    if ent is False:
+        return None
+    if not isinstance(ent, _Plan):
+        n = (ent or 0) + 1
+        if n <= WARM_STEPS:
+            table[key] = n
+            return None
+        if any(p.requires_grad for p in owner.parameters()) or owner._forward_hooks or owner._forward_pre_hooks:
+            table[key] = 0
+            return None
+        try:
+            with surface.suspended():  # (nothing inside the captured call builds graphs of its own)
+                ent = _Plan(owner, fn, args)
+        except Exception as e:  # noqa: BLE001 -- a configuration that cannot be captured stays op by op
+            import warnings
+
+            warnings.warn("samplenet_amd.graphed: capture of %r failed, it stays op by op (%s)" % (tag, repr(e)[:300]))
+            torch.cuda.synchronize(dev)
+            ent = False
+        table[key] = ent
+        if ent is False:
+            return None
+    plan = ent
+    if plan.busy():
+        return None
+    if not plan.guard.ok():
+        table[key] = 1
+        return None
+    outs = _GraphedFunction.apply(plan, *args)
+    return outs[0] if plan.single else outs

@@ -61,7 +61,7 @@ def _weight_planes(*Ws, tag=""):
     tag: distinguishes the images kept of the same weights (the backward's transposed planes)."""
     bases = [W._base if W._base is not None else W for W in Ws]
     key = (tag,) + tuple(id(b) for b in bases)
-    vers = tuple(b._version for b in bases)
+    vers = tuple((b._version, b.data_ptr()) for b in bases)  # (a write through .data keeps the version: the storage address is the second witness)
     numel = 3 * sum(W.numel() for W in Ws)
     hit = _PLANES.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
@@ -402,7 +402,22 @@ class PCRNet(nn.Module):
         self.fc5 = nn.Linear(512, 256)
         self.fc6 = nn.Linear(256, 7)
 
+    def __getstate__(self):  # (copy.deepcopy / pickling: captured graphs stay behind)
+        return {k: v for k, v in self.__dict__.items() if k != "_sn_graphed"}
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_sn_graphed", None)  # .to() / .cuda(): the graphs' addresses are void
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, x0, x1):
+        # a frozen network under a sampler's training step (main.py:557-563): replayed from two captured graphs once the
+        # configuration has been seen (graphed.py); None: op by op
+        from . import graphed
+
+        out = graphed.call(self, "forward", self._forward, (x0, x1))
+        return out if out is not None else self._forward(x0, x1)
+
+    def _forward(self, x0, x1):
         twist, pre_normalized_quat = self.forward_with_qnorm(x0, x1)[:2]
         return twist, pre_normalized_quat
 
@@ -531,6 +546,16 @@ def pcrnet_chamfer_loss(model, p0, p1, template_features=None):
     p0 template / p1 source, (B,N,3).  Returns (chamfer_loss, qnorm_loss, twist).  The rotation-matrix error terms of
     `--loss-type 0` go through kornia in the reference (not installed here) and stay with the caller.
     template_features: model.template_features(p0), when several evaluations of a step share the template."""
+    if template_features is None and isinstance(model, nn.Module):
+        from . import graphed
+
+        out = graphed.call(model, "pcrnet_chamfer_loss", lambda a, b: _pcrnet_chamfer_loss(model, a, b, None), (p0, p1))
+        if out is not None:  # (frozen network: the whole task term replays two captured graphs, graphed.py)
+            return out
+    return _pcrnet_chamfer_loss(model, p0, p1, template_features)
+
+
+def _pcrnet_chamfer_loss(model, p0, p1, template_features):
     from .ops import chamfer_mean_loss
 
     if hasattr(model, "forward_with_qnorm"):
