@@ -857,6 +857,16 @@ def main():
             from oracle.cpu_reference_model import time_cpu_baseline
 
             out["cpu_baseline"] = time_cpu_baseline(B, N, M, K, budget_s=args.cpu_budget)
+            # the port against the TRUE reference module, timed side by side in the build container (tools/time_reference_cpu.py;
+            # /root/reference does not exist on the GPU box) -- throughput ratio port / reference on the same step, same numbers
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04",
+                                       "cpu_baseline_reference_vs_port.json")) as f:
+                    legs = json.load(f)["legs"]
+                out["cpu_baseline"]["port_over_reference_module"] = {k: round(v["port_over_reference_throughput"], 3) for k, v in legs.items()}
+                out["cpu_baseline"]["pinned_by"] = "tests/test_oracle.py::test_cpu_baseline_port_matches_reference_run"
+            except (OSError, KeyError, ValueError):
+                pass
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -48,8 +48,17 @@ class _ChamferCPU(torch.autograd.Function):
         return gx1, gx2
 
 
+class _Project(nn.Module):
+    """Holds the temperature under the reference's state_dict key (project._temperature, soft_projection.py:50-56)."""
+
+    def __init__(self, initial_temperature):
+        super().__init__()
+        self._temperature = nn.Parameter(torch.tensor(initial_temperature, dtype=torch.float32))
+
+
 class SampleNetCPU(nn.Module):
-    """Same parameters / state_dict keys as the reference module."""
+    """Same parameters / state_dict keys as the reference module (a reference checkpoint loads with strict=True); pinned to a
+    run of the reference module itself by tests/test_oracle.py::test_cpu_baseline_port_matches_reference_run."""
 
     def __init__(self, num_out_points, bottleneck_size, group_size, initial_temperature=1.0, min_sigma=1e-2):
         super().__init__()
@@ -61,7 +70,11 @@ class SampleNetCPU(nn.Module):
         self.fc1, self.fc2, self.fc3 = nn.Linear(bottleneck_size, 256), nn.Linear(256, 256), nn.Linear(256, 256)
         self.fc4 = nn.Linear(256, 3 * num_out_points)
         self.bn_fc1, self.bn_fc2, self.bn_fc3 = nn.BatchNorm1d(256), nn.BatchNorm1d(256), nn.BatchNorm1d(256)
-        self.temperature = nn.Parameter(torch.tensor(initial_temperature, dtype=torch.float32))
+        self.project = _Project(initial_temperature)
+
+    @property
+    def temperature(self):
+        return self.project._temperature
 
     def sigma(self):
         return torch.max(self.temperature ** 2, torch.tensor(self.min_sigma))

@@ -143,14 +143,24 @@ def test_bench_path_matches_reference_c2(golden, oracle, tag):
     # state is checked by the module-surface test below
 
 
+@pytest.mark.parametrize("route", ["op_by_op", "captured"])
 @pytest.mark.parametrize("tag", ["k8", "k7"])
-def test_module_surface_matches_reference_c2(golden, oracle, tag):
+def test_module_surface_matches_reference_c2(golden, oracle, tag, route, monkeypatch):
     """The same step through the drop-in module surface (forward + get_simplification_loss + get_projection_loss +
-    autograd), as registration/main.py:507-531 issues it."""
+    autograd), as registration/main.py:507-531 issues it.  route "captured": those calls replay the two graphs of
+    samplenet_amd/surface.py (captured at the first call here instead of after two warm steps, so that exactly one training step
+    has run from the fixture's state -- the capture's own warm-up pass restores the running statistics it advanced)."""
+    from samplenet_amd import surface
+
     g = golden("samplenet_c2_reference.npz")
     net, (B, N, M, K) = _net(g, tag)
     x = torch.from_numpy(g[f"{tag}_x"]).cuda()
+    if route == "captured":
+        monkeypatch.setattr(surface, "WARM_STEPS", 0)
+    else:
+        net.graph_surface = False
     simp, proj = net(x)
+    assert any(isinstance(p, surface._Plan) for p in net.__dict__.get("_sn_surface", {}).values()) == (route == "captured")
     lsimp = net.get_simplification_loss(x, simp, M, GAMMA, DELTA)
     lproj = net.get_projection_loss()
     loss = ALPHA * lsimp + LMBDA * lproj + proj.mean()
@@ -206,6 +216,28 @@ def _task_fixture(g):
     return net.cuda().train(), pcr.cuda().eval(), torch.from_numpy(g["p0"]).cuda(), torch.from_numpy(g["p1"]).cuda()
 
 
+def test_script_with_task_network_on_captured_surfaces_matches_reference_run(golden, monkeypatch):
+    """registration/main.py:500-537 + 557-598 as a SCRIPT issues them -- net(x), the two loss getters, the frozen task network's
+    Chamfer term on the projected points, backward() -- with every call on captured work (surface.py for the sampler,
+    graphed.py for the task network), against the reference run, under the bars of test_task_step_matches_reference_run."""
+    from samplenet_amd import graphed, surface
+    from samplenet_amd.task_features import pcrnet_chamfer_loss
+
+    monkeypatch.setattr(surface, "WARM_STEPS", 0)
+    monkeypatch.setattr(graphed, "WARM_STEPS", 0)
+    g = golden("samplenet_task_reference.npz")
+    net, pcr, p0, p1 = _task_fixture(g)
+    simp, proj = net(p1)
+    loss = pcrnet_chamfer_loss(pcr, p0, proj)[0] + ALPHA * net.get_simplification_loss(p1, simp, 64, GAMMA, DELTA) \
+        + LMBDA * net.get_projection_loss()
+    loss.backward()
+    torch.cuda.synchronize()
+    net.check()
+    assert any(isinstance(p, surface._Plan) for p in net.__dict__["_sn_surface"].values())
+    assert any(isinstance(p, graphed._Plan) for p in pcr.__dict__["_sn_graphed"].values())
+    _check_task_step(g, "script", loss.detach(), simp.detach(), proj.detach(), net)
+
+
 @pytest.mark.parametrize("path", ["fused_graph", "fused_eager", "general"])
 def test_task_step_matches_reference_run(golden, path):
     """registration/main.py:500-537 + 557-598 (--loss-type 1, one sampled cloud) END TO END against the reference run
@@ -231,6 +263,10 @@ def test_task_step_matches_reference_run(golden, path):
     step.check()
     y, proj = step.outputs
     simp = y.permute(0, 2, 1) if path != "general" else y  # fast path: (B,3,M); general path: the module's 'bnc' output
+    _check_task_step(g, path, loss, simp, proj, net)
+
+
+def _check_task_step(g, path, loss, simp, proj, net):
     e_simp = float((simp.cpu() - torch.from_numpy(g["simp"])).abs().max())
     print("\n[%s] loss %.9f  ref fp32 %.9f  fp64 %.9f   simp max|d| %.2e" % (path, float(loss), float(g["loss"]), float(g["loss_f64"]), e_simp))
     assert e_simp <= 5e-5

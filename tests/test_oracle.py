@@ -232,3 +232,54 @@ def test_nn_matching_matches_reference(oracle, golden):
     k = g["idx"].shape[1]
     assert np.array_equal(oracle.nn_matching(g["pc"], g["idx"], k, True), g["out_fps"])
     assert np.array_equal(oracle.nn_matching(g["pc"], g["idx"], k, False), g["out_nofps"])
+
+
+# ------------------------------------------------------------------ the cpu_baseline port (bench.py's `cpu_baseline` leg)
+@pytest.mark.parametrize("tag", ["c1", "m"])
+def test_cpu_baseline_port_matches_reference_run(golden, tag):
+    """oracle/cpu_reference_model.SampleNetCPU -- what bench.py times as `cpu_baseline` ("kind": "port") -- against a RUN of the
+    reference module (tests/golden/samplenet_reference.npz, generator: make_golden.py golden_samplenet: reference SampleNet +
+    SoftProjection + the reference's compiled Chamfer loop): the reference's state_dict loads with strict=True, and one training
+    step as registration/main.py:507-531 issues it reproduces the simplified / projected clouds, both losses, every gradient
+    and the BatchNorm running statistics.  Same torch CPU ops in the same order: bars are rounding noise (kNN: the port's
+    broadcast + topk stand-in picks the same neighbour sets as the generator's (distance, index)-ordered one on this data).
+    (The generator's "m" case shares c1's initial state_dict.)"""
+    import torch
+
+    from oracle.cpu_reference_model import SampleNetCPU
+
+    g = golden("samplenet_reference.npz")
+    B, N, M, K, bneck, _ = [int(v) for v in g[f"{tag}_cfg"]]
+    net = SampleNetCPU(M, bneck, K, initial_temperature=1.0, min_sigma=1e-2)
+    sd = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("c1_sd_")}  # ("m" shares c1's initial state)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    net.train()
+    x = torch.from_numpy(g[f"{tag}_x"])
+    simp, proj = net(x)
+    lsimp = net.get_simplification_loss(x, simp, M, 1.0, 0.5 / M)
+    lproj = net.sigma()
+    gw = torch.from_numpy(g[f"{tag}_gw"])
+    loss = 0.01 * lsimp + 0.01 * lproj + (proj * gw).sum() / proj.numel()
+    loss.backward()
+    # "m" (B = 16) holds at any MKL thread count (measured 1..8 threads: clouds <= 1.5e-6, gradients <= 4e-4 of their norm, the worst at
+    # conv1 through nine BatchNorm backward passes; bit-equal at the generator's 8; bar 1e-3).  "c1" (B = 4, the survey's plumbing case): BatchNorm over FOUR rows of nearly identical pooled
+    # features turns the reduction order of the thread count into 4e-5 on the clouds and O(1) on some gradients -- the
+    # reference run itself is only reproducible there at its own thread count -- so c1 pins the outputs and losses only.
+    tight = tag == "m"
+    np.testing.assert_allclose(simp.detach().numpy(), g[f"{tag}_simp"], rtol=0, atol=2e-6 if tight else 1e-4)
+    close = np.isclose(proj.detach().numpy(), g[f"{tag}_proj"], rtol=0, atol=2e-6 if tight else 1e-4)
+    assert close.mean() >= (1.0 if tight else 0.99)
+    assert abs(float(lsimp.detach()) - float(g[f"{tag}_lsimp"])) <= (1e-6 if tight else 1e-4) * abs(float(g[f"{tag}_lsimp"]))
+    assert float(lproj.detach()) == float(g[f"{tag}_lproj"])
+    assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) <= (1e-6 if tight else 2e-5) * max(1.0, abs(float(g[f"{tag}_loss"])))
+    if not tight:
+        return
+    gmax = max(np.linalg.norm(g[k]) for k in g.files if k.startswith(f"{tag}_grad_"))
+    for name, p in net.named_parameters():
+        ref = g[f"{tag}_grad_{name}"].astype(np.float64)
+        err = np.linalg.norm(p.grad.numpy().astype(np.float64) - ref)
+        assert err <= max(1e-3 * np.linalg.norm(ref), 1e-5 * gmax), (name, err, np.linalg.norm(ref))
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            np.testing.assert_allclose(v.numpy(), g[f"{tag}_sd1_{k}"], rtol=1e-5, atol=1e-7, err_msg=k)
