@@ -6453,7 +6453,9 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
     else
         hipLaunchKernelGGL((linear_bwd_kernel<TileBig, DZ_POOL, ACT_BN_RELU>), grid, dim3(TileBig::THREADS), lds, st, d, w, n_w, wgx, wgy, dgx);
     const int nred = (Co * Ci) % 4 == 0 ? (Co * Ci + kRedElems - 1) / kRedElems : (Co * Ci + 63) / 64;
-    hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, nsplit, Co, Ci, part, dW, nblk, Ci,
+    // (the statistics partials THIS route fills: one per TileBig row block -- at R == 64 sn_linear_stats_blocks counts TileSmall
+    //  blocks, and summing that many read an unwritten block: wrong dgamma / dbeta / dbias of the layer below at exactly 64 rows)
+    hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, nsplit, Co, Ci, part, dW, dgx, Ci,
                        stats, bb);
     SN_LAUNCH_CHECK();
     return 0;

@@ -47,7 +47,12 @@ def _rel(a, b):
 
 
 CFGS = [(4, 1024, 64, 8, 128, "bnc"), (3, 96, 12, 5, 32, "bcn"), (32, 1024, 64, 8, 128, "bnc"), (6, 130, 7, 4, 40, "bnc"),
-        (70, 64, 16, 4, 128, "bnc"), (33, 1024, 64, 8, 128, "bnc"), (48, 512, 32, 8, 64, "bnc")]
+        (70, 64, 16, 4, 128, "bnc"), (33, 1024, 64, 8, 128, "bnc"), (48, 512, 32, 8, 64, "bnc"),
+        # exactly 64 rows in the FC head: the combined backward's statistics partials are one TileBig block where
+        # sn_linear_stats_blocks counts two TileSmall blocks (round 4: the BatchNorm-backward sums read an unwritten block)
+        # (shapes are picked where neither fp32 run takes another max-pool / ReLU branch than the fp64 run under this seed: at
+        #  (128, 128) the HIP run does -- 6e-4 on the conv gradients --, at (128, 256) torch's own fp32 run does -- 4e-3)
+        (64, 256, 64, 8, 128, "bnc"), (96, 128, 32, 8, 128, "bnc")]
 
 
 @pytest.mark.parametrize("cfg", CFGS)
