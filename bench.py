@@ -569,7 +569,7 @@ def time_config5_progressive(dev, steps=40):
             "graph": {"ms_per_step": gms, "value": B / gms * 1e3, "unit": "point-clouds/s"}}
 
 
-def time_batch_sweep(dev, N, M, K, batches=(32, 128, 512)):
+def time_batch_sweep(dev, N, M, K, batches=(32, 128, 512, 2048)):
     """The whole sampler step (the headline's unit of work) at growing batches: B = 32 is latency-bound by construction (14
     dependent launches), larger batches show what the kernels reach when fed.  Fractions: MLP flops / step time against the
     fp32 MFMA peak; SURVEY 8d's algorithmic bytes (3.73 MB per cloud: activations written once and read once per consumer,

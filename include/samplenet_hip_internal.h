@@ -47,6 +47,11 @@ int sn_sampler_step_loss_forward(int B, int M, int N, int G, const float *dist_q
                                  const float *temperature, float alpha, float lmbda, float weight, float min_sigma,
                                  float *dist_p, int *idx_p, int *argmax1, float *partial, float *loss, int defer_value,
                                  sn_stream_t stream);
+/* sn_sampler_step_loss_forward behind a scan that ran one workgroup per cloud (sn_pairscan_colmin_splits <= 1: batches that
+ * fill the chip on their own; dist_p / idx_p complete, e.g. from sn_pairscan_forward_ws): same partial / loss outputs. */
+int sn_sampler_step_loss_forward_direct(int B, int M, int N, const float *dist_q, const float *dist_p, const float *proj,
+                                        const float *temperature, float alpha, float lmbda, float weight, float min_sigma,
+                                        int *argmax1, float *partial, float *loss, int defer_value, sn_stream_t stream);
 int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,
                                   const int *knn_idx, const int *idx_q, const int *idx_p, const int *argmax1,
                                   const float *temperature, float min_sigma, float alpha, float lmbda, float weight,

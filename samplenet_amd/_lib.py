@@ -45,6 +45,7 @@ PROTOTYPES = {
     "sn_pairscan_forward_partial_fc": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f,
                                        _vp, ctypes.c_longlong, _vp],
     "sn_sampler_step_loss_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "sn_sampler_step_loss_forward_direct": [_i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _i, _vp],
     "sn_sampler_step_loss_backward": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp],
     "sn_pairscan_forward_keys": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp,

@@ -1345,6 +1345,59 @@ extern "C" int sn_sampler_step_loss_forward(int B, int M, int N, int G, const fl
     return 0;
 }
 
+// sn_sampler_step_loss_forward behind a scan that ran ONE workgroup per cloud (batches that fill the chip on their own:
+// sn_pairscan_colmin_splits(B, N, M) <= 1 -- dist_p / idx_p are complete, there are no partial key sets): per-cloud sums over
+// dist_q / dist_p / proj and the arg-max of dist_q, then the clouds in order.  Same partial layout, same final kernel.
+__global__ void __launch_bounds__(256) step_loss_partial_direct_kernel(int M, int N, int nproj, const float *__restrict__ dq,
+                                                                       const float *__restrict__ dp, const float *__restrict__ proj,
+                                                                       float *__restrict__ part, int *__restrict__ argmax1)
+{
+    constexpr int NT = 256;
+    __shared__ float r0[NT], r1[NT], r2[NT], r3[NT];
+    __shared__ int ri[NT];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float s1 = 0.f, mx = -INFINITY, s2 = 0.f, sp = 0.f;
+    int am = 0;
+    for (int j = t; j < M; j += NT) {
+        const float v = dq[(size_t)b * M + j];
+        s1 += v;
+        if (v > mx) mx = v, am = j;
+    }
+    for (int n = t; n < N; n += NT) s2 += dp[(size_t)b * N + n];
+    for (int i = t; i < nproj; i += NT) sp += proj[(size_t)b * nproj + i];
+    r0[t] = s1, r1[t] = mx, r2[t] = s2, r3[t] = sp, ri[t] = am;
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        __syncthreads();
+        if (t < s) {
+            r0[t] += r0[t + s];
+            r2[t] += r2[t + s];
+            r3[t] += r3[t + s];
+            if (r1[t + s] > r1[t] || (r1[t + s] == r1[t] && ri[t + s] < ri[t])) r1[t] = r1[t + s], ri[t] = ri[t + s];
+        }
+    }
+    if (t == 0) {
+        part[b * 4 + 0] = r0[0], part[b * 4 + 1] = r1[0], part[b * 4 + 2] = r2[0], part[b * 4 + 3] = r3[0];
+        argmax1[b] = ri[0];
+    }
+}
+
+extern "C" int sn_sampler_step_loss_forward_direct(int B, int M, int N, const float *dist_q, const float *dist_p, const float *proj,
+                                                   const float *temperature, float alpha, float lmbda, float weight,
+                                                   float min_sigma, int *argmax1, float *partial, float *loss, int defer_value,
+                                                   sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && M >= 1 && N >= 1, "bad size");
+    SN_REQUIRE(dist_q && dist_p && proj && temperature && argmax1 && partial && loss, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(step_loss_partial_direct_kernel, dim3(B), dim3(256), 0, st, M, N, 3 * M, dist_q, dist_p, proj, partial, argmax1);
+    if (!defer_value) {
+        const StepLossFinal f{B, M, N, 3 * M, weight, alpha, lmbda, min_sigma, partial, temperature, loss};
+        hipLaunchKernelGGL(step_loss_final_kernel, dim3(1), dim3(64), 0, st, f);
+    }
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 // grad_Q (B,3,M) channel-major (the FC head's layout), grad_T (1).  P: (B,N,3) or (B,3,N) by p_layout; Q: (B,3,M).
 // gsig_scratch: B * sn_soft_bwd_splits(B, M) floats.
 extern "C" int sn_sampler_step_loss_backward(int B, int N, int M, int K, const float *P, int p_layout, const float *Q,

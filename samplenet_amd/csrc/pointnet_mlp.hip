@@ -4028,37 +4028,110 @@ __global__ void __launch_bounds__(1024) bn_finalize_pool_kernel(int nblk, int C,
     }
 }
 
+// bn_finalize_pool_kernel for any batch: the last conv layer left, per cloud and channel, (max Z, first row) / (min Z, first row) as
+// 64-bit keys (FwdArgs::pool_keys) instead of per-64-row-block partials, so the pick is a decode, spread over the clouds (the
+// block-partial kernel reads B * N / 64 partials per channel with four workgroups: 6 us at B = 32, 50 us at B = 512).  Every
+// workgroup finalises the BatchNorm of all C <= 128 channels itself from the fixed-point sums (35 words per channel); workgroup 0
+// stores the coefficients / running statistics; the workgroup that arrives last at the counter word behind the poison word
+// clears the sums (every workgroup has read them by then); the accumulators the previous kernel consumed are cleared in shares.
+// Same expressions as the FC chain's pool stage: bit-identical pooled / argsel / zsel.
+constexpr int kFxArrive = kFxPoison + 8;  // spare word of a layer's accumulator block
+__global__ void __launch_bounds__(256) bn_finalize_pool_keys_kernel(BnFwd bn, int B, int C, int cpb,
+                                                                    const unsigned long long *__restrict__ keys,
+                                                                    float *__restrict__ pooled, int *__restrict__ argsel,
+                                                                    float *__restrict__ zsel, long long *__restrict__ acc,
+                                                                    long long *__restrict__ zero_ptr, int zero_n)
+{
+    __shared__ float s_sc[128], s_sh[128];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
+    if (tid < C) {
+        const BnFwdIn in = bn_fwd_inputs(bn, tid);
+        double s, ss;
+        fx_get2<kFxShiftFwd>(acc, tid, s, ss);
+        const float2 cf = bn_finalize_channel(bn, C, tid, s, ss, in, blockIdx.x == 0);
+        s_sc[tid] = cf.x, s_sh[tid] = cf.y;
+    }
+    fx_clear_share(zero_ptr, zero_n, blockIdx.x, gridDim.x, tid, 256);
+    __syncthreads();  // (every read of acc by this workgroup has returned)
+    if (tid == 0)
+        s_last = atomicAdd(reinterpret_cast<unsigned long long *>(acc + kFxArrive), 1ull) == (unsigned long long)gridDim.x - 1;
+    const int b0 = blockIdx.x * cpb, n = min(cpb, B - b0) * C;
+    for (int i = tid; i < n; i += 256) {
+        const int b = b0 + i / C, c = i % C;
+        const float sc = s_sc[c], sh = s_sh[c];
+        float v;
+        int row;
+        if (sc >= 0.f) {
+            pool_key_decode(keys[((size_t)b * 2) * C + c], v, row);
+        } else {
+            pool_key_decode(keys[((size_t)b * 2 + 1) * C + c], v, row);
+            v = -v;
+        }
+        const size_t o = (size_t)b * C + c;
+        pooled[o] = relu_np(fmaf(v, sc, sh)), argsel[o] = row, zsel[o] = v;
+    }
+    __syncthreads();
+    if (s_last)  // lo rows, hi rows and the arrival word; the poison word belongs to the first kernel of the next step
+        for (int i = tid; i < kFxLayer; i += 256)
+            if (i != kFxPoison) acc[i] = 0;
+}
+
 // Batch statistics of a SHORT activation matrix (the FC head at batches above 32: R rows, a few hundred at most) straight from
 // z in two passes -- mean, then the squares around it, in double.  Behind the max-pool the head's features are nearly the same
 // for every cloud (|mean| / std of 10..100): E[z^2] - mean^2 from fp32 block sums loses 2..4 digits of the variance there.
-__global__ void __launch_bounds__(256) bn_twopass_kernel(int R, int C, const float *__restrict__ z, BnFwd bn)
+__global__ void __launch_bounds__(1024) bn_twopass_kernel(int R, int C, const float *__restrict__ z, BnFwd bn)
 {
-    __shared__ double red[4][64];
+    // 64 channels x 16 row stripes per workgroup, eight independent loads in flight per thread (round 4: four stripes and one
+    // dependent load per trip took 46 us for 512 x 256 values -- a memory round trip per row); fixed summation order
+    __shared__ double red[16][64];
     if (blockIdx.x == 0 && threadIdx.x == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
     const int lane = threadIdx.x & 63, stripe = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const bool ok = c < C;
     BnFwdIn in{};
     if (ok && stripe == 0) in = bn_fwd_inputs(bn, c);
+    const float *zc = z + (ok ? c : 0);
+    const auto total = [&]() {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][lane];
+        return t;
+    };
     double s = 0.0;
-    if (ok)
-        for (int r = stripe; r < R; r += 4) s += (double)z[(size_t)r * C + c];
+    int r = stripe;
+    for (; r + 7 * 16 < R; r += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = zc[(size_t)(r + 16 * i) * C];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += (double)v[i];
+    }
+    for (; r < R; r += 16) s += (double)zc[(size_t)r * C];
     red[stripe][lane] = s;
     __syncthreads();
-    const double mean = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (double)R;
+    const double mean = total() / (double)R;
     __syncthreads();
     double q = 0.0;
-    if (ok)
-        for (int r = stripe; r < R; r += 4) {
-            const double d = (double)z[(size_t)r * C + c] - mean;
+    r = stripe;
+    for (; r + 7 * 16 < R; r += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = zc[(size_t)(r + 16 * i) * C];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double d = (double)v[i] - mean;
             q += d * d;
         }
+    }
+    for (; r < R; r += 16) {
+        const double d = (double)zc[(size_t)r * C] - mean;
+        q += d * d;
+    }
     red[stripe][lane] = q;
     __syncthreads();
-    if (stripe == 0 && ok) {
-        const double var = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) / (double)R;
-        bn_finalize_channel_mv(bn, C, c, mean, var, in);
-    }
+    if (stripe == 0 && ok) bn_finalize_channel_mv(bn, C, c, mean, total() / (double)R, in);
 }
 
 // eval: coefficients from the running statistics
@@ -4385,14 +4458,31 @@ __global__ void __launch_bounds__(1024) pool_bwd_kernel(int B, int C, const floa
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f, sz = 0.f;
-    if (c < C)
-        for (int b = sl; b < B; b += 16) {
+    if (c < C) {
+        int b = sl;
+        for (; b + 3 * 16 < B; b += 4 * 16) {  // (four trips' loads in flight; the sums keep their ascending order)
+            float pv[4], gv[4], zv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t o = (size_t)(b + 16 * i) * C + c;
+                pv[i] = pooled[o], gv[i] = g[o], zv[i] = zsel[o];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = pv[i] > 0.f ? gv[i] : 0.f;
+                gsel[(size_t)(b + 16 * i) * C + c] = v;
+                s += v;
+                sz += v * zv[i];
+            }
+        }
+        for (; b < B; b += 16) {
             const size_t o = (size_t)b * C + c;
             const float v = pooled[o] > 0.f ? g[o] : 0.f;
             gsel[o] = v;
             s += v;
             sz += v * zsel[o];
         }
+    }
     red[0][sl][cl] = s, red[1][sl][cl] = sz;
     __syncthreads();
     if (sl == 0 && c < C) {
@@ -5934,7 +6024,11 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         if (nb > R / 64) job.n = 0;  // (cannot happen for R > 64 * 44; keep the planes off then)
     }
 #endif
-    if (!pooled) {  // the last layer publishes pool keys (B, 2, Cn) into pool_val: cleared by this call's first kernel
+    // the last layer publishes pool keys (B, 2, Cn) into pool_val (cleared by this call's first kernel) when the FC chain's pool
+    // stage follows (pooled == NULL), and when this call finishes the pool itself above 32 clouds (bn_finalize_pool_keys_kernel:
+    // the block-partial pick does not scale with the batch) -- provided the caller's (R / 64, 2, Cn) float scratch holds them
+    const bool keys_pool = !pooled || (B > 32 && N >= 128 && channels[nlayers] <= 128);
+    if (keys_pool) {
         job.zero_keys = reinterpret_cast<unsigned long long *>(pool_val), job.nkeys = B * 2 * channels[nlayers];
         SN_REQUIRE((long long)job.nkeys <= (long long)(R / 64) * 256, "too few rows to clear the pool keys");
     }
@@ -5951,8 +6045,8 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         if (l >= 2) g.zero_ptr = acc + (size_t)(l - 2) * kFxLayer, g.zero_n = kFxLayer;
         if (l == nlayers - 1) {
             g.pool_npts = N;
-            if (pooled) g.pool_val = pool_val, g.pool_idx = pool_idx;
-            else g.pool_keys = reinterpret_cast<unsigned long long *>(pool_val);  // (the pool stage of the FC chain follows)
+            if (!keys_pool) g.pool_val = pool_val, g.pool_idx = pool_idx;
+            else g.pool_keys = reinterpret_cast<unsigned long long *>(pool_val);  // (decoded by the FC chain's pool stage / below)
         }
         g.wplanes = job.n > 0 ? planes[l] : nullptr;
         const bool pl = g.wplanes != nullptr;
@@ -5990,6 +6084,14 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
     const int Cn = channels[nlayers];
     long long *zp = nlayers >= 2 ? acc + (size_t)(nlayers - 2) * kFxLayer : nullptr;
     if (!pooled) {  // the last BatchNorm + the pool pick run as the first stage of sn_fc_chain_forward_pool
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
+    if (keys_pool) {
+        const int cpb = 8;  // clouds per workgroup
+        hipLaunchKernelGGL(bn_finalize_pool_keys_kernel, dim3((B + cpb - 1) / cpb), dim3(256), 0, st, bn_of(nlayers - 1), B, Cn, cpb,
+                           reinterpret_cast<const unsigned long long *>(pool_val), pooled, argsel, zsel,
+                           acc + (size_t)(nlayers - 1) * kFxLayer, zp, zp ? kFxLayer : 0);
         SN_LAUNCH_CHECK();
         return 0;
     }
@@ -6650,7 +6752,7 @@ extern "C" int sn_bn_batch_stats_twopass(int R, int C, const float *z, const flo
 {
     SN_REQUIRE(R >= 1 && C >= 1 && z && gamma && beta && coef, "bad argument");
     const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
-    hipLaunchKernelGGL(bn_twopass_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, R, C, z, bn);
+    hipLaunchKernelGGL(bn_twopass_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, R, C, z, bn);
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -77,7 +77,12 @@ class SamplerTrainStep:
         from ._lib import lib
 
         B, N, _ = self.x.shape
-        if lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) <= 1:
+        split = lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1
+        if self.task_loss is None:
+            # (batches that fill the chip with one workgroup per cloud: same single-node loss behind the plain scan -- fc4 as a
+            #  launch of its own, per-cloud loss partials; ops.step_loss_forward)
+            return split or N <= 2048
+        if not split:
             return False
         if self.task_loss is not None:
             from .fused_step import external_task_supported
@@ -129,7 +134,8 @@ class SamplerTrainStep:
                 else:  # a task term that does not depend on the sampler: the projection branch gets a zero gradient
                     loss.backward(self._one)
                 return loss.detach() + task.detach()
-            if self.fused_head and net.use_hip_mlp:
+            B, N, _ = x.shape
+            if self.fused_head and net.use_hip_mlp and ops.lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1:
                 from .fused_step import sampler_step
 
                 loss, y, proj = sampler_step(net, x, self.alpha, self.lmbda, weight, t_sink, True)  # fc4 inside the scan

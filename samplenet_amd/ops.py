@@ -551,16 +551,31 @@ def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight,
     N = x.shape[1]
     dev = y.device
     G = lib.sn_pairscan_colmin_splits(B, N, M)
-    if G <= 1:
-        raise ValueError("the single-node step loss needs a batch small enough for split clouds (use the op-by-op path)")
+    if G <= 1 and (fc is not None or keys is not None):
+        raise ValueError("fc4 inside the scan / the keys-mode step need a batch small enough for split clouds")
     proj = torch.empty(B, M, 3, device=dev, dtype=torch.float32)
     idx = torch.empty(B, M, K, device=dev, dtype=torch.int32)
     dq = torch.empty(B, M, device=dev, dtype=torch.float32)
     iq = torch.empty(B, M, device=dev, dtype=torch.int32)
     dp = torch.empty(B, N, device=dev, dtype=torch.float32)
     ip = torch.empty(B, N, device=dev, dtype=torch.int32)
-    ws = torch.empty(B * G * N, device=dev, dtype=torch.int64)
     argmax1 = torch.empty(B, device=dev, dtype=torch.int32)
+    if G <= 1:
+        # the batch fills the chip with one workgroup per cloud: the scan finishes dist_p / idx_p itself (no partial key sets);
+        # per-cloud loss partials in parallel, then the clouds in order -- the backward is the same fused launch
+        partial = torch.empty(B * 4, device=dev, dtype=torch.float32)
+        loss = torch.empty(2, device=dev, dtype=torch.float32)
+        T = temperature.detach().float().reshape(1)
+        wsb = lib.sn_pairscan_workspace_bytes(B, N, M)
+        wsd = torch.empty(wsb // 8, device=dev, dtype=torch.int64) if wsb else None
+        st = _stream(y)
+        check(lib.sn_pairscan_forward_ws(B, N, M, K, ptr(x), BNC, ptr(y), BCN, ptr(idx), None, ptr(dq), ptr(iq), ptr(dp), ptr(ip),
+                                         ptr(proj), BNC, None, ptr(T), float(min_sigma), ptr(wsd), wsb, st), "sn_pairscan_forward_ws")
+        check(lib.sn_sampler_step_loss_forward_direct(B, M, N, ptr(dq), ptr(dp), ptr(proj), ptr(T), float(alpha), float(lmbda),
+                                                      float(weight), float(min_sigma), ptr(argmax1), ptr(partial), ptr(loss),
+                                                      1 if defer_value else 0, st), "sn_sampler_step_loss_forward_direct")
+        return loss, proj, (idx, iq, ip, argmax1, (partial, loss) if defer_value else (None, None))
+    ws = torch.empty(B * G * N, device=dev, dtype=torch.int64)
     partial = torch.empty(B * 4, device=dev, dtype=torch.float32)
     loss = torch.empty(2, device=dev, dtype=torch.float32)
     T = temperature.detach().float().reshape(1)

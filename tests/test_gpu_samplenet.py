@@ -169,7 +169,10 @@ def test_fused_sampler_loss_equals_composition():
     assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("B,N,M,K", [(6, 512, 64, 8), (32, 1024, 64, 8), (3, 320, 20, 5)])
+# (512, 1024) / (600, 256): batches that fill the chip with one workgroup per cloud -- the scan finishes the per-point minima itself
+# (no partial key sets: sn_sampler_step_loss_forward_direct), the FC head runs layer by layer with two-pass statistics, the last
+# conv layer's max-pool is decoded from per-cloud keys (bn_finalize_pool_keys_kernel)
+@pytest.mark.parametrize("B,N,M,K", [(6, 512, 64, 8), (32, 1024, 64, 8), (3, 320, 20, 5), (512, 1024, 64, 8), (600, 256, 32, 8)])
 def test_single_node_step_loss_equals_composition(B, N, M, K):
     """engine fast path (ops.SamplerStepLossFunction: pair scan with partial per-point minima -> loss -> 3-launch backward)
     against (a) the same engine composing the loss through the module's own forward / get_simplification_loss and
