@@ -222,6 +222,22 @@ int sn_soft_project_backward(int b, int n, int m, int k, const float *P, int p_l
                              const float *grad_proj, int gproj_layout,
                              float *grad_Q, int gq_layout, float *grad_P, float *grad_sigma_partial,
                              sn_stream_t stream);
+/* The same three backward entries with a DETERMINISTIC gradient towards the point cloud / the features: the contributions are
+ * summed per destination point in the order of the reference's loops (query ascending, neighbour ascending;
+ * soft_projection.py:75-152 through autograd's index_add on CPU) instead of by unordered float atomics -- bit-identical from
+ * run to run and to the CPU oracle.  grad_P / grad_X (required) are OVERWRITTEN, not accumulated.  scratch: b * m * k * 3 floats
+ * (sn_weighted_gather_backward_ordered: b * c * m * k). */
+int sn_soft_project_backward_ordered(int b, int n, int m, int k, const float *P, int p_layout, const float *Q, int q_layout,
+                                     const int *idx, const float *temperature, float min_sigma, const float *grad_proj,
+                                     int gproj_layout, float *grad_Q, int gq_layout, float *grad_P,
+                                     float *grad_sigma_partial, float *scratch, sn_stream_t stream);
+int sn_soft_weights_backward_ordered(int b, int n, int m, int k, const float *P, const float *Q, const int *idx,
+                                     const float *temperature, float min_sigma, const float *weights,
+                                     const float *grad_weights, float *grad_Q, float *grad_P, float *grad_sigma_partial,
+                                     float *scratch, sn_stream_t stream);
+int sn_weighted_gather_backward_ordered(int b, int c, int n, int m, int k, const float *X, const int *idx,
+                                        const float *weights, const float *grad_out, float *grad_weights, float *grad_X,
+                                        float *scratch, sn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * EMD: approx_match / match_cost / match_cost_grad.

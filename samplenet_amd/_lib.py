@@ -70,6 +70,9 @@ PROTOTYPES = {
     "sn_weighted_gather_forward": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "sn_weighted_gather_backward": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_soft_project_backward": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp],
+    "sn_soft_project_backward_ordered": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "sn_soft_weights_backward_ordered": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_weighted_gather_backward_ordered": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_linear_stats_blocks": [_i],
     "sn_layer_forward_bn": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_conv_forward_bn_pool": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp,

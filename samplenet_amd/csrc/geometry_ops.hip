@@ -214,6 +214,10 @@ struct SoftBwdArgs {
     float *grad_Q;
     int gq_layout;
     float *grad_P;  // (b,3,n) channel-major in split mode, p_layout in fused mode; atomics
+    // ordered route (sn_*_backward_ordered): the per-(query, neighbour) contributions to grad_P are STORED here instead of added
+    // with atomics -- entry e = j * k + t; (b, m k, 3) for a point-major grad_P, (b, 3, m k) for a channel-major one -- and summed
+    // by index_add_ordered_kernel in ascending entry order: the reference's CPU loop, deterministic
+    float *gp_contrib;
     float *grad_sigma_partial;
     // fused mode, grad_proj == NULL: the upstream gradient is the same for every element, *gconst / gconst_div
     // (the sampler step's mean(proj) term); accumulate_q: add to grad_Q instead of overwriting it
@@ -351,7 +355,14 @@ __device__ __forceinline__ void soft_bwd_math(const SoftBwdArgs &a, int b, int j
             asg += readlane_f(sg, t);
         }
     }
-    if (a.grad_P && lane < K) {
+    if (a.gp_contrib && lane < K) {
+        const int lay = FUSED ? a.p_layout : SN_LAYOUT_BCN;
+        const float ex = FUSED ? go0 * w : 0.f, ey = FUSED ? go1 * w : 0.f, ez = FUSED ? go2 * w : 0.f;
+        const size_t ne = (size_t)m * K, e = (size_t)j * K + lane;
+        float *cb = a.gp_contrib + (size_t)b * ne * 3;
+        if (lay == SN_LAYOUT_BNC) cb[e * 3] = ex + cx, cb[e * 3 + 1] = ey + cy, cb[e * 3 + 2] = ez + cz;
+        else cb[e] = ex + cx, cb[ne + e] = ey + cy, cb[2 * ne + e] = ez + cz;
+    } else if (a.grad_P && lane < K) {
         float *gpb = a.grad_P + (size_t)b * 3 * n;
         const int lay = FUSED ? a.p_layout : SN_LAYOUT_BCN;
         const float ex = FUSED ? go0 * w : 0.f, ey = FUSED ? go1 * w : 0.f, ez = FUSED ? go2 * w : 0.f;
@@ -465,7 +476,8 @@ __global__ void __launch_bounds__(256) weighted_gather_bwd_kernel(int c, int n, 
                                                                   const int *__restrict__ idx,
                                                                   const float *__restrict__ w,
                                                                   const float *__restrict__ go,
-                                                                  float *__restrict__ gw, float *__restrict__ gX)
+                                                                  float *__restrict__ gw, float *__restrict__ gX,
+                                                                  float *__restrict__ contrib = nullptr)
 {
     const int b = blockIdx.y;
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over m*K
@@ -477,7 +489,8 @@ __global__ void __launch_bounds__(256) weighted_gather_bwd_kernel(int c, int n, 
     for (int ch = 0; ch < c; ++ch) {
         const float g = go[((size_t)b * c + ch) * m + j];
         acc += g * X[((size_t)b * c + ch) * n + id];
-        if (gX) atomicAdd(&gX[((size_t)b * c + ch) * n + id], g * wt);
+        if (contrib) contrib[((size_t)b * c + ch) * m * K + e] = g * wt;  // (b, c, m k): summed in entry order afterwards
+        else if (gX) atomicAdd(&gX[((size_t)b * c + ch) * n + id], g * wt);
     }
     if (gw) gw[(size_t)b * m * K + e] = acc;
 }
@@ -1220,6 +1233,59 @@ static int launch_index_add(int b, int n, int c, long long ne, const int *idx, c
     }
     SN_LAUNCH_CHECK();
     return 0;
+}
+
+// The three backward entries above with the gradient towards the point cloud / the features summed in the ORDER of the
+// reference's CPU loops (query ascending, neighbour ascending) instead of by unordered float atomics: the kernels store the
+// per-(query, neighbour) contributions in `scratch` (b * m * k * 3 floats; b * c * m * k for the gather) and
+// index_add_ordered_kernel adds, per destination row, the entries that name it in ascending entry order.  grad_P / grad_X are
+// OVERWRITTEN (every row is written), bit-identical to oracle/samplenet_oracle.c: orc_softproj_backward, run to run.
+extern "C" int sn_soft_project_backward_ordered(int b, int n, int m, int k, const float *P, int p_layout, const float *Q,
+                                                int q_layout, const int *idx, const float *temperature, float min_sigma,
+                                                const float *grad_proj, int gproj_layout, float *grad_Q, int gq_layout,
+                                                float *grad_P, float *grad_sigma_partial, float *scratch, sn_stream_t stream)
+{
+    SN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && k >= 1 && k <= 64, "bad size");
+    if (b == 0 || m == 0) return 0;
+    SN_REQUIRE(P && Q && idx && temperature && grad_proj && grad_P && scratch, "null pointer");
+    SoftBwdArgs a{};
+    a.P = P, a.Q = Q, a.idx = idx, a.temperature = temperature, a.min_sigma = min_sigma;
+    a.p_layout = p_layout, a.q_layout = q_layout, a.n = n, a.m = m, a.k = k;
+    a.grad_proj = grad_proj, a.gproj_layout = gproj_layout;
+    a.grad_Q = grad_Q, a.gq_layout = gq_layout, a.grad_P = grad_P, a.gp_contrib = scratch, a.grad_sigma_partial = grad_sigma_partial;
+    hipLaunchKernelGGL(soft_bwd_kernel<true>, dim3(b, sn_soft_bwd_splits(b, m)), dim3(256), 0, (hipStream_t)stream, a);
+    return p_layout == SN_LAYOUT_BNC ? launch_index_add<false>(b, n, 3, (long long)m * k, idx, scratch, grad_P, (hipStream_t)stream)
+                                     : launch_index_add<true>(b, n, 3, (long long)m * k, idx, scratch, grad_P, (hipStream_t)stream);
+}
+
+extern "C" int sn_soft_weights_backward_ordered(int b, int n, int m, int k, const float *P, const float *Q, const int *idx,
+                                                const float *temperature, float min_sigma, const float *weights,
+                                                const float *grad_weights, float *grad_Q, float *grad_P,
+                                                float *grad_sigma_partial, float *scratch, sn_stream_t stream)
+{
+    SN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && k >= 1 && k <= 64, "bad size");
+    if (b == 0 || m == 0) return 0;
+    SN_REQUIRE(P && Q && idx && temperature && grad_weights && grad_P && scratch, "null pointer");
+    SoftBwdArgs a{};
+    a.P = P, a.Q = Q, a.idx = idx, a.temperature = temperature, a.min_sigma = min_sigma;
+    a.p_layout = SN_LAYOUT_BCN, a.q_layout = SN_LAYOUT_BCN, a.n = n, a.m = m, a.k = k;
+    a.weights_in = weights, a.grad_weights = grad_weights;
+    a.grad_Q = grad_Q, a.gq_layout = SN_LAYOUT_BCN, a.grad_P = grad_P, a.gp_contrib = scratch, a.grad_sigma_partial = grad_sigma_partial;
+    hipLaunchKernelGGL(soft_bwd_kernel<false>, dim3(b, sn_soft_bwd_splits(b, m)), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_index_add<true>(b, n, 3, (long long)m * k, idx, scratch, grad_P, (hipStream_t)stream);
+}
+
+extern "C" int sn_weighted_gather_backward_ordered(int b, int c, int n, int m, int k, const float *X, const int *idx,
+                                                   const float *weights, const float *grad_out, float *grad_weights,
+                                                   float *grad_X, float *scratch, sn_stream_t stream)
+{
+    SN_REQUIRE(b >= 0 && c >= 0 && n >= 1 && m >= 0 && k >= 1, "bad size");
+    if (b == 0 || m == 0) return 0;
+    SN_REQUIRE(X && idx && weights && grad_out && grad_X && scratch, "null pointer");
+    hipLaunchKernelGGL(weighted_gather_bwd_kernel, dim3(((size_t)m * k + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, c, n, m,
+                       k, X, idx, weights, grad_out, grad_weights, grad_X, scratch);
+    if (c == 0) return 0;
+    return launch_index_add<true>(b, n, c, (long long)m * k, idx, scratch, grad_X, (hipStream_t)stream);
 }
 
 extern "C" int sn_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,

@@ -325,13 +325,22 @@ class SoftProjectFunction(torch.autograd.Function):
         dev = P.device
         grad_proj = grad_proj.contiguous()
         gQ = torch.empty_like(Q)
-        gP = torch.zeros_like(P) if ctx.needs_input_grad[0] else None
         gsig = torch.empty(B * lib.sn_soft_bwd_splits(B, M), device=dev, dtype=torch.float32)
         T = temperature.detach().float().reshape(1)
+        gP = None
         with torch.cuda.device(dev):
-            check(lib.sn_soft_project_backward(B, N, M, ctx.K, ptr(P), ctx.p_layout, ptr(Q), BCN, ptr(idx), ptr(T),
-                                               ctx.min_sigma, ptr(grad_proj), ctx.out_layout, ptr(gQ), BCN, ptr(gP), ptr(gsig),
-                                               _stream(P)), "sn_soft_project_backward")
+            if ctx.needs_input_grad[0]:
+                # gradient towards the point cloud: contributions stored per (query, neighbour), summed per point in the
+                # reference's order (deterministic; no atomics, no zero fill)
+                gP = torch.empty_like(P)
+                scratch = torch.empty(B * M * ctx.K * 3, device=dev, dtype=torch.float32)
+                check(lib.sn_soft_project_backward_ordered(B, N, M, ctx.K, ptr(P), ctx.p_layout, ptr(Q), BCN, ptr(idx), ptr(T),
+                                                           ctx.min_sigma, ptr(grad_proj), ctx.out_layout, ptr(gQ), BCN, ptr(gP),
+                                                           ptr(gsig), ptr(scratch), _stream(P)), "sn_soft_project_backward_ordered")
+            else:
+                check(lib.sn_soft_project_backward(B, N, M, ctx.K, ptr(P), ctx.p_layout, ptr(Q), BCN, ptr(idx), ptr(T),
+                                                   ctx.min_sigma, ptr(grad_proj), ctx.out_layout, ptr(gQ), BCN, None, ptr(gsig),
+                                                   _stream(P)), "sn_soft_project_backward")
         gT = None
         if ctx.needs_input_grad[2]:
             gT = _grad_temperature(gsig, temperature, ctx.min_sigma)
@@ -365,13 +374,20 @@ class SoftWeightsFunction(torch.autograd.Function):
         K = idx.shape[2]
         grad_w = grad_w.contiguous()
         gQ = torch.empty_like(Q)
-        gP = torch.zeros_like(P) if ctx.needs_input_grad[0] else None
         gsig = torch.empty(B * lib.sn_soft_bwd_splits(B, M), device=P.device, dtype=torch.float32)
         T = temperature.detach().float().reshape(1)
+        gP = None
         with torch.cuda.device(P.device):
-            check(lib.sn_soft_weights_backward(B, N, M, K, ptr(P), ptr(Q), ptr(idx), ptr(T), ctx.min_sigma, ptr(w),
-                                               ptr(grad_w), ptr(gQ), ptr(gP), ptr(gsig), _stream(P)),
-                  "sn_soft_weights_backward")
+            if ctx.needs_input_grad[0]:
+                gP = torch.empty_like(P)
+                scratch = torch.empty(B * M * K * 3, device=P.device, dtype=torch.float32)
+                check(lib.sn_soft_weights_backward_ordered(B, N, M, K, ptr(P), ptr(Q), ptr(idx), ptr(T), ctx.min_sigma, ptr(w),
+                                                           ptr(grad_w), ptr(gQ), ptr(gP), ptr(gsig), ptr(scratch), _stream(P)),
+                      "sn_soft_weights_backward_ordered")
+            else:
+                check(lib.sn_soft_weights_backward(B, N, M, K, ptr(P), ptr(Q), ptr(idx), ptr(T), ctx.min_sigma, ptr(w),
+                                                   ptr(grad_w), ptr(gQ), None, ptr(gsig), _stream(P)),
+                      "sn_soft_weights_backward")
         gT = None
         if ctx.needs_input_grad[3]:
             gT = _grad_temperature(gsig, temperature, ctx.min_sigma)
@@ -401,10 +417,16 @@ class WeightedGatherFunction(torch.autograd.Function):
         _, M, K = idx.shape
         grad_out = grad_out.contiguous()
         gw = torch.empty_like(w) if ctx.needs_input_grad[2] else None
-        gX = torch.zeros_like(X) if ctx.needs_input_grad[0] else None
+        gX = None
         with torch.cuda.device(X.device):
-            check(lib.sn_weighted_gather_backward(B, C, N, M, K, ptr(X), ptr(idx), ptr(w), ptr(grad_out), ptr(gw), ptr(gX),
-                                                  _stream(X)), "sn_weighted_gather_backward")
+            if ctx.needs_input_grad[0]:  # (ordered sum per point: deterministic, see sn_soft_project_backward_ordered)
+                gX = torch.empty_like(X)
+                scratch = torch.empty(B * C * M * K, device=X.device, dtype=torch.float32)
+                check(lib.sn_weighted_gather_backward_ordered(B, C, N, M, K, ptr(X), ptr(idx), ptr(w), ptr(grad_out), ptr(gw),
+                                                              ptr(gX), ptr(scratch), _stream(X)), "sn_weighted_gather_backward_ordered")
+            else:
+                check(lib.sn_weighted_gather_backward(B, C, N, M, K, ptr(X), ptr(idx), ptr(w), ptr(grad_out), ptr(gw), None,
+                                                      _stream(X)), "sn_weighted_gather_backward")
         return gX, None, gw
 
 

@@ -344,6 +344,68 @@ def golden_samplenet_c2(SampleNet):
     print("wrote tests/golden/samplenet_c2_reference.npz (%d arrays)" % len(out))
 
 
+def _selection_margin(x, simp, K):
+    """Smallest coordinate shift (first order) that would change one of the step's discrete selections on this simplified cloud:
+    the K-th / (K+1)-th neighbour of a query, a query's nearest point, the arg-max of the per-cloud maximum term.  fp64."""
+    x, q = x.astype(np.float64), simp.astype(np.float64)
+    d = ((q[:, :, None, :] - x[:, None, :, :]) ** 2).sum(-1)           # (B, M, N)
+    ds = np.sort(d, axis=2)
+    knn = ((ds[:, :, K] - ds[:, :, K - 1]) / (2 * np.sqrt(ds[:, :, K]) + 1e-12)).min()
+    nn = ((ds[:, :, 1] - ds[:, :, 0]) / (2 * np.sqrt(ds[:, :, 1]) + 1e-12)).min()
+    m = np.sort(ds[:, :, 0], axis=1)
+    amax = ((m[:, -1] - m[:, -2]) / (2 * np.sqrt(m[:, -1]) + 1e-12)).min()
+    return float(min(knn, nn, amax)), (float(knn), float(nn), float(amax))
+
+
+def golden_samplenet_c2_clean(SampleNet):
+    """A K = 7 headline fixture WITHOUT near-ties: the k7 case of samplenet_c2_reference.npz sits next to
+    neighbour swaps -- a 2e-5 shift of the simplified cloud flips a dozen kNN sets there, and its gradients can then only be
+    held to 3e-2.  Here the perturbation seed is searched for the step whose discrete selections (kNN sets, nearest points,
+    the arg-max of the maximum term) survive the LARGEST coordinate shift among 600 candidates (recorded as k7c_margin; the HIP
+    head sits within 2e-5 of the reference's, typically 5e-6) and whose fp32 / fp64 reference runs agree to 3e-4: that fixture is held to the K = 8 bars
+    (no selection flips, gradients 3e-4).  The flipping case stays in the other file as the named discontinuity test."""
+    B, N, M, K = 32, 1024, 64, 7
+    cand = []
+    for seed in range(1000, 1600):
+        torch.manual_seed(0)
+        net = SampleNet(M, 128, group_size=K, initial_temperature=1.0, is_temperature_trainable=True,
+                        min_sigma=1e-2, input_shape="bnc", output_shape="bnc")
+        x = torch.rand(B, N, 3) - 0.5
+        torch.manual_seed(100 + seed)
+        with torch.no_grad():
+            for nme, p in net.named_parameters():
+                if "bn" in nme:
+                    p.add_(0.1 * torch.randn_like(p))
+            net.project._temperature.fill_(0.3)
+            net.train()
+            simp, _ = net(x)
+        margin, parts = _selection_margin(x.numpy(), simp.numpy(), K)
+        cand.append((margin, seed, parts))
+    cand.sort(reverse=True)
+    print("best selection margins:", [(round(m * 1e5, 2), sd) for m, sd, _ in cand[:8]], "x 1e-5", flush=True)
+    for margin, seed, parts in cand[:12]:
+        res, tmp = _c2_case(SampleNet, B, N, M, K, True, seed)
+        g32 = np.concatenate([v.numpy().ravel() for v in res["f32"]["grads"].values()]).astype(np.float64)
+        g64 = np.concatenate([v.numpy().ravel() for v in res["f64"]["grads"].values()])
+        gap = np.linalg.norm(g32 - g64) / np.linalg.norm(g64)
+        print("seed", seed, "margin %.3g (knn %.3g, nn %.3g, argmax %.3g): reference fp32 vs fp64 gradient gap %.3g" % ((margin,) + parts + (gap,)), flush=True)
+        if gap < 3e-4:
+            break
+    else:
+        raise RuntimeError("no tie-free fixture found")
+    out = {"k7c_" + k: v for k, v in tmp.items()}
+    out["k7c_seed"], out["k7c_margin"] = np.array(seed), np.array(margin)
+    for prec, r in res.items():
+        sfx = "" if prec == "f32" else "_f64"
+        for k in ("simp", "proj", "lsimp", "lproj", "loss"):
+            v = r[k].detach().numpy()
+            out[f"k7c_{k}{sfx}"] = v if v.ndim == 0 else v.astype(np.float32)
+        for k, gr in r["grads"].items():
+            out[f"k7c_grad{sfx}_{k}"] = gr.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "samplenet_c2_clean_reference.npz"), **out)
+    print("wrote tests/golden/samplenet_c2_clean_reference.npz (%d arrays)" % len(out))
+
+
 def golden_nn_matching(sputils):
     rng = np.random.default_rng(3)
     B, N, k = 3, 200, 32
@@ -558,7 +620,8 @@ if __name__ == "__main__":
     sputils = importlib.import_module("src.sputils")
     jobs = {"known": golden_known_answers, "softproj": lambda: golden_softproj(sp_mod.SoftProjection),
             "chamfer": lambda: golden_chamfer(ChamferDistance), "samplenet": lambda: golden_samplenet(sn_mod.SampleNet),
-            "c2": lambda: golden_samplenet_c2(sn_mod.SampleNet), "nn_matching": lambda: golden_nn_matching(sputils),
+            "c2": lambda: golden_samplenet_c2(sn_mod.SampleNet), "c2clean": lambda: golden_samplenet_c2_clean(sn_mod.SampleNet),
+            "nn_matching": lambda: golden_nn_matching(sputils),
             "pcrnet": lambda: golden_pcrnet(ChamferDistance), "loaders": golden_loaders, "modelnet": golden_modelnet,
             "task": lambda: golden_samplenet_task(sn_mod.SampleNet, ChamferDistance)}
     for name in (sys.argv[1:] or list(jobs)):  # python make_golden.py [job ...]   (default: all)

@@ -361,11 +361,52 @@ def test_soft_project_fused_vs_oracle(oracle, cfg):
     assert np.array_equal(dp.cpu().numpy(), od[2]) and np.array_equal(ip.cpu().numpy(), od[3])
     gp = np.random.default_rng(9).standard_normal(oproj.shape).astype(np.float32)
     ogq, ogp, ogs = oracle.softproj_backward(P, Q, oi, sigma, gp, want_grad_P=True)
-    gP, gQ, gT = torch.autograd.grad(proj, [tP, tQ, tT], dev(gp))
+    gP, gQ, gT = torch.autograd.grad(proj, [tP, tQ, tT], dev(gp), retain_graph=True)
     np.testing.assert_allclose(gQ.cpu().numpy(), ogq, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(gP.cpu().numpy(), ogp, rtol=1e-4, atol=1e-5)
+    # the gradient towards the point cloud is summed per point in the reference loop's order (sn_soft_project_backward_ordered:
+    # no float atomics): the same bits on every run, and as close to the oracle as the gradient towards the query (the
+    # per-neighbour terms differ from the oracle's by the exponential's last bit, not by their order of addition)
+    gP2, gQ2, _ = torch.autograd.grad(proj, [tP, tQ, tT], dev(gp))
+    assert torch.equal(gP, gP2) and torch.equal(gQ, gQ2)
+    assert np.abs(gP.cpu().numpy() - ogp).max() <= 4 * max(np.abs(gQ.cpu().numpy() - ogq).max(), 1e-7)
     ogT = ogs * 2 * T if T * T > min_sigma else 0.0
     np.testing.assert_allclose(float(gT), ogT, rtol=1e-4, atol=1e-5)
+
+
+def test_propagation_gradients_are_deterministic(oracle):
+    """SoftProjection.project_and_propagate (soft_projection.py:101-120): gradients towards the point cloud AND the features
+    come out of ordered per-point sums (sn_soft_weights_backward_ordered / sn_weighted_gather_backward_ordered) -- bit-equal
+    from run to run, and equal to torch's own deterministic index_add composition of the same contributions to 1e-6."""
+    from samplenet_amd.soft_projection import SoftProjection
+
+    b, n, m, k, c = 4, 512, 96, 8, 24
+    Pn, Qn = clouds(77, b, n, m)
+    Qn = (Pn[:, :m] + 0.02 * np.random.default_rng(1).standard_normal((b, m, 3))).astype(np.float32)
+    P = dev(np.ascontiguousarray(Pn.transpose(0, 2, 1))).requires_grad_(True)
+    Q = dev(np.ascontiguousarray(Qn.transpose(0, 2, 1))).requires_grad_(True)
+    Fe = torch.randn(b, c, n, device="cuda", requires_grad=True)
+    sp = SoftProjection(k, initial_temperature=0.5).cuda()
+    runs = []
+    for _ in range(3):
+        pp, pf = sp(P, Q, Fe, action="project_and_propagate")
+        g = torch.autograd.grad([pp, pf], [P, Q, Fe], [torch.ones_like(pp) * 0.3, torch.cos(pf.detach())])
+        runs.append(g)
+    for g in runs[1:]:
+        for u, v in zip(runs[0], g):
+            assert torch.equal(u, v)
+    # same contributions through torch: weights w (b,m,k) and neighbours idx -> features gradient by index_add in fp64
+    _, oi = oracle.knn(k, Pn, Qn)
+    idx = torch.from_numpy(oi).cuda().long()
+    with torch.no_grad():
+        grouped = torch.gather(P.detach().unsqueeze(2).expand(b, 3, m, n), 3, idx.unsqueeze(1).expand(b, 3, m, k))
+        d = ((grouped - Q.detach().unsqueeze(-1)) ** 2).sum(1) / sp.sigma()
+        w = torch.softmax(-d, dim=2).double()                                     # (b, m, k)
+        gout = torch.cos(pf.detach()).double()                                    # (b, c, m)
+        contrib = gout.unsqueeze(-1) * w.unsqueeze(1)                             # (b, c, m, k)
+        ref = torch.zeros(b, c, n, device="cuda", dtype=torch.float64)
+        ref.scatter_add_(2, idx.reshape(b, 1, m * k).expand(b, c, m * k), contrib.reshape(b, c, m * k))
+    assert float((runs[0][2].double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
 
 
 def test_fused_scan_when_the_batch_fills_the_chip(oracle):

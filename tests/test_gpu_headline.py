@@ -36,6 +36,13 @@ def _net(g, tag):
     return net.cuda().train(), (B, N, M, K)
 
 
+def _fixture(golden, tag):
+    """k8 / k7: samplenet_c2_reference.npz.  k7c: samplenet_c2_clean_reference.npz -- K = 7 WITHOUT near-ties (the generator picked,
+    among 600 perturbation seeds, the step whose kNN sets / nearest points / arg-max survive the largest coordinate shift): held
+    to the K = 8 bars, no selection flips allowed; k7 stays as the named discontinuity case (flips tolerated, gradients 3e-2)."""
+    return golden("samplenet_c2_clean_reference.npz" if tag == "k7c" else "samplenet_c2_reference.npz")
+
+
 def _rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b)), float(np.linalg.norm(b))
@@ -70,6 +77,8 @@ def _check_against_reference(g, tag, oracle, x, y_bcn, proj_bmc, loss, lsimp, gr
     flips = _selection_flips(oracle, xn, simp, ref32, K)
     print("[%s] selection flips vs the reference's simplified cloud: %s" % (tag, flips))
     assert flips["knn"] <= 12 and flips["idx1"] <= 2 and flips["idx2"] <= 40 and flips["argmax"] <= 1
+    if tag != "k7":  # the tie-free fixtures: no kNN set, nearest point or arg-max may differ from the reference's
+        assert flips["knn"] == 0 and flips["idx1"] == 0 and flips["argmax"] == 0, flips
     # the geometry of THIS simplified cloud, restated by the oracle: indices bit-exact, projection / loss 1e-6
     _, oidx = oracle.knn(K, xn, simp)
     oproj, _, _ = oracle.softproj_forward(xn.transpose(0, 2, 1), simp.transpose(0, 2, 1), oidx, sigma)
@@ -116,13 +125,13 @@ def _check_against_reference(g, tag, oracle, x, y_bcn, proj_bmc, loss, lsimp, gr
     return worst
 
 
-@pytest.mark.parametrize("tag", ["k8", "k7"])
+@pytest.mark.parametrize("tag", ["k8", "k7", "k7c"])
 def test_bench_path_matches_reference_c2(golden, oracle, tag):
     """bench.py's own execution path (graph replay of the fused step on an input ring, gradients in the flat bucket)."""
     from samplenet_amd.engine import SamplerTrainStep
     from samplenet_amd.parallel import FlatGradAllReducer
 
-    g = golden("samplenet_c2_reference.npz")
+    g = _fixture(golden, tag)
     net, (B, N, M, K) = _net(g, tag)
     x = torch.from_numpy(g[f"{tag}_x"]).cuda()
     ring = [x.clone(), (torch.rand_like(x) - 0.5)]
@@ -144,7 +153,7 @@ def test_bench_path_matches_reference_c2(golden, oracle, tag):
 
 
 @pytest.mark.parametrize("route", ["op_by_op", "captured"])
-@pytest.mark.parametrize("tag", ["k8", "k7"])
+@pytest.mark.parametrize("tag", ["k8", "k7", "k7c"])
 def test_module_surface_matches_reference_c2(golden, oracle, tag, route, monkeypatch):
     """The same step through the drop-in module surface (forward + get_simplification_loss + get_projection_loss +
     autograd), as registration/main.py:507-531 issues it.  route "captured": those calls replay the two graphs of
@@ -152,7 +161,7 @@ def test_module_surface_matches_reference_c2(golden, oracle, tag, route, monkeyp
     has run from the fixture's state -- the capture's own warm-up pass restores the running statistics it advanced)."""
     from samplenet_amd import surface
 
-    g = golden("samplenet_c2_reference.npz")
+    g = _fixture(golden, tag)
     net, (B, N, M, K) = _net(g, tag)
     x = torch.from_numpy(g[f"{tag}_x"]).cuda()
     if route == "captured":
@@ -174,7 +183,7 @@ def test_module_surface_matches_reference_c2(golden, oracle, tag, route, monkeyp
             np.testing.assert_allclose(net.state_dict()[k[len(tag) + 5:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["k8", "k7"])
+@pytest.mark.parametrize("tag", ["k8", "k7", "k7c"])
 def test_external_task_path_matches_reference_c2(golden, oracle, tag):
     """The fused step with the task loss OUTSIDE the node (engine fast path, task_loss given: proj is a differentiable output
     and the task gradient re-enters the loss backward as an explicit tensor -- sn_sampler_step_loss_keys(grad_proj)) on the same
@@ -182,7 +191,7 @@ def test_external_task_path_matches_reference_c2(golden, oracle, tag):
     from samplenet_amd.engine import SamplerTrainStep
     from samplenet_amd.parallel import FlatGradAllReducer
 
-    g = golden("samplenet_c2_reference.npz")
+    g = _fixture(golden, tag)
     net, (B, N, M, K) = _net(g, tag)
     x = torch.from_numpy(g[f"{tag}_x"]).cuda()
     ring = [x.clone(), (torch.rand_like(x) - 0.5)]

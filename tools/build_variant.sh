@@ -1,17 +1,17 @@
 #!/bin/bash
 # tools/build_variant.sh NAME FILE.hip "-DFLAG=V ..." : a second build of libsamplenet_hip.so in which FILE.hip is compiled with extra
-# flags -> tools/_dbg/libsamplenet_hip_NAME.so (git-ignored, travels with gpurun).  Use: SAMPLENET_AMD_LIB=tools/_dbg/libsamplenet_hip_NAME.so
+# flags -> tools/_ab/libsamplenet_hip_NAME.so (git-ignored, travels with gpurun).  Use: SAMPLENET_AMD_LIB=tools/_ab/libsamplenet_hip_NAME.so
 # python bench.py ...   for a same-box A/B of a kernel change (box-to-box variance on the pool is ~10 %).
 set -e
 cd "$(dirname "$0")/.."
 NAME=$1; SRC=$2; EXTRA=$3
-mkdir -p tools/_dbg
+mkdir -p tools/_ab
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Isamplenet_amd/csrc -Wall -Wno-unused-function"
 case $SRC in pointnet_mlp.hip|capi_common.cpp) ;; *) F="$F -ffp-contract=off";; esac
-/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/$SRC -o tools/_dbg/${SRC%.*}_$NAME.o $F $EXTRA
+/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/$SRC -o tools/_ab/${SRC%.*}_$NAME.o $F $EXTRA
 OBJS=""
 for s in capi_common pairscan geometry_ops emd pointnet_mlp; do
-  if [ "$s" == "${SRC%.*}" ]; then OBJS="$OBJS tools/_dbg/${s}_$NAME.o"; else OBJS="$OBJS samplenet_amd/lib/$s.o"; fi
+  if [ "$s" == "${SRC%.*}" ]; then OBJS="$OBJS tools/_ab/${s}_$NAME.o"; else OBJS="$OBJS samplenet_amd/lib/$s.o"; fi
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_dbg/libsamplenet_hip_$NAME.so $OBJS
-echo tools/_dbg/libsamplenet_hip_$NAME.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_ab/libsamplenet_hip_$NAME.so $OBJS
+echo tools/_ab/libsamplenet_hip_$NAME.so
