@@ -92,6 +92,9 @@ int sn_surface_values_keys(int B, int N, int M, int G, const void *colmin_keys, 
                            float *dpsum, float *values, sn_stream_t stream);
 int sn_surface_gather_upstream(int nproj, const float *g_lsimp, const float *g_sigma, const float *g_proj, float *scalars,
                                float *proj_out, sn_stream_t stream);
+/* From how many 64-row tiles per workgroup sn_conv_stack_forward_bn runs its GEMM layers as persistent weight-stationary
+ * kernels (large batches; default 4, 0: never).  Returns the previous value.  A test / A-B hook: results are bit-identical. */
+int sn_conv_stack_set_persist_min_tiles(int tiles);
 int sn_step_tail_bytes(void);
 /* Names the error words of the step's FC chain launches (the `sync` buffers of sn_fc_chain_forward[_pool] /
  * sn_fc_chain_backward, either may be NULL) in a deferred-tail blob: the loss value the tail writes is NaN when a hand-off

@@ -1254,6 +1254,264 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent, weight-stationary form of the statistics-chain forward GEMM for LARGE batches (round 4).  linear_fwd_kernel runs
+// one workgroup per 64-row tile; at B = 512 that is 8192 workgroups per layer, each of which pays the statistics prologue (the
+// input BatchNorm's fixed-point sums -- lines that were just updated by atomics --, the coefficient arithmetic, the first operand
+// round trip: 5 us), re-stages all of W's planes from L2 (98 KB for 32 KB of activations) and ends with its own set of
+// statistics / pool atomics (2 us): 15 us of workgroup lifetime for 0.4 us of MFMAs (tools/timeline.py stack 512).  Here ONE
+// workgroup per CU (two for the 64-column layers) walks over a contiguous range of tiles:
+//   * the input BatchNorm is finalised once; the weights' split planes are read ONCE, straight into the B fragments of the
+//     wave's 32 columns, which stay in registers (3 planes x K / 16 fragments: 96 VGPRs at K = 128) -- the MFMA loop reads only
+//     A fragments from LDS;
+//   * the NEXT tile's activations (all K chunks: one or two 16-byte loads per thread and chunk) are requested before the
+//     current tile is touched, so a whole tile per CU is in flight under the staging / MFMAs / stores of the one before it;
+//   * A planes are double-buffered: chunk c + 1 is activated, split and stored while the other waves still multiply chunk c
+//     (one LDS-only barrier per chunk: global loads and stores stay in flight across it);
+//   * column sums are converted to fixed point per tile -- exactly as fx_add does -- and added up in registers; ONE atomic per
+//     column and workgroup leaves at the end (integer addition is associative: the totals are those of the per-tile kernel, bit
+//     for bit); pool keys are combined in registers over the 16 consecutive tiles of a cloud and published once per cloud.
+// Same products in the same order as gemm_tile_bx3: pre-activations, statistics and pooled features are bit-identical to
+// linear_fwd_kernel's (tests/test_gpu_mlp.py::test_persistent_forward_is_bit_identical).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int SHIFT>
+__device__ __forceinline__ void fx_local_add(long long &lo, long long *layer, int stat, int c, float v)
+{
+    const double d = (double)v * (double)(1ull << 30) * (double)(1ull << (SHIFT - 30));
+    if (fabs(d) < kFx2p50) {
+        lo += __double2ll_rn(d);
+    } else if (fabs(d) < kFx2p50 * kFx2p50) {  // (rare: the hi part goes out at once, as in fx_add)
+        const double hh = floor(d * (1.0 / kFx2p50));
+        lo += __double2ll_rn(d - hh * kFx2p50);
+        atomicAdd(reinterpret_cast<unsigned long long *>(layer + kFxHi + stat * kFxRow + c), (unsigned long long)(long long)hh);
+    } else {
+        layer[kFxPoison] = 1;
+    }
+}
+
+template <class T, int KT, bool IN3A, int WPE>
+__global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) linear_fwd_persist_kernel(FwdArgs g, int ntiles,
+                                                                                                                         int tpw)
+{
+#if SN_BF16X3
+    static_assert(T::TM == 1 && T::TN == 1 && KT % BKX == 0 && KT <= 128, "one 32 x 32 block per wave");
+    constexpr int NCH = KT / BKX, A4 = Bx3<T>::A4, KS = KT / 16, Ci = KT;
+    constexpr int ABUF = 3 * T::BM * LDX;  // bf16 elements of one A buffer (three planes of a chunk)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __bf16 *Abuf = reinterpret_cast<__bf16 *>(lds);  // [2][3][BM][LDX]
+    float *cf = lds + ABUF;                           // [2][Ci]   (2 buffers x ABUF bf16 = ABUF floats)
+    float *red = cf + 2 * Ci;                         // [WR][2][BN]
+    float *TsAll = red + T::WR * 2 * T::BN;           // [waves][32 x 36] transposes of the output fragments
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / T::WC, wc = wave % T::WC;
+    const int Co = g.w.co;
+    const int tile0 = blockIdx.x * tpw, tile1 = min(ntiles, tile0 + tpw);
+    const bool first = blockIdx.x == 0;
+    const BnFwd bp = g.bn_prev;
+    // ---- prologue: the input BatchNorm's sums, the first tile's activations, the weights' fragments -- all requested before
+    // anything is waited for
+    const int c = tid;
+    long long lo0[kFxSlots], lo1[kFxSlots], ha = 0, hb = 0, poison = 0;
+    float bg = 0.f, bb = 0.f, brm = 0.f, brv = 0.f;
+    if (c < Ci) {
+        poison = g.acc_in[kFxPoison];
+#pragma unroll
+        for (int q = 0; q < kFxSlots; ++q) lo0[q] = g.acc_in[(q * 2 + 0) * kFxRow + c], lo1[q] = g.acc_in[(q * 2 + 1) * kFxRow + c];
+        ha = g.acc_in[kFxHi + c], hb = g.acc_in[kFxHi + kFxRow + c];
+        bg = bp.gamma[c], bb = bp.beta[c];
+        if (first && bp.running_mean) brm = bp.running_mean[c], brv = bp.running_var[c];
+    }
+    const int colw = wc * 32 + l31;  // this lane's output column (T::BN == Co)
+    const float biasv = g.bias ? g.bias[colw] : 0.f;
+    float w3r[IN3A ? NCH : 1][4][3], b3r[IN3A ? NCH : 1][4];
+    if constexpr (IN3A) {
+        const int k4 = (tid % (BKX / 4)) * 4;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = ch * BKX + k4 + j;
+                w3r[ch][j][0] = g.w3[cc * 3], w3r[ch][j][1] = g.w3[cc * 3 + 1], w3r[ch][j][2] = g.w3[cc * 3 + 2];
+                b3r[ch][j] = g.b3 ? g.b3[cc] : 0.f;
+            }
+    }
+    const auto fetch_tile = [&](float4 (&ra)[NCH][A4], int tile) {
+        const size_t r0 = (size_t)tile * T::BM;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int q = 0; q < A4; ++q) {
+                const int f = tid + q * T::THREADS, x = f / (BKX / 4), k = ch * BKX + (f % (BKX / 4)) * 4;
+                if constexpr (IN3A) {
+                    const float *xr = g.x3 + (r0 + x) * 3;
+                    ra[ch][q] = make_float4(xr[0], xr[1], xr[2], 0.f);
+                } else {
+                    ra[ch][q] = *reinterpret_cast<const float4 *>(g.a.z + (r0 + x) * Ci + k);
+                }
+            }
+    };
+    float4 ra0[NCH][A4], ra1[NCH][A4];
+    if (tile0 < tile1) fetch_tile(ra0, tile0);
+    bf16x8 breg[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            breg[ks][p] = *reinterpret_cast<const bf16x8 *>(g.wplanes + ((size_t)p * Co + colw) * Ci + ks * 16 + 8 * h);
+    if (c < Ci) {  // (same arithmetic as linear_fwd_kernel's prologue)
+        long long sa = 0, sb = 0;
+#pragma unroll
+        for (int q = 0; q < kFxSlots; ++q) sa += lo0[q], sb += lo1[q];
+        const double x = (double)sa + (double)ha * kFx2p50, y = (double)sb + (double)hb * kFx2p50;
+        const double scl = (1.0 / (double)(1ull << 30)) * (1.0 / (double)(1ull << (kFxShiftFwd - 30)));
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        const double sum1 = poison ? nan : x * scl, sum2 = poison ? nan : y * scl;
+        const double rR = fast_rcp((double)bp.R);
+        const double mean = sum1 * rR;
+        double var = sum2 * rR - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)fast_rsqrt(var + (double)bp.eps);
+        const float sc = bg * invstd, sh = bb - (float)mean * sc;
+        cf[c] = sc, cf[Ci + c] = sh;
+        if (first) {
+            bp.coef[c] = sc, bp.coef[Ci + c] = sh, bp.coef[2 * Ci + c] = (float)mean, bp.coef[3 * Ci + c] = invstd;
+            if (bp.running_mean) {
+                const double unbiased = bp.R > 1 ? var * (double)bp.R * fast_rcp((double)(bp.R - 1)) : var;
+                bp.running_mean[c] = (1.f - bp.momentum) * brm + bp.momentum * (float)mean;
+                bp.running_var[c] = (1.f - bp.momentum) * brv + bp.momentum * (float)unbiased;
+            }
+        }
+    }
+    if (first && tid == 0 && bp.num_batches_tracked) *bp.num_batches_tracked += 1;
+    fx_clear_share(g.zero_ptr, g.zero_n, blockIdx.x, gridDim.x, tid, T::THREADS);
+    __syncthreads();
+    const auto xa = [&](float4 v, int k) {
+        const float4 sc = *reinterpret_cast<const float4 *>(cf + k), sh = *reinterpret_cast<const float4 *>(cf + Ci + k);
+        if constexpr (IN3A) {  // v = (x, y, z, -) of the row: the xyz layer's expression, bit for bit (conv_in3_fwd_kernel)
+#pragma clang fp contract(off)
+            const int ch = k / BKX;
+            const float x0 = v.x, x1 = v.y, x2 = v.z;
+            v.x = fmaf(w3r[ch][0][2], x2, fmaf(w3r[ch][0][1], x1, w3r[ch][0][0] * x0)) + b3r[ch][0];
+            v.y = fmaf(w3r[ch][1][2], x2, fmaf(w3r[ch][1][1], x1, w3r[ch][1][0] * x0)) + b3r[ch][1];
+            v.z = fmaf(w3r[ch][2][2], x2, fmaf(w3r[ch][2][1], x1, w3r[ch][2][0] * x0)) + b3r[ch][2];
+            v.w = fmaf(w3r[ch][3][2], x2, fmaf(w3r[ch][3][1], x1, w3r[ch][3][0] * x0)) + b3r[ch][3];
+        }
+        v.x = relu_np(fmaf(v.x, sc.x, sh.x)), v.y = relu_np(fmaf(v.y, sc.y, sh.y));
+        v.z = relu_np(fmaf(v.z, sc.z, sh.z)), v.w = relu_np(fmaf(v.w, sc.w, sh.w));
+        return v;
+    };
+    const auto stage = [&](const float4 (&ra)[NCH][A4], int ch, int buf) {
+        __bf16 *Ap = Abuf + buf * ABUF;
+#pragma unroll
+        for (int q = 0; q < A4; ++q) {
+            const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
+            stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[ch][q], ch * BKX + k4));
+        }
+    };
+    // running per-column sums (threads tid < BN) and the current cloud's pool keys (lanes < 32 of every wave)
+    long long fx0 = 0, fx1 = 0;
+    unsigned long long kmx = 0ull, kmn = 0ull;
+    int kcloud = -1;
+    const bool pool = g.pool_keys != nullptr;
+    float *Ts = TsAll + wave * (32 * 36);
+    const auto flush_keys = [&]() {
+        if (pool && kcloud >= 0 && lane < 32) {
+            unsigned long long *kk = g.pool_keys + ((size_t)kcloud * 2) * Co + colw;
+            atomicMax(kk, kmx);
+            if (!g.pool_max_only) atomicMax(kk + Co, kmn);
+        }
+    };
+    const auto process = [&](int tile, const float4 (&cur)[NCH][A4], float4 (&nxt)[NCH][A4]) {
+        if (tile + 1 < tile1) fetch_tile(nxt, tile + 1);  // a whole tile in flight under this one
+        const int row0 = tile * T::BM;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        stage(cur, 0, 0);
+        lds_only_barrier();
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch + 1 < NCH) stage(cur, ch + 1, (ch + 1) & 1);
+            const __bf16 *Ap = Abuf + (ch & 1) * ABUF;
+#pragma unroll
+            for (int kk = 0; kk < BKX / 16; ++kk) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(Ap + (p * T::BM + wr * 32 + l31) * LDX + kk * 16 + 8 * h);
+                const int ks = ch * (BKX / 16) + kk;
+                // smallest products first (the order of bx3_chunk_g)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], breg[ks][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][0], acc, 0, 0, 0);
+            }
+            lds_only_barrier();
+        }
+        // ---- epilogue: bias, column sums, pool candidates, 16-byte stores through the wave's transpose scratch
+        float s0 = 0.f, s1 = 0.f, pmax = -INFINITY, pmin = INFINITY;
+        int imax = 0, imin = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = row0 + wr * 32 + frag_row(e, lane);
+            const float v = acc[e] + biasv;
+            Ts[frag_row(e, lane) * 36 + l31] = v;
+            s0 += v;
+            s1 += v * v;
+            if (v > pmax) pmax = v, imax = row;
+            if (v < pmin) pmin = v, imin = row;
+        }
+        if (g.z) {
+            float *zt = g.z + (size_t)(row0 + wr * 32) * Co + wc * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rt = 8 * q + (lane >> 3);
+                *reinterpret_cast<float4 *>(zt + (size_t)rt * Co) = *reinterpret_cast<const float4 *>(Ts + rt * 36 + (lane & 7) * 4);
+            }
+        }
+        {  // column_reduce2: halves of a wave, then the row waves in index order
+            const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
+            if (lane < 32) red[(wr * 2 + 0) * T::BN + colw] = t0, red[(wr * 2 + 1) * T::BN + colw] = t1;
+        }
+        if (pool) {
+            const int cloud = row0 / g.pool_npts, cloud0 = cloud * g.pool_npts;
+            const float om = __shfl_xor(pmax, 32), on = __shfl_xor(pmin, 32);
+            const int oim = __shfl_xor(imax, 32), oin = __shfl_xor(imin, 32);
+            if (om > pmax || (om == pmax && oim < imax)) pmax = om, imax = oim;
+            if (on < pmin || (on == pmin && oin < imin)) pmin = on, imin = oin;
+            if (cloud != kcloud) {
+                flush_keys();
+                kcloud = cloud, kmx = 0ull, kmn = 0ull;
+            }
+            const unsigned long long k1 = pool_key(pmax, imax - cloud0), k2 = pool_key(-pmin, imin - cloud0);
+            kmx = k1 > kmx ? k1 : kmx, kmn = k2 > kmn ? k2 : kmn;
+        }
+        lds_only_barrier();
+        if (tid < T::BN) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < T::WR; ++r) a0 += red[(r * 2 + 0) * T::BN + tid], a1 += red[(r * 2 + 1) * T::BN + tid];
+            fx_local_add<kFxShiftFwd>(fx0, g.acc_out, 0, tid, a0);
+            fx_local_add<kFxShiftFwd>(fx1, g.acc_out, 1, tid, a1);
+        }
+    };
+    for (int tile = tile0; tile < tile1; tile += 2) {
+        process(tile, ra0, ra1);
+        if (tile + 1 < tile1) process(tile + 1, ra1, ra0);
+    }
+    flush_keys();
+    if (tid < T::BN && tile0 < tile1) {
+        const int slot = blockIdx.x % kFxSlots;
+        atomicAdd(reinterpret_cast<unsigned long long *>(g.acc_out + (slot * 2 + 0) * kFxRow + tid), (unsigned long long)fx0);
+        atomicAdd(reinterpret_cast<unsigned long long *>(g.acc_out + (slot * 2 + 1) * kFxRow + tid), (unsigned long long)fx1);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // dgrad:  dYprev[R][Ci] = relu_mask_prev . ( dZ[R][Co] . W[Co][Ci] ) ; stats partial [gridDim.x][2][Ci]
 //         (sum dYprev, sum dYprev * Zprev).  prev.mode == ACT_NONE: plain store, no mask / stats.
 // ------------------------------------------------------------------------------------------------
@@ -5983,6 +6241,30 @@ extern "C" long long sn_conv_stack_acc_elems(int nlayers)
     return nlayers > 0 ? (long long)nlayers * kFxLayer + (long long)(nlayers - 1) * kWPlaneLL : 0;
 }
 
+static int device_cus();
+// tiles per workgroup from which the conv stack's forward GEMMs run as persistent kernels (0: never); a test / A-B hook
+static int g_persist_min_tiles = 4;
+extern "C" int sn_conv_stack_set_persist_min_tiles(int tiles)
+{
+    const int old = g_persist_min_tiles;
+    g_persist_min_tiles = tiles;
+    return old;
+}
+template <class TT, int KT, bool IN3A>
+static int launch_fwd_persist(const FwdArgs &g, int ntiles, int tpw, int nwg, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * ((size_t)3 * TT::BM * LDX + 2 * KT + (size_t)TT::WR * 2 * TT::BN + (size_t)TT::WR * TT::WC * 32 * 36);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)linear_fwd_persist_kernel<TT, KT, IN3A, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return sn_set_error(SN_ERR_UNSUPPORTED, "linear_fwd_persist_kernel: %zu bytes of LDS refused", lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((linear_fwd_persist_kernel<TT, KT, IN3A, 2>), dim3(nwg), dim3(TT::THREADS), lds, st, g, ntiles, tpw);
+    return 0;
+}
+
 extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
                                         const float *const *bias, const float *const *gamma, const float *const *beta,
                                         float *const *running_mean, float *const *running_var,
@@ -6050,6 +6332,24 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         }
         g.wplanes = job.n > 0 ? planes[l] : nullptr;
         const bool pl = g.wplanes != nullptr;
+#if SN_BF16X3
+        // large batches: the persistent, weight-stationary form (linear_fwd_persist_kernel) once every workgroup has at least
+        // g_persist_min_tiles 64-row tiles to walk over
+        if (pl && g.z && (l < nlayers - 1 || keys_pool) && (l > 1 || z1free) && (Ci == 64 || Co == 128) && R % 64 == 0) {
+            const int ntiles = R / 64, per_cu = Co == 128 ? 1 : 2, nmax = device_cus() * per_cu;
+            if (g_persist_min_tiles > 0 && ntiles >= g_persist_min_tiles * nmax) {
+                const int tpw = (ntiles + nmax - 1) / nmax, nwg = (ntiles + tpw - 1) / tpw;
+                if (l == 1) g.x3 = x, g.w3 = W[0], g.b3 = bias ? bias[0] : nullptr;
+                int rc = 0;
+                if (l == 1) rc = launch_fwd_persist<T, 64, true>(g, ntiles, tpw, nwg, st);
+                else if (Co == 128 && Ci == 128) rc = launch_fwd_persist<SN_FWD_TW, 128, false>(g, ntiles, tpw, nwg, st);
+                else if (Co == 128) rc = launch_fwd_persist<SN_FWD_TW, 64, false>(g, ntiles, tpw, nwg, st);
+                else rc = launch_fwd_persist<T, 64, false>(g, ntiles, tpw, nwg, st);
+                if (rc) return rc;
+                continue;
+            }
+        }
+#endif
         if (l == 1 && z1free) {
             SN_REQUIRE(pl, "z[0] == NULL: the weight planes are missing");
             g.x3 = x, g.w3 = W[0], g.b3 = bias ? bias[0] : nullptr;

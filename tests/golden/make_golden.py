@@ -406,6 +406,39 @@ def golden_samplenet_c2_clean(SampleNet):
     print("wrote tests/golden/samplenet_c2_clean_reference.npz (%d arrays)" % len(out))
 
 
+def golden_samplenet_c2_eval(SampleNet):
+    """The eval branch (samplenet.py:119-141: KNN(1) + nn_matching with farthest-point completion) at C2 -- B = 32, 1024 -> 64,
+    the headline's shapes: default init under seed 0, one training-mode forward to move the running statistics, then the
+    module in eval mode; the matched cloud is stored together with how far the nearest / second-nearest input point of every
+    generated point are apart (k8e_nn_margin: the coordinate shift that would change a match)."""
+    B, N, M, K = 32, 1024, 64, 8
+    torch.manual_seed(0)
+    net = SampleNet(M, 128, group_size=K, initial_temperature=1.0, is_temperature_trainable=True, min_sigma=1e-2,
+                    input_shape="bnc", output_shape="bnc")
+    x = torch.rand(B, N, 3) - 0.5
+    net.train()
+    with torch.no_grad():
+        net(x)
+    out = {"k8e_sd_" + k: v.clone().numpy() for k, v in net.state_dict().items()}
+    net.eval()
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self  # (samplenet.py:141 hard-codes .cuda())
+    try:
+        with torch.no_grad():
+            simp, match = net(x)
+    finally:
+        torch.Tensor.cuda = orig
+    d = ((simp.numpy().astype(np.float64)[:, :, None, :] - x.numpy().astype(np.float64)[:, None, :, :]) ** 2).sum(-1)
+    ds = np.sort(d, axis=2)
+    margin = ((ds[:, :, 1] - ds[:, :, 0]) / (2 * np.sqrt(ds[:, :, 1]) + 1e-12))
+    out.update({"k8e_x": x.numpy(), "k8e_eval_simp": simp.numpy(), "k8e_eval_match": match.numpy(),
+                "k8e_nn_margin": margin.astype(np.float32), "k8e_cfg": np.array([B, N, M, K, 128, 0])})
+    print("C2 eval: smallest nearest-point margin %.3g, clouds whose matches are all distinct: %d / %d" % (
+        margin.min(), sum(len(np.unique(d[b].argmin(1))) == M for b in range(B)), B))
+    np.savez_compressed(os.path.join(HERE, "samplenet_c2_eval_reference.npz"), **out)
+    print("wrote tests/golden/samplenet_c2_eval_reference.npz (%d arrays)" % len(out))
+
+
 def golden_nn_matching(sputils):
     rng = np.random.default_rng(3)
     B, N, k = 3, 200, 32
@@ -621,7 +654,7 @@ if __name__ == "__main__":
     jobs = {"known": golden_known_answers, "softproj": lambda: golden_softproj(sp_mod.SoftProjection),
             "chamfer": lambda: golden_chamfer(ChamferDistance), "samplenet": lambda: golden_samplenet(sn_mod.SampleNet),
             "c2": lambda: golden_samplenet_c2(sn_mod.SampleNet), "c2clean": lambda: golden_samplenet_c2_clean(sn_mod.SampleNet),
-            "nn_matching": lambda: golden_nn_matching(sputils),
+            "c2eval": lambda: golden_samplenet_c2_eval(sn_mod.SampleNet), "nn_matching": lambda: golden_nn_matching(sputils),
             "pcrnet": lambda: golden_pcrnet(ChamferDistance), "loaders": golden_loaders, "modelnet": golden_modelnet,
             "task": lambda: golden_samplenet_task(sn_mod.SampleNet, ChamferDistance)}
     for name in (sys.argv[1:] or list(jobs)):  # python make_golden.py [job ...]   (default: all)

@@ -1305,3 +1305,44 @@ def test_fused_conv_backward_two_passes_for_256_channels(Ci, Co, R, mode):
     got = stats.double().sum(0)
     want_s = torch.stack([want_dy.sum(0), (want_dy * zprev.double()).sum(0)])
     assert float((got - want_s).abs().max()) <= 1e-4 * float(want_s.abs().max())
+
+
+@pytest.mark.parametrize("B,N", [(256, 1024), (160, 2048), (300, 512)])
+def test_persistent_forward_is_bit_identical(B, N):
+    """Large batches run the conv stack's GEMM layers as persistent, weight-stationary kernels (linear_fwd_persist_kernel: one
+    workgroup per CU walks over its tiles, B fragments in registers, the next tile's activations in flight, one set of statistics
+    atomics per workgroup).  Same products in the same order, integer statistics: every pre-activation, every BatchNorm
+    coefficient, the pooled features with their selected rows, the head's output and the running statistics are BIT-identical
+    to the one-workgroup-per-tile kernels; the accumulators are left zero."""
+    import copy
+
+    from samplenet_amd import SampleNet, pointnet
+    from samplenet_amd._lib import lib
+
+    torch.manual_seed(B + N)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    with torch.no_grad():
+        net_a.bn2.weight[::3] *= -1.0  # negative scales: the pool picks the minimum there
+        net_a.bn5.weight[::5] *= -1.0
+    net_b = copy.deepcopy(net_a)
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5).contiguous()
+    old = lib.sn_conv_stack_set_persist_min_tiles(1)
+    try:
+        ya, sa = pointnet.forward_impl(net_a, x, True, use_plan=False)
+        assert _acc_sums_zero(net_a._fx_acc)
+        ya2, sa2 = pointnet.forward_impl(net_a, x, True, use_plan=False)  # (a second step: accumulators were left clean)
+        lib.sn_conv_stack_set_persist_min_tiles(0)
+        yb, sb = pointnet.forward_impl(net_b, x, True, use_plan=False)
+        pointnet.forward_impl(net_b, x, True, use_plan=False)
+    finally:
+        lib.sn_conv_stack_set_persist_min_tiles(old)
+    for l in range(5):
+        assert torch.equal(sa["cc"][l], sb["cc"][l]), l
+        if sa["zc"][l] is not None:
+            assert torch.equal(sa["zc"][l], sb["zc"][l]), l
+            assert torch.equal(sa2["zc"][l], sa["zc"][l]), l
+    for k in ("pooled", "argsel", "zsel"):
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(ya, yb)
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), n

@@ -109,6 +109,38 @@ def test_eval_branch_matches_reference(golden, tag):
     assert float(net.get_simplification_loss(x, simp, 64)) == 0.0 and float(net.get_projection_loss()) == 0.0
 
 
+def test_eval_branch_matches_reference_run_at_c2(golden):
+    """The eval branch at the headline's shapes (B = 32, 1024 -> 64; tests/golden/samplenet_c2_eval_reference.npz: a run of the
+    reference module after one training-mode forward): simplified cloud within 1e-5; the matched cloud (nearest input points,
+    duplicates replaced by farthest-point picks -- on the device: sn_nn_matching) EXACTLY, on every cloud whose nearest-point
+    choices cannot be moved by that 1e-5 (the fixture stores each generated point's margin to its second-nearest input point;
+    one swapped index changes a cloud's whole completion order, so clouds with a margin below 5e-5 are only counted)."""
+    from samplenet_amd import SampleNet
+
+    g = golden("samplenet_c2_eval_reference.npz")
+    B, N, M, K, bneck, _ = [int(v) for v in g["k8e_cfg"]]
+    net = SampleNet(M, bneck, group_size=K, input_shape="bnc", output_shape="bnc")
+    missing, unexpected = net.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("k8e_sd_")}, strict=True)
+    assert not missing and not unexpected
+    net = net.cuda().eval()
+    x = torch.from_numpy(g["k8e_x"]).cuda()
+    with torch.no_grad():
+        simp, match = net(x)
+    e = np.abs(simp.cpu().numpy() - g["k8e_eval_simp"]).max()
+    print("C2 eval: simp max|d| %.2e" % e)
+    assert e <= 1e-5
+    safe = g["k8e_nn_margin"].min(1) > 5e-5
+    same = np.array([np.array_equal(match[b].cpu().numpy(), g["k8e_eval_match"][b]) for b in range(B)])
+    print("clouds with a safe margin: %d / %d, identical matched clouds: %d" % (safe.sum(), B, same.sum()))
+    assert safe.sum() >= B // 2 and same[safe].all()
+    # every matched point is an input point of its cloud, M distinct ones
+    xm = x.cpu().numpy()
+    for b in range(B):
+        rows = {tuple(r) for r in xm[b]}
+        pts = [tuple(r) for r in match[b].cpu().numpy()]
+        assert all(p in rows for p in pts) and len(set(pts)) == M
+
+
 def test_surface_and_errors():
     from samplenet_amd import SampleNet
 

@@ -4,12 +4,12 @@
 # waits for the memory operations before it (serialised phases); default 1: stamps only.
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p tools/_dbg
+mkdir -p tools/_ab
 L=${LEVEL:-1}
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Isamplenet_amd/csrc -Wno-unused-function"
 G="$F -ffp-contract=off -DSN_PS_TIMELINE=$L -DSN_CS_TIMELINE=$L"
-/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/pointnet_mlp.hip -o tools/_dbg/pointnet_mlp_tl.o $F -DSN_TIMELINE
-/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/capi_common.cpp -o tools/_dbg/capi_common_tl.o $F -DSN_TIMELINE
-/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/pairscan.hip -o tools/_dbg/pairscan_tl.o $G
-/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/geometry_ops.hip -o tools/_dbg/geometry_ops_tl.o $G
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_dbg/libsamplenet_hip_tl.so tools/_dbg/pointnet_mlp_tl.o tools/_dbg/capi_common_tl.o tools/_dbg/pairscan_tl.o tools/_dbg/geometry_ops_tl.o samplenet_amd/lib/emd.o
+/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/pointnet_mlp.hip -o tools/_ab/pointnet_mlp_tl.o $F -DSN_TIMELINE
+/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/capi_common.cpp -o tools/_ab/capi_common_tl.o $F -DSN_TIMELINE
+/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/pairscan.hip -o tools/_ab/pairscan_tl.o $G
+/opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/geometry_ops.hip -o tools/_ab/geometry_ops_tl.o $G
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_ab/libsamplenet_hip_tl.so tools/_ab/pointnet_mlp_tl.o tools/_ab/capi_common_tl.o tools/_ab/pairscan_tl.o tools/_ab/geometry_ops_tl.o samplenet_amd/lib/emd.o

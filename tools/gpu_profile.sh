@@ -15,8 +15,8 @@ done
 timeout 300 python bench.py --steps 1500 --warmup 100 --no-probes 2>/dev/null | tail -1 > $OUT/bench_n1_noprobes.json; cat $OUT/bench_n1_noprobes.json
 timeout 300 python tools/pairscan_scaling.py > $OUT/pairscan_scaling.txt 2>&1; cat $OUT/pairscan_scaling.txt
 timeout 300 python tools/emd_bench.py > $OUT/emd_bench.txt 2>&1; tail -3 $OUT/emd_bench.txt
-if [ -f tools/_dbg/libsamplenet_hip_tl.so ]; then
-  SAMPLENET_AMD_LIB=$PWD/tools/_dbg/libsamplenet_hip_tl.so timeout 200 python tools/fc_chain_timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/fc_chain_timeline.txt
+if [ -f tools/_ab/libsamplenet_hip_tl.so ]; then
+  SAMPLENET_AMD_LIB=$PWD/tools/_ab/libsamplenet_hip_tl.so timeout 200 python tools/fc_chain_timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/fc_chain_timeline.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 B="--no-probes"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of pointnet_narrow_fwd_kernel (timeline build, SAMPLENET_AMD_LIB=tools/_dbg/libsamplenet_hip_tl.so): thread 0 of
+"""Phase stamps of pointnet_narrow_fwd_kernel (timeline build, SAMPLENET_AMD_LIB=tools/_ab/libsamplenet_hip_tl.so): thread 0 of
 every workgroup, 100 MHz clock."""
 import ctypes
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of skinny_linear_kernel on PCRNet's trunk layers (timeline build, SAMPLENET_AMD_LIB=tools/_dbg/libsamplenet_hip_tl.so):
+"""Phase stamps of skinny_linear_kernel on PCRNet's trunk layers (timeline build, SAMPLENET_AMD_LIB=tools/_ab/libsamplenet_hip_tl.so):
 thread 0 of every workgroup, 100 MHz clock: start, operands loaded + MFMAs done, waves' partials summed, slice partial stored and
 drained, arrival passed, (last workgroup of a tile) slices summed."""
 import ctypes

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_dbg", "libsamplenet_hip_tl.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_ab", "libsamplenet_hip_tl.so"))
 vp, i = ctypes.c_void_p, ctypes.c_int
 
 
@@ -248,7 +248,7 @@ if __name__ == "__main__":
         small_fwd(32, 128, 256)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stack":
-        stack_fwd()
+        stack_fwd(B=int(sys.argv[2]) if len(sys.argv) > 2 else 32)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fwd":
         fwd(R, 64, 64)
