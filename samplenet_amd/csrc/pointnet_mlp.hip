@@ -1263,10 +1263,12 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
 //   * the input BatchNorm is finalised once; the weights' split planes are read ONCE, straight into the B fragments of the
 //     wave's 32 columns, which stay in registers (3 planes x K / 16 fragments: 96 VGPRs at K = 128) -- the MFMA loop reads only
 //     A fragments from LDS;
-//   * the NEXT tile's activations (all K chunks: one or two 16-byte loads per thread and chunk) are requested before the
-//     current tile is touched, so a whole tile per CU is in flight under the staging / MFMAs / stores of the one before it;
-//   * A planes are double-buffered: chunk c + 1 is activated, split and stored while the other waves still multiply chunk c
-//     (one LDS-only barrier per chunk: global loads and stores stay in flight across it);
+//   * the activations of the next two tiles (all K chunks: one or two 16-byte loads per thread and chunk, two register sets) are
+//     in flight under the staging / MFMAs / stores of the current one;
+//   * a WHOLE tile's A planes are double-buffered in LDS: tile t + 1 is activated, split and stored while the other waves still
+//     multiply tile t -- ONE LDS-only barrier per tile (global loads and stores stay in flight across it), 6 K / 16 MFMAs per
+//     wave back to back (per-chunk staging with a barrier per chunk: 154 instead of 200 us for the 128 -> 128 layer at B = 512,
+//     a chain of LDS write -> barrier -> read latencies; prefetching two tiles ahead instead of one changed nothing);
 //   * column sums are converted to fixed point per tile -- exactly as fx_add does -- and added up in registers; ONE atomic per
 //     column and workgroup leaves at the end (integer addition is associative: the totals are those of the per-tile kernel, bit
 //     for bit); pool keys are combined in registers over the 16 consecutive tiles of a cloud and published once per cloud.
@@ -1297,12 +1299,14 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
 #if SN_BF16X3
     static_assert(T::TM == 1 && T::TN == 1 && KT % BKX == 0 && KT <= 128, "one 32 x 32 block per wave");
     constexpr int NCH = KT / BKX, A4 = Bx3<T>::A4, KS = KT / 16, Ci = KT;
-    constexpr int ABUF = 3 * T::BM * LDX;  // bf16 elements of one A buffer (three planes of a chunk)
+    constexpr int ACH = 3 * T::BM * LDX;  // bf16 elements of one chunk's three planes
+    constexpr int ABUF = NCH * ACH;       // ... of a whole tile (all K chunks)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __bf16 *Abuf = reinterpret_cast<__bf16 *>(lds);  // [2][3][BM][LDX]
+    __bf16 *Abuf = reinterpret_cast<__bf16 *>(lds);  // [2][NCH][3][BM][LDX]: two whole tiles
     float *cf = lds + ABUF;                           // [2][Ci]   (2 buffers x ABUF bf16 = ABUF floats)
-    float *red = cf + 2 * Ci;                         // [WR][2][BN]
-    float *TsAll = red + T::WR * 2 * T::BN;           // [waves][32 x 36] transposes of the output fragments
+    float *red = cf + 2 * Ci;                         // [2][WR][2][BN]  (by tile parity: a fast wave may reach the next tile's
+                                                      //  sums while a slow one still reads this tile's)
+    float *TsAll = red + 2 * T::WR * 2 * T::BN;       // [waves][16 x 36] transposes of the output fragments, half a fragment at a time
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / T::WC, wc = wave % T::WC;
@@ -1352,8 +1356,10 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
                 }
             }
     };
+    // two register sets: tiles t + 1 and t + 2 (later t + 2 and t + 3) are in flight while tile t is multiplied
     float4 ra0[NCH][A4], ra1[NCH][A4];
     if (tile0 < tile1) fetch_tile(ra0, tile0);
+    if (tile0 + 1 < tile1) fetch_tile(ra1, tile0 + 1);
     bf16x8 breg[KS][3];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -1402,12 +1408,16 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
         v.z = relu_np(fmaf(v.z, sc.z, sh.z)), v.w = relu_np(fmaf(v.w, sc.w, sh.w));
         return v;
     };
-    const auto stage = [&](const float4 (&ra)[NCH][A4], int ch, int buf) {
-        __bf16 *Ap = Abuf + buf * ABUF;
+    // a whole tile: activated, split and stored into buffer `buf` (all K chunks, chunk-major as bx3_chunk_g lays one out)
+    const auto stage = [&](const float4 (&ra)[NCH][A4], int buf) {
 #pragma unroll
-        for (int q = 0; q < A4; ++q) {
-            const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
-            stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[ch][q], ch * BKX + k4));
+        for (int ch = 0; ch < NCH; ++ch) {
+            __bf16 *Ap = Abuf + buf * ABUF + ch * ACH;
+#pragma unroll
+            for (int q = 0; q < A4; ++q) {
+                const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
+                stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[ch][q], ch * BKX + k4));
+            }
         }
     };
     // running per-column sums (threads tid < BN) and the current cloud's pool keys (lanes < 32 of every wave)
@@ -1415,7 +1425,7 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
     unsigned long long kmx = 0ull, kmn = 0ull;
     int kcloud = -1;
     const bool pool = g.pool_keys != nullptr;
-    float *Ts = TsAll + wave * (32 * 36);
+    float *Ts = TsAll + wave * (16 * 36);
     const auto flush_keys = [&]() {
         if (pool && kcloud >= 0 && lane < 32) {
             unsigned long long *kk = g.pool_keys + ((size_t)kcloud * 2) * Co + colw;
@@ -1423,58 +1433,63 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
             if (!g.pool_max_only) atomicMax(kk + Co, kmn);
         }
     };
-    const auto process = [&](int tile, const float4 (&cur)[NCH][A4], float4 (&nxt)[NCH][A4]) {
-        if (tile + 1 < tile1) fetch_tile(nxt, tile + 1);  // a whole tile in flight under this one
+    // Iteration t: tile t + 1 is activated / split / stored into the OTHER buffer (its loads were issued two iterations ago), its
+    // register set is refilled with tile t + 3, then tile t is multiplied out of its buffer -- 6 K / 16 MFMAs per wave back to
+    // back, only A fragments read from LDS -- and leaves through the epilogue; ONE barrier per tile: the staging of a wave
+    // overlaps the MFMAs of the others.
+    const auto process = [&](int tile, float4 (&nxt)[NCH][A4]) {
+        const int buf = (tile - tile0) & 1;
+        if (tile + 1 < tile1) stage(nxt, buf ^ 1);
+        if (tile + 3 < tile1) fetch_tile(nxt, tile + 3);
         const int row0 = tile * T::BM;
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        stage(cur, 0, 0);
-        lds_only_barrier();
+        const __bf16 *At = Abuf + buf * ABUF;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            if (ch + 1 < NCH) stage(cur, ch + 1, (ch + 1) & 1);
-            const __bf16 *Ap = Abuf + (ch & 1) * ABUF;
+        for (int ks = 0; ks < KS; ++ks) {
+            const __bf16 *Ap = At + (ks / (BKX / 16)) * ACH;
+            const int kk = ks % (BKX / 16);
+            bf16x8 a[3];
 #pragma unroll
-            for (int kk = 0; kk < BKX / 16; ++kk) {
-                bf16x8 a[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(Ap + (p * T::BM + wr * 32 + l31) * LDX + kk * 16 + 8 * h);
-                const int ks = ch * (BKX / 16) + kk;
-                // smallest products first (the order of bx3_chunk_g)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], breg[ks][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][0], acc, 0, 0, 0);
-            }
-            lds_only_barrier();
+            for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(Ap + (p * T::BM + wr * 32 + l31) * LDX + kk * 16 + 8 * h);
+            // smallest products first (the order of bx3_chunk_g)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], breg[ks][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][0], acc, 0, 0, 0);
         }
         // ---- epilogue: bias, column sums, pool candidates, 16-byte stores through the wave's transpose scratch
         float s0 = 0.f, s1 = 0.f, pmax = -INFINITY, pmin = INFINITY;
         int imax = 0, imin = 0;
+        float *redt = red + ((tile - tile0) & 1) * (T::WR * 2 * T::BN);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = row0 + wr * 32 + frag_row(e, lane);
-            const float v = acc[e] + biasv;
-            Ts[frag_row(e, lane) * 36 + l31] = v;
-            s0 += v;
-            s1 += v * v;
-            if (v > pmax) pmax = v, imax = row;
-            if (v < pmin) pmin = v, imin = row;
-        }
-        if (g.z) {
-            float *zt = g.z + (size_t)(row0 + wr * 32) * Co + wc * 32 + (lane & 7) * 4;
+        for (int hf = 0; hf < 2; ++hf) {  // rows 16 hf .. 16 hf + 15 of the fragment: accumulator registers 8 hf .. 8 hf + 7
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rt = 8 * q + (lane >> 3);
-                *reinterpret_cast<float4 *>(zt + (size_t)rt * Co) = *reinterpret_cast<const float4 *>(Ts + rt * 36 + (lane & 7) * 4);
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int e = hf * 8 + e8;
+                const int row = row0 + wr * 32 + frag_row(e, lane);
+                const float v = acc[e] + biasv;
+                Ts[(frag_row(e, lane) - 16 * hf) * 36 + l31] = v;
+                s0 += v;
+                s1 += v * v;
+                if (v > pmax) pmax = v, imax = row;
+                if (v < pmin) pmin = v, imin = row;
+            }
+            if (g.z) {
+                float *zt = g.z + (size_t)(row0 + wr * 32 + 16 * hf) * Co + wc * 32 + (lane & 7) * 4;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int rt = 8 * q + (lane >> 3);
+                    *reinterpret_cast<float4 *>(zt + (size_t)rt * Co) = *reinterpret_cast<const float4 *>(Ts + rt * 36 + (lane & 7) * 4);
+                }
             }
         }
         {  // column_reduce2: halves of a wave, then the row waves in index order
             const float t0 = s0 + __shfl_xor(s0, 32), t1 = s1 + __shfl_xor(s1, 32);
-            if (lane < 32) red[(wr * 2 + 0) * T::BN + colw] = t0, red[(wr * 2 + 1) * T::BN + colw] = t1;
+            if (lane < 32) redt[(wr * 2 + 0) * T::BN + colw] = t0, redt[(wr * 2 + 1) * T::BN + colw] = t1;
         }
         if (pool) {
             const int cloud = row0 / g.pool_npts, cloud0 = cloud * g.pool_npts;
@@ -1493,14 +1508,19 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
         if (tid < T::BN) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < T::WR; ++r) a0 += red[(r * 2 + 0) * T::BN + tid], a1 += red[(r * 2 + 1) * T::BN + tid];
+            for (int r = 0; r < T::WR; ++r) a0 += redt[(r * 2 + 0) * T::BN + tid], a1 += redt[(r * 2 + 1) * T::BN + tid];
             fx_local_add<kFxShiftFwd>(fx0, g.acc_out, 0, tid, a0);
             fx_local_add<kFxShiftFwd>(fx1, g.acc_out, 1, tid, a1);
         }
     };
-    for (int tile = tile0; tile < tile1; tile += 2) {
-        process(tile, ra0, ra1);
-        if (tile + 1 < tile1) process(tile + 1, ra1, ra0);
+    if (tile0 < tile1) {  // tile0 into buffer 0; its register set takes tile0 + 2
+        stage(ra0, 0);
+        if (tile0 + 2 < tile1) fetch_tile(ra0, tile0 + 2);
+        lds_only_barrier();
+    }
+    for (int tile = tile0; tile < tile1; tile += 2) {  // (tile t + 1 waits in set (t + 1 - tile0) & 1)
+        process(tile, ra1);
+        if (tile + 1 < tile1) process(tile + 1, ra0);
     }
     flush_keys();
     if (tid < T::BN && tile0 < tile1) {
@@ -6253,7 +6273,7 @@ extern "C" int sn_conv_stack_set_persist_min_tiles(int tiles)
 template <class TT, int KT, bool IN3A>
 static int launch_fwd_persist(const FwdArgs &g, int ntiles, int tpw, int nwg, hipStream_t st)
 {
-    const size_t lds = sizeof(float) * ((size_t)3 * TT::BM * LDX + 2 * KT + (size_t)TT::WR * 2 * TT::BN + (size_t)TT::WR * TT::WC * 32 * 36);
+    const size_t lds = sizeof(float) * ((size_t)(KT / BKX) * 3 * TT::BM * LDX + 2 * KT + (size_t)2 * TT::WR * 2 * TT::BN + (size_t)TT::WR * TT::WC * 16 * 36);
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)linear_fwd_persist_kernel<TT, KT, IN3A, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
