@@ -3239,12 +3239,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         asm volatile("" ::: "memory");
         double s, ss;
         fx_total2<kFxShiftFwd>(fx, s, ss);
+        FC_TL(0, wg, 24);
         const bool owner = tid < 128 && (pc >> 4) == wg;
         const float2 cf = bn_finalize_channel(P.bn, CP, pc, s, ss, in, owner);
         if (wg == 0 && tid == 0 && P.bn.num_batches_tracked) *P.bn.num_batches_tracked += 1;
         float *cfs = Ta;  // [2][128] scale | shift (the tile scratch is idle until layer 0's epilogue)
         if (tid < 128) cfs[pc] = cf.x, cfs[CP + pc] = cf.y;
         lds_barrier();
+        FC_TL(0, wg, 25);
         {
             float pooled[16], zs[16];
             int ar[16];
@@ -3278,6 +3280,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 }
             }
         }
+        FC_TL(0, wg, 26);
 #pragma unroll
         for (int q = 0; q < npass; ++q) *reinterpret_cast<f32x4v *>(W0s + (r0 + q * rpp) * (C0 + 4) + c4) = wv[q];
 #pragma unroll
@@ -3285,6 +3288,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 *reinterpret_cast<f32x4v *>(Whs + (size_t)(l - 1) * 32 * (H + 4) + (hr0 + q * 4) * (H + 4) + hc4) = wh[l - 1][q];
+        FC_TL(0, wg, 27);
         fx_clear_share(P.zero_ptr, P.zero_n, wg, nwg, tid, 256);
     } else if constexpr (C0T > 0 && NLT > 0) {
         // compile-time shape: every load of the kernel's operands is issued before the first LDS write (no loop-carried

@@ -139,6 +139,9 @@ class SamplerStepFunction(torch.autograd.Function):
 def sampler_step(net, x_bnc, alpha, lmbda, weight, t_sink=None, defer_value=False, mean_proj=True):
     """-> (loss, simp (B,3,M), proj (B,M,3)) for a training-mode SampleNet with projection on a (B,N,3) batch.
     mean_proj=False: proj is differentiable and the loss carries no task term (see SamplerStepFunction)."""
+    if net.__dict__.get("_sn_sync_bn") is not None:
+        raise RuntimeError("sampler_step runs on per-process BatchNorm statistics; a module converted by "
+                           "syncbn.convert_sync_batchnorm takes the layer-by-layer route (SampleNet.forward / engine.SamplerTrainStep)")
     params = pointnet.param_list(net)
     proj = net.project
     return SamplerStepFunction.apply(net, x_bnc, proj._temperature, proj._group_size, proj._min_sigma_f, alpha, lmbda, weight,
@@ -167,6 +170,8 @@ class _DirectCtx:
 def sampler_step_direct(net, x_bnc, alpha, lmbda, weight, t_sink, grad_loss, after_fc):
     """forward + backward of SamplerStepFunction without autograd, on the calling thread; every gradient must have a sink
     (FlatGradAllReducer bucket).  after_fc() is invoked once the FC head's gradients have been enqueued."""
+    if net.__dict__.get("_sn_sync_bn") is not None:
+        raise RuntimeError("sampler_step_direct runs on per-process BatchNorm statistics (see sampler_step)")
     sink = getattr(net, "_grad_sink", None)
     if sink is None or (net.project._temperature.requires_grad and t_sink is None):
         raise RuntimeError("sampler_step_direct needs a gradient sink for every parameter (FlatGradAllReducer)")

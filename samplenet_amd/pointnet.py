@@ -45,7 +45,14 @@ def _layers(net):
     cached = d.get("_sn_layer_records")
     if cached is not None:
         convs, fcs, _, _ = cached
-        if all(mods[L.name]._parameters["weight"] is L.W for L in convs) and all(mods[L.name]._parameters["weight"] is L.W for L in fcs):
+        ok = True
+        for L in convs + fcs:  # weight, bias and the BatchNorm MODULE are still the recorded ones (a replaced bias / a layer swapped
+            m = mods[L.name]   # for torch.nn.SyncBatchNorm or a frozen copy would otherwise keep feeding stale pointers)
+            if m._parameters["weight"] is not L.W or m._parameters["bias"] is not L.b or \
+                    (L.bn is not None and mods.get(L.bn_name) is not L.bn):
+                ok = False
+                break
+        if ok:
             return convs, fcs
     convs = [_Layer("conv%d" % i, getattr(net, "conv%d" % i), "bn%d" % i, getattr(net, "bn%d" % i)) for i in range(1, 6)]
     nfc = getattr(net, "num_fc_layers", 4)

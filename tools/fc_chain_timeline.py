@@ -26,7 +26,7 @@ torch.cuda.synchronize()
 host = np.zeros((2, 16, 32), dtype=np.uint64)
 assert dbg.sn_debug_fc_timeline(host.ctypes.data_as(ctypes.c_void_p)) == 0
 t = host.astype(np.float64) / 100.0  # us
-names_f = {0: "start", 1: "pool stage + weights staged"}
+names_f = {0: "start", 1: "pool stage + weights staged", 24: "  (sums landed + totalled)", 25: "  (coefficients in LDS)", 26: "  (keys decoded, pooled in LDS)", 27: "  (weight slices in LDS)"}
 for l in range(3):
     names_f.update({2 + 6 * l: "L%d MFMA + wave sum" % l, 3 + 6 * l: "L%d epilogue" % l, 4 + 6 * l: "L%d tile stored + drained" % l,
                     5 + 6 * l: "L%d seam passed" % l, 6 + 6 * l: "L%d gather landed" % l, 7 + 6 * l: "L%d staged" % l})
@@ -42,7 +42,7 @@ for kind, label, names, wgs in ((0, "fc_chain_fwd_kernel", names_f, range(8)), (
     t0 = tt[:, 0][tt[:, 0] > 0].min()
     print("== %s" % label)
     prev = 0.0
-    for k in sorted(names):
+    for k in sorted(names, key=lambda k: (k if k < 24 or k == 31 else 0.5 + k / 100.0)):
         col = tt[:, k]
         ok = col > 0
         if not ok.any():
