@@ -48,7 +48,8 @@ class SamplerTrainStep:
         if overlap_allreduce is None:
             overlap_allreduce = False
         self.split = bool(use_graph and overlap_allreduce and reducer is not None and reducer.collective and self._fast_path()
-                          and task_loss is None and fused_head and getattr(net, "use_hip_mlp", False))
+                          and task_loss is None and fused_head and getattr(net, "use_hip_mlp", False)
+                          and getattr(net, "standard_arch", True))
         # Where the gradient collective of a captured step runs (N > 1):
         #   "graph"      (default) INSIDE the step's one graph, at its end on the capturing stream: RCCL's kernel is one more
         #                node of the replay -- no host-side launch path per step, nothing between the graph and the collective;
@@ -71,8 +72,12 @@ class SamplerTrainStep:
         net = self.net
         if net.__dict__.get("_sn_sync_bn") is not None:  # statistics over all ranks: collectives between the layers
             return False
-        if not self.fused_loss or not net.training or net.skip_projection or \
-                net.input_shape != "bnc" or not getattr(net, "standard_arch", True):
+        if not self.fused_loss or not net.training or net.skip_projection or net.input_shape != "bnc":
+            return False
+        if not getattr(net, "standard_arch", True) and self.task_loss is not None:
+            # the sampler variants of the TF packages (reconstruction: other widths, no BatchNorm in the FC head, clamped temperature;
+            # classification: a BatchNorm on the head's output): the single-node LOSS applies to them as it is (the head runs through
+            # net._features, the temperature through the module's own clamp); the fc4-in-scan / outside-task forms do not
             return False
         from ._lib import lib
 
@@ -106,9 +111,11 @@ class SamplerTrainStep:
         if self._fast_path():
             from . import ops
 
+            std = getattr(net, "standard_arch", True)
             T = net.project._temperature
+            floor = getattr(net.project, "_temperature_floor", None) is not None
             t_sink = None
-            if self.reducer is not None and T.requires_grad:
+            if self.reducer is not None and T.requires_grad and not floor:
                 self.reducer._rebind()  # (after an optimizer.zero_grad(): T.grad is the bucket's view again)
                 t_sink = T.grad.view(-1)[:1]  # a view of the flat bucket: written in place, nothing to zero or accumulate
             elif self.reducer is not None:
@@ -135,7 +142,9 @@ class SamplerTrainStep:
                     loss.backward(self._one)
                 return loss.detach() + task.detach()
             B, N, _ = x.shape
-            if self.fused_head and net.use_hip_mlp and ops.lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1:
+            if floor:
+                T = net.project._t()  # max(T, floor): the kernels square what they are given; its gradient gate is autograd's
+            if std and self.fused_head and net.use_hip_mlp and ops.lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1:
                 from .fused_step import sampler_step
 
                 loss, y, proj = sampler_step(net, x, self.alpha, self.lmbda, weight, t_sink, True)  # fc4 inside the scan

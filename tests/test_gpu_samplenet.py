@@ -241,6 +241,44 @@ def test_single_node_step_loss_equals_composition(B, N, M, K):
         assert torch.equal(ba, bb), n
 
 
+@pytest.mark.parametrize("variant,B,N,M,K", [("reconstruction", 50, 2048, 64, 16), ("reconstruction", 6, 320, 32, 5),
+                                              ("classification", 32, 1024, 64, 7), ("classification", 5, 256, 16, 4)])
+def test_single_node_loss_for_the_other_sampler_architectures(variant, B, N, M, K):
+    """the engine's single-node loss (one pair scan, fused loss forward / backward) is not tied to the registration
+    architecture.  The reconstruction sampler (reconstruction/src/samplers.py:23-38: conv 64-128-128-256, FC 256-256 without
+    BatchNorm, sigma = max(T, 1e-2)^2) and the classification sampler (classification/models/samplenet_model.py:30-108: BatchNorm
+    on the head's output, sigma = T^2) take it with the head through net._features and the temperature through the module's own
+    clamp; against the op-by-op composition through the module's methods: loss 1e-6, every gradient within fp32 rounding, captured
+    and eager."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    kw = (dict(conv_widths=(64, 128, 128, 256), fc_widths=(256, 256), fc_batchnorm=False, temperature_floor=1e-2, min_sigma=0.0)
+          if variant == "reconstruction" else dict(last_fc_batchnorm=True, min_sigma=0.0))
+    torch.manual_seed(B + N + K)
+    net_a = SampleNet(M, 128, group_size=K, initial_temperature=0.6, input_shape="bnc", output_shape="bnc", **kw).cuda().train()
+    assert not net_a.standard_arch
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    skw = dict(alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01)
+    red_a, red_b, red_c = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b), FlatGradAllReducer(net_c)
+    step_a = SamplerTrainStep(net_a, x, reducer=red_a, use_graph=False, **skw)
+    step_b = SamplerTrainStep(net_b, x, reducer=red_b, use_graph=False, fused_loss=False, **skw)
+    step_c = SamplerTrainStep(net_c, x, reducer=red_c, use_graph=True, **skw)
+    assert step_a._fast_path() and not step_b._fast_path() and step_c._fast_path()
+    la, lb, lc = step_a(x), step_b(x), step_c(x)
+    torch.cuda.synchronize()
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb))) and float(la) == float(lc)
+    assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
+    assert float(net_a.project._temperature.grad.abs()) > 0
+    # (the captured replica ran three warm-up steps: running statistics moved on, gradients are those of the same parameters;
+    #  torch's own BatchNorm on the classification head's output may take another backward kernel under capture: norm-relative)
+    assert float((red_a.flat - red_c.flat).norm()) <= 1e-5 * float(red_a.flat.norm())
+
+
 @pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (6, 512, 64, 8), (3, 320, 20, 5)])
 def test_head_fused_into_scan(B, N, M, K):
     """fused_step.SamplerStepFunction (fc4's forward computed by the pair-scan waves: sn_pairscan_forward_partial_fc) against
