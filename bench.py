@@ -283,7 +283,9 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
                 alpha*get_simplification_loss + lmbda*get_projection_loss + proj.mean(); backward() -- what an unmodified
                 train script gets without the engine: since round 4 those calls replay two captured graphs (surface.py);
       eager  -- the same with the PCRNet task loss (the task network's own launches stay op by op);
-      op_by_op_mean_proj / op_by_op -- the two legs above with graph_surface = False (every call launched from Python);
+      eager_two_clouds -- the script's DEFAULT step (--num-sampled-clouds 2, main.py:516-524): source and template both sampled under
+                one loss, the PCRNet task on the two 64-point projections; each sampler pass replays its own pair of graphs;
+      op_by_op_mean_proj / op_by_op / op_by_op_two_clouds -- the legs above with graph_surface = False (every call launched from Python);
       graph  -- engine.SamplerTrainStep(task_loss=...) captured once and replayed: the fused single-node step with the task
                 loss OUTSIDE the node -- proj is a differentiable output, the task gradient re-enters the loss backward as an
                 explicit tensor (same scan, fc4 inside the scan, deferred tail as the headline);
@@ -332,6 +334,17 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
         loss.backward()
         return loss
 
+    def two_clouds_step():  # registration/main.py:516-524, the script's DEFAULT (--num-sampled-clouds 2): source AND template sampled
+        for p in net.parameters():
+            p.grad = None
+        s1, p1 = net(x)
+        l1 = net.get_simplification_loss(x, s1, M, 1, 0)
+        s0, p0 = net(template)
+        l0 = net.get_simplification_loss(template, s0, M, 1, 0)
+        loss = 0.01 * 0.5 * (l1 + l0) + 0.01 * net.get_projection_loss() + pcrnet_chamfer_loss(pcr, p0, p1)[0]
+        loss.backward()
+        return loss
+
     out = {}
     # the script's calls op by op (graph_surface off: what every round before the captured surface measured) ...
     net.graph_surface = pcr.graph_surface = False
@@ -341,6 +354,8 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
     ms, loss = _wall_ms(eager_step, steps)
     assert torch.isfinite(loss).item()
     out["op_by_op"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms}
+    ms, loss = _wall_ms(two_clouds_step, steps)
+    out["op_by_op_two_clouds"] = {"value": 2 * B / ms * 1e3, "unit": "sampled point-clouds/s (two sampler passes per step)", "ms_per_step": ms}
     # ... and the SAME unmodified calls on the captured surface (samplenet_amd/surface.py: two hipGraphs behind net(x), the loss
     # getters and backward(); the default)
     net.graph_surface = pcr.graph_surface = True  # (graphed.py: the frozen task network's term replays two graphs of its own)
@@ -349,11 +364,15 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
     net.check()
     from samplenet_amd import surface
 
-    captured = any(isinstance(p, surface._Plan) for p in net.__dict__.get("_sn_surface", {}).values())
+    captured = bool(surface.plans(net))
     out["eager_mean_proj"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms, "captured_surface": captured}
     ms, loss = _wall_ms(eager_step, max(steps, 200))
     assert torch.isfinite(loss).item()
     out["eager"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms, "captured_surface": captured}
+    ms, loss = _wall_ms(two_clouds_step, max(steps, 200))
+    assert torch.isfinite(loss).item()
+    out["eager_two_clouds"] = {"value": 2 * B / ms * 1e3, "unit": "sampled point-clouds/s (two sampler passes per step)", "ms_per_step": ms,
+                               "captured_plans": len(surface.plans(net))}
     for name, kw in (("graph", dict(task_loss=task)), ("graph_general", dict(task_loss=task, fused_loss=False)),
                      ("general_path_mean_proj", dict(task_loss=lambda p: p.mean()))):
         gnet = replica()

@@ -138,9 +138,10 @@ class SampleNet(nn.Module):
     def forward(self, x: torch.Tensor):
         """x in `input_shape` -> (simplified cloud, projected cloud [train] | matched cloud [eval]) in `output_shape`
         (samplenet.py:85-142).  Internally the head's output y is (B,3,M); the cloud is used in whichever layout it came."""
-        self.__dict__["_sn_surface_live"] = None
         if self.training:
             out = surface.try_forward(self, x)  # captured forward of this configuration (None: op by op below)
+            if out is None and self.__dict__.get("_sn_surface_live"):
+                surface._demote_lives(self)
             if out is not None:
                 self._scan = None
                 return out
@@ -209,7 +210,7 @@ class SampleNet(nn.Module):
         if self.skip_projection or not self.training:
             return torch.tensor(0).to(ref_pc)
         # ref_pc and samp_pc are B x N x 3 matrices
-        if self.__dict__.get("_sn_surface_live") is not None:
+        if self.__dict__.get("_sn_surface_live"):
             loss = surface.simplification_loss(self, ref_pc, samp_pc, gamma + delta * pc_size)
             if loss is not None:  # (an output of the captured forward's own autograd node)
                 return loss
@@ -227,7 +228,7 @@ class SampleNet(nn.Module):
         return ops.SimplificationLossFunction.apply(samp_pc, ref_pc, dq, iq, dp, ip, gamma + delta * pc_size)
 
     def get_projection_loss(self):
-        if self.__dict__.get("_sn_surface_live") is not None and self.training and not self.skip_projection:
+        if self.__dict__.get("_sn_surface_live") and self.training and not self.skip_projection:
             sigma = surface.projection_loss(self)
             if sigma is not None:
                 return sigma

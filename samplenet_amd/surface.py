@@ -41,7 +41,11 @@ from ._lib import check, lib, ptr
 
 ENABLED = True   # test hook / global switch (per module: net.graph_surface)
 WARM_STEPS = 2   # eager steps of a configuration before its graphs are captured
+MAX_PLANS = 3    # pairs of graphs per configuration (forwards that may wait for their backward at the same time)
 _suspend = 0
+
+
+_VIEW_OWNER = {}  # id(gradient view) -> (weak reference to it, its plan)
 
 
 class suspended:
@@ -61,9 +65,34 @@ class _Token:
 
 
 class _Live:
-    """What the loss getters need to recognise the tensors of the last captured forward."""
+    """What the loss getters need to recognise the tensors of a captured forward that still waits for its backward.  The record of
+    the LATEST forward holds its outputs strongly (the getters are called right behind it); when another forward follows, the
+    older records keep weak references only -- a forward whose outputs the script dropped must not stay "in flight" because of
+    this bookkeeping (its plan is free again as soon as the outputs are gone)."""
 
-    __slots__ = ("x", "x_version", "simp", "lsimp", "sigma", "plan", "t_version")
+    __slots__ = ("x", "x_version", "_simp", "_lsimp", "_sigma", "plan", "t_version", "token", "weak")
+
+    def demote(self):
+        if not self.weak:
+            self._simp, self._lsimp, self._sigma = weakref.ref(self._simp), weakref.ref(self._lsimp), weakref.ref(self._sigma)
+            self.x = weakref.ref(self.x)
+            self.weak = True
+
+    @property
+    def simp(self):
+        return self._simp() if self.weak else self._simp
+
+    @property
+    def lsimp(self):
+        return self._lsimp() if self.weak else self._lsimp
+
+    @property
+    def sigma(self):
+        return self._sigma() if self.weak else self._sigma
+
+    @property
+    def cloud(self):
+        return self.x() if self.weak else self.x
 
 
 class _Guard:
@@ -128,6 +157,8 @@ class _Plan:
             self.grad_pairs = list(zip(self.params, self.view_list))
             if T.requires_grad:
                 self.grad_pairs.append((T, self.t_view))
+            for _, v in self.grad_pairs:  # (which plan a .grad tensor belongs to: commit_begin's mode 3)
+                _VIEW_OWNER[id(v)] = (weakref.ref(v), self)
             self._capture(net, x)
         self.guard = _Guard(net)
 
@@ -204,17 +235,26 @@ class _Plan:
 
     def commit_begin(self):
         """-> (mode, old): 0 every .grad is None (the views become the gradients), 1 every .grad IS its view (accumulate into
-        the bucket), 2 anything else (per parameter)."""
+        the bucket), 3 every .grad is the view of ONE other plan of this module (a second sampled cloud under the same loss: that
+        plan's bucket takes the sum in one launch), 2 anything else (per parameter)."""
         nnone = nours = 0
+        other = None
+        nother = 0
         for p, v in self.grad_pairs:
             g = p.grad
             if g is None:
                 nnone += 1
             elif g is v:
                 nours += 1
+            else:
+                o = _VIEW_OWNER.get(id(g))
+                if o is not None and o[0]() is g and (other is None or o[1] is other):
+                    other, nother = o[1], nother + 1
         n = len(self.grad_pairs)
         if nnone == n:
             return 0, None
+        if nother == n and len(other.grad_pairs) == n:
+            return 3, other
         old = self.bucket.clone() if nours else None
         return (1 if nours == n else 2), old
 
@@ -224,6 +264,8 @@ class _Plan:
                 p.grad = v
         elif mode == 1:
             self.bucket.add_(old)
+        elif mode == 3:
+            old.bucket.add_(self.bucket)  # (.grad stay the other plan's views)
         else:
             off = 0
             for p, v in self.grad_pairs:
@@ -316,54 +358,103 @@ def _supported(net, x):
     return True
 
 
+class _Config:
+    """Per (batch shape, device): the warm-step count, the captured plans, how often a forward found all of them taken."""
+
+    __slots__ = ("seen", "plans", "contended", "dead")
+
+    def __init__(self):
+        self.seen, self.plans, self.contended, self.dead = 0, [], 0, False
+
+
+def _build(net, x):
+    from .fused_step import external_task_supported
+
+    T = net.project._temperature
+    params = pointnet.param_list(net)
+    ok = (external_task_supported(net, x) and all(p.requires_grad for p in params) and T.dim() == 0 and
+          all(L.bn is not None and L.bn.momentum is not None and L.bn.track_running_stats
+              for L in sum(pointnet._layers(net), [])[:-1]))
+    if not ok:
+        return None
+    try:
+        return _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
+    except Exception as e:  # noqa: BLE001 -- a configuration that cannot be captured stays on the op-by-op route
+        import warnings
+
+        warnings.warn("samplenet_amd.surface: capture failed, this configuration stays op by op (%s)" % repr(e)[:300])
+        torch.cuda.synchronize(x.device)
+        return None
+
+
+def plans(net):
+    """The captured plans of a module (all configurations)."""
+    return [p for cfg in net.__dict__.get("_sn_surface", {}).values() for p in cfg.plans]
+
+
+def _lives(net):
+    """Live records of the forwards that still wait for their backward (pruned of finished / dropped ones)."""
+    lives = net.__dict__.get("_sn_surface_live")
+    if not lives:
+        return []
+    lives = [lv for lv in lives if lv.plan.owner is not None and lv.token() is not None and lv.plan.owner() is lv.token()]
+    net.__dict__["_sn_surface_live"] = lives
+    return lives
+
+
+def _demote_lives(net):
+    for lv in net.__dict__.get("_sn_surface_live") or ():
+        lv.demote()
+
+
 def try_forward(net, x):
     """-> (simp, proj) from the captured forward, or None: the caller runs the op-by-op forward."""
     if not ENABLED or _suspend or not _supported(net, x):
         return None
     if torch.cuda.is_current_stream_capturing():  # somebody captures the step themselves: plain launches for their graph
         return None
+    _demote_lives(net)  # (earlier forwards keep weak records only: dropped outputs free their plan)
     table = net.__dict__.setdefault("_sn_surface", {})
     key = (x.shape[0], x.shape[1], x.device)
-    ent = table.get(key)
-    if ent is False:
+    cfg = table.get(key)
+    if cfg is None:
+        cfg = table[key] = _Config()
+    if cfg.dead:
         return None
-    if not isinstance(ent, _Plan):
-        n = (ent or 0) + 1
-        if n <= WARM_STEPS:
-            table[key] = n
+    if cfg.plans and not cfg.plans[0].guard.ok():
+        # a parameter / buffer / layer was replaced: new graphs after the warm steps (this call is the first of them)
+        cfg.plans, cfg.seen, cfg.contended = [], 1, 0
+        return None
+    if not cfg.plans:
+        cfg.seen += 1
+        if cfg.seen <= WARM_STEPS:
             return None
-        from .fused_step import external_task_supported
-
-        T = net.project._temperature
-        params = pointnet.param_list(net)
-        ok = (external_task_supported(net, x) and all(p.requires_grad for p in params) and T.dim() == 0 and
-              all(L.bn is not None and L.bn.momentum is not None and L.bn.track_running_stats
-                  for L in sum(pointnet._layers(net), [])[:-1]))
-        if ok:
-            try:
-                ent = _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
-            except Exception as e:  # noqa: BLE001 -- a configuration that cannot be captured stays on the op-by-op route
-                import warnings
-
-                warnings.warn("samplenet_amd.surface: capture failed, this configuration stays op by op (%s)" % repr(e)[:300])
-                torch.cuda.synchronize(x.device)
-                ok = False
-        if not ok:
-            table[key] = False
+        plan = _build(net, x)
+        if plan is None:
+            cfg.dead = True
             return None
-        table[key] = ent
-    plan = ent
-    if plan.busy():
-        return None
-    if not plan.guard.ok():  # a parameter / buffer / layer was replaced: new graphs after the warm steps (this is the first)
-        table[key] = 1
-        return None
+        cfg.plans.append(plan)
+    plan = next((p for p in cfg.plans if not p.busy()), None)
+    if plan is None:
+        # every plan's activations wait for a backward: a script that samples several clouds under one loss (registration/
+        # main.py:516-524 -- its default).  Seen WARM_STEPS times, the configuration gets one more pair of graphs (up to MAX_PLANS)
+        cfg.contended += 1
+        if cfg.contended <= WARM_STEPS or len(cfg.plans) >= MAX_PLANS:
+            return None
+        plan = _build(net, x)
+        if plan is None:
+            cfg.contended = -(1 << 30)
+            return None
+        cfg.plans.append(plan)
+        cfg.contended = 0
     # (one differentiable input is enough to make the outputs differentiable: the gradients do not travel through autograd)
     simp, proj, lsimp, sigma = _SurfaceFunction.apply(plan, net, x, plan.params[0])
     live = _Live()
-    live.x, live.x_version, live.simp, live.lsimp, live.sigma, live.plan = x, x._version, simp, lsimp, sigma, plan
+    live.weak = False
+    live.x, live.x_version, live._simp, live._lsimp, live._sigma, live.plan = x, x._version, simp, lsimp, sigma, plan
     live.t_version = net.project._temperature._version
-    net.__dict__["_sn_surface_live"] = live
+    live.token = plan.owner
+    net.__dict__["_sn_surface_live"] = _lives(net) + [live]
     return simp, proj
 
 
@@ -383,29 +474,32 @@ class _ReweightFunction(torch.autograd.Function):
 
 def simplification_loss(net, ref_pc, samp_pc, weight):
     """The captured forward's L_simp when (ref_pc, samp_pc) are the tensors that forward consumed / returned, else None."""
-    live = net.__dict__.get("_sn_surface_live")
-    if live is None or samp_pc is not live.simp:
+    live = next((lv for lv in _lives(net) if samp_pc is lv.simp), None)
+    if live is None:
         return None
-    x = live.x
+    x, lsimp = live.cloud, live.lsimp
+    if x is None or lsimp is None:
+        return None
     same = ref_pc is x or (ref_pc.data_ptr() == x.data_ptr() and ref_pc.shape == x.shape and ref_pc.stride() == x.stride())
-    if not same or x._version != live.x_version or live.plan.owner is None:
+    if not same or x._version != live.x_version:
         return None
     weight = float(weight)
     net.__dict__["_sn_surface_weight"] = weight
     if weight == live.plan.weight:
-        return live.lsimp
+        return lsimp
     # another loss weight than the captured one: value from the components, eager backward this step, new graphs afterwards
     v = live.plan.values
     value = v[2] + v[3] + weight * v[4]
-    table = net.__dict__.get("_sn_surface", {})
-    for k, p in list(table.items()):
-        if p is live.plan:
-            table[k] = WARM_STEPS  # recaptured (with this weight) by the next forward
-    return _ReweightFunction.apply(live.lsimp, value, live.lsimp.grad_fn, weight)  # (a Function's ctx IS its outputs' grad_fn)
+    for cfg in net.__dict__.get("_sn_surface", {}).values():
+        if live.plan in cfg.plans:
+            cfg.plans, cfg.seen, cfg.contended = [], WARM_STEPS, 0  # recaptured (with this weight) by the next forward
+    return _ReweightFunction.apply(lsimp, value, lsimp.grad_fn, weight)  # (a Function's ctx IS its outputs' grad_fn)
 
 
 def projection_loss(net):
-    live = net.__dict__.get("_sn_surface_live")
-    if live is None or live.plan.owner is None or net.project._temperature._version != live.t_version:
+    """sigma as an output of the most recent captured forward that still waits for its backward (any of them carries the same
+    value; the gradient reaches the temperature through that node)."""
+    lives = _lives(net)
+    if not lives or net.project._temperature._version != lives[-1].t_version:
         return None
-    return live.sigma
+    return lives[-1].sigma  # (None when only a weak record is left: the caller takes sigma() through autograd)

@@ -169,7 +169,7 @@ def test_module_surface_matches_reference_c2(golden, oracle, tag, route, monkeyp
     else:
         net.graph_surface = False
     simp, proj = net(x)
-    assert any(isinstance(p, surface._Plan) for p in net.__dict__.get("_sn_surface", {}).values()) == (route == "captured")
+    assert bool(surface.plans(net)) == (route == "captured")
     lsimp = net.get_simplification_loss(x, simp, M, GAMMA, DELTA)
     lproj = net.get_projection_loss()
     loss = ALPHA * lsimp + LMBDA * lproj + proj.mean()
@@ -242,7 +242,7 @@ def test_script_with_task_network_on_captured_surfaces_matches_reference_run(gol
     loss.backward()
     torch.cuda.synchronize()
     net.check()
-    assert any(isinstance(p, surface._Plan) for p in net.__dict__["_sn_surface"].values())
+    assert bool(surface.plans(net))
     assert any(isinstance(p, graphed._Plan) for p in pcr.__dict__["_sn_graphed"].values())
     _check_task_step(g, "script", loss.detach(), simp.detach(), proj.detach(), net)
 

@@ -83,7 +83,7 @@ def timed(name, fn):
     return w
 
 
-plan = [p for p in net.__dict__["_sn_surface"].values() if isinstance(p, surface._Plan)][0]
+plan = surface.plans(net)[0]
 plan.commit_begin = timed("commit_begin", plan.commit_begin)
 plan.commit_end = timed("commit_end", plan.commit_end)
 plan.gb.replay = timed("gb.replay", plan.gb.replay)
