@@ -64,11 +64,20 @@ def csrc_sha16():
 
 
 def profile_dir():
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         d = os.path.join(ROOT, "profiles", rnd)
         if os.path.exists(os.path.join(d, "bench_graph_kernel_stats.csv")):
             return rnd, d
     return None, None
+
+
+def _profile_file(name):
+    """The newest committed profiles/rNN/<name> (None if no round holds it)."""
+    for rnd in ("r04", "r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(path):
+            return path
+    return None
 
 
 def profile_provenance():
@@ -486,8 +495,8 @@ def time_config3_emd(dev, reps=5):
     sq = None
     try:
         rnd, d = profile_dir()
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r03", "emd_sq_counters.json")))
-    except (OSError, ValueError):
+        sq = json.load(open(_profile_file("emd_sq_counters.json")))
+    except (OSError, ValueError, TypeError):
         pass
     for name, ms, exps, traffic_key in (("emd_loss", t_fused, 50.0, "emd_loss"), ("three_call", t_three, 40.0, "three_call")):
         lane_ops = pairs * (exps * (5.0 / 3.0) + 10 * 3 * 9.0 + 10.0)  # exps + ~9 packed-pair VALU slots per pair, level and pass
@@ -504,10 +513,10 @@ def time_config3_emd(dev, reps=5):
 
 
 def pmc_traffic_sum(key):
-    """HBM bytes per call of an EMD form from the committed PMC passes (profiles/r03/emd_pmc_summary.json), or None."""
+    """HBM bytes per call of an EMD form from the committed PMC passes (profiles/rNN/emd_pmc_summary.json), or None."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r03", "emd_pmc_summary.json"))).get(key)
-    except (OSError, ValueError):
+        return json.load(open(_profile_file("emd_pmc_summary.json"))).get(key)
+    except (OSError, ValueError, TypeError):
         return None
 
 
@@ -642,7 +651,7 @@ def time_fc_chain_backward(net, x, reps=20, inner=20):
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/: FETCH_SIZE x 2 + WRITE_SIZE, KiB, as
     MI355X_MICROARCH.md prescribes for gfx950), or None when no profile of that kernel is on disk."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
         try:
             with open(path) as f:

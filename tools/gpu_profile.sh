@@ -1,9 +1,9 @@
-# Round-end measurement bundle (run as: gpurun --timeout 1500 -- 'bash tools/gpu_profile.sh r03'): bench JSON (all legs), bench with the RCCL
+# Round-end measurement bundle (run as: gpurun --timeout 1500 -- 'bash tools/gpu_profile.sh r04'): bench JSON (all legs), bench with the RCCL
 # collective forced at world size 1 (inside the graph / after it), rocprofv3 kernel stats (graph replay and eager launches), PMC
 # passes for HBM traffic (FETCH_SIZE / WRITE_SIZE in their own runs), SQ counters of the forward GEMMs, of the fused conv
 # backward and of the EMD forms, the pair-scan batch sweep, the EMD timings, the FC-chain phase timeline, the task network's
 # kernel stats.  Everything lands in gpurun_out/<round>/ -- copy what is to be judged into profiles/<round>/.
-R=${1:-r03}
+R=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -14,9 +14,13 @@ for mode in graph after; do
 done
 timeout 300 python bench.py --steps 1500 --warmup 100 --no-probes 2>/dev/null | tail -1 > $OUT/bench_n1_noprobes.json; cat $OUT/bench_n1_noprobes.json
 timeout 300 python tools/pairscan_scaling.py > $OUT/pairscan_scaling.txt 2>&1; cat $OUT/pairscan_scaling.txt
+timeout 300 python tools/batch_sweep.py 32 128 512 2048 > $OUT/batch_sweep.txt 2>/dev/null; cat $OUT/batch_sweep.txt
+timeout 300 python tools/surface_bench.py > $OUT/surface_bench.json 2>/dev/null; head -c 600 $OUT/surface_bench.json
+timeout 200 python tools/surface_profile.py 500 2>/dev/null | grep -v "^ \|^$" > $OUT/surface_profile.txt; head -4 $OUT/surface_profile.txt
 timeout 300 python tools/emd_bench.py > $OUT/emd_bench.txt 2>&1; tail -3 $OUT/emd_bench.txt
 if [ -f tools/_ab/libsamplenet_hip_tl.so ]; then
   SAMPLENET_AMD_LIB=$PWD/tools/_ab/libsamplenet_hip_tl.so timeout 200 python tools/fc_chain_timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/fc_chain_timeline.txt
+  (python tools/timeline.py stack 32; python tools/timeline.py stack 512) 2>&1 | grep -A8 "5-layer" > $OUT/fwd_persist_timeline.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 B="--no-probes"
@@ -26,6 +30,15 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ea
 cp /tmp/prof_eager/bench_kernel_stats.csv $OUT/bench_eager_kernel_stats.csv
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_task -o task -- python $GRAFT_REPO_ROOT/tools/task_loop.py 100 > /tmp/prof_task.log 2>&1
 cp /tmp/prof_task/task_kernel_stats.csv $OUT/task_kernel_stats.csv
+# the secondary legs' captured steps and the large-batch steps (persistent forward GEMMs)
+for leg in config3_sampler config5_progressive; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$leg -o leg -- python $GRAFT_REPO_ROOT/tools/variant_loop.py $leg 100 > /tmp/prof_$leg.log 2>&1
+  cp /tmp/prof_$leg/leg_kernel_stats.csv $OUT/${leg}_kernel_stats.csv
+done
+for b in 512 2048; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b$b -o bench -- python $GRAFT_REPO_ROOT/bench.py --batch $b --steps 30 --warmup 10 --no-probes > /tmp/prof_b$b.log 2>&1
+  cp /tmp/prof_b$b/bench_kernel_stats.csv $OUT/b${b}_kernel_stats.csv
+done
 for form in emd_loss three_call; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_emd_$form -o emd -- python $GRAFT_REPO_ROOT/tools/emd_loop.py $form 3 > /tmp/prof_emd.log 2>&1
   cp /tmp/prof_emd_$form/emd_kernel_stats.csv $OUT/emd_${form}_kernel_stats.csv
