@@ -315,6 +315,11 @@ int sn_skinny_linear(int R, int K, int N, const float *x, const float *gate, con
 int sn_skinny_linear2(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *gate, const float *W, int transposed,
                       const float *bias, int relu, float *out, float *out2, int nsplit, float *scratch, unsigned *counters,
                       sn_stream_t stream);
+/* Weight gradient of such a layer (a trainable trunk: registration/models/pcrnet.py:62-82 under main.py --train-pcrnet):
+ * dW (N, K) = (dy . [gate > 0])^T . [x | x2], db (N, optional) = its column sums; R <= 256 rows, fp32 MFMA, rows in ascending
+ * order (deterministic).  gate (R, N, optional): the layer's own output (ReLU mask); x2 / ksplit as in sn_skinny_linear2. */
+int sn_skinny_wgrad(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *dy, const float *gate, float *dW,
+                    float *db, sn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -110,6 +110,7 @@ PROTOTYPES = {
     "sn_skinny_linear_scratch_bytes": [_i, _i, _i],
     "sn_skinny_linear": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "sn_skinny_linear2": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "sn_skinny_wgrad": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "sn_pool_dgrad_sparse_supported": [_i, _i, _i, _i],
     "sn_pool_dgrad_sparse": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_batch_stats_twopass": [_i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],

@@ -5928,6 +5928,68 @@ extern "C" int sn_skinny_linear2(int R, int K, int N, const float *x, const floa
     return 0;
 }
 
+// ---- weight gradient of those layers (round 4: a TRAINABLE trunk stays on the library -- registration/main.py --train-pcrnet,
+// models/pcrnet.py:62-82): dW (N, K) = dZ^T . X with dZ = dY . [gate > 0] (R, N) and X = [x | x2] (R, K); db (N) = column sums of
+// dZ.  R <= 128 rows are the whole contraction: a wave owns one 32 x 32 tile of dW and runs R / 2 fp32 MFMAs (32x32x2: exact
+// products, rows in ascending order -> deterministic), operands straight from memory (a row of dZ / X per lane pair, 128-byte
+// segments); the output -- 8 MB for PCRNet's first layer -- is the traffic.  Four waves per workgroup = 32 rows x 128 columns of dW.
+__global__ void __launch_bounds__(256) skinny_wgrad_kernel(int R, int K, int N, const float *__restrict__ x, const float *__restrict__ x2,
+                                                           int ksplit, const float *__restrict__ dy, const float *__restrict__ gate,
+                                                           float *__restrict__ dW, float *__restrict__ db)
+{
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.y * 32, k0 = (blockIdx.x * 4 + wave) * 32;
+    if (k0 >= K) return;
+    const int n = n0 + l31, k = k0 + l31;
+    const bool nok = n < N, kok = k < K;
+    // column k of X: from x (R, ksplit) or x2 (R, K - ksplit)
+    const float *xs = x;
+    int xk = k, xld = K;
+    if (x2) {
+        if (k < ksplit) xld = ksplit;
+        else xs = x2, xk = k - ksplit, xld = K - ksplit;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float bsum = 0.f;
+    for (int r0 = 0; r0 < R; r0 += 2) {
+        const int r = r0 + h;
+        float a = 0.f, b = 0.f;
+        if (r < R) {
+            if (nok) {
+                a = dy[(size_t)r * N + n];
+                if (gate) a = gate[(size_t)r * N + n] > 0.f ? a : 0.f;
+            }
+            if (kok) b = xs[(size_t)r * xld + xk];
+        }
+        bsum += a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int nn = n0 + frag_row(e, lane);
+        if (nn < N && kok) dW[(size_t)nn * K + k] = acc[e];
+    }
+    if (db && k0 == 0) {  // (the k-block 0 wave of every row block: even rows in lanes 0..31, odd rows in 32..63)
+        bsum += __shfl_xor(bsum, 32);
+        if (lane < 32 && nok) db[n] = bsum;
+    }
+}
+
+extern "C" int sn_skinny_wgrad(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *dy, const float *gate,
+                               float *dW, float *db, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && R <= 256 && K >= 1 && N >= 1, "bad size (at most 256 rows)");
+    SN_REQUIRE(x && dy && dW, "null pointer");
+    SN_REQUIRE(!x2 || (ksplit > 0 && ksplit < K), "x2: ksplit inside (0, K)");
+    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3((K + 127) / 128, (N + 31) / 32), dim3(256), 0, (hipStream_t)stream, R, K, N, x, x2,
+                       x2 ? ksplit : 0, dy, gate, dW, db);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- data gradient of that last layer when its dZ is SPARSE (BatchNorm-free stack: dZ = dY through the max over the points has one
 // non-zero per cloud and channel -- the pooled element; with a BatchNorm the k2 Z + k3 terms make it dense and the GEMM kernels
 // apply).  dYprev[b, n, :] = relu'_prev . sum over the channels c whose maximum sits at point n of  gsel[b][c] * W[c][:],

@@ -29,7 +29,7 @@ FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch
 FUSE_NARROW = True         # conv1..conv4 (3 -> 64 -> 64 -> 64 -> 128) as one launch (sn_pointnet_narrow_forward)
 WIDE_MAXPOOL = True        # ... as the wide kernel (A fragments resident, pre-split weight planes) where the shape allows
 FUSED_HEAD = True          # quaternion normalisation + regulariser as one launch (sn_pcrnet_head_*), else the torch op chain
-FUSED_TRUNK = True         # frozen FC trunk on <= 128 rows through sn_skinny_linear (forward and data gradient), else torch.nn.Linear
+FUSED_TRUNK = True         # FC trunk on <= 128 rows through sn_skinny_linear (forward, data gradient) + sn_skinny_wgrad (a trainable trunk), else torch.nn.Linear
 SPARSE_POOL_DGRAD = True   # last layer's data gradient from the one non-zero per cloud and channel (sn_pool_dgrad_sparse)
 
 _CONST = {}  # (rows, channels, device) -> constant coefficient table, built once (never written afterwards)
@@ -312,9 +312,21 @@ def _skinny(x, gate, W, transposed, bias, relu, x2=None, split_out=None, scratch
     return out if split_out is None else (out, out2)
 
 
+def _skinny_wgrad(x, x2, dy, gate, W, st):
+    """dW (N, K), db (N) of a layer out = act([x | x2] W^T + b) from dy (R, N) and the layer's own output `gate` (ReLU mask)."""
+    R, N = dy.shape
+    K = W.shape[1]
+    dW = torch.empty_like(W)
+    db = torch.empty(N, device=W.device, dtype=torch.float32)
+    check(lib.sn_skinny_wgrad(R, K, N, ptr(x), ptr(x2), x.shape[1] if x2 is not None else 0, ptr(dy), ptr(gate), ptr(dW), ptr(db), st),
+          "sn_skinny_wgrad")
+    return dW, db
+
+
 class _TrunkFunction(torch.autograd.Function):
-    """PCRNet's FC trunk with FROZEN weights on at most 128 rows: [f0 | f1] -> fc1 .. fc5 (ReLU) -> fc6, six sn_skinny_linear launches
-    forward and six for the data gradient (registration/models/pcrnet.py:56-77 as rocBLAS GEMMs + ReLU / mask kernels: 22 launches).
+    """PCRNet's FC trunk on at most 128 rows: [f0 | f1] -> fc1 .. fc5 (ReLU) -> fc6, six sn_skinny_linear launches forward and six
+    for the data gradient (registration/models/pcrnet.py:56-77 as rocBLAS GEMMs + ReLU / mask kernels: 22 launches); weights that
+    want a gradient get it from six sn_skinny_wgrad launches (frozen weights -- the sampler's training step -- skip them).
     The two clouds' feature vectors are read where they lie and each receives its own gradient tensor (no cat / slice copies)."""
 
     @staticmethod
@@ -331,6 +343,7 @@ class _TrunkFunction(torch.autograd.Function):
                 x = _skinny(x, None, Ws[i], False, bs[i], i < len(Ws) - 1, scratch=sc, st=st)
                 acts.append(x)
         ctx.save_for_backward(*acts[:-1], *Ws)
+        ctx.inputs = (f0, f1) if any(ctx.needs_input_grad[2:]) else (None, None)  # (the first layer's weight gradient reads them)
         ctx.nl = len(Ws)
         ctx.n0 = f0.shape[1]
         ctx.sc = sc  # (the backward's launches reuse the pair: the counters are back at zero)
@@ -344,11 +357,18 @@ class _TrunkFunction(torch.autograd.Function):
         with torch.cuda.device(g.device):
             sc = ctx.sc if ctx.sc[0].device == g.device else _trunk_scratch(g.shape[0], Ws, g)
             st = _st(g)
+            wgrads = [None] * (2 * nl)
+            f0, f1 = ctx.inputs
             for i in range(nl - 1, 0, -1):  # dX = (dY . [y_i > 0]) W_i; the last layer has no ReLU
-                g = _skinny(g, acts[i] if i < nl - 1 else None, Ws[i], True, None, False, scratch=sc, st=st)
+                gate = acts[i] if i < nl - 1 else None
+                if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:  # trainable trunk: dW_i, db_i
+                    wgrads[2 * i], wgrads[2 * i + 1] = _skinny_wgrad(acts[i - 1], None, g, gate, Ws[i], st)
+                g = _skinny(g, gate, Ws[i], True, None, False, scratch=sc, st=st)
+            if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+                wgrads[0], wgrads[1] = _skinny_wgrad(f0, f1, g, acts[0], Ws[0], st)
             g0, g1 = _skinny(g, acts[0], Ws[0], True, None, False, split_out=(ctx.n0, ctx.needs_input_grad[0], ctx.needs_input_grad[1]),
                              scratch=sc, st=st)
-        return (g0, g1) + (None,) * (2 * nl)
+        return (g0, g1) + tuple(wgrads)
 
 
 class _HeadFunction(torch.autograd.Function):
@@ -386,8 +406,9 @@ class PCRNet(nn.Module):
     """Drop-in for `registration/models/pcrnet.py:44-82` (same constructor, attribute and parameter names -> state_dict
     compatible, same `forward(x0, x1) -> (twist (B,7), pre_normalized_quat (B,4))`): the two feature extractions run on the
     HIP MLP kernels (`PointNetFeatures` above, the 99 % of the network's arithmetic); the six-layer FC trunk on B rows runs on
-    `sn_skinny_linear` (forward and data gradient) when its weights are frozen and B <= 32 -- the sampler's training step -- and
-    as plain library GEMMs (torch.nn.Linear -> rocBLAS) otherwise; the quaternion normalisation is torch."""
+    `sn_skinny_linear` (forward and data gradient) on up to 128 rows -- frozen as in the sampler's training step, or trainable
+    (main.py --train-pcrnet: weight / bias gradients on `sn_skinny_wgrad`) -- and as plain library GEMMs (torch.nn.Linear ->
+    rocBLAS) above that; the output head is one launch each way (`sn_pcrnet_head_*`)."""
 
     def __init__(self, bottleneck_size=1024, input_shape="bcn"):
         super().__init__()
@@ -435,8 +456,7 @@ class PCRNet(nn.Module):
         f0 = self.template_features(x0) if feat0 is None else feat0
         B = f0.shape[0]
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
-        frozen = not any(fc.weight.requires_grad or fc.bias.requires_grad for fc in fcs)  # (Module.parameters() is 20x dearer)
-        if not (FUSED_TRUNK and frozen and f0.is_cuda and E * B <= 128 and f0.shape[1] % 8 == 0 and E > 1):
+        if not (FUSED_TRUNK and f0.is_cuda and E * B <= 128 and f0.shape[1] % 8 == 0 and E > 1):
             return [self.forward_with_qnorm(x0, x1, feat0=f0) for x1 in x1_list]
         f1 = torch.cat([self.feat(x1) for x1 in x1_list], dim=0)
         wb = []
@@ -462,8 +482,7 @@ class PCRNet(nn.Module):
         (twist, pre_normalized_quat, qnorm, quat).  feat0: template_features(x0), computed by the caller (x0 is then unused)."""
         f0, f1 = (self.feat(x0) if feat0 is None else feat0), self.feat(x1)
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
-        frozen = not any(fc.weight.requires_grad or fc.bias.requires_grad for fc in fcs)  # (Module.parameters() is 20x dearer)
-        if FUSED_TRUNK and frozen and f0.is_cuda and f0.shape[0] <= 128 and f0.shape[1] % 8 == 0:
+        if FUSED_TRUNK and f0.is_cuda and f0.shape[0] <= 128 and f0.shape[1] % 8 == 0:
             wb = []
             for fc in fcs:
                 wb += [fc.weight, fc.bias]

@@ -1346,3 +1346,44 @@ def test_persistent_forward_is_bit_identical(B, N):
     assert torch.equal(ya, yb)
     for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
         assert torch.equal(ba, bb), n
+
+
+@pytest.mark.parametrize("B", [32, 5, 100])
+def test_trainable_pcrnet_trunk_stays_on_the_library(B):
+    """registration/models/pcrnet.py:62-82 under main.py --train-pcrnet: with a TRAINABLE FC trunk the six layers still run on
+    sn_skinny_linear (forward, data gradient) and their weight / bias gradients on sn_skinny_wgrad -- against the torch.nn.Linear
+    route (rocBLAS) on the same weights: twist 1e-5, every gradient of the trunk and the gradient that reaches both clouds within
+    1e-4 of its norm; deterministic from run to run."""
+    import copy
+
+    from samplenet_amd import task_features as tf
+
+    torch.manual_seed(B)
+    net = tf.PCRNet(bottleneck_size=1024, input_shape="bnc").cuda().train()
+    for p in net.feat.parameters():
+        p.requires_grad_(False)
+    ref = copy.deepcopy(net)
+    p0 = torch.rand(B, 256, 3, device="cuda") - 0.5
+    q = torch.rand(B, 64, 3, device="cuda") - 0.5
+    gw = torch.randn(B, 7, device="cuda")
+    outs = []
+    for model, fused in ((net, True), (ref, False), (net, True)):
+        old = tf.FUSED_TRUNK
+        tf.FUSED_TRUNK = fused
+        try:
+            for p in model.parameters():
+                p.grad = None
+            qq = q.clone().requires_grad_(True)
+            twist, pre = model(p0, qq)
+            ((twist * gw).sum() + (pre * pre).sum()).backward()
+        finally:
+            tf.FUSED_TRUNK = old
+        outs.append((twist.detach().clone(), qq.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (ta, ga, wa), (tb, gb, wb), (tc, gc, wc) = outs
+    assert len(wa) == 12 and set(wa) == set(wb)
+    assert float((ta - tb).abs().max()) <= 1e-5 * max(1.0, float(tb.abs().max()))
+    assert float((ga - gb).norm()) <= 1e-4 * float(gb.norm())
+    for n in wa:
+        assert float((wa[n] - wb[n]).norm()) <= 1e-4 * float(wb[n].norm()) + 1e-9, n
+        assert torch.equal(wa[n], wc[n]), n
+    assert torch.equal(ta, tc) and torch.equal(ga, gc)
