@@ -172,3 +172,16 @@ def check(rc, what=""):
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()
+
+
+try:  # the current stream's handle without building a torch.cuda.Stream object (~0.3 us instead of ~4 us per lookup; the eager
+    from torch._C import _cuda_getCurrentRawStream as _raw_stream  # module surface issues dozens of them per step)
+except ImportError:  # pragma: no cover
+    _raw_stream = None
+
+
+def stream_of(t):
+    """hipStream_t (as an int) of torch's current stream on tensor t's device."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(t.device).cuda_stream

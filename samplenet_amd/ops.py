@@ -6,13 +6,13 @@ requires CUDA(HIP) tensors and raises otherwise: there is no CPU path in the pro
 """
 import torch
 
-from ._lib import check, lib, ptr
+from ._lib import check, lib, ptr, stream_of
 
 BNC, BCN = 0, 1  # SN_LAYOUT_*
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return stream_of(t)
 
 
 def _need_gpu(*ts):

@@ -8,14 +8,14 @@ while the parameters stay ordinary nn.Conv1d / nn.BatchNorm1d / nn.Linear member
 """
 import torch
 
-from ._lib import check, lib, ptr
+from ._lib import check, lib, ptr, stream_of
 
 DZ_PLAIN, DZ_BN, DZ_POOL = 0, 1, 2
 SYNC_STRIDE = 32  # words between the words of a chain launch's sync state (sn_common.h: SN_FC_SYNC_STRIDE): [i, 0] is word i
 
 
 def _st(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return stream_of(t)
 
 
 def _empty(shape, like, dtype=torch.float32):

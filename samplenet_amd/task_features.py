@@ -15,13 +15,13 @@ import weakref
 import torch
 import torch.nn as nn
 
-from ._lib import check, lib, ptr
+from ._lib import check, lib, ptr, stream_of
 
 _DZ_PLAIN, _DZ_POOL = 0, 2
 
 
 def _st(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return stream_of(t)
 
 
 # Test hooks (the defaults are the product path; False = the route other shapes take anyway)
