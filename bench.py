@@ -120,7 +120,7 @@ def longest_kernel_of_profile():
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured by a float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz (dense fp32 matrix peak)
 # The conv-stack GEMMs compute fp32 products as six bf16 products of three-way split operands on the bf16 matrix cores
-# (pointnet_mlp.hip, gemm_tile_bx3 / conv_bwd_bx3_kernel): their matrix-pipe ceiling is the dense bf16 peak / 6
+# (mlp_device.h gemm_tile_bx3 / pointnet_mlp_backward.hip conv_bwd_bx3_kernel): their matrix-pipe ceiling is the dense bf16 peak / 6
 # (MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16; tools/micro/bf16x3_gemm.hip measures 392 fp32-equivalent TFLOP/s).
 MFMA_SPLIT_BF16_PEAK_TFLOPS = 2500.0 / 6.0
 
@@ -415,7 +415,7 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
 
 def _task_wide_layer_roofline(dev, B, N, Ci=128, Co=1024, reps=40):
     """The task step's longest kernel against its roof: PCRNet's 128 -> 1024 layer on the template cloud + max over the points
-    (sn_linear_forward_maxpool_wide, pointnet_mlp.hip) -- 2 R Ci Co fp32-equivalent flops as split-bf16 products (ceiling
+    (sn_linear_forward_maxpool_wide, task_network.hip) -- 2 R Ci Co fp32-equivalent flops as split-bf16 products (ceiling
     2.5 PF / 6 = 417 TFLOP/s), HIP events around back-to-back launches on the launch stream."""
     from samplenet_amd._lib import check, lib, ptr
 

@@ -269,7 +269,7 @@ int sn_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float
 /* ---------------------------------------------------------------------------------------------
  * PointNet feature extractor + FC head (registration/src/samplenet.py:40-59, :90-104): every layer is a
  * GEMM over rows (R = B*N points for the 1x1 convolutions, R = B for the Linear layers) on fp32 MFMA
- * with BatchNorm / ReLU / bias / reductions fused (samplenet_amd/csrc/pointnet_mlp.hip).
+ * with BatchNorm / ReLU / bias / reductions fused (samplenet_amd/csrc/pointnet_mlp.hip forward, pointnet_mlp_backward.hip, fc_chain.hip; the task network: task_network.hip).
  * All matrices are row-major with channels contiguous: activations [R][C], weights [Co][Ci] (the
  * memory layout of torch Conv1d(k=1).weight and Linear.weight).
  *

@@ -25,6 +25,9 @@ SOURCES = [
     ("geometry_ops.hip", ["-ffp-contract=off"]),
     ("emd.hip", ["-ffp-contract=off"]),
     ("pointnet_mlp.hip", []),
+    ("pointnet_mlp_backward.hip", []),
+    ("fc_chain.hip", []),
+    ("task_network.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
           "-Wall", "-Wno-unused-function"]
@@ -49,7 +52,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers += [os.path.join(ROOT, "include", h) for h in ("samplenet_hip.h", "samplenet_hip_internal.h")]
-    objs, rebuilt = [], False
+    objs, jobs = [], []
     for src, extra in SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
@@ -60,8 +63,11 @@ def build(force=False, verbose=False):
             cmd = [hipcc, "-x", "hip", "-c", path, "-o", obj] + COMMON + extra
             if verbose:
                 print(" ".join(cmd))
-            subprocess.check_call(cmd)
-            rebuilt = True
+            jobs.append((src, subprocess.Popen(cmd)))  # the translation units compile side by side
+    failed = [src for src, p in jobs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed on " + ", ".join(failed))
+    rebuilt = bool(jobs)
     if rebuilt or force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

@@ -27,7 +27,7 @@ int sn_set_error(int code, const char *fmt, ...);
 typedef unsigned long long sn_u64;
 
 // spacing (in 32-bit words) of the words of an FC chain launch's `sync` state: word i lives at sync[i * SN_FC_SYNC_STRIDE]
-// (pointnet_mlp.hip: kFcSyncStride; geometry_ops.hip: the step tail reads the error words)
+// (fc_chain.hip: kFcSyncStride; geometry_ops.hip: the step tail reads the error words)
 #ifndef SN_FC_SYNC_STRIDE
 #define SN_FC_SYNC_STRIDE 32
 #endif

@@ -1,7 +1,7 @@
 // step_tail.h -- the scalar tail of the sampler step's loss side (keys mode): temperature gradient from the per-workgroup
 // sigma partials, the loss value from the scan's query-side partials, and the reset of the per-point key table.  Nothing on
 // the step's critical path waits for these, so they can ride in ANY later launch: sigma_grad_kernel (geometry_ops.hip) runs
-// them as a launch of their own; the closing kernel of the conv-stack backward (pointnet_mlp.hip) runs them in two extra
+// them as a launch of their own; the closing kernel of the conv-stack backward (pointnet_mlp_backward.hip) runs them in two extra
 // workgroups when it is handed a StepTail (sn_conv_stack_backward, engine path: one launch less).
 #pragma once
 #include "sn_common.h"

@@ -1,5 +1,5 @@
 """PointNet feature extractor + FC head of SampleNet on the hand-written MFMA kernels
-(samplenet_amd/csrc/pointnet_mlp.hip), as ONE autograd node.
+(samplenet_amd/csrc/pointnet_mlp.hip, pointnet_mlp_backward.hip, fc_chain.hip), as ONE autograd node.
 
 Replaces the torch.nn call chain of registration/src/samplenet.py:90-104
     5 x relu(bn(conv1d_k1(.)))  ->  max over points  ->  3 x relu(bn(linear(.)))  ->  linear

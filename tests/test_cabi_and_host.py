@@ -143,18 +143,22 @@ def test_bench_self_launches_its_ranks(tmp_path):
 
 
 def test_fp32_mfma_twin_of_the_conv_gemms_still_compiles(tmp_path):
-    """pointnet_mlp.hip carries a second implementation of the conv-stack GEMMs and of the fused conv backward on the fp32 MFMA
-    (-DSN_BF16X3=0: exact fp32 products instead of six bf16 products of three-way split operands) -- the arithmetic reference
-    of the split kernels (tests/test_gpu_mlp.py::test_fp32_mfma_twin_agrees_with_the_split_bf16_build runs it on the GPU).
-    It is not a product build, so nothing else would notice if it stopped compiling."""
+    """pointnet_mlp.hip / pointnet_mlp_backward.hip carry a second implementation of the conv-stack GEMMs and of the fused conv
+    backward on the fp32 MFMA (-DSN_BF16X3=0: exact fp32 products instead of six bf16 products of three-way split operands) -- the
+    arithmetic reference of the split kernels (tests/test_gpu_mlp.py::test_fp32_mfma_twin_agrees_with_the_split_bf16_build runs it
+    on the GPU).  It is not a product build, so nothing else would notice if it stopped compiling."""
     import subprocess
 
-    src = os.path.join(ROOT, "samplenet_amd", "csrc", "pointnet_mlp.hip")
-    cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "-c", src, "-o", str(tmp_path / "pm0.o"), "-O3", "-std=c++17", "-fPIC",
-           "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "samplenet_amd", "csrc"),
-           "-Wall", "-Wno-unused-function", "-Werror", "-DSN_BF16X3=0"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    procs = []
+    for unit in ("pointnet_mlp", "pointnet_mlp_backward"):
+        src = os.path.join(ROOT, "samplenet_amd", "csrc", unit + ".hip")
+        cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "-c", src, "-o", str(tmp_path / (unit + "0.o")), "-O3", "-std=c++17", "-fPIC",
+               "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "samplenet_amd", "csrc"),
+               "-Wall", "-Wno-unused-function", "-Werror", "-DSN_BF16X3=0"]
+        procs.append((unit, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for unit, p in procs:
+        _, err = p.communicate(timeout=900)
+        assert p.returncode == 0, unit + ": " + err[-3000:]
 
 
 def test_bench_profile_provenance_helpers():

@@ -1,4 +1,4 @@
-"""GPU parity of the hand-written MFMA PointNet MLP (samplenet_amd/csrc/pointnet_mlp.hip) against the plain
+"""GPU parity of the hand-written MFMA PointNet MLP (samplenet_amd/csrc/pointnet_mlp.hip, pointnet_mlp_backward.hip, fc_chain.hip, task_network.hip) against the plain
 PyTorch fp32 modules of the same network (the reference's own op chain, samplenet.py:90-104) on the same
 weights and inputs: outputs, BatchNorm running statistics, and the gradient of every parameter."""
 import copy
@@ -855,7 +855,7 @@ def test_forward_plan_replays_are_identical_and_isolated():
 
 
 def test_fp32_mfma_twin_agrees_with_the_split_bf16_build(tmp_path):
-    """The -DSN_BF16X3=0 build of pointnet_mlp.hip (conv GEMMs and fused conv backward on the exact fp32 MFMA) against the
+    """The -DSN_BF16X3=0 build of pointnet_mlp.hip / pointnet_mlp_backward.hip (conv GEMMs and fused conv backward on the exact fp32 MFMA) against the
     product build (fp32 products as six bf16 products of split operands) through the same C entry points: one 64 -> 128 layer
     forward and its fused backward at R = 4096 -- outputs within 1e-6 of the largest value, i.e. the split products are
     fp32-accurate against the hardware's own fp32 matrix path."""
@@ -865,15 +865,18 @@ def test_fp32_mfma_twin_agrees_with_the_split_bf16_build(tmp_path):
     from samplenet_amd._lib import LIB_PATH, PROTOTYPES
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    objs = [os.path.join(root, "samplenet_amd", "lib", n + ".o") for n in ("capi_common", "pairscan", "geometry_ops", "emd")]
+    objs = [os.path.join(root, "samplenet_amd", "lib", n + ".o") for n in ("capi_common", "pairscan", "geometry_ops", "emd", "fc_chain", "task_network")]
     if not all(os.path.exists(o) for o in objs):
         pytest.skip("object files of the product build are not in the tree")
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(root, "include"),
              "-I" + os.path.join(root, "samplenet_amd", "csrc"), "-Wno-unused-function"]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-c", os.path.join(root, "samplenet_amd", "csrc", "pointnet_mlp.hip"),
-                           "-o", str(tmp_path / "pm0.o"), "-DSN_BF16X3=0"] + flags, timeout=900)
+    twins = []
+    for unit in ("pointnet_mlp", "pointnet_mlp_backward"):
+        twins.append(str(tmp_path / (unit + "0.o")))
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-c", os.path.join(root, "samplenet_amd", "csrc", unit + ".hip"),
+                               "-o", twins[-1], "-DSN_BF16X3=0"] + flags, timeout=900)
     so = str(tmp_path / "libsamplenet_hip_fp32.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so, str(tmp_path / "pm0.o")] + objs, timeout=600)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", so] + twins + objs, timeout=600)
     libs = []
     for path in (LIB_PATH, so):
         L = ctypes.CDLL(path)

@@ -7,10 +7,10 @@ cd "$(dirname "$0")/.."
 NAME=$1; SRC=$2; EXTRA=$3
 mkdir -p tools/_ab
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Isamplenet_amd/csrc -Wall -Wno-unused-function"
-case $SRC in pointnet_mlp.hip|capi_common.cpp) ;; *) F="$F -ffp-contract=off";; esac
+case $SRC in pointnet_mlp.hip|pointnet_mlp_backward.hip|fc_chain.hip|task_network.hip|capi_common.cpp) ;; *) F="$F -ffp-contract=off";; esac
 /opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/$SRC -o tools/_ab/${SRC%.*}_$NAME.o $F $EXTRA
 OBJS=""
-for s in capi_common pairscan geometry_ops emd pointnet_mlp; do
+for s in capi_common pairscan geometry_ops emd pointnet_mlp pointnet_mlp_backward fc_chain task_network; do
   if [ "$s" == "${SRC%.*}" ]; then OBJS="$OBJS tools/_ab/${s}_$NAME.o"; else OBJS="$OBJS samplenet_amd/lib/$s.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_ab/libsamplenet_hip_$NAME.so $OBJS

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of the two FC chain kernels inside the captured step (debug build: tools/build_variant.sh tl pointnet_mlp.hip
+"""Phase timeline of the two FC chain kernels inside the captured step (debug build: tools/build_variant.sh tl fc_chain.hip
 -DSN_TIMELINE; run with SAMPLENET_AMD_LIB=tools/_ab/libsamplenet_hip_tl.so).  Thread 0 of every chain workgroup stamps the
 100 MHz wall clock at the phase boundaries; printed: per phase the median over the workgroups of (stamp - kernel's first stamp)."""
 import ctypes

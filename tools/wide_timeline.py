@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of linear_fwd_wide_pool_kernel (timeline build: tools/build_variant.sh tl pointnet_mlp.hip -DSN_TIMELINE; run with
+"""Phase stamps of linear_fwd_wide_pool_kernel (timeline build: tools/build_timeline_lib.sh; run with
 SAMPLENET_AMD_LIB=tools/_ab/libsamplenet_hip_tl.so): start, prologue done, iteration 4: top / MFMAs done / next block staged /
 barrier passed, end -- thread 0 (wave 0) and thread 256 (wave 4) of every workgroup, 100 MHz clock."""
 import ctypes
