@@ -320,6 +320,13 @@ int sn_skinny_linear2(int R, int K, int N, const float *x, const float *x2, int 
  * order (deterministic).  gate (R, N, optional): the layer's own output (ReLU mask); x2 / ksplit as in sn_skinny_linear2. */
 int sn_skinny_wgrad(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *dy, const float *gate, float *dW,
                     float *db, sn_stream_t stream);
+/* sn_linear_forward for a layer of the FC head above 32 rows (rows = clouds, registration/src/samplenet.py:97-104 at a batch of
+ * 64 .. ~1000): no statistics (the head takes two-pass statistics from Z, sn_bn_batch_stats_twopass).  While (R / 32) x (Co / 32)
+ * workgroups fit the chip once, the R <= 32 kernel runs row block by row block -- every workgroup's operands in flight at once --
+ * instead of the 64 x 64 tile kernel's dependent K chunks (512 x 256 -> 256: 8.8 us instead of 14.8); same products, K summed in
+ * four partial chains.  Any other shape: sn_linear_forward's dispatch. */
+int sn_linear_forward_rows(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W, const float *bias, float *z,
+                           sn_stream_t stream);
 
 #ifdef __cplusplus
 }

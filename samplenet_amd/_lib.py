@@ -90,6 +90,7 @@ PROTOTYPES = {
     "sn_layer_backward_in3_stats_floats": [_i, _i, _i],
     "sn_layer_backward_in3": [_i, _i, _i] + [_vp] * 17 + [_vp],
     "sn_linear_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_linear_forward_rows": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_finalize": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_fc_chain_forward_supported": [_i, _i, _i, _i],
     "sn_fc_chain_forward_pool_supported": [_i, _i, _i, _i, _i],

@@ -722,6 +722,9 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
     const int LD = Ci + 4;
     float *As = sm, *Ws = sm + 32 * LD, *red = Ws + 32 * LD, *Ts = red + 3 * 16 * 64;
     const int col0 = blockIdx.x * 32;
+    // gridDim.y > 1 (32 < R, launch_fwd's row-tiled case): workgroup (x, y) owns rows [32 y, 32 y + 32) -- the statistics of a
+    // column are then spread over gridDim.y workgroups, so neither stats nor the BatchNorm finalisation may be requested
+    const int rb = blockIdx.y * 32;
     const int col = col0 + l31;
     const bool colok = col < Co;
     const int ccol = colok ? col : 0;
@@ -746,7 +749,7 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
     for (int q = 0; q < MAXP; ++q)
         if (q < npass) {
             const int r = r0 + q * rpp;
-            av[q] = *reinterpret_cast<const float4 *>(g.a.z + (size_t)min(r, R - 1) * Ci + c4);
+            av[q] = *reinterpret_cast<const float4 *>(g.a.z + (size_t)min(rb + r, R - 1) * Ci + c4);
             wv[q] = *reinterpret_cast<const float4 *>(g.w.w + (size_t)min(col0 + r, Co - 1) * Ci + c4);
         }
 #pragma unroll
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
                 a.x = relu_np(fmaf(a.x, sc4.x, sh4.x)), a.y = relu_np(fmaf(a.y, sc4.y, sh4.y));
                 a.z = relu_np(fmaf(a.z, sc4.z, sh4.z)), a.w = relu_np(fmaf(a.w, sc4.w, sh4.w));
             }
-            const float ma = r < R ? 1.f : 0.f, mw = col0 + r < Co ? 1.f : 0.f;
+            const float ma = rb + r < R ? 1.f : 0.f, mw = col0 + r < Co ? 1.f : 0.f;
             a.x *= ma, a.y *= ma, a.z *= ma, a.w *= ma;
             float4 w = wv[q];
             w.x *= mw, w.y *= mw, w.z *= mw, w.w *= mw;
@@ -791,10 +794,10 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
     for (int e = 0; e < 16; ++e) {
         const int row = frag_row(e, lane);
         const float v = acc[e] + bias;
-        if (row < R && colok) {
+        if (rb + row < R && colok) {
             s0 += v;
             s1 += v * v;
-            if (!vec_out) g.z[(size_t)row * Co + col] = v;
+            if (!vec_out) g.z[(size_t)(rb + row) * Co + col] = v;
         }
         Ts[row * 36 + l31] = v;
     }
@@ -803,7 +806,7 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
         for (int i = 0; i < 4; ++i) {
             const int row = 8 * i + (lane >> 3);
             const float4 v = *reinterpret_cast<const float4 *>(Ts + row * 36 + (lane & 7) * 4);
-            if (row < R) *reinterpret_cast<float4 *>(g.z + (size_t)row * Co + col0 + (lane & 7) * 4) = v;
+            if (rb + row < R) *reinterpret_cast<float4 *>(g.z + (size_t)(rb + row) * Co + col0 + (lane & 7) * 4) = v;
         }
     }
     s0 += __shfl_xor(s0, 32);
@@ -891,7 +894,8 @@ __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const 
                                                            const float *__restrict__ W, const float *__restrict__ bias,
                                                            float *__restrict__ z, float *__restrict__ stats,
                                                            long long *__restrict__ acc_out = nullptr,
-                                                           long long *__restrict__ clear_flags = nullptr, WSplitJob job = WSplitJob{})
+                                                           long long *__restrict__ clear_flags = nullptr, WSplitJob job = WSplitJob{},
+                                                           int nb = 1)
 {
     if (job.n > 0 && blockIdx.y == 0 && (int)blockIdx.x < job.first[job.n]) wsplit_block(job, blockIdx.x, threadIdx.x);
     if (job.zero_keys && blockIdx.y == 0) {
@@ -903,10 +907,13 @@ __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const 
     if (clear_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) clear_flags[0] = 0;
     // thread -> 4 consecutive channels (c4) x row slot rs (16 slots): 16-byte stores, a wave writes 4 whole 256-byte rows
     // per instruction (dword stores cost ~58 issue cycles per wave-instruction: the 16-per-thread version was issue-bound)
+    // nb > 1 (statistics chain at large batches): the workgroup walks nb consecutive 64-row blocks and keeps their fixed-point
+    // sums in registers -- ONE pair of atomics per channel and workgroup instead of one per 64 rows (at 512 x 1024 points 1 M
+    // 64-bit atomics on 2 K addresses paced this kernel at 25 us).  Every block's partial is converted on its own, as fx_add would:
+    // the integer totals, hence the statistics, are the same bit for bit.
     __shared__ float red[2][16][64];
     const int q = threadIdx.x & 15, rs = threadIdx.x >> 4;
     const int cl = q * 4, co = blockIdx.y * 64 + cl;
-    const int row0 = blockIdx.x * 64;
     const bool vec = (Co & 3) == 0 && co + 3 < Co;
     float w[4][3], b[4];
 #pragma unroll
@@ -916,51 +923,70 @@ __global__ void __launch_bounds__(256) conv_in3_fwd_kernel(int R, int Co, const 
         w[j][0] = W[c * 3 + 0] * m, w[j][1] = W[c * 3 + 1] * m, w[j][2] = W[c * 3 + 2] * m;
         b[j] = bias ? bias[c] * m : 0.f;
     }
-    float xs[4][3];
+    const int nblocks = (R + 63) / 64;
+    const int blk0 = blockIdx.x * nb, blk1 = min(blk0 + nb, nblocks);
+    long long fx0 = 0, fx1 = 0;
+    for (int blk = blk0; blk < blk1; ++blk) {
+        const int row0 = blk * 64;
+        float xs[4][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = min(row0 + rs + 16 * i, R - 1);
-        xs[i][0] = x[(size_t)r * 3], xs[i][1] = x[(size_t)r * 3 + 1], xs[i][2] = x[(size_t)r * 3 + 2];
-    }
-    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = row0 + rs + 16 * i;
-        const float m = r < R ? 1.f : 0.f;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = (fmaf(w[j][2], xs[i][2], fmaf(w[j][1], xs[i][1], w[j][0] * xs[i][0])) + b[j]) * m;
-            s0[j] += v[j];
-            s1[j] += v[j] * v[j];
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(row0 + rs + 16 * i, R - 1);
+            xs[i][0] = x[(size_t)r * 3], xs[i][1] = x[(size_t)r * 3 + 1], xs[i][2] = x[(size_t)r * 3 + 2];
         }
-        if (r < R && z) {  // (z == NULL: statistics only -- the consumers rebuild the activation from the cloud, FwdArgs::x3)
-            if (vec) {
-                *reinterpret_cast<float4 *>(z + (size_t)r * Co + co) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (co + j < Co) z[(size_t)r * Co + co + j] = v[j];
+        for (int i = 0; i < 4; ++i) {
+            const int r = row0 + rs + 16 * i;
+            const float m = r < R ? 1.f : 0.f;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = (fmaf(w[j][2], xs[i][2], fmaf(w[j][1], xs[i][1], w[j][0] * xs[i][0])) + b[j]) * m;
+                s0[j] += v[j];
+                s1[j] += v[j] * v[j];
+            }
+            if (r < R && z) {  // (z == NULL: statistics only -- the consumers rebuild the activation from the cloud, FwdArgs::x3)
+                if (vec) {
+                    *reinterpret_cast<float4 *>(z + (size_t)r * Co + co) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (co + j < Co) z[(size_t)r * Co + co + j] = v[j];
+                }
+            }
+        }
+        if (blk > blk0) __syncthreads();  // (the previous block's sums have been read)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[0][rs][cl + j] = s0[j], red[1][rs][cl + j] = s1[j];
+        __syncthreads();
+        if (threadIdx.x < 64 && (stats || acc_out)) {
+            const int c = blockIdx.y * 64 + threadIdx.x;
+            if (c < Co) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a0 += red[0][k][threadIdx.x], a1 += red[1][k][threadIdx.x];
+                if (acc_out) {  // fixed-point statistics chain (sn_conv_stack_forward_bn)
+                    if (nb == 1) {
+                        fx_add<kFxShiftFwd>(acc_out, blockIdx.x % kFxSlots, 0, c, a0);
+                        fx_add<kFxShiftFwd>(acc_out, blockIdx.x % kFxSlots, 1, c, a1);
+                    } else {
+                        fx_local_add<kFxShiftFwd>(fx0, acc_out, 0, c, a0);
+                        fx_local_add<kFxShiftFwd>(fx1, acc_out, 1, c, a1);
+                    }
+                } else {
+                    float *st = stats + (size_t)blk * 2 * Co;
+                    st[c] = a0;
+                    st[Co + c] = a1;
+                }
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) red[0][rs][cl + j] = s0[j], red[1][rs][cl + j] = s1[j];
-    __syncthreads();
-    if (threadIdx.x < 64 && (stats || acc_out)) {
-        const int c = blockIdx.y * 64 + threadIdx.x;
+    if (nb > 1 && acc_out && threadIdx.x < 64 && blk0 < blk1) {
+        const int c = blockIdx.y * 64 + threadIdx.x, slot = blockIdx.x % kFxSlots;
         if (c < Co) {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a0 += red[0][k][threadIdx.x], a1 += red[1][k][threadIdx.x];
-            if (acc_out) {  // fixed-point statistics chain (sn_conv_stack_forward_bn)
-                fx_add<kFxShiftFwd>(acc_out, blockIdx.x % kFxSlots, 0, c, a0);
-                fx_add<kFxShiftFwd>(acc_out, blockIdx.x % kFxSlots, 1, c, a1);
-            } else {
-                float *st = stats + (size_t)blockIdx.x * 2 * Co;
-                st[c] = a0;
-                st[Co + c] = a1;
-            }
+            atomicAdd(reinterpret_cast<unsigned long long *>(acc_out + (slot * 2 + 0) * kFxRow + c), (unsigned long long)fx0);
+            atomicAdd(reinterpret_cast<unsigned long long *>(acc_out + (slot * 2 + 1) * kFxRow + c), (unsigned long long)fx1);
         }
     }
 }
@@ -1228,7 +1254,7 @@ __global__ void __launch_bounds__(1024) pool_fwd_kernel(int N, int C, const floa
 }  // namespace sn
 
 template <int AMODE>
-static void launch_fwd(const FwdArgs &g, hipStream_t st)
+static void launch_fwd(const FwdArgs &g, hipStream_t st, bool few_rows = false)
 {
     const int R = g.a.rows, Ci = g.w.ci, Co = g.w.co;
     if (AMODE == ACT_NONE && Ci == 3 && R > 64) {  // xyz input layer: streaming kernel, same stats layout (64 rows / block)
@@ -1237,7 +1263,15 @@ static void launch_fwd(const FwdArgs &g, hipStream_t st)
                            g.bias, g.z, g.stats);
         return;
     }
-    if (R <= 32) {
+    // few_rows (sn_linear_forward_rows), 32 < R, a layer of the FC head at a mid-size batch: the tile kernels below put (R / 64) x (Co / 64) workgroups on the chip
+    // (32 at R = 512, Co = 256), each walking K in dependent 64-wide chunks -- 15 us of exposed load latency for 0.07 GFLOP.  While
+    // (R / 32) x (Co / 32) workgroups fit the chip in one wave, the R <= 32 kernel runs them row block by row block instead: both
+    // operands of a workgroup (32 rows, 32 columns, all of K) are in flight at once.  No statistics: the caller takes them from Z
+    // (sn_bn_batch_stats_twopass), as the FC head does above 32 rows.
+    const bool row_tiled = few_rows && R > 32 && Ci % 64 == 0 && Ci <= 512 && !g.stats && !g.bn.coef && !g.pool_val && !g.pool_keys && !g.wplanes &&
+                           AMODE != ACT_BN_RELU_FX && (long long)((R + 31) / 32) * ((Co + 31) / 32) <= device_cus();
+    if (R <= 32 || row_tiled) {
+        const dim3 grid((Co + 31) / 32, (R + 31) / 32);
         if (Ci % 64 == 0 && Ci <= 512) {
             const size_t lds = ((size_t)64 * (Ci + 4) + 3 * 16 * 64 + 32 * 36) * sizeof(float);
             static bool attr_done = false;
@@ -1246,7 +1280,7 @@ static void launch_fwd(const FwdArgs &g, hipStream_t st)
                                           (int)(((size_t)64 * 516 + 3 * 16 * 64 + 32 * 36) * sizeof(float)));
                 attr_done = true;
             }
-            hipLaunchKernelGGL((small_fwd_lds_kernel<AMODE>), dim3((Co + 31) / 32), dim3(256), lds, st, g);
+            hipLaunchKernelGGL((small_fwd_lds_kernel<AMODE>), grid, dim3(256), lds, st, g);
         } else if (Ci % 64 == 0)
             hipLaunchKernelGGL((small_fwd_kernel<AMODE, true>), dim3((Co + 31) / 32), dim3(256), 0, st, g);
         else
@@ -1276,6 +1310,23 @@ extern "C" int sn_linear_forward(int R, int Ci, int Co, const float *ain, const 
         launch_fwd<ACT_BN_RELU>(g, st);
     else
         launch_fwd<ACT_NONE>(g, st);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int sn_linear_forward_rows(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W, const float *bias,
+                                      float *z, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(ain && W && z, "null pointer");
+    FwdArgs g{};
+    g.a = make_act(ain, coef_prev, R, Ci);
+    g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+    g.bias = bias, g.z = z, g.stats = nullptr;
+    if (coef_prev)
+        launch_fwd<ACT_BN_RELU>(g, (hipStream_t)stream, true);
+    else
+        launch_fwd<ACT_NONE>(g, (hipStream_t)stream, true);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -1502,8 +1553,16 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         job.zero_keys = reinterpret_cast<unsigned long long *>(pool_val), job.nkeys = B * 2 * channels[nlayers];
         SN_REQUIRE((long long)job.nkeys <= (long long)(R / 64) * 256, "too few rows to clear the pool keys");
     }
-    hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3(R / 64, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
-                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * kFxLayer + kFxPoison, job);
+    // 64-row blocks per workgroup of the xyz layer: 1 until the batch is large (the headline's 512 blocks stay as they are), then up to
+    // 8 while the riders (weight split blocks, key clear: 256 keys per workgroup) still find their workgroups and >= 4 per CU remain
+    int in3_nb = 1;
+    {
+        const long long need = std::max<long long>(job.n > 0 ? job.first[job.n] : 0, keys_pool ? (job.nkeys + 255) / 256 : 0);
+        while (in3_nb < 8 && (R / 64) / (in3_nb * 2) >= std::max<long long>(need, 4 * device_cus()) && (R / 64) % (in3_nb * 2) == 0) in3_nb *= 2;
+    }
+    hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3(R / 64 / in3_nb, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
+                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * kFxLayer + kFxPoison, job,
+                       in3_nb);
     using T = TileBig;
     for (int l = 1; l < nlayers; ++l) {
         const int Ci = channels[l], Co = channels[l + 1];

@@ -118,6 +118,10 @@ class SamplerTrainStep:
             if self.reducer is not None and T.requires_grad and not floor:
                 self.reducer._rebind()  # (after an optimizer.zero_grad(): T.grad is the bucket's view again)
                 t_sink = T.grad.view(-1)[:1]  # a view of the flat bucket: written in place, nothing to zero or accumulate
+                if self.reducer.autograd_accumulated > 1:
+                    # classification sampler: torch applies a BatchNorm on the head's output -- its weight / bias gradients are
+                    # ACCUMULATED into their slices by autograd, step after step unless they are cleared here
+                    self.reducer.zero_grad(keep=T)
             elif self.reducer is not None:
                 self.reducer.zero_grad()
             weight = self.gamma + self.delta * net.num_out_points

@@ -107,12 +107,20 @@ class FlatGradAllReducer:
         if sink is not None:
             sink.reset()
 
-    def zero_grad(self):
+    def zero_grad(self, keep=None):
         """Start of a step: begin_step() + zero the autograd-accumulated slices.  optimizer.zero_grad() -- either flavour --
-        works too (pointnet.GradSink and _rebind() below take the views back); this is just the cheapest form."""
-        for _, v in self._autograd:
-            v.zero_()
+        works too (pointnet.GradSink and _rebind() below take the views back); this is just the cheapest form.
+        keep: a parameter whose slice a kernel of the step overwrites in place (the engine's temperature sink): not filled."""
+        for p, v in self._autograd:
+            if p is not keep:
+                v.zero_()
         self.begin_step()
+
+    @property
+    def autograd_accumulated(self):
+        """Number of parameters whose gradients reach the bucket through autograd's accumulate (temperature; a BatchNorm that
+        torch applies on the head's output)."""
+        return len(self._autograd)
 
     def _rebind(self, replayed=False):
         """Gradients autograd accumulated into tensors of its own (after zero_grad(set_to_none=True)) move into the bucket.

@@ -102,8 +102,12 @@ def _identity_coef(C, like):
     return t
 
 
-def _linear_fwd(R, L, a_in, coef_prev, want_stats):
+def _linear_fwd(R, L, a_in, coef_prev, want_stats, fc_rows=False):
     z = _empty((R, L.Co), a_in)
+    if fc_rows and not want_stats and R > 32:  # a layer of the FC head above 32 clouds (no statistics asked of the GEMM)
+        check(lib.sn_linear_forward_rows(R, L.Ci, L.Co, ptr(a_in), ptr(coef_prev), ptr(L.W), ptr(L.b), ptr(z), _st(a_in)),
+              "sn_linear_forward_rows")
+        return z, None, 0
     nblk = lib.sn_linear_stats_blocks(R)
     stats = _empty((nblk, 2, L.Co), a_in) if want_stats else None
     check(lib.sn_linear_forward(R, L.Ci, L.Co, ptr(a_in), ptr(coef_prev), ptr(L.W), ptr(L.b), ptr(z), ptr(stats), _st(a_in)),
@@ -385,12 +389,12 @@ def forward_impl(net, x_bnc, training, skip_last=False, use_plan=True):
         hidden = []
     for L in hidden:
         if L.bn is None:  # ReLU layer without BatchNorm
-            z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False)
+            z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False, fc_rows=True)
             coef = _identity_coef(L.Co, z)
         elif training and B > 32:
             # the GEMM, then two-pass batch statistics from z itself (above 32 rows the statistics are not complete inside one
             # workgroup, and sum / sum-of-squares partials lose digits on the head's nearly-constant features)
-            z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False)
+            z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False, fc_rows=True)
             coef = _empty((4, L.Co), z)
             bn, upd = L.bn, L.bn.track_running_stats
             check(lib.sn_bn_batch_stats_twopass(B, L.Co, ptr(z), ptr(bn.weight), ptr(bn.bias), float(bn.eps), _momentum(bn),
@@ -407,7 +411,7 @@ def forward_impl(net, x_bnc, training, skip_last=False, use_plan=True):
         a_in, coef_prev = z, coef
     y = None
     if not skip_last:
-        y, _, _ = _linear_fwd(B, fcs[-1], a_in, coef_prev, False)
+        y, _, _ = _linear_fwd(B, fcs[-1], a_in, coef_prev, False, fc_rows=True)
     if rec is not None and len(rec) == 2 and not convs and not hidden:
         # the whole head ran as the two fused calls (+ the last layer): from now on steps of this shape replay them
         _ForwardPlan.register(net, x_bnc, skip_last, rec, saved, fcs[-1])

@@ -155,6 +155,36 @@ def test_linear_kernels_exact_small_integers():
         assert torch.equal(db.double(), dZ.double().sum(0))
 
 
+@pytest.mark.parametrize("R,Ci,Co", [(512, 256, 256), (512, 128, 256), (100, 256, 192), (40, 64, 250), (1000, 256, 256), (33, 512, 64),
+                                      (128, 256, 256), (2048, 256, 256)])
+@pytest.mark.parametrize("act", [False, True])
+def test_row_tiled_layer_forward_exact_small_integers(R, Ci, Co, act):
+    """A layer of the FC head above 32 rows, no statistics requested (the caller takes two-pass statistics from Z): while
+    (R / 32) x (Co / 32) workgroups fit the chip, sn_linear_forward_rows runs the R <= 32 kernel row block by row block (all of K in flight per
+    workgroup) instead of the 64 x 64 tile kernel.  Small-integer operands (and a power-of-two BatchNorm scale) make every product and
+    sum exact: the result must equal the integer reference bit for bit at ragged rows / columns too ((2048, 256, 256) is past the
+    chip-filling bound and takes the tile kernel: same bar)."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    A = torch.randint(-4, 5, (R, Ci), device="cuda", generator=g).float()
+    W = torch.randint(-4, 5, (Co, Ci), device="cuda", generator=g).float()
+    b = torch.randint(-4, 5, (Co,), device="cuda", generator=g).float()
+    coef = None
+    Ain = A.double()
+    if act:  # relu(scale * a + shift) with scale in {1, 2, -1}, integer shifts
+        sc = torch.tensor([1.0, 2.0, -1.0], device="cuda")[torch.randint(0, 3, (Ci,), device="cuda", generator=g)]
+        sh = torch.randint(-2, 3, (Ci,), device="cuda", generator=g).float()
+        coef = torch.stack([sc, sh, torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda")]).contiguous()
+        Ain = torch.relu(A.double() * sc.double() + sh.double())
+    Z = torch.full((R + 1, Co), -7.0, device="cuda")  # one guard row behind the output
+    check(lib.sn_linear_forward_rows(R, Ci, Co, ptr(A), ptr(coef) if act else None, ptr(W), ptr(b), ptr(Z), st))
+    Zr = Ain @ W.double().t() + b.double()
+    assert torch.equal(Z[:R].double(), Zr), (R, Ci, Co)
+    assert bool((Z[R] == -7.0).all())
+
+
 @pytest.mark.parametrize("R,Ci,Co", [(4096, 128, 128), (2048, 64, 128), (1024, 64, 64)])
 def test_split_bf16_products_are_fp32_accurate(R, Ci, Co):
     """The conv-layer GEMMs run on the bf16 matrix cores with every fp32 operand split into three bf16 terms and six
