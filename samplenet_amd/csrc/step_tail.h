@@ -59,15 +59,18 @@ __device__ __forceinline__ void step_loss_keys_final(const StepLossKeysFinal &f,
         sp += __shfl_xor(sp, o);
     }
     if (t != 0) return;
-    const float c12 = s1 / ((float)f.B * (float)f.M), cmax = mx / (float)f.B, c21 = s2 / ((float)f.B * (float)f.N);
-    const float lsimp = c12 + cmax + f.w * c21;
-    float L = f.alpha * lsimp + f.lmbda * sn_sigma(T, f.min_sigma);
-    if (f.with_mean_proj) L = L + sp / ((float)f.B * (float)f.nproj);
-    unsigned err = 0;
-    if (f.chain_err[0]) err |= *f.chain_err[0];
-    if (f.chain_err[1]) err |= *f.chain_err[1];
-    f.loss[0] = err ? __builtin_nanf("") : L;
-    f.loss[1] = lsimp;
+    {
+#pragma clang fp contract(off)  // (as sigma_grad_block: the same value from either translation unit)
+        const float c12 = s1 / ((float)f.B * (float)f.M), cmax = mx / (float)f.B, c21 = s2 / ((float)f.B * (float)f.N);
+        const float lsimp = c12 + cmax + f.w * c21;
+        float L = f.alpha * lsimp + f.lmbda * sn_sigma(T, f.min_sigma);
+        if (f.with_mean_proj) L = L + sp / ((float)f.B * (float)f.nproj);
+        unsigned err = 0;
+        if (f.chain_err[0]) err |= *f.chain_err[0];
+        if (f.chain_err[1]) err |= *f.chain_err[1];
+        f.loss[0] = err ? __builtin_nanf("") : L;
+        f.loss[1] = lsimp;
+    }
 }
 
 // d loss / dT from the per-workgroup partials of d loss / d sigma:  sigma = max(T^2, min_sigma)
@@ -89,6 +92,9 @@ __device__ __forceinline__ void sigma_grad_block(int nparts, const float *__rest
     if (t < 256 && (t & 63) == 0) red[t >> 6] = acc;
     __syncthreads();
     if (t == 0) {
+        // (this block is compiled into two translation units with different contraction defaults -- the geometric kernels are built
+        //  with -ffp-contract=off, the MLP ones are not: product, then sum, wherever it runs)
+#pragma clang fp contract(off)
         const float tot = (red[0] + red[1]) + (red[2] + red[3]);
         const float t2 = T * T;
         const float w = t2 > min_sigma ? 1.f : (t2 == min_sigma ? 0.5f : 0.f);

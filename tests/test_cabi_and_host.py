@@ -142,6 +142,36 @@ def test_bench_self_launches_its_ranks(tmp_path):
         assert r.returncode == 2 and "exposes 0 GPU" in r.stderr and "Traceback" not in r.stderr
 
 
+def test_device_code_carries_no_packed_fp32_arithmetic(tmp_path):
+    """The product build switches the packed fp32 VALU ops off (samplenet_amd/build.py NO_PACKED_F32): with a second process on the
+    GPU, kernels carrying the compiler's SLP-packed v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 returned wrong low halves in ~1 % of
+    their launches (tests/test_gpu_cotenancy.py watches the effect on a GPU).  Here: every object of the library is
+    disassembled and must hold none of them -- a flag lost in a build script shows up without a GPU."""
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    libdir = os.path.join(ROOT, "samplenet_amd", "lib")
+    objs = sorted(f for f in os.listdir(libdir) if f.endswith(".o"))
+    assert len(objs) >= 8
+    checked = 0
+    for o in objs:
+        fat = str(tmp_path / (o + ".fat"))
+        r = subprocess.run([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, os.path.join(libdir, o)], capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(fat):
+            continue  # (capi_common: host code only)
+        lst = subprocess.run([llvm + "/clang-offload-bundler", "--list", "--type=o", "--input=" + fat], capture_output=True, text=True).stdout
+        tgt = [t for t in lst.split() if "gfx950" in t]
+        assert tgt, (o, lst)
+        co = str(tmp_path / (o + ".co"))
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=" + tgt[0], "--input=" + fat, "--output=" + co])
+        dis = subprocess.run([llvm + "/llvm-objdump", "-d", co], capture_output=True, text=True).stdout
+        n = len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", dis))
+        assert n == 0, "%s carries %d packed fp32 instructions" % (o, n)
+        assert "s_endpgm" in dis
+        checked += 1
+    assert checked >= 7
+
+
 def test_fp32_mfma_twin_of_the_conv_gemms_still_compiles(tmp_path):
     """pointnet_mlp.hip / pointnet_mlp_backward.hip carry a second implementation of the conv-stack GEMMs and of the fused conv
     backward on the fp32 MFMA (-DSN_BF16X3=0: exact fp32 products instead of six bf16 products of three-way split operands) -- the

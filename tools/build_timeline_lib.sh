@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/_ab
 L=${LEVEL:-1}
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Isamplenet_amd/csrc -Wno-unused-function"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Isamplenet_amd/csrc -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops"
 G="$F -ffp-contract=off -DSN_PS_TIMELINE=$L -DSN_CS_TIMELINE=$L"
 # the four MLP translation units as ONE (the stamp buffers of mlp_device.h then exist once, whichever kernel writes them)
 printf '#include "pointnet_mlp.hip"\n#include "pointnet_mlp_backward.hip"\n#include "fc_chain.hip"\n#include "task_network.hip"\n' > tools/_ab/pointnet_mlp_tl.hip
