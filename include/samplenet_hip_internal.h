@@ -320,6 +320,10 @@ int sn_skinny_linear2(int R, int K, int N, const float *x, const float *x2, int 
  * order (deterministic).  gate (R, N, optional): the layer's own output (ReLU mask); x2 / ksplit as in sn_skinny_linear2. */
 int sn_skinny_wgrad(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *dy, const float *gate, float *dW,
                     float *db, sn_stream_t stream);
+/* Test hook: 64-row blocks per workgroup of the xyz layer's statistics pass inside sn_conv_stack_forward_bn (0 = chosen per call:
+ * 1 until the batch is large, then up to 8 -- one pair of atomics per channel and workgroup instead of one per block; the integer
+ * totals are the same whatever the grouping).  Returns the previous setting. */
+int sn_conv_stack_set_in3_blocks(int blocks);
 /* sn_linear_forward for a layer of the FC head above 32 rows (rows = clouds, registration/src/samplenet.py:97-104 at a batch of
  * 64 .. ~1000): no statistics (the head takes two-pass statistics from Z, sn_bn_batch_stats_twopass).  While (R / 32) x (Co / 32)
  * workgroups fit the chip once, the R <= 32 kernel runs row block by row block -- every workgroup's operands in flight at once --

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "sn_surface_values_keys": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_surface_gather_upstream": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_conv_stack_set_persist_min_tiles": [_i],
+    "sn_conv_stack_set_in3_blocks": [_i],
     "sn_step_tail_bytes": [],
     "sn_step_tail_set_error_words": [_vp, _vp, _vp],
     "sn_prefix_point_minima": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -1483,6 +1483,14 @@ extern "C" long long sn_conv_stack_acc_elems(int nlayers)
 
 // tiles per workgroup from which the conv stack's forward GEMMs run as persistent kernels (0: never); a test / A-B hook
 static int g_persist_min_tiles = 4;
+// 64-row blocks per workgroup of the xyz layer's statistics pass (0: chosen per call, see sn_conv_stack_forward_bn); a test hook
+static int g_in3_blocks = 0;
+extern "C" int sn_conv_stack_set_in3_blocks(int blocks)
+{
+    const int prev = g_in3_blocks;
+    g_in3_blocks = blocks < 0 ? 0 : blocks;
+    return prev;
+}
 extern "C" int sn_conv_stack_set_persist_min_tiles(int tiles)
 {
     const int old = g_persist_min_tiles;
@@ -1559,8 +1567,9 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
     {
         const long long need = std::max<long long>(job.n > 0 ? job.first[job.n] : 0, keys_pool ? (job.nkeys + 255) / 256 : 0);
         while (in3_nb < 8 && (R / 64) / (in3_nb * 2) >= std::max<long long>(need, 4 * device_cus()) && (R / 64) % (in3_nb * 2) == 0) in3_nb *= 2;
+        if (g_in3_blocks > 0 && (R / 64) / g_in3_blocks >= std::max<long long>(need, 1)) in3_nb = g_in3_blocks;  // (test hook)
     }
-    hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3(R / 64 / in3_nb, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
+    hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3((R / 64 + in3_nb - 1) / in3_nb, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
                        bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * kFxLayer + kFxPoison, job,
                        in3_nb);
     using T = TileBig;

@@ -1340,6 +1340,36 @@ def test_fused_conv_backward_two_passes_for_256_channels(Ci, Co, R, mode):
     assert float((got - want_s).abs().max()) <= 1e-4 * float(want_s.abs().max())
 
 
+@pytest.mark.parametrize("B,N,blocks", [(256, 1024, 8), (128, 1024, 2), (96, 320, 4), (40, 1024, 3)])
+def test_xyz_layer_statistics_do_not_depend_on_the_block_grouping(B, N, blocks):
+    """Large batches: a workgroup of the xyz layer's statistics pass walks several 64-row blocks and issues ONE pair of atomics per
+    channel (1 M atomics on 2 K addresses paced the kernel at 512 x 1024 points).  Every block's float partial is converted to fixed
+    point on its own, so the integer totals -- hence every coefficient, activation and running statistic of the stack -- are the same
+    bit for bit whatever the grouping (also a grouping that leaves the last workgroup short)."""
+    import copy
+
+    from samplenet_amd import SampleNet, pointnet
+    from samplenet_amd._lib import lib
+
+    torch.manual_seed(B + N + blocks)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+    net_b = copy.deepcopy(net_a)
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5).contiguous()
+    old = lib.sn_conv_stack_set_in3_blocks(blocks)
+    try:
+        ya, sa = pointnet.forward_impl(net_a, x, True, use_plan=False)
+        assert _acc_sums_zero(net_a._fx_acc)
+        lib.sn_conv_stack_set_in3_blocks(1)
+        yb, sb = pointnet.forward_impl(net_b, x, True, use_plan=False)
+    finally:
+        lib.sn_conv_stack_set_in3_blocks(old)
+    for l in range(5):
+        assert torch.equal(sa["cc"][l], sb["cc"][l]), l
+    assert torch.equal(sa["pooled"], sb["pooled"]) and torch.equal(ya, yb)
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), n
+
+
 @pytest.mark.parametrize("B,N", [(256, 1024), (160, 2048), (300, 512)])
 def test_persistent_forward_is_bit_identical(B, N):
     """Large batches run the conv stack's GEMM layers as persistent, weight-stationary kernels (linear_fwd_persist_kernel: one
