@@ -22,6 +22,8 @@ import torch
 from . import surface
 
 WARM_STEPS = 2
+MAX_PLANS = 6  # captured configurations per owner: the least recently used idle one gives its graphs and static buffers up
+_clock = 0
 
 
 class _Token:
@@ -88,6 +90,7 @@ class _Plan:
             with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local"):
                 self.gins = torch.autograd.grad([self.outs[i] for i in self.req], self.ins_req, self.gouts, allow_unused=True)
         self.guard = _ModuleGuard(owner)
+        self.used = 0
 
     def busy(self):
         o = self.owner_token
@@ -163,6 +166,11 @@ def call(owner, tag, fn, args):
         if any(p.requires_grad for p in owner.parameters()) or owner._forward_hooks or owner._forward_pre_hooks:
             table[key] = 0
             return None
+        held = [(k, v) for k, v in table.items() if isinstance(v, _Plan)]
+        if len(held) >= MAX_PLANS:  # (a caller that walks through many shapes must not pin a set of buffers per shape)
+            idle = [(k, v) for k, v in held if not v.busy()]
+            if idle:
+                table[min(idle, key=lambda kv: kv[1].used)[0]] = 0
         try:
             with surface.suspended():  # (nothing inside the captured call builds graphs of its own)
                 ent = _Plan(owner, fn, args)
@@ -176,6 +184,9 @@ def call(owner, tag, fn, args):
         if ent is False:
             return None
     plan = ent
+    global _clock
+    _clock += 1
+    plan.used = _clock
     if plan.busy():
         return None
     if not plan.guard.ok():

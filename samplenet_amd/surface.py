@@ -43,10 +43,16 @@ from ._lib import check, lib, ptr, stream_of
 ENABLED = True   # test hook / global switch (per module: net.graph_surface)
 WARM_STEPS = 2   # eager steps of a configuration before its graphs are captured
 MAX_PLANS = 3    # pairs of graphs per configuration (forwards that may wait for their backward at the same time)
+MAX_CONFIGS = 4  # configurations (batch shape, device) of one module that keep graphs: the least recently used one gives its up
 _suspend = 0
 
 
-_VIEW_OWNER = {}  # id(gradient view) -> (weak reference to it, its plan)
+_VIEW_OWNER = {}  # id(gradient view) -> (weak reference to it, weak reference to its plan); entries leave with their view
+
+
+def _register_view(v, plan):
+    key = id(v)
+    _VIEW_OWNER[key] = (weakref.ref(v, lambda _r, k=key: _VIEW_OWNER.pop(k, None)), weakref.ref(plan))
 
 
 class suspended:
@@ -185,7 +191,7 @@ class _Plan:
             if T.requires_grad:
                 self.grad_pairs.append((T, self.t_view))
             for _, v in self.grad_pairs:  # (which plan a .grad tensor belongs to: commit_begin's mode 3)
-                _VIEW_OWNER[id(v)] = (weakref.ref(v), self)
+                _register_view(v, self)
             self._capture(net, x)
         self.guard = _Guard(net)
 
@@ -275,8 +281,9 @@ class _Plan:
                 nours += 1
             else:
                 o = _VIEW_OWNER.get(id(g))
-                if o is not None and o[0]() is g and (other is None or o[1] is other):
-                    other, nother = o[1], nother + 1
+                op = o[1]() if o is not None and o[0]() is g else None
+                if op is not None and (other is None or op is other):
+                    other, nother = op, nother + 1
         n = len(self.grad_pairs)
         if nnone == n:
             return 0, None
@@ -388,10 +395,27 @@ def _supported(net, x):
 class _Config:
     """Per (batch shape, device): the warm-step count, the captured plans, how often a forward found all of them taken."""
 
-    __slots__ = ("seen", "plans", "contended", "dead")
+    __slots__ = ("seen", "plans", "contended", "dead", "used")
 
     def __init__(self):
-        self.seen, self.plans, self.contended, self.dead = 0, [], 0, False
+        self.seen, self.plans, self.contended, self.dead, self.used = 0, [], 0, False, 0
+
+
+_clock = 0
+
+
+def _make_room(table, keep):
+    """Before a configuration captures its first graphs: at most MAX_CONFIGS - 1 others keep theirs (every plan holds the step's
+    activations, ~50 MB at 32 x 1024 points) -- the least recently used one whose plans are all idle starts over (a script that
+    walks through many batch shapes would otherwise pin a set of buffers per shape)."""
+    holders = [c for c in table.values() if c is not keep and c.plans]
+    while len(holders) >= MAX_CONFIGS:
+        idle = [c for c in holders if not any(p.busy() for p in c.plans)]
+        if not idle:
+            return
+        victim = min(idle, key=lambda c: c.used)
+        victim.plans, victim.seen, victim.contended = [], 0, 0
+        holders.remove(victim)
 
 
 def _build(net, x):
@@ -448,6 +472,9 @@ def try_forward(net, x):
         cfg = table[key] = _Config()
     if cfg.dead:
         return None
+    global _clock
+    _clock += 1
+    cfg.used = _clock
     if cfg.plans and not cfg.plans[0].guard.ok():
         # a parameter / buffer / layer was replaced: new graphs after the warm steps (this call is the first of them)
         cfg.plans, cfg.seen, cfg.contended = [], 1, 0
@@ -456,6 +483,7 @@ def try_forward(net, x):
         cfg.seen += 1
         if cfg.seen <= WARM_STEPS:
             return None
+        _make_room(table, cfg)
         plan = _build(net, x)
         if plan is None:
             cfg.dead = True

@@ -359,3 +359,46 @@ def test_frozen_task_network_on_captured_graphs():
     loss, _, _ = pcrnet_chamfer_loss(pcr, p0, qq)
     loss.backward()
     assert pcr.fc6.weight.grad is not None and qq.grad is not None
+
+
+def test_dropped_plans_are_released_and_configurations_are_capped():
+    """Every plan holds a step's activations and two graphs: (1) a plan the module has dropped (storage replaced: new graphs) is
+    really freed -- the bookkeeping of gradient views keeps weak references only; (2) a script that walks through many batch shapes
+    keeps graphs for at most surface.MAX_CONFIGS of them (the least recently used idle configuration starts over)."""
+    import gc
+    import weakref
+
+    from samplenet_amd import surface
+
+    a, _ = _nets(21)
+    xs = _batches(4, seed=12)
+    for x in xs[:3]:
+        _clear(a)
+        _script_step(a, x)
+    first = _plan(a)
+    assert first is not None
+    wr = weakref.ref(first)
+    nviews = len(surface._VIEW_OWNER)
+    del first
+    with torch.no_grad():
+        a.conv3.weight.data = a.conv3.weight.data.clone()  # guard: the graphs are dropped at the next forward
+    _clear(a)  # (.grad were views of the dropped plan's bucket)
+    for x in xs[:3]:
+        _clear(a)
+        _script_step(a, x)
+    gc.collect()
+    assert wr() is None, "the dropped plan is still referenced"
+    assert _plan(a) is not None and len(surface._VIEW_OWNER) <= nviews
+    # (2) six batch sizes, three steps each
+    torch.manual_seed(3)
+    for B in (4, 5, 6, 7, 8, 9):
+        x = torch.rand(B, 256, 3, device="cuda") - 0.5
+        for _ in range(3):
+            _clear(a)
+            _script_step(a, x)
+    table = a.__dict__["_sn_surface"]
+    holders = [k for k, c in table.items() if c.plans]
+    assert len(holders) <= surface.MAX_CONFIGS and (9, 256, x.device) in holders
+    _clear(a)
+    r1 = _script_step(a, x)  # the survivor still replays
+    assert torch.isfinite(r1[0]).all()
