@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode,n", [("fwd", 3000), ("step", 60)])
+@pytest.mark.parametrize("mode,n", [("fwd", 3000), ("step", 60), ("task", 25), ("emd", 120)])
 def test_results_do_not_depend_on_a_second_process_on_the_gpu(mode, n):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cotenancy_stress.py"), mode, str(n)], capture_output=True, text=True,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Do the library's results depend on what ELSE runs on the GPU?   python tools/cotenancy_stress.py [fwd|step] [passes] [--solo]
+"""Do the library's results depend on what ELSE runs on the GPU?   python tools/cotenancy_stress.py [fwd|step|task|emd] [passes] [--solo]
 
 Two processes work on cuda:0 at the same time (the second one is started here unless --solo), each repeating the same computation
 on the same inputs and comparing every pass with its first one, bit for bit:
@@ -7,6 +7,9 @@ on the same inputs and comparing every pass with its first one, bit for bit:
           the pooled features
     step  fresh replicas of one network, three captured fused training steps each (engine.SamplerTrainStep): losses, gradient
           bucket, running statistics
+    task  the reference call pattern with the frozen PCRNet + Chamfer task (registration/main.py:507-531, 557-577) on the captured
+          module surface: fresh replicas, five script steps each (the last three replay graphs): loss and every gradient
+    emd   sn_emd_loss (auction + cost + gradients, reconstruction's loss) on one batch: cost and both gradients
 Why this exists (round 4): alone on the device every pass repeats exactly (the statistics are integer sums); with a
 second process present, a build whose kernels carry the compiler's packed fp32 VALU ops (v_pk_fma_f32 ...) deviated in ~1 % of the
 forward passes -- low halves of the packed pairs, i.e. the even channels of the xyz layer's statistics, and everything downstream
@@ -82,15 +85,73 @@ def run_step(replicas):
     return bad, first
 
 
+def run_task(replicas):
+    from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss
+
+    state = {k: v.cpu().clone() for k, v in fresh().state_dict().items()}
+    torch.manual_seed(7)
+    pcr = PCRNet(bottleneck_size=1024, input_shape="bnc").cuda().eval()
+    for p in pcr.parameters():
+        p.requires_grad_(False)
+    x = (torch.rand(32, 1024, 3, device="cuda") - 0.5).contiguous()
+    template = (torch.rand(32, 1024, 3, device="cuda") - 0.5).contiguous()
+    ref, bad, first = None, 0, None
+    for it in range(replicas):
+        net = fresh()
+        net.load_state_dict(state)
+        losses = []
+        for _ in range(5):
+            for p in net.parameters():
+                p.grad = None
+            simp, proj = net(x)
+            loss = 0.01 * net.get_simplification_loss(x, simp, 64, 1, 0) + 0.01 * net.get_projection_loss() + pcrnet_chamfer_loss(pcr, template, proj)[0]
+            loss.backward()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        cur = (losses, [p.grad.detach().cpu().clone() for p in net.parameters()])
+        if ref is None:
+            ref = cur
+            continue
+        # (steps 1-2 run op by op, 3-5 on graphs: every replica takes the same route at the same step)
+        same = cur[0] == ref[0] and all(torch.equal(a, b) for a, b in zip(cur[1], ref[1]))
+        if not same:
+            bad += 1
+            if first is None:
+                first = "replica %d: losses %s (first replica %s)" % (it, cur[0], ref[0])
+    return bad, first
+
+
+def run_emd(passes):
+    from samplenet_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = (torch.rand(16, 1024, 3, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    b = (torch.rand(16, 1024, 3, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    ref, bad, first = None, 0, None
+    for it in range(passes):
+        a.grad = b.grad = None
+        cost = ops.emd_loss(a, b)
+        cost.sum().backward()
+        cur = (cost.detach().clone(), a.grad.clone(), b.grad.clone())
+        if ref is None:
+            ref = cur
+            continue
+        if not all(torch.equal(u, v) for u, v in zip(cur, ref)):
+            bad += 1
+            if first is None:
+                first = "pass %d: cost / grad1 / grad2 equal %s" % (it, [torch.equal(u, v) for u, v in zip(cur, ref)])
+    return bad, first
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     mode = args[0] if args else "fwd"
-    n = int(args[1]) if len(args) > 1 else (4000 if mode == "fwd" else 150)
+    n = int(args[1]) if len(args) > 1 else {"fwd": 4000, "step": 150, "task": 60, "emd": 300}[mode]
     other = None
     if "--solo" not in sys.argv and "--child" not in sys.argv:
         other = subprocess.Popen([sys.executable, os.path.abspath(__file__), mode, str(n), "--child"], stdout=subprocess.PIPE,
                                  stderr=subprocess.STDOUT, text=True)
-    bad, first = (run_fwd if mode == "fwd" else run_step)(n)
+    bad, first = {"fwd": run_fwd, "step": run_step, "task": run_task, "emd": run_emd}[mode](n)
     who = "child" if "--child" in sys.argv else ("solo" if other is None else "parent")
     print("cotenancy_stress %s %s: %d of %d deviated%s" % (mode, who, bad, n, (" -- " + first) if first else ""), flush=True)
     rc = 1 if bad else 0
