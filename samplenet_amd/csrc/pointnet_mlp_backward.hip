@@ -1395,6 +1395,159 @@ __global__ void __launch_bounds__(256) small_bwd_kernel(DgradArgs d, WgradArgs w
         small_wgrad_body<ZMODE, PMODE>(w, dW, db, tiles_n, ntiles, blockIdx.x - n_d);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Layers on a few dozen to a few hundred rows (the FC head above 32 clouds: 33 .. ~500 rows, any count -- not only multiples of 64).
+// The tile kernels treat these as small GEMMs of guarded 64 x 64 tiles walking K in dependent chunks plus a split-K weight gradient
+// with its reduction launch (at 96 rows: 24 us per data gradient, 13 + 5 us per weight gradient -- the head's backward cost 190 of
+// the step's 503 us; one row above the chain's 32 the step went from 0.19 to 0.32 ms).  Here the R <= 32 kernels run row block by
+// row block in ONE launch per layer, every operand in flight at once:
+//   data gradient    workgroup (column block, 64-row block) walks its two 32-row halves, mask / ReLU as small_dgrad_body; the
+//                    BatchNorm-backward sums of the layer below leave as ONE partial per 64 rows ([ceil(R / 64)][2][Ci]: the
+//                    layout bn_bwd_coef_kernel reduces)
+//   weight gradient  one wave per 32 x 32 tile of dW walks ALL rows in 32-row steps (K = R): no partials, no reduction launch;
+//                    the bias gradient is the ones column, as in small_wgrad_body
+// ------------------------------------------------------------------------------------------------
+template <int ZMODE, int PMODE, bool VEC>
+__device__ __forceinline__ void rows_dgrad_body(const DgradArgs &g, int bx, int rb64, float *lds)
+{
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int R = g.dz.rows, Co = g.w.co, Ci = g.w.ci;
+    const int col = bx * 32 + l31;  // ci
+    const bool colok = col < Ci;
+    const int cc = colok ? col : 0;
+    constexpr bool masked = PMODE == ACT_BN_RELU;
+    float sc = 0.f, sh = 0.f;
+    if (masked) sc = g.prev.scale[cc], sh = g.prev.shift[cc];
+    float s0 = 0.f, s1 = 0.f;
+    for (int sub = 0; sub < 2; ++sub) {
+        const int rbase = rb64 * 64 + sub * 32;
+        if (rbase >= R) break;  // (uniform)
+        float zpv[16];
+        if (masked) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + frag_row(e, lane);
+                zpv[e] = g.prev.z[(row < R && colok) ? (size_t)row * Ci + col : 0];
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int k0 = wave * 2 * KP; k0 < Co; k0 += 4 * 2 * KP) {
+            float a[KP], b[KP];
+            const int kb = k0 + h * KP;
+            if (VEC) {  // Co % 64 == 0
+                const int rr = rbase + l31 < R ? rbase + l31 : 0;
+                const float rmask = rbase + l31 < R ? 1.f : 0.f, cmask = colok ? 1.f : 0.f;
+#pragma unroll
+                for (int t = 0; t < KP; t += 4) {
+                    const float4 av = g.dz.template load_c4<true, ZMODE>(rr, kb + t);
+                    a[t] = av.x * rmask, a[t + 1] = av.y * rmask, a[t + 2] = av.z * rmask, a[t + 3] = av.w * rmask;
+                }
+#pragma unroll
+                for (int t = 0; t < KP; ++t) b[t] = g.w.w[(size_t)(kb + t) * Ci + cc] * cmask;
+            } else {
+#pragma unroll
+                for (int t = 0; t < KP; ++t) {
+                    const int k = kb + t;
+                    a[t] = g.dz.template at<ZMODE>(rbase + l31, k);
+                    const bool ok = colok && k < Co;
+                    b[t] = g.w.w[ok ? (size_t)k * Ci + col : 0] * (ok ? 1.f : 0.f);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < KP; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+        }
+        if (sub > 0) __syncthreads();  // (wave 0 has read the first half's partials)
+        wave_sum_to_wave0(acc, lds);
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = rbase + frag_row(e, lane);
+                if (row < R && colok) {
+                    float v = acc[e];
+                    if (masked) {
+                        const float zp = zpv[e];
+                        v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
+                        s0 += v;
+                        s1 += v * zp;
+                    }
+                    g.dyprev[(size_t)row * Ci + col] = v;
+                }
+            }
+        }
+    }
+    if (wave == 0 && masked && g.stats) {
+        s0 += __shfl_xor(s0, 32);
+        s1 += __shfl_xor(s1, 32);
+        if (lane < 32 && colok) {
+            float *st = g.stats + (size_t)rb64 * 2 * Ci;
+            st[col] = s0, st[Ci + col] = s1;
+        }
+    }
+}
+
+template <int ZMODE, int PMODE>
+__device__ __forceinline__ void rows_wgrad_body(const WgradArgs &g, float *__restrict__ dW, float *__restrict__ db, int tiles_n,
+                                                int ntiles, int bx)
+{
+    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+    const int tile = bx * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+    const int Co = g.dz.ch, Ci = g.prev.ch, Ce = g.ncols, R = g.dz.rows;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int rb = 0; rb < R; rb += 32) {
+        float a[16], b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int r = rb + h * 16 + t;
+            a[t] = g.dz.template at<ZMODE>(r, m0 + l31);
+            b[t] = g.prev.template at<PMODE>(r, n0 + l31);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+    }
+    if (Ce == Ci && (Ci & 31) == 0 && m0 + 32 <= Co) {  // whole tile: 16-byte stores through LDS (small_wgrad_body)
+        __shared__ float tw[4][32 * 36];
+        float *T = tw[threadIdx.x >> 6];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) T[frag_row(e, lane) * 36 + l31] = acc[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rt = 8 * i + (lane >> 3);
+            *reinterpret_cast<float4 *>(dW + (size_t)(m0 + rt) * Ci + n0 + (lane & 7) * 4) =
+                *reinterpret_cast<const float4 *>(T + rt * 36 + (lane & 7) * 4);
+        }
+        return;
+    }
+    const int col = n0 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + frag_row(e, lane);
+        if (row < Co && col < Ce) {
+            if (col < Ci)
+                dW[(size_t)row * Ci + col] = acc[e];
+            else if (db)
+                db[row] = acc[e];
+        }
+    }
+}
+
+template <int ZMODE, int PMODE, bool VEC>
+__global__ void __launch_bounds__(256) rows_bwd_kernel(DgradArgs d, WgradArgs w, float *__restrict__ dW, float *__restrict__ db,
+                                                       int tiles_n, int ntiles, int n_d, int ncb)
+{
+    __shared__ float lds[3 * 16 * 64];
+    if ((int)blockIdx.x < n_d)
+        rows_dgrad_body<ZMODE, PMODE, VEC>(d, blockIdx.x % ncb, blockIdx.x / ncb, lds);
+    else
+        rows_wgrad_body<ZMODE, PMODE>(w, dW, db, tiles_n, ntiles, blockIdx.x - n_d);
+}
+
 __global__ void __launch_bounds__(256) conv_in3_wgrad_kernel(int R, int Co, int rows_per_split, const float *__restrict__ x,
                                                              const float *__restrict__ dy, const float *__restrict__ z,
                                                              const float *__restrict__ kcoef, float *__restrict__ part)
@@ -2058,6 +2211,50 @@ extern "C" int sn_conv_backward_partials(int R, int Ci, int Co, int dz_mode, con
 
 // dgrad + wgrad of one layer.  Arguments as sn_linear_dgrad / sn_linear_wgrad (aprev == zprev: the previous layer's
 // pre-BN activations, or the raw input when coef_prev == NULL).  One launch on the fast path, else the two kernels.
+// ---- rows_bwd_kernel: one launch per layer on 33 .. 512 rows (see the kernel) ----------------------------------------------
+static bool rows_bwd_shape(int R, int dz_mode)
+{
+    // same-box sweep of the whole step (ms per step, tile kernels -> this launch): 48 rows 0.346 -> 0.290, 96 0.509 -> 0.422,
+    // 192 0.666 -> 0.618, 50 x 2048 points of configs[3] 0.842 -> 0.794; equal at 64 and 128, slower at 256 (0.716 -> 0.736: a
+    // weight-gradient wave walks all R rows -- the split-K tiles win from there).  So: every row count the tile kernels' fast path
+    // (whole 64-row blocks) does not serve, up to 512, and the multiples of 64 up to 192 except 64 itself
+    if (R <= 32 || dz_mode == DZ_POOL) return false;
+    return R % 64 != 0 ? R <= 512 : (R > 64 && R <= 192);
+}
+
+// -> the number of BatchNorm-backward partial blocks written to stats ([ceil(R / 64)][2][Ci], when coef_prev and stats)
+static int launch_rows_bwd(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef, const float *W,
+                           const float *zprev, const float *coef_prev, float *dyprev, float *stats, float *dW, float *db, hipStream_t st)
+{
+    DgradArgs g{};
+    g.dz = make_dz(dz_mode, dy, z, kcoef, nullptr, nullptr, R, Co, 1);
+    g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+    g.prev = make_act(zprev, coef_prev, R, Ci);
+    g.dyprev = dyprev, g.stats = stats;
+    WgradArgs wg{};
+    wg.dz = g.dz;
+    wg.prev = make_act(zprev, coef_prev, R, Ci, db ? Ci : -1);
+    wg.ncols = Ci + (db ? 1 : 0);
+    const int tm = (Co + 31) / 32, tn = (wg.ncols + 31) / 32, ntiles = tm * tn;
+    const int ncb = (Ci + 31) / 32, nrb = (R + 63) / 64, n_d = ncb * nrb, n_w = (ntiles + 3) / 4;
+    const dim3 grid(n_d + n_w), block(256);
+    const bool pm = coef_prev != nullptr, vec = Co % 64 == 0;
+#define SN_RB(ZM, PM)                                                                                                        \
+    do {                                                                                                                     \
+        if (vec)                                                                                                             \
+            hipLaunchKernelGGL((rows_bwd_kernel<ZM, PM, true>), grid, block, 0, st, g, wg, dW, db, tn, ntiles, n_d, ncb);     \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((rows_bwd_kernel<ZM, PM, false>), grid, block, 0, st, g, wg, dW, db, tn, ntiles, n_d, ncb);    \
+    } while (0)
+    if (dz_mode == DZ_PLAIN) {
+        if (pm) SN_RB(DZ_PLAIN, ACT_BN_RELU); else SN_RB(DZ_PLAIN, ACT_NONE);
+    } else {
+        if (pm) SN_RB(DZ_BN, ACT_BN_RELU); else SN_RB(DZ_BN, ACT_NONE);
+    }
+#undef SN_RB
+    return nrb;
+}
+
 extern "C" int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef,
                                   const float *gsel, const int *argsel, int npts, const float *W, const float *zprev,
                                   const float *coef_prev, float *dyprev, float *stats, float *part, float *dW,
@@ -2072,6 +2269,12 @@ extern "C" int sn_linear_backward(int R, int Ci, int Co, int dz_mode, const floa
                                             stats, part, (hipStream_t)stream);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((Co * Ci + 63) / 64), dim3(1024), 0, (hipStream_t)stream, G, Co, Ci, Ci,
                            part, dW, nullptr);
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rows_bwd_shape(R, dz_mode)) {
+        SN_REQUIRE((dz_mode == DZ_PLAIN || z) && dy, "null pointer");
+        launch_rows_bwd(R, Ci, Co, dz_mode, dy, z, kcoef, W, zprev, coef_prev, dyprev, stats, dW, nullptr, (hipStream_t)stream);
         SN_LAUNCH_CHECK();
         return 0;
     }
@@ -2173,6 +2376,13 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
         const int nred = (Co * Ci) % 4 == 0 ? (Co * Ci + kRedElems - 1) / kRedElems : (Co * Ci + 63) / 64;
         hipLaunchKernelGGL(post_bwd_kernel, dim3(nred + (Ci + kChan - 1) / kChan), dim3(1024), 0, st, nred, G, Co, Ci, part, dW,
                            G, Ci, stats, bb);
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rows_bwd_shape(R, dz_mode)) {
+        SN_REQUIRE((dz_mode == DZ_PLAIN || z) && dy, "null pointer");
+        const int nb = launch_rows_bwd(R, Ci, Co, dz_mode, dy, z, kcoef, W, zprev, coef_prev, dyprev, stats, dW, db, st);
+        if (coef_prev) hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Ci + kChan - 1) / kChan), dim3(1024), 0, st, nb, Ci, stats, bb);
         SN_LAUNCH_CHECK();
         return 0;
     }

@@ -185,6 +185,49 @@ def test_row_tiled_layer_forward_exact_small_integers(R, Ci, Co, act):
     assert bool((Z[R] == -7.0).all())
 
 
+@pytest.mark.parametrize("R,Ci,Co", [(50, 256, 256), (33, 128, 256), (96, 256, 192), (100, 256, 256), (192, 256, 256), (500, 128, 64),
+                                      (70, 40, 72)])
+@pytest.mark.parametrize("bn", [False, True])
+def test_row_blocked_layer_backward_exact_small_integers(R, Ci, Co, bn):
+    """A layer's backward on 33 .. 512 rows that are not whole 64-row blocks (and the small multiples of 64): ONE launch of the
+    R <= 32 kernels row block by row block (rows_bwd_kernel) instead of guarded tiles + split-K partials + a reduction launch.
+    Small-integer operands make everything exact: data gradient with the ReLU mask of the layer below, weight gradient over ALL rows,
+    the BatchNorm-backward sums as one partial per 64 rows -- bit for bit against the integer reference; dZ = k1 dY + k2 Z + k3 with
+    power-of-two coefficients in the bn case."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    g = torch.Generator(device="cuda").manual_seed(R + Ci + Co)
+    st = torch.cuda.current_stream().cuda_stream
+    ri = lambda lo, hi, *shape: torch.randint(lo, hi, shape, device="cuda", generator=g).float()  # noqa: E731
+    dy, W, zprev = ri(-3, 4, R, Co), ri(-4, 5, Co, Ci), ri(-4, 5, R, Ci)
+    sc = torch.tensor([1.0, 2.0, -1.0], device="cuda")[torch.randint(0, 3, (Ci,), device="cuda", generator=g)]
+    sh = ri(-2, 3, Ci)
+    coefp = torch.stack([sc, sh, torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda")]).contiguous()
+    z = kc = None
+    dz = dy.double()
+    if bn:
+        z = ri(-3, 4, R, Co)
+        kc = torch.stack([torch.tensor([1.0, 2.0, 0.5], device="cuda")[torch.randint(0, 3, (Co,), device="cuda", generator=g)],
+                          torch.tensor([0.0, 1.0, -0.5], device="cuda")[torch.randint(0, 3, (Co,), device="cuda", generator=g)],
+                          ri(-2, 3, Co)]).contiguous()
+        dz = kc[0].double() * dy.double() + kc[1].double() * z.double() + kc[2].double()
+    nblk = (R + 63) // 64
+    dyprev = torch.full((R + 1, Ci), -7.0, device="cuda")
+    stats = torch.full((lib.sn_linear_stats_blocks(R) + 1, 2, Ci), -7.0, device="cuda")
+    nsplit = lib.sn_linear_wgrad_splits(R, Ci, Co, 0)
+    part = torch.empty(nsplit * Co * Ci, device="cuda")
+    dW = torch.full((Co + 1, Ci), -7.0, device="cuda")
+    check(lib.sn_linear_backward(R, Ci, Co, 1 if bn else 0, ptr(dy), ptr(z), ptr(kc), None, None, 1, ptr(W), ptr(zprev), ptr(coefp),
+                                 ptr(dyprev), ptr(stats), ptr(part), ptr(dW), st))
+    act = zprev.double() * sc.double() + sh.double()
+    ref_dy = (dz @ W.double()) * (act > 0)
+    assert torch.equal(dyprev[:R].double(), ref_dy) and bool((dyprev[R] == -7.0).all())
+    assert torch.equal(dW[:Co].double(), dz.t() @ torch.relu(act)) and bool((dW[Co] == -7.0).all())
+    s = stats[:nblk].double().sum(0)
+    assert torch.equal(s[0], ref_dy.sum(0)) and torch.equal(s[1], (ref_dy * zprev.double()).sum(0))
+    assert bool((stats[nblk:] == -7.0).all())  # exactly ceil(R / 64) partial blocks
+
+
 @pytest.mark.parametrize("R,Ci,Co", [(4096, 128, 128), (2048, 64, 128), (1024, 64, 64)])
 def test_split_bf16_products_are_fp32_accurate(R, Ci, Co):
     """The conv-layer GEMMs run on the bf16 matrix cores with every fp32 operand split into three bf16 terms and six
