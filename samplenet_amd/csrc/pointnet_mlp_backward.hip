@@ -1410,6 +1410,8 @@ __global__ void __launch_bounds__(256) small_bwd_kernel(DgradArgs d, WgradArgs w
 template <int ZMODE, int PMODE, bool VEC>
 __device__ __forceinline__ void rows_dgrad_body(const DgradArgs &g, int bx, int rb64, float *lds)
 {
+    // both 32-row halves of the 64-row block in ONE pass: the weight operand is fetched once and feeds two accumulators (walking
+    // the halves one after the other doubled the launch's dependent latency: 14.3 us per 256 x 256 layer at 48 rows)
     const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int R = g.dz.rows, Co = g.w.co, Ci = g.w.ci;
@@ -1419,66 +1421,79 @@ __device__ __forceinline__ void rows_dgrad_body(const DgradArgs &g, int bx, int 
     constexpr bool masked = PMODE == ACT_BN_RELU;
     float sc = 0.f, sh = 0.f;
     if (masked) sc = g.prev.scale[cc], sh = g.prev.shift[cc];
-    float s0 = 0.f, s1 = 0.f;
-    for (int sub = 0; sub < 2; ++sub) {
-        const int rbase = rb64 * 64 + sub * 32;
-        if (rbase >= R) break;  // (uniform)
-        float zpv[16];
-        if (masked) {
+    const int rbase = rb64 * 64;
+    const bool two = rbase + 32 < R;  // (uniform)
+    float zpv[2][16];
+    if (masked) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = rbase + frag_row(e, lane);
-                zpv[e] = g.prev.z[(row < R && colok) ? (size_t)row * Ci + col : 0];
+                const int row = rbase + 32 * s2 + frag_row(e, lane);
+                zpv[s2][e] = g.prev.z[(row < R && colok) ? (size_t)row * Ci + col : 0];
             }
-        }
-        f32x16 acc;
+    }
+    f32x16 acc[2];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        for (int k0 = wave * 2 * KP; k0 < Co; k0 += 4 * 2 * KP) {
-            float a[KP], b[KP];
-            const int kb = k0 + h * KP;
-            if (VEC) {  // Co % 64 == 0
-                const int rr = rbase + l31 < R ? rbase + l31 : 0;
-                const float rmask = rbase + l31 < R ? 1.f : 0.f, cmask = colok ? 1.f : 0.f;
+    for (int e = 0; e < 16; ++e) acc[0][e] = 0.f, acc[1][e] = 0.f;
+    for (int k0 = wave * 2 * KP; k0 < Co; k0 += 4 * 2 * KP) {
+        float a[2][KP], b[KP];
+        const int kb = k0 + h * KP;
+        if (VEC) {  // Co % 64 == 0
+            const float cmask = colok ? 1.f : 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int r = rbase + 32 * s2 + l31;
+                const int rr = r < R ? r : 0;
+                const float rmask = r < R ? 1.f : 0.f;
 #pragma unroll
                 for (int t = 0; t < KP; t += 4) {
                     const float4 av = g.dz.template load_c4<true, ZMODE>(rr, kb + t);
-                    a[t] = av.x * rmask, a[t + 1] = av.y * rmask, a[t + 2] = av.z * rmask, a[t + 3] = av.w * rmask;
-                }
-#pragma unroll
-                for (int t = 0; t < KP; ++t) b[t] = g.w.w[(size_t)(kb + t) * Ci + cc] * cmask;
-            } else {
-#pragma unroll
-                for (int t = 0; t < KP; ++t) {
-                    const int k = kb + t;
-                    a[t] = g.dz.template at<ZMODE>(rbase + l31, k);
-                    const bool ok = colok && k < Co;
-                    b[t] = g.w.w[ok ? (size_t)k * Ci + col : 0] * (ok ? 1.f : 0.f);
+                    a[s2][t] = av.x * rmask, a[s2][t + 1] = av.y * rmask, a[s2][t + 2] = av.z * rmask, a[s2][t + 3] = av.w * rmask;
                 }
             }
 #pragma unroll
-            for (int t = 0; t < KP; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
-        }
-        if (sub > 0) __syncthreads();  // (wave 0 has read the first half's partials)
-        wave_sum_to_wave0(acc, lds);
-        if (wave == 0) {
+            for (int t = 0; t < KP; ++t) b[t] = g.w.w[(size_t)(kb + t) * Ci + cc] * cmask;
+        } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = rbase + frag_row(e, lane);
-                if (row < R && colok) {
-                    float v = acc[e];
-                    if (masked) {
-                        const float zp = zpv[e];
-                        v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
-                        s0 += v;
-                        s1 += v * zp;
-                    }
-                    g.dyprev[(size_t)row * Ci + col] = v;
+            for (int t = 0; t < KP; ++t) {
+                const int k = kb + t;
+                a[0][t] = g.dz.template at<ZMODE>(rbase + l31, k);
+                a[1][t] = g.dz.template at<ZMODE>(rbase + 32 + l31, k);
+                const bool ok = colok && k < Co;
+                b[t] = g.w.w[ok ? (size_t)k * Ci + col : 0] * (ok ? 1.f : 0.f);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < KP; ++t) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][t], b[t], acc[0], 0, 0, 0);
+        if (two) {
+#pragma unroll
+            for (int t = 0; t < KP; ++t) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][t], b[t], acc[1], 0, 0, 0);
+        }
+    }
+    wave_sum_to_wave0(acc[0], lds);
+    if (two) wave_sum_to_wave0(acc[1], lds + 3 * 16 * 64);
+    if (wave != 0) return;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 == 1 && !two) break;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = rbase + 32 * s2 + frag_row(e, lane);
+            if (row < R && colok) {
+                float v = acc[s2][e];
+                if (masked) {
+                    const float zp = zpv[s2][e];
+                    v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
+                    s0 += v;
+                    s1 += v * zp;
                 }
+                g.dyprev[(size_t)row * Ci + col] = v;
             }
         }
     }
-    if (wave == 0 && masked && g.stats) {
+    if (masked && g.stats) {
         s0 += __shfl_xor(s0, 32);
         s1 += __shfl_xor(s1, 32);
         if (lane < 32 && colok) {
@@ -1541,7 +1556,7 @@ template <int ZMODE, int PMODE, bool VEC>
 __global__ void __launch_bounds__(256) rows_bwd_kernel(DgradArgs d, WgradArgs w, float *__restrict__ dW, float *__restrict__ db,
                                                        int tiles_n, int ntiles, int n_d, int ncb)
 {
-    __shared__ float lds[3 * 16 * 64];
+    __shared__ float lds[2 * 3 * 16 * 64];
     if ((int)blockIdx.x < n_d)
         rows_dgrad_body<ZMODE, PMODE, VEC>(d, blockIdx.x % ncb, blockIdx.x / ncb, lds);
     else
@@ -2214,9 +2229,9 @@ extern "C" int sn_conv_backward_partials(int R, int Ci, int Co, int dz_mode, con
 // ---- rows_bwd_kernel: one launch per layer on 33 .. 512 rows (see the kernel) ----------------------------------------------
 static bool rows_bwd_shape(int R, int dz_mode)
 {
-    // same-box sweep of the whole step (ms per step, tile kernels -> this launch): 48 rows 0.346 -> 0.290, 96 0.509 -> 0.422,
-    // 192 0.666 -> 0.618, 50 x 2048 points of configs[3] 0.842 -> 0.794; equal at 64 and 128, slower at 256 (0.716 -> 0.736: a
-    // weight-gradient wave walks all R rows -- the split-K tiles win from there).  So: every row count the tile kernels' fast path
+    // same-box sweep of the whole step (ms per step, tile kernels -> this launch): 48 rows 0.346 -> 0.284, 96 0.509 -> 0.405,
+    // 128 0.470 -> 0.450, 192 0.666 -> 0.594, 50 x 2048 points of configs[3] 0.842 -> 0.774; equal at 64 and 320, slower at 256 /
+    // 384 / 512 (0.710 -> 0.737 at 256: a weight-gradient wave walks all R rows -- the split-K tiles win from there).  So: every row count the tile kernels' fast path
     // (whole 64-row blocks) does not serve, up to 512, and the multiples of 64 up to 192 except 64 itself
     if (R <= 32 || dz_mode == DZ_POOL) return false;
     return R % 64 != 0 ? R <= 512 : (R > 64 && R <= 192);
