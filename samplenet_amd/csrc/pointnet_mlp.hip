@@ -849,6 +849,143 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
     SN_TL(5);
 }
 
+// 33 .. 64 rows (the FC head just above the chain's 32 clouds): small_fwd_lds_kernel with BOTH 32-row halves in one workgroup --
+// the weight slice is staged once and feeds two accumulators, and the workgroup holds every row of its 32 columns, so the
+// BatchNorm finalisation (two-pass variance in registers, as there) stays in the epilogue: no statistics launch behind the GEMM
+// (4.9 us per layer; the step costs 0.19 ms at 32 clouds and this range is where a batch of 48 or 64 lands).  Ci % 64 == 0, <= 256.
+template <int AMODE>
+__global__ void __launch_bounds__(256) rows64_fwd_kernel(FwdArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = g.a.rows, Co = g.w.co, Ci = g.w.ci;
+    const int LD = Ci + 4;
+    float *As = sm, *Ws = sm + 64 * LD, *red = Ws + 32 * LD, *Ts = red + 2 * 3 * 16 * 64;
+    const int col0 = blockIdx.x * 32;
+    const int col = col0 + l31;
+    const bool colok = col < Co;
+    const int ccol = colok ? col : 0;
+    const float bias = g.bias ? g.bias[ccol] : 0.f;
+    float bn_g = 0.f, bn_b = 0.f, bn_rm = 0.f, bn_rv = 0.f;
+    if (g.bn.coef) {
+        bn_g = g.bn.gamma[ccol], bn_b = g.bn.beta[ccol];
+        if (g.bn.running_mean) bn_rm = g.bn.running_mean[ccol], bn_rv = g.bn.running_var[ccol];
+    }
+    const int q4 = Ci / 4, rpp = 256 / q4, npa = 64 / rpp, npw = 32 / rpp;  // Ci = 256: 64, 4, 16, 8
+    const int c4 = (tid % q4) * 4, r0 = tid / q4;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (AMODE == ACT_BN_RELU) {
+        sc4 = *reinterpret_cast<const float4 *>(g.a.scale + c4);
+        sh4 = *reinterpret_cast<const float4 *>(g.a.shift + c4);
+    }
+    constexpr int MAXA = 16, MAXW = 8;  // Ci >= 64
+    float4 av[MAXA], wv[MAXW];
+#pragma unroll
+    for (int q = 0; q < MAXA; ++q)
+        if (q < npa) av[q] = *reinterpret_cast<const float4 *>(g.a.z + (size_t)min(r0 + q * rpp, R - 1) * Ci + c4);
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q)
+        if (q < npw) wv[q] = *reinterpret_cast<const float4 *>(g.w.w + (size_t)min(col0 + r0 + q * rpp, Co - 1) * Ci + c4);
+#pragma unroll
+    for (int q = 0; q < MAXA; ++q)
+        if (q < npa) {
+            const int r = r0 + q * rpp;
+            float4 a = av[q];
+            if (AMODE == ACT_BN_RELU) {
+                a.x = relu_np(fmaf(a.x, sc4.x, sh4.x)), a.y = relu_np(fmaf(a.y, sc4.y, sh4.y));
+                a.z = relu_np(fmaf(a.z, sc4.z, sh4.z)), a.w = relu_np(fmaf(a.w, sc4.w, sh4.w));
+            }
+            const float ma = r < R ? 1.f : 0.f;
+            a.x *= ma, a.y *= ma, a.z *= ma, a.w *= ma;
+            *reinterpret_cast<float4 *>(As + r * LD + c4) = a;
+        }
+#pragma unroll
+    for (int q = 0; q < MAXW; ++q)
+        if (q < npw) {
+            const int r = r0 + q * rpp;
+            float4 w = wv[q];
+            const float mw = col0 + r < Co ? 1.f : 0.f;
+            w.x *= mw, w.y *= mw, w.z *= mw, w.w *= mw;
+            *reinterpret_cast<float4 *>(Ws + r * LD + c4) = w;
+        }
+    __syncthreads();
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc0[e] = 0.f, acc1[e] = 0.f;
+    const int kph = Ci / 8, kb = wave * (Ci / 4) + h * kph;
+    const float *ap0 = As + l31 * LD + kb, *ap1 = As + (32 + l31) * LD + kb, *bp = Ws + l31 * LD + kb;
+    for (int t = 0; t < kph; t += 4) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(ap0 + t), a1 = *reinterpret_cast<const float4 *>(ap1 + t);
+        const float4 b = *reinterpret_cast<const float4 *>(bp + t);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+    }
+    wave_sum_to_wave0(acc0, red);
+    wave_sum_to_wave0(acc1, red + 3 * 16 * 64);
+    if (wave != 0) return;
+    float s0 = 0.f;
+    const bool vec_out = Co % 32 == 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = 32 * s2 + frag_row(e, lane);
+            const float v = (s2 ? acc1[e] : acc0[e]) + bias;
+            if (row < R && colok) {
+                s0 += v;
+                if (!vec_out) g.z[(size_t)row * Co + col] = v;
+            }
+            Ts[row * 36 + l31] = v;
+        }
+    if (vec_out) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + (lane >> 3);
+            const float4 v = *reinterpret_cast<const float4 *>(Ts + row * 36 + (lane & 7) * 4);
+            if (row < R) *reinterpret_cast<float4 *>(g.z + (size_t)row * Co + col0 + (lane & 7) * 4) = v;
+        }
+    }
+    s0 += __shfl_xor(s0, 32);
+    if (g.bn.coef) {  // every row of these 32 columns is here: two-pass variance around the mean (see small_fwd_lds_kernel)
+        if (blockIdx.x == 0 && lane == 0 && g.bn.num_batches_tracked) *g.bn.num_batches_tracked += 1;
+        const float meanf = s0 / (float)g.bn.R;
+        float s2v = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = ((s2 ? acc1[e] : acc0[e]) + bias) - meanf;
+                if (32 * s2 + frag_row(e, lane) < R && colok) s2v += d * d;
+            }
+        s2v += __shfl_xor(s2v, 32);
+        if (lane < 32 && colok) {
+            const double rR = fast_rcp((double)g.bn.R);
+            const double mean = (double)s0 * rR;
+            const double dm = mean - (double)meanf;
+            double var = (double)s2v * rR - dm * dm;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)fast_rsqrt(var + (double)g.bn.eps);
+            const float sc = bn_g * invstd;
+            g.bn.coef[col] = sc;
+            g.bn.coef[Co + col] = bn_b - (float)mean * sc;
+            g.bn.coef[2 * Co + col] = (float)mean;
+            g.bn.coef[3 * Co + col] = invstd;
+            if (g.bn.running_mean) {
+                const double unbiased = g.bn.R > 1 ? var * (double)g.bn.R * fast_rcp((double)(g.bn.R - 1)) : var;
+                g.bn.running_mean[col] = (1.f - g.bn.momentum) * bn_rm + g.bn.momentum * (float)mean;
+                g.bn.running_var[col] = (1.f - g.bn.momentum) * bn_rv + g.bn.momentum * (float)unbiased;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // First layer (Ci = 3: the xyz input).  K = 3 is no GEMM: z = w0 x + w1 y + w2 z + b is a streaming kernel bound by
 // the 256 B/row it writes; the matrix-core path would spend 95 % of its tile on zero padding.
@@ -1398,6 +1535,25 @@ extern "C" int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, cons
     g.bias = bias, g.z = z, g.stats = stats;
     const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
     hipStream_t st = (hipStream_t)stream;
+    if (R > 32 && R <= 64 && Ci % 64 == 0 && Ci <= 256) {  // both halves in one workgroup, BatchNorm finalised in the epilogue
+        g.bn = bn;
+        g.stats = nullptr;
+        const size_t lds = ((size_t)96 * (Ci + 4) + 2 * 3 * 16 * 64 + 64 * 36) * sizeof(float);
+        static bool attr_done[2] = {false, false};
+        const int ai = coef_prev ? 1 : 0;
+        if (!attr_done[ai]) {
+            const int mx = (int)(((size_t)96 * 260 + 2 * 3 * 16 * 64 + 64 * 36) * sizeof(float));
+            if (coef_prev) (void)hipFuncSetAttribute((const void *)rows64_fwd_kernel<ACT_BN_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            else (void)hipFuncSetAttribute((const void *)rows64_fwd_kernel<ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            attr_done[ai] = true;
+        }
+        if (coef_prev)
+            hipLaunchKernelGGL((rows64_fwd_kernel<ACT_BN_RELU>), dim3((Co + 31) / 32), dim3(256), lds, st, g);
+        else
+            hipLaunchKernelGGL((rows64_fwd_kernel<ACT_NONE>), dim3((Co + 31) / 32), dim3(256), lds, st, g);
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
     if (R <= 32) {
         g.bn = bn;
         g.stats = nullptr;

@@ -1419,8 +1419,13 @@ __device__ __forceinline__ void rows_dgrad_body(const DgradArgs &g, int bx, int 
     const bool colok = col < Ci;
     const int cc = colok ? col : 0;
     constexpr bool masked = PMODE == ACT_BN_RELU;
-    float sc = 0.f, sh = 0.f;
-    if (masked) sc = g.prev.scale[cc], sh = g.prev.shift[cc];
+    float sc = 0.f, sh = 0.f, pmean = 0.f, pinv = 0.f;
+    if (masked) {
+        sc = g.prev.scale[cc], sh = g.prev.shift[cc];
+        // (R <= 64: the one 64-row block holds every row -- the host then asks for the BatchNorm-backward coefficients of the layer
+        //  below right here, as small_dgrad_body delivers them, instead of a partial + a launch of its own)
+        if (g.bb.coef) pmean = g.bb.coef[2 * Ci + cc], pinv = g.bb.coef[3 * Ci + cc];
+    }
     const int rbase = rb64 * 64;
     const bool two = rbase + 32 < R;  // (uniform)
     float zpv[2][16];
@@ -1474,7 +1479,7 @@ __device__ __forceinline__ void rows_dgrad_body(const DgradArgs &g, int bx, int 
     wave_sum_to_wave0(acc[0], lds);
     if (two) wave_sum_to_wave0(acc[1], lds + 3 * 16 * 64);
     if (wave != 0) return;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s1c = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         if (s2 == 1 && !two) break;
@@ -1488,18 +1493,31 @@ __device__ __forceinline__ void rows_dgrad_body(const DgradArgs &g, int bx, int 
                     v = (fmaf(zp, sc, sh) > 0.f) ? v : 0.f;
                     s0 += v;
                     s1 += v * zp;
+                    s1c += v * (zp - pmean);  // (centred, as small_dgrad_body)
                 }
                 g.dyprev[(size_t)row * Ci + col] = v;
             }
         }
     }
-    if (masked && g.stats) {
-        s0 += __shfl_xor(s0, 32);
-        s1 += __shfl_xor(s1, 32);
-        if (lane < 32 && colok) {
-            float *st = g.stats + (size_t)rb64 * 2 * Ci;
-            st[col] = s0, st[Ci + col] = s1;
-        }
+    if (!masked) return;
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    s1c += __shfl_xor(s1c, 32);
+    if (g.stats && lane < 32 && colok) {
+        float *st = g.stats + (size_t)rb64 * 2 * Ci;
+        st[col] = s0, st[Ci + col] = s1;
+    }
+    if (g.bb.coef && lane < 32 && colok) {  // bn_backward_channel on the prefetched mean / invstd (small_dgrad_body's epilogue)
+        const double scale = sc, mean = pmean, invstd = pinv, s = s0;
+        const double dg = invstd * (double)s1c;
+        g.bb.dgamma[col] = (float)dg;
+        g.bb.dbeta[col] = (float)s;
+        const double rinv = g.bb.R > 0 ? fast_rcp((double)g.bb.R) : 0.0;
+        const float k1 = (float)scale, k2 = (float)(-scale * invstd * dg * rinv);
+        const float k3 = (float)(scale * (invstd * mean * dg * rinv - s * rinv));
+        g.bb.kcoef[col] = k1, g.bb.kcoef[Ci + col] = k2, g.bb.kcoef[2 * Ci + col] = k3;
+        if (g.bb.dbias)
+            g.bb.dbias[col] = (float)((double)k1 * s + (double)k2 * (double)g.bb.R * mean + (double)g.bb.R * (double)k3);
     }
 }
 
@@ -2232,16 +2250,19 @@ static bool rows_bwd_shape(int R, int dz_mode)
     // same-box sweep of the whole step (ms per step, tile kernels -> this launch): 48 rows 0.346 -> 0.284, 96 0.509 -> 0.405,
     // 128 0.470 -> 0.450, 192 0.666 -> 0.594, 50 x 2048 points of configs[3] 0.842 -> 0.774; equal at 64 and 320, slower at 256 /
     // 384 / 512 (0.710 -> 0.737 at 256: a weight-gradient wave walks all R rows -- the split-K tiles win from there).  So: every row count the tile kernels' fast path
-    // (whole 64-row blocks) does not serve, up to 512, and the multiples of 64 up to 192 except 64 itself
+    // (whole 64-row blocks) does not serve, up to 512, and the multiples of 64 up to 192 (at 64 rows and below the launch also
+    // delivers the BatchNorm-backward coefficients of the layer below: one launch per layer)
     if (R <= 32 || dz_mode == DZ_POOL) return false;
-    return R % 64 != 0 ? R <= 512 : (R > 64 && R <= 192);
+    return R % 64 != 0 ? R <= 512 : R <= 192;
 }
 
 // -> the number of BatchNorm-backward partial blocks written to stats ([ceil(R / 64)][2][Ci], when coef_prev and stats)
 static int launch_rows_bwd(int R, int Ci, int Co, int dz_mode, const float *dy, const float *z, const float *kcoef, const float *W,
-                           const float *zprev, const float *coef_prev, float *dyprev, float *stats, float *dW, float *db, hipStream_t st)
+                           const float *zprev, const float *coef_prev, float *dyprev, float *stats, float *dW, float *db, hipStream_t st,
+                           const BnBwd *finalize = nullptr)
 {
     DgradArgs g{};
+    if (finalize) g.bb = *finalize;  // (R <= 64 only: one row block holds every row)
     g.dz = make_dz(dz_mode, dy, z, kcoef, nullptr, nullptr, R, Co, 1);
     g.w.w = W, g.w.co = Co, g.w.ci = Ci;
     g.prev = make_act(zprev, coef_prev, R, Ci);
@@ -2396,8 +2417,11 @@ extern "C" int sn_layer_backward(int R, int Ci, int Co, int dz_mode, const float
     }
     if (rows_bwd_shape(R, dz_mode)) {
         SN_REQUIRE((dz_mode == DZ_PLAIN || z) && dy, "null pointer");
-        const int nb = launch_rows_bwd(R, Ci, Co, dz_mode, dy, z, kcoef, W, zprev, coef_prev, dyprev, stats, dW, db, st);
-        if (coef_prev) hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Ci + kChan - 1) / kChan), dim3(1024), 0, st, nb, Ci, stats, bb);
+        const bool fin = coef_prev && R <= 64;  // the BatchNorm-backward coefficients of the layer below inside the launch
+        const int nb = launch_rows_bwd(R, Ci, Co, dz_mode, dy, z, kcoef, W, zprev, coef_prev, dyprev, fin ? nullptr : stats, dW, db, st,
+                                       fin ? &bb : nullptr);
+        if (coef_prev && !fin)
+            hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((Ci + kChan - 1) / kChan), dim3(1024), 0, st, nb, Ci, stats, bb);
         SN_LAUNCH_CHECK();
         return 0;
     }

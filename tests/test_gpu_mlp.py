@@ -185,6 +185,44 @@ def test_row_tiled_layer_forward_exact_small_integers(R, Ci, Co, act):
     assert bool((Z[R] == -7.0).all())
 
 
+@pytest.mark.parametrize("R,Ci,Co", [(50, 256, 256), (33, 128, 256), (64, 256, 192), (40, 64, 250)])
+@pytest.mark.parametrize("act", [False, True])
+def test_layer_forward_with_batchnorm_on_33_to_64_rows(R, Ci, Co, act):
+    """sn_layer_forward_bn on 33 .. 64 rows: both 32-row halves in one workgroup, the BatchNorm finalised in the epilogue (two-pass
+    variance over all rows in registers) -- no statistics launch.  Integer operands: Z exact; coefficients and running statistics
+    against a float64 evaluation of torch.nn.BatchNorm1d's training-mode formulas (1e-6 relative)."""
+    from samplenet_amd._lib import check, lib, ptr
+
+    g = torch.Generator(device="cuda").manual_seed(R * 7 + Ci + Co)
+    st = torch.cuda.current_stream().cuda_stream
+    ri = lambda lo, hi, *shape: torch.randint(lo, hi, shape, device="cuda", generator=g).float()  # noqa: E731
+    A, W, b = ri(-4, 5, R, Ci), ri(-4, 5, Co, Ci), ri(-4, 5, Co)
+    coefp, Ain = None, A.double()
+    if act:
+        sc = torch.tensor([1.0, 2.0, -1.0], device="cuda")[torch.randint(0, 3, (Ci,), device="cuda", generator=g)]
+        sh = ri(-2, 3, Ci)
+        coefp = torch.stack([sc, sh, torch.zeros(Ci, device="cuda"), torch.ones(Ci, device="cuda")]).contiguous()
+        Ain = torch.relu(A.double() * sc.double() + sh.double())
+    gamma, beta = torch.rand(Co, device="cuda", generator=g) + 0.5, torch.randn(Co, device="cuda", generator=g)
+    rm, rv = torch.randn(Co, device="cuda", generator=g), torch.rand(Co, device="cuda", generator=g) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    Z = torch.full((R + 1, Co), -7.0, device="cuda")
+    coef = torch.empty(4, Co, device="cuda")
+    stats = torch.empty(lib.sn_linear_stats_blocks(R), 2, Co, device="cuda")
+    eps, mom = 1e-5, 0.1
+    check(lib.sn_layer_forward_bn(R, Ci, Co, ptr(A), ptr(coefp), ptr(W), ptr(b), ptr(Z), ptr(stats), ptr(gamma), ptr(beta), eps, mom,
+                                  ptr(rm), ptr(rv), ptr(nbt), ptr(coef), st))
+    Zr = Ain @ W.double().t() + b.double()
+    assert torch.equal(Z[:R].double(), Zr) and bool((Z[R] == -7.0).all()) and int(nbt) == 1
+    mean, var = Zr.mean(0), Zr.var(0, unbiased=False)
+    invstd = (var + eps).rsqrt()
+    ref = torch.stack([gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd, mean, invstd])
+    assert float((coef.double() - ref).abs().max() / ref.abs().max()) <= 1e-6
+    assert torch.allclose(rm.double(), 0.9 * rm0.double() + 0.1 * mean, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(rv.double(), 0.9 * rv0.double() + 0.1 * Zr.var(0, unbiased=True), rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("R,Ci,Co", [(50, 256, 256), (33, 128, 256), (96, 256, 192), (100, 256, 256), (192, 256, 256), (500, 128, 64),
                                       (70, 40, 72)])
 @pytest.mark.parametrize("bn", [False, True])
