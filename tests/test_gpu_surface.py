@@ -402,3 +402,22 @@ def test_dropped_plans_are_released_and_configurations_are_capped():
     _clear(a)
     r1 = _script_step(a, x)  # the survivor still replays
     assert torch.isfinite(r1[0]).all()
+
+
+@pytest.mark.parametrize("batch", [48, 64, 100])
+def test_captured_surface_above_32_clouds_matches_the_eager_launches(batch):
+    """The captured surface is not tied to the reference batch: above 32 clouds the head runs layer by layer (row-blocked kernels,
+    no chain) inside the same two graphs -- same launches as the eager single-node step, bit for bit, at batches that are not whole
+    64-row blocks too."""
+    a, b = _nets(31 + batch)
+    g = torch.Generator(device="cuda").manual_seed(batch)
+    xs = [torch.rand(batch, N, 3, device="cuda", generator=g) - 0.5 for _ in range(4)]
+    _warm(a, b, xs[:2])
+    for x in xs[2:]:
+        _clear(a), _clear(b)
+        ra, rb = _script_step(a, x), _launches_step(b, x)
+        assert _plan(a) is not None
+        _outputs_match(ra, rb)
+        bad = _grad_mismatch(a, b)
+        assert not bad, bad
+    _same_buffers(a, b)
