@@ -68,8 +68,11 @@ def _check_against_reference(g, tag, oracle, x, y_bcn, proj_bmc, loss, lsimp, gr
     print("[%s] loss %.9f  ref fp32 %.9f  fp64 %.9f" % (tag, float(loss), float(g[f"{tag}_loss"]), float(g[f"{tag}_loss_f64"])))
     if lsimp is not None:
         print("[%s] lsimp %.8f  ref fp32 %.8f  fp64 %.8f" % (tag, float(lsimp), float(g[f"{tag}_lsimp"]), float(g[f"{tag}_lsimp_f64"])))
-    # measured 2.0e-5 / 1.3e-5: the HIP head is as close to exact arithmetic as the reference's own fp32 (MKL) run
-    assert e_simp32 <= 5e-5 and e_simp64 <= 2 * ref_err + 5e-6
+    # measured 2.0-2.6e-5 / 1.36-1.61e-5 over the three fixtures and four routes: the HIP head is as close to exact arithmetic as
+    # the reference's own fp32 (MKL) run is (1.5e-5) -- north_star's 1e-5 sits below the distance between two correct fp32
+    # evaluations of this head, so the bars are: within 10 % of the reference's own error against the fp64 run, and within the sum
+    # of the two fp32 errors of the reference's fp32 run
+    assert e_simp32 <= 3e-5 and e_simp64 <= 1.1 * ref_err + 1e-6
     # discrete selections of the geometry (kNN sets, both Chamfer argmins, the arg-max of the max term) on OUR simplified cloud
     # vs on the reference's: a 1e-5 shift of a query flips a handful of near-ties; each flip re-routes a gradient contribution
     # (the max term carries 1/B of the loss on ONE point), which is what bounds the gradient agreement below
@@ -253,7 +256,7 @@ def test_task_step_matches_reference_run(golden, path):
     (tests/golden/samplenet_task_reference.npz: reference SampleNet + reference PCRNet + reference Chamfer, fp32 and fp64):
         L = Chamfer(proj, rotate(p0 by PCRNet(p0, proj))) + 0.01 * L_simp + 0.01 * L_proj
     through engine.SamplerTrainStep(task_loss=...) -- the fused single-node step with the task loss outside the node, captured
-    and eager, and the op-by-op general path.  Bars as the headline test: loss 1e-5 (north_star), simplified cloud 5e-5, every
+    and eager, and the op-by-op general path.  Bars as the headline test: loss 1e-5 (north_star), simplified cloud 3e-5, every
     sampler gradient relative to its norm against the reference's fp32 run (3e-3) and no further from the fp64 run than
     4 x the reference's own fp32 error (or the same fixed bar)."""
     from samplenet_amd.engine import SamplerTrainStep
@@ -278,7 +281,7 @@ def test_task_step_matches_reference_run(golden, path):
 def _check_task_step(g, path, loss, simp, proj, net):
     e_simp = float((simp.cpu() - torch.from_numpy(g["simp"])).abs().max())
     print("\n[%s] loss %.9f  ref fp32 %.9f  fp64 %.9f   simp max|d| %.2e" % (path, float(loss), float(g["loss"]), float(g["loss_f64"]), e_simp))
-    assert e_simp <= 5e-5
+    assert e_simp <= 3e-5
     assert abs(float(loss) - float(g["loss"])) <= 1e-5 and abs(float(loss) - float(g["loss_f64"])) <= 1e-5
     close = np.isclose(proj.cpu().numpy(), g["proj"], rtol=0, atol=1e-4)
     assert close.mean() >= 0.995, close.mean()
