@@ -852,7 +852,8 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
 // 33 .. 64 rows (the FC head just above the chain's 32 clouds): small_fwd_lds_kernel with BOTH 32-row halves in one workgroup --
 // the weight slice is staged once and feeds two accumulators, and the workgroup holds every row of its 32 columns, so the
 // BatchNorm finalisation (two-pass variance in registers, as there) stays in the epilogue: no statistics launch behind the GEMM
-// (4.9 us per layer; the step costs 0.19 ms at 32 clouds and this range is where a batch of 48 or 64 lands).  Ci % 64 == 0, <= 256.
+// (4.9 us per layer; the step costs 0.19 ms at 32 clouds and this range is where a batch of 48 or 64 lands).  Ci = 64, 128 or 256
+// (Ci / 4 threads stage a row: must divide 256).
 template <int AMODE>
 __global__ void __launch_bounds__(256) rows64_fwd_kernel(FwdArgs g)
 {
@@ -1405,11 +1406,14 @@ static void launch_fwd(const FwdArgs &g, hipStream_t st, bool few_rows = false)
     // (R / 32) x (Co / 32) workgroups fit the chip in one wave, the R <= 32 kernel runs them row block by row block instead: both
     // operands of a workgroup (32 rows, 32 columns, all of K) are in flight at once.  No statistics: the caller takes them from Z
     // (sn_bn_batch_stats_twopass), as the FC head does above 32 rows.
-    const bool row_tiled = few_rows && R > 32 && Ci % 64 == 0 && Ci <= 512 && !g.stats && !g.bn.coef && !g.pool_val && !g.pool_keys && !g.wplanes &&
+    // (small_fwd_lds_kernel / rows64_fwd_kernel stage a row as Ci / 4 threads x 16 bytes: Ci / 4 must divide the 256 threads --
+    //  64, 128, 256, 512; at 192 / 320 / 384 / 448 the staging left rows half-filled: wrong outputs until round 4)
+    const bool lds_ci = Ci >= 64 && Ci <= 512 && (Ci & (Ci - 1)) == 0;
+    const bool row_tiled = few_rows && R > 32 && lds_ci && !g.stats && !g.bn.coef && !g.pool_val && !g.pool_keys && !g.wplanes &&
                            AMODE != ACT_BN_RELU_FX && (long long)((R + 31) / 32) * ((Co + 31) / 32) <= device_cus();
     if (R <= 32 || row_tiled) {
         const dim3 grid((Co + 31) / 32, (R + 31) / 32);
-        if (Ci % 64 == 0 && Ci <= 512) {
+        if (lds_ci) {
             const size_t lds = ((size_t)64 * (Ci + 4) + 3 * 16 * 64 + 32 * 36) * sizeof(float);
             static bool attr_done = false;
             if (!attr_done) {
@@ -1535,7 +1539,7 @@ extern "C" int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, cons
     g.bias = bias, g.z = z, g.stats = stats;
     const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
     hipStream_t st = (hipStream_t)stream;
-    if (R > 32 && R <= 64 && Ci % 64 == 0 && Ci <= 256) {  // both halves in one workgroup, BatchNorm finalised in the epilogue
+    if (R > 32 && R <= 64 && (Ci == 64 || Ci == 128 || Ci == 256)) {  // both halves in one workgroup, BatchNorm finalised in the epilogue
         g.bn = bn;
         g.stats = nullptr;
         const size_t lds = ((size_t)96 * (Ci + 4) + 2 * 3 * 16 * 64 + 64 * 36) * sizeof(float);

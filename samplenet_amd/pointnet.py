@@ -391,7 +391,7 @@ def forward_impl(net, x_bnc, training, skip_last=False, use_plan=True):
         if L.bn is None:  # ReLU layer without BatchNorm
             z, _, _ = _linear_fwd(B, L, a_in, coef_prev, False, fc_rows=True)
             coef = _identity_coef(L.Co, z)
-        elif training and B > 32 and not (B <= 64 and L.Ci % 64 == 0 and L.Ci <= 256):
+        elif training and B > 32 and not (B <= 64 and L.Ci in (64, 128, 256)):
             # (33 .. 64 rows: sn_layer_forward_bn keeps both 32-row halves in one workgroup and finalises the BatchNorm in its epilogue)
             # the GEMM, then two-pass batch statistics from z itself (above 32 rows the statistics are not complete inside one
             # workgroup, and sum / sum-of-squares partials lose digits on the head's nearly-constant features)

@@ -52,7 +52,10 @@ CFGS = [(4, 1024, 64, 8, 128, "bnc"), (3, 96, 12, 5, 32, "bcn"), (32, 1024, 64, 
         # sn_linear_stats_blocks counts two TileSmall blocks (round 4: the BatchNorm-backward sums read an unwritten block)
         # (shapes are picked where neither fp32 run takes another max-pool / ReLU branch than the fp64 run under this seed: at
         #  (128, 128) the HIP run does -- 6e-4 on the conv gradients --, at (128, 256) torch's own fp32 run does -- 4e-3)
-        (64, 256, 64, 8, 128, "bnc"), (96, 128, 32, 8, 128, "bnc")]
+        (64, 256, 64, 8, 128, "bnc"), (96, 128, 32, 8, 128, "bnc"),
+        # a bottleneck that is a multiple of 64 but not a power of two: fc1 outside the chain, on the register-direct R <= 32 kernel
+        # (the LDS-staged one needs Ci / 4 to divide its 256 threads; it was dispatched here and returned wrong rows until round 4)
+        (8, 256, 16, 4, 192, "bnc"), (40, 128, 16, 4, 192, "bnc")]
 
 
 @pytest.mark.parametrize("cfg", CFGS)
@@ -131,8 +134,10 @@ def test_linear_kernels_exact_small_integers():
     g = torch.Generator(device="cuda").manual_seed(3)
     st = torch.cuda.current_stream().cuda_stream
     # (the 64-aligned shapes take the split-bf16 path of the conv layers: small integers are exact in bf16 as well)
+    # ((32, 192, 256) .. (16, 448, 96): input widths that are multiples of 64 but not powers of two -- the LDS-staged R <= 32 kernel
+    #  stages a row with Ci / 4 threads, which must divide 256: those widths returned wrong outputs until round 4)
     for (R, Ci, Co) in [(300, 24, 40), (32, 128, 256), (1000, 3, 64), (129, 64, 128), (64, 256, 36), (4096, 128, 128),
-                        (1024, 64, 64), (640, 64, 128)]:
+                        (1024, 64, 64), (640, 64, 128), (32, 192, 256), (20, 320, 64), (32, 384, 128), (16, 448, 96), (7, 512, 64)]:
         A = torch.randint(-4, 5, (R, Ci), device="cuda", generator=g).float()
         W = torch.randint(-4, 5, (Co, Ci), device="cuda", generator=g).float()
         b = torch.randint(-4, 5, (Co,), device="cuda", generator=g).float()
@@ -156,7 +161,7 @@ def test_linear_kernels_exact_small_integers():
 
 
 @pytest.mark.parametrize("R,Ci,Co", [(512, 256, 256), (512, 128, 256), (100, 256, 192), (40, 64, 250), (1000, 256, 256), (33, 512, 64),
-                                      (128, 256, 256), (2048, 256, 256)])
+                                      (128, 256, 256), (2048, 256, 256), (48, 192, 256), (100, 384, 64)])
 @pytest.mark.parametrize("act", [False, True])
 def test_row_tiled_layer_forward_exact_small_integers(R, Ci, Co, act):
     """A layer of the FC head above 32 rows, no statistics requested (the caller takes two-pass statistics from Z): while
@@ -185,7 +190,7 @@ def test_row_tiled_layer_forward_exact_small_integers(R, Ci, Co, act):
     assert bool((Z[R] == -7.0).all())
 
 
-@pytest.mark.parametrize("R,Ci,Co", [(50, 256, 256), (33, 128, 256), (64, 256, 192), (40, 64, 250)])
+@pytest.mark.parametrize("R,Ci,Co", [(50, 256, 256), (33, 128, 256), (64, 256, 192), (40, 64, 250), (50, 192, 128), (20, 192, 256)])
 @pytest.mark.parametrize("act", [False, True])
 def test_layer_forward_with_batchnorm_on_33_to_64_rows(R, Ci, Co, act):
     """sn_layer_forward_bn on 33 .. 64 rows: both 32-row halves in one workgroup, the BatchNorm finalised in the epilogue (two-pass
