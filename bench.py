@@ -597,9 +597,10 @@ def time_config5_progressive(dev, steps=40):
             "graph": {"ms_per_step": gms, "value": B / gms * 1e3, "unit": "point-clouds/s"}}
 
 
-def time_batch_sweep(dev, N, M, K, batches=(32, 128, 512, 2048)):
+def time_batch_sweep(dev, N, M, K, batches=(32, 48, 96, 128, 512, 2048)):
     """The whole sampler step (the headline's unit of work) at growing batches: B = 32 is latency-bound by construction (14
-    dependent launches), larger batches show what the kernels reach when fed.  Fractions: MLP flops / step time against the
+    dependent launches), larger batches show what the kernels reach when fed; 48 and 96 are batches that are not whole 64-row
+    blocks (above 32 clouds the head runs layer by layer: row-blocked kernels).  Fractions: MLP flops / step time against the
     fp32 MFMA peak; SURVEY 8d's algorithmic bytes (3.73 MB per cloud: activations written once and read once per consumer,
     geometry 50.7 KB) / step time against 8 TB/s."""
     from samplenet_amd import SampleNet
