@@ -30,14 +30,39 @@ class _Token:
     __slots__ = ("__weakref__",)
 
 
+def _owned_modules(owner):
+    """The modules whose parameters a call of `owner` reads: its tree WITHOUT the children it merely carries for the script --
+    registration/main.py:296 attaches the (trainable) sampler to the task network as `model.sampler`, which PCRNet.forward
+    never calls.  owner._graphed_exclude names such children (default: "sampler")."""
+    skip = set(getattr(owner, "_graphed_exclude", ("sampler",)))
+    out, stack = [], [(owner, True)]
+    while stack:
+        m, top = stack.pop()
+        out.append(m)
+        for name, child in m._modules.items():
+            if child is not None and not (top and name in skip):
+                stack.append((child, False))
+    return out
+
+
+def _owned_parameters(owner):
+    for m in _owned_modules(owner):
+        for p in m._parameters.values():
+            if p is not None:
+                yield p
+
+
 class _ModuleGuard:
-    """Every parameter / buffer of the module tree is still the object at the address the graphs read, and still frozen."""
+    """Every parameter / buffer of the modules the call reads (_owned_modules) is still the object at the address the graphs
+    read, and still frozen; the children are still the same objects."""
 
     def __init__(self, module):
         self.mods, self.tens = [], []
-        for m in module.modules():
+        skip = set(getattr(module, "_graphed_exclude", ("sampler",)))
+        for m in _owned_modules(module):
             for name, child in m._modules.items():
-                self.mods.append((m._modules, name, child))
+                if not (m is module and name in skip):
+                    self.mods.append((m._modules, name, child))
             for d in (m._parameters, m._buffers):
                 for k, t in d.items():
                     if t is not None:
@@ -163,7 +188,7 @@ def call(owner, tag, fn, args):
         if n <= WARM_STEPS:
             table[key] = n
             return None
-        if any(p.requires_grad for p in owner.parameters()) or owner._forward_hooks or owner._forward_pre_hooks:
+        if any(p.requires_grad for p in _owned_parameters(owner)) or owner._forward_hooks or owner._forward_pre_hooks:
             table[key] = 0
             return None
         held = [(k, v) for k, v in table.items() if isinstance(v, _Plan)]

@@ -562,20 +562,21 @@ class SamplerStepLossFunction(torch.autograd.Function):
         return (gQ if ctx.needs_input_grad[0] else None), None, g_temp, None, None, None, None, None, None, None
 
 
-def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value, keys=None):
+def step_loss_forward(x, y, fc, temperature, K, min_sigma, alpha, lmbda, weight, defer_value, keys=None, proj_out=None):
     """Forward launches of the sampler step's loss side (SamplerStepLossFunction / fused_step.SamplerStepFunction).
     x (B,N,3), y (B,3,M): the simplified cloud -- read when fc is None, otherwise WRITTEN by the pair scan from
     fc = (z3 (B,Kfc), coef3 (>=2*Kfc: scale | shift), W4 (3M,Kfc), b4 (3M)).  Caller holds the device guard.
     -> loss (2,), proj (B,M,3), state = (idx, iq, ip, argmax1, (partial, loss) | (None, None)[, keys-mode record]).
     keys (needs N <= 2048; the backward must follow): zeroed (B*N) int64 table; only the pair scan runs here, the per-point
-    minima are combined in the table and the loss value is produced by the backward's launches (sn_sampler_step_loss_keys)."""
+    minima are combined in the table and the loss value is produced by the backward's launches (sn_sampler_step_loss_keys).
+    proj_out: a preallocated contiguous (B,M,3) fp32 tensor for the projected cloud (the captured surface's output block)."""
     B, _, M = y.shape
     N = x.shape[1]
     dev = y.device
     G = lib.sn_pairscan_colmin_splits(B, N, M)
     if G <= 1 and (fc is not None or keys is not None):
         raise ValueError("fc4 inside the scan / the keys-mode step need a batch small enough for split clouds")
-    proj = torch.empty(B, M, 3, device=dev, dtype=torch.float32)
+    proj = proj_out if proj_out is not None else torch.empty(B, M, 3, device=dev, dtype=torch.float32)
     idx = torch.empty(B, M, K, device=dev, dtype=torch.int32)
     dq = torch.empty(B, M, device=dev, dtype=torch.float32)
     iq = torch.empty(B, M, device=dev, dtype=torch.int32)

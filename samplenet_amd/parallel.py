@@ -79,10 +79,12 @@ class FlatGradAllReducer:
 
             params = dict(named)
             module._grad_sink = GradSink(sink, {n: params[n] for n in sink})
+            module._grad_sink.reducer = self  # (the captured module surface writes this bucket: surface.py)
         self.overlap = bool(overlap and self.collective and dev.type == "cuda" and hip_mlp)
         self._side = torch.cuda.Stream(device=dev) if (self.collective and dev.type == "cuda") else None
         self._early_work = None
         self._sentinel = None
+        self._graph_reduced = False  # set by a captured backward whose last node WAS the all-reduce (surface.py): reduce() skips it once
         self.capture_fork = False  # engine, "graph-fork" mode: the early collective may be issued while a graph is being captured
         if self.overlap:
             module._after_fc_grads = self._early_ready
@@ -174,6 +176,10 @@ class FlatGradAllReducer:
         """Call after backward(): on return (stream-ordered) every .grad holds the cross-rank mean.
         collective=False: only the .grad bookkeeping (the engine's captured step carries the collectives inside its graph);
         replayed=True: the step was a graph replay (see _rebind)."""
+        if self._graph_reduced:  # the module surface's backward graph carried the collective
+            self._graph_reduced = False
+            self._rebind(True)
+            return
         self._rebind(replayed)
         if not collective or not self.collective:
             return

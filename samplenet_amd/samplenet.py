@@ -91,20 +91,25 @@ class SampleNet(nn.Module):
         self.output_shape = output_shape
 
         self._scan = None  # Chamfer products of the last training forward (see get_simplification_loss)
-        # training steps of one configuration run on captured work behind forward() / the loss getters (surface.py: outputs are
-        # static tensors, gradients are written straight into .grad); False: every call op by op
+        # training steps of one configuration run on captured work behind forward() / the loss getters (surface.py: gradients are
+        # written straight into .grad; the surface steps aside where autograd hooks / DistributedDataParallel may listen);
+        # False: every call op by op; "force": captured even under a multi-rank process group without a FlatGradAllReducer
         self.graph_surface = True
+        # False: forward() hands out COPIES of the graphs' static outputs (what a script keeps across steps keeps its values, as
+        # with the reference module); True: the static tensors themselves (overwritten by the next forward of the configuration)
+        self.surface_static_outputs = False
         self.device_matching = True  # eval branch: nn_matching / FPS completion on the GPU (False: numpy, as the reference)
 
     # per-step / per-attachment state that must not travel with a copy of the module (graph tensors, views of another
     # module's gradient bucket, persistent kernel scratch)
     _TRANSIENT = ("_scan", "_grad_sink", "_after_fc_grads", "_colmin_keys", "_colmin_keys_owner", "_fx_acc", "_fx_acc_b",
-                  "_fc_sync", "_fc_sync_b", "_sn_layer_records", "_sn_plans", "_sn_sync_bn", "_sn_surface", "_sn_surface_live")
+                  "_fc_sync", "_fc_sync_b", "_sn_layer_records", "_sn_plans", "_sn_sync_bn", "_sn_surface", "_sn_surface_live",
+                  "_sn_hook_params", "_sn_surface_warned")
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float() ...: parameter storage moves -- recorded pointer arrays, captured graphs and persistent
         # scratch are void
-        for k in ("_sn_plans", "_sn_layer_records", "_sn_surface", "_sn_surface_live"):
+        for k in ("_sn_plans", "_sn_layer_records", "_sn_surface", "_sn_surface_live", "_sn_hook_params"):
             self.__dict__.pop(k, None)
         return super()._apply(fn, *args, **kwargs)
 

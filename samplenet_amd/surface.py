@@ -25,17 +25,30 @@ stays correct: a second forward before the first one's backward (main.py:516-524
 `simp` itself or a loss weight other than the captured one runs the backward launches eagerly on the graph's activations,
 a changed parameter storage / device / dtype drops the graphs (SampleNet._apply; pointer signature checked per step).
 
-Outputs are STATIC tensors: the next training forward of the same configuration overwrites simp / proj / the loss values in
-place (as torch.cuda.make_graphed_callables does); clone what must outlive a step.  Gradients are written straight into
-.grad (views of the plan's bucket; torch semantics kept: overwrite when .grad is None, accumulate otherwise) -- no
-AccumulateGrad nodes run, so per-parameter autograd hooks do not fire: set `net.graph_surface = False` for tooling that needs
-them (torch DistributedDataParallel; samplenet_amd.parallel.FlatGradAllReducer takes the engine route instead).
+Outputs: the graphs write simp / proj / the loss values into ONE static block; what the script receives is a copy of that
+block (one small launch), so tensors kept across steps (logging lists, an EMA of proj) keep their values as with the
+reference module.  `net.surface_static_outputs = True` hands out the static block itself (the next training forward of the
+same configuration then overwrites it in place, as torch.cuda.make_graphed_callables does).
+
+Gradients are written straight into .grad (views of the plan's bucket; torch semantics kept: overwrite when .grad is None,
+accumulate otherwise) -- no AccumulateGrad nodes run, so per-parameter autograd hooks would not fire.  Therefore the surface
+steps aside, op by op, with ONE warning, whenever something may depend on them:
+  * a parameter carries a hook (Tensor.register_hook, register_post_accumulate_grad_hook, optimizer-in-backward);
+  * torch.distributed runs with more than one rank and no samplenet_amd.parallel.FlatGradAllReducer is attached to the
+    module -- torch DistributedDataParallel hangs its reducer on the AccumulateGrad nodes, which a child module cannot see.
+    (`net.graph_surface = "force"` overrides this for scripts that all-reduce p.grad themselves after backward().)
+Data parallelism ON the captured surface: attach a FlatGradAllReducer -- the plan's gradient bucket IS the reducer's flat
+bucket (the backward graph writes the reducer's views), and where the backend can be captured (RCCL) the all-reduce is the
+last node of the backward graph; `reducer.reduce()` after `backward()` then only re-binds .grad (with gloo it runs the
+collective as usual).
 """
 import ctypes
 import operator
+import warnings
 import weakref
 
 import torch
+import torch.distributed as _dist
 
 from . import ops, pointnet
 from ._lib import check, lib, ptr, stream_of
@@ -122,6 +135,14 @@ _data_ptr = torch.Tensor.data_ptr
 _is = operator.is_
 
 
+def _hyper(net):
+    """Everything a plan's graphs have baked in besides tensors: the projection's hyper-parameters, the output size, the
+    train / eval flag of every sub-module, the gradient sink (a FlatGradAllReducer's) the backward graph writes."""
+    pr = net.project
+    return (net.num_out_points, pr._group_size, pr._min_sigma_f, tuple([m.training for m in net._modules.values()]),
+            id(net.__dict__.get("_grad_sink")), bool(net.__dict__.get("surface_static_outputs", False)))
+
+
 class _Guard:
     """What a plan's graphs have baked in, in a form that is cheap to re-check per step (~10 us): the sub-modules are still
     the module's, every parameter / buffer is still the object at the address the graphs read and write, every parameter
@@ -129,6 +150,8 @@ class _Guard:
 
     def __init__(self, net):
         self.mods, self.tens, self.consts = [], [], []
+        self.net_ref = weakref.ref(net)
+        self.hyper = _hyper(net)
         for name, m in net._modules.items():
             self.mods.append((net._modules, name, m))
             for d in (m._parameters, m._buffers):
@@ -143,6 +166,9 @@ class _Guard:
         self._rg = [r for _, _, _, _, r in self.tens]
 
     def ok(self):
+        net = self.net_ref()
+        if net is None or _hyper(net) != self.hyper:
+            return False
         for d, k, m in self.mods:
             if d.get(k) is not m:
                 return False
@@ -172,26 +198,49 @@ class _Plan:
         names = pointnet.param_order(net)
         T = net.project._temperature
         total = sum(p.numel() for p in params)
+        self.sink = net.__dict__.get("_grad_sink")
+        self.reducer = getattr(self.sink, "reducer", None) if self.sink is not None else None
+        self.static_out = bool(net.__dict__.get("surface_static_outputs", False))
         with torch.cuda.device(dev):
             self.x = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
             self.up_scalars = torch.zeros(2, device=dev, dtype=torch.float32)
             self.up_proj = torch.zeros(B, M, 3, device=dev, dtype=torch.float32)
             self.keys = torch.zeros(B * N, device=dev, dtype=torch.int64)
-            self.bucket = torch.zeros(total + 1, device=dev, dtype=torch.float32)
+            # one block for everything the script receives: [simp (B,M,3) | proj (B,M,3) | values (8)], sections 256-byte aligned
+            sec = (B * M * 3 + 63) // 64 * 64
+            self.outbuf = torch.zeros(2 * sec + 64, device=dev, dtype=torch.float32)
+            self.out_sec = sec
             self.views, self.view_list, off = {}, [], 0
-            for n, p in zip(names, params):
-                v = self.bucket[off:off + p.numel()].view(p.shape)
-                self.views[n] = v
-                self.view_list.append(v)
-                off += p.numel()
-            self.t_sink = self.bucket[total:total + 1]
-            self.t_view = self.t_sink.view(T.shape)
+            if self.reducer is None:
+                self.bucket = torch.zeros(total + 1, device=dev, dtype=torch.float32)
+                for n, p in zip(names, params):
+                    v = self.bucket[off:off + p.numel()].view(p.shape)
+                    self.views[n] = v
+                    self.view_list.append(v)
+                    off += p.numel()
+                self.t_sink = self.bucket[total:total + 1]
+                self.t_view = self.t_sink.view(T.shape)
+            else:
+                # data parallel: the backward graph writes the reducer's own views -- its flat bucket is the collective's operand
+                self.bucket = self.reducer.flat
+                for n in names:
+                    v = self.sink[n]
+                    self.views[n] = v
+                    self.view_list.append(v)
+                self.t_view = next((v for p, v in self.reducer._autograd if p is T), None)
+                if self.t_view is None:  # a frozen temperature: its (zero) gradient lands in a scratch word
+                    self.t_view = torch.zeros(T.shape, device=dev, dtype=torch.float32)
+                self.t_sink = self.t_view.view(-1)[:1]
             self.params = list(params)
             self.grad_pairs = list(zip(self.params, self.view_list))
             if T.requires_grad:
                 self.grad_pairs.append((T, self.t_view))
-            for _, v in self.grad_pairs:  # (which plan a .grad tensor belongs to: commit_begin's mode 3)
-                _register_view(v, self)
+            if self.reducer is None:
+                for _, v in self.grad_pairs:  # (which plan a .grad tensor belongs to: commit_begin's mode 3)
+                    _register_view(v, self)
+            # the collective as the last node of the backward graph where the backend's launches can be captured (RCCL)
+            self.collective_in_graph = bool(self.reducer is not None and self.reducer.collective and self.reducer._avg
+                                            and net.__dict__.get("surface_collective", "graph") == "graph")
             self._capture(net, x)
         self.guard = _Guard(net)
 
@@ -204,10 +253,12 @@ class _Plan:
         T = net.project._temperature
         self.y = torch.empty(B, 3, M, device=self.dev, dtype=torch.float32)
         fc = (saved["zf"][2], saved["cf"][2], fc4.weight.detach(), fc4.bias.detach())
-        _, proj, state = ops.step_loss_forward(x, self.y, fc, T, K, self.min_sigma, 1.0, 0.0, self.weight, True, keys=self.keys)
+        sec = self.out_sec
+        self.simp = self.outbuf[0:B * M * 3].view(B, M, 3)
+        self.values = self.outbuf[2 * sec:2 * sec + 8]
+        _, proj, state = ops.step_loss_forward(x, self.y, fc, T, K, self.min_sigma, 1.0, 0.0, self.weight, True, keys=self.keys,
+                                               proj_out=self.outbuf[sec:sec + B * M * 3].view(B, M, 3))
         _, keys, qpart, qmax, G = state[5]
-        self.simp = torch.empty(B, M, 3, device=self.dev, dtype=torch.float32)
-        self.values = torch.empty(8, device=self.dev, dtype=torch.float32)
         self.dpsum = torch.empty(B, device=self.dev, dtype=torch.float32)
         check(lib.sn_surface_values_keys(B, N, M, G, ptr(keys), ptr(qpart), ptr(qmax), ptr(T.detach().reshape(1)), self.min_sigma,
                                          self.weight, ptr(self.y), ptr(self.simp), ptr(self.dpsum), ptr(self.values),
@@ -228,6 +279,8 @@ class _Plan:
         missing = [n for n in self.views if grads.get(n) is not self.views[n]]
         if missing:
             raise RuntimeError("surface: the backward did not write %s into the gradient bucket" % missing[:3])
+        if self.collective_in_graph:
+            self.reducer._all_reduce_mean(self.reducer.flat)  # captured: RCCL's kernel replays as the graph's last node
         self.bwd_keep = (res, grads)
 
     def _capture(self, net, x):
@@ -265,6 +318,24 @@ class _Plan:
             self.owner = None
             return False
         return True
+
+    def commit_begin_sink(self):
+        """Data-parallel plan (the bucket is a FlatGradAllReducer's): -> old bucket to add after the replay, or None when this
+        backward may overwrite the views (GradSink.direct(): first backward of a step, or every .grad dropped by zero_grad())."""
+        return None if self.sink.direct() else self.bucket.clone()
+
+    def commit_end_sink(self, old):
+        if old is not None:
+            self.bucket.add_(old)
+        for p, v in self.grad_pairs:
+            g = p.grad
+            if g is not v:
+                if g is not None and g.data_ptr() != v.data_ptr():
+                    v.add_(g)  # somebody assigned another tensor as .grad: fold it in, take the slot back
+                p.grad = v
+        self.sink.written = True
+        if self.collective_in_graph:
+            self.reducer._graph_reduced = True  # reducer.reduce() after backward(): bookkeeping only
 
     def commit_begin(self):
         """-> (mode, old): 0 every .grad is None (the views become the gradients), 1 every .grad IS its view (accumulate into
@@ -321,13 +392,17 @@ class _SurfaceFunction(torch.autograd.Function):
         with _device_guard(plan.dev):
             plan.x.copy_(x, non_blocking=True)
             plan.gf.replay()
+            out = plan.outbuf if plan.static_out else plan.outbuf.clone()  # (one launch: what the script keeps is its own)
         token = _Token()
         plan.owner = weakref.ref(token)
         ctx.plan, ctx.net, ctx.token = plan, net, token
         ctx.weight = None  # set by a getter that was asked for another loss weight than the captured one
         ctx.done = False
         ctx.set_materialize_grads(False)
-        return plan.simp.detach(), plan.proj.detach(), plan.v_lsimp.detach(), plan.v_sigma.detach()
+        B, _, M, _ = plan.shape
+        sec, n = plan.out_sec, B * M * 3
+        return (out[0:n].view(B, M, 3).detach(), out[sec:sec + n].view(B, M, 3).detach(), out[2 * sec].detach(),
+                out[2 * sec + 1].detach())
 
     @staticmethod
     def backward(ctx, g_simp, g_proj, g_lsimp, g_sigma):
@@ -351,9 +426,14 @@ class _SurfaceFunction(torch.autograd.Function):
             if g_simp is None and ctx.weight is None:
                 check(lib.sn_surface_gather_upstream(B * M * 3, ptr(g_lsimp), ptr(g_sigma), ptr(g_proj), ptr(plan.up_scalars),
                                                      ptr(plan.up_proj), st), "sn_surface_gather_upstream")
-                mode, old = plan.commit_begin()
-                plan.gb.replay()
-                plan.commit_end(mode, old)
+                if plan.reducer is not None:
+                    old = plan.commit_begin_sink()
+                    plan.gb.replay()
+                    plan.commit_end_sink(old)
+                else:
+                    mode, old = plan.commit_begin()
+                    plan.gb.replay()
+                    plan.commit_end(mode, old)
             else:
                 # irregular upstream (a gradient on the simplified cloud itself / another loss weight): the same launches,
                 # eagerly, on the graph's activations
@@ -368,11 +448,17 @@ class _SurfaceFunction(torch.autograd.Function):
                 if g_simp is not None:
                     gQ = gQ + ops._f32c(g_simp).permute(0, 2, 1)
                 grads = pointnet.backward_impl(net, plan.saved, gQ.reshape(B, -1).contiguous(), None, None)
-                for n, p in zip(pointnet.param_order(net), plan.params):
-                    p.grad = grads[n] if p.grad is None else p.grad + grads[n]
-                if T.requires_grad:
-                    gT = gT.reshape(T.shape)
-                    T.grad = gT.clone() if T.grad is None else T.grad + gT
+                if plan.reducer is not None:
+                    plan.sink.commit(grads)  # (torch semantics on the reducer's views; no collective: reducer.reduce() follows)
+                    if T.requires_grad:
+                        plan.t_view.add_(gT.reshape(T.shape)) if T.grad is not None else plan.t_view.copy_(gT.reshape(T.shape))
+                        T.grad = plan.t_view
+                else:
+                    for n, p in zip(pointnet.param_order(net), plan.params):
+                        p.grad = grads[n] if p.grad is None else p.grad + grads[n]
+                    if T.requires_grad:
+                        gT = gT.reshape(T.shape)
+                        T.grad = gT.clone() if T.grad is None else T.grad + gT
         plan.owner = None
         return None, None, None, None
 
@@ -385,11 +471,57 @@ def _supported(net, x):
     if not torch.is_grad_enabled() or not x.is_cuda or x.requires_grad or x.dtype != torch.float32 or x.dim() != 3 or x.shape[2] != 3:
         return False
     d = net.__dict__
-    if d.get("_sn_sync_bn") is not None or d.get("_grad_sink") is not None or d.get("_after_fc_grads") is not None:
+    if d.get("_sn_sync_bn") is not None:
+        return False
+    sink = d.get("_grad_sink")
+    if sink is not None:
+        red = getattr(sink, "reducer", None)  # a FlatGradAllReducer's sink: the plan writes the reducer's bucket
+        if red is None:
+            return False
+        after = d.get("_after_fc_grads")
+        if after is not None and getattr(after, "__self__", None) is not red:
+            return False
+    elif d.get("_after_fc_grads") is not None:
         return False
     if net._forward_hooks or net._forward_pre_hooks or net._backward_hooks:
         return False
+    why = autograd_listeners(net)
+    if why is not None:
+        return _fallback(net, why)
     return True
+
+
+def autograd_listeners(net):
+    """Why the captured surface must step aside for this module, or None.  Captured gradients land in .grad without
+    AccumulateGrad nodes running, so anything that listens on those needs the op-by-op route: per-parameter hooks, and torch
+    DistributedDataParallel (its reducer hangs on the AccumulateGrad nodes, invisible from a child module -- assumed whenever
+    a multi-rank process group exists and the module has no FlatGradAllReducer of its own)."""
+    if _has_param_hooks(net):
+        return "a parameter carries an autograd hook"
+    if (net.__dict__.get("_grad_sink") is None and getattr(net, "graph_surface", True) != "force" and _dist.is_available()
+            and _dist.is_initialized() and _dist.get_world_size() > 1):
+        return ("torch.distributed runs %d ranks and no FlatGradAllReducer is attached (DistributedDataParallel's reducer hooks "
+                "would never fire on captured gradients; graph_surface='force' overrides)" % _dist.get_world_size())
+    return None
+
+
+def _has_param_hooks(net):
+    ps = net.__dict__.get("_sn_hook_params")
+    if ps is None or ps[0] != len(net._modules):
+        ps = net.__dict__["_sn_hook_params"] = (len(net._modules), [p for p in net.parameters()])
+    return any(map(_bw_hooks, ps[1])) or any(map(_pa_hooks, ps[1]))
+
+
+_bw_hooks = operator.attrgetter("_backward_hooks")
+_pa_hooks = (operator.attrgetter("_post_accumulate_grad_hooks") if hasattr(torch.Tensor, "_post_accumulate_grad_hooks")
+             else (lambda p: None))
+
+
+def _fallback(net, why):
+    if not net.__dict__.get("_sn_surface_warned"):
+        net.__dict__["_sn_surface_warned"] = True
+        warnings.warn("samplenet_amd.surface: %s -- this module runs op by op (no captured graphs)" % why)
+    return False
 
 
 class _Config:
@@ -421,18 +553,24 @@ def _make_room(table, keep):
 def _build(net, x):
     from .fused_step import external_task_supported
 
+    net.__dict__.pop("_sn_hook_params", None)  # (the parameter objects the hook check walks: re-read at every capture)
+    if autograd_listeners(net) is not None:
+        return None
+
     T = net.project._temperature
     params = pointnet.param_list(net)
     ok = (external_task_supported(net, x) and all(p.requires_grad for p in params) and T.dim() == 0 and
           all(L.bn is not None and L.bn.momentum is not None and L.bn.track_running_stats
               for L in sum(pointnet._layers(net), [])[:-1]))
+    sink = net.__dict__.get("_grad_sink")
+    if ok and sink is not None:  # every gradient the backward graph writes must be a view of the reducer's bucket
+        red = sink.reducer
+        ok = all(n in sink for n in pointnet.param_order(net)) and (not T.requires_grad or any(p is T for p, _ in red._autograd))
     if not ok:
         return None
     try:
         return _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
     except Exception as e:  # noqa: BLE001 -- a configuration that cannot be captured stays on the op-by-op route
-        import warnings
-
         warnings.warn("samplenet_amd.surface: capture failed, this configuration stays op by op (%s)" % repr(e)[:300])
         torch.cuda.synchronize(x.device)
         return None
@@ -478,6 +616,7 @@ def try_forward(net, x):
     if cfg.plans and not cfg.plans[0].guard.ok():
         # a parameter / buffer / layer was replaced: new graphs after the warm steps (this call is the first of them)
         cfg.plans, cfg.seen, cfg.contended = [], 1, 0
+        net.__dict__.pop("_sn_hook_params", None)
         return None
     if not cfg.plans:
         cfg.seen += 1

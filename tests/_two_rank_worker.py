@@ -5,7 +5,9 @@
 torch.distributed backend "gloo" (RCCL refuses two ranks on one device); the gradient bucket is a CUDA tensor -- where this
 build's gloo cannot take device tensors the collective is staged through the host for the test (the reducer's own call
 otherwise).  Modes: "fused" (captured fused step, per-rank statistics, allreduce='after'), "fixed" (running-statistics
-BatchNorm: two ranks on half batches = one process on the whole batch), "sync" (convert_sync_batchnorm)."""
+BatchNorm: two ranks on half batches = one process on the whole batch), "sync" (convert_sync_batchnorm), "surface" (the
+MODULE SURFACE as an unmodified script drives it -- net(x), the getters, backward(), reducer.reduce() -- on captured graphs
+with the reducer's bucket), "ddp" (torch DistributedDataParallel around the module: the surface must step aside)."""
 import os
 import sys
 
@@ -59,6 +61,44 @@ def fixed_stats_features(net):
     net.graph_surface = False
 
 
+def script_modes(mode, net, x, rank, world, out, native):
+    """registration/main.py:507-531 as a script issues it, data parallel: (surface) FlatGradAllReducer + the captured module
+    surface; (ddp) torch DistributedDataParallel -- the surface must step aside (one warning) and DDP's hooks synchronise."""
+    import warnings
+
+    from samplenet_amd import surface
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    M = net.num_out_points
+    red, model = None, net
+    if mode == "surface":
+        red = FlatGradAllReducer(net)
+    else:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])
+    captured = []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for it in range(5):
+            if red is not None:
+                red.zero_grad()
+            else:
+                for p in net.parameters():
+                    p.grad = None
+            simp, proj = model(x)
+            loss = 0.01 * net.get_simplification_loss(x, simp, M, 1.0, 0.0) + 0.01 * net.get_projection_loss() + proj.mean()
+            loss.backward()
+            if red is not None:
+                red.reduce()
+            captured.append(bool(surface.plans(net)))
+        nwarn = len([m for m in w if "op by op" in str(m.message)])
+    torch.cuda.synchronize()
+    flat = red.flat.cpu() if red is not None else torch.cat([p.grad.reshape(-1) for _, p in net.named_parameters()]).cpu()
+    torch.save({"flat": flat, "loss": float(loss), "native_gloo": native, "captured": captured, "warnings": nwarn,
+                "buffers": {k: v.cpu() for k, v in net.named_buffers()}}, os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world, port, mode, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
@@ -81,6 +121,9 @@ def main():
         convert_sync_batchnorm(net)
     elif mode == "fixed":
         fixed_stats_features(net)
+    if mode in ("surface", "ddp"):
+        script_modes(mode, net, x, rank, world, out, native)
+        return
     red = FlatGradAllReducer(net)
     assert red.world == world and red.collective
     step = SamplerTrainStep(net, x, reducer=red, use_graph=(mode == "fused"), allreduce="after",

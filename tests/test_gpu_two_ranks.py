@@ -110,3 +110,52 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path, mode):
             if "running" in k:
                 assert torch.allclose(r0["buffers"][k], v.cpu(), rtol=1e-4, atol=1e-6), k
                 assert torch.equal(r0["buffers"][k], r1["buffers"][k]), k
+
+
+def test_two_ranks_module_surface_on_captured_graphs(tmp_path):
+    """the MODULE SURFACE (net(x) -> getters -> backward() -> reducer.reduce()) under data parallelism replays
+    captured graphs whose backward writes the reducer's bucket; after five steps both ranks hold the same bucket, bit-equal to
+    what the ENGINE's captured step leaves for the same shards (mean of the two shards' gradients)."""
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    net = _fresh()
+    state = {k: v.cpu().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(64, 1024, 3, device="cuda") - 0.5
+    r0, r1 = _run_two("surface", tmp_path, state, x)
+    assert r0["captured"][-1] and r1["captured"][-1] and r0["warnings"] == 0
+    assert torch.equal(r0["flat"], r1["flat"]) and float(r0["flat"].abs().sum()) > 0
+    flats = []
+    for r in range(2):
+        local = _fresh()
+        local.load_state_dict(state)
+        red = FlatGradAllReducer(local)
+        # (the same launches as the surface's graphs: the task term outside the node; 3 warm-up steps + 2 = the ranks' 5 steps)
+        step = SamplerTrainStep(local, x[32 * r:32 * (r + 1)].contiguous(), reducer=red, use_graph=True,
+                                task_loss=lambda proj: proj.mean())
+        for _ in range(2):
+            step(x[32 * r:32 * (r + 1)].contiguous())
+        torch.cuda.synchronize()
+        flats.append(red.flat.cpu().clone())
+        for k, v in local.named_buffers():
+            assert torch.equal(v.cpu(), (r0, r1)[r]["buffers"][k]), k
+    want = (flats[0] + flats[1]) * 0.5
+    # the engine's node applies alpha inside the kernels, the script multiplies the getter's value outside (0.01 x 1 = 1 x 0.01):
+    # the MLP gradients are the same arithmetic; the temperature's direct term is formed in-kernel on one side (1e-6)
+    diff = (r0["flat"] - want).abs()
+    print("surface vs engine bucket: max |d| %.3e of max |g| %.3e, %d of %d entries differ" %
+          (float(diff.max()), float(want.abs().max()), int((diff > 0).sum()), diff.numel()))
+    assert float(diff.max()) <= 1e-6 * float(want.abs().max()), float(diff.max())
+
+
+def test_two_ranks_ddp_wrapped_module_is_synchronised_by_the_fallback(tmp_path):
+    """torch DistributedDataParallel around the HIP module -- the captured surface would write .grad past
+    DDP's reducer hooks; it must step aside (one warning per rank) so that DDP synchronises every step."""
+    net = _fresh()
+    state = {k: v.cpu().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(64, 1024, 3, device="cuda") - 0.5
+    r0, r1 = _run_two("ddp", tmp_path, state, x)
+    assert not any(r0["captured"]) and not any(r1["captured"])
+    assert r0["warnings"] == 1 and r1["warnings"] == 1
+    assert torch.equal(r0["flat"], r1["flat"]) and float(r0["flat"].abs().sum()) > 0  # identical gradients on both ranks: synchronised
+    assert r0["loss"] != r1["loss"]  # (different shards)
