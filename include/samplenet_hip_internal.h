@@ -332,6 +332,12 @@ int sn_conv_stack_set_in3_blocks(int blocks);
 int sn_linear_forward_rows(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W, const float *bias, float *z,
                            sn_stream_t stream);
 
+/* sn_emd_loss (samplenet_hip.h) with the reference op's own exponential -- __expf = v_exp_f32(x log2 e), tf_approxmatch_g.cu:52,97,151 --
+ * in the auction and in the cost / gradient sweeps: the form a training loss wants (cost within 1e-5 of the oracle); not
+ * bit-identical to the three-call composition, whose match matrix keeps the compensated exponential.  Same arguments / scratch. */
+int sn_emd_loss_fast(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
+                     float *temp, sn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

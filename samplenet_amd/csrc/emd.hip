@@ -46,36 +46,85 @@ __device__ __forceinline__ float emd_sq(float ax, float ay, float az, float bx, 
     return (dx * dx + dy * dy) + dz * dz;
 }
 
-// exp for the auction.  The reference op uses __expf (tf_approxmatch_g.cu:49), a 2-ulp hardware approximation; its CPU twin
-// (and the oracle) use expf.  The auction amplifies exp rounding through its 10 levels (plain v_exp_f32(x log2 e) -- what
-// __expf is -- moves ~2 % of the argmax picks of emd_matching and breaks the 5e-4 per-entry bar held here), so the hardware
-// exponential is used with a compensated argument: y = x log2(e) is split into its rounded value and the rounding residual
-// (one extra fma + the low word of log2 e), 2^y comes from v_exp_f32 (1 ulp) and the residual is applied as 1 + r ln 2 --
-// ~2 ulp overall at ~8 VALU operations instead of libm's ~20.  The level sweeps are VALU-bound on exactly this, so they
-// work on PAIRS of points with the packed fp32 instructions of gfx950 (v_pk_mul / v_pk_add / v_pk_fma: two lanes of one
-// 64-bit register pair per issue): everything but v_exp_f32 itself and the two sequential accumulations costs half.
-// exp(0) == 1 exactly (level 0 multiplies by zero), large negative arguments underflow to 0 like expf.
+// exp for the auction.  The reference op uses __expf (tf_approxmatch_g.cu:49,52,97,151) -- v_exp_f32(x log2 e) on this hardware;
+// its CPU twin (and the oracle) use expf.  Two forms, a template parameter of every sweep:
+//   FAST = false  (sn_approxmatch, sn_emd_loss: whatever hands out or must reproduce the MATCH matrix -- emd_matching takes its
+//           argmax): the auction amplifies exp rounding through its 10 levels (plain v_exp_f32 moves ~2 % of the argmax picks
+//           and breaks the 5e-4 per-entry bar held on `match`), so the hardware exponential gets a compensated argument:
+//           y = x log2(e) split into its rounded value and the rounding residual (one fma + the low word of log2 e), 2^y from
+//           v_exp_f32 (1 ulp), the residual applied as 1 + r ln 2 -- ~2 ulp overall at 6 packed operations + 2 v_exp per pair;
+//   FAST = true   (sn_emd_loss_fast: the LOSS -- cost and its gradients, bar 1e-5 on the cost): the reference's own
+//           __expf, 1 packed multiply + 2 v_exp per pair.
+// Every level is -4^j, a power of two, so x = level d is exact and fl(x c) == fl(d (level c)) for any constant c: the level is
+// folded into the constants (level log2e_hi, level log2e_lo) once per kernel -- same bits, one multiply less per exponential.
+//
+// The sweeps are VALU-issue-bound, so they work on PAIRS of points with gfx950's packed fp32 instructions (v_pk_mul / v_pk_add /
+// v_pk_fma_f32: two values in one 64-bit register pair per issue).  They are written as inline assembly with EARLY-CLOBBER
+// destinations, i.e. the destination pair never overlaps a source pair: the library is otherwise built without packed fp32
+// arithmetic (build.py, DESIGN.md 6c: with a second process on the GPU, compiler-packed code whose destination pair aliased a
+// source returned wrong low halves -- a wave restored in the middle of such a two-pass instruction re-executes it on a half it
+// has already overwritten); an instruction whose sources survive it computes the same result however often it is replayed.
+// This translation unit is compiled with the packed feature on and the SLP vectoriser off, and
+// tests/test_cabi_and_host.py::test_device_code_carries_no_packed_fp32_arithmetic checks in the disassembly that every packed
+// instruction left in emd.o has a destination disjoint from its sources (and that no other object has any).
 typedef float f2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2v emd_exp2(f2v x)
+__device__ __forceinline__ f2v pk_mul(f2v a, f2v b)
 {
-    constexpr float kLog2eHi = 1.44269502162933349609375f, kLog2eLo = 1.925963033500966e-8f, kLn2 = 0.693147180559945309f;
-    const f2v y = x * kLog2eHi;
-    const f2v r = __builtin_elementwise_fma(x, (f2v)(kLog2eHi), -y) + x * kLog2eLo;
-    const f2v e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
-    return e * __builtin_elementwise_fma(r, (f2v)(kLn2), (f2v)(1.0f));
+    f2v d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
 }
-__device__ __forceinline__ float emd_exp(float x)
+__device__ __forceinline__ f2v pk_add(f2v a, f2v b)
 {
-    constexpr float kLog2eHi = 1.44269502162933349609375f, kLog2eLo = 1.925963033500966e-8f, kLn2 = 0.693147180559945309f;
-    const float y = x * kLog2eHi;
-    const float r = __builtin_fmaf(x, kLog2eHi, -y) + x * kLog2eLo;
-    return __builtin_amdgcn_exp2f(y) * __builtin_fmaf(r, kLn2, 1.0f);
+    f2v d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
 }
-// squared distances of one point (ax, ay, az) to a PAIR of points: same expression / roundings as emd_sq, per lane
-__device__ __forceinline__ f2v emd_sq2(float ax, float ay, float az, f2v bx, f2v by, f2v bz)
+__device__ __forceinline__ f2v pk_sub(f2v a, f2v b)  // a - b
 {
-    const f2v dx = bx - ax, dy = by - ay, dz = bz - az;
-    return (dx * dx + dy * dy) + dz * dz;
+    f2v d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2v pk_fma(f2v a, f2v b, f2v c)  // a b + c, one rounding
+{
+    f2v d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f2v pk_fms(f2v a, f2v b, f2v c)  // a b - c, one rounding
+{
+    f2v d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f2v splat(float v) { return (f2v){v, v}; }
+
+constexpr float kLog2eHi = 1.44269502162933349609375f, kLog2eLo = 1.925963033500966e-8f, kLn2 = 0.693147180559945309f;
+// the per-level constants of the exponential: (level log2e_hi, level log2e_lo) as pairs (exact scalings: the level is a power of two)
+struct EmdLev {
+    f2v hi, lo;
+};
+__device__ __forceinline__ EmdLev emd_lev(float level) { return EmdLev{splat(level * kLog2eHi), splat(level * kLog2eLo)}; }
+// exp(level d2) for a pair of squared distances
+template <bool FAST>
+__device__ __forceinline__ f2v emd_exp2(f2v d2, const EmdLev &L)
+{
+    const f2v y = pk_mul(d2, L.hi);
+    f2v e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+    // gfx950 needs one wait state between a transcendental and a VALU instruction that reads its result; the compiler pads that
+    // hazard for its own instructions only -- it cannot see that the inline-assembly multiply behind this is one (without the
+    // pad the multiply read the register's OLD value: negative "exponentials", NaN losses)
+    asm("s_nop 0" : "+v"(e));
+    if (FAST) return e;
+    const f2v r = pk_add(pk_fms(d2, L.hi, y), pk_mul(d2, L.lo));
+    return pk_mul(e, pk_fma(r, splat(kLn2), splat(1.0f)));
+}
+// squared distances of one point (given as splat pairs) to a PAIR of points: (b - a)^2 summed as emd_sq does, per lane
+__device__ __forceinline__ f2v emd_sq2(f2v ax, f2v ay, f2v az, f2v bx, f2v by, f2v bz)
+{
+    const f2v dx = pk_sub(bx, ax), dy = pk_sub(by, ay), dz = pk_sub(bz, az);
+    return pk_add(pk_add(pk_mul(dx, dx), pk_mul(dy, dy)), pk_mul(dz, dz));
 }
 
 // Workspace layout per cloud (floats): remainL[n] remainR[m] ratioL[kLevels][n] ratioR[kLevels][m]
@@ -86,6 +135,7 @@ __host__ __device__ inline size_t emd_ws_floats(int n, int m) { return (size_t)(
 //   then      : pass 1 of level li   -> ratioL[li][k] = remainL[k] / (1e-9 + sum_l exp(lev d) remainR[l])
 // (pass 3 of the last level only updates remainL, which nothing reads afterwards: it is not run.)
 // li == 0 also initialises remainL (and, by its first block column, remainR).
+template <bool FAST>
 __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2, float *__restrict__ ws,
                                                          float multiL, float multiR)
@@ -131,27 +181,36 @@ __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, c
             if (do3) tileC[q] = make_float2(rR3[la], okb ? rR3[lb] : 0.f);
         }
         __syncthreads();
+        const f2v px = splat(x1), py = splat(y1), pz = splat(z1), prl = splat(rl);
+        const EmdLev L3 = emd_lev(lev3), L1 = emd_lev(lev1);
+        // four pairs per trip, written out (the unroller leaves loops with inline assembly alone): the packed work of the four
+        // is independent and interleaves; the sums still take their terms one by one in ascending l
         if (do3) {
-            const f2v l3 = (f2v)(lev3), l1 = (f2v)(lev1);
-            for (int q = 0; q < npair; ++q) {
+            auto body = [&](int q) __attribute__((always_inline)) {
                 const float4 ta = tileA[q], tb = tileB[q];
                 const float2 tc = tileC[q];
-                const f2v d2 = emd_sq2(x1, y1, z1, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y});
-                const f2v w3 = emd_exp2(l3 * d2) * rl * (f2v){tc.x, tc.y};
-                const f2v w1 = emd_exp2(l1 * d2) * (f2v){tb.z, tb.w};
+                const f2v d2 = emd_sq2(px, py, pz, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y});
+                const f2v w3 = pk_mul(pk_mul(emd_exp2<FAST>(d2, L3), prl), (f2v){tc.x, tc.y});
+                const f2v w1 = pk_mul(emd_exp2<FAST>(d2, L1), (f2v){tb.z, tb.w});
                 sum3 += w3.x;
                 sum3 += w3.y;
                 sum1 += w1.x;
                 sum1 += w1.y;
-            }
+            };
+            int q = 0;
+            for (; q + 4 <= npair; q += 4) body(q), body(q + 1), body(q + 2), body(q + 3);
+            for (; q < npair; ++q) body(q);
         } else {
-            const f2v l1 = (f2v)(lev1);
-            for (int q = 0; q < npair; ++q) {
+            auto body = [&](int q) __attribute__((always_inline)) {
                 const float4 ta = tileA[q], tb = tileB[q];
-                const f2v w1 = emd_exp2(l1 * emd_sq2(x1, y1, z1, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y})) * (f2v){tb.z, tb.w};
+                const f2v d2 = emd_sq2(px, py, pz, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y});
+                const f2v w1 = pk_mul(emd_exp2<FAST>(d2, L1), (f2v){tb.z, tb.w});
                 sum1 += w1.x;
                 sum1 += w1.y;
-            }
+            };
+            int q = 0;
+            for (; q + 4 <= npair; q += 4) body(q), body(q + 1), body(q + 2), body(q + 3);
+            for (; q < npair; ++q) body(q);
         }
     }
     float remL = multiL;
@@ -165,6 +224,7 @@ __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, c
 }
 
 // Kernel B(li): thread per xyz2 point l -- pass 2 of level li (tf_approxmatch_g.cu:75-110).
+template <bool FAST>
 __global__ void __launch_bounds__(256) emd_pass_l_kernel(int n, int m, int li, const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2, float *__restrict__ ws)
 {
@@ -182,7 +242,8 @@ __global__ void __launch_bounds__(256) emd_pass_l_kernel(int n, int m, int li, c
     if (l < m) x2 = X2[l * 3 + 0], y2 = X2[l * 3 + 1], z2 = X2[l * 3 + 2];
     float sumr = 0.f;
     float4 *tileA = tile, *tileB = tile + kTile / 2;  // pairs of xyz1 points, as in emd_pass_k_kernel (w = ratioL)
-    const f2v lv = (f2v)(level);
+    const EmdLev Lv = emd_lev(level);
+    const f2v px = splat(x2), py = splat(y2), pz = splat(z2);
     for (int k0 = 0; k0 < n; k0 += kTile) {
         const int kend = min(n, k0 + kTile) - k0, npair = (kend + 1) >> 1;
         __syncthreads();
@@ -194,14 +255,18 @@ __global__ void __launch_bounds__(256) emd_pass_l_kernel(int n, int m, int li, c
             tileB[q] = make_float4(X1[ka * 3 + 2], zb, ratioL[ka], okb ? ratioL[kb] : 0.f);
         }
         __syncthreads();
-        for (int q = 0; q < npair; ++q) {
+        auto body = [&](int q) __attribute__((always_inline)) {
             const float4 ta = tileA[q], tb = tileB[q];
             // (x2 - x1)^2 ...: the pair is the FIRST operand of emd_sq here; squares are sign-symmetric, so the packed form
             // (pair - point) gives the same values
-            const f2v w = emd_exp2(lv * emd_sq2(x2, y2, z2, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y})) * (f2v){tb.z, tb.w};
+            const f2v d2 = emd_sq2(px, py, pz, (f2v){ta.x, ta.y}, (f2v){ta.z, ta.w}, (f2v){tb.x, tb.y});
+            const f2v w = pk_mul(emd_exp2<FAST>(d2, Lv), (f2v){tb.z, tb.w});
             sumr += w.x;
             sumr += w.y;
-        }
+        };
+        int q = 0;
+        for (; q + 4 <= npair; q += 4) body(q), body(q + 1), body(q + 2), body(q + 3);
+        for (; q < npair; ++q) body(q);
     }
     if (l < m) {
         const float rr = remainR[l];
@@ -233,10 +298,12 @@ __global__ void __launch_bounds__(256) emd_materialize_kernel(int n, int m, cons
     for (int l = l0; l < min(m, l0 + 16); ++l) {  // l is block-uniform: scalar loads
         const float d2 = emd_sq(x1, y1, z1, X2[l * 3 + 0], X2[l * 3 + 1], X2[l * 3 + 2]);
         float acc = 0.f;
+        const f2v dd = splat(d2);
 #pragma unroll
         for (int li = 0; li < kLevels; li += 2) {  // two levels per packed issue; the terms still enter acc in level order
-            const f2v lv = {emd_level(li), emd_level(li + 1)};
-            const f2v w = emd_exp2(lv * d2) * (f2v){rl[li], rl[li + 1]} * (f2v){ratioR[(size_t)li * m + l], ratioR[(size_t)(li + 1) * m + l]};
+            const EmdLev L2{(f2v){emd_level(li) * kLog2eHi, emd_level(li + 1) * kLog2eHi}, (f2v){emd_level(li) * kLog2eLo, emd_level(li + 1) * kLog2eLo}};
+            const f2v w = pk_mul(pk_mul(emd_exp2<false>(dd, L2), (f2v){rl[li], rl[li + 1]}),
+                                 (f2v){ratioR[(size_t)li * m + l], ratioR[(size_t)(li + 1) * m + l]});
             acc += w.x;
             acc += w.y;
         }
@@ -355,7 +422,7 @@ __global__ void __launch_bounds__(256) emd_grad2_kernel(int n, int m, const floa
 // LDS tile of the other cloud: per point {x, y, z, pad} + its 10 ratios.
 // ------------------------------------------------------------------------------------------------
 constexpr int kLossTile = 256;
-template <bool KSIDE>
+template <bool KSIDE, bool FAST>
 __global__ void __launch_bounds__(256) emd_loss_sweep_kernel(int n, int m, const float *__restrict__ xyz1,
                                                              const float *__restrict__ xyz2, const float *__restrict__ ws,
                                                              float *__restrict__ partial, float *__restrict__ grad)
@@ -389,25 +456,29 @@ __global__ void __launch_bounds__(256) emd_loss_sweep_kernel(int n, int m, const
             for (int li = 0; li < kLevels; ++li) trat[li][o] = rother[(size_t)li * nother + o0 + o];
         }
         __syncthreads();
-        for (int o = 0; o < oend; ++o) {
+        auto body = [&](int o) __attribute__((always_inline)) {
             const float4 t = tpt[o];
             // emd_sq(x1, x2): (x2 - x1)^2 ... -- sign-symmetric, so one expression serves both sides
             const float ex = xs - t.x, ey = ys - t.y, ez = zs - t.z;  // x_self - x_other: the gradient's direction
             const float d2 = (ex * ex + ey * ey) + ez * ez;
             float mt = 0.f;  // match[l,k], levels in order (as emd_materialize_kernel)
+            const f2v dd = splat(d2);
 #pragma unroll
             for (int li = 0; li < kLevels; li += 2) {
-                const f2v lv = {emd_level(li), emd_level(li + 1)};
+                const EmdLev L2{(f2v){emd_level(li) * kLog2eHi, emd_level(li + 1) * kLog2eHi}, (f2v){emd_level(li) * kLog2eLo, emd_level(li + 1) * kLog2eLo}};
                 const f2v rl = KSIDE ? (f2v){rs[li], rs[li + 1]} : (f2v){trat[li][o], trat[li + 1][o]};
                 const f2v rr = KSIDE ? (f2v){trat[li][o], trat[li + 1][o]} : (f2v){rs[li], rs[li + 1]};
-                const f2v w = emd_exp2(lv * d2) * rl * rr;
+                const f2v w = pk_mul(pk_mul(emd_exp2<FAST>(dd, L2), rl), rr);
                 mt += w.x;
                 mt += w.y;
             }
             if (KSIDE) sub += sqrtf(d2) * mt;  // cost (tf_approxmatch_g.cu:183-213)
             const float g = mt * rsqrtf(fmaxf(d2, 1e-20f));  // (:229-291)
             gx += ex * g, gy += ey * g, gz += ez * g;
-        }
+        };
+        int o = 0;
+        for (; o + 2 <= oend; o += 2) body(o), body(o + 1);
+        for (; o < oend; ++o) body(o);
     }
     if (grad && i < nself) {
         float *go = grad + ((size_t)b * nself + i) * 3;
@@ -429,8 +500,8 @@ using namespace sn;
 
 long long sn_emd_workspace_floats(int b, int n, int m) { return (long long)b * (long long)emd_ws_floats(n, m); }
 
-extern "C" int sn_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
-                              sn_stream_t stream)
+template <bool FAST>
+static int emd_auction(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp, sn_stream_t stream)
 {
     SN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
     if (b == 0 || n == 0 || m == 0) return 0;
@@ -443,14 +514,20 @@ extern "C" int sn_approxmatch(int b, int n, int m, const float *xyz1, const floa
         multiL = (float)(m / n), multiR = 1;
     const dim3 gk((n + 255) / 256, b), gl((m + 255) / 256, b);
     for (int li = 0; li < kLevels; ++li) {
-        hipLaunchKernelGGL(emd_pass_k_kernel, gk, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp, multiL, multiR);
-        hipLaunchKernelGGL(emd_pass_l_kernel, gl, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp);
+        hipLaunchKernelGGL(emd_pass_k_kernel<FAST>, gk, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp, multiL, multiR);
+        hipLaunchKernelGGL(emd_pass_l_kernel<FAST>, gl, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp);
     }
     if (match)
         hipLaunchKernelGGL(emd_materialize_kernel, dim3((n + 255) / 256, (m + 15) / 16, b), dim3(256), 0, st, n, m,
                            xyz1, xyz2, temp, match);
     SN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sn_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                              sn_stream_t stream)
+{
+    return emd_auction<false>(b, n, m, xyz1, xyz2, match, temp, stream);
 }
 
 extern "C" int sn_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
@@ -487,27 +564,45 @@ extern "C" int sn_matchcost_grad(int b, int n, int m, const float *xyz1, const f
 
 // cost (b) = match_cost(approx_match(xyz1, xyz2)) and its gradients without materialising match (see emd_loss_sweep_kernel).
 // temp: sn_workspace_bytes("emd_loss", b, n, m, 0) bytes.  grad1 / grad2 may be NULL.
-extern "C" int sn_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
-                           float *temp, sn_stream_t stream)
+template <bool FAST>
+static int emd_loss_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
+                         float *temp, sn_stream_t stream, const char *who)
 {
-    SN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "negative size");
+    if (!(b >= 0 && n >= 0 && m >= 0)) return sn_set_error(SN_ERR_BAD_ARGUMENT, "%s: negative size", who);
     if (b == 0) return 0;
-    SN_REQUIRE(cost, "null pointer");
+    if (!cost) return sn_set_error(SN_ERR_BAD_ARGUMENT, "%s: null pointer", who);
     hipStream_t st = (hipStream_t)stream;
     if (n == 0 || m == 0) {
         hipError_t e = hipMemsetAsync(cost, 0, sizeof(float) * b, st);
-        return e == hipSuccess ? 0 : sn_set_error((int)e, "sn_emd_loss: %s", hipGetErrorString(e));
+        return e == hipSuccess ? 0 : sn_set_error((int)e, "%s: %s", who, hipGetErrorString(e));
     }
-    SN_REQUIRE(xyz1 && xyz2 && temp, "null pointer");
-    int rc = sn_approxmatch(b, n, m, xyz1, xyz2, nullptr, temp, stream);  // the 20 level passes; no materialisation
+    if (!(xyz1 && xyz2 && temp)) return sn_set_error(SN_ERR_BAD_ARGUMENT, "%s: null pointer", who);
+    int rc = emd_auction<FAST>(b, n, m, xyz1, xyz2, nullptr, temp, stream);  // the 20 level passes; no materialisation
     if (rc) return rc;
     float *partial = temp + sn_emd_workspace_floats(b, n, m);
     const int nparts = (n + 255) / 256;
-    hipLaunchKernelGGL((emd_loss_sweep_kernel<true>), dim3(nparts, b), dim3(256), 0, st, n, m, xyz1, xyz2, temp, partial, grad1);
+    hipLaunchKernelGGL((emd_loss_sweep_kernel<true, FAST>), dim3(nparts, b), dim3(256), 0, st, n, m, xyz1, xyz2, temp, partial, grad1);
     hipLaunchKernelGGL(emd_cost_final_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, nparts, partial, cost);
     if (grad2)
-        hipLaunchKernelGGL((emd_loss_sweep_kernel<false>), dim3((m + 255) / 256, b), dim3(256), 0, st, n, m, xyz1, xyz2, temp,
+        hipLaunchKernelGGL((emd_loss_sweep_kernel<false, FAST>), dim3((m + 255) / 256, b), dim3(256), 0, st, n, m, xyz1, xyz2, temp,
                            (float *)nullptr, grad2);
     SN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int sn_emd_loss(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
+                           float *temp, sn_stream_t stream)
+{
+    (void)hipGetLastError();
+    return emd_loss_impl<false>(b, n, m, xyz1, xyz2, cost, grad1, grad2, temp, stream, "sn_emd_loss");
+}
+
+// The same loss with the reference op's own exponential, __expf = v_exp_f32(x log2 e) (tf_approxmatch_g.cu:52,97,151), in the
+// auction and in the sweeps: the form a training loss wants (1e-5 on the cost); NOT bit-identical to the three-call
+// composition on sn_approxmatch's match, which keeps the compensated exponential for its per-entry bar.
+extern "C" int sn_emd_loss_fast(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1, float *grad2,
+                                float *temp, sn_stream_t stream)
+{
+    (void)hipGetLastError();
+    return emd_loss_impl<true>(b, n, m, xyz1, xyz2, cost, grad1, grad2, temp, stream, "sn_emd_loss_fast");
 }

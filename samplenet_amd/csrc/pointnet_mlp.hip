@@ -1415,12 +1415,10 @@ static void launch_fwd(const FwdArgs &g, hipStream_t st, bool few_rows = false)
         const dim3 grid((Co + 31) / 32, (R + 31) / 32);
         if (lds_ci) {
             const size_t lds = ((size_t)64 * (Ci + 4) + 3 * 16 * 64 + 32 * 36) * sizeof(float);
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute((const void *)small_fwd_lds_kernel<AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)(((size_t)64 * 516 + 3 * 16 * 64 + 32 * 36) * sizeof(float)));
-                attr_done = true;
-            }
+            static SnLdsAttr attr;
+            // (a refused request leaves the error text; the launch then fails and the entry point's launch check reports it)
+            (void)sn_lds_attr(attr, (const void *)small_fwd_lds_kernel<AMODE>, ((size_t)64 * 516 + 3 * 16 * 64 + 32 * 36) * sizeof(float),
+                              "small_fwd_lds_kernel");
             hipLaunchKernelGGL((small_fwd_lds_kernel<AMODE>), grid, dim3(256), lds, st, g);
         } else if (Ci % 64 == 0)
             hipLaunchKernelGGL((small_fwd_kernel<AMODE, true>), dim3((Co + 31) / 32), dim3(256), 0, st, g);
@@ -1543,14 +1541,11 @@ extern "C" int sn_layer_forward_bn(int R, int Ci, int Co, const float *ain, cons
         g.bn = bn;
         g.stats = nullptr;
         const size_t lds = ((size_t)96 * (Ci + 4) + 2 * 3 * 16 * 64 + 64 * 36) * sizeof(float);
-        static bool attr_done[2] = {false, false};
-        const int ai = coef_prev ? 1 : 0;
-        if (!attr_done[ai]) {
-            const int mx = (int)(((size_t)96 * 260 + 2 * 3 * 16 * 64 + 64 * 36) * sizeof(float));
-            if (coef_prev) (void)hipFuncSetAttribute((const void *)rows64_fwd_kernel<ACT_BN_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-            else (void)hipFuncSetAttribute((const void *)rows64_fwd_kernel<ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
-            attr_done[ai] = true;
-        }
+        static SnLdsAttr attr[2];
+        const size_t mx = ((size_t)96 * 260 + 2 * 3 * 16 * 64 + 64 * 36) * sizeof(float);
+        if (sn_lds_attr(attr[coef_prev ? 1 : 0], coef_prev ? (const void *)rows64_fwd_kernel<ACT_BN_RELU> : (const void *)rows64_fwd_kernel<ACT_NONE>,
+                        mx, "rows64_fwd_kernel"))
+            return SN_ERR_UNSUPPORTED;
         if (coef_prev)
             hipLaunchKernelGGL((rows64_fwd_kernel<ACT_BN_RELU>), dim3((Co + 31) / 32), dim3(256), lds, st, g);
         else
@@ -1661,13 +1656,8 @@ template <class TT, int KT, bool IN3A>
 static int launch_fwd_persist(const FwdArgs &g, int ntiles, int tpw, int nwg, hipStream_t st)
 {
     const size_t lds = sizeof(float) * ((size_t)(KT / BKX) * 3 * TT::BM * LDX + 2 * KT + (size_t)2 * TT::WR * 2 * TT::BN + (size_t)TT::WR * TT::WC * 16 * 36);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)linear_fwd_persist_kernel<TT, KT, IN3A, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return sn_set_error(SN_ERR_UNSUPPORTED, "linear_fwd_persist_kernel: %zu bytes of LDS refused", lds);
-        attr_done = true;
-    }
+    static SnLdsAttr attr;
+    if (sn_lds_attr(attr, (const void *)linear_fwd_persist_kernel<TT, KT, IN3A, 2>, lds, "linear_fwd_persist_kernel")) return SN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((linear_fwd_persist_kernel<TT, KT, IN3A, 2>), dim3(nwg), dim3(TT::THREADS), lds, st, g, ntiles, tpw);
     return 0;
 }

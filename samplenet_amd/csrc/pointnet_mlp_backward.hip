@@ -2034,12 +2034,10 @@ template <int CI, int CO, int ZMODE>
 static void launch_conv_bwd_bx3_t(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
 {
     constexpr size_t lds = CbxShape<CI, CO>::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<CI, CO, ZMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<CI, CO, ZMODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    // (a refused request leaves the error text; the launch below then fails and the entry point's launch check reports it)
+    static SnLdsAttr at, af;
+    (void)sn_lds_attr(at, (const void *)conv_bwd_bx3_kernel<CI, CO, ZMODE, true>, lds, "conv_bwd_bx3_kernel");
+    (void)sn_lds_attr(af, (const void *)conv_bwd_bx3_kernel<CI, CO, ZMODE, false>, lds, "conv_bwd_bx3_kernel");
     if (fullr)
         hipLaunchKernelGGL((conv_bwd_bx3_kernel<CI, CO, ZMODE, true>), dim3(G), dim3(512), lds, st, a);
     else
@@ -2052,14 +2050,9 @@ template <int ZMODE, int GZ, int GP, int GW, int DM>
 static void launch_conv_bwd_bx3_half(const ConvBwdArgs &a, int G, bool fullr, hipStream_t st)
 {
     constexpr size_t lds = CbxShape<128, 128>::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<128, 128, ZMODE, true, false, false, GZ, GP, GW, DM>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<128, 128, ZMODE, false, false, false, GZ, GP, GW, DM>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static SnLdsAttr at, af;
+    (void)sn_lds_attr(at, (const void *)conv_bwd_bx3_kernel<128, 128, ZMODE, true, false, false, GZ, GP, GW, DM>, lds, "conv_bwd_bx3_kernel");
+    (void)sn_lds_attr(af, (const void *)conv_bwd_bx3_kernel<128, 128, ZMODE, false, false, false, GZ, GP, GW, DM>, lds, "conv_bwd_bx3_kernel");
     if (fullr)
         hipLaunchKernelGGL((conv_bwd_bx3_kernel<128, 128, ZMODE, true, false, false, GZ, GP, GW, DM>), dim3(G), dim3(512), lds, st, a);
     else
@@ -2075,14 +2068,9 @@ static void launch_conv_bwd_fused_t(const ConvBwdArgs &a, int G, bool fullr, hip
     return;
 #endif
     constexpr size_t lds = CbfShape<CI, CO>::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {  // more than 64 KB of dynamic LDS must be requested explicitly
-        (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<CI, CO, ZMODE, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)conv_bwd_fused_kernel<CI, CO, ZMODE, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static SnLdsAttr at, af;  // more than 64 KB of dynamic LDS must be requested explicitly, per device
+    (void)sn_lds_attr(at, (const void *)conv_bwd_fused_kernel<CI, CO, ZMODE, true>, lds, "conv_bwd_fused_kernel");
+    (void)sn_lds_attr(af, (const void *)conv_bwd_fused_kernel<CI, CO, ZMODE, false>, lds, "conv_bwd_fused_kernel");
     if (fullr)
         hipLaunchKernelGGL((conv_bwd_fused_kernel<CI, CO, ZMODE, true>), dim3(G), dim3(512), lds, st, a);
     else
@@ -2504,12 +2492,9 @@ static void launch_conv_bwd_in3(int R, const float *dy, const float *z, const fl
 #define SN_CBF_IN3 conv_bwd_bx3_kernel
     constexpr size_t lds = CbxShape<64, 64>::LDS_BYTES_IN3;
     if (!zprev) {  // Zprev rebuilt from the cloud (the forward did not materialise it)
-        static bool attr_rz = false;
-        if (!attr_rz) {
-            (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<64, 64, DZ_BN, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void *)conv_bwd_bx3_kernel<64, 64, DZ_BN, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_rz = true;
-        }
+        static SnLdsAttr rt, rf;
+        (void)sn_lds_attr(rt, (const void *)conv_bwd_bx3_kernel<64, 64, DZ_BN, true, true, true>, lds, "conv_bwd_bx3_kernel");
+        (void)sn_lds_attr(rf, (const void *)conv_bwd_bx3_kernel<64, 64, DZ_BN, false, true, true>, lds, "conv_bwd_bx3_kernel");
         if (R % TR == 0)
             hipLaunchKernelGGL((conv_bwd_bx3_kernel<64, 64, DZ_BN, true, true, true>), dim3(G), dim3(512), lds, st, a);
         else
@@ -2520,12 +2505,9 @@ static void launch_conv_bwd_in3(int R, const float *dy, const float *z, const fl
 #define SN_CBF_IN3 conv_bwd_fused_kernel
     constexpr size_t lds = CbfShape<64, 64>::LDS_BYTES_IN3;
 #endif
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)SN_CBF_IN3<64, 64, DZ_BN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)SN_CBF_IN3<64, 64, DZ_BN, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static SnLdsAttr at, af;
+    (void)sn_lds_attr(at, (const void *)SN_CBF_IN3<64, 64, DZ_BN, true, true>, lds, "conv_bwd (xyz layer below)");
+    (void)sn_lds_attr(af, (const void *)SN_CBF_IN3<64, 64, DZ_BN, false, true>, lds, "conv_bwd (xyz layer below)");
     if (R % TR == 0)
         hipLaunchKernelGGL((SN_CBF_IN3<64, 64, DZ_BN, true, true>), dim3(G), dim3(512), lds, st, a);
     else

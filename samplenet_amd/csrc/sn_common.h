@@ -26,6 +26,24 @@ int sn_set_error(int code, const char *fmt, ...);
 
 typedef unsigned long long sn_u64;
 
+// More than 64 KB of dynamic LDS must be requested per kernel with hipFuncSetAttribute -- and the attribute is PER DEVICE: a
+// process that drives several GPUs needs it on each.  One SnLdsAttr per kernel (function-local static): a bit per
+// device ordinal, the request's return code checked.  bytes: the largest dynamic LDS size the kernel is ever launched with.
+struct SnLdsAttr {
+    sn_u64 done = 0;  // (benign race: two threads may both issue the idempotent request)
+};
+inline int sn_lds_attr(SnLdsAttr &a, const void *fn, size_t bytes, const char *who)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const sn_u64 bit = 1ull << (dev & 63);
+    if (a.done & bit) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return sn_set_error(SN_ERR_UNSUPPORTED, "%s: %zu bytes of dynamic LDS refused on device %d (%s)", who, bytes, dev, hipGetErrorString(e));
+    a.done |= bit;
+    return 0;
+}
+
 // spacing (in 32-bit words) of the words of an FC chain launch's `sync` state: word i lives at sync[i * SN_FC_SYNC_STRIDE]
 // (fc_chain.hip: kFcSyncStride; geometry_ops.hip: the step tail reads the error words)
 #ifndef SN_FC_SYNC_STRIDE

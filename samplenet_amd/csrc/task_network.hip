@@ -250,13 +250,10 @@ extern "C" int sn_linear_forward_maxpool_wide(int R, int Ci, int Co, int npts, c
     const bool sz = z != nullptr, arg = argsel != nullptr || sz;
 #define SN_WIDE_LAUNCH(KK, SZ, AR)                                                                                                  \
     do {                                                                                                                            \
-        static bool attr = false;                                                                                                   \
-        if (!attr) {                                                                                                                \
-            if (hipFuncSetAttribute((const void *)linear_fwd_wide_pool_kernel<KK, SZ, AR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)(2 * 3 * kWideBN * (KK + 8) * 2)) != hipSuccess)                                           \
-                return sn_set_error(SN_ERR_UNSUPPORTED, "sn_linear_forward_maxpool_wide: cannot reserve LDS");                      \
-            attr = true;                                                                                                            \
-        }                                                                                                                           \
+        static SnLdsAttr attr;                                                                                                      \
+        if (sn_lds_attr(attr, (const void *)linear_fwd_wide_pool_kernel<KK, SZ, AR>, (size_t)2 * 3 * kWideBN * (KK + 8) * 2,        \
+                        "sn_linear_forward_maxpool_wide"))                                                                          \
+            return SN_ERR_UNSUPPORTED;                                                                                              \
         hipLaunchKernelGGL((linear_fwd_wide_pool_kernel<KK, SZ, AR>), dim3(rb, cs), dim3(512), lds, st, g);                         \
     } while (0)
     if (Ci == 128) {
@@ -511,13 +508,10 @@ extern "C" int sn_pointnet_narrow_forward(int R, const float *x, const float *W1
     }
     NarrowArgs g{x, W1, b1, b2, b3, b4, P2, P3, P4, z1, z2, z3, z4, R, zero_keys, zero_keys ? zero_n : 0};
     const size_t lds = (size_t)(2 * 3 * 64 * 72 + 3 * 128 * 72) * 2 + 64 * 4 * 4 + 4 * 32 * 68 * 4;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void *)pointnet_narrow_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)pointnet_narrow_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pointnet_narrow_forward: cannot reserve LDS");
-        attr = true;
-    }
+    static SnLdsAttr at, af;
+    if (sn_lds_attr(at, (const void *)pointnet_narrow_fwd_kernel<true>, lds, "sn_pointnet_narrow_forward") ||
+        sn_lds_attr(af, (const void *)pointnet_narrow_fwd_kernel<false>, lds, "sn_pointnet_narrow_forward"))
+        return SN_ERR_UNSUPPORTED;
     const dim3 grid((R + kNarrowRows - 1) / kNarrowRows);
     if (z1)
         hipLaunchKernelGGL(pointnet_narrow_fwd_kernel<true>, grid, dim3(256), lds, st, g);
@@ -732,12 +726,8 @@ extern "C" int sn_pointnet_narrow_backward(int R, const float *dz4, const float 
     }
     NarrowBwdArgs g{dz4, z1, z2, z3, W1, Q4, Q3, Q2, dx, R};
     const size_t lds = (size_t)(3 * 64 * 136 + 2 * 3 * 64 * 72) * 2 + 64 * 4 * 4 + 4 * 32 * 68 * 4;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void *)pointnet_narrow_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return sn_set_error(SN_ERR_UNSUPPORTED, "sn_pointnet_narrow_backward: cannot reserve LDS");
-        attr = true;
-    }
+    static SnLdsAttr attr;
+    if (sn_lds_attr(attr, (const void *)pointnet_narrow_bwd_kernel, lds, "sn_pointnet_narrow_backward")) return SN_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pointnet_narrow_bwd_kernel, dim3((R + kNarrowRows - 1) / kNarrowRows), dim3(256), lds, st, g);
     SN_LAUNCH_CHECK();
     return 0;

@@ -716,11 +716,14 @@ match_cost = MatchCostFunction.apply
 
 class EmdLossFunction(torch.autograd.Function):
     """cost (B,) = match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) in one call, WITHOUT the (B,m,n) match matrix
-    (sn_emd_loss): forward runs the auction and one cost / gradient sweep per cloud; backward scales the saved gradients
-    (match is a constant of the gradient, tf_approxmatch.py:54-64)."""
+    (sn_emd_loss / sn_emd_loss_fast): forward runs the auction and one cost / gradient sweep per cloud; backward scales the saved
+    gradients (match is a constant of the gradient, tf_approxmatch.py:54-64).
+    exact=False (default): the reference op's own exponential (__expf = v_exp_f32(x log2 e), tf_approxmatch_g.cu:52,97,151) -- the
+    cost within 1e-5 of the oracle; exact=True: the compensated exponential of approx_match -- cost and the xyz1 gradient bit for
+    bit those of match_cost(approx_match(...))."""
 
     @staticmethod
-    def forward(ctx, xyz1, xyz2):
+    def forward(ctx, xyz1, xyz2, exact=False):
         _need_gpu(xyz1, xyz2)
         x1, x2 = _f32c(xyz1), _f32c(xyz2)
         b, n, _ = x1.shape
@@ -729,9 +732,13 @@ class EmdLossFunction(torch.autograd.Function):
         need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g1 = torch.empty_like(x1) if need1 else None
         g2 = torch.empty_like(x2) if need2 else None
+        # (measured and not kept, round 5: the batch split into 2..8 independent chains of clouds on side streams, to keep the
+        #  chip full across the 21 dependent launches of 1600 equal waves on 1024 SIMDs -- 3.19 -> 4.5 .. 9.0 ms: launches of
+        #  different streams did not overlap on this stack)
+        fn = lib.sn_emd_loss if exact else lib.sn_emd_loss_fast
         ws = torch.empty(max(1, lib.sn_workspace_bytes(b"emd_loss", b, n, m, 0) // 4), device=x1.device, dtype=torch.float32)
         with torch.cuda.device(x1.device):
-            check(lib.sn_emd_loss(b, n, m, ptr(x1), ptr(x2), ptr(cost), ptr(g1), ptr(g2), ptr(ws), _stream(x1)), "sn_emd_loss")
+            check(fn(b, n, m, ptr(x1), ptr(x2), ptr(cost), ptr(g1), ptr(g2), ptr(ws), _stream(x1)), "sn_emd_loss")
         ctx.save_for_backward(g1, g2)
         return cost
 
@@ -739,7 +746,8 @@ class EmdLossFunction(torch.autograd.Function):
     def backward(ctx, grad_cost):
         g1, g2 = ctx.saved_tensors
         gc = grad_cost.reshape(-1, 1, 1)
-        return (g1 * gc if g1 is not None else None), (g2 * gc if g2 is not None else None)
+        return (g1 * gc if g1 is not None else None), (g2 * gc if g2 is not None else None), None
 
 
-emd_loss = EmdLossFunction.apply
+def emd_loss(xyz1, xyz2, exact=False):
+    return EmdLossFunction.apply(xyz1, xyz2, exact)

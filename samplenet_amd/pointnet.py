@@ -446,13 +446,14 @@ class _ForwardPlan:
 
     A plan that a stream CAPTURE ran on has its buffer addresses baked into somebody's graph (engine.SamplerTrainStep, bench's
     graph legs, a user's own torch.cuda.graph around the step): from then on it is `captured` -- never evicted, never dropped
-    as stale, kept alive for the life of the process (_PINNED: a replay of that graph must not touch freed memory, whatever
-    happens to the module's own list), and never handed to an EAGER forward again (an eager step's saved activations would be
+    as stale, kept alive for the life of the MODULE (net._sn_pinned, which survives .to() / dropped plan lists: a replay of that
+    graph must not touch freed memory whatever happens to the module's own list; a graph cannot outlive the module it reads its
+    parameters from, so nothing needs the buffers beyond that -- a process that builds many engines on fresh modules gets
+    the memory back with them: ADVICE r4), and never handed to an EAGER forward again (an eager step's saved activations would be
     overwritten by the next replay of the graph); later captures may share it (the ring of graphs of one engine runs them one
     after the other)."""
 
     kMaxPlans = 4
-    _PINNED = []
     __slots__ = ("key", "busy", "calls", "saved", "sig", "last", "captured")
 
     @staticmethod
@@ -481,7 +482,7 @@ class _ForwardPlan:
                 if plan.sig == sig:
                     if capturing and not plan.captured:
                         plan.captured = True
-                        _ForwardPlan._PINNED.append(plan)
+                        net.__dict__.setdefault("_sn_pinned", []).append(plan)
                     return plan
         if sig is not None:  # stale plans of this shape (parameters were replaced): drop them (a captured one only leaves the list)
             net.__dict__["_sn_plans"] = [q for q in plans if q.sig == sig or q.key != key]

@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_surface.py tests/test_gpu_two_ranks.py tests/test_gpu_headline.py -x -q --timeout 900 2>&1 | tail -30
+echo "## product build (hand-written packed instructions in emd.o, destination disjoint from the sources), two processes"
+timeout 600 python tools/cotenancy_stress.py emd 1500
+echo "## round-3 sources of emd.hip with the COMPILER's packed code (plain -O3), two processes"
+SAMPLENET_AMD_LIB=$PWD/tools/_ab/libsamplenet_hip_emdcpk.so timeout 600 python tools/cotenancy_stress.py emd 1500

@@ -6,8 +6,13 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; SRC=$2; EXTRA=$3
 mkdir -p tools/_ab
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Isamplenet_amd/csrc -Wall -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops"
-case $SRC in pointnet_mlp.hip|pointnet_mlp_backward.hip|fc_chain.hip|task_network.hip|capi_common.cpp) ;; *) F="$F -ffp-contract=off";; esac
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Isamplenet_amd/csrc -Wall -Wno-unused-function"
+NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
+case $SRC in
+  emd.hip) F="$F -ffp-contract=off -fno-slp-vectorize";;   # hand-written packed instructions (see samplenet_amd/build.py)
+  pointnet_mlp.hip|pointnet_mlp_backward.hip|fc_chain.hip|task_network.hip|capi_common.cpp) F="$F $NOPK";;
+  *) F="$F $NOPK -ffp-contract=off";;
+esac
 /opt/rocm/bin/hipcc -x hip -c samplenet_amd/csrc/$SRC -o tools/_ab/${SRC%.*}_$NAME.o $F $EXTRA
 OBJS=""
 for s in capi_common pairscan geometry_ops emd pointnet_mlp pointnet_mlp_backward fc_chain task_network; do

@@ -129,17 +129,19 @@ def run_emd(passes):
     b = (torch.rand(16, 1024, 3, device="cuda", generator=g) - 0.5).requires_grad_(True)
     ref, bad, first = None, 0, None
     for it in range(passes):
-        a.grad = b.grad = None
-        cost = ops.emd_loss(a, b)
-        cost.sum().backward()
-        cur = (cost.detach().clone(), a.grad.clone(), b.grad.clone())
+        cur = ()
+        for exact in (False, True):  # both forms: the reference's own __expf (default) and the compensated exponential
+            a.grad = b.grad = None
+            cost = ops.emd_loss(a, b, exact)
+            cost.sum().backward()
+            cur += (cost.detach().clone(), a.grad.clone(), b.grad.clone())
         if ref is None:
             ref = cur
             continue
         if not all(torch.equal(u, v) for u, v in zip(cur, ref)):
             bad += 1
             if first is None:
-                first = "pass %d: cost / grad1 / grad2 equal %s" % (it, [torch.equal(u, v) for u, v in zip(cur, ref)])
+                first = "pass %d: (cost, grad1, grad2) x (fast, exact) equal %s" % (it, [torch.equal(u, v) for u, v in zip(cur, ref)])
     return bad, first
 
 
