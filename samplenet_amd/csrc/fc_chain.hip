@@ -787,14 +787,12 @@ extern "C" int sn_fc_chain_forward(int R, int C0, int H, int nl, const float *a0
                               z[l], coef[l], eps[l], momentum[l]};
     }
     const size_t lds = fc_chain_fwd_lds(C0, H, nl);
-    {   // (the LDS size depends on the shape: the largest one the layout admits, requested once per device)
-        static SnLdsAttr a0, a1, a2;
-        constexpr size_t kMaxLds = 160 * 1024;
-        if (sn_lds_attr(a0, (const void *)fc_chain_fwd_kernel<128, 3>, kMaxLds, "sn_fc_chain_forward") ||
-            sn_lds_attr(a1, (const void *)fc_chain_fwd_kernel<256, 3>, kMaxLds, "sn_fc_chain_forward") ||
-            sn_lds_attr(a2, (const void *)fc_chain_fwd_kernel<0, 0>, kMaxLds, "sn_fc_chain_forward"))
+    {   // (the LDS size depends on the shape: renewed per device whenever a call needs more than was granted)
+        static SnLdsAttrGrow a0, a1, a2;
+        if (sn_lds_attr_grow(a0, (const void *)fc_chain_fwd_kernel<128, 3>, lds, "sn_fc_chain_forward") ||
+            sn_lds_attr_grow(a1, (const void *)fc_chain_fwd_kernel<256, 3>, lds, "sn_fc_chain_forward") ||
+            sn_lds_attr_grow(a2, (const void *)fc_chain_fwd_kernel<0, 0>, lds, "sn_fc_chain_forward"))
             return SN_ERR_UNSUPPORTED;
-        if (lds > kMaxLds) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_fc_chain_forward: %zu bytes of LDS", lds);
     }
     // 8 x (H / 32) blocks: block b lands on XCD b % 8, the b % 8 == 0 ones do the work -- all on one XCD (same L2)
     g.rinv_rows = 1.0 / (double)R, g.unbias = R > 1 ? (double)R / (double)(R - 1) : 1.0;
@@ -847,8 +845,8 @@ extern "C" int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc,
                               z[l], coef[l], eps[l], momentum[l]};
     }
     const size_t lds = fc_chain_fwd_lds(C0, H, nl);
-    static SnLdsAttr attr;
-    if (sn_lds_attr(attr, (const void *)fc_chain_fwd_kernel<128, 3, true>, lds, "sn_fc_chain_forward_pool")) return SN_ERR_UNSUPPORTED;
+    static SnLdsAttrGrow attr;
+    if (sn_lds_attr_grow(attr, (const void *)fc_chain_fwd_kernel<128, 3, true>, lds, "sn_fc_chain_forward_pool")) return SN_ERR_UNSUPPORTED;
     g.rinv_rows = 1.0 / (double)B, g.unbias = B > 1 ? (double)B / (double)(B - 1) : 1.0;
     hipLaunchKernelGGL((fc_chain_fwd_kernel<128, 3, true>), dim3(8 * (H / 32)), dim3(256), lds, (hipStream_t)stream, g);
     SN_LAUNCH_CHECK();

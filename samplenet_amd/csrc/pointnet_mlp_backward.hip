@@ -765,6 +765,21 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16 *p, int pitch)  // rows r
     return __builtin_bit_cast(bf16x8, v);
 }
 
+#ifndef SN_CBX_PW
+#define SN_CBX_PW 3  // bit 0: the plain layers, bit 1: the layer above the xyz layer (the activation tile rebuilt from the coordinates)
+#endif
+#ifndef SN_CBX_PD
+#define SN_CBX_PD 1  // (2: tile t + 2 of the activation requested while t + 1 waits -- measured SLOWER, 909 -> 1050 us at B = 2048)
+#endif
+#ifndef SN_CBX_DG2
+#define SN_CBX_DG2 0  // (1: two accumulator chains in the data gradient -- measured equal: 939 vs 945 us at B = 2048, 21.3 vs 21.5 at B = 32)
+#endif
+#ifndef SN_CBX_ABL
+#define SN_CBX_ABL 0  // (timing experiments only: 1 no data-gradient MFMAs, 2 no weight-gradient MFMAs / fragment reads, 3 no dYprev stores,
+#endif                //  4 no staging, 5 no data-gradient epilogue -- results are then garbage)
+#ifndef SN_CBX_CONTIG
+#define SN_CBX_CONTIG 0  // (1: a contiguous range of tiles per workgroup -- measured equal to -6 %)
+#endif
 template <int CI, int CO>
 struct CbxShape {
     static constexpr int TR = CO == 128 ? 32 : 64;                  // two tile buffers of three planes must fit the LDS
@@ -781,7 +796,7 @@ struct CbxShape {
 };
 
 // RZ1: rp[q] holds the xyz coordinates of the row; w3 -> the xyz layer's (w0, w1, w2, bias) of this thread's four channels, in LDS
-template <int CO, int CI, int TR, int ZMODE, bool FULLR, int NZ4, int NP4, bool RZ1 = false>
+template <int CO, int CI, int TR, int ZMODE, bool FULLR, int NZ4, int NP4, bool RZ1 = false, bool SKIP_PS = false>
 __device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0, int tid, __bf16 *__restrict__ Zb,
                                           __bf16 *__restrict__ Pb, const float4 (&rz)[NZ4], const float4 (&rdy)[NZ4],
                                           const float4 (&rp)[NP4], const int4 &rag, const float4 &rgs, const float4 &k1,
@@ -816,7 +831,7 @@ __device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0
         stage_split_p<TR * LDZ, LDZ>(Zb, rt, zc4, v);
     }
 #pragma unroll
-    for (int q = 0; q < NP4; ++q) {
+    for (int q = 0; q < (SKIP_PS ? 0 : NP4); ++q) {
         float4 zp = rp[q];
         if (RZ1) {
 #pragma clang fp contract(off)
@@ -839,7 +854,11 @@ __device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0
 //   256 output channels: the passes take dZ columns / W rows [0,128) and [128,256); the data gradient is their SUM -- DM = 1 (first pass)
 //     stores it raw (no ReLU mask, no statistics), DM = 2 (second) adds ConvBwdArgs::dyacc at the fragment positions before the epilogue;
 //   256 input channels: the passes take W / Zprev / dYprev columns [0,128) and [128,256) and are independent (DM = 0).
-template <int CI, int CO, int ZMODE, bool FULLR, bool IN3 = false, bool RZ1 = false, int GZ = CO, int GP = CI, int GW = CI, int DM = 0>
+// PW: the activation tile relu(bn(Zprev)) is fetched, activated, split and staged by the WEIGHT-GRADIENT waves (behind their
+//   MFMAs, where they used to wait ~1.5 us per tile at the barrier for the producer waves: tools/timeline.py bwd), the dZ tile
+//   stays with the data-gradient waves -- the serial chain MFMAs -> epilogue -> staging of those waves loses its Zprev half
+template <int CI, int CO, int ZMODE, bool FULLR, bool IN3 = false, bool RZ1 = false, int GZ = CO, int GP = CI, int GW = CI, int DM = 0,
+          bool PW = (SN_CBX_PW != 0) && (!IN3 || (SN_CBX_PW & 2) != 0)>
 __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 {
     static_assert(DM == 0 || (!IN3 && CbxShape<CI, CO>::KS == 1), "two-pass modes: plain 128 x 128 tiles");
@@ -872,6 +891,12 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
     const int q0 = dwv * NWT;
     const int cob = q0 / NCB;
     const int G = gridDim.x;
+    // the tiles of a workgroup: a contiguous range (SN_CBX_CONTIG: sequential addresses per workgroup) or every G-th one
+    constexpr bool CT = SN_CBX_CONTIG != 0;
+    const int tpw = (g.ntiles + G - 1) / G;
+    const int tile0 = CT ? (int)blockIdx.x * tpw : (int)blockIdx.x;
+    const int tend = CT ? min(g.ntiles, tile0 + tpw) : g.ntiles;
+    const int tst = CT ? 1 : G;
 
     SN_TL(0);
 #ifdef SN_TIMELINE
@@ -918,8 +943,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
         for (int k = 0; k < 9; ++k) mom[k] = 0.f;
         const int tpc = ZMODE == DZ_POOL ? g.dz.npts / TR : 1;
-        const int bstep = G / tpc, tstep = G - bstep * tpc;
-        int cloud = (int)blockIdx.x / tpc, tic = (int)blockIdx.x - cloud * tpc;
+        const int bstep = tst / tpc, tstep = tst - bstep * tpc;
+        int cloud = tile0 / tpc, tic = tile0 - cloud * tpc;
         float4 rz[NZ4], rdy[NZ4], rp[NP4];
         int4 rag = make_int4(0, 0, 0, 0);
         float4 rgs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -941,9 +966,9 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) vout[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-        int tile = blockIdx.x;
-        cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1, GZ, GP>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
-        if (RZ1) load_xyz_rows(tile);
+        int tile = tile0;
+        cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1 || PW, GZ, GP>(rs, tile, cloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+        if (RZ1 && !PW) load_xyz_rows(tile);
         if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)tile * (TR * 12));
         // W^T fragments of this wave's 32 input channels: W[co = 16 kk + 8 h + t][ci = cb 32 + l31] (requested after the first
         // tile: its staging does not wait for them), split below once the first tile is staged
@@ -959,8 +984,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             k2 = *reinterpret_cast<const float4 *>(Ks + CO + zc4);
             k3 = *reinterpret_cast<const float4 *>(Ks + 2 * CO + zc4);
         }
-        cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4, RZ1>(g, tile, tic * TR, tid, Lb, Lb + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3, sc4, sh4,
-                                                           w3s);
+        cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4, RZ1, PW>(g, tile, tic * TR, tid, Lb, Lb + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3, sc4,
+                                                               sh4, w3s);
         if (xthr) Xs[xslot[0]] = rx.x, Xs[xslot[1]] = rx.y, Xs[xslot[2]] = rx.z, Xs[xslot[3]] = rx.w;
         bf16x8 wf[KD][3];
 #pragma unroll
@@ -972,10 +997,10 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 wf[kk][0][t] = h1, wf[kk][1][t] = h2, wf[kk][2][t] = h3;
             }
         __syncthreads();
-        for (int it = 0; tile < g.ntiles; ++it, tile += G) {
+        for (int it = 0; tile < tend; ++it, tile += tst) {
             const __bf16 *Zb = Lb + (it & 1) * BUF;
-            if (!IN3 && it > 0 && kh == 0) {
-                const unsigned oso = (unsigned)(tile - G) * (TR * GP * 4);
+            if (!IN3 && it > 0 && kh == 0 && SN_CBX_ABL != 3) {
+                const unsigned oso = (unsigned)(tile - tst) * (TR * GP * 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * GP * 4));
             }
@@ -988,37 +1013,51 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     pq[e] = buf_load1(rs.dyacc, qvo, (unsigned)tile * (TR * GP * 4) + ((e & 3) + 8 * (e >> 2)) * (GP * 4));
-            const bool more = tile + G < g.ntiles;
-            const int nxt = more ? tile + G : tile;
+            const bool more = tile + tst < tend;
+            const int nxt = more ? tile + tst : tile;
             int ncloud = cloud, ntic = tic;
             if (more) {
                 ncloud += bstep, ntic += tstep;
                 if (ntic >= tpc) ntic -= tpc, ++ncloud;
             }
-            cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1, GZ, GP>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
-            if (RZ1) load_xyz_rows(nxt);
+            cbf_issue_loads<CO, CI, TR, ZMODE, NZ4, NP4, RZ1 || PW, GZ, GP>(rs, nxt, ncloud, zvo, pvo, avo, rz, rdy, rp, rag, rgs);
+            if (RZ1 && !PW) load_xyz_rows(nxt);
             if (xthr) rx = buf_load4(rsx, (unsigned)tid * 16, (unsigned)nxt * (TR * 12));
             // the requests go out HERE: left alone, the scheduler sinks them below the MFMAs to their first use (the staging),
             // and every tile pays a full memory round trip
             __builtin_amdgcn_sched_barrier(0);
             if (it == 1) SN_TL(5);
 
-            f32x16 acc;
+            // two accumulator chains (even / odd k-steps, added at the end): one chain of KD x 6 dependent MFMAs issues at the
+            // accumulator's latency (~70 cycles apiece, 1.4 us per 128-channel tile: tools/timeline.py bwd), not at the pipe's rate
+            f32x16 acc, acc2;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f, acc2[e] = 0.f;
             const __bf16 *ap = Zb + (rb * 32 + l31) * LDZ + kh * KD * 16 + 8 * h;
 #pragma unroll
-            for (int kk = 0; kk < KD; ++kk) {
+            for (int kk = 0; kk < (SN_CBX_ABL == 1 ? 0 : KD); ++kk) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(ap + kk * 16);
                 const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(ap + ZPL + kk * 16);
                 const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(ap + 2 * ZPL + kk * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[kk][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][0], acc, 0, 0, 0);
+                if (SN_CBX_DG2 && (kk & 1)) {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][2], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[kk][0], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][1], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][1], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][0], acc2, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][0], acc2, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[kk][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][0], acc, 0, 0, 0);
+                }
             }
+            if (SN_CBX_DG2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
             if (it == 1) SN_TL(1);
             if (KS == 2) {  // the upper K range's partial tile joins the lower one's through the upper wave's scratch
                 float *Tx = Tf + (dwv | 1) * (32 * 36);
@@ -1030,7 +1069,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[e] += Tx[e * 64 + lane];
             }
-            if (kh == 0) {
+            if (kh == 0 && SN_CBX_ABL != 5) {
             if (RZ1) {  // Zprev at the fragment positions from the tile's coordinates in LDS (rows 4 q .. 4 q + 3 of a fragment are consecutive)
 #pragma clang fp contract(off)  // bit for bit the stored tensor: the bias add must not fuse with what consumes z below
                 const float4 wd = W3s[cb * 32 + l31];
@@ -1086,10 +1125,10 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             }
             }
             if (it == 1) SN_TL(2);
-            if (more) {
+            if (more && SN_CBX_ABL != 4) {
                 __bf16 *Zn = Lb + ((it + 1) & 1) * BUF;
-                cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4, RZ1>(g, nxt, ntic * TR, tid, Zn, Zn + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2, k3,
-                                                                   sc4, sh4, w3s);
+                cbx_stage<CO, CI, TR, ZMODE, FULLR, NZ4, NP4, RZ1, PW>(g, nxt, ntic * TR, tid, Zn, Zn + 3 * ZPL, rz, rdy, rp, rag, rgs, k1, k2,
+                                                                       k3, sc4, sh4, w3s);
                 if (xthr) {
                     float *Xn = Xs + ((it + 1) & 1) * (3 * TR);
                     Xn[xslot[0]] = rx.x, Xn[xslot[1]] = rx.y, Xn[xslot[2]] = rx.z, Xn[xslot[3]] = rx.w;
@@ -1101,8 +1140,8 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             if (it == 1) SN_TL(4);
         }
         SN_TL(6);
-        if (!IN3 && tile != (int)blockIdx.x && kh == 0) {
-            const unsigned oso = (unsigned)(tile - G) * (TR * GP * 4);
+        if (!IN3 && tile != tile0 && kh == 0) {
+            const unsigned oso = (unsigned)(tile - tst) * (TR * GP * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * GP * 4));
         }
@@ -1131,6 +1170,58 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         }
     } else {
         // ---------------- weight-gradient waves ----------------------------------------------------------
+        // (PW) this thread's part of the Zprev tile: 4 channels x NP4 rows, as the producer waves map theirs
+        constexpr int PSTEPW = 256 / (CI / 4);
+        const int tw = tid - 256;
+        const int pc4w = (tw % (CI / 4)) * 4, prw = tw / (CI / 4);
+        const unsigned pvow = (prw * GP + pc4w) * 4;
+        const sn_rsrc rzp = make_rsrc(g.zprev, (unsigned)R * GP * 4);
+        // two register sets: tile t + 2 is requested while tile t + 1 waits to be staged (the kernel moves ~48 KB per tile and CU;
+        // with one tile in flight per CU the chip's HBM latency x bytes-in-flight product tops out near 3.6 TB/s)
+        constexpr int PD = SN_CBX_PD;
+        float4 rpw[PD][NP4];
+        float4 scw = make_float4(0.f, 0.f, 0.f, 0.f), shw = scw;
+        // RZ1: the rows' coordinates (12 bytes per row) in place of the Zprev tile, and the xyz layer's (w0, w1, w2, bias) of this
+        // thread's four channels in registers (the weight-gradient waves of this layer hold one accumulator tile: room to spare)
+        const sn_rsrc rsxw = make_rsrc(IN3 ? (const void *)g.xin : (const void *)g.dz.z, (unsigned)R * 12);
+        const unsigned xvow = prw * 12;
+        float4 w3w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w3w[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PW && RZ1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w3w[j] = make_float4(g.w_in[(pc4w + j) * 3], g.w_in[(pc4w + j) * 3 + 1], g.w_in[(pc4w + j) * 3 + 2], g.b_in ? g.b_in[pc4w + j] : 0.f);
+        }
+        auto load_p = [&](int t, int s) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < NP4; ++q)
+                rpw[s][q] = RZ1 ? buf_load3(rsxw, xvow, (unsigned)t * (TR * 12) + q * (PSTEPW * 12))
+                                : buf_load4(rzp, pvow, (unsigned)t * (TR * GP * 4) + q * (PSTEPW * GP * 4));
+        };
+        auto stage_p = [&](__bf16 *Pb, int s) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < NP4; ++q) {
+                float4 zp = rpw[s][q];
+                if (RZ1) {  // the xyz kernel's own expression, bit for bit (cbx_stage's RZ1 branch)
+#pragma clang fp contract(off)
+                    const float x0 = rpw[s][q].x, x1 = rpw[s][q].y, x2 = rpw[s][q].z;
+                    zp.x = fmaf(w3w[0].z, x2, fmaf(w3w[0].y, x1, w3w[0].x * x0)) + w3w[0].w;
+                    zp.y = fmaf(w3w[1].z, x2, fmaf(w3w[1].y, x1, w3w[1].x * x0)) + w3w[1].w;
+                    zp.z = fmaf(w3w[2].z, x2, fmaf(w3w[2].y, x1, w3w[2].x * x0)) + w3w[2].w;
+                    zp.w = fmaf(w3w[3].z, x2, fmaf(w3w[3].y, x1, w3w[3].x * x0)) + w3w[3].w;
+                }
+                const float4 a = make_float4(relu_np(fmaf(zp.x, scw.x, shw.x)), relu_np(fmaf(zp.y, scw.y, shw.y)),
+                                             relu_np(fmaf(zp.z, scw.z, shw.z)), relu_np(fmaf(zp.w, scw.w, shw.w)));
+                stage_split_p<TR * LDP, LDP>(Pb, prw + q * PSTEPW, pc4w, a);
+            }
+        };
+        if (PW) {
+            load_p(tile0, 0);
+            if (PD == 2) load_p(min(tile0 + tst, g.ntiles - 1), 1);
+            scw = *reinterpret_cast<const float4 *>(g.scale_prev + pc4w);
+            shw = *reinterpret_cast<const float4 *>(g.shift_prev + pc4w);
+        }
         if (ZMODE == DZ_BN && g.acc_in != nullptr) {
             float *Ks = Tf;
             const int c = tid - 256;
@@ -1154,23 +1245,44 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         for (int n = 0; n < NWT; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) accw[n][e] = 0.f;
+        if (PW) stage_p(Lb + 3 * ZPL, 0);
         __syncthreads();
         // transposing reads: this lane's row / channel offsets inside a [16 rows][32 channels] fragment block
         const int trr = 8 * h + ((lane & 15) >> 2), trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-        int tile = blockIdx.x;
-        for (int it = 0; tile < g.ntiles; ++it, tile += G) {
+        int tile = tile0;
+        for (int it = 0; tile < tend; ++it, tile += tst) {
             const __bf16 *Zb = Lb + (it & 1) * BUF, *Pb = Zb + 3 * ZPL;
+            const bool more = tile + tst < tend;
+            if (PW) {
+                // (PD == 2: set (it + 1) % 2 holds the next tile already; the set this tile's staging freed takes the one after)
+                if (PD == 2) {
+                    if (it & 1) load_p(min(tile + 2 * tst, g.ntiles - 1), 1); else load_p(min(tile + 2 * tst, g.ntiles - 1), 0);
+                } else {
+                    load_p(more ? tile + tst : tile, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (the requests leave before the MFMAs, not next to the staging behind them)
+            }
             const __bf16 *ap = Zb + trr * LDZ + cob * 32 + trc;
             const __bf16 *bp = Pb + trr * LDP + trc;
-#pragma unroll
-            for (int kk = 0; kk < KW; ++kk) {
-                bf16x8 a[3], b[3][NWT];
+            // fragments of k-step kk + 1 are requested BEFORE the MFMAs of k-step kk and the scheduler is held to that order: left
+            // alone it interleaved a few transposing reads with a few MFMAs, each group behind its own wait (five to six exposed
+            // LDS round trips per k-step; the weight-gradient waves took 2.7 us for 48 MFMAs that occupy the pipe for 0.64 us)
+            bf16x8 fa[2][3], fb[2][3][NWT];
+            auto frag_load = [&](int kk, int s) __attribute__((always_inline)) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    a[p] = lds_tr8(ap + p * ZPL + kk * 16 * LDZ, LDZ);
+                    fa[s][p] = lds_tr8(ap + p * ZPL + kk * 16 * LDZ, LDZ);
 #pragma unroll
-                    for (int n = 0; n < NWT; ++n) b[p][n] = lds_tr8(bp + p * PPL + kk * 16 * LDP + ((q0 + n) % NCB) * 32, LDP);
+                    for (int n = 0; n < NWT; ++n) fb[s][p][n] = lds_tr8(bp + p * PPL + kk * 16 * LDP + ((q0 + n) % NCB) * 32, LDP);
                 }
+            };
+            if (SN_CBX_ABL != 2) frag_load(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < (SN_CBX_ABL == 2 ? 0 : KW); ++kk) {
+                if (kk + 1 < KW) frag_load(kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8(&a)[3] = fa[kk & 1];
+                const bf16x8(&b)[3][NWT] = fb[kk & 1];
 #define SN_BX3_TERM(PA, PB) \
     _Pragma("unroll") for (int n = 0; n < NWT; ++n) accw[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB][n], accw[n], 0, 0, 0)
                 SN_BX3_TERM(0, 2);
@@ -1180,9 +1292,14 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 SN_BX3_TERM(1, 0);
                 SN_BX3_TERM(0, 0);
 #undef SN_BX3_TERM
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (it == 1) SN_TL(1);
             if (KS == 2) __syncthreads();  // (the dgrad waves' partial-tile hand-off)
+            if (PW && more && SN_CBX_ABL != 4) {
+                if (PD == 2 && !(it & 1)) stage_p(Lb + ((it + 1) & 1) * BUF + 3 * ZPL, 1);
+                else stage_p(Lb + ((it + 1) & 1) * BUF + 3 * ZPL, 0);
+            }
             __syncthreads();
             if (it == 1) SN_TL(4);
         }

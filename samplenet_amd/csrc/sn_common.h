@@ -43,6 +43,22 @@ inline int sn_lds_attr(SnLdsAttr &a, const void *fn, size_t bytes, const char *w
     a.done |= bit;
     return 0;
 }
+// the same for a kernel whose LDS size depends on the call's shape: the request is renewed whenever a call needs more than this
+// device has been granted so far
+struct SnLdsAttrGrow {
+    size_t got[64] = {};
+};
+inline int sn_lds_attr_grow(SnLdsAttrGrow &a, const void *fn, size_t bytes, const char *who)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    size_t &g = a.got[dev & 63];
+    if (bytes <= g) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return sn_set_error(SN_ERR_UNSUPPORTED, "%s: %zu bytes of dynamic LDS refused on device %d (%s)", who, bytes, dev, hipGetErrorString(e));
+    g = bytes;
+    return 0;
+}
 
 // spacing (in 32-bit words) of the words of an FC chain launch's `sync` state: word i lives at sync[i * SN_FC_SYNC_STRIDE]
 // (fc_chain.hip: kFcSyncStride; geometry_ops.hip: the step tail reads the error words)

@@ -242,7 +242,7 @@ if __name__ == "__main__":
     lib.sn_debug_timeline.argtypes = [vp, i, i]
     lib.sn_linear_forward.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp, vp]
     lib.sn_linear_backward.argtypes = [i, i, i, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp]
-    R = 32 * 1024
+    R = int(os.environ.get("TL_BATCH", "32")) * 1024
     if len(sys.argv) > 1 and sys.argv[1] == "small":
         small_fwd(32, 256, 256)
         small_fwd(32, 128, 256)
@@ -259,6 +259,6 @@ if __name__ == "__main__":
         fwd(R, 64, 64)
         fwd(R, 64, 128)
         fwd(R, 128, 128)
-    bwd(R, 64, 64, 1)
-    bwd(R, 64, 128, 1)
-    bwd(R, 128, 128, 2)
+    bwd(R, 64, 64, 1, B=R // 1024)
+    bwd(R, 64, 128, 1, B=R // 1024)
+    bwd(R, 128, 128, 2, B=R // 1024)
