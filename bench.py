@@ -63,8 +63,11 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+ROUNDS = ("r05", "r04", "r03", "r02", "r01")
+
+
 def profile_dir():
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ROUNDS:
         d = os.path.join(ROOT, "profiles", rnd)
         if os.path.exists(os.path.join(d, "bench_graph_kernel_stats.csv")):
             return rnd, d
@@ -73,7 +76,7 @@ def profile_dir():
 
 def _profile_file(name):
     """The newest committed profiles/rNN/<name> (None if no round holds it)."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ROUNDS:
         path = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(path):
             return path
@@ -117,7 +120,22 @@ def longest_kernel_of_profile():
     return name[:name.index("(")] if "(" in name else name, float(best["AverageNs"]) / 1e3, max(1, round(int(best["Calls"]) / steps))
 
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.29 TB/s measured by a float4 copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (spec)
+HBM_ACHIEVABLE_GBS = 6290.0  # ... of which a float4 copy reaches 6.29 TB/s (same guide): reported beside the spec in every HBM block
+
+
+def hbm_block(gbs, **more):
+    """An HBM roofline block: fraction of the spec peak (`frac`, the contract's field) and of what a copy kernel reaches."""
+    d = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "peak_achievable": HBM_ACHIEVABLE_GBS, "frac_achievable": gbs / HBM_ACHIEVABLE_GBS}
+    d.update(more)
+    return d
+
+
+def step_algorithmic_bytes(B, N=1024):
+    # SURVEY.md 8d per cloud: activations written once forward + read once backward (2 x 448 ch x N x 4 B), the cloud (12 N), the
+    # geometry's 50,688 B (soft projection + Chamfer, forward + backward) -- 3.73 MB at N = 1024
+    return (2 * 448 * N * 4 + 12 * N + 50_688) * B
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz (dense fp32 matrix peak)
 # The conv-stack GEMMs compute fp32 products as six bf16 products of three-way split operands on the bf16 matrix cores
 # (mlp_device.h gemm_tile_bx3 / pointnet_mlp_backward.hip conv_bwd_bx3_kernel): their matrix-pipe ceiling is the dense bf16 peak / 6
@@ -460,8 +478,9 @@ def time_config3_emd(dev, reps=5):
     """BASELINE configs[3] (ShapeNet reconstruction, EMD loss): B = 50 clouds, approx_match / match_cost between the 2048-point
     reconstruction and its 2048-point target (reconstruction/src/samplenet_pointnet_ae.py:118-131; kernels
     classification/structural_losses/tf_approxmatch_g.cu).  Two forms, forward + gradients:
-      emd_loss   -- sn_emd_loss: the auction + two sweeps that re-evaluate match from the per-level ratio vectors; the
-                    (B, 2048, 2048) match matrix (839 MB) is never written;
+      emd_loss   -- ops.emd_loss = sn_emd_loss_fast: the auction + two sweeps that re-evaluate match from the per-level ratio vectors
+                    with the reference op's own __expf (v_exp_f32); the (B, 2048, 2048) match matrix (839 MB) is never written
+                    (`emd_loss_exact`: the same with approx_match's compensated exponential, bit-identical to three_call's cost);
       three_call -- approx_match -> match_cost -> its gradient, the reference's op sequence (match written once, read twice).
     Roofs: HBM on SURVEY 8d's algorithmic bytes (3 x 16.78 MB per cloud: the materialised form's minimum) and VALU issue --
     the kernels are exponential-bound: 3 exp per pair and level x 10 levels + 10 (three_call) or 2 x 10 (emd_loss) per pair;
@@ -486,6 +505,7 @@ def time_config3_emd(dev, reps=5):
         return e0.elapsed_time(e1) / reps
 
     t_fused = timed(lambda: torch.autograd.grad(ops.emd_loss(a, b).sum(), [a, b]))
+    t_exact = timed(lambda: torch.autograd.grad(ops.emd_loss(a, b, True).sum(), [a, b]))
     t_three = timed(lambda: torch.autograd.grad(ops.match_cost(a, b, ops.approx_match(a, b)).sum(), [a, b]))
     t_match = timed(lambda: ops.approx_match(a, b))
     pairs = float(B) * n * m
@@ -502,12 +522,12 @@ def time_config3_emd(dev, reps=5):
         lane_ops = pairs * (exps * (5.0 / 3.0) + 10 * 3 * 9.0 + 10.0)  # exps + ~9 packed-pair VALU slots per pair, level and pass
         gbs = alg / (ms * 1e-3) / 1e9
         out[name] = {"ms": ms, "clouds_per_s": B / (ms * 1e-3),
-                     "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                  "algorithmic_bytes": alg, "traffic": pmc_traffic_sum(traffic_key),
-                                  "note": "SURVEY 8d's minimum for the materialised form; emd_loss moves no match matrix at all"},
+                     "roofline": hbm_block(gbs, algorithmic_bytes=alg, traffic=pmc_traffic_sum(traffic_key),
+                                           note="SURVEY 8d's minimum for the materialised form; emd_loss moves no match matrix at all"),
                      "valu_issue": {"exp_per_pair": exps, "model_lane_ops": lane_ops, "achieved_lane_ops_per_s": lane_ops / (ms * 1e-3),
                                     "peak_lane_ops_per_s": valu_peak, "frac": lane_ops / (ms * 1e-3) / valu_peak,
                                     "valu_busy_profiled": (sq or {}).get(name)}}
+    out["emd_loss_exact"] = {"ms": t_exact, "clouds_per_s": B / (t_exact * 1e-3)}
     out["approx_match_only_ms"] = t_match
     return out
 
@@ -617,10 +637,11 @@ def time_batch_sweep(dev, N, M, K, batches=(32, 48, 96, 128, 512, 2048)):
         ms, loss = _wall_ms(lambda: st(x), max(20, min(300, int(6400 / B))))
         assert torch.isfinite(loss).item()
         flop = 3 * 2 * 33_964_032 * B
-        byts = (2 * 448 * N * 4 + 12 * N + 50_688) * B
+        byts = step_algorithmic_bytes(B, N)
         out.append({"batch": B, "ms_per_step": ms, "clouds_per_s": B / ms * 1e3, "fused_single_node_step": bool(st._fast_path()),
                     "mfma_frac_fp32_peak": flop / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                    "hbm_frac_algorithmic": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                    "hbm_frac_algorithmic": byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "hbm_frac_algorithmic_of_achievable": byts / (ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS})
         del st, net
     return out
 
@@ -652,7 +673,7 @@ def time_fc_chain_backward(net, x, reps=20, inner=20):
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/: FETCH_SIZE x 2 + WRITE_SIZE, KiB, as
     MI355X_MICROARCH.md prescribes for gfx950), or None when no profile of that kernel is on disk."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ROUNDS:
         path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
         try:
             with open(path) as f:
@@ -662,6 +683,20 @@ def pmc_traffic(kernel_prefix):
         for name, row in table.items():
             if kernel_prefix in name and "hbm_traffic_bytes_per_launch" in row:
                 return row["hbm_traffic_bytes_per_launch"]
+    return None
+
+
+def pmc_traffic_step():
+    """Sum over the step's kernels of the committed PMC traffic per launch (one launch each per step at B = 32), or None."""
+    for rnd in ROUNDS:
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")) as f:
+                table = json.load(f)
+        except OSError:
+            continue
+        tot = sum(row.get("hbm_traffic_bytes_per_launch", 0.0) for row in table.values())
+        if tot > 0:
+            return tot
     return None
 
 
@@ -807,14 +842,37 @@ def main():
             if lname.startswith("fc_chain_bwd_kernel") and B <= 32:
                 fms, fbytes, fflop = time_fc_chain_backward(net, pool[0])
                 fg, ft = fbytes / (fms * 1e-3) / 1e9, fflop / (fms * 1e-3) / 1e12
-                longest_out.update({"bound": "hbm", "achieved": fg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fg / HBM_PEAK_GBS,
-                                    "avg_launch_ms": fms, "algorithmic_bytes_per_launch": fbytes,
+                longest_out.update(hbm_block(fg))
+                longest_out.update({"avg_launch_ms": fms, "algorithmic_bytes_per_launch": fbytes,
                                     "algorithmic_flop_per_launch": fflop, "traffic": pmc_traffic("fc_chain_bwd_kernel"),
                                     "mfma": {"achieved": ft, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ft / MFMA_F32_PEAK_TFLOPS},
                                     "note": "a dependency chain (4 GEMM stages of 32 rows handed between 8 workgroups inside one "
                                             "launch): bound by hand-off latency, not by either roof"})
             elif lname.startswith("conv_bwd_bx3_kernel<128, 128"):
                 longest_out["same_as"] = "roofline"
+        heaviest = {"kernel": "sn::conv_bwd_bx3_kernel<128,128,DZ_POOL> (conv5 backward: dgrad + wgrad; fp32 products as "
+                              "six bf16 MFMAs of three-way split operands)",
+                    "bound": "hbm" if conv_hbm_bound else "mfma",
+                    "achieved": conv_gbs if conv_hbm_bound else conv_tf,
+                    "peak": HBM_PEAK_GBS if conv_hbm_bound else MFMA_SPLIT_BF16_PEAK_TFLOPS,
+                    "unit": "GB/s" if conv_hbm_bound else "TFLOP/s",
+                    "frac": conv_gbs / HBM_PEAK_GBS if conv_hbm_bound else conv_tf / MFMA_SPLIT_BF16_PEAK_TFLOPS,
+                    "traffic": pmc_traffic("conv_bwd_bx3_kernel<128, 128"),
+                    "algorithmic_bytes_per_launch": conv_bytes, "algorithmic_flop_per_launch": conv_flop,
+                    "avg_launch_ms": conv_ms,
+                    "hbm": hbm_block(conv_gbs),
+                    "mfma": {"achieved": conv_tf, "peak": MFMA_SPLIT_BF16_PEAK_TFLOPS, "unit": "fp32-equivalent TFLOP/s",
+                             "frac": conv_tf / MFMA_SPLIT_BF16_PEAK_TFLOPS,
+                             "vs_fp32_mfma_peak": conv_tf / MFMA_F32_PEAK_TFLOPS},
+                    "note": "the heaviest kernel (most bytes and flops of any launch); matrix ceiling = dense bf16 MFMA peak / 6 "
+                            "products (tools/micro/bf16x3_gemm.hip: 392 fp32-equivalent TFLOP/s measured, 155 for the fp32 MFMA)"}
+        if longest_out is not None and "frac" in longest_out:
+            roofline_main = dict(longest_out, role="the longest kernel of the step (largest per-step time in %s)" % prov["dir"])
+        elif longest_out is not None and longest_out.get("same_as") == "roofline":
+            roofline_main = dict(heaviest, role="the longest kernel of the step per %s = the heaviest one" % prov["dir"])
+        else:
+            roofline_main = dict(heaviest, role="the heaviest kernel of the step (no live probe for the profile's longest kernel %r)"
+                                 % (longest_out or {}).get("kernel"))
         out = {
             "metric": "point-clouds/sec fwd+bwd, Bx1024->64 soft-proj+Chamfer",
             "value": value, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -829,32 +887,23 @@ def main():
                        "execution": "eager launches" if args.no_graph else "whole step replayed as one hipGraph",
                        "mlp": "hand-written MFMA kernels: conv stack = fp32 via split-bf16 products (fp32-accurate), FC head = fp32 MFMA"},
             "profile": prov,
-            # the heaviest GEMM kernel of the step (most flops and most bytes of any launch): backward of the last 1x1 convolution.
-            # Both roofs are reported; "bound" names the nearer one.
-            "roofline": {"kernel": "sn::conv_bwd_bx3_kernel<128,128,DZ_POOL> (conv5 backward: dgrad + wgrad; fp32 products as "
-                                   "six bf16 MFMAs of three-way split operands)",
-                         "bound": "hbm" if conv_hbm_bound else "mfma",
-                         "achieved": conv_gbs if conv_hbm_bound else conv_tf,
-                         "peak": HBM_PEAK_GBS if conv_hbm_bound else MFMA_SPLIT_BF16_PEAK_TFLOPS,
-                         "unit": "GB/s" if conv_hbm_bound else "TFLOP/s",
-                         "frac": conv_gbs / HBM_PEAK_GBS if conv_hbm_bound else conv_tf / MFMA_SPLIT_BF16_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("conv_bwd_bx3_kernel<128, 128"),
-                         "algorithmic_bytes_per_launch": conv_bytes, "algorithmic_flop_per_launch": conv_flop,
-                         "avg_launch_ms": conv_ms,
-                         "hbm": {"achieved": conv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": conv_gbs / HBM_PEAK_GBS},
-                         "mfma": {"achieved": conv_tf, "peak": MFMA_SPLIT_BF16_PEAK_TFLOPS, "unit": "fp32-equivalent TFLOP/s",
-                                  "frac": conv_tf / MFMA_SPLIT_BF16_PEAK_TFLOPS,
-                                  "vs_fp32_mfma_peak": conv_tf / MFMA_F32_PEAK_TFLOPS},
-                         "note": "the heaviest kernel (most bytes and flops of any launch); matrix ceiling = dense bf16 MFMA peak / 6 "
-                                 "products (tools/micro/bf16x3_gemm.hip: 392 fp32-equivalent TFLOP/s measured, 155 for the fp32 MFMA)"},
+            # `roofline`: the kernel with the LARGEST per-step time in the committed profile (the honest one -- a
+            # latency chain far below either roof), measured live; the heaviest kernel and the whole step follow under their own keys
+            "roofline": roofline_main,
             "roofline_longest": longest_out,
+            # the heaviest GEMM kernel of the step (most flops and most bytes of any launch): backward of the last 1x1 convolution;
+            # both roofs, "bound" names the nearer one
+            "roofline_heaviest": heaviest,
+            # the whole step on SURVEY 8d's algorithmic bytes (launch gaps and the dependency chain are in the denominator)
+            "roofline_step": hbm_block(step_algorithmic_bytes(B, N) / (ms * 1e-3) / 1e9, algorithmic_bytes_per_step=step_algorithmic_bytes(B, N),
+                                       traffic=pmc_traffic_step() if B == 32 else None, ms_per_step=ms,
+                                       note="SURVEY 8d's bytes (3.73 MB per cloud) over the step time; traffic = sum of the committed "
+                                            "PMC passes over the step's 14 kernels at B = 32"),
             # the geometric kernel of the path (SURVEY 8d's per-cloud byte count applies to it)
-            "roofline_geometry": {"kernel": "sn::pairscan_kernel<16,true,true> (kNN + soft projection + both Chamfer directions)",
-                                  "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("pairscan_kernel<16"),
-                                  "algorithmic_bytes_per_launch": alg, "avg_launch_ms": kern_ms,
-                                  "saturating_batch": {"batch": Bsat, "achieved": sat_gbs, "frac": sat_gbs / HBM_PEAK_GBS,
-                                                       "clouds_per_s": Bsat / (sat_ms * 1e-3), "avg_launch_ms": sat_ms}},
+            "roofline_geometry": hbm_block(achieved, kernel="sn::pairscan_kernel<16,true,true> (kNN + soft projection + both Chamfer directions)",
+                                           traffic=pmc_traffic("pairscan_kernel<16"), algorithmic_bytes_per_launch=alg, avg_launch_ms=kern_ms,
+                                           saturating_batch=hbm_block(sat_gbs, batch=Bsat, clouds_per_s=Bsat / (sat_ms * 1e-3),
+                                                                      avg_launch_ms=sat_ms)),
             # the whole step against the fp32 matrix peak: MLP flops per step / step time (the geometric and scalar kernels, the
             # launch gaps and the dependency chain are all in the denominator)
             "step_mfma": {"flop_per_step": step_flop, "achieved": step_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -882,6 +931,11 @@ def main():
             leg("config3_sampler", time_config3_sampler, dev)
             leg("config5_progressive", time_config5_progressive, dev)
             leg("batch_sweep", time_batch_sweep, dev, N, M, K)
+            if isinstance(out.get("batch_sweep"), list):  # (the driver's `parsed` keeps top-level keys only)
+                for row in out["batch_sweep"]:
+                    if row["batch"] in (512, 2048):
+                        out["b%d_clouds_per_s" % row["batch"]] = row["clouds_per_s"]
+                        out["b%d_hbm_frac_algorithmic" % row["batch"]] = row["hbm_frac_algorithmic"]
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_reference_model import time_cpu_baseline
 
@@ -889,12 +943,11 @@ def main():
             # the port against the TRUE reference module, timed side by side in the build container (tools/time_reference_cpu.py;
             # /root/reference does not exist on the GPU box) -- throughput ratio port / reference on the same step, same numbers
             try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04",
-                                       "cpu_baseline_reference_vs_port.json")) as f:
+                with open(_profile_file("cpu_baseline_reference_vs_port.json")) as f:
                     legs = json.load(f)["legs"]
                 out["cpu_baseline"]["port_over_reference_module"] = {k: round(v["port_over_reference_throughput"], 3) for k, v in legs.items()}
                 out["cpu_baseline"]["pinned_by"] = "tests/test_oracle.py::test_cpu_baseline_port_matches_reference_run"
-            except (OSError, KeyError, ValueError):
+            except (OSError, KeyError, ValueError, TypeError):
                 pass
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

@@ -29,7 +29,7 @@ FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch
 FUSE_NARROW = True         # conv1..conv4 (3 -> 64 -> 64 -> 64 -> 128) as one launch (sn_pointnet_narrow_forward)
 WIDE_MAXPOOL = True        # ... as the wide kernel (A fragments resident, pre-split weight planes) where the shape allows
 FUSED_HEAD = True          # quaternion normalisation + regulariser as one launch (sn_pcrnet_head_*), else the torch op chain
-FUSED_TRUNK = True         # FC trunk on <= 128 rows through sn_skinny_linear (forward, data gradient) + sn_skinny_wgrad (a trainable trunk), else torch.nn.Linear
+FUSED_TRUNK = True         # FC trunk through sn_skinny_linear (forward, data gradient) + sn_skinny_wgrad (a trainable trunk), row blocks of <= 128; False: torch.nn.Linear (A/B, tests)
 SPARSE_POOL_DGRAD = True   # last layer's data gradient from the one non-zero per cloud and channel (sn_pool_dgrad_sparse)
 
 _CONST = {}  # (rows, channels, device) -> constant coefficient table, built once (never written afterwards)
@@ -371,6 +371,21 @@ class _TrunkFunction(torch.autograd.Function):
         return (g0, g1) + tuple(wgrads)
 
 
+TRUNK_ROWS = 128  # rows of one trunk pass (sn_skinny_linear multiplies the weight fragments with up to four 32-row tiles)
+
+
+def _trunk(f0, f1, wb):
+    """The FC trunk on any number of rows: blocks of TRUNK_ROWS rows, one _TrunkFunction pass each (the weights are streamed once
+    per block: 15.5 MB against ~1 MFLOP per row -- above a few hundred rows a tile GEMM would win, but nothing on the path gets
+    there: registration/main.py evaluates the network on batches of 32); per-row arithmetic does not depend on the blocking, so
+    the outputs are bit-identical to separate evaluations of the blocks; weight gradients of a trainable trunk are the blocks'
+    gradients added up by autograd in block order."""
+    R = f0.shape[0]
+    if R <= TRUNK_ROWS:
+        return _TrunkFunction.apply(f0, f1, *wb)
+    return torch.cat([_TrunkFunction.apply(f0[a:a + TRUNK_ROWS], f1[a:a + TRUNK_ROWS], *wb) for a in range(0, R, TRUNK_ROWS)], dim=0)
+
+
 class _HeadFunction(torch.autograd.Function):
     """y (B,7) -> twist (B,7) = [normalize(y[:, 0:4]) | y[:, 4:7]], quat (B,4) = the normalised quaternion as its own contiguous
     tensor (for the rotation: no slice / copy launches, no zero-padded slice gradient), qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2
@@ -406,9 +421,9 @@ class PCRNet(nn.Module):
     """Drop-in for `registration/models/pcrnet.py:44-82` (same constructor, attribute and parameter names -> state_dict
     compatible, same `forward(x0, x1) -> (twist (B,7), pre_normalized_quat (B,4))`): the two feature extractions run on the
     HIP MLP kernels (`PointNetFeatures` above, the 99 % of the network's arithmetic); the six-layer FC trunk on B rows runs on
-    `sn_skinny_linear` (forward and data gradient) on up to 128 rows -- frozen as in the sampler's training step, or trainable
-    (main.py --train-pcrnet: weight / bias gradients on `sn_skinny_wgrad`) -- and as plain library GEMMs (torch.nn.Linear ->
-    rocBLAS) above that; the output head is one launch each way (`sn_pcrnet_head_*`)."""
+    `sn_skinny_linear` (forward and data gradient) in row blocks of up to 128 -- frozen as in the sampler's training step, or
+    trainable (main.py --train-pcrnet: weight / bias gradients on `sn_skinny_wgrad`); no library GEMM (rocBLAS) on the GPU path at
+    any batch; the output head is one launch each way (`sn_pcrnet_head_*`)."""
 
     def __init__(self, bottleneck_size=1024, input_shape="bcn"):
         super().__init__()
@@ -482,12 +497,12 @@ class PCRNet(nn.Module):
         (twist, pre_normalized_quat, qnorm, quat).  feat0: template_features(x0), computed by the caller (x0 is then unused)."""
         f0, f1 = (self.feat(x0) if feat0 is None else feat0), self.feat(x1)
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
-        if FUSED_TRUNK and f0.is_cuda and f0.shape[0] <= 128 and f0.shape[1] % 8 == 0:
+        if FUSED_TRUNK and f0.is_cuda and f0.shape[1] % 8 == 0:
             wb = []
             for fc in fcs:
                 wb += [fc.weight, fc.bias]
-            y = _TrunkFunction.apply(f0, f1, *wb)  # (B, 7)
-        else:
+            y = _trunk(f0, f1, wb)  # (B, 7)
+        else:  # (CPU tensors, feature widths that are not a multiple of 8, FUSED_TRUNK switched off: the plain torch layers)
             y = torch.cat([f0, f1], dim=1)
             for fc in fcs[:-1]:
                 y = torch.relu(fc(y))

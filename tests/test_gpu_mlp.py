@@ -1497,16 +1497,28 @@ def test_persistent_forward_is_bit_identical(B, N):
         assert torch.equal(ba, bb), n
 
 
-@pytest.mark.parametrize("B", [32, 5, 100])
+@pytest.mark.parametrize("B", [32, 5, 100, 200, 300])
 def test_trainable_pcrnet_trunk_stays_on_the_library(B):
     """registration/models/pcrnet.py:62-82 under main.py --train-pcrnet: with a TRAINABLE FC trunk the six layers still run on
     sn_skinny_linear (forward, data gradient) and their weight / bias gradients on sn_skinny_wgrad -- against the torch.nn.Linear
     route (rocBLAS) on the same weights: twist 1e-5, every gradient of the trunk and the gradient that reaches both clouds within
-    1e-4 of its norm; deterministic from run to run."""
+    1e-4 of its norm; deterministic from run to run.  Above 128 rows the trunk runs in row blocks of 128 (no
+    torch.nn.Linear / rocBLAS on the GPU path at any batch)."""
     import copy
 
     from samplenet_amd import task_features as tf
 
+    if B > 128:  # the route must be the library's, not a silent torch fallback
+        calls = []
+        orig = tf._TrunkFunction.apply
+        try:
+            tf._TrunkFunction.apply = staticmethod(lambda *a: (calls.append(a[0].shape[0]), orig(*a))[1])
+            m = tf.PCRNet(bottleneck_size=1024, input_shape="bnc").cuda().eval()
+            with torch.no_grad():
+                m(torch.rand(B, 64, 3, device="cuda"), torch.rand(B, 64, 3, device="cuda"))
+        finally:
+            tf._TrunkFunction.apply = orig
+        assert sum(calls) == B and max(calls) <= 128 and len(calls) == (B + 127) // 128, calls
     torch.manual_seed(B)
     net = tf.PCRNet(bottleneck_size=1024, input_shape="bnc").cuda().train()
     for p in net.feat.parameters():
