@@ -574,7 +574,9 @@ def time_config5_progressive(dev, steps=40):
     """BASELINE configs[4] on one GPU (per-rank work of the DP job): progressive SampleNet 1024 -> {32, 64, 128, 256} + the PCRNet
     registration task (classification/train_samplenet_progressive.py:157-234 for the prefix semantics, registration/main.py:
     507-531,557-577 for the task): the largest set sampled and projected once, the task network fed every prefix of the
-    projected points, simplification loss summed over the prefixes; B = 32.  Eager and captured."""
+    projected points, simplification loss summed over the prefixes; B = 32.  `eager` = as a script issues it: the sampler's calls on
+    the captured module surface (the prefix losses' gradient on the simplified cloud is an operand of its backward graph), the frozen
+    task network's four evaluations on graphed.py's graphs, the prefix losses as launches; `graph` = the whole step captured by hand."""
     from samplenet_amd import SampleNetProgressive
     from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss_multi
 
@@ -594,8 +596,8 @@ def time_config5_progressive(dev, steps=40):
         simp, proj = net(x)
         loss = 0.01 * net.get_progressive_simplification_loss(x, simp, 1, 0, "sum") + 0.01 * net.get_projection_loss()
         # the four evaluations share the template cloud: its extractor pass runs once, and the trunk once on all 4 x 32 rows
-        f0 = pcr.template_features(template)
-        for task, _, _ in pcrnet_chamfer_loss_multi(pcr, template, [net.prefix(proj, s) for s in sizes], template_features=f0):
+        # (the frozen network's whole call -- extractor, trunk, heads, rotations, Chamfer terms -- replays captured graphs: graphed.py)
+        for task, _, _ in pcrnet_chamfer_loss_multi(pcr, template, [net.prefix(proj, s) for s in sizes]):
             loss = loss + task
         loss.backward()
         return loss

@@ -172,7 +172,8 @@ def call(owner, tag, fn, args):
     dev = None
     any_grad = False
     for a in args:
-        if not isinstance(a, torch.Tensor) or not a.is_cuda or (dev is not None and a.device != dev) or not a.is_contiguous():
+        # (views are fine -- prefixes of a projected cloud: the arguments are copied into the graphs' static inputs anyway)
+        if not isinstance(a, torch.Tensor) or not a.is_cuda or (dev is not None and a.device != dev):
             return None
         dev = a.device
         any_grad = any_grad or a.requires_grad

@@ -14,7 +14,7 @@ running minimum over the queries in index order, emitted at each prefix end).
 """
 import torch
 
-from . import ops
+from . import ops, surface
 from .samplenet import SampleNet
 
 
@@ -42,7 +42,9 @@ class SampleNetProgressive(SampleNet):
         super().__init__(sizes[-1], bottleneck_size, group_size, **kw)
         self.sizes = sizes
         self.name = "samplenet_progressive"
-        self.graph_surface = False  # the prefix losses hang off slices of the simplified cloud and reuse forward()'s scan
+        # the prefix losses hang off slices of the simplified cloud: the captured surface takes their gradient as an operand of its
+        # backward graph (surface.py: with_simp) from the first capture on
+        self.__dict__["_sn_surface_simp_grad"] = True
 
     def prefix(self, pc, size):
         """The first `size` points of a (B,M,3) ['bnc'] or (B,3,M) ['bcn'] cloud in the module's output layout."""
@@ -69,7 +71,12 @@ class SampleNetProgressive(SampleNet):
         d2, i2 = ops.prefix_point_minima(ref_pc, samp_pc, self.sizes)
         total = None
         for j, s in enumerate(self.sizes):
-            if s == M and scan is not None and not ref_pc.requires_grad:
+            live = None
+            if s == M and self.__dict__.get("_sn_surface_live"):  # the full size: the captured forward's own L_simp output
+                live = surface.simplification_loss(self, ref_pc, samp_pc, gamma + delta * s)
+            if live is not None:
+                term = live
+            elif s == M and scan is not None and not ref_pc.requires_grad:
                 term = self.get_simplification_loss(ref_pc, samp_pc, s, gamma, delta)  # hangs off the head's (B,3,M) output
             else:
                 sl = samp_pc[:, :s, :].contiguous()

@@ -140,7 +140,8 @@ def _hyper(net):
     train / eval flag of every sub-module, the gradient sink (a FlatGradAllReducer's) the backward graph writes."""
     pr = net.project
     return (net.num_out_points, pr._group_size, pr._min_sigma_f, tuple([m.training for m in net._modules.values()]),
-            id(net.__dict__.get("_grad_sink")), bool(net.__dict__.get("surface_static_outputs", False)))
+            id(net.__dict__.get("_grad_sink")), bool(net.__dict__.get("surface_static_outputs", False)),
+            bool(net.__dict__.get("_sn_surface_simp_grad", False)))
 
 
 class _Guard:
@@ -201,10 +202,15 @@ class _Plan:
         self.sink = net.__dict__.get("_grad_sink")
         self.reducer = getattr(self.sink, "reducer", None) if self.sink is not None else None
         self.static_out = bool(net.__dict__.get("surface_static_outputs", False))
+        # a loss that hangs off the simplified cloud itself (the progressive sampler's prefix losses, a script's own Chamfer on
+        # simp): its gradient enters the backward graph as one more static operand, added to the loss kernel's dL/dQ
+        self.with_simp = bool(net.__dict__.get("_sn_surface_simp_grad", False))
+        self.up_simp_dirty = False
         with torch.cuda.device(dev):
             self.x = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
             self.up_scalars = torch.zeros(2, device=dev, dtype=torch.float32)
             self.up_proj = torch.zeros(B, M, 3, device=dev, dtype=torch.float32)
+            self.up_simp = torch.zeros(B, M, 3, device=dev, dtype=torch.float32) if self.with_simp else None
             self.keys = torch.zeros(B * N, device=dev, dtype=torch.int64)
             # one block for everything the script receives: [simp (B,M,3) | proj (B,M,3) | values (8)], sections 256-byte aligned
             sec = (B * M * 3 + 63) // 64 * 64
@@ -275,6 +281,8 @@ class _Plan:
         res = ops.step_loss_backward(self.x, self.y, T, self.state, cfg, self.up_scalars[0:1], self.t_sink, blob, self.up_proj,
                                      grad_sigma=self.up_scalars[1:2])
         gQ = res[0]
+        if self.with_simp:
+            gQ = torch.add(gQ, self.up_simp.permute(0, 2, 1))  # (B,3,M): + the script's own gradient on the simplified cloud
         grads = pointnet.backward_impl(net, self.saved, gQ.view(B, -1), self.views, None, step_tail=blob)
         missing = [n for n in self.views if grads.get(n) is not self.views[n]]
         if missing:
@@ -423,7 +431,20 @@ class _SurfaceFunction(torch.autograd.Function):
                 g_lsimp = ops._f32c(g_lsimp)
             if g_sigma is not None:
                 g_sigma = ops._f32c(g_sigma)
-            if g_simp is None and ctx.weight is None:
+            if g_simp is not None and not plan.with_simp:
+                # first sight of a gradient on the simplified cloud: this step runs the launches eagerly (below); the next
+                # forward captures graphs that take it as an operand (no warm steps: the configuration is known)
+                net.__dict__["_sn_surface_simp_grad"] = True
+                for cfg in net.__dict__.get("_sn_surface", {}).values():
+                    cfg.plans, cfg.seen, cfg.contended = [], WARM_STEPS, 0
+            if (g_simp is None or plan.with_simp) and ctx.weight is None:
+                if plan.with_simp:
+                    if g_simp is not None:
+                        plan.up_simp.copy_(ops._f32c(g_simp), non_blocking=True)
+                        plan.up_simp_dirty = True
+                    elif plan.up_simp_dirty:
+                        plan.up_simp.zero_()
+                        plan.up_simp_dirty = False
                 check(lib.sn_surface_gather_upstream(B * M * 3, ptr(g_lsimp), ptr(g_sigma), ptr(g_proj), ptr(plan.up_scalars),
                                                      ptr(plan.up_proj), st), "sn_surface_gather_upstream")
                 if plan.reducer is not None:

@@ -519,10 +519,27 @@ class PCRNet(nn.Module):
 def pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features=None):
     """pcrnet_chamfer_loss for several source clouds against one template, the network evaluated by model.forward_multi (one
     trunk pass for all of them).  -> list of (chamfer_loss, qnorm_loss, twist)."""
-    from .ops import chamfer_mean_loss
-
     if not hasattr(model, "forward_multi"):
         return [pcrnet_chamfer_loss(model, p0, p1, template_features) for p1 in p1_list]
+    if template_features is None and isinstance(model, nn.Module) and len(p1_list) > 1:
+        # a frozen network: template extractor + the E evaluations + their losses replay two captured graphs (graphed.py)
+        from . import graphed
+
+        E = len(p1_list)
+
+        def flat(a, *ps):
+            res = _pcrnet_chamfer_loss_multi(model, a, list(ps), None)
+            return tuple(t for triple in res for t in triple)
+
+        got = graphed.call(model, "pcrnet_chamfer_loss_multi%d" % E, flat, (p0,) + tuple(p1_list))
+        if got is not None:
+            return [tuple(got[3 * e:3 * e + 3]) for e in range(E)]
+    return _pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features)
+
+
+def _pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features):
+    from .ops import chamfer_mean_loss
+
     out = []
     for p1, (twist, _pre, qnorm, quat) in zip(p1_list, model.forward_multi(p0, p1_list, feat0=template_features)):
         p1_est = qrot_cloud(quat, p0)

@@ -551,3 +551,61 @@ def test_frozen_task_network_with_the_sampler_attached_replays_graphs():
         (ALPHA * a.get_simplification_loss(x, simp, M, 1.0, 0.0) + LMBDA * a.get_projection_loss() + task).backward()
     held = [v for v in model.__dict__.get("_sn_graphed", {}).values() if isinstance(v, graphed._Plan)]
     assert held, "the task network's call stayed op by op although every parameter it reads is frozen"
+
+
+def test_progressive_sampler_on_the_captured_surface():
+    """VERDICT r4 #6 (configs[4]): SampleNetProgressive through the captured surface -- the prefix losses hang off slices of the
+    simplified cloud, whose gradient is one more static operand of the backward graph (plan.with_simp); the frozen task network's
+    four prefix evaluations replay graphed.py's graphs.  Against the same script on the op-by-op surface."""
+    import copy
+
+    from samplenet_amd import SampleNetProgressive, graphed
+    from samplenet_amd.task_features import PCRNet, pcrnet_chamfer_loss_multi
+
+    sizes = [8, 16, 32, 64]
+    torch.manual_seed(11)
+    a = SampleNetProgressive(sizes, 128, group_size=K, input_shape="bnc", output_shape="bnc").cuda().train()
+    b = copy.deepcopy(a)
+    b.graph_surface = False
+    pcr = PCRNet(bottleneck_size=1024, input_shape="bnc").cuda().eval()
+    pcr.requires_grad_(False)
+    pcr_b = copy.deepcopy(pcr)
+    pcr_b.graph_surface = False
+    g = torch.Generator(device="cuda").manual_seed(5)
+    template = torch.rand(B, N, 3, device="cuda", generator=g) - 0.5
+    xs = _batches(6, seed=21)
+
+    def step(net, model, x):
+        _clear(net)
+        simp, proj = net(x)
+        loss = ALPHA * net.get_progressive_simplification_loss(x, simp, 1, 0, "sum") + LMBDA * net.get_projection_loss()
+        for task, _, _ in pcrnet_chamfer_loss_multi(model, template, [net.prefix(proj, s) for s in sizes]):
+            loss = loss + task
+        loss.backward()
+        return loss.detach().clone(), simp.detach().clone()
+
+    for x in xs:
+        la, sa = step(a, pcr, x)
+        lb, sb = step(b, pcr_b, x)
+        torch.testing.assert_close(sa, sb, rtol=0, atol=2e-6)
+        assert abs(float(la) - float(lb)) <= 2e-5 * max(1.0, abs(float(lb))), (float(la), float(lb))
+        assert not _grad_mismatch(a, b, exact=False)
+    plan = _plan(a)
+    assert plan is not None and plan.with_simp
+    assert any(isinstance(v, graphed._Plan) for v in pcr.__dict__.get("_sn_graphed", {}).values())
+    assert _plan(b) is None
+
+
+def test_gradient_on_the_simplified_cloud_becomes_a_captured_operand():
+    """A script's own loss on `simp` (here: its mean square) reaches the captured backward as a static operand from the first
+    recapture on; every step equals the op-by-op surface."""
+    a, b = _nets(8)
+    xs = _batches(7, seed=22)
+    for i, x in enumerate(xs):
+        _clear(a), _clear(b)
+        ra = _script_step(a, x, task=lambda simp, proj: proj.mean() + 0.5 * (simp * simp).mean())
+        rb = _script_step(b, x, task=lambda simp, proj: proj.mean() + 0.5 * (simp * simp).mean())
+        _outputs_match(ra, rb, exact=False)
+        assert not _grad_mismatch(a, b, exact=False), i
+    plan = _plan(a)
+    assert plan is not None and plan.with_simp and plan.up_simp_dirty
