@@ -567,6 +567,25 @@ def time_config3_sampler(dev, steps=40):
         assert torch.isfinite(loss).item(), name
         out[name] = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "point-clouds/s", "fast_path": bool(st._fast_path())}
         del st, rep
+    # the same step as an unmodified script issues it (net(x), the two getters, backward()): on the captured module surface
+    # since round 5 (surface.py: the sampler variants outside the registration architecture)
+    import copy
+
+    from samplenet_amd import surface
+
+    rep = copy.deepcopy(net)
+
+    def script():
+        for p in rep.parameters():
+            p.grad = None
+        simp, proj = rep(x)
+        loss = 0.01 * rep.get_simplification_loss(x, simp, M, 1.0, 0.0) + 0.01 * rep.get_projection_loss() + proj.mean()
+        loss.backward()
+        return loss
+
+    ms, loss = _wall_ms(script, max(steps, 100))
+    assert torch.isfinite(loss).item()
+    out["script"] = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "point-clouds/s", "captured_surface": bool(surface.plans(rep))}
     return out
 
 

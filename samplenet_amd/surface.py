@@ -139,7 +139,7 @@ def _hyper(net):
     """Everything a plan's graphs have baked in besides tensors: the projection's hyper-parameters, the output size, the
     train / eval flag of every sub-module, the gradient sink (a FlatGradAllReducer's) the backward graph writes."""
     pr = net.project
-    return (net.num_out_points, pr._group_size, pr._min_sigma_f, tuple([m.training for m in net._modules.values()]),
+    return (net.num_out_points, pr._group_size, pr._min_sigma_f, pr._temperature_floor, tuple([m.training for m in net._modules.values()]),
             id(net.__dict__.get("_grad_sink")), bool(net.__dict__.get("surface_static_outputs", False)),
             bool(net.__dict__.get("_sn_surface_simp_grad", False)))
 
@@ -255,10 +255,17 @@ class _Plan:
         B, N, M, K = self.shape
         x = self.x
         _, saved = pointnet.forward_impl(net, x, True, skip_last=True, use_plan=False)
-        fc4 = net.fc4
+        fc4 = getattr(net, "fc%d" % net.num_fc_layers)  # the head's output layer (fc4 of the registration architecture)
         T = net.project._temperature
         self.y = torch.empty(B, 3, M, device=self.dev, dtype=torch.float32)
-        fc = (saved["zf"][2], saved["cf"][2], fc4.weight.detach(), fc4.bias.detach())
+        # (the reconstruction variant squares max(T, floor): the clamped value is a static tensor of the forward graph, its
+        #  gradient gate a launch of the backward graph)
+        floor = net.project._temperature_floor
+        self.t_eff = None
+        if floor is not None:
+            self.t_eff = torch.clamp(T.detach(), min=floor)
+            T = self.t_eff
+        fc = (saved["zf"][-1], saved["cf"][-1], fc4.weight.detach(), fc4.bias.detach())
         sec = self.out_sec
         self.simp = self.outbuf[0:B * M * 3].view(B, M, 3)
         self.values = self.outbuf[2 * sec:2 * sec + 8]
@@ -273,7 +280,7 @@ class _Plan:
 
     def _backward_body(self, net):
         B, N, M, K = self.shape
-        T = net.project._temperature
+        T = net.project._temperature if self.t_eff is None else self.t_eff
         blob = None
         if pointnet.conv_stack_backward_supported(net, B, N):
             blob = ctypes.create_string_buffer(lib.sn_step_tail_bytes())
@@ -287,6 +294,8 @@ class _Plan:
         missing = [n for n in self.views if grads.get(n) is not self.views[n]]
         if missing:
             raise RuntimeError("surface: the backward did not write %s into the gradient bucket" % missing[:3])
+        if self.t_eff is not None:  # d max(T, floor) / dT
+            self.t_sink.mul_((net.project._temperature.detach().reshape(1) >= net.project._temperature_floor).to(torch.float32))
         if self.collective_in_graph:
             self.reducer._all_reduce_mean(self.reducer.flat)  # captured: RCCL's kernel replays as the graph's last node
         self.bwd_keep = (res, grads)
@@ -463,9 +472,11 @@ class _SurfaceFunction(torch.autograd.Function):
                 gs = g_sigma.reshape(1) if g_sigma is not None else zero
                 gp = g_proj if g_proj is not None else torch.zeros(B, M, 3, device=plan.dev)
                 w = plan.weight if ctx.weight is None else ctx.weight
-                res = ops.step_loss_backward(plan.x, plan.y, T, plan.state, (K, plan.min_sigma, 1.0, 0.0, w), gl, None, None, gp,
-                                             grad_sigma=gs)
+                res = ops.step_loss_backward(plan.x, plan.y, T if plan.t_eff is None else plan.t_eff, plan.state,
+                                             (K, plan.min_sigma, 1.0, 0.0, w), gl, None, None, gp, grad_sigma=gs)
                 gQ, gT = res[0], res[1]
+                if plan.t_eff is not None:
+                    gT = gT * (T.detach().reshape(gT.shape) >= net.project._temperature_floor).to(gT.dtype)
                 if g_simp is not None:
                     gQ = gQ + ops._f32c(g_simp).permute(0, 2, 1)
                 grads = pointnet.backward_impl(net, plan.saved, gQ.reshape(B, -1).contiguous(), None, None)
@@ -485,7 +496,9 @@ class _SurfaceFunction(torch.autograd.Function):
 
 
 def _supported(net, x):
-    if not (getattr(net, "graph_surface", True) and net.use_hip_mlp and getattr(net, "standard_arch", False)) or net.skip_projection:
+    if not (getattr(net, "graph_surface", True) and net.use_hip_mlp) or net.skip_projection:
+        return False
+    if not getattr(net, "standard_arch", False) and not _variant_ok(net):
         return False
     if net.input_shape != "bnc" or net.output_shape != "bnc":
         return False
@@ -510,6 +523,18 @@ def _supported(net, x):
     if why is not None:
         return _fallback(net, why)
     return True
+
+
+def _variant_ok(net):
+    """The sampler variants of the TF packages besides the registration architecture: any conv / FC widths and FC layers without
+    BatchNorm (reconstruction/src/samplers.py:23-38) run the same launches -- the MLP entry points are generic over the layer
+    list, the scan computes its queries from the last hidden layer whatever its width.  Not the classification sampler: its
+    BatchNorm on the head's OUTPUT (samplenet_model.py:30-108) needs all clouds' queries before any scan can start."""
+    ok = net.__dict__.get("_sn_variant_ok")
+    if ok is None:
+        _, fcs = pointnet._layers(net)
+        ok = net.__dict__["_sn_variant_ok"] = bool(len(fcs) >= 2 and fcs[-1].bn is None and fcs[-2].Co % 4 == 0)
+    return ok
 
 
 def autograd_listeners(net):
@@ -581,7 +606,7 @@ def _build(net, x):
     T = net.project._temperature
     params = pointnet.param_list(net)
     ok = (external_task_supported(net, x) and all(p.requires_grad for p in params) and T.dim() == 0 and
-          all(L.bn is not None and L.bn.momentum is not None and L.bn.track_running_stats
+          all(L.bn is None or (L.bn.momentum is not None and L.bn.track_running_stats)
               for L in sum(pointnet._layers(net), [])[:-1]))
     sink = net.__dict__.get("_grad_sink")
     if ok and sink is not None:  # every gradient the backward graph writes must be a view of the reducer's bucket

@@ -609,3 +609,37 @@ def test_gradient_on_the_simplified_cloud_becomes_a_captured_operand():
         assert not _grad_mismatch(a, b, exact=False), i
     plan = _plan(a)
     assert plan is not None and plan.with_simp and plan.up_simp_dirty
+
+
+@pytest.mark.parametrize("variant", ["reconstruction", "narrow_head"])
+def test_sampler_variants_run_on_the_captured_surface(variant):
+    """the surface outside the registration architecture -- the reconstruction sampler (reconstruction/src/
+    samplers.py:23-38: conv 64-128-128-256, two FC layers WITHOUT BatchNorm, sigma = max(T, 1e-2)^2) and a head with other widths
+    -- replays captured graphs; against the same script on the op-by-op surface, incl. a temperature below its floor (gradient
+    gate of the clamp)."""
+    import copy
+
+    from samplenet_amd import SampleNet, surface
+
+    torch.manual_seed(17)
+    if variant == "reconstruction":
+        a = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc", conv_widths=(64, 128, 128, 256), fc_widths=(256, 256),
+                      fc_batchnorm=False, temperature_floor=1e-2, min_sigma=0.0).cuda().train()
+    else:
+        a = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc", fc_widths=(128, 256)).cuda().train()
+    b = copy.deepcopy(a)
+    b.graph_surface = False
+    assert not a.standard_arch
+    xs = _batches(7, seed=31)
+    for i, x in enumerate(xs):
+        if variant == "reconstruction" and i == 5:  # below the floor: sigma = floor^2, no gradient to the temperature
+            with torch.no_grad():
+                a.project._temperature.fill_(5e-3), b.project._temperature.fill_(5e-3)
+        _clear(a), _clear(b)
+        ra, rb = _script_step(a, x), _script_step(b, x)
+        _outputs_match(ra, rb, exact=False)
+        assert not _grad_mismatch(a, b, "step %d" % i, exact=False)
+        if variant == "reconstruction" and i >= 5:
+            assert float(a.project._temperature.grad.abs()) == 0.0 and float(b.project._temperature.grad.abs()) == 0.0
+    assert _plan(a) is not None and len(surface.plans(a)) >= 1
+    _same_buffers(a, b)

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_surface.py tests/test_gpu_samplenet.py tests/test_gpu_headline.py tests/test_gpu_two_ranks.py -x -q --timeout 900 2>&1 | tail -15
+python bench.py --steps 100 --warmup 20 --no-cpu-baseline --only-leg config3_sampler 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(json.dumps(d.get('config3_sampler'))[:900])"
