@@ -1,2 +1,4 @@
-cd $GRAFT_REPO_ROOT
-python bench.py --steps 100 --warmup 20 --no-cpu-baseline --only-leg config3_sampler 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(json.dumps(d.get('config3_sampler'))[:900])"
+cd $GRAFT_REPO_ROOT/tools/micro
+echo "## two processes, destination pair = a source pair"; (./pk_fma_cotenancy alias 3000 & ./pk_fma_cotenancy alias 3000; wait)
+echo "## two processes, destination disjoint from the sources"; (./pk_fma_cotenancy plain 3000 & ./pk_fma_cotenancy plain 3000; wait)
+echo "## one process alone, aliasing form"; ./pk_fma_cotenancy alias 3000

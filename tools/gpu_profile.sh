@@ -1,9 +1,9 @@
-# Round-end measurement bundle (run as: gpurun --timeout 1500 -- 'bash tools/gpu_profile.sh r04'): bench JSON (all legs), bench with the RCCL
+# Round-end measurement bundle (run as: gpurun --timeout 2400 -- 'bash tools/gpu_profile.sh r05'): bench JSON (all legs), bench with the RCCL
 # collective forced at world size 1 (inside the graph / after it), rocprofv3 kernel stats (graph replay and eager launches), PMC
 # passes for HBM traffic (FETCH_SIZE / WRITE_SIZE in their own runs), SQ counters of the forward GEMMs, of the fused conv
 # backward and of the EMD forms, the pair-scan batch sweep, the EMD timings, the FC-chain phase timeline, the task network's
 # kernel stats.  Everything lands in gpurun_out/<round>/ -- copy what is to be judged into profiles/<round>/.
-R=${1:-r04}
+R=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -64,6 +64,21 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_A
   cp /tmp/sqb_$i/p_counter_collection.csv $OUT/sq_bwd_$i.csv 2>/dev/null || tail -5 /tmp/sqb_$i.log
 done
 cd $GRAFT_REPO_ROOT
+# HBM counters of the whole step at the saturating batches (VERDICT r4 missing #4)
+bash tools/gpu_pmc_batch.sh $R 2048 512 > $OUT/pmc_batch.log 2>&1
+# results must not depend on what else runs on the GPU: two processes at once, and the stand-alone packed-fma probe
+{
+  echo "# tools/cotenancy_stress.py on one MI355X: two processes at once (parent + child), every pass compared with the process's first pass bit for bit"
+  echo "## product build (compiler-packed fp32 off; emd.o: hand-written packed instructions, destinations disjoint from their sources)"
+  timeout 300 python tools/cotenancy_stress.py fwd 8000 2>&1 | grep cotenancy_stress
+  timeout 300 python tools/cotenancy_stress.py step 200 2>&1 | grep cotenancy_stress
+  timeout 300 python tools/cotenancy_stress.py emd 6000 2>&1 | grep cotenancy_stress
+  if [ -x tools/micro/pk_fma_cotenancy ]; then
+    echo "## tools/micro/pk_fma_cotenancy (stand-alone: v_pk_fma_f32 with destination = source pair, exact-integer recurrence, every lane checked)"
+    (cd tools/micro; ./pk_fma_cotenancy alias 3000 & ./pk_fma_cotenancy alias 3000; wait)
+    (cd tools/micro; ./pk_fma_cotenancy plain 3000 & ./pk_fma_cotenancy plain 3000; wait)
+  fi
+} > $OUT/cotenancy_stress.txt 2>&1
 python tools/summarize_emd.py $OUT $OUT 3
 # the bench line last, against THIS run's kernel stats: assemble profiles/<round>/ on the box first so that the line's
 # roofline_longest / profile.stale fields refer to the profile it is committed with

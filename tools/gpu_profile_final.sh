@@ -1,0 +1,58 @@
+# Round-end measurement bundle, hard-bounded (run as: gpurun --timeout 900 -- 'bash tools/gpu_profile_final.sh r05'): every step under
+# `timeout -s KILL` (round 5 lost 38 GPU-minutes to a rocprofv3 pass that ignored SIGTERM), the most important artefacts first.
+# Everything lands in gpurun_out/<round>/; tools/assemble_profile.sh copies what is to be judged into profiles/<round>/.
+R=${1:-r05}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+T="timeout -s KILL"
+python -c "import bench; print(bench.csrc_sha16())" > $OUT/PROFILE_SRC_SHA
+cd /tmp && export TMPDIR=/tmp
+B="--no-probes"
+$T 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_graph -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 $B > /tmp/prof_graph.log 2>&1
+cp /tmp/prof_graph/bench_kernel_stats.csv $OUT/bench_graph_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  $T 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 $B --no-graph > /tmp/pmc_$c.log 2>&1
+  cp /tmp/pmc_$c/p_counter_collection.csv $OUT/pmc_$c.csv
+done
+$T 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_eager -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 20 $B --no-graph > /tmp/prof_eager.log 2>&1
+cp /tmp/prof_eager/bench_kernel_stats.csv $OUT/bench_eager_kernel_stats.csv
+for b in 512 2048; do
+  $T 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b$b -o bench -- python $GRAFT_REPO_ROOT/bench.py --batch $b --steps 30 --warmup 10 --no-probes > /tmp/prof_b$b.log 2>&1
+  cp /tmp/prof_b$b/bench_kernel_stats.csv $OUT/b${b}_kernel_stats.csv
+done
+cd $GRAFT_REPO_ROOT
+$T 200 bash tools/gpu_pmc_batch.sh $R 2048 512 > $OUT/pmc_batch.log 2>&1
+cd /tmp
+for form in emd_loss three_call; do
+  $T 100 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_emd_$form -o emd -- python $GRAFT_REPO_ROOT/tools/emd_loop.py $form 3 > /tmp/prof_emd.log 2>&1
+  cp /tmp/prof_emd_$form/emd_kernel_stats.csv $OUT/emd_${form}_kernel_stats.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    $T 100 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmce_${form}_$c -o p -- python $GRAFT_REPO_ROOT/tools/emd_loop.py $form 3 > /tmp/pmce.log 2>&1
+    cp /tmp/pmce_${form}_$c/p_counter_collection.csv $OUT/emd_${form}_pmc_$c.csv
+  done
+  $T 100 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d /tmp/sqe_$form -o p -- python $GRAFT_REPO_ROOT/tools/emd_loop.py $form 3 > /tmp/sqe.log 2>&1
+  cp /tmp/sqe_$form/p_counter_collection.csv $OUT/emd_${form}_sq.csv 2>/dev/null
+done
+cd $GRAFT_REPO_ROOT
+$T 60 python tools/summarize_emd.py $OUT $OUT 3 > /dev/null 2>&1
+$T 100 python tools/emd_bench.py > $OUT/emd_bench.txt 2>&1
+$T 100 python tools/pairscan_scaling.py > $OUT/pairscan_scaling.txt 2>&1
+$T 100 python tools/batch_sweep.py 32 128 512 2048 > $OUT/batch_sweep.txt 2>/dev/null
+{
+  echo "# tools/cotenancy_stress.py on one MI355X: two processes at once (parent + child), every pass compared with the process's first pass bit for bit"
+  echo "## product build (compiler-packed fp32 off; emd.o: hand-written packed instructions, destinations disjoint from their sources)"
+  $T 120 python tools/cotenancy_stress.py fwd 6000 2>&1 | grep cotenancy_stress
+  $T 150 python tools/cotenancy_stress.py step 60 2>&1 | grep cotenancy_stress
+  $T 120 python tools/cotenancy_stress.py emd 4000 2>&1 | grep cotenancy_stress
+  if [ -x tools/micro/pk_fma_cotenancy ]; then
+    echo "## tools/micro/pk_fma_cotenancy (stand-alone: v_pk_fma_f32 with destination = source pair, exact-integer recurrence, every lane checked)"
+    (cd tools/micro; $T 60 ./pk_fma_cotenancy alias 3000 & $T 60 ./pk_fma_cotenancy alias 3000; wait)
+    (cd tools/micro; $T 60 ./pk_fma_cotenancy plain 3000 & $T 60 ./pk_fma_cotenancy plain 3000; wait)
+  fi
+} > $OUT/cotenancy_stress.txt 2>&1
+# the bench line last, against THIS run's kernel stats (assembled on the box first: roofline / profile.stale refer to the profile it is committed with)
+bash tools/assemble_profile.sh $R > /dev/null 2>&1
+$T 400 python bench.py --steps 300 --warmup 30 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+tail -c 300 $OUT/bench_n1.json; echo
+ls $OUT | wc -l
