@@ -477,6 +477,11 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
         }
     };
     // running per-column sums (threads tid < BN) and the current cloud's pool keys (lanes < 32 of every wave)
+    // (HT, 32-row tiles: the two halves of a 64-row block are consecutive tiles of one workgroup; the first half's column sums wait
+    //  in pend0 / pend1 and the pair is converted to fixed point as ONE 64-row sum -- (rows 0..31) + (rows 32..63), the per-tile
+    //  kernel's own order: the totals stay bit-identical)
+    constexpr bool HT = T::BM == 32;
+    float pend0 = 0.f, pend1 = 0.f;
     long long fx0 = 0, fx1 = 0;
     unsigned long long kmx = 0ull, kmn = 0ull;
     int kcloud = -1;
@@ -565,8 +570,13 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int r = 0; r < T::WR; ++r) a0 += redt[(r * 2 + 0) * T::BN + tid], a1 += redt[(r * 2 + 1) * T::BN + tid];
-            fx_local_add<kFxShiftFwd>(fx0, g.acc_out, 0, tid, a0);
-            fx_local_add<kFxShiftFwd>(fx1, g.acc_out, 1, tid, a1);
+            if (HT && ((tile - tile0) & 1) == 0) {
+                pend0 = a0, pend1 = a1;
+            } else {
+                if (HT) a0 = pend0 + a0, a1 = pend1 + a1;
+                fx_local_add<kFxShiftFwd>(fx0, g.acc_out, 0, tid, a0);
+                fx_local_add<kFxShiftFwd>(fx1, g.acc_out, 1, tid, a1);
+            }
         }
     };
     if (tile0 < tile1) {  // tile0 into buffer 0; its register set takes tile0 + 2
@@ -1652,6 +1662,9 @@ extern "C" int sn_conv_stack_set_persist_min_tiles(int tiles)
     g_persist_min_tiles = tiles;
     return old;
 }
+#ifndef SN_FWD_HT
+#define SN_FWD_HT 1
+#endif
 template <class TT, int KT, bool IN3A>
 static int launch_fwd_persist(const FwdArgs &g, int ntiles, int tpw, int nwg, hipStream_t st)
 {
@@ -1747,7 +1760,16 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
                 const int tpw = (ntiles + nmax - 1) / nmax, nwg = (ntiles + tpw - 1) / tpw;
                 if (l == 1) g.x3 = x, g.w3 = W[0], g.b3 = bias ? bias[0] : nullptr;
                 int rc = 0;
+                // 128 output channels: TWO 256-thread workgroups per CU on 32-row tiles (SN_FWD_HT) instead of one 512-thread
+                // workgroup on 64-row tiles -- the eight waves of one tile stage, multiply and store in lockstep (one barrier per
+                // tile): a SIMD's two waves are always in the same phase; two independent workgroups drift apart and the
+                // dependent MFMA chain of one overlaps the staging / epilogue of the other
+                const bool ht = SN_FWD_HT && Co == 128 && l != 1;
+                const int nmax_h = device_cus() * 2, tpw_h = 2 * ((ntiles + nmax_h - 1) / nmax_h), nwg_h = (2 * ntiles + tpw_h - 1) / tpw_h;
+                using THT = Tile<32, 128, 1, 4>;
                 if (l == 1) rc = launch_fwd_persist<T, 64, true>(g, ntiles, tpw, nwg, st);
+                else if (ht && Ci == 128) rc = launch_fwd_persist<THT, 128, false>(g, 2 * ntiles, tpw_h, nwg_h, st);
+                else if (ht) rc = launch_fwd_persist<THT, 64, false>(g, 2 * ntiles, tpw_h, nwg_h, st);
                 else if (Co == 128 && Ci == 128) rc = launch_fwd_persist<SN_FWD_TW, 128, false>(g, ntiles, tpw, nwg, st);
                 else if (Co == 128) rc = launch_fwd_persist<SN_FWD_TW, 64, false>(g, ntiles, tpw, nwg, st);
                 else rc = launch_fwd_persist<T, 64, false>(g, ntiles, tpw, nwg, st);

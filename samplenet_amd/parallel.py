@@ -84,7 +84,11 @@ class FlatGradAllReducer:
         self._side = torch.cuda.Stream(device=dev) if (self.collective and dev.type == "cuda") else None
         self._early_work = None
         self._sentinel = None
-        self._graph_reduced = False  # set by a captured backward whose last node WAS the all-reduce (surface.py): reduce() skips it once
+        # set by a captured backward whose last node WAS the all-reduce (surface.py): reduce() skips the collective -- unless a
+        # contribution that was NOT reduced landed in the bucket in the same step (an op-by-op backward of a second sampled cloud,
+        # an irregular upstream): then the collective runs; averaging (reduced + local) over the ranks is reduced + mean(local)
+        self._graph_reduced = False
+        self._unreduced = False
         self.capture_fork = False  # engine, "graph-fork" mode: the early collective may be issued while a graph is being captured
         if self.overlap:
             module._after_fc_grads = self._early_ready
@@ -108,6 +112,7 @@ class FlatGradAllReducer:
         sink = getattr(self.module, "_grad_sink", None)
         if sink is not None:
             sink.reset()
+        self._graph_reduced = self._unreduced = False
 
     def zero_grad(self, keep=None):
         """Start of a step: begin_step() + zero the autograd-accumulated slices.  optimizer.zero_grad() -- either flavour --
@@ -176,8 +181,9 @@ class FlatGradAllReducer:
         """Call after backward(): on return (stream-ordered) every .grad holds the cross-rank mean.
         collective=False: only the .grad bookkeeping (the engine's captured step carries the collectives inside its graph);
         replayed=True: the step was a graph replay (see _rebind)."""
-        if self._graph_reduced:  # the module surface's backward graph carried the collective
-            self._graph_reduced = False
+        skip = self._graph_reduced and not self._unreduced  # the module surface's backward graph carried the collective
+        self._graph_reduced = self._unreduced = False
+        if skip:
             self._rebind(True)
             return
         self._rebind(replayed)

@@ -572,6 +572,9 @@ class GradSink(dict):
             if not mine:
                 p.grad = view
         self.written = True
+        red = getattr(self, "reducer", None)
+        if red is not None:
+            red._unreduced = True  # (a local contribution: a collective captured in a surface graph of this step does not cover it)
 
 
 def sink_for_backward(net):

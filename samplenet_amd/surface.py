@@ -481,7 +481,8 @@ class _SurfaceFunction(torch.autograd.Function):
                     gQ = gQ + ops._f32c(g_simp).permute(0, 2, 1)
                 grads = pointnet.backward_impl(net, plan.saved, gQ.reshape(B, -1).contiguous(), None, None)
                 if plan.reducer is not None:
-                    plan.sink.commit(grads)  # (torch semantics on the reducer's views; no collective: reducer.reduce() follows)
+                    plan.sink.commit(grads)  # (torch semantics on the reducer's views; no collective: reducer.reduce() follows,
+                    #  GradSink.commit marks the bucket as holding an unreduced contribution)
                     if T.requires_grad:
                         plan.t_view.add_(gT.reshape(T.shape)) if T.grad is not None else plan.t_view.copy_(gT.reshape(T.shape))
                         T.grad = plan.t_view

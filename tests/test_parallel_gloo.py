@@ -368,6 +368,12 @@ def _surface_listener_worker(rank, world, port, q):
         res["skipped_once"] = bool(torch.equal(red.flat, before)) and red._graph_reduced is False
         red.reduce()
         res["then_reduced"] = float(red.flat[0])
+        # ... but a local (unreduced) contribution of the same step forces the collective
+        red.flat.fill_(float(rank + 1))
+        red._graph_reduced, red._unreduced = True, True
+        red.reduce()
+        res["mixed_reduced"] = float(red.flat[0])
+        res["flags_cleared"] = (red._graph_reduced, red._unreduced) == (False, False)
         q.put((rank, res, ok1))
     finally:
         dist.destroy_process_group()
@@ -393,4 +399,5 @@ def test_captured_surface_steps_aside_under_ddp_and_hooks():
         assert res["force"] is None and res["reducer"] is None and res["sink_backref"]
         assert res["hook"] == "a parameter carries an autograd hook" and res["hook_removed"] is None
         assert res["skipped_once"] and abs(res["then_reduced"] - 1.5) < 1e-6  # mean of (1, 2) over the two ranks
+        assert abs(res["mixed_reduced"] - 1.5) < 1e-6 and res["flags_cleared"]
         assert ok1 is False

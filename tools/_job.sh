@@ -1,4 +1,2 @@
-cd $GRAFT_REPO_ROOT/tools/micro
-echo "## two processes, destination pair = a source pair"; (./pk_fma_cotenancy alias 3000 & ./pk_fma_cotenancy alias 3000; wait)
-echo "## two processes, destination disjoint from the sources"; (./pk_fma_cotenancy plain 3000 & ./pk_fma_cotenancy plain 3000; wait)
-echo "## one process alone, aliasing form"; ./pk_fma_cotenancy alias 3000
+cd $GRAFT_REPO_ROOT
+timeout -s KILL 400 python -m pytest tests/test_gpu_mlp.py tests/test_gpu_headline.py -x -q --timeout 300 2>&1 | tail -3
