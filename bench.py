@@ -312,6 +312,8 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
       eager  -- the same with the PCRNet task loss (the task network's own launches stay op by op);
       eager_two_clouds -- the script's DEFAULT step (--num-sampled-clouds 2, main.py:516-524): source and template both sampled under
                 one loss, the PCRNet task on the two 64-point projections; each sampler pass replays its own pair of graphs;
+      eager_mean_proj_reducer -- eager_mean_proj with a FlatGradAllReducer attached and reduce() after backward(): the data-parallel
+                form of the script's loop; under `--force-collective` the RCCL all-reduce is the last node of the surface's backward graph;
       op_by_op_mean_proj / op_by_op / op_by_op_two_clouds -- the legs above with graph_surface = False (every call launched from Python);
       graph  -- engine.SamplerTrainStep(task_loss=...) captured once and replayed: the fused single-node step with the task
                 loss OUTSIDE the node -- proj is a differentiable output, the task gradient re-enters the loss backward as an
@@ -400,6 +402,30 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
     assert torch.isfinite(loss).item()
     out["eager_two_clouds"] = {"value": 2 * B / ms * 1e3, "unit": "sampled point-clouds/s (two sampler passes per step)", "ms_per_step": ms,
                                "captured_plans": len(surface.plans(net))}
+    # ... and under data parallelism as a script issues it (round 5): a FlatGradAllReducer attached, reduce() after backward(); the
+    # plan's bucket is the reducer's, and with a process group (bench.py --force-collective: RCCL at world size 1) the all-reduce is
+    # the last node of the backward graph
+    import torch.distributed as dist
+
+    dnet = replica()
+    force = dist.is_available() and dist.is_initialized()
+    red = FlatGradAllReducer(dnet, force_collective=force)
+
+    def dp_script_step():
+        red.zero_grad()
+        simp, proj = dnet(x)
+        loss = 0.01 * dnet.get_simplification_loss(x, simp, M, 1, 0) + 0.01 * dnet.get_projection_loss() + proj.mean()
+        loss.backward()
+        red.reduce()
+        return loss
+
+    ms, loss = _wall_ms(dp_script_step, max(steps, 400))
+    assert torch.isfinite(loss).item()
+    dplans = surface.plans(dnet)
+    out["eager_mean_proj_reducer"] = {"value": B / ms * 1e3, "unit": "point-clouds/s", "ms_per_step": ms, "captured_surface": bool(dplans),
+                                      "collective": bool(red.collective),
+                                      "collective_in_backward_graph": bool(dplans and dplans[0].collective_in_graph)}
+    del dnet, red
     for name, kw in (("graph", dict(task_loss=task)), ("graph_general", dict(task_loss=task, fused_loss=False)),
                      ("general_path_mean_proj", dict(task_loss=lambda p: p.mean()))):
         gnet = replica()

@@ -618,8 +618,20 @@ def _build(net, x):
     try:
         return _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
     except Exception as e:  # noqa: BLE001 -- a configuration that cannot be captured stays on the op-by-op route
-        warnings.warn("samplenet_amd.surface: capture failed, this configuration stays op by op (%s)" % repr(e)[:300])
         torch.cuda.synchronize(x.device)
+        red = getattr(sink, "reducer", None) if sink is not None else None
+        if red is not None and red.collective and red._avg and net.__dict__.get("surface_collective", "graph") == "graph":
+            # the collective could not be captured on this stack: graphs without it, reducer.reduce() launches it (as the engine's
+            # allreduce="after")
+            warnings.warn("samplenet_amd.surface: capturing the gradient all-reduce inside the backward graph failed (%s); "
+                          "reducer.reduce() will launch it after backward()" % repr(e)[:200])
+            net.__dict__["surface_collective"] = "after"
+            try:
+                return _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
+            except Exception as e2:  # noqa: BLE001
+                e = e2
+                torch.cuda.synchronize(x.device)
+        warnings.warn("samplenet_amd.surface: capture failed, this configuration stays op by op (%s)" % repr(e)[:300])
         return None
 
 

@@ -125,3 +125,32 @@ def test_sync_batchnorm_over_rccl_at_world_size_one(rccl):
     torch.cuda.synchronize()
     assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(la)))
     assert float((ra.flat - rb.flat).norm()) <= 2e-4 * float(ra.flat.norm())
+
+
+def test_module_surface_with_the_collective_inside_its_backward_graph(rccl):
+    """VERDICT r4 #5b: the reference call pattern under data parallelism -- net(x), the getters, backward(), reducer.reduce() -- on the
+    captured module surface with the RCCL all-reduce as the LAST NODE of the backward graph (world size 1, collective forced: AVG is
+    the identity, so every step must leave exactly the gradients of the collective-free surface)."""
+    from samplenet_amd import surface
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    na, nb = _nets(2)
+    ra, rb = FlatGradAllReducer(na), FlatGradAllReducer(nb, force_collective=True)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xs = [torch.rand(32, 1024, 3, device="cuda", generator=g) - 0.5 for _ in range(6)]
+    for i, x in enumerate(xs):
+        for net, red in ((na, ra), (nb, rb)):
+            red.zero_grad()
+            simp, proj = net(x)
+            loss = 0.01 * net.get_simplification_loss(x, simp, 64, 1.0, 0.0) + 0.01 * net.get_projection_loss() + proj.mean()
+            loss.backward()
+            red.reduce()
+            net.last = float(loss)
+        torch.cuda.synchronize()
+        assert na.last == nb.last, i
+        assert torch.equal(ra.flat, rb.flat), i
+    pa, pb = surface.plans(na), surface.plans(nb)
+    assert pa and pb and pb[0].reducer is rb and pb[0].collective_in_graph and not pa[0].collective_in_graph
+    assert not rb._graph_reduced  # (consumed by reduce())
+    for (n, a), (_, b) in zip(na.named_buffers(), nb.named_buffers()):
+        assert torch.equal(a, b), n

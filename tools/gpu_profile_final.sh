@@ -39,6 +39,13 @@ $T 60 python tools/summarize_emd.py $OUT $OUT 3 > /dev/null 2>&1
 $T 100 python tools/emd_bench.py > $OUT/emd_bench.txt 2>&1
 $T 100 python tools/pairscan_scaling.py > $OUT/pairscan_scaling.txt 2>&1
 $T 100 python tools/batch_sweep.py 32 128 512 2048 > $OUT/batch_sweep.txt 2>/dev/null
+$T 200 python tools/surface_bench.py > $OUT/surface_bench.json 2>/dev/null
+# the module surface under data parallelism: reducer attached, RCCL all-reduce (forced at world size 1) inside the backward graph
+$T 200 python bench.py --gpus 1 --force-collective --steps 300 --warmup 30 --no-cpu-baseline --no-extra-legs 2> $OUT/bench_n1_rccl_surface.err | tail -1 > $OUT/bench_n1_rccl_surface.json
+for mode in graph after; do
+  $T 120 python bench.py --gpus 1 --force-collective --allreduce $mode --steps 1500 --warmup 100 --no-probes 2> $OUT/bench_n1_rccl_$mode.err | tail -1 > $OUT/bench_n1_rccl_$mode.json
+done
+$T 120 python bench.py --steps 1500 --warmup 100 --no-probes 2>/dev/null | tail -1 > $OUT/bench_n1_noprobes.json
 {
   echo "# tools/cotenancy_stress.py on one MI355X: two processes at once (parent + child), every pass compared with the process's first pass bit for bit"
   echo "## product build (compiler-packed fp32 off; emd.o: hand-written packed instructions, destinations disjoint from their sources)"
