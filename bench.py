@@ -278,6 +278,10 @@ def _graph_replay_ms(fn, warm=3, reps=30):
         for _ in range(warm):
             fn()
     torch.cuda.current_stream().wait_stream(side)
+    import gc
+
+    gc.collect()  # (graphs of earlier legs that sit in reference cycles must not be destroyed during the capture below)
+    torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
         out = fn()
@@ -962,6 +966,10 @@ def main():
             """A secondary leg must never cost the headline line: its failure is recorded in its place."""
             if args.only_leg and args.only_leg != name:
                 return
+            import gc
+
+            gc.collect()  # (the previous leg's modules and their captured graphs go now, not during a later capture)
+            torch.cuda.synchronize()
             try:
                 out[name] = fn(*a, **k)
             except Exception as e:  # noqa: BLE001

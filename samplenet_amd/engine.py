@@ -64,6 +64,15 @@ class SamplerTrainStep:
         if use_graph:
             self._capture(warmup)
 
+    def __del__(self):
+        try:
+            from .surface import bury
+
+            for graphs in self.__dict__.get("_ring_graphs", ()):
+                bury(*graphs)  # (a hipGraph must not be destroyed while a stream is capturing: surface.py)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
     def _fast_path(self):
         """forward + loss behind one autograd node (fused_step.SamplerStepFunction / ops.SamplerStepLossFunction): training
         mode with projection, (B,N,3) input, and a batch small enough that the pair scan splits clouds.  The task term is the
@@ -235,6 +244,9 @@ class SamplerTrainStep:
                     for p in self.net.parameters():
                         p.grad = None
         torch.cuda.current_stream().wait_stream(side)
+        from .surface import _collect_before_capture
+
+        _collect_before_capture()  # (no graph-holding garbage may be destroyed while the capture below is in progress)
         pool = torch.cuda.graph_pool_handle()
         bufs = self.ring if self.ring is not None else [self.x]
         for buf in bufs:

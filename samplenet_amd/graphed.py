@@ -104,6 +104,7 @@ class _Plan:
                 del outs, req
             cur.wait_stream(side)
             torch.cuda.synchronize(dev)
+            surface._collect_before_capture()
             self.pool = torch.cuda.graph_pool_handle()
             self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.gf, pool=self.pool, capture_error_mode="thread_local"):
@@ -116,6 +117,9 @@ class _Plan:
                 self.gins = torch.autograd.grad([self.outs[i] for i in self.req], self.ins_req, self.gouts, allow_unused=True)
         self.guard = _ModuleGuard(owner)
         self.used = 0
+
+    def __del__(self):
+        surface.bury(self.__dict__.get("gf"), self.__dict__.get("gb"))  # (never destroyed during somebody's capture: surface.py)
 
     def busy(self):
         o = self.owner_token
@@ -179,6 +183,8 @@ def call(owner, tag, fn, args):
         any_grad = any_grad or a.requires_grad
     if not any_grad or torch.cuda.is_current_stream_capturing():
         return None
+    if surface._GRAVE:
+        surface.flush_grave()
     table = owner.__dict__.setdefault("_sn_graphed", {})
     key = (tag,) + tuple((tuple(a.shape), a.dtype, a.device, a.requires_grad) for a in args)
     ent = table.get(key)

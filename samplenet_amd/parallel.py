@@ -15,6 +15,8 @@ unmodified module surface.  Design for xGMI (point-to-point, 7 links x ~153 GB/s
     local batch size); syncbn.convert_sync_batchnorm(net, group) switches the head to statistics over all ranks'
     rows (W x B clouds train like one process with W B clouds; a parity mode on the layer-by-layer kernels).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -79,7 +81,10 @@ class FlatGradAllReducer:
 
             params = dict(named)
             module._grad_sink = GradSink(sink, {n: params[n] for n in sink})
-            module._grad_sink.reducer = self  # (the captured module surface writes this bucket: surface.py)
+            # (the captured module surface writes this bucket: surface.py.  A WEAK reference: module -> sink -> reducer -> module
+            #  would be a cycle that only the garbage collector frees, and a captured graph destroyed by a collection that
+            #  happens to run during somebody's stream capture aborts the process)
+            module._grad_sink._reducer_ref = weakref.ref(self)
         self.overlap = bool(overlap and self.collective and dev.type == "cuda" and hip_mlp)
         self._side = torch.cuda.Stream(device=dev) if (self.collective and dev.type == "cuda") else None
         self._early_work = None

@@ -547,6 +547,11 @@ class GradSink(dict):
         super().__init__(views)
         self.params = params  # name -> nn.Parameter
         self.written = False
+        self._reducer_ref = None  # weak reference to the FlatGradAllReducer that owns the views (parallel.py)
+
+    @property
+    def reducer(self):
+        return self._reducer_ref() if self._reducer_ref is not None else None
 
     def reset(self):
         self.written = False

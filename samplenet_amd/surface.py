@@ -100,6 +100,38 @@ class _Token:
     __slots__ = ("__weakref__",)
 
 
+# A hipGraph destroyed while a stream of the calling thread is capturing raises hipErrorStreamCaptureUnsupported from the
+# destructor (~CUDAGraph) and ABORTS the process -- and a plan can lose its last reference at any time: a pruned record, a dropped
+# module, a garbage collection (round 5: bench.py's configs[4] leg died exactly so, inside its hand capture).  So the owners of
+# captured graphs (surface._Plan, graphed._Plan, engine.SamplerTrainStep) never let their graphs die with them: __del__ hands the
+# torch.cuda.CUDAGraph objects to this list, which is emptied at safe points only (a module-surface / graphed call or a plan
+# build of a thread that is NOT capturing).
+_GRAVE = []
+
+
+def bury(*graphs):
+    try:
+        _GRAVE.extend(g for g in graphs if g is not None)
+    except Exception:  # noqa: BLE001 -- interpreter shutdown
+        pass
+
+
+def flush_grave():
+    if _GRAVE and not torch.cuda.is_current_stream_capturing():
+        dead = _GRAVE[:]
+        del _GRAVE[:]
+        del dead  # (the graphs' destructors run here)
+
+
+def _collect_before_capture():
+    """Garbage that holds captured graphs (a dropped module's plans inside a reference cycle) is collected BEFORE a capture
+    begins, and the buried graphs go now."""
+    import gc
+
+    gc.collect()
+    flush_grave()
+
+
 class _Live:
     """What the loss getters need to recognise the tensors of a captured forward that still waits for its backward.  The record of
     the LATEST forward holds its outputs strongly (the getters are called right behind it); when another forward follows, the
@@ -200,7 +232,8 @@ class _Plan:
         T = net.project._temperature
         total = sum(p.numel() for p in params)
         self.sink = net.__dict__.get("_grad_sink")
-        self.reducer = getattr(self.sink, "reducer", None) if self.sink is not None else None
+        red = getattr(self.sink, "reducer", None) if self.sink is not None else None
+        self._reducer_ref = weakref.ref(red) if red is not None else None  # (weak: reducer -> module -> plans would be a cycle)
         self.static_out = bool(net.__dict__.get("surface_static_outputs", False))
         # a loss that hangs off the simplified cloud itself (the progressive sampler's prefix losses, a script's own Chamfer on
         # simp): its gradient enters the backward graph as one more static operand, added to the loss kernel's dL/dQ
@@ -249,6 +282,13 @@ class _Plan:
                                             and net.__dict__.get("surface_collective", "graph") == "graph")
             self._capture(net, x)
         self.guard = _Guard(net)
+
+    @property
+    def reducer(self):
+        return self._reducer_ref() if self._reducer_ref is not None else None
+
+    def __del__(self):
+        bury(self.__dict__.get("gf"), self.__dict__.get("gb"))
 
     # ---- the launches (eager warm-up, then captured) ------------------------------------------------------------------
     def _forward_body(self, net):
@@ -317,6 +357,7 @@ class _Plan:
         cur.wait_stream(side)
         torch.cuda.synchronize(self.dev)
         self.saved = self.state = self.bwd_keep = None
+        _collect_before_capture()
         self.pool = torch.cuda.graph_pool_handle()
         self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.gf, pool=self.pool, capture_error_mode="thread_local"):
@@ -534,7 +575,11 @@ def _variant_ok(net):
     ok = net.__dict__.get("_sn_variant_ok")
     if ok is None:
         _, fcs = pointnet._layers(net)
-        ok = net.__dict__["_sn_variant_ok"] = bool(len(fcs) >= 2 and fcs[-1].bn is None and fcs[-2].Co % 4 == 0)
+        # (pointnet._layers does not list a BatchNorm behind the LAST FC layer -- torch applies it on the head's output --: ask the
+        #  module itself)
+        last_bn = net._modules.get("bn_fc%d" % net.num_fc_layers) is not None
+        ok = net.__dict__["_sn_variant_ok"] = bool(len(fcs) >= 2 and not last_bn and fcs[-1].bn is None and fcs[-2].Co % 4 == 0
+                                                   and "_features" not in net.__dict__)
     return ok
 
 
@@ -661,6 +706,8 @@ def try_forward(net, x):
         return None
     if torch.cuda.is_current_stream_capturing():  # somebody captures the step themselves: plain launches for their graph
         return None
+    if _GRAVE:
+        flush_grave()
     _demote_lives(net)  # (earlier forwards keep weak records only: dropped outputs free their plan)
     table = net.__dict__.setdefault("_sn_surface", {})
     key = (x.shape[0], x.shape[1], x.device)

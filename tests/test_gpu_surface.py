@@ -643,3 +643,22 @@ def test_sampler_variants_run_on_the_captured_surface(variant):
             assert float(a.project._temperature.grad.abs()) == 0.0 and float(b.project._temperature.grad.abs()) == 0.0
     assert _plan(a) is not None and len(surface.plans(a)) >= 1
     _same_buffers(a, b)
+
+
+def test_classification_sampler_stays_off_the_captured_surface():
+    """The classification sampler (classification/models/samplenet_model.py:30-108) has a BatchNorm on the head's OUTPUT: no scan
+    can start before every cloud's queries exist, so the fc4-in-scan graphs do not apply -- it must stay op by op (and correct)."""
+    import copy
+
+    from samplenet_amd import SampleNet, surface
+
+    torch.manual_seed(19)
+    a = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc", last_fc_batchnorm=True, min_sigma=0.0).cuda().train()
+    b = copy.deepcopy(a)
+    b.graph_surface = False
+    for x in _batches(5, seed=33):
+        _clear(a), _clear(b)
+        ra, rb = _script_step(a, x), _script_step(b, x)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[4], rb[4])
+        assert not _grad_mismatch(a, b, exact=True)
+    assert not surface.plans(a)
