@@ -104,7 +104,7 @@ class SampleNet(nn.Module):
     # module's gradient bucket, persistent kernel scratch)
     _TRANSIENT = ("_scan", "_grad_sink", "_after_fc_grads", "_colmin_keys", "_colmin_keys_owner", "_fx_acc", "_fx_acc_b",
                   "_fc_sync", "_fc_sync_b", "_sn_layer_records", "_sn_plans", "_sn_sync_bn", "_sn_surface", "_sn_surface_live",
-                  "_sn_hook_params", "_sn_surface_warned", "_sn_pinned", "_sn_surface_simp_grad", "_sn_variant_ok")
+                  "_sn_hook_params", "_sn_surface_warned", "_sn_pinned", "_sn_variant_ok")
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float() ...: parameter storage moves -- recorded pointer arrays, captured graphs and persistent

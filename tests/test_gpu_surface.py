@@ -14,6 +14,7 @@ script on a replica with identical parameters:
     backward launches).  The simplified cloud then differs by fc4's summation order (1e-6), gradients by 1e-5 of their norm.
 """
 import copy
+import os
 
 import pytest
 import torch
@@ -662,3 +663,47 @@ def test_classification_sampler_stays_off_the_captured_surface():
         assert torch.equal(ra[0], rb[0]) and torch.equal(ra[4], rb[4])
         assert not _grad_mismatch(a, b, exact=True)
     assert not surface.plans(a)
+
+
+def test_a_plan_dropped_during_a_capture_does_not_abort_the_process(tmp_path):
+    """Round 5: a hipGraph destroyed while a stream of the calling thread is capturing raises from ~CUDAGraph and aborts the
+    process (bench.py's configs[4] leg died so).  Plans bury their graphs instead (surface.bury / flush_grave); run in a child
+    process -- a regression would take the interpreter down."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import gc, sys, torch
+        sys.path.insert(0, %r)
+        from samplenet_amd import SampleNet, surface
+        torch.manual_seed(0)
+        net = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
+        x = torch.rand(32, 1024, 3, device="cuda") - 0.5
+        for _ in range(4):
+            for p in net.parameters():
+                p.grad = None
+            simp, proj = net(x)
+            (0.01 * net.get_simplification_loss(x, simp, 64, 1, 0) + 0.01 * net.get_projection_loss() + proj.mean()).backward()
+        assert surface.plans(net)
+        del simp, proj
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            y = torch.zeros(8, device="cuda")
+            g.capture_begin(capture_error_mode="thread_local")
+            y += 1
+            net.__dict__.pop("_sn_surface"), net.__dict__.pop("_sn_surface_live", None)   # the plans lose their last references ...
+            for p in net.parameters():
+                p.grad = None
+            gc.collect()                                                                    # ... while this thread is capturing
+            buried = len(surface._GRAVE)
+            g.capture_end()
+        torch.cuda.synchronize()
+        surface.flush_grave()
+        print("BURIED", buried, "LEFT", len(surface._GRAVE))
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "BURIED 2 LEFT 0" in r.stdout, r.stdout[-500:]
