@@ -574,8 +574,8 @@ def time_config3_sampler(dev, steps=40):
     """BASELINE configs[3], the sampler's side (the EMD leg above is the loss side): the reconstruction task's SampleNet
     (reconstruction/src/samplers.py:23-38: conv widths 64, 128, 128, 256, bottleneck 128, FC 256, 256 without BatchNorm) on
     B = 50 clouds of 2048 points -> 64, K = 8: forward + simplification / projection losses + backward, eager and captured.  Its
-    128 -> 256 -> 128 layers run the fused backward kernel in two passes over the halves of the 256-channel side; the forward GEMMs
-    are the generic tile kernel and the step is the op-by-op general path."""
+    128 -> 256 -> 128 layers run the fused backward kernel in two passes over the halves of the 256-channel side; the forward runs on
+    the one-call statistics chain (sn_conv_stack_forward_bn: two accumulator blocks per layer, K = 256 on the pre-split planes)."""
     from samplenet_amd import SampleNet
     from samplenet_amd.engine import SamplerTrainStep
     from samplenet_amd.parallel import FlatGradAllReducer

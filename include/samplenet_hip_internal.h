@@ -124,7 +124,9 @@ int sn_conv_forward_bn_pool(int R, int Ci, int Co, int npts, const float *ain, c
 /* The training-mode conv stack (conv/bn/relu x nlayers on the xyz cloud + max over the points, samplenet.py:90-95) in one
  * call and nlayers + 1 launches.  Batch statistics travel as 64-bit fixed-point sums accumulated with integer atomics
  * (order-independent, hence deterministic); each layer finalises the BatchNorm of its input itself, so no reduction launch
- * sits between layers.  channels [nlayers+1] = 3, C1..Cn (64 or 128 each); N % 64 == 0 (query _supported first).
+ * sits between layers.  channels [nlayers+1] = 3, C1..Cn (64 or 128 each; inner layers up to 256 --
+ * reconstruction/src/samplers.py:23-38 -- when pooled != NULL and B * N / 64 row blocks can carry the weight split); N % 64 == 0
+ * (query _supported first).
  * Arrays of nlayers device pointers: W (C_{l+1},C_l), bias, gamma, beta, running_mean, running_var, num_batches_tracked,
  * z (B*N,C_{l+1}) pre-BN outputs, coef (4,C_{l+1}); eps / momentum: host arrays.  acc: sn_conv_stack_acc_elems(nlayers) long long of persistent
  * device scratch, zero before the first call (every call leaves it zero).  pool_val / pool_idx: (B*N/64)*2*Cn scratch.

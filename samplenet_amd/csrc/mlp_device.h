@@ -68,7 +68,8 @@ enum { ACT_NONE = 0, ACT_BN_RELU = 1, ACT_BN_RELU_FX = 2 };
 #define SN_FX_SLOTS 16
 #endif
 constexpr int kFxSlots = SN_FX_SLOTS;
-constexpr int kFxRow = 128;                           // channels per row (C <= 128)
+constexpr int kFxRow = 128;                           // channels per row (a layer of 129 .. 256 channels: TWO blocks back to back,
+                                                      //  channel c in block c >> 7 -- sn_conv_stack_forward_bn's wide layout)
 constexpr int kFxHi = kFxSlots * 2 * kFxRow;          // lo rows [slot][stat][128], then ONE pair of hi rows [stat][128]
 constexpr int kFxPoison = kFxHi + 2 * kFxRow;         // (large contributions are rare: they all share slot-less hi rows, so
 constexpr int kFxLayer = kFxPoison + 64;              //  consumers read them unconditionally -- no flag, no branch)

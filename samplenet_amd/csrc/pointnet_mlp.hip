@@ -75,14 +75,17 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
         float *cf = lds + T::LDS_FLOATS;  // [2][Ci] scale | shift
         const BnFwd bp = g.bn_prev;
         const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-        const int c = threadIdx.x;  // THREADS >= Ci (<= 128)
+        const int c = threadIdx.x;  // THREADS >= Ci (<= 256)
         long long lo0[kFxSlots], lo1[kFxSlots], ha = 0, hb = 0, poison = 0;
         float bg = 0.f, bb = 0.f, brm = 0.f, brv = 0.f;
         if (c < Ci) {
-            poison = g.acc_in[kFxPoison];
+            // (KT > 128: the input layer's sums fill two accumulator blocks back to back, channel c in block c >> 7)
+            const long long *ai = KT > kFxRow ? g.acc_in + (c / kFxRow) * kFxLayer : g.acc_in;
+            const int cl = KT > kFxRow ? c % kFxRow : c;
+            poison = ai[kFxPoison];
 #pragma unroll
-            for (int q = 0; q < kFxSlots; ++q) lo0[q] = g.acc_in[(q * 2 + 0) * kFxRow + c], lo1[q] = g.acc_in[(q * 2 + 1) * kFxRow + c];
-            ha = g.acc_in[kFxHi + c], hb = g.acc_in[kFxHi + kFxRow + c];
+            for (int q = 0; q < kFxSlots; ++q) lo0[q] = ai[(q * 2 + 0) * kFxRow + cl], lo1[q] = ai[(q * 2 + 1) * kFxRow + cl];
+            ha = ai[kFxHi + cl], hb = ai[kFxHi + kFxRow + cl];
             bg = bp.gamma[c], bb = bp.beta[c];
             if (first && bp.running_mean) brm = bp.running_mean[c], brv = bp.running_var[c];
         }
@@ -248,7 +251,10 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
     SN_TL_DRAIN();
     SN_TL(4);
     if (g.acc_out) {
-        column_reduce2<T, true>(s0, s1, lds, reinterpret_cast<float *>(g.acc_out), nullptr, col0, Co);
+        // (a layer of 256 output channels: columns 128 .. 255 add into the second accumulator block; col0 is uniform)
+        const int blk = col0 / kFxRow;
+        column_reduce2<T, true>(s0, s1, lds, reinterpret_cast<float *>(g.acc_out + blk * kFxLayer), nullptr, col0 - blk * kFxRow,
+                                Co - blk * kFxRow);
     } else if (g.stats) {
         float *st = g.stats + (size_t)blockIdx.x * 2 * Co;
         column_reduce2<T>(s0, s1, lds, st, st + Co, col0, Co);
@@ -1618,14 +1624,31 @@ extern "C" int sn_conv_stack_forward_supported(int B, int N, int nlayers, const 
     if (B < 1 || N < 1 || nlayers < 2 || !channels || channels[0] != 3) return 0;
     const long long R = (long long)B * N;
     if (R <= 64 || R > (1ll << 30) || N % 64) return 0;
-    for (int l = 1; l <= nlayers; ++l)
-        if (channels[l] % 64 || channels[l] > 128) return 0;
+    bool wide = false;
+    long long nb = 0;
+    for (int l = 1; l <= nlayers; ++l) {
+        if (channels[l] % 64 || channels[l] > 2 * kFxRow) return 0;
+        wide = wide || channels[l] > 128;
+        if (l < nlayers) nb += ((long long)channels[l] * channels[l + 1] + 1023) / 1024;
+    }
+    // a layer wider than 128 channels (reconstruction/src/samplers.py:23-38: 64-128-128-256-bottleneck) runs on the pre-split
+    // weight planes only (K = 256 known at compile time): the split must fit the xyz layer's workgroups, the pool keys 128 channels
+    if (wide && (!SN_BF16X3 || nlayers - 1 > 4 || nb > R / 64 || channels[nlayers] > 128 || channels[1] > 128)) return 0;
     return 1;
 }
 
 // (behind the accumulators: room for the split weights of the nlayers - 1 GEMM layers, 128 x 128 x 3 bf16 each -- scratch of the
 //  call, contents irrelevant between calls)
-constexpr long long kWPlaneLL = (long long)128 * 128 * 3 * 2 / 8;
+[[maybe_unused]] constexpr long long kWPlaneLL = (long long)128 * 128 * 3 * 2 / 8;
+// a stack with a layer above 128 channels ("wide"): two accumulator blocks per layer (back to back: one clear range), planes of
+// 256 x 256 x 3 bf16 per layer.  The stacks of 64 / 128 channels keep the layout they always had.
+[[maybe_unused]] constexpr long long kWPlaneWideLL = (long long)256 * 256 * 3 * 2 / 8;
+static bool conv_stack_wide(int nlayers, const int *channels)
+{
+    for (int l = 1; l <= nlayers; ++l)
+        if (channels[l] > kFxRow) return true;
+    return false;
+}
 // 1: sn_conv_stack_forward_bn accepts z[0] == NULL for this shape (the xyz layer's activation is not materialised; conv2's
 // forward and sn_conv_stack_backward rebuild it from the cloud): 3 -> 64 -> 64 channels and enough row blocks for the weight split
 extern "C" int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const int *channels)
@@ -1643,7 +1666,8 @@ extern "C" int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const 
 extern "C" long long sn_conv_stack_acc_sum_elems(int nlayers) { return nlayers > 0 ? (long long)nlayers * kFxLayer : 0; }
 extern "C" long long sn_conv_stack_acc_elems(int nlayers)
 {
-    return nlayers > 0 ? (long long)nlayers * kFxLayer + (long long)(nlayers - 1) * kWPlaneLL : 0;
+    // (sized for the wide layout: the caller allocates before it knows the channels)
+    return nlayers > 0 ? (long long)nlayers * 2 * kFxLayer + (long long)(nlayers - 1) * kWPlaneWideLL : 0;
 }
 
 // tiles per workgroup from which the conv stack's forward GEMMs run as persistent kernels (0: never); a test / A-B hook
@@ -1683,11 +1707,15 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
                                         float *pooled, int *argsel, float *zsel, sn_stream_t stream)
 {
     if (!sn_conv_stack_forward_supported(B, N, nlayers, channels))
-        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_stack_forward_bn: needs N % 64 == 0 and 64 / 128 channels");
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_conv_stack_forward_bn: needs N % 64 == 0 and 64 / 128 (/ 256 inside the stack) channels");
     SN_REQUIRE(x && W && gamma && beta && eps && momentum && z && coef && acc && pool_val && pool_idx, "null pointer");
     SN_REQUIRE((pooled && argsel && zsel) || (!pooled && !argsel && !zsel), "pooled / argsel / zsel: all or none");
     hipStream_t st = (hipStream_t)stream;
     const int R = B * N;
+    // accumulator blocks per layer: one, or two back to back when a layer has more than 128 channels (then for every layer: one stride)
+    const bool wide = conv_stack_wide(nlayers, channels);
+    const size_t S = wide ? 2 * (size_t)kFxLayer : (size_t)kFxLayer;
+    SN_REQUIRE(!wide || pooled, "a stack with a layer above 128 channels finishes its own pool (the FC chain's pool stage reads the 128-channel layout)");
     auto bn_of = [&](int l) {
         return BnFwd{gamma[l], beta[l], running_mean ? running_mean[l] : nullptr, running_var ? running_var[l] : nullptr,
                      num_batches_tracked ? num_batches_tracked[l] : nullptr, coef[l], eps[l], momentum[l], (long long)R};
@@ -1704,11 +1732,11 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
     __bf16 *planes[8] = {nullptr};
 #if SN_BF16X3
     if (nlayers - 1 <= 4) {
-        __bf16 *base = reinterpret_cast<__bf16 *>(acc + (size_t)nlayers * kFxLayer);
+        __bf16 *base = reinterpret_cast<__bf16 *>(acc + (size_t)nlayers * S);
         int nb = 0;
         for (int l = 1; l < nlayers; ++l) {
             const int li = l - 1, el = channels[l] * channels[l + 1];
-            planes[l] = base + (size_t)li * kWPlaneLL * 4;
+            planes[l] = base + (size_t)li * (wide ? kWPlaneWideLL : kWPlaneLL) * 4;
             job.w[li] = W[l], job.dst[li] = planes[l], job.elems[li] = el, job.first[li] = nb;
             nb += (el + 1023) / 1024;
         }
@@ -1733,7 +1761,7 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         if (g_in3_blocks > 0 && (R / 64) / g_in3_blocks >= std::max<long long>(need, 1)) in3_nb = g_in3_blocks;  // (test hook)
     }
     hipLaunchKernelGGL(conv_in3_fwd_kernel, dim3((R / 64 + in3_nb - 1) / in3_nb, channels[1] / 64), dim3(256), 0, st, R, channels[1], x, W[0],
-                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * kFxLayer + kFxPoison, job,
+                       bias ? bias[0] : nullptr, z[0], (float *)nullptr, acc, acc + (size_t)(nlayers - 1) * S + kFxPoison, job,
                        in3_nb);
     using T = TileBig;
     for (int l = 1; l < nlayers; ++l) {
@@ -1742,8 +1770,8 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         g.a = make_act(z[l - 1], nullptr, R, Ci);
         g.w.w = W[l], g.w.co = Co, g.w.ci = Ci;
         g.bias = bias ? bias[l] : nullptr, g.z = z[l], g.stats = nullptr;
-        g.acc_in = acc + (size_t)(l - 1) * kFxLayer, g.bn_prev = bn_of(l - 1), g.acc_out = acc + (size_t)l * kFxLayer;
-        if (l >= 2) g.zero_ptr = acc + (size_t)(l - 2) * kFxLayer, g.zero_n = kFxLayer;
+        g.acc_in = acc + (size_t)(l - 1) * S, g.bn_prev = bn_of(l - 1), g.acc_out = acc + (size_t)l * S;
+        if (l >= 2) g.zero_ptr = acc + (size_t)(l - 2) * S, g.zero_n = (int)S;
         if (l == nlayers - 1) {
             g.pool_npts = N;
             if (!keys_pool) g.pool_val = pool_val, g.pool_idx = pool_idx;
@@ -1754,7 +1782,7 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
 #if SN_BF16X3
         // large batches: the persistent, weight-stationary form (linear_fwd_persist_kernel) once every workgroup has at least
         // g_persist_min_tiles 64-row tiles to walk over
-        if (pl && g.z && (l < nlayers - 1 || keys_pool) && (l > 1 || z1free) && (Ci == 64 || Co == 128) && R % 64 == 0) {
+        if (pl && g.z && (l < nlayers - 1 || keys_pool) && (l > 1 || z1free) && (Ci == 64 || Co == 128) && Ci <= 128 && Co <= 128 && R % 64 == 0) {
             const int ntiles = R / 64, per_cu = Co == 128 ? 1 : 2, nmax = device_cus() * per_cu;
             if (g_persist_min_tiles > 0 && ntiles >= g_persist_min_tiles * nmax) {
                 const int tpw = (ntiles + nmax - 1) / nmax, nwg = (ntiles + tpw - 1) / tpw;
@@ -1786,18 +1814,22 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
             hipLaunchKernelGGL((linear_fwd_kernel<T, true, ACT_BN_RELU_FX, 64, SN_BF16X3 != 0, SN_BF16X3 != 0>), grid, dim3(T::THREADS), lds, st, g);
             continue;
         }
-        if (Co == 128) {
+        if (Co % 128 == 0) {
             // 128 output channels: one 512-thread workgroup per 64 rows computes all of them -- the input tile is fetched
             // once instead of once per 64-column block, and half as many workgroups run the statistics prologue
+            // (256 output channels: two such column blocks)
             using TW = SN_FWD_TW;
-            const dim3 grid(R / TW::BM, 1);
+            const dim3 grid(R / TW::BM, Co / TW::BN);
             const size_t lds = shaped_lds(lds_bytes<TW>() + (size_t)2 * Ci * sizeof(float), grid);
 #define SN_FWD_FX(TT, KT_)                                                                                                \
     do {                                                                                                                  \
         if (pl) hipLaunchKernelGGL((linear_fwd_kernel<TT, true, ACT_BN_RELU_FX, KT_, SN_BF16X3 != 0>), grid, dim3(TT::THREADS), lds, st, g); \
         else hipLaunchKernelGGL((linear_fwd_kernel<TT, true, ACT_BN_RELU_FX, KT_>), grid, dim3(TT::THREADS), lds, st, g);  \
     } while (0)
-            if (Ci == 128 && pl) SN_FWD_FX(TW, 128);
+            if (Ci == 256) {  // (sn_conv_stack_forward_supported: wide layers only with the planes)
+                SN_REQUIRE(pl, "a 256-channel input needs the pre-split weight planes");
+                hipLaunchKernelGGL((linear_fwd_kernel<TW, true, ACT_BN_RELU_FX, 256, SN_BF16X3 != 0>), grid, dim3(TW::THREADS), lds, st, g);
+            } else if (Ci == 128 && pl) SN_FWD_FX(TW, 128);
             else if (Ci == 128) SN_FWD_FX(TW, SN_FWD_KT128);
             else SN_FWD_FX(TW, 64);
             continue;
@@ -1810,7 +1842,7 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
 #undef SN_FWD_FX
     }
     const int Cn = channels[nlayers];
-    long long *zp = nlayers >= 2 ? acc + (size_t)(nlayers - 2) * kFxLayer : nullptr;
+    long long *zp = nlayers >= 2 ? acc + (size_t)(nlayers - 2) * S : nullptr;
     if (!pooled) {  // the last BatchNorm + the pool pick run as the first stage of sn_fc_chain_forward_pool
         SN_LAUNCH_CHECK();
         return 0;
@@ -1819,13 +1851,13 @@ extern "C" int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *ch
         const int cpb = 8;  // clouds per workgroup
         hipLaunchKernelGGL(bn_finalize_pool_keys_kernel, dim3((B + cpb - 1) / cpb), dim3(256), 0, st, bn_of(nlayers - 1), B, Cn, cpb,
                            reinterpret_cast<const unsigned long long *>(pool_val), pooled, argsel, zsel,
-                           acc + (size_t)(nlayers - 1) * kFxLayer, zp, zp ? kFxLayer : 0);
+                           acc + (size_t)(nlayers - 1) * S, zp, zp ? (int)S : 0);
         SN_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL(bn_finalize_pool_kernel, dim3((Cn + kChan - 1) / kChan), dim3(1024), 0, st, 0, Cn, (const float *)nullptr,
-                       bn_of(nlayers - 1), B, N / 64, pool_val, pool_idx, pooled, argsel, zsel, acc + (size_t)(nlayers - 1) * kFxLayer, zp,
-                       zp ? kFxLayer : 0);
+                       bn_of(nlayers - 1), B, N / 64, pool_val, pool_idx, pooled, argsel, zsel, acc + (size_t)(nlayers - 1) * S, zp,
+                       zp ? (int)S : 0);
     SN_LAUNCH_CHECK();
     return 0;
 }

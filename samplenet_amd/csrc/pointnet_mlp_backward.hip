@@ -2666,8 +2666,8 @@ static bool conv_stack_backward_ok(int B, int N, int nlayers, const int *ch)
     if (!sn_conv_stack_forward_supported(B, N, nlayers, ch) || nlayers < 3 || nlayers > 5) return false;
     const int R = B * N;
     if (ch[1] != 64 || ch[2] != 64 || R < 256) return false;
-    for (int l = 1; l < nlayers; ++l)
-        if (!conv_bwd_fused_shape(R, ch[l], ch[l + 1])) return false;
+    for (int l = 1; l < nlayers; ++l)  // (above 128 channels: the forward's two-block accumulator layout, two-pass backward kernels)
+        if (ch[l] > 128 || ch[l + 1] > 128 || !conv_bwd_fused_shape(R, ch[l], ch[l + 1])) return false;
     return true;
 }
 

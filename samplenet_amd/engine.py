@@ -124,7 +124,11 @@ class SamplerTrainStep:
             T = net.project._temperature
             floor = getattr(net.project, "_temperature_floor", None) is not None
             t_sink = None
-            if self.reducer is not None and T.requires_grad and not floor:
+            # (floor: the reconstruction variant squares max(T, floor); with a reducer and nothing else that autograd accumulates,
+            #  the kernels get the clamped value as data and write its gradient into the bucket as well -- the clamp's gate is then
+            #  one in-place launch behind the backward instead of autograd's compare / select / accumulate and a cleared bucket)
+            gate = floor and self.reducer is not None and T.requires_grad and boundary is None and self.task_loss is None
+            if self.reducer is not None and T.requires_grad and (not floor or gate):
                 self.reducer._rebind()  # (after an optimizer.zero_grad(): T.grad is the bucket's view again)
                 t_sink = T.grad.view(-1)[:1]  # a view of the flat bucket: written in place, nothing to zero or accumulate
                 if self.reducer.autograd_accumulated > 1:
@@ -155,7 +159,9 @@ class SamplerTrainStep:
                     loss.backward(self._one)
                 return loss.detach() + task.detach()
             B, N, _ = x.shape
-            if floor:
+            if gate:
+                T = torch.clamp(T.detach(), min=net.project._temperature_floor)
+            elif floor:
                 T = net.project._t()  # max(T, floor): the kernels square what they are given; its gradient gate is autograd's
             if std and self.fused_head and net.use_hip_mlp and ops.lib.sn_pairscan_colmin_splits(B, N, net.num_out_points) > 1:
                 from .fused_step import sampler_step
@@ -167,14 +173,17 @@ class SamplerTrainStep:
                                                                self.alpha, self.lmbda, weight, t_sink, True)
             self.outputs = (y.detach(), proj.detach())  # simplified cloud (B,3,M), projected cloud (B,M,3)
             loss.backward(self._one)  # preallocated upstream gradient: no ones_like fill per step
+            if gate:
+                net.project._gate_floor_(t_sink)
             return loss.detach()
         if self.reducer is not None:
             self.reducer.zero_grad()
         simp, proj = net(x)
         self.outputs = (simp.detach(), proj.detach())  # in the module's output_shape
         lsimp = net.get_simplification_loss(x, simp, net.num_out_points, self.gamma, self.delta)
-        if self.task_loss is None and net.training and not net.skip_projection:
-            # alpha * L_simp + lmbda * sigma + mean(proj) in one fused kernel pair (same value as the composition below)
+        if self.task_loss is None and net.training and not net.skip_projection and getattr(net.project, "_temperature_floor", None) is None:
+            # alpha * L_simp + lmbda * sigma + mean(proj) in one fused kernel pair (same value as the composition below; it squares
+            # the parameter itself: not for the variant whose sigma is max(T, floor)^2)
             from . import ops
 
             loss = ops.SamplerLossFunction.apply(lsimp, net.project._temperature, proj, self.alpha, self.lmbda,

@@ -190,6 +190,8 @@ def _conv_stack_fx(net, convs, x_bnc, B, N, saved, pooled, argsel, zsel, defer_p
         return False
     if not lib.sn_conv_stack_forward_supported(B, N, n, chans):
         return False
+    if defer_pool and max(chans) > 128:  # (the FC chain's pool stage reads the 128-channel accumulator layout)
+        return False
     R = B * N
     acc = getattr(net, "_fx_acc", None)
     nacc = lib.sn_conv_stack_acc_elems(n)

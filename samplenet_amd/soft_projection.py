@@ -52,6 +52,16 @@ class SoftProjection(nn.Module):
             return self._temperature
         return torch.clamp(self._temperature, min=self._temperature_floor)
 
+    def _gate_floor_(self, g):
+        """In place, ONE launch: g (the gradient w.r.t. max(T, floor), one element) -> the gradient w.r.t. T, i.e. g where
+        T >= floor and 0 elsewhere -- torch.clamp's own gate.  (aten's threshold_backward keeps g where self > threshold: the
+        threshold is the float below the floor.)"""
+        import numpy as np
+
+        thr = float(np.nextafter(np.float32(self._temperature_floor), np.float32(-np.inf)))
+        torch.ops.aten.threshold_backward.grad_input(g, self._temperature.detach().reshape(g.shape), thr, grad_input=g)
+        return g
+
     def sigma(self):
         if self._temperature_floor is not None:
             t = self._t()

@@ -335,7 +335,7 @@ class _Plan:
         if missing:
             raise RuntimeError("surface: the backward did not write %s into the gradient bucket" % missing[:3])
         if self.t_eff is not None:  # d max(T, floor) / dT
-            self.t_sink.mul_((net.project._temperature.detach().reshape(1) >= net.project._temperature_floor).to(torch.float32))
+            net.project._gate_floor_(self.t_sink)
         if self.collective_in_graph:
             self.reducer._all_reduce_mean(self.reducer.flat)  # captured: RCCL's kernel replays as the graph's last node
         self.bwd_keep = (res, grads)

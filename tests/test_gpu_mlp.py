@@ -433,6 +433,57 @@ def test_fixed_point_statistics_chain(B, N):
     assert torch.equal(s2["zc"][4], sa["zc"][4]) and torch.equal(s2["cc"][4][:2], sa["cc"][4][:2])
 
 
+@pytest.mark.parametrize("B,N", [(50, 2048), (32, 1024), (9, 640), (6, 320)])
+def test_fixed_point_statistics_chain_256_channels(B, N):
+    """The reconstruction sampler's conv stack (reconstruction/src/samplers.py:23-38: 3-64-128-128-256-bottleneck) on the one-call
+    statistics chain (two accumulator blocks per layer, K = 256 on the pre-split weight planes, two 128-column
+    blocks for the 256-wide layer) against the per-layer launches: as test_fixed_point_statistics_chain.  (6, 320): too few
+    64-row blocks to carry the weight split -- the per-layer route must run, and does."""
+    from samplenet_amd import SampleNet, pointnet
+    from samplenet_amd._lib import lib
+    import ctypes
+
+    torch.manual_seed(B * 5 + N)
+    net_a = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc", conv_widths=(64, 128, 128, 256), fc_widths=(256, 256),
+                      fc_batchnorm=False, temperature_floor=1e-2, min_sigma=0.0).cuda().train()
+    with torch.no_grad():
+        net_a.bn2.weight[::3] *= -1.0
+        net_a.bn4.weight[::7] *= -1.0
+        net_a.bn5.weight[::5] *= -1.0
+    net_b, net_c = copy.deepcopy(net_a), copy.deepcopy(net_a)
+    x = (torch.rand(B, N, 3, device="cuda") - 0.5).contiguous()
+    chans = (ctypes.c_int * 6)(3, 64, 128, 128, 256, 128)
+    wide = bool(lib.sn_conv_stack_forward_supported(B, N, 5, chans))
+    assert wide == (B * N // 64 >= 88)
+    old = pointnet.FX_STATS
+    try:
+        pointnet.FX_STATS = True
+        ya, sa = pointnet.forward_impl(net_a, x, True)
+        yc, sc = pointnet.forward_impl(net_c, x, True)
+        pointnet.FX_STATS = False
+        yb, sb = pointnet.forward_impl(net_b, x, True)
+    finally:
+        pointnet.FX_STATS = old
+    assert hasattr(net_a, "_fx_acc") == wide
+    if wide:  # (two accumulator blocks per layer in this layout)
+        assert int(net_a._fx_acc[:2 * lib.sn_conv_stack_acc_sum_elems(5)].abs().max()) == 0
+    for l in range(5):
+        assert torch.equal(sa["cc"][l], sc["cc"][l]), l  # run-to-run
+        assert torch.allclose(sa["cc"][l], sb["cc"][l], rtol=2e-6, atol=1e-7), l
+        assert torch.equal(sa["zc"][l], sc["zc"][l]), l
+        assert _rel(sa["zc"][l], sb["zc"][l]) <= 1e-5, l
+    assert torch.equal(ya, yc) and torch.equal(sa["argsel"], sc["argsel"])
+    assert float((sa["argsel"] == sb["argsel"]).float().mean()) >= 0.995
+    assert _rel(sa["pooled"], sb["pooled"]) <= 1e-5 and _rel(ya, yb) <= 1e-4
+    for (n, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        if ba.dtype == torch.long:
+            assert int(ba) == int(bb), n
+        else:
+            assert torch.allclose(ba, bb, rtol=2e-6, atol=1e-8), n
+    y2, s2 = pointnet.forward_impl(net_a, x, True)  # a second step on the same module: accumulators were left clean
+    assert torch.equal(s2["zc"][4], sa["zc"][4]) and torch.equal(s2["cc"][4][:2], sa["cc"][4][:2])
+
+
 @pytest.mark.parametrize("B,N", [(32, 1024), (5, 320), (3, 330)])
 def test_first_activation_rebuilt_from_the_cloud(B, N):
     """Z1_FREE: the xyz layer runs as a statistics-only pass and conv2's forward / backward rebuild its activation from the

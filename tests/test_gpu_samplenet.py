@@ -277,6 +277,47 @@ def test_single_node_loss_for_the_other_sampler_architectures(variant, B, N, M, 
     # (the captured replica ran three warm-up steps: running statistics moved on, gradients are those of the same parameters;
     #  torch's own BatchNorm on the classification head's output may take another backward kernel under capture: norm-relative)
     assert float((red_a.flat - red_c.flat).norm()) <= 1e-5 * float(red_a.flat.norm())
+    # a second step: nothing of the first one is left in, or added to, the bucket (the fast path does not clear it)
+    step_a(x), step_b(x)
+    assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("t0", [0.1, 0.2, 0.3])
+def test_temperature_floor_gate_in_the_engine(t0):
+    """reconstruction/src/soft_projection.py:51-54: sigma = max(T, floor)^2 (floor 0.2 here: a well-conditioned softmax on both sides
+    of it).  The engine hands the kernels the clamped value and
+    applies the clamp's gradient gate as one in-place launch on the bucket's slice (SoftProjection._gate_floor_): zero below the
+    floor, the kernel's gradient at and above it -- as autograd's own clamp (the op-by-op step) has it; a stale value from the
+    step before must not survive a step below the floor."""
+    import copy
+
+    from samplenet_amd import SampleNet
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    B, N, M, K = 8, 512, 32, 8
+    torch.manual_seed(7)
+    net_a = SampleNet(M, 128, group_size=K, initial_temperature=0.3, input_shape="bnc", output_shape="bnc", conv_widths=(64, 128, 128, 256),
+                      fc_widths=(256, 256), fc_batchnorm=False, temperature_floor=0.2, min_sigma=0.0).cuda().train()
+    net_b = copy.deepcopy(net_a)
+    x = torch.rand(B, N, 3, device="cuda") - 0.5
+    skw = dict(alpha=0.3, lmbda=0.7, gamma=1.0, delta=0.01, use_graph=False)
+    red_a, red_b = FlatGradAllReducer(net_a), FlatGradAllReducer(net_b)
+    step_a = SamplerTrainStep(net_a, x, reducer=red_a, **skw)
+    step_b = SamplerTrainStep(net_b, x, reducer=red_b, fused_loss=False, **skw)
+    assert step_a._fast_path() and not step_b._fast_path()
+    step_a(x), step_b(x)  # T = 0.3: a non-zero temperature gradient sits in both buckets
+    assert float(net_a.project._temperature.grad.abs()) > 0
+    with torch.no_grad():
+        net_a.project._temperature.fill_(t0), net_b.project._temperature.fill_(t0)
+    la, lb = step_a(x), step_b(x)
+    assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+    ga, gb = float(net_a.project._temperature.grad), float(net_b.project._temperature.grad)
+    if t0 < 0.2:
+        assert ga == 0.0 and gb == 0.0
+    else:
+        assert gb != 0.0 and abs(ga - gb) <= 1e-5 * abs(gb)
+    assert torch.allclose(red_a.flat, red_b.flat, rtol=1e-5, atol=1e-8)
 
 
 @pytest.mark.parametrize("B,N,M,K", [(32, 1024, 64, 8), (6, 512, 64, 8), (3, 320, 20, 5)])
