@@ -64,6 +64,48 @@ def test_emd_config4_size_matches_oracle(oracle, b):
     np.testing.assert_allclose(g2.cpu().numpy(), og2, rtol=1e-4, atol=1e-5)
 
 
+def test_emd_reference_harness_shape_matches_oracle(oracle):
+    """The reference harness's own shape (approxmatch.cpp:131-144: n = 4096, m = 1024, uniform(0,1)) through all three entry
+    points: approx_match per entry against the oracle (5e-4, the GPU-vs-oracle bar of this file: both are fp32 restatements
+    of tf_approxmatch_g.cu; the oracle itself sits within the reference's 1e-2 of the compiled double-precision reference
+    at this shape: tests/test_oracle.py::test_approxmatch_vs_compiled_reference_cpu_at_configuration_sizes), marginals
+    (mass 1 shipped per xyz1 point, n/m = 4 received per xyz2 point), match_cost / sn_emd_loss (exact) / sn_emd_loss_fast
+    on the cost within 1e-5 of the oracle's, gradients within the bars of the other tests."""
+    from samplenet_amd import ops
+
+    b, n, m = 1, 4096, 1024
+    rng = np.random.default_rng(101)
+    x1 = rng.random((b, n, 3), dtype=np.float32)
+    x2 = rng.random((b, m, 3), dtype=np.float32)
+    om = oracle.approxmatch(x1, x2)
+    ocost = oracle.matchcost(x1, x2, om)
+    og1, og2 = oracle.matchcost_grad(x1, x2, om)
+    t1, t2 = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
+    match = ops.approx_match(t1, t2)
+    mh = match.cpu().numpy()
+    assert mh.shape == (b, m, n)
+    print("approx_match (4096 x 1024) vs oracle: max |d| %.2e" % np.abs(mh - om).max())
+    np.testing.assert_allclose(mh, om, rtol=0, atol=5e-4)
+    np.testing.assert_allclose(mh.sum(1), 1.0, atol=2e-3)
+    np.testing.assert_allclose(mh.sum(2), 4.0, atol=8e-3)
+    cost3 = ops.match_cost(t1, t2, match)
+    g31, g32 = torch.autograd.grad(cost3.sum(), [t1, t2])
+    for name, exact in (("sn_emd_loss", True), ("sn_emd_loss_fast", False)):
+        a1, a2 = dev(x1).requires_grad_(True), dev(x2).requires_grad_(True)
+        cost = ops.emd_loss(a1, a2, exact=exact)
+        g1, g2 = torch.autograd.grad(cost.sum(), [a1, a2])
+        rel = float(np.abs(cost.detach().cpu().numpy() - ocost).max() / np.abs(ocost).max())
+        print("%s (4096 x 1024) vs oracle: cost rel %.2e" % (name, rel))
+        assert rel <= 1e-5, (name, rel)
+        if exact:
+            assert torch.equal(cost, cost3) and torch.equal(g1, g31)
+        for g, og in ((g1, og1), (g2, og2)):
+            err = np.abs(g.cpu().numpy() - og).max() / np.abs(og).max()
+            nerr = np.linalg.norm(g.cpu().numpy() - og) / np.linalg.norm(og)
+            assert err <= 2e-3 and nerr <= 1e-4, (name, err, nerr)
+    np.testing.assert_allclose(cost3.detach().cpu().numpy(), ocost, rtol=1e-5)
+
+
 def test_emd_full_size_properties():
     """Config 4 size (n = m = 2048): transport-plan marginals -- every xyz1 point ships mass 1, every xyz2 point
     receives n/m -- and permutation equivariance of the cost."""
