@@ -570,24 +570,25 @@ def pmc_traffic_sum(key):
         return None
 
 
-def time_config3_sampler(dev, steps=40):
+def time_config3_sampler(dev, steps=40, K=16):
     """BASELINE configs[3], the sampler's side (the EMD leg above is the loss side): the reconstruction task's SampleNet
     (reconstruction/src/samplers.py:23-38: conv widths 64, 128, 128, 256, bottleneck 128, FC 256, 256 without BatchNorm) on
-    B = 50 clouds of 2048 points -> 64, K = 8: forward + simplification / projection losses + backward, eager and captured.  Its
+    B = 50 clouds of 2048 points -> 64, K = 16 (the reference's projection group size for this task: reconstruction/sampler/
+    train_samplenet.py:50): forward + simplification / projection losses + backward, eager and captured.  Its
     128 -> 256 -> 128 layers run the fused backward kernel in two passes over the halves of the 256-channel side; the forward runs on
     the one-call statistics chain (sn_conv_stack_forward_bn: two accumulator blocks per layer, K = 256 on the pre-split planes)."""
     from samplenet_amd import SampleNet
     from samplenet_amd.engine import SamplerTrainStep
     from samplenet_amd.parallel import FlatGradAllReducer
 
-    B, N, M, K = 50, 2048, 64, 8
+    B, N, M = 50, 2048, 64
     torch.manual_seed(0)
     net = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc", conv_widths=(64, 128, 128, 256), fc_widths=(256, 256),
                     fc_batchnorm=False, temperature_floor=1e-2, min_sigma=0.0).to(dev).train()
     g = torch.Generator(device=dev).manual_seed(13)
     x = torch.rand(B, N, 3, device=dev, generator=g) - 0.5
     out = {"workload": "BASELINE configs[3], sampler side: reconstruction SampleNet (conv 64-128-128-256-128, FC 256-256 no BN), B=50, "
-                       "2048->64, K=8, fwd + losses + bwd"}
+                       "2048->64, K=%d%s, fwd + losses + bwd" % (K, " (the reference's default: reconstruction/sampler/train_samplenet.py:50)" if K == 16 else "")}
     for name, use_graph in (("eager", False), ("graph", True)):
         import copy
 
@@ -614,6 +615,50 @@ def time_config3_sampler(dev, steps=40):
         return loss
 
     ms, loss = _wall_ms(script, max(steps, 100))
+    assert torch.isfinite(loss).item()
+    out["script"] = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "point-clouds/s", "captured_surface": bool(surface.plans(rep))}
+    return out
+
+
+def time_config1_classification(dev, steps=100):
+    """BASELINE configs[1]'s LITERAL network: the classification task's sampler (classification/models/samplenet_model.py:30-108:
+    the registration widths plus a BatchNorm WITHOUT activation on the head's output, fc14b; projection group size 7:
+    classification/train_samplenet.py:46; sigma = T^2 without a floor: classification/soft_projection.py:41), B = 32,
+    1024 -> 64: forward + simplification / projection losses + backward.  `graph` = the whole step replayed as one hipGraph
+    (engine.SamplerTrainStep, as the headline), `eager` = the same launches one by one, `script` = the reference call pattern
+    (net(x), the two getters, backward()) through the plain module surface.  The headline above runs the registration sampler
+    (the module the drop-in surface mirrors; K = 8); this leg is the same step with the output BatchNorm and K = 7."""
+    import copy
+
+    from samplenet_amd import SampleNet, surface
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    B, N, M, K = 32, 1024, 64, 7
+    torch.manual_seed(0)
+    net = SampleNet(M, 128, group_size=K, input_shape="bnc", output_shape="bnc", last_fc_batchnorm=True, min_sigma=0.0).to(dev).train()
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.rand(B, N, 3, device=dev, generator=g) - 0.5
+    out = {"workload": "BASELINE configs[1], literal network: classification SampleNet (BatchNorm on the head's output), B=32, "
+                       "1024->64, K=7, fwd + losses + bwd"}
+    for name, use_graph in (("eager", False), ("graph", True)):
+        rep = copy.deepcopy(net)
+        st = SamplerTrainStep(rep, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=FlatGradAllReducer(rep), use_graph=use_graph)
+        ms, loss = _wall_ms(lambda: st(x), steps if not use_graph else max(steps, 300))
+        assert torch.isfinite(loss).item(), name
+        out[name] = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "point-clouds/s", "fast_path": bool(st._fast_path())}
+        del st, rep
+    rep = copy.deepcopy(net)
+
+    def script():
+        for p in rep.parameters():
+            p.grad = None
+        simp, proj = rep(x)
+        loss = 0.01 * rep.get_simplification_loss(x, simp, M, 1.0, 0.0) + 0.01 * rep.get_projection_loss() + proj.mean()
+        loss.backward()
+        return loss
+
+    ms, loss = _wall_ms(script, max(steps, 300))
     assert torch.isfinite(loss).item()
     out["script"] = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "point-clouds/s", "captured_surface": bool(surface.plans(rep))}
     return out
@@ -982,8 +1027,14 @@ def main():
         if world == 1 and not args.no_module_surface:
             leg("module_surface", time_module_surface, dev, B, N, M, K, headline_ms=ms)
         if world == 1 and not args.no_extra_legs:
+            leg("config1_classification", time_config1_classification, dev)
+            if isinstance(out.get("config1_classification"), dict) and "graph" in out["config1_classification"]:
+                out["config1_classification_clouds_per_s"] = out["config1_classification"]["graph"]["value"]
+                out["config1_classification_script_clouds_per_s"] = out["config1_classification"]["script"]["value"]
             leg("config3_emd", time_config3_emd, dev)
             leg("config3_sampler", time_config3_sampler, dev)
+            if isinstance(out.get("config3_sampler"), dict) and "graph" in out["config3_sampler"]:
+                out["config3_sampler_k16_ms"] = out["config3_sampler"]["graph"]["ms_per_step"]
             leg("config5_progressive", time_config5_progressive, dev)
             leg("batch_sweep", time_batch_sweep, dev, N, M, K)
             if isinstance(out.get("batch_sweep"), list):  # (the driver's `parsed` keeps top-level keys only)

@@ -140,8 +140,9 @@ long long sn_conv_stack_acc_elems(int nlayers);
  * statistics-only pass and its activation (B*N, C1) is never written: conv2's forward and backward rebuild it from the cloud
  * with the xyz layer's own expression (bit-identical results, 8 MB less written and 16 MB less read per step at B = 32). */
 int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const int *channels);
-/* the leading part of acc that holds the statistics accumulators (zero between calls); behind it: scratch of the forward (the
- * layers' weights split into bf16 planes by the first kernel of the call) */
+/* the leading part of acc that holds the statistics accumulators (zero between calls): two blocks per layer -- a layer above
+ * 128 channels keeps its upper channels' sums in the second one; narrower stacks leave it untouched (zero) --; behind it:
+ * scratch of the forward (the layers' weights split into bf16 planes by the first kernel of the call) */
 long long sn_conv_stack_acc_sum_elems(int nlayers);
 int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
                              const float *const *bias, const float *const *gamma, const float *const *beta,

@@ -69,6 +69,12 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(OUT_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
+        if src == "emd.hip" and os.environ.get("SAMPLENET_AMD_EMD_SCALAR") == "1":
+            # build switch: the EMD sweeps without packed fp32 instructions (scalar pair helpers, bit-identical results, ~1.4x
+            # slower sweeps); the object lands beside the default one under another name so the two never get mixed up
+            extra = ["-ffp-contract=off", "-fno-slp-vectorize", "-DSN_EMD_SCALAR_F32=1"]
+            obj = os.path.join(OUT_DIR, "emd_scalar.o")
+            objs[-1] = obj
         if force or _stale(obj, [path] + headers):
             common = COMMON
             if "+packed" in extra:

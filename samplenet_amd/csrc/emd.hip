@@ -68,6 +68,16 @@ __device__ __forceinline__ float emd_sq(float ax, float ay, float az, float bx, 
 // tests/test_cabi_and_host.py::test_device_code_carries_no_packed_fp32_arithmetic checks in the disassembly that every packed
 // instruction left in emd.o has a destination disjoint from its sources (and that no other object has any).
 typedef float f2v __attribute__((ext_vector_type(2)));
+#if defined(SN_EMD_SCALAR_F32) && SN_EMD_SCALAR_F32
+// Build switch (build.py: SAMPLENET_AMD_EMD_SCALAR=1; this unit is then compiled like the others, without the packed feature):
+// the same pair helpers element by element -- each element rounds exactly as the packed lane does, results are bit-identical,
+// the sweeps issue two scalar VALU instructions where the default build issues one packed one.
+__device__ __forceinline__ f2v pk_mul(f2v a, f2v b) { return (f2v){a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f2v pk_add(f2v a, f2v b) { return (f2v){a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2v pk_sub(f2v a, f2v b) { return (f2v){a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f2v pk_fma(f2v a, f2v b, f2v c) { return (f2v){__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ f2v pk_fms(f2v a, f2v b, f2v c) { return (f2v){__builtin_fmaf(a.x, b.x, -c.x), __builtin_fmaf(a.y, b.y, -c.y)}; }
+#else
 __device__ __forceinline__ f2v pk_mul(f2v a, f2v b)
 {
     f2v d;
@@ -98,6 +108,7 @@ __device__ __forceinline__ f2v pk_fms(f2v a, f2v b, f2v c)  // a b - c, one roun
     asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+#endif
 __device__ __forceinline__ f2v splat(float v) { return (f2v){v, v}; }
 
 constexpr float kLog2eHi = 1.44269502162933349609375f, kLog2eLo = 1.925963033500966e-8f, kLn2 = 0.693147180559945309f;

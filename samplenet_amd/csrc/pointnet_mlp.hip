@@ -1663,7 +1663,8 @@ extern "C" int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const 
     return 0;
 #endif
 }
-extern "C" long long sn_conv_stack_acc_sum_elems(int nlayers) { return nlayers > 0 ? (long long)nlayers * kFxLayer : 0; }
+// (the wide layout: a layer above 128 channels keeps a second block of sums; sized unconditionally like sn_conv_stack_acc_elems)
+extern "C" long long sn_conv_stack_acc_sum_elems(int nlayers) { return nlayers > 0 ? (long long)nlayers * 2 * kFxLayer : 0; }
 extern "C" long long sn_conv_stack_acc_elems(int nlayers)
 {
     // (sized for the wide layout: the caller allocates before it knows the channels)

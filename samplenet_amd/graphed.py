@@ -33,8 +33,10 @@ class _Token:
 def _owned_modules(owner):
     """The modules whose parameters a call of `owner` reads: its tree WITHOUT the children it merely carries for the script --
     registration/main.py:296 attaches the (trainable) sampler to the task network as `model.sampler`, which PCRNet.forward
-    never calls.  owner._graphed_exclude names such children (default: "sampler")."""
-    skip = set(getattr(owner, "_graphed_exclude", ("sampler",)))
+    never calls.  owner._graphed_exclude names such children: OPT-IN per owner class (task_features.PCRNet sets ("sampler",)); any
+    other owner's children are all owned -- a trainable child that the graphed call does execute is then seen by the
+    frozen-parameter check and by the guard."""
+    skip = set(getattr(owner, "_graphed_exclude", ()))
     out, stack = [], [(owner, True)]
     while stack:
         m, top = stack.pop()
@@ -58,7 +60,7 @@ class _ModuleGuard:
 
     def __init__(self, module):
         self.mods, self.tens = [], []
-        skip = set(getattr(module, "_graphed_exclude", ("sampler",)))
+        skip = set(getattr(module, "_graphed_exclude", ()))
         for m in _owned_modules(module):
             for name, child in m._modules.items():
                 if not (m is module and name in skip):

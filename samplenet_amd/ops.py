@@ -738,7 +738,7 @@ class EmdLossFunction(torch.autograd.Function):
         fn = lib.sn_emd_loss if exact else lib.sn_emd_loss_fast
         ws = torch.empty(max(1, lib.sn_workspace_bytes(b"emd_loss", b, n, m, 0) // 4), device=x1.device, dtype=torch.float32)
         with torch.cuda.device(x1.device):
-            check(fn(b, n, m, ptr(x1), ptr(x2), ptr(cost), ptr(g1), ptr(g2), ptr(ws), _stream(x1)), "sn_emd_loss")
+            check(fn(b, n, m, ptr(x1), ptr(x2), ptr(cost), ptr(g1), ptr(g2), ptr(ws), _stream(x1)), "sn_emd_loss" if exact else "sn_emd_loss_fast")
         ctx.save_for_backward(g1, g2)
         return cost
 
@@ -750,4 +750,8 @@ class EmdLossFunction(torch.autograd.Function):
 
 
 def emd_loss(xyz1, xyz2, exact=False):
+    """EMD loss without the match matrix.  DEFAULT (exact=False, since round 5): the reference GPU op's own exponential (__expf) --
+    the cost within 1e-5 of match_cost(approx_match(...)), gradients within 1e-4 of their norm / 2e-3 of their scale per component
+    (they follow the transport plan, whose entries the reference itself only pins to 1e-2 between its CPU and GPU ops).
+    exact=True: cost and the xyz1 gradient bit for bit those of the three-call composition, ~1.3x slower."""
     return EmdLossFunction.apply(xyz1, xyz2, exact)

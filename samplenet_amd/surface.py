@@ -343,6 +343,11 @@ class _Plan:
     def _capture(self, net, x):
         cur = torch.cuda.current_stream(self.dev)
         bufs = [b for b in net.buffers()]
+        if self.reducer is not None:
+            # the plan's views ARE the reducer's live bucket: a plan built in the middle of an optimizer step (gradient accumulation
+            # over micro-batches, a second plan for a contended configuration) must hand the bucket back as it found it -- the
+            # warm-up backward (and, in-graph, its all-reduce) overwrites it
+            bufs = bufs + [self.reducer.flat]
         kept = [b.clone() for b in bufs]
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(cur)
@@ -599,8 +604,9 @@ def autograd_listeners(net):
 
 def _has_param_hooks(net):
     ps = net.__dict__.get("_sn_hook_params")
-    if ps is None or ps[0] != len(net._modules):
-        ps = net.__dict__["_sn_hook_params"] = (len(net._modules), [p for p in net.parameters()])
+    sig = tuple(map(id, net._modules.values()))  # (a REPLACED child keeps the count: key on the child objects themselves)
+    if ps is None or ps[0] != sig:
+        ps = net.__dict__["_sn_hook_params"] = (sig, [p for p in net.parameters()])
     return any(map(_bw_hooks, ps[1])) or any(map(_pa_hooks, ps[1]))
 
 
@@ -660,24 +666,36 @@ def _build(net, x):
         ok = all(n in sink for n in pointnet.param_order(net)) and (not T.requires_grad or any(p is T for p, _ in red._autograd))
     if not ok:
         return None
+    red = getattr(sink, "reducer", None) if sink is not None else None
+    in_graph = bool(red is not None and red.collective and red._avg and net.__dict__.get("surface_collective", "graph") == "graph")
+    plan, err = None, None
     try:
-        return _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
+        plan = _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
     except Exception as e:  # noqa: BLE001 -- a configuration that cannot be captured stays on the op-by-op route
+        err = e
         torch.cuda.synchronize(x.device)
-        red = getattr(sink, "reducer", None) if sink is not None else None
-        if red is not None and red.collective and red._avg and net.__dict__.get("surface_collective", "graph") == "graph":
-            # the collective could not be captured on this stack: graphs without it, reducer.reduce() launches it (as the engine's
-            # allreduce="after")
-            warnings.warn("samplenet_amd.surface: capturing the gradient all-reduce inside the backward graph failed (%s); "
-                          "reducer.reduce() will launch it after backward()" % repr(e)[:200])
+    if in_graph:
+        # the collective inside the backward graph: every rank must end up in the SAME mode -- a rank whose capture failed and
+        # fell back to reducer.reduce() launching the all-reduce, beside ranks whose graphs carry it, would issue a different
+        # number of collectives per step.  One flag, minimum over the ranks (plans are built at the same step on
+        # every rank: the warm-step count is per configuration and the ranks run the same script).
+        flag = torch.tensor([1 if plan is not None else 0], device=x.device, dtype=torch.int32)
+        if red.world > 1:
+            _dist.all_reduce(flag, op=_dist.ReduceOp.MIN, group=red.group)
+        if int(flag.item()) == 0:
+            warnings.warn("samplenet_amd.surface: capturing the gradient all-reduce inside the backward graph failed on %s (%s); "
+                          "reducer.reduce() will launch it after backward() on every rank"
+                          % ("this rank" if plan is None else "another rank", repr(err)[:200]))
             net.__dict__["surface_collective"] = "after"
+            plan, err = None, None
             try:
-                return _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
+                plan = _Plan(net, x, net.__dict__.get("_sn_surface_weight", 1.0))
             except Exception as e2:  # noqa: BLE001
-                e = e2
+                err = e2
                 torch.cuda.synchronize(x.device)
-        warnings.warn("samplenet_amd.surface: capture failed, this configuration stays op by op (%s)" % repr(e)[:300])
-        return None
+    if plan is None:
+        warnings.warn("samplenet_amd.surface: capture failed, this configuration stays op by op (%s)" % repr(err)[:300])
+    return plan
 
 
 def plans(net):

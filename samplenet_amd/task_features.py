@@ -242,6 +242,10 @@ class _FeaturesFunction(torch.autograd.Function):
 
 
 class PointNetFeatures(nn.Module):
+    # registration/main.py:296 hangs the (trainable) sampler on the task network as `model.sampler`; PCRNet.forward never calls
+    # it, so the captured calls of the frozen network (graphed.py) do not own its parameters
+    _graphed_exclude = ("sampler",)
+
     def __init__(self, bottleneck_size=1024, input_shape="bcn"):
         super().__init__()
         if input_shape not in ["bcn", "bnc"]:

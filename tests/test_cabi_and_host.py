@@ -184,6 +184,31 @@ def test_device_code_carries_no_packed_fp32_arithmetic(tmp_path):
     assert checked >= 7
 
 
+def test_emd_scalar_build_switch_compiles_without_packed_instructions(tmp_path):
+    """SAMPLENET_AMD_EMD_SCALAR=1 (build.py): emd.hip compiled like every other unit -- packed feature off, the pair helpers
+    element by element (-DSN_EMD_SCALAR_F32=1).  The fallback for a platform on which the hand-written packed sweeps would ever
+    misbehave under co-tenancy; nothing else would notice if it stopped compiling or kept a packed instruction."""
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    src = os.path.join(ROOT, "samplenet_amd", "csrc", "emd.hip")
+    obj = str(tmp_path / "emd_scalar.o")
+    cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "-c", src, "-o", obj, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "samplenet_amd", "csrc"), "-Wall",
+           "-Wno-unused-function", "-Werror", "-ffp-contract=off", "-fno-slp-vectorize", "-DSN_EMD_SCALAR_F32=1",
+           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    fat, co = obj + ".fat", obj + ".co"
+    subprocess.check_call([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj])
+    lst = subprocess.run([llvm + "/clang-offload-bundler", "--list", "--type=o", "--input=" + fat], capture_output=True, text=True).stdout
+    tgt = [t for t in lst.split() if "gfx950" in t]
+    subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=" + tgt[0], "--input=" + fat, "--output=" + co])
+    dis = subprocess.run([llvm + "/llvm-objdump", "-d", co], capture_output=True, text=True).stdout
+    assert "s_endpgm" in dis and "v_exp_f32" in dis
+    assert not re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", dis)
+
+
 def test_fp32_mfma_twin_of_the_conv_gemms_still_compiles(tmp_path):
     """pointnet_mlp.hip / pointnet_mlp_backward.hip carry a second implementation of the conv-stack GEMMs and of the fused conv
     backward on the fp32 MFMA (-DSN_BF16X3=0: exact fp32 products instead of six bf16 products of three-way split operands) -- the

@@ -23,15 +23,19 @@ def _stress(mode, n):
     return r.returncode == 0 and all(" 0 of %d deviated" % n in l for l in lines), lines
 
 
-@pytest.mark.parametrize("mode,n", [("fwd", 3000), ("step", 60), ("task", 25), ("emd", 120)])
+@pytest.mark.parametrize("mode,n", [("fwd", 3000), ("step", 60), ("task", 25), ("emd", 400)])
 def test_results_do_not_depend_on_a_second_process_on_the_gpu(mode, n):
-    """A build that is affected deviates in ~1 % of the passes (dozens of events in a run of the `fwd` mode).  Round 5 saw ONE
-    deviating `step` run in some 1 500 replicas of the clean build (not reproduced in 13 further runs; message not captured): a
-    single event is reported as a warning and the mode is run again at twice the length, which must be clean."""
+    """STRICT: one deviating pass fails the test.  A build that is affected deviates in ~1 % of the passes (dozens of events in a run
+    of the `fwd` mode).  The summary lines -- with the first deviation's description when there is one -- are appended to
+    gpurun_out/cotenancy_first_deviation.txt (merged back from the GPU box), so that an event leaves more than a red test behind.
+    `emd` covers the one object that carries packed fp32 instructions (hand-written, destinations disjoint from their sources:
+    emd.hip); SAMPLENET_AMD_EMD_SCALAR=1 at build time compiles that unit without them (build.py)."""
     ok, lines = _stress(mode, n)
     if not ok:
-        import warnings
-
-        warnings.warn("cotenancy_stress %s deviated once: %s -- running it again at twice the length" % (mode, " | ".join(lines)))
-        ok2, lines2 = _stress(mode, 2 * n)
-        assert ok2, "\n".join(lines + lines2)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "cotenancy_first_deviation.txt"), "a") as f:
+                f.write("\n".join(lines) + "\n")
+        except OSError:
+            pass
+    assert ok, "\n".join(lines)
