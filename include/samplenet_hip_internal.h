@@ -140,10 +140,11 @@ long long sn_conv_stack_acc_elems(int nlayers);
  * statistics-only pass and its activation (B*N, C1) is never written: conv2's forward and backward rebuild it from the cloud
  * with the xyz layer's own expression (bit-identical results, 8 MB less written and 16 MB less read per step at B = 32). */
 int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const int *channels);
-/* the leading part of acc that holds the statistics accumulators (zero between calls): two blocks per layer -- a layer above
- * 128 channels keeps its upper channels' sums in the second one; narrower stacks leave it untouched (zero) --; behind it:
- * scratch of the forward (the layers' weights split into bf16 planes by the first kernel of the call) */
-long long sn_conv_stack_acc_sum_elems(int nlayers);
+/* the leading part of acc that holds the statistics accumulators (zero between calls): one block of sums per layer, two when a
+ * layer of the stack is wider than 128 channels (channels: the nlayers + 1 widths as passed to sn_conv_stack_forward_bn, or NULL for
+ * the narrow layout); behind it: scratch of the forward (the layers' weights split into bf16 planes by the first kernel of the
+ * call), which is not zero between calls */
+long long sn_conv_stack_acc_sum_elems(int nlayers, const int *channels);
 int sn_conv_stack_forward_bn(int B, int N, int nlayers, const int *channels, const float *x, const float *const *W,
                              const float *const *bias, const float *const *gamma, const float *const *beta,
                              float *const *running_mean, float *const *running_var, long long *const *num_batches_tracked,
@@ -236,6 +237,26 @@ int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci, const floa
 int sn_bn_batch_stats_twopass(int R, int C, const float *z, const float *gamma, const float *beta, float eps, float momentum,
                               float *running_mean, float *running_var, long long *num_batches_tracked, float *coef,
                               sn_stream_t stream);
+
+/* The BatchNorm WITHOUT activation on the head's output -- the classification task's sampler (classification/models/
+ * samplenet_model.py:100-108: fc14b with bn=True, activation_fn=None; the registration sampler has no such layer, registration/
+ * src/samplenet.py:59,104).
+ *   sn_layer_forward_bn_out   R <= 32 rows, Ci a power of two in 64 .. 512: ONE launch -- z (R, Co) = act(ain) W^T + bias (act =
+ *                             relu(scale x + shift) with coef_prev, identity when NULL), training-mode batch statistics over the R
+ *                             rows -> coef (4, Co) = scale, shift, mean, invstd + running statistics as torch.nn.BatchNorm1d, and
+ *                             y (R, Co) = z scale + shift.  Other shapes: SN_ERR_UNSUPPORTED (sn_linear_forward_rows + the next one).
+ *   sn_bn_output_forward      any R, C % 4 == 0: training != 0: two-pass batch statistics of z (as sn_bn_batch_stats_twopass), else
+ *                             coefficients from the running statistics; then y = z scale + shift.
+ *   sn_bn_output_backward     gy (R, C) -> dz (R, C), dgamma (C), dbeta (C); fixed != 0: the forward ran on running statistics
+ *                             (dz = scale gy).  Sums in double, fixed order (deterministic). */
+int sn_layer_forward_bn_out(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W, const float *bias,
+                            float *z, const float *gamma, const float *beta, float eps, float momentum, float *running_mean,
+                            float *running_var, long long *num_batches_tracked, float *coef, float *y, sn_stream_t stream);
+int sn_bn_output_forward(int R, int C, int training, const float *z, const float *gamma, const float *beta, float eps,
+                         float momentum, float *running_mean, float *running_var, long long *num_batches_tracked, float *coef,
+                         float *y, sn_stream_t stream);
+int sn_bn_output_backward(int R, int C, int fixed, const float *gy, const float *z, const float *coef, float *dz, float *dgamma,
+                          float *dbeta, sn_stream_t stream);
 
 /* sn_pool_backward + sn_bn_backward_coef of the last conv layer (R = B * N rows seen by its BatchNorm) in one launch */
 int sn_pool_backward_bn(int B, int C, long long R, const float *g, const float *pooled, const float *zsel, float *gsel,

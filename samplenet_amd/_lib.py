@@ -84,7 +84,7 @@ PROTOTYPES = {
     "sn_conv_stack_forward_supported": [_i, _i, _i, _vp],
     "sn_conv_stack_acc_elems": [_i],
     "sn_conv_stack_z1_free_supported": [_i, _i, _i, _vp],
-    "sn_conv_stack_acc_sum_elems": [_i],
+    "sn_conv_stack_acc_sum_elems": [_i, ctypes.c_void_p],
     "sn_conv_stack_backward_scratch_floats": [_i, _i, _i, _vp],
     "sn_conv_stack_backward": [_i, _i, _i] + [_vp] * 17,
     "sn_conv_stack_forward_bn": [_i, _i, _i] + [_vp] * 20,
@@ -117,6 +117,9 @@ PROTOTYPES = {
     "sn_pool_dgrad_sparse": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_batch_stats_twopass": [_i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_eval_coef": [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp],
+    "sn_layer_forward_bn_out": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_bn_output_forward": [_i, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_bn_output_backward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_pool_forward": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_pool_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_pool_backward_bn": [_i, _i, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -918,6 +918,9 @@ struct FwdArgs {
     float *z;
     float *stats;  // may be null
     BnFwd bn;      // small-R kernels only: finalise the BatchNorm in the epilogue (bn.coef != NULL)
+    // small_fwd_lds_kernel with bn.coef: also the NORMALISED output y = z scale + shift, no activation, (R, Co) -- the head's
+    // output layer of the classification sampler (classification/models/samplenet_model.py:100-108: fc14b, bn, activation_fn=None)
+    float *bn_y;
     // last conv layer (FULL tiles, 64-row blocks inside one cloud): per block and column the maximum and minimum of the
     // pre-BN output with their first row -- the max-pool over the points is then finished by bn_finalize_pool_kernel
     float *pool_val;  // [gridDim.x][2][Co]  (max, min)

@@ -842,22 +842,41 @@ __global__ void __launch_bounds__(256) small_fwd_lds_kernel(FwdArgs g)
             if (frag_row(e, lane) < R && colok) s2 += d * d;
         }
         s2 += __shfl_xor(s2, 32);
-        if (lane < 32 && colok) {  // same arithmetic as bn_finalize_channel, on the prefetched parameters
-            const double rR = fast_rcp((double)g.bn.R);
-            const double mean = (double)s0 * rR;
-            const double dm = mean - (double)meanf;  // sum (z - meanf)^2 = sum (z - mean)^2 + R dm^2
-            double var = (double)s2 * rR - dm * dm;
-            if (var < 0.0) var = 0.0;
-            const float invstd = (float)fast_rsqrt(var + (double)g.bn.eps);
-            const float sc = bn_g * invstd;
+        // same arithmetic as bn_finalize_channel, on the prefetched parameters (both lanes of a column evaluate it: each holds
+        // 16 of the column's rows for the normalised output below; one of them stores)
+        const double rR = fast_rcp((double)g.bn.R);
+        const double mean = (double)s0 * rR;
+        const double dm = mean - (double)meanf;  // sum (z - meanf)^2 = sum (z - mean)^2 + R dm^2
+        double var = (double)s2 * rR - dm * dm;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)fast_rsqrt(var + (double)g.bn.eps);
+        const float sc = bn_g * invstd, sh = bn_b - (float)mean * sc;
+        if (lane < 32 && colok) {
             g.bn.coef[col] = sc;
-            g.bn.coef[Co + col] = bn_b - (float)mean * sc;
+            g.bn.coef[Co + col] = sh;
             g.bn.coef[2 * Co + col] = (float)mean;
             g.bn.coef[3 * Co + col] = invstd;
             if (g.bn.running_mean) {
                 const double unbiased = g.bn.R > 1 ? var * (double)g.bn.R * fast_rcp((double)(g.bn.R - 1)) : var;
                 g.bn.running_mean[col] = (1.f - g.bn.momentum) * bn_rm + g.bn.momentum * (float)mean;
                 g.bn.running_var[col] = (1.f - g.bn.momentum) * bn_rv + g.bn.momentum * (float)unbiased;
+            }
+        }
+        if (g.bn_y) {  // y = z scale + shift (no activation) through the same transposing tile as z
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = frag_row(e, lane);
+                const float y = fmaf(acc[e] + bias, sc, sh);
+                if (!vec_out && rb + row < R && colok) g.bn_y[(size_t)(rb + row) * Co + col] = y;
+                Ts[row * 36 + l31] = y;
+            }
+            if (vec_out) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + (lane >> 3);
+                    const float4 v = *reinterpret_cast<const float4 *>(Ts + row * 36 + (lane & 7) * 4);
+                    if (rb + row < R) *reinterpret_cast<float4 *>(g.bn_y + (size_t)(rb + row) * Co + col0 + (lane & 7) * 4) = v;
+                }
             }
         }
     }
@@ -1334,6 +1353,62 @@ __global__ void __launch_bounds__(1024) bn_twopass_kernel(int R, int C, const fl
     if (stripe == 0 && ok) bn_finalize_channel_mv(bn, C, c, mean, total() / (double)R, in);
 }
 
+// y = z scale + shift, no activation: the BatchNorm on the head's OUTPUT (classification sampler) where the GEMM kernel could
+// not apply it in its epilogue (more than 32 rows: statistics from bn_twopass_kernel; eval mode: running statistics)
+__global__ void __launch_bounds__(256) bn_apply_kernel(long long n4, int C, const float *__restrict__ z, const float *__restrict__ coef,
+                                                       float *__restrict__ y)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // float4 index; C % 4 == 0
+    if (i >= n4) return;
+    const int c = (int)((i * 4) % C);
+    const float4 v = reinterpret_cast<const float4 *>(z)[i];
+    const float4 sc = *reinterpret_cast<const float4 *>(coef + c), sh = *reinterpret_cast<const float4 *>(coef + C + c);
+    reinterpret_cast<float4 *>(y)[i] = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+}
+
+// Backward of that output BatchNorm: gy (R, C) upstream gradient, z (R, C) its input, coef (4, C) of the forward ->
+// dz (R, C), dgamma, dbeta (C).  Batch statistics (fixed == 0):  dbeta = sum gy, dgamma = invstd sum gy (z - mean),
+// dz = k1 gy + k2 z + k3 with k1 = scale, k2 = -scale invstd dgamma / R, k3 = scale (invstd mean dgamma / R - dbeta / R) -- the
+// expressions of the GEMM kernels' BatchNorm-backward epilogues (fc_chain_bwd_kernel), without a ReLU mask.  Running statistics
+// (fixed != 0, an eval-mode forward): dz = scale gy.  64 channels x 16 row stripes per workgroup, sums in double, fixed order.
+__global__ void __launch_bounds__(1024) bn_output_bwd_kernel(int R, int C, int fixed, const float *__restrict__ gy,
+                                                             const float *__restrict__ z, const float *__restrict__ coef,
+                                                             float *__restrict__ dz, float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    __shared__ double red[2][16][64];
+    __shared__ float ks[3][64];
+    const int lane = threadIdx.x & 63, stripe = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < C;
+    const int cc = ok ? c : 0;
+    const float scale = coef[cc], mean = coef[2 * C + cc], invstd = coef[3 * C + cc];
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = stripe; r < R; r += 16) {
+        const float g = gy[(size_t)r * C + cc], v = z[(size_t)r * C + cc];
+        s0 += (double)g;
+        s1 += (double)g * (double)(v - mean);
+    }
+    red[0][stripe][lane] = s0, red[1][stripe][lane] = s1;
+    __syncthreads();
+    if (stripe == 0) {
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t0 += red[0][q][lane], t1 += red[1][q][lane];
+        const double dg = (double)invstd * t1, rinv = 1.0 / (double)R, sc = scale;
+        if (ok) dgamma[c] = (float)dg, dbeta[c] = (float)t0;
+        ks[0][lane] = scale;
+        ks[1][lane] = fixed ? 0.f : (float)(-sc * (double)invstd * dg * rinv);
+        ks[2][lane] = fixed ? 0.f : (float)(sc * ((double)invstd * (double)mean * dg * rinv - t0 * rinv));
+    }
+    __syncthreads();
+    const float k1 = ks[0][lane], k2 = ks[1][lane], k3 = ks[2][lane];
+    if (ok)
+        for (int r = stripe; r < R; r += 16) {
+            const size_t o = (size_t)r * C + c;
+            dz[o] = fmaf(k1, gy[o], fmaf(k2, z[o], k3));
+        }
+}
+
 // eval: coefficients from the running statistics
 __global__ void bn_eval_coef_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                     const float *__restrict__ running_mean, const float *__restrict__ running_var,
@@ -1663,8 +1738,13 @@ extern "C" int sn_conv_stack_z1_free_supported(int B, int N, int nlayers, const 
     return 0;
 #endif
 }
-// (the wide layout: a layer above 128 channels keeps a second block of sums; sized unconditionally like sn_conv_stack_acc_elems)
-extern "C" long long sn_conv_stack_acc_sum_elems(int nlayers) { return nlayers > 0 ? (long long)nlayers * 2 * kFxLayer : 0; }
+// the statistics region at the head of acc: one block of sums per layer, TWO when a layer of the stack is wider than 128 channels
+// (channels == NULL: the narrow layout).  Behind it sits the forward's scratch (split-weight planes), which is NOT zero between calls.
+extern "C" long long sn_conv_stack_acc_sum_elems(int nlayers, const int *channels)
+{
+    if (nlayers <= 0) return 0;
+    return (long long)nlayers * ((channels && conv_stack_wide(nlayers, channels)) ? 2 : 1) * kFxLayer;
+}
 extern "C" long long sn_conv_stack_acc_elems(int nlayers)
 {
     // (sized for the wide layout: the caller allocates before it knows the channels)
@@ -1885,6 +1965,68 @@ extern "C" int sn_bn_batch_stats_twopass(int R, int C, const float *z, const flo
     SN_REQUIRE(R >= 1 && C >= 1 && z && gamma && beta && coef, "bad argument");
     const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
     hipLaunchKernelGGL(bn_twopass_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, R, C, z, bn);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The head's OUTPUT layer with a BatchNorm and no activation behind it (classification sampler: classification/models/
+// samplenet_model.py:100-108) as ONE launch for R <= 32 rows: z = ain' W^T + bias (ain' = relu(bn(ain)) when coef_prev),
+// training-mode batch statistics over the R rows -> coef (4, Co) + running statistics, y = z scale + shift.  Needs
+// Ci in {64, 128, 256, 512} (the LDS-staged small-R kernel); otherwise SN_ERR_UNSUPPORTED (compose sn_linear_forward_rows +
+// sn_bn_output_forward).
+extern "C" int sn_layer_forward_bn_out(int R, int Ci, int Co, const float *ain, const float *coef_prev, const float *W,
+                                       const float *bias, float *z, const float *gamma, const float *beta, float eps, float momentum,
+                                       float *running_mean, float *running_var, long long *num_batches_tracked, float *coef,
+                                       float *y, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && Ci >= 1 && Co >= 1, "bad size");
+    SN_REQUIRE(ain && W && z && gamma && beta && coef && y, "null pointer");
+    if (R > 32 || Ci < 64 || Ci > 512 || (Ci & (Ci - 1)))
+        return sn_set_error(SN_ERR_UNSUPPORTED, "sn_layer_forward_bn_out: R <= 32 rows, Ci a power of two in 64 .. 512");
+    FwdArgs g{};
+    g.a = make_act(ain, coef_prev, R, Ci);
+    g.w.w = W, g.w.co = Co, g.w.ci = Ci;
+    g.bias = bias, g.z = z, g.stats = nullptr;
+    g.bn = BnFwd{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
+    g.bn_y = y;
+    hipStream_t st = (hipStream_t)stream;
+    if (coef_prev)
+        launch_fwd<ACT_BN_RELU>(g, st);
+    else
+        launch_fwd<ACT_NONE>(g, st);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// BatchNorm WITHOUT activation on a short matrix z (R, C), C % 4 == 0: training != 0 -- two-pass batch statistics (as
+// sn_bn_batch_stats_twopass: coef, running statistics), else coefficients from the running statistics; then y = z scale + shift.
+extern "C" int sn_bn_output_forward(int R, int C, int training, const float *z, const float *gamma, const float *beta, float eps,
+                                    float momentum, float *running_mean, float *running_var, long long *num_batches_tracked,
+                                    float *coef, float *y, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && C >= 4 && C % 4 == 0 && z && gamma && beta && coef && y, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (training) {
+        const BnFwd bn{gamma, beta, running_mean, running_var, num_batches_tracked, coef, eps, momentum, (long long)R};
+        hipLaunchKernelGGL(bn_twopass_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, R, C, z, bn);
+    } else {
+        SN_REQUIRE(running_mean && running_var, "eval mode needs the running statistics");
+        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, gamma, beta, eps, running_mean, running_var, coef);
+    }
+    const long long n4 = (long long)R * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, n4, C, z, coef, y);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of sn_layer_forward_bn_out / sn_bn_output_forward's BatchNorm: see bn_output_bwd_kernel.  fixed != 0: the forward ran
+// on running statistics.
+extern "C" int sn_bn_output_backward(int R, int C, int fixed, const float *gy, const float *z, const float *coef, float *dz,
+                                     float *dgamma, float *dbeta, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && C >= 1 && gy && z && coef && dz && dgamma && dbeta, "bad argument");
+    hipLaunchKernelGGL(bn_output_bwd_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, R, C, fixed, gy, z, coef, dz,
+                       dgamma, dbeta);
     SN_LAUNCH_CHECK();
     return 0;
 }

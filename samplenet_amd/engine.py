@@ -83,7 +83,7 @@ class SamplerTrainStep:
             return False
         if not self.fused_loss or not net.training or net.skip_projection or net.input_shape != "bnc":
             return False
-        if not getattr(net, "standard_arch", True) and self.task_loss is not None:
+        if not (getattr(net, "standard_arch", True) or getattr(net, "standard_arch_out_bn", False)) and self.task_loss is not None:
             # the sampler variants of the TF packages (reconstruction: other widths, no BatchNorm in the FC head, clamped temperature;
             # classification: a BatchNorm on the head's output): the single-node LOSS applies to them as it is (the head runs through
             # net._features, the temperature through the module's own clamp); the fc4-in-scan / outside-task forms do not
@@ -120,7 +120,8 @@ class SamplerTrainStep:
         if self._fast_path():
             from . import ops
 
-            std = getattr(net, "standard_arch", True)
+            # (registration architecture, or the same with the classification sampler's BatchNorm on the head's output)
+            std = getattr(net, "standard_arch", True) or getattr(net, "standard_arch_out_bn", False)
             T = net.project._temperature
             floor = getattr(net.project, "_temperature_floor", None) is not None
             t_sink = None
@@ -132,8 +133,8 @@ class SamplerTrainStep:
                 self.reducer._rebind()  # (after an optimizer.zero_grad(): T.grad is the bucket's view again)
                 t_sink = T.grad.view(-1)[:1]  # a view of the flat bucket: written in place, nothing to zero or accumulate
                 if self.reducer.autograd_accumulated > 1:
-                    # classification sampler: torch applies a BatchNorm on the head's output -- its weight / bias gradients are
-                    # ACCUMULATED into their slices by autograd, step after step unless they are cleared here
+                    # parameters besides the temperature that torch differentiates (a SyncBatchNorm on the head's output): their
+                    # gradients are ACCUMULATED into their slices by autograd, step after step unless they are cleared here
                     self.reducer.zero_grad(keep=T)
             elif self.reducer is not None:
                 self.reducer.zero_grad()

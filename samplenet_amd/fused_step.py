@@ -49,10 +49,15 @@ class SamplerStepFunction(torch.autograd.Function):
         B = x.shape[0]
         M = net.num_out_points
         with torch.cuda.device(x.device):
-            _, saved = pointnet.forward_impl(net, x, True, skip_last=True)
-            fc4 = net.fc4
-            y = torch.empty(B, 3, M, device=x.device, dtype=torch.float32)
-            fc = (saved["zf"][2], saved["cf"][2], fc4.weight.detach(), fc4.bias.detach())
+            yo, saved = pointnet.forward_impl(net, x, True, skip_last=True)
+            if yo is None:  # the wave that scans query j computes its coordinates itself (the head's output layer inside the scan)
+                fc4 = getattr(net, "fc%d" % getattr(net, "num_fc_layers", 4))
+                y = torch.empty(B, 3, M, device=x.device, dtype=torch.float32)
+                fc = (saved["zf"][-1], saved["cf"][-1], fc4.weight.detach(), fc4.bias.detach())
+            else:
+                # classification sampler: a BatchNorm over the clouds sits on the head's output (pointnet.out_bn) -- every cloud's
+                # queries exist before any scan starts: the scan reads them (one more launch forward, one more backward)
+                y, fc = yo.view(B, 3, M), None
             keys = None
             token = None
             if defer_value and KEYS_LOSS and x.shape[1] <= 2048:

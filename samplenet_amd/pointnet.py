@@ -37,15 +37,17 @@ def _layers(net):
     """conv1..conv5 (each with its BatchNorm) and fc1..fcK of the sampler.  Hidden FC layers carry a BatchNorm in the
     registration / classification samplers (samplenet.py:52-59) and none in the reconstruction sampler (samplers.py:33-38);
     the last FC layer is always returned without one -- a BatchNorm behind it (classification/models/samplenet_model.py:
-    100-108) is applied by the caller on the head's output (pointnet_head).
+    100-108; no activation) is a record of its own (out_bn): forward_impl / backward_impl run it on sn_layer_forward_bn_out /
+    sn_bn_output_backward, its weight and bias close the parameter list.
     The records are kept on the module (this runs several times per step and nn.Module attribute lookups are slow) and
     rebuilt when a layer's weight Parameter is no longer the one recorded (a layer was replaced)."""
     d = net.__dict__
     mods = d["_modules"]
     cached = d.get("_sn_layer_records")
+    out_bn = _plain_out_bn(net, mods)
     if cached is not None:
-        convs, fcs, _, _ = cached
-        ok = True
+        convs, fcs = cached[0], cached[1]
+        ok = (cached[4][1] if cached[4] is not None else None) is out_bn
         for L in convs + fcs:  # weight, bias and the BatchNorm MODULE are still the recorded ones (a replaced bias / a layer swapped
             m = mods[L.name]   # for torch.nn.SyncBatchNorm or a frozen copy would otherwise keep feeding stale pointers)
             if m._parameters["weight"] is not L.W or m._parameters["bias"] is not L.b or \
@@ -70,8 +72,29 @@ def _layers(net):
     for L in convs + fcs:
         if L.bn is not None:
             params += [L.bn.weight, L.bn.bias]
-    d["_sn_layer_records"] = (convs, fcs, tuple(names), tuple(params))
+    ob = None
+    if out_bn is not None:  # the BatchNorm behind the last FC layer: differentiated by the node as well (out_bn below)
+        ob = ("bn_fc%d" % nfc, out_bn)
+        names += [ob[0] + ".weight", ob[0] + ".bias"]
+        params += [out_bn.weight, out_bn.bias]
+    d["_sn_layer_records"] = (convs, fcs, tuple(names), tuple(params), ob)
     return convs, fcs
+
+
+def _plain_out_bn(net, mods):
+    """The BatchNorm module behind the LAST FC layer when the HIP path applies it itself: a plain torch.nn.BatchNorm1d of the
+    classification sampler (classification/models/samplenet_model.py:100-108).  None: no such layer, or one that torch applies on
+    the head's output (torch.nn.SyncBatchNorm after syncbn.convert_sync_batchnorm: statistics over all ranks)."""
+    m = mods.get("bn_fc%d" % net.__dict__.get("num_fc_layers", 4))
+    if m is None or type(m) is not torch.nn.BatchNorm1d or not m.affine or net.__dict__.get("_sn_sync_bn") is not None:
+        return None
+    return m
+
+
+def out_bn(net):
+    """(module attribute name, BatchNorm1d) of the output BatchNorm the head's node applies and differentiates, or None."""
+    _layers(net)
+    return net.__dict__["_sn_layer_records"][4]
 
 
 def param_order(net):
@@ -413,12 +436,41 @@ def forward_impl(net, x_bnc, training, skip_last=False, use_plan=True):
         saved["cf"].append(coef)
         a_in, coef_prev = z, coef
     y = None
-    if not skip_last:
-        y, _, _ = _linear_fwd(B, fcs[-1], a_in, coef_prev, False, fc_rows=True)
+    ob = out_bn(net)
+    if ob is not None or not skip_last:  # (an output BatchNorm needs every cloud's row: the caller cannot produce y itself)
+        y = _last_layer(B, fcs[-1], ob, a_in, coef_prev, training, saved)
     if rec is not None and len(rec) == 2 and not convs and not hidden:
         # the whole head ran as the two fused calls (+ the last layer): from now on steps of this shape replay them
-        _ForwardPlan.register(net, x_bnc, skip_last, rec, saved, fcs[-1])
+        _ForwardPlan.register(net, x_bnc, skip_last, rec, saved, (fcs[-1], ob))
     return y, saved
+
+
+def _last_layer(B, L, ob, a_in, coef_prev, training, saved):
+    """The head's output layer: y (B, Co) = act(a_in) W^T + b, and -- classification sampler -- the BatchNorm without activation
+    behind it (ob = out_bn(net)): one launch up to 32 clouds (sn_layer_forward_bn_out), GEMM + two-pass statistics + apply above.
+    Leaves saved["z_out"] / saved["c_out"] (pre-BN output, coefficients) for backward_impl."""
+    if ob is None:
+        return _linear_fwd(B, L, a_in, coef_prev, False, fc_rows=True)[0]
+    bn = ob[1]
+    batch_stats = bool(training or not bn.track_running_stats)
+    upd = bool(training and bn.track_running_stats)
+    coef = _empty((4, L.Co), a_in)
+    y = _empty((B, L.Co), a_in)
+    rm, rv, nbt = (ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)) if upd else (None, None, None)
+    if batch_stats and B <= 32 and L.Ci in (64, 128, 256, 512):
+        z = _empty((B, L.Co), a_in)
+        check(lib.sn_layer_forward_bn_out(B, L.Ci, L.Co, ptr(a_in), ptr(coef_prev), ptr(L.W), ptr(L.b), ptr(z), ptr(bn.weight),
+                                          ptr(bn.bias), float(bn.eps), _momentum(bn), rm, rv, nbt, ptr(coef), ptr(y), _st(a_in)),
+              "sn_layer_forward_bn_out")
+    else:
+        z = _linear_fwd(B, L, a_in, coef_prev, False, fc_rows=True)[0]
+        if not batch_stats:
+            rm, rv = ptr(bn.running_mean), ptr(bn.running_var)
+        check(lib.sn_bn_output_forward(B, L.Co, 1 if batch_stats else 0, ptr(z), ptr(bn.weight), ptr(bn.bias), float(bn.eps),
+                                       _momentum(bn) if batch_stats else 0.0, rm, rv, nbt, ptr(coef), ptr(y), _st(a_in)),
+              "sn_bn_output_forward")
+    saved["z_out"], saved["c_out"], saved["out_fixed"] = z, coef, not batch_stats
+    return y
 
 
 class _Lease:
@@ -468,6 +520,11 @@ class _ForwardPlan:
                 bn = L.bn
                 sig += [bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                         bn.num_batches_tracked.data_ptr(), bn.eps, bn.momentum]
+        ob = out_bn(net)
+        if ob is not None:
+            bn = ob[1]
+            sig += [bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps, bn.momentum, bn.track_running_stats] + (
+                [bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()] if bn.track_running_stats else [])
         return tuple(sig)
 
     @staticmethod
@@ -506,7 +563,7 @@ class _ForwardPlan:
         plan.saved = dict(saved)
         plan.saved.pop("_lease", None)
         plan.saved["_bwd_cache"] = saved["_bwd_cache"] = {}  # static pieces of the backward's argument lists (_conv_stack_bwd_fx)
-        plan.last = None if skip_last else last_layer
+        plan.last = None if (skip_last and last_layer[1] is None) else last_layer  # (fcs[-1], out_bn record)
         plan.busy = False
         saved["_lease"] = _Lease(plan)  # the recording step itself runs on these buffers
         plans.append(plan)
@@ -528,7 +585,7 @@ class _ForwardPlan:
                 check(rc, name)
         y = None
         if self.last is not None:
-            y, _, _ = _linear_fwd(saved["B"], self.last, saved["zf"][-1], saved["cf"][-1], False)
+            y = _last_layer(saved["B"], self.last[0], self.last[1], saved["zf"][-1], saved["cf"][-1], True, saved)
         return y, saved
 
 
@@ -840,6 +897,17 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
     fixed = not saved.get("training", True)
     bn_rows = -1 if fixed else 0
 
+    if "z_out" in saved:
+        # the BatchNorm (no activation) behind the last FC layer: dZ of that layer, the BatchNorm's own gradients
+        obn, ob = out_bn(net)
+        zo = saved["z_out"]
+        dz = _empty(tuple(zo.shape), zo)
+        dgo, dbo = _out(sink, obn + ".weight", ob.weight), _out(sink, obn + ".bias", ob.bias)
+        check(lib.sn_bn_output_backward(B, zo.shape[1], 1 if saved["out_fixed"] else 0, ptr(grad_y), ptr(zo), ptr(saved["c_out"]),
+                                        ptr(dz), ptr(dgo), ptr(dbo), _st(zo)), "sn_bn_output_backward")
+        grads[obn + ".weight"], grads[obn + ".bias"] = dgo, dbo
+        grad_y = dz
+
     # ---- FC head (rows = B): fc4 -> fc3 -> fc2 -> fc1 -> pooled features ----
     dy, kcoef = grad_y, None
     chain = FC_CHAIN and B <= 32 and _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed)
@@ -922,7 +990,8 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
 
 
 class PointNetMLPFunction(torch.autograd.Function):
-    """y (B, 3M) = head(x (B,N,3)); differentiable w.r.t. all 34 parameter tensors (x is data: no gradient)."""
+    """y (B, 3M) = head(x (B,N,3)); differentiable w.r.t. all 34 parameter tensors (36 with an output BatchNorm; x is data: no
+    gradient)."""
 
     @staticmethod
     def forward(ctx, net, x_bnc, training, *params):
@@ -967,7 +1036,8 @@ def pointnet_head(net, x_bnc):
     else:
         with torch.cuda.device(x_bnc.device):
             y, _ = forward_impl(net, x_bnc, net.training)
-    last_bn = getattr(net, "bn_fc%d" % getattr(net, "num_fc_layers", 4), None)
-    if last_bn is not None:  # classification sampler: BatchNorm (no activation) on the head's output, B x 3M values: torch
-        y = last_bn(y)
+    if out_bn(net) is None:
+        last_bn = getattr(net, "bn_fc%d" % getattr(net, "num_fc_layers", 4), None)
+        if last_bn is not None:  # only torch.nn.SyncBatchNorm gets here (syncbn.convert_sync_batchnorm): statistics over all ranks
+            y = last_bn(y)
     return y.view(-1, 3, net.num_out_points)

@@ -76,6 +76,10 @@ class SampleNet(nn.Module):
         self.standard_arch = (conv_widths[1:5] == (64, 64, 64, 128) and fc_widths[1:-1] == (256, 256, 256) and fc_batchnorm
                               and not last_fc_batchnorm and temperature_floor is None)
 
+        # ... and to the classification sampler: the same layers plus a BatchNorm on the head's output (the scan then reads
+        # the queries instead of computing fc4 in its waves: fused_step.py)
+        self.standard_arch_out_bn = (conv_widths[1:5] == (64, 64, 64, 128) and fc_widths[1:-1] == (256, 256, 256) and fc_batchnorm
+                                     and last_fc_batchnorm and temperature_floor is None)
         self.project = SoftProjection(group_size, initial_temperature, is_temperature_trainable, min_sigma,
                                       temperature_floor=temperature_floor)
         self.skip_projection = skip_projection

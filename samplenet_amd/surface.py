@@ -294,10 +294,12 @@ class _Plan:
     def _forward_body(self, net):
         B, N, M, K = self.shape
         x = self.x
-        _, saved = pointnet.forward_impl(net, x, True, skip_last=True, use_plan=False)
+        yo, saved = pointnet.forward_impl(net, x, True, skip_last=True, use_plan=False)
         fc4 = getattr(net, "fc%d" % net.num_fc_layers)  # the head's output layer (fc4 of the registration architecture)
         T = net.project._temperature
-        self.y = torch.empty(B, 3, M, device=self.dev, dtype=torch.float32)
+        # (yo: the classification sampler's BatchNorm on the head's output needs every cloud's row -- the head produced the queries
+        #  itself, the scan reads them instead of computing the output layer in its waves)
+        self.y = torch.empty(B, 3, M, device=self.dev, dtype=torch.float32) if yo is None else yo.view(B, 3, M)
         # (the reconstruction variant squares max(T, floor): the clamped value is a static tensor of the forward graph, its
         #  gradient gate a launch of the backward graph)
         floor = net.project._temperature_floor
@@ -305,7 +307,7 @@ class _Plan:
         if floor is not None:
             self.t_eff = torch.clamp(T.detach(), min=floor)
             T = self.t_eff
-        fc = (saved["zf"][-1], saved["cf"][-1], fc4.weight.detach(), fc4.bias.detach())
+        fc = (saved["zf"][-1], saved["cf"][-1], fc4.weight.detach(), fc4.bias.detach()) if yo is None else None
         sec = self.out_sec
         self.simp = self.outbuf[0:B * M * 3].view(B, M, 3)
         self.values = self.outbuf[2 * sec:2 * sec + 8]
@@ -575,15 +577,17 @@ def _supported(net, x):
 def _variant_ok(net):
     """The sampler variants of the TF packages besides the registration architecture: any conv / FC widths and FC layers without
     BatchNorm (reconstruction/src/samplers.py:23-38) run the same launches -- the MLP entry points are generic over the layer
-    list, the scan computes its queries from the last hidden layer whatever its width.  Not the classification sampler: its
-    BatchNorm on the head's OUTPUT (samplenet_model.py:30-108) needs all clouds' queries before any scan can start."""
+    list, the scan computes its queries from the last hidden layer whatever its width.  The classification sampler's BatchNorm
+    on the head's OUTPUT (samplenet_model.py:30-108) needs all clouds' queries before any scan can start: the head then ends in
+    sn_layer_forward_bn_out and the scan reads the queries (pointnet.out_bn; one launch more in either graph).  A last BatchNorm
+    that torch applies (SyncBatchNorm) stays op by op."""
     ok = net.__dict__.get("_sn_variant_ok")
     if ok is None:
         _, fcs = pointnet._layers(net)
-        # (pointnet._layers does not list a BatchNorm behind the LAST FC layer -- torch applies it on the head's output --: ask the
-        #  module itself)
-        last_bn = net._modules.get("bn_fc%d" % net.num_fc_layers) is not None
-        ok = net.__dict__["_sn_variant_ok"] = bool(len(fcs) >= 2 and not last_bn and fcs[-1].bn is None and fcs[-2].Co % 4 == 0
+        last_bn = net._modules.get("bn_fc%d" % net.num_fc_layers)
+        ob = pointnet.out_bn(net)
+        hip_last = last_bn is None or (ob is not None and ob[1] is last_bn and last_bn.momentum is not None)
+        ok = net.__dict__["_sn_variant_ok"] = bool(len(fcs) >= 2 and hip_last and fcs[-1].bn is None and fcs[-2].Co % 4 == 0
                                                    and "_features" not in net.__dict__)
     return ok
 

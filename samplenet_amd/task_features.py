@@ -242,10 +242,6 @@ class _FeaturesFunction(torch.autograd.Function):
 
 
 class PointNetFeatures(nn.Module):
-    # registration/main.py:296 hangs the (trainable) sampler on the task network as `model.sampler`; PCRNet.forward never calls
-    # it, so the captured calls of the frozen network (graphed.py) do not own its parameters
-    _graphed_exclude = ("sampler",)
-
     def __init__(self, bottleneck_size=1024, input_shape="bcn"):
         super().__init__()
         if input_shape not in ["bcn", "bnc"]:
@@ -428,6 +424,10 @@ class PCRNet(nn.Module):
     `sn_skinny_linear` (forward and data gradient) in row blocks of up to 128 -- frozen as in the sampler's training step, or
     trainable (main.py --train-pcrnet: weight / bias gradients on `sn_skinny_wgrad`); no library GEMM (rocBLAS) on the GPU path at
     any batch; the output head is one launch each way (`sn_pcrnet_head_*`)."""
+
+    # registration/main.py:296 hangs the (trainable) sampler on the task network as `model.sampler`; PCRNet.forward never calls
+    # it, so the captured calls of the frozen network (graphed.py) do not own its parameters
+    _graphed_exclude = ("sampler",)
 
     def __init__(self, bottleneck_size=1024, input_shape="bcn"):
         super().__init__()

@@ -31,12 +31,15 @@ def _pair(B, N, M, K, bneck, shape, seed=0):
     return hip, ref, x
 
 
-def _acc_sums_zero(acc, nlayers=5):
+def _acc_sums_zero(acc, nlayers=5, channels=None):
     """The statistics accumulators at the head of the conv stack's persistent scratch are zero between calls (behind them:
-    the forward's split-weight planes, scratch)."""
+    the forward's split-weight planes, scratch).  channels: the stack's widths (a layer above 128 channels doubles the region)."""
+    import ctypes
+
     from samplenet_amd._lib import lib
 
-    n = lib.sn_conv_stack_acc_sum_elems(nlayers)
+    ch = (ctypes.c_int * (nlayers + 1))(*channels) if channels is not None else None
+    n = lib.sn_conv_stack_acc_sum_elems(nlayers, ch)
     assert 0 < n <= acc.numel()
     return int(acc[:n].abs().max()) == 0
 
@@ -466,7 +469,7 @@ def test_fixed_point_statistics_chain_256_channels(B, N):
         pointnet.FX_STATS = old
     assert hasattr(net_a, "_fx_acc") == wide
     if wide:  # (two accumulator blocks per layer in this layout)
-        assert int(net_a._fx_acc[:lib.sn_conv_stack_acc_sum_elems(5)].abs().max()) == 0
+        assert _acc_sums_zero(net_a._fx_acc, 5, (3, 64, 128, 128, 256, 128))
     for l in range(5):
         assert torch.equal(sa["cc"][l], sc["cc"][l]), l  # run-to-run
         assert torch.allclose(sa["cc"][l], sb["cc"][l], rtol=2e-6, atol=1e-7), l
@@ -770,6 +773,53 @@ def test_sampler_variants_vs_torch(variant, B, N, M, K):
         with torch.no_grad():
             net.project._temperature.fill_(-0.3)
         assert abs(float(net.get_projection_loss()) - 1e-4) < 1e-9  # max(T, 1e-2)^2
+
+
+@pytest.mark.parametrize("B,Ci,Co", [(32, 256, 192), (7, 256, 96), (1, 128, 48), (33, 256, 192), (200, 256, 192), (32, 192, 60)])
+@pytest.mark.parametrize("training", [True, False])
+def test_output_batchnorm_kernels_vs_torch(B, Ci, Co, training):
+    """The classification sampler's output layer -- Linear then BatchNorm1d WITHOUT activation (classification/models/
+    samplenet_model.py:100-108) -- through pointnet._last_layer / backward_impl's first stage (sn_layer_forward_bn_out up to 32 rows
+    and power-of-two widths, sn_linear_forward_rows + sn_bn_output_forward otherwise; sn_bn_output_backward) against torch in fp64:
+    output, running statistics, dZ, dgamma, dbeta -- batch statistics (training) and running statistics (eval)."""
+    from samplenet_amd import pointnet
+    from samplenet_amd._lib import check, lib, ptr, stream_of
+
+    if B == 1 and training:
+        pytest.skip("torch refuses one row in training mode (the kernel normalises it to beta)")
+    torch.manual_seed(B * 7 + Co)
+    lin = torch.nn.Linear(Ci, Co).cuda()
+    bn = torch.nn.BatchNorm1d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(Co) * 0.5 + 1.0), bn.bias.copy_(torch.randn(Co) * 0.3)
+        bn.running_mean.copy_(torch.randn(Co) * 0.1), bn.running_var.copy_(torch.rand(Co) + 0.5)
+    bn.train(training)
+    ref_lin, ref_bn = copy.deepcopy(lin).double(), copy.deepcopy(bn).double()
+    a = torch.randn(B, Ci, device="cuda")
+    gy = torch.randn(B, Co, device="cuda")
+    L = pointnet._Layer("fc4", lin, "bn_fc4", None)
+    saved = {}
+    y = pointnet._last_layer(B, L, ("bn_fc4", bn), a, None, training, saved)
+    a64 = a.double().requires_grad_(True)
+    z64 = ref_lin(a64)
+    z64.retain_grad()
+    y64 = ref_bn(z64)
+    y64.backward(gy.double())
+    assert float((y.double() - y64).abs().max()) <= 2e-5 * max(1.0, float(y64.abs().max()))
+    assert torch.allclose(bn.running_mean.double(), ref_bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var.double(), ref_bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+    assert saved["out_fixed"] == (not training)
+    dz, dg, db = torch.empty(B, Co, device="cuda"), torch.empty(Co, device="cuda"), torch.empty(Co, device="cuda")
+    check(lib.sn_bn_output_backward(B, Co, 0 if training else 1, ptr(gy), ptr(saved["z_out"]), ptr(saved["c_out"]), ptr(dz), ptr(dg),
+                                    ptr(db), stream_of(gy)), "sn_bn_output_backward")
+    for got, want in ((dz, z64.grad), (dg, ref_bn.weight.grad), (db, ref_bn.bias.grad)):
+        assert float((got.double() - want).norm()) <= 2e-5 * float(want.norm()) + 1e-6
+    # deterministic
+    dz2 = torch.empty_like(dz)
+    check(lib.sn_bn_output_backward(B, Co, 0 if training else 1, ptr(gy), ptr(saved["z_out"]), ptr(saved["c_out"]), ptr(dz2), ptr(dg),
+                                    ptr(db), stream_of(gy)), "sn_bn_output_backward")
+    assert torch.equal(dz, dz2)
 
 
 @pytest.mark.parametrize("B,bneck", [(32, 128), (4, 128), (17, 256), (32, 64)])
