@@ -283,7 +283,7 @@ def _graph_replay_ms(fn, warm=3, reps=30):
     gc.collect()  # (graphs of earlier legs that sit in reference cycles must not be destroyed during the capture below)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):  # (the warm-up's stream: its per-stream scratch is reused)
         out = fn()
     for _ in range(3):
         g.replay()
@@ -337,6 +337,7 @@ def time_module_surface(dev, B, N, M, K, steps=60, headline_ms=None):
     pcr = PCRNet(bottleneck_size=1024, input_shape="bnc").to(dev).eval()
     for p in pcr.parameters():
         p.requires_grad_(False)
+    pcr.static_weights()  # frozen for the sampler's training (main.py:272-277): constants of the graphs captured around it
     g = torch.Generator(device=dev).manual_seed(5)
     x = torch.rand(B, N, 3, device=dev, generator=g) - 0.5        # source cloud p1 (sampled)
     template = torch.rand(B, N, 3, device=dev, generator=g) - 0.5  # template cloud p0 (complete, NUM_SAMPLED_CLOUDS == 1)
@@ -688,6 +689,7 @@ def time_config5_progressive(dev, steps=40):
     pcr = PCRNet(bottleneck_size=1024, input_shape="bnc").to(dev).eval()
     for p in pcr.parameters():
         p.requires_grad_(False)
+    pcr.static_weights()  # frozen for the sampler's training (main.py:272-277): constants of the graphs captured around it
     g = torch.Generator(device=dev).manual_seed(9)
     x = torch.rand(B, N, 3, device=dev, generator=g) - 0.5
     template = torch.rand(B, N, 3, device=dev, generator=g) - 0.5

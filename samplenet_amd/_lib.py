@@ -38,6 +38,8 @@ PROTOTYPES = {
     "sn_chamfer_mean_loss_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_pcrnet_head_forward": [_i, _vp, _vp, _vp, _vp, _vp],
     "sn_pcrnet_head_backward": [_i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_pcrnet_head_rot_forward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_pcrnet_head_rot_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_sampler_loss_forward": [_i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
     "sn_sampler_loss_backward": [_i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp],
     "sn_pairscan_colmin_splits": [_i, _i, _i],

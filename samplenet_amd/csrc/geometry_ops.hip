@@ -1765,6 +1765,146 @@ __global__ void __launch_bounds__(256) qrot_bwd_kernel(int N, const float *__res
     if (threadIdx.x < 4) gq[b * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// PCRNet's output head AND the rotation of the template by the estimated quaternion as ONE launch each way (the registration
+// task term, registration/main.py:557-577: twist = model(p0, p1); p1_est = rotate(p0, twist[:, 0:4])): the arithmetic of
+// pcrnet_head_fwd_kernel + qrot_fwd_kernel / qrot_bwd_kernel + pcrnet_head_bwd_kernel, expression for expression (results are
+// bit-identical to the two launches), one dependent launch less in either direction of a latency-bound step.
+//   forward : grid (x, B); every workgroup normalises its cloud's quaternion from y[b] itself and rotates its share of the points;
+//             workgroup (0, b) stores twist[b] / quat[b]; workgroup (0, 0) also the regulariser (fixed-order sum over the batch).
+//   backward: one workgroup per cloud: gv (optional), the quaternion's gradient by the fixed-order reduction of qrot_bwd_kernel,
+//             then the head's backward of row b with that gradient in the place of g_quat.
+__global__ void __launch_bounds__(256) pcrnet_head_rot_fwd_kernel(int B, int N, const float *__restrict__ y, const float *__restrict__ v,
+                                                                  float *__restrict__ twist, float *__restrict__ quat,
+                                                                  float *__restrict__ qnorm, float *__restrict__ out)
+{
+    __shared__ float red[256];
+    const int b = blockIdx.y;
+    const float *r = y + (size_t)b * 7;
+    const float n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+    const float q0 = r[0] * inv, q1 = r[1] * inv, q2 = r[2] * inv, q3 = r[3] * inv;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float *o = twist + (size_t)b * 7;
+        o[0] = q0, o[1] = q1, o[2] = q2, o[3] = q3, o[4] = r[4], o[5] = r[5], o[6] = r[6];
+        quat[b * 4 + 0] = q0, quat[b * 4 + 1] = q1, quat[b * 4 + 2] = q2, quat[b * 4 + 3] = q3;
+    }
+    const float w = q0;
+    const sn_v3 u{q1, q2, q3};
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const sn_xyz3 p = *reinterpret_cast<const sn_xyz3 *>(v + ((size_t)b * N + n) * 3);
+        const sn_v3 x{p.x, p.y, p.z};
+        const sn_v3 uv = cross3(u, x), uuv = cross3(u, uv);
+        sn_xyz3 o;
+        o.x = x.x + 2.0f * (w * uv.x + uuv.x), o.y = x.y + 2.0f * (w * uv.y + uuv.y), o.z = x.z + 2.0f * (w * uv.z + uuv.z);
+        *reinterpret_cast<sn_xyz3 *>(out + ((size_t)b * N + n) * 3) = o;
+    }
+    if (blockIdx.x != 0 || b != 0 || !qnorm) return;
+    float acc = 0.f;  // (pcrnet_head_fwd_kernel's sum: strided per-thread partials, halving tree)
+    for (int bb = threadIdx.x; bb < B; bb += 256) {
+        const float *rr = y + (size_t)bb * 7;
+        const float m2 = rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3];
+        acc += (m2 - 1.0f) * (m2 - 1.0f);
+    }
+    red[threadIdx.x] = acc;
+    for (int s = 128; s > 0; s >>= 1) {
+        __syncthreads();
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    }
+    if (threadIdx.x == 0) qnorm[0] = red[0] / (float)B;
+}
+
+__global__ void __launch_bounds__(256) pcrnet_head_rot_bwd_kernel(int B, int N, const float *__restrict__ y, const float *__restrict__ q,
+                                                                  const float *__restrict__ v, const float *__restrict__ g,
+                                                                  const float *__restrict__ g_twist, const float *__restrict__ g_quat,
+                                                                  const float *__restrict__ g_qnorm, float *__restrict__ gv,
+                                                                  float *__restrict__ g_y)
+{
+    __shared__ float red[4][4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float w = q[b * 4];
+    const sn_v3 u{q[b * 4 + 1], q[b * 4 + 2], q[b * 4 + 3]};
+    float aw = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    if (g)
+        for (int n = threadIdx.x; n < N; n += 256) {
+            const sn_xyz3 gp = *reinterpret_cast<const sn_xyz3 *>(g + ((size_t)b * N + n) * 3);
+            const sn_v3 gg{gp.x, gp.y, gp.z};
+            if (gv) {
+                const sn_v3 ug = cross3(u, gg), uug = cross3(u, ug);
+                sn_xyz3 o;
+                o.x = gg.x + 2.0f * (uug.x - w * ug.x), o.y = gg.y + 2.0f * (uug.y - w * ug.y), o.z = gg.z + 2.0f * (uug.z - w * ug.z);
+                *reinterpret_cast<sn_xyz3 *>(gv + ((size_t)b * N + n) * 3) = o;
+            }
+            const sn_xyz3 p = *reinterpret_cast<const sn_xyz3 *>(v + ((size_t)b * N + n) * 3);
+            const sn_v3 x{p.x, p.y, p.z};
+            const sn_v3 uv = cross3(u, x), vg = cross3(x, gg);
+            const float ug = dot3(u, gg), ux = dot3(u, x), xg = dot3(x, gg);
+            aw += 2.0f * dot3(uv, gg);
+            ax += 2.0f * (w * vg.x + ug * x.x + ux * gg.x) - 4.0f * xg * u.x;
+            ay += 2.0f * (w * vg.y + ug * x.y + ux * gg.y) - 4.0f * xg * u.y;
+            az += 2.0f * (w * vg.z + ug * x.z + ux * gg.z) - 4.0f * xg * u.z;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        aw += __shfl_xor(aw, o), ax += __shfl_xor(ax, o), ay += __shfl_xor(ay, o), az += __shfl_xor(az, o);
+    }
+    if (lane == 0) red[wave][0] = aw, red[wave][1] = ax, red[wave][2] = ay, red[wave][3] = az;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float gq4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gq4[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    // ---- the head's backward of row b (pcrnet_head_bwd_kernel) with gq4 (+ an explicit g_quat) as the normalised quaternion's gradient
+    const float gqn = g_qnorm ? g_qnorm[0] : 0.f;
+    const float *r = y + (size_t)b * 7;
+    const float n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
+    const float nrm = sqrtf(n2);
+    float *o = g_y + (size_t)b * 7;
+    float gt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gt[i] = (g_twist ? g_twist[(size_t)b * 7 + i] : 0.f) + ((g ? gq4[i] : 0.f) + (g_quat ? g_quat[b * 4 + i] : 0.f));
+    float gp[4];
+    if (nrm > 1e-12f) {
+        const float inv = 1.0f / nrm;
+        const float qq[4] = {r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv};
+        const float dot = qq[0] * gt[0] + qq[1] * gt[1] + qq[2] * gt[2] + qq[3] * gt[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gp[i] = (gt[i] - qq[i] * dot) * inv;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gp[i] = gt[i] * 1e12f;
+    }
+#pragma unroll
+    for (int i = 4; i < 7; ++i) o[i] = g_twist ? g_twist[(size_t)b * 7 + i] : 0.f;
+    const float cq = gqn * 4.0f * (n2 - 1.0f) / (float)B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = gp[i] + cq * r[i];
+}
+
+// y (B,7), v (B,N,3) -> twist (B,7), quat (B,4), qnorm (scalar, may be NULL), out (B,N,3) = v rotated by quat.
+extern "C" int sn_pcrnet_head_rot_forward(int B, int N, const float *y, const float *v, float *twist, float *quat, float *qnorm,
+                                          float *out, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && y && v && twist && quat && out, "bad argument");
+    hipLaunchKernelGGL(pcrnet_head_rot_fwd_kernel, dim3(std::min((N + 255) / 256, 64), B), dim3(256), 0, (hipStream_t)stream, B, N, y, v,
+                       twist, quat, qnorm, out);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of sn_pcrnet_head_rot_forward: grad_out (B,N,3) (NULL: no gradient came through the rotated cloud), grad_twist (B,7),
+// grad_quat (B,4), grad_qnorm (scalar) -- each may be NULL -- -> grad_y (B,7) and, when grad_v != NULL, grad_v (B,N,3) (needs grad_out).
+extern "C" int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat, const float *v, const float *grad_out,
+                                           const float *grad_twist, const float *grad_quat, const float *grad_qnorm, float *grad_v,
+                                           float *grad_y, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && N >= 1 && y && quat && v && grad_y, "bad argument");
+    SN_REQUIRE(!grad_v || grad_out, "grad_v needs grad_out");
+    hipLaunchKernelGGL(pcrnet_head_rot_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, N, y, quat, v, grad_out, grad_twist,
+                       grad_quat, grad_qnorm, grad_v, grad_y);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sn_qrot_forward(int B, int N, const float *quat, const float *v, float *out, sn_stream_t stream)
 {
     SN_REQUIRE(B >= 0 && N >= 0, "negative size");

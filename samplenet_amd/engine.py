@@ -206,7 +206,7 @@ class SamplerTrainStep:
                 self.reducer.capture_fork = True
                 self.net._after_fc_grads = self.reducer._early_ready
             try:
-                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                with torch.cuda.graph(g, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
                     loss = self._step()
                     if self.in_graph:
                         self.reducer.reduce()  # captured: the collective(s) replay with the step
@@ -243,7 +243,9 @@ class SamplerTrainStep:
         if self.reducer is None:
             for p in self.net.parameters():
                 p.grad = None
-        side = torch.cuda.Stream()
+        # (the warm-up passes and the captures share ONE stream: per-stream scratch the warm-up created -- the task network's
+        #  counters and constant tables -- is found again under capture instead of being allocated and filled inside the graph)
+        side = self._cap_stream = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):

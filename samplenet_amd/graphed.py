@@ -68,14 +68,16 @@ class _ModuleGuard:
             for d in (m._parameters, m._buffers):
                 for k, t in d.items():
                     if t is not None:
-                        self.tens.append((d, k, t, t.data_ptr()))
+                        self.tens.append((d, k, t, t.data_ptr(), t._version))
 
     def ok(self):
         for d, k, m in self.mods:
             if d.get(k) is not m:
                 return False
-        for d, k, t, p in self.tens:
-            if d.get(k) is not t or t.data_ptr() != p or t.requires_grad:
+        # (the version counter: the graphs were captured with the frozen weights' bf16 planes split OUTSIDE them -- task_features.
+        #  static_capture -- so a weight written in place since (load_state_dict, an optimizer step) needs new graphs)
+        for d, k, t, p, v in self.tens:
+            if d.get(k) is not t or t.data_ptr() != p or t.requires_grad or t._version != v:
                 return False
         return True
 
@@ -109,15 +111,22 @@ class _Plan:
             surface._collect_before_capture()
             self.pool = torch.cuda.graph_pool_handle()
             self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.gf, pool=self.pool, capture_error_mode="thread_local"):
-                out = fn(*self.ins)
-            self.single = not isinstance(out, (tuple, list))
-            self.outs = _flat(out)
-            self.req = [i for i, o in enumerate(self.outs) if o.requires_grad]
-            self.gouts = [torch.zeros_like(self.outs[i]) for i in self.req]
-            with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local"):
-                self.gins = torch.autograd.grad([self.outs[i] for i in self.req], self.ins_req, self.gouts, allow_unused=True)
-        self.guard = _ModuleGuard(owner)
+            self.guard = _ModuleGuard(owner)  # (before the capture: the versions the graphs' constant weight planes belong to)
+            # captured on the stream the eager passes ran on: the per-stream scratch they created (skinny counters, constant
+            # tables) is found again -- no allocation + fill launches inside the graphs; the owner's frozen weights are constants
+            # of these graphs (their bf16 planes exist since the eager passes: no split launches either)
+            from .task_features import static_capture
+
+            self.stream = side
+            with static_capture(list(_owned_parameters(owner))):
+                with torch.cuda.graph(self.gf, pool=self.pool, stream=side, capture_error_mode="thread_local"):
+                    out = fn(*self.ins)
+                self.single = not isinstance(out, (tuple, list))
+                self.outs = _flat(out)
+                self.req = [i for i, o in enumerate(self.outs) if o.requires_grad]
+                self.gouts = [torch.zeros_like(self.outs[i]) for i in self.req]
+                with torch.cuda.graph(self.gb, pool=self.pool, stream=side, capture_error_mode="thread_local"):
+                    self.gins = torch.autograd.grad([self.outs[i] for i in self.req], self.ins_req, self.gouts, allow_unused=True)
         self.used = 0
 
     def __del__(self):

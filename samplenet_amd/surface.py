@@ -367,9 +367,10 @@ class _Plan:
         _collect_before_capture()
         self.pool = torch.cuda.graph_pool_handle()
         self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.gf, pool=self.pool, capture_error_mode="thread_local"):
+        self.stream = side  # (captured on the warm-up's stream: see engine._capture)
+        with torch.cuda.graph(self.gf, pool=self.pool, stream=side, capture_error_mode="thread_local"):
             self._forward_body(net)
-        with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.gb, pool=self.pool, stream=side, capture_error_mode="thread_local"):
             self._backward_body(net)
         self.v_lsimp, self.v_sigma = self.values[0], self.values[1]
 
@@ -387,7 +388,19 @@ class _Plan:
     def commit_begin_sink(self):
         """Data-parallel plan (the bucket is a FlatGradAllReducer's): -> old bucket to add after the replay, or None when this
         backward may overwrite the views (GradSink.direct(): first backward of a step, or every .grad dropped by zero_grad())."""
-        return None if self.sink.direct() else self.bucket.clone()
+        if self.sink.direct():
+            return None
+        old = self.bucket.clone()
+        # a slot whose parameter's .grad is NOT the bucket's view right now holds nothing of this step (the temperature after
+        # optimizer.zero_grad(set_to_none=True): its slice still has the previous step's total, while this step's first
+        # contribution sits in a tensor autograd made -- commit_end_sink folds that one in): it must not be added back
+        base = self.bucket.data_ptr()
+        for p, v in self.grad_pairs:
+            g = p.grad
+            if g is None or g.data_ptr() != v.data_ptr():
+                off = (v.data_ptr() - base) // 4
+                old[off:off + v.numel()].zero_()
+        return old
 
     def commit_end_sink(self, old):
         if old is not None:

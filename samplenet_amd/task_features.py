@@ -51,13 +51,44 @@ def _unit_rows(rows, c, like):
 
 
 _PLANES = {}  # ids of the weight parameters -> (weak references to them, their versions, their bf16 planes)
+# Weights declared CONSTANT for captured graphs: under a stream capture the split of such weights is not recorded again when the
+# cached planes are those of the current version -- a frozen task network's graphs then carry no split launches (four of 37
+# launches of the registration task term).  Two ways in: PCRNet.static_weights(True) (a promise of the caller, for graphs it
+# captures itself: engine.SamplerTrainStep(task_loss=...), torch.cuda.graph around a step -- after changing the weights in place,
+# recapture), and graphed.py's own graphs (automatic: its guard compares the parameters' version counters before every replay and
+# recaptures).  The planes a graph was captured on stay alive with the registry (_STATIC_KEEP).
+_STATIC = {}        # id(parameter) -> weak reference to it (ids, not a WeakSet: tensors compare elementwise)
+_static_ctx = []    # stack of sets of id(parameter): static for the duration of a capture (graphed.static_capture)
+_STATIC_KEEP = {}   # id(planes tensor) -> planes tensor (never dropped: a replayed graph may read them)
+
+
+def _is_static(bases):
+    def declared(b):
+        r = _STATIC.get(id(b))
+        return r is not None and r() is b
+
+    return all(declared(b) or any(id(b) in ctx for ctx in _static_ctx) for b in bases)
+
+
+class static_capture:
+    """with static_capture(parameters): these parameters are constant for graphs captured inside (see _STATIC)."""
+
+    def __init__(self, params):
+        self.ids = {id(p._base if p._base is not None else p) for p in params}
+
+    def __enter__(self):
+        _static_ctx.append(self.ids)
+
+    def __exit__(self, *exc):
+        _static_ctx.remove(self.ids)
 
 
 def _weight_planes(*Ws, tag=""):
     """Scratch for the split of the weights Ws into three bf16 planes each (sn_linear_forward_maxpool_wide, sn_pointnet_narrow_forward)
     and whether it already holds the split of these very weights: eager calls reuse it while the parameter objects are the same
     and their version counters stand still (the two clouds of a registration step, every step of a frozen task network); under
-    a stream capture the split is always recorded -- a replay must see weights that were updated in place since.
+    a stream capture the split is recorded again -- a replay must see weights that were updated in place since -- unless the
+    weights were declared constant (_STATIC / static_capture above).
     tag: distinguishes the images kept of the same weights (the backward's transposed planes)."""
     bases = [W._base if W._base is not None else W for W in Ws]
     key = (tag,) + tuple(id(b) for b in bases)
@@ -67,7 +98,10 @@ def _weight_planes(*Ws, tag=""):
     capturing = torch.cuda.is_current_stream_capturing()
     if (hit is not None and all(r() is b for r, b in zip(hit[0], bases)) and hit[2].numel() == numel
             and hit[2].device == Ws[0].device):
-        ready = hit[1] == vers and not capturing
+        static = capturing and hit[1] == vers and _is_static(bases)
+        ready = hit[1] == vers and (not capturing or static)
+        if static:
+            _STATIC_KEEP[id(hit[2])] = hit[2]
         if not capturing:
             _PLANES[key] = (hit[0], vers, hit[2])
         return hit[2], ready
@@ -417,6 +451,43 @@ class _HeadFunction(torch.autograd.Function):
         return gy
 
 
+class _HeadRotFunction(torch.autograd.Function):
+    """_HeadFunction + _QrotCloudFunction as ONE launch each way: y (B,7), v (B,N,3) -> twist (B,7), quat (B,4), qnorm (),
+    rotated (B,N,3) = qrot(quat, v)  (sn_pcrnet_head_rot_*; bit-identical to the two launches)."""
+
+    @staticmethod
+    def forward(ctx, y, v):
+        y, x = y.contiguous().float(), v.contiguous().float()
+        B, N, _ = x.shape
+        twist = torch.empty_like(y)
+        quat = torch.empty(B, 4, device=y.device, dtype=torch.float32)
+        qnorm = torch.empty((), device=y.device, dtype=torch.float32)
+        out = torch.empty_like(x)
+        with torch.cuda.device(y.device):
+            check(lib.sn_pcrnet_head_rot_forward(B, N, ptr(y), ptr(x), ptr(twist), ptr(quat), ptr(qnorm), ptr(out), _st(y)),
+                  "sn_pcrnet_head_rot_forward")
+        ctx.save_for_backward(y, quat, x)
+        ctx.set_materialize_grads(False)
+        return twist, quat, qnorm, out
+
+    @staticmethod
+    def backward(ctx, g_twist, g_quat, g_qnorm, g_out):
+        y, quat, x = ctx.saved_tensors
+        B, N, _ = x.shape
+        gy = torch.empty_like(y)
+        gt = g_twist.contiguous().float() if g_twist is not None else None
+        gqt = g_quat.contiguous().float() if g_quat is not None else None
+        gq = g_qnorm.contiguous().float() if g_qnorm is not None else None
+        go = g_out.contiguous().float() if g_out is not None else None
+        gv = torch.empty_like(x) if (ctx.needs_input_grad[1] and go is not None) else None
+        with torch.cuda.device(y.device):
+            check(lib.sn_pcrnet_head_rot_backward(B, N, ptr(y), ptr(quat), ptr(x), ptr(go), ptr(gt), ptr(gqt), ptr(gq), ptr(gv), ptr(gy),
+                                                  _st(y)), "sn_pcrnet_head_rot_backward")
+        if ctx.needs_input_grad[1] and gv is None:
+            gv = torch.zeros_like(x)
+        return gy, gv
+
+
 class PCRNet(nn.Module):
     """Drop-in for `registration/models/pcrnet.py:44-82` (same constructor, attribute and parameter names -> state_dict
     compatible, same `forward(x0, x1) -> (twist (B,7), pre_normalized_quat (B,4))`): the two feature extractions run on the
@@ -441,6 +512,20 @@ class PCRNet(nn.Module):
         self.fc4 = nn.Linear(512, 512)
         self.fc5 = nn.Linear(512, 256)
         self.fc6 = nn.Linear(256, 7)
+
+    def static_weights(self, flag=True):
+        """Declare this network's weights CONSTANT for graphs the caller captures around it (engine.SamplerTrainStep(task_loss=...),
+        torch.cuda.graph): the bf16 planes of the frozen weights are then split once, outside the graphs, instead of by four launches
+        of every replay (registration/main.py:272-277 freezes the task network for the sampler's training).  A promise: after
+        changing a weight in place (load_state_dict, an optimizer step) such graphs must be captured again -- the frozen network's
+        own captured calls (graphed.py) need no promise, they check the parameters' version counters themselves.  -> self."""
+        for p in self.parameters():
+            b = p._base if p._base is not None else p
+            if flag:
+                _STATIC[id(b)] = weakref.ref(b, lambda _r, k=id(b): _STATIC.pop(k, None))
+            else:
+                _STATIC.pop(id(b), None)
+        return self
 
     def __getstate__(self):  # (copy.deepcopy / pickling: captured graphs stay behind)
         return {k: v for k, v in self.__dict__.items() if k != "_sn_graphed"}
@@ -467,16 +552,17 @@ class PCRNet(nn.Module):
         network's arithmetic -- runs once."""
         return self.feat(x0)
 
-    def forward_multi(self, x0, x1_list, feat0=None):
+    def forward_multi(self, x0, x1_list, feat0=None, rotate=None):
         """forward_with_qnorm for several source clouds against ONE template (the progressive sampler's prefixes) with the FC trunk
         run once on all of them: the trunk is a stream of 15.5 MB of weights per pass whatever the number of rows, so E evaluations of
-        B clouds cost one pass on E B rows (at most 128) instead of E passes.  -> list of (twist, pre_normalized_quat, qnorm, quat)."""
+        B clouds cost one pass on E B rows (at most 128) instead of E passes.  -> list of (twist, pre_normalized_quat, qnorm, quat
+        [, rotate rotated by quat: see forward_with_qnorm])."""
         E = len(x1_list)
         f0 = self.template_features(x0) if feat0 is None else feat0
         B = f0.shape[0]
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
         if not (FUSED_TRUNK and f0.is_cuda and E * B <= 128 and f0.shape[1] % 8 == 0 and E > 1):
-            return [self.forward_with_qnorm(x0, x1, feat0=f0) for x1 in x1_list]
+            return [self.forward_with_qnorm(x0, x1, feat0=f0, rotate=rotate) for x1 in x1_list]
         f1 = torch.cat([self.feat(x1) for x1 in x1_list], dim=0)
         wb = []
         for fc in fcs:
@@ -485,6 +571,10 @@ class PCRNet(nn.Module):
         out = []
         for e in range(E):
             ye = y[e * B:(e + 1) * B]
+            if FUSED_HEAD and rotate is not None:
+                twist, quat, qnorm, rotated = _HeadRotFunction.apply(ye, rotate)
+                out.append((twist, ye[:, 0:4], qnorm, quat, rotated))
+                continue
             if FUSED_HEAD:
                 twist, quat, qnorm = _HeadFunction.apply(ye)
             else:
@@ -492,13 +582,15 @@ class PCRNet(nn.Module):
                 quat = torch.nn.functional.normalize(pre, dim=1)
                 qnorm = torch.mean((torch.sum(pre ** 2, dim=1) - 1) ** 2)
                 twist = torch.cat([quat, ye[:, 4:]], dim=1)
-            out.append((twist, ye[:, 0:4], qnorm, quat))
+            out.append((twist, ye[:, 0:4], qnorm, quat) + ((qrot_cloud(quat, rotate),) if rotate is not None else ()))
         return out
 
-    def forward_with_qnorm(self, x0, x1, feat0=None):
+    def forward_with_qnorm(self, x0, x1, feat0=None, rotate=None):
         """forward() plus the QuaterNet regulariser mean((||pre_normalized_quat||^2 - 1)^2) of registration/main.py:565 and the
         normalised quaternion as a contiguous (B,4) tensor, both of which the output head's kernel produces on the side:
-        (twist, pre_normalized_quat, qnorm, quat).  feat0: template_features(x0), computed by the caller (x0 is then unused)."""
+        (twist, pre_normalized_quat, qnorm, quat).  feat0: template_features(x0), computed by the caller (x0 is then unused).
+        rotate: a (B,N,3) cloud (bnc) -- the head's launch also rotates it by the estimated quaternion (main.py:569-571
+        est_transform.rotate(p0)); the rotated cloud is returned as a fifth element."""
         f0, f1 = (self.feat(x0) if feat0 is None else feat0), self.feat(x1)
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
         if FUSED_TRUNK and f0.is_cuda and f0.shape[1] % 8 == 0:
@@ -513,11 +605,15 @@ class PCRNet(nn.Module):
             y = self.fc6(y)  # (B, 7)
         pre_normalized_quat = y[:, 0:4]
         if FUSED_HEAD and y.is_cuda:
+            if rotate is not None:
+                twist, quat, qnorm, rotated = _HeadRotFunction.apply(y, rotate)
+                return twist, pre_normalized_quat, qnorm, quat, rotated
             twist, quat, qnorm = _HeadFunction.apply(y)
             return twist, pre_normalized_quat, qnorm, quat
         normalized_quat = torch.nn.functional.normalize(pre_normalized_quat, dim=1)
         qnorm = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
-        return torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat, qnorm, normalized_quat
+        out = (torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat, qnorm, normalized_quat)
+        return out + (qrot_cloud(normalized_quat, rotate),) if rotate is not None else out
 
 
 def pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features=None):
@@ -545,8 +641,7 @@ def _pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features):
     from .ops import chamfer_mean_loss
 
     out = []
-    for p1, (twist, _pre, qnorm, quat) in zip(p1_list, model.forward_multi(p0, p1_list, feat0=template_features)):
-        p1_est = qrot_cloud(quat, p0)
+    for p1, (twist, _pre, qnorm, _quat, p1_est) in zip(p1_list, model.forward_multi(p0, p1_list, feat0=template_features, rotate=p0)):
         out.append((chamfer_mean_loss(p1.contiguous(), p1_est.contiguous()), qnorm, twist))
     return out
 
@@ -614,11 +709,11 @@ def _pcrnet_chamfer_loss(model, p0, p1, template_features):
     from .ops import chamfer_mean_loss
 
     if hasattr(model, "forward_with_qnorm"):
-        twist, _pre, qnorm_loss, quat = model.forward_with_qnorm(p0, p1, feat0=template_features)
+        # (the output head's launch rotates the template as well: one launch each way instead of two)
+        twist, _pre, qnorm_loss, _quat, p1_est = model.forward_with_qnorm(p0, p1, feat0=template_features, rotate=p0)
     else:
         twist, pre_normalized_quat = model(p0, p1)
         qnorm_loss = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
-        quat = twist[:, 0:4]
-    p1_est = qrot_cloud(quat, p0)  # = qrot(twist[:, 0:4] expanded over the points, p0)
+        p1_est = qrot_cloud(twist[:, 0:4], p0)  # = qrot(twist[:, 0:4] expanded over the points, p0)
     # mean(d(p1 -> p1_est)) + mean(d(p1_est -> p1)): scan + one fused reduction, implicit-gradient backward
     return chamfer_mean_loss(p1.contiguous(), p1_est.contiguous()), qnorm_loss, twist

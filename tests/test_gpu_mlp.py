@@ -1365,6 +1365,46 @@ def test_pcrnet_head_and_chamfer_mean_loss_match_the_op_chain():
     assert float((ga - ra).abs().max()) <= 1e-6 * float(ra.abs().max()) and float((gb - rb).abs().max()) <= 1e-6 * float(rb.abs().max())
 
 
+@pytest.mark.parametrize("B,N,vgrad", [(32, 1024, False), (32, 1024, True), (5, 300, True), (1, 7, False), (128, 64, False)])
+def test_head_with_rotation_is_bit_identical_to_the_two_launches(B, N, vgrad):
+    """sn_pcrnet_head_rot_* (PCRNet's output head AND the rotation of the template by the estimated quaternion as one launch each
+    way: registration/main.py:563-571) against _HeadFunction + qrot_cloud: twist, quaternion, regulariser, rotated cloud and the
+    gradients to y (through all four outputs) and to the cloud are EQUAL, bit for bit -- incl. a rotated cloud nobody differentiates
+    and an unused twist."""
+    from samplenet_amd import task_features as TF
+
+    torch.manual_seed(B + N)
+    y0 = torch.randn(B, 7, device="cuda")
+    v0 = torch.rand(B, N, 3, device="cuda") - 0.5
+    wt, w4, wo = torch.randn(B, 7, device="cuda"), torch.randn(B, 4, device="cuda"), torch.randn(B, N, 3, device="cuda")
+
+    def run(fused, use):
+        y = y0.clone().requires_grad_(True)
+        v = v0.clone().requires_grad_(vgrad)
+        if fused:
+            twist, quat, qn, rot = TF._HeadRotFunction.apply(y, v)
+        else:
+            twist, quat, qn = TF._HeadFunction.apply(y)
+            rot = TF.qrot_cloud(quat, v)
+        loss = 0.0
+        if "t" in use:
+            loss = loss + (twist * wt).sum()
+        if "q" in use:
+            loss = loss + (quat * w4).sum()
+        if "n" in use:
+            loss = loss + 0.7 * qn
+        if "r" in use:
+            loss = loss + (rot * wo).sum()
+        gs = torch.autograd.grad(loss, [y, v] if vgrad and "r" in use else [y])
+        return (twist, quat, qn, rot) + tuple(gs)
+
+    for use in ("tqnr", "nr", "r", "tn", "rq"):
+        a, b = run(True, use), run(False, use)
+        assert len(a) == len(b)
+        for i, (u, w) in enumerate(zip(a, b)):
+            assert torch.equal(u, w), (use, i, float((u - w).abs().max()))
+
+
 @pytest.mark.parametrize("B,N,grad", [(32, 1024, False), (32, 64, True), (3, 64, True), (5, 192, True), (3, 50, True), (2, 1024, True)])
 def test_task_features_narrow_front_is_bit_identical(B, N, grad):
     """conv1..conv4 of PointNetFeatures as one launch (sn_pointnet_narrow_forward: a wave takes 32 rows through 3 -> 64 -> 64 -> 64 -> 128,
