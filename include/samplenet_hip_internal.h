@@ -344,22 +344,6 @@ int sn_skinny_linear2(int R, int K, int N, const float *x, const float *x2, int 
  * order (deterministic).  gate (R, N, optional): the layer's own output (ReLU mask); x2 / ksplit as in sn_skinny_linear2. */
 int sn_skinny_wgrad(int R, int K, int N, const float *x, const float *x2, int ksplit, const float *dy, const float *gate, float *dW,
                     float *db, sn_stream_t stream);
-/* Up to six of those layers, one direction of PCRNet's trunk (registration/models/pcrnet.py:62-77), as ONE launch of 256 resident
- * workgroups: every workgroup requests the weight fragments of its work item of every layer up front, then the layers follow each
- * other through in-kernel seams (write-through activations, one arrival counter per layer).  out_l = act_l((x_l . [gate_l > 0]) W_l^T
- * + bias_l), x_0 = [x | x2] (ksplit as sn_skinny_linear2), x_l = out_{l-1}.  K / N: the layers' input / output widths (K[l] ==
- * N[l-1]); transposed != 0: every W_l is (K_l, N_l) (the data gradient); bias / gate (arrays of nl pointers, or NULL) entries may
- * be NULL; relu: nl flags; out: nl tensors (R, N_l) -- with nsplit_last > 0 the last layer's output leaves as out[nl-1] (R, nsplit_last)
- * and out2_last (R, N - nsplit_last), either may be NULL.  scratch: sn_skinny_chain_scratch_bytes bytes; state:
- * sn_skinny_chain_state_words() 32-bit words, zero before the first launch (every launch leaves them zero unless a seam timed out:
- * the error word state[words - 16 * 32 + 15 * 32] is then non-zero, the outputs are NaN, and the caller zeroes the state).
- * Per-element arithmetic is sn_skinny_linear's: bit-identical outputs.  R <= 128; every layer must fit 256 work items. */
-int sn_skinny_chain_supported(int R, int nl, const int *K, const int *N);
-long long sn_skinny_chain_scratch_bytes(int R, int nl, const int *K, const int *N);
-int sn_skinny_chain_state_words(void);
-int sn_skinny_chain(int R, int nl, const int *K, const int *N, const float *x, const float *x2, int ksplit, const float *const *W,
-                    int transposed, const float *const *bias, const float *const *gate, const int *relu, float *const *out,
-                    float *out2_last, int nsplit_last, float *scratch, unsigned *state, sn_stream_t stream);
 /* Test hook: 64-row blocks per workgroup of the xyz layer's statistics pass inside sn_conv_stack_forward_bn (0 = chosen per call:
  * 1 until the batch is large, then up to 8 -- one pair of atomics per channel and workgroup instead of one per block; the integer
  * totals are the same whatever the grouping).  Returns the previous setting. */

@@ -115,10 +115,6 @@ PROTOTYPES = {
     "sn_skinny_linear": [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "sn_skinny_linear2": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "sn_skinny_wgrad": [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
-    "sn_skinny_chain_supported": [_i, _i, _vp, _vp],
-    "sn_skinny_chain_scratch_bytes": [_i, _i, _vp, _vp],
-    "sn_skinny_chain_state_words": [],
-    "sn_skinny_chain": [_i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "sn_pool_dgrad_sparse_supported": [_i, _i, _i, _i],
     "sn_pool_dgrad_sparse": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_bn_batch_stats_twopass": [_i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
@@ -141,7 +137,7 @@ PROTOTYPES = {
     "sn_emd_loss": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_emd_loss_fast": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
-_RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong, "sn_skinny_chain_scratch_bytes": ctypes.c_longlong,
+_RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong,
              "sn_pairscan_workspace_bytes": ctypes.c_longlong, "sn_linear_forward_maxpool_wide_scratch_bytes": ctypes.c_longlong,
              "sn_skinny_linear_scratch_bytes": ctypes.c_longlong,
              "sn_layer_backward_in3_stats_floats": ctypes.c_longlong,

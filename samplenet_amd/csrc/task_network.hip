@@ -996,374 +996,6 @@ extern "C" int sn_skinny_linear2(int R, int K, int N, const float *x, const floa
     return 0;
 }
 
-// ---- The whole trunk -- up to six of those layers, one direction -- as ONE launch.  Launched one by one the
-// layers cost 5 .. 12 us each (86 us for the 12 of a task step: 0.38 TB/s on a 15.5 MB weight stream): a kernel boundary per
-// layer, and behind every boundary a cold weight fetch.  But the weights do not depend on the activations: here 256 workgroups
-// stay resident for the whole trunk, each requests the weight fragments of ITS (tile, K slice) work item of EVERY layer before
-// anything else (the entire stream is in flight from the first microsecond; fragments of later layers wait in registers) and
-// then walks the layers: wait until the previous layer's output tiles are all published (one monotonic counter per layer) ->
-// A fragments (write-through data: sc1 loads) -> the six bf16 products per k-step -> the slice hand-off of skinny_linear_kernel
-// unchanged (partials as sc1 stores, per-tile arrival counter, the last workgroup sums the slices in order) -> bias / ReLU ->
-// the output tile as sc1 stores, drained, one arrival on the layer's counter.  Only the R x N activations cross a seam.
-// Per-element arithmetic (products, k order within a slice, slice order, epilogue) is skinny_linear_kernel's: bit-identical
-// results.  The data gradient's ReLU gate -- the layer's own forward output, known before the launch -- travels as one bit per
-// element, fetched with the weights.
-// Co-residency: 256 workgroups x 256 threads, 20 KB of LDS: one per CU on an idle chip; a workgroup that is scheduled late only
-// delays the seam it owes a tile to.  A poll that exceeds its bound (a device kept full by other work for seconds) sets the
-// error word, the workgroup then publishes NaN in place of its tiles (the trunk's output is NaN: nothing looks like a result),
-// and the host re-arms the state (sn_skinny_chain's caller: task_features.check_trunk_chain).
-// sync words (stride kSkSync): [1 + l] tiles of layer l published, [12] workgroups that left, [13] poll bound override (tests), [15] error.
-constexpr int kSkMaxLayers = 6, kSkSync = 32, kSkGrid = 256;
-struct SkinnyChainLayer {
-    const float *W, *bias, *gate;  // gate: (R, K) the ReLU mask source of the A operand (data gradient), NULL: none
-    const float *x, *x2;           // A operand: (R, K), or [x (R, ksplit) | x2 (R, K - ksplit)]; layers > 0: the previous layer's out
-    float *out, *out2;             // (R, N), or [out (R, nsplit) | out2 (R, N - nsplit)] (either may be NULL then)
-    float *part;                   // this layer's slice partials [S][tiles][RT][1024]
-    int K, N, S, ksteps, wmode, relu, ksplit, nsplit, tiles;
-};
-struct SkinnyChainArgs {
-    SkinnyChainLayer L[kSkMaxLayers];
-    int nl, R;
-    unsigned *counter;  // [kSkMaxLayers][64] per-tile slice arrivals (zero between launches)
-    unsigned *sync;
-};
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void sk_store_sc1(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-
-template <int RT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) skinny_chain_kernel(SkinnyChainArgs g)
-{
-    __shared__ __attribute__((aligned(16))) float red[kRsFloats];
-    __shared__ int s_last, s_bad;
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = blockIdx.x, R = g.R, nl = g.nl;
-    if (tid == 0) s_bad = 0;
-    // ---- every layer's weight fragments (and gate bits) of this workgroup's work item: all requested before anything is waited for
-    float eb[kSkMaxLayers][4][8];
-    unsigned gbits[kSkMaxLayers][RT];
-#pragma unroll
-    for (int l = 0; l < kSkMaxLayers; ++l) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) gbits[l][rt] = 0xFFFFFFFFu;
-        if (l >= nl) continue;
-        const SkinnyChainLayer &Ly = g.L[l];
-        if (w >= Ly.tiles * Ly.S) continue;
-        const int tile = w % Ly.tiles, sl = w / Ly.tiles, K = Ly.K, N = Ly.N;
-        const int kslice = Ly.ksteps * 64, kb = sl * kslice + wave * (kslice / 4);
-        const int n = tile * 32 + l31;
-        const bool nok = n < N, kvec = (K & 3) == 0;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            if (st >= Ly.ksteps) continue;
-            const int k8 = kb + st * 16 + 8 * h;
-            const bool full = k8 + 8 <= K && kvec;
-            if (Ly.wmode == 0) {
-                if (full && nok) {
-                    const float4 v0 = *reinterpret_cast<const float4 *>(Ly.W + (size_t)n * K + k8), v1 = *reinterpret_cast<const float4 *>(Ly.W + (size_t)n * K + k8 + 4);
-                    eb[l][st][0] = v0.x, eb[l][st][1] = v0.y, eb[l][st][2] = v0.z, eb[l][st][3] = v0.w;
-                    eb[l][st][4] = v1.x, eb[l][st][5] = v1.y, eb[l][st][6] = v1.z, eb[l][st][7] = v1.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) eb[l][st][t] = (nok && k8 + t < K) ? Ly.W[(size_t)n * K + k8 + t] : 0.f;
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) eb[l][st][t] = (nok && k8 + t < K) ? Ly.W[(size_t)(k8 + t) * N + n] : 0.f;
-            }
-        }
-        if (Ly.gate) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int m = rt * 32 + l31;
-                unsigned bits = 0;
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    if (st >= Ly.ksteps) continue;
-                    const int k8 = kb + st * 16 + 8 * h;
-                    if (m < R && k8 + 8 <= K && kvec) {
-                        const float4 g0 = *reinterpret_cast<const float4 *>(Ly.gate + (size_t)m * K + k8), g1 = *reinterpret_cast<const float4 *>(Ly.gate + (size_t)m * K + k8 + 4);
-                        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) bits |= (gv[t] > 0.f ? 1u : 0u) << (st * 8 + t);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 8; ++t)
-                            if (m < R && k8 + t < K) bits |= (Ly.gate[(size_t)m * K + k8 + t] > 0.f ? 1u : 0u) << (st * 8 + t);
-                    }
-                }
-                gbits[l][rt] = bits;
-            }
-        }
-    }
-    __syncthreads();
-    const int limit = [&]() {
-        const unsigned lim = g.sync[13 * kSkSync];
-        return lim ? (int)lim : (1 << 22);
-    }();
-    const float kNaN = __builtin_nanf("");
-
-#pragma unroll
-    for (int l = 0; l < kSkMaxLayers; ++l) {
-        if (l >= nl) break;
-        const SkinnyChainLayer &Ly = g.L[l];
-        if (w >= Ly.tiles * Ly.S) continue;
-        const int tile = w % Ly.tiles, sl = w / Ly.tiles, K = Ly.K, N = Ly.N, S = Ly.S;
-        const int kslice = Ly.ksteps * 64, kb = sl * kslice + wave * (kslice / 4);
-        const int n0 = tile * 32;
-        const bool kvec = (K & 3) == 0;
-        if (l > 0) {  // every output tile of the previous layer is published
-            if (tid == 0) {
-                const unsigned want = (unsigned)g.L[l - 1].tiles;
-                int spins = 0;
-                while (__hip_atomic_load(g.sync + (1 + (l - 1)) * kSkSync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    if (++spins > limit) {
-                        __hip_atomic_store(g.sync + 15 * kSkSync, 1u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        s_bad = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            lds_barrier();
-        }
-        // ---- A fragments: 8 consecutive k of row m, per row tile (layer 0: plain loads of the caller's tensors; later layers: data
-        // written during this launch, sc1)
-        // (the asm loads land in xa; NOTHING may read xa before the explicit wait below, whose operands they are -- a copy into
-        //  another register in between would copy whatever the register held before the load returned)
-        f32x4v xa[RT][4][2];
-        float ea[RT][4][8];
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            if (st >= Ly.ksteps) continue;
-            const int k8 = kb + st * 16 + 8 * h;
-            const bool full = k8 + 8 <= K && kvec;
-            const float *xs = Ly.x;
-            int ldx = K, kx = k8;
-            if (Ly.x2) {
-                if (k8 >= Ly.ksplit) xs = Ly.x2, ldx = K - Ly.ksplit, kx = k8 - Ly.ksplit;
-                else ldx = Ly.ksplit;
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int m = rt * 32 + l31;
-                const bool mok = m < R;
-                xa[rt][st][0] = xa[rt][st][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
-                if (full && mok) {
-                    const float *ap = xs + (size_t)m * ldx + kx;
-                    if (l > 0) {
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(xa[rt][st][0]) : "v"(ap) : "memory");
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(xa[rt][st][1]) : "v"(ap + 4) : "memory");
-                    } else {
-                        xa[rt][st][0] = *reinterpret_cast<const f32x4v *>(ap), xa[rt][st][1] = *reinterpret_cast<const f32x4v *>(ap + 4);
-                    }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        float v = 0.f;
-                        if (mok && k8 + t < K) {
-                            const float *ap = xs + (size_t)m * ldx + kx + t;
-                            if (l > 0) asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ap) : "memory");
-                            else v = *ap;
-                        }
-                        xa[rt][st][t >> 2][t & 3] = v;
-                    }
-                }
-            }
-        }
-        if (l > 0) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-                    if (st < Ly.ksteps) asm volatile("s_waitcnt vmcnt(0)" : "+v"(xa[rt][st][0]), "+v"(xa[rt][st][1])::"memory");
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) ea[rt][st][t] = xa[rt][st][t >> 2][t & 3];
-        f32x16 acc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            if (st >= Ly.ksteps) continue;
-            bf16x8 b[3];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                __bf16 h1, h2, h3;
-                split3(eb[l][st][t], h1, h2, h3);
-                b[0][t] = h1, b[1][t] = h2, b[2][t] = h3;
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                bf16x8 a[3];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float av = ((gbits[l][rt] >> (st * 8 + t)) & 1u) ? ea[rt][st][t] : 0.f;
-                    __bf16 h1, h2, h3;
-                    split3(av, h1, h2, h3);
-                    a[0][t] = h1, a[1][t] = h2, a[2][t] = h3;
-                }
-#define SN_SK_TERM(PA, PB) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA], b[PB], acc[rt], 0, 0, 0)
-                SN_SK_TERM(0, 2);
-                SN_SK_TERM(2, 0);
-                SN_SK_TERM(1, 1);
-                SN_SK_TERM(0, 1);
-                SN_SK_TERM(1, 0);
-                SN_SK_TERM(0, 0);
-#undef SN_SK_TERM
-            }
-        }
-        float4 v[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            lds_barrier();  // (the exchange area is read by other waves until they pass this point -- also those of the layer before)
-            v[rt] = wave_reduce_scatter4(acc[rt], red);
-        }
-        typedef float sk4 __attribute__((ext_vector_type(4)));
-        bool last = true;
-        if (S > 1) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                float *P = Ly.part + (((size_t)sl * Ly.tiles + tile) * RT + rt) * 1024 + (size_t)tid * 4;
-                const sk4 pv = {v[rt].x, v[rt].y, v[rt].z, v[rt].w};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 4" ::"v"(P), "v"(pv) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                unsigned *ctr = g.counter + l * 64 + tile;
-                const unsigned t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = t == (unsigned)(S - 1);
-                if (s_last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // armed for the next launch
-            }
-            __syncthreads();
-            last = s_last != 0;
-            if (last) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    sk4 accv = {0.f, 0.f, 0.f, 0.f};
-                    for (int q0 = 0; q0 < S; q0 += 8) {  // slices in ascending order, eight loads in flight
-                        sk4 r[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int qq = min(q0 + q, S - 1);
-                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[q]) : "v"(Ly.part + (((size_t)qq * Ly.tiles + tile) * RT + rt) * 1024 + (size_t)tid * 4) : "memory");
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])::"memory");
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if (q0 + q < S) accv = accv + r[q];
-                    }
-                    v[rt] = make_float4(accv.x, accv.y, accv.z, accv.w);
-                }
-            }
-        }
-        if (last) {
-            const int col = n0 + wave * 8 + (lane >> 3), r0 = 4 * (lane & 7);
-            const bool bad = s_bad != 0;
-            if (col < N) {
-                const float bv = Ly.bias ? Ly.bias[col] : 0.f;
-                float *dst = Ly.out;
-                int ldo = N, c = col;
-                if (Ly.nsplit > 0) {
-                    if (col >= Ly.nsplit) dst = Ly.out2, ldo = N - Ly.nsplit, c = col - Ly.nsplit;
-                    else ldo = Ly.nsplit;
-                }
-                if (dst)
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        const float o[4] = {v[rt].x + bv, v[rt].y + bv, v[rt].z + bv, v[rt].w + bv};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (rt * 32 + r0 + i < R) sk_store_sc1(dst + (size_t)(rt * 32 + r0 + i) * ldo + c, bad ? kNaN : (Ly.relu ? relu_np(o[i]) : o[i]));
-                    }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(g.sync + (1 + l) * kSkSync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // ---- the last workgroup to leave clears the layer counters for the next launch (nobody polls them any more)
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(g.sync + 12 * kSkSync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == gridDim.x - 1) {
-            for (int l = 0; l < kSkMaxLayers; ++l) __hip_atomic_store(g.sync + (1 + l) * kSkSync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.sync + 12 * kSkSync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-static bool skinny_chain_plan(int R, int nl, const int *K, const int *N, int *S, int *ks, long long *part_off, long long *part_total)
-{
-    if (R < 1 || R > 128 || nl < 1 || nl > kSkMaxLayers) return false;
-    const int rt = R <= 32 ? 1 : R <= 64 ? 2 : 4;
-    long long off = 0;
-    for (int l = 0; l < nl; ++l) {
-        if (K[l] < 1 || N[l] < 1) return false;
-        if (l > 0 && K[l] != N[l - 1]) return false;
-        skinny_plan(K[l], N[l], S[l], ks[l]);
-        const int tiles = (N[l] + 31) / 32;
-        if (ks[l] > 4 || tiles > 64 || tiles * S[l] > kSkGrid) return false;
-        if (part_off) part_off[l] = off;
-        off += (long long)S[l] * tiles * rt * 1024;
-    }
-    if (part_total) *part_total = off;
-    return true;
-}
-extern "C" int sn_skinny_chain_supported(int R, int nl, const int *K, const int *N)
-{
-    int S[kSkMaxLayers], ks[kSkMaxLayers];
-    return (K && N && skinny_chain_plan(R, nl, K, N, S, ks, nullptr, nullptr)) ? 1 : 0;
-}
-extern "C" long long sn_skinny_chain_scratch_bytes(int R, int nl, const int *K, const int *N)
-{
-    int S[kSkMaxLayers], ks[kSkMaxLayers];
-    long long tot = 0;
-    if (!K || !N || !skinny_chain_plan(R, nl, K, N, S, ks, nullptr, &tot)) return 0;
-    return tot * (long long)sizeof(float);
-}
-extern "C" int sn_skinny_chain_state_words(void) { return kSkMaxLayers * 64 + 16 * kSkSync; }
-// nl layers out_l = act_l((x_l . [gate_l > 0]) W_l^T + bias_l), x_0 = [x | x2] (ksplit as sn_skinny_linear2), x_l = out_{l-1}; the
-// last layer's output may leave as two tensors (out2_last / nsplit_last as sn_skinny_linear2; out[nl - 1] may then be NULL).
-// K / N: the layers' input / output widths (K[l] == N[l-1]); transposed: W_l is (K, N) (the data gradient); bias / gate entries may
-// be NULL; relu: per layer.  scratch: sn_skinny_chain_scratch_bytes; state: sn_skinny_chain_state_words() 32-bit words, zeroed
-// once (left zero by every launch that did not time out); word [kSkMaxLayers * 64 + 15 * 32] = error (0: healthy).
-extern "C" int sn_skinny_chain(int R, int nl, const int *K, const int *N, const float *x, const float *x2, int ksplit,
-                               const float *const *W, int transposed, const float *const *bias, const float *const *gate, const int *relu,
-                               float *const *out, float *out2_last, int nsplit_last, float *scratch, unsigned *state, sn_stream_t stream)
-{
-    SN_REQUIRE(K && N && x && W && out && relu && scratch && state, "null pointer");
-    int S[kSkMaxLayers], ks[kSkMaxLayers];
-    long long off[kSkMaxLayers];
-    if (!skinny_chain_plan(R, nl, K, N, S, ks, off, nullptr)) return sn_set_error(SN_ERR_UNSUPPORTED, "sn_skinny_chain: shape not supported");
-    SN_REQUIRE(!x2 || (ksplit > 0 && ksplit < K[0] && ksplit % 8 == 0), "x2: ksplit must be a multiple of 8 inside (0, K)");
-    SN_REQUIRE(nsplit_last >= 0 && nsplit_last < N[nl - 1] && (nsplit_last > 0 ? (out[nl - 1] || out2_last) : out[nl - 1] != nullptr), "bad output split");
-    SkinnyChainArgs g{};
-    g.nl = nl, g.R = R, g.counter = state, g.sync = state + kSkMaxLayers * 64;
-    for (int l = 0; l < nl; ++l) {
-        SkinnyChainLayer &L = g.L[l];
-        SN_REQUIRE(W[l] && (l == nl - 1 || out[l]), "null layer pointer");
-        L.W = W[l], L.bias = bias ? bias[l] : nullptr, L.gate = gate ? gate[l] : nullptr;
-        L.x = l == 0 ? x : out[l - 1], L.x2 = l == 0 ? x2 : nullptr, L.ksplit = (l == 0 && x2) ? ksplit : 0;
-        SN_REQUIRE(!(L.gate && L.x2), "gate with a two-part input");
-        L.out = out[l], L.out2 = l == nl - 1 ? out2_last : nullptr, L.nsplit = l == nl - 1 ? nsplit_last : 0;
-        L.part = scratch + off[l];
-        L.K = K[l], L.N = N[l], L.S = S[l], L.ksteps = ks[l], L.wmode = transposed ? 1 : 0, L.relu = relu[l], L.tiles = (N[l] + 31) / 32;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    if (R <= 32) hipLaunchKernelGGL((skinny_chain_kernel<1>), dim3(kSkGrid), dim3(256), 0, st, g);
-    else if (R <= 64) hipLaunchKernelGGL((skinny_chain_kernel<2>), dim3(kSkGrid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((skinny_chain_kernel<4>), dim3(kSkGrid), dim3(256), 0, st, g);
-    SN_LAUNCH_CHECK();
-    return 0;
-}
-
 // ---- weight gradient of those layers (round 4: a TRAINABLE trunk stays on the library -- registration/main.py --train-pcrnet,
 // models/pcrnet.py:62-82): dW (N, K) = dZ^T . X with dZ = dY . [gate > 0] (R, N) and X = [x | x2] (R, K); db (N) = column sums of
 // dZ.  R <= 128 rows are the whole contraction: a wave owns one 32 x 32 tile of dW and runs R / 2 fp32 MFMAs (32x32x2: exact

@@ -357,85 +357,6 @@ def _skinny_wgrad(x, x2, dy, gate, W, st):
     return dW, db
 
 
-TRUNK_CHAIN = True  # the trunk's layers of a direction as ONE launch (sn_skinny_chain); False: one sn_skinny_linear launch per layer (tests, A/B)
-
-
-def _chain_state(like):
-    """Persistent state (arrival counters, error word) + scratch of the chain launches of one device and stream (launches of a
-    stream run one after the other and leave the state zero)."""
-    key = ("skchain", like.device, torch.cuda.current_stream(like.device).cuda_stream)
-    t = _CONST.get(key)
-    if t is None:
-        t = [torch.zeros(lib.sn_skinny_chain_state_words(), device=like.device, dtype=torch.int32), None]
-        if not torch.cuda.is_current_stream_capturing():
-            _CONST[key] = t
-    return t
-
-
-def _chain_scratch(state, nbytes, like):
-    if state[1] is None or state[1].numel() * 4 < nbytes:
-        state[1] = torch.empty(max(1, nbytes // 4), device=like.device, dtype=torch.float32)
-    return state[1]
-
-
-def check_trunk_chain(device=None, raise_error=True):
-    """Host-side health check of the trunk chain launches (sn_skinny_chain: 256 resident workgroups that hand activations to each
-    other inside one launch): a seam that timed out -- a device kept full by other work for seconds -- left NaN in the trunk's
-    output and a non-zero error word; here the state is re-armed and SampleNetHipError raised.  Synchronises: call it where the
-    loss is read back.  -> True when an error was found (raise_error=False)."""
-    from ._lib import SampleNetHipError
-
-    found = False
-    words = lib.sn_skinny_chain_state_words()
-    for key, t in list(_CONST.items()):
-        if isinstance(key, tuple) and key and key[0] == "skchain" and (device is None or key[1] == torch.device(device)):
-            if int(t[0][words - 16 * 32 + 15 * 32].item()) != 0:
-                found = True
-                t[0].zero_()
-    if found and raise_error:
-        raise SampleNetHipError("PCRNet trunk chain launch timed out at a seam (the device was too busy to hold its 256 workgroups "
-                                "together); its outputs were NaN -- this step's loss / gradients are invalid.  The launch state was reset.")
-    return found
-
-
-def _chain_dims(Ks, Ns):
-    import ctypes
-
-    n = len(Ks)
-    return (ctypes.c_int * n)(*Ks), (ctypes.c_int * n)(*Ns)
-
-
-def _trunk_chain(x, x2, Ws, transposed, biases, gates, relus, Ks, Ns, split_last=None, st=None):
-    """One direction of the trunk as one launch -> list of the layers' outputs (the last one as (out0 | None, out1 | None) with
-    split_last = (n0, want0, want1)), or None when the shape is not supported (the per-layer launches run instead)."""
-    import ctypes
-
-    nl = len(Ws)
-    R = x.shape[0]
-    Kc, Nc = _chain_dims(Ks, Ns)
-    if not (TRUNK_CHAIN and lib.sn_skinny_chain_supported(R, nl, Kc, Nc)):
-        return None
-    state = _chain_state(x)
-    scratch = _chain_scratch(state, lib.sn_skinny_chain_scratch_bytes(R, nl, Kc, Nc), x)
-    outs = [torch.empty(R, Ns[l], device=x.device, dtype=torch.float32) for l in range(nl - 1)]
-    nsplit, last, last2 = 0, None, None
-    if split_last is None:
-        last = torch.empty(R, Ns[-1], device=x.device, dtype=torch.float32)
-    else:
-        nsplit, want0, want1 = split_last
-        last = torch.empty(R, nsplit, device=x.device, dtype=torch.float32) if want0 else None
-        last2 = torch.empty(R, Ns[-1] - nsplit, device=x.device, dtype=torch.float32) if want1 else None
-        if last is None and last2 is None:  # (nobody wants the last layer's output: the kernel still needs one destination)
-            last = torch.empty(R, nsplit, device=x.device, dtype=torch.float32)
-    VP = ctypes.c_void_p * nl
-    arr = lambda ts: VP(*[ptr(t) for t in ts])  # noqa: E731
-    check(lib.sn_skinny_chain(R, nl, Kc, Nc, ptr(x), ptr(x2), x.shape[1] if x2 is not None else 0, arr(Ws), int(transposed),
-                              arr(biases) if biases is not None else None, arr(gates) if gates is not None else None,
-                              (ctypes.c_int * nl)(*[int(r) for r in relus]), arr(outs + [last]), ptr(last2), nsplit, ptr(scratch),
-                              ptr(state[0]), st if st is not None else _st(x)), "sn_skinny_chain")
-    return outs + [last if split_last is None else (last if (split_last[1] or last2 is None) else None, last2)]
-
-
 class _TrunkFunction(torch.autograd.Function):
     """PCRNet's FC trunk on at most 128 rows: [f0 | f1] -> fc1 .. fc5 (ReLU) -> fc6, six sn_skinny_linear launches forward and six
     for the data gradient (registration/models/pcrnet.py:56-77 as rocBLAS GEMMs + ReLU / mask kernels: 22 launches); weights that
@@ -447,24 +368,14 @@ class _TrunkFunction(torch.autograd.Function):
         Ws, bs = wb[0::2], wb[1::2]
         f0, f1 = f0.contiguous().float(), f1.contiguous().float()
         acts = []
-        nl = len(Ws)
         with torch.cuda.device(f0.device):
+            sc = _trunk_scratch(f0.shape[0], Ws, f0)
             st = _st(f0)  # (one stream lookup per pass: torch.cuda.current_stream costs ~5 us of host time)
-            sc = None
-            chained = None
-            if f0.shape[1] % 8 == 0:
-                chained = _trunk_chain(f0, f1, Ws, False, bs, None, [i < nl - 1 for i in range(nl)],
-                                       [W.shape[1] for W in Ws], [W.shape[0] for W in Ws], st=st)
-            if chained is not None:  # the six layers as one launch (sn_skinny_chain)
-                acts = chained
-                x = acts[-1]
-            else:
-                sc = _trunk_scratch(f0.shape[0], Ws, f0)
-                x = _skinny(f0, None, Ws[0], False, bs[0], True, x2=f1, scratch=sc, st=st)
+            x = _skinny(f0, None, Ws[0], False, bs[0], True, x2=f1, scratch=sc, st=st)
+            acts.append(x)
+            for i in range(1, len(Ws)):
+                x = _skinny(x, None, Ws[i], False, bs[i], i < len(Ws) - 1, scratch=sc, st=st)
                 acts.append(x)
-                for i in range(1, nl):
-                    x = _skinny(x, None, Ws[i], False, bs[i], i < nl - 1, scratch=sc, st=st)
-                    acts.append(x)
         ctx.save_for_backward(*acts[:-1], *Ws)
         ctx.inputs = (f0, f1) if any(ctx.needs_input_grad[2:]) else (None, None)  # (the first layer's weight gradient reads them)
         ctx.nl = len(Ws)
@@ -478,27 +389,10 @@ class _TrunkFunction(torch.autograd.Function):
         acts, Ws = ctx.saved_tensors[:nl - 1], ctx.saved_tensors[nl - 1:]
         g = g.contiguous().float()
         with torch.cuda.device(g.device):
+            sc = ctx.sc if ctx.sc[0].device == g.device else _trunk_scratch(g.shape[0], Ws, g)
             st = _st(g)
             wgrads = [None] * (2 * nl)
             f0, f1 = ctx.inputs
-            # the data gradient through all layers as one launch (sn_skinny_chain on the transposed weights, the layers' own
-            # outputs as ReLU gates); a trainable trunk reads the per-layer gradients it leaves behind for its weight gradients
-            order = list(range(nl - 1, -1, -1))
-            chained = _trunk_chain(g, None, [Ws[i] for i in order], True, None, [acts[i] if i < nl - 1 else None for i in order],
-                                   [False] * nl, [Ws[i].shape[0] for i in order], [Ws[i].shape[1] for i in order],
-                                   split_last=(ctx.n0, ctx.needs_input_grad[0], ctx.needs_input_grad[1]), st=st)
-            if chained is not None:
-                gs = [g] + chained[:-1]  # gs[j]: the gradient entering layer order[j]
-                for j, i in enumerate(order):
-                    if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
-                        gate = acts[i] if i < nl - 1 else None
-                        if i > 0:
-                            wgrads[2 * i], wgrads[2 * i + 1] = _skinny_wgrad(acts[i - 1], None, gs[j], gate, Ws[i], st)
-                        else:
-                            wgrads[0], wgrads[1] = _skinny_wgrad(f0, f1, gs[j], gate, Ws[0], st)
-                g0, g1 = chained[-1]
-                return (g0 if ctx.needs_input_grad[0] else None, g1) + tuple(wgrads)
-            sc = ctx.sc if (ctx.sc is not None and ctx.sc[0].device == g.device) else _trunk_scratch(g.shape[0], Ws, g)
             for i in range(nl - 1, 0, -1):  # dX = (dY . [y_i > 0]) W_i; the last layer has no ReLU
                 gate = acts[i] if i < nl - 1 else None
                 if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:  # trainable trunk: dW_i, db_i

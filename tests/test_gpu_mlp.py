@@ -1328,54 +1328,6 @@ def test_skinny_linear_trunk_matches_torch(R):
     assert eg <= max(2 * eg32, 2e-6 * sg), (eg, eg32, sg)
 
 
-@pytest.mark.parametrize("R,bneck,train", [(32, 1024, False), (32, 1024, True), (5, 1024, False), (64, 1024, False), (128, 1024, True),
-                                            (96, 256, False), (17, 64, True)])
-def test_trunk_chain_is_bit_identical_to_the_per_layer_launches(R, bneck, train):
-    """sn_skinny_chain (PCRNet's six trunk layers of a direction as ONE launch of 256 resident workgroups -- weight
-    fragments of every layer requested up front, activations handed over through in-kernel seams) against the per-layer
-    sn_skinny_linear launches: output, the gradients to both clouds' features and -- a trainable trunk -- every weight / bias
-    gradient are EQUAL bit for bit (same products, same slice order), repeated calls keep working (the launch state is left
-    zero), and the error word stays clear."""
-    from samplenet_amd import task_features as TF
-
-    torch.manual_seed(R + bneck)
-    net = TF.PCRNet(bottleneck_size=bneck, input_shape="bnc").cuda().eval()
-    for p in net.parameters():
-        p.requires_grad_(train)
-    fcs = [net.fc1, net.fc2, net.fc3, net.fc4, net.fc5, net.fc6]
-    wb = []
-    for fc in fcs:
-        wb += [fc.weight, fc.bias]
-    params = [p for p in wb if p.requires_grad]
-    old = TF.TRUNK_CHAIN
-    try:
-        for rep in range(3):
-            f0 = torch.randn(R, bneck, device="cuda").requires_grad_(rep != 1)
-            f1 = torch.randn(R, bneck, device="cuda").requires_grad_(True)
-            go = torch.randn(R, 7, device="cuda")
-            res = []
-            for chain in (True, False):
-                TF.TRUNK_CHAIN = chain
-                o = TF._TrunkFunction.apply(f0, f1, *wb)
-                gs = torch.autograd.grad(o, ([f0] if f0.requires_grad else []) + [f1] + params, go)
-                res.append((o.detach(),) + tuple(gs))
-            assert len(res[0]) == len(res[1])
-            for i, (u, w) in enumerate(zip(*res)):
-                assert torch.equal(u, w), (rep, i, float((u - w).abs().max()))
-            assert torch.isfinite(res[0][0]).all()
-    finally:
-        TF.TRUNK_CHAIN = old
-    assert TF.check_trunk_chain(raise_error=False) is False
-    # the chain really ran
-    import ctypes
-
-    Ks = (ctypes.c_int * 6)(*[fc.weight.shape[1] for fc in fcs])
-    Ns = (ctypes.c_int * 6)(*[fc.weight.shape[0] for fc in fcs])
-    from samplenet_amd._lib import lib
-
-    assert lib.sn_skinny_chain_supported(R, 6, Ks, Ns) == 1
-
-
 def test_pcrnet_head_and_chamfer_mean_loss_match_the_op_chain():
     """The registration task's loss pieces as fused launches against the torch op chain of registration/main.py:557-577 and
     models/pcrnet.py:78-82: twist = [normalize(y[:, :4]) | y[:, 4:]], qnorm = mean((||y[:, :4]||^2 - 1)^2) with gradients to y from
