@@ -817,9 +817,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-module-surface", action="store_true", help="skip the secondary module-surface legs")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip config3_emd / config5_progressive / batch_sweep")
-    ap.add_argument("--allreduce", choices=("graph", "graph-fork", "after", "split"), default="graph",
-                    help="N > 1, where the gradient collective runs: inside the step's graph at its end (default), inside it with "
-                         "the FC-head segment forked to a side stream, from Python after each replay, or between two graphs")
+    ap.add_argument("--allreduce", choices=("auto", "graph", "graph-fork", "after", "split"), default="auto",
+                    help="N > 1, where the gradient collective runs: inside the step's graph at its end, inside it with the FC-head "
+                         "segment forked to a side stream, from Python after each replay, or between two graphs; auto (default): "
+                         "the first three are each captured and timed for 20 replays at start-up, the fastest is kept")
     ap.add_argument("--overlap-allreduce", action="store_true", help="same as --allreduce split")
     ap.add_argument("--no-probes", action="store_true",
                     help="profiling runs: only the timed steps (no roofline kernel probes, no cpu_baseline, no secondary legs)")
@@ -910,17 +911,40 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(loss).item()
     train_step.check()  # FC-chain hand-off error words (a timed-out launch would also have left a NaN loss)
+    # the gradient collective ALONE (every rank: it is a collective), outside the timed region: what one all-reduce of the flat
+    # bucket costs back to back at this world size -- the number the scaling curve is read against (a 0.18 ms step leaves no
+    # room for a fully exposed 30-40 us collective at N = 8)
+    allreduce_alone_us = None
+    if reducer.collective:
+        for _ in range(5):
+            reducer._all_reduce_mean(reducer.flat)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            reducer._all_reduce_mean(reducer.flat)
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / 50 * 1e3], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_alone_us = float(t.item())
 
     if not train_step.split and train_step.in_graph:
         ar = "flat 1 MB bucket over RCCL, captured INSIDE the step's graph (%s)" % (
-            "FC-head segment forked to a side stream, joined at the end" if args.allreduce == "graph-fork" else "one collective at its end")
+            "FC-head segment forked to a side stream, joined at the end" if train_step.allreduce == "graph-fork" else "one collective at its end")
     elif train_step.split:
         ar = "flat bucket over RCCL: FC-head segment between the step's two graphs on a side stream, conv segment after"
     else:
         ar = "flat bucket over RCCL: one collective launched after each step"
+    if train_step.allreduce_probe is not None:
+        ar += " -- chosen by allreduce='auto' (ms per step at start-up, slowest rank: %s)" % ", ".join(
+            "%s %.4f" % kv for kv in train_step.allreduce_probe["ms_per_step"].items())
     if rank == 0 and args.no_probes:
         print(json.dumps({"value": world * B * total_steps / dt, "ms_per_step": dt / total_steps * 1e3, "n_gpus": world,
-                          "grad_allreduce": ar if reducer.collective else "none", "note": "--no-probes run"}), flush=True)
+                          "grad_allreduce": ar if reducer.collective else "none",
+                       "allreduce_alone_us": allreduce_alone_us, "allreduce_bytes": int(reducer.flat.numel() * 4), "allreduce_alone_us": allreduce_alone_us,
+                          "note": "--no-probes run"}), flush=True)
     elif rank == 0:
         ms = dt / total_steps * 1e3
         value = world * B * total_steps / dt
@@ -984,7 +1008,7 @@ def main():
             "value": value, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "timed_steps": total_steps, "timed_region_s": dt,
+            "timed_steps": total_steps, "timed_region_s": dt, "allreduce_alone_us": allreduce_alone_us,
             "config": {"workload": "BASELINE configs[1]: SampleNet sampler train step (fwd + simplification/projection "
                                    "losses + bwd), B=%d per GPU, 1024->64 points, K=8, bottleneck 128; no optimizer step" % B,
                        "batch_per_gpu": B, "global_batch": B * world, "n_in": N, "n_out": M, "group_size": K,

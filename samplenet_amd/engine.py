@@ -57,12 +57,83 @@ class SamplerTrainStep:
         #                those gradients are final and joined at the end: hidden under the conv stack's backward at the price of
         #                two cross-stream edges in the graph;
         #   "after"      one collective launched from Python behind each replay (round-2 behaviour).
-        if allreduce not in ("graph", "graph-fork", "after"):
-            raise ValueError("allreduce: 'graph', 'graph-fork' or 'after'")
+        #   "auto"       the three placements above are each captured on the first ring entry and timed (20 replays, the
+        #                slowest rank's time counts), the fastest one is kept: which of them wins depends on what the collective
+        #                costs beside the step's own kernels at THIS world size (a ~1 MB ring all-reduce over xGMI is latency-
+        #                bound: tens of microseconds against a 0.18 ms step) -- unknowable from a single-GPU run.  The choice and
+        #                the three times are left in self.allreduce_probe.
+        if allreduce not in ("graph", "graph-fork", "after", "auto"):
+            raise ValueError("allreduce: 'graph', 'graph-fork', 'after' or 'auto'")
+        self.allreduce_probe = None
+        auto = allreduce == "auto" and bool(use_graph and not self.split and reducer is not None and reducer.collective)
+        if allreduce == "auto":
+            allreduce = "graph"
         self.allreduce = allreduce
         self.in_graph = bool(use_graph and not self.split and reducer is not None and reducer.collective and allreduce != "after")
-        if use_graph:
+        if use_graph and auto:
+            self._choose_allreduce(warmup)
+        elif use_graph:
             self._capture(warmup)
+
+    def _choose_allreduce(self, warmup, replays=20):
+        """allreduce='auto': see __init__."""
+        import torch.distributed as dist
+
+        from .surface import bury
+
+        ring = self.ring
+        times = {}
+        for mode in ("graph", "after", "graph-fork"):
+            self.allreduce, self.in_graph = mode, mode != "after"
+            self._ring_graphs, self._ring_loss, self._ring_outputs = [], [], []
+            if ring is not None:
+                self.ring = ring[:1]
+            ms = float("inf")
+            multi = dist.is_initialized() and dist.get_world_size(self.reducer.group) > 1
+            try:
+                ok = True
+                try:
+                    self._capture(warmup)
+                except RuntimeError:
+                    torch.cuda.synchronize()
+                    ok = False
+                ok = ok and self.allreduce == mode  # (a capture that fell back to 'after' is not a measurement of `mode`)
+                if multi:  # the timed replays below issue collectives: every rank runs them, or none does
+                    flag = torch.tensor([1 if ok else 0], device=self.x.device, dtype=torch.int32)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.reducer.group)
+                    ok = bool(int(flag.item()))
+                if ok:
+                    for _ in range(3):
+                        self._probe_step()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(replays):
+                        self._probe_step()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / replays
+            except RuntimeError:
+                torch.cuda.synchronize()
+            finally:
+                self.ring = ring
+            for graphs in self._ring_graphs:
+                bury(*graphs)
+            times[mode] = ms
+        # every rank must pick the same placement: the slowest rank's time per mode, ties in the fixed order above
+        t = torch.tensor([min(times[m], 1e9) for m in ("graph", "after", "graph-fork")], device=self.x.device, dtype=torch.float64)
+        if dist.is_initialized() and dist.get_world_size(self.reducer.group) > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.reducer.group)
+        vals = [float(v) for v in t.tolist()]
+        best = ("graph", "after", "graph-fork")[min(range(3), key=lambda i: vals[i])]
+        self.allreduce_probe = {"ms_per_step": dict(zip(("graph", "after", "graph-fork"), vals)), "chosen": best, "replays": replays}
+        self.allreduce, self.in_graph = best, best != "after"
+        self._ring_graphs, self._ring_loss, self._ring_outputs = [], [], []
+        self._capture(1)
+
+    def _probe_step(self):
+        self._replay_graphs(0)
+        self.reducer.reduce(collective=not (self.in_graph and self._ring_graphs), replayed=True)
 
     def __del__(self):
         try:
@@ -206,7 +277,11 @@ class SamplerTrainStep:
                 self.reducer.capture_fork = True
                 self.net._after_fc_grads = self.reducer._early_ready
             try:
-                with torch.cuda.graph(g, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+                # (with a collective in play the capture keeps torch's own capture stream: the process group's watchdog thread still
+                #  polls the END events of the warm-up's eager collectives, which were recorded on the warm-up stream -- HIP refuses
+                #  a query of an event whose stream is capturing, and the watchdog aborts the process)
+                kw = {} if (self.reducer is not None and self.reducer.collective) else {"stream": self._cap_stream}
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local", **kw):
                     loss = self._step()
                     if self.in_graph:
                         self.reducer.reduce()  # captured: the collective(s) replay with the step

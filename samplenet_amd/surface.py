@@ -367,10 +367,13 @@ class _Plan:
         _collect_before_capture()
         self.pool = torch.cuda.graph_pool_handle()
         self.gf, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        self.stream = side  # (captured on the warm-up's stream: see engine._capture)
-        with torch.cuda.graph(self.gf, pool=self.pool, stream=side, capture_error_mode="thread_local"):
+        # captured on the warm-up's stream (its per-stream scratch is found again: see engine._capture) -- unless a collective is in
+        # play: the process group's watchdog polls events the warm-up recorded on that stream, which HIP refuses while it captures
+        self.stream = side
+        kw = {} if (self.reducer is not None and self.reducer.collective) else {"stream": side}
+        with torch.cuda.graph(self.gf, pool=self.pool, capture_error_mode="thread_local", **kw):
             self._forward_body(net)
-        with torch.cuda.graph(self.gb, pool=self.pool, stream=side, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.gb, pool=self.pool, capture_error_mode="thread_local", **kw):
             self._backward_body(net)
         self.v_lsimp, self.v_sigma = self.values[0], self.values[1]
 

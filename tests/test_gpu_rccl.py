@@ -88,6 +88,40 @@ def test_captured_step_with_collectives(rccl, mode):
         assert torch.equal(a, b), n  # BatchNorm running statistics moved identically
 
 
+def test_allreduce_auto_picks_one_placement_and_stays_exact(rccl):
+    """SamplerTrainStep(allreduce='auto') (VERDICT r5 #7b): the three placements of the gradient collective are each captured and
+    timed at start-up, one is kept -- and whichever it is, the replays leave exactly the gradients of the collective-free step
+    (one rank: AVG is the identity).  The probe's record names the choice and a finite time for every placement that could be
+    captured."""
+    import math
+
+    from samplenet_amd.engine import SamplerTrainStep
+    from samplenet_amd.parallel import FlatGradAllReducer
+
+    na, nb = _nets(2)
+    ring_a = [torch.rand(32, 1024, 3, device="cuda") - 0.5 for _ in range(2)]
+    ring_b = [t.clone() for t in ring_a]
+    ra = FlatGradAllReducer(na)
+    rb = FlatGradAllReducer(nb, force_collective=True)
+    sb = SamplerTrainStep(nb, ring_b[0], reducer=rb, input_ring=ring_b, allreduce="auto")
+    probe = sb.allreduce_probe
+    assert probe is not None and probe["chosen"] == sb.allreduce and sb.allreduce in ("graph", "after", "graph-fork")
+    assert math.isfinite(probe["ms_per_step"][sb.allreduce]) and probe["ms_per_step"][sb.allreduce] < 1e8
+    assert sb.in_graph == (sb.allreduce != "after") and len(sb._ring_graphs) == 2
+    print("allreduce='auto' at world size 1 (collective forced):", probe)
+    # (the probes ran extra steps on replica b: its running statistics are ahead; training-mode gradients do not read them)
+    sa = SamplerTrainStep(na, ring_a[0], reducer=ra, input_ring=ring_a)
+    for i in (0, 1, 1, 0):
+        la, lb = sa.replay(i), sb.replay(i)
+        torch.cuda.synchronize()
+        assert float(la) == float(lb), i
+        assert torch.equal(ra.flat, rb.flat), i
+    # without a collective 'auto' is the plain captured step
+    nc = _nets(1)[0]
+    sc = SamplerTrainStep(nc, ring_a[0], reducer=FlatGradAllReducer(nc), input_ring=ring_a, allreduce="auto")
+    assert sc.allreduce_probe is None and not sc.in_graph
+
+
 def test_in_graph_collective_with_an_outside_task_loss(rccl):
     """The captured fused step with a task loss outside the node (proj differentiable) and the all-reduce inside the graph."""
     from samplenet_amd.engine import SamplerTrainStep
