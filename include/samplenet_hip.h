@@ -145,15 +145,6 @@ int sn_chamfer_mean_loss_backward(int B, int n1, const float *xyz1, int n2, cons
 int sn_pcrnet_head_forward(int B, const float *y, float *twist, float *quat, float *qnorm, sn_stream_t stream);
 int sn_pcrnet_head_backward(int B, const float *y, const float *g_twist, const float *g_quat, const float *g_qnorm, float *g_y,
                             sn_stream_t stream);
-/* sn_pcrnet_head_forward + sn_qrot_forward as ONE launch (main.py:563-571: twist = model(p0, p1); est_transform.rotate(p0)):
- * y (B,7), v (B,N,3) -> twist (B,7), quat (B,4), qnorm (device scalar, may be NULL), out (B,N,3) = v rotated by quat; and the
- * backward of that pair as one launch: grad_out (B,N,3), grad_twist (B,7), grad_quat (B,4), grad_qnorm (device scalar), each
- * may be NULL -> grad_y (B,7) and, when grad_v != NULL, grad_v (B,N,3).  Bit-identical to the two launches each way. */
-int sn_pcrnet_head_rot_forward(int B, int N, const float *y, const float *v, float *twist, float *quat, float *qnorm, float *out,
-                               sn_stream_t stream);
-int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat, const float *v, const float *grad_out,
-                                const float *grad_twist, const float *grad_quat, const float *grad_qnorm, float *grad_v, float *grad_y,
-                                sn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * kNN alone (no gradient).  xyz1 dataset, xyz2 queries, layouts selectable.

@@ -329,6 +329,19 @@ int sn_pointnet_narrow_backward(int R, const float *dz4, const float *z1, const 
  * arrive (deterministic); fp32 products as split-bf16 MFMAs.
  *   transposed == 0: W (N, K) -- forward;  != 0: W (K, N) -- data gradient dX = (dY . [y > 0]) W with gate = the layer's output y
  *   gate, bias: optional.  scratch: _scratch_bytes; counters: (N + 31) / 32 zeroed 32-bit words (left zeroed). */
+/* sn_pcrnet_head_forward + sn_qrot_forward as ONE launch (main.py:563-571: twist = model(p0, p1); est_transform.rotate(p0)):
+ * y (B,7), v (B,N,3) -> twist (B,7), quat (B,4), qnorm (device scalar, may be NULL), out (B,N,3) = v rotated by quat; and the
+ * backward of that pair as one launch: grad_out (B,N,3), grad_twist (B,7), grad_quat (B,4), grad_qnorm (device scalar), each
+ * may be NULL -> grad_y (B,7) and, when grad_v != NULL, grad_v (B,N,3).  Bit-identical to the two launches each way. */
+int sn_pcrnet_head_rot_forward(int B, int N, const float *y, const float *v, float *twist, float *quat, float *qnorm, float *out,
+                               sn_stream_t stream);
+int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat, const float *v, const float *grad_out,
+                                const float *grad_twist, const float *grad_quat, const float *grad_qnorm, float *grad_v, float *grad_y,
+                                sn_stream_t stream);
+
+/* Test hook: the packed-distance variant of the large-batch pair scan (B >= 512 with one workgroup per cloud: point-pair distances
+ * on v_pk_add_f32 / v_pk_mul_f32, bit-identical to the scalar form) on (1, default) / off (0); returns the previous setting. */
+int sn_pairscan_set_packed(int on);
 int sn_skinny_linear_supported(int R, int K, int N);
 long long sn_skinny_linear_scratch_bytes(int R, int K, int N);
 int sn_skinny_linear(int R, int K, int N, const float *x, const float *gate, const float *W, int transposed, const float *bias, int relu,

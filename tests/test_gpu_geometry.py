@@ -631,3 +631,59 @@ def test_prefix_point_minima_match_chamfer_per_prefix(oracle, B, N, M, sizes):
         assert np.array_equal(i[j].cpu().numpy(), oi2), s
     _, _, _, _, hd2, hi2 = ops.chamfer_forward_impl(dev(Q), dev(P))
     assert torch.equal(d[-1], hd2) and torch.equal(i[-1], hi2)
+
+
+@pytest.mark.parametrize("B,N,M,K,kind", [(512, 1024, 64, 8, "random"), (512, 1024, 64, 7, "near"), (600, 1000, 64, 16, "clusters"),
+                                          (512, 2048, 64, 16, "random"), (512, 1024, 64, 8, "identical"), (700, 900, 33, 3, "near")])
+def test_packed_distance_scan_is_bit_identical_to_the_scalar_form(oracle, B, N, M, K, kind):
+    """VERDICT r5 #5a: once the batch alone fills the chip (B >= 512, one workgroup per cloud) the pair scan computes the distances of
+    point PAIRS on v_pk_add_f32 / v_pk_mul_f32 (hand-written, early-clobber destinations; each element rounds as the scalar
+    instruction: no FMA).  Against the scalar variant of the same launch (sn_pairscan_set_packed(0)): kNN indices and distances,
+    both Chamfer directions and the projection are EQUAL bit for bit -- on random clouds, near-surface queries (near-ties),
+    coincident clusters and all-identical clouds (ties resolve to the lowest index) -- and a sample of clouds equals the oracle."""
+    import numpy as np
+    import torch
+
+    from samplenet_amd import ops
+    from samplenet_amd._lib import lib
+
+    g = torch.Generator(device="cuda").manual_seed(B + N + K)
+    P = torch.rand(B, N, 3, device="cuda", generator=g) - 0.5
+    if kind == "near":
+        perm = torch.randperm(N, device="cuda", generator=g)[:M]
+        Q = P[:, perm] + 0.02 * torch.randn(B, M, 3, device="cuda", generator=g)
+    elif kind == "clusters":
+        P = P[:, : N // 8].repeat(1, 8, 1).contiguous()  # every point eight times
+        Q = torch.rand(B, M, 3, device="cuda", generator=g) - 0.5
+    elif kind == "identical":
+        P = P[:, :1].expand(B, N, 3).contiguous()
+        Q = torch.rand(B, M, 3, device="cuda", generator=g) - 0.5
+    else:
+        Q = torch.rand(B, M, 3, device="cuda", generator=g) - 0.5
+    P, Q = P.contiguous(), Q.contiguous()
+    T = torch.tensor(0.7, device="cuda")
+
+    def run():
+        idx, dist = ops.knn(K, P, Q, ops.BNC, ops.BNC)
+        d1, d2, i1, i2 = ops.ChamferDistanceFunction.apply(Q, P)
+        proj = ops.SoftProjectFunction.apply(P, Q.permute(0, 2, 1).contiguous(), T, 1e-2, K, False, ops.BNC, ops.BNC)[0]
+        torch.cuda.synchronize()
+        return idx, dist, d1, d2, i1, i2, proj
+
+    prev = lib.sn_pairscan_set_packed(1)
+    try:
+        a = run()
+        lib.sn_pairscan_set_packed(0)
+        b = run()
+    finally:
+        lib.sn_pairscan_set_packed(prev)
+    for i, (u, w) in enumerate(zip(a, b)):
+        assert torch.equal(u, w), (kind, i)
+    # anchor a few clouds to the oracle (the scalar form is anchored on every shape elsewhere in this file)
+    sel = [0, B // 2, B - 1]
+    od, oi = oracle.knn(K, P[sel].cpu().numpy(), Q[sel].cpu().numpy())
+    assert np.array_equal(a[0][sel].cpu().numpy(), oi) and np.array_equal(a[1][sel].cpu().numpy(), od)
+    c1, ci1, c2, ci2 = oracle.chamfer_forward(Q[sel].cpu().numpy(), P[sel].cpu().numpy())
+    # (ChamferDistanceFunction returns dist1, dist2, idx1, idx2)
+    assert np.array_equal(a[2][sel].cpu().numpy(), c1) and np.array_equal(a[4][sel].cpu().numpy(), ci1)
+    assert np.array_equal(a[3][sel].cpu().numpy(), c2) and np.array_equal(a[5][sel].cpu().numpy(), ci2)

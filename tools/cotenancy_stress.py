@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Do the library's results depend on what ELSE runs on the GPU?   python tools/cotenancy_stress.py [fwd|step|task|emd] [passes] [--solo]
+"""Do the library's results depend on what ELSE runs on the GPU?   python tools/cotenancy_stress.py [fwd|step|task|emd|scan] [passes] [--solo]
 
 Two processes work on cuda:0 at the same time (the second one is started here unless --solo), each repeating the same computation
 on the same inputs and comparing every pass with its first one, bit for bit:
@@ -10,6 +10,7 @@ on the same inputs and comparing every pass with its first one, bit for bit:
     task  the reference call pattern with the frozen PCRNet + Chamfer task (registration/main.py:507-531, 557-577) on the captured
           module surface: fresh replicas, five script steps each (the last three replay graphs): loss and every gradient
     emd   sn_emd_loss (auction + cost + gradients, reconstruction's loss) on one batch: cost and both gradients
+    scan  the large-batch pair scan (B = 512: point-pair distances on hand-written packed fp32 instructions): kNN + Chamfer products
 Why this exists (round 4): alone on the device every pass repeats exactly (the statistics are integer sums); with a
 second process present, a build whose kernels carry the compiler's packed fp32 VALU ops (v_pk_fma_f32 ...) deviated in ~1 % of the
 forward passes -- low halves of the packed pairs, i.e. the even channels of the xyz layer's statistics, and everything downstream
@@ -145,15 +146,38 @@ def run_emd(passes):
     return bad, first
 
 
+def run_scan(passes):
+    """The large-batch pair scan (B = 512: the variant whose point-pair distances run on hand-written packed fp32 instructions):
+    kNN indices / distances, both Chamfer directions."""
+    from samplenet_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    P = (torch.rand(512, 1024, 3, device="cuda", generator=g) - 0.5).contiguous()
+    Q = (torch.rand(512, 64, 3, device="cuda", generator=g) - 0.5).contiguous()
+    ref, bad, first = None, 0, None
+    for it in range(passes):
+        idx, dist = ops.knn(8, P, Q, ops.BNC, ops.BNC)
+        _, _, d1, i1, d2, i2 = ops.chamfer_forward_impl(Q, P)
+        cur = (idx, dist, d1, i1, d2, i2)
+        if ref is None:
+            ref = cur
+            continue
+        if not all(torch.equal(u, v) for u, v in zip(cur, ref)):
+            bad += 1
+            if first is None:
+                first = "pass %d: (knn idx, knn dist, dist_q, idx_q, dist_p, idx_p) equal %s" % (it, [torch.equal(u, v) for u, v in zip(cur, ref)])
+    return bad, first
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     mode = args[0] if args else "fwd"
-    n = int(args[1]) if len(args) > 1 else {"fwd": 4000, "step": 150, "task": 60, "emd": 300}[mode]
+    n = int(args[1]) if len(args) > 1 else {"fwd": 4000, "step": 150, "task": 60, "emd": 300, "scan": 1000}[mode]
     other = None
     if "--solo" not in sys.argv and "--child" not in sys.argv:
         other = subprocess.Popen([sys.executable, os.path.abspath(__file__), mode, str(n), "--child"], stdout=subprocess.PIPE,
                                  stderr=subprocess.STDOUT, text=True)
-    bad, first = {"fwd": run_fwd, "step": run_step, "task": run_task, "emd": run_emd}[mode](n)
+    bad, first = {"fwd": run_fwd, "step": run_step, "task": run_task, "emd": run_emd, "scan": run_scan}[mode](n)
     who = "child" if "--child" in sys.argv else ("solo" if other is None else "parent")
     print("cotenancy_stress %s %s: %d of %d deviated%s" % (mode, who, bad, n, (" -- " + first) if first else ""), flush=True)
     rc = 1 if bad else 0
