@@ -339,9 +339,6 @@ int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat,
                                 const float *grad_twist, const float *grad_quat, const float *grad_qnorm, float *grad_v, float *grad_y,
                                 sn_stream_t stream);
 
-/* Test hook: the packed-distance variant of the large-batch pair scan (B >= 512 with one workgroup per cloud: point-pair distances
- * on v_pk_add_f32 / v_pk_mul_f32, bit-identical to the scalar form) on (1, default) / off (0); returns the previous setting. */
-int sn_pairscan_set_packed(int on);
 int sn_skinny_linear_supported(int R, int K, int N);
 long long sn_skinny_linear_scratch_bytes(int R, int K, int N);
 int sn_skinny_linear(int R, int K, int N, const float *x, const float *gate, const float *W, int transposed, const float *bias, int relu,

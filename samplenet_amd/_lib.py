@@ -43,7 +43,6 @@ PROTOTYPES = {
     "sn_sampler_loss_forward": [_i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp],
     "sn_sampler_loss_backward": [_i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp],
     "sn_pairscan_colmin_splits": [_i, _i, _i],
-    "sn_pairscan_set_packed": [_i],
     "sn_pairscan_forward_partial": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, ctypes.c_longlong, _vp],
     "sn_pairscan_forward_partial_fc": [_i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _f,
                                        _vp, ctypes.c_longlong, _vp],

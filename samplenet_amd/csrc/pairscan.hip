@@ -64,39 +64,6 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, float px, 
     return s + zz;
 }
 
-// The same expression for a PAIR of points with gfx950's packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32: two values in one
-// 64-bit register pair per issue): (px - qx)^2 + (py - qy)^2 summed first, then + (pz - qz)^2 -- every element rounds exactly as the
-// scalar instruction does (no fused multiply-add anywhere), so distances, hence every index, are bit-identical to sqdist().
-// Eight issue slots for two points instead of sixteen: the scan is VALU-issue-bound once the batch fills the chip (85 % VALU-busy
-// at 510 VALU per query, profiles/r05/pairscan_sq_counters.json).  Hand-written with EARLY-CLOBBER destinations -- the destination
-// pair never overlaps a source pair -- as in emd.hip: the library is built without compiler-generated packed fp32 arithmetic
-// (build.py), and tests/test_cabi_and_host.py checks this object's disassembly for exactly that form.
-typedef float f2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2v pk_mul(f2v a, f2v b)
-{
-    f2v d;
-    asm("v_pk_mul_f32 %0, %1, %2" : "=&v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f2v pk_add(f2v a, f2v b)
-{
-    f2v d;
-    asm("v_pk_add_f32 %0, %1, %2" : "=&v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f2v pk_sub(f2v a, f2v b)  // a - b
-{
-    f2v d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=&v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ f2v sqdist2(f2v qx, f2v qy, f2v qz, f2v px, f2v py, f2v pz)
-{
-    const f2v dx = pk_sub(px, qx), dy = pk_sub(py, qy), dz = pk_sub(pz, qz);
-    const f2v xx = pk_mul(dx, dx), yy = pk_mul(dy, dy), zz = pk_mul(dz, dz);
-    return pk_add(pk_add(xx, yy), zz);
-}
-
 // Keep the K smallest of list[0..cnt) in list[0..min(K,cnt)) sorted ascending (rank by counting;
 // keys are unique).  Wave-synchronous: every lane of the wave calls it with the same arguments.
 __device__ __forceinline__ int merge_topk(sn_u64 *list, int cnt, int K, int lane)
@@ -310,12 +277,9 @@ __device__ __forceinline__ void fc_query(const PairscanArgs &a, int b, int j, in
     }
 }
 
-// PK: the distances of point pairs on the packed fp32 instructions (sqdist2) -- the variant for launches in which the batch alone
-// fills the chip (many queries per wave: issue-bound); the latency-bound small-batch launches keep the scalar form.
-template <int PPL, bool SINGLE, bool COLMIN, int LOGG, bool PK = false>
+template <int PPL, bool SINGLE, bool COLMIN, int LOGG>
 __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(PairscanArgs a)
 {
-    static_assert(!PK || (SINGLE && PPL % 2 == 0), "packed distances: single-chunk variants with an even number of points per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -350,16 +314,6 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
         ci[i] = 0;
     }
     if (SINGLE) load_chunk<PPL>(px, py, pz, Pb, a.p_layout, N, 0, lane);
-    // PK: the points as register pairs (2 i, 2 i + 1), built once per workgroup
-    f2v ppx[PK ? PPL / 2 : 1], ppy[PK ? PPL / 2 : 1], ppz[PK ? PPL / 2 : 1];
-    if constexpr (PK) {
-#pragma unroll
-        for (int i = 0; i < PPL / 2; ++i) {
-            ppx[i] = f2v{px[2 * i], px[2 * i + 1]};
-            ppy[i] = f2v{py[2 * i], py[2 * i + 1]};
-            ppz[i] = f2v{pz[2 * i], pz[2 * i + 1]};
-        }
-    }
     PS_TL_DRAIN();
     PS_TL(1);
 
@@ -383,17 +337,9 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
             if (!SINGLE) load_chunk<PPL>(px, py, pz, Pb, a.p_layout, N, c0, lane);
             float d[PPL];
             float lmin = INFINITY;
-            if constexpr (PK) {
-                const f2v qxx = f2v{qx, qx}, qyy = f2v{qy, qy}, qzz = f2v{qz, qz};
-#pragma unroll
-                for (int i = 0; i < PPL / 2; ++i) {
-                    const f2v dd = sqdist2(qxx, qyy, qzz, ppx[i], ppy[i], ppz[i]);
-                    d[2 * i] = dd.x, d[2 * i + 1] = dd.y;
-                }
-            }
 #pragma unroll
             for (int i = 0; i < PPL; ++i) {
-                if constexpr (!PK) d[i] = sqdist(qx, qy, qz, px[i], py[i], pz[i]);
+                d[i] = sqdist(qx, qy, qz, px[i], py[i], pz[i]);
                 lmin = fminf(lmin, d[i]);
                 if (COLMIN) {
                     if (d[i] < cd[i]) {  // strict '<', ascending j: lowest query index wins
@@ -634,20 +580,11 @@ __global__ void __launch_bounds__(256) colmin_finalize_kernel(int N, int G, cons
 }
 
 template <int PPL, bool SINGLE, bool COLMIN>
-static int launch_pairscan(const PairscanArgs &a, int waves, int ysplit, hipStream_t st, bool packed = false)
+static int launch_pairscan(const PairscanArgs &a, int waves, int ysplit, hipStream_t st)
 {
     const size_t lds = (size_t)waves * kListPitch * 8 + (COLMIN ? (size_t)kWave * PPL * 8 + (size_t)waves * 16 : 0);
     const dim3 grid(a.B, ysplit), block(waves * kWave);
     // number of lane groups for the threshold = power of two >= K (instantiated: 1, 8, 16, 64)
-    if constexpr (SINGLE && (PPL == 16 || PPL == 32)) {
-        if (packed && a.K > 1 && a.K <= 16) {  // the batch fills the chip: packed distances (the sampler's group sizes)
-            if (a.K <= 8)
-                hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN, 3, true>), grid, block, lds, st, a);
-            else
-                hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN, 4, true>), grid, block, lds, st, a);
-            return 0;
-        }
-    }
     if (a.K <= 1)
         hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN, 0>), grid, block, lds, st, a);
     else if (a.K <= 8)
@@ -658,9 +595,6 @@ static int launch_pairscan(const PairscanArgs &a, int waves, int ysplit, hipStre
         hipLaunchKernelGGL((pairscan_kernel<PPL, SINGLE, COLMIN, 6>), grid, block, lds, st, a);
     return 0;
 }
-
-// test / A-B hook: 0 switches the packed-distance variant of the large-batch launches off (sn_pairscan_set_packed)
-static int g_pairscan_packed = 1;
 
 // number of workgroups the queries of one cloud are spread over (single-chunk path, N <= 2048): the batch alone cannot
 // fill the chip at B = 32, so aim at >= 2 workgroups per CU
@@ -695,14 +629,11 @@ int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finaliz
         // holds 153 VGPRs -> 3 waves per SIMD = 12 per CU: three workgroups of 4 instead of one of 8; swept 8 / 6 / 4 /
         // 3 / 2 at B = 8192: 10.1 / 8.4 / 15.0 / 14.4 / 14.3 M clouds/s)
         if (ysplit == 1 && a.B >= 512) waves = std::min(waves, 4);
-        // ... and every wave then walks >= 16 queries: the issue-bound regime, where the packed-distance variant pays (the
-        // small-batch launches are latency-bound: one query per wave, unchanged)
-        const bool packed = g_pairscan_packed && ysplit == 1 && a.B >= 512 && !a.fc_w;
         a.colmin_ws = (colmin && ysplit > 1 && !a.colmin_keys) ? (sn_u64 *)ws : nullptr;
         if (used_split) *used_split = ysplit;
 #define SN_PS(PPL_)                                                                      \
-    (colmin ? launch_pairscan<PPL_, true, true>(a, waves, ysplit, st, packed)            \
-            : launch_pairscan<PPL_, true, false>(a, waves, ysplit, st, packed))
+    (colmin ? launch_pairscan<PPL_, true, true>(a, waves, ysplit, st)                    \
+            : launch_pairscan<PPL_, true, false>(a, waves, ysplit, st))
         switch (ppl) {
             case 1: SN_PS(1); break;
             case 4: SN_PS(4); break;
@@ -727,15 +658,6 @@ int pairscan_dispatch(PairscanArgs a, void *ws, long long ws_bytes, bool finaliz
 }  // namespace sn
 
 using sn::PairscanArgs;
-
-// Test hook: packed-distance variant of the large-batch pair scan on (1, default) / off (0); returns the previous setting.  Results
-// are bit-identical either way (tests/test_gpu_geometry.py compares them).
-extern "C" int sn_pairscan_set_packed(int on)
-{
-    const int prev = sn::g_pairscan_packed;
-    sn::g_pairscan_packed = on ? 1 : 0;
-    return prev;
-}
 
 extern "C" long long sn_pairscan_workspace_bytes(int B, int N, int M)
 {

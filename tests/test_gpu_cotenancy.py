@@ -23,14 +23,14 @@ def _stress(mode, n):
     return r.returncode == 0 and all(" 0 of %d deviated" % n in l for l in lines), lines
 
 
-@pytest.mark.parametrize("mode,n", [("fwd", 3000), ("step", 60), ("task", 25), ("emd", 400), ("scan", 1500)])
+@pytest.mark.parametrize("mode,n", [("fwd", 3000), ("step", 60), ("task", 25), ("emd", 400), ("scan", 800)])
 def test_results_do_not_depend_on_a_second_process_on_the_gpu(mode, n):
     """STRICT: one deviating pass fails the test.  A build that is affected deviates in ~1 % of the passes (dozens of events in a run
     of the `fwd` mode).  The summary lines -- with the first deviation's description when there is one -- are appended to
     gpurun_out/cotenancy_first_deviation.txt (merged back from the GPU box), so that an event leaves more than a red test behind.
-    `emd` and `scan` cover the two objects that carry packed fp32 instructions (hand-written, destinations disjoint from their
-    sources: emd.hip, pairscan.hip's large-batch variants); SAMPLENET_AMD_EMD_SCALAR=1 at build time compiles emd.hip without them
-    (build.py), sn_pairscan_set_packed(0) switches the scan's packed variants off at run time."""
+    `emd` covers the one object that carries packed fp32 instructions (hand-written, destinations disjoint from their sources:
+    emd.hip); SAMPLENET_AMD_EMD_SCALAR=1 at build time compiles that unit without them (build.py).  `scan`: the pair scan's
+    large-batch launch shape."""
     ok, lines = _stress(mode, n)
     if not ok:
         try:

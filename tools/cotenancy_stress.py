@@ -10,7 +10,7 @@ on the same inputs and comparing every pass with its first one, bit for bit:
     task  the reference call pattern with the frozen PCRNet + Chamfer task (registration/main.py:507-531, 557-577) on the captured
           module surface: fresh replicas, five script steps each (the last three replay graphs): loss and every gradient
     emd   sn_emd_loss (auction + cost + gradients, reconstruction's loss) on one batch: cost and both gradients
-    scan  the large-batch pair scan (B = 512: point-pair distances on hand-written packed fp32 instructions): kNN + Chamfer products
+    scan  the large-batch pair scan (B = 512: one workgroup per cloud, many queries per wave): kNN + Chamfer products
 Why this exists (round 4): alone on the device every pass repeats exactly (the statistics are integer sums); with a
 second process present, a build whose kernels carry the compiler's packed fp32 VALU ops (v_pk_fma_f32 ...) deviated in ~1 % of the
 forward passes -- low halves of the packed pairs, i.e. the even channels of the xyz layer's statistics, and everything downstream
@@ -147,8 +147,8 @@ def run_emd(passes):
 
 
 def run_scan(passes):
-    """The large-batch pair scan (B = 512: the variant whose point-pair distances run on hand-written packed fp32 instructions):
-    kNN indices / distances, both Chamfer directions."""
+    """The large-batch pair scan (B = 512: one workgroup per cloud, many queries per wave): kNN indices / distances, both Chamfer
+    directions."""
     from samplenet_amd import ops
 
     g = torch.Generator(device="cuda").manual_seed(11)

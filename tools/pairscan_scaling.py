@@ -11,10 +11,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from samplenet_amd._lib import check, lib, ptr  # noqa: E402
 
 N, M, K = 1024, 64, 8
-# SN_PS_PACKED=0: the large-batch launches on the scalar distances (A/B of the packed-distance variant, same box)
-if os.environ.get("SN_PS_PACKED") == "0":
-    lib.sn_pairscan_set_packed(0)
-    print("# packed-distance variant OFF")
 for B in ([int(v) for v in sys.argv[1:]] or [32, 128, 512, 2048, 8192]):
     dev = "cuda"
     x = torch.rand(B, N, 3, device=dev) - 0.5
