@@ -24,12 +24,11 @@ def _st(t):
     return stream_of(t)
 
 
-# Test hooks (the defaults are the product path; False = the route other shapes take anyway)
+# Test hooks (the defaults are the product path; False = the route other shapes take anyway).  The FC trunk and the output head
+# have ONE route -- sn_skinny_linear / sn_skinny_wgrad, sn_pcrnet_head_* -- on the GPU, whatever the widths: no torch.nn.Linear.
 FUSE_MAXPOOL = True        # last layer + max over the points as one GEMM launch (sn_linear_forward_maxpool)
 FUSE_NARROW = True         # conv1..conv4 (3 -> 64 -> 64 -> 64 -> 128) as one launch (sn_pointnet_narrow_forward)
 WIDE_MAXPOOL = True        # ... as the wide kernel (A fragments resident, pre-split weight planes) where the shape allows
-FUSED_HEAD = True          # quaternion normalisation + regulariser as one launch (sn_pcrnet_head_*), else the torch op chain
-FUSED_TRUNK = True         # FC trunk through sn_skinny_linear (forward, data gradient) + sn_skinny_wgrad (a trainable trunk), row blocks of <= 128; False: torch.nn.Linear (A/B, tests)
 SPARSE_POOL_DGRAD = True   # last layer's data gradient from the one non-zero per cloud and channel (sn_pool_dgrad_sparse)
 
 _CONST = {}  # (rows, channels, device) -> constant coefficient table, built once (never written afterwards)
@@ -561,7 +560,7 @@ class PCRNet(nn.Module):
         f0 = self.template_features(x0) if feat0 is None else feat0
         B = f0.shape[0]
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
-        if not (FUSED_TRUNK and f0.is_cuda and E * B <= 128 and f0.shape[1] % 8 == 0 and E > 1):
+        if not (E * B <= 128 and f0.shape[1] % 8 == 0 and E > 1):
             return [self.forward_with_qnorm(x0, x1, feat0=f0, rotate=rotate) for x1 in x1_list]
         f1 = torch.cat([self.feat(x1) for x1 in x1_list], dim=0)
         wb = []
@@ -571,18 +570,12 @@ class PCRNet(nn.Module):
         out = []
         for e in range(E):
             ye = y[e * B:(e + 1) * B]
-            if FUSED_HEAD and rotate is not None:
+            if rotate is not None:
                 twist, quat, qnorm, rotated = _HeadRotFunction.apply(ye, rotate)
                 out.append((twist, ye[:, 0:4], qnorm, quat, rotated))
-                continue
-            if FUSED_HEAD:
-                twist, quat, qnorm = _HeadFunction.apply(ye)
             else:
-                pre = ye[:, 0:4]
-                quat = torch.nn.functional.normalize(pre, dim=1)
-                qnorm = torch.mean((torch.sum(pre ** 2, dim=1) - 1) ** 2)
-                twist = torch.cat([quat, ye[:, 4:]], dim=1)
-            out.append((twist, ye[:, 0:4], qnorm, quat) + ((qrot_cloud(quat, rotate),) if rotate is not None else ()))
+                twist, quat, qnorm = _HeadFunction.apply(ye)
+                out.append((twist, ye[:, 0:4], qnorm, quat))
         return out
 
     def forward_with_qnorm(self, x0, x1, feat0=None, rotate=None):
@@ -593,27 +586,22 @@ class PCRNet(nn.Module):
         est_transform.rotate(p0)); the rotated cloud is returned as a fifth element."""
         f0, f1 = (self.feat(x0) if feat0 is None else feat0), self.feat(x1)
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
-        if FUSED_TRUNK and f0.is_cuda and f0.shape[1] % 8 == 0:
-            wb = []
-            for fc in fcs:
-                wb += [fc.weight, fc.bias]
-            y = _trunk(f0, f1, wb)  # (B, 7)
-        else:  # (CPU tensors, feature widths that are not a multiple of 8, FUSED_TRUNK switched off: the plain torch layers)
-            y = torch.cat([f0, f1], dim=1)
-            for fc in fcs[:-1]:
-                y = torch.relu(fc(y))
-            y = self.fc6(y)  # (B, 7)
+        wb = []
+        for fc in fcs:
+            wb += [fc.weight, fc.bias]
+        if f0.shape[1] % 8:
+            # the kernels read the first layer's input as two parts that meet at a multiple of 8 columns: a bottleneck width
+            # that is not one is re-cut there (copies of B x 2 C values; the layers themselves stay on sn_skinny_linear)
+            cat = torch.cat([f0, f1], dim=1)
+            k8 = max(8, (cat.shape[1] // 2) // 8 * 8)
+            f0, f1 = cat[:, :k8].contiguous(), cat[:, k8:].contiguous()
+        y = _trunk(f0, f1, wb)  # (B, 7)
         pre_normalized_quat = y[:, 0:4]
-        if FUSED_HEAD and y.is_cuda:
-            if rotate is not None:
-                twist, quat, qnorm, rotated = _HeadRotFunction.apply(y, rotate)
-                return twist, pre_normalized_quat, qnorm, quat, rotated
-            twist, quat, qnorm = _HeadFunction.apply(y)
-            return twist, pre_normalized_quat, qnorm, quat
-        normalized_quat = torch.nn.functional.normalize(pre_normalized_quat, dim=1)
-        qnorm = torch.mean((torch.sum(pre_normalized_quat ** 2, dim=1) - 1) ** 2)
-        out = (torch.cat([normalized_quat, y[:, 4:]], dim=1), pre_normalized_quat, qnorm, normalized_quat)
-        return out + (qrot_cloud(normalized_quat, rotate),) if rotate is not None else out
+        if rotate is not None:
+            twist, quat, qnorm, rotated = _HeadRotFunction.apply(y, rotate)
+            return twist, pre_normalized_quat, qnorm, quat, rotated
+        twist, quat, qnorm = _HeadFunction.apply(y)
+        return twist, pre_normalized_quat, qnorm, quat
 
 
 def pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features=None):

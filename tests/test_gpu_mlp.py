@@ -1638,11 +1638,49 @@ def test_persistent_forward_is_bit_identical(B, N):
         assert torch.equal(ba, bb), n
 
 
+@pytest.mark.parametrize("bneck", [100, 36])
+def test_pcrnet_trunk_with_a_bottleneck_that_is_not_a_multiple_of_eight(bneck):
+    """until round 5 such widths fell back to torch.nn.Linear (rocBLAS).  Now the two clouds' feature vectors are
+    re-cut at a multiple of 8 columns and the trunk stays on sn_skinny_linear: against the torch composition in fp64 -- twist,
+    the gradient to the source cloud -- and the library's trunk function is what ran."""
+    from samplenet_amd import task_features as tf
+
+    torch.manual_seed(bneck)
+    net = tf.PCRNet(bottleneck_size=bneck, input_shape="bnc").cuda().eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    p0 = torch.rand(6, 128, 3, device="cuda") - 0.5
+    q = (torch.rand(6, 64, 3, device="cuda") - 0.5).requires_grad_(True)
+    calls = []
+    orig = tf._TrunkFunction.apply
+    try:
+        tf._TrunkFunction.apply = staticmethod(lambda *a: (calls.append(a[0].shape), orig(*a))[1])
+        twist, pre = net(p0, q)
+    finally:
+        tf._TrunkFunction.apply = orig
+    assert len(calls) == 1 and calls[0][1] % 8 == 0
+    gw = torch.randn(6, 7, device="cuda")
+    (gq,) = torch.autograd.grad((twist * gw).sum(), [q])
+    ref = copy.deepcopy(net).double()
+    q64 = q.detach().double().requires_grad_(True)
+    f0, f1 = net.feat(p0).double(), None
+    # fp64 trunk on the library's fp32 features of the template and an fp64 recomputation through the source cloud's features
+    f1 = net.feat(q)
+    y = torch.cat([f0, f1.double()], dim=1)
+    for fc in (ref.fc1, ref.fc2, ref.fc3, ref.fc4, ref.fc5):
+        y = torch.relu(fc(y))
+    y = ref.fc6(y)
+    tr = torch.cat([torch.nn.functional.normalize(y[:, 0:4], dim=1), y[:, 4:]], dim=1)
+    (gr,) = torch.autograd.grad((tr * gw.double()).sum(), [q])
+    assert float((twist.double() - tr).abs().max()) <= 1e-5
+    assert float((gq.double() - gr.double()).norm()) <= 1e-4 * float(gr.double().norm())
+
+
 @pytest.mark.parametrize("B", [32, 5, 100, 200, 300])
 def test_trainable_pcrnet_trunk_stays_on_the_library(B):
     """registration/models/pcrnet.py:62-82 under main.py --train-pcrnet: with a TRAINABLE FC trunk the six layers still run on
     sn_skinny_linear (forward, data gradient) and their weight / bias gradients on sn_skinny_wgrad -- against the torch.nn.Linear
-    route (rocBLAS) on the same weights: twist 1e-5, every gradient of the trunk and the gradient that reaches both clouds within
+    composition (rocBLAS; spelled out HERE, the product has no such route) on the same weights: twist 1e-5, every gradient of the trunk and the gradient that reaches both clouds within
     1e-4 of its norm; deterministic from run to run.  Above 128 rows the trunk runs in row blocks of 128 (no
     torch.nn.Linear / rocBLAS on the GPU path at any batch)."""
     import copy
@@ -1668,18 +1706,22 @@ def test_trainable_pcrnet_trunk_stays_on_the_library(B):
     p0 = torch.rand(B, 256, 3, device="cuda") - 0.5
     q = torch.rand(B, 64, 3, device="cuda") - 0.5
     gw = torch.randn(B, 7, device="cuda")
+    def torch_route(model, p0, qq):
+        # the reference composition (models/pcrnet.py:62-82) on torch.nn ops behind the library's feature extractor
+        y = torch.cat([model.feat(p0), model.feat(qq)], dim=1)
+        for fc in (model.fc1, model.fc2, model.fc3, model.fc4, model.fc5):
+            y = torch.relu(fc(y))
+        y = model.fc6(y)
+        pre = y[:, 0:4]
+        return torch.cat([torch.nn.functional.normalize(pre, dim=1), y[:, 4:]], dim=1), pre
+
     outs = []
     for model, fused in ((net, True), (ref, False), (net, True)):
-        old = tf.FUSED_TRUNK
-        tf.FUSED_TRUNK = fused
-        try:
-            for p in model.parameters():
-                p.grad = None
-            qq = q.clone().requires_grad_(True)
-            twist, pre = model(p0, qq)
-            ((twist * gw).sum() + (pre * pre).sum()).backward()
-        finally:
-            tf.FUSED_TRUNK = old
+        for p in model.parameters():
+            p.grad = None
+        qq = q.clone().requires_grad_(True)
+        twist, pre = model(p0, qq) if fused else torch_route(model, p0, qq)
+        ((twist * gw).sum() + (pre * pre).sum()).backward()
         outs.append((twist.detach().clone(), qq.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
     (ta, ga, wa), (tb, gb, wb), (tc, gc, wc) = outs
     assert len(wa) == 12 and set(wa) == set(wb)
