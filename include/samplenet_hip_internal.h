@@ -216,6 +216,22 @@ int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc, const floa
                              float *const *running_var, long long *const *num_batches_tracked, const float *eps,
                              const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
                              sn_stream_t stream);
+/* sn_fc_chain_forward_pool with the head's OUTPUT layer behind the hidden layers as the chain's last stage: Linear (Co x H) +
+ * BatchNorm WITHOUT activation -- the classification task's sampler (classification/models/samplenet_model.py:100-108).  Wo (Co, H),
+ * bo (Co), gamma_o / beta_o (Co), running statistics of that BatchNorm (may be NULL), eps_o / momentum_o -> zo (B, Co) pre-BatchNorm
+ * output, coef_o (4, Co), y (B, Co) = zo scale + shift.  Co: a multiple of 32, at most H.  One launch instead of this one +
+ * sn_layer_forward_bn_out. */
+int sn_fc_chain_forward_pool_out_supported(int B, int N, int C0, int H, int nl, int Co);
+int sn_fc_chain_forward_pool_out(int B, int N, int nconv, long long *acc, const float *pool_val, const int *pool_idx,
+                                 const float *gamma5, const float *beta5, float *running_mean5, float *running_var5,
+                                 long long *num_batches_tracked5, float eps5, float momentum5, float *coef5, float *pooled,
+                                 int *argsel, float *zsel, int H, int nl, const float *const *W, const float *const *bias,
+                                 const float *const *gamma, const float *const *beta, float *const *running_mean,
+                                 float *const *running_var, long long *const *num_batches_tracked, const float *eps,
+                                 const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync, int Co,
+                                 const float *Wo, const float *bo, const float *gamma_o, const float *beta_o, float *running_mean_o,
+                                 float *running_var_o, long long *num_batches_tracked_o, float eps_o, float momentum_o, float *zo,
+                                 float *coef_o, float *y, sn_stream_t stream);
 /* The FC head's backward (R <= 32 rows) as ONE launch, the mirror of sn_fc_chain_forward.  Stage s = GEMM layer, TOP first:
  * W[s] (Co[s], Ci[s]); below it: zprev[s] (R, Ci[s]) pre-BN output seen through coefprev[s] (4, Ci[s]) (the pooled-feature
  * stage: zsel with the last conv layer's coefficients and bn_rows[s] = B * N; bn_rows < 0: fixed statistics); outputs per
@@ -232,6 +248,15 @@ int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci, const floa
                          float *const *dgamma, float *const *dbeta, float *const *dbias, float *const *dW, float *db_top,
                          const float *const *aprev, const int *araw, float *gout, float *kout, float *xbuf,
                          unsigned *sync, sn_stream_t stream);
+/* sn_fc_chain_backward for a head whose output went through a BatchNorm WITHOUT activation (the classification sampler's output
+ * layer: sn_layer_forward_bn_out / sn_fc_chain_forward_pool_out): gy is the gradient behind that BatchNorm, zo (R, Co[0]) its
+ * input, coef_o (4, Co[0]) the forward's coefficients; the launch opens with that BatchNorm's backward (the arithmetic of
+ * sn_bn_output_backward, rows summed in order) and leaves dgamma_o / dbeta_o (Co[0]).  fixed != 0: running statistics. */
+int sn_fc_chain_backward_obn(int R, int ns, const int *Co, const int *Ci, const float *gy, const float *zo, const float *coef_o, int fixed,
+                             float *dgamma_o, float *dbeta_o, const float *const *W, const float *const *zprev,
+                             const float *const *coefprev, const long long *bn_rows, float *const *dgamma, float *const *dbeta,
+                             float *const *dbias, float *const *dW, float *db_top, const float *const *aprev, const int *araw, float *gout,
+                             float *kout, float *xbuf, unsigned *sync, sn_stream_t stream);
 /* sn_bn_finalize for a SHORT matrix z (R, C) (the FC head at batches above 32): statistics in two passes over z itself (mean,
  * then squares around it) instead of from sum / sum-of-squares partials -- behind the max-pool |mean| / std reaches 10..100. */
 int sn_bn_batch_stats_twopass(int R, int C, const float *z, const float *gamma, const float *beta, float eps, float momentum,

@@ -98,9 +98,13 @@ PROTOTYPES = {
     "sn_fc_chain_forward_supported": [_i, _i, _i, _i],
     "sn_fc_chain_forward_pool_supported": [_i, _i, _i, _i, _i],
     "sn_fc_chain_forward_pool": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i] + [_vp] * 14,
+    "sn_fc_chain_forward_pool_out_supported": [_i, _i, _i, _i, _i, _i],
+    "sn_fc_chain_forward_pool_out": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _i, _i] + [_vp] * 13 +
+                                    [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp],
     "sn_fc_chain_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_fc_chain_backward_supported": [_i, _i, _vp, _vp],
     "sn_fc_chain_backward": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_fc_chain_backward_obn": [_i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp] + [_vp] * 16,
     "sn_linear_forward_maxpool_supported": [_i, _i, _i, _i],
     "sn_linear_forward_maxpool": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "sn_linear_forward_maxpool_wide_supported": [_i, _i, _i, _i],

@@ -40,10 +40,24 @@ struct FcChainPool {
     float *pooled, *zsel;  // (R, C0)
     int *argsel;
 };
+// OUT variant: the head's OUTPUT layer behind the hidden layers -- Linear (Co x H) + BatchNorm WITHOUT activation, the classification
+// task's sampler (classification/models/samplenet_model.py:100-108) -- as one more stage of the chain: the last hidden layer hands its
+// activations over like the others, workgroups 0 .. Co / 32 - 1 then multiply their 32-column slice (weights fetched up front with
+// everything else, parked in registers, staged into the LDS slot of a hidden layer that is done) and finish the BatchNorm of their
+// columns (all R rows are local): z (R, Co) pre-BN, coef (4, Co), y (R, Co) = z scale + shift, running statistics.
+struct FcChainOut {
+    const float *W, *bias, *gamma, *beta;
+    float *running_mean, *running_var;
+    long long *num_batches_tracked;
+    float *z, *coef, *y;
+    float eps, momentum;
+    int Co;
+};
 struct FcChainArgs {
     const float *a0;  // (R, C0): input of the first layer, used as is (pooled features)
     int R, C0, H, nl;
     FcChainPool P;
+    FcChainOut O;
     FcChainLayer L[kFcChainMaxLayers];
     float *xbuf;     // [2][32][H] exchange slabs
     unsigned *sync;  // [0] epoch, [1 + s] arrivals at seam s, [15] error flag -- persistent, zero-initialised once
@@ -113,9 +127,10 @@ __device__ __forceinline__ bool fc_chain_seam(unsigned *sync, int ctr, unsigned 
     return false;
 }
 
-template <int C0T, int NLT, bool POOL = false>
+template <int C0T, int NLT, bool POOL = false, bool OUT = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) fc_chain_fwd_kernel(FcChainArgs g)
 {
+    static_assert(!OUT || (POOL && NLT >= 2), "output stage: the pooled 128 -> 256 x 3 head");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ unsigned s_epoch, s_limit, s_bad;
     if (blockIdx.x & 7) return;
@@ -139,6 +154,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 
     // ---- every layer's weight slice + the first operand: all fetches issued up front, staged into LDS as they land
+    f32x4v wo[OUT ? 8 : 1];  // (OUT: the output layer's 32 x H slice, 4 rows per pass as the hidden slices)
     if constexpr (POOL) {
         // ---- stage -1: BatchNorm of the last conv layer from its fixed-point sums + the max-pool pick.  The producing layer
         // left, per cloud and channel, (max Z, first row) and (min Z, first row) as 64-bit keys (FwdArgs::pool_keys); EVERY
@@ -171,6 +187,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int l = 1; l < NLT; ++l)
 #pragma unroll
             for (int q = 0; q < 8; ++q) wh[l - 1][q] = *reinterpret_cast<const f32x4v *>(g.L[l].W + (size_t)(col0 + hr0 + q * 4) * H + hc4);
+        if constexpr (OUT) {  // the output layer's slice (rows clamped: workgroups past its width fetch a valid row they never use)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wo[q] = *reinterpret_cast<const f32x4v *>(g.O.W + (size_t)min(col0 + hr0 + q * 4, g.O.Co - 1) * H + hc4);
+        }
         // every fetch of the kernel is in flight now; nothing below may be hoisted between them
         asm volatile("" ::: "memory");
         double s, ss;
@@ -353,10 +373,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             float4 zv = *reinterpret_cast<const float4 *>(Ts + trow * 36 + tc4);
             // a seam of this launch timed out: what the layers above computed is built on incomplete activations -- the head's
             // output must not look like a result (NaN flows through fc4 / the pair scan into the loss and every gradient)
-            if (l == nl - 1 && s_bad) zv.x = zv.y = zv.z = zv.w = __builtin_nanf("");
+            if (!OUT && l == nl - 1 && s_bad) zv.x = zv.y = zv.z = zv.w = __builtin_nanf("");
             *reinterpret_cast<float4 *>(Lr.z + (size_t)trow * H + col0 + tc4) = zv;
         }
-        if (l == nl - 1) break;
+        if (!OUT && l == nl - 1) break;
         float *xb = g.xbuf + (size_t)(l & 1) * 32 * H;
         {
             const float4 v = *reinterpret_cast<const float4 *>(Ta + trow * 36 + tc4);
@@ -396,8 +416,83 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     *reinterpret_cast<float4 *>(As + (idx / hq4) * LDA + (idx % hq4) * 4) = make_float4(r[i].x, r[i].y, r[i].z, r[i].w);
             }
         }
+        if constexpr (OUT) {
+            if (l == 1) {  // layer 1's MFMAs are long done (several barriers ago): its slice's slot takes the output layer's
+                const int hc4 = (tid % 64) * 4, hr0 = tid / 64;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4v *>(Whs + (hr0 + q * 4) * (H + 4) + hc4) = wo[q];
+            }
+        }
         lds_barrier();
         FC_TL(0, wg, 7 + 6 * l);
+    }
+    if constexpr (OUT) {
+        // ---- the output layer: y = bn(As W_out^T + b), no activation.  As holds the last hidden layer's activations (gathered above)
+        const FcChainOut &O = g.O;
+        const int Co = O.Co;
+        if (col0 < Co) {
+            const int er0 = 4 * (lane & 7), ecl = wave * 8 + (lane >> 3), ecol = col0 + ecl;
+            const float ebias = O.bias[ecol], eg = O.gamma[ecol], eb = O.beta[ecol];
+            float bn_rm = 0.f, bn_rv = 0.f;
+            if (O.running_mean) bn_rm = O.running_mean[ecol], bn_rv = O.running_var[ecol];
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const int kph = H / 8, kb = wave * (H / 4) + h * kph;
+            const float *ap = As + l31 * LDA + kb, *bp = Whs + l31 * (H + 4) + kb;
+            for (int t = 0; t < kph; t += 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(ap + t), b = *reinterpret_cast<const float4 *>(bp + t);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+            const float4 zs4 = wave_reduce_scatter4(acc, red);
+            {
+                const float zv[4] = {zs4.x + ebias, zs4.y + ebias, zs4.z + ebias, zs4.w + ebias};
+                float t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = er0 + i < R ? zv[i] : 0.f;
+                const float s0 = col_sum_seq(t, lane & 7);
+                const float meanf = s0 / (float)R;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = zv[i] - meanf;
+                    t[i] = er0 + i < R ? d * d : 0.f;
+                }
+                const float s2 = col_sum_seq(t, lane & 7);
+                const double mean = (double)s0 * g.rinv_rows;
+                const double dm = mean - (double)meanf;
+                double var = (double)s2 * g.rinv_rows - dm * dm;
+                if (var < 0.0) var = 0.0;
+                const float invstd = (float)fast_rsqrt(var + (double)O.eps);
+                const float sc = eg * invstd, sh = eb - (float)mean * sc;
+                if ((lane & 7) == 0) {
+                    O.coef[ecol] = sc, O.coef[Co + ecol] = sh, O.coef[2 * Co + ecol] = (float)mean, O.coef[3 * Co + ecol] = invstd;
+                    if (O.running_mean) {
+                        const double unbiased = var * g.unbias;
+                        O.running_mean[ecol] = (1.f - O.momentum) * bn_rm + O.momentum * (float)mean;
+                        O.running_var[ecol] = (1.f - O.momentum) * bn_rv + O.momentum * (float)unbiased;
+                    }
+                    if (wg == 0 && tid == 0 && O.num_batches_tracked) *O.num_batches_tracked += 1;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = er0 + i;
+                    Ts[row * 36 + ecl] = zv[i];
+                    Ta[row * 36 + ecl] = fmaf(zv[i], sc, sh);
+                }
+            }
+            lds_barrier();
+            const int trow = tid >> 3, tc4 = (tid & 7) * 4;
+            if (trow < R) {
+                float4 zv = *reinterpret_cast<const float4 *>(Ts + trow * 36 + tc4), yv = *reinterpret_cast<const float4 *>(Ta + trow * 36 + tc4);
+                // a seam of this launch timed out: the head's output must not look like a result (see the hidden layers' note)
+                if (s_bad) yv.x = yv.y = yv.z = yv.w = zv.x = zv.y = zv.z = zv.w = __builtin_nanf("");
+                *reinterpret_cast<float4 *>(O.z + (size_t)trow * Co + col0 + tc4) = zv;
+                *reinterpret_cast<float4 *>(O.y + (size_t)trow * Co + col0 + tc4) = yv;
+            }
+        }
     }
     SN_TL_DRAIN();
     FC_TL(0, wg, 31);
@@ -436,6 +531,13 @@ struct FcBwdStage {
 };
 struct FcBwdArgs {
     const float *gy;  // (R, Co of stage 0): gradient w.r.t. the head's output
+    // Optional: the head's output went through a BatchNorm WITHOUT activation (classification sampler, FcChainOut): gy is the
+    // gradient behind it, and stage 0 opens with that BatchNorm's backward -- oz (R, Co) its input, ocoef (4, Co) the forward's
+    // coefficients -> dZ = k1 gy + k2 z + k3 per column (sums over the R rows: local to every workgroup that holds the columns),
+    // odgamma / odbeta (Co) written by chain workgroup 0.  ofixed: the forward ran on running statistics (dZ = scale gy).
+    const float *oz, *ocoef;
+    float *odgamma, *odbeta;
+    int ofixed;
     int R, ns;
     FcBwdStage S[kFcBwdMaxStages];
     float *xbuf;     // [ns][32][256] hand-off slabs, one per stage
@@ -450,6 +552,30 @@ __device__ __forceinline__ bool fc_wait_arrivals(unsigned *ctr, unsigned target,
         __builtin_amdgcn_s_sleep(1);
     }
     return true;
+}
+
+// Backward of the output BatchNorm on `ncols` columns held in LDS: G [32][ldg] the upstream gradient (rewritten in place with
+// dZ), Z [32][ldz] the BatchNorm's input; thread t < ncols owns column t (global column c0 + t).  Sums in double, rows in order.
+__device__ __forceinline__ void fc_out_bn_backward(const FcBwdArgs &g, float *G, int ldg, const float *Z, int ldz, int ncols, int c0, int Co,
+                                                   bool write_params)
+{
+    const int t = threadIdx.x;
+    if (t < ncols) {
+        const int c = c0 + t;
+        const float scale = g.ocoef[c], mean = g.ocoef[2 * Co + c], invstd = g.ocoef[3 * Co + c];
+        double s0 = 0.0, s1 = 0.0;
+        for (int r = 0; r < g.R; ++r) {
+            const float gv = G[r * ldg + t], zv = Z[r * ldz + t];
+            s0 += (double)gv;
+            s1 += (double)gv * (double)(zv - mean);
+        }
+        const double dg = (double)invstd * s1, rinv = 1.0 / (double)g.R, sc = scale;
+        const float k1 = scale;
+        const float k2 = g.ofixed ? 0.f : (float)(-sc * (double)invstd * dg * rinv);
+        const float k3 = g.ofixed ? 0.f : (float)(sc * ((double)invstd * (double)mean * dg * rinv - s0 * rinv));
+        if (write_params) g.odgamma[c] = (float)dg, g.odbeta[c] = (float)s0;
+        for (int r = 0; r < g.R; ++r) G[r * ldg + t] = fmaf(k1, G[r * ldg + t], fmaf(k2, Z[r * ldz + t], k3));
+    }
 }
 
 __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
@@ -510,6 +636,13 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (trow < R) v = *reinterpret_cast<const float4 *>(g.gy + (size_t)trow * Co + col0 + tc4);
                 *reinterpret_cast<float4 *>(Tz + trow * 36 + tc4) = v;
+                if (g.oz) {  // the output BatchNorm's backward on this workgroup's 32 columns (its input tile parked in Tw)
+                    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (trow < R) zv = *reinterpret_cast<const float4 *>(g.oz + (size_t)trow * Co + col0 + tc4);
+                    *reinterpret_cast<float4 *>(Tw + trow * 36 + tc4) = zv;
+                    lds_barrier();
+                    fc_out_bn_backward(g, Tz, 36, Tw, 36, 32, col0, Co, false);
+                }
             } else {
                 if (tid == 0 && !fc_wait_arrivals(g.sync + s * kFcSyncStride, target, limit)) {  // sync[1 + (s - 1)]
                     __hip_atomic_store(g.sync + 15 * kFcSyncStride, 16u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -605,6 +738,23 @@ __global__ void __launch_bounds__(256) fc_chain_bwd_kernel(FcBwdArgs g)
                     Wt0[(c4 + 0) * LD + co] = wv[i].x, Wt0[(c4 + 1) * LD + co] = wv[i].y, Wt0[(c4 + 2) * LD + co] = wv[i].z, Wt0[(c4 + 3) * LD + co] = wv[i].w;
                 }
             }
+        if (g.oz) {
+            // the head's output went through a BatchNorm: gy -> dZ of the output layer, all Co columns, before the first product.
+            // Its input z parks in the weight buffer of stage 1 (free until the first hand-off).
+            float *Zo = Wt0 + 32 * LD;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < ng) {
+                    const int r = idx / q4;
+                    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r < R) zv = *reinterpret_cast<const float4 *>(g.oz + (size_t)r * S.Co + (idx % q4) * 4);
+                    *reinterpret_cast<float4 *>(Zo + r * LD + (idx % q4) * 4) = zv;
+                }
+            }
+            lds_barrier();
+            fc_out_bn_backward(g, dZs, LD, Zo, LD, S.Co, 0, S.Co, wgi == 0);
+        }
     }
     lds_barrier();
     FC_TL(1, wgi, 1);
@@ -853,6 +1003,62 @@ extern "C" int sn_fc_chain_forward_pool(int B, int N, int nconv, long long *acc,
     return 0;
 }
 
+// sn_fc_chain_forward_pool with the head's OUTPUT layer -- Linear (Co x H) + BatchNorm without activation (classification/models/
+// samplenet_model.py:100-108) -- as the chain's last stage: Wo (Co, H), bo, gamma_o / beta_o (Co), running statistics (may be NULL),
+// -> zo (B, Co) pre-BatchNorm, coef_o (4, Co), y (B, Co).  Co a multiple of 32, at most H.
+extern "C" int sn_fc_chain_forward_pool_out_supported(int B, int N, int C0, int H, int nl, int Co)
+{
+    return sn_fc_chain_forward_pool_supported(B, N, C0, H, nl) && Co >= 32 && Co <= H && Co % 32 == 0;
+}
+
+extern "C" int sn_fc_chain_forward_pool_out(int B, int N, int nconv, long long *acc, const float *pool_val, const int *pool_idx,
+                                            const float *gamma5, const float *beta5, float *running_mean5, float *running_var5,
+                                            long long *num_batches_tracked5, float eps5, float momentum5, float *coef5, float *pooled,
+                                            int *argsel, float *zsel, int H, int nl, const float *const *W, const float *const *bias,
+                                            const float *const *gamma, const float *const *beta, float *const *running_mean,
+                                            float *const *running_var, long long *const *num_batches_tracked, const float *eps,
+                                            const float *momentum, float *const *z, float *const *coef, float *xbuf, unsigned *sync,
+                                            int Co, const float *Wo, const float *bo, const float *gamma_o, const float *beta_o,
+                                            float *running_mean_o, float *running_var_o, long long *num_batches_tracked_o, float eps_o,
+                                            float momentum_o, float *zo, float *coef_o, float *y, sn_stream_t stream)
+{
+    constexpr int C0 = 128;
+    SN_REQUIRE(sn_fc_chain_forward_pool_out_supported(B, N, C0, H, nl, Co) && nconv >= 2, "shape not supported (sn_fc_chain_forward_pool_out_supported)");
+    SN_REQUIRE(acc && pool_val && pool_idx && gamma5 && beta5 && running_mean5 && running_var5 && coef5 && pooled && argsel && zsel,
+               "null pointer");
+    SN_REQUIRE(W && bias && gamma && beta && eps && momentum && z && coef && xbuf && sync, "null pointer");
+    SN_REQUIRE(Wo && bo && gamma_o && beta_o && zo && coef_o && y, "null output-layer pointer");
+    FcChainArgs g{};
+    g.a0 = pooled, g.R = B, g.C0 = C0, g.H = H, g.nl = nl, g.xbuf = xbuf, g.sync = sync;
+    g.P.acc = acc + (size_t)(nconv - 1) * kFxLayer, g.P.zero_ptr = acc + (size_t)(nconv - 2) * kFxLayer, g.P.zero_n = kFxLayer;
+    g.P.keys = reinterpret_cast<const unsigned long long *>(pool_val);
+    (void)pool_idx;
+    g.P.bn = BnFwd{gamma5, beta5, running_mean5, running_var5, num_batches_tracked5, coef5, eps5, momentum5, (long long)B * N};
+    g.P.pooled = pooled, g.P.argsel = argsel, g.P.zsel = zsel;
+    for (int l = 0; l < nl; ++l) {
+        SN_REQUIRE(W[l] && bias[l] && gamma[l] && beta[l] && z[l] && coef[l], "null layer pointer");
+        g.L[l] = FcChainLayer{W[l], bias[l], gamma[l], beta[l], running_mean ? running_mean[l] : nullptr,
+                              running_var ? running_var[l] : nullptr, num_batches_tracked ? num_batches_tracked[l] : nullptr,
+                              z[l], coef[l], eps[l], momentum[l]};
+    }
+    g.O = FcChainOut{Wo, bo, gamma_o, beta_o, running_mean_o, running_var_o, num_batches_tracked_o, zo, coef_o, y, eps_o, momentum_o, Co};
+    const size_t lds = fc_chain_fwd_lds(C0, H, nl);
+    static SnLdsAttrGrow attr;
+    if (sn_lds_attr_grow(attr, (const void *)fc_chain_fwd_kernel<128, 3, true, true>, lds, "sn_fc_chain_forward_pool_out")) return SN_ERR_UNSUPPORTED;
+    g.rinv_rows = 1.0 / (double)B, g.unbias = B > 1 ? (double)B / (double)(B - 1) : 1.0;
+    hipLaunchKernelGGL((fc_chain_fwd_kernel<128, 3, true, true>), dim3(8 * (H / 32)), dim3(256), lds, (hipStream_t)stream, g);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// (sn_fc_chain_backward_obn hands the output BatchNorm's operands to the launch below: thread-local, consumed by the next call)
+struct FcBwdOutBn {
+    const float *z, *coef;
+    float *dgamma, *dbeta;
+    int fixed;
+};
+static thread_local FcBwdOutBn g_obn{};
+
 // 1: sn_fc_chain_backward runs this FC head's backward (ns GEMM layers, top first: Co[s] x Ci[s]) as one launch
 extern "C" int sn_fc_chain_backward_supported(int R, int ns, const int *Co, const int *Ci)
 {
@@ -884,6 +1090,8 @@ extern "C" int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci,
         S.aprev = aprev[s], S.araw = araw[s];
         S.gout = s == ns - 1 ? gout : nullptr, S.kout = s == ns - 1 ? kout : nullptr;
     }
+    if (g_obn.z) g.oz = g_obn.z, g.ocoef = g_obn.coef, g.odgamma = g_obn.dgamma, g.odbeta = g_obn.dbeta, g.ofixed = g_obn.fixed;
+    g_obn = FcBwdOutBn{};
     const size_t lds = ((size_t)3 * 32 * 260 + kRsFloats + 32 * 36) * sizeof(float);
     static SnLdsAttr attr;
     if (sn_lds_attr(attr, (const void *)fc_chain_bwd_kernel, lds, "sn_fc_chain_backward")) return SN_ERR_UNSUPPORTED;
@@ -891,4 +1099,22 @@ extern "C" int sn_fc_chain_backward(int R, int ns, const int *Co, const int *Ci,
     hipLaunchKernelGGL(fc_chain_bwd_kernel, dim3(128), dim3(256), lds, (hipStream_t)stream, g);
     SN_LAUNCH_CHECK();
     return 0;
+}
+
+// sn_fc_chain_backward for a head whose output went through a BatchNorm WITHOUT activation (classification sampler: sn_layer_forward_bn_out
+// / sn_fc_chain_forward_pool_out): gy is the gradient behind that BatchNorm, zo (R, Co[0]) its input and coef_o (4, Co[0]) the forward's
+// coefficients; the launch opens with its backward (as sn_bn_output_backward) and leaves dgamma_o / dbeta_o (Co[0]).  fixed != 0: the
+// forward ran on running statistics.
+extern "C" int sn_fc_chain_backward_obn(int R, int ns, const int *Co, const int *Ci, const float *gy, const float *zo, const float *coef_o,
+                                        int fixed, float *dgamma_o, float *dbeta_o, const float *const *W, const float *const *zprev,
+                                        const float *const *coefprev, const long long *bn_rows, float *const *dgamma, float *const *dbeta,
+                                        float *const *dbias, float *const *dW, float *db_top, const float *const *aprev, const int *araw,
+                                        float *gout, float *kout, float *xbuf, unsigned *sync, sn_stream_t stream)
+{
+    SN_REQUIRE(zo && coef_o && dgamma_o && dbeta_o, "null output-BatchNorm pointer");
+    g_obn = FcBwdOutBn{zo, coef_o, dgamma_o, dbeta_o, fixed ? 1 : 0};
+    const int rc = sn_fc_chain_backward(R, ns, Co, Ci, gy, W, zprev, coefprev, bn_rows, dgamma, dbeta, dbias, dW, db_top, aprev, araw, gout,
+                                        kout, xbuf, sync, stream);
+    g_obn = FcBwdOutBn{};
+    return rc;
 }

@@ -270,10 +270,13 @@ def _fc_chain_shape(hidden, B):
     return C0, H, n
 
 
-def _fc_chain_fwd(net, hidden, pooled, B, saved, rec=None):
+def _fc_chain_fwd(net, hidden, pooled, B, saved, rec=None, out=None):
     """The FC head's BatchNorm + ReLU layers as one launch (sn_fc_chain_forward; with saved["pool_tail"] from a deferred
     conv stack: sn_fc_chain_forward_pool, which also finishes the last conv BatchNorm and the max-pool).  Fills saved["zf"] /
-    saved["cf"]; returns False when the shape is not supported (the per-layer launches run instead)."""
+    saved["cf"]; returns False when the shape is not supported (the per-layer launches run instead).
+    out = (last FC layer, out_bn record): the classification sampler's output layer + BatchNorm as the chain's last stage
+    (sn_fc_chain_forward_pool_out) where the shape allows -- saved["y_out"] then holds the head's output and saved["z_out"] /
+    saved["c_out"] what backward_impl needs; otherwise the caller runs _last_layer."""
     import ctypes
 
     shape = _fc_chain_shape(hidden, B)
@@ -306,13 +309,25 @@ def _fc_chain_fwd(net, hidden, pooled, B, saved, rec=None):
                 ptr(bn5.running_mean), ptr(bn5.running_var), ptr(bn5.num_batches_tracked),
                 float(bn5.eps), float(bn5.momentum), ptr(saved["cc"][-1]), ptr(pooled), ptr(argsel),
                 ptr(zsel), H, n, *layer_args]
+        fn, name, keep = lib.sn_fc_chain_forward_pool, "sn_fc_chain_forward_pool", ()
+        if out is not None:
+            Lo, (_, obn) = out
+            if (Lo.Ci == H and obn.momentum is not None and lib.sn_fc_chain_forward_pool_out_supported(B, N, C0, H, n, Lo.Co)):
+                upd = obn.track_running_stats
+                zo, co, yo = _empty((B, Lo.Co), pooled), _empty((4, Lo.Co), pooled), _empty((B, Lo.Co), pooled)
+                args = args[:-1] + [Lo.Co, ptr(Lo.W), ptr(Lo.b), ptr(obn.weight), ptr(obn.bias),
+                                    ptr(obn.running_mean) if upd else None, ptr(obn.running_var) if upd else None,
+                                    ptr(obn.num_batches_tracked) if upd else None, float(obn.eps), float(obn.momentum),
+                                    ptr(zo), ptr(co), ptr(yo), args[-1]]
+                fn, name, keep = lib.sn_fc_chain_forward_pool_out, "sn_fc_chain_forward_pool_out", (zo, co, yo)
+                saved["z_out"], saved["c_out"], saved["out_fixed"], saved["y_out"] = zo, co, False, yo
         try:
-            check(lib.sn_fc_chain_forward_pool(*args), "sn_fc_chain_forward_pool")
+            check(fn(*args), name)
         except Exception:
             acc.zero_()
             raise
         if rec is not None:
-            rec.append((lib.sn_fc_chain_forward_pool, "sn_fc_chain_forward_pool", args, None, acc, ()))
+            rec.append((fn, name, args, None, acc, keep))
     else:
         check(lib.sn_fc_chain_forward(B, C0, H, n, ptr(pooled), *layer_args), "sn_fc_chain_forward")
     saved["zf"], saved["cf"] = zs, cs
@@ -409,7 +424,8 @@ def forward_impl(net, x_bnc, training, skip_last=False, use_plan=True):
     saved.update(pooled=pooled, argsel=argsel, zsel=zsel)
     a_in, coef_prev = pooled, None
     hidden = fcs[:-1]
-    if training and FC_CHAIN and _fc_chain_fwd(net, hidden, pooled, B, saved, rec):
+    ob = out_bn(net)
+    if training and FC_CHAIN and _fc_chain_fwd(net, hidden, pooled, B, saved, rec, (fcs[-1], ob) if ob is not None else None):
         a_in, coef_prev = saved["zf"][-1], saved["cf"][-1]
         hidden = []
     for L in hidden:
@@ -435,9 +451,8 @@ def forward_impl(net, x_bnc, training, skip_last=False, use_plan=True):
         saved["zf"].append(z)
         saved["cf"].append(coef)
         a_in, coef_prev = z, coef
-    y = None
-    ob = out_bn(net)
-    if ob is not None or not skip_last:  # (an output BatchNorm needs every cloud's row: the caller cannot produce y itself)
+    y = saved.get("y_out")  # (the chain's output stage produced the head's output already)
+    if y is None and (ob is not None or not skip_last):  # (an output BatchNorm needs every cloud's row: the caller cannot produce y itself)
         y = _last_layer(B, fcs[-1], ob, a_in, coef_prev, training, saved)
     if rec is not None and len(rec) == 2 and not convs and not hidden:
         # the whole head ran as the two fused calls (+ the last layer): from now on steps of this shape replay them
@@ -563,7 +578,8 @@ class _ForwardPlan:
         plan.saved = dict(saved)
         plan.saved.pop("_lease", None)
         plan.saved["_bwd_cache"] = saved["_bwd_cache"] = {}  # static pieces of the backward's argument lists (_conv_stack_bwd_fx)
-        plan.last = None if (skip_last and last_layer[1] is None) else last_layer  # (fcs[-1], out_bn record)
+        # (fcs[-1], out_bn record); None: the caller computes the output layer itself, or the chain's output stage did
+        plan.last = None if ((skip_last and last_layer[1] is None) or "y_out" in saved) else last_layer
         plan.busy = False
         saved["_lease"] = _Lease(plan)  # the recording step itself runs on these buffers
         plans.append(plan)
@@ -586,6 +602,11 @@ class _ForwardPlan:
         y = None
         if self.last is not None:
             y = _last_layer(saved["B"], self.last[0], self.last[1], saved["zf"][-1], saved["cf"][-1], True, saved)
+        elif "y_out" in saved:
+            # the chain's output stage wrote the plan's own buffer: an eager caller receives a copy (the head's output is handed
+            # to the script as the simplified cloud, which it may keep across steps); a capture takes the buffer itself (its
+            # graph's outputs are static tensors anyway: one launch less per replay)
+            y = saved["y_out"] if torch.cuda.is_current_stream_capturing() else saved["y_out"].clone()
         return y, saved
 
 
@@ -801,7 +822,7 @@ def _conv_stack_bwd_fx(net, convs, saved, gsel, kcoef_top, sink, grads, names_c,
     return True
 
 
-def _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed):
+def _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed, obn=None):
     """The FC head's backward as one launch (sn_fc_chain_backward).  Fills `grads` for every FC parameter and for the last
     conv layer's BatchNorm / bias; returns (gsel, kcoef_top) for the conv stack's backward, or False when the shape is not
     supported (the per-layer launches run instead)."""
@@ -865,9 +886,14 @@ def _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed):
     if ins is None:  # (pointer arrays of the operands: static with the plan's buffers)
         ins = (arr(W), arr(zprev), arr(coefprev), (ctypes.c_longlong * nf)(*rows), arr(aprev), (ctypes.c_int * nf)(*araw))
         st["ins"] = ins
-    check(lib.sn_fc_chain_backward(B, nf, Co, Ci, ptr(grad_y), ins[0], ins[1], ins[2], ins[3],
-                                   arr(dg), arr(dbt), arr(dbs), arr(dW), ptr(db_top), ins[4], ins[5],
-                                   ptr(gsel), ptr(kcoef), ptr(xbuf), ptr(sync), _st(like)), "sn_fc_chain_backward")
+    if obn is not None:  # the output BatchNorm's backward opens the launch (obn: z, coef, fixed, dgamma, dbeta)
+        check(lib.sn_fc_chain_backward_obn(B, nf, Co, Ci, ptr(grad_y), ptr(obn[0]), ptr(obn[1]), int(obn[2]), ptr(obn[3]), ptr(obn[4]),
+                                           ins[0], ins[1], ins[2], ins[3], arr(dg), arr(dbt), arr(dbs), arr(dW), ptr(db_top), ins[4],
+                                           ins[5], ptr(gsel), ptr(kcoef), ptr(xbuf), ptr(sync), _st(like)), "sn_fc_chain_backward_obn")
+    else:
+        check(lib.sn_fc_chain_backward(B, nf, Co, Ci, ptr(grad_y), ins[0], ins[1], ins[2], ins[3],
+                                       arr(dg), arr(dbt), arr(dbs), arr(dW), ptr(db_top), ins[4], ins[5],
+                                       ptr(gsel), ptr(kcoef), ptr(xbuf), ptr(sync), _st(like)), "sn_fc_chain_backward")
     saved["fc_chain_b"] = (xbuf, keep)  # (scratch of the asynchronous launch)
     return gsel, kcoef
 
@@ -897,20 +923,24 @@ def backward_impl(net, saved, grad_y, sink=None, after_fc=None, step_tail=None):
     fixed = not saved.get("training", True)
     bn_rows = -1 if fixed else 0
 
+    obn_args = None
     if "z_out" in saved:
-        # the BatchNorm (no activation) behind the last FC layer: dZ of that layer, the BatchNorm's own gradients
+        # the BatchNorm (no activation) behind the last FC layer: dZ of that layer, the BatchNorm's own gradients -- as the
+        # opening of the FC chain's backward launch where that one runs, else a launch of its own
         obn, ob = out_bn(net)
         zo = saved["z_out"]
-        dz = _empty(tuple(zo.shape), zo)
         dgo, dbo = _out(sink, obn + ".weight", ob.weight), _out(sink, obn + ".bias", ob.bias)
-        check(lib.sn_bn_output_backward(B, zo.shape[1], 1 if saved["out_fixed"] else 0, ptr(grad_y), ptr(zo), ptr(saved["c_out"]),
-                                        ptr(dz), ptr(dgo), ptr(dbo), _st(zo)), "sn_bn_output_backward")
         grads[obn + ".weight"], grads[obn + ".bias"] = dgo, dbo
-        grad_y = dz
+        obn_args = (zo, saved["c_out"], saved["out_fixed"], dgo, dbo)
 
     # ---- FC head (rows = B): fc4 -> fc3 -> fc2 -> fc1 -> pooled features ----
+    chain = FC_CHAIN and B <= 32 and _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed, obn_args)
+    if obn_args is not None and not chain:
+        dz = _empty(tuple(zo.shape), zo)
+        check(lib.sn_bn_output_backward(B, zo.shape[1], 1 if saved["out_fixed"] else 0, ptr(grad_y), ptr(zo), ptr(saved["c_out"]),
+                                        ptr(dz), ptr(dgo), ptr(dbo), _st(zo)), "sn_bn_output_backward")
+        grad_y = dz
     dy, kcoef = grad_y, None
-    chain = FC_CHAIN and B <= 32 and _fc_chain_bwd(net, convs, fcs, saved, grad_y, sink, grads, fixed)
     if chain:
         dy, kcoef = chain
     for j in (range(nf - 1, -1, -1) if not chain else ()):

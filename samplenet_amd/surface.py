@@ -274,6 +274,7 @@ class _Plan:
             self.grad_pairs = list(zip(self.params, self.view_list))
             if T.requires_grad:
                 self.grad_pairs.append((T, self.t_view))
+            self._grad_params = [p for p, _ in self.grad_pairs]
             if self.reducer is None:
                 for _, v in self.grad_pairs:  # (which plan a .grad tensor belongs to: commit_begin's mode 3)
                     _register_view(v, self)
@@ -422,11 +423,14 @@ class _Plan:
         """-> (mode, old): 0 every .grad is None (the views become the gradients), 1 every .grad IS its view (accumulate into
         the bucket), 3 every .grad is the view of ONE other plan of this module (a second sampled cloud under the same loss: that
         plan's bucket takes the sum in one launch), 2 anything else (per parameter)."""
+        n = len(self.grad_pairs)
+        grads = [p.grad for p in self._grad_params]  # (one pass of attribute reads; the usual step -- every .grad dropped by
+        if grads.count(None) == n:                    #  zero_grad() -- is decided without looking at the views at all)
+            return 0, None
         nnone = nours = 0
         other = None
         nother = 0
-        for p, v in self.grad_pairs:
-            g = p.grad
+        for g, (p, v) in zip(grads, self.grad_pairs):
             if g is None:
                 nnone += 1
             elif g is v:
@@ -436,9 +440,6 @@ class _Plan:
                 op = o[1]() if o is not None and o[0]() is g else None
                 if op is not None and (other is None or op is other):
                     other, nother = op, nother + 1
-        n = len(self.grad_pairs)
-        if nnone == n:
-            return 0, None
         if nother == n and len(other.grad_pairs) == n:
             return 3, other
         old = self.bucket.clone() if nours else None
@@ -482,8 +483,11 @@ class _SurfaceFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         B, _, M, _ = plan.shape
         sec, n = plan.out_sec, B * M * 3
-        return (out[0:n].view(B, M, 3).detach(), out[sec:sec + n].view(B, M, 3).detach(), out[2 * sec].detach(),
-                out[2 * sec + 1].detach())
+        if plan.static_out:  # (views of the plan's own block: handed out detached from it)
+            return (out[0:n].view(B, M, 3).detach(), out[sec:sec + n].view(B, M, 3).detach(), out[2 * sec].detach(),
+                    out[2 * sec + 1].detach())
+        # (views of a tensor made inside this forward: nothing to detach from)
+        return out[0:n].view(B, M, 3), out[sec:sec + n].view(B, M, 3), out[2 * sec], out[2 * sec + 1]
 
     @staticmethod
     def backward(ctx, g_simp, g_proj, g_lsimp, g_sigma):

@@ -822,6 +822,58 @@ def test_output_batchnorm_kernels_vs_torch(B, Ci, Co, training):
     assert torch.equal(dz, dz2)
 
 
+@pytest.mark.parametrize("B,M", [(32, 64), (5, 32), (17, 64)])
+def test_fc_chain_output_stage_equals_the_separate_output_layer(B, M):
+    """sn_fc_chain_forward_pool_out (the classification sampler's output layer + BatchNorm as the LAST STAGE of the forward FC
+    chain) against the chain without it + sn_layer_forward_bn_out: hidden layers bit-identical (the added hand-off of the last
+    hidden layer changes no arithmetic), the output layer's pre-BN values bit-identical (same K split and summation order), its
+    BatchNorm coefficients / the head's output / running statistics within 2 ulp-level tolerances (fp32 1/sqrt with host-side
+    reciprocals in the chain, as its hidden layers), the backward's gradients accordingly; repeated calls, error word clear."""
+    from samplenet_amd import SampleNet, pointnet
+    from samplenet_amd._lib import lib
+
+    torch.manual_seed(B + M)
+    net_a = SampleNet(M, 128, group_size=4, input_shape="bnc", output_shape="bnc", last_fc_batchnorm=True, min_sigma=0.0).cuda().train()
+    with torch.no_grad():
+        net_a.bn_fc4.weight.copy_(torch.rand_like(net_a.bn_fc4.weight) + 0.5), net_a.bn_fc4.bias.normal_(0, 0.2)
+    net_b = copy.deepcopy(net_a)
+    orig = lib.sn_fc_chain_forward_pool_out_supported
+    for it in range(3):
+        x = (torch.rand(B, 256, 3, device="cuda") - 0.5).contiguous()
+        ya, sa = pointnet.forward_impl(net_a, x, True, use_plan=False)
+        assert "y_out" in sa and ya is sa["y_out"]
+        try:  # the same module with the output stage refused: chain + separate output layer launch
+            lib.sn_fc_chain_forward_pool_out_supported = lambda *a: 0
+            yb, sb = pointnet.forward_impl(net_b, x, True, use_plan=False)
+        finally:
+            lib.sn_fc_chain_forward_pool_out_supported = orig
+        assert "y_out" not in sb and "z_out" in sb
+        for l in range(3):
+            assert torch.equal(sa["zf"][l], sb["zf"][l]) and torch.equal(sa["cf"][l], sb["cf"][l]), (it, l)
+        assert torch.equal(sa["z_out"], sb["z_out"]), it
+        assert torch.allclose(sa["c_out"], sb["c_out"], rtol=3e-6, atol=1e-7), it
+        assert torch.allclose(ya, yb, rtol=1e-5, atol=2e-6), it
+        gy = torch.randn(B, 3 * M, device="cuda")
+        ga = pointnet.backward_impl(net_a, sa, gy)  # (the output BatchNorm's backward opens the FC chain's backward launch)
+        orig_b = pointnet._fc_chain_bwd
+        try:  # reference: the stand-alone sn_bn_output_backward launch in front of the chain
+            def plain(net, convs, fcs, saved, grad_y, sink, grads, fixed, obn=None):
+                if obn is None:
+                    return orig_b(net, convs, fcs, saved, grad_y, sink, grads, fixed)
+                return False
+            pointnet._fc_chain_bwd = plain
+            gb = pointnet.backward_impl(net_b, sb, gy)
+        finally:
+            pointnet._fc_chain_bwd = orig_b
+        gmax = max(float(v.norm()) for v in gb.values())
+        for n in gb:
+            # (a bias in front of a BatchNorm has a zero gradient up to rounding noise of the size 1e-6 gmax: absolute floor)
+            assert float((ga[n] - gb[n]).norm()) <= 2e-5 * float(gb[n].norm()) + 1e-5 * gmax, (it, n)
+    for (n, a), (_, b) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-7), n
+    assert pointnet.chain_error_words(net_a) == (0, 0)
+
+
 @pytest.mark.parametrize("B,bneck", [(32, 128), (4, 128), (17, 256), (32, 64)])
 def test_fc_chain_forward_equals_per_layer_launches(B, bneck):
     """sn_fc_chain_forward (the FC head's three BatchNorm + ReLU layers as ONE launch, activations handed between the
