@@ -509,12 +509,13 @@ def time_config3_emd(dev, reps=5):
     """BASELINE configs[3] (ShapeNet reconstruction, EMD loss): B = 50 clouds, approx_match / match_cost between the 2048-point
     reconstruction and its 2048-point target (reconstruction/src/samplenet_pointnet_ae.py:118-131; kernels
     classification/structural_losses/tf_approxmatch_g.cu).  Two forms, forward + gradients:
-      emd_loss   -- ops.emd_loss = sn_emd_loss_fast: the auction + two sweeps that re-evaluate match from the per-level ratio vectors
-                    with the reference op's own __expf (v_exp_f32); the (B, 2048, 2048) match matrix (839 MB) is never written
+      emd_loss   -- ops.emd_loss = sn_emd_loss_fast: the auction + ONE sweep over 64 x 64 tiles that re-evaluates match from the per-level
+                    ratio vectors once per pair for cost, grad1 and grad2, with the reference op's own __expf (v_exp_f32); the
+                    (B, 2048, 2048) match matrix (839 MB) is never written
                     (`emd_loss_exact`: the same with approx_match's compensated exponential, bit-identical to three_call's cost);
       three_call -- approx_match -> match_cost -> its gradient, the reference's op sequence (match written once, read twice).
     Roofs: HBM on SURVEY 8d's algorithmic bytes (3 x 16.78 MB per cloud: the materialised form's minimum) and VALU issue --
-    the kernels are exponential-bound: 3 exp per pair and level x 10 levels + 10 (three_call) or 2 x 10 (emd_loss) per pair;
+    the kernels are exponential-bound: 3 exp per pair and level x 10 levels + 10 per pair (three_call's materialisation; emd_loss's sweep);
     256 CUs x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s, v_exp_f32 priced at 5/3 of a plain VALU op
     (MI355X_MICROARCH.md).  `valu_busy_profiled`: SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES of the committed rocprofv3 --pmc pass."""
     from samplenet_amd import ops
@@ -549,7 +550,9 @@ def time_config3_emd(dev, reps=5):
         sq = json.load(open(_profile_file("emd_sq_counters.json")))
     except (OSError, ValueError, TypeError):
         pass
-    for name, ms, exps, traffic_key in (("emd_loss", t_fused, 50.0, "emd_loss"), ("three_call", t_three, 40.0, "three_call")):
+    # (emd_loss since round 6: 30 exponentials per pair in the auction + 10 in ONE cost / gradient sweep -- each pair's match value is
+    #  evaluated once for cost, grad1 and grad2 (emd_loss_sweep2d_kernel); until round 5 two sweeps: 50)
+    for name, ms, exps, traffic_key in (("emd_loss", t_fused, 40.0, "emd_loss"), ("three_call", t_three, 40.0, "three_call")):
         lane_ops = pairs * (exps * (5.0 / 3.0) + 10 * 3 * 9.0 + 10.0)  # exps + ~9 packed-pair VALU slots per pair, level and pass
         gbs = alg / (ms * 1e-3) / 1e9
         out[name] = {"ms": ms, "clouds_per_s": B / (ms * 1e-3),

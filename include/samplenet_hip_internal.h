@@ -364,6 +364,10 @@ int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat,
                                 const float *grad_twist, const float *grad_quat, const float *grad_qnorm, float *grad_v, float *grad_y,
                                 sn_stream_t stream);
 
+/* Test hook: sn_emd_loss_fast on the one-sweep form (1, default: every pair's match value evaluated once for cost, grad1 and grad2;
+ * 64 x 64 tiles, tile partials added in ascending order) or on the two order-preserving sweeps of sn_emd_loss (0); returns the
+ * previous setting.  Both meet the loss bar (cost 1e-5 of the oracle's). */
+int sn_emd_set_sweep2d(int on);
 int sn_skinny_linear_supported(int R, int K, int N);
 long long sn_skinny_linear_scratch_bytes(int R, int K, int N);
 int sn_skinny_linear(int R, int K, int N, const float *x, const float *gate, const float *W, int transposed, const float *bias, int relu,

@@ -6,6 +6,7 @@
 #include "sn_common.h"
 
 long long sn_emd_workspace_floats(int b, int n, int m);
+long long sn_emd_sweep2d_floats(int b, int n, int m);
 
 static thread_local char g_err[512] = "";
 
@@ -28,6 +29,7 @@ extern "C" long long sn_workspace_bytes(const char *op, int B, int N, int M, int
     // implementation keeps the ratio vectors of all 10 levels so that `match` is written once.
     if (!strcmp(op, "approxmatch")) return sn_emd_workspace_floats(B, N, M) * 4;
     if (!strcmp(op, "matchcost")) return (long long)B * ((N + 255) / 256) * 4;  // per-workgroup partial sums
-    if (!strcmp(op, "emd_loss")) return sn_emd_workspace_floats(B, N, M) * 4 + (long long)B * ((N + 255) / 256) * 4;
+    if (!strcmp(op, "emd_loss"))  // level workspace + cost partials + the one-sweep form's tile partials
+        return sn_emd_workspace_floats(B, N, M) * 4 + (long long)B * ((N + 255) / 256) * 4 + sn_emd_sweep2d_floats(B, N, M) * 4;
     return 0;
 }

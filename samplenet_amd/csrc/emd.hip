@@ -505,11 +505,164 @@ __global__ void __launch_bounds__(256) emd_loss_sweep_kernel(int n, int m, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The two sweeps above evaluate match[l,k] -- ten exponentials per pair -- TWICE, once per reduction axis (791 + 640 us of the
+// 3.3 ms loss at B = 50, 2048 x 2048).  ONE sweep, each pair evaluated once: a workgroup owns a 64 x 64 tile of the pair matrix,
+// a thread a 4 x 4 block of it (its four k-points and four l-points with their ten ratios each live in registers); the thread
+// adds cost / grad1 terms of its k's over its four l's and grad2 terms of its l's over its four k's, the 16 threads that share a
+// k-block (an l-block) combine through LDS in a fixed order, and the tile leaves one partial per k (cost, grad1) and per l
+// (grad2): P1 [b][tiles_l][n][4], P2 [b][tiles_k][m][3].  emd_loss_reduce2d_kernel adds the tiles in ascending order:
+// deterministic, no atomics.  The summation ORDER differs from emd_cost_partial_kernel / emd_grad*_kernel, so this form serves
+// sn_emd_loss_fast only (the loss bar: cost 1e-5); sn_emd_loss keeps the two order-preserving sweeps (bit-identical to the
+// three-call composition).
+// ------------------------------------------------------------------------------------------------
+constexpr int kT2 = 64;
+template <bool FAST>
+__global__ void __launch_bounds__(256) emd_loss_sweep2d_kernel(int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                               const float *__restrict__ ws, float *__restrict__ P1, float *__restrict__ P2)
+{
+    __shared__ float sk[3 + kLevels][kT2], sl[3 + kLevels][kT2];
+    __shared__ float red1[16][kT2][4];
+    __shared__ float red2[16][kT2][3];
+    const int b = blockIdx.z, kt = blockIdx.x, lt = blockIdx.y;
+    const int tid = threadIdx.x;
+    const float *X1 = xyz1 + (size_t)b * n * 3, *X2 = xyz2 + (size_t)b * m * 3;
+    const float *base = ws + (size_t)b * emd_ws_floats(n, m);
+    const float *ratioL = base + n + m, *ratioR = ratioL + (size_t)kLevels * n;
+    if (tid < kT2) {
+        const int k = kt * kT2 + tid;
+        const bool ok = k < n;
+        sk[0][tid] = ok ? X1[k * 3 + 0] : 0.f, sk[1][tid] = ok ? X1[k * 3 + 1] : 0.f, sk[2][tid] = ok ? X1[k * 3 + 2] : 0.f;
+#pragma unroll
+        for (int li = 0; li < kLevels; ++li) sk[3 + li][tid] = ok ? ratioL[(size_t)li * n + k] : 0.f;  // (a zero ratio: no contribution)
+    } else if (tid < 2 * kT2) {
+        const int t = tid - kT2, l = lt * kT2 + t;
+        const bool ok = l < m;
+        sl[0][t] = ok ? X2[l * 3 + 0] : 0.f, sl[1][t] = ok ? X2[l * 3 + 1] : 0.f, sl[2][t] = ok ? X2[l * 3 + 2] : 0.f;
+#pragma unroll
+        for (int li = 0; li < kLevels; ++li) sl[3 + li][t] = ok ? ratioR[(size_t)li * m + l] : 0.f;
+    }
+    __syncthreads();
+    const int tk = tid & 15, tl = tid >> 4;
+    float kx[4], ky[4], kz[4], kr[4][kLevels], lx[4], ly[4], lz[4], lr[4][kLevels];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        kx[a] = sk[0][tk * 4 + a], ky[a] = sk[1][tk * 4 + a], kz[a] = sk[2][tk * 4 + a];
+        lx[a] = sl[0][tl * 4 + a], ly[a] = sl[1][tl * 4 + a], lz[a] = sl[2][tl * 4 + a];
+#pragma unroll
+        for (int li = 0; li < kLevels; ++li) kr[a][li] = sk[3 + li][tk * 4 + a], lr[a][li] = sl[3 + li][tl * 4 + a];
+    }
+    float cst[4], g1x[4], g1y[4], g1z[4], g2x[4], g2y[4], g2z[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) cst[a] = g1x[a] = g1y[a] = g1z[a] = g2x[a] = g2y[a] = g2z[a] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float ex = kx[a] - lx[c], ey = ky[a] - ly[c], ez = kz[a] - lz[c];  // x_k - x_l
+            const float d2 = (ex * ex + ey * ey) + ez * ez;
+            float mt = 0.f;
+            const f2v dd = splat(d2);
+#pragma unroll
+            for (int li = 0; li < kLevels; li += 2) {
+                const EmdLev L2{(f2v){emd_level(li) * kLog2eHi, emd_level(li + 1) * kLog2eHi}, (f2v){emd_level(li) * kLog2eLo, emd_level(li + 1) * kLog2eLo}};
+                const f2v w = pk_mul(pk_mul(emd_exp2<FAST>(dd, L2), (f2v){kr[a][li], kr[a][li + 1]}), (f2v){lr[c][li], lr[c][li + 1]});
+                mt += w.x;
+                mt += w.y;
+            }
+            cst[a] += sqrtf(d2) * mt;
+            const float g = mt * rsqrtf(fmaxf(d2, 1e-20f));
+            const float tx = ex * g, ty = ey * g, tz = ez * g;
+            g1x[a] += tx, g1y[a] += ty, g1z[a] += tz;
+            g2x[c] -= tx, g2y[c] -= ty, g2z[c] -= tz;  // (x_l - x_k) g
+        }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        *reinterpret_cast<float4 *>(&red1[tl][tk * 4 + a][0]) = make_float4(g1x[a], g1y[a], g1z[a], cst[a]);
+        red2[tk][tl * 4 + a][0] = g2x[a], red2[tk][tl * 4 + a][1] = g2y[a], red2[tk][tl * 4 + a][2] = g2z[a];
+    }
+    __syncthreads();
+    if (tid < kT2) {  // k-local tid: the 16 l-blocks in order
+        float4 s4 = *reinterpret_cast<const float4 *>(&red1[0][tid][0]);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(&red1[q][tid][0]);
+            s4.x += v.x, s4.y += v.y, s4.z += v.z, s4.w += v.w;
+        }
+        const int k = kt * kT2 + tid;
+        if (k < n) *reinterpret_cast<float4 *>(P1 + (((size_t)b * gridDim.y + lt) * n + k) * 4) = s4;
+    } else if (tid < 2 * kT2) {  // l-local: the 16 k-blocks in order
+        const int t = tid - kT2;
+        float sx = red2[0][t][0], sy = red2[0][t][1], sz = red2[0][t][2];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) sx += red2[q][t][0], sy += red2[q][t][1], sz += red2[q][t][2];
+        const int l = lt * kT2 + t;
+        if (l < m) {
+            float *o = P2 + (((size_t)b * gridDim.x + kt) * m + l) * 3;
+            o[0] = sx, o[1] = sy, o[2] = sz;
+        }
+    }
+}
+
+// tiles in ascending order -> grad1 (b, n, 3), grad2 (b, m, 3) (either may be NULL) and the per-workgroup cost partials that
+// emd_cost_final_kernel adds up: partial [b][gridDim.x of the k side].  grid ((max(n, m) + 255) / 256, b).
+__global__ void __launch_bounds__(256) emd_loss_reduce2d_kernel(int n, int m, int nkt, int nlt, const float *__restrict__ P1,
+                                                                const float *__restrict__ P2, float *__restrict__ partial,
+                                                                float *__restrict__ grad1, float *__restrict__ grad2)
+{
+    __shared__ float red[256];
+    const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    float c = 0.f;
+    if (i < n) {
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < nlt; ++t) {
+            const float4 v = *reinterpret_cast<const float4 *>(P1 + (((size_t)b * nlt + t) * n + i) * 4);
+            s4.x += v.x, s4.y += v.y, s4.z += v.z, s4.w += v.w;
+        }
+        c = s4.w;
+        if (grad1) {
+            float *o = grad1 + ((size_t)b * n + i) * 3;
+            o[0] = s4.x, o[1] = s4.y, o[2] = s4.z;
+        }
+    }
+    if (grad2 && i < m) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int t = 0; t < nkt; ++t) {
+            const float *v = P2 + (((size_t)b * nkt + t) * m + i) * 3;
+            sx += v[0], sy += v[1], sz += v[2];
+        }
+        float *o = grad2 + ((size_t)b * m + i) * 3;
+        o[0] = sx, o[1] = sy, o[2] = sz;
+    }
+    if (blockIdx.x < (unsigned)((n + 255) / 256)) {
+        red[threadIdx.x] = c;
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            __syncthreads();
+            if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        }
+        if (threadIdx.x == 0) partial[(size_t)b * ((n + 255) / 256) + blockIdx.x] = red[0];
+    }
+}
+
 }  // namespace sn
 
 using namespace sn;
 
 long long sn_emd_workspace_floats(int b, int n, int m) { return (long long)b * (long long)emd_ws_floats(n, m); }
+// floats behind the level workspace and the cost partials that the one-sweep form of sn_emd_loss_fast needs (tile partials P1, P2)
+long long sn_emd_sweep2d_floats(int b, int n, int m)
+{
+    const long long nkt = (n + kT2 - 1) / kT2, nlt = (m + kT2 - 1) / kT2;
+    return (long long)b * (nlt * n * 4 + nkt * m * 3);
+}
+// test / A-B hook: 0 = sn_emd_loss_fast on the two order-preserving sweeps (as sn_emd_loss), 1 (default) = the one-sweep form
+static int g_emd_sweep2d = 1;
+extern "C" int sn_emd_set_sweep2d(int on)
+{
+    const int prev = g_emd_sweep2d;
+    g_emd_sweep2d = on ? 1 : 0;
+    return prev;
+}
 
 template <bool FAST>
 static int emd_auction(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp, sn_stream_t stream)
@@ -592,6 +745,17 @@ static int emd_loss_impl(int b, int n, int m, const float *xyz1, const float *xy
     if (rc) return rc;
     float *partial = temp + sn_emd_workspace_floats(b, n, m);
     const int nparts = (n + 255) / 256;
+    if (FAST && g_emd_sweep2d) {
+        // the default loss form: every pair's match value evaluated once for cost, grad1 and grad2 (see emd_loss_sweep2d_kernel)
+        const int nkt = (n + kT2 - 1) / kT2, nlt = (m + kT2 - 1) / kT2;
+        float *P1 = partial + (size_t)b * nparts, *P2 = P1 + (size_t)b * nlt * n * 4;
+        hipLaunchKernelGGL((emd_loss_sweep2d_kernel<FAST>), dim3(nkt, nlt, b), dim3(256), 0, st, n, m, xyz1, xyz2, temp, P1, P2);
+        hipLaunchKernelGGL(emd_loss_reduce2d_kernel, dim3((std::max(n, m) + 255) / 256, b), dim3(256), 0, st, n, m, nkt, nlt, P1, P2, partial,
+                           grad1, grad2);
+        hipLaunchKernelGGL(emd_cost_final_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, nparts, partial, cost);
+        SN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL((emd_loss_sweep_kernel<true, FAST>), dim3(nparts, b), dim3(256), 0, st, n, m, xyz1, xyz2, temp, partial, grad1);
     hipLaunchKernelGGL(emd_cost_final_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, nparts, partial, cost);
     if (grad2)

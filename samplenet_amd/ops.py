@@ -716,8 +716,9 @@ match_cost = MatchCostFunction.apply
 
 class EmdLossFunction(torch.autograd.Function):
     """cost (B,) = match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) in one call, WITHOUT the (B,m,n) match matrix
-    (sn_emd_loss / sn_emd_loss_fast): forward runs the auction and one cost / gradient sweep per cloud; backward scales the saved
-    gradients (match is a constant of the gradient, tf_approxmatch.py:54-64).
+    (sn_emd_loss / sn_emd_loss_fast): forward runs the auction and the cost / gradient sweep(s) -- the default form ONE sweep that
+    evaluates every pair's match value once for cost and both gradients, the exact form two order-preserving ones --; backward
+    scales the saved gradients (match is a constant of the gradient, tf_approxmatch.py:54-64).
     exact=False (default): the reference op's own exponential (__expf = v_exp_f32(x log2 e), tf_approxmatch_g.cu:52,97,151) -- the
     cost within 1e-5 of the oracle; exact=True: the compensated exponential of approx_match -- cost and the xyz1 gradient bit for
     bit those of match_cost(approx_match(...))."""

@@ -225,3 +225,37 @@ def test_emd_loss_default_form_matches_the_oracle(oracle, shape):
         nerr = np.linalg.norm(g.cpu().numpy() - og) / np.linalg.norm(og)
         print("   gradient: max err / scale %.2e, |d| / |g| %.2e" % (err, nerr))
         assert err <= 2e-3 and nerr <= 1e-4, (err, nerr)
+
+
+@pytest.mark.parametrize("shape", [(2, 2048, 2048), (3, 100, 300), (2, 7, 5), (1, 4096, 1024), (2, 65, 129)])
+def test_emd_loss_one_sweep_form_matches_the_two_sweeps(shape):
+    """sn_emd_loss_fast's one-sweep form (every pair's match value evaluated ONCE for cost, grad1 and grad2 -- 64 x 64
+    tiles, 4 x 4 pairs per thread, tile partials added in ascending order) against the two order-preserving sweeps
+    (sn_emd_set_sweep2d(0)): the same ten exponentials per pair, only the order of the sums differs -- cost 1e-6 relative, gradients
+    1e-5 of their scale --, ragged tiles included; and two runs of the one-sweep form agree bit for bit (no atomics)."""
+    from samplenet_amd import ops
+    from samplenet_amd._lib import lib
+
+    b, n, m = shape
+    g = torch.Generator(device="cuda").manual_seed(n * 3 + m)
+    x1 = torch.rand(b, n, 3, device="cuda", generator=g)
+    x2 = torch.rand(b, m, 3, device="cuda", generator=g)
+
+    def run():
+        a1, a2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        cost = ops.emd_loss(a1, a2)
+        g1, g2 = torch.autograd.grad(cost.sum(), [a1, a2])
+        return cost.detach(), g1, g2
+
+    prev = lib.sn_emd_set_sweep2d(1)
+    try:
+        one, again = run(), run()
+        lib.sn_emd_set_sweep2d(0)
+        two = run()
+    finally:
+        lib.sn_emd_set_sweep2d(prev)
+    for u, w in zip(one, again):
+        assert torch.equal(u, w)
+    assert float(((one[0] - two[0]) / two[0]).abs().max()) <= 1e-6
+    for u, w in zip(one[1:], two[1:]):
+        assert float((u - w).abs().max()) <= 1e-5 * float(w.abs().max()) + 1e-7, float((u - w).abs().max()) / float(w.abs().max())
