@@ -63,7 +63,7 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-ROUNDS = ("r05", "r04", "r03", "r02", "r01")
+ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")
 
 
 def profile_dir():

@@ -17,8 +17,8 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = SampleNet(64, 128, group_size=K, input_shape="bnc", output_shape="bnc", last_fc_batchnorm=True, min_sigma=0.0).to(dev).train()
 x = torch.rand(32, 1024, 3, device=dev) - 0.5
-st = SamplerTrainStep(net, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=FlatGradAllReducer(net), use_graph=True)
+st = SamplerTrainStep(net, x, alpha=0.01, lmbda=0.01, gamma=1.0, delta=0.0, reducer=FlatGradAllReducer(net), use_graph=True, input_ring=[x])
 for _ in range(steps):
-    loss = st(x)
+    loss = st.replay(0)
 torch.cuda.synchronize()
 print("loss", float(loss), "fast", st._fast_path())
