@@ -425,7 +425,9 @@ class _Plan:
         plan's bucket takes the sum in one launch), 2 anything else (per parameter)."""
         n = len(self.grad_pairs)
         grads = [p.grad for p in self._grad_params]  # (one pass of attribute reads; the usual step -- every .grad dropped by
-        if grads.count(None) == n:                    #  zero_grad() -- is decided without looking at the views at all)
+        #  zero_grad() -- is decided without looking at the views at all.  `is None`, never list.count(None): == on a tensor
+        #  goes through torch's operator dispatch, microseconds apiece)
+        if len([1 for g in grads if g is None]) == n:
             return 0, None
         nnone = nours = 0
         other = None
