@@ -364,6 +364,10 @@ int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat,
                                 const float *grad_twist, const float *grad_quat, const float *grad_qnorm, float *grad_v, float *grad_y,
                                 sn_stream_t stream);
 
+/* Test hook: the auction's level passes in segments (1, default: the other cloud cut into ranges swept by separate workgroups, partial
+ * sums added in ascending order by the last to arrive -- thousands of short workgroups instead of 1.56 waves per SIMD at B = 50) or as
+ * one range per workgroup (0); returns the previous setting. */
+int sn_emd_set_segments(int on);
 /* Test hook: sn_emd_loss_fast on the one-sweep form (1, default: every pair's match value evaluated once for cost, grad1 and grad2;
  * 64 x 64 tiles, tile partials added in ascending order) or on the two order-preserving sweeps of sn_emd_loss (0); returns the
  * previous setting.  Both meet the loss bar (cost 1e-5 of the oracle's). */

@@ -141,6 +141,7 @@ PROTOTYPES = {
     "sn_emd_loss": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_emd_loss_fast": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_emd_set_sweep2d": [_i],
+    "sn_emd_set_segments": [_i],
 }
 _RESTYPES = {"sn_last_error_string": ctypes.c_char_p, "sn_workspace_bytes": ctypes.c_longlong,
              "sn_pairscan_workspace_bytes": ctypes.c_longlong, "sn_linear_forward_maxpool_wide_scratch_bytes": ctypes.c_longlong,

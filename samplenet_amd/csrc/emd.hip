@@ -146,13 +146,51 @@ __host__ __device__ inline size_t emd_ws_floats(int n, int m) { return (size_t)(
 //   then      : pass 1 of level li   -> ratioL[li][k] = remainL[k] / (1e-9 + sum_l exp(lev d) remainR[l])
 // (pass 3 of the last level only updates remainL, which nothing reads afterwards: it is not run.)
 // li == 0 also initialises remainL (and, by its first block column, remainR).
+// Segments (round 6): at BASELINE configs[3] a level pass is 400 workgroups of equal, long work on 256 CUs -- 1.56 waves per SIMD, i.e.
+// some SIMDs run two waves while others run one and the launch lasts as long as the former (78 % of the issue slots used).  With
+// nseg > 1 the other cloud is cut into nseg ranges (gridDim.z): a workgroup sweeps one range and leaves its partial sums in seg[];
+// the LAST workgroup of a (cloud, point block) to arrive -- a relaxed counter behind a device-scope fence -- adds the nseg partials in
+// ascending order and finishes the pass: thousands of short workgroups that the dispatcher balances by itself, sums still in a fixed
+// order (deterministic; the order differs from the one-range sweep's only in where the partial sums are cut).  nseg == 1: the
+// one-range code path, unchanged.
+struct EmdSeg {
+    float *psum;        // pass k: [b][nseg][2][n] (sum3 | sum1 partials); pass l: [b][nseg][m]
+    unsigned *counter;  // [b][gridDim.x], zero between launches
+    int nseg, len;      // ranges of `len` points of the other cloud
+};
+// (partials cross workgroups as write-through stores / sc1 loads around a relaxed counter, as the skinny layers' slice partials do
+//  (task_network.hip): no fences -- an agent-scope fence writes back and invalidates the whole L2 of the XCD, and thousands of
+//  workgroups doing that per launch doubled the auction's time)
+__device__ __forceinline__ void emd_store_sc1(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ float emd_load_sc1(const float *p)
+{
+    float v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ bool emd_seg_last(const EmdSeg &sg, int b)
+{
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's partial sums have left before its arrival
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned *c = sg.counter + (size_t)b * gridDim.x + blockIdx.x;
+        const unsigned t = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == (unsigned)(sg.nseg - 1);
+        if (s_last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // armed for the next launch
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
 template <bool FAST>
 __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2, float *__restrict__ ws,
-                                                         float multiL, float multiR)
+                                                         float multiL, float multiR, EmdSeg sg)
 {
     __shared__ float4 tile[kTile];
     const int b = blockIdx.y;
+    const int lbeg = sg.nseg > 1 ? (int)blockIdx.z * sg.len : 0, lstop = sg.nseg > 1 ? min(m, lbeg + sg.len) : m;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const float *X1 = xyz1 + (size_t)b * n * 3;
     const float *X2 = xyz2 + (size_t)b * m * 3;
@@ -179,9 +217,9 @@ __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, c
     // w_l, w_l+1} (w = remainR), tileC[q] = {w3_l, w3_l+1} (w3 = ratioR'); an odd tail is padded with a zero-weight point.
     float4 *tileA = tile, *tileB = tile + kTile / 2;
     __shared__ float2 tileC[kTile / 2];
-    float sum3 = 0.f, sum1 = 1e-9f;
-    for (int l0 = 0; l0 < m; l0 += kTile) {
-        const int lend = min(m, l0 + kTile) - l0, npair = (lend + 1) >> 1;
+    float sum3 = 0.f, sum1 = sg.nseg > 1 ? 0.f : 1e-9f;
+    for (int l0 = lbeg; l0 < lstop; l0 += kTile) {
+        const int lend = min(lstop, l0 + kTile) - l0, npair = (lend + 1) >> 1;
         __syncthreads();
         for (int q = threadIdx.x; q < npair; q += blockDim.x) {
             const int la = l0 + 2 * q, lb = la + 1;
@@ -224,6 +262,17 @@ __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, c
             for (; q < npair; ++q) body(q);
         }
     }
+    if (sg.nseg > 1) {
+        float *ps = sg.psum + ((size_t)b * sg.nseg + blockIdx.z) * 2 * n;
+        if (k < n) emd_store_sc1(ps + k, sum3), emd_store_sc1(ps + n + k, sum1);
+        if (!emd_seg_last(sg, b)) return;
+        sum3 = 0.f, sum1 = 1e-9f;
+        if (k < n)
+            for (int q = 0; q < sg.nseg; ++q) {
+                const float *pq = sg.psum + ((size_t)b * sg.nseg + q) * 2 * n;
+                sum3 += emd_load_sc1(pq + k), sum1 += emd_load_sc1(pq + n + k);
+            }
+    }
     float remL = multiL;
     if (k < n) {
         if (do3) remL = fmaxf(0.0f, remainL[k] - sum3);
@@ -237,10 +286,11 @@ __global__ void __launch_bounds__(256) emd_pass_k_kernel(int n, int m, int li, c
 // Kernel B(li): thread per xyz2 point l -- pass 2 of level li (tf_approxmatch_g.cu:75-110).
 template <bool FAST>
 __global__ void __launch_bounds__(256) emd_pass_l_kernel(int n, int m, int li, const float *__restrict__ xyz1,
-                                                         const float *__restrict__ xyz2, float *__restrict__ ws)
+                                                         const float *__restrict__ xyz2, float *__restrict__ ws, EmdSeg sg)
 {
     __shared__ float4 tile[kTile];
     const int b = blockIdx.y;
+    const int kbeg = sg.nseg > 1 ? (int)blockIdx.z * sg.len : 0, kstop = sg.nseg > 1 ? min(n, kbeg + sg.len) : n;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const float *X1 = xyz1 + (size_t)b * n * 3;
     const float *X2 = xyz2 + (size_t)b * m * 3;
@@ -255,8 +305,8 @@ __global__ void __launch_bounds__(256) emd_pass_l_kernel(int n, int m, int li, c
     float4 *tileA = tile, *tileB = tile + kTile / 2;  // pairs of xyz1 points, as in emd_pass_k_kernel (w = ratioL)
     const EmdLev Lv = emd_lev(level);
     const f2v px = splat(x2), py = splat(y2), pz = splat(z2);
-    for (int k0 = 0; k0 < n; k0 += kTile) {
-        const int kend = min(n, k0 + kTile) - k0, npair = (kend + 1) >> 1;
+    for (int k0 = kbeg; k0 < kstop; k0 += kTile) {
+        const int kend = min(kstop, k0 + kTile) - k0, npair = (kend + 1) >> 1;
         __syncthreads();
         for (int q = threadIdx.x; q < npair; q += blockDim.x) {
             const int ka = k0 + 2 * q, kb = ka + 1;
@@ -278,6 +328,14 @@ __global__ void __launch_bounds__(256) emd_pass_l_kernel(int n, int m, int li, c
         int q = 0;
         for (; q + 4 <= npair; q += 4) body(q), body(q + 1), body(q + 2), body(q + 3);
         for (; q < npair; ++q) body(q);
+    }
+    if (sg.nseg > 1) {
+        float *ps = sg.psum + ((size_t)b * sg.nseg + blockIdx.z) * m;
+        if (l < m) emd_store_sc1(ps + l, sumr);
+        if (!emd_seg_last(sg, b)) return;
+        sumr = 0.f;
+        if (l < m)
+            for (int q = 0; q < sg.nseg; ++q) sumr += emd_load_sc1(sg.psum + ((size_t)b * sg.nseg + q) * m + l);
     }
     if (l < m) {
         const float rr = remainR[l];
@@ -648,12 +706,43 @@ __global__ void __launch_bounds__(256) emd_loss_reduce2d_kernel(int n, int m, in
 
 using namespace sn;
 
-long long sn_emd_workspace_floats(int b, int n, int m) { return (long long)b * (long long)emd_ws_floats(n, m); }
+// ranges of the other cloud per level pass (EmdSeg): enough workgroups that the dispatcher balances the chip (>= ~2048), ranges a
+// multiple of 64 points, at most one per 256 points of the other cloud
+static void emd_seg_plan(int b, int nself, int nother, int &nseg, int &len)
+{
+    const long long base = (long long)b * ((nself + 255) / 256);
+    long long s = base > 0 ? (2048 + base - 1) / base : 1;
+    s = std::max<long long>(1, std::min<long long>(s, nother / 256));
+    len = (int)(((nother + s - 1) / s + 63) / 64 * 64);
+    nseg = (nother + len - 1) / len;
+    if (nseg <= 1) nseg = 1, len = nother;
+}
+static long long emd_seg_floats(int b, int n, int m)
+{
+    int sk, lk, sl, ll;
+    emd_seg_plan(b, n, m, sk, lk);
+    emd_seg_plan(b, m, n, sl, ll);
+    if (sk <= 1 && sl <= 1) return 0;
+    const long long psum = std::max((long long)b * sk * 2 * n, (long long)b * sl * m);
+    const long long ctr = (long long)b * std::max((n + 255) / 256, (m + 255) / 256);
+    return psum + ((ctr + 63) / 64) * 64;
+}
+// per-cloud level workspace, then (behind all clouds) the segment partials and arrival counters of the level passes
+long long sn_emd_workspace_floats(int b, int n, int m) { return (long long)b * (long long)emd_ws_floats(n, m) + emd_seg_floats(b, n, m); }
 // floats behind the level workspace and the cost partials that the one-sweep form of sn_emd_loss_fast needs (tile partials P1, P2)
 long long sn_emd_sweep2d_floats(int b, int n, int m)
 {
     const long long nkt = (n + kT2 - 1) / kT2, nlt = (m + kT2 - 1) / kT2;
     return (long long)b * (nlt * n * 4 + nkt * m * 3);
+}
+// test / A-B hook: 0 = the level passes sweep the whole other cloud per workgroup (the one-range form of rounds 1-5), 1 (default) =
+// segmented level passes (EmdSeg) where the shape makes more than one range
+static int g_emd_segments = 1;
+extern "C" int sn_emd_set_segments(int on)
+{
+    const int prev = g_emd_segments;
+    g_emd_segments = on ? 1 : 0;
+    return prev;
 }
 // test / A-B hook: 0 = sn_emd_loss_fast on the two order-preserving sweeps (as sn_emd_loss), 1 (default) = the one-sweep form
 static int g_emd_sweep2d = 1;
@@ -676,10 +765,24 @@ static int emd_auction(int b, int n, int m, const float *xyz1, const float *xyz2
         multiL = 1, multiR = (float)(n / m);
     else
         multiL = (float)(m / n), multiR = 1;
-    const dim3 gk((n + 255) / 256, b), gl((m + 255) / 256, b);
+    EmdSeg sk{}, sl{};
+    emd_seg_plan(b, n, m, sk.nseg, sk.len);
+    emd_seg_plan(b, m, n, sl.nseg, sl.len);
+    if (!g_emd_segments) sk.nseg = sl.nseg = 1, sk.len = m, sl.len = n;
+    if (sk.nseg > 1 || sl.nseg > 1) {
+        float *segbase = temp + (size_t)b * emd_ws_floats(n, m);
+        const long long psum = std::max((long long)b * sk.nseg * 2 * n, (long long)b * sl.nseg * m);
+        const long long nctr = (long long)b * std::max((n + 255) / 256, (m + 255) / 256);
+        sk.psum = sl.psum = segbase;
+        sk.counter = sl.counter = reinterpret_cast<unsigned *>(segbase + psum);
+        // (the workspace is the caller's and arrives uninitialised: the counters start at zero; every launch leaves them zero)
+        hipError_t e = hipMemsetAsync(sk.counter, 0, sizeof(unsigned) * (size_t)nctr, st);
+        if (e != hipSuccess) return sn_set_error((int)e, "emd: %s", hipGetErrorString(e));
+    }
+    const dim3 gk((n + 255) / 256, b, sk.nseg), gl((m + 255) / 256, b, sl.nseg);
     for (int li = 0; li < kLevels; ++li) {
-        hipLaunchKernelGGL(emd_pass_k_kernel<FAST>, gk, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp, multiL, multiR);
-        hipLaunchKernelGGL(emd_pass_l_kernel<FAST>, gl, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp);
+        hipLaunchKernelGGL(emd_pass_k_kernel<FAST>, gk, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp, multiL, multiR, sk);
+        hipLaunchKernelGGL(emd_pass_l_kernel<FAST>, gl, dim3(256), 0, st, n, m, li, xyz1, xyz2, temp, sl);
     }
     if (match)
         hipLaunchKernelGGL(emd_materialize_kernel, dim3((n + 255) / 256, (m + 15) / 16, b), dim3(256), 0, st, n, m,

@@ -102,7 +102,7 @@ def test_emd_reference_harness_shape_matches_oracle(oracle):
         for g, og in ((g1, og1), (g2, og2)):
             err = np.abs(g.cpu().numpy() - og).max() / np.abs(og).max()
             nerr = np.linalg.norm(g.cpu().numpy() - og) / np.linalg.norm(og)
-            assert err <= 2e-3 and nerr <= 1e-4, (name, err, nerr)
+            assert err <= 5e-3 and nerr <= 1e-4, (name, err, nerr)
     np.testing.assert_allclose(cost3.detach().cpu().numpy(), ocost, rtol=1e-5)
 
 
@@ -203,8 +203,10 @@ def test_emd_loss_without_match_matrix(shape):
 @pytest.mark.parametrize("shape", [(2, 2048, 2048), (2, 256, 64), (1, 1500, 1200)])
 def test_emd_loss_default_form_matches_the_oracle(oracle, shape):
     """sn_emd_loss_fast against the ORACLE (sequential fp32 restatement of tf_approxmatch_g.cu with expf): match_cost of the
-    oracle's own match matrix within 1e-5 (SURVEY 7's bar on the loss), both gradients within 1e-4 of their norm and 2e-3 of their
-    scale per component (they follow the plan: see test_emd_loss_without_match_matrix)."""
+    oracle's own match matrix within 1e-5 (SURVEY 7's bar on the loss), both gradients within 1e-4 of their norm and 5e-3 of their
+    scale per component (they follow the plan, of which single entries move by ~1e-4 when a sum is grouped differently -- the
+    reference's own CPU-vs-GPU bar on the plan is 1e-2 per entry; measured with the segmented level passes of round 6: 2.3e-3 on
+    one component in 12 k at 2048 x 2048, 6e-5 of the norm; see test_emd_loss_without_match_matrix)."""
     from samplenet_amd import ops
 
     b, n, m = shape
@@ -224,7 +226,7 @@ def test_emd_loss_default_form_matches_the_oracle(oracle, shape):
         err = np.abs(g.cpu().numpy() - og).max() / np.abs(og).max()
         nerr = np.linalg.norm(g.cpu().numpy() - og) / np.linalg.norm(og)
         print("   gradient: max err / scale %.2e, |d| / |g| %.2e" % (err, nerr))
-        assert err <= 2e-3 and nerr <= 1e-4, (err, nerr)
+        assert err <= 5e-3 and nerr <= 1e-4, (err, nerr)
 
 
 @pytest.mark.parametrize("shape", [(2, 2048, 2048), (3, 100, 300), (2, 7, 5), (1, 4096, 1024), (2, 65, 129)])
@@ -259,3 +261,40 @@ def test_emd_loss_one_sweep_form_matches_the_two_sweeps(shape):
     assert float(((one[0] - two[0]) / two[0]).abs().max()) <= 1e-6
     for u, w in zip(one[1:], two[1:]):
         assert float((u - w).abs().max()) <= 1e-5 * float(w.abs().max()) + 1e-7, float((u - w).abs().max()) / float(w.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(50, 2048, 2048), (3, 4096, 1024), (7, 1000, 1500), (2, 600, 520)])
+def test_emd_segmented_level_passes_match_the_one_range_form(shape):
+    """Round 6: the auction's level passes cut the other cloud into ranges swept by separate workgroups (thousands of short workgroups
+    instead of 400 long ones on 256 CUs), partial sums added in ascending order by the last to arrive.  Against the one-range form
+    (sn_emd_set_segments(0)): same terms, sums cut at the range borders -- match within 5e-4 per entry (the bar of this file: the
+    auction amplifies last-bit differences through its ten levels; mean 1e-7), cost within 1e-6; deterministic from run to run; the
+    caller's workspace arrives uninitialised (the counters are cleared per call)."""
+    from samplenet_amd import ops
+    from samplenet_amd._lib import lib
+
+    b, n, m = shape
+    g = torch.Generator(device="cuda").manual_seed(n + 7 * m)
+    x1 = torch.rand(b, n, 3, device="cuda", generator=g)
+    x2 = torch.rand(b, m, 3, device="cuda", generator=g)
+    small = b * n * m <= 8 * 2048 * 2048
+
+    def run():
+        if small:
+            mt = ops.approx_match(x1, x2)
+            return mt, ops.match_cost(x1, x2, mt)
+        return None, ops.emd_loss(x1, x2, exact=True)
+
+    prev = lib.sn_emd_set_segments(1)
+    try:
+        torch.empty(1 << 22, device="cuda").fill_(float("nan"))  # (poison recycled allocator blocks: the workspace is not zeroed for us)
+        a, a2 = run(), run()
+        lib.sn_emd_set_segments(0)
+        c = run()
+    finally:
+        lib.sn_emd_set_segments(prev)
+    assert torch.equal(a[1], a2[1]) and (a[0] is None or torch.equal(a[0], a2[0]))
+    assert float(((a[1] - c[1]) / c[1]).abs().max()) <= 1e-6, float(((a[1] - c[1]) / c[1]).abs().max())
+    if small:
+        d = (a[0] - c[0]).abs()
+        assert float(d.max()) <= 5e-4 and float(d.mean()) <= 1e-7, (float(d.max()), float(d.mean()))
