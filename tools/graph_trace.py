@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""python tools/graph_trace.py task|module|cls [replays]: capture one step as a hipGraph, replay it, for
+"""python tools/graph_trace.py task|module|cls|c5 [replays]: capture one step as a hipGraph, replay it, for
     rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python tools/graph_trace.py task 30
 then  python tools/graph_trace.py --analyze DIR/t_kernel_trace.csv  prints the LAST replay as a timeline: per kernel start offset,
 duration and the gap in front of it (what the dependent launches of a latency-bound step are made of).
@@ -21,11 +21,21 @@ def analyze(path):
     names = [r["Kernel_Name"] for r in rows]
     # period detection: smallest p such that the last 2p names are two equal halves
     n = len(names)
+    # one replay = the stretch between two occurrences of a kernel that runs ONCE per step: the rarest name of the trace's tail (its
+    # last two occurrences delimit the last complete replay; kernels of forked branches may interleave differently from replay to
+    # replay, so comparing name sequences for an exact period is not robust)
+    from collections import Counter
+
+    tail = names[-min(n, 4000):]
+    cnt = Counter(tail)
+    marker = min((k for k, v in cnt.items() if v >= 3), key=lambda k: (cnt[k], k), default=None)
     per = None
-    for p in range(5, n // 2):
-        if names[n - p:] == names[n - 2 * p:n - p]:
-            per = p
-            break
+    if marker is not None:
+        occ = [i for i, nm in enumerate(names) if nm == marker]
+        if len(occ) >= 3:
+            per = occ[-1] - occ[-2]
+            n = occ[-1]  # the last COMPLETE replay ends where the marker starts again
+            rows, names = rows[:n], names[:n]
     if per is None:
         per = min(n, 60)
     last = rows[n - per:]
@@ -98,6 +108,9 @@ elif mode == "module":
         st.replay(0)
     torch.cuda.synchronize()
     print("module step done")
+elif mode == "c5":
+    out = bench.time_config5_progressive(dev, steps=5)
+    print({k: v for k, v in out.items() if isinstance(v, dict)})
 else:
     out = bench.time_config1_classification(dev, steps=reps)
     print(out)

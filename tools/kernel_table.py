@@ -42,7 +42,8 @@ for r in mine:
 lines.sort(reverse=True)
 with open(os.path.join(prof, "kernel_table.md"), "w") as f:
     f.write("# Kernels of one sampler training step (B = 32, 1024 -> 64, K = 8), graph replay on 1 x MI355X\n\n")
-    f.write("bench: %.1f k clouds/s, %.1f us/step; summed kernel time below: %.1f us (the rest is inter-kernel gap).\n" %
+    f.write("bench (THIS profile's box, bench_n1.json beside this file; the driver's BENCH_rNN.json comes from another box of the pool: "
+            "+- 3 %%): %.1f k clouds/s, %.1f us/step; summed kernel time below: %.1f us (the rest is inter-kernel gap).\n" %
             (bench["value"] / 1e3, bench["ms_per_step"] * 1e3, tot))
     f.write("HBM traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 --pmc passes; rate = traffic / duration.\n\n")
     f.write("| kernel | launches/step | avg us | share | HBM MB/launch | HBM GB/s |\n|---|---|---|---|---|---|\n")
