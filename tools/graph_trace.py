@@ -28,7 +28,11 @@ def analyze(path):
 
     tail = names[-min(n, 4000):]
     cnt = Counter(tail)
-    marker = min((k for k, v in cnt.items() if v >= 3), key=lambda k: (cnt[k], k), default=None)
+    # (most kernel NAMES of a step occur once per step: the most common occurrence count among the names is the number of steps in
+    #  the tail; a name with exactly that count is a once-per-step kernel -- names seen only during warm-up / capture do not qualify)
+    common = Counter(v for v in cnt.values() if v >= 3).most_common(1)
+    steps_in_tail = common[0][0] if common else 0
+    marker = min((k for k, v in cnt.items() if v == steps_in_tail), default=None)
     per = None
     if marker is not None:
         occ = [i for i, nm in enumerate(names) if nm == marker]
