@@ -704,7 +704,7 @@ def time_config5_progressive(dev, steps=40):
         loss = 0.01 * net.get_progressive_simplification_loss(x, simp, 1, 0, "sum") + 0.01 * net.get_projection_loss()
         # the four evaluations share the template cloud: its extractor pass runs once, and the trunk once on all 4 x 32 rows
         # (the frozen network's whole call -- extractor, trunk, heads, rotations, Chamfer terms -- replays captured graphs: graphed.py)
-        for task, _, _ in pcrnet_chamfer_loss_multi(pcr, template, [net.prefix(proj, s) for s in sizes]):
+        for task, _, _ in pcrnet_chamfer_loss_multi(pcr, template, net.prefixes(proj)):
             loss = loss + task
         loss.backward()
         return loss

@@ -364,6 +364,21 @@ int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat,
                                 const float *grad_twist, const float *grad_quat, const float *grad_qnorm, float *grad_v, float *grad_y,
                                 sn_stream_t stream);
 
+/* The progressive sampler's nested prefixes (classification/train_samplenet_progressive.py:157-234) as contiguous tensors in ONE launch:
+ * src (B, M, C) of 4-byte elements -> dst[j] (B, sizes[j], C) = src[:, :sizes[j], :] (dst: HOST array of nprefix <= 16 device
+ * pointers, NULL entries skipped); and the gradient of that in one launch: out (B, M, C) = sum over j of grads[j] zero-padded to
+ * M points, ascending j (NULL entries contribute nothing). */
+int sn_prefix_pack(int B, int M, int C, int nprefix, const int *sizes, const void *src, void *const *dst, sn_stream_t stream);
+int sn_prefix_scatter_sum(int B, int M, int C, int nprefix, const int *sizes, const float *const *grads, float *out, sn_stream_t stream);
+/* The simplification losses (samplenet.py:171-181) of the first nterms nested prefixes of the simplified cloud, summed ascending
+ * (classification/train_samplenet_progressive.py:204-216), behind one node: dq / iq (B,M) the per-query Chamfer products of the full
+ * set, d2 / i2 (S,B,N) sn_prefix_point_minima's products; partial 3 * nterms * B floats, argmax1 nterms * B ints (forward -> backward).
+ * Bit-identical to nterms sn_simplification_loss_forward / _backward calls on contiguous copies of the prefixes, added ascending. */
+int sn_prefix_simplification_loss_forward(int B, int M, int N, int nterms, const int *sizes, const float *weights, const float *dq,
+                                          const float *d2, float *partial, int *argmax1, float *loss, sn_stream_t stream);
+int sn_prefix_simplification_loss_backward(int B, int M, int N, int nterms, const int *sizes, const float *weights, const float *samp_pc,
+                                           const float *ref_pc, const int *iq, const int *i2, const int *argmax1, const float *grad_loss,
+                                           float *grad_samp, sn_stream_t stream);
 /* Test hook: the auction's level passes in segments (1, default: the other cloud cut into ranges swept by separate workgroups, partial
  * sums added in ascending order by the last to arrive -- thousands of short workgroups instead of 1.56 waves per SIMD at B = 50) or as
  * one range per workgroup (0); returns the previous setting. */

@@ -61,6 +61,10 @@ PROTOTYPES = {
     "sn_step_tail_bytes": [],
     "sn_step_tail_set_error_words": [_vp, _vp, _vp],
     "sn_prefix_point_minima": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_prefix_simplification_loss_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_prefix_simplification_loss_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_prefix_pack": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_prefix_scatter_sum": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],
     "sn_qrot_forward": [_i, _i, _vp, _vp, _vp, _vp],

@@ -2116,6 +2116,250 @@ extern "C" int sn_prefix_point_minima(int B, int N, int M, int nprefix, const in
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The progressive sampler's prefixes (classification/train_samplenet_progressive.py:157-234: every nested size s uses the first s
+// points of the ONE simplified / projected set) as contiguous tensors, all of them in one launch, and the gradient of that --
+// grad[b, m, :] = sum over the prefixes that contain point m of their gradients, ascending prefix order -- in one launch.  As
+// torch ops this is a strided copy per prefix forward and zeros + copy + accumulate per prefix backward: 33 launches of the 177 in
+// BASELINE configs[4]'s step (profiles/r06/config5_graph_timeline.txt).  src (B, M, C) -> dst[j] (B, size_j, C); element size 4 bytes.
+// ------------------------------------------------------------------------------------------------
+struct PrefixPtrs {
+    void *p[kMaxPrefixes];
+    int size[kMaxPrefixes];
+    int n;
+};
+__global__ void __launch_bounds__(256) prefix_pack_kernel(int M, int C, const unsigned *__restrict__ src, PrefixPtrs d)
+{
+    const int b = blockIdx.y;
+    const int tot = M * C;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+        const unsigned v = src[(size_t)b * tot + e];
+        const int m = e / C;
+        for (int j = 0; j < d.n; ++j)
+            if (m < d.size[j] && d.p[j]) reinterpret_cast<unsigned *>(d.p[j])[(size_t)b * d.size[j] * C + e] = v;
+    }
+}
+__global__ void __launch_bounds__(256) prefix_scatter_sum_kernel(int M, int C, PrefixPtrs g, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int tot = M * C;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+        const int m = e / C;
+        float acc = 0.f;
+        for (int j = 0; j < g.n; ++j)  // ascending prefix order; a prefix nobody differentiated contributes nothing
+            if (m < g.size[j] && g.p[j]) acc += reinterpret_cast<const float *>(g.p[j])[(size_t)b * g.size[j] * C + e];
+        out[(size_t)b * tot + e] = acc;
+    }
+}
+
+// dst: HOST array of nprefix device pointers (entries may be NULL: that prefix is not wanted), each (B, sizes[j], C) of 4-byte elements
+extern "C" int sn_prefix_pack(int B, int M, int C, int nprefix, const int *sizes, const void *src, void *const *dst, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && M >= 1 && C >= 1 && nprefix >= 1 && nprefix <= kMaxPrefixes && sizes && src && dst, "bad argument");
+    PrefixPtrs d{};
+    d.n = nprefix;
+    for (int j = 0; j < nprefix; ++j) {
+        SN_REQUIRE(sizes[j] >= 1 && sizes[j] <= M, "prefix size outside [1, M]");
+        d.p[j] = dst[j], d.size[j] = sizes[j];
+    }
+    const int blocks = std::min((M * C + 255) / 256, 64);
+    hipLaunchKernelGGL(prefix_pack_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, M, C, (const unsigned *)src, d);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// grads: HOST array of nprefix device pointers (NULL: no gradient came through that prefix), each (B, sizes[j], C) fp32 -> out (B, M, C)
+extern "C" int sn_prefix_scatter_sum(int B, int M, int C, int nprefix, const int *sizes, const float *const *grads, float *out,
+                                     sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && M >= 1 && C >= 1 && nprefix >= 1 && nprefix <= kMaxPrefixes && sizes && grads && out, "bad argument");
+    PrefixPtrs g{};
+    g.n = nprefix;
+    for (int j = 0; j < nprefix; ++j) {
+        SN_REQUIRE(sizes[j] >= 1 && sizes[j] <= M, "prefix size outside [1, M]");
+        g.p[j] = const_cast<float *>(grads[j]), g.size[j] = sizes[j];
+    }
+    const int blocks = std::min((M * C + 255) / 256, 64);
+    hipLaunchKernelGGL(prefix_scatter_sum_kernel, dim3(blocks, B), dim3(256), 0, (hipStream_t)stream, M, C, g, out);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The simplification losses of the first P nested prefixes (samplenet.py:171-181 per prefix, summed ascending as classification/
+// train_samplenet_progressive.py:204-216 adds them) behind ONE autograd node: forward = the per-cloud reductions of every prefix in
+// one launch + one combining workgroup; backward = the gradient on the simplified cloud of all P terms in one launch.  Every prefix's
+// term is reduced in simp_loss_partial_kernel's order and its gradient formed in chamfer_bwd_reg_kernel's order (own term first,
+// then the reference points that chose the target, ascending); the terms are added ascending, their gradients largest prefix first
+// (the order autograd accumulates the separate terms' gradients in): the same bits as P separate sn_simplification_loss_forward /
+// _backward calls on contiguous copies of the prefixes, without the copies (12 launches -> 3 at BASELINE configs[4]).  dq / iq (B,M): the per-query products of the FULL simplified set (they do not depend on the prefix);
+// d2 / i2 (S,B,N): sn_prefix_point_minima's products, prefix p at p * B * N.
+// ------------------------------------------------------------------------------------------------
+struct PrefixLoss {
+    int n;
+    int size[kMaxPrefixes];
+    float w[kMaxPrefixes];   // gamma + delta * size
+    float c1[kMaxPrefixes];  // 1 / (B size), formed on the host like sn_simplification_loss_backward's
+    float c2[kMaxPrefixes];  // w / (B N)
+    float cm;                // 1 / B
+};
+
+__global__ void __launch_bounds__(256) prefix_simp_partial_kernel(int M, int N, PrefixLoss pl, const float *__restrict__ dq,
+                                                                  const float *__restrict__ d2, float *__restrict__ part,
+                                                                  int *__restrict__ argmax1)
+{
+    __shared__ float r0[256], r1[256], r2[256];
+    __shared__ int ri[256];
+    const int b = blockIdx.x, p = blockIdx.y, B = gridDim.x, t = threadIdx.x;
+    const int n1 = pl.size[p];
+    const float *d1 = dq + (size_t)b * M, *dd = d2 + ((size_t)p * B + b) * N;
+    float s1 = 0.f, mx = -INFINITY, s2 = 0.f;
+    int am = 0;
+    for (int j = t; j < n1; j += 256) {
+        const float v = d1[j];
+        s1 += v;
+        if (v > mx) mx = v, am = j;
+    }
+    for (int j = t; j < N; j += 256) s2 += dd[j];
+    r0[t] = s1, r1[t] = mx, r2[t] = s2, ri[t] = am;
+    for (int s = 128; s > 0; s >>= 1) {
+        __syncthreads();
+        if (t < s) {
+            r0[t] += r0[t + s];
+            r2[t] += r2[t + s];
+            if (r1[t + s] > r1[t] || (r1[t + s] == r1[t] && ri[t + s] < ri[t])) r1[t] = r1[t + s], ri[t] = ri[t + s];
+        }
+    }
+    if (t == 0) {
+        float *o = part + ((size_t)p * B + b) * 3;
+        o[0] = r0[0], o[1] = r1[0], o[2] = r2[0];
+        argmax1[p * B + b] = ri[0];
+    }
+}
+
+__global__ void __launch_bounds__(64) prefix_simp_final_kernel(int B, int N, PrefixLoss pl, const float *__restrict__ part,
+                                                               float *__restrict__ loss)
+{
+    __shared__ float term[kMaxPrefixes];
+    const int p = threadIdx.x;
+    if (p < pl.n) {
+        const float *q = part + (size_t)p * B * 3;
+        float s1 = 0.f, mx = 0.f, s2 = 0.f;
+        for (int b = 0; b < B; ++b) s1 += q[b * 3], mx += q[b * 3 + 1], s2 += q[b * 3 + 2];
+        const float c12 = s1 / ((float)B * (float)pl.size[p]), cmax = mx / (float)B, c21 = s2 / ((float)B * (float)N);
+        term[p] = c12 + cmax + pl.w[p] * c21;
+    }
+    __syncthreads();
+    if (p == 0) {
+        float tot = term[0];
+        for (int j = 1; j < pl.n; ++j) tot += term[j];
+        loss[0] = tot;
+    }
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(256) prefix_simp_bwd_kernel(int M, int N, PrefixLoss pl, const float *__restrict__ T,
+                                                              const float *__restrict__ S, const int *__restrict__ iq,
+                                                              const int *__restrict__ i2, const int *__restrict__ argmax1,
+                                                              const float *__restrict__ gL, float *__restrict__ gradT)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x, B = gridDim.x;
+    T += (size_t)b * M * 3, S += (size_t)b * N * 3, iq += (size_t)b * M, gradT += (size_t)b * M * 3;
+    const float gLv = *gL;
+    float sx[PPL], sy[PPL], sz[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int l = i * 64 + lane;
+        const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)(l < N ? l : 0) * 3);
+        sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
+    }
+    for (int j = blockIdx.y * nwaves + wave; j < M; j += gridDim.y * nwaves) {
+        const float tx = T[j * 3], ty = T[j * 3 + 1], tz = T[j * 3 + 2];
+        const int j2 = iq[j];
+        const float dx = tx - S[j2 * 3 + 0], dy = ty - S[j2 * 3 + 1], dz = tz - S[j2 * 3 + 2];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        for (int p = pl.n - 1; p >= 0; --p) {  // largest prefix first: the order autograd adds the terms' gradients in (last term first)
+            const int n1 = pl.size[p];
+            if (j >= n1) continue;  // (wave-uniform)
+            const float g = gLv * (pl.c1[p] + (j == argmax1[p * B + b] ? pl.cm : 0.f)) * 2;
+            const float gg = gLv * (pl.c2[p] + 0.f) * 2;
+            float ax = g * dx, ay = g * dy, az = g * dz;
+            const int *is = i2 + ((size_t)p * B + b) * N;
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                const int l = i * 64 + lane;
+                sn_u64 mask = __ballot(l < N && is[l < N ? l : 0] == j);
+                if (mask) {
+                    const float cx = gg * (sx[i] - tx), cy = gg * (sy[i] - ty), cz = gg * (sz[i] - tz);
+                    while (mask) {
+                        const int t = __builtin_ctzll(mask);
+                        mask &= mask - 1;
+                        ax -= readlane_f(cx, t);
+                        ay -= readlane_f(cy, t);
+                        az -= readlane_f(cz, t);
+                    }
+                }
+            }
+            gx += ax, gy += ay, gz += az;
+        }
+        if (lane < 3) gradT[j * 3 + lane] = lane == 0 ? gx : (lane == 1 ? gy : gz);
+    }
+}
+
+static int prefix_loss_args(int B, int M, int N, int nterms, const int *sizes, const float *weights, PrefixLoss &pl)
+{
+    SN_REQUIRE(nterms >= 1 && nterms <= kMaxPrefixes && sizes && weights, "1..16 prefix terms");
+    pl.n = nterms;
+    for (int j = 0; j < nterms; ++j) {
+        SN_REQUIRE(sizes[j] >= 1 && sizes[j] <= M, "prefix size outside [1, M]");
+        pl.size[j] = sizes[j], pl.w[j] = weights[j];
+        pl.c1[j] = 1.0f / ((float)B * (float)sizes[j]), pl.c2[j] = weights[j] / ((float)B * (float)N);
+    }
+    pl.cm = 1.0f / (float)B;
+    return 0;
+}
+
+// partial: 3 * nterms * B floats, argmax1: nterms * B ints (kept for the backward), loss: device scalar = sum over the nterms
+// first prefixes of [mean(dq[:, :s]) + mean_b(max dq[:, :s]) + w * mean(d2[p])]
+extern "C" int sn_prefix_simplification_loss_forward(int B, int M, int N, int nterms, const int *sizes, const float *weights,
+                                                     const float *dq, const float *d2, float *partial, int *argmax1, float *loss,
+                                                     sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && M >= 1 && N >= 1 && dq && d2 && partial && argmax1 && loss, "bad argument");
+    PrefixLoss pl{};
+    if (int rc = prefix_loss_args(B, M, N, nterms, sizes, weights, pl)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(prefix_simp_partial_kernel, dim3(B, nterms), dim3(256), 0, st, M, N, pl, dq, d2, partial, argmax1);
+    hipLaunchKernelGGL(prefix_simp_final_kernel, dim3(1), dim3(64), 0, st, B, N, pl, partial, loss);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// grad_samp (B,M,3) = d loss / d samp_pc * *grad_loss (rows >= the largest of the nterms sizes: 0); N <= 2048
+extern "C" int sn_prefix_simplification_loss_backward(int B, int M, int N, int nterms, const int *sizes, const float *weights,
+                                                      const float *samp_pc, const float *ref_pc, const int *iq, const int *i2,
+                                                      const int *argmax1, const float *grad_loss, float *grad_samp, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && M >= 1 && N >= 1 && N <= 2048, "bad size (N <= 2048)");
+    SN_REQUIRE(samp_pc && ref_pc && iq && i2 && argmax1 && grad_loss && grad_samp, "null pointer");
+    PrefixLoss pl{};
+    if (int rc = prefix_loss_args(B, M, N, nterms, sizes, weights, pl)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(B, std::max(1, std::min((M + 3) / 4, (kChamferBwdGroups + B - 1) / B))), block(256);
+#define SN_PB(PPL_) \
+    hipLaunchKernelGGL(prefix_simp_bwd_kernel<PPL_>, grid, block, 0, st, M, N, pl, samp_pc, ref_pc, iq, i2, argmax1, grad_loss, grad_samp)
+    if (N <= 64) SN_PB(1);
+    else if (N <= 256) SN_PB(4);
+    else if (N <= 1024) SN_PB(16);
+    else SN_PB(32);
+#undef SN_PB
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 #ifdef SN_CS_TIMELINE
 // copies the first nblocks x 16 stamps of the last chamfer_soft_bwd_kernel launch to the host and clears them
 extern "C" int sn_debug_chamfer_soft_bwd_timeline(void *host, int nblocks)

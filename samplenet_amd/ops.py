@@ -147,6 +147,50 @@ def prefix_point_minima(ref_pc, samp_pc, sizes):
     return dist, idx
 
 
+class PrefixPackFunction(torch.autograd.Function):
+    """prefixes[j] = t[:, :sizes[j], :] as CONTIGUOUS tensors, all in one launch; backward: the sum of the prefixes' gradients
+    (zero-padded), ascending prefix order, in one launch (sn_prefix_pack / sn_prefix_scatter_sum).  t (B, M, C) fp32 / int32."""
+
+    @staticmethod
+    def forward(ctx, t, *sizes):
+        import ctypes
+
+        _need_gpu(t)
+        src = t.contiguous()
+        B, M, C = src.shape
+        S = len(sizes)
+        outs = [torch.empty(B, int(s), C, device=src.device, dtype=src.dtype) for s in sizes]
+        with torch.cuda.device(src.device):
+            check(lib.sn_prefix_pack(B, M, C, S, (ctypes.c_int * S)(*[int(s) for s in sizes]), ptr(src),
+                                     (ctypes.c_void_p * S)(*[ptr(o) for o in outs]), _stream(src)), "sn_prefix_pack")
+        ctx.shape, ctx.sizes = (B, M, C), tuple(int(s) for s in sizes)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+
+        B, M, C = ctx.shape
+        S = len(ctx.sizes)
+        if all(g is None for g in grads):
+            return (None,) * (1 + S)
+        gs = [(_f32c(g) if g is not None else None) for g in grads]
+        like = next(g for g in gs if g is not None)
+        out = torch.empty(B, M, C, device=like.device, dtype=torch.float32)
+        with torch.cuda.device(like.device):
+            check(lib.sn_prefix_scatter_sum(B, M, C, S, (ctypes.c_int * S)(*ctx.sizes), (ctypes.c_void_p * S)(*[ptr(g) for g in gs]),
+                                            ptr(out), _stream(like)), "sn_prefix_scatter_sum")
+        return (out,) + (None,) * S
+
+
+def prefix_pack(t, sizes):
+    """[t[:, :s, :].contiguous() for s in sizes] in one launch (and one for the backward).  t (B, M, C) or (B, M): fp32 / int32."""
+    if t.dim() == 2:
+        return [o.squeeze(2) for o in PrefixPackFunction.apply(t.unsqueeze(2), *sizes)]
+    return list(PrefixPackFunction.apply(t, *sizes))
+
+
 # --------------------------------------------------------------------------------------------- kNN
 def knn(k, ref, query, ref_layout=BCN, query_layout=BCN, return_dist=True):
     """K nearest `ref` points of every `query` point (no gradient).
@@ -489,6 +533,49 @@ class SimplificationLossFunction(torch.autograd.Function):
                                                       ptr(gl), ptr(g1), ptr(g2), ctx.samp_layout, _stream(x1)),
                   "sn_simplification_loss_backward")
         return g1, g2, None, None, None, None, None, None
+
+
+class PrefixSimplificationLossFunction(torch.autograd.Function):
+    """sum over the first len(sizes) nested prefixes of SimplificationLossFunction(samp_pc[:, :s], ref_pc, dist1[:, :s], idx1[:, :s],
+    dist2[p], idx2[p], weights[p]) -- the progressive sampler's loss (classification/train_samplenet_progressive.py:204-216) --
+    as ONE node: two launches forward, one backward, no copies of the prefixes; bit-identical to the separate terms added ascending.
+    samp_pc (B,M,3), ref_pc (B,N,3) [constant], dist1 / idx1 (B,M), dist2 / idx2 (S,B,N) from prefix_point_minima."""
+
+    @staticmethod
+    def forward(ctx, samp_pc, ref_pc, dist1, idx1, dist2, idx2, sizes, weights):
+        import ctypes
+
+        _need_gpu(samp_pc, ref_pc, dist1, dist2)
+        B, M = dist1.shape
+        N = dist2.shape[2]
+        P = len(sizes)
+        dev = dist1.device
+        partial = torch.empty(P * B * 3, device=dev, dtype=torch.float32)
+        argmax1 = torch.empty(P * B, device=dev, dtype=torch.int32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        cs, cw = (ctypes.c_int * P)(*[int(v) for v in sizes]), (ctypes.c_float * P)(*[float(w) for w in weights])
+        d1, d2 = _f32c(dist1), _f32c(dist2)
+        with torch.cuda.device(dev):
+            check(lib.sn_prefix_simplification_loss_forward(B, M, N, P, cs, cw, ptr(d1), ptr(d2), ptr(partial), ptr(argmax1), ptr(loss),
+                                                            _stream(d1)), "sn_prefix_simplification_loss_forward")
+        ctx.save_for_backward(samp_pc, ref_pc, idx1, idx2, argmax1)
+        ctx.cfg = (cs, cw, P)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        samp_pc, ref_pc, idx1, idx2, argmax1 = ctx.saved_tensors
+        cs, cw, P = ctx.cfg
+        x1, x2 = _f32c(samp_pc), _f32c(ref_pc)
+        B, M, _ = x1.shape
+        N = x2.shape[1]
+        g1 = torch.empty_like(x1)
+        gl = grad_loss.contiguous().float()
+        with torch.cuda.device(x1.device):
+            check(lib.sn_prefix_simplification_loss_backward(B, M, N, P, cs, cw, ptr(x1), ptr(x2), ptr(idx1.contiguous()),
+                                                             ptr(idx2.contiguous()), ptr(argmax1), ptr(gl), ptr(g1), _stream(x1)),
+                  "sn_prefix_simplification_loss_backward")
+        return g1, None, None, None, None, None, None, None
 
 
 class SamplerLossFunction(torch.autograd.Function):

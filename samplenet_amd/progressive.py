@@ -50,6 +50,14 @@ class SampleNetProgressive(SampleNet):
         """The first `size` points of a (B,M,3) ['bnc'] or (B,3,M) ['bcn'] cloud in the module's output layout."""
         return pc[:, :size, :] if self.output_shape == "bnc" else pc[:, :, :size]
 
+    def prefixes(self, pc, sizes=None):
+        """[prefix(pc, s) for s in sizes] (default: the module's sizes) as CONTIGUOUS tensors from one launch -- and their gradients
+        come back summed in one launch (ops.prefix_pack) -- for the 'bnc' output layout on the GPU; the plain slices otherwise."""
+        sizes = self.sizes if sizes is None else list(sizes)
+        if self.output_shape == "bnc" and pc.is_cuda and pc.dim() == 3 and pc.dtype == torch.float32 and len(sizes) <= 16:
+            return ops.prefix_pack(pc, sizes)
+        return [self.prefix(pc, s) for s in sizes]
+
     def get_progressive_simplification_loss(self, ref_pc, samp_pc, gamma=1, delta=0, reduction="sum"):
         """sum (classification) or mean (auto-encoder) over the sizes of
         get_simplification_loss(ref_pc, samp_pc[:, :s], s, gamma, delta)      [ref_pc, samp_pc: (B,N,3), (B,M,3)]"""
@@ -69,8 +77,16 @@ class SampleNetProgressive(SampleNet):
         else:
             _, _, dq, iq, _, _ = ops.chamfer_forward_impl(samp_pc.detach(), ref_pc.detach())
         d2, i2 = ops.prefix_point_minima(ref_pc, samp_pc, self.sizes)
+        # the terms of the proper prefixes as one autograd node (two launches forward, one backward, no copies of the prefixes);
+        # a reference cloud that takes a gradient itself, or more than 2048 points: term by term on contiguous copies
+        part = [s for s in self.sizes if s != M]
+        fused = bool(part) and samp_pc.is_cuda and not ref_pc.requires_grad and ref_pc.shape[1] <= 2048 and len(part) <= 16
         total = None
+        if fused:
+            total = ops.PrefixSimplificationLossFunction.apply(samp_pc, ref_pc, dq, iq, d2, i2, part, [gamma + delta * s for s in part])
         for j, s in enumerate(self.sizes):
+            if fused and s != M:
+                continue
             live = None
             if s == M and self.__dict__.get("_sn_surface_live"):  # the full size: the captured forward's own L_simp output
                 live = surface.simplification_loss(self, ref_pc, samp_pc, gamma + delta * s)

@@ -568,8 +568,7 @@ class PCRNet(nn.Module):
             wb += [fc.weight, fc.bias]
         y = _TrunkFunction.apply(f0.repeat(E, 1), f1, *wb)  # (E B, 7)
         out = []
-        for e in range(E):
-            ye = y[e * B:(e + 1) * B]
+        for ye in y.view(E, B, -1).unbind(0):  # (one stack in the backward instead of zeros + copy + add per evaluation)
             if rotate is not None:
                 twist, quat, qnorm, rotated = _HeadRotFunction.apply(ye, rotate)
                 out.append((twist, ye[:, 0:4], qnorm, quat, rotated))

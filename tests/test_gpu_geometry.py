@@ -676,3 +676,73 @@ def test_large_batch_scan_matches_the_oracle(oracle, B, N, M, K, kind):
     # (ChamferDistanceFunction returns dist1, dist2, idx1, idx2)
     assert np.array_equal(a[2][sel].cpu().numpy(), c1) and np.array_equal(a[4][sel].cpu().numpy(), ci1)
     assert np.array_equal(a[3][sel].cpu().numpy(), c2) and np.array_equal(a[5][sel].cpu().numpy(), ci2)
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 3), (32, 256, 3), (5, 100, 1), (2, 1000, 7)])
+def test_prefix_pack_and_its_gradient_equal_the_slices(shape):
+    """ops.prefix_pack (sn_prefix_pack / sn_prefix_scatter_sum: the progressive sampler's nested prefixes, classification/
+    train_samplenet_progressive.py:157-234, as contiguous tensors from one launch): bit-equal to the slices; the gradient equals
+    autograd through the slices (same ascending accumulation order -> bit-equal), also when a prefix receives no gradient; int32
+    payloads (the scan's indices) travel unchanged."""
+    from samplenet_amd import ops
+
+    B, M, C = shape
+    sizes = sorted({1, M // 4, M // 2, M - 1, M} - {0})
+    g = torch.Generator(device="cuda").manual_seed(5)
+    t = torch.randn(B, M, C, device="cuda", generator=g, requires_grad=True)
+    outs = ops.prefix_pack(t, sizes)
+    for o, s in zip(outs, sizes):
+        assert o.is_contiguous() and torch.equal(o, t[:, :s, :])
+    w = [torch.randn(B, s, C, device="cuda", generator=g) for s in sizes]
+    for skip in (None, 1):
+        terms = [(o * wi).sum() for j, (o, wi) in enumerate(zip(outs, w)) if j != skip]
+        refs = [(t[:, :s, :] * wi).sum() for j, (s, wi) in enumerate(zip(sizes, w)) if j != skip]
+        ga, = torch.autograd.grad(sum(terms), t, retain_graph=True)
+        acc = torch.zeros_like(t)  # ascending prefix order, zero-padded: what the kernel sums
+        for j, (s, wi) in enumerate(zip(sizes, w)):
+            if j != skip:
+                acc[:, :s, :] += wi
+        assert torch.equal(ga, acc)
+        gb, = torch.autograd.grad(sum(refs), t, retain_graph=True)
+        assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-6)
+    idx = torch.randint(0, 1 << 30, (B, M), device="cuda", dtype=torch.int32, generator=g)
+    for o, s in zip(ops.prefix_pack(idx, sizes), sizes):
+        assert o.dtype == torch.int32 and torch.equal(o, idx[:, :s])
+    with pytest.raises(RuntimeError):
+        ops.prefix_pack(t.detach(), [M + 1])
+
+
+@pytest.mark.parametrize("cfg", [(4, 200, 64, [8, 16, 32]), (32, 1024, 256, [32, 64, 128]), (3, 1500, 96, [5, 96]), (2, 60, 40, [1, 7, 39])])
+def test_prefix_simplification_loss_is_bit_identical_to_the_separate_terms(cfg):
+    """ops.PrefixSimplificationLossFunction (the progressive sampler's prefix terms, classification/train_samplenet_progressive.py:
+    204-216, as one node) against SimplificationLossFunction term by term on contiguous copies of the prefixes, added ascending:
+    the same loss and the same gradient on the simplified cloud, bit for bit."""
+    from samplenet_amd import ops
+
+    B, N, M, sizes = cfg
+    g = torch.Generator(device="cuda").manual_seed(B + N)
+    ref = torch.rand(B, N, 3, device="cuda", generator=g) - 0.5
+    samp = (torch.rand(B, M, 3, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    all_sizes = sizes if sizes[-1] == M else sizes + [M]
+    _, _, dq, iq, _, _ = ops.chamfer_forward_impl(samp.detach(), ref)
+    d2, i2 = ops.prefix_point_minima(ref, samp, all_sizes)
+    w = [1.0 + 0.02 * s for s in sizes]
+    fused = ops.PrefixSimplificationLossFunction.apply(samp, ref, dq, iq, d2, i2, sizes, w)
+    tot = None
+    for j, s in enumerate(sizes):
+        term = ops.SimplificationLossFunction.apply(samp[:, :s, :].contiguous(), ref, dq[:, :s].contiguous(), iq[:, :s].contiguous(),
+                                                    d2[j], i2[j], w[j])
+        tot = term if tot is None else tot + term
+    assert torch.equal(fused, tot)
+    ga, = torch.autograd.grad(fused * 0.37, samp)
+    gb, = torch.autograd.grad(tot * 0.37, samp)
+    assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-9)
+    # bit for bit: every term's own gradient, added largest prefix first (the order autograd adds them in)
+    acc = torch.zeros_like(samp)
+    for j in reversed(range(len(sizes))):
+        sl = samp.detach()[:, :sizes[j], :].contiguous().requires_grad_(True)
+        term = ops.SimplificationLossFunction.apply(sl, ref, dq[:, :sizes[j]].contiguous(), iq[:, :sizes[j]].contiguous(), d2[j], i2[j], w[j])
+        gj, = torch.autograd.grad(term * 0.37, sl)
+        acc[:, :sizes[j], :] += gj
+    assert torch.equal(ga, acc)
+    assert float(ga[:, sizes[-1]:].abs().sum()) == 0.0
