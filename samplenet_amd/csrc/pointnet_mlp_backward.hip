@@ -765,6 +765,14 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16 *p, int pitch)  // rows r
     return __builtin_bit_cast(bf16x8, v);
 }
 
+__device__ __forceinline__ bf16x8 lds_tr8_2(const __bf16 *plo, const __bf16 *phi)  // the two halves from separate addresses
+{
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(plo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(phi));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 #ifndef SN_CBX_PW
 #define SN_CBX_PW 3  // bit 0: the plain layers, bit 1: the layer above the xyz layer (the activation tile rebuilt from the coordinates)
 #endif
@@ -777,6 +785,12 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16 *p, int pitch)  // rows r
 #ifndef SN_CBX_ABL
 #define SN_CBX_ABL 0  // (timing experiments only: 1 no data-gradient MFMAs, 2 no weight-gradient MFMAs / fragment reads, 3 no dYprev stores,
 #endif                //  4 no staging, 5 no data-gradient epilogue -- results are then garbage)
+#ifndef SN_CBX_SWZ
+#define SN_CBX_SWZ 1  // conflict-free LDS layout of the 128 x 128 kernel's tile planes (CbxShape::SWZ); 0: the round-5 layout (A/B)
+#endif
+#ifndef SN_CBX_SKEW
+#define SN_CBX_SKEW 1  // the 128 x 128 kernel's two wave groups half a tile apart (see kSkew in conv_bwd_bx3_kernel); 0: in lockstep (A/B)
+#endif
 #ifndef SN_CBX_CONTIG
 #define SN_CBX_CONTIG 0  // (1: a contiguous range of tiles per workgroup -- measured equal to -6 %)
 #endif
@@ -784,7 +798,12 @@ template <int CI, int CO>
 struct CbxShape {
     static constexpr int TR = CO == 128 ? 32 : 64;                  // two tile buffers of three planes must fit the LDS
     static constexpr int KS = (CI == 64 && CO == 128) ? 2 : 1;      // 32 x 64 dgrad block = two 32 x 32 tiles: four waves split K too
-    static constexpr int LDZ = CO + 8, LDP = CI + 8;                // bf16 pitches
+    // bf16 pitches.  SWZ (128 x 128 tiles): 320-byte rows -- the four consecutive rows a 32-lane group of a transposing read touches
+    // land on four disjoint 16-bank windows (272-byte rows: 4-way conflicts, half of the kernel's LDS cycles) -- and, in the dZ planes,
+    // the 16-byte slots of a row XOR-ed with (row / 4) % 4, which keeps the data-gradient waves' row-wise 16-byte reads (lane groups
+    // {0-3, 12-15, 20-27}, ...) conflict-free at that pitch; the XOR stays inside a 64-byte window, so the transposing reads keep theirs
+    static constexpr bool SWZ = SN_CBX_SWZ != 0 && CO == 128;
+    static constexpr int LDZ = SWZ ? 160 : CO + 8, LDP = SWZ ? (CI == 128 ? 160 : 96) : CI + 8;  // (96: 192-byte rows, windows 0, 48, 32, 16)
     static constexpr int ZPL = TR * LDZ, PPL = TR * LDP;            // one plane
     static constexpr int BUF = 3 * (ZPL + PPL);                     // bf16 elements per tile buffer
     static constexpr int TSZ = 4 * 32 * 36;                         // floats: per dgrad wave 32 x 32 transpose scratch
@@ -804,7 +823,7 @@ __device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0
                                           const float4 *w3 = nullptr)
 {
     constexpr int ZSTEP = 256 / (CO / 4), PSTEP = 256 / (CI / 4);
-    constexpr int LDZ = CO + 8, LDP = CI + 8;
+    constexpr int LDZ = CbxShape<CI, CO>::LDZ, LDP = CbxShape<CI, CO>::LDP;
     const int R = g.dz.rows;
     const int row0 = tile * TR;
     const int zc4 = (tid % (CO / 4)) * 4, zr = tid / (CO / 4);
@@ -828,7 +847,7 @@ __device__ __forceinline__ void cbx_stage(const ConvBwdArgs &g, int tile, int n0
             const float m = row0 + rt < R ? 1.f : 0.f;
             v.x *= m, v.y *= m, v.z *= m, v.w *= m;
         }
-        stage_split_p<TR * LDZ, LDZ>(Zb, rt, zc4, v);
+        stage_split_p<TR * LDZ, LDZ>(Zb, rt, CbxShape<CI, CO>::SWZ ? zc4 ^ (((rt >> 2) & 3) << 3) : zc4, v);
     }
 #pragma unroll
     for (int q = 0; q < (SKIP_PS ? 0 : NP4); ++q) {
@@ -870,6 +889,12 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
     constexpr int NZ4 = TR * CO / 4 / 256, NP4 = TR * CI / 4 / 256;
     constexpr int NCB = CI / 32, NOB = CO / 32, RB = TR / 32;
     constexpr int KS = S::KS;              // dgrad waves per 32 x 32 tile (each takes a K range; summed through LDS)
+    // kSkew (128 x 128 tiles): the two wave groups run half a tile apart -- slot A: the data-gradient waves' MFMAs (two accumulator
+    // chains: they own the matrix pipe in this slot) beside the weight-gradient waves' staging of the next activation tile; slot B: the
+    // data-gradient epilogue + staging of the next dZ tile beside the weight-gradient MFMAs; one barrier per slot.  In lockstep (one
+    // barrier per tile) both groups' MFMAs share the pipe for 1.4 us and then both groups run VALU work with the pipe idle.
+    constexpr bool kSkew = SN_CBX_SKEW != 0 && PW && !IN3 && CI == 128 && CO == 128;
+    constexpr bool kDg2 = SN_CBX_DG2 != 0 || kSkew;
     constexpr int NDW = RB * NCB * KS;
     constexpr int NWT = NOB * NCB / 4;
     constexpr int KD = CO / 16 / KS, KW = TR / 16;  // K = 16 steps of a dgrad wave / of a row tile's wgrad
@@ -1033,13 +1058,17 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             f32x16 acc, acc2;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f, acc2[e] = 0.f;
-            const __bf16 *ap = Zb + (rb * 32 + l31) * LDZ + kh * KD * 16 + 8 * h;
+            // (SWZ: slot 2 kk + h of the row sits at slot (2 kk + h) ^ f, f = (row / 4) % 4: two base pointers, even and odd k-steps)
+            const int fsw = S::SWZ ? ((l31 >> 2) & 3) ^ h : 0;
+            const __bf16 *apr = Zb + (rb * 32 + l31) * LDZ + kh * KD * 16;
+            const __bf16 *ape = S::SWZ ? apr + (fsw << 3) : apr + 8 * h, *apo = S::SWZ ? apr + ((fsw ^ 2) << 3) : apr + 8 * h + 16;
 #pragma unroll
             for (int kk = 0; kk < (SN_CBX_ABL == 1 ? 0 : KD); ++kk) {
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(ap + kk * 16);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(ap + ZPL + kk * 16);
-                const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(ap + 2 * ZPL + kk * 16);
-                if (SN_CBX_DG2 && (kk & 1)) {
+                const __bf16 *ap = ((kk & 1) ? apo : ape) + (kk >> 1) * 32;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(ap);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(ap + ZPL);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8 *>(ap + 2 * ZPL);
+                if (kDg2 && (kk & 1)) {
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][2], acc2, 0, 0, 0);
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wf[kk][0], acc2, 0, 0, 0);
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][1], acc2, 0, 0, 0);
@@ -1055,10 +1084,11 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][0], acc, 0, 0, 0);
                 }
             }
-            if (SN_CBX_DG2)
+            if (kDg2)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
             if (it == 1) SN_TL(1);
+            if (kSkew) __syncthreads();  // end of slot A
             if (KS == 2) {  // the upper K range's partial tile joins the lower one's through the upper wave's scratch
                 float *Tx = Tf + (dwv | 1) * (32 * 36);
                 if (kh == 1)
@@ -1246,6 +1276,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) accw[n][e] = 0.f;
         if (PW) stage_p(Lb + 3 * ZPL, 0);
+        if (kSkew) load_p(tile0 + tst < tend ? tile0 + tst : tile0, 0);  // (slot A of the first tile stages it)
         __syncthreads();
         // transposing reads: this lane's row / channel offsets inside a [16 rows][32 channels] fragment block
         const int trr = 8 * h + ((lane & 15) >> 2), trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -1253,7 +1284,15 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         for (int it = 0; tile < tend; ++it, tile += tst) {
             const __bf16 *Zb = Lb + (it & 1) * BUF, *Pb = Zb + 3 * ZPL;
             const bool more = tile + tst < tend;
-            if (PW) {
+            if (kSkew) {
+                // slot A: the next activation tile (requested one slot ago) into the other buffer, beside the data-gradient MFMAs
+                if (more) stage_p(Lb + ((it + 1) & 1) * BUF + 3 * ZPL, 0);
+                if (it == 1) SN_TL(2);
+                __syncthreads();
+                if (it == 1) SN_TL(3);
+                load_p(tile + 2 * tst < tend ? tile + 2 * tst : tile, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (PW) {
                 // (PD == 2: set (it + 1) % 2 holds the next tile already; the set this tile's staging freed takes the one after)
                 if (PD == 2) {
                     if (it & 1) load_p(min(tile + 2 * tst, g.ntiles - 1), 1); else load_p(min(tile + 2 * tst, g.ntiles - 1), 0);
@@ -1262,7 +1301,9 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                 }
                 __builtin_amdgcn_sched_barrier(0);  // (the requests leave before the MFMAs, not next to the staging behind them)
             }
-            const __bf16 *ap = Zb + trr * LDZ + cob * 32 + trc;
+            // (SWZ: rows 16 kk + 8 h + 0..3 carry f = 2 h, the rows four below f = 2 h + 1)
+            const __bf16 *ap = Zb + trr * LDZ + (S::SWZ ? (cob * 32 + trc) ^ ((2 * h) << 3) : cob * 32 + trc);
+            const __bf16 *aph = Zb + (trr + 4) * LDZ + (S::SWZ ? (cob * 32 + trc) ^ ((2 * h + 1) << 3) : cob * 32 + trc);
             const __bf16 *bp = Pb + trr * LDP + trc;
             // fragments of k-step kk + 1 are requested BEFORE the MFMAs of k-step kk and the scheduler is held to that order: left
             // alone it interleaved a few transposing reads with a few MFMAs, each group behind its own wait (five to six exposed
@@ -1271,7 +1312,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             auto frag_load = [&](int kk, int s) __attribute__((always_inline)) {
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    fa[s][p] = lds_tr8(ap + p * ZPL + kk * 16 * LDZ, LDZ);
+                    fa[s][p] = lds_tr8_2(ap + p * ZPL + kk * 16 * LDZ, aph + p * ZPL + kk * 16 * LDZ);
 #pragma unroll
                     for (int n = 0; n < NWT; ++n) fb[s][p][n] = lds_tr8(bp + p * PPL + kk * 16 * LDP + ((q0 + n) % NCB) * 32, LDP);
                 }
@@ -1296,7 +1337,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             }
             if (it == 1) SN_TL(1);
             if (KS == 2) __syncthreads();  // (the dgrad waves' partial-tile hand-off)
-            if (PW && more && SN_CBX_ABL != 4) {
+            if (PW && !kSkew && more && SN_CBX_ABL != 4) {
                 if (PD == 2 && !(it & 1)) stage_p(Lb + ((it + 1) & 1) * BUF + 3 * ZPL, 1);
                 else stage_p(Lb + ((it + 1) & 1) * BUF + 3 * ZPL, 0);
             }

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "_ab", "libsamplenet_hip_tl.so"))
+lib = ctypes.CDLL(os.environ.get("TL_LIB") or os.path.join(ROOT, "tools", "_ab", "libsamplenet_hip_tl.so"))
 vp, i = ctypes.c_void_p, ctypes.c_int
 
 
