@@ -354,6 +354,9 @@ __device__ __forceinline__ void fx_local_add(long long &lo, long long *layer, in
     }
 }
 
+#ifndef SN_FWDP_ABL
+#define SN_FWDP_ABL 0  // (timing experiments only: 1 no MFMAs, 2 no staging of the next tile, 3 no stores of Z, 6 two accumulator chains)
+#endif
 template <class T, int KT, bool IN3A, int WPE>
 __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) linear_fwd_persist_kernel(FwdArgs g, int ntiles,
                                                                                                                          int tpw)
@@ -506,21 +509,37 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
     // overlaps the MFMAs of the others.
     const auto process = [&](int tile, float4 (&nxt)[NCH][A4]) {
         const int buf = (tile - tile0) & 1;
-        if (tile + 1 < tile1) stage(nxt, buf ^ 1);
+        if (tile + 1 < tile1 && SN_FWDP_ABL != 2) stage(nxt, buf ^ 1);
         if (tile + 3 < tile1) fetch_tile(nxt, tile + 3);
         const int row0 = tile * T::BM;
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         const __bf16 *At = Abuf + buf * ABUF;
+#if SN_FWDP_ABL == 6
+        f32x16 acc2;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+#endif
+#pragma unroll
+        for (int ks = 0; ks < (SN_FWDP_ABL == 1 ? 0 : KS); ++ks) {
             const __bf16 *Ap = At + (ks / (BKX / 16)) * ACH;
             const int kk = ks % (BKX / 16);
             bf16x8 a[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(Ap + (p * T::BM + wr * 32 + l31) * LDX + kk * 16 + 8 * h);
             // smallest products first (the order of bx3_chunk_g)
+#if SN_FWDP_ABL == 6
+            if (ks & 1) {
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][2], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], breg[ks][0], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][1], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][1], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][0], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][0], acc2, 0, 0, 0);
+                continue;
+            }
+#endif
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], breg[ks][0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][1], acc, 0, 0, 0);
@@ -528,6 +547,10 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], breg[ks][0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], breg[ks][0], acc, 0, 0, 0);
         }
+#if SN_FWDP_ABL == 6
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acc2[e];
+#endif
         // ---- epilogue: bias, column sums, pool candidates, 16-byte stores through the wave's transpose scratch
         float s0 = 0.f, s1 = 0.f, pmax = -INFINITY, pmin = INFINITY;
         int imax = 0, imin = 0;
@@ -545,7 +568,7 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
                 if (v > pmax) pmax = v, imax = row;
                 if (v < pmin) pmin = v, imin = row;
             }
-            if (g.z) {
+            if (g.z && SN_FWDP_ABL != 3) {
                 float *zt = g.z + (size_t)(row0 + wr * 32 + 16 * hf) * Co + wc * 32 + (lane & 7) * 4;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {

@@ -784,7 +784,7 @@ __device__ __forceinline__ bf16x8 lds_tr8_2(const __bf16 *plo, const __bf16 *phi
 #endif
 #ifndef SN_CBX_ABL
 #define SN_CBX_ABL 0  // (timing experiments only: 1 no data-gradient MFMAs, 2 no weight-gradient MFMAs / fragment reads, 3 no dYprev stores,
-#endif                //  4 no staging, 5 no data-gradient epilogue -- results are then garbage)
+#endif                //  4 no staging, 5 no data-gradient epilogue, 6 no Zprev re-loads for the epilogue -- results are then garbage)
 #ifndef SN_CBX_SWZ
 #define SN_CBX_SWZ 1  // conflict-free LDS layout of the 128 x 128 kernel's tile planes (CbxShape::SWZ); 0: the round-5 layout (A/B)
 #endif
@@ -1033,7 +1033,7 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
             if (!RZ1 && DM != 1 && (KS == 1 || kh == 0))
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    zq[e] = buf_load1(rs.zprev, qvo, (unsigned)tile * (TR * GP * 4) + ((e & 3) + 8 * (e >> 2)) * (GP * 4));
+                    zq[e] = SN_CBX_ABL == 6 ? 1.0f : buf_load1(rs.zprev, qvo, (unsigned)tile * (TR * GP * 4) + ((e & 3) + 8 * (e >> 2)) * (GP * 4));
             if (DM == 2)  // the first pass's raw data gradient at this lane's fragment positions
 #pragma unroll
                 for (int e = 0; e < 16; ++e)

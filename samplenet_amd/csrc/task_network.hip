@@ -40,6 +40,9 @@ __global__ void __launch_bounds__(256) split_planes_kernel(int n, const float *_
 // spread over the eight k-steps of block k + 1's MFMAs -- two waves share a SIMD and all eight meet at a barrier every block, so
 // an epilogue phase of its own is a phase in which no matrix instruction issues anywhere on the CU (measured: 63 us of which 31
 // were MFMA time); as fillers between MFMAs the same instructions are nearly free (MI355X_MICROARCH.md: <= 5 per gap).
+#ifndef SN_WIDE_X
+#define SN_WIDE_X 0  // (timing experiments: 1 no sched_barriers, 2 static priority for waves 4-7, 4 no epilogue fillers, 5 no weight-block traffic)
+#endif
 template <int K, bool STORE_Z, bool ARG>
 __global__ void __launch_bounds__(512) linear_fwd_wide_pool_kernel(WideArgs g)
 {
@@ -111,6 +114,7 @@ __global__ void __launch_bounds__(512) linear_fwd_wide_pool_kernel(WideArgs g)
     stage_b(Bs);
     __syncthreads();
     SN_TL(1);
+    if (SN_WIDE_X == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     const int rin0 = row0 % g.npts;                    // this wave's first row inside its cloud
     const int wpg = g.group_rows / 32, ngrp = 4 / wpg;  // row waves per key group, key groups per workgroup
     const int boff = (cw * 32 + l31) * PITCH + 8 * h;   // this lane's B fragment inside a plane of a buffer (k-step 0)
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(512) linear_fwd_wide_pool_kernel(WideArgs g)
         if (blk == 4) SN_TL(2);
         const __bf16 *cur = Bs + (blk & 1) * BUF + boff;
         const int col0 = blk_col(blk), colp = blk_col(blk - 1 + nblk);  // this block's first column, the previous block's
-        if (blk + 1 < nblk) fetch_b(blk_col(blk + 1));
+        if (blk + 1 < nblk && SN_WIDE_X != 5) fetch_b(blk_col(blk + 1));
         const float biasv = (mm && g.bias) ? g.bias[col0 + cw * 32 + l31] : 0.f;
         f32x16 acc;
 #pragma unroll
@@ -146,20 +150,20 @@ __global__ void __launch_bounds__(512) linear_fwd_wide_pool_kernel(WideArgs g)
 #define SN_WIDE_TERM(PA, PB) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][kk], b[kk & 1][PB], acc, 0, 0, 0)
                 // the six MFMAs of a k-step run on ONE accumulator: kept back to back (a filler between two of them costs ~43 cycles,
                 // MI355X_MICROARCH.md); the fragment reads and the epilogue pieces go between the groups
-                __builtin_amdgcn_sched_barrier(0);
+                if (SN_WIDE_X != 1) __builtin_amdgcn_sched_barrier(0);
                 SN_WIDE_TERM(0, 2);
                 SN_WIDE_TERM(2, 0);
                 SN_WIDE_TERM(1, 1);
                 SN_WIDE_TERM(0, 1);
                 SN_WIDE_TERM(1, 0);
                 SN_WIDE_TERM(0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                if (SN_WIDE_X != 1) __builtin_amdgcn_sched_barrier(0);
 #undef SN_WIDE_TERM
             }
             // the next block's weights (requested at the top of the iteration) go to the other buffer under the last MFMA groups; that
             // buffer's readers passed the barrier that ended iteration blk - 1
-            if (kk == KS - 2 && blk + 1 < nblk) stage_b(Bs + ((blk + 1) & 1) * BUF);
-            if (ep) {
+            if (kk == KS - 2 && blk + 1 < nblk && SN_WIDE_X != 5) stage_b(Bs + ((blk + 1) & 1) * BUF);
+            if (ep && SN_WIDE_X != 4) {
 #pragma unroll
                 for (int e = kk * EPK; e < (kk + 1) * EPK; ++e) {  // rows ascend with e inside a lane: strict compare = first occurrence
                     const float v = accp[e] + biasp;
