@@ -791,6 +791,10 @@ __device__ __forceinline__ bf16x8 lds_tr8_2(const __bf16 *plo, const __bf16 *phi
 #ifndef SN_CBX_SKEW
 #define SN_CBX_SKEW 1  // the 128 x 128 kernel's two wave groups half a tile apart (see kSkew in conv_bwd_bx3_kernel); 0: in lockstep (A/B)
 #endif
+#ifndef SN_CBX_SKEW_DG2
+#define SN_CBX_SKEW_DG2 0  // (1: two accumulator chains in the skewed kernel's data gradient -- measured equal, 795 vs 784-794 us: one chain
+                          //  issues at the pipe's rate, tools/micro/mfma_bf16_chain.hip; 0 keeps the round-5 kernel's bits)
+#endif
 #ifndef SN_CBX_CONTIG
 #define SN_CBX_CONTIG 0  // (1: a contiguous range of tiles per workgroup -- measured equal to -6 %)
 #endif
@@ -889,12 +893,12 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
     constexpr int NZ4 = TR * CO / 4 / 256, NP4 = TR * CI / 4 / 256;
     constexpr int NCB = CI / 32, NOB = CO / 32, RB = TR / 32;
     constexpr int KS = S::KS;              // dgrad waves per 32 x 32 tile (each takes a K range; summed through LDS)
-    // kSkew (128 x 128 tiles): the two wave groups run half a tile apart -- slot A: the data-gradient waves' MFMAs (two accumulator
-    // chains: they own the matrix pipe in this slot) beside the weight-gradient waves' staging of the next activation tile; slot B: the
+    // kSkew (128 x 128 tiles): the two wave groups run half a tile apart -- slot A: the data-gradient waves' MFMAs (they own the
+    // matrix pipe in this slot) beside the weight-gradient waves' staging of the next activation tile; slot B: the
     // data-gradient epilogue + staging of the next dZ tile beside the weight-gradient MFMAs; one barrier per slot.  In lockstep (one
     // barrier per tile) both groups' MFMAs share the pipe for 1.4 us and then both groups run VALU work with the pipe idle.
     constexpr bool kSkew = SN_CBX_SKEW != 0 && PW && !IN3 && CI == 128 && CO == 128;
-    constexpr bool kDg2 = SN_CBX_DG2 != 0 || kSkew;
+    constexpr bool kDg2 = SN_CBX_DG2 != 0 || (kSkew && SN_CBX_SKEW_DG2 != 0);
     constexpr int NDW = RB * NCB * KS;
     constexpr int NWT = NOB * NCB / 4;
     constexpr int KD = CO / 16 / KS, KW = TR / 16;  // K = 16 steps of a dgrad wave / of a row tile's wgrad
