@@ -533,6 +533,26 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BKX = 32;       // K chunk of the split-bf16 path
 constexpr int LDX = BKX + 8;  // LDS row pitch in bf16: 80 bytes -- 16 consecutive rows' 16-byte fragments tile all 64 banks
 
+// Staging map of the K chunks: item f (4 consecutive k of one row: 8 bytes per plane) -> row.  The 16 lanes of a ds_write_b64 lane
+// group hold two rows; rows x and x + 1 are 80 bytes apart (banks 20-35 wrap onto 0-3: a 2-way conflict on every store of the three
+// planes -- the 20-29 % conflict share of the forward kernels' LDS cycles in profiles/r06/lds_map.txt).  SN_BX3_ROWMAP=1 pairs rows x
+// and x + 4 instead (320 bytes apart: disjoint halves of the stores' 32 banks; a bijection inside every block of 8 rows) -- built and
+// measured in round 6: bit-identical, and NOT faster (B = 2048: 548.7 / 324.6 / 215.2 / 185.4 us against 551.0 / 330.0 / 214.1 / 183.1;
+// B = 32 equal): LDS stores are paced by the register transfer, not by the array (MI355X_MICROARCH.md, LDS).  Left off.
+#ifndef SN_BX3_ROWMAP
+#define SN_BX3_ROWMAP 0
+#endif
+__device__ __forceinline__ constexpr int bx3_row(int f)
+{
+    return SN_BX3_ROWMAP ? (((f >> 6) << 3) + ((f >> 4) & 3) + (((f >> 3) & 1) << 2)) : f / (BKX / 4);
+}
+static_assert(BKX == 32, "bx3_row: 8 items per row");
+// the same for 16-byte items (pre-split weight planes: 4 items per row, ds_write_b128 in lane groups of 8 = two rows)
+__device__ __forceinline__ constexpr int bx3_row8(int f)
+{
+    return SN_BX3_ROWMAP ? (((f >> 5) << 3) + ((f >> 3) & 3) + (((f >> 2) & 1) << 2)) : f / (BKX / 8);
+}
+
 __device__ __forceinline__ void split3(float a, __bf16 &h1, __bf16 &h2, __bf16 &h3)
 {
     h1 = (__bf16)a;
@@ -585,12 +605,12 @@ __device__ __forceinline__ void fetch_chunk_x(float4 (&ra)[Bx3<T>::A4], float4 (
 #pragma unroll
     for (int q = 0; q < Bx3<T>::A4; ++q) {
         const int f = tid + q * T::THREADS;
-        ra[q] = fa(f / (BKX / 4), k0 + (f % (BKX / 4)) * 4);
+        ra[q] = fa(bx3_row(f), k0 + (f % (BKX / 4)) * 4);
     }
 #pragma unroll
     for (int q = 0; q < Bx3<T>::B4; ++q) {
         const int f = tid + q * T::THREADS;
-        rb[q] = fb(f / (BKX / 4), k0 + (f % (BKX / 4)) * 4);
+        rb[q] = fb(bx3_row(f), k0 + (f % (BKX / 4)) * 4);
     }
 }
 // one K chunk: registers -> split -> LDS -> barrier -> [prefetch()] -> MFMAs -> barrier
@@ -605,7 +625,7 @@ __device__ __forceinline__ void bx3_chunk(f32x16 (&acc)[T::TM][T::TN], int k0, c
 #pragma unroll
         for (int q = 0; q < Bx3<T>::B4; ++q) {
             const int f = threadIdx.x + q * T::THREADS;
-            stage_split<T::BN>(Bp, f / (BKX / 4), (f % (BKX / 4)) * 4, rb[q]);
+            stage_split<T::BN>(Bp, bx3_row(f), (f % (BKX / 4)) * 4, rb[q]);
         }
     }, prefetch);
 }
@@ -620,7 +640,7 @@ __device__ __forceinline__ void bx3_chunk_g(f32x16 (&acc)[T::TM][T::TN], int k0,
 #pragma unroll
     for (int q = 0; q < Bx3<T>::A4; ++q) {
         const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
-        stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[q], k0 + k4));
+        stage_split<T::BM>(Ap, bx3_row(f), k4, xa(ra[q], k0 + k4));
     }
     stage_b(Bp);
     __syncthreads();
@@ -663,7 +683,7 @@ __device__ __forceinline__ void fetch_planes_x(bf16x8 (&rb)[Bx3P<T>::NB][3], con
 {
 #pragma unroll
     for (int q = 0; q < Bx3P<T>::NB; ++q) {
-        const int f = tid + q * T::THREADS, x = f / (BKX / 8), k8 = (f % (BKX / 8)) * 8;
+        const int f = tid + q * T::THREADS, x = bx3_row8(f), k8 = (f % (BKX / 8)) * 8;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             rb[q][p] = *reinterpret_cast<const bf16x8 *>(wp + ((size_t)p * co + col0 + x) * ci + k0 + k8);
@@ -674,7 +694,7 @@ __device__ __forceinline__ void stage_planes_x(__bf16 *__restrict__ Bp, const bf
 {
 #pragma unroll
     for (int q = 0; q < Bx3P<T>::NB; ++q) {
-        const int f = tid + q * T::THREADS, x = f / (BKX / 8), k8 = (f % (BKX / 8)) * 8;
+        const int f = tid + q * T::THREADS, x = bx3_row8(f), k8 = (f % (BKX / 8)) * 8;
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8 *>(Bp + (p * T::BN + x) * LDX + k8) = rb[q][p];
     }
@@ -718,7 +738,7 @@ __device__ __forceinline__ void fetch_a_x(float4 (&ra)[Bx3<T>::A4], const FA &fa
 #pragma unroll
     for (int q = 0; q < Bx3<T>::A4; ++q) {
         const int f = tid + q * T::THREADS;
-        ra[q] = fa(f / (BKX / 4), k0 + (f % (BKX / 4)) * 4);
+        ra[q] = fa(bx3_row(f), k0 + (f % (BKX / 4)) * 4);
     }
 }
 template <class T, class FA, class XA>

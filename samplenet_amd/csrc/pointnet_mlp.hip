@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
             for (int q = 0; q < A4; ++q) {
-                const int f = tid + q * T::THREADS, x = f / (BKX / 4), k = ch * BKX + (f % (BKX / 4)) * 4;
+                const int f = tid + q * T::THREADS, x = bx3_row(f), k = ch * BKX + (f % (BKX / 4)) * 4;
                 if constexpr (IN3A) {
                     const float *xr = g.x3 + (r0 + x) * 3;
                     ra[ch][q] = make_float4(xr[0], xr[1], xr[2], 0.f);
@@ -481,7 +481,7 @@ __global__ void __launch_bounds__(T::THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int q = 0; q < A4; ++q) {
                 const int f = tid + q * T::THREADS, k4 = (f % (BKX / 4)) * 4;
-                stage_split<T::BM>(Ap, f / (BKX / 4), k4, xa(ra[ch][q], ch * BKX + k4));
+                stage_split<T::BM>(Ap, bx3_row(f), k4, xa(ra[ch][q], ch * BKX + k4));
             }
         }
     };
