@@ -791,6 +791,10 @@ __device__ __forceinline__ bf16x8 lds_tr8_2(const __bf16 *plo, const __bf16 *phi
 #ifndef SN_CBX_SKEW
 #define SN_CBX_SKEW 1  // the 128 x 128 kernel's two wave groups half a tile apart (see kSkew in conv_bwd_bx3_kernel); 0: in lockstep (A/B)
 #endif
+#ifndef SN_CBX_LATE_ST
+#define SN_CBX_LATE_ST 0  // (1: the previous tile's dYprev stores behind the first k-step's MFMAs, see store_prev -- measured: 128 x 128 772 -> 765 us,
+                          //  64 -> 128 616 -> 648, 64 x 64 376 -> 395 at B = 2048: the acknowledgements are not what the waves wait for)
+#endif
 #ifndef SN_CBX_SKEW_DG2
 #define SN_CBX_SKEW_DG2 0  // (1: two accumulator chains in the skewed kernel's data gradient -- measured equal, 795 vs 784-794 us: one chain
                           //  issues at the pipe's rate, tools/micro/mfma_bf16_chain.hip; 0 keeps the round-5 kernel's bits)
@@ -1028,11 +1032,18 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
         __syncthreads();
         for (int it = 0; tile < tend; ++it, tile += tst) {
             const __bf16 *Zb = Lb + (it & 1) * BUF;
-            if (!IN3 && it > 0 && kh == 0 && SN_CBX_ABL != 3) {
-                const unsigned oso = (unsigned)(tile - tst) * (TR * GP * 4);
+            // the previous tile's dYprev leaves at the top of the iteration.  (The register allocator gives the accumulator the registers
+            // of `vout`, dead once stored, so the first MFMA waits for the four stores' acknowledgements -- s_waitcnt vmcnt on a store-data
+            // hazard.  SN_CBX_LATE_ST=1 issues them behind the first k-step's MFMAs instead, from registers of their own: measured, and
+            // not faster -- the write-back L2 acknowledges at once.)
+            const auto store_prev = [&]() __attribute__((always_inline)) {
+                if (!IN3 && it > 0 && kh == 0 && SN_CBX_ABL != 3) {
+                    const unsigned oso = (unsigned)(tile - tst) * (TR * GP * 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * GP * 4));
-            }
+                    for (int i = 0; i < 4; ++i) buf_store4(vout[i], rs.dyprev, ovo, oso + i * (8 * GP * 4));
+                }
+            };
+            if (!SN_CBX_LATE_ST || SN_CBX_ABL == 1) store_prev();
             float zq[16], pq[16];
             if (!RZ1 && DM != 1 && (KS == 1 || kh == 0))
 #pragma unroll
@@ -1086,6 +1097,11 @@ __global__ void __launch_bounds__(512) conv_bwd_bx3_kernel(ConvBwdArgs g)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[kk][0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[kk][0], acc, 0, 0, 0);
+                }
+                if (SN_CBX_LATE_ST && kk == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_prev();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (kDg2)
