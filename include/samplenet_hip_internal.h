@@ -370,6 +370,9 @@ int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat,
  * M points, ascending j (NULL entries contribute nothing). */
 int sn_prefix_pack(int B, int M, int C, int nprefix, const int *sizes, const void *src, void *const *dst, sn_stream_t stream);
 int sn_prefix_scatter_sum(int B, int M, int C, int nprefix, const int *sizes, const float *const *grads, float *out, sn_stream_t stream);
+/* sigma[0] = max(T^2, min_sigma) (registration/src/soft_projection.py:97-99: the projection loss of get_projection_loss) in one launch;
+ * its backward is sn_sigma_grad with the upstream gradient as the single partial. */
+int sn_sigma_forward(const float *temperature, float min_sigma, float *sigma, sn_stream_t stream);
 /* The simplification losses (samplenet.py:171-181) of the first nterms nested prefixes of the simplified cloud, summed ascending
  * (classification/train_samplenet_progressive.py:204-216), behind one node: dq / iq (B,M) the per-query Chamfer products of the full
  * set, d2 / i2 (S,B,N) sn_prefix_point_minima's products; partial 3 * nterms * B floats, argmax1 nterms * B ints (forward -> backward).

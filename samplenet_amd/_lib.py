@@ -30,6 +30,7 @@ PROTOTYPES = {
                                ctypes.c_longlong, _vp],
     "sn_soft_bwd_splits": [_i, _i],
     "sn_sigma_grad": [_i, _vp, _vp, _f, _vp, _vp],
+    "sn_sigma_forward": [_vp, _f, _vp, _vp],
     "sn_chamfer_forward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_chamfer_backward": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_simplification_loss_forward": [_i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp],

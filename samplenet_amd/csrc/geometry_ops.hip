@@ -1134,6 +1134,20 @@ __global__ void __launch_bounds__(256) sigma_grad_kernel(int nparts, const float
     sn::sigma_grad_block(nparts, partial, temperature, min_sigma, grad_T, gsigma_direct, direct_scale, red);
 }
 
+// sigma = max(T^2, min_sigma) (soft_projection.py:97-99) as a device scalar: the projection loss of a script, one launch
+// (torch: pow + maximum forward, seven launches backward; sn_sigma_grad with the upstream gradient as its one partial is the backward)
+__global__ void sigma_forward_kernel(const float *__restrict__ temperature, float min_sigma, float *__restrict__ sigma)
+{
+    if (threadIdx.x == 0) sigma[0] = sn_sigma(temperature[0], min_sigma);
+}
+extern "C" int sn_sigma_forward(const float *temperature, float min_sigma, float *sigma, sn_stream_t stream)
+{
+    SN_REQUIRE(temperature && sigma, "null pointer");
+    hipLaunchKernelGGL(sigma_forward_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, temperature, min_sigma, sigma);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int sn_sigma_grad(int nparts, const float *partial, const float *temperature, float min_sigma, float *grad_T,
                              sn_stream_t stream)
 {

@@ -316,6 +316,27 @@ def _grad_temperature(gsig, temperature, min_sigma):
     return gT.reshape(temperature.shape)
 
 
+class SigmaFunction(torch.autograd.Function):
+    """sigma = max(T^2, min_sigma) of the one-element temperature (soft_projection.py:97-99) -- what get_projection_loss returns -- as
+    one launch each way (torch: pow + maximum, and seven launches of their backwards); the same bits, torch.max's even split on a tie."""
+
+    @staticmethod
+    def forward(ctx, temperature, min_sigma):
+        _need_gpu(temperature)
+        T = temperature.detach().float().reshape(1)
+        out = torch.empty(1, device=T.device, dtype=torch.float32)
+        with torch.cuda.device(T.device):
+            check(lib.sn_sigma_forward(ptr(T), float(min_sigma), ptr(out), _stream(T)), "sn_sigma_forward")
+        ctx.save_for_backward(temperature)
+        ctx.min_sigma = float(min_sigma)
+        return out.reshape(temperature.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (temperature,) = ctx.saved_tensors
+        return _grad_temperature(_f32c(g).reshape(1), temperature, ctx.min_sigma), None
+
+
 class SoftProjectFunction(torch.autograd.Function):
     """Fused SoftProjection.project (soft_projection.py:138-152): kNN + softmax weights + weighted sum
     in ONE kernel (sn_pairscan_forward), optionally together with both Chamfer directions between the

@@ -66,6 +66,8 @@ class SoftProjection(nn.Module):
         if self._temperature_floor is not None:
             t = self._t()
             return torch.clamp(t * t, min=self._min_sigma_f)
+        if self._temperature.is_cuda and self._temperature.dtype == torch.float32 and self._temperature.numel() == 1:
+            return ops.SigmaFunction.apply(self._temperature, self._min_sigma_f)  # one launch each way
         device = self._temperature.device
         ms = self._min_sigma_dev.get(device)
         if ms is None:

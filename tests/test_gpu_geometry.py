@@ -746,3 +746,20 @@ def test_prefix_simplification_loss_is_bit_identical_to_the_separate_terms(cfg):
         acc[:, :sizes[j], :] += gj
     assert torch.equal(ga, acc)
     assert float(ga[:, sizes[-1]:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("T,ms", [(1.0, 1e-2), (0.05, 1e-2), (0.1, 1e-2), (-0.7, 1e-2), (0.3, 0.0), (0.0, 0.0)])
+def test_sigma_op_equals_torch(T, ms):
+    """SoftProjection.sigma() (registration/src/soft_projection.py:97-99: max(T^2, min_sigma), what get_projection_loss returns) as
+    ops.SigmaFunction -- one launch each way -- against the torch expression: the same value and the same gradient, bit for bit,
+    incl. the floor (no gradient), the exact tie (torch.max splits the gradient evenly) and a negative temperature."""
+    from samplenet_amd import SoftProjection
+
+    sp = SoftProjection(8, initial_temperature=T, is_temperature_trainable=True, min_sigma=ms).cuda()
+    s = sp.sigma()
+    t = sp._temperature.detach().clone().requires_grad_(True)
+    ref = torch.max(t ** 2, torch.tensor(ms, device="cuda", dtype=torch.float32))
+    assert s.shape == ref.shape and torch.equal(s.detach(), ref.detach())
+    (g,) = torch.autograd.grad(0.37 * s, sp._temperature)
+    (gr,) = torch.autograd.grad(0.37 * ref, t)
+    assert torch.equal(g, gr), (float(g), float(gr))
