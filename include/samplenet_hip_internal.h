@@ -370,6 +370,13 @@ int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const float *quat,
  * M points, ascending j (NULL entries contribute nothing). */
 int sn_prefix_pack(int B, int M, int C, int nprefix, const int *sizes, const void *src, void *const *dst, sn_stream_t stream);
 int sn_prefix_scatter_sum(int B, int M, int C, int nprefix, const int *sizes, const float *const *grads, float *out, sn_stream_t stream);
+/* Clouds of different sizes as one batch of equal-size clouds for a max-pooling extractor without BatchNorm (PCRNet's PointNetFeatures,
+ * registration/models/pcrnet.py:23-46): out[(j B + b), m, :] = src[j][b, m mod sizes[j], :] for m < len (src: HOST array of nclouds <= 16
+ * device pointers, cloud j (B, sizes[j], C) fp32); the pooled features of every cloud are unchanged, bit for bit.  _backward: the
+ * copies' gradients added onto their originals (grads[j] overwritten; NULL entries skipped). */
+int sn_cyclic_pad_cat(int B, int len, int C, int nclouds, const int *sizes, const float *const *src, float *out, sn_stream_t stream);
+int sn_cyclic_pad_cat_backward(int B, int len, int C, int nclouds, const int *sizes, const float *grad_out, float *const *grads,
+                               sn_stream_t stream);
 /* sigma[0] = max(T^2, min_sigma) (registration/src/soft_projection.py:97-99: the projection loss of get_projection_loss) in one launch;
  * its backward is sn_sigma_grad with the upstream gradient as the single partial. */
 int sn_sigma_forward(const float *temperature, float min_sigma, float *sigma, sn_stream_t stream);

@@ -65,6 +65,8 @@ PROTOTYPES = {
     "sn_prefix_simplification_loss_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_prefix_simplification_loss_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_prefix_pack": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_cyclic_pad_cat": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_cyclic_pad_cat_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_prefix_scatter_sum": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_knn": [_i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp],
     "sn_nn_matching": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp],

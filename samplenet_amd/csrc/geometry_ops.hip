@@ -2200,6 +2200,73 @@ extern "C" int sn_prefix_scatter_sum(int B, int M, int C, int nprefix, const int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Clouds of different sizes as ONE batch of equal-size clouds for a network whose only reduction over the points is a maximum (PCRNet's
+// PointNetFeatures, registration/models/pcrnet.py:23-46: per-point layers without BatchNorm + max-pool): cloud j (B, s_j, C) is
+// repeated cyclically up to `len` points -- out[(j B + b), m, :] = src_j[b, m mod s_j, :] -- which leaves every cloud's pooled features
+// unchanged, bit for bit (the copies add values the maximum already contains; the first occurrence wins ties, so the pooling backward
+// hands its gradient to the ORIGINAL row).  The progressive sampler's four prefixes (32 .. 256 points) then take one extractor pass of
+// 128 clouds x 256 points instead of four latency-bound passes.  Backward: the copies' gradients added onto their originals, in order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) cyclic_pad_cat_kernel(int B, int len, int C, PrefixPtrs s, float *__restrict__ out)
+{
+    const int jb = blockIdx.y, j = jb / B, b = jb - j * B;
+    const int sz = s.size[j];
+    const float *src = reinterpret_cast<const float *>(s.p[j]) + (size_t)b * sz * C;
+    float *dst = out + (size_t)jb * len * C;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len * C; e += gridDim.x * blockDim.x) {
+        const int m = e / C, c = e - m * C;
+        dst[e] = src[(m % sz) * C + c];
+    }
+}
+__global__ void __launch_bounds__(256) cyclic_pad_cat_bwd_kernel(int B, int len, int C, const float *__restrict__ gout, PrefixPtrs g)
+{
+    const int jb = blockIdx.y, j = jb / B, b = jb - j * B;
+    if (!g.p[j]) return;
+    const int sz = g.size[j];
+    float *dst = reinterpret_cast<float *>(g.p[j]) + (size_t)b * sz * C;
+    const float *src = gout + (size_t)jb * len * C;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < sz * C; e += gridDim.x * blockDim.x) {
+        const int m = e / C, c = e - m * C;
+        float acc = 0.f;
+        for (int r = m; r < len; r += sz) acc += src[r * C + c];  // the original first, then its copies in order
+        dst[e] = acc;
+    }
+}
+
+// src: HOST array of nclouds device pointers, cloud j (B, sizes[j], C) fp32 -> out (nclouds * B, len, C), len >= every size
+extern "C" int sn_cyclic_pad_cat(int B, int len, int C, int nclouds, const int *sizes, const float *const *src, float *out,
+                                 sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && len >= 1 && C >= 1 && nclouds >= 1 && nclouds <= kMaxPrefixes && sizes && src && out, "bad argument");
+    PrefixPtrs s{};
+    s.n = nclouds;
+    for (int j = 0; j < nclouds; ++j) {
+        SN_REQUIRE(sizes[j] >= 1 && sizes[j] <= len && src[j], "cloud size outside [1, len]");
+        s.p[j] = const_cast<float *>(src[j]), s.size[j] = sizes[j];
+    }
+    const int blocks = std::min((len * C + 255) / 256, 16);
+    hipLaunchKernelGGL(cyclic_pad_cat_kernel, dim3(blocks, nclouds * B), dim3(256), 0, (hipStream_t)stream, B, len, C, s, out);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+// grads: HOST array of nclouds device pointers (NULL: that cloud wants no gradient), cloud j (B, sizes[j], C), overwritten
+extern "C" int sn_cyclic_pad_cat_backward(int B, int len, int C, int nclouds, const int *sizes, const float *grad_out,
+                                          float *const *grads, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && len >= 1 && C >= 1 && nclouds >= 1 && nclouds <= kMaxPrefixes && sizes && grad_out && grads, "bad argument");
+    PrefixPtrs g{};
+    g.n = nclouds;
+    for (int j = 0; j < nclouds; ++j) {
+        SN_REQUIRE(sizes[j] >= 1 && sizes[j] <= len, "cloud size outside [1, len]");
+        g.p[j] = grads[j], g.size[j] = sizes[j];
+    }
+    const int blocks = std::min((len * C + 255) / 256, 16);
+    hipLaunchKernelGGL(cyclic_pad_cat_bwd_kernel, dim3(blocks, nclouds * B), dim3(256), 0, (hipStream_t)stream, B, len, C, grad_out, g);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // The simplification losses of the first P nested prefixes (samplenet.py:171-181 per prefix, summed ascending as classification/
 // train_samplenet_progressive.py:204-216 adds them) behind ONE autograd node: forward = the per-cloud reductions of every prefix in
 // one launch + one combining workgroup; backward = the gradient on the simplified cloud of all P terms in one launch.  Every prefix's

@@ -184,6 +184,47 @@ class PrefixPackFunction(torch.autograd.Function):
         return (out,) + (None,) * S
 
 
+class CyclicPadCatFunction(torch.autograd.Function):
+    """clouds (B, s_j, C) of different sizes -> (E B, len, C), every cloud repeated cyclically up to len = max s_j points (one launch
+    each way: sn_cyclic_pad_cat / _backward).  For a BatchNorm-free max-pooling extractor the padded batch gives every cloud's features
+    unchanged -- E evaluations as one pass."""
+
+    @staticmethod
+    def forward(ctx, *clouds):
+        import ctypes
+
+        _need_gpu(*clouds)
+        cs = [_f32c(c) for c in clouds]
+        B, _, C = cs[0].shape
+        E = len(cs)
+        sizes = [int(c.shape[1]) for c in cs]
+        P = max(sizes)
+        out = torch.empty(E * B, P, C, device=cs[0].device, dtype=torch.float32)
+        with torch.cuda.device(out.device):
+            check(lib.sn_cyclic_pad_cat(B, P, C, E, (ctypes.c_int * E)(*sizes), (ctypes.c_void_p * E)(*[ptr(c) for c in cs]), ptr(out),
+                                        _stream(out)), "sn_cyclic_pad_cat")
+        ctx.cfg = (B, P, C, tuple(sizes))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+
+        B, P, C, sizes = ctx.cfg
+        E = len(sizes)
+        g = _f32c(g)
+        outs = [torch.empty(B, s, C, device=g.device, dtype=torch.float32) if need else None
+                for s, need in zip(sizes, ctx.needs_input_grad)]
+        with torch.cuda.device(g.device):
+            check(lib.sn_cyclic_pad_cat_backward(B, P, C, E, (ctypes.c_int * E)(*sizes), ptr(g),
+                                                 (ctypes.c_void_p * E)(*[ptr(o) for o in outs]), _stream(g)), "sn_cyclic_pad_cat_backward")
+        return tuple(outs)
+
+
+def cyclic_pad_cat(clouds):
+    return CyclicPadCatFunction.apply(*clouds)
+
+
 def prefix_pack(t, sizes):
     """[t[:, :s, :].contiguous() for s in sizes] in one launch (and one for the backward).  t (B, M, C) or (B, M): fp32 / int32."""
     if t.dim() == 2:

@@ -562,7 +562,7 @@ class PCRNet(nn.Module):
         fcs = (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6)
         if not (E * B <= 128 and f0.shape[1] % 8 == 0 and E > 1):
             return [self.forward_with_qnorm(x0, x1, feat0=f0, rotate=rotate) for x1 in x1_list]
-        f1 = torch.cat([self.feat(x1) for x1 in x1_list], dim=0)
+        f1 = self._feat_multi(x1_list)
         wb = []
         for fc in fcs:
             wb += [fc.weight, fc.bias]
@@ -576,6 +576,20 @@ class PCRNet(nn.Module):
                 twist, quat, qnorm = _HeadFunction.apply(ye)
                 out.append((twist, ye[:, 0:4], qnorm, quat))
         return out
+
+    def _feat_multi(self, x1_list):
+        """self.feat of several source clouds, concatenated over the batch.  Clouds of DIFFERENT sizes (the progressive sampler's
+        prefixes) go through the extractor as ONE batch: every cloud repeated cyclically up to the largest size (ops.cyclic_pad_cat) --
+        the extractor has no BatchNorm and reduces over the points with a maximum only, so the copies change nothing (bit for bit) --
+        instead of one latency-bound pass per cloud.  Taken while the padded batch stays below ~2.5 x the clouds' own points."""
+        sizes = [x.shape[1] if self.input_shape == "bnc" else x.shape[2] for x in x1_list]
+        P = max(sizes)
+        if (len(x1_list) > 1 and len(set(sizes)) > 1 and len(x1_list) <= 16 and self.input_shape == "bnc" and x1_list[0].is_cuda
+                and P * len(sizes) <= 2.5 * sum(sizes) and type(self.feat) is PointNetFeatures):
+            from .ops import cyclic_pad_cat
+
+            return self.feat(cyclic_pad_cat(x1_list))  # (E B, K)
+        return torch.cat([self.feat(x1) for x1 in x1_list], dim=0)
 
     def forward_with_qnorm(self, x0, x1, feat0=None, rotate=None):
         """forward() plus the QuaterNet regulariser mean((||pre_normalized_quat||^2 - 1)^2) of registration/main.py:565 and the

@@ -1531,6 +1531,45 @@ def test_pcrnet_shared_template_features():
         assert torch.equal(a, b)
 
 
+def test_cyclic_pad_cat_and_the_one_pass_extractor():
+    """ops.cyclic_pad_cat (sn_cyclic_pad_cat / _backward) against torch indexing, and what it is for: PCRNet's extractor (per-point
+    layers without BatchNorm + a maximum over the points, registration/models/pcrnet.py:23-46) on the progressive sampler's four
+    prefixes as ONE batch of 128 clouds x 256 points gives every prefix's features and the gradient to every prefix EQUAL, bit for
+    bit, to its own pass (BASELINE configs[4]'s shape: the padded batch runs the wide pooled layer, the single passes the tile kernel)."""
+    from samplenet_amd import ops
+    from samplenet_amd import task_features as TF
+
+    g = torch.Generator(device="cuda").manual_seed(12)
+    B, sizes = 5, [3, 7, 8, 20]
+    cl = [torch.randn(B, s, 3, device="cuda", generator=g).requires_grad_(s != 7) for s in sizes]
+    out = ops.cyclic_pad_cat(cl)
+    P = max(sizes)
+    ref = torch.cat([c[:, torch.arange(P, device="cuda") % c.shape[1], :] for c in cl], dim=0)
+    assert out.shape == (len(sizes) * B, P, 3) and torch.equal(out, ref)
+    w = torch.randn_like(out)
+    need = [c for c in cl if c.requires_grad]
+    ga = torch.autograd.grad((out * w).sum(), need)
+    gb = torch.autograd.grad((ref * w).sum(), need)
+    for a, b in zip(ga, gb):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+
+    torch.manual_seed(4)
+    pcr = TF.PCRNet(bottleneck_size=1024, input_shape="bnc").cuda().eval()
+    for p in pcr.parameters():
+        p.requires_grad_(False)
+    B, sizes = 32, [32, 64, 128, 256]
+    cloud = torch.rand(B, 256, 3, device="cuda", generator=g) - 0.5
+    qs = [cloud[:, :s, :].contiguous().requires_grad_(True) for s in sizes]
+    f_multi = pcr._feat_multi(qs)
+    f_single = torch.cat([pcr.feat(q) for q in qs], dim=0)
+    assert torch.equal(f_multi, f_single)
+    wf = torch.randn_like(f_multi)
+    gm = torch.autograd.grad((f_multi * wf).sum(), qs)
+    gs = torch.autograd.grad((f_single * wf).sum(), qs)
+    for a, b in zip(gm, gs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,N", [(32, 64), (4, 256), (3, 50), (2, 1024)])
 def test_task_features_narrow_backward(B, N):
     """Frozen PointNetFeatures: the data gradient through conv4..conv1 as one launch (sn_pointnet_narrow_backward, split-bf16 MFMAs
