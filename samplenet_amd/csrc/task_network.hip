@@ -1087,6 +1087,20 @@ __global__ void __launch_bounds__(kPdsThreads) pool_dgrad_sparse_kernel(int npts
     const int ci = ci0 + l;
     const bool act = ci < Ci;
     float *out = lds + wave * (kPdsPts * 64) + hh * 32 + l;  // + row * 64
+    // A workgroup whose rows hold no maximum of its cloud writes zeros and leaves before it has touched the weights or its LDS tile:
+    // clouds that are cyclic repetitions of a shorter cloud (ops.cyclic_pad_cat: the progressive sampler's prefixes as one batch) have
+    // every maximum in their first copy, i.e. three of the four row chunks of a 64-point cloud padded to 256 are empty.
+    if (gridDim.z > 1) {  // (a cloud of one chunk holds all of its maxima: nothing to ask)
+        bool hit = false;
+        for (int c = threadIdx.x; c < Co; c += kPdsThreads) hit |= (unsigned)(argsel[(size_t)b * Co + c] - r0) < (unsigned)nch;
+        if (!__syncthreads_or(hit)) {
+            for (int e = threadIdx.x; e < nch * kPdsCi; e += kPdsThreads) {
+                const int n = e >> 5, col = e & 31;
+                if (ci0 + col < Ci) dyprev[((size_t)b * npts + r0 + n) * Ci + ci0 + col] = 0.f;
+            }
+            return;
+        }
+    }
     {
         float4 *z4 = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < 8 * kPdsPts * 64 / 4; i += kPdsThreads) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
