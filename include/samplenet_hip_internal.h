@@ -377,6 +377,24 @@ int sn_prefix_scatter_sum(int B, int M, int C, int nprefix, const int *sizes, co
 int sn_cyclic_pad_cat(int B, int len, int C, int nclouds, const int *sizes, const float *const *src, float *out, sn_stream_t stream);
 int sn_cyclic_pad_cat_backward(int B, int len, int C, int nclouds, const int *sizes, const float *grad_out, float *const *grads,
                                sn_stream_t stream);
+/* Several evaluations of the registration task term against ONE template in one batch (the progressive sampler's prefixes,
+ * classification/train_samplenet_progressive.py:181-216 with registration/main.py:557-577 as the task): rows / clouds [e group, (e+1) group)
+ * are evaluation e.
+ *   sn_pcrnet_head_rot_*_grouped : sn_pcrnet_head_rot_* on R = E group rows, v = the `group` template clouds (row b rotates v[b % group]),
+ *                                  qnorm / grad_qnorm one value per evaluation;
+ *   sn_chamfer_mean_loss_*_grouped: mean(dist1) + mean(dist2) per evaluation on clouds padded to n1 points by sn_cyclic_pad_cat, nvalid[e]
+ *                                  of them real (HOST array): the copies are not counted forward and get / give no gradient backward.
+ * Every number equals the evaluation's own ungrouped call on the unpadded cloud, bit for bit. */
+int sn_pcrnet_head_rot_forward_grouped(int R, int N, int group, const float *y, const float *v, float *twist, float *quat, float *qnorm,
+                                       float *out, sn_stream_t stream);
+int sn_pcrnet_head_rot_backward_grouped(int R, int N, int group, const float *y, const float *quat, const float *v, const float *grad_out,
+                                        const float *grad_twist, const float *grad_quat, const float *grad_qnorm, float *grad_y,
+                                        sn_stream_t stream);
+int sn_chamfer_mean_loss_forward_grouped(int R, int n1, int n2, int group, int nev, const int *nvalid, const float *dist1,
+                                         const float *dist2, float *partial, float *loss, sn_stream_t stream);
+int sn_chamfer_mean_loss_backward_grouped(int R, int n1, const float *xyz1, int n2, const float *xyz2, int group, int nev, const int *nvalid,
+                                          const int *idx1, const int *idx2, const float *grad_loss, float *grad_xyz1, float *grad_xyz2,
+                                          sn_stream_t stream);
 /* sigma[0] = max(T^2, min_sigma) (registration/src/soft_projection.py:97-99: the projection loss of get_projection_loss) in one launch;
  * its backward is sn_sigma_grad with the upstream gradient as the single partial. */
 int sn_sigma_forward(const float *temperature, float min_sigma, float *sigma, sn_stream_t stream);

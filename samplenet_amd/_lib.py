@@ -65,6 +65,10 @@ PROTOTYPES = {
     "sn_prefix_simplification_loss_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_prefix_simplification_loss_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_prefix_pack": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_pcrnet_head_rot_forward_grouped": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_pcrnet_head_rot_backward_grouped": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_chamfer_mean_loss_forward_grouped": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sn_chamfer_mean_loss_backward_grouped": [_i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_cyclic_pad_cat": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_cyclic_pad_cat_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "sn_prefix_scatter_sum": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],

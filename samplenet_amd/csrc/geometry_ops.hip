@@ -34,6 +34,8 @@ struct sn_xyz3 {
     float x, y, z;
 };
 
+constexpr int kMaxPrefixes = 16;  // nested prefixes / grouped evaluations a launch takes by value
+
 struct ImplicitGrad {
     const float *gL;
     const int *argmax_t, *argmax_s;
@@ -967,6 +969,177 @@ extern "C" int sn_chamfer_mean_loss_backward(int B, int n1, const float *xyz1, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// The Chamfer term of the registration task loss for SEVERAL evaluations in one batch (the progressive sampler's prefixes against one
+// template: clouds [e group, (e + 1) group) are evaluation e): xyz1 (R, n1, 3) holds clouds of nv[e] <= n1 valid points each -- the rest
+// are cyclic copies (sn_cyclic_pad_cat), which the scan may see (a copy never wins a minimum: the lowest index does) but the loss must
+// not count --, xyz2 (R, n2, 3).  loss[e] = mean over the evaluation's clouds and VALID points of dist1 + mean of dist2, reduced in
+// sn_chamfer_mean_loss_forward's order; the backward is chamfer_bwd_reg_kernel's with the evaluation's own upstream gradient and
+// 1 / (group nv[e]), copies as targets get zero and as sources are skipped: every number equals the evaluation's own
+// sn_chamfer_mean_loss_forward / _backward on the unpadded cloud, bit for bit -- 2 + 2 launches where E evaluations take 2 E + 2 E.
+// ------------------------------------------------------------------------------------------------
+struct GroupSizes {
+    int n;
+    int nv[kMaxPrefixes];
+};
+__global__ void __launch_bounds__(256) chamfer_mean_grouped_partial_kernel(int n1, int n2, int group, GroupSizes gs,
+                                                                           const float *__restrict__ d1, const float *__restrict__ d2,
+                                                                           float *__restrict__ part)
+{
+    __shared__ float r0[256], r2[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int nv = gs.nv[b / group];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = t; j < nv; j += 256) s1 += d1[(size_t)b * n1 + j];
+    for (int j = t; j < n2; j += 256) s2 += d2[(size_t)b * n2 + j];
+    r0[t] = s1, r2[t] = s2;
+    for (int s = 128; s > 0; s >>= 1) {
+        __syncthreads();
+        if (t < s) r0[t] += r0[t + s], r2[t] += r2[t + s];
+    }
+    if (t == 0) part[b * 2] = r0[0], part[b * 2 + 1] = r2[0];
+}
+__global__ void __launch_bounds__(64) chamfer_mean_grouped_final_kernel(int n2, int group, GroupSizes gs, const float *__restrict__ part,
+                                                                        float *__restrict__ loss)
+{
+    const int e = threadIdx.x;
+    if (e >= gs.n) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = e * group; b < (e + 1) * group; ++b) s1 += part[b * 2], s2 += part[b * 2 + 1];
+    const float c12 = s1 / ((float)group * (float)gs.nv[e]), c21 = s2 / ((float)group * (float)n2);
+    loss[e] = c12 + 1.0f * c21;
+}
+
+static int group_sizes(int R, int n1, int group, int nev, const int *nvalid, GroupSizes &gs)
+{
+    SN_REQUIRE(group >= 1 && nev >= 1 && nev <= kMaxPrefixes && R == nev * group && nvalid, "R = nev * group, at most 16 evaluations");
+    gs.n = nev;
+    for (int e = 0; e < nev; ++e) {
+        SN_REQUIRE(nvalid[e] >= 1 && nvalid[e] <= n1, "valid points outside [1, n1]");
+        gs.nv[e] = nvalid[e];
+    }
+    return 0;
+}
+
+// dist1 (R, n1), dist2 (R, n2): sn_chamfer_forward's products of the padded batch; partial: 2 R floats; loss: nev floats
+extern "C" int sn_chamfer_mean_loss_forward_grouped(int R, int n1, int n2, int group, int nev, const int *nvalid, const float *dist1,
+                                                    const float *dist2, float *partial, float *loss, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && n1 >= 1 && n2 >= 1 && dist1 && dist2 && partial && loss, "bad argument");
+    GroupSizes gs{};
+    if (int rc = group_sizes(R, n1, group, nev, nvalid, gs)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(chamfer_mean_grouped_partial_kernel, dim3(R), dim3(256), 0, st, n1, n2, group, gs, dist1, dist2, partial);
+    hipLaunchKernelGGL(chamfer_mean_grouped_final_kernel, dim3(1), dim3(64), 0, st, n2, group, gs, partial, loss);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// chamfer_bwd_reg_kernel for grouped evaluations: gL one upstream gradient per evaluation; ntv / nsv = the evaluation's valid targets /
+// sources (the other side: all of them); ct / cs as sn_chamfer_mean_loss_backward forms them, per evaluation
+struct GroupedGrad {
+    const float *gL;
+    int group;
+    int t_valid;  // 1: the TARGET side is the padded one (nv[] bounds the targets), 0: the source side
+    GroupSizes gs;
+    float c_pad[kMaxPrefixes];  // 1 / (group nv[e]): the coefficient of the padded side
+    float c_full;               // 1 / (group n_other)
+};
+template <int PPL>
+__global__ void __launch_bounds__(256) chamfer_bwd_grouped_kernel(int nt, int ns, const float *__restrict__ T, const float *__restrict__ S,
+                                                                  const int *__restrict__ idxT, const int *__restrict__ idxS,
+                                                                  float *__restrict__ gradT, int own_first, GroupedGrad gg)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x, e = b / gg.group;
+    T += (size_t)b * nt * 3, S += (size_t)b * ns * 3;
+    idxT += (size_t)b * nt, idxS += (size_t)b * ns;
+    gradT += (size_t)b * nt * 3;
+    const float gLv = gg.gL[e] * 1.f;
+    const float ct = gg.t_valid ? gg.c_pad[e] : gg.c_full, cs = gg.t_valid ? gg.c_full : gg.c_pad[e];
+    const int ntv = gg.t_valid ? gg.gs.nv[e] : nt, nsv = gg.t_valid ? ns : gg.gs.nv[e];
+    float sx[PPL], sy[PPL], sz[PPL], gs2[PPL];
+    int is[PPL];
+#pragma unroll
+    for (int i = 0; i < PPL; ++i) {
+        const int l = i * 64 + lane;
+        const int lc = l < ns ? l : 0;
+        const sn_xyz3 sv = *reinterpret_cast<const sn_xyz3 *>(S + (size_t)lc * 3);
+        sx[i] = sv.x, sy[i] = sv.y, sz[i] = sv.z;
+        is[i] = l < nsv ? idxS[lc] : -1;  // (copies among the sources are not counted)
+        gs2[i] = (gLv * (cs + 0.f)) * 2;
+    }
+    for (int j = blockIdx.y * nwaves + wave; j < nt; j += gridDim.y * nwaves) {
+        if (j >= ntv) {  // a copy among the targets: no gradient
+            if (lane < 3) gradT[j * 3 + lane] = 0.f;
+            continue;
+        }
+        const float tx = T[j * 3], ty = T[j * 3 + 1], tz = T[j * 3 + 2];
+        const int j2 = idxT[j];
+        const float g = (gLv * (ct + 0.f)) * 2;
+        const float ox = g * (tx - S[j2 * 3 + 0]);
+        const float oy = g * (ty - S[j2 * 3 + 1]);
+        const float oz = g * (tz - S[j2 * 3 + 2]);
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (own_first) ax += ox, ay += oy, az += oz;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            sn_u64 mask = __ballot(is[i] == j);
+            if (mask) {
+                const float cx = gs2[i] * (sx[i] - tx), cy = gs2[i] * (sy[i] - ty), cz = gs2[i] * (sz[i] - tz);
+                while (mask) {
+                    const int t = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    ax -= readlane_f(cx, t);
+                    ay -= readlane_f(cy, t);
+                    az -= readlane_f(cz, t);
+                }
+            }
+        }
+        if (!own_first) ax += ox, ay += oy, az += oz;
+        if (lane < 3) gradT[j * 3 + lane] = lane == 0 ? ax : (lane == 1 ? ay : az);
+    }
+}
+
+// grad_xyz1 (R, n1, 3) [zero at the copies] and / or grad_xyz2 (R, n2, 3); grad_loss: nev floats on the device; n1, n2 <= 2048
+extern "C" int sn_chamfer_mean_loss_backward_grouped(int R, int n1, const float *xyz1, int n2, const float *xyz2, int group, int nev,
+                                                     const int *nvalid, const int *idx1, const int *idx2, const float *grad_loss,
+                                                     float *grad_xyz1, float *grad_xyz2, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && n1 >= 1 && n2 >= 1 && n1 <= 2048 && n2 <= 2048, "bad size (at most 2048 points a side)");
+    SN_REQUIRE(xyz1 && xyz2 && idx1 && idx2 && grad_loss, "null pointer");
+    GroupedGrad gg{};
+    if (int rc = group_sizes(R, n1, group, nev, nvalid, gg.gs)) return rc;
+    gg.gL = grad_loss, gg.group = group;
+    for (int e = 0; e < nev; ++e) gg.c_pad[e] = 1.0f / ((float)group * (float)nvalid[e]);
+    gg.c_full = 1.0f / ((float)group * (float)n2);
+    hipStream_t st = (hipStream_t)stream;
+    auto ysplit = [&](int nt) { return std::max(1, std::min((nt + 3) / 4, (kChamferBwdGroups + R - 1) / R)); };
+#define SN_CBG(PPL_, NT, NS, TT, SS, IT, IS, GT, OF)                                                                              \
+    hipLaunchKernelGGL(chamfer_bwd_grouped_kernel<PPL_>, dim3(R, ysplit(NT)), dim3(256), 0, st, NT, NS, TT, SS, IT, IS, GT, OF, gg)
+#define SN_CBG_ANY(NT, NS, TT, SS, IT, IS, GT, OF)           \
+    do {                                                     \
+        if (NS <= 64) SN_CBG(1, NT, NS, TT, SS, IT, IS, GT, OF);        \
+        else if (NS <= 256) SN_CBG(4, NT, NS, TT, SS, IT, IS, GT, OF);  \
+        else if (NS <= 1024) SN_CBG(16, NT, NS, TT, SS, IT, IS, GT, OF); \
+        else SN_CBG(32, NT, NS, TT, SS, IT, IS, GT, OF);                \
+    } while (0)
+    if (grad_xyz1) {
+        gg.t_valid = 1;
+        SN_CBG_ANY(n1, n2, xyz1, xyz2, idx1, idx2, grad_xyz1, 1);
+    }
+    if (grad_xyz2) {
+        gg.t_valid = 0;
+        SN_CBG_ANY(n2, n1, xyz2, xyz1, idx2, idx1, grad_xyz2, 0);
+    }
+#undef SN_CBG_ANY
+#undef SN_CBG
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // PCRNet's output head (registration/models/pcrnet.py:78-82 + the QuaterNet regulariser of registration/main.py:565):
 //   twist (B,7) = [ y[:, 0:4] / max(||y[:, 0:4]||, 1e-12) | y[:, 4:7] ],   qnorm = mean_b (||y[:, 0:4]||^2 - 1)^2
 // one single-workgroup launch forward, one backward (torch: slice, norm, clamp, expand, div, cat + pow, sum, sub, pow, mean and
@@ -1787,12 +1960,15 @@ __global__ void __launch_bounds__(256) qrot_bwd_kernel(int N, const float *__res
 //             workgroup (0, b) stores twist[b] / quat[b]; workgroup (0, 0) also the regulariser (fixed-order sum over the batch).
 //   backward: one workgroup per cloud: gv (optional), the quaternion's gradient by the fixed-order reduction of qrot_bwd_kernel,
 //             then the head's backward of row b with that gradient in the place of g_quat.
+// group > 0 (several evaluations against ONE template, the progressive sampler's prefixes): rows [e group, (e + 1) group) are evaluation e,
+// v holds `group` clouds (row b rotates v[b % group]) and qnorm / g_qnorm hold one value per evaluation; 0: one evaluation of B rows.
 __global__ void __launch_bounds__(256) pcrnet_head_rot_fwd_kernel(int B, int N, const float *__restrict__ y, const float *__restrict__ v,
                                                                   float *__restrict__ twist, float *__restrict__ quat,
-                                                                  float *__restrict__ qnorm, float *__restrict__ out)
+                                                                  float *__restrict__ qnorm, float *__restrict__ out, int group)
 {
     __shared__ float red[256];
     const int b = blockIdx.y;
+    const int vb = group ? b % group : b;
     const float *r = y + (size_t)b * 7;
     const float n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3];
     const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
@@ -1805,17 +1981,19 @@ __global__ void __launch_bounds__(256) pcrnet_head_rot_fwd_kernel(int B, int N, 
     const float w = q0;
     const sn_v3 u{q1, q2, q3};
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-        const sn_xyz3 p = *reinterpret_cast<const sn_xyz3 *>(v + ((size_t)b * N + n) * 3);
+        const sn_xyz3 p = *reinterpret_cast<const sn_xyz3 *>(v + ((size_t)vb * N + n) * 3);
         const sn_v3 x{p.x, p.y, p.z};
         const sn_v3 uv = cross3(u, x), uuv = cross3(u, uv);
         sn_xyz3 o;
         o.x = x.x + 2.0f * (w * uv.x + uuv.x), o.y = x.y + 2.0f * (w * uv.y + uuv.y), o.z = x.z + 2.0f * (w * uv.z + uuv.z);
         *reinterpret_cast<sn_xyz3 *>(out + ((size_t)b * N + n) * 3) = o;
     }
-    if (blockIdx.x != 0 || b != 0 || !qnorm) return;
+    if (blockIdx.x != 0 || vb != 0 || !qnorm) return;  // (the first row of an evaluation: its regulariser)
+    const int base = b;
+    if (group) B = group, qnorm += b / group;
     float acc = 0.f;  // (pcrnet_head_fwd_kernel's sum: strided per-thread partials, halving tree)
     for (int bb = threadIdx.x; bb < B; bb += 256) {
-        const float *rr = y + (size_t)bb * 7;
+        const float *rr = y + (size_t)(base + bb) * 7;
         const float m2 = rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3];
         acc += (m2 - 1.0f) * (m2 - 1.0f);
     }
@@ -1831,10 +2009,13 @@ __global__ void __launch_bounds__(256) pcrnet_head_rot_bwd_kernel(int B, int N, 
                                                                   const float *__restrict__ v, const float *__restrict__ g,
                                                                   const float *__restrict__ g_twist, const float *__restrict__ g_quat,
                                                                   const float *__restrict__ g_qnorm, float *__restrict__ gv,
-                                                                  float *__restrict__ g_y)
+                                                                  float *__restrict__ g_y, int group)
 {
     __shared__ float red[4][4];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v += (long long)((group ? b % group : b) - b) * N * 3;  // (v[b] below = the template of row b)
+    if (group) B = group;
+    if (group && g_qnorm) g_qnorm += b / group;
     const float w = q[b * 4];
     const sn_v3 u{q[b * 4 + 1], q[b * 4 + 2], q[b * 4 + 3]};
     float aw = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
@@ -1900,7 +2081,17 @@ extern "C" int sn_pcrnet_head_rot_forward(int B, int N, const float *y, const fl
 {
     SN_REQUIRE(B >= 1 && N >= 1 && y && v && twist && quat && out, "bad argument");
     hipLaunchKernelGGL(pcrnet_head_rot_fwd_kernel, dim3(std::min((N + 255) / 256, 64), B), dim3(256), 0, (hipStream_t)stream, B, N, y, v,
-                       twist, quat, qnorm, out);
+                       twist, quat, qnorm, out, 0);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+// R = E * group rows: E evaluations against the SAME `group` template clouds v (group, N, 3); qnorm: E values (may be NULL)
+extern "C" int sn_pcrnet_head_rot_forward_grouped(int R, int N, int group, const float *y, const float *v, float *twist, float *quat,
+                                                  float *qnorm, float *out, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && N >= 1 && group >= 1 && R % group == 0 && y && v && twist && quat && out, "bad argument");
+    hipLaunchKernelGGL(pcrnet_head_rot_fwd_kernel, dim3(std::min((N + 255) / 256, 64), R), dim3(256), 0, (hipStream_t)stream, R, N, y, v,
+                       twist, quat, qnorm, out, group);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -1914,7 +2105,18 @@ extern "C" int sn_pcrnet_head_rot_backward(int B, int N, const float *y, const f
     SN_REQUIRE(B >= 1 && N >= 1 && y && quat && v && grad_y, "bad argument");
     SN_REQUIRE(!grad_v || grad_out, "grad_v needs grad_out");
     hipLaunchKernelGGL(pcrnet_head_rot_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, N, y, quat, v, grad_out, grad_twist,
-                       grad_quat, grad_qnorm, grad_v, grad_y);
+                       grad_quat, grad_qnorm, grad_v, grad_y, 0);
+    SN_LAUNCH_CHECK();
+    return 0;
+}
+// backward of the grouped form: grad_qnorm E values (may be NULL); no gradient to the shared template clouds
+extern "C" int sn_pcrnet_head_rot_backward_grouped(int R, int N, int group, const float *y, const float *quat, const float *v,
+                                                   const float *grad_out, const float *grad_twist, const float *grad_quat,
+                                                   const float *grad_qnorm, float *grad_y, sn_stream_t stream)
+{
+    SN_REQUIRE(R >= 1 && N >= 1 && group >= 1 && R % group == 0 && y && quat && v && grad_y, "bad argument");
+    hipLaunchKernelGGL(pcrnet_head_rot_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, R, N, y, quat, v, grad_out, grad_twist,
+                       grad_quat, grad_qnorm, (float *)nullptr, grad_y, group);
     SN_LAUNCH_CHECK();
     return 0;
 }
@@ -2079,7 +2281,6 @@ extern "C" int sn_nn_matching(int B, int N, int k, const float *xyz, int layout,
 // (minimum, first argmin) and emits it whenever a prefix ends.  Same expression / strict-< tie rule as the Chamfer scan
 // (chamfer_distance.cpp:59-112), so dist / idx of prefix j equal sn_chamfer_forward(Q[:, :s_j], P)'s dist2 / idx2 bit for bit.
 // ------------------------------------------------------------------------------------------------
-constexpr int kMaxPrefixes = 16;
 struct PrefixEnds {
     int n;
     int end[kMaxPrefixes];  // ascending, end[n-1] == M

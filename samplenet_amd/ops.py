@@ -120,6 +120,49 @@ class ChamferMeanLossFunction(torch.autograd.Function):
         return g1, g2
 
 
+class ChamferMeanLossGroupedFunction(torch.autograd.Function):
+    """chamfer_mean_loss for E evaluations in one batch: xyz1 (E G, n1, 3) clouds padded to n1 points by cyclic_pad_cat, nvalid[e] real
+    points in evaluation e's G clouds; xyz2 (E G, n2, 3) -> losses (E,), each equal -- bit for bit, gradients included -- to
+    chamfer_mean_loss(xyz1[e G:(e+1) G, :nvalid[e]], xyz2[e G:(e+1) G]).  One scan + two reduction launches forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, group, nvalid):
+        import ctypes
+
+        xyz1, xyz2, dist1, idx1, dist2, idx2 = chamfer_forward_impl(xyz1, xyz2)
+        R, n1 = dist1.shape
+        n2 = dist2.shape[1]
+        E = len(nvalid)
+        dev = dist1.device
+        partial = torch.empty(R * 2, device=dev, dtype=torch.float32)
+        loss = torch.empty(E, device=dev, dtype=torch.float32)
+        nv = (ctypes.c_int * E)(*[int(v) for v in nvalid])
+        with torch.cuda.device(dev):
+            check(lib.sn_chamfer_mean_loss_forward_grouped(R, n1, n2, int(group), E, nv, ptr(dist1), ptr(dist2), ptr(partial), ptr(loss),
+                                                           _stream(dist1)), "sn_chamfer_mean_loss_forward_grouped")
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        ctx.cfg = (int(group), E, nv)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        group, E, nv = ctx.cfg
+        R, n1, _ = xyz1.shape
+        n2 = xyz2.shape[1]
+        g1 = torch.empty_like(xyz1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(xyz2) if ctx.needs_input_grad[1] else None
+        gl = grad_loss.contiguous().float()
+        with torch.cuda.device(xyz1.device):
+            check(lib.sn_chamfer_mean_loss_backward_grouped(R, n1, ptr(xyz1), n2, ptr(xyz2), group, E, nv, ptr(idx1), ptr(idx2), ptr(gl),
+                                                            ptr(g1), ptr(g2), _stream(xyz1)), "sn_chamfer_mean_loss_backward_grouped")
+        return g1, g2, None, None
+
+
+def chamfer_mean_loss_grouped(xyz1, xyz2, group, nvalid):
+    return ChamferMeanLossGroupedFunction.apply(xyz1, xyz2, group, nvalid)
+
+
 def chamfer_mean_loss(xyz1, xyz2):
     return ChamferMeanLossFunction.apply(xyz1, xyz2)
 

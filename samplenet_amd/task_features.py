@@ -487,6 +487,42 @@ class _HeadRotFunction(torch.autograd.Function):
         return gy, gv
 
 
+class _HeadRotGroupedFunction(torch.autograd.Function):
+    """_HeadRotFunction for E evaluations against the same `group` template clouds in one launch each way: y (E group, 7),
+    v (group, N, 3) [no gradient] -> twist (E group, 7), quat (E group, 4), qnorm (E,), rotated (E group, N, 3); every row equals its
+    evaluation's own _HeadRotFunction call (sn_pcrnet_head_rot_*_grouped)."""
+
+    @staticmethod
+    def forward(ctx, y, v, group):
+        y, x = y.contiguous().float(), v.contiguous().float()
+        R, N = y.shape[0], x.shape[1]
+        twist = torch.empty_like(y)
+        quat = torch.empty(R, 4, device=y.device, dtype=torch.float32)
+        qnorm = torch.empty(R // group, device=y.device, dtype=torch.float32)
+        out = torch.empty(R, N, 3, device=y.device, dtype=torch.float32)
+        with torch.cuda.device(y.device):
+            check(lib.sn_pcrnet_head_rot_forward_grouped(R, N, int(group), ptr(y), ptr(x), ptr(twist), ptr(quat), ptr(qnorm), ptr(out),
+                                                         _st(y)), "sn_pcrnet_head_rot_forward_grouped")
+        ctx.save_for_backward(y, quat, x)
+        ctx.group = int(group)
+        ctx.set_materialize_grads(False)
+        return twist, quat, qnorm, out
+
+    @staticmethod
+    def backward(ctx, g_twist, g_quat, g_qnorm, g_out):
+        y, quat, x = ctx.saved_tensors
+        R, N = y.shape[0], x.shape[1]
+        gy = torch.empty_like(y)
+        gt = g_twist.contiguous().float() if g_twist is not None else None
+        gqt = g_quat.contiguous().float() if g_quat is not None else None
+        gq = g_qnorm.contiguous().float() if g_qnorm is not None else None
+        go = g_out.contiguous().float() if g_out is not None else None
+        with torch.cuda.device(y.device):
+            check(lib.sn_pcrnet_head_rot_backward_grouped(R, N, ctx.group, ptr(y), ptr(quat), ptr(x), ptr(go), ptr(gt), ptr(gqt), ptr(gq),
+                                                          ptr(gy), _st(y)), "sn_pcrnet_head_rot_backward_grouped")
+        return gy, None, None
+
+
 class PCRNet(nn.Module):
     """Drop-in for `registration/models/pcrnet.py:44-82` (same constructor, attribute and parameter names -> state_dict
     compatible, same `forward(x0, x1) -> (twist (B,7), pre_normalized_quat (B,4))`): the two feature extractions run on the
@@ -577,6 +613,37 @@ class PCRNet(nn.Module):
                 out.append((twist, ye[:, 0:4], qnorm, quat))
         return out
 
+    def _one_batch_ok(self, x0, x1_list, feat0=None):
+        """Several evaluations against one template as ONE batch through extractor, trunk, head + rotation and Chamfer term
+        (_pcrnet_chamfer_loss_multi): 'bnc' clouds on the GPU, at most 16 of them and 128 trunk rows, the padded batch below ~2.5 x
+        the clouds' own points, at most 2048 points a side (the grouped Chamfer backward keeps a cloud in registers)."""
+        E = len(x1_list)
+        if not (1 < E <= 16 and self.input_shape == "bnc" and x0.is_cuda and type(self.feat) is PointNetFeatures):
+            return False
+        sizes = [x.shape[1] for x in x1_list]
+        B = x0.shape[0]
+        K2 = self.fc1.in_features // 2
+        return (E * B <= 128 and K2 % 8 == 0 and max(sizes) * E <= 2.5 * sum(sizes) and max(sizes) <= 2048 and x0.shape[1] <= 2048
+                and all(x.dim() == 3 and x.shape[0] == B and x.shape[2] == 3 for x in x1_list)
+                and not any(p.requires_grad for p in self.parameters()))
+
+    def forward_multi_one_batch(self, x0, x1_list, feat0=None):
+        """forward_multi with everything batched: -> (twist (E B, 7), y (E B, 7), qnorm (E,), quat (E B, 4), rotated template
+        (E B, N, 3), the clouds padded to one size (E B, P, 3)).  Row e B + b = evaluation e, cloud b."""
+        from .ops import cyclic_pad_cat
+
+        E = len(x1_list)
+        f0 = self.template_features(x0) if feat0 is None else feat0
+        B = f0.shape[0]
+        xpad = cyclic_pad_cat(x1_list)
+        f1 = self.feat(xpad)
+        wb = []
+        for fc in (self.fc1, self.fc2, self.fc3, self.fc4, self.fc5, self.fc6):
+            wb += [fc.weight, fc.bias]
+        y = _TrunkFunction.apply(f0.repeat(E, 1), f1, *wb)
+        twist, quat, qnorm, rotated = _HeadRotGroupedFunction.apply(y, x0, B)
+        return twist, y, qnorm, quat, rotated, xpad
+
     def _feat_multi(self, x1_list):
         """self.feat of several source clouds, concatenated over the batch.  Clouds of DIFFERENT sizes (the progressive sampler's
         prefixes) go through the extractor as ONE batch: every cloud repeated cyclically up to the largest size (ops.cyclic_pad_cat) --
@@ -639,8 +706,15 @@ def pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features=None):
 
 
 def _pcrnet_chamfer_loss_multi(model, p0, p1_list, template_features):
-    from .ops import chamfer_mean_loss
+    from .ops import chamfer_mean_loss, chamfer_mean_loss_grouped
 
+    if hasattr(model, "_one_batch_ok") and model._one_batch_ok(p0, p1_list, template_features):
+        # every evaluation in ONE batch: extractor pass, trunk pass, head + rotation launch, Chamfer scan and reductions -- the clouds
+        # padded to one size by cyclic repetition, the copies left out of the loss; the same numbers as evaluation by evaluation
+        E, B = len(p1_list), p0.shape[0]
+        twist, _y, qnorm, _quat, rotated, xpad = model.forward_multi_one_batch(p0, p1_list, feat0=template_features)
+        losses = chamfer_mean_loss_grouped(xpad, rotated, B, [p.shape[1] for p in p1_list])
+        return list(zip(losses.unbind(0), qnorm.unbind(0), twist.view(E, B, -1).unbind(0)))
     out = []
     for p1, (twist, _pre, qnorm, _quat, p1_est) in zip(p1_list, model.forward_multi(p0, p1_list, feat0=template_features, rotate=p0)):
         out.append((chamfer_mean_loss(p1.contiguous(), p1_est.contiguous()), qnorm, twist))

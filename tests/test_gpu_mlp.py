@@ -1568,6 +1568,19 @@ def test_cyclic_pad_cat_and_the_one_pass_extractor():
     gs = torch.autograd.grad((f_single * wf).sum(), qs)
     for a, b in zip(gm, gs):
         assert torch.equal(a, b)
+    # ... and the whole task term of the four evaluations as ONE batch (extractor, trunk, grouped head + rotation, grouped Chamfer term:
+    # the copies left out of the loss) against evaluation by evaluation: losses, regularisers, twists and the gradient to every prefix
+    template = torch.rand(B, 1024, 3, device="cuda", generator=g) - 0.5
+    assert pcr._one_batch_ok(template, qs)
+    many = TF.pcrnet_chamfer_loss_multi(pcr, template, qs)
+    one = [TF.pcrnet_chamfer_loss(pcr, template, q) for q in qs]
+    for (la, qa, ta), (lb, qb, tb) in zip(one, many):
+        assert torch.equal(la, lb) and torch.equal(qa, qb) and torch.equal(ta, tb)
+    wl = [0.3, 1.0, 0.7, 1.9]
+    ga = torch.autograd.grad(sum(w * (l + 0.1 * q) for w, (l, q, _) in zip(wl, one)), qs)
+    gb = torch.autograd.grad(sum(w * (l + 0.1 * q) for w, (l, q, _) in zip(wl, many)), qs)
+    for a, b in zip(ga, gb):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("B,N", [(32, 64), (4, 256), (3, 50), (2, 1024)])
