@@ -2311,6 +2311,53 @@ __global__ void __launch_bounds__(256) prefix_colmin_kernel(int N, int M, const 
     }
 }
 
+// The same products with EIGHT threads per point (kPcSeg query ranges of ceil(M / 8) queries, one per thread): prefix_colmin_kernel has one
+// thread per point walking all M queries -- at B = 32, N = 1024 that is 512 waves on 1024 SIMDs for 256 dependent steps each (28.6 us
+// in BASELINE configs[4]'s step).  A thread leaves, per prefix, the running minimum of ITS range as it stood at the prefix's end (the
+// whole range's when the prefix ends behind it, nothing when it ends in front); the ranges are then joined in ascending order with
+// the strict compare of the one-thread walk -- minimum and arg-minimum are associative, the lowest query still wins a tie: same bits.
+constexpr int kPcSeg = 8, kPcPts = 32;  // 256 threads: 32 points x 8 ranges
+__global__ void __launch_bounds__(256) prefix_colmin_seg_kernel(int N, int M, const float *__restrict__ P, const float *__restrict__ Q,
+                                                                PrefixEnds pe, float *__restrict__ dist, int *__restrict__ idx,
+                                                                size_t stride)
+{
+    extern __shared__ float q_lds[];  // [M][3], then the snapshots
+    float *sd = q_lds + (size_t)M * 3;                                         // [kPcPts][kMaxPrefixes][kPcSeg] distances
+    int *si = reinterpret_cast<int *>(sd + kPcPts * kMaxPrefixes * kPcSeg);   // ... and queries
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < M * 3; i += blockDim.x) q_lds[i] = Q[(size_t)b * M * 3 + i];
+    __syncthreads();
+    const int pl = threadIdx.x >> 3, k = threadIdx.x & 7;
+    const int n = blockIdx.x * kPcPts + pl;
+    const int L = (M + kPcSeg - 1) / kPcSeg, m0 = k * L, m1 = min(M, m0 + L);
+    const int nc = n < N ? n : N - 1;
+    const sn_xyz3 pv = *reinterpret_cast<const sn_xyz3 *>(P + ((size_t)b * N + nc) * 3);
+    float best = INFINITY;
+    int besti = 0, j = 0;
+    auto snap = [&](int jj) { sd[(pl * kMaxPrefixes + jj) * kPcSeg + k] = best, si[(pl * kMaxPrefixes + jj) * kPcSeg + k] = besti; };
+    while (j < pe.n && pe.end[j] <= m0) snap(j), ++j;  // prefixes that end in front of this range: nothing (+inf)
+    for (int m = m0; m < m1; ++m) {
+        const float dx = q_lds[m * 3 + 0] - pv.x, dy = q_lds[m * 3 + 1] - pv.y, dz = q_lds[m * 3 + 2] - pv.z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        if (m == m0 || d < best) best = d, besti = m;
+        if (j < pe.n && m + 1 == pe.end[j]) snap(j), ++j;
+    }
+    while (j < pe.n) snap(j), ++j;  // prefixes that end behind this range: all of it
+    __syncthreads();
+    if (n >= N) return;
+    for (int jj = k; jj < pe.n; jj += kPcSeg) {  // thread k of a point joins the ranges of prefixes k, k + 8
+        const float *d8 = sd + (pl * kMaxPrefixes + jj) * kPcSeg;
+        const int *i8 = si + (pl * kMaxPrefixes + jj) * kPcSeg;
+        float bd = d8[0];
+        int bi = i8[0];
+#pragma unroll
+        for (int q = 1; q < kPcSeg; ++q)
+            if (d8[q] < bd) bd = d8[q], bi = i8[q];
+        dist[jj * stride + (size_t)b * N + n] = bd;
+        idx[jj * stride + (size_t)b * N + n] = bi;
+    }
+}
+
 extern "C" int sn_prefix_point_minima(int B, int N, int M, int nprefix, const int *prefix_sizes, const float *P, const float *Q,
                                       float *dist, int *idx, sn_stream_t stream)
 {
@@ -2324,9 +2371,16 @@ extern "C" int sn_prefix_point_minima(int B, int N, int M, int nprefix, const in
         SN_REQUIRE(pe.end[j] >= 1 && (j == 0 || pe.end[j] > pe.end[j - 1]), "prefix sizes must be ascending");
     }
     SN_REQUIRE(pe.end[nprefix - 1] == M, "the last prefix is the whole simplified cloud");
-    const dim3 grid((N + 255) / 256, B), block(256);
-    hipLaunchKernelGGL(prefix_colmin_kernel, grid, block, (size_t)M * 12, (hipStream_t)stream, N, M, P, Q, pe, dist, idx,
-                       (size_t)B * N);
+    // few clouds: eight threads per point (the chip is not full otherwise); many: one thread per point walks all the queries
+    const size_t lds_seg = (size_t)M * 12 + (size_t)kPcPts * kMaxPrefixes * kPcSeg * 8;
+    if ((long long)B * N < 256 * 1024 && M >= 16 && lds_seg <= 64 * 1024) {
+        hipLaunchKernelGGL(prefix_colmin_seg_kernel, dim3((N + kPcPts - 1) / kPcPts, B), dim3(256), lds_seg, (hipStream_t)stream, N, M, P, Q,
+                           pe, dist, idx, (size_t)B * N);
+    } else {
+        const dim3 grid((N + 255) / 256, B), block(256);
+        hipLaunchKernelGGL(prefix_colmin_kernel, grid, block, (size_t)M * 12, (hipStream_t)stream, N, M, P, Q, pe, dist, idx,
+                           (size_t)B * N);
+    }
     SN_LAUNCH_CHECK();
     return 0;
 }

@@ -613,7 +613,8 @@ def test_hard_projection_is_nearest_input_point(oracle):
 
 
 @pytest.mark.parametrize("B,N,M,sizes", [(4, 1024, 256, [32, 64, 128, 256]), (2, 300, 50, [1, 7, 50]), (32, 1024, 64, [8, 16, 32, 64]),
-                                          (1, 2048, 1024, [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024])])
+                                          (1, 2048, 1024, [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024]), (3, 777, 21, [5, 6, 20, 21]),
+                                          (300, 1024, 16, [8, 16])])  # (the last: the one-thread-per-point kernel of large batches)
 def test_prefix_point_minima_match_chamfer_per_prefix(oracle, B, N, M, sizes):
     """sn_prefix_point_minima (progressive sampler): the per-point Chamfer products of every nested prefix from ONE
     pass == the oracle's Chamfer scan of that prefix, bit for bit (distances and first-minimum indices, duplicated points
