@@ -620,6 +620,8 @@ class PCRNet(nn.Module):
         E = len(x1_list)
         if not (1 < E <= 16 and self.input_shape == "bnc" and x0.is_cuda and type(self.feat) is PointNetFeatures):
             return False
+        if x0.requires_grad and torch.is_grad_enabled():  # (the grouped head + rotation hands no gradient to the shared template)
+            return False
         sizes = [x.shape[1] for x in x1_list]
         B = x0.shape[0]
         K2 = self.fc1.in_features // 2
