@@ -385,6 +385,11 @@ int sn_cyclic_pad_cat_backward(int B, int len, int C, int nclouds, const int *si
  *   sn_chamfer_mean_loss_*_grouped: mean(dist1) + mean(dist2) per evaluation on clouds padded to n1 points by sn_cyclic_pad_cat, nvalid[e]
  *                                  of them real (HOST array): the copies are not counted forward and get / give no gradient backward.
  * Every number equals the evaluation's own ungrouped call on the unpadded cloud, bit for bit. */
+/* sn_chamfer_forward for such a padded batch: only the first q_valid[b / q_group] points (device array) of the smaller cloud of pair b
+ * are scanned; the copies' dist / idx stay unwritten, everything else equals sn_chamfer_forward's products. */
+int sn_chamfer_forward_valid(int B, int m, const float *xyz_small, int n, const float *xyz_large, const int *q_valid, int q_group,
+                             float *dist_small, int *idx_small, float *dist_large, int *idx_large, void *workspace,
+                             long long workspace_bytes, sn_stream_t stream);
 int sn_pcrnet_head_rot_forward_grouped(int R, int N, int group, const float *y, const float *v, float *twist, float *quat, float *qnorm,
                                        float *out, sn_stream_t stream);
 int sn_pcrnet_head_rot_backward_grouped(int R, int N, int group, const float *y, const float *quat, const float *v, const float *grad_out,

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "sn_prefix_simplification_loss_forward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_prefix_simplification_loss_backward": [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_prefix_pack": [_i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "sn_chamfer_forward_valid": [_i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp],
     "sn_pcrnet_head_rot_forward_grouped": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_pcrnet_head_rot_backward_grouped": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sn_chamfer_mean_loss_forward_grouped": [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -230,6 +230,11 @@ struct PairscanArgs {
     sn_u64 *colmin_keys;
     float *qpart;
     sn_u64 *qmax;
+    // Optional: only the first q_valid[b / q_group] queries of cloud b are scanned (the rest are cyclic copies of them,
+    // sn_cyclic_pad_cat: a copy never wins a per-point minimum, and its own products are read by nobody) -- dist_q / idx_q / the kNN
+    // outputs of the others are left unwritten.
+    const int *q_valid;
+    int q_group;
 };
 
 // coordinate c of query j (see PairscanArgs::fc_w): lane partial sums in k order, then a fixed xor tree
@@ -286,9 +291,10 @@ __global__ void __launch_bounds__(max_threads(PPL, COLMIN)) pairscan_kernel(Pair
     const int nwaves = blockDim.x >> 6;
     const int b = blockIdx.x;
     const int N = a.N, M = a.M, K = a.K;
-    const int qpb = (M + gridDim.y - 1) / gridDim.y;
+    const int Mv = a.q_valid ? a.q_valid[b / a.q_group] : M;  // (queries to scan: the valid ones, spread over the cloud's workgroups)
+    const int qpb = (Mv + gridDim.y - 1) / gridDim.y;
     const int q0 = blockIdx.y * qpb;
-    const int q1 = min(M, q0 + qpb);
+    const int q1 = min(Mv, q0 + qpb);
     PS_TL(0);
 
     sn_u64 *list = reinterpret_cast<sn_u64 *>(smem) + wave * kListPitch;
@@ -778,6 +784,27 @@ extern "C" int sn_pairscan_forward_partial(int B, int N, int M, int K, const flo
     if (rc) return rc;
     SN_LAUNCH_CHECK();  // (first: SN_REQUIRE discards the pending launch status)
     if (used != G) return sn_set_error(SN_ERR_BAD_ARGUMENT, "%s: internal: split mismatch", __func__);
+    return 0;
+}
+
+// sn_chamfer_forward on a batch whose SMALLER clouds are padded with cyclic copies (sn_cyclic_pad_cat): only the first
+// q_valid[b / q_group] points of the smaller cloud of pair b are scanned as queries (device array, one int per group of q_group clouds);
+// dist / idx of the copies are left unwritten, every other product equals sn_chamfer_forward's.  Needs the clouds' roles fixed by the
+// caller: xyz_small (B, m, 3) the padded side, xyz_large (B, n, 3), m <= n <= 2048.  workspace as sn_pairscan_workspace_bytes(B, n, m).
+extern "C" int sn_chamfer_forward_valid(int B, int m, const float *xyz_small, int n, const float *xyz_large, const int *q_valid, int q_group,
+                                        float *dist_small, int *idx_small, float *dist_large, int *idx_large, void *workspace,
+                                        long long workspace_bytes, sn_stream_t stream)
+{
+    SN_REQUIRE(B >= 1 && m >= 1 && n >= m && n <= sn::kWave * 32 && q_group >= 1, "bad size (m <= n <= 2048)");
+    SN_REQUIRE(xyz_small && xyz_large && q_valid && dist_small && idx_small && dist_large && idx_large, "null pointer");
+    PairscanArgs a{};
+    a.P = xyz_large, a.Q = xyz_small, a.p_layout = SN_LAYOUT_BNC, a.q_layout = SN_LAYOUT_BNC;
+    a.B = B, a.N = n, a.M = m, a.K = 1;
+    a.dist_q = dist_small, a.idx_q = idx_small, a.dist_p = dist_large, a.idx_p = idx_large;
+    a.q_valid = q_valid, a.q_group = q_group;
+    int rc = sn::pairscan_dispatch(a, workspace, workspace_bytes, true, nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    SN_LAUNCH_CHECK();
     return 0;
 }
 

@@ -120,6 +120,9 @@ class ChamferMeanLossFunction(torch.autograd.Function):
         return g1, g2
 
 
+_QVALID = {}  # (n1, n2, valid counts, device) -> the counts on the device (made outside captures; constants of the graphs that use them)
+
+
 class ChamferMeanLossGroupedFunction(torch.autograd.Function):
     """chamfer_mean_loss for E evaluations in one batch: xyz1 (E G, n1, 3) clouds padded to n1 points by cyclic_pad_cat, nvalid[e] real
     points in evaluation e's G clouds; xyz2 (E G, n2, 3) -> losses (E,), each equal -- bit for bit, gradients included -- to
@@ -129,9 +132,27 @@ class ChamferMeanLossGroupedFunction(torch.autograd.Function):
     def forward(ctx, xyz1, xyz2, group, nvalid):
         import ctypes
 
-        xyz1, xyz2, dist1, idx1, dist2, idx2 = chamfer_forward_impl(xyz1, xyz2)
-        R, n1 = dist1.shape
-        n2 = dist2.shape[1]
+        _need_gpu(xyz1, xyz2)
+        n1, n2, R = xyz1.shape[1], xyz2.shape[1], xyz1.shape[0]
+        key = (n1, n2, tuple(int(v) for v in nvalid), xyz1.device)
+        qv = _QVALID.get(key)
+        if qv is None and n1 <= n2 <= 2048 and not torch.cuda.is_current_stream_capturing():
+            qv = _QVALID[key] = torch.tensor(list(key[2]), device=xyz1.device, dtype=torch.int32)
+        if qv is not None:
+            # the scan walks the valid queries only (the copies' own products are read by nobody)
+            xyz1, xyz2 = _f32c(xyz1), _f32c(xyz2)
+            dev = xyz1.device
+            dist1 = torch.empty(R, n1, device=dev, dtype=torch.float32)
+            dist2 = torch.empty(R, n2, device=dev, dtype=torch.float32)
+            idx1 = torch.empty(R, n1, device=dev, dtype=torch.int32)
+            idx2 = torch.empty(R, n2, device=dev, dtype=torch.int32)
+            wsb = lib.sn_pairscan_workspace_bytes(R, n2, n1)
+            ws = torch.empty(max(wsb, 8) // 8, device=dev, dtype=torch.int64)
+            with torch.cuda.device(dev):
+                check(lib.sn_chamfer_forward_valid(R, n1, ptr(xyz1), n2, ptr(xyz2), ptr(qv), int(group), ptr(dist1), ptr(idx1), ptr(dist2),
+                                                   ptr(idx2), ptr(ws), wsb, _stream(xyz1)), "sn_chamfer_forward_valid")
+        else:
+            xyz1, xyz2, dist1, idx1, dist2, idx2 = chamfer_forward_impl(xyz1, xyz2)
         E = len(nvalid)
         dev = dist1.device
         partial = torch.empty(R * 2, device=dev, dtype=torch.float32)
