@@ -8,7 +8,7 @@ for f in PROFILE_SRC_SHA bench_n1.json bench_n1_noprobes.json bench_n1_rccl_grap
          bench_eager_kernel_stats.csv task_kernel_stats.csv emd_emd_loss_kernel_stats.csv emd_three_call_kernel_stats.csv emd_bench.txt \
          emd_pmc_summary.json emd_sq_counters.json pairscan_scaling.txt fc_chain_timeline.txt pmc_FETCH_SIZE.csv pmc_WRITE_SIZE.csv \
          config3_sampler_kernel_stats.csv config5_progressive_kernel_stats.csv b512_kernel_stats.csv b2048_kernel_stats.csv batch_sweep.txt \
-         surface_bench.json surface_profile.txt fwd_persist_timeline.txt cotenancy_stress.txt pmc_summary_b2048.json pmc_summary_b512.json bench_n1_rccl_surface.json \
+         conv_bwd_sq_counters_b2048.json linear_fwd_sq_counters_b2048.json surface_bench.json surface_profile.txt fwd_persist_timeline.txt cotenancy_stress.txt pmc_summary_b2048.json pmc_summary_b512.json bench_n1_rccl_surface.json \
          bench_n1_rccl_auto.json config1_classification_kernel_stats.csv task_graph_timeline.txt; do
   [ -f $S/$f ] && cp $S/$f $D/$f
 done

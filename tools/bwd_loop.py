@@ -35,7 +35,9 @@ def bwd(R, Ci, Co, mode, B=32, reps=10):
 
 
 if __name__ == "__main__":
-    R = 32 * 1024
-    bwd(R, 64, 64, 1)
-    bwd(R, 64, 128, 1)
-    bwd(R, 128, 128, 2)
+    B = int(os.environ.get("SQ_BATCH", "32"))  # (2048: the saturating batch)
+    R = B * 1024
+    reps = 10 if B <= 64 else 4
+    bwd(R, 64, 64, 1, B=B, reps=reps)
+    bwd(R, 64, 128, 1, B=B, reps=reps)
+    bwd(R, 128, 128, 2, B=B, reps=reps)

@@ -11,8 +11,9 @@ from samplenet_amd import SampleNet, pointnet  # noqa: E402
 
 torch.manual_seed(0)
 net = SampleNet(64, 128, group_size=8, input_shape="bnc", output_shape="bnc").cuda().train()
-x = (torch.rand(32, 1024, 3, device="cuda") - 0.5).contiguous()
+B = int(os.environ.get("SQ_BATCH", "32"))  # (2048: the saturating batch -- the persistent forward kernels)
+x = (torch.rand(B, 1024, 3, device="cuda") - 0.5).contiguous()
 with torch.no_grad():
-    for _ in range(10):
+    for _ in range(10 if B <= 64 else 4):
         pointnet.forward_impl(net, x, True)
 torch.cuda.synchronize()

@@ -20,7 +20,8 @@ for f in glob.glob(pattern):
     for r in csv.DictReader(open(f)):
         if needle in r["Kernel_Name"]:
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"note": "rocprofv3 --pmc, three passes of 8 SQ counters each (tools/gpu_pmc_bwd.sh), means over the launches of the profiled loop at R = 32768; "
+rows = sys.argv[4] if len(sys.argv) > 4 else "32768"
+out = {"note": "rocprofv3 --pmc, passes of 8 SQ counters each (tools/gpu_sq_r06.sh / gpu_profile_sq.sh), means over the launches of the profiled loop at R = " + rows + "; "
                "SQ_* wave counters are in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over all SIMDs", "kernels": {}}
 for k, v in sorted(agg.items()):
     d = {c: int(round(sum(x) / len(x))) for c, x in sorted(v.items())}
